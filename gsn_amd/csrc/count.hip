@@ -1,0 +1,275 @@
+// HP-1 counting kernel for gfx950 (MI355X) + its C-ABI launcher gsn_count_hip.
+//
+// One workgroup = one graph.  The graph lives in LDS for the whole kernel:
+//   * adjacency bit matrix A[n][W] (W = ceil(n/64) 64-bit words per row), built from the edge_index columns with
+//     LDS atomic-or (self loops dropped, parallel edges merged -> the simple undirected graph graph-tool matches on),
+//   * edge mode: the column endpoints (u8), a CSR rank  slot(u,v) = rowstart[u] + popcount(A[u] & below(v))  and
+//     last[slot] = highest column holding (u,v)  ("last duplicate wins", utils_graph_processing.py:142-144),
+//   * the packed plan table, a lane-interleaved candidate stack, and (if it fits) a staging copy of the output rows.
+// Work is a pool of tasks (output column, output row); lanes pull tasks with a wave-aggregated LDS atomic
+// (ballot + mbcnt prefix) so that lanes whose search finished early are refilled immediately -- rooted searches have
+// wildly different lengths.  Every (row, column) cell is produced by exactly one lane: no atomics on the counts, no
+// global atomics, deterministic.  HBM traffic = read edge_index once (16 B/column) + write the int64 rows once.
+#include <hip/hip_runtime.h>
+
+#include "count_core.h"
+
+namespace gsn {
+
+struct CountArgs {
+    const uint32_t *plan;      // device
+    int plan_words;
+    int mode, n_cols, n_plans, plans_off, kmax;
+    const int64_t *node_ptr, *edge_ptr, *src, *dst;
+    int ids_are_global;
+    const int32_t *graph_ids;  // or null
+    int n_cap, e_cap;          // LDS capacities (rows of A, columns)
+    int stage_out;             // 1: output rows staged in LDS then written coalesced
+    int64_t *out;
+    int32_t *status;
+    // LDS byte offsets
+    int off_valid, off_stack, off_plan, off_eu, off_ev, off_rowstart, off_last, off_out, off_misc;
+};
+
+template <int W, int T>
+__global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t *A = reinterpret_cast<uint64_t *>(smem);
+    uint64_t *valid = reinterpret_cast<uint64_t *>(smem + a.off_valid);
+    uint64_t *stack = reinterpret_cast<uint64_t *>(smem + a.off_stack);
+    uint32_t *plan = reinterpret_cast<uint32_t *>(smem + a.off_plan);
+    uint8_t *eu = smem + a.off_eu;
+    uint8_t *ev = smem + a.off_ev;
+    int *rowstart = reinterpret_cast<int *>(smem + a.off_rowstart);
+    int *last = reinterpret_cast<int *>(smem + a.off_last);
+    uint64_t *out_lds = reinterpret_cast<uint64_t *>(smem + a.off_out);
+    int *misc = reinterpret_cast<int *>(smem + a.off_misc);  // [0] next task  [1] n_active  [2] status
+
+    const int tid = threadIdx.x;
+    const int g = a.graph_ids ? a.graph_ids[blockIdx.x] : (int)blockIdx.x;
+    const int64_t n0 = a.node_ptr[g], e0 = a.edge_ptr[g];
+    const int64_t n64 = a.node_ptr[g + 1] - n0, E64 = a.edge_ptr[g + 1] - e0;
+    const bool edge_mode = a.mode == GSN_MODE_EDGE;
+    const int64_t rows64 = edge_mode ? E64 : n64;
+    const int64_t row0 = edge_mode ? e0 : n0;
+    const int n_cols = a.n_cols;
+
+    if (n64 > a.n_cap || E64 > a.e_cap || n64 > W * 64) {
+        // caller under-declared max_nodes / max_edges: report, leave zeros
+        for (int64_t i = tid; i < rows64 * n_cols; i += T) a.out[row0 * n_cols + i] = 0;
+        if (tid == 0) a.status[g] = GSN_ST_TOO_LARGE;
+        return;
+    }
+    const int n = (int)n64, E = (int)E64, rows = (int)rows64;
+
+    // ---- phase 0: clear LDS state, copy the plan table ------------------------------------------------------------
+    for (int i = tid; i < n * W; i += T) A[i] = 0ull;
+    for (int i = tid; i < a.plan_words; i += T) plan[i] = a.plan[i];
+    if (tid < 3) misc[tid] = 0;
+    __syncthreads();
+
+    // ---- phase 1: adjacency bit matrix from the columns -----------------------------------------------------------
+    const int64_t off = a.ids_are_global ? n0 : 0;
+    for (int c = tid; c < E; c += T) {
+        const int64_t u64 = a.src[e0 + c] - off, v64 = a.dst[e0 + c] - off;
+        if (u64 < 0 || v64 < 0 || u64 >= n || v64 >= n) {
+            atomicMax(&misc[2], (int)GSN_ST_BAD_INDEX);
+            if (edge_mode) { eu[c] = 0; ev[c] = 0; }
+            continue;
+        }
+        const int u = (int)u64, v = (int)v64;
+        if (edge_mode) { eu[c] = (uint8_t)u; ev[c] = (uint8_t)v; }
+        atomicMax(&misc[1], (u > v ? u : v) + 1);  // graph-tool creates vertices 0..max id, self-loop columns included
+        if (u != v) {
+            atomicOr(reinterpret_cast<unsigned long long *>(&A[u * W + (v >> 6)]), 1ull << (v & 63));
+            atomicOr(reinterpret_cast<unsigned long long *>(&A[v * W + (u >> 6)]), 1ull << (u & 63));
+        }
+    }
+    __syncthreads();
+    const int n_active = misc[1];
+    if (tid < W) valid[tid] = below_word(n_active, tid);
+
+    // ---- phase 2 (edge mode): CSR rank of every directed pair, last-duplicate-wins column -------------------------
+    if (edge_mode) {
+        for (int u = tid; u <= n; u += T) {
+            int s = 0;
+            for (int x = 0; x < u; ++x) {
+#pragma unroll
+                for (int w = 0; w < W; ++w) s += popc64(A[x * W + w]);
+            }
+            rowstart[u] = s;
+        }
+        for (int i = tid; i < E; i += T) last[i] = -1;
+        __syncthreads();
+        for (int c = tid; c < E; c += T) {
+            const int u = eu[c], v = ev[c];
+            if (u == v) continue;
+            int r = rowstart[u];
+#pragma unroll
+            for (int w = 0; w < W; ++w) r += popc64(A[u * W + w] & below_word(v, w));
+            atomicMax(&last[r], c);
+        }
+    }
+    __syncthreads();
+    if (misc[2] != 0) {  // bad index: zeros + status
+        for (int i = tid; i < rows * n_cols; i += T) a.out[row0 * n_cols + i] = 0;
+        if (tid == 0) a.status[g] = misc[2];
+        return;
+    }
+
+    // ---- phase 3: task pool -- (column, row) cells, pulled by lanes as they go idle --------------------------------
+    const int n_tasks = rows * n_cols;
+    const uint32_t *col_ptr = plan + PLAN_HEADER_WORDS;
+    const uint32_t *plans = plan + a.plans_off;
+    const int lane = tid & 63;
+    const uint64_t lane_lt = (1ull << lane) - 1ull;
+
+    Lane s;
+    s.l = -1; s.cnt = 0; s.k = 0; s.nfix = 0; s.fvec = 0; s.plan = plans;
+    bool has_task = false, exhausted = false;
+    int t_row = 0, t_col = 0, p_i = 0, p_e = 0;
+    uint64_t roots = 0;
+    bool rev_missing = false;
+
+    for (;;) {
+        const bool need = !has_task && !exhausted;
+        const uint64_t m = __ballot(need);
+        if (m) {
+            const int leader = __ffsll((unsigned long long)m) - 1;
+            int base = 0;
+            if (lane == leader) base = atomicAdd(&misc[0], __popcll(m));
+            base = __shfl(base, leader);
+            if (need) {
+                const int t = base + __popcll(m & lane_lt);
+                if (t < n_tasks) {
+                    t_col = t / rows;
+                    t_row = t - t_col * rows;
+                    has_task = true;
+                    s.cnt = 0; s.l = -1;
+                    p_i = (int)col_ptr[t_col]; p_e = (int)col_ptr[t_col + 1];
+                    rev_missing = false;
+                    if (edge_mode) {
+                        const int u = eu[t_row], v = ev[t_row];
+                        bool live = u != v;
+                        if (live) {
+                            int r = rowstart[u];
+#pragma unroll
+                            for (int w = 0; w < W; ++w) r += popc64(A[u * W + w] & below_word(v, w));
+                            live = last[r] == t_row;  // earlier duplicates of (u,v) keep 0 (utils_graph_processing.py:142-144)
+                            int rr = rowstart[v];
+#pragma unroll
+                            for (int w = 0; w < W; ++w) rr += popc64(A[v * W + w] & below_word(u, w));
+                            rev_missing = last[rr] < 0;
+                        }
+                        if (!live) p_i = p_e;
+                        roots = (uint64_t)u | ((uint64_t)v << 8);
+                    } else {
+                        if (t_row >= n_active) p_i = p_e;  // vertex beyond the largest id: not a vertex of the matched graph
+                        roots = (uint64_t)t_row;
+                    }
+                } else {
+                    exhausted = true;
+                }
+            }
+        }
+        if (__ballot(has_task) == 0ull) break;
+        if (has_task) {
+            if (s.l < 0) {
+                if (p_i < p_e) {
+                    lane_begin<W>(s, plans + p_i * PLAN_STRIDE_WORDS, roots, A, valid, stack, T, tid);
+                    ++p_i;
+                } else {
+                    // cell finished
+                    if (a.stage_out) out_lds[t_row * n_cols + t_col] = s.cnt;
+                    else a.out[(row0 + t_row) * n_cols + t_col] = (int64_t)s.cnt;
+                    if (edge_mode && rev_missing && s.cnt != 0) atomicMax(&misc[2], (int)GSN_ST_KEYERROR);
+                    has_task = false;
+                }
+            } else {
+                lane_step<W>(s, A, valid, stack, T, tid);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 4: coalesced write of the staged rows --------------------------------------------------------------
+    if (a.stage_out) {
+        int64_t *dst = a.out + row0 * n_cols;
+        for (int i = tid; i < n_tasks; i += T) dst[i] = (int64_t)out_lds[i];
+    }
+    if (tid == 0) a.status[g] = misc[2];
+}
+
+static inline int align_up(int x, int a) { return (x + a - 1) / a * a; }
+
+template <int W, int T>
+static int launch(CountArgs &a, int n_items, size_t lds, hipStream_t stream) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&count_kernel<W, T>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return set_error(GSN_E_HIP, "hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
+    hipLaunchKernelGGL((count_kernel<W, T>), dim3((unsigned)n_items), dim3(T), lds, stream, a);
+    e = hipGetLastError();
+    if (e != hipSuccess) return set_error(GSN_E_HIP, "count_kernel launch: %s", hipGetErrorString(e));
+    return GSN_OK;
+}
+
+}  // namespace gsn
+
+using namespace gsn;
+
+extern "C" int gsn_count_hip(const uint32_t *plan_host, const uint32_t *plan_dev, int64_t plan_words, int64_t n_graphs,
+                             const int64_t *node_ptr, const int64_t *edge_ptr, const int64_t *edge_index,
+                             int64_t edge_row_stride, int ids_are_global, const int32_t *graph_ids, int64_t n_items,
+                             int64_t max_nodes, int64_t max_edges, int64_t *out, int32_t *status, void *stream) {
+    if (!plan_host || !plan_dev || plan_words < PLAN_HEADER_WORDS || plan_host[0] != PLAN_MAGIC)
+        return set_error(GSN_E_INVALID, "gsn_count_hip: not a plan table (build it with gsn_count_plan_build)");
+    if (!node_ptr || !edge_ptr || !out || !status) return set_error(GSN_E_INVALID, "gsn_count_hip: null pointer argument");
+    if (!graph_ids) n_items = n_graphs;
+    if (n_items <= 0) return GSN_OK;
+    if (max_nodes > 256)
+        return set_error(GSN_E_UNSUPPORTED, "graphs with more than 256 vertices (%lld) are outside this build", (long long)max_nodes);
+    if (max_nodes < 1) max_nodes = 1;
+    if (max_edges < 0) max_edges = 0;
+
+    CountArgs a{};
+    a.plan = plan_dev; a.plan_words = (int)plan_words;
+    a.mode = (int)plan_host[1]; a.n_plans = (int)plan_host[3]; a.n_cols = (int)plan_host[4]; a.kmax = (int)plan_host[5];
+    a.plans_off = (int)plan_host[7];
+    a.node_ptr = node_ptr; a.edge_ptr = edge_ptr;
+    a.src = edge_index; a.dst = edge_index ? edge_index + edge_row_stride : nullptr;
+    a.ids_are_global = ids_are_global; a.graph_ids = graph_ids;
+    a.out = out; a.status = status;
+    if (max_edges > 0 && !edge_index) return set_error(GSN_E_INVALID, "gsn_count_hip: edge_index is null");
+
+    const int W = max_nodes <= 64 ? 1 : (max_nodes <= 128 ? 2 : 4);
+    const bool edge_mode = a.mode == GSN_MODE_EDGE;
+    const int64_t rows_cap = edge_mode ? max_edges : max_nodes;
+    const int T = rows_cap * a.n_cols <= 512 ? 64 : 256;
+    a.n_cap = (int)max_nodes; a.e_cap = (int)max_edges;
+
+    int o = align_up((int)max_nodes * W * 8, 16);
+    a.off_valid = o; o += align_up(W * 8, 16);
+    const int depth = a.kmax > 1 ? a.kmax - 1 : 1;
+    a.off_stack = o; o += depth * W * T * 8;
+    a.off_plan = o; o += align_up((int)plan_words * 4, 16);
+    a.off_eu = o; o += edge_mode ? align_up((int)max_edges, 16) : 0;
+    a.off_ev = o; o += edge_mode ? align_up((int)max_edges, 16) : 0;
+    a.off_rowstart = o; o += edge_mode ? align_up(((int)max_nodes + 1) * 4, 16) : 0;
+    a.off_last = o; o += edge_mode ? align_up((int)max_edges * 4, 16) : 0;
+    a.off_misc = o; o += 16;
+    a.off_out = o;
+    const int64_t stage_bytes = rows_cap * a.n_cols * 8;
+    const int64_t lds_budget = 64 * 1024;  // keep >= 2 workgroups per CU
+    a.stage_out = (o + stage_bytes <= lds_budget) ? 1 : 0;
+    if (a.stage_out) o += (int)stage_bytes;
+    if (o > 160 * 1024) return set_error(GSN_E_UNSUPPORTED, "graph too large for LDS (%d B needed)", o);
+
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int items = (int)n_items;
+    if (W == 1 && T == 64) return launch<1, 64>(a, items, (size_t)o, st);
+    if (W == 1) return launch<1, 256>(a, items, (size_t)o, st);
+    if (W == 2 && T == 64) return launch<2, 64>(a, items, (size_t)o, st);
+    if (W == 2) return launch<2, 256>(a, items, (size_t)o, st);
+    if (T == 64) return launch<4, 64>(a, items, (size_t)o, st);
+    return launch<4, 256>(a, items, (size_t)o, st);
+}

@@ -1,0 +1,23 @@
+// Internal declarations shared by the translation units of libgsn_hip.so (not part of the ABI).
+#pragma once
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/gsn_abi.h"
+
+namespace gsn {
+
+// packed counting-plan table (uint32 words) -- written by gsn_count_plan_build, read by the kernel
+//   header : [0] magic  [1] mode  [2] induced  [3] n_plans  [4] n_cols  [5] kmax  [6] directed_orbits  [7] plans_off
+//   col_ptr: [8 .. 8+n_cols]  plans col_ptr[c]..col_ptr[c+1] all write output column c (plans are sorted by column)
+//   plan p : at plans_off + p*PLAN_STRIDE_WORDS: [0] k | n_fixed<<8 | out_col<<16     [1] pattern | root_a<<16 | root_b<<24
+//            [2+l] level l: adj_mask | nonadj_mask<<8 | gt_mask<<16 | lt_mask<<24   (bit j = earlier level j)
+constexpr uint32_t PLAN_MAGIC = 0x47534e31u;  // 'GSN1'
+constexpr int PLAN_HEADER_WORDS = 8;
+constexpr int PLAN_STRIDE_WORDS = 2 + GSN_KMAX;
+
+int set_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
+}  // namespace gsn

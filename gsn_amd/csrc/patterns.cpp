@@ -1,0 +1,266 @@
+// Host-side pattern analysis and counting-plan compiler (C ABI: gsn_pattern_orbits, gsn_count_plan_build).
+//
+// Product code.  Mirrors the *results* of utils_graph_processing.automorphism_orbits (:10-56) and
+// induced_edge_automorphism_orbits (:58-100) of the reference, computed here by a direct permutation search over the
+// <= 8 pattern vertices (no graph-tool), and compiles each pattern into rooted search plans for the HIP kernel:
+//
+//   vertex mode: counts[v, o] = #occurrences of H that contain v at a position of vertex orbit o
+//                             = #maps f with f(rep_o) = v that satisfy the symmetry-breaking constraints of Stab(rep_o)
+//   edge   mode: counts[(u,v), c] = sum over directed-edge orbits Omega (under Aut(H)) inside edge class c of
+//                               #maps f with f(a)=u, f(b)=v, (a,b)=rep(Omega), satisfying the constraints of Stab(a,b)
+//
+// Both identities follow from orbit-stabiliser (DESIGN.md "Counting identity"); every quantity is an exact integer, so
+// the result is bit-identical to "enumerate all |Aut| maps per occurrence, then divide by |Aut|" (what the reference does).
+#include "gsn_internal.h"
+
+#include <algorithm>
+#include <array>
+#include <cstring>
+#include <vector>
+
+namespace gsn {
+
+struct Pattern {
+    int k = 0;
+    uint8_t adj[GSN_KMAX] = {0};                 // adj[i] bit j
+    std::vector<std::array<uint8_t, GSN_KMAX>> aut;  // all automorphisms sigma: sigma[i] = image of i
+    int vorbit[GSN_KMAX] = {0};
+    int n_vorbits = 0;
+    std::vector<std::pair<int, int>> arcs;       // sorted directed edges
+    std::vector<int> arc_class;                  // reference's "induced" edge orbit id per arc
+    int n_classes = 0;
+};
+
+static bool has(const Pattern &P, int i, int j) { return (P.adj[i] >> j) & 1; }
+
+// all edge-preserving bijections V(H)->V(H)  (= non-induced self-monomorphisms, which for equal edge counts are automorphisms)
+static void enum_aut(const Pattern &P, int l, std::array<uint8_t, GSN_KMAX> &sigma, unsigned used,
+                     std::vector<std::array<uint8_t, GSN_KMAX>> &out) {
+    if (l == P.k) { out.push_back(sigma); return; }
+    for (int v = 0; v < P.k; ++v) {
+        if ((used >> v) & 1) continue;
+        bool ok = true;
+        for (int j = 0; j < l && ok; ++j)
+            if (has(P, l, j) && !has(P, v, sigma[j])) ok = false;
+        if (!ok) continue;
+        sigma[l] = (uint8_t)v;
+        enum_aut(P, l + 1, sigma, used | (1u << v), out);
+    }
+}
+
+static int analyse(int64_t n_edges, const int64_t *edges, int directed_orbits, Pattern &P) {
+    int64_t mx = -1;
+    for (int64_t i = 0; i < 2 * n_edges; ++i) {
+        if (edges[i] < 0) return set_error(GSN_E_INVALID, "pattern vertex id < 0");
+        mx = std::max(mx, edges[i]);
+    }
+    if (mx + 1 > GSN_KMAX) return set_error(GSN_E_UNSUPPORTED, "pattern has %lld vertices; this build handles k <= %d", (long long)(mx + 1), GSN_KMAX);
+    if (mx < 0) return set_error(GSN_E_INVALID, "empty pattern edge list");
+    P.k = (int)mx + 1;
+    for (int64_t i = 0; i < n_edges; ++i) {
+        int u = (int)edges[2 * i], v = (int)edges[2 * i + 1];
+        if (u == v) continue;  // gt.stats.remove_self_loops
+        P.adj[u] |= (uint8_t)(1u << v);
+        P.adj[v] |= (uint8_t)(1u << u);
+    }
+    std::array<uint8_t, GSN_KMAX> sigma{};
+    enum_aut(P, 0, sigma, 0, P.aut);
+    // vertex orbits: orbit id = rank of the orbit's smallest vertex (np.unique(..., return_inverse) on the per-vertex minima)
+    int minrep[GSN_KMAX];
+    for (int v = 0; v < P.k; ++v) minrep[v] = v;
+    for (auto &s : P.aut)
+        for (int i = 0; i < P.k; ++i) minrep[s[i]] = std::min(minrep[s[i]], i);
+    std::vector<int> reps(minrep, minrep + P.k);
+    std::sort(reps.begin(), reps.end());
+    reps.erase(std::unique(reps.begin(), reps.end()), reps.end());
+    P.n_vorbits = (int)reps.size();
+    for (int v = 0; v < P.k; ++v) P.vorbit[v] = (int)(std::lower_bound(reps.begin(), reps.end(), minrep[v]) - reps.begin());
+    // sorted directed edge list + first-seen class numbering
+    std::vector<std::pair<int, int>> keys;
+    for (int u = 0; u < P.k; ++u)
+        for (int v = 0; v < P.k; ++v) {
+            if (!has(P, u, v)) continue;
+            P.arcs.push_back({u, v});
+            int a = P.vorbit[u], b = P.vorbit[v];
+            if (!directed_orbits && a > b) std::swap(a, b);
+            auto it = std::find(keys.begin(), keys.end(), std::make_pair(a, b));
+            if (it == keys.end()) { keys.push_back({a, b}); it = keys.end() - 1; }
+            P.arc_class.push_back((int)(it - keys.begin()));
+        }
+    P.n_classes = (int)keys.size();
+    return GSN_OK;
+}
+
+// ---- plan compilation -----------------------------------------------------------------------------------------
+
+struct Plan {
+    int k, n_fixed, out_col, pattern, root_a, root_b;
+    uint32_t level[GSN_KMAX];
+};
+
+// Matching order: fixed roots first, then greedily the unplaced vertex with most placed neighbours (ties: higher degree,
+// lower id) so candidate sets shrink as early as possible.
+static void matching_order(const Pattern &P, const int *fixed, int n_fixed, int *order) {
+    bool placed[GSN_KMAX] = {false};
+    for (int i = 0; i < n_fixed; ++i) { order[i] = fixed[i]; placed[fixed[i]] = true; }
+    for (int l = n_fixed; l < P.k; ++l) {
+        int best = -1, best_conn = -1, best_deg = -1;
+        for (int v = 0; v < P.k; ++v) {
+            if (placed[v]) continue;
+            int conn = 0;
+            for (int j = 0; j < l; ++j) conn += has(P, v, order[j]);
+            int deg = __builtin_popcount(P.adj[v]);
+            if (conn > best_conn || (conn == best_conn && deg > best_deg)) { best = v; best_conn = conn; best_deg = deg; }
+        }
+        order[l] = best; placed[best] = true;
+    }
+}
+
+// Symmetry-breaking constraints (Grochow & Kellis 2007) for the subgroup A of Aut(H) fixing the roots pointwise:
+// repeatedly take the earliest-ordered vertex v moved by A, require f(v) < f(u) for every other u in v's A-orbit, and
+// descend to the stabiliser of v.  Exactly one map of every A-class satisfies all constraints.
+static void symmetry_constraints(const Pattern &P, const int *fixed, int n_fixed, const int *order,
+                                 std::vector<std::pair<int, int>> &less /* f(first) < f(second) */) {
+    std::vector<std::array<uint8_t, GSN_KMAX>> A;
+    for (auto &s : P.aut) {
+        bool ok = true;
+        for (int i = 0; i < n_fixed; ++i) ok = ok && s[fixed[i]] == fixed[i];
+        if (ok) A.push_back(s);
+    }
+    while (A.size() > 1) {
+        int v = -1;
+        for (int l = 0; l < P.k && v < 0; ++l)
+            for (auto &s : A)
+                if (s[order[l]] != order[l]) { v = order[l]; break; }
+        if (v < 0) break;
+        bool in_orbit[GSN_KMAX] = {false};
+        for (auto &s : A) in_orbit[s[v]] = true;
+        for (int u = 0; u < P.k; ++u)
+            if (u != v && in_orbit[u]) less.push_back({v, u});
+        std::vector<std::array<uint8_t, GSN_KMAX>> S;
+        for (auto &s : A)
+            if (s[v] == v) S.push_back(s);
+        A.swap(S);
+    }
+}
+
+static Plan make_plan(const Pattern &P, int pattern_id, const int *fixed, int n_fixed, int out_col, bool induced) {
+    Plan pl{};
+    pl.k = P.k; pl.n_fixed = n_fixed; pl.out_col = out_col; pl.pattern = pattern_id;
+    pl.root_a = fixed[0]; pl.root_b = n_fixed > 1 ? fixed[1] : 0;
+    int order[GSN_KMAX], pos[GSN_KMAX];
+    matching_order(P, fixed, n_fixed, order);
+    for (int l = 0; l < P.k; ++l) pos[order[l]] = l;
+    std::vector<std::pair<int, int>> less;
+    symmetry_constraints(P, fixed, n_fixed, order, less);
+    for (int l = 0; l < P.k; ++l) {
+        uint32_t adj = 0, nonadj = 0, gt = 0, lt = 0;
+        for (int j = 0; j < l; ++j) {
+            if (has(P, order[l], order[j])) adj |= 1u << j;
+            else if (induced) nonadj |= 1u << j;
+        }
+        for (auto &c : less) {
+            // f(c.first) < f(c.second)
+            if (c.second == order[l] && pos[c.first] < l) gt |= 1u << pos[c.first];   // f_l > f_j
+            if (c.first == order[l] && pos[c.second] < l) lt |= 1u << pos[c.second];  // f_l < f_j
+        }
+        pl.level[l] = adj | (nonadj << 8) | (gt << 16) | (lt << 24);
+    }
+    return pl;
+}
+
+// orbit representatives of the directed edges under Aut(H)
+static void arc_orbits(const Pattern &P, std::vector<int> &rep_arc /* indices into P.arcs */) {
+    std::vector<int> orbit_of(P.arcs.size(), -1);
+    for (size_t i = 0; i < P.arcs.size(); ++i) {
+        if (orbit_of[i] >= 0) continue;
+        rep_arc.push_back((int)i);
+        for (auto &s : P.aut) {
+            std::pair<int, int> img{s[P.arcs[i].first], s[P.arcs[i].second]};
+            size_t j = std::lower_bound(P.arcs.begin(), P.arcs.end(), img) - P.arcs.begin();
+            orbit_of[j] = (int)rep_arc.size() - 1;
+        }
+    }
+}
+
+}  // namespace gsn
+
+using namespace gsn;
+
+extern "C" int gsn_pattern_orbits(int64_t n_edges, const int64_t *edges, int directed_orbits, int64_t *out_k,
+                                  int64_t *out_vertex_orbit, int64_t *out_n_vertex_orbits, int64_t *out_arcs,
+                                  int64_t *out_arc_orbit, int64_t *out_n_arcs, int64_t *out_n_edge_orbits,
+                                  int64_t *out_aut_count) {
+    if (!edges || n_edges <= 0) return set_error(GSN_E_INVALID, "gsn_pattern_orbits: no edges");
+    Pattern P;
+    int rc = analyse(n_edges, edges, directed_orbits, P);
+    if (rc) return rc;
+    if (out_k) *out_k = P.k;
+    if (out_vertex_orbit) for (int v = 0; v < P.k; ++v) out_vertex_orbit[v] = P.vorbit[v];
+    if (out_n_vertex_orbits) *out_n_vertex_orbits = P.n_vorbits;
+    for (size_t i = 0; i < P.arcs.size(); ++i) {
+        if (out_arcs) { out_arcs[2 * i] = P.arcs[i].first; out_arcs[2 * i + 1] = P.arcs[i].second; }
+        if (out_arc_orbit) out_arc_orbit[i] = P.arc_class[i];
+    }
+    if (out_n_arcs) *out_n_arcs = (int64_t)P.arcs.size();
+    if (out_n_edge_orbits) *out_n_edge_orbits = P.n_classes;
+    if (out_aut_count) *out_aut_count = (int64_t)P.aut.size();
+    return GSN_OK;
+}
+
+extern "C" int gsn_count_plan_build(int mode, int induced, int directed_orbits, int64_t n_patterns, const int64_t *pat_ptr,
+                                    const int64_t *pat_edges, uint32_t *plan, int64_t capacity, int64_t *out_words,
+                                    int64_t *out_n_cols) {
+    if (mode != GSN_MODE_VERTEX && mode != GSN_MODE_EDGE) return set_error(GSN_E_INVALID, "mode must be 0 (vertex) or 1 (edge)");
+    if (n_patterns <= 0 || !pat_ptr || !pat_edges) return set_error(GSN_E_INVALID, "no patterns");
+    std::vector<Plan> plans;
+    int col0 = 0, kmax = 0;
+    for (int64_t p = 0; p < n_patterns; ++p) {
+        Pattern P;
+        int rc = analyse(pat_ptr[p + 1] - pat_ptr[p], pat_edges + 2 * pat_ptr[p], directed_orbits, P);
+        if (rc) return rc;
+        kmax = std::max(kmax, P.k);
+        if (mode == GSN_MODE_VERTEX) {
+            for (int o = 0; o < P.n_vorbits; ++o) {
+                int rep = 0;
+                while (P.vorbit[rep] != o) ++rep;  // smallest vertex of the orbit
+                plans.push_back(make_plan(P, (int)p, &rep, 1, col0 + o, induced != 0));
+            }
+            col0 += P.n_vorbits;
+        } else {
+            std::vector<int> reps;
+            arc_orbits(P, reps);
+            for (int r : reps) {
+                int fixed[2] = {P.arcs[r].first, P.arcs[r].second};
+                plans.push_back(make_plan(P, (int)p, fixed, 2, col0 + P.arc_class[r], induced != 0));
+            }
+            col0 += P.n_classes;
+        }
+    }
+    // group the plans of one output column together: a kernel task is (column, row) and runs that column's plans
+    std::stable_sort(plans.begin(), plans.end(), [](const Plan &a, const Plan &b) { return a.out_col < b.out_col; });
+    const int64_t plans_off = PLAN_HEADER_WORDS + (col0 + 1);
+    int64_t words = plans_off + (int64_t)plans.size() * PLAN_STRIDE_WORDS;
+    if (out_words) *out_words = words;
+    if (out_n_cols) *out_n_cols = col0;
+    if (!plan) return GSN_OK;
+    if (capacity < words) return set_error(GSN_E_NOSPACE, "plan buffer too small: need %lld words", (long long)words);
+    plan[0] = PLAN_MAGIC; plan[1] = (uint32_t)mode; plan[2] = (uint32_t)(induced != 0); plan[3] = (uint32_t)plans.size();
+    plan[4] = (uint32_t)col0; plan[5] = (uint32_t)kmax; plan[6] = (uint32_t)(directed_orbits != 0); plan[7] = (uint32_t)plans_off;
+    {   // col_ptr[c] .. col_ptr[c+1]: plan indices of column c
+        uint32_t *cp = plan + PLAN_HEADER_WORDS;
+        size_t i = 0;
+        for (int c = 0; c <= col0; ++c) {
+            while (i < plans.size() && plans[i].out_col < c) ++i;
+            cp[c] = (uint32_t)i;
+        }
+    }
+    for (size_t i = 0; i < plans.size(); ++i) {
+        uint32_t *w = plan + plans_off + i * PLAN_STRIDE_WORDS;
+        const Plan &pl = plans[i];
+        w[0] = (uint32_t)pl.k | ((uint32_t)pl.n_fixed << 8) | ((uint32_t)pl.out_col << 16);
+        w[1] = (uint32_t)pl.pattern | ((uint32_t)pl.root_a << 16) | ((uint32_t)pl.root_b << 24);
+        for (int l = 0; l < GSN_KMAX; ++l) w[2 + l] = pl.level[l];
+    }
+    return GSN_OK;
+}

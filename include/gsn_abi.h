@@ -1,0 +1,168 @@
+/*
+ * gsn_abi.h -- C ABI of libgsn_hip.so, the MI355X-native (gfx950) replacement for GSN's two data-parallel
+ * hot paths.  Plain pointers and sizes only; no torch / C++ types cross this boundary.
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to gbouritsas/GSN).  The
+ * reference's "plugin API" for these paths is plain Python imports; INTEGRATION.md shows the
+ * ctypes binding a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - every function returns int: GSN_OK (0) or a negative GSN_E_* code; gsn_last_error() returns a thread-local
+ *     message for the last failing call on this thread.  No C++ exception crosses the ABI.
+ *   - the library never allocates or frees caller-visible memory: outputs and scratch are caller buffers
+ *     (query sizes first).  Device entry points take device pointers plus `stream` (a hipStream_t passed as
+ *     void*, e.g. torch.cuda.current_stream().cuda_stream) and are asynchronous on that stream.
+ *   - host entry points (pattern analysis, plan building) are synchronous, re-entrant and thread-safe.
+ *   - int64 index tensors are accepted as PyTorch hands them over (edge_index is int64 [2, E], row-major).
+ */
+#ifndef GSN_ABI_H
+#define GSN_ABI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSN_ABI_VERSION 1
+#define GSN_KMAX 8 /* max pattern vertices the counting kernel handles (reference configs use k <= 8) */
+
+enum {
+    GSN_OK = 0,
+    GSN_E_INVALID = -1,     /* bad argument */
+    GSN_E_UNSUPPORTED = -2, /* valid in the reference but outside this build (e.g. k > GSN_KMAX, n > 1024) */
+    GSN_E_HIP = -3,         /* HIP runtime error (message has hipGetErrorString) */
+    GSN_E_NOSPACE = -4,     /* caller buffer too small */
+    GSN_E_NODEVICE = -5     /* no gfx950 device visible */
+};
+
+enum { GSN_MODE_VERTEX = 0, GSN_MODE_EDGE = 1 };
+
+/* per-graph status written by gsn_count_hip into `status` (int32 per graph) */
+enum {
+    GSN_ST_OK = 0,
+    GSN_ST_KEYERROR = 1, /* a match uses an edge direction that is not a column of edge_index: the reference raises
+                            KeyError at utils_graph_processing.py:173 */
+    GSN_ST_TOO_LARGE = 2, /* graph exceeds max_nodes / max_edges given to the call */
+    GSN_ST_BAD_INDEX = 3  /* a vertex id outside [0, num_nodes) */
+};
+
+const char *gsn_last_error(void);
+int gsn_version(void);
+/* number of visible gfx950 devices (0 if none / no driver); never fails */
+int gsn_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * HP-1  pattern analysis (host).  Replaces utils_graph_processing.automorphism_orbits (:10-56) and
+ * induced_edge_automorphism_orbits (:58-100): vertex orbits of Aut(H) numbered by rank of the orbit's smallest
+ * vertex; the pattern's directed edges sorted by (u,v); edge-orbit ids in first-seen order of the key
+ * {orbit(u),orbit(v)} (ordered pair iff directed_orbits); |Aut(H)|.
+ *   edges            [n_edges][2] int64, vertices 0..k-1; self loops / duplicates are dropped like the reference does
+ *   out_vertex_orbit [GSN_KMAX]
+ *   out_arcs         [k*(k-1)][2]  sorted directed edge list;  out_arc_orbit [k*(k-1)]
+ * ---------------------------------------------------------------------------------------------------------------- */
+int gsn_pattern_orbits(int64_t n_edges, const int64_t *edges, int directed_orbits, int64_t *out_k,
+                       int64_t *out_vertex_orbit, int64_t *out_n_vertex_orbits, int64_t *out_arcs,
+                       int64_t *out_arc_orbit, int64_t *out_n_arcs, int64_t *out_n_edge_orbits,
+                       int64_t *out_aut_count);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * HP-1  counting plan (host).  Compiles a list of patterns (the reference's `subgraph_dicts`,
+ * utils_data_gen.py:31-42) into the packed table the kernel executes: one rooted search per (pattern, vertex orbit)
+ * [vertex mode] or per (pattern, directed-edge orbit) [edge mode], with symmetry-breaking order constraints for the
+ * root's stabiliser.  Output columns follow utils_ids.py:19-25: patterns in the given order, orbit ids ascending.
+ *   pat_ptr [n_patterns+1] into pat_edges [.][2]
+ *   plan    caller buffer of `capacity` uint32 words (call with plan=NULL to get *out_words)
+ * ---------------------------------------------------------------------------------------------------------------- */
+int gsn_count_plan_build(int mode, int induced, int directed_orbits, int64_t n_patterns, const int64_t *pat_ptr,
+                         const int64_t *pat_edges, uint32_t *plan, int64_t capacity, int64_t *out_words,
+                         int64_t *out_n_cols);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * HP-1  batched counting (device).  Replaces utils_ids.subgraph_counts2ids (:7-29) applied to every graph of a batch,
+ * i.e. the per-graph / per-pattern calls of subgraph_isomorphism_vertex_counts (utils_graph_processing.py:103-131) or
+ * subgraph_isomorphism_edge_counts (:134-179) and the graph-tool VF2 enumeration under them.  One launch per batch.
+ *   plan_host / plan_dev  the same plan table on host (launch configuration) and in device memory (kernel input)
+ *   node_ptr [G+1], edge_ptr [G+1]   int64 device: graph g owns vertices node_ptr[g]..node_ptr[g+1] and columns
+ *                                    edge_ptr[g]..edge_ptr[g+1] of edge_index
+ *   edge_index            int64 device [2][E_total] (row 1 starts at edge_index + edge_row_stride); both directions
+ *                         present as in PyG; self loops tolerated (their rows stay 0); duplicates: last column wins
+ *   ids_are_global        1: vertex ids carry the batch offset node_ptr[g] (PyG collate), 0: graph-local ids
+ *   graph_ids             optional int32 device [n_items]: process only these graphs (NULL = all G, n_items = G)
+ *   max_nodes, max_edges  upper bounds over the processed graphs (sizes LDS); violators get GSN_ST_TOO_LARGE
+ *   out                   int64 device [rows_total][n_cols] (rows = vertices or columns); fully overwritten for the
+ *                         processed graphs, zeros included
+ *   status                int32 device [G], written per processed graph (GSN_ST_*)
+ * ---------------------------------------------------------------------------------------------------------------- */
+int gsn_count_hip(const uint32_t *plan_host, const uint32_t *plan_dev, int64_t plan_words, int64_t n_graphs,
+                  const int64_t *node_ptr, const int64_t *edge_ptr, const int64_t *edge_index,
+                  int64_t edge_row_stride, int ids_are_global, const int32_t *graph_ids, int64_t n_items,
+                  int64_t max_nodes, int64_t max_edges, int64_t *out, int32_t *status, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * HP-2  aggregation target index (device).  The scatter-add of the layers,
+ *   torch.sparse.FloatTensor(edge_index, msgs, [N,N,d]) + torch.sparse.sum(msgs, aggr_dim).to_dense()
+ * (GSN_sparse.py:140-143, GSN_edge_sparse.py:136-139, MPNN_*.py, *_ogb.py), is executed as a segmented sum over a
+ * target-sorted edge permutation.  This builds that CSR once per batch (stable counting sort by target):
+ *   index   int64 device [E]  aggregation targets (edge_index[1] for flow=source_to_target, [0] otherwise)
+ *   seg_ptr int32 device [N+1] out; perm int32 device [E] out (edge ids grouped by target, original order kept inside)
+ *   scratch int32 device [N+1]
+ * ---------------------------------------------------------------------------------------------------------------- */
+int gsn_csr_build_hip(int64_t n_nodes, int64_t n_edges, const int64_t *index, int32_t *seg_ptr, int32_t *perm,
+                      int32_t *scratch, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * HP-2  propagate: fused gather -> message -> segmented sum (device, fp32).
+ *   out[t, :] = sum_{e : tgt(e) = t} msg_e,   msg_e assembled on the fly from up to three sources
+ *     kind GSN_MSG_CAT  : msg_e = concat(a[src_e] (da), b_e or b[src_e] (db), c_e (dc))   -- 'gin' messages
+ *                         (GSN_sparse.py:160-164, GSN_edge_sparse.py:154-158) and plain pre-computed messages (da=0,dc=0)
+ *     kind GSN_MSG_RELU_SUM : msg_e = relu(a[src_e] + b_e or b[src_e] + c_e), all width d  -- 'ogb' messages
+ *                         (GSN_edge_sparse_ogb.py:119-125, MPNN_edge_sparse_ogb.py message)
+ *   a: per-node [N][da];  b: per-edge [E][db] (b_per_node=0) or per-node [N][db] gathered at src (b_per_node=1);
+ *   c: per-edge [E][dc];  any of a/b/c may be NULL with width 0.   out: [N][d_out], fully overwritten.
+ *   src int64 [E] message source vertex (edge_index[0] for source_to_target); seg_ptr/perm from gsn_csr_build_hip.
+ * gsn_propagate_bwd_hip is the adjoint: given g_out [N][d_out] it writes g_a [N][da] (overwritten, gathers through the
+ * source-sorted CSR seg_ptr_src/perm_src), g_b ([E][db] or [N][db]) and g_c [E][dc]; for RELU_SUM the forward inputs
+ * are needed again to recompute the relu mask.
+ * ---------------------------------------------------------------------------------------------------------------- */
+enum { GSN_MSG_CAT = 0, GSN_MSG_RELU_SUM = 1 };
+
+int gsn_propagate_fwd_hip(int kind, int64_t n_nodes, int64_t n_edges, const int64_t *src, const int32_t *seg_ptr,
+                          const int32_t *perm, const float *a, int64_t da, const float *b, int64_t db,
+                          int b_per_node, const float *c, int64_t dc, float *out, void *stream);
+
+int gsn_propagate_bwd_hip(int kind, int64_t n_nodes, int64_t n_edges, const int64_t *src, const int64_t *tgt,
+                          const int32_t *seg_ptr_src, const int32_t *perm_src, const float *a, int64_t da,
+                          const float *b, int64_t db, int b_per_node, const float *c, int64_t dc,
+                          const float *g_out, float *g_a, float *g_b, float *g_c, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * HP-2  fused dense stage (device, fp32 MFMA v_mfma_f32_32x32x2_f32).  One models_misc.mlp layer
+ * (models_misc.py:52-58)   Y = act( bn( X W^T + bias ) )   over M rows, where the rows of X are assembled on the fly
+ * as a concatenation of up to four blocks, each either direct ([M][w]) or gathered through an int64 index
+ * ([R][w] rows picked by idx[M]) -- this is torch.cat((x_i, x_j, identifiers.., edge_features), -1) feeding msg_fn
+ * (GSN_sparse.py:166-171, GSN_edge_sparse.py:160-165) without materialising the cat or the gathers -- and, optionally,
+ * a segmented-sum epilogue  out[t] = sum_{rows r of segment t} Y[r]  (the scatter-add, rows taken in `perm` order).
+ *   W [n_out][k_total] row-major fp32 as nn.Linear stores it; bias [n_out] or NULL
+ *   bn_scale/bn_shift [n_out] or NULL: eval-mode BatchNorm1d folded to y*scale+shift by the caller
+ *       (scale = gamma/sqrt(running_var+eps), shift = beta - running_mean*scale)
+ *   act: 0 identity, 1 relu, 2 elu, 3 tanh   (models_misc.choose_activation)
+ *   row_perm int32 [M] or NULL: row r of the tile space reads logical row row_perm[r] (edge ids in target order)
+ *   seg_ptr  int32 [n_seg+1] or NULL: if given, Y is not written; out is [n_seg][n_out] segmented sums over tile-space rows
+ *   stats    double [2][n_out] or NULL: if given (train-mode BN, first pass) accumulates per-column sum and sum of
+ *            squares of the PRE-BN values (X W^T + bias) and skips bn/act/output
+ * ---------------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    const float *data;   /* [rows][width] fp32, row stride = width */
+    const int64_t *idx;  /* NULL: direct (row r); else gather data[idx[r]] */
+    int64_t width;
+} gsn_block;
+
+int gsn_linear_fwd_hip(int64_t m_rows, int n_blocks, const gsn_block *blocks, const float *W, const float *bias,
+                       int64_t n_out, const float *bn_scale, const float *bn_shift, int act, const int32_t *row_perm,
+                       const int32_t *seg_ptr, int64_t n_seg, float *out, double *stats, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSN_ABI_H */

@@ -1,0 +1,630 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE's own Python.
+
+Runs only in the build container (needs /root/reference); the GPU box and the tests read the
+committed ``*.npz`` files, never the reference.  Nothing from the reference is copied: its modules
+are imported from where they lie, with two things it cannot import here replaced by stand-ins
+that live in this script:
+
+* ``graph_tool`` (C++/Boost, not installable here) -> a small networkx-backed module exposing only
+  the surface utils_graph_processing.py touches.  Enumeration is done by networkx 3.4.2's VF2
+  (``GraphMatcher.subgraph_monomorphisms_iter`` for induced=False, ``subgraph_isomorphisms_iter``
+  for induced=True), i.e. an implementation independent of both graph-tool and our oracle.
+* ``torch_geometric.utils`` / ``ogb`` -> the handful of helpers the hot-path files import
+  (semantics per PyG >= 1.4.3 docs: remove_self_loops keeps order, to_undirected = concat both
+  directions + coalesce (sort by row*N+col, unique), degree = scatter-add of ones).
+
+Because graph-tool itself is absent, parity is pinned to "reference Python semantics over an
+independent VF2", cross-checked against closed forms for strongly regular graphs (see
+tests/test_oracle_golden.py).  Usage:  python tests/golden/make_golden.py [--only orbits,counts,layers]
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+import types
+import warnings
+
+import numpy as np
+import torch
+import networkx as nx
+from networkx.algorithms import isomorphism as nxiso
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+
+from gsn_amd import synth  # noqa: E402  (ours)
+
+
+# ----------------------------------------------------------------------------------------------
+# stand-in for graph_tool (only what the reference's hot path touches)
+# ----------------------------------------------------------------------------------------------
+class _Map:
+    """What graph-tool yields per match: a vertex property map indexed by pattern vertex."""
+
+    def __init__(self, arr):
+        self._a = np.asarray(arr, dtype=np.int32)
+
+    def __iter__(self):
+        return iter(self._a.tolist())
+
+    def __len__(self):
+        return len(self._a)
+
+    def get_array(self):
+        return self._a
+
+
+class _Graph:
+    def __init__(self, directed=True):
+        self.directed = directed
+        self._edges = []
+        self._n = 0
+
+    def add_edge_list(self, edge_list):
+        for e in edge_list:
+            u, v = int(e[0]), int(e[1])
+            self._edges.append((u, v))
+            self._n = max(self._n, u + 1, v + 1)
+
+    def get_edges(self):
+        return np.asarray(self._edges, dtype=np.int64).reshape(-1, 2)
+
+    def get_vertices(self):
+        return np.arange(self._n)
+
+    def to_nx(self):
+        g = nx.DiGraph() if self.directed else nx.Graph()
+        g.add_nodes_from(range(self._n))
+        g.add_edges_from(self._edges)
+        return g
+
+
+def _remove_self_loops(g):
+    g._edges = [(u, v) for (u, v) in g._edges if u != v]
+
+
+def _remove_parallel_edges(g):
+    seen = set()
+    out = []
+    for (u, v) in g._edges:
+        key = (u, v) if g.directed else (min(u, v), max(u, v))
+        if key not in seen:
+            seen.add(key)
+            out.append((u, v))
+    g._edges = out
+
+
+def _subgraph_isomorphism(sub, g, max_n=0, vertex_label=None, edge_label=None, induced=False,
+                          subgraph=True, generator=False):
+    assert subgraph
+    H, G = sub.to_nx(), g.to_nx()
+    k = H.number_of_nodes()
+    gm = (nxiso.DiGraphMatcher if g.directed else nxiso.GraphMatcher)(G, H)
+    it = gm.subgraph_isomorphisms_iter() if induced else gm.subgraph_monomorphisms_iter()
+
+    def gen():
+        for m in it:  # dict: G node -> H node
+            arr = np.empty(k, dtype=np.int32)
+            for gv, hv in m.items():
+                arr[hv] = gv
+            yield _Map(arr)
+
+    return gen() if generator else list(gen())
+
+
+def install_stubs():
+    gt = types.ModuleType("graph_tool")
+    gt.Graph = _Graph
+    gt.stats = types.ModuleType("graph_tool.stats")
+    gt.stats.remove_self_loops = _remove_self_loops
+    gt.stats.remove_parallel_edges = _remove_parallel_edges
+    gt.topology = types.ModuleType("graph_tool.topology")
+    gt.topology.subgraph_isomorphism = _subgraph_isomorphism
+    sys.modules["graph_tool"] = gt
+    sys.modules["graph_tool.stats"] = gt.stats
+    sys.modules["graph_tool.topology"] = gt.topology
+
+    tg = types.ModuleType("torch_geometric")
+    tgu = types.ModuleType("torch_geometric.utils")
+
+    def remove_self_loops(edge_index, edge_attr=None):
+        mask = edge_index[0] != edge_index[1]
+        return edge_index[:, mask], (None if edge_attr is None else edge_attr[mask])
+
+    def to_undirected(edge_index, num_nodes=None):
+        n = int(edge_index.max()) + 1 if num_nodes is None else num_nodes
+        row, col = edge_index
+        row, col = torch.cat([row, col]), torch.cat([col, row])
+        key = torch.unique(row * n + col)  # sorted
+        return torch.stack([key // n, key % n], 0)
+
+    def degree(index, num_nodes=None, dtype=None):
+        n = int(index.max()) + 1 if num_nodes is None else num_nodes
+        out = torch.zeros(n, dtype=dtype or torch.float)
+        return out.scatter_add_(0, index, torch.ones_like(index, dtype=out.dtype))
+
+    def is_undirected(edge_index, *a, **k):
+        return True
+
+    tgu.remove_self_loops = remove_self_loops
+    tgu.to_undirected = to_undirected
+    tgu.degree = degree
+    tgu.is_undirected = is_undirected
+    tg.utils = tgu
+    sys.modules["torch_geometric"] = tg
+    sys.modules["torch_geometric.utils"] = tgu
+
+    ogb = types.ModuleType("ogb")
+    gpp = types.ModuleType("ogb.graphproppred")
+    me = types.ModuleType("ogb.graphproppred.mol_encoder")
+    me.AtomEncoder = me.BondEncoder = object
+    ou = types.ModuleType("ogb.utils")
+    of = types.ModuleType("ogb.utils.features")
+    of.get_atom_feature_dims = lambda: [119, 4, 12, 12, 10, 6, 6, 2, 2]
+    of.get_bond_feature_dims = lambda: [5, 6, 2]
+    for name, m in [("ogb", ogb), ("ogb.graphproppred", gpp), ("ogb.graphproppred.mol_encoder", me),
+                    ("ogb.utils", ou), ("ogb.utils.features", of)]:
+        sys.modules[name] = m
+
+
+def import_reference():
+    install_stubs()
+    sys.path.insert(1, REF)
+    import importlib
+    mods = {}
+    for name in ["utils_graph_processing", "utils_ids", "models_misc", "utils_graph_learning"]:
+        mods[name] = importlib.import_module(name)
+    for name in ["GSN_sparse", "GSN_edge_sparse", "MPNN_sparse", "MPNN_edge_sparse",
+                 "GSN_edge_sparse_ogb", "MPNN_edge_sparse_ogb"]:
+        mods[name] = importlib.import_module("graph_filters." + name)
+    for m in mods.values():
+        assert m.__file__.startswith(REF), m.__file__
+    return mods
+
+
+# ----------------------------------------------------------------------------------------------
+# pattern families (how utils.get_custom_edge_list builds them: networkx generators / read_graph6,
+# utils.py:16-33) -- edge lists "as networkx orders them"
+# ----------------------------------------------------------------------------------------------
+def pattern_families():
+    fams = {}
+    fams["cycle_graph"] = [list(nx.cycle_graph(k).edges) for k in range(3, 9)]
+    fams["complete_graph"] = [list(nx.complete_graph(k).edges) for k in range(3, 7)]
+    fams["path_graph"] = [list(nx.path_graph(k).edges) for k in range(3, 7)]
+    fams["star_graph"] = [list(nx.star_graph(k).edges) for k in range(2, 6)]
+    fams["binomial_tree"] = [list(nx.binomial_tree(k).edges) for k in range(2, 4)]
+    fams["diamond_graph"] = [list(nx.diamond_graph().edges)]
+    fams["nonisomorphic_trees"] = [list(g.edges) for k in range(3, 7) for g in nx.nonisomorphic_trees(k)]
+    for k in range(3, 7):
+        gs = nx.read_graph6(os.path.join(REF, "datasets/all_simple_graphs/graph%dc.g6" % k))
+        gs = gs if isinstance(gs, list) else [gs]
+        fams["all_simple_graphs_%d" % k] = [list(g.edges) for g in gs]
+    return fams
+
+
+def pack_edge_lists(edge_lists):
+    """ragged list of edge lists -> (ptr, flat [m,2])"""
+    ptr = np.cumsum([0] + [len(e) for e in edge_lists]).astype(np.int64)
+    flat = np.asarray([p for e in edge_lists for p in e], dtype=np.int64).reshape(-1, 2)
+    return ptr, flat
+
+
+def gen_orbits(ref, out):
+    ugp = ref["utils_graph_processing"]
+    fams = pattern_families()
+    rec = {}
+    names = []
+    import io
+    import contextlib
+    for fam, edge_lists in fams.items():
+        for pi, el in enumerate(edge_lists):
+            key = "%s/%d" % (fam, pi)
+            names.append(key)
+            with contextlib.redirect_stdout(io.StringIO()):
+                _, part, memb, aut = ugp.automorphism_orbits(edge_list=el, print_msgs=False, directed=False,
+                                                             directed_orbits=False)
+                k = len(memb)
+                rec[key + "/edges"] = np.asarray(el, dtype=np.int64).reshape(-1, 2)
+                rec[key + "/v_membership"] = np.asarray([memb[v] for v in range(k)], dtype=np.int64)
+                rec[key + "/aut_count"] = np.int64(aut)
+                rec[key + "/n_vorbits"] = np.int64(len(part))
+                for dirorb in (False, True):
+                    _, epart, ememb, aut2 = ugp.induced_edge_automorphism_orbits(edge_list=el, directed=False,
+                                                                                 directed_orbits=dirorb)
+                    assert aut2 == aut
+                    sfx = "_dir" if dirorb else ""
+                    rec[key + "/e_membership" + sfx] = np.asarray([ememb[i] for i in range(len(ememb))], dtype=np.int64)
+                    rec[key + "/n_eorbits" + sfx] = np.int64(len(epart))
+                    # the sorted bidirectional edge list the membership is indexed by: recover it from the partition
+                    elist = [None] * len(ememb)
+                    seen = {}
+                    for orb, edges in epart.items():
+                        for e in edges:
+                            seen.setdefault(orb, []).append(tuple(int(x) for x in e))
+                    # positions: edges were visited in sorted order; rebuild by sorting all directed edges
+                    alle = sorted(e for edges in seen.values() for e in edges)
+                    rec[key + "/e_list" + sfx] = np.asarray(alle, dtype=np.int64).reshape(-1, 2)
+                # deprecated line-graph variant (utils_graph_processing.py:189) for a few small patterns
+                if fam in ("cycle_graph", "path_graph", "star_graph", "diamond_graph", "all_simple_graphs_4") and len(el) > 1:
+                    _, lpart, lmemb, aut3 = ugp.edge_automorphism_orbits(edge_list=el, directed=False)
+                    rec[key + "/line_membership"] = np.asarray([lmemb[i] for i in range(len(lmemb))], dtype=np.int64)
+                    rec[key + "/line_n_orbits"] = np.int64(len(lpart))
+    rec["names"] = np.asarray(names)
+    np.savez_compressed(os.path.join(out, "orbits.npz"), **rec)
+    print("orbits: %d patterns" % len(names))
+
+
+# ----------------------------------------------------------------------------------------------
+# counting cases
+# ----------------------------------------------------------------------------------------------
+def sr25_graphs():
+    gs = nx.read_graph6(os.path.join(REF, "datasets/SR_graphs/sr251256/sr251256.g6"))
+    out = []
+    for g in gs:
+        n = g.number_of_nodes()
+        out.append((n, synth.undirected_to_edge_index(n, list(g.edges()))))  # = to_undirected(edges), sorted
+    return out
+
+
+def imdb_graphs():
+    """edge_mat exactly as the reference's TU loader builds it (utils_data_prep.py:58-110): networkx
+    graph filled row by row, then g.edges() followed by the reversed pairs."""
+    out = []
+    with open(os.path.join(REF, "datasets/social/IMDBBINARY/IMDBBINARY.txt")) as f:
+        n_g = int(f.readline())
+        for _ in range(n_g):
+            n, _l = (int(w) for w in f.readline().split())
+            g = nx.Graph()
+            for j in range(n):
+                g.add_node(j)
+                row = [int(w) for w in f.readline().split()]
+                for k in row[2:2 + row[1]]:
+                    g.add_edge(j, k)
+            edges = [list(p) for p in g.edges()]
+            edges.extend([[i, j] for j, i in edges])
+            ei = np.asarray(edges, dtype=np.int64).reshape(-1, 2).T
+            out.append((n, np.ascontiguousarray(ei)))
+    return out
+
+
+def run_counts(ref, graphs, edge_lists, mode, induced, directed_orbits=False, num_nodes=None):
+    """-> list of int64 arrays [rows, sum orbits] via the reference's subgraph_counts2ids-style loop
+    (count_fn per pattern, concat, .long()), calling the reference functions directly."""
+    import io
+    import contextlib
+    ugp = ref["utils_graph_processing"]
+    dicts = []
+    with contextlib.redirect_stdout(io.StringIO()):
+        for el in edge_lists:
+            fn = ugp.automorphism_orbits if mode == "vertex" else ugp.induced_edge_automorphism_orbits
+            sg, part, memb, aut = fn(edge_list=el, directed=False, directed_orbits=directed_orbits)
+            dicts.append({"subgraph": sg, "orbit_partition": part, "orbit_membership": memb, "aut_count": aut})
+    cfn = ugp.subgraph_isomorphism_vertex_counts if mode == "vertex" else ugp.subgraph_isomorphism_edge_counts
+    outs = []
+    for gi, (n, ei) in enumerate(graphs):
+        nn = n if num_nodes is None else num_nodes[gi]
+        ids = None
+        for d in dicts:
+            c = cfn(torch.from_numpy(ei), subgraph_dict=d, induced=induced, num_nodes=nn, directed=False)
+            assert c.dtype == torch.float64
+            ids = c if ids is None else torch.cat((ids, c), 1)
+        outs.append(ids.long().numpy())
+    return outs
+
+
+def save_case(rec, name, graphs, edge_lists, mode, induced, outs, directed_orbits=False, num_nodes=None):
+    b = synth.collate([(n if num_nodes is None else num_nodes[i], ei) for i, (n, ei) in enumerate(graphs)])
+    pptr, pflat = pack_edge_lists(edge_lists)
+    rec[name + "/node_ptr"] = b.node_ptr
+    rec[name + "/edge_ptr"] = b.edge_ptr
+    rec[name + "/edge_index_local"] = np.concatenate([ei for _, ei in graphs], axis=1) if graphs else np.zeros((2, 0), np.int64)
+    rec[name + "/pattern_ptr"] = pptr
+    rec[name + "/pattern_edges"] = pflat
+    rec[name + "/mode"] = np.asarray(mode)
+    rec[name + "/induced"] = np.bool_(induced)
+    rec[name + "/directed_orbits"] = np.bool_(directed_orbits)
+    rec[name + "/counts"] = np.concatenate(outs, axis=0) if outs else np.zeros((0, 0), np.int64)
+    rec.setdefault("names", []).append(name)
+
+
+def gen_counts(ref, out):
+    rec = {}
+    t0 = time.time()
+    cyc = lambda ks: [list(nx.cycle_graph(k).edges) for k in ks]
+    clq = lambda ks: [list(nx.complete_graph(k).edges) for k in ks]
+
+    # --- SR(25,12,5,6): BASELINE config 1.  induced (README.md:84) for all 15 graphs; non-induced for 2.
+    sr = sr25_graphs()
+    for mode in ("vertex", "edge"):
+        o = run_counts(ref, sr, cyc(range(3, 7)), mode, True)
+        save_case(rec, "sr25_cycle3-6_induced_%s" % mode, sr, cyc(range(3, 7)), mode, True, o)
+        print("sr25 induced", mode, "%.0fs" % (time.time() - t0), flush=True)
+    for mode in ("vertex", "edge"):
+        o = run_counts(ref, sr[:2], cyc(range(3, 6)), mode, False)
+        save_case(rec, "sr25_cycle3-5_mono_%s" % mode, sr[:2], cyc(range(3, 6)), mode, False, o)
+        print("sr25 mono", mode, "%.0fs" % (time.time() - t0), flush=True)
+    o = run_counts(ref, sr[:1], cyc([6]), "edge", False)
+    save_case(rec, "sr25_cycle6_mono_edge_g0", sr[:1], cyc([6]), "edge", False, o)
+    print("sr25 C6 mono", "%.0fs" % (time.time() - t0), flush=True)
+
+    # --- IMDB-BINARY (config 3): cliques k<=5, GSN-v (vertex) and GSN-e (edge), non-induced (README.md:99)
+    imdb = imdb_graphs()
+    sizes = np.array([n for n, _ in imdb])
+    sel = [i for i in range(24) if i not in (8, 11, 15)] + [int(i) for i in np.argsort(-sizes)[2:5]]  # skip the 3 with >1M K5 maps (networkx speed)
+    sub = [imdb[i] for i in sel]
+    for mode in ("vertex", "edge"):
+        o = run_counts(ref, sub, clq(range(3, 6)), mode, False)
+        save_case(rec, "imdb_clique3-5_mono_%s" % mode, sub, clq(range(3, 6)), mode, False, o)
+        print("imdb", mode, "%.0fs" % (time.time() - t0), flush=True)
+    big = [imdb[int(np.argmax(sizes))]]
+    o = run_counts(ref, big, clq([3, 4]), "vertex", False)
+    save_case(rec, "imdb_largest_clique3-4_mono_vertex", big, clq([3, 4]), "vertex", False, o)
+    print("imdb largest n=%d E=%d" % (big[0][0], big[0][1].shape[1]), "%.0fs" % (time.time() - t0), flush=True)
+
+    # --- ZINC-shape synthetic molecules (config 2): cycles 3..6 (and up to 8 for GSN-v as README.md:112)
+    zb = synth.zinc_shape_batch(48, seed=0)
+    zg = [zb.graph(g) for g in range(zb.num_graphs)]
+    for mode, ks in (("edge", range(3, 7)), ("vertex", range(3, 9))):
+        for induced in (False, True):
+            o = run_counts(ref, zg, cyc(ks), mode, induced)
+            save_case(rec, "zinc48_cycle%d-%d_%s_%s" % (ks[0], ks[-1], "induced" if induced else "mono", mode),
+                      zg, cyc(ks), mode, induced, o)
+    print("zinc", "%.0fs" % (time.time() - t0), flush=True)
+
+    # --- ER graphs with the 21 connected 5-vertex patterns (config 5) + k=3,4 families
+    g5 = nx.read_graph6(os.path.join(REF, "datasets/all_simple_graphs/graph5c.g6"))
+    pats5 = [list(g.edges) for g in g5]
+    pats345 = []
+    for k in (3, 4, 5):
+        gs = nx.read_graph6(os.path.join(REF, "datasets/all_simple_graphs/graph%dc.g6" % k))
+        pats345 += [list(g.edges) for g in (gs if isinstance(gs, list) else [gs])]
+    er = [synth.er_graph(8, 12, 1), synth.er_graph(16, 40, 2), synth.er_graph(32, 80, 3), synth.er_graph(20, 60, 4)]
+    for mode in ("vertex", "edge"):
+        for induced in (False, True):
+            o = run_counts(ref, er, pats345, mode, induced)
+            save_case(rec, "er_small_allsimple3-5_%s_%s" % ("induced" if induced else "mono", mode),
+                      er, pats345, mode, induced, o)
+        print("er small", mode, "%.0fs" % (time.time() - t0), flush=True)
+    er128 = [synth.er_graph(128, 260, 5), synth.er_graph(70, 200, 6)]
+    for mode in ("vertex", "edge"):
+        o = run_counts(ref, er128, pats5, mode, True)
+        save_case(rec, "er128_allsimple5_induced_%s" % mode, er128, pats5, mode, True, o)
+        print("er128", mode, "%.0fs" % (time.time() - t0), flush=True)
+    # directed_orbits=True variant (utils_graph_processing.py:78-79)
+    o = run_counts(ref, er[:3], pats345, "edge", False, directed_orbits=True)
+    save_case(rec, "er_small_allsimple3-5_mono_edge_dirorb", er[:3], pats345, "edge", False, o, directed_orbits=True)
+
+    # --- other families: paths, stars, trees (non-induced and induced) on small graphs
+    fam = [list(nx.path_graph(k).edges) for k in (3, 4, 5, 6)] + [list(nx.star_graph(k).edges) for k in (2, 3, 4)] \
+        + [list(nx.diamond_graph().edges)] + [list(nx.binomial_tree(3).edges)]
+    small = [synth.er_graph(12, 20, 7), synth.er_graph(14, 30, 8)] + zg[:4]
+    for mode in ("vertex", "edge"):
+        for induced in (False, True):
+            o = run_counts(ref, small, fam, mode, induced)
+            save_case(rec, "mixed_families_%s_%s" % ("induced" if induced else "mono", mode), small, fam, mode, induced, o)
+    print("families", "%.0fs" % (time.time() - t0), flush=True)
+
+    # --- edge cases (fidelity checklist): trailing isolated vertices, duplicate columns,
+    #     self loops passed straight to the count fn, unsorted columns, an edgeless graph (vertex mode)
+    rng = np.random.default_rng(11)
+    n, ei = synth.er_graph(10, 18, 9)
+    perm = rng.permutation(ei.shape[1])
+    ei_shuf = ei[:, perm]
+    dup = np.concatenate([ei_shuf, ei_shuf[:, :7], ei_shuf[:, 3:5]], axis=1)           # duplicates: last wins
+    loops = np.concatenate([ei_shuf[:, :5], np.array([[2, 7], [2, 7]]), ei_shuf[:, 5:]], axis=1)  # self loops inside
+    graphs = [(n, ei_shuf), (n, dup), (n, loops), (n, ei)]
+    nn = [n, n, n, n + 3]
+    pats = cyc([3, 4]) + [list(nx.path_graph(3).edges)]
+    for mode in ("vertex", "edge"):
+        o = run_counts(ref, graphs, pats, mode, False, num_nodes=nn)
+        save_case(rec, "edge_cases_%s" % mode, graphs, pats, mode, False, o, num_nodes=nn)
+    empty = [(5, np.zeros((2, 0), dtype=np.int64))]
+    o = run_counts(ref, empty, pats, "vertex", False)
+    save_case(rec, "empty_graph_vertex", empty, pats, "vertex", False, o)
+
+    rec["names"] = np.asarray(rec["names"])
+    np.savez_compressed(os.path.join(out, "counts.npz"), **rec)
+    print("counts: %d cases, %.0fs" % (len(rec["names"]), time.time() - t0))
+
+    # --- subgraph_counts2ids end to end (utils_ids.py:7-29) incl. self-loop stripping with edge_features
+    uid = ref["utils_ids"]
+    ugp = ref["utils_graph_processing"]
+    rec2 = {}
+    import io
+    import contextlib
+    for mode in ("vertex", "edge"):
+        with contextlib.redirect_stdout(io.StringIO()):
+            dicts = []
+            for el in cyc([3, 4, 5]):
+                fn = ugp.automorphism_orbits if mode == "vertex" else ugp.induced_edge_automorphism_orbits
+                sg, part, memb, aut = fn(edge_list=el, directed=False, directed_orbits=False)
+                dicts.append({"subgraph": sg, "orbit_partition": part, "orbit_membership": memb, "aut_count": aut})
+        data = types.SimpleNamespace()
+        data.x = torch.ones(n + 2, 1)
+        data.edge_index = torch.from_numpy(loops.copy())
+        data.edge_features = torch.arange(loops.shape[1]) + 100
+        cfn = ugp.subgraph_isomorphism_vertex_counts if mode == "vertex" else ugp.subgraph_isomorphism_edge_counts
+        res = uid.subgraph_counts2ids(cfn, data, dicts, {"induced": False, "directed": False})
+        rec2[mode + "/in_edge_index"] = loops
+        rec2[mode + "/in_num_nodes"] = np.int64(n + 2)
+        rec2[mode + "/out_edge_index"] = res.edge_index.numpy()
+        rec2[mode + "/out_edge_features"] = res.edge_features.numpy()
+        rec2[mode + "/identifiers"] = res.identifiers.numpy()
+        assert res.identifiers.dtype == torch.int64
+    pptr, pflat = pack_edge_lists(cyc([3, 4, 5]))
+    rec2["pattern_ptr"], rec2["pattern_edges"] = pptr, pflat
+    np.savez_compressed(os.path.join(out, "counts2ids.npz"), **rec2)
+
+
+# ----------------------------------------------------------------------------------------------
+# HP-2 layer vectors
+# ----------------------------------------------------------------------------------------------
+def gen_layers(ref, out):
+    warnings.filterwarnings("ignore")
+    rec = {}
+    names = []
+    zb = synth.zinc_shape_batch(3, seed=3)
+    N, E = zb.num_nodes, zb.num_edges
+    ei = torch.from_numpy(zb.edge_index)
+    # a second, irregular graph: random multigraph-free digraph with isolated nodes and a hub
+    rng = np.random.default_rng(5)
+    N2 = 40
+    e2 = set()
+    while len(e2) < 110:
+        a, b = rng.integers(0, N2 - 4, 2)
+        if a != b:
+            e2.add((int(a), int(b)))
+    for t in range(1, 20):
+        e2.add((t, 0))
+    ei2 = torch.tensor(sorted(e2), dtype=torch.long).T.contiguous()
+    ei2 = ei2[:, torch.from_numpy(rng.permutation(ei2.shape[1]))]
+
+    def run(name, cls_name, ctor, graph, d_x, d_id, d_ef, id_scope, train, seed, x_1d=False):
+        torch.manual_seed(seed)
+        cls = getattr(ref[cls_name], cls_name)
+        layer = cls(**ctor)
+        # make BN statistics / affine non-trivial
+        for m in layer.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.uniform_(-0.5, 0.5)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.data.uniform_(0.5, 1.5)
+                m.bias.data.uniform_(-0.5, 0.5)
+        layer.train(train)
+        eidx, n_nodes = graph
+        n_edges = eidx.shape[1]
+        x = torch.randn(n_nodes, d_x) if not x_1d else torch.randn(n_nodes)
+        x.requires_grad_(True)
+        kw = {"degrees": torch.randn(n_nodes, ctor.get("d_degree", 1))}
+        ids = None
+        if d_id is not None:
+            ids = torch.randn(n_edges if id_scope == "local" else n_nodes, d_id, requires_grad=True)
+            kw["identifiers"] = ids
+        elif cls_name == "MPNN_edge_sparse_ogb":
+            kw["identifiers"] = None  # the key is read (MPNN_edge_sparse_ogb.py:66) but never used
+        ef = None
+        if d_ef is not None:
+            ef = torch.randn(n_edges, d_ef, requires_grad=True)
+            kw["edge_features"] = ef
+        sd0 = {k: v.detach().clone() for k, v in layer.state_dict().items()}
+        y = layer(x, eidx, **kw)
+        w = torch.randn_like(y)
+        (y * w).sum().backward()
+        rec[name + "/edge_index"] = eidx.numpy()
+        rec[name + "/x"] = x.detach().numpy()
+        rec[name + "/degrees"] = kw["degrees"].numpy()
+        if ids is not None:
+            rec[name + "/identifiers"] = ids.detach().numpy()
+            rec[name + "/g_identifiers"] = ids.grad.numpy()
+        if ef is not None:
+            rec[name + "/edge_features"] = ef.detach().numpy()
+            rec[name + "/g_edge_features"] = ef.grad.numpy()
+        rec[name + "/y"] = y.detach().numpy()
+        rec[name + "/w"] = w.numpy()
+        rec[name + "/g_x"] = x.grad.numpy()
+        for k, v in sd0.items():
+            rec[name + "/sd/" + k] = v.numpy()
+        for k, p in layer.named_parameters():
+            if p.grad is not None:
+                rec[name + "/gp/" + k] = p.grad.numpy()
+        sd1 = layer.state_dict()
+        for k, v in sd1.items():  # BN running stats after a train-mode forward
+            if "running" in k or "num_batches" in k:
+                rec[name + "/sd_after/" + k] = v.numpy()
+        rec[name + "/ctor"] = np.asarray(repr(sorted((k, v) for k, v in ctor.items())))
+        rec[name + "/cls"] = np.asarray(cls_name)
+        rec[name + "/train"] = np.bool_(train)
+        names.append(name)
+
+    graphs = {"zinc": (ei, N), "hub": (ei2, N2)}
+    seed = 0
+    base = dict(d_degree=1, degree_as_tag=False, retain_features=True, seed=0, aggr="add", eps=0,
+                extend_dims=True)
+    for gname, graph in graphs.items():
+        for msg_kind in ("general", "gin"):
+            for id_scope in ("local", "global"):
+                for flow in ("source_to_target", "target_to_source"):
+                    for bn in (True, False):
+                        for train in (False, True):
+                            if not bn and train and flow == "target_to_source":
+                                continue  # trim
+                            act = "relu" if bn else "elu"
+                            emb = "one_hot_encoder" if (seed % 2 == 0) else "embedding"
+                            # GSN_edge_sparse
+                            ctor = dict(base, d_in=7, d_ef=3, d_id=5, id_scope=id_scope, d_msg=12, d_up=10, d_h=[16],
+                                        activation_name=act, bn=bn, msg_kind=msg_kind, train_eps=(seed % 3 == 0),
+                                        flow=flow, edge_embedding=emb, id_embedding=emb)
+                            seed += 1
+                            run("GSN_edge_sparse/%s/%s/%s/%s/bn%d/train%d" % (gname, msg_kind, id_scope, flow, bn, train),
+                                "GSN_edge_sparse", ctor, graph, 7, 5, 3, id_scope, train, seed)
+                            # GSN_sparse
+                            ctor = dict(base, d_in=6, d_id=4, id_scope=id_scope, d_msg=None if seed % 5 == 0 else 9,
+                                        d_up=11, d_h=[8], activation_name=act, bn=bn, msg_kind=msg_kind,
+                                        train_eps=(seed % 3 == 0), flow=flow, id_embedding=emb)
+                            seed += 1
+                            run("GSN_sparse/%s/%s/%s/%s/bn%d/train%d" % (gname, msg_kind, id_scope, flow, bn, train),
+                                "GSN_sparse", ctor, graph, 6, 4, None, id_scope, train, seed)
+        for msg_kind in ("general", "gin"):
+            for flow in ("source_to_target", "target_to_source"):
+                for train in (False, True):
+                    ctor = dict(base, d_in=7, d_ef=3, d_msg=12, d_up=10, d_h=[16], activation_name="relu", bn=True,
+                                msg_kind=msg_kind, train_eps=False, flow=flow, edge_embedding="one_hot_encoder")
+                    seed += 1
+                    run("MPNN_edge_sparse/%s/%s/%s/train%d" % (gname, msg_kind, flow, train),
+                        "MPNN_edge_sparse", ctor, graph, 7, None, 3, "local", train, seed)
+                    ctor = dict(base, d_in=6, d_msg=9, d_up=11, d_h=[8], activation_name="tanh", bn=True,
+                                msg_kind=msg_kind, train_eps=True, flow=flow)
+                    seed += 1
+                    run("MPNN_sparse/%s/%s/%s/train%d" % (gname, msg_kind, flow, train),
+                        "MPNN_sparse", ctor, graph, 6, None, None, "local", train, seed)
+        for id_scope in ("local", "global"):
+            for train in (False, True):
+                ctor = dict(base, d_in=8, d_ef=8, d_id=8, id_scope=id_scope, d_msg=None, d_up=8, d_h=[16],
+                            activation_name="relu", bn=True, msg_kind="ogb", train_eps=True)
+                seed += 1
+                run("GSN_edge_sparse_ogb/%s/%s/train%d" % (gname, id_scope, train),
+                    "GSN_edge_sparse_ogb", ctor, graph, 8, 8, 8, id_scope, train, seed)
+        ctor = dict(base, d_in=8, d_ef=8, d_msg=None, d_up=8, d_h=[16], activation_name="relu", bn=True,
+                    msg_kind="ogb", train_eps=False)
+        seed += 1
+        run("MPNN_edge_sparse_ogb/%s/train0" % gname, "MPNN_edge_sparse_ogb", ctor, graph, 8, None, 8, "local", False, seed)
+    # degree_as_tag + 1-D inputs (GSN_sparse.py:96-100)
+    ctor = dict(base, d_in=1, d_id=4, id_scope="local", d_msg=9, d_up=11, d_h=[8], activation_name="relu", bn=True,
+                msg_kind="general", train_eps=False, flow="source_to_target", id_embedding="one_hot_encoder",
+                degree_as_tag=True, retain_features=True, d_degree=1)
+    run("GSN_sparse/zinc/degree_as_tag_1d", "GSN_sparse", ctor, graphs["zinc"], 1, 4, None, "local", False, 999, x_1d=True)
+    # one ZINC-shaped batch at the real layer-0 widths of config 2 (d_in 28, d_id 12, d_ef 4, d 128), eval + train
+    zb2 = synth.zinc_shape_batch(8, seed=4)
+    g2 = (torch.from_numpy(zb2.edge_index), zb2.num_nodes)
+    for train in (False, True):
+        ctor = dict(base, d_in=28, d_ef=4, d_id=12, id_scope="local", d_msg=128, d_up=128, d_h=[128],
+                    activation_name="relu", bn=True, msg_kind="general", train_eps=False, flow="source_to_target",
+                    edge_embedding="one_hot_encoder", id_embedding="one_hot_encoder")
+        run("GSN_edge_sparse/zinc8_real_widths/train%d" % train, "GSN_edge_sparse", ctor, g2, 28, 12, 4, "local", train, 1234)
+    rec["names"] = np.asarray(names)
+    np.savez_compressed(os.path.join(out, "layers.npz"), **rec)
+    print("layers: %d cases" % len(names))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="orbits,counts,layers")
+    ap.add_argument("--out", default=HERE)
+    args = ap.parse_args()
+    ref = import_reference()
+    only = set(args.only.split(","))
+    if "orbits" in only:
+        gen_orbits(ref, args.out)
+    if "counts" in only:
+        gen_counts(ref, args.out)
+    if "layers" in only:
+        gen_layers(ref, args.out)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,68 @@
+// TEST-ONLY logic harness (not product code, never shipped in libgsn_hip.so).
+// Compiles the kernel's per-lane search core (gsn_amd/csrc/count_core.h) and the plan compiler
+// (gsn_amd/csrc/patterns.cpp) for the HOST and runs every (column,row) task sequentially, so that plan
+// compilation + symmetry breaking + the search itself can be checked against the oracle on a machine
+// without a GPU.  The HIP kernel's own setup phases are covered by the -m gpu tests.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../gsn_amd/csrc/count_core.h"
+
+namespace gsn {
+int set_error(int code, const char *fmt, ...) {
+    va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr);
+    return code;
+}
+}
+using namespace gsn;
+
+template <int W>
+static int run(const uint32_t *plan, int64_t n, int64_t E, const int64_t *src, const int64_t *dst, int64_t *out) {
+    const int mode = (int)plan[1], n_cols = (int)plan[4], kmax = (int)plan[5], plans_off = (int)plan[7];
+    const uint32_t *col_ptr = plan + PLAN_HEADER_WORDS, *plans = plan + plans_off;
+    std::vector<uint64_t> A((size_t)(n ? n : 1) * W, 0), stack((size_t)kmax * W, 0);
+    int n_active = 0;
+    for (int64_t c = 0; c < E; ++c) {
+        int u = (int)src[c], v = (int)dst[c];
+        n_active = std::max(n_active, std::max(u, v) + 1);
+        if (u == v) continue;
+        A[(size_t)u * W + (v >> 6)] |= 1ull << (v & 63);
+        A[(size_t)v * W + (u >> 6)] |= 1ull << (u & 63);
+    }
+    uint64_t valid[W];
+    for (int w = 0; w < W; ++w) valid[w] = below_word(n_active, w);
+    std::vector<int64_t> last((size_t)(n * n ? n * n : 1), -1);
+    for (int64_t c = 0; c < E; ++c) last[(size_t)src[c] * n + dst[c]] = c;
+    const int64_t rows = mode == GSN_MODE_EDGE ? E : n;
+    int status = 0;
+    for (int col = 0; col < n_cols; ++col)
+        for (int64_t row = 0; row < rows; ++row) {
+            Lane s; s.l = -1; s.cnt = 0; s.k = 0; s.nfix = 0; s.fvec = 0; s.plan = plans;
+            uint64_t roots; bool live = true, rev_missing = false;
+            if (mode == GSN_MODE_EDGE) {
+                int u = (int)src[row], v = (int)dst[row];
+                live = u != v && last[(size_t)u * n + v] == row;
+                rev_missing = u != v && last[(size_t)v * n + u] < 0;
+                roots = (uint64_t)u | ((uint64_t)v << 8);
+            } else {
+                live = row < n_active; roots = (uint64_t)row;
+            }
+            if (live)
+                for (uint32_t p = col_ptr[col]; p < col_ptr[col + 1]; ++p) {
+                    lane_begin<W>(s, plans + p * PLAN_STRIDE_WORDS, roots, A.data(), valid, stack.data(), 1, 0);
+                    while (s.l >= 0) lane_step<W>(s, A.data(), valid, stack.data(), 1, 0);
+                }
+            out[row * n_cols + col] = (int64_t)s.cnt;
+            if (rev_missing && s.cnt) status = 1;
+        }
+    return status;
+}
+
+extern "C" int harness_count(const uint32_t *plan, int64_t n, int64_t E, const int64_t *src, const int64_t *dst, int64_t *out) {
+    if (n <= 64) return run<1>(plan, n, E, src, dst, out);
+    if (n <= 128) return run<2>(plan, n, E, src, dst, out);
+    if (n <= 256) return run<4>(plan, n, E, src, dst, out);
+    return -1;
+}
