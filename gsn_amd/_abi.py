@@ -1,0 +1,106 @@
+"""ctypes binding of libgsn_hip.so (the C ABI declared in include/gsn_abi.h).
+
+There is no CPU fallback: if the shared library is missing, or a device entry point is called without a
+visible gfx950 GPU, this module raises.  ``build()`` compiles the library in-tree with hipcc
+(``gsn_amd/csrc/Makefile`` -> ``gsn_amd/lib/libgsn_hip.so``); hipcc cross-compiles gfx950 without a GPU.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgsn_hip.so")
+_lib = None
+
+c_i64 = ctypes.c_int64
+c_i32 = ctypes.c_int32
+c_int = ctypes.c_int
+c_vp = ctypes.c_void_p
+
+
+class GsnError(RuntimeError):
+    """A libgsn_hip.so entry point returned a negative status."""
+
+
+class gsn_block(ctypes.Structure):
+    _fields_ = [("data", c_vp), ("idx", c_vp), ("width", c_i64)]
+
+
+# name -> (restype, argtypes); kept in one place so tests can check it against include/gsn_abi.h
+SIGNATURES = {
+    "gsn_last_error": (ctypes.c_char_p, []),
+    "gsn_version": (c_int, []),
+    "gsn_device_count": (c_int, []),
+    "gsn_pattern_orbits": (c_int, [c_i64, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "gsn_count_plan_build": (c_int, [c_int, c_int, c_int, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
+    "gsn_count_hip": (c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_i64, c_i64,
+                              c_vp, c_vp, c_vp]),
+    "gsn_csr_scratch_elems": (c_i64, [c_i64]),
+    "gsn_csr_build_hip": (c_int, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "gsn_propagate_fwd_hip": (c_int, [c_int, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_vp,
+                                      c_i64, c_vp, c_vp]),
+    "gsn_propagate_bwd_hip": (c_int, [c_int, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_int,
+                                      c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "gsn_linear_fwd_hip": (c_int, [c_i64, c_int, ctypes.POINTER(gsn_block), c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_int,
+                                   c_vp, c_vp, c_vp, c_vp]),
+}
+
+
+def build(verbose: bool = False) -> str:
+    """Compile libgsn_hip.so for gfx950 (idempotent: make only rebuilds what changed)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j8"]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("building libgsn_hip.so failed:\n" + res.stdout)
+    if verbose:
+        print(res.stdout)
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library; raises if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "gsn_amd: %s not found. Build the HIP extension first (python -c 'import __graft_entry__ as g; "
+                "g.build()' or make -C gsn_amd/csrc). There is no CPU fallback." % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the build is stale: loud by design
+            fn.restype = res
+            fn.argtypes = args
+        if handle.gsn_version() != 1:
+            raise ImportError("gsn_amd: libgsn_hip.so ABI version %d != 1" % handle.gsn_version())
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().gsn_last_error()
+        raise GsnError("%s failed (%d): %s" % (what or "libgsn_hip", rc, msg.decode() if msg else ""))
+
+
+def require_gpu() -> None:
+    """Device entry points need a real gfx950; refuse loudly otherwise."""
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("gsn_amd: no GPU visible to PyTorch-ROCm; the counting / message-passing kernels are "
+                           "HIP-only (gfx950) and there is no CPU fallback.")
+
+
+def ptr(t) -> int:
+    """data pointer of a torch tensor / numpy array / None"""
+    if t is None:
+        return None
+    if hasattr(t, "data_ptr"):
+        return t.data_ptr()
+    return t.ctypes.data
+
+
+def current_stream() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,214 @@
+"""Substructure / orbit counting on the GPU: host-side mirror of the reference's counting interface.
+
+* :func:`subgraph_isomorphism_vertex_counts` / :func:`subgraph_isomorphism_edge_counts` -- same signatures and return
+  type (CPU float64 tensor) as utils_graph_processing.py:103-131 / :134-179; a G=1 call into the batched kernel.
+* :func:`subgraph_counts2ids` -- same signature and side effects as utils_ids.py:7-29 (strips self loops, concatenates
+  the per-pattern counts, writes ``data.edge_index`` and ``data.identifiers`` int64); all patterns go down in ONE
+  kernel launch instead of one graph-tool call per pattern.
+* :func:`count_batch` / :func:`counts2ids_batch` -- the batched driver: a whole dataset shard per launch.
+
+Everything routes through ``gsn_count_hip`` in libgsn_hip.so.  No CPU fallback: without a GPU these raise.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _abi
+from .patterns import PatternGraph
+
+__all__ = ["CountPlan", "count_batch", "counts2ids_batch", "subgraph_isomorphism_vertex_counts",
+           "subgraph_isomorphism_edge_counts", "subgraph_counts2ids"]
+
+_MODE = {"vertex": 0, "edge": 1}
+_STATUS_MSG = {2: "graph larger than the max_nodes / max_edges given to the call", 3: "vertex id outside [0, num_nodes)"}
+_PLAN_CACHE = {}
+
+
+class CountPlan:
+    """Compiled search plans for a list of patterns (built on the host by gsn_count_plan_build, cached per device)."""
+
+    def __init__(self, pattern_edge_lists, mode, induced, directed_orbits=False):
+        self.mode = mode
+        self.induced = bool(induced)
+        self.directed_orbits = bool(directed_orbits)
+        pats = [np.asarray(list(el), dtype=np.int64).reshape(-1, 2) for el in pattern_edge_lists]
+        if not pats:
+            raise ValueError("no patterns given")
+        pat_ptr = np.cumsum([0] + [len(p) for p in pats]).astype(np.int64)
+        pat_edges = np.ascontiguousarray(np.concatenate(pats, axis=0))
+        L = _abi.lib()
+        words, ncols = ctypes.c_int64(), ctypes.c_int64()
+        args = (_MODE[mode], int(self.induced), int(self.directed_orbits), len(pats), _abi.ptr(pat_ptr), _abi.ptr(pat_edges))
+        _abi.check(L.gsn_count_plan_build(*args, None, 0, ctypes.addressof(words), ctypes.addressof(ncols)),
+                   "gsn_count_plan_build")
+        self.table = np.zeros(words.value, dtype=np.uint32)
+        _abi.check(L.gsn_count_plan_build(*args, _abi.ptr(self.table), len(self.table), ctypes.addressof(words),
+                                          ctypes.addressof(ncols)), "gsn_count_plan_build")
+        self.n_cols = int(ncols.value)
+        self.n_plans = int(self.table[3])
+        self.kmax = int(self.table[5])
+        self._dev = {}
+
+    @staticmethod
+    def get(pattern_edge_lists, mode, induced, directed_orbits=False):
+        key = (tuple(tuple((int(u), int(v)) for u, v in el) for el in pattern_edge_lists), mode, bool(induced),
+               bool(directed_orbits))
+        if key not in _PLAN_CACHE:
+            _PLAN_CACHE[key] = CountPlan(pattern_edge_lists, mode, induced, directed_orbits)
+        return _PLAN_CACHE[key]
+
+    def device_table(self, device):
+        device = torch.device(device)
+        if device not in self._dev:
+            self._dev[device] = torch.from_numpy(self.table.view(np.int32)).to(device)
+        return self._dev[device]
+
+
+def _as_dev_i64(x, device):
+    if isinstance(x, torch.Tensor):
+        return x.to(device=device, dtype=torch.int64).contiguous()
+    return torch.as_tensor(np.ascontiguousarray(x, dtype=np.int64), device=device)
+
+
+def count_batch(plan: CountPlan, node_ptr, edge_ptr, edge_index, ids_are_global=True, max_nodes=None, max_edges=None,
+                device=None, graph_ids=None, out=None, check=True):
+    """Run the counting kernel over a batch.
+
+    node_ptr / edge_ptr: int64 [G+1] (host or device); edge_index: int64 [2, E_total].  Returns
+    ``(out, status)``: ``out`` int64 device tensor [rows_total, plan.n_cols] (rows = vertices in vertex mode, columns
+    of edge_index in edge mode), ``status`` int32 [G].  With ``check`` the statuses are read back and the reference's
+    errors are raised (KeyError when a match uses a direction that is not a column, utils_graph_processing.py:173).
+    """
+    _abi.require_gpu()
+    if device is None:
+        device = edge_index.device if isinstance(edge_index, torch.Tensor) and edge_index.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    device = torch.device(device)
+    if max_nodes is None or max_edges is None:
+        npt = node_ptr.cpu().numpy() if isinstance(node_ptr, torch.Tensor) else np.asarray(node_ptr)
+        ept = edge_ptr.cpu().numpy() if isinstance(edge_ptr, torch.Tensor) else np.asarray(edge_ptr)
+        max_nodes = int(np.diff(npt).max()) if len(npt) > 1 else 1
+        max_edges = int(np.diff(ept).max()) if len(ept) > 1 else 0
+    node_ptr_d = _as_dev_i64(node_ptr, device)
+    edge_ptr_d = _as_dev_i64(edge_ptr, device)
+    ei = _as_dev_i64(edge_index, device)
+    if ei.dim() != 2 or ei.shape[0] != 2:
+        raise ValueError("edge_index must be [2, E]")
+    n_graphs = node_ptr_d.numel() - 1
+    E_total = ei.shape[1]
+    # rows follow the pointers the kernel uses, not the tensor length
+    rows_total = int((edge_ptr_d if plan.mode == "edge" else node_ptr_d)[-1].item()) if n_graphs > 0 else 0
+    if out is None:
+        out = torch.empty((rows_total, plan.n_cols), dtype=torch.int64, device=device)
+    status = torch.zeros(max(n_graphs, 1), dtype=torch.int32, device=device)
+    gid = None
+    n_items = n_graphs
+    if graph_ids is not None:
+        gid = torch.as_tensor(graph_ids, dtype=torch.int32, device=device).contiguous()
+        n_items = gid.numel()
+    if n_graphs > 0 and n_items > 0:
+        tab = plan.device_table(device)
+        with torch.cuda.device(device):
+            rc = _abi.lib().gsn_count_hip(_abi.ptr(plan.table), tab.data_ptr(), len(plan.table), n_graphs,
+                                          node_ptr_d.data_ptr(), edge_ptr_d.data_ptr(), ei.data_ptr() if E_total else None,
+                                          ei.stride(0), int(bool(ids_are_global)), None if gid is None else gid.data_ptr(),
+                                          n_items, int(max_nodes), int(max_edges), out.data_ptr(), status.data_ptr(),
+                                          _abi.current_stream())
+        _abi.check(rc, "gsn_count_hip")
+    if check:
+        st = status.cpu().numpy()
+        if (st == 1).any():
+            raise KeyError("graph %d: a match maps a pattern edge onto a direction that is not a column of edge_index "
+                           "(reference: utils_graph_processing.py:173)" % int(np.nonzero(st == 1)[0][0]))
+        bad = np.nonzero(st > 1)[0]
+        if len(bad):
+            raise ValueError("graph %d: %s" % (int(bad[0]), _STATUS_MSG.get(int(st[bad[0]]), "status %d" % st[bad[0]])))
+    return out, status
+
+
+def counts2ids_batch(batch, pattern_edge_lists, mode, induced, directed_orbits=False, device=None):
+    """Batched ``subgraph_counts2ids`` over a :class:`gsn_amd.synth.Batch`-like object (node_ptr, edge_ptr, edge_index
+    with batch-global ids, self loops already stripped).  -> int64 device tensor [rows_total, sum orbits]."""
+    plan = CountPlan.get(pattern_edge_lists, mode, induced, directed_orbits)
+    out, _ = count_batch(plan, batch.node_ptr, batch.edge_ptr, batch.edge_index, ids_are_global=True, device=device)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the reference's per-graph signatures
+# ------------------------------------------------------------------------------------------------------------------
+def _pattern_of(subgraph_dict):
+    sg = subgraph_dict["subgraph"]
+    if not isinstance(sg, PatternGraph):
+        raise TypeError("subgraph_dict['subgraph'] must come from gsn_amd's automorphism_orbits / "
+                        "induced_edge_automorphism_orbits (got %r)" % type(sg))
+    return sg
+
+
+def _single_graph(edge_index, num_nodes):
+    ei = edge_index if isinstance(edge_index, torch.Tensor) else torch.as_tensor(np.asarray(edge_index))
+    ei = ei.to(torch.int64)
+    E = ei.shape[1]
+    n = int(num_nodes)
+    if E:
+        n = max(n, int(ei.max().item()) + 1)
+    return ei, n, E
+
+
+def subgraph_isomorphism_vertex_counts(edge_index, **kwargs):
+    """GSN-v identifiers of one graph and one pattern (utils_graph_processing.py:103-131): CPU float64 tensor
+    [num_nodes, n_orbits], counts[v, o] = number of occurrences containing v at a position of orbit o."""
+    subgraph_dict, induced, num_nodes = kwargs["subgraph_dict"], kwargs["induced"], kwargs["num_nodes"]
+    if kwargs.get("directed", False):
+        raise NotImplementedError("directed=True is not supported")
+    sg = _pattern_of(subgraph_dict)
+    plan = CountPlan.get([sg.edge_list], "vertex", induced, False)
+    ei, n, E = _single_graph(edge_index, num_nodes)
+    out, _ = count_batch(plan, [0, n], [0, E], ei, ids_are_global=False, max_nodes=n, max_edges=E)
+    return out[:int(num_nodes)].cpu().to(torch.float64)
+
+
+def subgraph_isomorphism_edge_counts(edge_index, **kwargs):
+    """GSN-e identifiers of one graph and one pattern (utils_graph_processing.py:134-179): CPU float64 tensor
+    [E, n_edge_orbits] with rows in edge_index column order."""
+    subgraph_dict, induced = kwargs["subgraph_dict"], kwargs["induced"]
+    if kwargs.get("directed", False):
+        raise NotImplementedError("directed=True is not supported (NameError in the reference, utils_graph_processing.py:164)")
+    sg = _pattern_of(subgraph_dict)
+    plan = CountPlan.get([sg.edge_list], "edge", induced, sg.directed_orbits)
+    ei, n, E = _single_graph(edge_index, 0)
+    out, _ = count_batch(plan, [0, max(n, 1)], [0, E], ei, ids_are_global=False, max_nodes=max(n, 1), max_edges=E)
+    return out.cpu().to(torch.float64)
+
+
+def subgraph_counts2ids(count_fn, data, subgraph_dicts, subgraph_params):
+    """Remove self loops, count every pattern, attach ``identifiers`` (int64) -- utils_ids.py:7-29.
+
+    ``count_fn`` selects the mode exactly like the reference's callers do (by function identity / ``__name__``,
+    utils_data_gen.py:103); all patterns are counted in one launch."""
+    ei = data.edge_index
+    mask = ei[0] != ei[1]
+    if hasattr(data, "edge_features"):
+        setattr(data, "edge_features", data.edge_features[mask])
+    edge_index = ei[:, mask]
+    num_nodes = data.x.shape[0]
+    if subgraph_params.get("directed", False):
+        raise NotImplementedError("directed=True is not supported")
+    name = getattr(count_fn, "__name__", "")
+    if name == "subgraph_isomorphism_edge_counts":
+        mode = "edge"
+    elif name == "subgraph_isomorphism_vertex_counts":
+        mode = "vertex"
+    else:
+        raise TypeError("count_fn must be subgraph_isomorphism_vertex_counts or subgraph_isomorphism_edge_counts")
+    pats = [_pattern_of(d) for d in subgraph_dicts]
+    dirorb = any(p.directed_orbits for p in pats) if mode == "edge" else False
+    plan = CountPlan.get([p.edge_list for p in pats], mode, subgraph_params["induced"], dirorb)
+    e_cpu, n, E = _single_graph(edge_index, num_nodes)
+    out, _ = count_batch(plan, [0, n], [0, E], e_cpu, ids_are_global=False, max_nodes=n, max_edges=E)
+    ids = out[:num_nodes] if mode == "vertex" else out
+    setattr(data, "edge_index", edge_index)
+    setattr(data, "identifiers", ids.cpu().long())
+    return data

@@ -1,0 +1,412 @@
+// HP-2 propagate stage for gfx950: target-sorted CSR build + fused gather -> message -> segmented sum (fwd and adjoint).
+//
+// Replaces  torch.sparse.FloatTensor(edge_index, msgs, [N,N,d]) + torch.sparse.sum(.., aggr_dim).to_dense()
+// (GSN_sparse.py:140-143, GSN_edge_sparse.py:136-139 and the MPNN / ogb twins) and the index_select gathers in front of
+// it (GSN_*.py:125-136).  HBM-bound, zero dense flops: every input row is read once through L2, the output row is
+// written once, no [E,d] message tensor and no COO sort.  Rows are summed in edge order inside a segment, so the fp32
+// result is deterministic (no float atomics).
+//
+// Work mapping: one "row group" of LPR lanes per target vertex (LPR = lanes per row, a power of two chosen so that
+// LPR * VEC >= d_out where possible), 64/LPR vertices per wave, 4 waves per workgroup; lanes stride over the feature
+// dimension with float4 (VEC=4) accesses when every block width is a multiple of 4, scalar otherwise.
+#include <hip/hip_runtime.h>
+
+#include "gsn_internal.h"
+
+namespace gsn {
+
+// ----------------------------------------------------------------------------------------------------------------
+// CSR build: stable counting sort of edge ids by aggregation target
+// ----------------------------------------------------------------------------------------------------------------
+__global__ void csr_zero(int32_t *cnt, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) cnt[i] = 0;
+}
+
+__global__ void csr_hist(const int64_t *__restrict__ index, int64_t n_edges, int32_t *cnt) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_edges; e += (int64_t)gridDim.x * blockDim.x)
+        atomicAdd(&cnt[index[e]], 1);
+}
+
+constexpr int SCAN_T = 256;
+constexpr int SCAN_ITEMS = 4;
+constexpr int SCAN_TILE = SCAN_T * SCAN_ITEMS;
+
+// per-tile sums
+__global__ __launch_bounds__(SCAN_T) void scan_tile_sums(const int32_t *__restrict__ in, int64_t n, int32_t *tile_sums) {
+    __shared__ int32_t red[SCAN_T / 64];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE;
+    int32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        const int64_t j = base + threadIdx.x * SCAN_ITEMS + i;
+        if (j < n) s += in[j];
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int32_t t = 0;
+        for (int i = 0; i < SCAN_T / 64; ++i) t += red[i];
+        tile_sums[blockIdx.x] = t;
+    }
+}
+
+// exclusive scan of the tile sums by one workgroup (n_tiles is small: n / 1024)
+__global__ __launch_bounds__(1024) void scan_tile_offsets(int32_t *tile_sums, int64_t n_tiles) {
+    __shared__ int32_t buf[1024];
+    __shared__ int32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < n_tiles; base += 1024) {
+        const int64_t j = base + threadIdx.x;
+        const int32_t v = j < n_tiles ? tile_sums[j] : 0;
+        buf[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const int32_t t = threadIdx.x >= o ? buf[threadIdx.x - o] : 0;
+            __syncthreads();
+            buf[threadIdx.x] += t;
+            __syncthreads();
+        }
+        const int32_t incl = buf[threadIdx.x];
+        const int32_t c = carry;
+        __syncthreads();
+        if (j < n_tiles) tile_sums[j] = c + incl - v;
+        if (threadIdx.x == 1023) carry = c + incl;
+        __syncthreads();
+    }
+}
+
+// out[j] = tile_offset + exclusive scan inside the tile;  also copies the result into `cursor`
+__global__ __launch_bounds__(SCAN_T) void scan_apply(const int32_t *__restrict__ in, int64_t n, const int32_t *__restrict__ tile_off,
+                                                    int32_t *out, int32_t *cursor) {
+    __shared__ int32_t wsum[SCAN_T / 64];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    int32_t v[SCAN_ITEMS];
+    int32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        v[i] = (base + i < n) ? in[base + i] : 0;
+        s += v[i];
+    }
+    // wave inclusive scan of s
+    int32_t incl = s;
+    const int lane = threadIdx.x & 63;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int32_t t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int32_t woff = 0;
+    for (int i = 0; i < (int)(threadIdx.x >> 6); ++i) woff += wsum[i];
+    int32_t run = tile_off[blockIdx.x] + woff + incl - s;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        if (base + i < n) {
+            out[base + i] = run;
+            cursor[base + i] = run;
+        }
+        run += v[i];
+    }
+}
+
+__global__ void csr_fill(const int64_t *__restrict__ index, int64_t n_edges, int32_t *cursor, int32_t *perm) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_edges; e += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t pos = atomicAdd(&cursor[index[e]], 1);
+        perm[pos] = (int32_t)e;
+    }
+}
+
+// restore original edge order inside every segment (atomics above place them in arbitrary order)
+__global__ void csr_sort_segments(const int32_t *__restrict__ seg_ptr, int64_t n_nodes, int32_t *perm) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_nodes) return;
+    const int32_t lo = seg_ptr[t], hi = seg_ptr[t + 1];
+    for (int32_t i = lo + 1; i < hi; ++i) {
+        const int32_t x = perm[i];
+        int32_t j = i - 1;
+        while (j >= lo && perm[j] > x) { perm[j + 1] = perm[j]; --j; }
+        perm[j + 1] = x;
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// forward: out[t] = sum over the segment of t of msg_e
+// ----------------------------------------------------------------------------------------------------------------
+struct PropArgs {
+    int kind;
+    int64_t n_nodes, n_edges;
+    const int64_t *src;
+    const int32_t *seg_ptr, *perm;
+    const float *a, *b, *c;
+    int da, db, dc, d_out;
+    int b_per_node;
+    float *out;
+};
+
+template <int VEC>
+struct VecT;
+template <>
+struct VecT<1> { using type = float; };
+template <>
+struct VecT<4> { using type = float4; };
+
+__device__ __forceinline__ float vadd(float x, float y) { return x + y; }
+__device__ __forceinline__ float4 vadd(float4 x, float4 y) { return make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w); }
+__device__ __forceinline__ float vrelu(float x) { return x > 0.f ? x : 0.f; }
+__device__ __forceinline__ float4 vrelu(float4 x) { return make_float4(vrelu(x.x), vrelu(x.y), vrelu(x.z), vrelu(x.w)); }
+__device__ __forceinline__ void vzero(float &x) { x = 0.f; }
+__device__ __forceinline__ void vzero(float4 &x) { x = make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// MAXC: column chunks of width LPR*VEC each lane accumulates (d_out <= MAXC*LPR*VEC)
+template <int VEC, int LPR, int MAXC>
+__global__ __launch_bounds__(256) void propagate_fwd_kernel(PropArgs p) {
+    using V = typename VecT<VEC>::type;
+    constexpr int RPW = 64 / LPR;  // rows (targets) per wave
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / LPR, li = lane % LPR;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t t0 = wave * RPW; t0 < p.n_nodes; t0 += n_waves * RPW) {
+        const int64_t t = t0 + sub;
+        if (t >= p.n_nodes) continue;
+        V acc[MAXC];
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) vzero(acc[i]);
+        const int32_t lo = p.seg_ptr[t], hi = p.seg_ptr[t + 1];
+        for (int32_t q = lo; q < hi; ++q) {
+            const int64_t e = p.perm ? (int64_t)p.perm[q] : (int64_t)q;
+            const int64_t s = p.src[e];
+#pragma unroll
+            for (int i = 0; i < MAXC; ++i) {
+                const int col = (i * LPR + li) * VEC;
+                if (col < p.d_out) {
+                    V m;
+                    if (p.kind == GSN_MSG_CAT) {
+                        if (col < p.da) m = *reinterpret_cast<const V *>(p.a + s * p.da + col);
+                        else if (col < p.da + p.db)
+                            m = *reinterpret_cast<const V *>(p.b + (p.b_per_node ? s : e) * p.db + (col - p.da));
+                        else m = *reinterpret_cast<const V *>(p.c + e * p.dc + (col - p.da - p.db));
+                    } else {
+                        vzero(m);
+                        if (p.a) m = vadd(m, *reinterpret_cast<const V *>(p.a + s * p.d_out + col));
+                        if (p.b) m = vadd(m, *reinterpret_cast<const V *>(p.b + (p.b_per_node ? s : e) * p.d_out + col));
+                        if (p.c) m = vadd(m, *reinterpret_cast<const V *>(p.c + e * p.d_out + col));
+                        m = vrelu(m);
+                    }
+                    acc[i] = vadd(acc[i], m);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int col = (i * LPR + li) * VEC;
+            if (col < p.d_out) *reinterpret_cast<V *>(p.out + t * p.d_out + col) = acc[i];
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// backward
+// ----------------------------------------------------------------------------------------------------------------
+struct PropBwdArgs {
+    int kind;
+    int64_t n_nodes, n_edges;
+    const int64_t *src, *tgt;
+    const int32_t *seg_ptr_src, *perm_src;
+    const float *a, *b, *c, *g_out;
+    int da, db, dc, d_out;
+    int b_per_node;
+    float *g_a, *g_b, *g_c;
+};
+
+// per-edge gradients: g_b[e] (if per-edge) and g_c[e]; one row group per edge, scalar columns
+__global__ __launch_bounds__(256) void propagate_bwd_edge_kernel(PropBwdArgs p) {
+    const int64_t total = p.n_edges * (int64_t)p.d_out;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = i / p.d_out;
+        const int col = (int)(i - e * p.d_out);
+        const int64_t t = p.tgt[e];
+        float g = p.g_out[t * p.d_out + col];
+        if (p.kind == GSN_MSG_CAT) {
+            if (col >= p.da && col < p.da + p.db) {
+                if (!p.b_per_node && p.g_b) p.g_b[e * p.db + (col - p.da)] = g;
+            } else if (col >= p.da + p.db) {
+                if (p.g_c) p.g_c[e * p.dc + (col - p.da - p.db)] = g;
+            }
+        } else {
+            const int64_t s = p.src[e];
+            float pre = 0.f;
+            if (p.a) pre += p.a[s * p.d_out + col];
+            if (p.b) pre += p.b[(p.b_per_node ? s : e) * p.d_out + col];
+            if (p.c) pre += p.c[e * p.d_out + col];
+            g = pre > 0.f ? g : 0.f;
+            if (!p.b_per_node && p.g_b) p.g_b[e * p.d_out + col] = g;
+            if (p.g_c) p.g_c[e * p.d_out + col] = g;
+        }
+    }
+}
+
+// per-node gradients through the source-sorted CSR: g_a[s] (and g_b[s] if per node) = sum over edges leaving s
+__global__ __launch_bounds__(256) void propagate_bwd_node_kernel(PropBwdArgs p) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int width = p.kind == GSN_MSG_CAT ? p.da + (p.b_per_node ? p.db : 0) : p.d_out;
+    for (int64_t s = wave; s < p.n_nodes; s += n_waves) {
+        const int32_t lo = p.seg_ptr_src[s], hi = p.seg_ptr_src[s + 1];
+        for (int col = lane; col < width; col += 64) {
+            float acc = 0.f;
+            for (int32_t q = lo; q < hi; ++q) {
+                const int64_t e = p.perm_src[q];
+                const int64_t t = p.tgt[e];
+                float g = p.g_out[t * p.d_out + col];
+                if (p.kind != GSN_MSG_CAT) {
+                    float pre = 0.f;
+                    if (p.a) pre += p.a[s * p.d_out + col];
+                    if (p.b) pre += p.b[(p.b_per_node ? s : e) * p.d_out + col];
+                    if (p.c) pre += p.c[e * p.d_out + col];
+                    g = pre > 0.f ? g : 0.f;
+                }
+                acc += g;
+            }
+            if (p.kind == GSN_MSG_CAT) {
+                if (col < p.da) { if (p.g_a) p.g_a[s * p.da + col] = acc; }
+                else if (p.g_b) p.g_b[s * p.db + (col - p.da)] = acc;
+            } else {
+                if (p.g_a) p.g_a[s * p.d_out + col] = acc;
+                if (p.b_per_node && p.g_b) p.g_b[s * p.d_out + col] = acc;
+            }
+        }
+    }
+}
+
+static int hip_check(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(GSN_E_HIP, "%s: %s", what, hipGetErrorString(e));
+    return GSN_OK;
+}
+
+template <int VEC, int LPR, int MAXC>
+static int launch_fwd(const PropArgs &p, hipStream_t st) {
+    constexpr int RPW = 64 / LPR;
+    const int64_t waves_needed = (p.n_nodes + RPW - 1) / RPW;
+    int64_t blocks = (waves_needed + 3) / 4;
+    const int64_t cap = 256 * 8 * 4;  // enough workgroups to fill 256 CUs several times; grid-stride beyond
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL((propagate_fwd_kernel<VEC, LPR, MAXC>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+    return hip_check("propagate_fwd_kernel");
+}
+
+}  // namespace gsn
+
+using namespace gsn;
+
+extern "C" int64_t gsn_csr_scratch_elems(int64_t n_nodes) { return (n_nodes + 1) + (n_nodes + 1) / SCAN_TILE + 2; }
+
+extern "C" int gsn_csr_build_hip(int64_t n_nodes, int64_t n_edges, const int64_t *index, int32_t *seg_ptr, int32_t *perm,
+                                 int32_t *scratch, void *stream) {
+    if (n_nodes < 0 || n_edges < 0 || !seg_ptr || !scratch || (n_edges > 0 && (!index || !perm)))
+        return set_error(GSN_E_INVALID, "gsn_csr_build_hip: bad argument");
+    if (n_edges >= (int64_t)1 << 31 || n_nodes >= ((int64_t)1 << 31) - 1)
+        return set_error(GSN_E_UNSUPPORTED, "gsn_csr_build_hip: more than 2^31 edges or vertices");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int64_t n1 = n_nodes + 1;
+    int32_t *cnt = scratch;                 // [n1] histogram, later the fill cursor
+    int32_t *tiles = scratch + n1;          // [n_tiles]
+    const int64_t n_tiles = (n1 + SCAN_TILE - 1) / SCAN_TILE;
+    hipLaunchKernelGGL(csr_zero, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, st, cnt, n1);
+    if (n_edges > 0) {
+        int64_t blocks = (n_edges + 255) / 256;
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(csr_hist, dim3((unsigned)blocks), dim3(256), 0, st, index, n_edges, cnt);
+    }
+    hipLaunchKernelGGL(scan_tile_sums, dim3((unsigned)n_tiles), dim3(SCAN_T), 0, st, cnt, n1, tiles);
+    hipLaunchKernelGGL(scan_tile_offsets, dim3(1), dim3(1024), 0, st, tiles, n_tiles);
+    hipLaunchKernelGGL(scan_apply, dim3((unsigned)n_tiles), dim3(SCAN_T), 0, st, cnt, n1, tiles, seg_ptr, cnt);
+    if (n_edges > 0) {
+        int64_t blocks = (n_edges + 255) / 256;
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(csr_fill, dim3((unsigned)blocks), dim3(256), 0, st, index, n_edges, cnt, perm);
+        hipLaunchKernelGGL(csr_sort_segments, dim3((unsigned)((n_nodes + 255) / 256)), dim3(256), 0, st, seg_ptr, n_nodes, perm);
+    }
+    return hip_check("gsn_csr_build_hip");
+}
+
+extern "C" int gsn_propagate_fwd_hip(int kind, int64_t n_nodes, int64_t n_edges, const int64_t *src, const int32_t *seg_ptr,
+                                     const int32_t *perm, const float *a, int64_t da, const float *b, int64_t db,
+                                     int b_per_node, const float *c, int64_t dc, float *out, void *stream) {
+    if (kind != GSN_MSG_CAT && kind != GSN_MSG_RELU_SUM) return set_error(GSN_E_INVALID, "gsn_propagate_fwd_hip: unknown kind %d", kind);
+    if (!seg_ptr || !out || (n_edges > 0 && !src)) return set_error(GSN_E_INVALID, "gsn_propagate_fwd_hip: null pointer");
+    if (!a) da = 0;
+    if (!b) db = 0;
+    if (!c) dc = 0;
+    int64_t d_out;
+    if (kind == GSN_MSG_CAT) d_out = da + db + dc;
+    else {
+        d_out = da > db ? da : db;
+        d_out = d_out > dc ? d_out : dc;
+        if ((a && da != d_out) || (b && db != d_out) || (c && dc != d_out))
+            return set_error(GSN_E_INVALID, "gsn_propagate_fwd_hip: relu-sum blocks must share one width");
+    }
+    if (d_out <= 0 || n_nodes <= 0) return GSN_OK;
+    if (d_out > 1024) return set_error(GSN_E_UNSUPPORTED, "gsn_propagate_fwd_hip: message width %lld > 1024", (long long)d_out);
+    PropArgs p{};
+    p.kind = kind; p.n_nodes = n_nodes; p.n_edges = n_edges; p.src = src; p.seg_ptr = seg_ptr; p.perm = perm;
+    p.a = a; p.b = b; p.c = c; p.da = (int)da; p.db = (int)db; p.dc = (int)dc; p.d_out = (int)d_out;
+    p.b_per_node = b_per_node; p.out = out;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const bool aligned = ((da | db | dc) % 4 == 0) && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)out) % 16 == 0);
+    if (aligned) {
+        const int64_t q = d_out / 4;  // float4 per row
+        if (q <= 8) return launch_fwd<4, 8, 1>(p, st);
+        if (q <= 16) return launch_fwd<4, 16, 1>(p, st);
+        if (q <= 32) return launch_fwd<4, 32, 1>(p, st);
+        if (q <= 64) return launch_fwd<4, 64, 1>(p, st);
+        if (q <= 128) return launch_fwd<4, 64, 2>(p, st);
+        return launch_fwd<4, 64, 4>(p, st);
+    }
+    if (d_out <= 16) return launch_fwd<1, 16, 1>(p, st);
+    if (d_out <= 32) return launch_fwd<1, 32, 1>(p, st);
+    if (d_out <= 64) return launch_fwd<1, 64, 1>(p, st);
+    if (d_out <= 256) return launch_fwd<1, 64, 4>(p, st);
+    return launch_fwd<1, 64, 16>(p, st);
+}
+
+extern "C" int gsn_propagate_bwd_hip(int kind, int64_t n_nodes, int64_t n_edges, const int64_t *src, const int64_t *tgt,
+                                     const int32_t *seg_ptr_src, const int32_t *perm_src, const float *a, int64_t da,
+                                     const float *b, int64_t db, int b_per_node, const float *c, int64_t dc,
+                                     const float *g_out, float *g_a, float *g_b, float *g_c, void *stream) {
+    if (kind != GSN_MSG_CAT && kind != GSN_MSG_RELU_SUM) return set_error(GSN_E_INVALID, "gsn_propagate_bwd_hip: unknown kind %d", kind);
+    if (!g_out || (n_edges > 0 && (!src || !tgt))) return set_error(GSN_E_INVALID, "gsn_propagate_bwd_hip: null pointer");
+    int64_t d_out;
+    if (kind == GSN_MSG_CAT) d_out = da + db + dc;
+    else { d_out = da > db ? da : db; d_out = d_out > dc ? d_out : dc; }
+    if (d_out <= 0 || n_nodes <= 0) return GSN_OK;
+    if (kind == GSN_MSG_RELU_SUM && ((da && !a) || (db && !b) || (dc && !c)))
+        return set_error(GSN_E_INVALID, "gsn_propagate_bwd_hip: relu-sum needs the forward inputs");
+    PropBwdArgs p{};
+    p.kind = kind; p.n_nodes = n_nodes; p.n_edges = n_edges; p.src = src; p.tgt = tgt;
+    p.seg_ptr_src = seg_ptr_src; p.perm_src = perm_src;
+    p.a = da ? a : nullptr; p.b = db ? b : nullptr; p.c = dc ? c : nullptr; p.g_out = g_out;
+    p.da = (int)da; p.db = (int)db; p.dc = (int)dc; p.d_out = (int)d_out; p.b_per_node = b_per_node;
+    p.g_a = g_a; p.g_b = g_b; p.g_c = g_c;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const bool need_edge = (g_b && !b_per_node && db) || (g_c && dc);
+    if (need_edge && n_edges > 0) {
+        int64_t blocks = (n_edges * d_out + 255) / 256;
+        if (blocks > 16384) blocks = 16384;
+        hipLaunchKernelGGL(propagate_bwd_edge_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
+    }
+    const bool need_node = (g_a && da) || (g_b && b_per_node && db);
+    if (need_node) {
+        if (!seg_ptr_src || (n_edges > 0 && !perm_src)) return set_error(GSN_E_INVALID, "gsn_propagate_bwd_hip: source CSR missing");
+        int64_t blocks = (n_nodes + 3) / 4;
+        if (blocks > 16384) blocks = 16384;
+        hipLaunchKernelGGL(propagate_bwd_node_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
+    }
+    return hip_check("gsn_propagate_bwd_hip");
+}

@@ -1,0 +1,597 @@
+"""Sparse GSN / MPNN message-passing layers on HIP kernels: host-side mirror of the reference's ``graph_filters``.
+
+Classes, constructor arguments, ``forward(x, edge_index, **kwargs)`` signature, error behaviour and state_dict key
+names follow graph_filters/GSN_sparse.py, GSN_edge_sparse.py, MPNN_sparse.py, MPNN_edge_sparse.py,
+GSN_edge_sparse_ogb.py, MPNN_edge_sparse_ogb.py and models_misc.mlp of the reference, so reference checkpoints load
+(`load_state_dict`) and ``models_graph_classification.py`` can instantiate them unchanged.
+
+Forward pass = libgsn_hip.so kernels only:
+  * gsn_csr_build_hip      target-sorted CSR of the batch (cached per edge_index)
+  * gsn_linear_fwd_hip     every Linear(+BatchNorm1d)(+activation) stage, input rows gathered / concatenated on the fly
+  * gsn_propagate_fwd_hip  the scatter-add (and the gin / ogb message assembly)
+Restructuring that only changes fp32 rounding order (tolerance 1e-5, tests/test_layers_gpu.py): for
+``msg_kind='general'`` the last Linear of ``msg_fn`` is applied after the sum aggregation,
+``sum_e (W r_e + b) = W (sum_e r_e) + deg * b`` (SURVEY.md 7 "design notes for the MP kernels").
+Backward: the scatter-add has its own HIP adjoint (gsn_propagate_bwd_hip); the dense stages are re-computed through
+PyTorch autograd on the GPU (rocBLAS) -- see DESIGN.md "what is not native yet".
+There is no CPU path: calling a layer on CPU tensors raises.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _abi
+
+__all__ = ["mlp", "central_encoder", "GSN_sparse", "GSN_edge_sparse", "MPNN_sparse", "MPNN_edge_sparse",
+           "GSN_edge_sparse_ogb", "MPNN_edge_sparse_ogb", "build_csr", "propagate", "linear_stage"]
+
+_ACT_CODE = {"identity": 0, "relu": 1, "elu": 2, "tanh": 3}
+_MAX_BLOCKS = 5
+
+
+def choose_activation(activation):
+    """models_misc.py:5-15"""
+    if activation == "elu":
+        return nn.ELU()
+    if activation == "relu":
+        return nn.ReLU()
+    if activation == "tanh":
+        return nn.Tanh()
+    if activation == "identity":
+        return lambda x: x
+    raise NotImplementedError
+
+
+def _need_cuda(t, what):
+    if not t.is_cuda:
+        raise RuntimeError("gsn_amd.layers: %s is on %s; the layers run on HIP kernels only (no CPU fallback)" % (what, t.device))
+
+
+def _f32c(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# CSR of the aggregation index (cached per edge_index tensor)
+# ------------------------------------------------------------------------------------------------------------------
+class _CSR:
+    __slots__ = ("seg_ptr", "perm", "deg")
+
+
+_CSR_CACHE = {}
+
+
+def build_csr(index, n_nodes):
+    """(seg_ptr int32 [N+1], perm int32 [E]) grouping edge ids by ``index`` (stable), via gsn_csr_build_hip."""
+    _need_cuda(index, "edge_index")
+    index = index.contiguous()
+    E = index.numel()
+    L = _abi.lib()
+    dev = index.device
+    seg_ptr = torch.empty(n_nodes + 1, dtype=torch.int32, device=dev)
+    perm = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+    scratch = torch.empty(int(L.gsn_csr_scratch_elems(n_nodes)), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _abi.check(L.gsn_csr_build_hip(n_nodes, E, index.data_ptr() if E else None, seg_ptr.data_ptr(), perm.data_ptr(),
+                                       scratch.data_ptr(), _abi.current_stream()), "gsn_csr_build_hip")
+    return seg_ptr, perm[:E]
+
+
+def _csr_for(edge_index, row, n_nodes):
+    key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), row, n_nodes, edge_index.device)
+    c = _CSR_CACHE.get(key)
+    if c is None:
+        if len(_CSR_CACHE) > 64:
+            _CSR_CACHE.clear()
+        c = _CSR()
+        c.seg_ptr, c.perm = build_csr(edge_index[row], n_nodes)
+        c.deg = (c.seg_ptr[1:] - c.seg_ptr[:-1]).to(torch.float32).unsqueeze(1).contiguous()
+        _CSR_CACHE[key] = c
+    return c
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# propagate (scatter-add with fused message assembly) -- HIP forward and HIP adjoint
+# ------------------------------------------------------------------------------------------------------------------
+class _PropagateFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, kind, edge_index, sel, n_nodes, b_per_node, a, b, c):
+        tgt_row, src_row = sel, 1 - sel
+        csr_t = _csr_for(edge_index, tgt_row, n_nodes)
+        src = edge_index[src_row].contiguous()
+        E = src.numel()
+        ts = [None if t is None else _f32c(t) for t in (a, b, c)]
+        widths = [0 if t is None else t.shape[1] for t in ts]
+        d_out = sum(widths) if kind == 0 else max(widths)
+        out = torch.empty((n_nodes, d_out), dtype=torch.float32, device=edge_index.device)
+        with torch.cuda.device(edge_index.device):
+            rc = _abi.lib().gsn_propagate_fwd_hip(kind, n_nodes, E, src.data_ptr() if E else None, csr_t.seg_ptr.data_ptr(),
+                                                  csr_t.perm.data_ptr() if E else None, _abi.ptr(ts[0]), widths[0],
+                                                  _abi.ptr(ts[1]), widths[1], int(b_per_node), _abi.ptr(ts[2]), widths[2],
+                                                  out.data_ptr(), _abi.current_stream())
+        _abi.check(rc, "gsn_propagate_fwd_hip")
+        ctx.kind, ctx.sel, ctx.n_nodes, ctx.b_per_node = kind, sel, n_nodes, b_per_node
+        ctx.edge_index = edge_index
+        ctx.widths = widths
+        ctx.save_for_backward(*[t if t is not None else torch.empty(0, device=edge_index.device) for t in ts])
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        a, b, c = [t if t.numel() else None for t in ctx.saved_tensors]
+        ei, sel, n = ctx.edge_index, ctx.sel, ctx.n_nodes
+        src = ei[1 - sel].contiguous()
+        tgt = ei[sel].contiguous()
+        E = src.numel()
+        csr_s = _csr_for(ei, 1 - sel, n)
+        g_out = _f32c(g_out)
+        need = ctx.needs_input_grad[5:8]
+        dev = ei.device
+        wa, wb, wc = ctx.widths
+        g_a = torch.zeros((n, wa), dtype=torch.float32, device=dev) if (need[0] and wa) else None
+        g_b = None
+        if need[1] and wb:
+            g_b = torch.zeros((n if ctx.b_per_node else E, wb), dtype=torch.float32, device=dev)
+        g_c = torch.zeros((E, wc), dtype=torch.float32, device=dev) if (need[2] and wc) else None
+        with torch.cuda.device(dev):
+            rc = _abi.lib().gsn_propagate_bwd_hip(ctx.kind, n, E, src.data_ptr() if E else None, tgt.data_ptr() if E else None,
+                                                  csr_s.seg_ptr.data_ptr(), csr_s.perm.data_ptr() if E else None,
+                                                  _abi.ptr(a), wa, _abi.ptr(b), wb, int(ctx.b_per_node), _abi.ptr(c), wc,
+                                                  g_out.data_ptr(), _abi.ptr(g_a), _abi.ptr(g_b), _abi.ptr(g_c),
+                                                  _abi.current_stream())
+        _abi.check(rc, "gsn_propagate_bwd_hip")
+        return None, None, None, None, None, g_a, g_b, g_c
+
+
+def propagate(kind, edge_index, sel, n_nodes, a=None, b=None, c=None, b_per_node=False):
+    """out[t] = sum_{e: edge_index[sel, e] = t} msg_e  with msg_e = cat(a[src_e], b, c) (kind 0) or
+    relu(a[src_e] + b + c) (kind 1); b is per edge, or per node gathered at src if ``b_per_node``."""
+    return _PropagateFn.apply(kind, edge_index, sel, n_nodes, bool(b_per_node), a, b, c)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# fused Linear (+BN) (+activation) stage
+# ------------------------------------------------------------------------------------------------------------------
+def _linear_hip(blocks, weight, bias, bn_mean, bn_scale, bn_shift, act, m_rows, out=True, stats=None):
+    """blocks: list of (data [R,w] fp32 cuda, idx int64 [M] or None)."""
+    if len(blocks) > _MAX_BLOCKS:
+        raise NotImplementedError("more than %d input blocks" % _MAX_BLOCKS)
+    dev = weight.device
+    arr = (_abi.gsn_block * len(blocks))()
+    keep = []
+    for i, (d, idx) in enumerate(blocks):
+        d = _f32c(d)
+        keep.append(d)
+        arr[i].data = d.data_ptr()
+        if idx is not None:
+            idx = idx.contiguous()
+            keep.append(idx)
+            arr[i].idx = idx.data_ptr()
+        else:
+            arr[i].idx = None
+        arr[i].width = d.shape[1]
+    n_out = weight.shape[0]
+    y = torch.empty((m_rows, n_out), dtype=torch.float32, device=dev) if out else None
+    w = _f32c(weight)
+    vecs = [None if v is None else _f32c(v) for v in (bias, bn_mean, bn_scale, bn_shift)]
+    with torch.cuda.device(dev):
+        rc = _abi.lib().gsn_linear_fwd_hip(m_rows, len(blocks), arr, w.data_ptr(), _abi.ptr(vecs[0]), n_out, _abi.ptr(vecs[1]),
+                                           _abi.ptr(vecs[2]), _abi.ptr(vecs[3]), act, None, _abi.ptr(y), _abi.ptr(stats),
+                                           _abi.current_stream())
+    _abi.check(rc, "gsn_linear_fwd_hip")
+    return y
+
+
+def linear_stage(blocks, m_rows, fc, bn, act_name, training):
+    """One stage of models_misc.mlp: act(bn(fc(cat(blocks)))) on the HIP kernel.  Train-mode BatchNorm1d uses two
+    passes (column statistics in fp64, then normalise) and updates the running statistics like nn.BatchNorm1d."""
+    act = _ACT_CODE[act_name]
+    if bn is None:
+        return _linear_hip(blocks, fc.weight, fc.bias, None, None, None, act, m_rows)
+    if training:
+        n_out = fc.weight.shape[0]
+        stats = torch.zeros((2, n_out), dtype=torch.float64, device=fc.weight.device)
+        _linear_hip(blocks, fc.weight, fc.bias, None, None, None, 0, m_rows, out=False, stats=stats)
+        mean = stats[0] / m_rows
+        var = (stats[1] / m_rows - mean * mean).clamp_min_(0.0)
+        if bn.track_running_stats and bn.running_mean is not None:
+            with torch.no_grad():
+                mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
+                bn.num_batches_tracked += 1
+                unbiased = var * (m_rows / max(m_rows - 1, 1))
+                bn.running_mean.mul_(1 - mom).add_(mean.to(torch.float32) * mom)
+                bn.running_var.mul_(1 - mom).add_(unbiased.to(torch.float32) * mom)
+        mean32 = mean.to(torch.float32)
+        invstd = torch.rsqrt(var + bn.eps).to(torch.float32)
+    else:
+        mean32 = bn.running_mean
+        invstd = torch.rsqrt(bn.running_var.to(torch.float64) + bn.eps).to(torch.float32)
+    scale = invstd * bn.weight.detach() if bn.affine else invstd
+    shift = bn.bias.detach() if bn.affine else torch.zeros_like(invstd)
+    return _linear_hip(blocks, fc.weight, fc.bias, mean32, scale, shift, act, m_rows)
+
+
+class mlp(nn.Module):
+    """models_misc.mlp (models_misc.py:18-59): Linear -> [BatchNorm1d] -> activation ... -> Linear, same attribute
+    names (``fc``, ``bn``) so state dicts are interchangeable; forward runs on the HIP dense stage."""
+
+    def __init__(self, in_features, out_features, d_k, seed, activation="elu", batch_norm=False):
+        super().__init__()
+        self.in_features, self.out_features, self.d_k, self.seed = in_features, out_features, d_k, seed
+        self.activation_name, self.batch_norm = activation, batch_norm
+        fc, bn = [], []
+        d_in = [in_features]
+        d_k = d_k + [out_features]
+        for i in range(len(d_k)):
+            fc.append(nn.Linear(d_in[i], d_k[i], bias=True))
+            d_in = d_in + [d_k[i]]
+            if self.batch_norm and i != len(d_k) - 1:
+                bn.append(nn.BatchNorm1d(d_k[i]))
+        self.fc = nn.ModuleList(fc)
+        self.bn = nn.ModuleList(bn)
+        self.activation = choose_activation(activation)
+
+    # -- HIP forward over on-the-fly concatenated / gathered input blocks
+    def hip_forward(self, blocks, m_rows, upto=None):
+        n = len(self.fc) if upto is None else upto
+        y = None
+        for i in range(n):
+            last = i == len(self.fc) - 1
+            blk = blocks if i == 0 else [(y, None)]
+            if last:
+                y = _linear_hip(blk, self.fc[i].weight, self.fc[i].bias, None, None, None, 0, m_rows)
+            else:
+                y = linear_stage(blk, m_rows, self.fc[i], self.bn[i] if self.batch_norm else None, self.activation_name,
+                                 self.training)
+        return y
+
+    # -- differentiable PyTorch twin (used to back-propagate through the dense stages)
+    def torch_forward(self, x, upto=None):
+        n = len(self.fc) if upto is None else upto
+        for i in range(n):
+            x = self.fc[i](x)
+            if i != len(self.fc) - 1:
+                if self.batch_norm:
+                    b = self.bn[i]
+                    x = F.batch_norm(x, None if self.training else b.running_mean, None if self.training else b.running_var,
+                                     b.weight, b.bias, self.training, 0.0, b.eps)
+                x = self.activation(x)
+        return x
+
+    def forward(self, x):
+        _need_cuda(x, "mlp input")
+        return _run(self, lambda: self.hip_forward([(x, None)], x.shape[0]), lambda x_: self.torch_forward(x_), [x])
+
+
+class _HipWithTorchBackward(torch.autograd.Function):
+    """y = hip_fn() in forward; gradients by re-running the differentiable twin under autograd."""
+
+    @staticmethod
+    def forward(ctx, hip_fn, torch_fn, n_inputs, *tensors):
+        ctx.torch_fn, ctx.n_inputs = torch_fn, n_inputs
+        ctx.params = list(tensors[n_inputs:])   # the module's own Parameter objects (the twin reads them directly)
+        ctx.save_for_backward(*tensors[:n_inputs])
+        with torch.no_grad():
+            return hip_fn()
+
+    @staticmethod
+    def backward(ctx, gy):
+        tensors = ctx.saved_tensors
+        ins = [t.detach().requires_grad_(ctx.needs_input_grad[3 + i]) for i, t in enumerate(tensors)]
+        params = ctx.params
+        with torch.enable_grad():
+            y = ctx.torch_fn(*ins)
+            wanted = [t for t in ins if t.requires_grad] + [p for i, p in enumerate(params) if ctx.needs_input_grad[3 + ctx.n_inputs + i]]
+            grads = torch.autograd.grad(y, wanted, gy, allow_unused=True) if wanted else []
+        it = iter(grads)
+        out = [None, None, None]
+        for t in ins:
+            out.append(next(it) if t.requires_grad else None)
+        for i, p in enumerate(params):
+            out.append(next(it) if ctx.needs_input_grad[3 + ctx.n_inputs + i] else None)
+        return tuple(out)
+
+
+def _run(module, hip_fn, torch_fn, inputs):
+    params = [p for p in module.parameters()]
+    need_grad = torch.is_grad_enabled() and (any(t.requires_grad for t in inputs) or any(p.requires_grad for p in params))
+    if not need_grad:
+        with torch.no_grad():
+            return hip_fn()
+    return _HipWithTorchBackward.apply(hip_fn, torch_fn, len(inputs), *inputs, *params)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# central_encoder (utils_graph_learning.py:211-260): dummy "self loop" value of ids / edge features for GIN-style sums
+# ------------------------------------------------------------------------------------------------------------------
+class _SumEmbedding(nn.Module):
+    """the reference's multi_embedding([1], d, aggr='sum') -> parameter name ``encoder.0.weight``"""
+
+    def __init__(self, d_out):
+        super().__init__()
+        emb = nn.Embedding(1, d_out)
+        torch.nn.init.xavier_uniform_(emb.weight.data)
+        self.encoder = nn.ModuleList([emb])
+
+
+class _DiscreteEmbeddingShim(nn.Module):
+    def __init__(self, d_out):
+        super().__init__()
+        self.encoder = _SumEmbedding(d_out)
+
+
+class central_encoder(nn.Module):
+    def __init__(self, nb_encoder, d_ef, extend=True):
+        super().__init__()
+        self.extend, self.nb_encoder = extend, nb_encoder
+        self.one_hot = "one_hot_encoder" in nb_encoder
+        if self.one_hot:
+            self.d_out = d_ef + 1 if extend else d_ef
+        else:
+            self.d_out = d_ef
+            if extend:
+                self.encoder = _DiscreteEmbeddingShim(d_ef)  # state key: encoder.encoder.encoder.0.weight
+
+    def forward(self, x_nb, num_nodes):
+        if self.one_hot and self.extend:
+            x_nb = torch.cat((torch.zeros((x_nb.shape[0], 1), device=x_nb.device), x_nb), -1)
+            x_central = torch.zeros((num_nodes, self.d_out), device=x_nb.device)
+            x_central[:, 0] = 1.0
+        elif (not self.one_hot) and self.extend:
+            x_central = self.encoder.encoder.encoder[0].weight[0:1].expand(num_nodes, -1)
+        else:
+            x_central = torch.zeros((num_nodes, self.d_out), device=x_nb.device)
+        return x_central, x_nb
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the layers
+# ------------------------------------------------------------------------------------------------------------------
+class _SparseLayer(nn.Module):
+    """Shared implementation; subclasses fix (has_ids, has_ef, ogb)."""
+
+    has_ids = True
+    has_ef = False
+    ogb = False
+
+    def __init__(self, d_in, d_degree, degree_as_tag, retain_features, d_msg, d_up, d_h, seed, activation_name, bn,
+                 d_ef=None, d_id=None, id_scope=None, aggr="add", msg_kind=None, eps=0, train_eps=False,
+                 flow="source_to_target", **kwargs):
+        super().__init__()
+        if msg_kind is None:
+            msg_kind = "ogb" if self.ogb else "general"
+        if not self.ogb:
+            d_msg = d_in if d_msg is None else d_msg
+        self.flow, self.aggr, self.msg_kind = flow, aggr, msg_kind
+        if self.has_ids:
+            self.id_scope = id_scope
+        self.degree_as_tag, self.retain_features = degree_as_tag, retain_features
+        if degree_as_tag:
+            d_in = d_in + d_degree if retain_features else d_degree
+        d_id = d_id if self.has_ids else 0
+        d_ef = d_ef if self.has_ef else 0
+        name = self.__class__.__name__
+        if self.ogb:
+            if msg_kind != "ogb":
+                raise NotImplementedError("msg kind {} is not currently supported.".format(msg_kind))
+            self._init_eps(eps, train_eps)
+            update_input_dim = d_in
+        elif msg_kind == "gin":
+            if self.has_ef:
+                self.central_node_edge_encoder = central_encoder(kwargs["edge_embedding"], d_ef, extend=kwargs["extend_dims"])
+                d_ef = self.central_node_edge_encoder.d_out
+            if self.has_ids and id_scope == "local":
+                self.central_node_id_encoder = central_encoder(kwargs["id_embedding"], d_id, extend=kwargs["extend_dims"])
+                d_id = self.central_node_id_encoder.d_out
+            self._init_eps(eps, train_eps)
+            self.msg_fn = None
+            update_input_dim = d_in + d_id + d_ef
+        elif msg_kind == "general":
+            local = (not self.has_ids) or id_scope == "local"
+            msg_input_dim = 2 * d_in + d_id + d_ef if local else 2 * (d_in + d_id) + d_ef
+            self.msg_fn = mlp(msg_input_dim, d_msg, d_h, seed, activation_name, bn)
+            update_input_dim = d_in + d_msg
+        else:
+            raise NotImplementedError("msg kind {} is not currently supported.".format(msg_kind))
+        self.update_fn = mlp(update_input_dim, d_up, d_h, seed, activation_name, bn)
+        del name
+
+    def _init_eps(self, eps, train_eps):
+        self.initial_eps = eps
+        if train_eps:
+            self.eps = torch.nn.Parameter(torch.Tensor([eps]))
+        else:
+            self.register_buffer("eps", torch.Tensor([eps]))
+        self.eps.data.fill_(self.initial_eps)
+
+    # -- input preparation shared by both paths (reference: forward() prologue of every layer)
+    def _prepare(self, x, kwargs):
+        x = x.unsqueeze(-1) if x.dim() == 1 else x
+        degrees = kwargs["degrees"]
+        identifiers = kwargs["identifiers"] if self.has_ids or self.ogb else None
+        if not self.has_ids:
+            identifiers = None
+        if degrees is not None:
+            degrees = degrees.unsqueeze(-1) if degrees.dim() == 1 else degrees
+        if self.degree_as_tag:
+            x = torch.cat([x, degrees], -1) if self.retain_features else degrees
+        ef = None
+        if self.has_ef:
+            ef = kwargs["edge_features"]
+            ef = ef.unsqueeze(-1) if ef.dim() == 1 else ef
+        return x, identifiers, ef
+
+    def forward(self, x, edge_index, **kwargs):
+        if self.aggr == "mean":
+            raise NameError("name 'aggr_index' is not defined")  # the reference's 'mean' branch is dead code (GSN_sparse.py:148)
+        if self.aggr != "add":
+            raise NotImplementedError("Aggregation kind {} is not currently supported.".format(self.aggr))
+        if self.msg_kind not in ("gin", "general", "ogb"):
+            raise NotImplementedError("Message kind {} is not currently supported.".format(self.msg_kind))
+        x, ids, ef = self._prepare(x, kwargs)
+        _need_cuda(x, "x")
+        _need_cuda(edge_index, "edge_index")
+        inputs = [x] + ([ids] if ids is not None else []) + ([ef] if ef is not None else [])
+
+        def unpack(ts):
+            ts = list(ts)
+            x_ = ts.pop(0)
+            ids_ = ts.pop(0) if ids is not None else None
+            ef_ = ts.pop(0) if ef is not None else None
+            return x_, ids_, ef_
+
+        return _run(self, lambda: self._hip(edge_index, x, ids, ef), lambda *ts: self._twin(edge_index, *unpack(ts)), inputs)
+
+    # -- message blocks ------------------------------------------------------------------------------------------
+    def _sel(self):
+        return 0 if self.flow == "target_to_source" else 1
+
+    def _gin_parts(self, x, ids, ef, n):
+        """(self parts, neighbour ids, neighbour ef, ids per node?) for the gin formulation"""
+        self_parts = [x]
+        ids_nb, ids_per_node = None, False
+        if self.has_ids:
+            if self.id_scope == "global":
+                self_parts.append(ids); ids_nb, ids_per_node = ids, True
+            else:
+                c, ids_nb = self.central_node_id_encoder(ids, n)
+                self_parts.append(c)
+        ef_nb = None
+        if self.has_ef:
+            c, ef_nb = self.central_node_edge_encoder(ef, n)
+            self_parts.append(c)
+        return self_parts, ids_nb, ef_nb, ids_per_node
+
+    # -- HIP forward ---------------------------------------------------------------------------------------------
+    def _hip(self, edge_index, x, ids, ef):
+        n = x.shape[0]
+        sel = self._sel()
+        E = edge_index.shape[1]
+        x = _f32c(x)
+        if self.ogb:
+            per_node = self.has_ids and self.id_scope == "global"
+            agg = propagate(1, edge_index, sel, n, a=x, b=ids if self.has_ids else None, c=ef, b_per_node=per_node)
+            self_msg = x + ids if per_node else x
+            xin = (1 + self.eps) * self_msg + agg
+            return self.update_fn.hip_forward([(xin, None)], n)
+        if self.msg_kind == "gin":
+            self_parts, ids_nb, ef_nb, per_node = self._gin_parts(x, ids, ef, n)
+            agg = propagate(0, edge_index, sel, n, a=x, b=ids_nb, c=ef_nb, b_per_node=per_node)
+            xin = (1 + self.eps) * torch.cat(self_parts, -1) + agg
+            return self.update_fn.hip_forward([(xin, None)], n)
+        # general
+        idx_i, idx_j = edge_index[sel].contiguous(), edge_index[1 - sel].contiguous()
+        blocks = [(x, idx_i), (x, idx_j)]
+        if self.has_ids:
+            blocks += [(ids, None)] if self.id_scope == "local" else [(ids, idx_i), (ids, idx_j)]
+        if self.has_ef:
+            blocks.append((ef, None))
+        mf = self.msg_fn
+        if len(mf.fc) >= 2:
+            # all stages but the last Linear on E rows, sum-aggregate, then the last Linear on N rows (+ deg * bias)
+            r = mf.hip_forward(blocks, E, upto=len(mf.fc) - 1)
+            s = propagate(0, edge_index, sel, n, b=r)
+            csr = _csr_for(edge_index, sel, n)
+            last = mf.fc[-1]
+            w_ext = torch.cat([last.weight.detach(), last.bias.detach().unsqueeze(1)], 1)
+            agg = _linear_hip([(s, None), (csr.deg, None)], w_ext, None, None, None, None, 0, n)
+        else:
+            msgs = mf.hip_forward(blocks, E)
+            agg = propagate(0, edge_index, sel, n, b=msgs)
+        return self.update_fn.hip_forward([(x, None), (agg, None)], n)
+
+    # -- differentiable twin (PyTorch ops + the HIP propagate with its own adjoint) ---------------------------------
+    def _twin(self, edge_index, x, ids, ef):
+        n = x.shape[0]
+        sel = self._sel()
+        if self.ogb:
+            per_node = self.has_ids and self.id_scope == "global"
+            agg = propagate(1, edge_index, sel, n, a=x, b=ids if self.has_ids else None, c=ef, b_per_node=per_node)
+            self_msg = x + ids if per_node else x
+            return self.update_fn.torch_forward((1 + self.eps) * self_msg + agg)
+        if self.msg_kind == "gin":
+            self_parts, ids_nb, ef_nb, per_node = self._gin_parts(x, ids, ef, n)
+            agg = propagate(0, edge_index, sel, n, a=x, b=ids_nb, c=ef_nb, b_per_node=per_node)
+            return self.update_fn.torch_forward((1 + self.eps) * torch.cat(self_parts, -1) + agg)
+        idx_i, idx_j = edge_index[sel], edge_index[1 - sel]
+        parts = [x[idx_i], x[idx_j]]
+        if self.has_ids:
+            parts += [ids] if self.id_scope == "local" else [ids[idx_i], ids[idx_j]]
+        if self.has_ef:
+            parts.append(ef)
+        msgs = self.msg_fn.torch_forward(torch.cat(parts, -1))
+        agg = propagate(0, edge_index, sel, n, b=msgs)
+        return self.update_fn.torch_forward(torch.cat((x, agg), -1))
+
+    def __repr__(self):
+        if self.ogb:
+            return "{}(update_fn = {})".format(self.__class__.__name__, self.update_fn)
+        return "{}(msg_fn = {}, update_fn = {})".format(self.__class__.__name__, self.msg_fn, self.update_fn)
+
+
+class GSN_sparse(_SparseLayer):
+    """graph_filters/GSN_sparse.py:8-181 (GSN-v: id_scope='global', GSN-e: 'local'; no edge features)."""
+    has_ids, has_ef, ogb = True, False, False
+
+    def __init__(self, d_in, d_id, d_degree, degree_as_tag, retain_features, id_scope, d_msg, d_up, d_h, seed,
+                 activation_name, bn, aggr="add", msg_kind="general", eps=0, train_eps=False, flow="source_to_target", **kwargs):
+        kwargs.pop("d_ef", None)
+        super().__init__(d_in, d_degree, degree_as_tag, retain_features, d_msg, d_up, d_h, seed, activation_name, bn,
+                         d_id=d_id, id_scope=id_scope, aggr=aggr, msg_kind=msg_kind, eps=eps, train_eps=train_eps, flow=flow, **kwargs)
+
+
+class GSN_edge_sparse(_SparseLayer):
+    """graph_filters/GSN_edge_sparse.py:8-175."""
+    has_ids, has_ef, ogb = True, True, False
+
+    def __init__(self, d_in, d_ef, d_id, d_degree, degree_as_tag, retain_features, id_scope, d_msg, d_up, d_h, seed,
+                 activation_name, bn, aggr="add", msg_kind="general", eps=0, train_eps=False, flow="source_to_target", **kwargs):
+        super().__init__(d_in, d_degree, degree_as_tag, retain_features, d_msg, d_up, d_h, seed, activation_name, bn,
+                         d_ef=d_ef, d_id=d_id, id_scope=id_scope, aggr=aggr, msg_kind=msg_kind, eps=eps, train_eps=train_eps,
+                         flow=flow, **kwargs)
+
+
+class MPNN_sparse(_SparseLayer):
+    """graph_filters/MPNN_sparse.py (identifier-free twin of GSN_sparse)."""
+    has_ids, has_ef, ogb = False, False, False
+
+    def __init__(self, d_in, d_degree, degree_as_tag, retain_features, d_msg, d_up, d_h, seed, activation_name, bn,
+                 aggr="add", msg_kind="general", eps=0, train_eps=False, flow="source_to_target", **kwargs):
+        kwargs.pop("d_ef", None)
+        super().__init__(d_in, d_degree, degree_as_tag, retain_features, d_msg, d_up, d_h, seed, activation_name, bn,
+                         aggr=aggr, msg_kind=msg_kind, eps=eps, train_eps=train_eps, flow=flow, **kwargs)
+
+
+class MPNN_edge_sparse(_SparseLayer):
+    """graph_filters/MPNN_edge_sparse.py (identifier-free twin of GSN_edge_sparse)."""
+    has_ids, has_ef, ogb = False, True, False
+
+    def __init__(self, d_in, d_ef, d_degree, degree_as_tag, retain_features, d_msg, d_up, d_h, seed, activation_name, bn,
+                 aggr="add", msg_kind="general", eps=0, train_eps=False, flow="source_to_target", **kwargs):
+        super().__init__(d_in, d_degree, degree_as_tag, retain_features, d_msg, d_up, d_h, seed, activation_name, bn,
+                         d_ef=d_ef, aggr=aggr, msg_kind=msg_kind, eps=eps, train_eps=train_eps, flow=flow, **kwargs)
+
+
+class GSN_edge_sparse_ogb(_SparseLayer):
+    """graph_filters/GSN_edge_sparse_ogb.py:9-134: msg = relu(x_j + id + e), GIN-style update."""
+    has_ids, has_ef, ogb = True, True, True
+
+    def __init__(self, d_in, d_ef, d_id, d_degree, degree_as_tag, retain_features, id_scope, d_msg, d_up, d_h, seed,
+                 activation_name, bn, aggr="add", msg_kind="ogb", eps=0, train_eps=False, flow="source_to_target", **kwargs):
+        super().__init__(d_in, d_degree, degree_as_tag, retain_features, d_msg, d_up, d_h, seed, activation_name, bn,
+                         d_ef=d_ef, d_id=d_id, id_scope=id_scope, aggr=aggr, msg_kind=msg_kind, eps=eps, train_eps=train_eps,
+                         flow=flow, **kwargs)
+
+
+class MPNN_edge_sparse_ogb(_SparseLayer):
+    """graph_filters/MPNN_edge_sparse_ogb.py: msg = relu(x_j + e)."""
+    has_ids, has_ef, ogb = False, True, True
+
+    def __init__(self, d_in, d_ef, d_degree, degree_as_tag, retain_features, d_msg, d_up, d_h, seed, activation_name, bn,
+                 aggr="add", msg_kind="ogb", eps=0, train_eps=False, flow="source_to_target", **kwargs):
+        super().__init__(d_in, d_degree, degree_as_tag, retain_features, d_msg, d_up, d_h, seed, activation_name, bn,
+                         d_ef=d_ef, aggr=aggr, msg_kind=msg_kind, eps=eps, train_eps=train_eps, flow=flow, **kwargs)

@@ -106,8 +106,9 @@ int gsn_count_hip(const uint32_t *plan_host, const uint32_t *plan_dev, int64_t p
  * target-sorted edge permutation.  This builds that CSR once per batch (stable counting sort by target):
  *   index   int64 device [E]  aggregation targets (edge_index[1] for flow=source_to_target, [0] otherwise)
  *   seg_ptr int32 device [N+1] out; perm int32 device [E] out (edge ids grouped by target, original order kept inside)
- *   scratch int32 device [N+1]
+ *   scratch int32 device [gsn_csr_scratch_elems(N)]
  * ---------------------------------------------------------------------------------------------------------------- */
+int64_t gsn_csr_scratch_elems(int64_t n_nodes);
 int gsn_csr_build_hip(int64_t n_nodes, int64_t n_edges, const int64_t *index, int32_t *seg_ptr, int32_t *perm,
                       int32_t *scratch, void *stream);
 
@@ -139,18 +140,17 @@ int gsn_propagate_bwd_hip(int kind, int64_t n_nodes, int64_t n_edges, const int6
 /* ------------------------------------------------------------------------------------------------------------------
  * HP-2  fused dense stage (device, fp32 MFMA v_mfma_f32_32x32x2_f32).  One models_misc.mlp layer
  * (models_misc.py:52-58)   Y = act( bn( X W^T + bias ) )   over M rows, where the rows of X are assembled on the fly
- * as a concatenation of up to four blocks, each either direct ([M][w]) or gathered through an int64 index
+ * as a concatenation of up to five blocks, each either direct ([M][w]) or gathered through an int64 index
  * ([R][w] rows picked by idx[M]) -- this is torch.cat((x_i, x_j, identifiers.., edge_features), -1) feeding msg_fn
- * (GSN_sparse.py:166-171, GSN_edge_sparse.py:160-165) without materialising the cat or the gathers -- and, optionally,
- * a segmented-sum epilogue  out[t] = sum_{rows r of segment t} Y[r]  (the scatter-add, rows taken in `perm` order).
- *   W [n_out][k_total] row-major fp32 as nn.Linear stores it; bias [n_out] or NULL
- *   bn_scale/bn_shift [n_out] or NULL: eval-mode BatchNorm1d folded to y*scale+shift by the caller
- *       (scale = gamma/sqrt(running_var+eps), shift = beta - running_mean*scale)
+ * (GSN_sparse.py:166-171, GSN_edge_sparse.py:160-165) without materialising the cat or the gathers.
+ *   W [n_out][k_total] row-major fp32 as nn.Linear stores it (k_total = sum of block widths); bias [n_out] or NULL
+ *   bn_mean / bn_scale / bn_shift [n_out], all three or none:  y = (h - mean) * scale + shift  with
+ *       scale = gamma / sqrt(var + eps), shift = beta  (eval: running stats; train: the batch stats of pass 1)
  *   act: 0 identity, 1 relu, 2 elu, 3 tanh   (models_misc.choose_activation)
- *   row_perm int32 [M] or NULL: row r of the tile space reads logical row row_perm[r] (edge ids in target order)
- *   seg_ptr  int32 [n_seg+1] or NULL: if given, Y is not written; out is [n_seg][n_out] segmented sums over tile-space rows
- *   stats    double [2][n_out] or NULL: if given (train-mode BN, first pass) accumulates per-column sum and sum of
- *            squares of the PRE-BN values (X W^T + bias) and skips bn/act/output
+ *   row_perm int32 [M] or NULL: output row r is computed from logical input row row_perm[r]
+ *   out   [M][n_out] fp32, or NULL when only statistics are wanted
+ *   stats double [2][n_out] or NULL: if given (train-mode BatchNorm1d, first pass) the kernel ADDS per-column sum and
+ *         sum of squares of the PRE-BN values h = X W^T + bias into it (caller zeroes it) and skips bn / act / out
  * ---------------------------------------------------------------------------------------------------------------- */
 typedef struct {
     const float *data;   /* [rows][width] fp32, row stride = width */
@@ -159,8 +159,8 @@ typedef struct {
 } gsn_block;
 
 int gsn_linear_fwd_hip(int64_t m_rows, int n_blocks, const gsn_block *blocks, const float *W, const float *bias,
-                       int64_t n_out, const float *bn_scale, const float *bn_shift, int act, const int32_t *row_perm,
-                       const int32_t *seg_ptr, int64_t n_seg, float *out, double *stats, void *stream);
+                       int64_t n_out, const float *bn_mean, const float *bn_scale, const float *bn_shift, int act,
+                       const int32_t *row_perm, float *out, double *stats, void *stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,140 @@
+"""CPU checks of the boundary: the C-ABI library loads and exports every symbol include/gsn_abi.h declares, the
+host-side entry points (pattern orbits, plan compiler) agree with the golden vectors, and the product path refuses
+to run without a GPU instead of silently falling back."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import load, case_names, count_case
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from gsn_amd import _abi
+    _abi.build()
+    return _abi.lib()
+
+
+def test_header_symbols_exported(lib):
+    hdr = open(os.path.join(REPO, "include", "gsn_abi.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(gsn_[a-z0-9_]+)\s*\(", hdr))
+    assert {"gsn_count_hip", "gsn_pattern_orbits", "gsn_linear_fwd_hip", "gsn_propagate_fwd_hip"} <= declared
+    raw = ctypes.CDLL(os.path.join(REPO, "gsn_amd", "lib", "libgsn_hip.so"))
+    for name in declared:
+        assert hasattr(raw, name), "libgsn_hip.so does not export %s" % name
+    from gsn_amd import _abi
+    assert declared == set(_abi.SIGNATURES), "ctypes signature table out of sync with include/gsn_abi.h"
+    assert lib.gsn_version() == 1
+
+
+@pytest.mark.parametrize("name", case_names("orbits"))
+def test_pattern_orbits_match_reference(lib, name):
+    from gsn_amd import patterns
+    z = load("orbits")
+    edges = z[name + "/edges"]
+    k = int(edges.max()) + 1
+    if k > 8:
+        with pytest.raises(Exception):
+            patterns.analyse(edges)
+        return
+    info = patterns.analyse(edges, False)
+    assert info["vertex_orbit"].tolist() == z[name + "/v_membership"].tolist()
+    assert info["aut_count"] == int(z[name + "/aut_count"])
+    assert info["arcs"].tolist() == z[name + "/e_list"].tolist()
+    assert info["arc_orbit"].tolist() == z[name + "/e_membership"].tolist()
+    info = patterns.analyse(edges, True)
+    assert info["arc_orbit"].tolist() == z[name + "/e_membership_dir"].tolist()
+    assert info["n_edge_orbits"] == int(z[name + "/n_eorbits_dir"])
+
+
+def test_reference_style_return_values(lib, capsys):
+    from gsn_amd import patterns
+    g, part, memb, aut = patterns.automorphism_orbits(edge_list=[(0, 1), (1, 2), (2, 3)], directed=False, directed_orbits=False)
+    assert part == {0: [0, 3], 1: [1, 2]} and memb == {0: 0, 1: 1, 2: 1, 3: 0} and aut == 2
+    assert "Automorphism count: 2" in capsys.readouterr().out
+    g, epart, ememb, aut = patterns.induced_edge_automorphism_orbits(edge_list=[(0, 1), (1, 2), (2, 3)], directed=False, directed_orbits=False)
+    assert epart == {0: [(0, 1), (1, 0), (2, 3), (3, 2)], 1: [(1, 2), (2, 1)]}
+    assert ememb == {0: 0, 1: 0, 2: 1, 3: 1, 4: 0, 5: 0}
+    import pickle
+    assert pickle.loads(pickle.dumps(g)).edge_list == g.edge_list   # joblib workers pickle subgraph_dicts
+    with pytest.raises(NotImplementedError):
+        patterns.edge_automorphism_orbits(edge_list=[(0, 1), (1, 2)])
+
+
+@pytest.fixture(scope="module")
+def harness():
+    so = os.path.join(REPO, "tests", "_build", "libharness.so")
+    os.makedirs(os.path.dirname(so), exist_ok=True)
+    srcs = [os.path.join(REPO, "tests", "host_harness.cpp"), os.path.join(REPO, "gsn_amd", "csrc", "patterns.cpp")]
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so] + srcs)
+    return ctypes.CDLL(so)
+
+
+@pytest.mark.parametrize("name", case_names("counts"))
+def test_plans_and_search_core_on_host(lib, harness, name):
+    """Plan compiler (product code) + per-lane search core (shared with the HIP kernel), run on the host by the
+    test-only harness, against the golden counts of the reference."""
+    from gsn_amd.counting import CountPlan
+    c = count_case(name)
+    plan = CountPlan(c["patterns"], c["mode"], c["induced"], c["directed_orbits"])
+    npt, ept, ei = c["node_ptr"], c["edge_ptr"], c["edge_index_local"]
+    I64P, U32P = ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_uint32)
+    outs = []
+    for g in range(len(npt) - 1):
+        n, E = int(npt[g + 1] - npt[g]), int(ept[g + 1] - ept[g])
+        src = np.ascontiguousarray(ei[0, ept[g]:ept[g + 1]])
+        dst = np.ascontiguousarray(ei[1, ept[g]:ept[g + 1]])
+        rows = E if c["mode"] == "edge" else n
+        out = np.zeros((rows, plan.n_cols), dtype=np.int64)
+        st = harness.harness_count(plan.table.ctypes.data_as(U32P), ctypes.c_int64(n), ctypes.c_int64(E),
+                                   src.ctypes.data_as(I64P), dst.ctypes.data_as(I64P), out.ctypes.data_as(I64P))
+        assert st == 0
+        outs.append(out)
+    got = np.concatenate(outs, axis=0) if outs else np.zeros((0, plan.n_cols), np.int64)
+    assert np.array_equal(got, c["counts"])
+
+
+def test_no_cpu_fallback(lib):
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from gsn_amd import counting, layers, patterns
+    _, part, memb, aut = patterns.automorphism_orbits(edge_list=[(0, 1), (1, 2), (2, 0)], print_msgs=False)
+    d = {"subgraph": patterns.PatternGraph([(0, 1), (1, 2), (2, 0)]), "orbit_partition": part, "orbit_membership": memb, "aut_count": aut}
+    ei = torch.tensor([[0, 1, 1, 2, 2, 0], [1, 0, 2, 1, 0, 2]])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        counting.subgraph_isomorphism_vertex_counts(ei, subgraph_dict=d, induced=False, num_nodes=3)
+    layer = layers.MPNN_sparse(d_in=4, d_degree=1, degree_as_tag=False, retain_features=True, d_msg=4, d_up=4, d_h=[4], seed=0,
+                               activation_name="relu", bn=False)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        layer(torch.randn(3, 4), ei, degrees=torch.zeros(3))
+
+
+def test_product_does_not_import_oracle():
+    for root, _, files in os.walk(os.path.join(REPO, "gsn_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                txt = open(os.path.join(root, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "liboracle" not in txt, f
+
+
+def test_state_dict_keys_and_seeded_init_match_reference():
+    """Same constructor + same torch seed -> same parameter tensors as the reference layer (golden 'sd/')."""
+    from gsn_amd import layers
+    from helpers import layer_case
+    for name in ["GSN_edge_sparse/zinc/general/local/source_to_target/bn1/train0",
+                 "GSN_edge_sparse/zinc/gin/local/source_to_target/bn1/train0",
+                 "GSN_sparse/zinc/gin/global/source_to_target/bn1/train0",
+                 "GSN_edge_sparse_ogb/zinc/local/train0", "MPNN_sparse/zinc/general/source_to_target/train0"]:
+        c = layer_case(name)
+        layer = getattr(layers, c["cls"])(**c["ctor"])
+        keys = {k[3:] for k in c if k.startswith("sd/")}
+        assert set(layer.state_dict().keys()) == keys, name
+        layer.load_state_dict({k: torch.from_numpy(c["sd/" + k]) for k in keys})

@@ -1,0 +1,184 @@
+"""HP-1 parity on a real MI355X: the HIP counting kernel (through the C ABI) against the golden vectors of the
+reference and against the oracle on larger seeded inputs.  Integer work: bit-exact."""
+import numpy as np
+import pytest
+import torch
+import networkx as nx
+
+from helpers import load, case_names, count_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _global_ei(c):
+    npt, ept, ei = c["node_ptr"], c["edge_ptr"], c["edge_index_local"].copy()
+    for g in range(len(npt) - 1):
+        ei[:, ept[g]:ept[g + 1]] += npt[g]
+    return ei
+
+
+@pytest.mark.parametrize("name", case_names("counts"))
+def test_golden_counts(name):
+    from gsn_amd.counting import CountPlan, count_batch
+    c = count_case(name)
+    plan = CountPlan.get(c["patterns"], c["mode"], c["induced"], c["directed_orbits"])
+    out, st = count_batch(plan, c["node_ptr"], c["edge_ptr"], _global_ei(c), ids_are_global=True)
+    assert out.dtype == torch.int64 and out.is_cuda
+    assert (st.cpu().numpy() == 0).all()
+    assert np.array_equal(out.cpu().numpy(), c["counts"])
+    # graph-local ids, one graph at a time through the reference's per-graph signature
+    out2, _ = count_batch(plan, c["node_ptr"], c["edge_ptr"], c["edge_index_local"], ids_are_global=False)
+    assert torch.equal(out, out2)
+
+
+def _cycles(ks):
+    return [list(nx.cycle_graph(k).edges) for k in ks]
+
+
+@pytest.mark.parametrize("mode,ks,induced", [("edge", range(3, 7), False), ("edge", range(3, 7), True),
+                                             ("vertex", range(3, 9), False), ("vertex", range(3, 7), True)])
+def test_zinc_batch_vs_oracle(mode, ks, induced):
+    from gsn_amd import synth
+    from gsn_amd.counting import counts2ids_batch
+    from oracle import oracle
+    b = synth.zinc_shape_batch(3000, seed=7)
+    pats = _cycles(ks)
+    got = counts2ids_batch(b, pats, mode, induced).cpu().numpy()
+    local = b.edge_index - np.repeat(b.node_ptr[:-1], np.diff(b.edge_ptr))[None, :]
+    ref = oracle.counts2ids(mode, induced, b.node_ptr, b.edge_ptr, local, pats, n_threads=8)
+    assert np.array_equal(got, ref)
+    assert got.sum() > 0
+
+
+@pytest.mark.parametrize("mode", ["vertex", "edge"])
+@pytest.mark.parametrize("induced", [False, True])
+def test_er128_all_simple5_vs_oracle(mode, induced):
+    """BASELINE config 5 shape: G(128, 1000), the 21 connected 5-vertex patterns (58 vertex / 56 edge orbit columns)."""
+    from gsn_amd import synth
+    from gsn_amd.counting import counts2ids_batch
+    from oracle import oracle
+    z = load("orbits")
+    pats = [z["all_simple_graphs_5/%d/edges" % i].tolist() for i in range(21)]
+    graphs = [synth.er_graph(128, 1000, s) for s in (0, 1)] + [synth.er_graph(100, 420, 2), synth.er_graph(128, 600, 3)]
+    b = synth.collate(graphs)
+    got = counts2ids_batch(b, pats, mode, induced).cpu().numpy()
+    assert got.shape[1] == (58 if mode == "vertex" else 56)
+    local = b.edge_index - np.repeat(b.node_ptr[:-1], np.diff(b.edge_ptr))[None, :]
+    ref = oracle.counts2ids(mode, induced, b.node_ptr, b.edge_ptr, local, pats, n_threads=8)
+    assert np.array_equal(got, ref)
+
+
+def test_dense_cliques_vs_oracle():
+    """IMDB-like: near-cliques with a hub, K3..K5, W=4 path (n up to 200)."""
+    from gsn_amd import synth
+    from gsn_amd.counting import counts2ids_batch
+    from oracle import oracle
+    rng = np.random.default_rng(3)
+    graphs = []
+    for n, p in ((40, 0.6), (136, 0.14), (200, 0.05), (64, 0.3), (65, 0.3)):
+        a = np.triu(rng.random((n, n)) < p, 1)
+        a[0, 1:] = True  # hub
+        und = np.argwhere(a)
+        graphs.append((n, synth.undirected_to_edge_index(n, und)))
+    b = synth.collate(graphs)
+    pats = [list(nx.complete_graph(k).edges) for k in (3, 4, 5)]
+    for mode in ("vertex", "edge"):
+        got = counts2ids_batch(b, pats, mode, False).cpu().numpy()
+        local = b.edge_index - np.repeat(b.node_ptr[:-1], np.diff(b.edge_ptr))[None, :]
+        ref = oracle.counts2ids(mode, False, b.node_ptr, b.edge_ptr, local, pats, n_threads=8)
+        assert np.array_equal(got, ref)
+
+
+def test_vertex_edge_consistency_at_full_size():
+    """Size-independent property at the ZINC-12k size of BASELINE config 2: for the cycle C_k,
+    sum_v counts_v = k * #cycles and sum_e counts_e = 2k * #cycles, so both modes must agree; and the run is deterministic."""
+    from gsn_amd import synth
+    from gsn_amd.counting import counts2ids_batch
+    b = synth.zinc_shape_batch(12000, seed=0)
+    ks = list(range(3, 7))
+    v = counts2ids_batch(b, _cycles(ks), "vertex", False)
+    e = counts2ids_batch(b, _cycles(ks), "edge", False)
+    e2 = counts2ids_batch(b, _cycles(ks), "edge", False)
+    assert torch.equal(e, e2)
+    for i, k in enumerate(ks):
+        sv, se = int(v[:, i].sum()), int(e[:, i].sum())
+        assert sv % k == 0 and se == 2 * sv
+    assert int(v[:, 3].sum()) > 0  # six-rings exist
+    # rows (u,v) and (v,u) carry the same counts (undirected orbits)
+    ei = torch.from_numpy(b.edge_index).cuda()
+    key = ei[0] * b.num_nodes + ei[1]
+    rkey = ei[1] * b.num_nodes + ei[0]
+    order, rorder = torch.argsort(key), torch.argsort(rkey)
+    assert torch.equal(e[order], e[rorder])
+
+
+def test_reference_signatures_and_counts2ids():
+    from gsn_amd import patterns, counting
+    z = load("counts2ids")
+    ptr, flat = z["pattern_ptr"], z["pattern_edges"]
+    pats = [flat[ptr[i]:ptr[i + 1]].tolist() for i in range(len(ptr) - 1)]
+    for mode in ("vertex", "edge"):
+        fn_orb = patterns.automorphism_orbits if mode == "vertex" else patterns.induced_edge_automorphism_orbits
+        dicts = []
+        for el in pats:
+            sg, part, memb, aut = fn_orb(edge_list=el, directed=False, directed_orbits=False)
+            dicts.append({"subgraph": sg, "orbit_partition": part, "orbit_membership": memb, "aut_count": aut})
+        cfn = counting.subgraph_isomorphism_vertex_counts if mode == "vertex" else counting.subgraph_isomorphism_edge_counts
+
+        class Data:
+            pass
+        data = Data()
+        ei = torch.from_numpy(z[mode + "/in_edge_index"])
+        n = int(z[mode + "/in_num_nodes"])
+        data.x = torch.ones(n, 1)
+        data.edge_index = ei
+        data.edge_features = torch.arange(ei.shape[1]) + 100
+        res = counting.subgraph_counts2ids(cfn, data, dicts, {"induced": False, "directed": False})
+        assert res is data
+        assert torch.equal(res.edge_index, torch.from_numpy(z[mode + "/out_edge_index"]))
+        assert torch.equal(res.edge_features, torch.from_numpy(z[mode + "/out_edge_features"]))
+        assert res.identifiers.dtype == torch.int64 and not res.identifiers.is_cuda
+        assert np.array_equal(res.identifiers.numpy(), z[mode + "/identifiers"])
+        # per-pattern, per-graph call: CPU float64 like the reference (self loops passed straight in)
+        c0 = cfn(ei, subgraph_dict=dicts[0], induced=False, num_nodes=n, directed=False)
+        assert c0.dtype == torch.float64 and not c0.is_cuda
+        ids_with_loops = np.zeros((ei.shape[1], 1)) if mode == "edge" else None
+        if mode == "vertex":
+            assert np.array_equal(c0.numpy()[:, 0], z[mode + "/identifiers"][:, 0])
+        else:
+            keep = (ei[0] != ei[1]).numpy()
+            assert np.array_equal(c0.numpy()[keep, 0], z[mode + "/identifiers"][:, 0])
+            assert (c0.numpy()[~keep] == 0).all()
+
+
+def test_errors():
+    from gsn_amd.counting import CountPlan, count_batch
+    tri = [[(0, 1), (1, 2), (2, 0)]]
+    plan = CountPlan.get(tri, "edge", False)
+    ei = np.array([[0, 1, 1, 2, 2], [1, 0, 2, 1, 0]], dtype=np.int64)  # (0,2) missing but used by the triangle
+    with pytest.raises(KeyError):
+        count_batch(plan, [0, 3], [0, 5], ei, ids_are_global=False)
+    # same graph, pattern that never touches the missing direction -> fine
+    plan2 = CountPlan.get([[(0, 1), (1, 2), (2, 3), (3, 0)]], "edge", False)
+    out, st = count_batch(plan2, [0, 3], [0, 5], ei, ids_are_global=False)
+    assert int(out.sum()) == 0 and int(st[0]) == 0
+    # under-declared sizes are reported, not silently wrong
+    big = np.stack([np.arange(10), (np.arange(10) + 1) % 10]).astype(np.int64)
+    big = np.concatenate([big, big[::-1]], axis=1)
+    with pytest.raises(ValueError):
+        count_batch(CountPlan.get(tri, "vertex", False), [0, 10], [0, 20], big, ids_are_global=False, max_nodes=4, max_edges=20)
+    with pytest.raises(ValueError):   # id out of range
+        count_batch(CountPlan.get(tri, "vertex", False), [0, 5], [0, 20], big, ids_are_global=False)
+    # graph subset
+    from gsn_amd import synth
+    b = synth.zinc_shape_batch(10, seed=1)
+    planv = CountPlan.get(tri + [[(0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (5, 0)]], "vertex", False)
+    full, _ = count_batch(planv, b.node_ptr, b.edge_ptr, b.edge_index)
+    part = torch.full_like(full, -7)
+    count_batch(planv, b.node_ptr, b.edge_ptr, b.edge_index, graph_ids=[2, 5], out=part)
+    for g in range(10):
+        rows = slice(int(b.node_ptr[g]), int(b.node_ptr[g + 1]))
+        if g in (2, 5):
+            assert torch.equal(part[rows], full[rows])
+        else:
+            assert (part[rows] == -7).all()

@@ -1,0 +1,193 @@
+"""HP-2 parity on a real MI355X: HIP kernels (through the C ABI) against the golden vectors produced by the reference
+layers and against plain PyTorch fp32.  Tolerance: 1e-5 relative to the output's max magnitude (BASELINE north_star)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import case_names, layer_case
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def rel_err(a, b):
+    return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
+
+
+def test_csr_and_propagate_vs_torch():
+    from gsn_amd.layers import build_csr, propagate
+    torch.manual_seed(0)
+    dev = "cuda"
+    for N, E in ((1, 0), (7, 3), (300, 2000), (5000, 40000), (70000, 150000)):
+        ei = torch.randint(0, N, (2, E), device=dev)
+        seg, perm = build_csr(ei[1], N)
+        deg = torch.bincount(ei[1], minlength=N)
+        assert torch.equal(seg[1:] - seg[:-1], deg.int())
+        if E:
+            assert torch.equal(ei[1][perm.long()], torch.sort(ei[1], stable=True)[0])
+            assert torch.equal(perm.long(), torch.sort(ei[1], stable=True)[1])   # stable: original order inside a segment
+        for (da, db, dc, per_node) in ((28, 12, 4, False), (7, 5, 3, True), (0, 128, 0, False), (13, 0, 4, False), (300, 0, 0, False)):
+            a = torch.randn(N, da, device=dev) if da else None
+            b = (torch.randn(N if per_node else E, db, device=dev) if db else None)
+            c = torch.randn(E, dc, device=dev) if dc else None
+            out = propagate(0, ei, 1, N, a=a, b=b, c=c, b_per_node=per_node)
+            parts = []
+            if da: parts.append(a[ei[0]])
+            if db: parts.append(b[ei[0]] if per_node else b)
+            if dc: parts.append(c)
+            ref = torch.zeros(N, da + db + dc, device=dev).index_add_(0, ei[1], torch.cat(parts, 1)) if E else torch.zeros(N, da + db + dc, device=dev)
+            assert rel_err(out, ref) < TOL if E else (out == 0).all()
+        for d, per_node in ((8, False), (300, True), (33, False)):
+            a = torch.randn(N, d, device=dev); b = torch.randn(N if per_node else E, d, device=dev); c = torch.randn(E, d, device=dev)
+            out = propagate(1, ei, 0, N, a=a, b=b, c=c, b_per_node=per_node)   # target_to_source: aggregate at row 0, gather at row 1
+            msg = torch.relu(a[ei[1]] + (b[ei[1]] if per_node else b) + c)
+            ref = torch.zeros(N, d, device=dev).index_add_(0, ei[0], msg)
+            if E:
+                assert rel_err(out, ref) < TOL
+
+
+def test_propagate_backward_vs_autograd():
+    from gsn_amd.layers import propagate
+    torch.manual_seed(1)
+    dev = "cuda"
+    N, E = 500, 3000
+    ei = torch.randint(0, N, (2, E), device=dev)
+    for kind, (da, db, dc), per_node in ((0, (6, 5, 3), False), (0, (6, 5, 0), True), (1, (9, 9, 9), False), (1, (9, 9, 9), True), (0, (0, 16, 0), False)):
+        a = torch.randn(N, da, device=dev, requires_grad=True) if da else None
+        b = torch.randn(N if per_node else E, db, device=dev, requires_grad=True) if db else None
+        c = torch.randn(E, dc, device=dev, requires_grad=True) if dc else None
+        out = propagate(kind, ei, 1, N, a=a, b=b, c=c, b_per_node=per_node)
+        w = torch.randn_like(out)
+        (out * w).sum().backward()
+        got = [t.grad.clone() if t is not None else None for t in (a, b, c)]
+        for t in (a, b, c):
+            if t is not None: t.grad = None
+        parts = [a[ei[0]] if a is not None else None, (b[ei[0]] if per_node else b) if b is not None else None, c]
+        parts = [p for p in parts if p is not None]
+        msg = torch.cat(parts, 1) if kind == 0 else torch.relu(sum(parts))
+        ref = torch.zeros(N, msg.shape[1], device=dev).index_add(0, ei[1], msg)
+        (ref * w).sum().backward()
+        for g, t in zip(got, (a, b, c)):
+            if t is not None:
+                assert rel_err(g, t.grad) < TOL
+
+
+def test_linear_kernel_vs_torch():
+    """Asymmetric data (transposes would show), ragged sizes, gathered + concatenated inputs, every epilogue."""
+    from gsn_amd.layers import _linear_hip
+    torch.manual_seed(2)
+    dev = "cuda"
+    for M, widths, n_out in ((1, [3], 5), (130, [28, 28, 12, 4], 128), (1000, [13, 1], 70), (257, [64, 33, 7, 2, 40], 300), (4096, [156], 128)):
+        R = 50
+        blocks, cols = [], []
+        for i, w in enumerate(widths):
+            if i % 2 == 0 and M > 1:
+                data = torch.randn(R, w, device=dev) * (1 + i)
+                idx = torch.randint(0, R, (M,), device=dev)
+                blocks.append((data, idx)); cols.append(data[idx])
+            else:
+                data = torch.randn(M, w, device=dev) + 0.5
+                blocks.append((data, None)); cols.append(data)
+        X = torch.cat(cols, 1).double()
+        K = X.shape[1]
+        W = torch.randn(n_out, K, device=dev) / K ** 0.5
+        bias = torch.randn(n_out, device=dev)
+        h = X @ W.double().T + bias.double()
+        y = _linear_hip(blocks, W, bias, None, None, None, 0, M)
+        assert rel_err(y.double(), h) < TOL
+        mean = torch.randn(n_out, device=dev); scale = torch.rand(n_out, device=dev) + 0.5; shift = torch.randn(n_out, device=dev)
+        z = (h - mean.double()) * scale.double() + shift.double()
+        for act, fn in ((1, torch.relu), (2, torch.nn.functional.elu), (3, torch.tanh), (0, lambda t: t)):
+            y = _linear_hip(blocks, W, bias, mean, scale, shift, act, M)
+            assert rel_err(y.double(), fn(z)) < TOL
+        stats = torch.zeros(2, n_out, dtype=torch.float64, device=dev)
+        _linear_hip(blocks, W, bias, None, None, None, 0, M, out=False, stats=stats)
+        assert torch.allclose(stats[0], h.sum(0), rtol=1e-6, atol=1e-4)
+        assert torch.allclose(stats[1], (h * h).sum(0), rtol=1e-6, atol=1e-4)
+
+
+def _build(c):
+    from gsn_amd import layers
+    layer = getattr(layers, c["cls"])(**c["ctor"])
+    layer.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in c.items() if k.startswith("sd/")})
+    return layer.cuda().train(c["train"])
+
+
+def _inputs(c, grad=False):
+    t = lambda k: torch.from_numpy(c[k]).cuda() if k in c else None
+    x, ids, ef = t("x"), t("identifiers"), t("edge_features")
+    if grad:
+        for v in (x, ids, ef):
+            if v is not None:
+                v.requires_grad_(True)
+    kw = {"degrees": t("degrees")}
+    if ids is not None or c["cls"] == "MPNN_edge_sparse_ogb":
+        kw["identifiers"] = ids
+    if ef is not None:
+        kw["edge_features"] = ef
+    return x, t("edge_index"), kw, ids, ef
+
+
+@pytest.mark.parametrize("name", case_names("layers"))
+def test_layer_forward_golden(name):
+    c = layer_case(name)
+    layer = _build(c)
+    x, ei, kw, _, _ = _inputs(c)
+    with torch.no_grad():
+        y = layer(x, ei, **kw)
+    ref = torch.from_numpy(c["y"]).cuda()
+    assert y.shape == ref.shape and y.is_cuda
+    assert rel_err(y, ref) < TOL, rel_err(y, ref)
+    if c["train"]:
+        sd = layer.state_dict()
+        for k in c:
+            if k.startswith("sd_after/") and "num_batches" not in k:
+                assert torch.allclose(sd[k[9:]].cpu(), torch.from_numpy(c[k]), rtol=1e-4, atol=1e-6), k
+            elif k.startswith("sd_after/"):
+                assert int(sd[k[9:]]) == int(c[k])
+
+
+@pytest.mark.parametrize("name", [n for n in case_names("layers") if "/zinc/" in n or "real_widths" in n or "degree_as_tag" in n])
+def test_layer_backward_golden(name):
+    c = layer_case(name)
+    layer = _build(c)
+    x, ei, kw, ids, ef = _inputs(c, grad=True)
+    y = layer(x, ei, **kw)
+    assert rel_err(y.detach(), torch.from_numpy(c["y"]).cuda()) < TOL
+    (y * torch.from_numpy(c["w"]).cuda()).sum().backward()
+    BT = 5e-5  # gradients go through train-mode BN statistics twice; a little looser than the forward bar
+    assert rel_err(x.grad, torch.from_numpy(c["g_x"]).cuda().reshape(x.shape)) < BT
+    if ids is not None:
+        assert rel_err(ids.grad, torch.from_numpy(c["g_identifiers"]).cuda()) < BT
+    if ef is not None:
+        assert rel_err(ef.grad, torch.from_numpy(c["g_edge_features"]).cuda()) < BT
+    for k, p in layer.named_parameters():
+        if "gp/" + k in c:
+            assert p.grad is not None, k
+            assert rel_err(p.grad, torch.from_numpy(c["gp/" + k]).cuda()) < BT, k
+
+
+def test_layer_vs_oracle_big_batch():
+    """A 4096-graph ZINC-shaped batch at the real layer-0 widths (BASELINE config 2) against the oracle's fp32 torch restatement."""
+    from gsn_amd import layers, synth
+    from oracle import oracle
+    torch.manual_seed(5)
+    b = synth.zinc_shape_batch(4096, seed=11)
+    N, E = b.num_nodes, b.num_edges
+    ctor = dict(d_in=28, d_ef=4, d_id=12, d_degree=1, degree_as_tag=False, retain_features=True, id_scope="local", d_msg=128,
+                d_up=128, d_h=[128], seed=0, activation_name="relu", bn=True, msg_kind="general", flow="source_to_target")
+    layer = layers.GSN_edge_sparse(**ctor)
+    for m in layer.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.uniform_(-0.3, 0.3); m.running_var.uniform_(0.5, 1.5); m.weight.data.uniform_(0.5, 1.5); m.bias.data.uniform_(-0.3, 0.3)
+    layer.eval()
+    x = torch.nn.functional.one_hot(torch.from_numpy(b.atom_type), 28).float()
+    ef = torch.nn.functional.one_hot(torch.from_numpy(b.bond_type), 4).float()
+    ids = (torch.rand(E, 12) < 0.2).float()
+    ei = torch.from_numpy(b.edge_index)
+    sd = {k: v.clone() for k, v in layer.state_dict().items()}
+    ref = oracle.layer_forward("GSN_edge_sparse", ctor, sd, x, ei, identifiers=ids, degrees=None, edge_features=ef, training=False)
+    layer.cuda()
+    with torch.no_grad():
+        y = layer(x.cuda(), ei.cuda(), identifiers=ids.cuda(), degrees=torch.zeros(N, device="cuda"), edge_features=ef.cuda())
+    assert rel_err(y.cpu(), ref) < TOL
