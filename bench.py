@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path named by BASELINE.json: orbit counting + GSN-e forward on ZINC-shaped batches.
+
+One "step" = one pass over one batch of G synthetic ZINC-shaped graphs resident in HBM:
+    (1) gsn_count_hip           cycle_graph k = 3..6, id_scope=local (GSN-e), non-induced  -> int64 [E, 4]
+    (2) identifier encoding      per-column one-hot of min(count, 2)  -> float [E, 12]   (PyTorch glue, in the timed region;
+                                 the reference does this in DiscreteEmbedding('one_hot_encoder'), utils_graph_learning.py:78)
+    (3) GSN_edge_sparse forward  layer 0 of BASELINE config 2: msg_kind=general, d_in=28, d_ef=4, d_id=12, d_h=d_msg=d_up=128,
+                                 bn=True, eval mode; includes building the target-sorted CSR (cache cleared every step)
+Prints ONE JSON line (rank 0).  Multi-GPU: one process per GPU (torch.distributed / RCCL only for the barrier and the
+max-over-ranks timing); graphs are sharded across ranks, the data path has no collective ("weak" scaling: G per GPU fixed).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--graphs G]
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TF = 157.3    # MI355X_MICROARCH.md: fp32 MFMA (v_mfma_f32_32x32x2_f32) dense peak
+
+
+def make_batch(n_graphs, seed):
+    """n_graphs ZINC-shaped graphs: `unique` distinct seeded graphs tiled to size (generation is Python-side and not timed)."""
+    from gsn_amd import synth
+    unique = min(n_graphs, 4096)
+    base = synth.zinc_shape_batch(unique, seed=seed)
+    reps = (n_graphs + unique - 1) // unique
+    if reps == 1:
+        return base
+    node_ptr = [base.node_ptr]
+    edge_ptr = [base.edge_ptr]
+    eis, at, bt = [base.edge_index], [base.atom_type], [base.bond_type]
+    for r in range(1, reps):
+        node_ptr.append(base.node_ptr[1:] + r * base.num_nodes)
+        edge_ptr.append(base.edge_ptr[1:] + r * base.num_edges)
+        eis.append(base.edge_index + r * base.num_nodes)
+        at.append(base.atom_type)
+        bt.append(base.bond_type)
+    b = synth.Batch(np.concatenate(node_ptr)[:n_graphs + 1], np.concatenate(edge_ptr)[:n_graphs + 1], np.concatenate(eis, axis=1))
+    E, N = int(b.edge_ptr[-1]), int(b.node_ptr[-1])
+    b.edge_index = np.ascontiguousarray(b.edge_index[:, :E])
+    b.num_edges, b.num_nodes = E, N
+    b.atom_type = np.concatenate(at)[:N]
+    b.bond_type = np.concatenate(bt)[:E]
+    return b
+
+
+CTOR = dict(d_in=28, d_ef=4, d_id=12, d_degree=1, degree_as_tag=False, retain_features=True, id_scope="local", d_msg=128,
+            d_up=128, d_h=[128], seed=0, activation_name="relu", bn=True, msg_kind="general", flow="source_to_target")
+
+
+def cpu_baseline(n_graphs, seed):
+    """The oracle (CPU port of the reference path) timed on this box's host cores on a bounded sample of the same workload."""
+    import torch
+    import networkx as nx
+    from gsn_amd import synth
+    from oracle import oracle
+    cores = os.cpu_count() or 1
+    b = synth.zinc_shape_batch(n_graphs, seed=seed)
+    pats = [list(nx.cycle_graph(k).edges) for k in range(3, 7)]
+    local = b.edge_index - np.repeat(b.node_ptr[:-1], np.diff(b.edge_ptr))[None, :]
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    from gsn_amd import layers
+    layer = layers.GSN_edge_sparse(**CTOR).eval()
+    sd = {k: v.clone() for k, v in layer.state_dict().items()}
+    x = torch.nn.functional.one_hot(torch.from_numpy(b.atom_type), 28).float()
+    ef = torch.nn.functional.one_hot(torch.from_numpy(b.bond_type), 4).float()
+    ei = torch.from_numpy(b.edge_index)
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        ids = oracle.counts2ids("edge", False, b.node_ptr, b.edge_ptr, local, pats, n_threads=cores)
+        idt = torch.from_numpy(ids).clamp(max=2)
+        idf = torch.nn.functional.one_hot(idt, 3).reshape(idt.shape[0], 12).float()
+        with torch.no_grad():
+            oracle.layer_forward("GSN_edge_sparse", CTOR, sd, x, ei, identifiers=idf, degrees=None, edge_features=ef)
+        reps += 1
+        dt = time.perf_counter() - t0
+        if dt > 12.0:
+            break
+    return {"value": round(reps * n_graphs / dt, 1), "unit": "graphs/s", "cores": cores, "kind": "port",
+            "sample": "%d passes over %d ZINC-shaped graphs: oracle/count_oracle.c (OpenMP over graphs) + plain PyTorch fp32 "
+                      "layer forward, %d threads, %.1f s" % (reps, n_graphs, cores, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--graphs", type=int, default=65536, help="graphs per step per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import networkx as nx
+    from gsn_amd import layers
+    from gsn_amd.counting import CountPlan, count_batch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the hot path is HIP-only; there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if args.gpus != world:
+        if rank == 0:
+            print("note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+
+    G = args.graphs
+    b = make_batch(G, seed=1000 + rank)       # every rank owns a different shard of graphs
+    N, E = b.num_nodes, b.num_edges
+    max_nodes = int(np.diff(b.node_ptr).max())
+    max_edges = int(np.diff(b.edge_ptr).max())
+    node_ptr = torch.from_numpy(b.node_ptr).to(dev)
+    edge_ptr = torch.from_numpy(b.edge_ptr).to(dev)
+    ei = torch.from_numpy(b.edge_index).to(dev)
+    x = torch.nn.functional.one_hot(torch.from_numpy(b.atom_type), 28).float().to(dev)
+    ef = torch.nn.functional.one_hot(torch.from_numpy(b.bond_type), 4).float().to(dev)
+    degrees = torch.zeros(N, device=dev)
+    plan = CountPlan.get([list(nx.cycle_graph(k).edges) for k in range(3, 7)], "edge", False)
+    plan.device_table(dev)
+    ids_out = torch.empty((E, plan.n_cols), dtype=torch.int64, device=dev)
+    torch.manual_seed(0)
+    layer = layers.GSN_edge_sparse(**CTOR).to(dev).eval()
+
+    def step():
+        layers._CSR_CACHE.clear()             # the CSR of a fresh batch is part of the forward pass
+        with layers._timed("count", 16.0 * E + 8.0 * E * plan.n_cols):
+            count_batch(plan, node_ptr, edge_ptr, ei, ids_are_global=True, max_nodes=max_nodes, max_edges=max_edges,
+                        device=dev, out=ids_out, check=False)
+        with layers._timed("encode_ids"):
+            idf = torch.nn.functional.one_hot(ids_out.clamp(max=2), 3).reshape(E, 12).float()
+        with torch.no_grad():
+            return layer(x, ei, identifiers=idf, degrees=degrees, edge_features=ef)
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    layers.KERNEL_TIMER = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        y = step()
+    sync()
+    dt = time.perf_counter() - t0
+    timer, layers.KERNEL_TIMER = layers.KERNEL_TIMER, None
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(y).all()
+
+    if rank == 0:
+        kernels = {}
+        for name, evs in timer.items():
+            ms = [e0.elapsed_time(e1) for e0, e1, _ in evs]
+            work = sum(w for _, _, w in evs)
+            kernels[name] = {"launches_per_step": len(evs) / args.steps, "ms_per_step": sum(ms) / args.steps, "work_per_step": work / args.steps}
+        dom = max(("linear_fwd", "propagate_fwd", "count"), key=lambda k: kernels[k]["ms_per_step"])
+        kd = kernels[dom]
+        if dom == "linear_fwd":
+            ach = kd["work_per_step"] / (kd["ms_per_step"] * 1e-3) / 1e12
+            roof = {"kernel": "linear_fwd_kernel", "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TF,
+                    "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TF, 4), "traffic": None}
+        else:
+            ach = kd["work_per_step"] / (kd["ms_per_step"] * 1e-3) / 1e9
+            roof = {"kernel": {"propagate_fwd": "propagate_fwd_kernel", "count": "count_kernel"}[dom], "bound": "hbm",
+                    "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
+        roof["launches_per_step"] = kd["launches_per_step"]
+        roof["avg_launch_ms"] = round(kd["ms_per_step"] / kd["launches_per_step"], 4)
+        pk = kernels["propagate_fwd"]
+        ck = kernels["count"]
+        extra = {
+            "propagate_hbm_GBs": round(pk["work_per_step"] / (pk["ms_per_step"] * 1e-3) / 1e9, 1),
+            "propagate_hbm_frac": round(pk["work_per_step"] / (pk["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "count_graphs_per_s": round(G / (ck["ms_per_step"] * 1e-3), 1),
+            "count_hbm_GBs": round(ck["work_per_step"] / (ck["ms_per_step"] * 1e-3) / 1e9, 1),
+            "ms_per_step_by_kernel": {k: round(v["ms_per_step"], 4) for k, v in kernels.items()},
+        }
+        res = {
+            "metric": "graphs/sec (orbit-count + GSN-e fwd), ZINC-shape batch; % HBM roofline",
+            "value": round(world * G * args.steps / dt, 1), "unit": "graphs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int64 counts + f32 message passing", "data": "synthetic",
+            "config": {"workload": "ZINC-shape x%d graphs/GPU (N=%d, E=%d): cycle_graph k<=6 GSN-e (id_scope=local) orbit count "
+                                   "+ GSN_edge_sparse layer-0 forward (general, d_in=28, d_ef=4, d_id=12, d=128, bn, eval)" % (G, N, E),
+                       "graphs_per_step_per_gpu": G, "parallelism": "graph-shard x%d, no data-path collective" % world},
+            "roofline": roof, "kernels": extra,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(2048, seed=1000)
+        print(json.dumps(res))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -98,9 +98,9 @@ def count_batch(plan: CountPlan, node_ptr, edge_ptr, edge_index, ids_are_global=
         raise ValueError("edge_index must be [2, E]")
     n_graphs = node_ptr_d.numel() - 1
     E_total = ei.shape[1]
-    # rows follow the pointers the kernel uses, not the tensor length
-    rows_total = int((edge_ptr_d if plan.mode == "edge" else node_ptr_d)[-1].item()) if n_graphs > 0 else 0
     if out is None:
+        # rows follow the pointers the kernel uses, not the tensor length (one host read; pass `out` to avoid it)
+        rows_total = int((edge_ptr_d if plan.mode == "edge" else node_ptr_d)[-1].item()) if n_graphs > 0 else 0
         out = torch.empty((rows_total, plan.n_cols), dtype=torch.int64, device=device)
     status = torch.zeros(max(n_graphs, 1), dtype=torch.int32, device=device)
     gid = None

@@ -341,22 +341,24 @@ extern "C" int gsn_propagate_fwd_hip(int kind, int64_t n_nodes, int64_t n_edges,
                                      int b_per_node, const float *c, int64_t dc, float *out, void *stream) {
     if (kind != GSN_MSG_CAT && kind != GSN_MSG_RELU_SUM) return set_error(GSN_E_INVALID, "gsn_propagate_fwd_hip: unknown kind %d", kind);
     if (!seg_ptr || !out || (n_edges > 0 && !src)) return set_error(GSN_E_INVALID, "gsn_propagate_fwd_hip: null pointer");
-    if (!a) da = 0;
-    if (!b) db = 0;
-    if (!c) dc = 0;
+    // widths are authoritative; a null pointer is only legal for a block that is never dereferenced
+    if ((da > 0 && !a && n_edges > 0) || (db > 0 && !b && n_edges > 0) || (dc > 0 && !c && n_edges > 0))
+        return set_error(GSN_E_INVALID, "gsn_propagate_fwd_hip: a block has width > 0 but no data");
+    if (da < 0 || db < 0 || dc < 0) return set_error(GSN_E_INVALID, "gsn_propagate_fwd_hip: negative width");
     int64_t d_out;
     if (kind == GSN_MSG_CAT) d_out = da + db + dc;
     else {
         d_out = da > db ? da : db;
         d_out = d_out > dc ? d_out : dc;
-        if ((a && da != d_out) || (b && db != d_out) || (c && dc != d_out))
+        if ((da && da != d_out) || (db && db != d_out) || (dc && dc != d_out))
             return set_error(GSN_E_INVALID, "gsn_propagate_fwd_hip: relu-sum blocks must share one width");
     }
     if (d_out <= 0 || n_nodes <= 0) return GSN_OK;
     if (d_out > 1024) return set_error(GSN_E_UNSUPPORTED, "gsn_propagate_fwd_hip: message width %lld > 1024", (long long)d_out);
     PropArgs p{};
     p.kind = kind; p.n_nodes = n_nodes; p.n_edges = n_edges; p.src = src; p.seg_ptr = seg_ptr; p.perm = perm;
-    p.a = a; p.b = b; p.c = c; p.da = (int)da; p.db = (int)db; p.dc = (int)dc; p.d_out = (int)d_out;
+    p.a = da ? a : nullptr; p.b = db ? b : nullptr; p.c = dc ? c : nullptr;
+    p.da = (int)da; p.db = (int)db; p.dc = (int)dc; p.d_out = (int)d_out;
     p.b_per_node = b_per_node; p.out = out;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const bool aligned = ((da | db | dc) % 4 == 0) && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)out) % 16 == 0);

@@ -32,6 +32,28 @@ __all__ = ["mlp", "central_encoder", "GSN_sparse", "GSN_edge_sparse", "MPNN_spar
 _ACT_CODE = {"identity": 0, "relu": 1, "elu": 2, "tanh": 3}
 _MAX_BLOCKS = 5
 
+# Optional per-kernel timing hook for bench.py: a dict name -> list of (start_event, end_event, work) recorded on the
+# launch stream around every kernel family; None = off (no events, no overhead).
+KERNEL_TIMER = None
+
+
+class _timed:
+    def __init__(self, name, work=0.0):
+        self.name, self.work = name, work
+
+    def __enter__(self):
+        if KERNEL_TIMER is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if KERNEL_TIMER is not None:
+            self.e1.record()
+            KERNEL_TIMER.setdefault(self.name, []).append((self.e0, self.e1, self.work))
+        return False
+
 
 def choose_activation(activation):
     """models_misc.py:5-15"""
@@ -75,7 +97,7 @@ def build_csr(index, n_nodes):
     seg_ptr = torch.empty(n_nodes + 1, dtype=torch.int32, device=dev)
     perm = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
     scratch = torch.empty(int(L.gsn_csr_scratch_elems(n_nodes)), dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with torch.cuda.device(dev), _timed("csr_build", 12.0 * E + 8.0 * n_nodes):
         _abi.check(L.gsn_csr_build_hip(n_nodes, E, index.data_ptr() if E else None, seg_ptr.data_ptr(), perm.data_ptr(),
                                        scratch.data_ptr(), _abi.current_stream()), "gsn_csr_build_hip")
     return seg_ptr, perm[:E]
@@ -108,7 +130,10 @@ class _PropagateFn(torch.autograd.Function):
         widths = [0 if t is None else t.shape[1] for t in ts]
         d_out = sum(widths) if kind == 0 else max(widths)
         out = torch.empty((n_nodes, d_out), dtype=torch.float32, device=edge_index.device)
-        with torch.cuda.device(edge_index.device):
+        # algorithmic bytes: src (8) + perm (4) per edge, every message element read once, output written once
+        per_edge = (0 if ts[0] is None else widths[0]) + (0 if (ts[1] is None or b_per_node) else widths[1]) + (0 if ts[2] is None else widths[2])
+        bytes_alg = 12.0 * E + 4.0 * n_nodes + 4.0 * (E * per_edge + n_nodes * d_out)
+        with torch.cuda.device(edge_index.device), _timed("propagate_fwd", bytes_alg):
             rc = _abi.lib().gsn_propagate_fwd_hip(kind, n_nodes, E, src.data_ptr() if E else None, csr_t.seg_ptr.data_ptr(),
                                                   csr_t.perm.data_ptr() if E else None, _abi.ptr(ts[0]), widths[0],
                                                   _abi.ptr(ts[1]), widths[1], int(b_per_node), _abi.ptr(ts[2]), widths[2],
@@ -178,7 +203,7 @@ def _linear_hip(blocks, weight, bias, bn_mean, bn_scale, bn_shift, act, m_rows, 
     y = torch.empty((m_rows, n_out), dtype=torch.float32, device=dev) if out else None
     w = _f32c(weight)
     vecs = [None if v is None else _f32c(v) for v in (bias, bn_mean, bn_scale, bn_shift)]
-    with torch.cuda.device(dev):
+    with torch.cuda.device(dev), _timed("linear_fwd", 2.0 * m_rows * w.shape[1] * n_out):
         rc = _abi.lib().gsn_linear_fwd_hip(m_rows, len(blocks), arr, w.data_ptr(), _abi.ptr(vecs[0]), n_out, _abi.ptr(vecs[1]),
                                            _abi.ptr(vecs[2]), _abi.ptr(vecs[3]), act, None, _abi.ptr(y), _abi.ptr(stats),
                                            _abi.current_stream())

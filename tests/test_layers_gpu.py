@@ -10,8 +10,8 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-5
 
 
-def rel_err(a, b):
-    return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
+def rel_err(a, b, floor=1e-30):
+    return (a - b).abs().max().item() / max(b.abs().max().item(), floor)
 
 
 def test_csr_and_propagate_vs_torch():
@@ -102,8 +102,9 @@ def test_linear_kernel_vs_torch():
             assert rel_err(y.double(), fn(z)) < TOL
         stats = torch.zeros(2, n_out, dtype=torch.float64, device=dev)
         _linear_hip(blocks, W, bias, None, None, None, 0, M, out=False, stats=stats)
-        assert torch.allclose(stats[0], h.sum(0), rtol=1e-6, atol=1e-4)
-        assert torch.allclose(stats[1], (h * h).sum(0), rtol=1e-6, atol=1e-4)
+        # the kernel sums fp32 h values (each carrying ~1e-7 relative rounding) in fp64
+        assert torch.allclose(stats[0], h.sum(0), rtol=1e-5, atol=1e-5 * M)
+        assert torch.allclose(stats[1], (h * h).sum(0), rtol=1e-5, atol=1e-5 * M)
 
 
 def _build(c):
@@ -156,15 +157,16 @@ def test_layer_backward_golden(name):
     assert rel_err(y.detach(), torch.from_numpy(c["y"]).cuda()) < TOL
     (y * torch.from_numpy(c["w"]).cuda()).sum().backward()
     BT = 5e-5  # gradients go through train-mode BN statistics twice; a little looser than the forward bar
-    assert rel_err(x.grad, torch.from_numpy(c["g_x"]).cuda().reshape(x.shape)) < BT
+    FL = 1e-2  # a bias in front of a train-mode BatchNorm has an exactly-zero gradient: both sides hold ~1e-6 noise there
+    assert rel_err(x.grad, torch.from_numpy(c["g_x"]).cuda().reshape(x.shape), FL) < BT
     if ids is not None:
-        assert rel_err(ids.grad, torch.from_numpy(c["g_identifiers"]).cuda()) < BT
+        assert rel_err(ids.grad, torch.from_numpy(c["g_identifiers"]).cuda(), FL) < BT
     if ef is not None:
-        assert rel_err(ef.grad, torch.from_numpy(c["g_edge_features"]).cuda()) < BT
+        assert rel_err(ef.grad, torch.from_numpy(c["g_edge_features"]).cuda(), FL) < BT
     for k, p in layer.named_parameters():
         if "gp/" + k in c:
             assert p.grad is not None, k
-            assert rel_err(p.grad, torch.from_numpy(c["gp/" + k]).cuda()) < BT, k
+            assert rel_err(p.grad, torch.from_numpy(c["gp/" + k]).cuda(), FL) < BT, k
 
 
 def test_layer_vs_oracle_big_batch():
