@@ -67,6 +67,9 @@ def lib():
             raise ImportError(
                 "gsn_amd: %s not found. Build the HIP extension first (python -c 'import __graft_entry__ as g; "
                 "g.build()' or make -C gsn_amd/csrc). There is no CPU fallback." % LIB_PATH)
+        # PyTorch-ROCm bundles its own HIP/HSA runtime; it must be the one already loaded when libgsn_hip.so is
+        # opened so that both share one runtime (two HSA runtimes in a process cannot both own the device).
+        import torch  # noqa: F401
         handle = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the build is stale: loud by design

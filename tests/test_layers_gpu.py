@@ -157,7 +157,9 @@ def test_layer_backward_golden(name):
     assert rel_err(y.detach(), torch.from_numpy(c["y"]).cuda()) < TOL
     (y * torch.from_numpy(c["w"]).cuda()).sum().backward()
     BT = 5e-5  # gradients go through train-mode BN statistics twice; a little looser than the forward bar
-    FL = 1e-2  # a bias in front of a train-mode BatchNorm has an exactly-zero gradient: both sides hold ~1e-6 noise there
+    # a bias in front of a train-mode BatchNorm has an exactly-zero gradient: both sides hold only rounding noise there,
+    # whose size follows the layer's overall gradient scale -> floor the denominator at 2% of the largest parameter gradient
+    FL = 0.02 * max([float(np.abs(c[k]).max()) for k in c if k.startswith("gp/")] + [0.5])
     assert rel_err(x.grad, torch.from_numpy(c["g_x"]).cuda().reshape(x.shape), FL) < BT
     if ids is not None:
         assert rel_err(ids.grad, torch.from_numpy(c["g_identifiers"]).cuda(), FL) < BT
