@@ -207,11 +207,11 @@ __device__ __forceinline__ void rowsrc_store(int *dst /*[MAX_BLOCKS][BM]*/, int 
     }
 }
 
-// global loads of slice c (columns c*32 .. c*32+31 of the concatenated row) for 16 rows of this thread
+// global loads of slice c (columns c*32 .. c*32+31 of the concatenated row) for 16 rows of this thread.
+// Loads are unconditional (row / column clamped into the block, result masked) so the 16 of them issue back to back.
 __device__ __forceinline__ void slice_fetch(const LinArgs &a, const int *rsrc, int c, int tid, float (&pre)[NPRE]) {
     const int kc = tid & 31, r0 = tid >> 5;
     const int kg = c * BK + kc;
-    // which block does column kg belong to?
     int blk = 0, col = kg;
 #pragma unroll
     for (int b = 0; b < MAX_BLOCKS - 1; ++b) {
@@ -223,16 +223,18 @@ __device__ __forceinline__ void slice_fetch(const LinArgs &a, const int *rsrc, i
 #pragma unroll
     for (int b = 1; b < MAX_BLOCKS; ++b)
         if (blk == b) { bd = a.bdata[b]; bw = a.bwidth[b]; }
-    const int *rs = rsrc + blk * BM;
+    col = kok ? col : 0;
+    const float *bcol = bd + col;
+    const int *rs = rsrc + blk * BM + r0;
 #pragma unroll
     for (int i = 0; i < NPRE; ++i) {
-        const int sr = rs[r0 + 8 * i];
-        float v = 0.f;
-        if (kok && sr >= 0) v = bd[(int64_t)sr * bw + col];
-        pre[i] = v;
+        const int sr = rs[8 * i];
+        const float v = bcol[(int64_t)(sr < 0 ? 0 : sr) * bw];
+        pre[i] = (kok && sr >= 0) ? v : 0.f;
     }
 }
 
+template <bool STATS>
 __global__ __launch_bounds__(256) void linear_fwd_kernel(LinArgs a, int k_pad) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *Wt = lds;                                   // [k_pad][WPITCH]
@@ -300,20 +302,34 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(LinArgs a, int k_pad) {
             const float *ap0 = Ab + (wm * 64 + li) * APITCH + lh;
             const float *ap1 = ap0 + 32 * APITCH;
             const float *bp0 = Wt + (c * BK + lh) * WPITCH + wn * 64 + li;
-#pragma unroll 4
-            for (int ks = 0; ks < ksteps; ++ks) {
-                const float a0 = ap0[2 * ks], a1 = ap1[2 * ks];
-                const float b0 = bp0[2 * ks * WPITCH], b1 = bp0[2 * ks * WPITCH + 32];
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            if (ksteps == BK / 2) {
+                // full slice: fully unrolled so the scheduler hoists the LDS operand reads of later k-steps above the
+                // MFMAs of earlier ones (4 independent accumulators keep the matrix pipe issuing back to back)
+#pragma unroll
+                for (int ks = 0; ks < BK / 2; ++ks) {
+                    const float a0 = ap0[2 * ks], a1 = ap1[2 * ks];
+                    const float b0 = bp0[2 * ks * WPITCH], b1 = bp0[2 * ks * WPITCH + 32];
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                }
+            } else {
+                for (int ks = 0; ks < ksteps; ++ks) {
+                    const float a0 = ap0[2 * ks], a1 = ap1[2 * ks];
+                    const float b0 = bp0[2 * ks * WPITCH], b1 = bp0[2 * ks * WPITCH + 32];
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                }
             }
             cur_as ^= 1;
         }
         cur_rs ^= 1;
 
         // epilogue.  C layout of a 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+        const bool full = (row0 + BM <= a.m_rows) && (n0 + BN <= a.n_out);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int col = n0 + wn * 64 + j * 32 + li;
@@ -323,25 +339,26 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(LinArgs a, int k_pad) {
             if (cok && a.bn_scale) { mean = a.bn_mean[col]; scale = a.bn_scale[col]; shift = a.bn_shift[col]; }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
+                const int64_t rbase = row0 + wm * 64 + i * 32 + 4 * lh;
+                float *op = a.out + rbase * a.n_out + col;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int64_t row = row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (!cok || row >= a.m_rows) continue;
+                    const int dr = (r & 3) + 8 * (r >> 2);
+                    if (!full && (!cok || rbase + dr >= a.m_rows)) continue;
                     const float h = acc[i][j][r] + bias;
-                    if (a.stats) {
+                    if (STATS) {
                         st_sum[j] += (double)h;
                         st_sq[j] += (double)h * (double)h;
                     } else {
-                        float y = h;
-                        if (a.bn_scale) y = (h - mean) * scale + shift;
-                        a.out[row * a.n_out + col] = apply_act(y, a.act);
+                        const float y = a.bn_scale ? (h - mean) * scale + shift : h;
+                        op[(int64_t)dr * a.n_out] = apply_act(y, a.act);
                     }
                 }
             }
         }
     }
 
-    if (a.stats) {
+    if (STATS) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int col = n0 + wn * 64 + j * 32 + li;
@@ -399,12 +416,16 @@ extern "C" int gsn_linear_fwd_hip(int64_t m_rows, int n_blocks, const gsn_block 
         if (col_tiles > 1) gx = n_tiles < 128 ? n_tiles : 128;
         static bool attr_set = false;
         if (!attr_set) {
-            hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_fwd_kernel),
+            hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_fwd_kernel<false>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e0 == hipSuccess)
+                e0 = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_fwd_kernel<true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e0 != hipSuccess) return set_error(GSN_E_HIP, "hipFuncSetAttribute(linear_fwd_kernel): %s", hipGetErrorString(e0));
             attr_set = true;
         }
-        hipLaunchKernelGGL(linear_fwd_kernel, dim3((unsigned)gx, (unsigned)col_tiles), dim3(256), lds, st, a, k_pad);
+        if (stats) hipLaunchKernelGGL(linear_fwd_kernel<true>, dim3((unsigned)gx, (unsigned)col_tiles), dim3(256), lds, st, a, k_pad);
+        else hipLaunchKernelGGL(linear_fwd_kernel<false>, dim3((unsigned)gx, (unsigned)col_tiles), dim3(256), lds, st, a, k_pad);
     } else {
         int64_t gx = n_tiles < 1024 ? n_tiles : 1024;
         hipLaunchKernelGGL(linear_fwd_stream_kernel, dim3((unsigned)gx, (unsigned)col_tiles), dim3(256), 0, st, a);
