@@ -28,6 +28,11 @@ class gsn_block(ctypes.Structure):
     _fields_ = [("data", c_vp), ("idx", c_vp), ("width", c_i64)]
 
 
+class gsn_chain_stage(ctypes.Structure):
+    _fields_ = [("blocks", ctypes.POINTER(gsn_block)), ("n_blocks", c_int), ("W", c_vp), ("bias", c_vp), ("n_out", c_i64),
+                ("bn_mean", c_vp), ("bn_scale", c_vp), ("bn_shift", c_vp), ("act", c_int)]
+
+
 # name -> (restype, argtypes); kept in one place so tests can check it against include/gsn_abi.h
 SIGNATURES = {
     "gsn_last_error": (ctypes.c_char_p, []),
@@ -45,6 +50,8 @@ SIGNATURES = {
                                       c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "gsn_linear_fwd_hip": (c_int, [c_i64, c_int, ctypes.POINTER(gsn_block), c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_int,
                                    c_vp, c_vp, c_vp, c_vp]),
+    "gsn_mlp_chain_supported": (c_int, [c_int, ctypes.POINTER(gsn_chain_stage)]),
+    "gsn_mlp_chain_fwd_hip": (c_int, [c_i64, c_int, ctypes.POINTER(gsn_chain_stage), c_vp, c_vp, c_vp, c_vp]),
 }
 
 

@@ -1,0 +1,390 @@
+// HP-2 fused MLP chain for gfx950: one or two models_misc.mlp stages on one row tile without leaving the chip.
+//
+//   stage s:  Y_s = act_s( (X_s W_s^T + b_s - mean_s) * scale_s + shift_s ),   X_s = [ HBM blocks of stage s | Y_{s-1} ]
+//
+// e.g. update_fn of every layer:  h = relu(bn(X W3^T + b3)) ; out = h W4^T + b4  (models_misc.py:52-58), whose [N,128]
+// intermediate never touches HBM (for msg_kind='general' X = [x | S | deg] with the deferred last Linear of msg_fn folded
+// into W3, layers.py); and the single edge stage  r = relu(bn(cat(x_i, x_j, id, e) W1^T + b1)).
+//
+// Why this shape (measured on the previous kernel, profiles/r01_*): with K ~ N_out ~ 128 one fp32 stage has only ~32 flop
+// per HBM byte, so un-fused stages wait on memory (SQ_WAIT_ANY 55 %).  Here
+//   * the WEIGHTS LIVE IN REGISTERS: wave w owns output columns [32w, 32w+32) of every stage and keeps its B fragments
+//     (lane (li,lh): W_s[32w+li][2q+lh], ceil(K/2) floats per stage) in VGPRs for the whole persistent kernel -- no LDS or
+//     L2 traffic for weights at all, and LDS is free for activations;
+//   * a tile is 64 rows x full K in LDS (pitch odd -> conflict-free fragment reads), so there is one barrier per stage,
+//     not per K-slice; each wave runs 2 row fragments x 1 column fragment = 2 independent v_mfma_f32_32x32x2_f32 chains;
+//   * the HBM inputs of the NEXT tile (all stages) are prefetched into registers while the current tile computes
+//     (>= 5k MFMA cycles of cover), gather indices two tiles ahead;
+//   * stage outputs are written by the epilogue straight into the next stage's LDS input tile.
+// fp32 in / fp32 accumulate, exact f32 MFMA (157.3 TF peak).  Limits: K_s <= 16*MAXCH, n_out_s <= 128, HBM part of a
+// stage s >= 1 at most 64 columns; anything else goes through linear.hip.
+#include <hip/hip_runtime.h>
+
+#include "gsn_internal.h"
+
+namespace gsn {
+
+constexpr int CBM = 64;         // rows per tile
+constexpr int CHK = 16;         // k per register chunk (8 k-steps of 2)
+constexpr int CMAX_BLOCKS = 6;  // input blocks over all stages
+constexpr int CMAX_STAGES = 2;  // 3 stages x 80 weight registers per lane would spill
+constexpr int PF1_J = 2;        // stage>=1 HBM part: up to 2 x 32 columns
+
+struct ChainStage {
+    const float *W, *bias, *bn_mean, *bn_scale, *bn_shift;
+    int k_total, k_hbm, n_out, act;
+    int first_block, n_blocks;
+};
+
+struct ChainArgs {
+    int64_t m_rows;
+    int n_stages, n_blocks;
+    const float *bdata[CMAX_BLOCKS];
+    const int64_t *bidx[CMAX_BLOCKS];
+    int bwidth[CMAX_BLOCKS];
+    ChainStage st[CMAX_STAGES];
+    const int32_t *row_perm;
+    float *out;
+    double *stats;  // statistics of the LAST stage's pre-BN values instead of an output
+    int pitch;      // LDS row pitch in floats (odd)
+};
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float chain_act(float y, int act) {
+    switch (act) {
+        case 1: return y > 0.f ? y : 0.f;
+        case 2: return y > 0.f ? y : expm1f(y);
+        case 3: return tanhf(y);
+        default: return y;
+    }
+}
+
+// which block / column of stage `s` does concatenated column kc belong to
+struct ColMap {
+    const float *base;  // bdata[blk] + col
+    int bw;             // row stride of that block
+    int rsoff;          // blk * CBM: offset into the row-source table
+    bool ok;
+};
+
+__device__ __forceinline__ ColMap col_map(const ChainArgs &a, int s, int kc) {
+    ColMap m;
+    const ChainStage &st = a.st[s];
+    int blk = st.first_block, col = kc;
+    m.ok = kc < st.k_hbm;
+#pragma unroll
+    for (int b = 0; b < CMAX_BLOCKS - 1; ++b) {
+        if (b >= st.first_block && b < st.first_block + st.n_blocks - 1 && blk == b && col >= a.bwidth[b]) { col -= a.bwidth[b]; blk = b + 1; }
+    }
+    if (!m.ok) { blk = st.n_blocks > 0 ? st.first_block : 0; col = 0; }
+    const float *bd = a.bdata[0];
+    int bw = a.bwidth[0];
+#pragma unroll
+    for (int b = 1; b < CMAX_BLOCKS; ++b)
+        if (blk == b) { bd = a.bdata[b]; bw = a.bwidth[b]; }
+    m.base = bd + col;
+    m.bw = bw;
+    m.rsoff = blk * CBM;
+    return m;
+}
+
+struct RowSrcC {
+    int v[CMAX_BLOCKS];
+};
+
+__device__ __forceinline__ void rs_fetch(const ChainArgs &a, int64_t row0, int tid, RowSrcC &rs) {
+    if (tid < CBM) {
+        const int64_t grow = row0 + tid;
+        const bool ok = grow < a.m_rows;
+        int64_t logical = 0;
+        if (ok) logical = a.row_perm ? (int64_t)a.row_perm[grow] : grow;
+#pragma unroll
+        for (int b = 0; b < CMAX_BLOCKS; ++b) {
+            int r = -1;
+            if (b < a.n_blocks && ok) r = a.bidx[b] ? (int)a.bidx[b][logical] : (int)logical;
+            rs.v[b] = r;
+        }
+    }
+}
+
+__device__ __forceinline__ void rs_store(int *dst, int tid, const RowSrcC &rs) {
+    if (tid < CBM) {
+#pragma unroll
+        for (int b = 0; b < CMAX_BLOCKS; ++b) dst[b * CBM + tid] = rs.v[b];
+    }
+}
+
+// single-stage instantiations are asked to fit 2 waves per SIMD (<= 256 registers) so that one workgroup's staging /
+// epilogue overlaps the other's MFMA phase; two-stage chains hold 160 weight registers and run 1 wave per SIMD.
+template <int NST, int MAXCH>
+__global__ __launch_bounds__(256, ((NST == 1 && MAXCH == 5) ? 2 : 1)) void mlp_chain_kernel(ChainArgs a) {
+    constexpr int PF0_J = (MAXCH * CHK + 31) / 32;  // 32-column groups of the stage-0 input
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int pitch = a.pitch;
+    float *buf0 = lds;
+    float *buf1 = lds + CBM * pitch;
+    int *rsrc = reinterpret_cast<int *>(lds + 2 * CBM * pitch);  // [2][CMAX_BLOCKS][CBM]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int kc0 = tid & 31, r0 = tid >> 5;
+    const int64_t n_tiles = (a.m_rows + CBM - 1) / CBM;
+
+    // ---- weights -> registers (once) ----------------------------------------------------------------------------
+    float B[NST][MAXCH][8];
+    int nch[NST];
+#pragma unroll
+    for (int s = 0; s < NST; ++s) {
+        const ChainStage &st = a.st[s];
+        nch[s] = (st.k_total + CHK - 1) / CHK;
+        const int col = 32 * w + li;
+#pragma unroll
+        for (int ch = 0; ch < MAXCH; ++ch)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int k = ch * CHK + 2 * q + lh;
+                float v = 0.f;
+                if (k < st.k_total && col < st.n_out) v = st.W[(int64_t)col * st.k_total + k];
+                B[s][ch][q] = v;
+            }
+    }
+
+    // ---- per-thread column maps of the HBM parts ----------------------------------------------------------------
+    ColMap cm0[PF0_J];
+#pragma unroll
+    for (int j = 0; j < PF0_J; ++j) cm0[j] = col_map(a, 0, kc0 + 32 * j);
+    ColMap cm1[PF1_J];
+    if (NST > 1) {
+#pragma unroll
+        for (int j = 0; j < PF1_J; ++j) cm1[j] = col_map(a, 1, kc0 + 32 * j);
+    }
+
+    // zero both activation tiles once: padded columns must hold finite values (their weights are zero)
+    for (int i = tid; i < 2 * CBM * pitch; i += 256) lds[i] = 0.f;
+
+    double st_sum = 0.0, st_sq = 0.0;
+    float pf0[PF0_J][8], pf1[PF1_J][8];
+    RowSrcC rsn;
+
+    auto prefetch = [&](const int *rs) {
+#pragma unroll
+        for (int j = 0; j < PF0_J; ++j)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int sr = rs[cm0[j].rsoff + r0 + 8 * i];
+                const float v = cm0[j].base[(int64_t)(sr < 0 ? 0 : sr) * cm0[j].bw];
+                pf0[j][i] = (cm0[j].ok && sr >= 0) ? v : 0.f;
+            }
+        if (NST > 1) {
+#pragma unroll
+            for (int j = 0; j < PF1_J; ++j)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int sr = rs[cm1[j].rsoff + r0 + 8 * i];
+                    float v = 0.f;
+                    if (a.st[1].k_hbm > 32 * j) v = cm1[j].base[(int64_t)(sr < 0 ? 0 : sr) * cm1[j].bw];
+                    pf1[j][i] = (cm1[j].ok && sr >= 0) ? v : 0.f;
+                }
+        }
+    };
+
+    // ---- prologue: row sources of the first two tiles, inputs of the first tile --------------------------------------
+    int64_t tile = blockIdx.x;
+    {
+        RowSrcC r;
+        rs_fetch(a, tile * CBM, tid, r);
+        rs_store(rsrc, tid, r);
+        rs_fetch(a, (tile + gridDim.x) * CBM, tid, rsn);
+    }
+    __syncthreads();
+    if (tile < n_tiles) prefetch(rsrc);
+    int slot = 0;
+
+    for (; tile < n_tiles; tile += gridDim.x) {
+        const int64_t row0 = tile * CBM;
+        __syncthreads();  // every wave is done with the previous tile's buffers
+        // step 1: this tile's prefetched inputs -> LDS; next tile's row sources -> table
+#pragma unroll
+        for (int j = 0; j < PF0_J; ++j)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) buf0[(r0 + 8 * i) * pitch + kc0 + 32 * j] = pf0[j][i];
+        if (NST > 1) {
+#pragma unroll
+            for (int j = 0; j < PF1_J; ++j)
+                if (a.st[1].k_hbm > 32 * j) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) buf1[(r0 + 8 * i) * pitch + kc0 + 32 * j] = pf1[j][i];
+                }
+        }
+        rs_store(rsrc + (slot ^ 1) * (CMAX_BLOCKS * CBM), tid, rsn);
+        __syncthreads();
+        // step 2: issue the next tile's loads (they land while this tile computes); indices two tiles ahead
+        if (tile + gridDim.x < n_tiles) prefetch(rsrc + (slot ^ 1) * (CMAX_BLOCKS * CBM));
+        rs_fetch(a, (tile + 2 * (int64_t)gridDim.x) * CBM, tid, rsn);
+        slot ^= 1;
+
+        float *in = buf0, *nxt = buf1;
+#pragma unroll
+        for (int s = 0; s < NST; ++s) {
+            const ChainStage &st = a.st[s];
+            const bool active = 32 * w < st.n_out;  // wave-uniform
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+            if (active) {
+                const float *ap0 = in + li * pitch + lh;
+                const float *ap1 = ap0 + 32 * pitch;
+#pragma unroll
+                for (int ch = 0; ch < MAXCH; ++ch) {
+                    if (ch < nch[s]) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const float a0 = ap0[ch * CHK + 2 * q], a1 = ap1[ch * CHK + 2 * q];
+                            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, B[s][ch][q], acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, B[s][ch][q], acc1, 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            // epilogue.  C layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+            const int col = 32 * w + li;
+            const bool cok = col < st.n_out;
+            const float bias = (cok && st.bias) ? st.bias[col] : 0.f;
+            float mean = 0.f, scale = 1.f, shift = 0.f;
+            const bool has_bn = st.bn_scale != nullptr;
+            if (cok && has_bn) { mean = st.bn_mean[col]; scale = st.bn_scale[col]; shift = st.bn_shift[col]; }
+            const bool last = s == NST - 1;
+            if (last) {
+                const bool stats = a.stats != nullptr;
+#pragma unroll
+                for (int rf = 0; rf < 2; ++rf) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int64_t row = row0 + rf * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        if (!cok || row >= a.m_rows) continue;
+                        const float h = (rf ? acc1[r] : acc0[r]) + bias;
+                        if (stats) {
+                            st_sum += (double)h;
+                            st_sq += (double)h * (double)h;
+                        } else {
+                            const float y = has_bn ? (h - mean) * scale + shift : h;
+                            a.out[row * st.n_out + col] = chain_act(y, st.act);
+                        }
+                    }
+                }
+            } else {
+                const int koff = a.st[s + 1].k_hbm;
+                if (cok) {
+#pragma unroll
+                    for (int rf = 0; rf < 2; ++rf) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = rf * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                            const float h = (rf ? acc1[r] : acc0[r]) + bias;
+                            const float y = has_bn ? (h - mean) * scale + shift : h;
+                            nxt[row * pitch + koff + col] = chain_act(y, st.act);
+                        }
+                    }
+                }
+                __syncthreads();
+                float *t = in; in = nxt; nxt = t;
+            }
+        }
+    }
+
+    if (a.stats) {
+        const int col = 32 * w + li;
+        double s = st_sum, q = st_sq;
+        s += __shfl_xor(s, 32);
+        q += __shfl_xor(q, 32);
+        const int n_out = a.st[NST - 1].n_out;
+        if (lh == 0 && col < n_out) {
+            atomicAdd(&a.stats[col], s);
+            atomicAdd(&a.stats[n_out + col], q);
+        }
+    }
+}
+
+template <int NST, int MAXCH>
+static int launch_chain(const ChainArgs &a, hipStream_t st) {
+    const size_t lds = (size_t)2 * CBM * a.pitch * 4 + 2 * CMAX_BLOCKS * CBM * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_chain_kernel<NST, MAXCH>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e0 != hipSuccess) return set_error(GSN_E_HIP, "hipFuncSetAttribute(mlp_chain_kernel): %s", hipGetErrorString(e0));
+        attr_set = true;
+    }
+    const int64_t n_tiles = (a.m_rows + CBM - 1) / CBM;
+    const int per_cu = lds <= 72 * 1024 ? 2 : 1;
+    int64_t gx = 256 * per_cu;
+    if (gx > n_tiles) gx = n_tiles;
+    hipLaunchKernelGGL((mlp_chain_kernel<NST, MAXCH>), dim3((unsigned)gx), dim3(256), lds, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(GSN_E_HIP, "mlp_chain_kernel: %s", hipGetErrorString(e));
+    return GSN_OK;
+}
+
+}  // namespace gsn
+
+using namespace gsn;
+
+extern "C" int gsn_mlp_chain_supported(int n_stages, const gsn_chain_stage *stages) {
+    if (n_stages < 1 || n_stages > CMAX_STAGES || !stages) return 0;
+    int nb = 0;
+    for (int s = 0; s < n_stages; ++s) {
+        int k_hbm = 0;
+        for (int b = 0; b < stages[s].n_blocks; ++b) k_hbm += (int)stages[s].blocks[b].width;
+        nb += stages[s].n_blocks;
+        const int k_total = k_hbm + (s > 0 ? (int)stages[s - 1].n_out : 0);
+        if (k_total > 160 || k_total < 1) return 0;
+        if (stages[s].n_out > 128 || stages[s].n_out < 1) return 0;
+        if (s == 0 && stages[s].n_blocks < 1) return 0;
+        if (s == 1 && k_hbm > 32 * PF1_J) return 0;
+    }
+    return nb <= CMAX_BLOCKS ? 1 : 0;
+}
+
+extern "C" int gsn_mlp_chain_fwd_hip(int64_t m_rows, int n_stages, const gsn_chain_stage *stages, const int32_t *row_perm,
+                                     float *out, double *stats, void *stream) {
+    if (!gsn_mlp_chain_supported(n_stages, stages))
+        return set_error(GSN_E_UNSUPPORTED, "gsn_mlp_chain_fwd_hip: shape outside the fused kernel (K<=160, n_out<=128, <=6 blocks); use gsn_linear_fwd_hip");
+    if (!out && !stats) return set_error(GSN_E_INVALID, "gsn_mlp_chain_fwd_hip: neither out nor stats given");
+    if (m_rows <= 0) return GSN_OK;
+    ChainArgs a{};
+    a.m_rows = m_rows; a.n_stages = n_stages; a.row_perm = row_perm; a.out = out; a.stats = stats;
+    int nb = 0, kmax = 0;
+    for (int s = 0; s < n_stages; ++s) {
+        const gsn_chain_stage &g = stages[s];
+        ChainStage &c = a.st[s];
+        if (!g.W) return set_error(GSN_E_INVALID, "gsn_mlp_chain_fwd_hip: stage %d has no weight", s);
+        if ((g.bn_scale != nullptr) != (g.bn_shift != nullptr) || (g.bn_scale != nullptr) != (g.bn_mean != nullptr))
+            return set_error(GSN_E_INVALID, "gsn_mlp_chain_fwd_hip: bn_mean, bn_scale and bn_shift go together");
+        if (g.act < 0 || g.act > 3) return set_error(GSN_E_INVALID, "gsn_mlp_chain_fwd_hip: act must be 0..3");
+        c.W = g.W; c.bias = g.bias; c.bn_mean = g.bn_mean; c.bn_scale = g.bn_scale; c.bn_shift = g.bn_shift;
+        c.n_out = (int)g.n_out; c.act = g.act; c.first_block = nb; c.n_blocks = g.n_blocks;
+        int k_hbm = 0;
+        for (int b = 0; b < g.n_blocks; ++b) {
+            if (!g.blocks[b].data || g.blocks[b].width <= 0) return set_error(GSN_E_INVALID, "gsn_mlp_chain_fwd_hip: stage %d block %d is empty", s, b);
+            a.bdata[nb] = g.blocks[b].data; a.bidx[nb] = g.blocks[b].idx; a.bwidth[nb] = (int)g.blocks[b].width;
+            k_hbm += (int)g.blocks[b].width;
+            ++nb;
+        }
+        c.k_hbm = k_hbm;
+        c.k_total = k_hbm + (s > 0 ? (int)stages[s - 1].n_out : 0);
+        kmax = c.k_total > kmax ? c.k_total : kmax;
+    }
+    a.n_blocks = nb;
+    const int maxch = kmax <= 80 ? 5 : 10;
+    // the staging writes cover whole 32-column groups, so a row holds ceil(16*maxch / 32) * 32 floats (+1: odd pitch)
+    a.pitch = (maxch * CHK + 31) / 32 * 32 + 1;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (maxch == 5) {
+        if (n_stages == 1) return launch_chain<1, 5>(a, st);
+        return launch_chain<2, 5>(a, st);
+    }
+    if (n_stages == 1) return launch_chain<1, 10>(a, st);
+    return launch_chain<2, 10>(a, st);
+}

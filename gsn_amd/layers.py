@@ -27,7 +27,7 @@ import torch.nn.functional as F
 from . import _abi
 
 __all__ = ["mlp", "central_encoder", "GSN_sparse", "GSN_edge_sparse", "MPNN_sparse", "MPNN_edge_sparse",
-           "GSN_edge_sparse_ogb", "MPNN_edge_sparse_ogb", "build_csr", "propagate", "linear_stage"]
+           "GSN_edge_sparse_ogb", "MPNN_edge_sparse_ogb", "build_csr", "propagate", "run_stages"]
 
 _ACT_CODE = {"identity": 0, "relu": 1, "elu": 2, "tanh": 3}
 _MAX_BLOCKS = 5
@@ -211,22 +211,98 @@ def _linear_hip(blocks, weight, bias, bn_mean, bn_scale, bn_shift, act, m_rows, 
     return y
 
 
-def linear_stage(blocks, m_rows, fc, bn, act_name, training):
-    """One stage of models_misc.mlp: act(bn(fc(cat(blocks)))) on the HIP kernel.  Train-mode BatchNorm1d uses two
-    passes (column statistics in fp64, then normalise) and updates the running statistics like nn.BatchNorm1d."""
-    act = _ACT_CODE[act_name]
+class _Stage:
+    """One Linear (+BatchNorm1d) (+activation) stage: ``act(bn([blocks | previous output] W^T + b))``."""
+    __slots__ = ("blocks", "weight", "bias", "bn", "act", "bn_params")
+
+    def __init__(self, weight, bias, bn=None, act="identity", blocks=()):
+        self.blocks, self.weight, self.bias, self.bn, self.act = list(blocks), weight, bias, bn, act
+        self.bn_params = None  # (mean, scale, shift) once resolved
+
+
+def _launch_stages(stages, m_rows, stats=None):
+    """Run resolved stages: fused gsn_mlp_chain_fwd_hip where it fits (<= 2 stages per launch), else stage by stage."""
+    L = _abi.lib()
+    dev = stages[0].weight.device
+    y = None
+    i = 0
+    while i < len(stages):
+        group = None
+        for n in (2, 1):
+            cand = stages[i:i + n]
+            if len(cand) < n:
+                continue
+            carry = [(y, None)] if y is not None else []
+            arr = (_abi.gsn_chain_stage * n)()
+            keep = []
+            for j, st in enumerate(cand):
+                blks = (carry if j == 0 else []) + st.blocks
+                if j == 0 and y is not None:
+                    blks = st.blocks + carry          # concatenation order: own HBM blocks, then the previous output
+                barr = (_abi.gsn_block * max(len(blks), 1))()
+                for b, (d, idx) in enumerate(blks):
+                    d = _f32c(d); keep.append(d)
+                    barr[b].data = d.data_ptr(); barr[b].width = d.shape[1]
+                    if idx is not None:
+                        idx = idx.contiguous(); keep.append(idx); barr[b].idx = idx.data_ptr()
+                    else:
+                        barr[b].idx = None
+                keep.append(barr)
+                w = _f32c(st.weight); keep.append(w)
+                arr[j].blocks = barr; arr[j].n_blocks = len(blks)
+                arr[j].W = w.data_ptr(); arr[j].n_out = w.shape[0]
+                vecs = [None if v is None else _f32c(v) for v in ((st.bias,) + (st.bn_params or (None, None, None)))]
+                keep.extend(vecs)
+                arr[j].bias, arr[j].bn_mean, arr[j].bn_scale, arr[j].bn_shift = [_abi.ptr(v) for v in vecs]
+                arr[j].act = _ACT_CODE[st.act]
+            if L.gsn_mlp_chain_supported(n, arr):
+                group = (n, arr, keep, cand)
+                break
+        last_group = group is not None and i + group[0] == len(stages)
+        if group is not None:
+            n, arr, keep, cand = group
+            want_stats = stats is not None and last_group
+            n_out = cand[-1].weight.shape[0]
+            out = None if want_stats else torch.empty((m_rows, n_out), dtype=torch.float32, device=dev)
+            flops = 0.0
+            kprev = 0
+            for j, st in enumerate(cand):
+                flops += 2.0 * m_rows * st.weight.shape[1] * st.weight.shape[0]
+            with torch.cuda.device(dev), _timed("mlp_chain%d" % n, flops):
+                rc = L.gsn_mlp_chain_fwd_hip(m_rows, n, arr, None, _abi.ptr(out), _abi.ptr(stats) if want_stats else None,
+                                             _abi.current_stream())
+            _abi.check(rc, "gsn_mlp_chain_fwd_hip")
+            y = out
+            i += n
+        else:
+            st = stages[i]
+            blks = st.blocks + ([(y, None)] if y is not None else [])
+            last = i == len(stages) - 1
+            bp = st.bn_params or (None, None, None)
+            if last and stats is not None:
+                _linear_hip(blks, st.weight, st.bias, None, None, None, 0, m_rows, out=False, stats=stats)
+                y = None
+            else:
+                y = _linear_hip(blks, st.weight, st.bias, bp[0], bp[1], bp[2], _ACT_CODE[st.act], m_rows)
+            i += 1
+    return y
+
+
+def _bn_resolve(stage, stats_fn, m_rows, training):
+    """Fill stage.bn_params = (mean, scale, shift).  Train mode: batch statistics from a statistics pass (fp64 column
+    sums), running statistics updated exactly like nn.BatchNorm1d."""
+    bn = stage.bn
     if bn is None:
-        return _linear_hip(blocks, fc.weight, fc.bias, None, None, None, act, m_rows)
-    if training:
-        n_out = fc.weight.shape[0]
-        stats = torch.zeros((2, n_out), dtype=torch.float64, device=fc.weight.device)
-        _linear_hip(blocks, fc.weight, fc.bias, None, None, None, 0, m_rows, out=False, stats=stats)
+        stage.bn_params = None
+        return
+    if training or bn.running_mean is None:
+        stats = stats_fn()
         mean = stats[0] / m_rows
         var = (stats[1] / m_rows - mean * mean).clamp_min_(0.0)
-        if bn.track_running_stats and bn.running_mean is not None:
+        if training and bn.track_running_stats and bn.running_mean is not None:
             with torch.no_grad():
-                mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
                 bn.num_batches_tracked += 1
+                mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
                 unbiased = var * (m_rows / max(m_rows - 1, 1))
                 bn.running_mean.mul_(1 - mom).add_(mean.to(torch.float32) * mom)
                 bn.running_var.mul_(1 - mom).add_(unbiased.to(torch.float32) * mom)
@@ -237,12 +313,27 @@ def linear_stage(blocks, m_rows, fc, bn, act_name, training):
         invstd = torch.rsqrt(bn.running_var.to(torch.float64) + bn.eps).to(torch.float32)
     scale = invstd * bn.weight.detach() if bn.affine else invstd
     shift = bn.bias.detach() if bn.affine else torch.zeros_like(invstd)
-    return _linear_hip(blocks, fc.weight, fc.bias, mean32, scale, shift, act, m_rows)
+    stage.bn_params = (mean32, scale, shift)
+
+
+def run_stages(stages, m_rows, training):
+    """Evaluate a list of _Stage on the HIP kernels.  A train-mode BatchNorm1d stage costs one extra statistics pass over
+    the chain prefix that ends at it (the prefix is recomputed, nothing is stored)."""
+    for i, st in enumerate(stages):
+        if st.bn is not None:
+            def stats_fn(i=i):
+                n_out = stages[i].weight.shape[0]
+                stats = torch.zeros((2, n_out), dtype=torch.float64, device=stages[i].weight.device)
+                probe = _Stage(stages[i].weight, stages[i].bias, None, "identity", stages[i].blocks)
+                _launch_stages(stages[:i] + [probe], m_rows, stats=stats)
+                return stats
+            _bn_resolve(st, stats_fn, m_rows, training)
+    return _launch_stages(stages, m_rows)
 
 
 class mlp(nn.Module):
     """models_misc.mlp (models_misc.py:18-59): Linear -> [BatchNorm1d] -> activation ... -> Linear, same attribute
-    names (``fc``, ``bn``) so state dicts are interchangeable; forward runs on the HIP dense stage."""
+    names (``fc``, ``bn``) so state dicts are interchangeable; forward runs on the HIP dense stages."""
 
     def __init__(self, in_features, out_features, d_k, seed, activation="elu", batch_norm=False):
         super().__init__()
@@ -260,19 +351,20 @@ class mlp(nn.Module):
         self.bn = nn.ModuleList(bn)
         self.activation = choose_activation(activation)
 
-    # -- HIP forward over on-the-fly concatenated / gathered input blocks
-    def hip_forward(self, blocks, m_rows, upto=None):
+    def stages(self, blocks, upto=None, first_weight=None, first_bias=None):
+        """The mlp as a list of _Stage; ``blocks`` feed the first Linear (optionally with a replaced first weight)."""
         n = len(self.fc) if upto is None else upto
-        y = None
+        out = []
         for i in range(n):
             last = i == len(self.fc) - 1
-            blk = blocks if i == 0 else [(y, None)]
-            if last:
-                y = _linear_hip(blk, self.fc[i].weight, self.fc[i].bias, None, None, None, 0, m_rows)
-            else:
-                y = linear_stage(blk, m_rows, self.fc[i], self.bn[i] if self.batch_norm else None, self.activation_name,
-                                 self.training)
-        return y
+            w = self.fc[i].weight if (i > 0 or first_weight is None) else first_weight
+            b = self.fc[i].bias if (i > 0 or first_bias is None) else first_bias
+            out.append(_Stage(w, b, (self.bn[i] if (self.batch_norm and not last) else None),
+                              "identity" if last else self.activation_name, blocks if i == 0 else ()))
+        return out
+
+    def hip_forward(self, blocks, m_rows, upto=None, first_weight=None, first_bias=None):
+        return run_stages(self.stages(blocks, upto, first_weight, first_bias), m_rows, self.training)
 
     # -- differentiable PyTorch twin (used to back-propagate through the dense stages)
     def torch_forward(self, x, upto=None):
@@ -516,18 +608,27 @@ class _SparseLayer(nn.Module):
         if self.has_ef:
             blocks.append((ef, None))
         mf = self.msg_fn
+        uf = self.update_fn
         if len(mf.fc) >= 2:
-            # all stages but the last Linear on E rows, sum-aggregate, then the last Linear on N rows (+ deg * bias)
+            # all stages but the last Linear of msg_fn on E rows, then the sum aggregation S = sum_e r_e; the last Linear
+            # commutes with the sum:  agg = W2 S + deg*b2, and it feeds update_fn's first Linear (weights [W3x | W3a]):
+            #     [x | agg] W3^T = x W3x^T + S (W3a W2)^T + deg (W3a b2)^T
+            # so it is folded into that Linear's weight (a [d_h x d_msg] by [d_msg x d_h] product, once per call).
             r = mf.hip_forward(blocks, E, upto=len(mf.fc) - 1)
-            s = propagate(0, edge_index, sel, n, b=r)
+            s_agg = propagate(0, edge_index, sel, n, b=r)
             csr = _csr_for(edge_index, sel, n)
             last = mf.fc[-1]
-            w_ext = torch.cat([last.weight.detach(), last.bias.detach().unsqueeze(1)], 1)
-            agg = _linear_hip([(s, None), (csr.deg, None)], w_ext, None, None, None, None, 0, n)
-        else:
-            msgs = mf.hip_forward(blocks, E)
-            agg = propagate(0, edge_index, sel, n, b=msgs)
-        return self.update_fn.hip_forward([(x, None), (agg, None)], n)
+            d_x = x.shape[1]
+            w3 = uf.fc[0].weight.detach()
+            w3x, w3a = w3[:, :d_x], w3[:, d_x:].contiguous()
+            w2t = last.weight.detach().t().contiguous()                       # [d_h_msg, d_msg]: rows = input index
+            w_fold = _linear_hip([(w3a, None)], w2t, None, None, None, None, 0, w3a.shape[0])   # = W3a @ W2
+            b_fold = _linear_hip([(w3a, None)], last.bias.detach().unsqueeze(0).contiguous(), None, None, None, None, 0, w3a.shape[0])
+            w_first = torch.cat([w3x, w_fold, b_fold], 1).contiguous()
+            return uf.hip_forward([(x, None), (s_agg, None), (csr.deg, None)], n, first_weight=w_first)
+        msgs = mf.hip_forward(blocks, E)
+        agg = propagate(0, edge_index, sel, n, b=msgs)
+        return uf.hip_forward([(x, None), (agg, None)], n)
 
     # -- differentiable twin (PyTorch ops + the HIP propagate with its own adjoint) ---------------------------------
     def _twin(self, edge_index, x, ids, ef):

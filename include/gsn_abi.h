@@ -162,6 +162,31 @@ int gsn_linear_fwd_hip(int64_t m_rows, int n_blocks, const gsn_block *blocks, co
                        int64_t n_out, const float *bn_mean, const float *bn_scale, const float *bn_shift, int act,
                        const int32_t *row_perm, float *out, double *stats, void *stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * HP-2  fused MLP chain (device, fp32 MFMA).  One or two dependent stages of models_misc.mlp (models_misc.py:52-58)
+ * evaluated per 64-row tile without writing the intermediates to HBM:
+ *     Y_s = act_s( bn_s( [ blocks_s | Y_{s-1} ] W_s^T + bias_s ) ),   out = Y_last   ([M][n_out_last])
+ * i.e. the input of stage s > 0 is the concatenation of its own HBM blocks (e.g. x in update_fn's cat((x, agg)),
+ * GSN_sparse.py:114 / GSN_edge_sparse.py:112) followed by the previous stage's output.  Weights are held in registers,
+ * activations in LDS.  Same per-stage parameters as gsn_linear_fwd_hip.  `stats` (double [2][n_out_last]) replaces the
+ * output by column sums / sums of squares of the LAST stage's pre-BN values (train-mode BatchNorm1d, pass 1).
+ * gsn_mlp_chain_supported() tells whether a chain fits the fused kernel (<= 2 stages, every K_s <= 160, n_out_s <= 128,
+ * at most 6 blocks, stage-1 blocks <= 64 columns); otherwise run the stages one by one with gsn_linear_fwd_hip.
+ * ---------------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    const gsn_block *blocks;
+    int n_blocks;
+    const float *W;       /* [n_out][k_total] row-major; k_total = sum(block widths) + (s > 0 ? n_out of stage s-1 : 0) */
+    const float *bias;    /* [n_out] or NULL */
+    int64_t n_out;
+    const float *bn_mean, *bn_scale, *bn_shift; /* all three or none */
+    int act;
+} gsn_chain_stage;
+
+int gsn_mlp_chain_supported(int n_stages, const gsn_chain_stage *stages);
+int gsn_mlp_chain_fwd_hip(int64_t m_rows, int n_stages, const gsn_chain_stage *stages, const int32_t *row_perm,
+                          float *out, double *stats, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
