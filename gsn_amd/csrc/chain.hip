@@ -51,6 +51,12 @@ struct ChainArgs {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Workgroup barrier that orders LDS only.  __syncthreads() is fence + barrier and drains vmcnt(0) first, i.e. it would
+// wait for the just-issued prefetch loads of the next tile and for the epilogue's global stores at every stage
+// boundary (measured: SQ_WAIT_ANY 37-48 % of wave cycles).  The tile buffers are LDS, so lgkmcnt(0) is all that is
+// needed; registers fed by global loads are still guarded by the compiler's own counted vmcnt waits at their first use.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ float chain_act(float y, int act) {
     switch (act) {
         case 1: return y > 0.f ? y : 0.f;
@@ -117,8 +123,11 @@ __device__ __forceinline__ void rs_store(int *dst, int tid, const RowSrcC &rs) {
 
 // single-stage instantiations are asked to fit 2 waves per SIMD (<= 256 registers) so that one workgroup's staging /
 // epilogue overlaps the other's MFMA phase; two-stage chains hold 160 weight registers and run 1 wave per SIMD.
-template <int NST, int MAXCH>
-__global__ __launch_bounds__(256, ((NST == 1 && MAXCH == 5) ? 2 : 1)) void mlp_chain_kernel(ChainArgs a) {
+// WPE = waves per SIMD the kernel is compiled for: small single-stage chains use 2 (<= 256 registers; two co-resident
+// workgroups overlap each other's staging / epilogue with MFMA), everything else exactly 1 so the register allocator may
+// use the whole 512-entry file for the weight fragments instead of spilling.
+template <int NST, int MAXCH, bool STATS, int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void mlp_chain_kernel(ChainArgs a) {
     constexpr int PF0_J = (MAXCH * CHK + 31) / 32;  // 32-column groups of the stage-0 input
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int pitch = a.pitch;
@@ -164,28 +173,43 @@ __global__ __launch_bounds__(256, ((NST == 1 && MAXCH == 5) ? 2 : 1)) void mlp_c
     // zero both activation tiles once: padded columns must hold finite values (their weights are zero)
     for (int i = tid; i < 2 * CBM * pitch; i += 256) lds[i] = 0.f;
 
+    // per-stage epilogue constants of this lane's output column (loaded once: a load inside the tile loop would put a
+    // vmcnt(0) in front of every use and drain the prefetch / the stores)
+    float e_bias[NST], e_mean[NST], e_scale[NST], e_shift[NST];
+#pragma unroll
+    for (int s = 0; s < NST; ++s) {
+        const ChainStage &st = a.st[s];
+        const int col = 32 * w + li;
+        const bool cok = col < st.n_out;
+        e_bias[s] = (cok && st.bias) ? st.bias[col] : 0.f;
+        e_mean[s] = 0.f; e_scale[s] = 1.f; e_shift[s] = 0.f;
+        if (cok && st.bn_scale) { e_mean[s] = st.bn_mean[col]; e_scale[s] = st.bn_scale[col]; e_shift[s] = st.bn_shift[col]; }
+    }
+
     double st_sum = 0.0, st_sq = 0.0;
     float pf0[PF0_J][8], pf1[PF1_J][8];
     RowSrcC rsn;
 
+    // NOTE: the loaded values are kept RAW in the prefetch registers; masking (padded columns, rows past the end) is
+    // applied when they are written to LDS one tile later.  Selecting on the value right here would make the compiler
+    // wait for every load immediately after issuing it (vmcnt countdown) and serialise the prefetch.
     auto prefetch = [&](const int *rs) {
 #pragma unroll
         for (int j = 0; j < PF0_J; ++j)
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int sr = rs[cm0[j].rsoff + r0 + 8 * i];
-                const float v = cm0[j].base[(int64_t)(sr < 0 ? 0 : sr) * cm0[j].bw];
-                pf0[j][i] = (cm0[j].ok && sr >= 0) ? v : 0.f;
+                pf0[j][i] = cm0[j].base[(int64_t)(sr < 0 ? 0 : sr) * cm0[j].bw];
             }
         if (NST > 1) {
 #pragma unroll
             for (int j = 0; j < PF1_J; ++j)
+                if (a.st[1].k_hbm > 32 * j) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int sr = rs[cm1[j].rsoff + r0 + 8 * i];
-                    float v = 0.f;
-                    if (a.st[1].k_hbm > 32 * j) v = cm1[j].base[(int64_t)(sr < 0 ? 0 : sr) * cm1[j].bw];
-                    pf1[j][i] = (cm1[j].ok && sr >= 0) ? v : 0.f;
+                    for (int i = 0; i < 8; ++i) {
+                        const int sr = rs[cm1[j].rsoff + r0 + 8 * i];
+                        pf1[j][i] = cm1[j].base[(int64_t)(sr < 0 ? 0 : sr) * cm1[j].bw];
+                    }
                 }
         }
     };
@@ -204,25 +228,31 @@ __global__ __launch_bounds__(256, ((NST == 1 && MAXCH == 5) ? 2 : 1)) void mlp_c
 
     for (; tile < n_tiles; tile += gridDim.x) {
         const int64_t row0 = tile * CBM;
-        __syncthreads();  // every wave is done with the previous tile's buffers
-        // step 1: this tile's prefetched inputs -> LDS; next tile's row sources -> table
+        lds_barrier();  // every wave is done with the previous tile's buffers
+        // step 1: this tile's prefetched inputs -> LDS (masked here, see prefetch); next tile's row sources -> table
 #pragma unroll
         for (int j = 0; j < PF0_J; ++j)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) buf0[(r0 + 8 * i) * pitch + kc0 + 32 * j] = pf0[j][i];
+            for (int i = 0; i < 8; ++i) {
+                const bool ok = cm0[j].ok && (row0 + r0 + 8 * i < a.m_rows);
+                buf0[(r0 + 8 * i) * pitch + kc0 + 32 * j] = ok ? pf0[j][i] : 0.f;
+            }
         if (NST > 1) {
 #pragma unroll
             for (int j = 0; j < PF1_J; ++j)
                 if (a.st[1].k_hbm > 32 * j) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) buf1[(r0 + 8 * i) * pitch + kc0 + 32 * j] = pf1[j][i];
+                    for (int i = 0; i < 8; ++i) {
+                        const bool ok = cm1[j].ok && (row0 + r0 + 8 * i < a.m_rows);
+                        buf1[(r0 + 8 * i) * pitch + kc0 + 32 * j] = ok ? pf1[j][i] : 0.f;
+                    }
                 }
         }
         rs_store(rsrc + (slot ^ 1) * (CMAX_BLOCKS * CBM), tid, rsn);
-        __syncthreads();
+        lds_barrier();
         // step 2: issue the next tile's loads (they land while this tile computes); indices two tiles ahead
-        if (tile + gridDim.x < n_tiles) prefetch(rsrc + (slot ^ 1) * (CMAX_BLOCKS * CBM));
-        rs_fetch(a, (tile + 2 * (int64_t)gridDim.x) * CBM, tid, rsn);
+        rs_fetch(a, (tile + 2 * (int64_t)gridDim.x) * CBM, tid, rsn);   // (before the prefetch: its dependent index load must
+        if (tile + gridDim.x < n_tiles) prefetch(rsrc + (slot ^ 1) * (CMAX_BLOCKS * CBM));   //  not wait behind 40 loads)
         slot ^= 1;
 
         float *in = buf0, *nxt = buf1;
@@ -248,53 +278,69 @@ __global__ __launch_bounds__(256, ((NST == 1 && MAXCH == 5) ? 2 : 1)) void mlp_c
                     }
                 }
             }
-            // epilogue.  C layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+            // epilogue.  C layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).  Straight-line for full tiles
+            // (activation switch hoisted out of the 32-element loops) so the stores / LDS writes issue back to back.
             const int col = 32 * w + li;
             const bool cok = col < st.n_out;
-            const float bias = (cok && st.bias) ? st.bias[col] : 0.f;
-            float mean = 0.f, scale = 1.f, shift = 0.f;
-            const bool has_bn = st.bn_scale != nullptr;
-            if (cok && has_bn) { mean = st.bn_mean[col]; scale = st.bn_scale[col]; shift = st.bn_shift[col]; }
+            const float bias = e_bias[s], mean = e_mean[s], scale = e_scale[s], shift = e_shift[s];
             const bool last = s == NST - 1;
-            if (last) {
-                const bool stats = a.stats != nullptr;
+            auto value = [&](int rf, int r) { return ((rf ? acc1[r] : acc0[r]) + bias - mean) * scale + shift; };
+            if (last && STATS) {
 #pragma unroll
-                for (int rf = 0; rf < 2; ++rf) {
+                for (int rf = 0; rf < 2; ++rf)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int64_t row = row0 + rf * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        if (!cok || row >= a.m_rows) continue;
                         const float h = (rf ? acc1[r] : acc0[r]) + bias;
-                        if (stats) {
-                            st_sum += (double)h;
-                            st_sq += (double)h * (double)h;
-                        } else {
-                            const float y = has_bn ? (h - mean) * scale + shift : h;
-                            a.out[row * st.n_out + col] = chain_act(y, st.act);
-                        }
+                        if (cok && row < a.m_rows) { st_sum += (double)h; st_sq += (double)h * (double)h; }
                     }
+            } else if (last) {
+                float *op = a.out + (row0 + 4 * lh) * st.n_out + col;
+                const bool full = row0 + CBM <= a.m_rows;
+                auto emit = [&](auto actf) {
+                    if (full) {
+                        if (cok) {
+#pragma unroll
+                            for (int rf = 0; rf < 2; ++rf)
+#pragma unroll
+                                for (int r = 0; r < 16; ++r)
+                                    op[(int64_t)(rf * 32 + (r & 3) + 8 * (r >> 2)) * st.n_out] = actf(value(rf, r));
+                        }
+                    } else {
+#pragma unroll
+                        for (int rf = 0; rf < 2; ++rf)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int dr = rf * 32 + (r & 3) + 8 * (r >> 2);
+                                if (cok && row0 + 4 * lh + dr < a.m_rows) op[(int64_t)dr * st.n_out] = actf(value(rf, r));
+                            }
+                    }
+                };
+                switch (st.act) {
+                    case 1: emit([](float y) { return y > 0.f ? y : 0.f; }); break;
+                    default: emit([](float y) { return y; }); break;
                 }
             } else {
-                const int koff = a.st[s + 1].k_hbm;
-                if (cok) {
+                float *lp = nxt + (4 * lh) * pitch + a.st[s + 1].k_hbm + col;
+                auto emit = [&](auto actf) {
+                    if (cok) {
 #pragma unroll
-                    for (int rf = 0; rf < 2; ++rf) {
+                        for (int rf = 0; rf < 2; ++rf)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int row = rf * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                            const float h = (rf ? acc1[r] : acc0[r]) + bias;
-                            const float y = has_bn ? (h - mean) * scale + shift : h;
-                            nxt[row * pitch + koff + col] = chain_act(y, st.act);
-                        }
+                            for (int r = 0; r < 16; ++r) lp[(rf * 32 + (r & 3) + 8 * (r >> 2)) * pitch] = actf(value(rf, r));
                     }
+                };
+                switch (st.act) {
+                    case 1: emit([](float y) { return y > 0.f ? y : 0.f; }); break;
+                    default: emit([](float y) { return y; }); break;
                 }
-                __syncthreads();
+                lds_barrier();
                 float *t = in; in = nxt; nxt = t;
             }
         }
     }
 
-    if (a.stats) {
+    if (STATS) {
         const int col = 32 * w + li;
         double s = st_sum, q = st_sq;
         s += __shfl_xor(s, 32);
@@ -307,24 +353,31 @@ __global__ __launch_bounds__(256, ((NST == 1 && MAXCH == 5) ? 2 : 1)) void mlp_c
     }
 }
 
-template <int NST, int MAXCH>
-static int launch_chain(const ChainArgs &a, hipStream_t st) {
+template <int NST, int MAXCH, bool STATS>
+static int launch_chain_impl(const ChainArgs &a, hipStream_t st) {
+    constexpr bool W2 = (NST == 1 && MAXCH == 5);
+    constexpr int WPE = W2 ? 2 : 1;
+    const void *fn = reinterpret_cast<const void *>(&mlp_chain_kernel<NST, MAXCH, STATS, WPE>);
     const size_t lds = (size_t)2 * CBM * a.pitch * 4 + 2 * CMAX_BLOCKS * CBM * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_chain_kernel<NST, MAXCH>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e0 = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e0 != hipSuccess) return set_error(GSN_E_HIP, "hipFuncSetAttribute(mlp_chain_kernel): %s", hipGetErrorString(e0));
         attr_set = true;
     }
     const int64_t n_tiles = (a.m_rows + CBM - 1) / CBM;
-    const int per_cu = lds <= 72 * 1024 ? 2 : 1;
+    const int per_cu = (W2 && lds <= 72 * 1024) ? 2 : 1;
     int64_t gx = 256 * per_cu;
     if (gx > n_tiles) gx = n_tiles;
-    hipLaunchKernelGGL((mlp_chain_kernel<NST, MAXCH>), dim3((unsigned)gx), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((mlp_chain_kernel<NST, MAXCH, STATS, WPE>), dim3((unsigned)gx), dim3(256), lds, st, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(GSN_E_HIP, "mlp_chain_kernel: %s", hipGetErrorString(e));
     return GSN_OK;
+}
+
+template <int NST, int MAXCH>
+static int launch_chain(const ChainArgs &a, hipStream_t st) {
+    return a.stats ? launch_chain_impl<NST, MAXCH, true>(a, st) : launch_chain_impl<NST, MAXCH, false>(a, st);
 }
 
 }  // namespace gsn
@@ -341,6 +394,9 @@ extern "C" int gsn_mlp_chain_supported(int n_stages, const gsn_chain_stage *stag
         const int k_total = k_hbm + (s > 0 ? (int)stages[s - 1].n_out : 0);
         if (k_total > 160 || k_total < 1) return 0;
         if (stages[s].n_out > 128 || stages[s].n_out < 1) return 0;
+        // elu / tanh epilogues call into the device math library; a call inside this kernel makes the register allocator
+        // spill the weight fragments around it, so those activations go through gsn_linear_fwd_hip instead
+        if (stages[s].act != 0 && stages[s].act != 1) return 0;
         if (s == 0 && stages[s].n_blocks < 1) return 0;
         if (s == 1 && k_hbm > 32 * PF1_J) return 0;
     }
@@ -362,7 +418,7 @@ extern "C" int gsn_mlp_chain_fwd_hip(int64_t m_rows, int n_stages, const gsn_cha
         if (!g.W) return set_error(GSN_E_INVALID, "gsn_mlp_chain_fwd_hip: stage %d has no weight", s);
         if ((g.bn_scale != nullptr) != (g.bn_shift != nullptr) || (g.bn_scale != nullptr) != (g.bn_mean != nullptr))
             return set_error(GSN_E_INVALID, "gsn_mlp_chain_fwd_hip: bn_mean, bn_scale and bn_shift go together");
-        if (g.act < 0 || g.act > 3) return set_error(GSN_E_INVALID, "gsn_mlp_chain_fwd_hip: act must be 0..3");
+        if (g.act < 0 || g.act > 1) return set_error(GSN_E_INVALID, "gsn_mlp_chain_fwd_hip: act must be 0 (identity) or 1 (relu)");
         c.W = g.W; c.bias = g.bias; c.bn_mean = g.bn_mean; c.bn_scale = g.bn_scale; c.bn_shift = g.bn_shift;
         c.n_out = (int)g.n_out; c.act = g.act; c.first_block = nb; c.n_blocks = g.n_blocks;
         int k_hbm = 0;

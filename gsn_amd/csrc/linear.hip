@@ -229,9 +229,8 @@ __device__ __forceinline__ void slice_fetch(const LinArgs &a, const int *rsrc, i
 #pragma unroll
     for (int i = 0; i < NPRE; ++i) {
         const int sr = rs[8 * i];
-        const float v = bcol[(int64_t)(sr < 0 ? 0 : sr) * bw];
-        pre[i] = (kok && sr >= 0) ? v : 0.f;
-    }
+        pre[i] = bcol[(int64_t)(sr < 0 ? 0 : sr) * bw];   // raw; masked when written to LDS (a select here would force
+    }                                                      // an immediate vmcnt wait and serialise the prefetch)
 }
 
 template <bool STATS>
@@ -289,7 +288,10 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(LinArgs a, int k_pad) {
             {
                 const int kc = tid & 31, r0 = tid >> 5;
 #pragma unroll
-                for (int i = 0; i < NPRE; ++i) Ab[(r0 + 8 * i) * APITCH + kc] = pre[i];
+                for (int i = 0; i < NPRE; ++i) {
+                    const bool ok = (c * BK + kc < a.k_total) && (row0 + r0 + 8 * i < a.m_rows);
+                    Ab[(r0 + 8 * i) * APITCH + kc] = ok ? pre[i] : 0.f;
+                }
             }
             const bool last = c == n_slices - 1;
             if (last && has_next) rowsrc_store(rsrc + (cur_rs ^ 1) * (MAX_BLOCKS * BM), tid, rs_next);

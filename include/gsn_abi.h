@@ -171,7 +171,8 @@ int gsn_linear_fwd_hip(int64_t m_rows, int n_blocks, const gsn_block *blocks, co
  * activations in LDS.  Same per-stage parameters as gsn_linear_fwd_hip.  `stats` (double [2][n_out_last]) replaces the
  * output by column sums / sums of squares of the LAST stage's pre-BN values (train-mode BatchNorm1d, pass 1).
  * gsn_mlp_chain_supported() tells whether a chain fits the fused kernel (<= 2 stages, every K_s <= 160, n_out_s <= 128,
- * at most 6 blocks, stage-1 blocks <= 64 columns); otherwise run the stages one by one with gsn_linear_fwd_hip.
+ * at most 6 blocks, stage-1 blocks <= 64 columns, activations identity / relu); otherwise run the stages one by one
+ * with gsn_linear_fwd_hip.
  * ---------------------------------------------------------------------------------------------------------------- */
 typedef struct {
     const gsn_block *blocks;
