@@ -198,15 +198,17 @@ def main():
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
         roof["launches_per_step"] = kd["launches_per_step"]
         roof["avg_launch_ms"] = round(kd["ms_per_step"] / kd["launches_per_step"], 4)
-        pk = kernels["propagate_fwd"]
         ck = kernels["count"]
-        extra = {
-            "propagate_hbm_GBs": round(pk["work_per_step"] / (pk["ms_per_step"] * 1e-3) / 1e9, 1),
-            "propagate_hbm_frac": round(pk["work_per_step"] / (pk["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        extra = {}
+        if "propagate_fwd" in kernels:   # only when the scatter-add is not fused into the edge stage
+            pk = kernels["propagate_fwd"]
+            extra["propagate_hbm_GBs"] = round(pk["work_per_step"] / (pk["ms_per_step"] * 1e-3) / 1e9, 1)
+            extra["propagate_hbm_frac"] = round(pk["work_per_step"] / (pk["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        extra.update({
             "count_graphs_per_s": round(G / (ck["ms_per_step"] * 1e-3), 1),
             "count_hbm_GBs": round(ck["work_per_step"] / (ck["ms_per_step"] * 1e-3) / 1e9, 1),
             "ms_per_step_by_kernel": per_launch,
-        }
+        })
         res = {
             "metric": "graphs/sec (orbit-count + GSN-e fwd), ZINC-shape batch; % HBM roofline",
             "value": round(world * G * args.steps / dt, 1), "unit": "graphs/s", "n_gpus": world, "steps": args.steps,

@@ -43,7 +43,8 @@ SIGNATURES = {
     "gsn_count_hip": (c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_i64, c_i64,
                               c_vp, c_vp, c_vp]),
     "gsn_csr_scratch_elems": (c_i64, [c_i64]),
-    "gsn_csr_build_hip": (c_int, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "gsn_csr_build_hip": (c_int, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "gsn_segsum_prepare_hip": (c_int, [c_i64, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp]),
     "gsn_propagate_fwd_hip": (c_int, [c_int, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_vp,
                                       c_i64, c_vp, c_vp]),
     "gsn_propagate_bwd_hip": (c_int, [c_int, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_int,
@@ -51,7 +52,7 @@ SIGNATURES = {
     "gsn_linear_fwd_hip": (c_int, [c_i64, c_int, ctypes.POINTER(gsn_block), c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_int,
                                    c_vp, c_vp, c_vp, c_vp]),
     "gsn_mlp_chain_supported": (c_int, [c_int, ctypes.POINTER(gsn_chain_stage)]),
-    "gsn_mlp_chain_fwd_hip": (c_int, [c_i64, c_int, ctypes.POINTER(gsn_chain_stage), c_vp, c_vp, c_vp, c_vp]),
+    "gsn_mlp_chain_fwd_hip": (c_int, [c_i64, c_int, ctypes.POINTER(gsn_chain_stage), c_vp, c_vp, c_vp, c_vp, c_vp]),
 }
 
 

@@ -44,10 +44,13 @@ struct ChainArgs {
     int bwidth[CMAX_BLOCKS];
     ChainStage st[CMAX_STAGES];
     const int32_t *row_perm;
-    float *out;
-    double *stats;  // statistics of the LAST stage's pre-BN values instead of an output
-    int pitch;      // LDS row pitch in floats (odd)
+    const int32_t *seg_target;  // [m_rows] target segment of every tile-space row (rows sorted by target) or null
+    float *out;                 // [m_rows][n_out], or [n_seg][n_out] segment sums when seg_target is given
+    double *stats;              // statistics of the LAST stage's pre-BN values instead of an output
+    int pitch;                  // LDS row pitch in floats (odd)
 };
+
+constexpr int RS_STRIDE = (CMAX_BLOCKS + 1) * CBM + 2;  // per slot: row sources per block, row targets, prev / next target
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -97,6 +100,7 @@ __device__ __forceinline__ ColMap col_map(const ChainArgs &a, int s, int kc) {
 
 struct RowSrcC {
     int v[CMAX_BLOCKS];
+    int tg, edge;  // target segment of the row; for lane 0 / 63: target of the row before / after the tile
 };
 
 __device__ __forceinline__ void rs_fetch(const ChainArgs &a, int64_t row0, int tid, RowSrcC &rs) {
@@ -111,6 +115,12 @@ __device__ __forceinline__ void rs_fetch(const ChainArgs &a, int64_t row0, int t
             if (b < a.n_blocks && ok) r = a.bidx[b] ? (int)a.bidx[b][logical] : (int)logical;
             rs.v[b] = r;
         }
+        rs.tg = -1; rs.edge = -2;
+        if (a.seg_target) {
+            if (ok) rs.tg = a.seg_target[grow];
+            if (tid == 0 && row0 > 0 && row0 - 1 < a.m_rows) rs.edge = a.seg_target[row0 - 1];
+            if (tid == CBM - 1 && row0 + CBM < a.m_rows) rs.edge = a.seg_target[row0 + CBM];
+        }
     }
 }
 
@@ -118,6 +128,9 @@ __device__ __forceinline__ void rs_store(int *dst, int tid, const RowSrcC &rs) {
     if (tid < CBM) {
 #pragma unroll
         for (int b = 0; b < CMAX_BLOCKS; ++b) dst[b * CBM + tid] = rs.v[b];
+        dst[CMAX_BLOCKS * CBM + tid] = rs.tg;
+        if (tid == 0) dst[(CMAX_BLOCKS + 1) * CBM] = rs.edge;
+        if (tid == CBM - 1) dst[(CMAX_BLOCKS + 1) * CBM + 1] = rs.edge;
     }
 }
 
@@ -126,14 +139,14 @@ __device__ __forceinline__ void rs_store(int *dst, int tid, const RowSrcC &rs) {
 // WPE = waves per SIMD the kernel is compiled for: small single-stage chains use 2 (<= 256 registers; two co-resident
 // workgroups overlap each other's staging / epilogue with MFMA), everything else exactly 1 so the register allocator may
 // use the whole 512-entry file for the weight fragments instead of spilling.
-template <int NST, int MAXCH, bool STATS, int WPE>
+template <int NST, int MAXCH, bool STATS, int WPE, bool SEG>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void mlp_chain_kernel(ChainArgs a) {
     constexpr int PF0_J = (MAXCH * CHK + 31) / 32;  // 32-column groups of the stage-0 input
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int pitch = a.pitch;
     float *buf0 = lds;
     float *buf1 = lds + CBM * pitch;
-    int *rsrc = reinterpret_cast<int *>(lds + 2 * CBM * pitch);  // [2][CMAX_BLOCKS][CBM]
+    int *rsrc = reinterpret_cast<int *>(lds + 2 * CBM * pitch);  // [2][RS_STRIDE]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
@@ -248,11 +261,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
                     }
                 }
         }
-        rs_store(rsrc + (slot ^ 1) * (CMAX_BLOCKS * CBM), tid, rsn);
+        rs_store(rsrc + (slot ^ 1) * RS_STRIDE, tid, rsn);
         lds_barrier();
         // step 2: issue the next tile's loads (they land while this tile computes); indices two tiles ahead
         rs_fetch(a, (tile + 2 * (int64_t)gridDim.x) * CBM, tid, rsn);   // (before the prefetch: its dependent index load must
-        if (tile + gridDim.x < n_tiles) prefetch(rsrc + (slot ^ 1) * (CMAX_BLOCKS * CBM));   //  not wait behind 40 loads)
+        if (tile + gridDim.x < n_tiles) prefetch(rsrc + (slot ^ 1) * RS_STRIDE);   //  not wait behind 40 loads)
         slot ^= 1;
 
         float *in = buf0, *nxt = buf1;
@@ -294,6 +307,52 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
                         const float h = (rf ? acc1[r] : acc0[r]) + bias;
                         if (cok && row < a.m_rows) { st_sum += (double)h; st_sq += (double)h * (double)h; }
                     }
+            } else if (last && SEG) {
+                // segmented-sum epilogue (the scatter-add of the layer, fused): activated tile -> LDS, then every thread
+                // reduces one column over 32 consecutive rows, whose targets are sorted; a segment that lies inside
+                // the 32-row range is stored, one that straddles a range boundary is added atomically (its output row
+                // was zeroed by gsn_segsum_prepare_hip).  Summation order inside a segment = row order.
+                float *Y = nxt + (4 * lh) * pitch + col;
+                if (cok) {
+                    if (st.act == 1) {
+#pragma unroll
+                        for (int rf = 0; rf < 2; ++rf)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) { const float y = value(rf, r); Y[(rf * 32 + (r & 3) + 8 * (r >> 2)) * pitch] = y > 0.f ? y : 0.f; }
+                    } else {
+#pragma unroll
+                        for (int rf = 0; rf < 2; ++rf)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) Y[(rf * 32 + (r & 3) + 8 * (r >> 2)) * pitch] = value(rf, r);
+                    }
+                }
+                lds_barrier();
+                const int c = tid & 127, rb = (tid >> 7) * 32;
+                if (c < st.n_out) {
+                    const int *tg = rsrc + (slot ^ 1) * RS_STRIDE + CMAX_BLOCKS * CBM;   // this tile's targets
+                    const int prev_t = rb > 0 ? tg[rb - 1] : tg[CBM];
+                    const int next_t = rb + 32 < CBM ? tg[rb + 32] : tg[CBM + 1];
+                    const float *yp = nxt + rb * pitch + c;
+                    float *op = a.out + c;
+                    int cur = tg[rb];
+                    bool straddle = cur == prev_t;
+                    float sum = 0.f;
+                    for (int r = 0; r < 32; ++r) {
+                        const int t = tg[rb + r];
+                        if (t != cur) {
+                            if (cur >= 0) {
+                                if (straddle) atomicAdd(op + (int64_t)cur * st.n_out, sum);
+                                else op[(int64_t)cur * st.n_out] = sum;
+                            }
+                            cur = t; sum = 0.f; straddle = false;
+                        }
+                        sum += yp[r * pitch];
+                    }
+                    if (cur >= 0) {
+                        if (straddle || cur == next_t) atomicAdd(op + (int64_t)cur * st.n_out, sum);
+                        else op[(int64_t)cur * st.n_out] = sum;
+                    }
+                }
             } else if (last) {
                 float *op = a.out + (row0 + 4 * lh) * st.n_out + col;
                 const bool full = row0 + CBM <= a.m_rows;
@@ -353,12 +412,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     }
 }
 
-template <int NST, int MAXCH, bool STATS>
+template <int NST, int MAXCH, bool STATS, bool SEG>
 static int launch_chain_impl(const ChainArgs &a, hipStream_t st) {
     constexpr bool W2 = (NST == 1 && MAXCH == 5);
     constexpr int WPE = W2 ? 2 : 1;
-    const void *fn = reinterpret_cast<const void *>(&mlp_chain_kernel<NST, MAXCH, STATS, WPE>);
-    const size_t lds = (size_t)2 * CBM * a.pitch * 4 + 2 * CMAX_BLOCKS * CBM * 4;
+    const void *fn = reinterpret_cast<const void *>(&mlp_chain_kernel<NST, MAXCH, STATS, WPE, SEG>);
+    const size_t lds = (size_t)2 * CBM * a.pitch * 4 + 2 * RS_STRIDE * 4;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e0 = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -369,7 +428,7 @@ static int launch_chain_impl(const ChainArgs &a, hipStream_t st) {
     const int per_cu = (W2 && lds <= 72 * 1024) ? 2 : 1;
     int64_t gx = 256 * per_cu;
     if (gx > n_tiles) gx = n_tiles;
-    hipLaunchKernelGGL((mlp_chain_kernel<NST, MAXCH, STATS, WPE>), dim3((unsigned)gx), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((mlp_chain_kernel<NST, MAXCH, STATS, WPE, SEG>), dim3((unsigned)gx), dim3(256), lds, st, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(GSN_E_HIP, "mlp_chain_kernel: %s", hipGetErrorString(e));
     return GSN_OK;
@@ -377,7 +436,9 @@ static int launch_chain_impl(const ChainArgs &a, hipStream_t st) {
 
 template <int NST, int MAXCH>
 static int launch_chain(const ChainArgs &a, hipStream_t st) {
-    return a.stats ? launch_chain_impl<NST, MAXCH, true>(a, st) : launch_chain_impl<NST, MAXCH, false>(a, st);
+    if (a.stats) return launch_chain_impl<NST, MAXCH, true, false>(a, st);
+    if (a.seg_target) return launch_chain_impl<NST, MAXCH, false, true>(a, st);
+    return launch_chain_impl<NST, MAXCH, false, false>(a, st);
 }
 
 }  // namespace gsn
@@ -404,13 +465,14 @@ extern "C" int gsn_mlp_chain_supported(int n_stages, const gsn_chain_stage *stag
 }
 
 extern "C" int gsn_mlp_chain_fwd_hip(int64_t m_rows, int n_stages, const gsn_chain_stage *stages, const int32_t *row_perm,
-                                     float *out, double *stats, void *stream) {
+                                     const int32_t *seg_target, float *out, double *stats, void *stream) {
     if (!gsn_mlp_chain_supported(n_stages, stages))
         return set_error(GSN_E_UNSUPPORTED, "gsn_mlp_chain_fwd_hip: shape outside the fused kernel (K<=160, n_out<=128, <=6 blocks); use gsn_linear_fwd_hip");
     if (!out && !stats) return set_error(GSN_E_INVALID, "gsn_mlp_chain_fwd_hip: neither out nor stats given");
     if (m_rows <= 0) return GSN_OK;
     ChainArgs a{};
     a.m_rows = m_rows; a.n_stages = n_stages; a.row_perm = row_perm; a.out = out; a.stats = stats;
+    a.seg_target = stats ? nullptr : seg_target;
     int nb = 0, kmax = 0;
     for (int s = 0; s < n_stages; ++s) {
         const gsn_chain_stage &g = stages[s];
@@ -436,6 +498,7 @@ extern "C" int gsn_mlp_chain_fwd_hip(int64_t m_rows, int n_stages, const gsn_cha
     const int maxch = kmax <= 80 ? 5 : 10;
     // the staging writes cover whole 32-column groups, so a row holds ceil(16*maxch / 32) * 32 floats (+1: odd pitch)
     a.pitch = (maxch * CHK + 31) / 32 * 32 + 1;
+    if (a.seg_target && a.pitch < 129) a.pitch = 129;  // the segmented-sum epilogue stages a [64][n_out <= 128] tile
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (maxch == 5) {
         if (n_stages == 1) return launch_chain<1, 5>(a, st);

@@ -120,7 +120,7 @@ __global__ void csr_fill(const int64_t *__restrict__ index, int64_t n_edges, int
 }
 
 // restore original edge order inside every segment (atomics above place them in arbitrary order)
-__global__ void csr_sort_segments(const int32_t *__restrict__ seg_ptr, int64_t n_nodes, int32_t *perm) {
+__global__ void csr_sort_segments(const int32_t *__restrict__ seg_ptr, int64_t n_nodes, int32_t *perm, int32_t *sorted_target) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_nodes) return;
     const int32_t lo = seg_ptr[t], hi = seg_ptr[t + 1];
@@ -129,6 +129,32 @@ __global__ void csr_sort_segments(const int32_t *__restrict__ seg_ptr, int64_t n
         int32_t j = i - 1;
         while (j >= lo && perm[j] > x) { perm[j + 1] = perm[j]; --j; }
         perm[j + 1] = x;
+    }
+    if (sorted_target)
+        for (int32_t i = lo; i < hi; ++i) sorted_target[i] = (int32_t)t;
+}
+
+// Output rows the fused segmented-sum epilogue (chain.hip) reaches with atomics or not at all must start at zero:
+// empty segments, and segments that straddle a 32-row boundary of the target-sorted row space.
+__global__ __launch_bounds__(256) void segsum_prepare_kernel(const int32_t *__restrict__ seg_ptr, const int32_t *__restrict__ row_target,
+                                                             int64_t n_seg, int64_t n_rows, int n_out, float *out) {
+    const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n_bound = n_rows / 32;  // boundaries at rows 32, 64, ...
+    int row = -1;
+    if (item < n_seg) {
+        if (seg_ptr[item] == seg_ptr[item + 1]) row = (int)item;
+    } else if (item - n_seg < n_bound) {
+        const int64_t r = (item - n_seg + 1) * 32;
+        if (r < n_rows && row_target[r - 1] == row_target[r]) row = row_target[r];
+    }
+    // the wave zeroes the rows its lanes found, one row at a time, all 64 lanes on the columns
+    unsigned long long m = __ballot(row >= 0);
+    const int lane = threadIdx.x & 63;
+    while (m) {
+        const int src = __ffsll(m) - 1;
+        m &= m - 1;
+        const int r = __shfl(row, src);
+        for (int c = lane; c < n_out; c += 64) out[(int64_t)r * n_out + c] = 0.f;
     }
 }
 
@@ -307,8 +333,18 @@ using namespace gsn;
 
 extern "C" int64_t gsn_csr_scratch_elems(int64_t n_nodes) { return (n_nodes + 1) + (n_nodes + 1) / SCAN_TILE + 2; }
 
+extern "C" int gsn_segsum_prepare_hip(int64_t n_seg, int64_t n_rows, const int32_t *seg_ptr, const int32_t *row_target,
+                                      int64_t n_out, float *out, void *stream) {
+    if (!seg_ptr || !out || (n_rows > 0 && !row_target) || n_out <= 0) return set_error(GSN_E_INVALID, "gsn_segsum_prepare_hip: bad argument");
+    const int64_t items = n_seg + n_rows / 32;
+    if (items <= 0) return GSN_OK;
+    hipLaunchKernelGGL(segsum_prepare_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       seg_ptr, row_target, n_seg, n_rows, (int)n_out, out);
+    return hip_check("gsn_segsum_prepare_hip");
+}
+
 extern "C" int gsn_csr_build_hip(int64_t n_nodes, int64_t n_edges, const int64_t *index, int32_t *seg_ptr, int32_t *perm,
-                                 int32_t *scratch, void *stream) {
+                                 int32_t *sorted_target, int32_t *scratch, void *stream) {
     if (n_nodes < 0 || n_edges < 0 || !seg_ptr || !scratch || (n_edges > 0 && (!index || !perm)))
         return set_error(GSN_E_INVALID, "gsn_csr_build_hip: bad argument");
     if (n_edges >= (int64_t)1 << 31 || n_nodes >= ((int64_t)1 << 31) - 1)
@@ -331,7 +367,7 @@ extern "C" int gsn_csr_build_hip(int64_t n_nodes, int64_t n_edges, const int64_t
         int64_t blocks = (n_edges + 255) / 256;
         if (blocks > 8192) blocks = 8192;
         hipLaunchKernelGGL(csr_fill, dim3((unsigned)blocks), dim3(256), 0, st, index, n_edges, cnt, perm);
-        hipLaunchKernelGGL(csr_sort_segments, dim3((unsigned)((n_nodes + 255) / 256)), dim3(256), 0, st, seg_ptr, n_nodes, perm);
+        hipLaunchKernelGGL(csr_sort_segments, dim3((unsigned)((n_nodes + 255) / 256)), dim3(256), 0, st, seg_ptr, n_nodes, perm, sorted_target);
     }
     return hip_check("gsn_csr_build_hip");
 }

@@ -81,14 +81,15 @@ def _f32c(t):
 # CSR of the aggregation index (cached per edge_index tensor)
 # ------------------------------------------------------------------------------------------------------------------
 class _CSR:
-    __slots__ = ("seg_ptr", "perm", "deg")
+    __slots__ = ("seg_ptr", "perm", "deg", "tgt")
 
 
 _CSR_CACHE = {}
 
 
-def build_csr(index, n_nodes):
-    """(seg_ptr int32 [N+1], perm int32 [E]) grouping edge ids by ``index`` (stable), via gsn_csr_build_hip."""
+def build_csr(index, n_nodes, with_targets=False):
+    """(seg_ptr int32 [N+1], perm int32 [E]) grouping edge ids by ``index`` (stable), via gsn_csr_build_hip;
+    with_targets: also sorted_target int32 [E] = index[perm]."""
     _need_cuda(index, "edge_index")
     index = index.contiguous()
     E = index.numel()
@@ -97,9 +98,12 @@ def build_csr(index, n_nodes):
     seg_ptr = torch.empty(n_nodes + 1, dtype=torch.int32, device=dev)
     perm = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
     scratch = torch.empty(int(L.gsn_csr_scratch_elems(n_nodes)), dtype=torch.int32, device=dev)
+    tgt = torch.empty(max(E, 1), dtype=torch.int32, device=dev) if with_targets else None
     with torch.cuda.device(dev), _timed("csr_build", 12.0 * E + 8.0 * n_nodes):
         _abi.check(L.gsn_csr_build_hip(n_nodes, E, index.data_ptr() if E else None, seg_ptr.data_ptr(), perm.data_ptr(),
-                                       scratch.data_ptr(), _abi.current_stream()), "gsn_csr_build_hip")
+                                       _abi.ptr(tgt), scratch.data_ptr(), _abi.current_stream()), "gsn_csr_build_hip")
+    if with_targets:
+        return seg_ptr, perm[:E], tgt[:E]
     return seg_ptr, perm[:E]
 
 
@@ -110,7 +114,7 @@ def _csr_for(edge_index, row, n_nodes):
         if len(_CSR_CACHE) > 64:
             _CSR_CACHE.clear()
         c = _CSR()
-        c.seg_ptr, c.perm = build_csr(edge_index[row], n_nodes)
+        c.seg_ptr, c.perm, c.tgt = build_csr(edge_index[row], n_nodes, with_targets=True)
         c.deg = (c.seg_ptr[1:] - c.seg_ptr[:-1]).to(torch.float32).unsqueeze(1).contiguous()
         _CSR_CACHE[key] = c
     return c
@@ -220,8 +224,10 @@ class _Stage:
         self.bn_params = None  # (mean, scale, shift) once resolved
 
 
-def _launch_stages(stages, m_rows, stats=None):
-    """Run resolved stages: fused gsn_mlp_chain_fwd_hip where it fits (<= 2 stages per launch), else stage by stage."""
+def _launch_stages(stages, m_rows, stats=None, csr=None):
+    """Run resolved stages: fused gsn_mlp_chain_fwd_hip where it fits (<= 2 stages per launch), else stage by stage.
+    With ``csr`` the rows are visited in target-sorted order and the LAST stage's rows are summed per target (fused
+    scatter-add) -> [n_nodes, n_out]; returns None if that cannot be fused (caller falls back to propagate)."""
     L = _abi.lib()
     dev = stages[0].weight.device
     y = None
@@ -259,18 +265,29 @@ def _launch_stages(stages, m_rows, stats=None):
                 group = (n, arr, keep, cand)
                 break
         last_group = group is not None and i + group[0] == len(stages)
+        if csr is not None and not (last_group and i == 0):
+            return None   # the fused scatter-add needs the whole stage list in one launch
         if group is not None:
             n, arr, keep, cand = group
             want_stats = stats is not None and last_group
             n_out = cand[-1].weight.shape[0]
-            out = None if want_stats else torch.empty((m_rows, n_out), dtype=torch.float32, device=dev)
+            seg = csr is not None and not want_stats
+            if seg:
+                n_seg = csr.seg_ptr.numel() - 1
+                out = torch.empty((n_seg, n_out), dtype=torch.float32, device=dev)
+                with torch.cuda.device(dev), _timed("segsum_prepare"):
+                    _abi.check(L.gsn_segsum_prepare_hip(n_seg, m_rows, csr.seg_ptr.data_ptr(), csr.tgt.data_ptr(), n_out,
+                                                        out.data_ptr(), _abi.current_stream()), "gsn_segsum_prepare_hip")
+            else:
+                out = None if want_stats else torch.empty((m_rows, n_out), dtype=torch.float32, device=dev)
             flops = 0.0
             kprev = 0
             for j, st in enumerate(cand):
                 flops += 2.0 * m_rows * st.weight.shape[1] * st.weight.shape[0]
             with torch.cuda.device(dev), _timed("mlp_chain%d" % n, flops):
-                rc = L.gsn_mlp_chain_fwd_hip(m_rows, n, arr, None, _abi.ptr(out), _abi.ptr(stats) if want_stats else None,
-                                             _abi.current_stream())
+                rc = L.gsn_mlp_chain_fwd_hip(m_rows, n, arr, csr.perm.data_ptr() if csr is not None else None,
+                                             csr.tgt.data_ptr() if seg else None, _abi.ptr(out),
+                                             _abi.ptr(stats) if want_stats else None, _abi.current_stream())
             _abi.check(rc, "gsn_mlp_chain_fwd_hip")
             y = out
             i += n
@@ -286,6 +303,23 @@ def _launch_stages(stages, m_rows, stats=None):
                 y = _linear_hip(blks, st.weight, st.bias, bp[0], bp[1], bp[2], _ACT_CODE[st.act], m_rows)
             i += 1
     return y
+
+
+def _chain_fits(stages):
+    """True if the whole stage list runs as ONE gsn_mlp_chain_fwd_hip launch (needed for the fused scatter-add)."""
+    n = len(stages)
+    if n < 1 or n > 2:
+        return False
+    arr = (_abi.gsn_chain_stage * n)()
+    keep = []
+    for j, st in enumerate(stages):
+        barr = (_abi.gsn_block * max(len(st.blocks), 1))()
+        for b, (d, idx) in enumerate(st.blocks):
+            barr[b].data = 1; barr[b].idx = None; barr[b].width = d.shape[1]
+        keep.append(barr)
+        arr[j].blocks = barr; arr[j].n_blocks = len(st.blocks)
+        arr[j].W = 1; arr[j].n_out = st.weight.shape[0]; arr[j].act = _ACT_CODE[st.act]
+    return bool(_abi.lib().gsn_mlp_chain_supported(n, arr))
 
 
 def _bn_resolve(stage, stats_fn, m_rows, training):
@@ -316,9 +350,12 @@ def _bn_resolve(stage, stats_fn, m_rows, training):
     stage.bn_params = (mean32, scale, shift)
 
 
-def run_stages(stages, m_rows, training):
+def run_stages(stages, m_rows, training, csr=None):
     """Evaluate a list of _Stage on the HIP kernels.  A train-mode BatchNorm1d stage costs one extra statistics pass over
-    the chain prefix that ends at it (the prefix is recomputed, nothing is stored)."""
+    the chain prefix that ends at it (the prefix is recomputed, nothing is stored).  ``csr``: fuse the scatter-add
+    (returns None, before touching any BatchNorm state, if the stages do not fit one fused launch)."""
+    if csr is not None and not _chain_fits(stages):
+        return None
     for i, st in enumerate(stages):
         if st.bn is not None:
             def stats_fn(i=i):
@@ -328,7 +365,7 @@ def run_stages(stages, m_rows, training):
                 _launch_stages(stages[:i] + [probe], m_rows, stats=stats)
                 return stats
             _bn_resolve(st, stats_fn, m_rows, training)
-    return _launch_stages(stages, m_rows)
+    return _launch_stages(stages, m_rows, csr=csr)
 
 
 class mlp(nn.Module):
@@ -363,8 +400,8 @@ class mlp(nn.Module):
                               "identity" if last else self.activation_name, blocks if i == 0 else ()))
         return out
 
-    def hip_forward(self, blocks, m_rows, upto=None, first_weight=None, first_bias=None):
-        return run_stages(self.stages(blocks, upto, first_weight, first_bias), m_rows, self.training)
+    def hip_forward(self, blocks, m_rows, upto=None, first_weight=None, first_bias=None, csr=None):
+        return run_stages(self.stages(blocks, upto, first_weight, first_bias), m_rows, self.training, csr=csr)
 
     # -- differentiable PyTorch twin (used to back-propagate through the dense stages)
     def torch_forward(self, x, upto=None):
@@ -614,9 +651,11 @@ class _SparseLayer(nn.Module):
             # commutes with the sum:  agg = W2 S + deg*b2, and it feeds update_fn's first Linear (weights [W3x | W3a]):
             #     [x | agg] W3^T = x W3x^T + S (W3a W2)^T + deg (W3a b2)^T
             # so it is folded into that Linear's weight (a [d_h x d_msg] by [d_msg x d_h] product, once per call).
-            r = mf.hip_forward(blocks, E, upto=len(mf.fc) - 1)
-            s_agg = propagate(0, edge_index, sel, n, b=r)
             csr = _csr_for(edge_index, sel, n)
+            s_agg = mf.hip_forward(blocks, E, upto=len(mf.fc) - 1, csr=csr) if E > 0 else None   # scatter-add fused
+            if s_agg is None:
+                r = mf.hip_forward(blocks, E, upto=len(mf.fc) - 1)
+                s_agg = propagate(0, edge_index, sel, n, b=r)
             last = mf.fc[-1]
             d_x = x.shape[1]
             w3 = uf.fc[0].weight.detach()

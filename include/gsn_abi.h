@@ -106,11 +106,12 @@ int gsn_count_hip(const uint32_t *plan_host, const uint32_t *plan_dev, int64_t p
  * target-sorted edge permutation.  This builds that CSR once per batch (stable counting sort by target):
  *   index   int64 device [E]  aggregation targets (edge_index[1] for flow=source_to_target, [0] otherwise)
  *   seg_ptr int32 device [N+1] out; perm int32 device [E] out (edge ids grouped by target, original order kept inside)
+ *   sorted_target int32 device [E] out or NULL: sorted_target[q] = index[perm[q]] (the target of the q-th sorted edge)
  *   scratch int32 device [gsn_csr_scratch_elems(N)]
  * ---------------------------------------------------------------------------------------------------------------- */
 int64_t gsn_csr_scratch_elems(int64_t n_nodes);
 int gsn_csr_build_hip(int64_t n_nodes, int64_t n_edges, const int64_t *index, int32_t *seg_ptr, int32_t *perm,
-                      int32_t *scratch, void *stream);
+                      int32_t *sorted_target, int32_t *scratch, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * HP-2  propagate: fused gather -> message -> segmented sum (device, fp32).
@@ -173,7 +174,7 @@ int gsn_linear_fwd_hip(int64_t m_rows, int n_blocks, const gsn_block *blocks, co
  * gsn_mlp_chain_supported() tells whether a chain fits the fused kernel (<= 2 stages, every K_s <= 160, n_out_s <= 128,
  * at most 6 blocks, stage-1 blocks <= 64 columns, activations identity / relu); otherwise run the stages one by one
  * with gsn_linear_fwd_hip.
- * ---------------------------------------------------------------------------------------------------------------- */
+ */
 typedef struct {
     const gsn_block *blocks;
     int n_blocks;
@@ -184,9 +185,18 @@ typedef struct {
     int act;
 } gsn_chain_stage;
 
+/* Fused scatter-add: with `seg_target` (int32 [M], the target of every row, rows visited in target-sorted order through
+ * row_perm = perm and seg_target = sorted_target of gsn_csr_build_hip) the last stage's rows are summed per target
+ * inside the kernel and `out` is [n_seg][n_out_last] -- the torch.sparse.sum of GSN_sparse.py:140-143 without writing
+ * the [E, d] messages.  `out` must first be prepared with gsn_segsum_prepare_hip (zeroes the rows of empty segments
+ * and of segments that straddle a 32-row boundary, which the kernel adds to atomically; all other rows are plain stores,
+ * so a segment's summation order is its row order except for segments longer than 32 rows).
+ * ---------------------------------------------------------------------------------------------------------------- */
 int gsn_mlp_chain_supported(int n_stages, const gsn_chain_stage *stages);
 int gsn_mlp_chain_fwd_hip(int64_t m_rows, int n_stages, const gsn_chain_stage *stages, const int32_t *row_perm,
-                          float *out, double *stats, void *stream);
+                          const int32_t *seg_target, float *out, double *stats, void *stream);
+int gsn_segsum_prepare_hip(int64_t n_seg, int64_t n_rows, const int32_t *seg_ptr, const int32_t *row_target,
+                           int64_t n_out, float *out, void *stream);
 
 #ifdef __cplusplus
 }
