@@ -3,8 +3,8 @@
 
 One "step" = one pass over one batch of G synthetic ZINC-shaped graphs resident in HBM:
     (1) gsn_count_hip           cycle_graph k = 3..6, id_scope=local (GSN-e), non-induced  -> int64 [E, 4]
-    (2) identifier encoding      per-column one-hot of min(count, 2)  -> float [E, 12]   (PyTorch glue, in the timed region;
-                                 the reference does this in DiscreteEmbedding('one_hot_encoder'), utils_graph_learning.py:78)
+    (2) gsn_one_hot_hip          per-column one-hot of min(count, 2)  -> float [E, 12]   (the reference does this in
+                                 DiscreteEmbedding('one_hot_encoder'), utils_graph_learning.py:78 / :170-187)
     (3) GSN_edge_sparse forward  layer 0 of BASELINE config 2: msg_kind=general, d_in=28, d_ef=4, d_id=12, d_h=d_msg=d_up=128,
                                  bn=True, eval mode; includes building the target-sorted CSR (cache cleared every step)
 Prints ONE JSON line (rank 0).  Multi-GPU: one process per GPU (torch.distributed / RCCL only for the barrier and the
@@ -147,8 +147,7 @@ def main():
         with layers._timed("count", 16.0 * E + 8.0 * E * plan.n_cols):
             count_batch(plan, node_ptr, edge_ptr, ei, ids_are_global=True, max_nodes=max_nodes, max_edges=max_edges,
                         device=dev, out=ids_out, check=False)
-        with layers._timed("encode_ids"):
-            idf = torch.nn.functional.one_hot(ids_out.clamp(max=2), 3).reshape(E, 12).float()
+        idf = layers.one_hot_identifiers(ids_out, [3, 3, 3, 3], clamp=True)   # [E, 12] fp32 (gsn_one_hot_hip)
         with torch.no_grad():
             return layer(x, ei, identifiers=idf, degrees=degrees, edge_features=ef)
 

@@ -25,7 +25,7 @@ class GsnError(RuntimeError):
 
 
 class gsn_block(ctypes.Structure):
-    _fields_ = [("data", c_vp), ("idx", c_vp), ("width", c_i64)]
+    _fields_ = [("data", c_vp), ("idx", c_vp), ("width", c_i64), ("idx32", c_vp)]
 
 
 class gsn_chain_stage(ctypes.Structure):
@@ -43,7 +43,7 @@ SIGNATURES = {
     "gsn_count_hip": (c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_i64, c_i64,
                               c_vp, c_vp, c_vp]),
     "gsn_csr_scratch_elems": (c_i64, [c_i64]),
-    "gsn_csr_build_hip": (c_int, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "gsn_csr_build_hip": (c_int, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "gsn_segsum_prepare_hip": (c_int, [c_i64, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp]),
     "gsn_propagate_fwd_hip": (c_int, [c_int, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_vp,
                                       c_i64, c_vp, c_vp]),
@@ -51,6 +51,7 @@ SIGNATURES = {
                                       c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "gsn_linear_fwd_hip": (c_int, [c_i64, c_int, ctypes.POINTER(gsn_block), c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_int,
                                    c_vp, c_vp, c_vp, c_vp]),
+    "gsn_one_hot_hip": (c_int, [c_i64, c_int, c_vp, c_vp, c_int, c_vp, c_vp]),
     "gsn_mlp_chain_supported": (c_int, [c_int, ctypes.POINTER(gsn_chain_stage)]),
     "gsn_mlp_chain_fwd_hip": (c_int, [c_i64, c_int, ctypes.POINTER(gsn_chain_stage), c_vp, c_vp, c_vp, c_vp, c_vp]),
 }

@@ -20,6 +20,8 @@
 // stage s >= 1 at most 64 columns; anything else goes through linear.hip.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "gsn_internal.h"
 
 namespace gsn {
@@ -28,7 +30,6 @@ constexpr int CBM = 64;         // rows per tile
 constexpr int CHK = 16;         // k per register chunk (8 k-steps of 2)
 constexpr int CMAX_BLOCKS = 6;  // input blocks over all stages
 constexpr int CMAX_STAGES = 2;  // 3 stages x 80 weight registers per lane would spill
-constexpr int PF1_J = 2;        // stage>=1 HBM part: up to 2 x 32 columns
 
 struct ChainStage {
     const float *W, *bias, *bn_mean, *bn_scale, *bn_shift;
@@ -41,6 +42,7 @@ struct ChainArgs {
     int n_stages, n_blocks;
     const float *bdata[CMAX_BLOCKS];
     const int64_t *bidx[CMAX_BLOCKS];
+    const int32_t *bidx32[CMAX_BLOCKS];
     int bwidth[CMAX_BLOCKS];
     ChainStage st[CMAX_STAGES];
     const int32_t *row_perm;
@@ -48,6 +50,7 @@ struct ChainArgs {
     float *out;                 // [m_rows][n_out], or [n_seg][n_out] segment sums when seg_target is given
     double *stats;              // statistics of the LAST stage's pre-BN values instead of an output
     int pitch;                  // LDS row pitch in floats (odd)
+    int dbg;                    // ablation switches for profiling (env GSN_CHAIN_DBG): 1 no prefetch loads, 2 no MFMA, 4 no output
 };
 
 constexpr int RS_STRIDE = (CMAX_BLOCKS + 1) * CBM + 2;  // per slot: row sources per block, row targets, prev / next target
@@ -112,7 +115,7 @@ __device__ __forceinline__ void rs_fetch(const ChainArgs &a, int64_t row0, int t
 #pragma unroll
         for (int b = 0; b < CMAX_BLOCKS; ++b) {
             int r = -1;
-            if (b < a.n_blocks && ok) r = a.bidx[b] ? (int)a.bidx[b][logical] : (int)logical;
+            if (b < a.n_blocks && ok) r = a.bidx32[b] ? a.bidx32[b][logical] : (a.bidx[b] ? (int)a.bidx[b][logical] : (int)logical);
             rs.v[b] = r;
         }
         rs.tg = -1; rs.edge = -2;
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     const int pitch = a.pitch;
     float *buf0 = lds;
     float *buf1 = lds + CBM * pitch;
-    int *rsrc = reinterpret_cast<int *>(lds + 2 * CBM * pitch);  // [2][RS_STRIDE]
+    int *rsrc = reinterpret_cast<int *>(lds + 2 * CBM * pitch);  // [3][RS_STRIDE] ring: tiles t, t+1, t+2
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
@@ -173,39 +176,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
             }
     }
 
-    // ---- per-thread column maps of the HBM parts ----------------------------------------------------------------
+    // ---- per-thread column maps of the stage-0 input ------------------------------------------------------------
     ColMap cm0[PF0_J];
 #pragma unroll
     for (int j = 0; j < PF0_J; ++j) cm0[j] = col_map(a, 0, kc0 + 32 * j);
-    ColMap cm1[PF1_J];
-    if (NST > 1) {
-#pragma unroll
-        for (int j = 0; j < PF1_J; ++j) cm1[j] = col_map(a, 1, kc0 + 32 * j);
-    }
 
     // zero both activation tiles once: padded columns must hold finite values (their weights are zero)
     for (int i = tid; i < 2 * CBM * pitch; i += 256) lds[i] = 0.f;
 
     // per-stage epilogue constants of this lane's output column (loaded once: a load inside the tile loop would put a
     // vmcnt(0) in front of every use and drain the prefetch / the stores)
-    float e_bias[NST], e_mean[NST], e_scale[NST], e_shift[NST];
+    float e_bias[NST], e_scale[NST], e_c0[NST];   // y = acc * scale + c0,  c0 = (bias - mean) * scale + shift
 #pragma unroll
     for (int s = 0; s < NST; ++s) {
         const ChainStage &st = a.st[s];
         const int col = 32 * w + li;
         const bool cok = col < st.n_out;
         e_bias[s] = (cok && st.bias) ? st.bias[col] : 0.f;
-        e_mean[s] = 0.f; e_scale[s] = 1.f; e_shift[s] = 0.f;
-        if (cok && st.bn_scale) { e_mean[s] = st.bn_mean[col]; e_scale[s] = st.bn_scale[col]; e_shift[s] = st.bn_shift[col]; }
+        e_scale[s] = 1.f; e_c0[s] = e_bias[s];
+        if (cok && st.bn_scale) { e_scale[s] = st.bn_scale[col]; e_c0[s] = (e_bias[s] - st.bn_mean[col]) * e_scale[s] + st.bn_shift[col]; }
     }
 
     double st_sum = 0.0, st_sq = 0.0;
-    float pf0[PF0_J][8], pf1[PF1_J][8];
+    float pf0[PF0_J][8];
     RowSrcC rsn;
 
     // NOTE: the loaded values are kept RAW in the prefetch registers; masking (padded columns, rows past the end) is
-    // applied when they are written to LDS one tile later.  Selecting on the value right here would make the compiler
-    // wait for every load immediately after issuing it (vmcnt countdown) and serialise the prefetch.
+    // applied when they are written to LDS.  Selecting on the value right here would make the compiler wait for every
+    // load immediately after issuing it (vmcnt countdown) and serialise the prefetch.
     auto prefetch = [&](const int *rs) {
 #pragma unroll
         for (int j = 0; j < PF0_J; ++j)
@@ -214,61 +212,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
                 const int sr = rs[cm0[j].rsoff + r0 + 8 * i];
                 pf0[j][i] = cm0[j].base[(int64_t)(sr < 0 ? 0 : sr) * cm0[j].bw];
             }
-        if (NST > 1) {
+    };
+    // prefetched rows -> LDS.  No masking needed: a padded column (k >= K) holds a finite clamped-address value and meets a
+    // zero weight; a row past the end holds row 0's values and is never emitted (store guard / target -1 / stats guard).
+    auto stage_in = [&](float *dst) {
 #pragma unroll
-            for (int j = 0; j < PF1_J; ++j)
-                if (a.st[1].k_hbm > 32 * j) {
+        for (int j = 0; j < PF0_J; ++j)
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const int sr = rs[cm1[j].rsoff + r0 + 8 * i];
-                        pf1[j][i] = cm1[j].base[(int64_t)(sr < 0 ? 0 : sr) * cm1[j].bw];
-                    }
-                }
-        }
+            for (int i = 0; i < 8; ++i) dst[(r0 + 8 * i) * pitch + kc0 + 32 * j] = pf0[j][i];
     };
 
-    // ---- prologue: row sources of the first two tiles, inputs of the first tile --------------------------------------
+    // ---- prologue: row sources of the first two tiles; the first tile's inputs go to LDS synchronously -------------------
     int64_t tile = blockIdx.x;
     {
         RowSrcC r;
         rs_fetch(a, tile * CBM, tid, r);
         rs_store(rsrc, tid, r);
-        rs_fetch(a, (tile + gridDim.x) * CBM, tid, rsn);
+        rs_fetch(a, (tile + gridDim.x) * CBM, tid, r);
+        rs_store(rsrc + RS_STRIDE, tid, r);
     }
     __syncthreads();
     if (tile < n_tiles) prefetch(rsrc);
-    int slot = 0;
+    if (tile < n_tiles) stage_in(buf0);
+    __syncthreads();
+    int slot = 0;      // row-source table slot of the CURRENT tile; (slot+1)%3: next tile; (slot+2)%3: tile after next
+    int cur = 0;       // NST == 1: which buffer holds the current tile's input (they alternate); NST == 2: always buf0
 
+    // Tile pipeline (per wave):   issue loads of tile t+1  |  MFMA(t)  |  loads(t+1) -> LDS  |  stores / atomics of tile t
+    // The only vmcnt wait sits AFTER the MFMA phase and BEFORE this tile's stores are issued, so it never waits for a
+    // store: the stores of tile t complete under the MFMAs of tile t+1 (vmcnt is in-order and the compiler cannot count
+    // the data-dependent stores of the segmented epilogue, i.e. a wait placed after them would drain them).
     for (; tile < n_tiles; tile += gridDim.x) {
         const int64_t row0 = tile * CBM;
-        lds_barrier();  // every wave is done with the previous tile's buffers
-        // step 1: this tile's prefetched inputs -> LDS (masked here, see prefetch); next tile's row sources -> table
-#pragma unroll
-        for (int j = 0; j < PF0_J; ++j)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const bool ok = cm0[j].ok && (row0 + r0 + 8 * i < a.m_rows);
-                buf0[(r0 + 8 * i) * pitch + kc0 + 32 * j] = ok ? pf0[j][i] : 0.f;
-            }
-        if (NST > 1) {
-#pragma unroll
-            for (int j = 0; j < PF1_J; ++j)
-                if (a.st[1].k_hbm > 32 * j) {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const bool ok = cm1[j].ok && (row0 + r0 + 8 * i < a.m_rows);
-                        buf1[(r0 + 8 * i) * pitch + kc0 + 32 * j] = ok ? pf1[j][i] : 0.f;
-                    }
-                }
-        }
-        rs_store(rsrc + (slot ^ 1) * RS_STRIDE, tid, rsn);
-        lds_barrier();
-        // step 2: issue the next tile's loads (they land while this tile computes); indices two tiles ahead
-        rs_fetch(a, (tile + 2 * (int64_t)gridDim.x) * CBM, tid, rsn);   // (before the prefetch: its dependent index load must
-        if (tile + gridDim.x < n_tiles) prefetch(rsrc + (slot ^ 1) * RS_STRIDE);   //  not wait behind 40 loads)
-        slot ^= 1;
+        const bool has_next = tile + gridDim.x < n_tiles;
+        float *in0 = (NST == 1 && cur) ? buf1 : buf0;         // stage-0 input of this tile
+        float *other = (NST == 1 && cur) ? buf0 : buf1;       // NST==1: next tile's input; NST==2: stage-1 input
+        const int slot_n = slot == 2 ? 0 : slot + 1, slot_nn = slot_n == 2 ? 0 : slot_n + 1;
+        if (has_next && !(a.dbg & 1)) prefetch(rsrc + slot_n * RS_STRIDE);       // lands under the MFMAs below
+        rs_fetch(a, (tile + 2 * (int64_t)gridDim.x) * CBM, tid, rsn);         // row sources two tiles ahead
 
-        float *in = buf0, *nxt = buf1;
+        float *in = in0;
 #pragma unroll
         for (int s = 0; s < NST; ++s) {
             const ChainStage &st = a.st[s];
@@ -276,7 +259,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
             f32x16 acc0, acc1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-            if (active) {
+            if (active && !(a.dbg & 2)) {
                 const float *ap0 = in + li * pitch + lh;
                 const float *ap1 = ap0 + 32 * pitch;
 #pragma unroll
@@ -295,10 +278,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
             // (activation switch hoisted out of the 32-element loops) so the stores / LDS writes issue back to back.
             const int col = 32 * w + li;
             const bool cok = col < st.n_out;
-            const float bias = e_bias[s], mean = e_mean[s], scale = e_scale[s], shift = e_shift[s];
+            const float bias = e_bias[s], scale = e_scale[s], c0 = e_c0[s];
             const bool last = s == NST - 1;
-            auto value = [&](int rf, int r) { return ((rf ? acc1[r] : acc0[r]) + bias - mean) * scale + shift; };
-            if (last && STATS) {
+            auto value = [&](int rf, int r) { return fmaf(rf ? acc1[r] : acc0[r], scale, c0); };
+            if (!last) {
+                // stage output -> the next stage's LDS input tile
+                float *lp = buf1 + (4 * lh) * pitch + col;
+                if (cok) {
+                    if (st.act == 1) {
+#pragma unroll
+                        for (int rf = 0; rf < 2; ++rf)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) { const float y = value(rf, r); lp[(rf * 32 + (r & 3) + 8 * (r >> 2)) * pitch] = y > 0.f ? y : 0.f; }
+                    } else {
+#pragma unroll
+                        for (int rf = 0; rf < 2; ++rf)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) lp[(rf * 32 + (r & 3) + 8 * (r >> 2)) * pitch] = value(rf, r);
+                    }
+                }
+                lds_barrier();
+                in = buf1;
+                continue;
+            }
+            // ---- last stage ------------------------------------------------------------------------------------------
+            // where the next tile's input goes: NST==1 -> the other buffer; NST==2 -> buf0 (free since the barrier above)
+            float *next_in = (NST == 1) ? other : buf0;
+            if (STATS) {
+                if (has_next) stage_in(next_in);
+                rs_store(rsrc + slot_nn * RS_STRIDE, tid, rsn);   // row sources of tile t+2
 #pragma unroll
                 for (int rf = 0; rf < 2; ++rf)
 #pragma unroll
@@ -307,12 +315,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
                         const float h = (rf ? acc1[r] : acc0[r]) + bias;
                         if (cok && row < a.m_rows) { st_sum += (double)h; st_sq += (double)h * (double)h; }
                     }
-            } else if (last && SEG) {
-                // segmented-sum epilogue (the scatter-add of the layer, fused): activated tile -> LDS, then every thread
-                // reduces one column over 32 consecutive rows, whose targets are sorted; a segment that lies inside
-                // the 32-row range is stored, one that straddles a range boundary is added atomically (its output row
-                // was zeroed by gsn_segsum_prepare_hip).  Summation order inside a segment = row order.
-                float *Y = nxt + (4 * lh) * pitch + col;
+                lds_barrier();
+            } else if (SEG) {
+                // segmented-sum epilogue (the scatter-add of the layer, fused): activated tile -> LDS (over this stage's
+                // own input tile, once every wave is done reading it), then every thread reduces one column over 32
+                // consecutive rows, whose targets are sorted; a segment that lies inside the 32-row range is stored, one
+                // that straddles a range boundary is added atomically (its output row was zeroed by
+                // gsn_segsum_prepare_hip).  Summation order inside a segment = row order.
+                lds_barrier();                                   // all waves finished the MFMAs on `in`
+                float *Y = in + (4 * lh) * pitch + col;
                 if (cok) {
                     if (st.act == 1) {
 #pragma unroll
@@ -326,38 +337,49 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
                             for (int r = 0; r < 16; ++r) Y[(rf * 32 + (r & 3) + 8 * (r >> 2)) * pitch] = value(rf, r);
                     }
                 }
-                lds_barrier();
+                if (has_next) stage_in(next_in);     // (the one vmcnt wait of the tile: before any store)
+                rs_store(rsrc + slot_nn * RS_STRIDE, tid, rsn);  // row sources of tile t+2
                 const int c = tid & 127, rb = (tid >> 7) * 32;
-                if (c < st.n_out) {
-                    const int *tg = rsrc + (slot ^ 1) * RS_STRIDE + CMAX_BLOCKS * CBM;   // this tile's targets
-                    const int prev_t = rb > 0 ? tg[rb - 1] : tg[CBM];
-                    const int next_t = rb + 32 < CBM ? tg[rb + 32] : tg[CBM + 1];
-                    const float *yp = nxt + rb * pitch + c;
+                const int *tg = rsrc + slot * RS_STRIDE + CMAX_BLOCKS * CBM;   // this tile's targets
+                int tgl[32];
+                const int prev_t = rb > 0 ? tg[rb - 1] : tg[CBM];
+                const int next_t = rb + 32 < CBM ? tg[rb + 32] : tg[CBM + 1];
+#pragma unroll
+                for (int r = 0; r < 32; ++r) tgl[r] = tg[rb + r];
+                lds_barrier();
+                if (c < st.n_out && !(a.dbg & 4)) {
+                    const float *yp = in + rb * pitch + c;
                     float *op = a.out + c;
-                    int cur = tg[rb];
-                    bool straddle = cur == prev_t;
+                    int curt = tgl[0];
+                    bool straddle = curt == prev_t;
                     float sum = 0.f;
+#pragma unroll
                     for (int r = 0; r < 32; ++r) {
-                        const int t = tg[rb + r];
-                        if (t != cur) {
-                            if (cur >= 0) {
-                                if (straddle) atomicAdd(op + (int64_t)cur * st.n_out, sum);
-                                else op[(int64_t)cur * st.n_out] = sum;
+                        const int t = tgl[r];
+                        if (t != curt) {
+                            if (curt >= 0) {
+                                if (straddle) atomicAdd(op + (int64_t)curt * st.n_out, sum);
+                                else op[(int64_t)curt * st.n_out] = sum;
                             }
-                            cur = t; sum = 0.f; straddle = false;
+                            curt = t; sum = 0.f; straddle = false;
                         }
                         sum += yp[r * pitch];
                     }
-                    if (cur >= 0) {
-                        if (straddle || cur == next_t) atomicAdd(op + (int64_t)cur * st.n_out, sum);
-                        else op[(int64_t)cur * st.n_out] = sum;
+                    if (curt >= 0) {
+                        if (straddle || curt == next_t) atomicAdd(op + (int64_t)curt * st.n_out, sum);
+                        else op[(int64_t)curt * st.n_out] = sum;
                     }
                 }
-            } else if (last) {
+                // next tile's MFMAs read `next_in` (complete before the barrier above); its own pre-Y barrier orders the
+                // reduction above against the following writes into `in`
+            } else {
+                if (has_next) stage_in(next_in);     // (the one vmcnt wait of the tile: before any store)
+                rs_store(rsrc + slot_nn * RS_STRIDE, tid, rsn);  // row sources of tile t+2
                 float *op = a.out + (row0 + 4 * lh) * st.n_out + col;
                 const bool full = row0 + CBM <= a.m_rows;
                 auto emit = [&](auto actf) {
-                    if (full) {
+                    if (a.dbg & 4) {
+                    } else if (full) {
                         if (cok) {
 #pragma unroll
                             for (int rf = 0; rf < 2; ++rf)
@@ -379,24 +401,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
                     case 1: emit([](float y) { return y > 0.f ? y : 0.f; }); break;
                     default: emit([](float y) { return y; }); break;
                 }
-            } else {
-                float *lp = nxt + (4 * lh) * pitch + a.st[s + 1].k_hbm + col;
-                auto emit = [&](auto actf) {
-                    if (cok) {
-#pragma unroll
-                        for (int rf = 0; rf < 2; ++rf)
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) lp[(rf * 32 + (r & 3) + 8 * (r >> 2)) * pitch] = actf(value(rf, r));
-                    }
-                };
-                switch (st.act) {
-                    case 1: emit([](float y) { return y > 0.f ? y : 0.f; }); break;
-                    default: emit([](float y) { return y; }); break;
-                }
-                lds_barrier();
-                float *t = in; in = nxt; nxt = t;
+                lds_barrier();   // next tile's input tile + row-source table complete
             }
         }
+        slot = slot_n;
+        cur ^= 1;
     }
 
     if (STATS) {
@@ -417,7 +426,7 @@ static int launch_chain_impl(const ChainArgs &a, hipStream_t st) {
     constexpr bool W2 = (NST == 1 && MAXCH == 5);
     constexpr int WPE = W2 ? 2 : 1;
     const void *fn = reinterpret_cast<const void *>(&mlp_chain_kernel<NST, MAXCH, STATS, WPE, SEG>);
-    const size_t lds = (size_t)2 * CBM * a.pitch * 4 + 2 * RS_STRIDE * 4;
+    const size_t lds = (size_t)2 * CBM * a.pitch * 4 + 3 * RS_STRIDE * 4;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e0 = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -425,7 +434,8 @@ static int launch_chain_impl(const ChainArgs &a, hipStream_t st) {
         attr_set = true;
     }
     const int64_t n_tiles = (a.m_rows + CBM - 1) / CBM;
-    const int per_cu = (W2 && lds <= 72 * 1024) ? 2 : 1;
+    int per_cu = (W2 && lds <= 72 * 1024) ? 2 : 1;
+    { const char *d = getenv("GSN_CHAIN_PERCU"); if (d) per_cu = atoi(d); }
     int64_t gx = 256 * per_cu;
     if (gx > n_tiles) gx = n_tiles;
     hipLaunchKernelGGL((mlp_chain_kernel<NST, MAXCH, STATS, WPE, SEG>), dim3((unsigned)gx), dim3(256), lds, st, a);
@@ -459,7 +469,7 @@ extern "C" int gsn_mlp_chain_supported(int n_stages, const gsn_chain_stage *stag
         // spill the weight fragments around it, so those activations go through gsn_linear_fwd_hip instead
         if (stages[s].act != 0 && stages[s].act != 1) return 0;
         if (s == 0 && stages[s].n_blocks < 1) return 0;
-        if (s == 1 && k_hbm > 32 * PF1_J) return 0;
+        if (s >= 1 && k_hbm > 0) return 0;   // later stages take only the previous stage's output
     }
     return nb <= CMAX_BLOCKS ? 1 : 0;
 }
@@ -473,6 +483,7 @@ extern "C" int gsn_mlp_chain_fwd_hip(int64_t m_rows, int n_stages, const gsn_cha
     ChainArgs a{};
     a.m_rows = m_rows; a.n_stages = n_stages; a.row_perm = row_perm; a.out = out; a.stats = stats;
     a.seg_target = stats ? nullptr : seg_target;
+    { const char *d = getenv("GSN_CHAIN_DBG"); a.dbg = d ? atoi(d) : 0; }
     int nb = 0, kmax = 0;
     for (int s = 0; s < n_stages; ++s) {
         const gsn_chain_stage &g = stages[s];
@@ -486,7 +497,7 @@ extern "C" int gsn_mlp_chain_fwd_hip(int64_t m_rows, int n_stages, const gsn_cha
         int k_hbm = 0;
         for (int b = 0; b < g.n_blocks; ++b) {
             if (!g.blocks[b].data || g.blocks[b].width <= 0) return set_error(GSN_E_INVALID, "gsn_mlp_chain_fwd_hip: stage %d block %d is empty", s, b);
-            a.bdata[nb] = g.blocks[b].data; a.bidx[nb] = g.blocks[b].idx; a.bwidth[nb] = (int)g.blocks[b].width;
+            a.bdata[nb] = g.blocks[b].data; a.bidx[nb] = g.blocks[b].idx; a.bidx32[nb] = g.blocks[b].idx32; a.bwidth[nb] = (int)g.blocks[b].width;
             k_hbm += (int)g.blocks[b].width;
             ++nb;
         }

@@ -29,6 +29,7 @@ struct LinArgs {
     int n_blocks, n_chunks;
     const float *bdata[MAX_BLOCKS];
     const int64_t *bidx[MAX_BLOCKS];
+    const int32_t *bidx32[MAX_BLOCKS];
     int bwidth[MAX_BLOCKS];
     // chunk c: block, column offset inside the block, length (<= BK), k offset inside a row of W
     unsigned char cblock[MAX_CHUNKS], clen[MAX_CHUNKS];
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256) void linear_fwd_stream_kernel(LinArgs a) {
             if (grow < a.m_rows) logical = a.row_perm ? (int64_t)a.row_perm[grow] : grow;
 #pragma unroll
             for (int b = 0; b < MAX_BLOCKS; ++b)
-                if (b < a.n_blocks) rowsrc[b][tid] = (grow < a.m_rows) ? (a.bidx[b] ? a.bidx[b][logical] : logical) : -1;
+                if (b < a.n_blocks) rowsrc[b][tid] = (grow < a.m_rows) ? (a.bidx32[b] ? (int64_t)a.bidx32[b][logical] : (a.bidx[b] ? a.bidx[b][logical] : logical)) : -1;
         }
         f32x16 acc[2][2];
 #pragma unroll
@@ -194,7 +195,7 @@ __device__ __forceinline__ void rowsrc_fetch(const LinArgs &a, int64_t row0, int
 #pragma unroll
         for (int b = 0; b < MAX_BLOCKS; ++b) {
             int r = -1;
-            if (b < a.n_blocks && ok) r = a.bidx[b] ? (int)a.bidx[b][logical] : (int)logical;
+            if (b < a.n_blocks && ok) r = a.bidx32[b] ? a.bidx32[b][logical] : (a.bidx[b] ? (int)a.bidx[b][logical] : (int)logical);
             rs.v[b] = r;
         }
     }
@@ -395,7 +396,7 @@ extern "C" int gsn_linear_fwd_hip(int64_t m_rows, int n_blocks, const gsn_block 
     for (int b = 0; b < n_blocks; ++b) {
         if (!blocks[b].data || blocks[b].width <= 0 || blocks[b].width > 32767)
             return set_error(GSN_E_INVALID, "gsn_linear_fwd_hip: block %d has no data or a bad width", b);
-        a.bdata[b] = blocks[b].data; a.bidx[b] = blocks[b].idx; a.bwidth[b] = (int)blocks[b].width;
+        a.bdata[b] = blocks[b].data; a.bidx[b] = blocks[b].idx; a.bidx32[b] = blocks[b].idx32; a.bwidth[b] = (int)blocks[b].width;
         for (int off = 0; off < (int)blocks[b].width; off += BK) {
             if (nc >= MAX_CHUNKS) return set_error(GSN_E_UNSUPPORTED, "gsn_linear_fwd_hip: input wider than %d chunks of %d", MAX_CHUNKS, BK);
             const int len = (int)blocks[b].width - off < BK ? (int)blocks[b].width - off : BK;

@@ -120,7 +120,8 @@ __global__ void csr_fill(const int64_t *__restrict__ index, int64_t n_edges, int
 }
 
 // restore original edge order inside every segment (atomics above place them in arbitrary order)
-__global__ void csr_sort_segments(const int32_t *__restrict__ seg_ptr, int64_t n_nodes, int32_t *perm, int32_t *sorted_target) {
+__global__ void csr_sort_segments(const int32_t *__restrict__ seg_ptr, int64_t n_nodes, int32_t *perm, int32_t *sorted_target,
+                                  const int64_t *__restrict__ other, int32_t *sorted_other) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_nodes) return;
     const int32_t lo = seg_ptr[t], hi = seg_ptr[t + 1];
@@ -132,6 +133,8 @@ __global__ void csr_sort_segments(const int32_t *__restrict__ seg_ptr, int64_t n
     }
     if (sorted_target)
         for (int32_t i = lo; i < hi; ++i) sorted_target[i] = (int32_t)t;
+    if (sorted_other)
+        for (int32_t i = lo; i < hi; ++i) sorted_other[i] = (int32_t)other[perm[i]];
 }
 
 // Output rows the fused segmented-sum epilogue (chain.hip) reaches with atomics or not at all must start at zero:
@@ -343,8 +346,9 @@ extern "C" int gsn_segsum_prepare_hip(int64_t n_seg, int64_t n_rows, const int32
     return hip_check("gsn_segsum_prepare_hip");
 }
 
-extern "C" int gsn_csr_build_hip(int64_t n_nodes, int64_t n_edges, const int64_t *index, int32_t *seg_ptr, int32_t *perm,
-                                 int32_t *sorted_target, int32_t *scratch, void *stream) {
+extern "C" int gsn_csr_build_hip(int64_t n_nodes, int64_t n_edges, const int64_t *index, const int64_t *other, int32_t *seg_ptr,
+                                 int32_t *perm, int32_t *sorted_target, int32_t *sorted_other, int32_t *scratch, void *stream) {
+    if (sorted_other && !other) return set_error(GSN_E_INVALID, "gsn_csr_build_hip: sorted_other needs `other`");
     if (n_nodes < 0 || n_edges < 0 || !seg_ptr || !scratch || (n_edges > 0 && (!index || !perm)))
         return set_error(GSN_E_INVALID, "gsn_csr_build_hip: bad argument");
     if (n_edges >= (int64_t)1 << 31 || n_nodes >= ((int64_t)1 << 31) - 1)
@@ -367,7 +371,7 @@ extern "C" int gsn_csr_build_hip(int64_t n_nodes, int64_t n_edges, const int64_t
         int64_t blocks = (n_edges + 255) / 256;
         if (blocks > 8192) blocks = 8192;
         hipLaunchKernelGGL(csr_fill, dim3((unsigned)blocks), dim3(256), 0, st, index, n_edges, cnt, perm);
-        hipLaunchKernelGGL(csr_sort_segments, dim3((unsigned)((n_nodes + 255) / 256)), dim3(256), 0, st, seg_ptr, n_nodes, perm, sorted_target);
+        hipLaunchKernelGGL(csr_sort_segments, dim3((unsigned)((n_nodes + 255) / 256)), dim3(256), 0, st, seg_ptr, n_nodes, perm, sorted_target, other, sorted_other);
     }
     return hip_check("gsn_csr_build_hip");
 }

@@ -27,7 +27,7 @@ import torch.nn.functional as F
 from . import _abi
 
 __all__ = ["mlp", "central_encoder", "GSN_sparse", "GSN_edge_sparse", "MPNN_sparse", "MPNN_edge_sparse",
-           "GSN_edge_sparse_ogb", "MPNN_edge_sparse_ogb", "build_csr", "propagate", "run_stages"]
+           "GSN_edge_sparse_ogb", "MPNN_edge_sparse_ogb", "build_csr", "propagate", "run_stages", "one_hot_identifiers"]
 
 _ACT_CODE = {"identity": 0, "relu": 1, "elu": 2, "tanh": 3}
 _MAX_BLOCKS = 5
@@ -81,15 +81,15 @@ def _f32c(t):
 # CSR of the aggregation index (cached per edge_index tensor)
 # ------------------------------------------------------------------------------------------------------------------
 class _CSR:
-    __slots__ = ("seg_ptr", "perm", "deg", "tgt")
+    __slots__ = ("seg_ptr", "perm", "deg", "tgt", "src")
 
 
 _CSR_CACHE = {}
 
 
-def build_csr(index, n_nodes, with_targets=False):
+def build_csr(index, n_nodes, with_targets=False, other=None):
     """(seg_ptr int32 [N+1], perm int32 [E]) grouping edge ids by ``index`` (stable), via gsn_csr_build_hip;
-    with_targets: also sorted_target int32 [E] = index[perm]."""
+    with_targets: also sorted_target int32 [E] = index[perm] (and sorted_other = other[perm] if ``other`` is given)."""
     _need_cuda(index, "edge_index")
     index = index.contiguous()
     E = index.numel()
@@ -99,11 +99,16 @@ def build_csr(index, n_nodes, with_targets=False):
     perm = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
     scratch = torch.empty(int(L.gsn_csr_scratch_elems(n_nodes)), dtype=torch.int32, device=dev)
     tgt = torch.empty(max(E, 1), dtype=torch.int32, device=dev) if with_targets else None
+    src = torch.empty(max(E, 1), dtype=torch.int32, device=dev) if (with_targets and other is not None) else None
+    if other is not None:
+        other = other.contiguous()
     with torch.cuda.device(dev), _timed("csr_build", 12.0 * E + 8.0 * n_nodes):
-        _abi.check(L.gsn_csr_build_hip(n_nodes, E, index.data_ptr() if E else None, seg_ptr.data_ptr(), perm.data_ptr(),
-                                       _abi.ptr(tgt), scratch.data_ptr(), _abi.current_stream()), "gsn_csr_build_hip")
+        _abi.check(L.gsn_csr_build_hip(n_nodes, E, index.data_ptr() if E else None,
+                                       other.data_ptr() if (other is not None and E) else None, seg_ptr.data_ptr(),
+                                       perm.data_ptr(), _abi.ptr(tgt), _abi.ptr(src) if (E and other is not None) else None,
+                                       scratch.data_ptr(), _abi.current_stream()), "gsn_csr_build_hip")
     if with_targets:
-        return seg_ptr, perm[:E], tgt[:E]
+        return seg_ptr, perm[:E], tgt[:E], (src[:E] if src is not None else None)
     return seg_ptr, perm[:E]
 
 
@@ -114,10 +119,28 @@ def _csr_for(edge_index, row, n_nodes):
         if len(_CSR_CACHE) > 64:
             _CSR_CACHE.clear()
         c = _CSR()
-        c.seg_ptr, c.perm, c.tgt = build_csr(edge_index[row], n_nodes, with_targets=True)
+        c.seg_ptr, c.perm, c.tgt, c.src = build_csr(edge_index[row], n_nodes, with_targets=True, other=edge_index[1 - row])
         c.deg = (c.seg_ptr[1:] - c.seg_ptr[:-1]).to(torch.float32).unsqueeze(1).contiguous()
         _CSR_CACHE[key] = c
     return c
+
+
+def one_hot_identifiers(values, n_classes, clamp=False):
+    """Multi-hot float encoding of integer identifier columns on the device (gsn_one_hot_hip): the reference's
+    one_hot_encoder (utils_graph_learning.py:170-187).  values: int64 [M, C] cuda; n_classes: list of C ints."""
+    import numpy as np
+    _need_cuda(values, "identifiers")
+    values = values.to(torch.int64).contiguous()
+    if values.dim() == 1:
+        values = values.unsqueeze(-1)
+    ncls = np.ascontiguousarray(n_classes, dtype=np.int32)
+    if len(ncls) != values.shape[1]:
+        raise ValueError("one_hot_identifiers: %d columns but %d class counts" % (values.shape[1], len(ncls)))
+    out = torch.empty((values.shape[0], int(ncls.sum())), dtype=torch.float32, device=values.device)
+    with torch.cuda.device(values.device), _timed("one_hot", 8.0 * values.numel() + 4.0 * out.numel()):
+        _abi.check(_abi.lib().gsn_one_hot_hip(values.shape[0], values.shape[1], values.data_ptr(), _abi.ptr(ncls), int(bool(clamp)),
+                                              out.data_ptr(), _abi.current_stream()), "gsn_one_hot_hip")
+    return out
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -196,12 +219,15 @@ def _linear_hip(blocks, weight, bias, bn_mean, bn_scale, bn_shift, act, m_rows, 
         d = _f32c(d)
         keep.append(d)
         arr[i].data = d.data_ptr()
+        arr[i].idx = None
+        arr[i].idx32 = None
         if idx is not None:
             idx = idx.contiguous()
             keep.append(idx)
-            arr[i].idx = idx.data_ptr()
-        else:
-            arr[i].idx = None
+            if idx.dtype == torch.int32:
+                arr[i].idx32 = idx.data_ptr()
+            else:
+                arr[i].idx = idx.data_ptr()
         arr[i].width = d.shape[1]
     n_out = weight.shape[0]
     y = torch.empty((m_rows, n_out), dtype=torch.float32, device=dev) if out else None
@@ -249,10 +275,13 @@ def _launch_stages(stages, m_rows, stats=None, csr=None):
                 for b, (d, idx) in enumerate(blks):
                     d = _f32c(d); keep.append(d)
                     barr[b].data = d.data_ptr(); barr[b].width = d.shape[1]
+                    barr[b].idx = None; barr[b].idx32 = None
                     if idx is not None:
-                        idx = idx.contiguous(); keep.append(idx); barr[b].idx = idx.data_ptr()
-                    else:
-                        barr[b].idx = None
+                        idx = idx.contiguous(); keep.append(idx)
+                        if idx.dtype == torch.int32:
+                            barr[b].idx32 = idx.data_ptr()
+                        else:
+                            barr[b].idx = idx.data_ptr()
                 keep.append(barr)
                 w = _f32c(st.weight); keep.append(w)
                 arr[j].blocks = barr; arr[j].n_blocks = len(blks)
@@ -285,7 +314,7 @@ def _launch_stages(stages, m_rows, stats=None, csr=None):
             for j, st in enumerate(cand):
                 flops += 2.0 * m_rows * st.weight.shape[1] * st.weight.shape[0]
             with torch.cuda.device(dev), _timed("mlp_chain%d" % n, flops):
-                rc = L.gsn_mlp_chain_fwd_hip(m_rows, n, arr, csr.perm.data_ptr() if csr is not None else None,
+                rc = L.gsn_mlp_chain_fwd_hip(m_rows, n, arr, None,
                                              csr.tgt.data_ptr() if seg else None, _abi.ptr(out),
                                              _abi.ptr(stats) if want_stats else None, _abi.current_stream())
             _abi.check(rc, "gsn_mlp_chain_fwd_hip")
@@ -315,7 +344,7 @@ def _chain_fits(stages):
     for j, st in enumerate(stages):
         barr = (_abi.gsn_block * max(len(st.blocks), 1))()
         for b, (d, idx) in enumerate(st.blocks):
-            barr[b].data = 1; barr[b].idx = None; barr[b].width = d.shape[1]
+            barr[b].data = 1; barr[b].idx = None; barr[b].idx32 = None; barr[b].width = d.shape[1]
         keep.append(barr)
         arr[j].blocks = barr; arr[j].n_blocks = len(st.blocks)
         arr[j].W = 1; arr[j].n_out = st.weight.shape[0]; arr[j].act = _ACT_CODE[st.act]
@@ -652,22 +681,39 @@ class _SparseLayer(nn.Module):
             #     [x | agg] W3^T = x W3x^T + S (W3a W2)^T + deg (W3a b2)^T
             # so it is folded into that Linear's weight (a [d_h x d_msg] by [d_msg x d_h] product, once per call).
             csr = _csr_for(edge_index, sel, n)
-            s_agg = mf.hip_forward(blocks, E, upto=len(mf.fc) - 1, csr=csr) if E > 0 else None   # scatter-add fused
+            # fused path: rows walked in target-sorted order; every block is gathered through ONE int32 index
+            # (x_i: sorted target, x_j: sorted source, per-edge rows: perm), the scatter-add happens in the epilogue
+            sblocks = [(x, csr.tgt), (x, csr.src)]
+            if self.has_ids:
+                sblocks += [(ids, csr.perm)] if self.id_scope == "local" else [(ids, csr.tgt), (ids, csr.src)]
+            if self.has_ef:
+                sblocks.append((ef, csr.perm))
+            s_agg = mf.hip_forward(sblocks, E, upto=len(mf.fc) - 1, csr=csr) if E > 0 else None
             if s_agg is None:
                 r = mf.hip_forward(blocks, E, upto=len(mf.fc) - 1)
                 s_agg = propagate(0, edge_index, sel, n, b=r)
-            last = mf.fc[-1]
-            d_x = x.shape[1]
-            w3 = uf.fc[0].weight.detach()
-            w3x, w3a = w3[:, :d_x], w3[:, d_x:].contiguous()
-            w2t = last.weight.detach().t().contiguous()                       # [d_h_msg, d_msg]: rows = input index
-            w_fold = _linear_hip([(w3a, None)], w2t, None, None, None, None, 0, w3a.shape[0])   # = W3a @ W2
-            b_fold = _linear_hip([(w3a, None)], last.bias.detach().unsqueeze(0).contiguous(), None, None, None, None, 0, w3a.shape[0])
-            w_first = torch.cat([w3x, w_fold, b_fold], 1).contiguous()
+            w_first = self._folded_first_weight(x.shape[1])
             return uf.hip_forward([(x, None), (s_agg, None), (csr.deg, None)], n, first_weight=w_first)
         msgs = mf.hip_forward(blocks, E)
         agg = propagate(0, edge_index, sel, n, b=msgs)
         return uf.hip_forward([(x, None), (agg, None)], n)
+
+    def _folded_first_weight(self, d_x):
+        """[W3x | W3a W2 | W3a b2] (see _hip); recomputed only when one of the three parameters changed."""
+        mf, uf = self.msg_fn, self.update_fn
+        last, w3p = mf.fc[-1], uf.fc[0].weight
+        key = (last.weight._version, last.bias._version, w3p._version, last.weight.data_ptr(), w3p.data_ptr(), d_x)
+        cache = getattr(self, "_fold_cache", None)
+        if cache is not None and cache[0] == key:
+            return cache[1]
+        w3 = w3p.detach()
+        w3x, w3a = w3[:, :d_x], w3[:, d_x:].contiguous()
+        w2t = last.weight.detach().t().contiguous()                       # [d_h_msg, d_msg]: rows = input index
+        w_fold = _linear_hip([(w3a, None)], w2t, None, None, None, None, 0, w3a.shape[0])   # = W3a @ W2
+        b_fold = _linear_hip([(w3a, None)], last.bias.detach().unsqueeze(0).contiguous(), None, None, None, None, 0, w3a.shape[0])
+        w_first = torch.cat([w3x, w_fold, b_fold], 1).contiguous()
+        self._fold_cache = (key, w_first)
+        return w_first
 
     # -- differentiable twin (PyTorch ops + the HIP propagate with its own adjoint) ---------------------------------
     def _twin(self, edge_index, x, ids, ef):

@@ -107,11 +107,14 @@ int gsn_count_hip(const uint32_t *plan_host, const uint32_t *plan_dev, int64_t p
  *   index   int64 device [E]  aggregation targets (edge_index[1] for flow=source_to_target, [0] otherwise)
  *   seg_ptr int32 device [N+1] out; perm int32 device [E] out (edge ids grouped by target, original order kept inside)
  *   sorted_target int32 device [E] out or NULL: sorted_target[q] = index[perm[q]] (the target of the q-th sorted edge)
+ *   other int64 device [E] or NULL (the other row of edge_index), sorted_other int32 device [E] out or NULL:
+ *         sorted_other[q] = other[perm[q]] (the message source of the q-th sorted edge) -- lets a kernel that walks the
+ *         edges in target order gather x_i / x_j / per-edge rows through ONE index load each
  *   scratch int32 device [gsn_csr_scratch_elems(N)]
  * ---------------------------------------------------------------------------------------------------------------- */
 int64_t gsn_csr_scratch_elems(int64_t n_nodes);
-int gsn_csr_build_hip(int64_t n_nodes, int64_t n_edges, const int64_t *index, int32_t *seg_ptr, int32_t *perm,
-                      int32_t *sorted_target, int32_t *scratch, void *stream);
+int gsn_csr_build_hip(int64_t n_nodes, int64_t n_edges, const int64_t *index, const int64_t *other, int32_t *seg_ptr,
+                      int32_t *perm, int32_t *sorted_target, int32_t *sorted_other, int32_t *scratch, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * HP-2  propagate: fused gather -> message -> segmented sum (device, fp32).
@@ -154,9 +157,11 @@ int gsn_propagate_bwd_hip(int kind, int64_t n_nodes, int64_t n_edges, const int6
  *         sum of squares of the PRE-BN values h = X W^T + bias into it (caller zeroes it) and skips bn / act / out
  * ---------------------------------------------------------------------------------------------------------------- */
 typedef struct {
-    const float *data;   /* [rows][width] fp32, row stride = width */
-    const int64_t *idx;  /* NULL: direct (row r); else gather data[idx[r]] */
+    const float *data;     /* [rows][width] fp32, row stride = width */
+    const int64_t *idx;    /* int64 gather index (a row of edge_index) or NULL */
     int64_t width;
+    const int32_t *idx32;  /* int32 gather index (perm / sorted_target / sorted_source of gsn_csr_build_hip) or NULL;
+                              at most one of idx / idx32; both NULL: direct (row r) */
 } gsn_block;
 
 int gsn_linear_fwd_hip(int64_t m_rows, int n_blocks, const gsn_block *blocks, const float *W, const float *bias,
@@ -197,6 +202,16 @@ int gsn_mlp_chain_fwd_hip(int64_t m_rows, int n_stages, const gsn_chain_stage *s
                           const int32_t *seg_target, float *out, double *stats, void *stream);
 int gsn_segsum_prepare_hip(int64_t n_seg, int64_t n_rows, const int32_t *seg_ptr, const int32_t *row_target,
                            int64_t n_out, float *out, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Identifier encoding (device).  The multi-hot encoding the reference applies to the integer identifiers in front of
+ * every GSN layer: utils_graph_learning.one_hot_encoder.forward (:170-187) via DiscreteEmbedding('one_hot_encoder')
+ * (models_graph_classification.py:222).  values int64 [M][C] -> out fp32 [M][sum n_classes], column c becoming
+ * n_classes[c] floats with a single 1 at index values[r][c].  n_classes is a HOST array.  clamp != 0: indices are
+ * clamped into [0, n_classes[c]-1] (the reference would raise on an out-of-range index).
+ * ---------------------------------------------------------------------------------------------------------------- */
+int gsn_one_hot_hip(int64_t m_rows, int n_cols, const int64_t *values, const int32_t *n_classes, int clamp, float *out,
+                    void *stream);
 
 #ifdef __cplusplus
 }

@@ -195,3 +195,16 @@ def test_layer_vs_oracle_big_batch():
     with torch.no_grad():
         y = layer(x.cuda(), ei.cuda(), identifiers=ids.cuda(), degrees=torch.zeros(N, device="cuda"), edge_features=ef.cuda())
     assert rel_err(y.cpu(), ref) < TOL
+
+
+def test_one_hot_identifiers_vs_torch():
+    from gsn_amd.layers import one_hot_identifiers
+    torch.manual_seed(3)
+    v = torch.randint(0, 7, (5000, 4), device="cuda")
+    ncls = [7, 9, 7, 8]
+    got = one_hot_identifiers(v, ncls)
+    ref = torch.cat([torch.nn.functional.one_hot(v[:, c], ncls[c]).float() for c in range(4)], 1)
+    assert torch.equal(got, ref)
+    got = one_hot_identifiers(v, [3, 3, 3, 3], clamp=True)
+    ref = torch.nn.functional.one_hot(v.clamp(max=2), 3).reshape(5000, 12).float()
+    assert torch.equal(got, ref)
