@@ -124,8 +124,10 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
     const int lane = tid & 63;
     const uint64_t lane_lt = (1ull << lane) - 1ull;
 
-    Lane s;
+    Lane<W> s;
     s.l = -1; s.cnt = 0; s.k = 0; s.nfix = 0; s.fvec = 0; s.plan = plans;
+#pragma unroll
+    for (int w = 0; w < W; ++w) s.used.w[w] = 0ull;
     bool has_task = false, exhausted = false;
     int t_row = 0, t_col = 0, p_i = 0, p_e = 0;
     uint64_t roots = 0;

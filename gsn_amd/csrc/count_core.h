@@ -60,48 +60,67 @@ GSN_HD int popc(const Bits<W> &b) {
     return c;
 }
 
-// Candidate set of level l given the packed partial map fvec (levels 0..l-1 assigned).
+// Candidate set of level l given the packed partial map fvec (levels 0..l-1 assigned) and the set `used` of their images.
 //   desc = adj_mask | nonadj_mask<<8 | gt_mask<<16 | lt_mask<<24  (bit j <-> earlier level j)
 //   adj    : candidate must be a neighbour of f_j          (pattern edge)
 //   nonadj : candidate must NOT be a neighbour of f_j      (induced matching, pattern non-edge)
 //   gt/lt  : symmetry breaking, candidate id must be > / < f_j
-// Every earlier f_j is excluded (injectivity).
+// Only the levels named in desc are visited (a cycle or path level has one or two), everything else is covered by
+// `valid & ~used` -- the kernel is VALU-issue bound, so the per-step instruction count is what matters.
 template <int W>
-GSN_HD void candidates(Bits<W> &C, uint32_t desc, int l, uint64_t fvec, const uint64_t *A, const uint64_t *valid) {
+GSN_HD void candidates(Bits<W> &C, uint32_t desc, uint64_t fvec, const Bits<W> &used, const uint64_t *A, const uint64_t *valid) {
 #pragma unroll
-    for (int w = 0; w < W; ++w) C.w[w] = valid[w];
+    for (int w = 0; w < W; ++w) C.w[w] = valid[w] & ~used.w[w];
+    uint32_t m = desc & 0xffu;
+    while (m) {
+        const int j = ctz64(m);
+        m &= m - 1u;
+        const uint64_t *row = A + (int)((fvec >> (8 * j)) & 0xffu) * W;
 #pragma unroll
-    for (int j = 0; j < GSN_KMAX - 1; ++j) {
-        if (j < l) {
-            const int fj = (int)((fvec >> (8 * j)) & 0xffu);
-            const bool a = (desc >> j) & 1u, na = (desc >> (8 + j)) & 1u;
-            const bool gt = (desc >> (16 + j)) & 1u, lt = (desc >> (24 + j)) & 1u;
-            const uint64_t *row = A + fj * W;
+        for (int w = 0; w < W; ++w) C.w[w] &= row[w];
+    }
+    m = (desc >> 8) & 0xffu;
+    while (m) {
+        const int j = ctz64(m);
+        m &= m - 1u;
+        const uint64_t *row = A + (int)((fvec >> (8 * j)) & 0xffu) * W;
 #pragma unroll
-            for (int w = 0; w < W; ++w) {
-                uint64_t m = ~0ull;
-                if (a | na) {
-                    const uint64_t r = row[w];
-                    m = a ? r : ~r;
-                }
-                const uint64_t bl = below_word(fj, w);
-                const uint64_t self = (w == (fj >> 6)) ? (1ull << (fj & 63)) : 0ull;
-                m &= ~self;
-                if (gt) m &= ~(bl | self);
-                if (lt) m &= bl;
-                C.w[w] &= m;
-            }
+        for (int w = 0; w < W; ++w) C.w[w] &= ~row[w];
+    }
+    m = desc >> 16;
+    while (m) {
+        const int jj = ctz64(m);
+        m &= m - 1u;
+        const bool lt = jj >= 8;
+        const int fj = (int)((fvec >> (8 * (jj & 7))) & 0xffu);
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            const uint64_t bl = below_word(fj, w);                       // ids < fj
+            C.w[w] &= lt ? bl : ~(bl | ((w == (fj >> 6)) ? (1ull << (fj & 63)) : 0ull));
         }
     }
 }
 
+template <int W>
 struct Lane {
     int l;          // level whose frame is being consumed; < 0: no search in progress
     int k, nfix;
     uint64_t fvec;  // partial map, 8 bits per level
     uint64_t cnt;   // matches found so far for the current task (accumulates over the task's plans)
+    Bits<W> used;   // images of levels 0 .. l-1
     const uint32_t *plan;
 };
+
+template <int W>
+GSN_HD void bit_set(Bits<W> &b, int v) {
+#pragma unroll
+    for (int w = 0; w < W; ++w) b.w[w] |= (w == (v >> 6)) ? (1ull << (v & 63)) : 0ull;
+}
+template <int W>
+GSN_HD void bit_clear(Bits<W> &b, int v) {
+#pragma unroll
+    for (int w = 0; w < W; ++w) b.w[w] &= ~((w == (v >> 6)) ? (1ull << (v & 63)) : 0ull);
+}
 
 // frame addressing: word w of level l of lane `tid` lives at stack[((l * W + w) * sstride) + tid]
 template <int W>
@@ -117,7 +136,7 @@ GSN_HD void frame_load(const uint64_t *stack, int sstride, int tid, int l, Bits<
 
 // Start the rooted search of `plan` with the root levels already in fvec.  May finish immediately (s.l < 0).
 template <int W>
-GSN_HD void lane_begin(Lane &s, const uint32_t *plan, uint64_t fvec_roots, const uint64_t *A, const uint64_t *valid,
+GSN_HD void lane_begin(Lane<W> &s, const uint32_t *plan, uint64_t fvec_roots, const uint64_t *A, const uint64_t *valid,
                        uint64_t *stack, int sstride, int tid) {
     const uint32_t h = plan[0];
     s.k = (int)(h & 0xffu);
@@ -125,17 +144,26 @@ GSN_HD void lane_begin(Lane &s, const uint32_t *plan, uint64_t fvec_roots, const
     s.plan = plan;
     s.fvec = fvec_roots;
     s.l = -1;
+#pragma unroll
+    for (int w = 0; w < W; ++w) s.used.w[w] = 0ull;
+    bit_set<W>(s.used, (int)(fvec_roots & 0xffu));
+    if (s.nfix > 1) bit_set<W>(s.used, (int)((fvec_roots >> 8) & 0xffu));
     if (s.nfix == s.k) { s.cnt += 1; return; }
     Bits<W> C;
-    candidates<W>(C, plan[2 + s.nfix], s.nfix, s.fvec, A, valid);
+    candidates<W>(C, plan[2 + s.nfix], s.fvec, s.used, A, valid);
     if (s.nfix == s.k - 1) { s.cnt += (uint64_t)popc<W>(C); return; }
+    bool cempty = true;
+#pragma unroll
+    for (int w = 0; w < W; ++w) cempty = cempty && (C.w[w] == 0ull);
+    if (cempty) return;  // invariant: the frame of the current level is never empty when lane_step runs
     s.l = s.nfix;
     frame_store<W>(stack, sstride, tid, s.l, C);
 }
 
-// One search step.  Precondition: s.l >= 0.
+// One search step.  Precondition: s.l >= 0.  Pops one candidate of the current level; at the last-but-one level the
+// whole last level is counted by popcount.  A level that runs empty backtracks in the same step (no wasted iteration).
 template <int W>
-GSN_HD void lane_step(Lane &s, const uint64_t *A, const uint64_t *valid, uint64_t *stack, int sstride, int tid) {
+GSN_HD void lane_step(Lane<W> &s, const uint64_t *A, const uint64_t *valid, uint64_t *stack, int sstride, int tid) {
     Bits<W> M;
     frame_load<W>(stack, sstride, tid, s.l, M);
     int v = -1;
@@ -146,22 +174,50 @@ GSN_HD void lane_step(Lane &s, const uint64_t *A, const uint64_t *valid, uint64_
             M.w[w] &= M.w[w] - 1ull;
         }
     }
-    if (v < 0) {  // level exhausted: backtrack
-        s.l -= 1;
-        if (s.l < s.nfix) s.l = -1;
-        return;
-    }
-    frame_store<W>(stack, sstride, tid, s.l, M);
-    s.fvec = (s.fvec & ~(0xffull << (8 * s.l))) | ((uint64_t)v << (8 * s.l));
-    const int nl = s.l + 1;
+    bool empty = true;
+#pragma unroll
+    for (int w = 0; w < W; ++w) empty = empty && (M.w[w] == 0ull);
+    // v >= 0 always: a frame is only ever stored non-empty or left through the `empty` path below
+    const int l = s.l;
+    s.fvec = (s.fvec & ~(0xffull << (8 * l))) | ((uint64_t)v << (8 * l));
+    const int nl = l + 1;
+    Bits<W> used2 = s.used;
+    bit_set<W>(used2, v);
     Bits<W> C;
-    candidates<W>(C, s.plan[2 + nl], nl, s.fvec, A, valid);
+    candidates<W>(C, s.plan[2 + nl], s.fvec, used2, A, valid);
+    bool descend = false;
     if (nl == s.k - 1) {
         s.cnt += (uint64_t)popc<W>(C);
     } else {
+        bool cempty = true;
+#pragma unroll
+        for (int w = 0; w < W; ++w) cempty = cempty && (C.w[w] == 0ull);
+        descend = !cempty;
+    }
+    if (descend) {
+        frame_store<W>(stack, sstride, tid, l, M);   // possibly empty: the climb below finds it so on the way back
+        s.used = used2;
         s.l = nl;
         frame_store<W>(stack, sstride, tid, nl, C);
+        return;
     }
+    if (!empty) {
+        frame_store<W>(stack, sstride, tid, l, M);
+        return;
+    }
+    // this level is exhausted: climb to the nearest level that still has candidates
+    int cl = l - 1;
+    while (cl >= s.nfix) {
+        bit_clear<W>(s.used, (int)((s.fvec >> (8 * cl)) & 0xffu));
+        Bits<W> P;
+        frame_load<W>(stack, sstride, tid, cl, P);
+        bool pe = true;
+#pragma unroll
+        for (int w = 0; w < W; ++w) pe = pe && (P.w[w] == 0ull);
+        if (!pe) break;
+        --cl;
+    }
+    s.l = cl >= s.nfix ? cl : -1;
 }
 
 }  // namespace gsn

@@ -39,7 +39,8 @@ static int run(const uint32_t *plan, int64_t n, int64_t E, const int64_t *src, c
     int status = 0;
     for (int col = 0; col < n_cols; ++col)
         for (int64_t row = 0; row < rows; ++row) {
-            Lane s; s.l = -1; s.cnt = 0; s.k = 0; s.nfix = 0; s.fvec = 0; s.plan = plans;
+            Lane<W> s; s.l = -1; s.cnt = 0; s.k = 0; s.nfix = 0; s.fvec = 0; s.plan = plans;
+            for (int w = 0; w < W; ++w) s.used.w[w] = 0;
             uint64_t roots; bool live = true, rev_missing = false;
             if (mode == GSN_MODE_EDGE) {
                 int u = (int)src[row], v = (int)dst[row];
