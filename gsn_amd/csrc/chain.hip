@@ -101,44 +101,68 @@ __device__ __forceinline__ ColMap col_map(const ChainArgs &a, int s, int kc) {
     return m;
 }
 
+// Row sources (which row of each input block feeds tile row r) are resolved by ALL 256 threads: thread t owns tile
+// row t&63 of block t>>6 and of block (t>>6)+4; its index pointers are chosen once, before the tile loop, and live in
+// VGPRs -- looping over the block table per row instead keeps ~40 kernarg pointers in SGPRs and spills them to VGPR lanes.
+struct RowSrcThread {
+    const int32_t *p32[2];
+    const int64_t *p64[2];
+    bool on[2];        // block exists
+    const int32_t *perm, *seg;
+    int64_t m_rows;
+    int b[2], r;
+};
 struct RowSrcC {
-    int v[CMAX_BLOCKS];
-    int tg, edge;  // target segment of the row; for lane 0 / 63: target of the row before / after the tile
+    int v[2];
+    int tg, edge;  // (threads of block 0 only) target segment of the row; lane 0 / 63: target of the row before / after the tile
 };
 
-__device__ __forceinline__ void rs_fetch(const ChainArgs &a, int64_t row0, int tid, RowSrcC &rs) {
-    if (tid < CBM) {
-        const int64_t grow = row0 + tid;
-        const bool ok = grow < a.m_rows;
-        int64_t logical = 0;
-        if (ok) logical = a.row_perm ? (int64_t)a.row_perm[grow] : grow;
+__device__ __forceinline__ RowSrcThread rs_thread(const ChainArgs &a, int tid) {
+    RowSrcThread t;
+    t.r = tid & (CBM - 1);
+    t.perm = a.row_perm; t.seg = a.seg_target; t.m_rows = a.m_rows;
 #pragma unroll
-        for (int b = 0; b < CMAX_BLOCKS; ++b) {
-            int r = -1;
-            if (b < a.n_blocks && ok) r = a.bidx32[b] ? a.bidx32[b][logical] : (a.bidx[b] ? (int)a.bidx[b][logical] : (int)logical);
-            rs.v[b] = r;
-        }
-        rs.tg = -1; rs.edge = -2;
-        if (a.seg_target) {
-            if (ok) rs.tg = a.seg_target[grow];
-            if (tid == 0 && row0 > 0 && row0 - 1 < a.m_rows) rs.edge = a.seg_target[row0 - 1];
-            if (tid == CBM - 1 && row0 + CBM < a.m_rows) rs.edge = a.seg_target[row0 + CBM];
-        }
+    for (int h = 0; h < 2; ++h) {
+        const int b = (tid >> 6) + 4 * h;
+        t.b[h] = b;
+        t.on[h] = b < a.n_blocks;
+        t.p32[h] = nullptr; t.p64[h] = nullptr;
+#pragma unroll
+        for (int q = 0; q < CMAX_BLOCKS; ++q)
+            if (q == b) { t.p32[h] = a.bidx32[q]; t.p64[h] = a.bidx[q]; }
+    }
+    return t;
+}
+
+__device__ __forceinline__ void rs_fetch(const RowSrcThread &t, int64_t row0, RowSrcC &rs) {
+    const int64_t grow = row0 + t.r;
+    const bool ok = grow < t.m_rows;
+    int64_t logical = 0;
+    if (ok) logical = t.perm ? (int64_t)t.perm[grow] : grow;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        int r = -1;
+        if (t.on[h] && ok) r = t.p32[h] ? t.p32[h][logical] : (t.p64[h] ? (int)t.p64[h][logical] : (int)logical);
+        rs.v[h] = r;
+    }
+    rs.tg = -1; rs.edge = -2;
+    if (t.seg && t.b[0] == 0) {
+        if (ok) rs.tg = t.seg[grow];
+        if (t.r == 0 && row0 > 0 && row0 - 1 < t.m_rows) rs.edge = t.seg[row0 - 1];
+        if (t.r == CBM - 1 && row0 + CBM < t.m_rows) rs.edge = t.seg[row0 + CBM];
     }
 }
 
-__device__ __forceinline__ void rs_store(int *dst, int tid, const RowSrcC &rs) {
-    if (tid < CBM) {
-#pragma unroll
-        for (int b = 0; b < CMAX_BLOCKS; ++b) dst[b * CBM + tid] = rs.v[b];
-        dst[CMAX_BLOCKS * CBM + tid] = rs.tg;
-        if (tid == 0) dst[(CMAX_BLOCKS + 1) * CBM] = rs.edge;
-        if (tid == CBM - 1) dst[(CMAX_BLOCKS + 1) * CBM + 1] = rs.edge;
+__device__ __forceinline__ void rs_store(int *dst, const RowSrcThread &t, const RowSrcC &rs) {
+    if (t.on[0]) dst[t.b[0] * CBM + t.r] = rs.v[0];
+    if (t.on[1]) dst[t.b[1] * CBM + t.r] = rs.v[1];
+    if (t.b[0] == 0) {
+        dst[CMAX_BLOCKS * CBM + t.r] = rs.tg;
+        if (t.r == 0) dst[(CMAX_BLOCKS + 1) * CBM] = rs.edge;
+        if (t.r == CBM - 1) dst[(CMAX_BLOCKS + 1) * CBM + 1] = rs.edge;
     }
 }
 
-// single-stage instantiations are asked to fit 2 waves per SIMD (<= 256 registers) so that one workgroup's staging /
-// epilogue overlaps the other's MFMA phase; two-stage chains hold 160 weight registers and run 1 wave per SIMD.
 // WPE = waves per SIMD the kernel is compiled for: small single-stage chains use 2 (<= 256 registers; two co-resident
 // workgroups overlap each other's staging / epilogue with MFMA), everything else exactly 1 so the register allocator may
 // use the whole 512-entry file for the weight fragments instead of spilling.
@@ -200,6 +224,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     double st_sum = 0.0, st_sq = 0.0;
     float pf0[PF0_J][8];
     RowSrcC rsn;
+    const RowSrcThread rst = rs_thread(a, tid);
 
     // NOTE: the loaded values are kept RAW in the prefetch registers; masking (padded columns, rows past the end) is
     // applied when they are written to LDS.  Selecting on the value right here would make the compiler wait for every
@@ -226,10 +251,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     int64_t tile = blockIdx.x;
     {
         RowSrcC r;
-        rs_fetch(a, tile * CBM, tid, r);
-        rs_store(rsrc, tid, r);
-        rs_fetch(a, (tile + gridDim.x) * CBM, tid, r);
-        rs_store(rsrc + RS_STRIDE, tid, r);
+        rs_fetch(rst, tile * CBM, r);
+        rs_store(rsrc, rst, r);
+        rs_fetch(rst, (tile + gridDim.x) * CBM, r);
+        rs_store(rsrc + RS_STRIDE, rst, r);
     }
     __syncthreads();
     if (tile < n_tiles) prefetch(rsrc);
@@ -249,7 +274,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         float *other = (NST == 1 && cur) ? buf0 : buf1;       // NST==1: next tile's input; NST==2: stage-1 input
         const int slot_n = slot == 2 ? 0 : slot + 1, slot_nn = slot_n == 2 ? 0 : slot_n + 1;
         if (has_next && !(a.dbg & 1)) prefetch(rsrc + slot_n * RS_STRIDE);       // lands under the MFMAs below
-        rs_fetch(a, (tile + 2 * (int64_t)gridDim.x) * CBM, tid, rsn);         // row sources two tiles ahead
+        rs_fetch(rst, (tile + 2 * (int64_t)gridDim.x) * CBM, rsn);         // row sources two tiles ahead
 
         float *in = in0;
 #pragma unroll
@@ -306,7 +331,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
             float *next_in = (NST == 1) ? other : buf0;
             if (STATS) {
                 if (has_next) stage_in(next_in);
-                rs_store(rsrc + slot_nn * RS_STRIDE, tid, rsn);   // row sources of tile t+2
+                rs_store(rsrc + slot_nn * RS_STRIDE, rst, rsn);   // row sources of tile t+2
 #pragma unroll
                 for (int rf = 0; rf < 2; ++rf)
 #pragma unroll
@@ -338,7 +363,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
                     }
                 }
                 if (has_next) stage_in(next_in);     // (the one vmcnt wait of the tile: before any store)
-                rs_store(rsrc + slot_nn * RS_STRIDE, tid, rsn);  // row sources of tile t+2
+                rs_store(rsrc + slot_nn * RS_STRIDE, rst, rsn);  // row sources of tile t+2
                 const int c = tid & 127, rb = (tid >> 7) * 32;
                 const int *tg = rsrc + slot * RS_STRIDE + CMAX_BLOCKS * CBM;   // this tile's targets
                 int tgl[32];
@@ -374,8 +399,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
                 // reduction above against the following writes into `in`
             } else {
                 if (has_next) stage_in(next_in);     // (the one vmcnt wait of the tile: before any store)
-                rs_store(rsrc + slot_nn * RS_STRIDE, tid, rsn);  // row sources of tile t+2
-                float *op = a.out + (row0 + 4 * lh) * st.n_out + col;
+                rs_store(rsrc + slot_nn * RS_STRIDE, rst, rsn);  // row sources of tile t+2
+                float *tile_out = a.out + row0 * st.n_out;                 // wave-uniform base (SGPR pair)
+                const int lane_off = 4 * lh * st.n_out + col;              // 32-bit per-lane offset inside the tile
                 const bool full = row0 + CBM <= a.m_rows;
                 auto emit = [&](auto actf) {
                     if (a.dbg & 4) {
@@ -385,7 +411,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
                             for (int rf = 0; rf < 2; ++rf)
 #pragma unroll
                                 for (int r = 0; r < 16; ++r)
-                                    op[(int64_t)(rf * 32 + (r & 3) + 8 * (r >> 2)) * st.n_out] = actf(value(rf, r));
+                                    tile_out[lane_off + (rf * 32 + (r & 3) + 8 * (r >> 2)) * st.n_out] = actf(value(rf, r));
                         }
                     } else {
 #pragma unroll
@@ -393,7 +419,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 #pragma unroll
                             for (int r = 0; r < 16; ++r) {
                                 const int dr = rf * 32 + (r & 3) + 8 * (r >> 2);
-                                if (cok && row0 + 4 * lh + dr < a.m_rows) op[(int64_t)dr * st.n_out] = actf(value(rf, r));
+                                if (cok && row0 + 4 * lh + dr < a.m_rows) tile_out[lane_off + dr * st.n_out] = actf(value(rf, r));
                             }
                     }
                 };
