@@ -25,6 +25,7 @@ struct CountArgs {
     const int32_t *graph_ids;  // or null
     int n_cap, e_cap;          // LDS capacities (rows of A, columns)
     int stage_out;             // 1: output rows staged in LDS then written coalesced
+    int split;                 // workgroups per graph (each takes a contiguous slice of the (column,row) task space)
     int64_t *out;
     int32_t *status;
     // LDS byte offsets
@@ -46,7 +47,8 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
     int *misc = reinterpret_cast<int *>(smem + a.off_misc);  // [0] next task  [1] n_active  [2] status
 
     const int tid = threadIdx.x;
-    const int g = a.graph_ids ? a.graph_ids[blockIdx.x] : (int)blockIdx.x;
+    const int item = (int)blockIdx.x / a.split, part = (int)blockIdx.x - item * a.split;
+    const int g = a.graph_ids ? a.graph_ids[item] : item;
     const int64_t n0 = a.node_ptr[g], e0 = a.edge_ptr[g];
     const int64_t n64 = a.node_ptr[g + 1] - n0, E64 = a.edge_ptr[g + 1] - e0;
     const bool edge_mode = a.mode == GSN_MODE_EDGE;
@@ -56,8 +58,10 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
 
     if (n64 > a.n_cap || E64 > a.e_cap || n64 > W * 64) {
         // caller under-declared max_nodes / max_edges: report, leave zeros
-        for (int64_t i = tid; i < rows64 * n_cols; i += T) a.out[row0 * n_cols + i] = 0;
-        if (tid == 0) a.status[g] = GSN_ST_TOO_LARGE;
+        if (part == 0) {
+            for (int64_t i = tid; i < rows64 * n_cols; i += T) a.out[row0 * n_cols + i] = 0;
+            if (tid == 0) atomicMax(&a.status[g], (int)GSN_ST_TOO_LARGE);
+        }
         return;
     }
     const int n = (int)n64, E = (int)E64, rows = (int)rows64;
@@ -112,13 +116,18 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
     }
     __syncthreads();
     if (misc[2] != 0) {  // bad index: zeros + status
-        for (int i = tid; i < rows * n_cols; i += T) a.out[row0 * n_cols + i] = 0;
-        if (tid == 0) a.status[g] = misc[2];
+        if (part == 0) {
+            for (int i = tid; i < rows * n_cols; i += T) a.out[row0 * n_cols + i] = 0;
+            if (tid == 0) atomicMax(&a.status[g], misc[2]);
+        }
         return;
     }
 
     // ---- phase 3: task pool -- (column, row) cells, pulled by lanes as they go idle --------------------------------
-    const int n_tasks = rows * n_cols;
+    // this workgroup takes the tasks  part, part + split, part + 2*split, ...  (strided, so the heavy columns of a
+    // pattern family are spread over all the workgroups of a graph); n_tasks = how many of them
+    const int n_tasks_all = rows * n_cols;
+    const int n_tasks = n_tasks_all > part ? (n_tasks_all - part + a.split - 1) / a.split : 0;
     const uint32_t *col_ptr = plan + PLAN_HEADER_WORDS;
     const uint32_t *plans = plan + a.plans_off;
     const int lane = tid & 63;
@@ -144,8 +153,9 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
             if (need) {
                 const int t = base + __popcll(m & lane_lt);
                 if (t < n_tasks) {
-                    t_col = t / rows;
-                    t_row = t - t_col * rows;
+                    const int tt = part + t * a.split;
+                    t_col = tt / rows;
+                    t_row = tt - t_col * rows;
                     has_task = true;
                     s.cnt = 0; s.l = -1;
                     p_i = (int)col_ptr[t_col]; p_e = (int)col_ptr[t_col + 1];
@@ -195,11 +205,16 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
     __syncthreads();
 
     // ---- phase 4: coalesced write of the staged rows --------------------------------------------------------------
-    if (a.stage_out) {
+    if (a.stage_out) {   // (only with split == 1)
         int64_t *dst = a.out + row0 * n_cols;
         for (int i = tid; i < n_tasks; i += T) dst[i] = (int64_t)out_lds[i];
     }
-    if (tid == 0) a.status[g] = misc[2];
+    if (tid == 0 && misc[2] != 0) atomicMax(&a.status[g], misc[2]);   // status[] is zeroed by the launcher
+}
+
+__global__ void status_zero_kernel(const int32_t *graph_ids, int n, int32_t *status) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) status[graph_ids[i]] = 0;
 }
 
 static inline int align_up(int x, int a) { return (x + a - 1) / a * a; }
@@ -261,13 +276,30 @@ extern "C" int gsn_count_hip(const uint32_t *plan_host, const uint32_t *plan_dev
     a.off_misc = o; o += 16;
     a.off_out = o;
     const int64_t stage_bytes = rows_cap * a.n_cols * 8;
-    const int64_t lds_budget = 64 * 1024;  // keep >= 2 workgroups per CU
+    // Stage the output rows in LDS (coalesced final write) only while that keeps the workgroup small: the search is
+    // latency-bound on dependent LDS reads, so heavy graphs want as many co-resident workgroups per CU as possible
+    // (>= 8 waves per SIMD) and write their cells straight to HBM instead.
+    const int64_t lds_budget = (T == 64 ? 160 * 1024 / 32 : 160 * 1024 / 8);
     a.stage_out = (o + stage_bytes <= lds_budget) ? 1 : 0;
+    // few heavy graphs: several workgroups per graph so that every CU gets >= 8 of them
+    a.split = 1;
+    const int64_t tasks_cap = rows_cap * a.n_cols;
+    if (n_items < 2048 && tasks_cap >= 1024) {
+        int64_t sp = (2048 + n_items - 1) / n_items;
+        if (sp > 32) sp = 32;
+        if (sp > tasks_cap / 256) sp = tasks_cap / 256;
+        if (sp > 1) { a.split = (int)sp; a.stage_out = 0; }
+    }
     if (a.stage_out) o += (int)stage_bytes;
     if (o > 160 * 1024) return set_error(GSN_E_UNSUPPORTED, "graph too large for LDS (%d B needed)", o);
 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int items = (int)n_items;
+    {   // per-graph status words start at OK; workgroups raise them with atomicMax
+        hipError_t e = graph_ids ? hipSuccess : hipMemsetAsync(status, 0, sizeof(int32_t) * (size_t)n_graphs, st);
+        if (graph_ids) hipLaunchKernelGGL(status_zero_kernel, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, st, graph_ids, (int)n_items, status);
+        if (e != hipSuccess) return set_error(GSN_E_HIP, "hipMemsetAsync(status): %s", hipGetErrorString(e));
+    }
+    const int items = (int)n_items * a.split;
     if (W == 1 && T == 64) return launch<1, 64>(a, items, (size_t)o, st);
     if (W == 1) return launch<1, 256>(a, items, (size_t)o, st);
     if (W == 2 && T == 64) return launch<2, 64>(a, items, (size_t)o, st);
