@@ -1,19 +1,25 @@
-// HP-2 dense stage for gfx950: one fused models_misc.mlp layer on the fp32 matrix cores.
+// HP-2 dense stage for gfx950, general shapes: one fused models_misc.mlp layer on the fp32 matrix cores.
 //
-//   Y = act( (X W^T + bias - mean) * scale + shift )        X rows assembled on the fly from up to 4 blocks
+//   Y = act( (X W^T + bias - mean) * scale + shift )        X rows assembled on the fly from up to 5 blocks
 //
 // replaces  torch.cat((x_i, x_j, identifiers.., edge_features), -1) -> nn.Linear -> BatchNorm1d -> activation
 // (models_misc.py:52-58 driven by GSN_sparse.py:166-171 / GSN_edge_sparse.py:160-165): neither the gathered
 // x[edge_index_i] / x[edge_index_j] copies nor the [E, msg_in] concatenation ever exist in HBM.
+// This is the any-shape kernel (any K, any n_out via column tiles, elu / tanh epilogues, statistics pass); the common
+// small shapes (K <= 160, n_out <= 128, identity / relu) run on the fused weights-in-registers kernel of chain.hip.
 //
 // fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32 (exact f32, 64 FLOP/clk/SIMD = the chip's 157 TF fp32 peak;
 // gfx950 has no TF32, and the 1e-5 parity tolerance rules out bf16).  Tiling for 64-wide waves:
-//   workgroup = 4 waves = 128 x 128 output tile; each wave owns 64 x 64 = 2 x 2 MFMA tiles (64 accumulator VGPRs);
-//   K is walked in chunks of <= 32 that never straddle two input blocks; per chunk the A tile [128][32] and the
-//   W^T tile [32][128] are staged in LDS with +1 padding (row pitch 33 / 129 words) so that both the staging writes
-//   and the per-lane fragment reads (A[i=lane&31][k=lane>>5], B[k=lane>>5][j=lane&31]) are bank-conflict free.
-//   Workgroups are persistent over row tiles (grid-stride) so the train-mode BatchNorm statistics pass can keep
-//   per-column partial sums in registers (fp64) and issue one atomic per column per workgroup.
+//   workgroup = 4 waves = 128 x 128 output tile; each wave owns 64 x 64 = 2 x 2 MFMA tiles (64 accumulator registers);
+//   K is walked in 32-wide slices of the CONCATENATED input row; A slices [128][32] and W^T slices [32][128] go through
+//   registers into double-buffered LDS tiles with +1 padding (pitch 33 / 129 words: staging writes and the per-lane
+//   fragment reads A[i=lane&31][k=lane>>5], B[k=lane>>5][j=lane&31] are all bank-conflict free).  Software pipeline per
+//   slice:  write slice c (registers -> LDS) | LDS-only barrier | issue the global loads of slice c+1 | 64 MFMAs on
+//   slice c.  With WRES the whole W^T tile is instead loaded into LDS once per (persistent) workgroup.
+//   Lessons baked in (profiles/r01_*): loaded values are consumed RAW one step later (a select on a just-loaded value
+//   makes the compiler wait for it on the spot and serialises the prefetch), barriers wait on lgkmcnt only
+//   (__syncthreads would drain the prefetch), epilogue constants live in registers, and the train-mode BatchNorm
+//   statistics pass keeps per-column fp64 partial sums in registers (one atomic per column per workgroup).
 #include <hip/hip_runtime.h>
 
 #include "gsn_internal.h"
@@ -22,18 +28,16 @@ namespace gsn {
 
 constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int APITCH = BK + 1, WPITCH = BN + 1;
-constexpr int MAX_BLOCKS = 5, MAX_CHUNKS = 24;
+constexpr int MAX_BLOCKS = 5;
+constexpr int NPRE = BM / 8;  // staged elements per thread per slice (A); a W^T slice needs BN / 8 = 16 as well
 
 struct LinArgs {
     int64_t m_rows;
-    int n_blocks, n_chunks;
+    int n_blocks;
     const float *bdata[MAX_BLOCKS];
     const int64_t *bidx[MAX_BLOCKS];
     const int32_t *bidx32[MAX_BLOCKS];
     int bwidth[MAX_BLOCKS];
-    // chunk c: block, column offset inside the block, length (<= BK), k offset inside a row of W
-    unsigned char cblock[MAX_CHUNKS], clen[MAX_CHUNKS];
-    short ccol[MAX_CHUNKS], cwk[MAX_CHUNKS];
     const float *W, *bias, *bn_mean, *bn_scale, *bn_shift;
     int k_total, n_out, act;
     const int32_t *row_perm;
@@ -42,6 +46,8 @@ struct LinArgs {
 };
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ void lds_barrier_l() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __device__ __forceinline__ float apply_act(float y, int act) {
     switch (act) {
@@ -52,229 +58,140 @@ __device__ __forceinline__ float apply_act(float y, int act) {
     }
 }
 
-__global__ __launch_bounds__(256) void linear_fwd_stream_kernel(LinArgs a) {
-    __shared__ float As[BM * APITCH];
-    __shared__ float Ws[BK * WPITCH];
-    __shared__ int64_t rowsrc[MAX_BLOCKS][BM];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int li = lane & 31, lh = lane >> 5;
-    const int n0 = blockIdx.y * BN;
-    const int64_t n_tiles = (a.m_rows + BM - 1) / BM;
-
-    double st_sum[2] = {0.0, 0.0}, st_sq[2] = {0.0, 0.0};
-
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int64_t row0 = tile * BM;
-        // resolve the source row of every tile row for every block once
-        if (tid < BM) {
-            const int64_t grow = row0 + tid;
-            int64_t logical = 0;
-            if (grow < a.m_rows) logical = a.row_perm ? (int64_t)a.row_perm[grow] : grow;
-#pragma unroll
-            for (int b = 0; b < MAX_BLOCKS; ++b)
-                if (b < a.n_blocks) rowsrc[b][tid] = (grow < a.m_rows) ? (a.bidx32[b] ? (int64_t)a.bidx32[b][logical] : (a.bidx[b] ? a.bidx[b][logical] : logical)) : -1;
-        }
-        f32x16 acc[2][2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        __syncthreads();
-
-        for (int c = 0; c < a.n_chunks; ++c) {
-            const int blk = a.cblock[c], len = a.clen[c], coff = a.ccol[c], wk = a.cwk[c];
-            const float *bd = a.bdata[blk];
-            const int bw = a.bwidth[blk];
-            // stage A chunk: lanes along k (contiguous 128 B per row), 8 rows per pass
-            {
-                const int kc = tid & 31, r0 = tid >> 5;
-#pragma unroll
-                for (int i = 0; i < BM / 8; ++i) {
-                    const int r = r0 + 8 * i;
-                    const int64_t sr = rowsrc[blk][r];
-                    float v = 0.f;
-                    if (kc < len && sr >= 0) v = bd[sr * bw + coff + kc];
-                    As[r * APITCH + kc] = v;
-                }
-                // stage W^T chunk: Ws[k][j] = W[n0+j][wk+k]
-#pragma unroll
-                for (int i = 0; i < BN / 8; ++i) {
-                    const int j = r0 + 8 * i;
-                    float v = 0.f;
-                    if (kc < len && n0 + j < a.n_out) v = a.W[(int64_t)(n0 + j) * a.k_total + wk + kc];
-                    Ws[kc * WPITCH + j] = v;
-                }
-            }
-            __syncthreads();
-            const int ksteps = (len + 1) >> 1;
-            const float *ap0 = As + (wm * 64 + li) * APITCH + lh;
-            const float *ap1 = ap0 + 32 * APITCH;
-            const float *bp0 = Ws + lh * WPITCH + wn * 64 + li;
-            for (int ks = 0; ks < ksteps; ++ks) {
-                const float a0 = ap0[2 * ks], a1 = ap1[2 * ks];
-                const float b0 = bp0[2 * ks * WPITCH], b1 = bp0[2 * ks * WPITCH + 32];
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-            }
-            __syncthreads();
-        }
-
-        // epilogue.  C layout of a 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn * 64 + j * 32 + li;
-            const bool cok = col < a.n_out;
-            const float bias = (cok && a.bias) ? a.bias[col] : 0.f;
-            float mean = 0.f, scale = 1.f, shift = 0.f;
-            if (cok && a.bn_scale) { mean = a.bn_mean[col]; scale = a.bn_scale[col]; shift = a.bn_shift[col]; }
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int64_t row = row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (!cok || row >= a.m_rows) continue;
-                    const float h = acc[i][j][r] + bias;
-                    if (a.stats) {
-                        st_sum[j] += (double)h;
-                        st_sq[j] += (double)h * (double)h;
-                    } else {
-                        float y = h;
-                        if (a.bn_scale) y = (h - mean) * scale + shift;
-                        a.out[row * a.n_out + col] = apply_act(y, a.act);
-                    }
-                }
-            }
-        }
-        __syncthreads();  // rowsrc is rewritten by the next tile
-    }
-
-    if (a.stats) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn * 64 + j * 32 + li;
-            double s = st_sum[j], q = st_sq[j];
-            s += __shfl_xor(s, 32);
-            q += __shfl_xor(q, 32);
-            if (lh == 0 && col < a.n_out) {
-                atomicAdd(&a.stats[col], s);
-                atomicAdd(&a.stats[a.n_out + col], q);
-            }
-        }
-    }
-}
-
-
-// ----------------------------------------------------------------------------------------------------------------
-// Main kernel: W^T resident in LDS for the whole (persistent) workgroup, A staged in 32-wide slices of the
-// CONCATENATED input row (a slice may straddle input blocks), software-pipelined:
-//     write slice c (registers -> LDS buffer c&1) | barrier | issue global loads of slice c+1 into registers |
-//     16 k-steps x 4 MFMA on slice c
-// so HBM/L2 latency of the gathers hides under the 4096-cycle MFMA phase (one wave per SIMD, 4 independent
-// accumulators keep the matrix pipe issuing back to back), one barrier per slice, and the gather indices of the NEXT
-// row tile are fetched while the current tile computes.  Used when K_pad*129*4 + 38 KB fits the 160 KB LDS (K <= 224).
-// ----------------------------------------------------------------------------------------------------------------
-constexpr int NPRE = BM / 8;  // staged elements per thread per slice
-
-struct RowSrc {
-    int v[MAX_BLOCKS];
+// which block / column does concatenated column kg belong to (clamped to a valid address when kg >= K: its W row is 0)
+struct ColMapL {
+    const float *base;
+    int bw, rsoff;
 };
 
-__device__ __forceinline__ void rowsrc_fetch(const LinArgs &a, int64_t row0, int tid, RowSrc &rs) {
-    if (tid < BM) {
-        const int64_t grow = row0 + tid;
-        const bool ok = grow < a.m_rows;
-        int64_t logical = 0;
-        if (ok) logical = a.row_perm ? (int64_t)a.row_perm[grow] : grow;
-#pragma unroll
-        for (int b = 0; b < MAX_BLOCKS; ++b) {
-            int r = -1;
-            if (b < a.n_blocks && ok) r = a.bidx32[b] ? a.bidx32[b][logical] : (a.bidx[b] ? (int)a.bidx[b][logical] : (int)logical);
-            rs.v[b] = r;
-        }
-    }
-}
-
-__device__ __forceinline__ void rowsrc_store(int *dst /*[MAX_BLOCKS][BM]*/, int tid, const RowSrc &rs) {
-    if (tid < BM) {
-#pragma unroll
-        for (int b = 0; b < MAX_BLOCKS; ++b) dst[b * BM + tid] = rs.v[b];
-    }
-}
-
-// global loads of slice c (columns c*32 .. c*32+31 of the concatenated row) for 16 rows of this thread.
-// Loads are unconditional (row / column clamped into the block, result masked) so the 16 of them issue back to back.
-__device__ __forceinline__ void slice_fetch(const LinArgs &a, const int *rsrc, int c, int tid, float (&pre)[NPRE]) {
-    const int kc = tid & 31, r0 = tid >> 5;
-    const int kg = c * BK + kc;
+__device__ __forceinline__ ColMapL col_map_l(const LinArgs &a, int kg) {
     int blk = 0, col = kg;
 #pragma unroll
     for (int b = 0; b < MAX_BLOCKS - 1; ++b) {
         if (b < a.n_blocks - 1 && blk == b && col >= a.bwidth[b]) { col -= a.bwidth[b]; blk = b + 1; }
     }
-    const bool kok = kg < a.k_total;
+    if (kg >= a.k_total) { blk = 0; col = 0; }
     const float *bd = a.bdata[0];
     int bw = a.bwidth[0];
 #pragma unroll
     for (int b = 1; b < MAX_BLOCKS; ++b)
         if (blk == b) { bd = a.bdata[b]; bw = a.bwidth[b]; }
-    col = kok ? col : 0;
-    const float *bcol = bd + col;
-    const int *rs = rsrc + blk * BM + r0;
-#pragma unroll
-    for (int i = 0; i < NPRE; ++i) {
-        const int sr = rs[8 * i];
-        pre[i] = bcol[(int64_t)(sr < 0 ? 0 : sr) * bw];   // raw; masked when written to LDS (a select here would force
-    }                                                      // an immediate vmcnt wait and serialise the prefetch)
+    ColMapL m;
+    m.base = bd + col; m.bw = bw; m.rsoff = blk * BM;
+    return m;
 }
 
-template <bool STATS>
-__global__ __launch_bounds__(256) void linear_fwd_kernel(LinArgs a, int k_pad) {
+struct RowSrcL {
+    int v[3];
+};
+
+template <bool STATS, bool WRES>
+__global__ __launch_bounds__(256, 2) void linear_fwd_kernel(LinArgs a, int k_pad) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *Wt = lds;                                   // [k_pad][WPITCH]
-    float *As = Wt + k_pad * WPITCH;                   // [2][BM][APITCH]
+    // WRES: Wt [k_pad][WPITCH] resident;  else: Wt [2][BK][WPITCH] double buffer
+    float *Wt = lds;
+    float *As = Wt + (WRES ? k_pad : 2 * BK) * WPITCH;          // [2][BM][APITCH]
     int *rsrc = reinterpret_cast<int *>(As + 2 * BM * APITCH);  // [2][MAX_BLOCKS][BM]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
+    const int kc = tid & 31, r0 = tid >> 5;
     const int n0 = blockIdx.y * BN;
     const int64_t n_tiles = (a.m_rows + BM - 1) / BM;
     const int n_slices = k_pad / BK;
 
-    // W^T resident: Wt[k][j] = W[n0+j][k], zero padded
-    for (int i = tid; i < k_pad * BN; i += 256) {
-        const int j = i / k_pad, k = i - j * k_pad;   // consecutive threads walk k: coalesced rows of W
-        float v = 0.f;
-        if (k < a.k_total && n0 + j < a.n_out) v = a.W[(int64_t)(n0 + j) * a.k_total + k];
-        Wt[k * WPITCH + j] = v;
+    if (WRES) {
+        for (int i = tid; i < k_pad * BN; i += 256) {
+            const int j = i / k_pad, k = i - j * k_pad;   // consecutive threads walk k: coalesced rows of W
+            float v = 0.f;
+            if (k < a.k_total && n0 + j < a.n_out) v = a.W[(int64_t)(n0 + j) * a.k_total + k];
+            Wt[k * WPITCH + j] = v;
+        }
+    }
+
+    // row sources: thread t resolves tile row t&127 of blocks t>>7, (t>>7)+2, (t>>7)+4; its index pointers are picked
+    // once and live in VGPRs (looping over the block table per row keeps the whole table in SGPRs and spills it)
+    const int rs_r = tid & (BM - 1);
+    const int32_t *rp32[3];
+    const int64_t *rp64[3];
+    bool ron[3];
+#pragma unroll
+    for (int h = 0; h < 3; ++h) {
+        const int b = (tid >> 7) + 2 * h;
+        ron[h] = b < a.n_blocks;
+        rp32[h] = nullptr; rp64[h] = nullptr;
+#pragma unroll
+        for (int q = 0; q < MAX_BLOCKS; ++q)
+            if (q == b) { rp32[h] = a.bidx32[q]; rp64[h] = a.bidx[q]; }
+    }
+    auto rs_fetch = [&](int64_t row0, RowSrcL &rs) {
+        const int64_t grow = row0 + rs_r;
+        const bool ok = grow < a.m_rows;
+        int64_t logical = 0;
+        if (ok) logical = a.row_perm ? (int64_t)a.row_perm[grow] : grow;
+#pragma unroll
+        for (int h = 0; h < 3; ++h) {
+            int r = 0;   // rows past the end read row 0 (never emitted)
+            if (ron[h] && ok) r = rp32[h] ? rp32[h][logical] : (rp64[h] ? (int)rp64[h][logical] : (int)logical);
+            rs.v[h] = r;
+        }
+    };
+    auto rs_store = [&](int *dst, const RowSrcL &rs) {
+#pragma unroll
+        for (int h = 0; h < 3; ++h)
+            if (ron[h]) dst[((tid >> 7) + 2 * h) * BM + rs_r] = rs.v[h];
+    };
+
+    // epilogue constants of this lane's two output columns:  y = acc * scale + c0
+    float e_bias[2], e_scale[2], e_c0[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + li;
+        const bool cok = col < a.n_out;
+        e_bias[j] = (cok && a.bias) ? a.bias[col] : 0.f;
+        e_scale[j] = 1.f; e_c0[j] = e_bias[j];
+        if (cok && a.bn_scale) { e_scale[j] = a.bn_scale[col]; e_c0[j] = (e_bias[j] - a.bn_mean[col]) * e_scale[j] + a.bn_shift[col]; }
     }
 
     double st_sum[2] = {0.0, 0.0}, st_sq[2] = {0.0, 0.0};
-    float pre[NPRE];
-    RowSrc rs_next;
+    float preA[NPRE], preW[NPRE];
+
+    // global loads of slice c: A columns c*32 + kc for 16 rows; W^T rows (n0 + r0 + 8i) at k = c*32 + kc
+    auto fetch = [&](const int *rs, int c) {
+        const ColMapL cm = col_map_l(a, c * BK + kc);
+        const int *rp = rs + cm.rsoff + r0;
+#pragma unroll
+        for (int i = 0; i < NPRE; ++i) preA[i] = cm.base[(int64_t)rp[8 * i] * cm.bw];
+        if (!WRES) {
+            const int kg = c * BK + kc;
+            const int kk = kg < a.k_total ? kg : 0;
+#pragma unroll
+            for (int i = 0; i < NPRE; ++i) {
+                int j = n0 + r0 + 8 * i;
+                j = j < a.n_out ? j : 0;
+                preW[i] = a.W[(int64_t)j * a.k_total + kk];
+            }
+        }
+    };
+
     int64_t tile = blockIdx.x;
-    if (tile < n_tiles) {
-        RowSrc rs0;
-        rowsrc_fetch(a, tile * BM, tid, rs0);
-        rowsrc_store(rsrc, tid, rs0);
+    {
+        RowSrcL r;
+        rs_fetch(tile * BM, r);
+        rs_store(rsrc, r);
     }
     __syncthreads();
-    if (tile < n_tiles) slice_fetch(a, rsrc, 0, tid, pre);
+    if (tile < n_tiles) fetch(rsrc, 0);
     int cur_rs = 0, cur_as = 0;
+    RowSrcL rs_next;
 
     for (; tile < n_tiles; tile += gridDim.x) {
         const int64_t row0 = tile * BM;
         const int64_t next_tile = tile + gridDim.x;
         const bool has_next = next_tile < n_tiles;
-        if (has_next) rowsrc_fetch(a, next_tile * BM, tid, rs_next);   // lands while this tile computes
+        rs_fetch(next_tile * BM, rs_next);   // lands while this tile computes
 
         f32x16 acc[2][2];
 #pragma unroll
@@ -286,28 +203,31 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(LinArgs a, int k_pad) {
 
         for (int c = 0; c < n_slices; ++c) {
             float *Ab = As + cur_as * (BM * APITCH);
-            {
-                const int kc = tid & 31, r0 = tid >> 5;
+            float *Wb = WRES ? Wt + c * BK * WPITCH : Wt + cur_as * (BK * WPITCH);
+#pragma unroll
+            for (int i = 0; i < NPRE; ++i) Ab[(r0 + 8 * i) * APITCH + kc] = preA[i];
+            if (!WRES) {
+                // rows of W^T past K / columns past n_out are zeroed by a per-thread 0/1 factor applied to values that
+                // were loaded one slice earlier (no select on fresh loads)
+                const float km = (c * BK + kc < a.k_total) ? 1.f : 0.f;
 #pragma unroll
                 for (int i = 0; i < NPRE; ++i) {
-                    const bool ok = (c * BK + kc < a.k_total) && (row0 + r0 + 8 * i < a.m_rows);
-                    Ab[(r0 + 8 * i) * APITCH + kc] = ok ? pre[i] : 0.f;
+                    const float jm = (n0 + r0 + 8 * i < a.n_out) ? km : 0.f;
+                    Wb[kc * WPITCH + r0 + 8 * i] = preW[i] * jm;
                 }
             }
             const bool last = c == n_slices - 1;
-            if (last && has_next) rowsrc_store(rsrc + (cur_rs ^ 1) * (MAX_BLOCKS * BM), tid, rs_next);
-            __syncthreads();
-            if (!last) slice_fetch(a, rsrc + cur_rs * (MAX_BLOCKS * BM), c + 1, tid, pre);
-            else if (has_next) slice_fetch(a, rsrc + (cur_rs ^ 1) * (MAX_BLOCKS * BM), 0, tid, pre);
+            if (last && has_next) rs_store(rsrc + (cur_rs ^ 1) * (MAX_BLOCKS * BM), rs_next);
+            lds_barrier_l();
+            if (!last) fetch(rsrc + cur_rs * (MAX_BLOCKS * BM), c + 1);
+            else if (has_next) fetch(rsrc + (cur_rs ^ 1) * (MAX_BLOCKS * BM), 0);
 
             int ksteps = (a.k_total - c * BK + 1) >> 1;
             ksteps = ksteps > BK / 2 ? BK / 2 : ksteps;
             const float *ap0 = Ab + (wm * 64 + li) * APITCH + lh;
             const float *ap1 = ap0 + 32 * APITCH;
-            const float *bp0 = Wt + (c * BK + lh) * WPITCH + wn * 64 + li;
+            const float *bp0 = Wb + lh * WPITCH + wn * 64 + li;
             if (ksteps == BK / 2) {
-                // full slice: fully unrolled so the scheduler hoists the LDS operand reads of later k-steps above the
-                // MFMAs of earlier ones (4 independent accumulators keep the matrix pipe issuing back to back)
 #pragma unroll
                 for (int ks = 0; ks < BK / 2; ++ks) {
                     const float a0 = ap0[2 * ks], a1 = ap1[2 * ks];
@@ -337,9 +257,6 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(LinArgs a, int k_pad) {
         for (int j = 0; j < 2; ++j) {
             const int col = n0 + wn * 64 + j * 32 + li;
             const bool cok = col < a.n_out;
-            const float bias = (cok && a.bias) ? a.bias[col] : 0.f;
-            float mean = 0.f, scale = 1.f, shift = 0.f;
-            if (cok && a.bn_scale) { mean = a.bn_mean[col]; scale = a.bn_scale[col]; shift = a.bn_shift[col]; }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int64_t rbase = row0 + wm * 64 + i * 32 + 4 * lh;
@@ -348,13 +265,12 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(LinArgs a, int k_pad) {
                 for (int r = 0; r < 16; ++r) {
                     const int dr = (r & 3) + 8 * (r >> 2);
                     if (!full && (!cok || rbase + dr >= a.m_rows)) continue;
-                    const float h = acc[i][j][r] + bias;
                     if (STATS) {
+                        const float h = acc[i][j][r] + e_bias[j];
                         st_sum[j] += (double)h;
                         st_sq[j] += (double)h * (double)h;
                     } else {
-                        const float y = a.bn_scale ? (h - mean) * scale + shift : h;
-                        op[(int64_t)dr * a.n_out] = apply_act(y, a.act);
+                        op[(int64_t)dr * a.n_out] = apply_act(fmaf(acc[i][j][r], e_scale[j], e_c0[j]), a.act);
                     }
                 }
             }
@@ -376,6 +292,21 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(LinArgs a, int k_pad) {
     }
 }
 
+template <bool STATS, bool WRES>
+static int launch_linear(const LinArgs &a, int k_pad, size_t lds, int64_t gx, int col_tiles, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_fwd_kernel<STATS, WRES>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e0 != hipSuccess) return set_error(GSN_E_HIP, "hipFuncSetAttribute(linear_fwd_kernel): %s", hipGetErrorString(e0));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((linear_fwd_kernel<STATS, WRES>), dim3((unsigned)gx, (unsigned)col_tiles), dim3(256), lds, st, a, k_pad);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(GSN_E_HIP, "linear_fwd_kernel: %s", hipGetErrorString(e));
+    return GSN_OK;
+}
+
 }  // namespace gsn
 
 using namespace gsn;
@@ -392,48 +323,29 @@ extern "C" int gsn_linear_fwd_hip(int64_t m_rows, int n_blocks, const gsn_block 
     if (m_rows <= 0) return GSN_OK;
     LinArgs a{};
     a.m_rows = m_rows; a.n_blocks = n_blocks;
-    int k_total = 0, nc = 0;
+    int k_total = 0;
     for (int b = 0; b < n_blocks; ++b) {
-        if (!blocks[b].data || blocks[b].width <= 0 || blocks[b].width > 32767)
+        if (!blocks[b].data || blocks[b].width <= 0 || blocks[b].width > (1 << 20))
             return set_error(GSN_E_INVALID, "gsn_linear_fwd_hip: block %d has no data or a bad width", b);
         a.bdata[b] = blocks[b].data; a.bidx[b] = blocks[b].idx; a.bidx32[b] = blocks[b].idx32; a.bwidth[b] = (int)blocks[b].width;
-        for (int off = 0; off < (int)blocks[b].width; off += BK) {
-            if (nc >= MAX_CHUNKS) return set_error(GSN_E_UNSUPPORTED, "gsn_linear_fwd_hip: input wider than %d chunks of %d", MAX_CHUNKS, BK);
-            const int len = (int)blocks[b].width - off < BK ? (int)blocks[b].width - off : BK;
-            a.cblock[nc] = (unsigned char)b; a.clen[nc] = (unsigned char)len; a.ccol[nc] = (short)off; a.cwk[nc] = (short)(k_total + off);
-            ++nc;
-        }
         k_total += (int)blocks[b].width;
     }
-    a.n_chunks = nc; a.k_total = k_total; a.n_out = (int)n_out; a.act = act;
+    a.k_total = k_total; a.n_out = (int)n_out; a.act = act;
     a.W = W; a.bias = bias; a.bn_mean = bn_mean; a.bn_scale = bn_scale; a.bn_shift = bn_shift;
     a.row_perm = row_perm; a.out = out; a.stats = stats;
     const int64_t n_tiles = (m_rows + BM - 1) / BM;
     const int col_tiles = (int)((n_out + BN - 1) / BN);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int k_pad = (k_total + BK - 1) / BK * BK;
-    const size_t lds = (size_t)k_pad * WPITCH * 4 + 2 * BM * APITCH * 4 + 2 * MAX_BLOCKS * BM * 4;
-    if (lds <= 160 * 1024) {
-        // persistent: one workgroup per CU (LDS-bound), grid-stride over row tiles
-        int64_t gx = n_tiles < 256 ? n_tiles : 256;
-        if (col_tiles > 1) gx = n_tiles < 128 ? n_tiles : 128;
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_fwd_kernel<false>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e0 == hipSuccess)
-                e0 = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_fwd_kernel<true>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e0 != hipSuccess) return set_error(GSN_E_HIP, "hipFuncSetAttribute(linear_fwd_kernel): %s", hipGetErrorString(e0));
-            attr_set = true;
-        }
-        if (stats) hipLaunchKernelGGL(linear_fwd_kernel<true>, dim3((unsigned)gx, (unsigned)col_tiles), dim3(256), lds, st, a, k_pad);
-        else hipLaunchKernelGGL(linear_fwd_kernel<false>, dim3((unsigned)gx, (unsigned)col_tiles), dim3(256), lds, st, a, k_pad);
-    } else {
-        int64_t gx = n_tiles < 1024 ? n_tiles : 1024;
-        hipLaunchKernelGGL(linear_fwd_stream_kernel, dim3((unsigned)gx, (unsigned)col_tiles), dim3(256), 0, st, a);
-    }
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return set_error(GSN_E_HIP, "linear_fwd_kernel: %s", hipGetErrorString(e));
-    return GSN_OK;
+    const size_t common = (size_t)2 * BM * APITCH * 4 + 2 * MAX_BLOCKS * BM * 4;
+    const size_t lds_res = (size_t)k_pad * WPITCH * 4 + common;
+    const size_t lds_str = (size_t)2 * BK * WPITCH * 4 + common;
+    // resident W only when it leaves room for two workgroups per CU (they hide each other's staging); else stream W
+    const bool wres = lds_res <= 78 * 1024;
+    const size_t lds = wres ? lds_res : lds_str;
+    int64_t gx = 512 / col_tiles;   // persistent: ~2 workgroups per CU in total
+    if (gx < 1) gx = 1;
+    if (gx > n_tiles) gx = n_tiles;
+    if (stats) return wres ? launch_linear<true, true>(a, k_pad, lds, gx, col_tiles, st) : launch_linear<true, false>(a, k_pad, lds, gx, col_tiles, st);
+    return wres ? launch_linear<false, true>(a, k_pad, lds, gx, col_tiles, st) : launch_linear<false, false>(a, k_pad, lds, gx, col_tiles, st);
 }
