@@ -12,7 +12,10 @@
 //     (lane (li,lh): W_s[32w+li][2q+lh], ceil(K/2) floats per stage) in VGPRs for the whole persistent kernel -- no LDS or
 //     L2 traffic for weights at all, and LDS is free for activations;
 //   * a tile is 64 rows x full K in LDS (pitch odd -> conflict-free fragment reads), so there is one barrier per stage,
-//     not per K-slice; each wave runs 2 row fragments x 1 column fragment = 2 independent v_mfma_f32_32x32x2_f32 chains;
+//     not per K-slice; the workgroup has 8 waves = 2 per SIMD: waves w and w+4 own the same 32 output columns and the two
+//     32-row halves of the tile (one v_mfma_f32_32x32x2_f32 chain each, back-to-back issue = its 64-cycle latency), so
+//     the per-wave staging / epilogue work -- which is VALU-issue bound and cannot overlap the wave's own MFMAs --
+//     halves, and two waves issue it concurrently on every SIMD;
 //   * the HBM inputs of the NEXT tile (all stages) are prefetched into registers while the current tile computes
 //     (>= 5k MFMA cycles of cover), gather indices two tiles ahead;
 //   * stage outputs are written by the epilogue straight into the next stage's LDS input tile.
@@ -101,28 +104,32 @@ __device__ __forceinline__ ColMap col_map(const ChainArgs &a, int s, int kc) {
     return m;
 }
 
-// Row sources (which row of each input block feeds tile row r) are resolved by ALL 256 threads: thread t owns tile
-// row t&63 of block t>>6 and of block (t>>6)+4; its index pointers are chosen once, before the tile loop, and live in
-// VGPRs -- looping over the block table per row instead keeps ~40 kernarg pointers in SGPRs and spills them to VGPR lanes.
+// Row sources (which row of each input block feeds tile row r) are resolved by all threads of the workgroup: thread t owns
+// tile row t&63 of block t>>6 (and of block (t>>6)+4 in a 4-wave workgroup); its index pointers are chosen once, before
+// the tile loop, and live in VGPRs -- looping over the block table per row instead keeps ~40 kernarg pointers in SGPRs
+// and spills them to VGPR lanes.
+template <int NP>
 struct RowSrcThread {
-    const int32_t *p32[2];
-    const int64_t *p64[2];
-    bool on[2];        // block exists
+    const int32_t *p32[NP];
+    const int64_t *p64[NP];
+    bool on[NP];       // block exists
     const int32_t *perm, *seg;
     int64_t m_rows;
-    int b[2], r;
+    int b[NP], r;
 };
+template <int NP>
 struct RowSrcC {
-    int v[2];
-    int tg, edge;  // (threads of block 0 only) target segment of the row; lane 0 / 63: target of the row before / after the tile
+    int v[NP];
+    int tg, edge;  // (threads of block 0 only) target segment of the row; row 0 / 63: target of the row before / after the tile
 };
 
-__device__ __forceinline__ RowSrcThread rs_thread(const ChainArgs &a, int tid) {
-    RowSrcThread t;
+template <int NP>
+__device__ __forceinline__ RowSrcThread<NP> rs_thread(const ChainArgs &a, int tid) {
+    RowSrcThread<NP> t;
     t.r = tid & (CBM - 1);
     t.perm = a.row_perm; t.seg = a.seg_target; t.m_rows = a.m_rows;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NP; ++h) {
         const int b = (tid >> 6) + 4 * h;
         t.b[h] = b;
         t.on[h] = b < a.n_blocks;
@@ -134,13 +141,14 @@ __device__ __forceinline__ RowSrcThread rs_thread(const ChainArgs &a, int tid) {
     return t;
 }
 
-__device__ __forceinline__ void rs_fetch(const RowSrcThread &t, int64_t row0, RowSrcC &rs) {
+template <int NP>
+__device__ __forceinline__ void rs_fetch(const RowSrcThread<NP> &t, int64_t row0, RowSrcC<NP> &rs) {
     const int64_t grow = row0 + t.r;
     const bool ok = grow < t.m_rows;
     int64_t logical = 0;
     if (ok) logical = t.perm ? (int64_t)t.perm[grow] : grow;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NP; ++h) {
         int r = -1;
         if (t.on[h] && ok) r = t.p32[h] ? t.p32[h][logical] : (t.p64[h] ? (int)t.p64[h][logical] : (int)logical);
         rs.v[h] = r;
@@ -153,9 +161,11 @@ __device__ __forceinline__ void rs_fetch(const RowSrcThread &t, int64_t row0, Ro
     }
 }
 
-__device__ __forceinline__ void rs_store(int *dst, const RowSrcThread &t, const RowSrcC &rs) {
-    if (t.on[0]) dst[t.b[0] * CBM + t.r] = rs.v[0];
-    if (t.on[1]) dst[t.b[1] * CBM + t.r] = rs.v[1];
+template <int NP>
+__device__ __forceinline__ void rs_store(int *dst, const RowSrcThread<NP> &t, const RowSrcC<NP> &rs) {
+#pragma unroll
+    for (int h = 0; h < NP; ++h)
+        if (t.on[h]) dst[t.b[h] * CBM + t.r] = rs.v[h];
     if (t.b[0] == 0) {
         dst[CMAX_BLOCKS * CBM + t.r] = rs.tg;
         if (t.r == 0) dst[(CMAX_BLOCKS + 1) * CBM] = rs.edge;
@@ -163,12 +173,22 @@ __device__ __forceinline__ void rs_store(int *dst, const RowSrcThread &t, const 
     }
 }
 
-// WPE = waves per SIMD the kernel is compiled for: small single-stage chains use 2 (<= 256 registers; two co-resident
-// workgroups overlap each other's staging / epilogue with MFMA), everything else exactly 1 so the register allocator may
-// use the whole 512-entry file for the weight fragments instead of spilling.
-template <int NST, int MAXCH, bool STATS, int WPE, bool SEG>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void mlp_chain_kernel(ChainArgs a) {
-    constexpr int PF0_J = (MAXCH * CHK + 31) / 32;  // 32-column groups of the stage-0 input
+constexpr int SEG_ROWS = GSN_SEG_RANGE_ROWS;  // rows per reduction range of the segmented-sum epilogue
+
+// CH0 / CH1 = register chunks (16 k each) of the two stages' weight fragments; WPE = waves per SIMD the kernel is
+// compiled for; NW = waves per workgroup:
+//   NW = 8 (single-stage chains): waves w and w+4 own the same 32 output columns and the two 32-row halves of the tile,
+//           so the VALU-issue-bound staging / epilogue work per wave halves and 2-4 waves share every SIMD;
+//   NW = 4 (two-stage chains): one wave per SIMD with both row halves (two independent accumulator chains) -- 144+
+//           weight registers per lane leave no room for a second wave (it spills and the MFMA phase collapses).
+template <int NST, int CH0, int CH1, bool STATS, int WPE, bool SEG, int NW>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void mlp_chain_kernel(ChainArgs a) {
+    constexpr int CT = 64 * NW;                     // threads per workgroup
+    constexpr int NACC = NW == 4 ? 2 : 1;           // row halves handled by one wave
+    constexpr int RSTEP = CT / 32;                  // tile rows covered by one staging pass
+    constexpr int NROW = CBM / RSTEP;               // staging passes (rows per thread)
+    constexpr int NP = NW == 4 ? 2 : 1;             // row-source passes (blocks per thread)
+    constexpr int PF0_J = (CH0 * CHK + 31) / 32;    // 32-column groups of the stage-0 input
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int pitch = a.pitch;
     float *buf0 = lds;
@@ -176,27 +196,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     int *rsrc = reinterpret_cast<int *>(lds + 2 * CBM * pitch);  // [3][RS_STRIDE] ring: tiles t, t+1, t+2
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, w = tid >> 6;
+    const int lane = tid & 63, w8 = tid >> 6;
+    const int w = w8 & 3;                  // column block: output columns 32w .. 32w+31
+    const int rh = NW == 8 ? (w8 >> 2) : 0;  // row half of the tile owned by this wave (NW == 8)
     const int li = lane & 31, lh = lane >> 5;
-    const int kc0 = tid & 31, r0 = tid >> 5;
+    const int kc0 = tid & 31, r0 = tid >> 5;   // staging: column kc0 (+32j), rows r0 + RSTEP * i
     const int64_t n_tiles = (a.m_rows + CBM - 1) / CBM;
 
     // ---- weights -> registers (once) ----------------------------------------------------------------------------
-    float B[NST][MAXCH][8];
-    int nch[NST];
-#pragma unroll
-    for (int s = 0; s < NST; ++s) {
-        const ChainStage &st = a.st[s];
-        nch[s] = (st.k_total + CHK - 1) / CHK;
+    float B0[CH0][8], B1[CH1 > 0 ? CH1 : 1][8];
+    int nch[2] = {0, 0};
+    {
+        const ChainStage &st = a.st[0];
+        nch[0] = (st.k_total + CHK - 1) / CHK;
         const int col = 32 * w + li;
 #pragma unroll
-        for (int ch = 0; ch < MAXCH; ++ch)
+        for (int ch = 0; ch < CH0; ++ch)
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int k = ch * CHK + 2 * q + lh;
                 float v = 0.f;
                 if (k < st.k_total && col < st.n_out) v = st.W[(int64_t)col * st.k_total + k];
-                B[s][ch][q] = v;
+                B0[ch][q] = v;
+            }
+    }
+    if (NST > 1) {
+        const ChainStage &st = a.st[1];
+        nch[1] = (st.k_total + CHK - 1) / CHK;
+        const int col = 32 * w + li;
+#pragma unroll
+        for (int ch = 0; ch < CH1; ++ch)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int k = ch * CHK + 2 * q + lh;
+                float v = 0.f;
+                if (k < st.k_total && col < st.n_out) v = st.W[(int64_t)col * st.k_total + k];
+                B1[ch][q] = v;
             }
     }
 
@@ -206,7 +241,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     for (int j = 0; j < PF0_J; ++j) cm0[j] = col_map(a, 0, kc0 + 32 * j);
 
     // zero both activation tiles once: padded columns must hold finite values (their weights are zero)
-    for (int i = tid; i < 2 * CBM * pitch; i += 256) lds[i] = 0.f;
+    for (int i = tid; i < 2 * CBM * pitch; i += CT) lds[i] = 0.f;
 
     // per-stage epilogue constants of this lane's output column (loaded once: a load inside the tile loop would put a
     // vmcnt(0) in front of every use and drain the prefetch / the stores)
@@ -222,9 +257,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     }
 
     double st_sum = 0.0, st_sq = 0.0;
-    float pf0[PF0_J][8];
-    RowSrcC rsn;
-    const RowSrcThread rst = rs_thread(a, tid);
+    float pf0[PF0_J][NROW];
+    RowSrcC<NP> rsn;
+    const RowSrcThread<NP> rst = rs_thread<NP>(a, tid);
 
     // NOTE: the loaded values are kept RAW in the prefetch registers; masking (padded columns, rows past the end) is
     // applied when they are written to LDS.  Selecting on the value right here would make the compiler wait for every
@@ -233,8 +268,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 #pragma unroll
         for (int j = 0; j < PF0_J; ++j)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int sr = rs[cm0[j].rsoff + r0 + 8 * i];
+            for (int i = 0; i < NROW; ++i) {
+                const int sr = rs[cm0[j].rsoff + r0 + RSTEP * i];
                 pf0[j][i] = cm0[j].base[(int64_t)(sr < 0 ? 0 : sr) * cm0[j].bw];
             }
     };
@@ -244,13 +279,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 #pragma unroll
         for (int j = 0; j < PF0_J; ++j)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) dst[(r0 + 8 * i) * pitch + kc0 + 32 * j] = pf0[j][i];
+            for (int i = 0; i < NROW; ++i) dst[(r0 + RSTEP * i) * pitch + kc0 + 32 * j] = pf0[j][i];
     };
 
     // ---- prologue: row sources of the first two tiles; the first tile's inputs go to LDS synchronously -------------------
     int64_t tile = blockIdx.x;
     {
-        RowSrcC r;
+        RowSrcC<NP> r;
         rs_fetch(rst, tile * CBM, r);
         rs_store(rsrc, rst, r);
         rs_fetch(rst, (tile + gridDim.x) * CBM, r);
@@ -281,20 +316,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         for (int s = 0; s < NST; ++s) {
             const ChainStage &st = a.st[s];
             const bool active = 32 * w < st.n_out;  // wave-uniform
-            f32x16 acc0, acc1;
+            f32x16 acc[NACC];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+            for (int h = 0; h < NACC; ++h)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[h][r] = 0.f;
             if (active && !(a.dbg & 2)) {
-                const float *ap0 = in + li * pitch + lh;
-                const float *ap1 = ap0 + 32 * pitch;
+                const float *ap = in + (32 * rh + li) * pitch + lh;
+                if (s == 0) {
 #pragma unroll
-                for (int ch = 0; ch < MAXCH; ++ch) {
-                    if (ch < nch[s]) {
+                    for (int ch = 0; ch < CH0; ++ch) {
+                        if (ch < nch[0]) {
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) {
-                            const float a0 = ap0[ch * CHK + 2 * q], a1 = ap1[ch * CHK + 2 * q];
-                            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, B[s][ch][q], acc0, 0, 0, 0);
-                            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, B[s][ch][q], acc1, 0, 0, 0);
+                            for (int q = 0; q < 8; ++q) {
+#pragma unroll
+                                for (int h = 0; h < NACC; ++h)
+                                    acc[h] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[h * 32 * pitch + ch * CHK + 2 * q], B0[ch][q], acc[h], 0, 0, 0);
+                            }
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int ch = 0; ch < CH1; ++ch) {
+                        if (ch < nch[1]) {
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) {
+#pragma unroll
+                                for (int h = 0; h < NACC; ++h)
+                                    acc[h] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[h * 32 * pitch + ch * CHK + 2 * q], B1[ch][q], acc[h], 0, 0, 0);
+                            }
                         }
                     }
                 }
@@ -305,21 +355,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
             const bool cok = col < st.n_out;
             const float bias = e_bias[s], scale = e_scale[s], c0 = e_c0[s];
             const bool last = s == NST - 1;
-            auto value = [&](int rf, int r) { return fmaf(rf ? acc1[r] : acc0[r], scale, c0); };
+            auto value = [&](int h, int r) { return fmaf(acc[h][r], scale, c0); };
             if (!last) {
                 // stage output -> the next stage's LDS input tile
-                float *lp = buf1 + (4 * lh) * pitch + col;
+                float *lp = buf1 + (32 * rh + 4 * lh) * pitch + col;
                 if (cok) {
                     if (st.act == 1) {
 #pragma unroll
-                        for (int rf = 0; rf < 2; ++rf)
+                        for (int h = 0; h < NACC; ++h)
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) { const float y = value(rf, r); lp[(rf * 32 + (r & 3) + 8 * (r >> 2)) * pitch] = y > 0.f ? y : 0.f; }
+                            for (int r = 0; r < 16; ++r) { const float y = value(h, r); lp[(h * 32 + (r & 3) + 8 * (r >> 2)) * pitch] = y > 0.f ? y : 0.f; }
                     } else {
 #pragma unroll
-                        for (int rf = 0; rf < 2; ++rf)
+                        for (int h = 0; h < NACC; ++h)
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) lp[(rf * 32 + (r & 3) + 8 * (r >> 2)) * pitch] = value(rf, r);
+                            for (int r = 0; r < 16; ++r) lp[(h * 32 + (r & 3) + 8 * (r >> 2)) * pitch] = value(h, r);
                     }
                 }
                 lds_barrier();
@@ -333,11 +383,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
                 if (has_next) stage_in(next_in);
                 rs_store(rsrc + slot_nn * RS_STRIDE, rst, rsn);   // row sources of tile t+2
 #pragma unroll
-                for (int rf = 0; rf < 2; ++rf)
+                for (int hh = 0; hh < NACC; ++hh)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int64_t row = row0 + rf * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        const float h = (rf ? acc1[r] : acc0[r]) + bias;
+                        const int64_t row = row0 + 32 * (rh + hh) + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        const float h = acc[hh][r] + bias;
                         if (cok && row < a.m_rows) { st_sum += (double)h; st_sq += (double)h * (double)h; }
                     }
                 lds_barrier();
@@ -348,51 +398,54 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
                 // that straddles a range boundary is added atomically (its output row was zeroed by
                 // gsn_segsum_prepare_hip).  Summation order inside a segment = row order.
                 lds_barrier();                                   // all waves finished the MFMAs on `in`
-                float *Y = in + (4 * lh) * pitch + col;
+                float *Y = in + (32 * rh + 4 * lh) * pitch + col;
                 if (cok) {
                     if (st.act == 1) {
 #pragma unroll
-                        for (int rf = 0; rf < 2; ++rf)
+                        for (int h = 0; h < NACC; ++h)
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) { const float y = value(rf, r); Y[(rf * 32 + (r & 3) + 8 * (r >> 2)) * pitch] = y > 0.f ? y : 0.f; }
+                            for (int r = 0; r < 16; ++r) { const float y = value(h, r); Y[(h * 32 + (r & 3) + 8 * (r >> 2)) * pitch] = y > 0.f ? y : 0.f; }
                     } else {
 #pragma unroll
-                        for (int rf = 0; rf < 2; ++rf)
+                        for (int h = 0; h < NACC; ++h)
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) Y[(rf * 32 + (r & 3) + 8 * (r >> 2)) * pitch] = value(rf, r);
+                            for (int r = 0; r < 16; ++r) Y[(h * 32 + (r & 3) + 8 * (r >> 2)) * pitch] = value(h, r);
                     }
                 }
                 if (has_next) stage_in(next_in);     // (the one vmcnt wait of the tile: before any store)
                 rs_store(rsrc + slot_nn * RS_STRIDE, rst, rsn);  // row sources of tile t+2
-                const int c = tid & 127, rb = (tid >> 7) * 32;
-                const int *tg = rsrc + slot * RS_STRIDE + CMAX_BLOCKS * CBM;   // this tile's targets
-                int tgl[32];
-                const int prev_t = rb > 0 ? tg[rb - 1] : tg[CBM];
-                const int next_t = rb + 32 < CBM ? tg[rb + 32] : tg[CBM + 1];
-#pragma unroll
-                for (int r = 0; r < 32; ++r) tgl[r] = tg[rb + r];
                 lds_barrier();
+                // thread -> column c, NRANGE consecutive ranges of SEG_ROWS rows
+                constexpr int NRANGE = (CBM * 128 / CT) / SEG_ROWS;
+                const int c = tid & 127;
+                const int *tg = rsrc + slot * RS_STRIDE + CMAX_BLOCKS * CBM;   // this tile's targets (slot is recycled two tiles later)
                 if (c < st.n_out && !(a.dbg & 4)) {
-                    const float *yp = in + rb * pitch + c;
                     float *op = a.out + c;
-                    int curt = tgl[0];
-                    bool straddle = curt == prev_t;
-                    float sum = 0.f;
 #pragma unroll
-                    for (int r = 0; r < 32; ++r) {
-                        const int t = tgl[r];
-                        if (t != curt) {
-                            if (curt >= 0) {
-                                if (straddle) atomicAdd(op + (int64_t)curt * st.n_out, sum);
-                                else op[(int64_t)curt * st.n_out] = sum;
+                    for (int g = 0; g < NRANGE; ++g) {
+                        const int rb = ((tid >> 7) * NRANGE + g) * SEG_ROWS;
+                        const float *yp = in + rb * pitch + c;
+                        const int prev_t = rb > 0 ? tg[rb - 1] : tg[CBM];
+                        const int next_t = rb + SEG_ROWS < CBM ? tg[rb + SEG_ROWS] : tg[CBM + 1];
+                        int curt = tg[rb];
+                        bool straddle = curt == prev_t;
+                        float sum = 0.f;
+#pragma unroll
+                        for (int r = 0; r < SEG_ROWS; ++r) {
+                            const int t = tg[rb + r];
+                            if (t != curt) {
+                                if (curt >= 0) {
+                                    if (straddle) atomicAdd(op + (int64_t)curt * st.n_out, sum);
+                                    else op[(int64_t)curt * st.n_out] = sum;
+                                }
+                                curt = t; sum = 0.f; straddle = false;
                             }
-                            curt = t; sum = 0.f; straddle = false;
+                            sum += yp[r * pitch];
                         }
-                        sum += yp[r * pitch];
-                    }
-                    if (curt >= 0) {
-                        if (straddle || curt == next_t) atomicAdd(op + (int64_t)curt * st.n_out, sum);
-                        else op[(int64_t)curt * st.n_out] = sum;
+                        if (curt >= 0) {
+                            if (straddle || curt == next_t) atomicAdd(op + (int64_t)curt * st.n_out, sum);
+                            else op[(int64_t)curt * st.n_out] = sum;
+                        }
                     }
                 }
                 // next tile's MFMAs read `next_in` (complete before the barrier above); its own pre-Y barrier orders the
@@ -400,26 +453,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
             } else {
                 if (has_next) stage_in(next_in);     // (the one vmcnt wait of the tile: before any store)
                 rs_store(rsrc + slot_nn * RS_STRIDE, rst, rsn);  // row sources of tile t+2
-                float *tile_out = a.out + row0 * st.n_out;                 // wave-uniform base (SGPR pair)
-                const int lane_off = 4 * lh * st.n_out + col;              // 32-bit per-lane offset inside the tile
+                float *tile_out = a.out + row0 * st.n_out;                       // wave-uniform base (SGPR pair)
+                const int lane_off = (32 * rh + 4 * lh) * st.n_out + col;        // 32-bit per-lane offset inside the tile
                 const bool full = row0 + CBM <= a.m_rows;
                 auto emit = [&](auto actf) {
                     if (a.dbg & 4) {
                     } else if (full) {
                         if (cok) {
 #pragma unroll
-                            for (int rf = 0; rf < 2; ++rf)
+                            for (int h = 0; h < NACC; ++h)
 #pragma unroll
-                                for (int r = 0; r < 16; ++r)
-                                    tile_out[lane_off + (rf * 32 + (r & 3) + 8 * (r >> 2)) * st.n_out] = actf(value(rf, r));
+                                for (int r = 0; r < 16; ++r) tile_out[lane_off + (h * 32 + (r & 3) + 8 * (r >> 2)) * st.n_out] = actf(value(h, r));
                         }
                     } else {
 #pragma unroll
-                        for (int rf = 0; rf < 2; ++rf)
+                        for (int h = 0; h < NACC; ++h)
 #pragma unroll
                             for (int r = 0; r < 16; ++r) {
-                                const int dr = rf * 32 + (r & 3) + 8 * (r >> 2);
-                                if (cok && row0 + 4 * lh + dr < a.m_rows) tile_out[lane_off + dr * st.n_out] = actf(value(rf, r));
+                                const int dr = h * 32 + (r & 3) + 8 * (r >> 2);
+                                if (cok && row0 + 32 * rh + 4 * lh + dr < a.m_rows) tile_out[lane_off + dr * st.n_out] = actf(value(h, r));
                             }
                     }
                 };
@@ -447,11 +499,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     }
 }
 
-template <int NST, int MAXCH, bool STATS, bool SEG>
+template <int NST, int CH0, int CH1, bool STATS, bool SEG>
 static int launch_chain_impl(const ChainArgs &a, hipStream_t st) {
-    constexpr bool W2 = (NST == 1 && MAXCH == 5);
-    constexpr int WPE = W2 ? 2 : 1;
-    const void *fn = reinterpret_cast<const void *>(&mlp_chain_kernel<NST, MAXCH, STATS, WPE, SEG>);
+    constexpr bool SMALL = (NST == 1 && CH0 == 5);
+    constexpr int NW = NST == 1 ? 8 : 4;
+    constexpr int WPE = NST == 1 ? (SMALL ? 4 : 2) : 1;
+    const void *fn = reinterpret_cast<const void *>(&mlp_chain_kernel<NST, CH0, CH1, STATS, WPE, SEG, NW>);
     const size_t lds = (size_t)2 * CBM * a.pitch * 4 + 3 * RS_STRIDE * 4;
     static bool attr_set = false;
     if (!attr_set) {
@@ -460,21 +513,21 @@ static int launch_chain_impl(const ChainArgs &a, hipStream_t st) {
         attr_set = true;
     }
     const int64_t n_tiles = (a.m_rows + CBM - 1) / CBM;
-    int per_cu = (W2 && lds <= 72 * 1024) ? 2 : 1;
+    int per_cu = (SMALL && lds <= 76 * 1024) ? 2 : 1;
     { const char *d = getenv("GSN_CHAIN_PERCU"); if (d) per_cu = atoi(d); }
     int64_t gx = 256 * per_cu;
     if (gx > n_tiles) gx = n_tiles;
-    hipLaunchKernelGGL((mlp_chain_kernel<NST, MAXCH, STATS, WPE, SEG>), dim3((unsigned)gx), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((mlp_chain_kernel<NST, CH0, CH1, STATS, WPE, SEG, NW>), dim3((unsigned)gx), dim3(64 * NW), lds, st, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(GSN_E_HIP, "mlp_chain_kernel: %s", hipGetErrorString(e));
     return GSN_OK;
 }
 
-template <int NST, int MAXCH>
+template <int NST, int CH0, int CH1>
 static int launch_chain(const ChainArgs &a, hipStream_t st) {
-    if (a.stats) return launch_chain_impl<NST, MAXCH, true, false>(a, st);
-    if (a.seg_target) return launch_chain_impl<NST, MAXCH, false, true>(a, st);
-    return launch_chain_impl<NST, MAXCH, false, false>(a, st);
+    if (a.stats) return launch_chain_impl<NST, CH0, CH1, true, false>(a, st);
+    if (a.seg_target) return launch_chain_impl<NST, CH0, CH1, false, true>(a, st);
+    return launch_chain_impl<NST, CH0, CH1, false, false>(a, st);
 }
 
 }  // namespace gsn
@@ -529,18 +582,24 @@ extern "C" int gsn_mlp_chain_fwd_hip(int64_t m_rows, int n_stages, const gsn_cha
         }
         c.k_hbm = k_hbm;
         c.k_total = k_hbm + (s > 0 ? (int)stages[s - 1].n_out : 0);
-        kmax = c.k_total > kmax ? c.k_total : kmax;
+        if (s == 0) kmax = c.k_total;
     }
     a.n_blocks = nb;
     const int maxch = kmax <= 80 ? 5 : 10;
-    // the staging writes cover whole 32-column groups, so a row holds ceil(16*maxch / 32) * 32 floats (+1: odd pitch)
-    a.pitch = (maxch * CHK + 31) / 32 * 32 + 1;
-    if (a.seg_target && a.pitch < 129) a.pitch = 129;  // the segmented-sum epilogue stages a [64][n_out <= 128] tile
+    // LDS row pitch: the staging writes cover whole 32-column groups of stage 0; a later stage's input tile holds the
+    // previous stage's n_out columns; the segmented-sum epilogue stages n_out_last columns.  +1 / odd: conflict-free.
+    int cols = (maxch * CHK + 31) / 32 * 32;
+    for (int s = 1; s < n_stages; ++s) cols = a.st[s].k_total > cols ? a.st[s].k_total : cols;
+    if (a.seg_target && a.st[n_stages - 1].n_out > cols) cols = a.st[n_stages - 1].n_out;
+    a.pitch = cols | 1;
+    if (a.pitch == cols) a.pitch += 2;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (n_stages == 2 && a.st[1].k_total > 8 * CHK)
+        return set_error(GSN_E_UNSUPPORTED, "gsn_mlp_chain_fwd_hip: second stage wider than 128 inputs");
     if (maxch == 5) {
-        if (n_stages == 1) return launch_chain<1, 5>(a, st);
-        return launch_chain<2, 5>(a, st);
+        if (n_stages == 1) return launch_chain<1, 5, 0>(a, st);
+        return launch_chain<2, 5, 8>(a, st);
     }
-    if (n_stages == 1) return launch_chain<1, 10>(a, st);
-    return launch_chain<2, 10>(a, st);
+    if (n_stages == 1) return launch_chain<1, 10, 0>(a, st);
+    return launch_chain<2, 10, 8>(a, st);
 }

@@ -138,16 +138,16 @@ __global__ void csr_sort_segments(const int32_t *__restrict__ seg_ptr, int64_t n
 }
 
 // Output rows the fused segmented-sum epilogue (chain.hip) reaches with atomics or not at all must start at zero:
-// empty segments, and segments that straddle a 32-row boundary of the target-sorted row space.
+// empty segments, and segments that straddle a GSN_SEG_RANGE_ROWS-row boundary of the target-sorted row space.
 __global__ __launch_bounds__(256) void segsum_prepare_kernel(const int32_t *__restrict__ seg_ptr, const int32_t *__restrict__ row_target,
                                                              int64_t n_seg, int64_t n_rows, int n_out, float *out) {
     const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t n_bound = n_rows / 32;  // boundaries at rows 32, 64, ...
+    const int64_t n_bound = n_rows / GSN_SEG_RANGE_ROWS;  // boundaries at rows R, 2R, ...
     int row = -1;
     if (item < n_seg) {
         if (seg_ptr[item] == seg_ptr[item + 1]) row = (int)item;
     } else if (item - n_seg < n_bound) {
-        const int64_t r = (item - n_seg + 1) * 32;
+        const int64_t r = (item - n_seg + 1) * GSN_SEG_RANGE_ROWS;
         if (r < n_rows && row_target[r - 1] == row_target[r]) row = row_target[r];
     }
     // the wave zeroes the rows its lanes found, one row at a time, all 64 lanes on the columns
@@ -339,7 +339,7 @@ extern "C" int64_t gsn_csr_scratch_elems(int64_t n_nodes) { return (n_nodes + 1)
 extern "C" int gsn_segsum_prepare_hip(int64_t n_seg, int64_t n_rows, const int32_t *seg_ptr, const int32_t *row_target,
                                       int64_t n_out, float *out, void *stream) {
     if (!seg_ptr || !out || (n_rows > 0 && !row_target) || n_out <= 0) return set_error(GSN_E_INVALID, "gsn_segsum_prepare_hip: bad argument");
-    const int64_t items = n_seg + n_rows / 32;
+    const int64_t items = n_seg + n_rows / GSN_SEG_RANGE_ROWS;
     if (items <= 0) return GSN_OK;
     hipLaunchKernelGGL(segsum_prepare_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        seg_ptr, row_target, n_seg, n_rows, (int)n_out, out);

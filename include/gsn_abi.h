@@ -26,6 +26,7 @@ extern "C" {
 
 #define GSN_ABI_VERSION 1
 #define GSN_KMAX 8 /* max pattern vertices the counting kernel handles (reference configs use k <= 8) */
+#define GSN_SEG_RANGE_ROWS 16 /* rows one thread reduces in the fused scatter-add epilogue (see gsn_segsum_prepare_hip) */
 
 enum {
     GSN_OK = 0,
@@ -194,8 +195,8 @@ typedef struct {
  * row_perm = perm and seg_target = sorted_target of gsn_csr_build_hip) the last stage's rows are summed per target
  * inside the kernel and `out` is [n_seg][n_out_last] -- the torch.sparse.sum of GSN_sparse.py:140-143 without writing
  * the [E, d] messages.  `out` must first be prepared with gsn_segsum_prepare_hip (zeroes the rows of empty segments
- * and of segments that straddle a 32-row boundary, which the kernel adds to atomically; all other rows are plain stores,
- * so a segment's summation order is its row order except for segments longer than 32 rows).
+ * and of segments that straddle a GSN_SEG_RANGE_ROWS-row boundary, which the kernel adds to atomically; all other rows
+ * are plain stores, so a segment's summation order is its row order except for segments longer than that range).
  * ---------------------------------------------------------------------------------------------------------------- */
 int gsn_mlp_chain_supported(int n_stages, const gsn_chain_stage *stages);
 int gsn_mlp_chain_fwd_hip(int64_t m_rows, int n_stages, const gsn_chain_stage *stages, const int32_t *row_perm,
