@@ -264,22 +264,26 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
     // NOTE: the loaded values are kept RAW in the prefetch registers; masking (padded columns, rows past the end) is
     // applied when they are written to LDS.  Selecting on the value right here would make the compiler wait for every
     // load immediately after issuing it (vmcnt countdown) and serialise the prefetch.
-    auto prefetch = [&](const int *rs) {
+    auto prefetch_j = [&](const int *rs, int j) {   // j must be a compile-time constant at the call site (register index)
 #pragma unroll
-        for (int j = 0; j < PF0_J; ++j)
-#pragma unroll
-            for (int i = 0; i < NROW; ++i) {
-                const int sr = rs[cm0[j].rsoff + r0 + RSTEP * i];
-                pf0[j][i] = cm0[j].base[(int64_t)(sr < 0 ? 0 : sr) * cm0[j].bw];
-            }
+        for (int i = 0; i < NROW; ++i) {
+            const int sr = rs[cm0[j].rsoff + r0 + RSTEP * i];
+            pf0[j][i] = cm0[j].base[(int64_t)(sr < 0 ? 0 : sr) * cm0[j].bw];
+        }
     };
     // prefetched rows -> LDS.  No masking needed: a padded column (k >= K) holds a finite clamped-address value and meets a
     // zero weight; a row past the end holds row 0's values and is never emitted (store guard / target -1 / stats guard).
+    auto stage_in_j = [&](float *dst, int j) {
+#pragma unroll
+        for (int i = 0; i < NROW; ++i) dst[(r0 + RSTEP * i) * pitch + kc0 + 32 * j] = pf0[j][i];
+    };
+    auto prefetch = [&](const int *rs) {
+#pragma unroll
+        for (int j = 0; j < PF0_J; ++j) prefetch_j(rs, j);
+    };
     auto stage_in = [&](float *dst) {
 #pragma unroll
-        for (int j = 0; j < PF0_J; ++j)
-#pragma unroll
-            for (int i = 0; i < NROW; ++i) dst[(r0 + RSTEP * i) * pitch + kc0 + 32 * j] = pf0[j][i];
+        for (int j = 0; j < PF0_J; ++j) stage_in_j(dst, j);
     };
 
     // ---- prologue: row sources of the first two tiles; the first tile's inputs go to LDS synchronously -------------------
@@ -308,7 +312,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
         float *in0 = (NST == 1 && cur) ? buf1 : buf0;         // stage-0 input of this tile
         float *other = (NST == 1 && cur) ? buf0 : buf1;       // NST==1: next tile's input; NST==2: stage-1 input
         const int slot_n = slot == 2 ? 0 : slot + 1, slot_nn = slot_n == 2 ? 0 : slot_n + 1;
-        if (has_next && !(a.dbg & 1)) prefetch(rsrc + slot_n * RS_STRIDE);       // lands under the MFMAs below
+        const int *rs_next_tab = rsrc + slot_n * RS_STRIDE;
+        const bool do_pf = has_next && !(a.dbg & 1);
         rs_fetch(rst, (tile + 2 * (int64_t)gridDim.x) * CBM, rsn);         // row sources two tiles ahead
 
         float *in = in0;
@@ -327,6 +332,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
 #pragma unroll
                     for (int ch = 0; ch < CH0; ++ch) {
                         if (ch < nch[0]) {
+                            // the next tile's global loads (address arithmetic + issue) ride in the shadow of this chunk's
+                            // MFMAs instead of standing in front of the whole MFMA phase (one wave per SIMD: nothing else
+                            // would fill the matrix pipe meanwhile)
+                            if (ch < PF0_J && do_pf) prefetch_j(rs_next_tab, ch);
 #pragma unroll
                             for (int q = 0; q < 8; ++q) {
 #pragma unroll
@@ -339,6 +348,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
 #pragma unroll
                     for (int ch = 0; ch < CH1; ++ch) {
                         if (ch < nch[1]) {
+                            if (ch < PF0_J && has_next) stage_in_j(buf0, ch);   // next tile's rows -> buf0 (free since the mid barrier)
 #pragma unroll
                             for (int q = 0; q < 8; ++q) {
 #pragma unroll
@@ -379,8 +389,17 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
             // ---- last stage ------------------------------------------------------------------------------------------
             // where the next tile's input goes: NST==1 -> the other buffer; NST==2 -> buf0 (free since the barrier above)
             float *next_in = (NST == 1) ? other : buf0;
+            // next tile's prefetched rows -> LDS: everything (single-stage kernels) or what the stage-1 MFMA loop above
+            // did not already interleave (two-stage kernels: column groups >= nch[1], or a wave without output columns)
+            auto finish_stage_in = [&]() {
+                if (!has_next) return;
+                if (NST == 1) { stage_in(next_in); return; }
+#pragma unroll
+                for (int j = 0; j < PF0_J; ++j)
+                    if (!(active && j < CH1 && j < nch[1])) stage_in_j(buf0, j);
+            };
             if (STATS) {
-                if (has_next) stage_in(next_in);
+                finish_stage_in();
                 rs_store(rsrc + slot_nn * RS_STRIDE, rst, rsn);   // row sources of tile t+2
 #pragma unroll
                 for (int hh = 0; hh < NACC; ++hh)
@@ -412,7 +431,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
                             for (int r = 0; r < 16; ++r) Y[(h * 32 + (r & 3) + 8 * (r >> 2)) * pitch] = value(h, r);
                     }
                 }
-                if (has_next) stage_in(next_in);     // (the one vmcnt wait of the tile: before any store)
+                finish_stage_in();                    // (the one vmcnt wait of the tile: before any store)
                 rs_store(rsrc + slot_nn * RS_STRIDE, rst, rsn);  // row sources of tile t+2
                 lds_barrier();
                 // thread -> column c, NRANGE consecutive ranges of SEG_ROWS rows
@@ -451,7 +470,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
                 // next tile's MFMAs read `next_in` (complete before the barrier above); its own pre-Y barrier orders the
                 // reduction above against the following writes into `in`
             } else {
-                if (has_next) stage_in(next_in);     // (the one vmcnt wait of the tile: before any store)
+                finish_stage_in();                    // (the one vmcnt wait of the tile: before any store)
                 rs_store(rsrc + slot_nn * RS_STRIDE, rst, rsn);  // row sources of tile t+2
                 float *tile_out = a.out + row0 * st.n_out;                       // wave-uniform base (SGPR pair)
                 const int lane_off = (32 * rh + 4 * lh) * st.n_out + col;        // 32-bit per-lane offset inside the tile
