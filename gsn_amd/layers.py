@@ -19,6 +19,7 @@ There is no CPU path: calling a layer on CPU tensors raises.
 from __future__ import annotations
 
 import ctypes
+import weakref
 
 import torch
 import torch.nn as nn
@@ -27,7 +28,8 @@ import torch.nn.functional as F
 from . import _abi
 
 __all__ = ["mlp", "central_encoder", "GSN_sparse", "GSN_edge_sparse", "MPNN_sparse", "MPNN_edge_sparse",
-           "GSN_edge_sparse_ogb", "MPNN_edge_sparse_ogb", "build_csr", "propagate", "run_stages", "one_hot_identifiers"]
+           "GSN_edge_sparse_ogb", "MPNN_edge_sparse_ogb", "build_csr", "propagate", "run_stages", "one_hot_identifiers",
+           "global_add_pool_sparse", "global_mean_pool_sparse"]
 
 _ACT_CODE = {"identity": 0, "relu": 1, "elu": 2, "tanh": 3}
 _MAX_BLOCKS = 5
@@ -113,16 +115,40 @@ def build_csr(index, n_nodes, with_targets=False, other=None):
 
 
 def _csr_for(edge_index, row, n_nodes):
-    key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), row, n_nodes, edge_index.device)
-    c = _CSR_CACHE.get(key)
-    if c is None:
-        if len(_CSR_CACHE) > 64:
-            _CSR_CACHE.clear()
-        c = _CSR()
-        c.seg_ptr, c.perm, c.tgt, c.src = build_csr(edge_index[row], n_nodes, with_targets=True, other=edge_index[1 - row])
-        c.deg = (c.seg_ptr[1:] - c.seg_ptr[:-1]).to(torch.float32).unsqueeze(1).contiguous()
-        _CSR_CACHE[key] = c
+    """CSR of ``edge_index[row]`` cached on the tensor OBJECT (weak reference + version counter): a freed tensor's address
+    is reused by the caching allocator, so (data_ptr, shape) alone would return a stale CSR for a different graph of the
+    same size (e.g. the 15 SR(25,12,5,6) graphs all have E = 300)."""
+    key = (id(edge_index), row, n_nodes)
+    hit = _CSR_CACHE.get(key)
+    if hit is not None:
+        ref, version, csr = hit
+        if ref() is edge_index and version == edge_index._version:
+            return csr
+    if len(_CSR_CACHE) > 64:
+        _CSR_CACHE.clear()
+    c = _CSR()
+    c.seg_ptr, c.perm, c.tgt, c.src = build_csr(edge_index[row], n_nodes, with_targets=True, other=edge_index[1 - row])
+    c.deg = (c.seg_ptr[1:] - c.seg_ptr[:-1]).to(torch.float32).unsqueeze(1).contiguous()
+    _CSR_CACHE[key] = (weakref.ref(edge_index), edge_index._version, c)
     return c
+
+
+def global_add_pool_sparse(x, batch, num_graphs=None):
+    """Sum readout (utils_graph_learning.py:23-29: COO [G, N, d] + torch.sparse.sum) as a segmented sum keyed by the
+    ``batch`` vector, on the propagate kernel."""
+    _need_cuda(x, "x")
+    n_rows = x.shape[0]
+    g = int(batch.max().item()) + 1 if num_graphs is None else int(num_graphs)
+    # rows are "edges" whose target is their graph id; the message is the row itself
+    ei = torch.stack([torch.arange(n_rows, device=x.device, dtype=torch.int64), batch.to(torch.int64)], 0)
+    return propagate(0, ei, 1, g, b=x)
+
+
+def global_mean_pool_sparse(x, batch, num_graphs=None):
+    """Mean readout (utils_graph_learning.py:32-41): sum readout divided by the graph sizes (empty graphs divide by 1)."""
+    s = global_add_pool_sparse(x, batch, num_graphs)
+    sizes = torch.bincount(batch.to(torch.int64), minlength=s.shape[0]).to(s.dtype).clamp_(min=1.0)
+    return s / sizes.unsqueeze(1)
 
 
 def one_hot_identifiers(values, n_classes, clamp=False):
@@ -179,11 +205,13 @@ class _PropagateFn(torch.autograd.Function):
         src = ei[1 - sel].contiguous()
         tgt = ei[sel].contiguous()
         E = src.numel()
-        csr_s = _csr_for(ei, 1 - sel, n)
         g_out = _f32c(g_out)
         need = ctx.needs_input_grad[5:8]
         dev = ei.device
         wa, wb, wc = ctx.widths
+        # the source-sorted CSR is only needed for per-node gradients (g_a, per-node g_b)
+        need_node = (need[0] and wa) or (need[1] and wb and ctx.b_per_node)
+        csr_s = _csr_for(ei, 1 - sel, n) if need_node else None
         g_a = torch.zeros((n, wa), dtype=torch.float32, device=dev) if (need[0] and wa) else None
         g_b = None
         if need[1] and wb:
@@ -191,7 +219,8 @@ class _PropagateFn(torch.autograd.Function):
         g_c = torch.zeros((E, wc), dtype=torch.float32, device=dev) if (need[2] and wc) else None
         with torch.cuda.device(dev):
             rc = _abi.lib().gsn_propagate_bwd_hip(ctx.kind, n, E, src.data_ptr() if E else None, tgt.data_ptr() if E else None,
-                                                  csr_s.seg_ptr.data_ptr(), csr_s.perm.data_ptr() if E else None,
+                                                  csr_s.seg_ptr.data_ptr() if csr_s is not None else None,
+                                                  csr_s.perm.data_ptr() if (csr_s is not None and E) else None,
                                                   _abi.ptr(a), wa, _abi.ptr(b), wb, int(ctx.b_per_node), _abi.ptr(c), wc,
                                                   g_out.data_ptr(), _abi.ptr(g_a), _abi.ptr(g_b), _abi.ptr(g_c),
                                                   _abi.current_stream())

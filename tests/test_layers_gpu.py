@@ -208,3 +208,42 @@ def test_one_hot_identifiers_vs_torch():
     got = one_hot_identifiers(v, [3, 3, 3, 3], clamp=True)
     ref = torch.nn.functional.one_hot(v.clamp(max=2), 3).reshape(5000, 12).float()
     assert torch.equal(got, ref)
+
+
+def test_readout_pooling_vs_torch():
+    """global_add/mean_pool_sparse (utils_graph_learning.py:23-41) on the segmented-sum kernel, forward and backward."""
+    from gsn_amd.layers import global_add_pool_sparse, global_mean_pool_sparse
+    torch.manual_seed(4)
+    sizes = torch.randint(1, 40, (300,))
+    batch = torch.repeat_interleave(torch.arange(300), sizes).cuda()
+    x = torch.randn(batch.numel(), 64, device="cuda", requires_grad=True)
+    ref = torch.zeros(300, 64, device="cuda").index_add(0, batch, x)
+    got = global_add_pool_sparse(x, batch)
+    assert rel_err(got, ref.detach()) < TOL
+    w = torch.randn_like(got)
+    (got * w).sum().backward()
+    g1 = x.grad.clone(); x.grad = None
+    (ref * w).sum().backward()
+    assert rel_err(g1, x.grad) < TOL
+    mean = global_mean_pool_sparse(x.detach(), batch)
+    assert rel_err(mean, ref.detach() / sizes.cuda().float().unsqueeze(1)) < TOL
+
+
+def test_csr_cache_is_not_fooled_by_address_reuse():
+    """Different graphs with identical shapes allocated at the same address must not share a cached CSR."""
+    from gsn_amd.layers import propagate
+    torch.manual_seed(6)
+    N, E = 50, 300
+    for trial in range(6):
+        ei = torch.randint(0, N, (2, E), device="cuda")
+        b = torch.randn(E, 16, device="cuda")
+        out = propagate(0, ei, 1, N, b=b)
+        ref = torch.zeros(N, 16, device="cuda").index_add_(0, ei[1], b)
+        assert rel_err(out, ref) < TOL
+        del ei, b, out, ref   # frees the blocks; the next iteration's tensors land on the same addresses
+    ei = torch.randint(0, N, (2, E), device="cuda")
+    b = torch.randn(E, 16, device="cuda")
+    propagate(0, ei, 1, N, b=b)
+    ei[1] = torch.randint(0, N, (E,), device="cuda")     # in-place change bumps the version counter
+    out = propagate(0, ei, 1, N, b=b)
+    assert rel_err(out, torch.zeros(N, 16, device="cuda").index_add_(0, ei[1], b)) < TOL
