@@ -247,3 +247,82 @@ def test_csr_cache_is_not_fooled_by_address_reuse():
     ei[1] = torch.randint(0, N, (E,), device="cuda")     # in-place change bumps the version counter
     out = propagate(0, ei, 1, N, b=b)
     assert rel_err(out, torch.zeros(N, 16, device="cuda").index_add_(0, ei[1], b)) < TOL
+
+
+@pytest.mark.parametrize("shape", [
+    # (M, block widths, hidden widths per stage, gathered?, bn, act)
+    (1000, [72], [128], True, True, "relu"),            # single stage, K<=80 (8-wave kernel)
+    (777, [100, 37], [64], False, True, "identity"),    # single stage, K in (80,160]
+    (5000, [28, 128, 1], [128, 128], False, True, "relu"),   # two stages, K0=157 (the node chain of the bench layer)
+    (333, [40], [100, 33], True, False, "relu"),        # two stages, K0<=80, odd widths, no bn
+    (64, [16], [16, 8], False, True, "relu"),           # one exact tile
+    (65, [3], [5], True, False, "identity"),            # tiny everything, tail row
+    (4096, [160], [128, 96], False, True, "relu"),      # K0 at the limit
+])
+def test_chain_kernel_shapes_vs_torch(shape):
+    """gsn_mlp_chain_fwd_hip across its shape classes (kernel variants, tails, inactive waves) against fp64 torch."""
+    from gsn_amd.layers import _Stage, _launch_stages, _chain_fits
+    M, widths, hidden, gathered, bn, act = shape
+    torch.manual_seed(sum(widths) + M)
+    dev = "cuda"
+    blocks, cols = [], []
+    for i, w in enumerate(widths):
+        if gathered and i % 2 == 0:
+            data = torch.randn(97, w, device=dev); idx = torch.randint(0, 97, (M,), device=dev, dtype=torch.int32 if i % 4 == 0 else torch.int64)
+            blocks.append((data, idx)); cols.append(data[idx.long()])
+        else:
+            data = torch.randn(M, w, device=dev); blocks.append((data, None)); cols.append(data)
+    x = torch.cat(cols, 1).double()
+    stages, k = [], x.shape[1]
+    ref = x
+    for s, n_out in enumerate(hidden):
+        W = torch.randn(n_out, k, device=dev) / k ** 0.5
+        b = torch.randn(n_out, device=dev)
+        st = _Stage(W, b, None, act if s < len(hidden) - 1 or len(hidden) == 1 else "identity", blocks if s == 0 else ())
+        h = ref @ W.double().T + b.double()
+        if bn:
+            mean, scale, shift = torch.randn(n_out, device=dev), torch.rand(n_out, device=dev) + 0.5, torch.randn(n_out, device=dev)
+            st.bn_params = (mean, scale, shift)
+            h = (h - mean.double()) * scale.double() + shift.double()
+        ref = torch.relu(h) if st.act == "relu" else h
+        stages.append(st); k = n_out
+    assert _chain_fits(stages)
+    y = _launch_stages(stages, M)
+    assert y.shape == (M, hidden[-1])
+    assert rel_err(y.double(), ref) < TOL
+    # statistics pass of the last stage (pre-BN values)
+    stats = torch.zeros(2, hidden[-1], dtype=torch.float64, device=dev)
+    probe = stages[:-1] + [_Stage(stages[-1].weight, stages[-1].bias, None, "identity", stages[-1].blocks)]
+    _launch_stages(probe, M, stats=stats)
+    prev = x
+    for st in stages[:-1]:
+        h = prev @ st.weight.double().T + st.bias.double()
+        if st.bn_params is not None:
+            h = (h - st.bn_params[0].double()) * st.bn_params[1].double() + st.bn_params[2].double()
+        prev = torch.relu(h) if st.act == "relu" else h
+    hl = prev @ stages[-1].weight.double().T + stages[-1].bias.double()
+    assert torch.allclose(stats[0], hl.sum(0), rtol=1e-5, atol=1e-5 * M)
+    assert torch.allclose(stats[1], (hl * hl).sum(0), rtol=1e-5, atol=1e-5 * M)
+
+
+@pytest.mark.parametrize("N,E,hub", [(500, 4000, 0), (300, 5000, 700), (2000, 1500, 40), (64, 64, 64)])
+def test_fused_scatter_add_vs_torch(N, E, hub):
+    """The segmented-sum epilogue: empty segments, segments longer than one reduction range (atomics), tile tails."""
+    from gsn_amd.layers import _Stage, run_stages, _csr_for
+    torch.manual_seed(N + E)
+    dev = "cuda"
+    tgt = torch.randint(0, N, (E,), device=dev)
+    if hub:
+        tgt[:hub] = 3                                  # one target with a very long segment
+    src = torch.randint(0, N, (E,), device=dev)
+    ei = torch.stack([src, tgt], 0)
+    x = torch.randn(N, 20, device=dev); ef = torch.randn(E, 7, device=dev)
+    csr = _csr_for(ei, 1, N)
+    W = torch.randn(96, 47, device=dev) / 7.0; b = torch.randn(96, device=dev)
+    st = _Stage(W, b, None, "relu", [(x, csr.tgt), (x, csr.src), (ef, csr.perm)])
+    out = run_stages([st], E, False, csr=csr)
+    assert out is not None and out.shape == (N, 96)
+    msg = torch.relu(torch.cat([x[tgt], x[src], ef], 1).double() @ W.double().T + b.double())
+    ref = torch.zeros(N, 96, dtype=torch.float64, device=dev).index_add_(0, tgt, msg)
+    assert rel_err(out.double(), ref) < TOL
+    assert (out[torch.bincount(tgt, minlength=N) == 0] == 0).all()
