@@ -1,0 +1,180 @@
+"""Batched preprocessing driver: the reference's ``generate_dataset`` / ``_prepare`` (utils_data_gen.py:17-108) with ONE
+counting launch per dataset shard instead of one Python call per graph and pattern.
+
+What stays identical to the reference, graph by graph: the attributes each prepared graph carries and their order
+(``edge_index`` without self loops, ``x``, ``graph_size``, ``degrees``, ``edge_features`` filtered in lock-step, ``y``,
+``identifiers`` int64 [rows, sum orbits] with columns in pattern order then orbit index -- utils_ids.py:7-29), the
+returned tuple, the ``.pt`` cache tuple ``(graphs, num_classes, orbit_partition_sizes)`` (utils.py:272-274) and
+``downgrade_k`` slicing (utils.py:332-345).  Collation of the raw graphs is host-side numpy; the counts come from the
+HIP kernel (gsn_count_hip) -- there is no CPU counting path here.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import counting, data as gdata, dist
+from .patterns import PatternGraph
+
+
+def _mode_of(count_fn):
+    name = count_fn if isinstance(count_fn, str) else getattr(count_fn, "__name__", "")
+    if name in ("subgraph_isomorphism_edge_counts", "edge"):
+        return "edge"
+    if name in ("subgraph_isomorphism_vertex_counts", "vertex"):
+        return "vertex"
+    raise TypeError("count_fn must be subgraph_isomorphism_vertex_counts or subgraph_isomorphism_edge_counts")
+
+
+def _label_tensor(label, as_float):
+    t = label.detach().clone() if isinstance(label, torch.Tensor) else torch.tensor(label)
+    t = t.unsqueeze(0)
+    return t.float() if as_float else t.long()
+
+
+def prepare_graphs(graphs, subgraph_dicts, subgraph_params, regression, dataset_name, count_fn, data_cls=None,
+                   device=None, shard=None):
+    """``[_prepare(g, ...) for g in graphs]`` (utils_data_gen.py:86-108) with all counting done in one launch.
+
+    ``graphs``: records with ``edge_mat`` int64 [2,E], ``node_features`` [n, ...], ``label`` and optionally
+    ``edge_features`` [E, ...] (what the loaders of :mod:`gsn_amd.data` return).  ``shard=(rank, world)`` prepares only this
+    rank's cost-balanced contiguous chunk (graphs are independent, no collective) and returns
+    ``(prepared, (lo, hi))`` instead of the list.
+
+    Two deviations, both where the reference raises by accident: a zero-edge graph in edge mode gets the empty
+    ``[0, sum orbits]`` identifier matrix the reference intends (its line :104 dies on an undefined name), and
+    ``directed=True`` is refused up front."""
+    mode = _mode_of(count_fn)
+    if subgraph_params.get("directed", False):
+        raise NotImplementedError("directed=True is not supported")
+    data_cls = data_cls or gdata.Data
+    pats = []
+    for d in subgraph_dicts:
+        sg = d["subgraph"]
+        if not isinstance(sg, PatternGraph):
+            raise TypeError("subgraph_dicts must come from gsn_amd's automorphism functions")
+        pats.append(sg)
+    dirorb = any(p.directed_orbits for p in pats) if mode == "edge" else False
+    plan = counting.CountPlan.get([p.edge_list for p in pats], mode, subgraph_params["induced"], dirorb)
+
+    span = (0, len(graphs))
+    if shard is not None:
+        rank, world = shard
+        cost = np.array([float(g.edge_mat.shape[1]) ** 1.5 + 1.0 for g in graphs])
+        bounds = dist.shard_by_cost(cost, world)
+        span = (int(bounds[rank]), int(bounds[rank + 1]))
+        graphs = graphs[span[0]:span[1]]
+
+    G = len(graphs)
+    n_nodes = np.array([int(g.node_features.shape[0]) for g in graphs], dtype=np.int64)
+    n_raw = np.array([int(g.edge_mat.shape[1]) for g in graphs], dtype=np.int64)
+    node_ptr = np.concatenate([[0], np.cumsum(n_nodes)]).astype(np.int64)
+    raw_ptr = np.concatenate([[0], np.cumsum(n_raw)]).astype(np.int64)
+    if G and raw_ptr[-1]:
+        ei_raw = torch.cat([g.edge_mat.reshape(2, -1).to(torch.int64) for g in graphs], 1).numpy()
+    else:
+        ei_raw = np.zeros((2, 0), dtype=np.int64)
+    gid = np.repeat(np.arange(G), n_raw)
+    keep = ei_raw[0] != ei_raw[1]
+    ei = np.ascontiguousarray(ei_raw[:, keep])
+    n_kept = np.bincount(gid[keep], minlength=G).astype(np.int64) if G else np.zeros(0, np.int64)
+    edge_ptr = np.concatenate([[0], np.cumsum(n_kept)]).astype(np.int64)
+
+    # degrees = torch_geometric.utils.degree(edge_mat[0]) BEFORE self-loop removal; without num_nodes its length is
+    # max(source id)+1, so trailing vertices that never occur as a source are cut (utils_data_gen.py:93-96)
+    if ei_raw.shape[1]:
+        deg_all = np.bincount(node_ptr[gid] + ei_raw[0], minlength=int(node_ptr[-1])).astype(np.float32)
+        max_src = np.full(G, -1, dtype=np.int64)
+        np.maximum.at(max_src, gid, ei_raw[0])
+    else:
+        deg_all = np.zeros(int(node_ptr[-1]), dtype=np.float32)
+        max_src = np.full(G, -1, dtype=np.int64)
+
+    n_cols = plan.n_cols
+    if G and (mode == "vertex" or edge_ptr[-1] > 0):
+        out, _ = counting.count_batch(plan, node_ptr, edge_ptr, torch.from_numpy(ei), ids_are_global=False,
+                                      max_nodes=int(max(n_nodes.max(), 1)), max_edges=int(n_kept.max()), device=device)
+        ids_all = out.cpu()
+    else:
+        ids_all = torch.zeros((0, n_cols), dtype=torch.int64)
+    row_ptr = node_ptr if mode == "vertex" else edge_ptr
+    ei_t = torch.from_numpy(ei)
+    keep_t = torch.from_numpy(keep)
+
+    as_float = bool(regression) or dataset_name in {"ogbg-molpcba", "ogbg-molhiv", "ZINC"}
+    prepared = []
+    for g, src in enumerate(graphs):
+        d = data_cls()
+        has_edges = n_raw[g] > 0
+        untouched = (not has_edges) and mode == "edge"      # the reference skips the id extraction for these
+        if untouched:
+            setattr(d, "edge_index", src.edge_mat)
+        else:
+            setattr(d, "edge_index", ei_t[:, edge_ptr[g]:edge_ptr[g + 1]].clone())
+        setattr(d, "x", src.node_features)
+        setattr(d, "graph_size", int(n_nodes[g]))
+        if not has_edges:
+            setattr(d, "degrees", torch.zeros((int(n_nodes[g]),)))
+        else:
+            lo = int(node_ptr[g])
+            setattr(d, "degrees", torch.from_numpy(deg_all[lo:lo + int(max_src[g]) + 1].copy()))
+        if hasattr(src, "edge_features"):
+            ef = src.edge_features
+            if not untouched:
+                ef = ef[keep_t[raw_ptr[g]:raw_ptr[g + 1]]]
+            setattr(d, "edge_features", ef)
+        setattr(d, "y", _label_tensor(src.label, as_float))
+        if untouched:
+            setattr(d, "identifiers", torch.zeros((0, n_cols)).long())
+        else:
+            setattr(d, "identifiers", ids_all[int(row_ptr[g]):int(row_ptr[g + 1])].clone())
+        prepared.append(d)
+    if shard is not None:
+        return prepared, span
+    return prepared
+
+
+def generate_dataset(data_path, dataset_name, k, extract_ids_fn, count_fn, automorphism_fn, regression, id_type,
+                     multiprocessing=False, num_processes=1, **subgraph_params):
+    """Same signature and return tuple as utils_data_gen.py:17-81:
+    ``(graphs_ptg, num_classes, num_node_type, num_edge_type, orbit_partition_sizes)``.
+
+    ``extract_ids_fn`` / ``multiprocessing`` / ``num_processes`` are accepted and have no effect: the identifier
+    extraction is batched inside (one launch for the whole dataset), which is what the worker pool was for."""
+    if "edge_list" not in subgraph_params:
+        raise ValueError("Edge list not provided.")
+    subgraph_dicts, orbit_partition_sizes = [], []
+    for edge_list in subgraph_params["edge_list"]:
+        subgraph, orbit_partition, orbit_membership, aut_count = automorphism_fn(
+            edge_list=edge_list, directed=subgraph_params["directed"], directed_orbits=subgraph_params["directed_orbits"])
+        subgraph_dicts.append({"subgraph": subgraph, "orbit_partition": orbit_partition,
+                               "orbit_membership": orbit_membership, "aut_count": aut_count})
+        orbit_partition_sizes.append(len(orbit_partition))
+    graphs, num_classes, num_node_type, num_edge_type = gdata.load_raw(data_path, dataset_name)
+    data_cls = subgraph_params.get("data_cls")
+    graphs_ptg = prepare_graphs(graphs, subgraph_dicts, subgraph_params, regression, dataset_name, count_fn, data_cls=data_cls)
+    return graphs_ptg, num_classes, num_node_type, num_edge_type, orbit_partition_sizes
+
+
+def downgrade_k(dataset, k, orbit_partition_sizes, k_min):
+    """Keep only the identifier columns of the patterns up to size ``k`` (utils.py:332-345)."""
+    width = sum(orbit_partition_sizes[0:k - k_min + 1])
+    out = []
+    for d in dataset:
+        nd = type(d)()
+        for name, value in d:
+            setattr(nd, name, value)
+        setattr(nd, "identifiers", d.identifiers[:, 0:width])
+        out.append(nd)
+    return out, orbit_partition_sizes[0:k - k_min + 1]
+
+
+def save_dataset(graphs_ptg, num_classes, orbit_partition_sizes, data_file):
+    """The reference's cache tuple (utils.py:256, :274)."""
+    torch.save((graphs_ptg, num_classes, orbit_partition_sizes), data_file)
+
+
+def load_dataset(data_file):
+    """utils.py:277-287."""
+    obj = torch.load(data_file, weights_only=False)
+    return obj[0], obj[1], obj[2]

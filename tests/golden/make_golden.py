@@ -155,14 +155,34 @@ def install_stubs():
     tgu.to_undirected = to_undirected
     tgu.degree = degree
     tgu.is_undirected = is_undirected
+    tgu.sort_edge_index = lambda ei, *a, **k: ei          # imported by utils_data_gen.py:3, never called
     tg.utils = tgu
+    tgd = types.ModuleType("torch_geometric.data")
+
+    class Data:                                           # attribute bag; iteration as PyG 1.x (sorted keys)
+        def __init__(self, **kw):
+            for k_, v_ in kw.items():
+                setattr(self, k_, v_)
+
+        @property
+        def keys(self):
+            return [k_ for k_ in self.__dict__ if self.__dict__[k_] is not None]
+
+        def __iter__(self):
+            for k_ in sorted(self.keys):
+                yield k_, getattr(self, k_)
+
+    tgd.Data = Data
+    tg.data = tgd
     sys.modules["torch_geometric"] = tg
     sys.modules["torch_geometric.utils"] = tgu
+    sys.modules["torch_geometric.data"] = tgd
 
     ogb = types.ModuleType("ogb")
     gpp = types.ModuleType("ogb.graphproppred")
     me = types.ModuleType("ogb.graphproppred.mol_encoder")
     me.AtomEncoder = me.BondEncoder = object
+    gpp.PygGraphPropPredDataset = object                  # imported by utils_data_prep.py:10, not used here
     ou = types.ModuleType("ogb.utils")
     of = types.ModuleType("ogb.utils.features")
     of.get_atom_feature_dims = lambda: [119, 4, 12, 12, 10, 6, 6, 2, 2]
@@ -177,7 +197,8 @@ def import_reference():
     sys.path.insert(1, REF)
     import importlib
     mods = {}
-    for name in ["utils_graph_processing", "utils_ids", "models_misc", "utils_graph_learning"]:
+    for name in ["utils_graph_processing", "utils_ids", "models_misc", "utils_graph_learning", "utils_data_prep",
+                 "utils_data_gen", "utils_encoding", "utils"]:
         mods[name] = importlib.import_module(name)
     for name in ["GSN_sparse", "GSN_edge_sparse", "MPNN_sparse", "MPNN_edge_sparse",
                  "GSN_edge_sparse_ogb", "MPNN_edge_sparse_ogb"]:
@@ -611,6 +632,207 @@ def gen_layers(ref, out):
     print("layers: %d cases" % len(names))
 
 
+# ----------------------------------------------------------------------------------------------
+# preprocessing driver, loaders, encoders
+# ----------------------------------------------------------------------------------------------
+def _write_tu_fixture(dst_dir):
+    """tests/golden/raw/TUTRIM.txt: the first 12 graphs of the reference's IMDBBINARY.txt plus a hand-made graph whose
+    adjacency rows name high vertex ids first (exercises the networkx insertion-order edge order) -- data only."""
+    src = os.path.join(REF, "datasets/social/IMDBBINARY/IMDBBINARY.txt")
+    lines = []
+    with open(src) as f:
+        f.readline()
+        for _ in range(12):
+            head = f.readline()
+            lines.append(head)
+            for _j in range(int(head.split()[0])):
+                lines.append(f.readline())
+    extra = ["6 1\n", "3 2 4 2\n", "5 1 5\n", "3 2 0 3\n", "7 1 2\n", "3 1 0\n", "5 1 1\n"]
+    with open(os.path.join(dst_dir, "TUTRIM.txt"), "w") as f:
+        f.write("13\n")
+        f.writelines(lines + extra)
+
+
+def _write_zinc_fixture(dst_dir, rng):
+    """tests/golden/raw/ZINC: a synthetic stand-in in the benchmarking-gnns pickle layout (lists of dicts with
+    atom_type / dense bond_type / logP_SA_cycle_normalized) + indices/*.index; one molecule has a nonzero diagonal entry
+    (a self loop with an edge feature) and one has no bonds at all."""
+    import pickle
+    os.makedirs(os.path.join(dst_dir, "molecules"), exist_ok=True)
+    os.makedirs(os.path.join(dst_dir, "indices"), exist_ok=True)
+    for split, n_mol, pick in (("train", 6, [0, 2, 3, 5]), ("val", 3, [1, 2]), ("test", 3, [0, 1])):
+        mols = []
+        for m in range(n_mol):
+            n, ei = synth.zinc_shape_graph(rng)[:2]
+            adj = torch.zeros(n, n, dtype=torch.long)
+            for (a, b) in ei.T.tolist():
+                if a < b:
+                    adj[a, b] = adj[b, a] = int(rng.integers(1, 4))
+            if split == "train" and m == 2:
+                adj[1, 1] = 2
+            if split == "val" and m == 2:
+                adj.zero_()
+            mols.append({"atom_type": torch.from_numpy(rng.integers(0, 28, size=n)), "bond_type": adj,
+                         "logP_SA_cycle_normalized": torch.tensor(float(rng.normal()))})
+        with open(os.path.join(dst_dir, "molecules", split + ".pickle"), "wb") as f:
+            pickle.dump(mols, f)
+        with open(os.path.join(dst_dir, "indices", split + ".index"), "w") as f:
+            f.write(",".join(str(i) for i in pick) + "\n")
+
+
+def _dump_prepared(rec, key, graphs):
+    rec[key + "/n_graphs"] = np.int64(len(graphs))
+    for g, d in enumerate(graphs):
+        names = [k_ for k_ in d.__dict__]
+        rec["%s/%d/attr_order" % (key, g)] = np.array(names)
+        for k_ in names:
+            v = getattr(d, k_)
+            rec["%s/%d/%s" % (key, g, k_)] = v.numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+            if isinstance(v, torch.Tensor):
+                rec["%s/%d/%s.dtype" % (key, g, k_)] = np.array(str(v.dtype))
+
+
+def gen_dataset(ref, out):
+    import io
+    import contextlib
+    import shutil
+    raw = os.path.join(out, "raw")
+    os.makedirs(raw, exist_ok=True)
+    rng = np.random.default_rng(11)
+    _write_tu_fixture(raw)
+    _write_zinc_fixture(os.path.join(raw, "ZINC"), rng)
+    shutil.copyfile(os.path.join(REF, "datasets/SR_graphs/sr251256/sr251256.g6"), os.path.join(raw, "sr251256.g6"))
+    os.chmod(os.path.join(raw, "sr251256.g6"), 0o644)
+    udp, udg, uenc, uu, ugp, uid = (ref[k_] for k_ in ("utils_data_prep", "utils_data_gen", "utils_encoding", "utils",
+                                                       "utils_graph_processing", "utils_ids"))
+    rec = {}
+    sink = io.StringIO()
+    # --- loaders
+    for tag in (False, True):
+        with contextlib.redirect_stdout(sink):
+            gl, ncls = udp.load_data(raw, "TUTRIM", tag)
+        key = "tu_tag%d" % int(tag)
+        rec[key + "/num_classes"] = np.int64(ncls)
+        for g, s in enumerate(gl):
+            rec["%s/%d/edge_mat" % (key, g)] = s.edge_mat.numpy().reshape(2, -1)
+            rec["%s/%d/node_features" % (key, g)] = s.node_features.numpy()
+            rec["%s/%d/label" % (key, g)] = np.int64(s.label)
+            rec["%s/%d/node_tags" % (key, g)] = np.asarray(s.node_tags, dtype=np.int64)
+            rec["%s/%d/max_neighbor" % (key, g)] = np.int64(s.max_neighbor)
+    gl, ncls = udp.load_g6_graphs(raw, "sr251256")
+    rec["g6/num_classes"] = np.int64(ncls)
+    for g, s in enumerate(gl):
+        rec["g6/%d/edge_mat" % g] = s.edge_mat.numpy()
+        rec["g6/%d/node_features" % g] = s.node_features.numpy()
+        rec["g6/%d/label" % g] = s.label.numpy()
+    gl, ncls, nnt, net = udp.load_zinc_data(os.path.join(raw, "ZINC"), "ZINC", False)
+    rec["zinc/meta"] = np.array([len(gl), ncls, nnt, net], dtype=np.int64)
+    for g, s in enumerate(gl):
+        rec["zinc/%d/edge_mat" % g] = s.edge_mat.numpy()
+        rec["zinc/%d/node_features" % g] = s.node_features.numpy()
+        rec["zinc/%d/edge_features" % g] = s.edge_features.numpy()
+        rec["zinc/%d/label" % g] = np.float64(float(s.label))
+
+    # --- generate_dataset end to end (utils_data_gen.py:17-81) through the reference's own _prepare / counts2ids
+    def run(key, path, name, ks, fam, id_type_fn, count_fn, induced, regression):
+        els = [list(fam(k_).edges) for k_ in ks]
+        with contextlib.redirect_stdout(sink), contextlib.redirect_stderr(sink):
+            res = udg.generate_dataset(path, name, ks[-1], uid.subgraph_counts2ids, count_fn, id_type_fn, regression,
+                                       "x", multiprocessing=False, num_processes=1, edge_list=els, induced=induced,
+                                       directed=False, directed_orbits=False)
+        graphs, ncls, nnt, net, sizes = res
+        rec[key + "/num_classes"] = np.int64(ncls)
+        rec[key + "/orbit_partition_sizes"] = np.asarray(sizes, dtype=np.int64)
+        rec[key + "/node_edge_types"] = np.asarray([-1 if nnt is None else nnt, -1 if net is None else net], dtype=np.int64)
+        pptr, pflat = pack_edge_lists(els)
+        rec[key + "/pattern_ptr"], rec[key + "/pattern_edges"] = pptr, pflat
+        _dump_prepared(rec, key, graphs)
+        return graphs, sizes
+
+    run("gd_sr25_edge", raw, "sr251256", [3, 4, 5], nx.cycle_graph, ugp.induced_edge_automorphism_orbits,
+        ugp.subgraph_isomorphism_edge_counts, True, False)
+    tu_graphs, tu_sizes = run("gd_tu_vertex", raw, "TUTRIM", [3, 4], nx.complete_graph, ugp.automorphism_orbits,
+                              ugp.subgraph_isomorphism_vertex_counts, False, False)
+    run("gd_zinc_vertex", os.path.join(raw, "ZINC"), "ZINC", [3, 4, 5, 6], nx.cycle_graph, ugp.automorphism_orbits,
+        ugp.subgraph_isomorphism_vertex_counts, False, True)
+    # edge mode on ZINC: the bond-free molecule makes the reference die on an undefined name (utils_data_gen.py:104);
+    # record the graphs it does handle by running _prepare per graph
+    zg, _, _, _ = udp.load_zinc_data(os.path.join(raw, "ZINC"), "ZINC", False)
+    els = [list(nx.cycle_graph(k_).edges) for k_ in (3, 4, 5, 6)]
+    dicts = []
+    with contextlib.redirect_stdout(sink):
+        for el in els:
+            sg, part, memb, aut = ugp.induced_edge_automorphism_orbits(edge_list=el, directed=False, directed_orbits=False)
+            dicts.append({"subgraph": sg, "orbit_partition": part, "orbit_membership": memb, "aut_count": aut})
+    prepared, died = [], []
+    for g, s in enumerate(zg):
+        try:
+            prepared.append(udg._prepare(s, dicts, {"induced": False, "directed": False}, True, "ZINC",
+                                         uid.subgraph_counts2ids, ugp.subgraph_isomorphism_edge_counts))
+        except NameError:
+            died.append(g)
+            prepared.append(None)
+    assert len(died) == 1
+    rec["gd_zinc_edge/reference_nameerror_at"] = np.asarray(died, dtype=np.int64)
+    pptr, pflat = pack_edge_lists(els)
+    rec["gd_zinc_edge/pattern_ptr"], rec["gd_zinc_edge/pattern_edges"] = pptr, pflat
+    rec["gd_zinc_edge/n_graphs"] = np.int64(len(prepared))
+    for g, d in enumerate(prepared):
+        if d is None:
+            continue
+        names = [k_ for k_ in d.__dict__]
+        rec["gd_zinc_edge/%d/attr_order" % g] = np.array(names)
+        for k_ in names:
+            v = getattr(d, k_)
+            rec["gd_zinc_edge/%d/%s" % (g, k_)] = v.numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+
+    # --- downgrade_k (utils.py:332-345): keep the k=3 columns of the k<=4 clique dataset
+    dg, dsizes = uu.downgrade_k(tu_graphs, 3, tu_sizes, 3)
+    rec["downgrade/sizes"] = np.asarray(dsizes, dtype=np.int64)
+    for g, d in enumerate(dg):
+        rec["downgrade/%d/identifiers" % g] = d.identifiers.numpy()
+
+    # --- encode (utils_encoding.py:8-59): dataset-level one_hot_unique / one_hot_max of identifiers and degrees
+    for enc in ("one_hot_unique", "one_hot_max"):
+        with contextlib.redirect_stdout(sink):
+            graphs, _ = run("enc_src_" + enc, raw, "sr251256", [3, 4, 5], nx.cycle_graph, ugp.automorphism_orbits,
+                            ugp.subgraph_isomorphism_vertex_counts, True, False)
+        graphs, enc_ids, d_id, enc_deg, d_deg = uenc.encode(graphs, enc, enc, ids={}, degree={})
+        rec["enc_%s/d_id" % enc] = np.asarray(d_id, dtype=np.int64)
+        rec["enc_%s/d_degree" % enc] = np.asarray(d_deg, dtype=np.int64)
+        for g, d in enumerate(graphs):
+            rec["enc_%s/%d/identifiers" % (enc, g)] = np.asarray(d.identifiers.numpy())
+            rec["enc_%s/%d/degrees" % (enc, g)] = np.asarray(d.degrees.numpy())
+            rec["enc_%s/%d/degrees.dtype" % (enc, g)] = np.array(str(d.degrees.dtype))
+
+    # --- DiscreteEmbedding (utils_graph_learning.py:28-130): one-hot and embedding encoders
+    ugl = ref["utils_graph_learning"]
+    codes = torch.from_numpy(rng.integers(0, [3, 5, 2, 7], size=(40, 4)))
+    d_in = [3, 5, 2, 7]
+    rec["emb/codes"] = codes.numpy()
+    rec["emb/d_in"] = np.asarray(d_in, dtype=np.int64)
+    m = ugl.DiscreteEmbedding("one_hot_encoder", 4, d_in, 16)
+    rec["emb/one_hot/out"] = m(codes).numpy()
+    rec["emb/one_hot/d_out"] = np.int64(m.d_out)
+    for aggr in ("sum", "concat"):
+        torch.manual_seed(5)
+        with contextlib.redirect_stdout(sink):
+            m = ugl.DiscreteEmbedding("embedding", 4, d_in, 16, aggr=aggr, init=None)
+        c = codes.clone()
+        y = m(c)
+        gy = torch.from_numpy(rng.standard_normal(tuple(y.shape)).astype(np.float32))
+        (y * gy).sum().backward()
+        rec["emb/%s/out" % aggr] = y.detach().numpy()
+        rec["emb/%s/gy" % aggr] = gy.numpy()
+        rec["emb/%s/d_out" % aggr] = np.int64(m.d_out)
+        for k_, v in m.state_dict().items():
+            rec["emb/%s/sd/%s" % (aggr, k_)] = v.numpy()
+        for k_, p_ in m.named_parameters():
+            rec["emb/%s/grad/%s" % (aggr, k_)] = p_.grad.numpy()
+    np.savez_compressed(os.path.join(out, "dataset.npz"), **rec)
+    print("dataset: %d arrays" % len(rec))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="orbits,counts,layers")
@@ -624,6 +846,8 @@ def main():
         gen_counts(ref, args.out)
     if "layers" in only:
         gen_layers(ref, args.out)
+    if "dataset" in only:
+        gen_dataset(ref, args.out)
 
 
 if __name__ == "__main__":
