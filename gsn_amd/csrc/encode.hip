@@ -68,3 +68,215 @@ extern "C" int gsn_one_hot_hip(int64_t m_rows, int n_cols, const int64_t *values
     if (e != hipSuccess) return set_error(GSN_E_HIP, "one_hot_kernel: %s", hipGetErrorString(e));
     return GSN_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Dataset-level dense recoding of integer columns (utils_encoding.one_hot_unique, utils_encoding.py:37-59): every column
+// of the concatenated identifier matrix is replaced by the rank of its value among the column's distinct values
+// (np.unique(..., return_inverse=True)).  Counts are small non-negative integers, so instead of a sort the values index
+// a presence table:  range pass (min/max per column) -> mark -> exclusive scan of the table -> gather.
+// HBM-bound and run once per dataset.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace gsn {
+
+__global__ __launch_bounds__(256) void column_range_init_kernel(int n_cols, int64_t *mn, int64_t *mx) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < n_cols) {
+        mn[c] = INT64_MAX;
+        mx[c] = INT64_MIN;
+    }
+}
+
+// grid (blocks_x, n_cols): every block reduces a strided slice of one column, one atomic pair per block
+__global__ __launch_bounds__(256) void column_range_kernel(int64_t m_rows, int n_cols, const int64_t *values, int64_t *mn,
+                                                           int64_t *mx) {
+    const int c = blockIdx.y;
+    int64_t lo = INT64_MAX, hi = INT64_MIN;
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < m_rows; r += (int64_t)gridDim.x * 256) {
+        const int64_t v = values[r * n_cols + c];
+        lo = v < lo ? v : lo;
+        hi = v > hi ? v : hi;
+    }
+    __shared__ int64_t slo[256], shi[256];
+    slo[threadIdx.x] = lo;
+    shi[threadIdx.x] = hi;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            slo[threadIdx.x] = slo[threadIdx.x + s] < slo[threadIdx.x] ? slo[threadIdx.x + s] : slo[threadIdx.x];
+            shi[threadIdx.x] = shi[threadIdx.x + s] > shi[threadIdx.x] ? shi[threadIdx.x + s] : shi[threadIdx.x];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        atomicMin((long long *)&mn[c], (long long)slo[0]);
+        atomicMax((long long *)&mx[c], (long long)shi[0]);
+    }
+}
+
+__global__ __launch_bounds__(256) void rank_mark_kernel(int64_t m_rows, int n_cols, const int64_t *values,
+                                                        const int64_t *col_min, const int64_t *col_base, int32_t *table) {
+    const int64_t total = m_rows * n_cols;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % n_cols);
+        table[col_base[c] + (values[i] - col_min[c])] = 1;
+    }
+}
+
+// one workgroup per column: exclusive prefix sum of the 0/1 presence flags in place, number of distinct values to d_out
+__global__ __launch_bounds__(1024) void rank_scan_kernel(const int64_t *col_base, int32_t *table, int64_t *d_out) {
+    const int c = blockIdx.x;
+    int32_t *t = table + col_base[c];
+    const int64_t len = col_base[c + 1] - col_base[c];
+    __shared__ int32_t wsum[16];
+    __shared__ int32_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t base = 0; base < len; base += 1024) {
+        const int64_t i = base + threadIdx.x;
+        const int32_t v = i < len ? t[i] : 0;
+        int32_t x = v;                                   // inclusive scan inside the wave
+        for (int d = 1; d < 64; d <<= 1) {
+            const int32_t y = __shfl_up(x, d, 64);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        int32_t woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wsum[w];
+        const int32_t carry = carry_s;
+        if (i < len) t[i] = carry + woff + x - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + x;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) d_out[c] = carry_s;
+}
+
+__global__ __launch_bounds__(256) void rank_gather_kernel(int64_t m_rows, int n_cols, const int64_t *values,
+                                                          const int64_t *col_min, const int64_t *col_base,
+                                                          const int32_t *table, int64_t *codes) {
+    const int64_t total = m_rows * n_cols;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % n_cols);
+        codes[i] = table[col_base[c] + (values[i] - col_min[c])];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Embedding of several categorical columns (utils_graph_learning.multi_embedding, :134-167; also the shape of ogb's
+// AtomEncoder / BondEncoder): out[r] = concat_c T_c[code[r][c]]  or  sum_c T_c[code[r][c]].
+// meta (device, int64): [0..C) table base pointers, [C..2C) table row counts.  One thread per output float; codes are
+// broadcast within a row, table rows are read coalesced.  status (device int32) is raised to GSN_ST_BAD_INDEX on a code
+// outside its table (the reference's nn.Embedding raises IndexError).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_fwd_kernel(int64_t m_rows, int n_cols, int d, int concat, const int64_t *codes,
+                                                        const int64_t *meta, float *out, int32_t *status) {
+    const int width = concat ? n_cols * d : d;
+    const int64_t total = m_rows * width;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / width;
+        const int w = (int)(i - r * width);
+        float acc = 0.f;
+        if (concat) {
+            const int c = w / d, j = w - c * d;
+            const int64_t code = codes[r * n_cols + c];
+            if (code < 0 || code >= meta[n_cols + c]) { atomicMax(status, GSN_ST_BAD_INDEX); continue; }
+            acc = reinterpret_cast<const float *>(meta[c])[code * d + j];
+        } else {
+            for (int c = 0; c < n_cols; ++c) {
+                const int64_t code = codes[r * n_cols + c];
+                if (code < 0 || code >= meta[n_cols + c]) { atomicMax(status, GSN_ST_BAD_INDEX); continue; }
+                acc += reinterpret_cast<const float *>(meta[c])[code * d + w];
+            }
+        }
+        out[i] = acc;
+    }
+}
+
+// adjoint: gT_c[code[r][c]] += g_out[r][...]; meta holds the GRADIENT table pointers.  fp32 atomics (rows collide).
+__global__ __launch_bounds__(256) void embed_bwd_kernel(int64_t m_rows, int n_cols, int d, int concat, const int64_t *codes,
+                                                        const int64_t *meta, const float *gout) {
+    const int64_t total = m_rows * n_cols * d;
+    const int gw = concat ? n_cols * d : d;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / (n_cols * d);
+        const int rem = (int)(i - r * (n_cols * d));
+        const int c = rem / d, j = rem - c * d;
+        const int64_t code = codes[r * n_cols + c];
+        if (code < 0 || code >= meta[n_cols + c]) continue;
+        const float g = gout[r * gw + (concat ? c * d + j : j)];
+        atomicAdd(reinterpret_cast<float *>(meta[c]) + code * d + j, g);
+    }
+}
+
+static int grid_for(int64_t items) {
+    int64_t b = (items + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 256 * 16 ? 256 * 16 : b));
+}
+
+}  // namespace gsn
+
+#define GSN_LAUNCH_CHECK(name)                                                                  \
+    do {                                                                                        \
+        hipError_t e_ = hipGetLastError();                                                      \
+        if (e_ != hipSuccess) return set_error(GSN_E_HIP, name ": %s", hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" int gsn_column_range_hip(int64_t m_rows, int n_cols, const int64_t *values, int64_t *col_min, int64_t *col_max,
+                                    void *stream) {
+    if (n_cols < 1 || n_cols > 65535 || !col_min || !col_max || (m_rows > 0 && !values))
+        return set_error(GSN_E_INVALID, "gsn_column_range_hip: bad arguments");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(column_range_init_kernel, dim3((n_cols + 255) / 256), dim3(256), 0, s, n_cols, col_min, col_max);
+    if (m_rows > 0) {
+        int bx = grid_for(m_rows);
+        if (bx > 1024) bx = 1024;
+        hipLaunchKernelGGL(column_range_kernel, dim3(bx, n_cols), dim3(256), 0, s, m_rows, n_cols, values, col_min, col_max);
+    }
+    GSN_LAUNCH_CHECK("column_range_kernel");
+    return GSN_OK;
+}
+
+extern "C" int gsn_column_ranks_hip(int64_t m_rows, int n_cols, const int64_t *values, const int64_t *col_min,
+                                    const int64_t *col_base, int64_t table_elems, int32_t *table, int64_t *codes,
+                                    int64_t *n_distinct, void *stream) {
+    if (n_cols < 1 || n_cols > 65535 || !col_min || !col_base || !n_distinct || table_elems < 0 ||
+        (table_elems > 0 && !table) || (m_rows > 0 && (!values || !codes)))
+        return set_error(GSN_E_INVALID, "gsn_column_ranks_hip: bad arguments");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (table_elems > 0 && hipMemsetAsync(table, 0, (size_t)table_elems * sizeof(int32_t), s) != hipSuccess)
+        return set_error(GSN_E_HIP, "gsn_column_ranks_hip: memset failed");
+    if (m_rows > 0)
+        hipLaunchKernelGGL(rank_mark_kernel, dim3(grid_for(m_rows * n_cols)), dim3(256), 0, s, m_rows, n_cols, values, col_min,
+                           col_base, table);
+    hipLaunchKernelGGL(rank_scan_kernel, dim3(n_cols), dim3(1024), 0, s, col_base, table, n_distinct);
+    if (m_rows > 0)
+        hipLaunchKernelGGL(rank_gather_kernel, dim3(grid_for(m_rows * n_cols)), dim3(256), 0, s, m_rows, n_cols, values,
+                           col_min, col_base, table, codes);
+    GSN_LAUNCH_CHECK("rank kernels");
+    return GSN_OK;
+}
+
+extern "C" int gsn_embed_fwd_hip(int64_t m_rows, int n_cols, int d, int concat, const int64_t *codes, const int64_t *meta,
+                                 float *out, int32_t *status, void *stream) {
+    if (n_cols < 1 || d < 1 || !meta || !status || (m_rows > 0 && (!codes || !out)))
+        return set_error(GSN_E_INVALID, "gsn_embed_fwd_hip: bad arguments");
+    if (m_rows <= 0) return GSN_OK;
+    const int64_t total = m_rows * (concat ? (int64_t)n_cols * d : d);
+    hipLaunchKernelGGL(embed_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), m_rows,
+                       n_cols, d, concat, codes, meta, out, status);
+    GSN_LAUNCH_CHECK("embed_fwd_kernel");
+    return GSN_OK;
+}
+
+extern "C" int gsn_embed_bwd_hip(int64_t m_rows, int n_cols, int d, int concat, const int64_t *codes, const int64_t *grad_meta,
+                                 const float *grad_out, void *stream) {
+    if (n_cols < 1 || d < 1 || !grad_meta || (m_rows > 0 && (!codes || !grad_out)))
+        return set_error(GSN_E_INVALID, "gsn_embed_bwd_hip: bad arguments");
+    if (m_rows <= 0) return GSN_OK;
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for(m_rows * n_cols * d)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), m_rows, n_cols, d, concat, codes, grad_meta, grad_out);
+    GSN_LAUNCH_CHECK("embed_bwd_kernel");
+    return GSN_OK;
+}

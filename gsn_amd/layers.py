@@ -517,6 +517,13 @@ def _run(module, hip_fn, torch_fn, inputs):
     return _HipWithTorchBackward.apply(hip_fn, torch_fn, len(inputs), *inputs, *params)
 
 
+def run_linear_module(lin, x):
+    """A lone ``nn.Linear`` on the HIP dense stage (DiscreteEmbedding('linear'), utils_graph_learning.py:63-65)."""
+    _need_cuda(x, "linear input")
+    stage = lambda: run_stages([_Stage(lin.weight, lin.bias, None, "identity", [(x, None)])], x.shape[0], False)
+    return _run(lin, stage, lambda x_: F.linear(x_, lin.weight, lin.bias), [x])
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # central_encoder (utils_graph_learning.py:211-260): dummy "self loop" value of ids / edge features for GIN-style sums
 # ------------------------------------------------------------------------------------------------------------------

@@ -214,6 +214,37 @@ int gsn_segsum_prepare_hip(int64_t n_seg, int64_t n_rows, const int32_t *seg_ptr
 int gsn_one_hot_hip(int64_t m_rows, int n_cols, const int64_t *values, const int32_t *n_classes, int clamp, float *out,
                     void *stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Dataset-level dense recoding of integer columns (device): utils_encoding.one_hot_unique (utils_encoding.py:37-59),
+ * i.e. per column np.unique(values[:, c], return_inverse=True): codes[r][c] = rank of values[r][c] among the distinct
+ * values of column c, n_distinct[c] = their number (the reference's `d`).
+ *   gsn_column_range_hip : col_min / col_max (device int64 [C]) of values int64 [M][C]; also what one_hot_max needs
+ *                          (utils_encoding.py:62-69: d[c] = max + 1).
+ *   gsn_column_ranks_hip : col_min as produced above; col_base (device int64 [C+1]) = prefix sums of the per-column table
+ *                          sizes (max - min + 1), which the caller computes after reading the ranges back;
+ *                          table = device scratch of table_elems = col_base[C] int32.
+ * All asynchronous on `stream`.
+ * ---------------------------------------------------------------------------------------------------------------- */
+int gsn_column_range_hip(int64_t m_rows, int n_cols, const int64_t *values, int64_t *col_min, int64_t *col_max,
+                         void *stream);
+int gsn_column_ranks_hip(int64_t m_rows, int n_cols, const int64_t *values, const int64_t *col_min,
+                         const int64_t *col_base, int64_t table_elems, int32_t *table, int64_t *codes,
+                         int64_t *n_distinct, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Embedding of categorical columns (device): utils_graph_learning.multi_embedding.forward (:151-163), the
+ * DiscreteEmbedding('embedding') of identifiers / degrees / node and edge types, and the same shape as ogb's
+ * AtomEncoder / BondEncoder ('atom_encoder' / 'bond_encoder', :99-107).  codes int64 [M][C]; table c is fp32
+ * [rows_c][d] row-major.  meta (device int64 [2C]) = table base addresses then rows_c.  concat != 0: out [M][C*d] is the
+ * concatenation, else out [M][d] the sum over columns.  status (device int32, caller-zeroed) is raised to
+ * GSN_ST_BAD_INDEX when a code is outside its table.  bwd accumulates grad_out into the gradient tables named by
+ * grad_meta with fp32 atomics (caller zero-fills them).
+ * ---------------------------------------------------------------------------------------------------------------- */
+int gsn_embed_fwd_hip(int64_t m_rows, int n_cols, int d, int concat, const int64_t *codes, const int64_t *meta,
+                      float *out, int32_t *status, void *stream);
+int gsn_embed_bwd_hip(int64_t m_rows, int n_cols, int d, int concat, const int64_t *codes, const int64_t *grad_meta,
+                      const float *grad_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

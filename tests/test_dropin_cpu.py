@@ -1,4 +1,4 @@
-"""The drop-in directory resolves the reference's import statements (utils.py:2-3, utils_data_gen.py:6,
+"""The drop-in directory resolves the reference's import statements (utils.py:2-5, main.py:19, utils_data_gen.py:6,
 models_graph_classification.py:5-8, models_graph_classification_ogb_original.py:7-8) to our implementations."""
 import os
 import subprocess
@@ -17,7 +17,16 @@ from graph_filters.MPNN_sparse import MPNN_sparse
 from graph_filters.MPNN_edge_sparse import MPNN_edge_sparse
 from graph_filters.GSN_edge_sparse_ogb import GSN_edge_sparse_ogb
 from graph_filters.MPNN_edge_sparse_ogb import MPNN_edge_sparse_ogb
-import gsn_amd.layers, gsn_amd.counting
+from utils_data_gen import generate_dataset
+from utils_encoding import encode
+from utils_graph_learning import multi_class_accuracy, global_add_pool_sparse, global_mean_pool_sparse, \
+    DiscreteEmbedding, central_encoder
+from models_misc import mlp, choose_activation
+import gsn_amd.layers, gsn_amd.counting, gsn_amd.encoding, gsn_amd.dataset
+assert encode is gsn_amd.encoding.encode and mlp is gsn_amd.layers.mlp
+assert generate_dataset.__wrapped__ is gsn_amd.dataset.generate_dataset
+import torch
+assert float(multi_class_accuracy(torch.tensor([[0.1, 0.9], [0.8, 0.2]]), torch.tensor([1, 1]))) == 1.0
 assert GSN_edge_sparse is gsn_amd.layers.GSN_edge_sparse
 assert subgraph_counts2ids is gsn_amd.counting.subgraph_counts2ids
 # how the reference picks the functions (utils.py:40-48) and tells the modes apart (utils_data_gen.py:103)

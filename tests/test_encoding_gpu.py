@@ -1,0 +1,130 @@
+"""Encoders vs outputs of the reference's utils_encoding.encode and utils_graph_learning.DiscreteEmbedding
+(tests/golden/dataset.npz)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gsn_amd import data as gdata
+from gsn_amd import encoding
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(HERE, "golden", "dataset.npz"), allow_pickle=False)
+
+
+def _source_graphs(gold, key):
+    out = []
+    for g in range(int(gold[key + "/n_graphs"])):
+        d = gdata.Data()
+        d.identifiers = torch.from_numpy(gold["%s/%d/identifiers" % (key, g)])
+        d.degrees = torch.from_numpy(gold["%s/%d/degrees" % (key, g)])
+        out.append(d)
+    return out
+
+
+@pytest.mark.parametrize("enc", ["one_hot_unique", "one_hot_max"])
+def test_encode_matches_reference(gold, enc):
+    graphs = _source_graphs(gold, "enc_src_" + enc)
+    graphs, enc_ids, d_id, enc_deg, d_deg = encoding.encode(graphs, enc, enc, ids={}, degree={})
+    assert list(d_id) == gold["enc_%s/d_id" % enc].tolist()
+    assert list(d_deg) == gold["enc_%s/d_degree" % enc].tolist()
+    for g, d in enumerate(graphs):
+        assert np.array_equal(d.identifiers.numpy(), gold["enc_%s/%d/identifiers" % (enc, g)])
+        want = gold["enc_%s/%d/degrees" % (enc, g)]
+        assert np.array_equal(np.asarray(d.degrees.numpy()).reshape(want.shape), want)
+        assert str(d.degrees.dtype) == str(gold["enc_%s/%d/degrees.dtype" % (enc, g)])
+
+
+def test_encode_without_encoders_keeps_data(gold):
+    graphs = _source_graphs(gold, "enc_src_one_hot_unique")
+    before = [g.identifiers.clone() for g in graphs]
+    graphs, e1, d_id, e2, d_deg = encoding.encode(graphs, None, None)
+    assert e1 is None and e2 is None and d_deg == [] and d_id == [1] * before[0].shape[1]
+    assert all(torch.equal(a.identifiers, b) for a, b in zip(graphs, before))
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (5, 3), (4097, 7), (70000, 2)])
+def test_unique_codes_random(shape):
+    rng = np.random.default_rng(shape[0])
+    vals = rng.integers(-5, [3 + 40 * c * c for c in range(shape[1])], size=shape)
+    vals[:, 0] = rng.integers(0, 3000, size=shape[0]) * 7 - 1000      # sparse range: forces multi-tile scans
+    codes, d = encoding.unique_codes(torch.from_numpy(vals))
+    for c in range(shape[1]):
+        u, inv = np.unique(vals[:, c], return_inverse=True)
+        assert d[c] == len(u)
+        assert np.array_equal(codes[:, c].numpy(), inv)
+
+
+def test_unique_codes_edge_cases():
+    codes, d = encoding.unique_codes(torch.zeros((0, 3), dtype=torch.int64))
+    assert codes.shape == (0, 3) and d == [0, 0, 0]
+    codes, d = encoding.unique_codes(torch.tensor([[2.0], [0.0], [2.0]]))
+    assert codes[:, 0].tolist() == [1, 0, 1] and d == [2]
+    with pytest.raises(NotImplementedError):
+        encoding.unique_codes(torch.tensor([[0.5]]))
+    with pytest.raises(NotImplementedError):
+        encoding.unique_codes(torch.tensor([[0], [1 << 40]]))
+
+
+def test_one_hot_encoder_matches_reference(gold):
+    codes = torch.from_numpy(gold["emb/codes"]).cuda()
+    m = encoding.DiscreteEmbedding("one_hot_encoder", 4, gold["emb/d_in"].tolist(), 16)
+    assert m.d_out == int(gold["emb/one_hot/d_out"])
+    assert np.array_equal(m(codes).cpu().numpy(), gold["emb/one_hot/out"])
+    assert len(list(m.parameters())) == 0
+
+
+@pytest.mark.parametrize("aggr", ["sum", "concat"])
+def test_embedding_matches_reference_fwd_bwd(gold, aggr):
+    codes = torch.from_numpy(gold["emb/codes"]).cuda()
+    m = encoding.DiscreteEmbedding("embedding", 4, gold["emb/d_in"].tolist(), 16, aggr=aggr, init=None)
+    sd = {k[len("emb/%s/sd/" % aggr):]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith("emb/%s/sd/" % aggr)}
+    assert set(sd) == set(m.state_dict())
+    m.load_state_dict(sd)
+    m = m.cuda()
+    assert m.d_out == int(gold["emb/%s/d_out" % aggr])
+    y = m(codes)
+    want = gold["emb/%s/out" % aggr]
+    assert np.allclose(y.detach().cpu().numpy(), want, rtol=1e-6, atol=1e-7)
+    (y * torch.from_numpy(gold["emb/%s/gy" % aggr]).cuda()).sum().backward()
+    for k, p in m.named_parameters():
+        assert np.allclose(p.grad.cpu().numpy(), gold["emb/%s/grad/%s" % (aggr, k)], rtol=1e-5, atol=1e-6), k
+
+
+def test_embedding_out_of_range_raises():
+    m = encoding.multi_embedding([3, 3], 4, "sum").cuda()
+    with pytest.raises(IndexError):
+        m(torch.tensor([[0, 3]]).cuda())
+
+
+def test_ogb_style_encoders_and_linear():
+    torch.manual_seed(0)
+    a = encoding.DiscreteEmbedding("atom_encoder", 9, None, 32).cuda()
+    assert sorted(a.state_dict())[0] == "encoder.atom_embedding_list.0.weight" and len(a.state_dict()) == 9
+    x = torch.stack([torch.randint(0, d, (50,)) for d in encoding.ATOM_FEATURE_DIMS], 1).cuda()
+    want = sum(a.encoder.atom_embedding_list[i].weight[x[:, i]] for i in range(9))
+    assert torch.allclose(a(x), want, rtol=1e-6, atol=1e-6)
+    b = encoding.DiscreteEmbedding("bond_encoder", 3, None, 8).cuda()
+    assert "encoder.bond_embedding_list.2.weight" in b.state_dict()
+    assert b(torch.zeros(5, 3, dtype=torch.long).cuda()).shape == (5, 8)
+    oh = encoding.DiscreteEmbedding("atom_one_hot_encoder", 9, None, 0, features_scope="simple")
+    assert oh.d_out == 123 and oh(x[:, :2]).sum().item() == 100.0
+    lin = encoding.DiscreteEmbedding("linear", 6, None, 10).cuda()
+    v = torch.randn(33, 6).cuda().requires_grad_(True)
+    y = lin(v)
+    ref = torch.nn.functional.linear(v, lin.encoder.weight, lin.encoder.bias)
+    assert torch.allclose(y, ref, rtol=1e-5, atol=1e-5)
+    y.sum().backward()
+    assert v.grad is not None and lin.encoder.weight.grad is not None
+    none = encoding.DiscreteEmbedding("None", 5, None, 0)
+    assert none.d_out == 5 and none(torch.arange(4)).shape == (4, 1)
+    z = encoding.DiscreteEmbedding("zero_encoder", 1, None, 7)
+    assert z(torch.zeros(3, 1).cuda()).shape == (3, 7)
+    with pytest.raises(NotImplementedError):
+        encoding.DiscreteEmbedding("nope", 1, None, 1)
