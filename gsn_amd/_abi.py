@@ -34,6 +34,11 @@ class gsn_chain_stage(ctypes.Structure):
 
 
 # name -> (restype, argtypes); kept in one place so tests can check it against include/gsn_abi.h
+class gsn_code_slot(ctypes.Structure):
+    _fields_ = [("codes", ctypes.c_void_p), ("idx", ctypes.c_void_p), ("stride", ctypes.c_int32), ("col", ctypes.c_int32),
+                ("w_off", ctypes.c_int32), ("n_classes", ctypes.c_int32)]
+
+
 SIGNATURES = {
     "gsn_last_error": (ctypes.c_char_p, []),
     "gsn_version": (c_int, []),
@@ -56,6 +61,9 @@ SIGNATURES = {
     "gsn_column_ranks_hip": (c_int, [c_i64, c_int, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "gsn_embed_fwd_hip": (c_int, [c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "gsn_embed_bwd_hip": (c_int, [c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
+    "gsn_code_stage_supported": (c_int, [c_int, c_i64, c_i64]),
+    "gsn_code_stage_fwd_hip": (c_int, [c_i64, c_int, ctypes.POINTER(gsn_code_slot), c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp,
+                                       c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "gsn_mlp_chain_supported": (c_int, [c_int, ctypes.POINTER(gsn_chain_stage)]),
     "gsn_mlp_chain_fwd_hip": (c_int, [c_i64, c_int, ctypes.POINTER(gsn_chain_stage), c_vp, c_vp, c_vp, c_vp, c_vp]),
 }

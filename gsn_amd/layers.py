@@ -29,7 +29,7 @@ from . import _abi
 
 __all__ = ["mlp", "central_encoder", "GSN_sparse", "GSN_edge_sparse", "MPNN_sparse", "MPNN_edge_sparse",
            "GSN_edge_sparse_ogb", "MPNN_edge_sparse_ogb", "build_csr", "propagate", "run_stages", "one_hot_identifiers",
-           "global_add_pool_sparse", "global_mean_pool_sparse"]
+           "global_add_pool_sparse", "global_mean_pool_sparse", "Codes", "run_linear_module"]
 
 _ACT_CODE = {"identity": 0, "relu": 1, "elu": 2, "tanh": 3}
 _MAX_BLOCKS = 5
@@ -77,6 +77,49 @@ def _need_cuda(t, what):
 
 def _f32c(t):
     return t.detach().to(torch.float32).contiguous()
+
+
+class Codes:
+    """Integer category codes standing in for their one-hot encoding (the output of the reference's
+    DiscreteEmbedding('one_hot_encoder'), utils_graph_learning.py:170-187) as a layer input.
+
+    ``codes`` int64 [R, C] on the GPU, ``n_classes`` C ints; equivalent to the float tensor ``dense()`` of shape
+    [R, sum(n_classes)].  Layers accept it for ``x``, ``identifiers`` and ``edge_features``; where all inputs of msg_fn's
+    first Linear are Codes that Linear becomes a weight-row gather (gsn_code_stage_fwd_hip) and the dense one-hot
+    matrix is never built; everywhere else the layer densifies it."""
+    __slots__ = ("codes", "n_classes", "_dense")
+
+    def __init__(self, codes, n_classes):
+        codes = codes.unsqueeze(-1) if codes.dim() == 1 else codes
+        _need_cuda(codes, "codes")
+        self.codes = codes.to(torch.int64).contiguous()
+        self.n_classes = [int(c) for c in n_classes]
+        if len(self.n_classes) != self.codes.shape[1]:
+            raise ValueError("Codes: %d columns but %d class counts" % (self.codes.shape[1], len(self.n_classes)))
+        self._dense = None
+
+    @property
+    def shape(self):
+        return torch.Size((self.codes.shape[0], sum(self.n_classes)))
+
+    @property
+    def device(self):
+        return self.codes.device
+
+    is_cuda = True
+    requires_grad = False
+
+    def dim(self):
+        return 2
+
+    def dense(self):
+        if self._dense is None:
+            self._dense = one_hot_identifiers(self.codes, self.n_classes)
+        return self._dense
+
+
+def _dense(v):
+    return v.dense() if isinstance(v, Codes) else v
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -426,6 +469,69 @@ def run_stages(stages, m_rows, training, csr=None):
     return _launch_stages(stages, m_rows, csr=csr)
 
 
+CODE_STATUS_CHECK = True   # read the out-of-range flag back after every code-gather launch (one host sync)
+
+
+def _transposed_weight(lin):
+    key = (lin.weight._version, lin.weight.data_ptr())
+    hit = getattr(lin, "_gsn_wt", None)
+    if hit is None or hit[0] != key:
+        hit = (key, lin.weight.detach().to(torch.float32).t().contiguous())
+        lin._gsn_wt = hit
+    return hit[1]
+
+
+def _code_stage_segsum(mf, cblocks, csr, m_rows):
+    """msg_fn's first stage over Codes blocks + sum per target: gsn_code_stage_fwd_hip.  ``cblocks``: (Codes, int32 row
+    index per target-sorted position) in concatenation order.  Returns [n_nodes, d_h] or None if the shape does not fit."""
+    L = _abi.lib()
+    lin = mf.fc[0]
+    bn = mf.bn[0] if mf.batch_norm else None
+    n_out, k_total = lin.weight.shape
+    n_slots = sum(len(c.n_classes) for c, _ in cblocks)
+    if n_slots > 16 or sum(sum(c.n_classes) for c, _ in cblocks) != k_total or not L.gsn_code_stage_supported(n_slots, k_total, n_out):
+        return None
+    dev = lin.weight.device
+    arr = (_abi.gsn_code_slot * n_slots)()
+    s, off = 0, 0
+    for c, idx in cblocks:
+        for col, ncls in enumerate(c.n_classes):
+            arr[s].codes = c.codes.data_ptr(); arr[s].idx = idx.data_ptr()
+            arr[s].stride = c.codes.shape[1]; arr[s].col = col; arr[s].w_off = off; arr[s].n_classes = ncls
+            s += 1
+            off += ncls
+    wt = _transposed_weight(lin)
+    bias = _f32c(lin.bias)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def launch(bn_params, out, stats):
+        vecs = [None if v is None else _f32c(v) for v in (bn_params or (None, None, None))]
+        with torch.cuda.device(dev), _timed("code_stage", 4.0 * m_rows * n_slots * n_out):
+            rc = L.gsn_code_stage_fwd_hip(m_rows, n_slots, arr, wt.data_ptr(), k_total, bias.data_ptr(), n_out,
+                                          _abi.ptr(vecs[0]), _abi.ptr(vecs[1]), _abi.ptr(vecs[2]), _ACT_CODE[mf.activation_name],
+                                          csr.tgt.data_ptr(), _abi.ptr(out), _abi.ptr(stats), status.data_ptr(),
+                                          _abi.current_stream())
+        _abi.check(rc, "gsn_code_stage_fwd_hip")
+
+    stage = _Stage(lin.weight, lin.bias, bn, mf.activation_name)
+
+    def stats_fn():
+        stats = torch.zeros((2, n_out), dtype=torch.float64, device=dev)
+        launch(None, None, stats)
+        return stats
+
+    _bn_resolve(stage, stats_fn, m_rows, mf.training)
+    n_seg = csr.seg_ptr.numel() - 1
+    out = torch.empty((n_seg, n_out), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev), _timed("segsum_prepare"):
+        _abi.check(L.gsn_segsum_prepare_hip(n_seg, m_rows, csr.seg_ptr.data_ptr(), csr.tgt.data_ptr(), n_out, out.data_ptr(),
+                                            _abi.current_stream()), "gsn_segsum_prepare_hip")
+    launch(stage.bn_params, out, None)
+    if CODE_STATUS_CHECK and int(status.item()) != 0:
+        raise IndexError("a code is outside [0, n_classes) of its column")
+    return out
+
+
 class mlp(nn.Module):
     """models_misc.mlp (models_misc.py:18-59): Linear -> [BatchNorm1d] -> activation ... -> Linear, same attribute
     names (``fc``, ``bn``) so state dicts are interchangeable; forward runs on the HIP dense stages."""
@@ -630,6 +736,8 @@ class _SparseLayer(nn.Module):
     # -- input preparation shared by both paths (reference: forward() prologue of every layer)
     def _prepare(self, x, kwargs):
         x = x.unsqueeze(-1) if x.dim() == 1 else x
+        if self.degree_as_tag:
+            x = _dense(x)
         degrees = kwargs["degrees"]
         identifiers = kwargs["identifiers"] if self.has_ids or self.ogb else None
         if not self.has_ids:
@@ -654,14 +762,12 @@ class _SparseLayer(nn.Module):
         x, ids, ef = self._prepare(x, kwargs)
         _need_cuda(x, "x")
         _need_cuda(edge_index, "edge_index")
-        inputs = [x] + ([ids] if ids is not None else []) + ([ef] if ef is not None else [])
+        given = [x, ids, ef]
+        inputs = [t for t in given if t is not None and not isinstance(t, Codes)]
 
-        def unpack(ts):
+        def unpack(ts):     # float inputs come back from autograd, Codes are densified for the differentiable twin
             ts = list(ts)
-            x_ = ts.pop(0)
-            ids_ = ts.pop(0) if ids is not None else None
-            ef_ = ts.pop(0) if ef is not None else None
-            return x_, ids_, ef_
+            return tuple(None if t is None else (t.dense() if isinstance(t, Codes) else ts.pop(0)) for t in given)
 
         return _run(self, lambda: self._hip(edge_index, x, ids, ef), lambda *ts: self._twin(edge_index, *unpack(ts)), inputs)
 
@@ -690,7 +796,12 @@ class _SparseLayer(nn.Module):
         n = x.shape[0]
         sel = self._sel()
         E = edge_index.shape[1]
-        x = _f32c(x)
+        raw = (x, ids, ef)
+        use_codes = (not self.ogb and self.msg_kind == "general" and len(self.msg_fn.fc) == 2 and E > 0
+                     and all(isinstance(t, Codes) for t in raw if t is not None))
+        x = _f32c(_dense(x))
+        if not use_codes:
+            ids, ef = _dense(ids), _dense(ef)
         if self.ogb:
             per_node = self.has_ids and self.id_scope == "global"
             agg = propagate(1, edge_index, sel, n, a=x, b=ids if self.has_ids else None, c=ef, b_per_node=per_node)
@@ -717,14 +828,31 @@ class _SparseLayer(nn.Module):
             #     [x | agg] W3^T = x W3x^T + S (W3a W2)^T + deg (W3a b2)^T
             # so it is folded into that Linear's weight (a [d_h x d_msg] by [d_msg x d_h] product, once per call).
             csr = _csr_for(edge_index, sel, n)
+            s_agg = None
+            if use_codes:
+                # every input of msg_fn's first Linear is a one-hot code column: weight-row gather, no dense one-hot
+                cblocks = [(raw[0], csr.tgt), (raw[0], csr.src)]
+                if self.has_ids:
+                    cblocks += [(raw[1], csr.perm)] if self.id_scope == "local" else [(raw[1], csr.tgt), (raw[1], csr.src)]
+                if self.has_ef:
+                    cblocks.append((raw[2], csr.perm))
+                s_agg = _code_stage_segsum(mf, cblocks, csr, E)
+                if s_agg is None:
+                    ids, ef = _dense(ids), _dense(ef)
+                    blocks = [(x, idx_i), (x, idx_j)]
+                    if self.has_ids:
+                        blocks += [(ids, None)] if self.id_scope == "local" else [(ids, idx_i), (ids, idx_j)]
+                    if self.has_ef:
+                        blocks.append((ef, None))
             # fused path: rows walked in target-sorted order; every block is gathered through ONE int32 index
             # (x_i: sorted target, x_j: sorted source, per-edge rows: perm), the scatter-add happens in the epilogue
-            sblocks = [(x, csr.tgt), (x, csr.src)]
-            if self.has_ids:
-                sblocks += [(ids, csr.perm)] if self.id_scope == "local" else [(ids, csr.tgt), (ids, csr.src)]
-            if self.has_ef:
-                sblocks.append((ef, csr.perm))
-            s_agg = mf.hip_forward(sblocks, E, upto=len(mf.fc) - 1, csr=csr) if E > 0 else None
+            if s_agg is None and E > 0:
+                sblocks = [(x, csr.tgt), (x, csr.src)]
+                if self.has_ids:
+                    sblocks += [(ids, csr.perm)] if self.id_scope == "local" else [(ids, csr.tgt), (ids, csr.src)]
+                if self.has_ef:
+                    sblocks.append((ef, csr.perm))
+                s_agg = mf.hip_forward(sblocks, E, upto=len(mf.fc) - 1, csr=csr)
             if s_agg is None:
                 r = mf.hip_forward(blocks, E, upto=len(mf.fc) - 1)
                 s_agg = propagate(0, edge_index, sel, n, b=r)

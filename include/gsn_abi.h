@@ -245,6 +245,34 @@ int gsn_embed_fwd_hip(int64_t m_rows, int n_cols, int d, int concat, const int64
 int gsn_embed_bwd_hip(int64_t m_rows, int n_cols, int d, int concat, const int64_t *codes, const int64_t *grad_meta,
                       const float *grad_out, void *stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * First Linear of msg_fn over one-hot encoded inputs as a weight-row gather with fused bias / BatchNorm / activation
+ * and fused scatter-add (device).  Replaces, for inputs that are DiscreteEmbedding('one_hot_encoder') outputs
+ * (utils_graph_learning.py:78-81, models_graph_classification.py:205-222), the reference's sequence
+ *     one_hot -> cat(x_i, x_j, ids, e) -> msg_fn.fc[0] -> bn -> act     (GSN_edge_sparse.py:152-170, models_misc.py:52-59)
+ *     -> torch.sparse.sum scatter-add                                   (GSN_edge_sparse.py:136-139)
+ * Row q of the target-sorted edge order takes, per slot s, the code  codes[idx[q] * stride + col]  (idx NULL: row q) and
+ * adds row  w_off + code  of WT = W^T ([k_total][n_out] fp32 row-major):
+ *     out[seg_target[q]] += act(bn(bias + sum_s WT[w_off_s + code_s]))
+ * `out` [n_targets][n_out] must have been prepared with gsn_segsum_prepare_hip; seg_target int32 [m_rows] ascending.
+ * stats != NULL: statistics pass instead -- fp64 [2][n_out] column sums of (bias + sum) and of its square (caller
+ * zero-fills), no `out`.  status (device int32, caller-zeroed) is raised to GSN_ST_BAD_INDEX if a code is outside
+ * [0, n_classes) (the code is then treated as 0).  act: 0 identity, 1 relu, 2 elu, 3 tanh.
+ * ---------------------------------------------------------------------------------------------------------------- */
+#define GSN_MAX_CODE_SLOTS 16
+typedef struct gsn_code_slot {
+    const int64_t *codes;  /* device, [rows][stride] */
+    const int32_t *idx;    /* device int32 [m_rows] row of `codes` feeding sorted position q, or NULL */
+    int32_t stride, col;   /* row pitch of `codes` in elements, column used */
+    int32_t w_off;         /* first row of this slot's block in WT */
+    int32_t n_classes;     /* number of rows of that block */
+} gsn_code_slot;
+int gsn_code_stage_supported(int n_slots, int64_t k_total, int64_t n_out);
+int gsn_code_stage_fwd_hip(int64_t m_rows, int n_slots, const gsn_code_slot *slots, const float *WT, int64_t k_total,
+                           const float *bias, int64_t n_out, const float *bn_mean, const float *bn_scale,
+                           const float *bn_shift, int act, const int32_t *seg_target, float *out, double *stats,
+                           int32_t *status, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -120,6 +120,60 @@ def main():
     layer_case("GSN_edge_sparse general d=128 eval fwd (config 2 layer)", layers.GSN_edge_sparse(**gen), x28, kw, False, False)
     layer_case("GSN_edge_sparse general d=128 train fwd (batch-stat BN)", layers.GSN_edge_sparse(**gen), x28, kw, True, False)
     layer_case("GSN_edge_sparse general d=128 train fwd+bwd", layers.GSN_edge_sparse(**gen), x28, kw, True, True)
+    # ---- batched preprocessing driver, dataset-level recoding, code-gather edge stage
+    import time
+    from collections import namedtuple
+    from gsn_amd import dataset as gds, encoding, patterns
+    res["next_rows"] = []
+    Graph = namedtuple("Graph", ["node_features", "edge_mat", "edge_features", "label"])
+    raw = []
+    for i in range(12000):
+        n, e = zb.graph(i)
+        raw.append(Graph(torch.zeros(n, dtype=torch.long), torch.from_numpy(np.ascontiguousarray(e)), torch.ones(e.shape[1], dtype=torch.long), 0.0))
+    dicts = []
+    for el in cyc(range(3, 7)):
+        sg, part, memb, aut = patterns.induced_edge_automorphism_orbits(edge_list=el, directed=False, directed_orbits=False)
+        dicts.append({"subgraph": sg, "orbit_partition": part, "orbit_membership": memb, "aut_count": aut})
+    params = {"induced": False, "directed": False}
+    gds.prepare_graphs(raw[:64], dicts, params, True, "ZINC", "edge")
+    t0 = time.perf_counter()
+    prepared = gds.prepare_graphs(raw, dicts, params, True, "ZINC", "edge")
+    dt = time.perf_counter() - t0
+    res["next_rows"].append({"case": "prepare_graphs: ZINC-shape x12000, cycle 3..6 edge ids (host collate + 1 launch + per-graph split)",
+                             "s": round(dt, 3), "graphs_per_s": round(12000 / dt, 1)})
+    ids = [g.identifiers for g in prepared]
+    encoding.one_hot_unique(ids[:8])
+    t0 = time.perf_counter()
+    enc = encoding.one_hot_unique(ids)
+    dt = time.perf_counter() - t0
+    res["next_rows"].append({"case": "one_hot_unique over %d rows x 4 columns (incl. host cat + H2D/D2H)" % enc.codes.shape[0],
+                             "s": round(dt, 4), "d": enc.d})
+    big = torch.randint(0, 40, (1 << 24, 4), device=dev)
+    dt = timeit(lambda: encoding.column_range(big), reps=5, warm=2)
+    res["next_rows"].append({"case": "gsn_column_range_hip 2^24 x 4 int64", "ms": round(dt * 1e3, 3), "GBps": round(big.numel() * 8 / dt / 1e9, 1)})
+
+    bb = __import__("bench").make_batch(65536, 5)
+    Nb, Eb = bb.num_nodes, bb.num_edges
+    eib = torch.from_numpy(bb.edge_index).to(dev)
+    xcodes = layers.Codes(torch.from_numpy(bb.atom_type).to(dev), [28])
+    efcodes = layers.Codes(torch.from_numpy(bb.bond_type).to(dev), [4])
+    idcodes = layers.Codes(torch.randint(0, 3, (Eb, 4), device=dev), [3, 3, 3, 3])
+    torch.manual_seed(0)
+    lay = layers.GSN_edge_sparse(**gen).to(dev).eval()
+    layers.CODE_STATUS_CHECK = False
+    degb = torch.zeros(Nb, device=dev)
+    xd, idd, efd = xcodes.dense(), idcodes.dense(), efcodes.dense()
+    for name, args_ in (("dense one-hot inputs (reference boundary)", (xd, idd, efd)), ("integer codes (weight-row gather edge stage)", (xcodes, idcodes, efcodes))):
+        def run():
+            with torch.no_grad():
+                lay(args_[0], eib, identifiers=args_[1], degrees=degb, edge_features=args_[2])
+        dt = timeit(run, reps=10, warm=3)
+        layers.KERNEL_TIMER = {}
+        run(); torch.cuda.synchronize()
+        kt = {k: round(sum(a.elapsed_time(b_) for a, b_, _ in v), 3) for k, v in layers.KERNEL_TIMER.items()}
+        layers.KERNEL_TIMER = None
+        res["next_rows"].append({"case": "GSN_edge_sparse L0 general d=128 eval fwd, 65536 graphs, " + name, "ms": round(dt * 1e3, 3),
+                                 "graphs_per_s": round(65536 / dt, 1), "kernels": kt})
     print(json.dumps(res))
 
 
