@@ -313,7 +313,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
         float *other = (NST == 1 && cur) ? buf0 : buf1;       // NST==1: next tile's input; NST==2: stage-1 input
         const int slot_n = slot == 2 ? 0 : slot + 1, slot_nn = slot_n == 2 ? 0 : slot_n + 1;
         const int *rs_next_tab = rsrc + slot_n * RS_STRIDE;
-        const bool do_pf = has_next && !(a.dbg & 1);
         rs_fetch(rst, (tile + 2 * (int64_t)gridDim.x) * CBM, rsn);         // row sources two tiles ahead
 
         float *in = in0;
@@ -335,7 +334,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
                             // the next tile's global loads (address arithmetic + issue) ride in the shadow of this chunk's
                             // MFMAs instead of standing in front of the whole MFMA phase (one wave per SIMD: nothing else
                             // would fill the matrix pipe meanwhile)
-                            if (ch < PF0_J && do_pf) prefetch_j(rs_next_tab, ch);
+                            // Unconditional (row sources past the end read row 0): without a branch the chunk is one
+                            // basic block and the scheduler interleaves the address arithmetic with the MFMAs.
+                            if (ch < PF0_J) prefetch_j(rs_next_tab, ch);
 #pragma unroll
                             for (int q = 0; q < 8; ++q) {
 #pragma unroll

@@ -9,7 +9,8 @@
 // Work is a pool of tasks (output column, output row); lanes pull tasks with a wave-aggregated LDS atomic
 // (ballot + mbcnt prefix) so that lanes whose search finished early are refilled immediately -- rooted searches have
 // wildly different lengths.  Every (row, column) cell is produced by exactly one lane: no atomics on the counts, no
-// global atomics, deterministic.  HBM traffic = read edge_index once (16 B/column) + write the int64 rows once.
+// global atomics, deterministic.  Edge mode with undirected orbit classes: rows (u,v) and (v,u) are equal, the u < v row
+// searches and writes both.  HBM traffic = read edge_index once (16 B/column) + write the int64 rows once.
 #include <hip/hip_runtime.h>
 
 #include "count_core.h"
@@ -25,6 +26,7 @@ struct CountArgs {
     const int32_t *graph_ids;  // or null
     int n_cap, e_cap;          // LDS capacities (rows of A, columns)
     int stage_out;             // 1: output rows staged in LDS then written coalesced
+    int sym;                   // edge mode with undirected orbit classes: rows (u,v) and (v,u) are equal -> search once
     int split;                 // workgroups per graph (each takes a contiguous slice of the (column,row) task space)
     int64_t *out;
     int32_t *status;
@@ -141,6 +143,7 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
     int t_row = 0, t_col = 0, p_i = 0, p_e = 0;
     uint64_t roots = 0;
     bool rev_missing = false;
+    int mirror_row = -1;
 
     for (;;) {
         const bool need = !has_task && !exhausted;
@@ -160,6 +163,7 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
                     s.cnt = 0; s.l = -1;
                     p_i = (int)col_ptr[t_col]; p_e = (int)col_ptr[t_col + 1];
                     rev_missing = false;
+                    mirror_row = -1;
                     if (edge_mode) {
                         const int u = eu[t_row], v = ev[t_row];
                         bool live = u != v;
@@ -171,7 +175,14 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
                             int rr = rowstart[v];
 #pragma unroll
                             for (int w = 0; w < W; ++w) rr += popc64(A[v * W + w] & below_word(u, w));
-                            rev_missing = last[rr] < 0;
+                            const int rev = last[rr];
+                            rev_missing = rev < 0;
+                            // Undirected orbit classes: every map that puts a pattern edge (a,b) on (u,v) puts (b,a), same
+                            // class, on (v,u), so the two rows are equal.  The u < v row searches and writes both cells.
+                            if (live && a.sym && rev >= 0) {
+                                if (u > v) has_task = false;
+                                else mirror_row = rev;
+                            }
                         }
                         if (!live) p_i = p_e;
                         roots = (uint64_t)u | ((uint64_t)v << 8);
@@ -194,6 +205,10 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
                     // cell finished
                     if (a.stage_out) out_lds[t_row * n_cols + t_col] = s.cnt;
                     else a.out[(row0 + t_row) * n_cols + t_col] = (int64_t)s.cnt;
+                    if (mirror_row >= 0) {
+                        if (a.stage_out) out_lds[mirror_row * n_cols + t_col] = s.cnt;
+                        else a.out[(row0 + mirror_row) * n_cols + t_col] = (int64_t)s.cnt;
+                    }
                     if (edge_mode && rev_missing && s.cnt != 0) atomicMax(&misc[2], (int)GSN_ST_KEYERROR);
                     has_task = false;
                 }
@@ -252,6 +267,7 @@ extern "C" int gsn_count_hip(const uint32_t *plan_host, const uint32_t *plan_dev
     a.plan = plan_dev; a.plan_words = (int)plan_words;
     a.mode = (int)plan_host[1]; a.n_plans = (int)plan_host[3]; a.n_cols = (int)plan_host[4]; a.kmax = (int)plan_host[5];
     a.plans_off = (int)plan_host[7];
+    a.sym = (a.mode == GSN_MODE_EDGE && plan_host[6] == 0) ? 1 : 0;
     a.node_ptr = node_ptr; a.edge_ptr = edge_ptr;
     a.src = edge_index; a.dst = edge_index ? edge_index + edge_row_stride : nullptr;
     a.ids_are_global = ids_are_global; a.graph_ids = graph_ids;
