@@ -552,23 +552,31 @@ class mlp(nn.Module):
         self.bn = nn.ModuleList(bn)
         self.activation = choose_activation(activation)
 
-    def stages(self, blocks, upto=None, first_weight=None, first_bias=None):
-        """The mlp as a list of _Stage; ``blocks`` feed the first Linear (optionally with a replaced first weight)."""
+    def stages(self, blocks, upto=None, first_weight=None, first_bias=None, post=None):
+        """The mlp as a list of _Stage; ``blocks`` feed the first Linear (optionally with a replaced first weight).
+        ``post = (BatchNorm1d or None, activation name)`` is applied to the output of the last Linear (the model's
+        between-layer BatchNorm + activation, models_graph_classification.py:226-228, fused into the stage epilogue)."""
         n = len(self.fc) if upto is None else upto
         out = []
         for i in range(n):
             last = i == len(self.fc) - 1
             w = self.fc[i].weight if (i > 0 or first_weight is None) else first_weight
             b = self.fc[i].bias if (i > 0 or first_bias is None) else first_bias
-            out.append(_Stage(w, b, (self.bn[i] if (self.batch_norm and not last) else None),
-                              "identity" if last else self.activation_name, blocks if i == 0 else ()))
+            bn = self.bn[i] if (self.batch_norm and not last) else None
+            act = "identity" if last else self.activation_name
+            if last and post is not None:
+                bn, act = post
+            out.append(_Stage(w, b, bn, act, blocks if i == 0 else ()))
         return out
 
-    def hip_forward(self, blocks, m_rows, upto=None, first_weight=None, first_bias=None, csr=None):
-        return run_stages(self.stages(blocks, upto, first_weight, first_bias), m_rows, self.training, csr=csr)
+    def hip_forward(self, blocks, m_rows, upto=None, first_weight=None, first_bias=None, csr=None, post=None):
+        stages = self.stages(blocks, upto, first_weight, first_bias, post)
+        if post is not None and post[0] is not None and post[0].training != self.training:
+            raise RuntimeError("mlp and the fused BatchNorm1d must be in the same train/eval mode")
+        return run_stages(stages, m_rows, self.training, csr=csr)
 
     # -- differentiable PyTorch twin (used to back-propagate through the dense stages)
-    def torch_forward(self, x, upto=None):
+    def torch_forward(self, x, upto=None, post=None):
         n = len(self.fc) if upto is None else upto
         for i in range(n):
             x = self.fc[i](x)
@@ -578,11 +586,19 @@ class mlp(nn.Module):
                     x = F.batch_norm(x, None if self.training else b.running_mean, None if self.training else b.running_var,
                                      b.weight, b.bias, self.training, 0.0, b.eps)
                 x = self.activation(x)
+            elif post is not None:
+                b, act = post
+                if b is not None:
+                    x = F.batch_norm(x, None if b.training else b.running_mean, None if b.training else b.running_var,
+                                     b.weight, b.bias, b.training, 0.0, b.eps)
+                x = choose_activation(act)(x)
         return x
 
-    def forward(self, x):
+    def forward(self, x, post=None):
         _need_cuda(x, "mlp input")
-        return _run(self, lambda: self.hip_forward([(x, None)], x.shape[0]), lambda x_: self.torch_forward(x_), [x])
+        extra = list(post[0].parameters()) if (post is not None and post[0] is not None) else []
+        return _run(self, lambda: self.hip_forward([(x, None)], x.shape[0], post=post),
+                    lambda x_: self.torch_forward(x_, post=post), [x], extra_params=extra)
 
 
 class _HipWithTorchBackward(torch.autograd.Function):
@@ -614,8 +630,8 @@ class _HipWithTorchBackward(torch.autograd.Function):
         return tuple(out)
 
 
-def _run(module, hip_fn, torch_fn, inputs):
-    params = [p for p in module.parameters()]
+def _run(module, hip_fn, torch_fn, inputs, extra_params=()):
+    params = [p for p in module.parameters()] + list(extra_params)
     need_grad = torch.is_grad_enabled() and (any(t.requires_grad for t in inputs) or any(p.requires_grad for p in params))
     if not need_grad:
         with torch.no_grad():
@@ -759,6 +775,9 @@ class _SparseLayer(nn.Module):
             raise NotImplementedError("Aggregation kind {} is not currently supported.".format(self.aggr))
         if self.msg_kind not in ("gin", "general", "ogb"):
             raise NotImplementedError("Message kind {} is not currently supported.".format(self.msg_kind))
+        post = None
+        if kwargs.get("post_bn") is not None or kwargs.get("post_act") is not None:
+            post = (kwargs.get("post_bn"), kwargs.get("post_act") or "identity")
         x, ids, ef = self._prepare(x, kwargs)
         _need_cuda(x, "x")
         _need_cuda(edge_index, "edge_index")
@@ -769,7 +788,9 @@ class _SparseLayer(nn.Module):
             ts = list(ts)
             return tuple(None if t is None else (t.dense() if isinstance(t, Codes) else ts.pop(0)) for t in given)
 
-        return _run(self, lambda: self._hip(edge_index, x, ids, ef), lambda *ts: self._twin(edge_index, *unpack(ts)), inputs)
+        extra = list(post[0].parameters()) if (post is not None and post[0] is not None) else []
+        return _run(self, lambda: self._hip(edge_index, x, ids, ef, post), lambda *ts: self._twin(edge_index, *unpack(ts), post=post), inputs,
+                    extra_params=extra)
 
     # -- message blocks ------------------------------------------------------------------------------------------
     def _sel(self):
@@ -792,7 +813,7 @@ class _SparseLayer(nn.Module):
         return self_parts, ids_nb, ef_nb, ids_per_node
 
     # -- HIP forward ---------------------------------------------------------------------------------------------
-    def _hip(self, edge_index, x, ids, ef):
+    def _hip(self, edge_index, x, ids, ef, post=None):
         n = x.shape[0]
         sel = self._sel()
         E = edge_index.shape[1]
@@ -807,12 +828,12 @@ class _SparseLayer(nn.Module):
             agg = propagate(1, edge_index, sel, n, a=x, b=ids if self.has_ids else None, c=ef, b_per_node=per_node)
             self_msg = x + ids if per_node else x
             xin = (1 + self.eps) * self_msg + agg
-            return self.update_fn.hip_forward([(xin, None)], n)
+            return self.update_fn.hip_forward([(xin, None)], n, post=post)
         if self.msg_kind == "gin":
             self_parts, ids_nb, ef_nb, per_node = self._gin_parts(x, ids, ef, n)
             agg = propagate(0, edge_index, sel, n, a=x, b=ids_nb, c=ef_nb, b_per_node=per_node)
             xin = (1 + self.eps) * torch.cat(self_parts, -1) + agg
-            return self.update_fn.hip_forward([(xin, None)], n)
+            return self.update_fn.hip_forward([(xin, None)], n, post=post)
         # general
         idx_i, idx_j = edge_index[sel].contiguous(), edge_index[1 - sel].contiguous()
         blocks = [(x, idx_i), (x, idx_j)]
@@ -857,10 +878,10 @@ class _SparseLayer(nn.Module):
                 r = mf.hip_forward(blocks, E, upto=len(mf.fc) - 1)
                 s_agg = propagate(0, edge_index, sel, n, b=r)
             w_first = self._folded_first_weight(x.shape[1])
-            return uf.hip_forward([(x, None), (s_agg, None), (csr.deg, None)], n, first_weight=w_first)
+            return uf.hip_forward([(x, None), (s_agg, None), (csr.deg, None)], n, first_weight=w_first, post=post)
         msgs = mf.hip_forward(blocks, E)
         agg = propagate(0, edge_index, sel, n, b=msgs)
-        return uf.hip_forward([(x, None), (agg, None)], n)
+        return uf.hip_forward([(x, None), (agg, None)], n, post=post)
 
     def _folded_first_weight(self, d_x):
         """[W3x | W3a W2 | W3a b2] (see _hip); recomputed only when one of the three parameters changed."""
@@ -880,18 +901,18 @@ class _SparseLayer(nn.Module):
         return w_first
 
     # -- differentiable twin (PyTorch ops + the HIP propagate with its own adjoint) ---------------------------------
-    def _twin(self, edge_index, x, ids, ef):
+    def _twin(self, edge_index, x, ids, ef, post=None):
         n = x.shape[0]
         sel = self._sel()
         if self.ogb:
             per_node = self.has_ids and self.id_scope == "global"
             agg = propagate(1, edge_index, sel, n, a=x, b=ids if self.has_ids else None, c=ef, b_per_node=per_node)
             self_msg = x + ids if per_node else x
-            return self.update_fn.torch_forward((1 + self.eps) * self_msg + agg)
+            return self.update_fn.torch_forward((1 + self.eps) * self_msg + agg, post=post)
         if self.msg_kind == "gin":
             self_parts, ids_nb, ef_nb, per_node = self._gin_parts(x, ids, ef, n)
             agg = propagate(0, edge_index, sel, n, a=x, b=ids_nb, c=ef_nb, b_per_node=per_node)
-            return self.update_fn.torch_forward((1 + self.eps) * torch.cat(self_parts, -1) + agg)
+            return self.update_fn.torch_forward((1 + self.eps) * torch.cat(self_parts, -1) + agg, post=post)
         idx_i, idx_j = edge_index[sel], edge_index[1 - sel]
         parts = [x[idx_i], x[idx_j]]
         if self.has_ids:
@@ -900,7 +921,7 @@ class _SparseLayer(nn.Module):
             parts.append(ef)
         msgs = self.msg_fn.torch_forward(torch.cat(parts, -1))
         agg = propagate(0, edge_index, sel, n, b=msgs)
-        return self.update_fn.torch_forward(torch.cat((x, agg), -1))
+        return self.update_fn.torch_forward(torch.cat((x, agg), -1), post=post)
 
     def __repr__(self):
         if self.ogb:

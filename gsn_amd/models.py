@@ -1,0 +1,136 @@
+"""GNNSubstructures (models_graph_classification.py:14-246) assembled from this package's modules -- SURVEY.md 8(f) row 3.
+
+Same constructor arguments, same parameter / buffer names (``input_node_encoder``, ``edge_encoder.{i}``, ``id_encoder.{i}``,
+``degree_encoder``, ``conv.{i}.*``, ``lin_proj.{i}.*``, ``batch_norms.{i}.*``) so reference checkpoints load, same forward.
+What differs is where the work happens: the between-layer ``BatchNorm1d`` + activation (:226-228) is folded into the epilogue
+of the layer's last dense stage (no extra pass over [N, d]), the readout is the segmented-sum kernel, encoders and jk
+projections run on the HIP stages.  The reference's own model class also runs unchanged on the drop-in modules
+(INTEGRATION.md); this one is the version without PyTorch compute between the kernels.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import layers
+from .encoding import DiscreteEmbedding
+from .layers import (GSN_edge_sparse, GSN_sparse, MPNN_edge_sparse, MPNN_sparse, choose_activation,
+                     global_add_pool_sparse, global_mean_pool_sparse, mlp, run_linear_module)
+
+
+class GNNSubstructures(nn.Module):
+    def __init__(self, in_features, out_features, encoder_ids, d_in_id, in_edge_features=None, d_in_node_encoder=None,
+                 d_in_edge_encoder=None, encoder_degrees=None, d_degree=None, **kwargs):
+        super().__init__()
+        seed = kwargs["seed"]
+        self.model_name = kwargs["model_name"]
+        self.readout = kwargs["readout"] if kwargs["readout"] is not None else "sum"
+        self.dropout_features = kwargs["dropout_features"]
+        self.bn = kwargs["bn"]
+        self.final_projection = kwargs["final_projection"]
+        self.inject_ids = kwargs["inject_ids"]
+        self.inject_edge_features = kwargs["inject_edge_features"]
+        self.random_features = kwargs["random_features"]
+        id_scope = kwargs["id_scope"]
+        d_msg, d_out, d_h = kwargs["d_msg"], kwargs["d_out"], kwargs["d_h"]
+        aggr = kwargs["aggr"] if kwargs["aggr"] is not None else "add"
+        flow = kwargs["flow"] if kwargs["flow"] is not None else "target_to_source"
+        msg_kind = kwargs["msg_kind"] if kwargs["msg_kind"] is not None else "general"
+        train_eps = kwargs["train_eps"] if kwargs["train_eps"] is not None else [False for _ in range(len(d_out))]
+        activation_mlp, bn_mlp, jk_mlp = kwargs["activation_mlp"], kwargs["bn_mlp"], kwargs["jk_mlp"]
+        degree_embedding = kwargs["degree_embedding"] if kwargs["degree_as_tag"][0] else "None"
+        degree_as_tag, retain_features = kwargs["degree_as_tag"], kwargs["retain_features"]
+        enc_kw = {"seed": seed, "activation_mlp": activation_mlp, "bn_mlp": bn_mlp, "aggr": kwargs["multi_embedding_aggr"]}
+
+        self.input_node_encoder = DiscreteEmbedding(kwargs["input_node_encoder"], in_features, d_in_node_encoder,
+                                                    kwargs["d_out_node_encoder"], **enc_kw)
+        d_in = self.input_node_encoder.d_out
+        if self.random_features:
+            self.r_d_out = d_out[0]
+            d_in = d_in + self.r_d_out
+        edge_enc, d_ef = [], []
+        for i in range(len(d_out) if kwargs["inject_edge_features"] else 1):
+            e = DiscreteEmbedding(kwargs["edge_encoder"], in_edge_features, d_in_edge_encoder,
+                                  kwargs["d_out_edge_encoder"][i], **enc_kw)
+            edge_enc.append(e)
+            d_ef.append(e.d_out)
+        self.edge_encoder = nn.ModuleList(edge_enc)
+        id_enc, d_id = [], []
+        for i in range(len(d_out) if kwargs["inject_ids"] else 1):
+            e = DiscreteEmbedding(kwargs["id_embedding"], len(d_in_id), d_in_id, kwargs["d_out_id_embedding"], **enc_kw)
+            id_enc.append(e)
+            d_id.append(e.d_out)
+        self.id_encoder = nn.ModuleList(id_enc)
+        self.degree_encoder = DiscreteEmbedding(degree_embedding, 1, d_degree, kwargs["d_out_degree_embedding"], **enc_kw)
+        d_degree = self.degree_encoder.d_out
+
+        conv, bns, proj = [], [], []
+        for i in range(len(d_out)):
+            kw = {"d_in": d_in, "d_degree": d_degree, "degree_as_tag": degree_as_tag[i], "retain_features": retain_features[i],
+                  "d_msg": d_msg[i], "d_up": d_out[i], "d_h": d_h[i],
+                  "d_ef": d_ef[i] if self.inject_edge_features else d_ef[0], "seed": seed, "activation_name": activation_mlp,
+                  "bn": bn_mlp, "aggr": aggr, "msg_kind": msg_kind, "eps": 0, "train_eps": train_eps[i], "flow": flow,
+                  "edge_embedding": kwargs["edge_encoder"], "id_embedding": kwargs["id_embedding"],
+                  "extend_dims": kwargs["extend_dims"]}
+            use_ids = ((i > 0 and kwargs["inject_ids"]) or i == 0) and self.model_name in {"GSN_sparse", "GSN_edge_sparse"}
+            use_efs = ((i > 0 and kwargs["inject_edge_features"]) or i == 0) and self.model_name in {"GSN_edge_sparse", "MPNN_edge_sparse"}
+            if use_ids:
+                fn = GSN_edge_sparse if use_efs else GSN_sparse
+                kw["d_id"] = d_id[i] if self.inject_ids else d_id[0]
+                kw["id_scope"] = id_scope
+            else:
+                fn = MPNN_edge_sparse if use_efs else MPNN_sparse
+            conv.append(fn(**kw))
+            if self.final_projection[i]:
+                jk = mlp(d_in, out_features, d_h[i], seed, activation_mlp, bn_mlp) if jk_mlp else nn.Linear(d_in, out_features)
+            else:
+                jk = None
+            proj.append(jk)
+            bns.append(nn.BatchNorm1d(d_out[i]) if self.bn[i] else None)
+            d_in = d_out[i]
+        if self.final_projection[-1]:
+            jk = mlp(d_in, out_features, d_h[-1], seed, activation_mlp, bn_mlp) if jk_mlp else nn.Linear(d_in, out_features)
+        else:
+            jk = None
+        proj.append(jk)
+        self.conv = nn.ModuleList(conv)
+        self.lin_proj = nn.ModuleList(proj)
+        self.batch_norms = nn.ModuleList(bns)
+        if self.readout == "sum":
+            self.global_pool = global_add_pool_sparse
+        elif self.readout == "mean":
+            self.global_pool = global_mean_pool_sparse
+        else:
+            raise ValueError("Invalid graph pooling type.")
+        self.activation_name = kwargs["activation"]
+        self.activation = choose_activation(kwargs["activation"])
+
+    def forward(self, data, print_flag=False, return_intermediate=False):
+        kwargs = {"degrees": self.degree_encoder(data.degrees)}
+        edge_index = data.edge_index
+        x = self.input_node_encoder(data.x)
+        if self.random_features:
+            r = torch.rand(size=(x.shape[0], self.r_d_out), device=x.device).float()
+            x = torch.cat((x, r), 1)
+        x_interm = [x]
+        for i in range(len(self.conv)):
+            kwargs["identifiers"] = (self.id_encoder[i] if self.inject_ids else self.id_encoder[0])(data.identifiers)
+            if hasattr(data, "edge_features"):
+                kwargs["edge_features"] = (self.edge_encoder[i] if self.inject_edge_features else self.edge_encoder[0])(data.edge_features)
+            else:
+                kwargs["edge_features"] = None
+            # BatchNorm1d + activation of models_graph_classification.py:226-228 ride in the layer's last epilogue
+            x = self.conv[i](x, edge_index, post_bn=self.batch_norms[i] if self.bn[i] else None,
+                             post_act=self.activation_name, **kwargs)
+            x_interm.append(x)
+        prediction = 0
+        for i in range(len(self.conv) + 1):
+            if self.final_projection[i]:
+                x_global = self.global_pool(x_interm[i], data.batch)
+                jk = self.lin_proj[i]
+                y = jk(x_global) if isinstance(jk, mlp) else run_linear_module(jk, x_global)
+                prediction = prediction + F.dropout(y, p=self.dropout_features[i], training=self.training)
+        if return_intermediate:
+            return prediction, x_interm
+        return prediction

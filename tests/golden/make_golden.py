@@ -833,6 +833,136 @@ def gen_dataset(ref, out):
     print("dataset: %d arrays" % len(rec))
 
 
+# ----------------------------------------------------------------------------------------------
+# whole-model forward: GNNSubstructures (models_graph_classification.py) with the reference's own layers
+# ----------------------------------------------------------------------------------------------
+def _model_kwargs(model_name, n_layers, d, msg_kind, id_scope, bn, jk_mlp, readout, activation, inject_ids, node_enc,
+                  edge_enc, id_emb, d_emb):
+    return dict(seed=0, model_name=model_name, readout=readout, dropout_features=[0.0] * (n_layers + 1), bn=[bn] * n_layers,
+                final_projection=[True] * (n_layers + 1), inject_ids=inject_ids, inject_edge_features=True,
+                random_features=False, id_scope=id_scope, d_msg=[d] * n_layers, d_out=[d] * n_layers, d_h=[[d]] * n_layers,
+                aggr="add", flow="source_to_target", msg_kind=msg_kind, train_eps=[False] * n_layers, activation_mlp="relu",
+                bn_mlp=True, jk_mlp=jk_mlp, degree_embedding="None", degree_as_tag=[False] * n_layers,
+                retain_features=[True] * n_layers, multi_embedding_aggr="sum", input_node_encoder=node_enc,
+                d_out_node_encoder=d_emb, edge_encoder=edge_enc, d_out_edge_encoder=[d_emb] * n_layers, id_embedding=id_emb,
+                d_out_id_embedding=d_emb, d_out_degree_embedding=d_emb, extend_dims=True, activation=activation)
+
+
+def gen_model(ref, out):
+    import importlib
+    import io
+    import contextlib
+    mgc = importlib.import_module("models_graph_classification")
+    assert mgc.__file__.startswith(REF)
+    z = np.load(os.path.join(out, "dataset.npz"))
+    rec = {}
+    sink = io.StringIO()
+
+    def collate(key, n_graphs, id_key="identifiers"):
+        xs, eis, ids, efs, batch, degs = [], [], [], [], [], []
+        off = 0
+        for g in range(n_graphs):
+            x = torch.from_numpy(z["%s/%d/x" % (key, g)])
+            ei = torch.from_numpy(z["%s/%d/edge_index" % (key, g)])
+            xs.append(x); eis.append(ei + off); ids.append(torch.from_numpy(z["%s/%d/%s" % (key, g, id_key)]))
+            if "%s/%d/edge_features" % (key, g) in z.files:
+                efs.append(torch.from_numpy(z["%s/%d/edge_features" % (key, g)]))
+            batch.append(torch.full((x.shape[0],), g, dtype=torch.long))
+            degs.append(torch.zeros(x.shape[0]))
+            off += x.shape[0]
+        d = types.SimpleNamespace(x=torch.cat(xs), edge_index=torch.cat(eis, 1), identifiers=torch.cat(ids),
+                                  batch=torch.cat(batch), degrees=torch.cat(degs))
+        if efs:
+            d.edge_features = torch.cat(efs)
+        return d
+
+    def run(name, data, d_id, ctor_args, kw, train):
+        torch.manual_seed(0)
+        with contextlib.redirect_stdout(sink):
+            model = mgc.GNNSubstructures(*ctor_args, **kw)
+        # non-trivial BatchNorm statistics and affine parameters
+        g = torch.Generator().manual_seed(7)
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+                m.weight.data.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+                m.bias.data.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+        model.train(train)
+        sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+        pred, interm = model(data, return_intermediate=True)
+        for k, v in sd0.items():
+            rec["%s/sd/%s" % (name, k)] = v.numpy()
+        for k, v in model.state_dict().items():
+            rec["%s/sd_after/%s" % (name, k)] = v.numpy()
+        rec[name + "/pred"] = pred.detach().numpy()
+        for i, t in enumerate(interm):
+            rec["%s/interm/%d" % (name, i)] = t.detach().numpy()
+        if train:
+            gy = torch.from_numpy(np.random.default_rng(3).standard_normal(tuple(pred.shape)).astype(np.float32))
+            (pred * gy).sum().backward()
+            rec[name + "/gy"] = gy.numpy()
+            for k, p_ in model.named_parameters():
+                if p_.grad is not None:
+                    rec["%s/grad/%s" % (name, k)] = p_.grad.numpy()
+        for attr in ("x", "edge_index", "identifiers", "batch", "degrees", "edge_features"):
+            if hasattr(data, attr):
+                rec["%s/data/%s" % (name, attr)] = getattr(data, attr).numpy()
+        rec[name + "/d_id"] = np.asarray(d_id, dtype=np.int64)
+        rec[name + "/train"] = np.int64(train)
+
+    # (i) README config 1: SR(25,12,5,6), GSN_sparse general/local, one_hot_unique ids, 2 x 64, jk mlp, sum readout, eval
+    enc_key = "enc_one_hot_unique"
+    n = 15
+    data = collate("enc_src_one_hot_unique", n)
+    # edge-mode identifiers for the local scope come from the gd_sr25_edge run (induced cycles 3..5)
+    data = collate("gd_sr25_edge", n)
+    uenc = ref["utils_encoding"]
+    ids_list = [torch.from_numpy(z["gd_sr25_edge/%d/identifiers" % g]) for g in range(n)]
+    enc = uenc.one_hot_unique(ids_list)
+    data.identifiers = torch.cat(enc.fit(ids_list))
+    d_id = enc.d
+    kw = _model_kwargs("GSN_sparse", 2, 64, "general", "local", True, True, "sum", "relu", False, "None", "None",
+                       "one_hot_encoder", 16)
+    run("sr25_gsn_sparse_eval", data, d_id, (1, 10, None, d_id), kw, False)
+    rec["sr25_gsn_sparse_eval/ctor"] = np.array(["1", "10", "None"])
+    kw_t = dict(kw)
+    run("sr25_gsn_sparse_train", data, d_id, (1, 10, None, d_id), kw_t, True)
+
+    # (ii) config 2 shape: ZINC fixture, GSN_edge_sparse general/local, one-hot atoms / bonds / ids, 3 x 32, linear jk, mean
+    nz = int(z["gd_zinc_edge/n_graphs"])
+    keep = [g for g in range(nz) if g not in z["gd_zinc_edge/reference_nameerror_at"].tolist()]
+    xs, eis, ids, efs, batch, degs, off = [], [], [], [], [], [], 0
+    for j, g in enumerate(keep):
+        x = torch.from_numpy(z["gd_zinc_edge/%d/x" % g])
+        xs.append(x); eis.append(torch.from_numpy(z["gd_zinc_edge/%d/edge_index" % g]) + off)
+        ids.append(torch.from_numpy(z["gd_zinc_edge/%d/identifiers" % g]))
+        efs.append(torch.from_numpy(z["gd_zinc_edge/%d/edge_features" % g]))
+        batch.append(torch.full((x.shape[0],), j, dtype=torch.long)); degs.append(torch.zeros(x.shape[0]))
+        off += x.shape[0]
+    enc = uenc.one_hot_unique(ids)
+    data = types.SimpleNamespace(x=torch.cat(xs), edge_index=torch.cat(eis, 1), identifiers=torch.cat(enc.fit(ids)),
+                                 batch=torch.cat(batch), degrees=torch.cat(degs), edge_features=torch.cat(efs))
+    d_id = enc.d
+    for train in (False, True):
+        kw = _model_kwargs("GSN_edge_sparse", 3, 32, "general", "local", True, False, "mean", "relu", False,
+                           "one_hot_encoder", "one_hot_encoder", "one_hot_encoder", 16)
+        run("zinc_gsn_edge_%s" % ("train" if train else "eval"), data, d_id, (1, 1, None, d_id, 1, [28], [4]), kw, train)
+    # (iii) gin / global with embedding encoders and injected ids (vertex ids of the TU fixture)
+    nt = int(z["gd_tu_vertex/n_graphs"])
+    data = collate("gd_tu_vertex", nt)
+    ids_list = [torch.from_numpy(z["gd_tu_vertex/%d/identifiers" % g]) for g in range(nt)]
+    enc = uenc.one_hot_unique(ids_list)
+    data.identifiers = torch.cat(enc.fit(ids_list))
+    data.x = data.x.argmax(1, keepdim=True)         # node tags as integer codes for the embedding encoder
+    d_id = enc.d
+    kw = _model_kwargs("GSN_sparse", 2, 32, "gin", "global", True, True, "sum", "elu", True, "embedding", "None",
+                       "embedding", 8)
+    run("tu_gin_global_eval", data, d_id, (1, 2, None, d_id, None, [int(data.x.max()) + 1]), kw, False)
+    np.savez_compressed(os.path.join(out, "model.npz"), **rec)
+    print("model: %d arrays" % len(rec))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="orbits,counts,layers")
@@ -848,6 +978,8 @@ def main():
         gen_layers(ref, args.out)
     if "dataset" in only:
         gen_dataset(ref, args.out)
+    if "model" in only:
+        gen_model(ref, args.out)
 
 
 if __name__ == "__main__":
