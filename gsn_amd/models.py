@@ -1,4 +1,5 @@
-"""GNNSubstructures (models_graph_classification.py:14-246) assembled from this package's modules -- SURVEY.md 8(f) row 3.
+"""GNNSubstructures (models_graph_classification.py:14-246) and GNN_OGB (models_graph_classification_ogb_original.py:17-268,
+the virtual-node model of BASELINE config 4) assembled from this package's modules -- SURVEY.md 8(f) row 3.
 
 Same constructor arguments, same parameter / buffer names (``input_node_encoder``, ``edge_encoder.{i}``, ``id_encoder.{i}``,
 ``degree_encoder``, ``conv.{i}.*``, ``lin_proj.{i}.*``, ``batch_norms.{i}.*``) so reference checkpoints load, same forward.
@@ -15,8 +16,8 @@ import torch.nn.functional as F
 
 from . import layers
 from .encoding import DiscreteEmbedding
-from .layers import (GSN_edge_sparse, GSN_sparse, MPNN_edge_sparse, MPNN_sparse, choose_activation,
-                     global_add_pool_sparse, global_mean_pool_sparse, mlp, run_linear_module)
+from .layers import (GSN_edge_sparse, GSN_edge_sparse_ogb, GSN_sparse, MPNN_edge_sparse, MPNN_edge_sparse_ogb, MPNN_sparse,
+                     choose_activation, global_add_pool_sparse, global_mean_pool_sparse, mlp, run_linear_module)
 
 
 class GNNSubstructures(nn.Module):
@@ -134,3 +135,137 @@ class GNNSubstructures(nn.Module):
         if return_intermediate:
             return prediction, x_interm
         return prediction
+
+
+class GNN_OGB(nn.Module):
+    """models_graph_classification_ogb_original.py:17-268: ogb-style layers, optional virtual node (one embedding per graph,
+    added to every vertex before each layer and updated from the pooled layer input, :252-259), residuals, sum of the
+    selected intermediate representations -> readout -> Linear."""
+
+    def __init__(self, in_features, out_features, encoder_ids, d_in_id, in_edge_features=None, d_in_node_encoder=None,
+                 d_in_edge_encoder=None, encoder_degrees=None, d_degree=None, **kwargs):
+        super().__init__()
+        import copy
+        seed = kwargs["seed"]
+        self.model_name = kwargs["model_name"]
+        self.readout = kwargs["readout"] if kwargs["readout"] is not None else "sum"
+        self.dropout_features = kwargs["dropout_features"]
+        self.bn = kwargs["bn"]
+        self.final_projection = kwargs["final_projection"]
+        self.residual = kwargs["residual"]
+        self.inject_ids = kwargs["inject_ids"]
+        self.vn = kwargs["vn"]
+        id_scope = kwargs["id_scope"]
+        d_msg, d_out, d_h = kwargs["d_msg"], kwargs["d_out"], kwargs["d_h"]
+        aggr = kwargs["aggr"] if kwargs["aggr"] is not None else "add"
+        flow = kwargs["flow"] if kwargs["flow"] is not None else "target_to_source"
+        msg_kind = kwargs["msg_kind"] if kwargs["msg_kind"] is not None else "general"
+        train_eps = kwargs["train_eps"] if kwargs["train_eps"] is not None else [False for _ in range(len(d_out))]
+        activation_mlp, bn_mlp = kwargs["activation_mlp"], kwargs["bn_mlp"]
+        degree_embedding = kwargs["degree_embedding"] if kwargs["degree_as_tag"][0] else "None"
+        degree_as_tag, retain_features = kwargs["degree_as_tag"], kwargs["retain_features"]
+        enc_kw = {"seed": seed, "activation_mlp": activation_mlp, "bn_mlp": bn_mlp, "aggr": kwargs["multi_embedding_aggr"],
+                  "features_scope": kwargs["features_scope"]}
+        self.input_node_encoder = DiscreteEmbedding(kwargs["input_node_encoder"], in_features, d_in_node_encoder,
+                                                    kwargs["d_out_node_encoder"], **enc_kw)
+        d_in = self.input_node_encoder.d_out
+        if self.vn:
+            vn_kw = copy.deepcopy(enc_kw)
+            vn_kw["init"] = "zeros"
+            self.vn_encoder = DiscreteEmbedding(kwargs["input_vn_encoder"], 1, [1], kwargs["d_out_vn_encoder"], **vn_kw)
+            d_in_vn = self.vn_encoder.d_out
+        edge_enc, d_ef = [], []
+        for i in range(len(d_out)):
+            e = DiscreteEmbedding(kwargs["edge_encoder"], in_edge_features, d_in_edge_encoder, kwargs["d_out_edge_encoder"][i], **enc_kw)
+            edge_enc.append(e)
+            d_ef.append(e.d_out)
+        self.edge_encoder = nn.ModuleList(edge_enc)
+        id_enc, d_id = [], []
+        for i in range(len(d_out) if kwargs["inject_ids"] else 1):
+            e = DiscreteEmbedding(kwargs["id_embedding"], len(d_in_id), d_in_id, kwargs["d_out_id_embedding"], **enc_kw)
+            id_enc.append(e)
+            d_id.append(e.d_out)
+        self.id_encoder = nn.ModuleList(id_enc)
+        self.degree_encoder = DiscreteEmbedding(degree_embedding, 1, d_degree, kwargs["d_out_degree_embedding"], **enc_kw)
+        d_degree = self.degree_encoder.d_out
+        conv, bns, mlp_vn = [], [], []
+        for i in range(len(d_out)):
+            if i > 0 and self.vn:
+                mlp_vn.append(mlp(d_in_vn, kwargs["d_out_vn"][i - 1], d_h[i], seed, activation_mlp, bn_mlp))
+                d_in_vn = kwargs["d_out_vn"][i - 1]
+            kw = {"d_in": d_in, "d_degree": d_degree, "degree_as_tag": degree_as_tag[i], "retain_features": retain_features[i],
+                  "d_msg": d_msg[i], "d_up": d_out[i], "d_h": d_h[i], "seed": seed, "activation_name": activation_mlp,
+                  "bn": bn_mlp, "aggr": aggr, "msg_kind": msg_kind, "eps": 0, "train_eps": train_eps[i], "flow": flow,
+                  "d_ef": d_ef[i], "edge_embedding": kwargs["edge_encoder"], "id_embedding": kwargs["id_embedding"],
+                  "extend_dims": kwargs["extend_dims"]}
+            use_ids = ((i > 0 and kwargs["inject_ids"]) or i == 0) and self.model_name == "GSN_edge_sparse_ogb"
+            if use_ids:
+                fn = GSN_edge_sparse_ogb
+                kw["d_id"] = d_id[i] if self.inject_ids else d_id[0]
+                kw["id_scope"] = id_scope
+            else:
+                fn = MPNN_edge_sparse_ogb
+            conv.append(fn(**kw))
+            bns.append(nn.BatchNorm1d(d_out[i]) if self.bn[i] else None)
+            d_in = d_out[i]
+        self.conv = nn.ModuleList(conv)
+        self.batch_norms = nn.ModuleList(bns)
+        if kwargs["vn"]:
+            self.mlp_vn = nn.ModuleList(mlp_vn)
+        if self.readout == "sum":
+            self.global_pool = global_add_pool_sparse
+        elif self.readout == "mean":
+            self.global_pool = global_mean_pool_sparse
+        else:
+            raise ValueError("Invalid graph pooling type.")
+        if self.vn:
+            if kwargs["vn_pooling"] == "sum":
+                self.global_vn_pool = global_add_pool_sparse
+            elif kwargs["vn_pooling"] == "mean":
+                self.global_vn_pool = global_mean_pool_sparse
+            else:
+                raise ValueError("Invalid graph virtual node pooling type.")
+        self.lin_proj = nn.Linear(d_out[-1], out_features)
+        self.activation_name = kwargs["activation"]
+        self.activation = choose_activation(kwargs["activation"])
+
+    def forward(self, data, return_intermediate=False):
+        kwargs = {"degrees": self.degree_encoder(data.degrees)}
+        edge_index = data.edge_index
+        if self.vn:
+            n_graphs = int(data.batch[-1].item()) + 1
+            vn_embedding = self.vn_encoder(torch.zeros(n_graphs, dtype=edge_index.dtype, device=edge_index.device))
+        x = self.input_node_encoder(data.x)
+        x_interm = [x]
+        n_layers = len(self.conv)
+        for i in range(n_layers):
+            kwargs["identifiers"] = (self.id_encoder[i] if self.inject_ids else self.id_encoder[0])(data.identifiers)
+            kwargs["edge_features"] = self.edge_encoder[i](data.edge_features) if hasattr(data, "edge_features") else None
+            if self.vn:
+                x_interm[i] = x_interm[i] + vn_embedding[data.batch]
+            last = i == n_layers - 1
+            # BatchNorm1d (+ activation on all but the last layer) fused into the layer's last stage (:241-246)
+            x = self.conv[i](x_interm[i], edge_index, post_bn=self.batch_norms[i] if self.bn[i] else None,
+                             post_act="identity" if last else self.activation_name, **kwargs)
+            x = F.dropout(x, self.dropout_features[i], training=self.training)
+            if self.residual:
+                x = x + x_interm[-1]
+            x_interm.append(x)
+            if not last and self.vn:
+                vn_temp = self.global_vn_pool(x_interm[i], data.batch) + vn_embedding
+                # the activation after mlp_vn rides in its last stage unless the residual form needs the raw output
+                if self.residual:
+                    vn_embedding = self.mlp_vn[i](vn_temp)
+                    vn_embedding = vn_embedding + F.dropout(self.activation(vn_embedding), self.dropout_features[i], training=self.training)
+                else:
+                    vn_embedding = F.dropout(self.mlp_vn[i](vn_temp, post=(None, self.activation_name)),
+                                             self.dropout_features[i], training=self.training)
+        prediction = 0
+        for i in range(n_layers + 1):
+            if self.final_projection[i]:
+                prediction = prediction + x_interm[i]
+        x_global = self.global_pool(prediction, data.batch)
+        out = run_linear_module(self.lin_proj, x_global)
+        if return_intermediate:
+            return out, x_interm
+        return out

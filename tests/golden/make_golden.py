@@ -959,6 +959,58 @@ def gen_model(ref, out):
     kw = _model_kwargs("GSN_sparse", 2, 32, "gin", "global", True, True, "sum", "elu", True, "embedding", "None",
                        "embedding", 8)
     run("tu_gin_global_eval", data, d_id, (1, 2, None, d_id, None, [int(data.x.max()) + 1]), kw, False)
+    # (iv) GNN_OGB (models_graph_classification_ogb_original.py): ogb layers, virtual node, residuals -- config 4 shape
+    mogb = importlib.import_module("models_graph_classification_ogb_original")
+    assert mogb.__file__.startswith(REF)
+    rng = np.random.default_rng(21)
+    b = synth.zinc_shape_batch(10, seed=4)
+    Nn, Ee = b.num_nodes, b.num_edges
+    atom_dims, bond_dims, id_dims = [7, 3, 4], [4, 2], [3, 5]
+    dd = types.SimpleNamespace(
+        x=torch.from_numpy(rng.integers(0, atom_dims, size=(Nn, 3))), edge_index=torch.from_numpy(b.edge_index),
+        edge_features=torch.from_numpy(rng.integers(0, bond_dims, size=(Ee, 2))),
+        identifiers=torch.from_numpy(rng.integers(0, id_dims, size=(Ee, 2))),
+        batch=torch.from_numpy(np.asarray(b.batch).astype(np.int64)), degrees=torch.zeros(Nn))
+    for tag, vn, residual, train in (("ogb_vn_res_eval", True, True, False), ("ogb_vn_train", True, False, True), ("ogb_plain_eval", False, False, False)):
+        L, dm = 3, 24
+        kw = dict(seed=0, model_name="GSN_edge_sparse_ogb", readout="mean", dropout_features=[0.0] * (L + 1), bn=[True] * L,
+                  final_projection=[False] * L + [True], residual=residual, inject_ids=True, vn=vn, id_scope="local",
+                  d_msg=[dm] * L, d_out=[dm] * L, d_h=[[2 * dm]] * L, aggr="add", flow="source_to_target", msg_kind="ogb",
+                  train_eps=[True] * L, activation_mlp="relu", bn_mlp=True, jk_mlp=False, degree_embedding="None",
+                  degree_as_tag=[False] * L, retain_features=[True] * L, multi_embedding_aggr="sum", features_scope="full",
+                  input_node_encoder="embedding", d_out_node_encoder=dm, input_vn_encoder="embedding", d_out_vn_encoder=dm,
+                  edge_encoder="embedding", d_out_edge_encoder=[dm] * L, id_embedding="embedding", d_out_id_embedding=dm,
+                  d_out_degree_embedding=dm, d_out_vn=[dm] * (L - 1), vn_pooling="sum", extend_dims=True, activation="relu")
+        torch.manual_seed(0)
+        with contextlib.redirect_stdout(sink):
+            model = mogb.GNN_OGB(3, 2, None, id_dims, 2, atom_dims, bond_dims, None, None, **kw)
+        g = torch.Generator().manual_seed(11)
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+                m.weight.data.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+                m.bias.data.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+        if vn:      # the reference initialises the virtual node to zero; make it visible
+            model.vn_encoder.encoder.encoder[0].weight.data.copy_(torch.randn(1, dm, generator=g) * 0.3)
+        model.train(train)
+        for k, v in model.state_dict().items():
+            rec["%s/sd/%s" % (tag, k)] = v.clone().numpy()
+        pred = model(dd)
+        for k, v in model.state_dict().items():
+            rec["%s/sd_after/%s" % (tag, k)] = v.numpy()
+        rec[tag + "/pred"] = pred.detach().numpy()
+        rec[tag + "/train"] = np.int64(train)
+        rec[tag + "/flags"] = np.asarray([int(vn), int(residual)], dtype=np.int64)
+        if train:
+            gy = torch.from_numpy(rng.standard_normal(tuple(pred.shape)).astype(np.float32))
+            (pred * gy).sum().backward()
+            rec[tag + "/gy"] = gy.numpy()
+            for k, p_ in model.named_parameters():
+                if p_.grad is not None:
+                    rec["%s/grad/%s" % (tag, k)] = p_.grad.numpy()
+    for attr in ("x", "edge_index", "identifiers", "batch", "degrees", "edge_features"):
+        rec["ogb/data/%s" % attr] = getattr(dd, attr).numpy()
     np.savez_compressed(os.path.join(out, "model.npz"), **rec)
     print("model: %d arrays" % len(rec))
 
