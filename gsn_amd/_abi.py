@@ -126,5 +126,26 @@ def ptr(t) -> int:
 
 
 def current_stream() -> int:
+    """Raw handle of PyTorch's current stream on the current device (the fast C getter: this runs before every launch)."""
     import torch
-    return torch.cuda.current_stream().cuda_stream
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+
+
+class _NullGuard:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NULL_GUARD = _NullGuard()
+
+
+def device_guard(device):
+    """``torch.cuda.device(device)`` only when ``device`` is not already current (the context manager costs ~10 us)."""
+    import torch
+    idx = device.index
+    if idx is None or idx == torch._C._cuda_getDevice():
+        return _NULL_GUARD
+    return torch.cuda.device(device)

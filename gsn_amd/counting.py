@@ -110,7 +110,7 @@ def count_batch(plan: CountPlan, node_ptr, edge_ptr, edge_index, ids_are_global=
         n_items = gid.numel()
     if n_graphs > 0 and n_items > 0:
         tab = plan.device_table(device)
-        with torch.cuda.device(device):
+        with _abi.device_guard(device):
             rc = _abi.lib().gsn_count_hip(_abi.ptr(plan.table), tab.data_ptr(), len(plan.table), n_graphs,
                                           node_ptr_d.data_ptr(), edge_ptr_d.data_ptr(), ei.data_ptr() if E_total else None,
                                           ei.stride(0), int(bool(ids_are_global)), None if gid is None else gid.data_ptr(),

@@ -137,6 +137,68 @@ __global__ void csr_sort_segments(const int32_t *__restrict__ seg_ptr, int64_t n
         for (int32_t i = lo; i < hi; ++i) sorted_other[i] = (int32_t)other[perm[i]];
 }
 
+// Small batches (the reference's 32..128 graphs per step): the whole build in ONE workgroup -- histogram, scan, fill and
+// the per-segment order restore in LDS -- instead of seven launches whose enqueue cost exceeds their run time.
+constexpr int CSR_SMALL_NODES = 12287;   // n_nodes + 1 counters + the same number of cursors in LDS (2 x 48 KiB)
+constexpr int CSR_SMALL_EDGES = 1 << 15;
+
+__global__ __launch_bounds__(1024) void csr_small_kernel(const int64_t *__restrict__ index, int64_t n_edges, int n_nodes,
+                                                         int32_t *seg_ptr, int32_t *perm, int32_t *sorted_target,
+                                                         const int64_t *__restrict__ other, int32_t *sorted_other) {
+    extern __shared__ int32_t sm[];
+    int32_t *cnt = sm;                    // [n_nodes + 1]
+    int32_t *cur = sm + n_nodes + 1;      // [n_nodes + 1]
+    __shared__ int32_t wsum[16];
+    __shared__ int32_t carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i <= n_nodes; i += 1024) cnt[i] = 0;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t e = tid; e < n_edges; e += 1024) atomicAdd(&cnt[index[e]], 1);
+    __syncthreads();
+    for (int base = 0; base <= n_nodes; base += 1024) {       // exclusive scan, 1024 counters per pass
+        const int i = base + tid;
+        const int32_t v = i <= n_nodes ? cnt[i] : 0;
+        int32_t x = v;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int32_t y = __shfl_up(x, d, 64);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        int32_t woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wsum[w];
+        const int32_t carry = carry_s;
+        if (i <= n_nodes) {
+            const int32_t ex = carry + woff + x - v;
+            cur[i] = ex;
+            seg_ptr[i] = ex;
+        }
+        __syncthreads();
+        if (tid == 1023) carry_s = carry + woff + x;
+        __syncthreads();
+    }
+    for (int64_t e = tid; e < n_edges; e += 1024) {
+        const int32_t pos = atomicAdd(&cur[index[e]], 1);
+        perm[pos] = (int32_t)e;
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int t = tid; t < n_nodes; t += 1024) {               // cur[t] is now the segment end
+        const int32_t hi = cur[t], lo = hi - cnt[t];
+        for (int32_t i = lo + 1; i < hi; ++i) {
+            const int32_t x = perm[i];
+            int32_t j = i - 1;
+            while (j >= lo && perm[j] > x) { perm[j + 1] = perm[j]; --j; }
+            perm[j + 1] = x;
+        }
+        if (sorted_target)
+            for (int32_t i = lo; i < hi; ++i) sorted_target[i] = (int32_t)t;
+        if (sorted_other)
+            for (int32_t i = lo; i < hi; ++i) sorted_other[i] = (int32_t)other[perm[i]];
+    }
+}
+
 // Output rows the fused segmented-sum epilogue (chain.hip) reaches with atomics or not at all must start at zero:
 // empty segments, and segments that straddle a GSN_SEG_RANGE_ROWS-row boundary of the target-sorted row space.
 __global__ __launch_bounds__(256) void segsum_prepare_kernel(const int32_t *__restrict__ seg_ptr, const int32_t *__restrict__ row_target,
@@ -354,6 +416,18 @@ extern "C" int gsn_csr_build_hip(int64_t n_nodes, int64_t n_edges, const int64_t
     if (n_edges >= (int64_t)1 << 31 || n_nodes >= ((int64_t)1 << 31) - 1)
         return set_error(GSN_E_UNSUPPORTED, "gsn_csr_build_hip: more than 2^31 edges or vertices");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (n_nodes <= CSR_SMALL_NODES && n_edges <= CSR_SMALL_EDGES) {
+        static bool lds_set = false;
+        if (!lds_set) {   // up to 2 x 48 KiB of dynamic LDS
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&csr_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    2 * (CSR_SMALL_NODES + 1) * (int)sizeof(int32_t)) != hipSuccess)
+                return set_error(GSN_E_HIP, "gsn_csr_build_hip: cannot raise the LDS limit of csr_small_kernel");
+            lds_set = true;
+        }
+        hipLaunchKernelGGL(csr_small_kernel, dim3(1), dim3(1024), (size_t)(2 * (n_nodes + 1)) * sizeof(int32_t), st, index, n_edges,
+                           (int)n_nodes, seg_ptr, perm, sorted_target, other, sorted_other);
+        return hip_check("gsn_csr_build_hip");
+    }
     const int64_t n1 = n_nodes + 1;
     int32_t *cnt = scratch;                 // [n1] histogram, later the fill cursor
     int32_t *tiles = scratch + n1;          // [n_tiles]

@@ -52,7 +52,7 @@ def column_range(values):
     M, C = values.shape
     mn = torch.empty(C, dtype=torch.int64, device=values.device)
     mx = torch.empty(C, dtype=torch.int64, device=values.device)
-    with torch.cuda.device(values.device):
+    with _abi.device_guard(values.device):
         rc = _abi.lib().gsn_column_range_hip(M, C, values.data_ptr() if M else None, mn.data_ptr(), mx.data_ptr(),
                                              _abi.current_stream())
     _abi.check(rc, "gsn_column_range_hip")
@@ -77,7 +77,7 @@ def unique_codes(values):
     table = torch.empty(int(base[-1]), dtype=torch.int32, device=dev)
     codes = torch.empty_like(v)
     nd = torch.empty(C, dtype=torch.int64, device=dev)
-    with torch.cuda.device(dev):
+    with _abi.device_guard(dev):
         rc = _abi.lib().gsn_column_ranks_hip(M, C, v.data_ptr(), mn.data_ptr(), base_d.data_ptr(), int(base[-1]),
                                              table.data_ptr(), codes.data_ptr(), nd.data_ptr(), _abi.current_stream())
     _abi.check(rc, "gsn_column_ranks_hip")
@@ -189,7 +189,7 @@ class _EmbedFn(torch.autograd.Function):
         meta = _table_meta(tabs, dev)
         out = torch.empty((M, C * d if concat else d), dtype=torch.float32, device=dev)
         status = torch.zeros(1, dtype=torch.int32, device=dev)
-        with torch.cuda.device(dev):
+        with _abi.device_guard(dev):
             rc = _abi.lib().gsn_embed_fwd_hip(M, C, d, int(concat), codes.data_ptr() if M else None, meta.data_ptr(),
                                               out.data_ptr() if M else None, status.data_ptr(), _abi.current_stream())
         _abi.check(rc, "gsn_embed_fwd_hip")
@@ -208,7 +208,7 @@ class _EmbedFn(torch.autograd.Function):
         grads = [torch.zeros(s, dtype=torch.float32, device=dev) for s in ctx.shapes]
         meta = _table_meta(grads, dev)
         g = gout.to(torch.float32).contiguous()
-        with torch.cuda.device(dev):
+        with _abi.device_guard(dev):
             rc = _abi.lib().gsn_embed_bwd_hip(M, C, d, int(ctx.concat), codes.data_ptr() if M else None, meta.data_ptr(),
                                               g.data_ptr() if M else None, _abi.current_stream())
         _abi.check(rc, "gsn_embed_bwd_hip")

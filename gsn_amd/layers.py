@@ -76,6 +76,8 @@ def _need_cuda(t, what):
 
 
 def _f32c(t):
+    if t.dtype is torch.float32 and t.is_contiguous():
+        return t.detach() if t.requires_grad else t
     return t.detach().to(torch.float32).contiguous()
 
 
@@ -147,7 +149,7 @@ def build_csr(index, n_nodes, with_targets=False, other=None):
     src = torch.empty(max(E, 1), dtype=torch.int32, device=dev) if (with_targets and other is not None) else None
     if other is not None:
         other = other.contiguous()
-    with torch.cuda.device(dev), _timed("csr_build", 12.0 * E + 8.0 * n_nodes):
+    with _abi.device_guard(dev), _timed("csr_build", 12.0 * E + 8.0 * n_nodes):
         _abi.check(L.gsn_csr_build_hip(n_nodes, E, index.data_ptr() if E else None,
                                        other.data_ptr() if (other is not None and E) else None, seg_ptr.data_ptr(),
                                        perm.data_ptr(), _abi.ptr(tgt), _abi.ptr(src) if (E and other is not None) else None,
@@ -206,7 +208,7 @@ def one_hot_identifiers(values, n_classes, clamp=False):
     if len(ncls) != values.shape[1]:
         raise ValueError("one_hot_identifiers: %d columns but %d class counts" % (values.shape[1], len(ncls)))
     out = torch.empty((values.shape[0], int(ncls.sum())), dtype=torch.float32, device=values.device)
-    with torch.cuda.device(values.device), _timed("one_hot", 8.0 * values.numel() + 4.0 * out.numel()):
+    with _abi.device_guard(values.device), _timed("one_hot", 8.0 * values.numel() + 4.0 * out.numel()):
         _abi.check(_abi.lib().gsn_one_hot_hip(values.shape[0], values.shape[1], values.data_ptr(), _abi.ptr(ncls), int(bool(clamp)),
                                               out.data_ptr(), _abi.current_stream()), "gsn_one_hot_hip")
     return out
@@ -229,7 +231,7 @@ class _PropagateFn(torch.autograd.Function):
         # algorithmic bytes: src (8) + perm (4) per edge, every message element read once, output written once
         per_edge = (0 if ts[0] is None else widths[0]) + (0 if (ts[1] is None or b_per_node) else widths[1]) + (0 if ts[2] is None else widths[2])
         bytes_alg = 12.0 * E + 4.0 * n_nodes + 4.0 * (E * per_edge + n_nodes * d_out)
-        with torch.cuda.device(edge_index.device), _timed("propagate_fwd", bytes_alg):
+        with _abi.device_guard(edge_index.device), _timed("propagate_fwd", bytes_alg):
             rc = _abi.lib().gsn_propagate_fwd_hip(kind, n_nodes, E, src.data_ptr() if E else None, csr_t.seg_ptr.data_ptr(),
                                                   csr_t.perm.data_ptr() if E else None, _abi.ptr(ts[0]), widths[0],
                                                   _abi.ptr(ts[1]), widths[1], int(b_per_node), _abi.ptr(ts[2]), widths[2],
@@ -260,7 +262,7 @@ class _PropagateFn(torch.autograd.Function):
         if need[1] and wb:
             g_b = torch.zeros((n if ctx.b_per_node else E, wb), dtype=torch.float32, device=dev)
         g_c = torch.zeros((E, wc), dtype=torch.float32, device=dev) if (need[2] and wc) else None
-        with torch.cuda.device(dev):
+        with _abi.device_guard(dev):
             rc = _abi.lib().gsn_propagate_bwd_hip(ctx.kind, n, E, src.data_ptr() if E else None, tgt.data_ptr() if E else None,
                                                   csr_s.seg_ptr.data_ptr() if csr_s is not None else None,
                                                   csr_s.perm.data_ptr() if (csr_s is not None and E) else None,
@@ -305,7 +307,7 @@ def _linear_hip(blocks, weight, bias, bn_mean, bn_scale, bn_shift, act, m_rows, 
     y = torch.empty((m_rows, n_out), dtype=torch.float32, device=dev) if out else None
     w = _f32c(weight)
     vecs = [None if v is None else _f32c(v) for v in (bias, bn_mean, bn_scale, bn_shift)]
-    with torch.cuda.device(dev), _timed("linear_fwd", 2.0 * m_rows * w.shape[1] * n_out):
+    with _abi.device_guard(dev), _timed("linear_fwd", 2.0 * m_rows * w.shape[1] * n_out):
         rc = _abi.lib().gsn_linear_fwd_hip(m_rows, len(blocks), arr, w.data_ptr(), _abi.ptr(vecs[0]), n_out, _abi.ptr(vecs[1]),
                                            _abi.ptr(vecs[2]), _abi.ptr(vecs[3]), act, None, _abi.ptr(y), _abi.ptr(stats),
                                            _abi.current_stream())
@@ -376,7 +378,7 @@ def _launch_stages(stages, m_rows, stats=None, csr=None):
             if seg:
                 n_seg = csr.seg_ptr.numel() - 1
                 out = torch.empty((n_seg, n_out), dtype=torch.float32, device=dev)
-                with torch.cuda.device(dev), _timed("segsum_prepare"):
+                with _abi.device_guard(dev), _timed("segsum_prepare"):
                     _abi.check(L.gsn_segsum_prepare_hip(n_seg, m_rows, csr.seg_ptr.data_ptr(), csr.tgt.data_ptr(), n_out,
                                                         out.data_ptr(), _abi.current_stream()), "gsn_segsum_prepare_hip")
             else:
@@ -385,7 +387,7 @@ def _launch_stages(stages, m_rows, stats=None, csr=None):
             kprev = 0
             for j, st in enumerate(cand):
                 flops += 2.0 * m_rows * st.weight.shape[1] * st.weight.shape[0]
-            with torch.cuda.device(dev), _timed("mlp_chain%d" % n, flops):
+            with _abi.device_guard(dev), _timed("mlp_chain%d" % n, flops):
                 rc = L.gsn_mlp_chain_fwd_hip(m_rows, n, arr, None,
                                              csr.tgt.data_ptr() if seg else None, _abi.ptr(out),
                                              _abi.ptr(stats) if want_stats else None, _abi.current_stream())
@@ -444,8 +446,20 @@ def _bn_resolve(stage, stats_fn, m_rows, training):
         mean32 = mean.to(torch.float32)
         invstd = torch.rsqrt(var + bn.eps).to(torch.float32)
     else:
+        # eval mode: the three vectors depend only on the module's buffers / parameters -> cached on their versions
+        key = (bn.running_mean._version, bn.running_var._version, bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+               (bn.weight._version, bn.bias._version, bn.weight.data_ptr(), bn.bias.data_ptr()) if bn.affine else None)
+        hit = getattr(bn, "_gsn_eval_cache", None)
+        if hit is not None and hit[0] == key:
+            stage.bn_params = hit[1]
+            return
         mean32 = bn.running_mean
         invstd = torch.rsqrt(bn.running_var.to(torch.float64) + bn.eps).to(torch.float32)
+        scale = invstd * bn.weight.detach() if bn.affine else invstd
+        shift = bn.bias.detach() if bn.affine else torch.zeros_like(invstd)
+        stage.bn_params = (mean32.contiguous(), scale.contiguous(), shift.contiguous())
+        bn._gsn_eval_cache = (key, stage.bn_params)
+        return
     scale = invstd * bn.weight.detach() if bn.affine else invstd
     shift = bn.bias.detach() if bn.affine else torch.zeros_like(invstd)
     stage.bn_params = (mean32, scale, shift)
@@ -506,7 +520,7 @@ def _code_stage_segsum(mf, cblocks, csr, m_rows):
 
     def launch(bn_params, out, stats):
         vecs = [None if v is None else _f32c(v) for v in (bn_params or (None, None, None))]
-        with torch.cuda.device(dev), _timed("code_stage", 4.0 * m_rows * n_slots * n_out):
+        with _abi.device_guard(dev), _timed("code_stage", 4.0 * m_rows * n_slots * n_out):
             rc = L.gsn_code_stage_fwd_hip(m_rows, n_slots, arr, wt.data_ptr(), k_total, bias.data_ptr(), n_out,
                                           _abi.ptr(vecs[0]), _abi.ptr(vecs[1]), _abi.ptr(vecs[2]), _ACT_CODE[mf.activation_name],
                                           csr.tgt.data_ptr(), _abi.ptr(out), _abi.ptr(stats), status.data_ptr(),
@@ -523,7 +537,7 @@ def _code_stage_segsum(mf, cblocks, csr, m_rows):
     _bn_resolve(stage, stats_fn, m_rows, mf.training)
     n_seg = csr.seg_ptr.numel() - 1
     out = torch.empty((n_seg, n_out), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev), _timed("segsum_prepare"):
+    with _abi.device_guard(dev), _timed("segsum_prepare"):
         _abi.check(L.gsn_segsum_prepare_hip(n_seg, m_rows, csr.seg_ptr.data_ptr(), csr.tgt.data_ptr(), n_out, out.data_ptr(),
                                             _abi.current_stream()), "gsn_segsum_prepare_hip")
     launch(stage.bn_params, out, None)
@@ -631,6 +645,8 @@ class _HipWithTorchBackward(torch.autograd.Function):
 
 
 def _run(module, hip_fn, torch_fn, inputs, extra_params=()):
+    if not torch.is_grad_enabled():
+        return hip_fn()
     params = [p for p in module.parameters()] + list(extra_params)
     need_grad = torch.is_grad_enabled() and (any(t.requires_grad for t in inputs) or any(p.requires_grad for p in params))
     if not need_grad:
