@@ -36,7 +36,7 @@ class gsn_chain_stage(ctypes.Structure):
 # name -> (restype, argtypes); kept in one place so tests can check it against include/gsn_abi.h
 class gsn_code_slot(ctypes.Structure):
     _fields_ = [("codes", ctypes.c_void_p), ("idx", ctypes.c_void_p), ("stride", ctypes.c_int32), ("col", ctypes.c_int32),
-                ("w_off", ctypes.c_int32), ("n_classes", ctypes.c_int32)]
+                ("w_off", ctypes.c_int32), ("n_classes", ctypes.c_int32), ("clamp", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 SIGNATURES = {

@@ -138,8 +138,8 @@ __global__ __launch_bounds__(256) void code_stage_kernel(CodeStageArgs a) {
                     const int64_t r = d.idx ? (int64_t)d.idx[qr] : qr;
                     int64_t code = d.codes[r * d.stride + d.col];
                     if (code < 0 || code >= d.n_classes) {
-                        atomicMax(a.status, GSN_ST_BAD_INDEX);
-                        code = 0;
+                        if (d.clamp) code = code < 0 ? 0 : d.n_classes - 1;
+                        else { atomicMax(a.status, GSN_ST_BAD_INDEX); code = 0; }
                     }
                     off = (d.w_off + (int)code) * row_bytes;
                 }

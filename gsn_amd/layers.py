@@ -89,15 +89,16 @@ class Codes:
     [R, sum(n_classes)].  Layers accept it for ``x``, ``identifiers`` and ``edge_features``; where all inputs of msg_fn's
     first Linear are Codes that Linear becomes a weight-row gather (gsn_code_stage_fwd_hip) and the dense one-hot
     matrix is never built; everywhere else the layer densifies it."""
-    __slots__ = ("codes", "n_classes", "_dense")
+    __slots__ = ("codes", "n_classes", "clamp", "_dense")
 
-    def __init__(self, codes, n_classes):
+    def __init__(self, codes, n_classes, clamp=False):
         codes = codes.unsqueeze(-1) if codes.dim() == 1 else codes
         _need_cuda(codes, "codes")
         self.codes = codes.to(torch.int64).contiguous()
         self.n_classes = [int(c) for c in n_classes]
         if len(self.n_classes) != self.codes.shape[1]:
             raise ValueError("Codes: %d columns but %d class counts" % (self.codes.shape[1], len(self.n_classes)))
+        self.clamp = bool(clamp)      # values above the last class count as the last class (as gsn_one_hot_hip's clamp)
         self._dense = None
 
     @property
@@ -116,7 +117,7 @@ class Codes:
 
     def dense(self):
         if self._dense is None:
-            self._dense = one_hot_identifiers(self.codes, self.n_classes)
+            self._dense = one_hot_identifiers(self.codes, self.n_classes, clamp=self.clamp)
         return self._dense
 
 
@@ -512,6 +513,7 @@ def _code_stage_segsum(mf, cblocks, csr, m_rows):
         for col, ncls in enumerate(c.n_classes):
             arr[s].codes = c.codes.data_ptr(); arr[s].idx = idx.data_ptr()
             arr[s].stride = c.codes.shape[1]; arr[s].col = col; arr[s].w_off = off; arr[s].n_classes = ncls
+            arr[s].clamp = int(c.clamp)
             s += 1
             off += ncls
     wt = _transposed_weight(lin)

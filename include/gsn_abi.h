@@ -266,6 +266,8 @@ typedef struct gsn_code_slot {
     int32_t stride, col;   /* row pitch of `codes` in elements, column used */
     int32_t w_off;         /* first row of this slot's block in WT */
     int32_t n_classes;     /* number of rows of that block */
+    int32_t clamp;         /* != 0: codes are clamped into [0, n_classes-1] instead of being reported (cf. gsn_one_hot_hip) */
+    int32_t reserved;
 } gsn_code_slot;
 int gsn_code_stage_supported(int n_slots, int64_t k_total, int64_t n_out);
 int gsn_code_stage_fwd_hip(int64_t m_rows, int n_slots, const gsn_code_slot *slots, const float *WT, int64_t k_total,
