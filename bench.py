@@ -226,6 +226,20 @@ def main():
             ach = kd["work_per_step"] / (kd["ms_per_step"] * 1e-3) / 1e9
             roof = {"kernel": {"propagate_fwd": "propagate_fwd_kernel", "count": "count_kernel"}[dom], "bound": "hbm",
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
+        # HBM traffic cannot be read from inside the run: PMC needs rocprofv3 around the process.  Report the committed
+        # measurement of the same command (scripts/profile_bench.sh -> profiles/r01_bench_pmc.csv): per launch of the dominant
+        # kernel family, FETCH_SIZE x2 (gfx950 under-reports wide reads, MI355X_MICROARCH.md) + WRITE_SIZE, in bytes.
+        try:
+            import csv
+            pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_bench_pmc.csv")
+            rows = [r for r in csv.DictReader(open(pmc)) if roof["kernel"] in r["kernel"]]
+            if rows and G == 65536:
+                tot = sum((2.0 * float(r["FETCH_SIZE_per_dispatch"]) + float(r["WRITE_SIZE_per_dispatch"])) * 1024.0 for r in rows)
+                roof["traffic"] = round(tot / len(rows))
+                roof["traffic_source"] = "profiles/r01_bench_pmc.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; mean over the family's launches)"
+                roof["algorithmic_bytes"] = round(sum(4.0 * (m_in + m_out) for m_in, m_out in ((E * 72.0 + 0, N * 128.0), (N * 157.0, N * 128.0))) / 2)
+        except Exception:
+            pass
         roof["launches_per_step"] = kd["launches_per_step"]
         roof["avg_launch_ms"] = round(kd["ms_per_step"] / kd["launches_per_step"], 4)
         ck = kernels["count"]
