@@ -231,6 +231,7 @@ struct PropArgs {
     int64_t n_nodes, n_edges;
     const int64_t *src;
     const int32_t *seg_ptr, *perm;
+    const int32_t *sorted_src;   // src[perm[q]] per segment position, or null
     const float *a, *b, *c;
     int da, db, dc, d_out;
     int b_per_node;
@@ -251,7 +252,10 @@ __device__ __forceinline__ float4 vrelu(float4 x) { return make_float4(vrelu(x.x
 __device__ __forceinline__ void vzero(float &x) { x = 0.f; }
 __device__ __forceinline__ void vzero(float4 &x) { x = make_float4(0.f, 0.f, 0.f, 0.f); }
 
-// MAXC: column chunks of width LPR*VEC each lane accumulates (d_out <= MAXC*LPR*VEC)
+// MAXC: column chunks of width LPR*VEC each lane accumulates (d_out <= MAXC*LPR*VEC).  With `sorted_src` the source
+// vertex comes from the segment-ordered copy the CSR build writes (one dependent load less than src[perm[q]]).
+// (Taking the edges of a segment four at a time with all row loads in flight together was measured and is no faster:
+// the kernel is limited by DRAM efficiency on 512-byte gathers, not by load latency.)
 template <int VEC, int LPR, int MAXC>
 __global__ __launch_bounds__(256) void propagate_fwd_kernel(PropArgs p) {
     using V = typename VecT<VEC>::type;
@@ -269,7 +273,7 @@ __global__ __launch_bounds__(256) void propagate_fwd_kernel(PropArgs p) {
         const int32_t lo = p.seg_ptr[t], hi = p.seg_ptr[t + 1];
         for (int32_t q = lo; q < hi; ++q) {
             const int64_t e = p.perm ? (int64_t)p.perm[q] : (int64_t)q;
-            const int64_t s = p.src[e];
+            const int64_t s = p.sorted_src ? (int64_t)p.sorted_src[q] : p.src[e];
 #pragma unroll
             for (int i = 0; i < MAXC; ++i) {
                 const int col = (i * LPR + li) * VEC;
@@ -451,7 +455,7 @@ extern "C" int gsn_csr_build_hip(int64_t n_nodes, int64_t n_edges, const int64_t
 }
 
 extern "C" int gsn_propagate_fwd_hip(int kind, int64_t n_nodes, int64_t n_edges, const int64_t *src, const int32_t *seg_ptr,
-                                     const int32_t *perm, const float *a, int64_t da, const float *b, int64_t db,
+                                     const int32_t *perm, const int32_t *sorted_src, const float *a, int64_t da, const float *b, int64_t db,
                                      int b_per_node, const float *c, int64_t dc, float *out, void *stream) {
     if (kind != GSN_MSG_CAT && kind != GSN_MSG_RELU_SUM) return set_error(GSN_E_INVALID, "gsn_propagate_fwd_hip: unknown kind %d", kind);
     if (!seg_ptr || !out || (n_edges > 0 && !src)) return set_error(GSN_E_INVALID, "gsn_propagate_fwd_hip: null pointer");
@@ -471,6 +475,7 @@ extern "C" int gsn_propagate_fwd_hip(int kind, int64_t n_nodes, int64_t n_edges,
     if (d_out > 1024) return set_error(GSN_E_UNSUPPORTED, "gsn_propagate_fwd_hip: message width %lld > 1024", (long long)d_out);
     PropArgs p{};
     p.kind = kind; p.n_nodes = n_nodes; p.n_edges = n_edges; p.src = src; p.seg_ptr = seg_ptr; p.perm = perm;
+    p.sorted_src = sorted_src;
     p.a = da ? a : nullptr; p.b = db ? b : nullptr; p.c = dc ? c : nullptr;
     p.da = (int)da; p.db = (int)db; p.dc = (int)dc; p.d_out = (int)d_out;
     p.b_per_node = b_per_node; p.out = out;

@@ -234,9 +234,10 @@ class _PropagateFn(torch.autograd.Function):
         bytes_alg = 12.0 * E + 4.0 * n_nodes + 4.0 * (E * per_edge + n_nodes * d_out)
         with _abi.device_guard(edge_index.device), _timed("propagate_fwd", bytes_alg):
             rc = _abi.lib().gsn_propagate_fwd_hip(kind, n_nodes, E, src.data_ptr() if E else None, csr_t.seg_ptr.data_ptr(),
-                                                  csr_t.perm.data_ptr() if E else None, _abi.ptr(ts[0]), widths[0],
-                                                  _abi.ptr(ts[1]), widths[1], int(b_per_node), _abi.ptr(ts[2]), widths[2],
-                                                  out.data_ptr(), _abi.current_stream())
+                                                  csr_t.perm.data_ptr() if E else None,
+                                                  csr_t.src.data_ptr() if (E and csr_t.src is not None) else None,
+                                                  _abi.ptr(ts[0]), widths[0], _abi.ptr(ts[1]), widths[1], int(b_per_node),
+                                                  _abi.ptr(ts[2]), widths[2], out.data_ptr(), _abi.current_stream())
         _abi.check(rc, "gsn_propagate_fwd_hip")
         ctx.kind, ctx.sel, ctx.n_nodes, ctx.b_per_node = kind, sel, n_nodes, b_per_node
         ctx.edge_index = edge_index

@@ -126,7 +126,8 @@ int gsn_csr_build_hip(int64_t n_nodes, int64_t n_edges, const int64_t *index, co
  *                         (GSN_edge_sparse_ogb.py:119-125, MPNN_edge_sparse_ogb.py message)
  *   a: per-node [N][da];  b: per-edge [E][db] (b_per_node=0) or per-node [N][db] gathered at src (b_per_node=1);
  *   c: per-edge [E][dc];  any of a/b/c may be NULL with width 0.   out: [N][d_out], fully overwritten.
- *   src int64 [E] message source vertex (edge_index[0] for source_to_target); seg_ptr/perm from gsn_csr_build_hip.
+ *   src int64 [E] message source vertex (edge_index[0] for source_to_target); seg_ptr/perm from gsn_csr_build_hip;
+ *   sorted_src int32 [E] = src[perm[q]] (gsn_csr_build_hip's sorted_other) or NULL -- saves one dependent load per edge.
  * gsn_propagate_bwd_hip is the adjoint: given g_out [N][d_out] it writes g_a [N][da] (overwritten, gathers through the
  * source-sorted CSR seg_ptr_src/perm_src), g_b ([E][db] or [N][db]) and g_c [E][dc]; for RELU_SUM the forward inputs
  * are needed again to recompute the relu mask.
@@ -134,7 +135,7 @@ int gsn_csr_build_hip(int64_t n_nodes, int64_t n_edges, const int64_t *index, co
 enum { GSN_MSG_CAT = 0, GSN_MSG_RELU_SUM = 1 };
 
 int gsn_propagate_fwd_hip(int kind, int64_t n_nodes, int64_t n_edges, const int64_t *src, const int32_t *seg_ptr,
-                          const int32_t *perm, const float *a, int64_t da, const float *b, int64_t db,
+                          const int32_t *perm, const int32_t *sorted_src, const float *a, int64_t da, const float *b, int64_t db,
                           int b_per_node, const float *c, int64_t dc, float *out, void *stream);
 
 int gsn_propagate_bwd_hip(int kind, int64_t n_nodes, int64_t n_edges, const int64_t *src, const int64_t *tgt,
