@@ -32,6 +32,7 @@ struct CountArgs {
     int32_t *status;
     // LDS byte offsets
     int off_valid, off_stack, off_plan, off_eu, off_ev, off_rowstart, off_last, off_out, off_misc;
+    int off_ball;              // distance-pruning tables (radius 2, radius 3: n_cap rows each) or -1
 };
 
 template <int W, int T>
@@ -47,6 +48,7 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
     int *last = reinterpret_cast<int *>(smem + a.off_last);
     uint64_t *out_lds = reinterpret_cast<uint64_t *>(smem + a.off_out);
     int *misc = reinterpret_cast<int *>(smem + a.off_misc);  // [0] next task  [1] n_active  [2] status
+    uint64_t *balls = a.off_ball >= 0 ? reinterpret_cast<uint64_t *>(smem + a.off_ball) : nullptr;
 
     const int tid = threadIdx.x;
     const int item = (int)blockIdx.x / a.split, part = (int)blockIdx.x - item * a.split;
@@ -94,6 +96,12 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
     __syncthreads();
     const int n_active = misc[1];
     if (tid < W) valid[tid] = below_word(n_active, tid);
+    // distance pruning tables: vertices within 2 / 3 hops (count_core.h, candidates())
+    if (balls) {
+        for (int v = tid; v < n; v += T) ball_expand<W>(A, nullptr, v, balls);
+        __syncthreads();
+        for (int v = tid; v < n; v += T) ball_expand<W>(A, balls, v, balls + a.n_cap * W);
+    }
 
     // ---- phase 2 (edge mode): CSR rank of every directed pair, last-duplicate-wins column -------------------------
     if (edge_mode) {
@@ -137,6 +145,7 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
 
     Lane<W> s;
     s.l = -1; s.cnt = 0; s.k = 0; s.nfix = 0; s.fvec = 0; s.plan = plans;
+    s.balls = balls; s.ball_n = a.n_cap;
 #pragma unroll
     for (int w = 0; w < W; ++w) s.used.w[w] = 0ull;
     bool has_task = false, exhausted = false;
@@ -290,6 +299,10 @@ extern "C" int gsn_count_hip(const uint32_t *plan_host, const uint32_t *plan_dev
     a.off_rowstart = o; o += edge_mode ? align_up(((int)max_nodes + 1) * 4, 16) : 0;
     a.off_last = o; o += edge_mode ? align_up((int)max_edges * 4, 16) : 0;
     a.off_misc = o; o += 16;
+    // pruning tables only for graphs of <= 64 vertices (molecules): on larger, denser targets the balls are (nearly)
+    // everything and the extra AND per step costs more than it saves (measured: ER G(128,1000) +8 %)
+    a.off_ball = -1;
+    if (W == 1 && a.kmax >= 4) { a.off_ball = o; o += align_up(2 * (int)max_nodes * W * 8, 16); }
     a.off_out = o;
     const int64_t stage_bytes = rows_cap * a.n_cols * 8;
     // Stage the output rows in LDS (coalesced final write) only while that keeps the workgroup small: the search is

@@ -67,10 +67,19 @@ GSN_HD int popc(const Bits<W> &b) {
 //   gt/lt  : symmetry breaking, candidate id must be > / < f_j
 // Only the levels named in desc are visited (a cycle or path level has one or two), everything else is covered by
 // `valid & ~used` -- the kernel is VALU-issue bound, so the per-step instruction count is what matters.
+// `ball` = j | r<<3 (r = 0: none) with `balls` = the r-hop balls of the target graph, radius 2 at balls[v*W], radius 3 at
+// balls[(ball_n + v)*W] (nullptr: pruning off -- it never changes the result, only the work).
 template <int W>
-GSN_HD void candidates(Bits<W> &C, uint32_t desc, uint64_t fvec, const Bits<W> &used, const uint64_t *A, const uint64_t *valid) {
+GSN_HD void candidates(Bits<W> &C, uint32_t desc, uint32_t ball, uint64_t fvec, const Bits<W> &used, const uint64_t *A,
+                       const uint64_t *valid, const uint64_t *balls, int ball_n) {
 #pragma unroll
     for (int w = 0; w < W; ++w) C.w[w] = valid[w] & ~used.w[w];
+    if (balls && (ball >> 3)) {
+        const int fj = (int)((fvec >> (8 * (ball & 7u))) & 0xffu);
+        const uint64_t *row = balls + (size_t)(((ball >> 3) == 3 ? ball_n : 0) + fj) * W;
+#pragma unroll
+        for (int w = 0; w < W; ++w) C.w[w] &= row[w];
+    }
     uint32_t m = desc & 0xffu;
     while (m) {
         const int j = ctz64(m);
@@ -101,6 +110,27 @@ GSN_HD void candidates(Bits<W> &C, uint32_t desc, uint64_t fvec, const Bits<W> &
     }
 }
 
+// r-hop balls of vertex v from the adjacency bit matrix: ball2 = v + N(v) + N(N(v)), ball3 = one more hop (needs every
+// ball2 first).  One call per vertex; the caller parallelises over v.
+template <int W>
+GSN_HD void ball_expand(const uint64_t *A, const uint64_t *from /* [n][W] or nullptr: the adjacency itself */, int v, uint64_t *out) {
+    Bits<W> acc;
+#pragma unroll
+    for (int w = 0; w < W; ++w) acc.w[w] = (from ? from[v * W + w] : A[v * W + w]) | ((w == (v >> 6)) ? (1ull << (v & 63)) : 0ull);
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        uint64_t m = A[v * W + w];
+        while (m) {
+            const int u = w * 64 + ctz64(m);
+            m &= m - 1ull;
+#pragma unroll
+            for (int x = 0; x < W; ++x) acc.w[x] |= from ? from[u * W + x] : A[u * W + x];
+        }
+    }
+#pragma unroll
+    for (int w = 0; w < W; ++w) out[v * W + w] = acc.w[w];
+}
+
 template <int W>
 struct Lane {
     int l;          // level whose frame is being consumed; < 0: no search in progress
@@ -109,7 +139,11 @@ struct Lane {
     uint64_t cnt;   // matches found so far for the current task (accumulates over the task's plans)
     Bits<W> used;   // images of levels 0 .. l-1
     const uint32_t *plan;
+    const uint64_t *balls;   // distance-pruning tables of the target graph or nullptr
+    int ball_n;              // vertex capacity of one table
 };
+
+GSN_HD uint32_t plan_ball(const uint32_t *plan, int l) { return (plan[2 + GSN_KMAX + (l >> 2)] >> (8 * (l & 3))) & 0xffu; }
 
 template <int W>
 GSN_HD void bit_set(Bits<W> &b, int v) {
@@ -150,7 +184,7 @@ GSN_HD void lane_begin(Lane<W> &s, const uint32_t *plan, uint64_t fvec_roots, co
     if (s.nfix > 1) bit_set<W>(s.used, (int)((fvec_roots >> 8) & 0xffu));
     if (s.nfix == s.k) { s.cnt += 1; return; }
     Bits<W> C;
-    candidates<W>(C, plan[2 + s.nfix], s.fvec, s.used, A, valid);
+    candidates<W>(C, plan[2 + s.nfix], plan_ball(plan, s.nfix), s.fvec, s.used, A, valid, s.balls, s.ball_n);
     if (s.nfix == s.k - 1) { s.cnt += (uint64_t)popc<W>(C); return; }
     bool cempty = true;
 #pragma unroll
@@ -184,7 +218,7 @@ GSN_HD void lane_step(Lane<W> &s, const uint64_t *A, const uint64_t *valid, uint
     Bits<W> used2 = s.used;
     bit_set<W>(used2, v);
     Bits<W> C;
-    candidates<W>(C, s.plan[2 + nl], s.fvec, used2, A, valid);
+    candidates<W>(C, s.plan[2 + nl], plan_ball(s.plan, nl), s.fvec, used2, A, valid, s.balls, s.ball_n);
     bool descend = false;
     if (nl == s.k - 1) {
         s.cnt += (uint64_t)popc<W>(C);

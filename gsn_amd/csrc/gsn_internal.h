@@ -14,9 +14,11 @@ namespace gsn {
 //   col_ptr: [8 .. 8+n_cols]  plans col_ptr[c]..col_ptr[c+1] all write output column c (plans are sorted by column)
 //   plan p : at plans_off + p*PLAN_STRIDE_WORDS: [0] k | n_fixed<<8 | out_col<<16     [1] pattern | root_a<<16 | root_b<<24
 //            [2+l] level l: adj_mask | nonadj_mask<<8 | gt_mask<<16 | lt_mask<<24   (bit j = earlier level j)
+//            [2+KMAX + l/4] byte l%4: distance constraint of level l:  j | r<<3  (r = 0 none, 2 or 3): the image of level
+//                         l must lie within r hops of the image of level j (r = their distance in the pattern)
 constexpr uint32_t PLAN_MAGIC = 0x47534e31u;  // 'GSN1'
 constexpr int PLAN_HEADER_WORDS = 8;
-constexpr int PLAN_STRIDE_WORDS = 2 + GSN_KMAX;
+constexpr int PLAN_STRIDE_WORDS = 2 + GSN_KMAX + GSN_KMAX / 4;
 
 int set_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 

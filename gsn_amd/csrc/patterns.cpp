@@ -96,6 +96,7 @@ static int analyse(int64_t n_edges, const int64_t *edges, int directed_orbits, P
 struct Plan {
     int k, n_fixed, out_col, pattern, root_a, root_b;
     uint32_t level[GSN_KMAX];
+    uint8_t ball[GSN_KMAX];
 };
 
 // Matching order: fixed roots first, then greedily the unplaced vertex with most placed neighbours (ties: higher degree,
@@ -165,6 +166,24 @@ static Plan make_plan(const Pattern &P, int pattern_id, const int *fixed, int n_
             if (c.first == order[l] && pos[c.second] < l) lt |= 1u << pos[c.second];  // f_l < f_j
         }
         pl.level[l] = adj | (nonadj << 8) | (gt << 16) | (lt << 24);
+    }
+    // Distance pruning: a subgraph isomorphism maps a path of the pattern onto a path of the target, so
+    // dist_G(f(a), f(b)) <= dist_H(a, b).  Per level keep the tightest such bound of radius 2 or 3 against an earlier level
+    // (radius 1 is the adjacency mask itself); the kernel intersects the candidates with the r-hop ball of that image.
+    int dist[GSN_KMAX][GSN_KMAX];
+    for (int a = 0; a < P.k; ++a)
+        for (int b = 0; b < P.k; ++b) dist[a][b] = a == b ? 0 : (has(P, a, b) ? 1 : 99);
+    for (int m = 0; m < P.k; ++m)
+        for (int a = 0; a < P.k; ++a)
+            for (int b = 0; b < P.k; ++b) dist[a][b] = std::min(dist[a][b], dist[a][m] + dist[m][b]);
+    for (int l = 0; l < GSN_KMAX; ++l) pl.ball[l] = 0;
+    for (int l = n_fixed; l < P.k; ++l) {
+        int best_j = -1, best_r = 99;
+        for (int j = 0; j < l; ++j) {
+            const int d = dist[order[l]][order[j]];
+            if (d >= 2 && d <= 3 && d < best_r) { best_r = d; best_j = j; }
+        }
+        if (best_j >= 0) pl.ball[l] = (uint8_t)(best_j | (best_r << 3));
     }
     return pl;
 }
@@ -261,6 +280,8 @@ extern "C" int gsn_count_plan_build(int mode, int induced, int directed_orbits, 
         w[0] = (uint32_t)pl.k | ((uint32_t)pl.n_fixed << 8) | ((uint32_t)pl.out_col << 16);
         w[1] = (uint32_t)pl.pattern | ((uint32_t)pl.root_a << 16) | ((uint32_t)pl.root_b << 24);
         for (int l = 0; l < GSN_KMAX; ++l) w[2 + l] = pl.level[l];
+        for (int l = 0; l < GSN_KMAX / 4; ++l) w[2 + GSN_KMAX + l] = 0;
+        for (int l = 0; l < GSN_KMAX; ++l) w[2 + GSN_KMAX + l / 4] |= (uint32_t)pl.ball[l] << (8 * (l % 4));
     }
     return GSN_OK;
 }

@@ -5,6 +5,7 @@
 // without a GPU.  The HIP kernel's own setup phases are covered by the -m gpu tests.
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -33,6 +34,11 @@ static int run(const uint32_t *plan, int64_t n, int64_t E, const int64_t *src, c
     }
     uint64_t valid[W];
     for (int w = 0; w < W; ++w) valid[w] = below_word(n_active, w);
+    const int nb = (int)(n ? n : 1);
+    std::vector<uint64_t> balls((size_t)2 * nb * W, 0);           // radius 2, then radius 3
+    for (int v = 0; v < (int)n; ++v) ball_expand<W>(A.data(), nullptr, v, balls.data());
+    for (int v = 0; v < (int)n; ++v) ball_expand<W>(A.data(), balls.data(), v, balls.data() + (size_t)nb * W);
+    const bool prune = getenv("GSN_HARNESS_NO_PRUNE") == nullptr;
     std::vector<int64_t> last((size_t)(n * n ? n * n : 1), -1);
     for (int64_t c = 0; c < E; ++c) last[(size_t)src[c] * n + dst[c]] = c;
     const int64_t rows = mode == GSN_MODE_EDGE ? E : n;
@@ -40,6 +46,7 @@ static int run(const uint32_t *plan, int64_t n, int64_t E, const int64_t *src, c
     for (int col = 0; col < n_cols; ++col)
         for (int64_t row = 0; row < rows; ++row) {
             Lane<W> s; s.l = -1; s.cnt = 0; s.k = 0; s.nfix = 0; s.fvec = 0; s.plan = plans;
+            s.balls = prune ? balls.data() : nullptr; s.ball_n = nb;
             for (int w = 0; w < W; ++w) s.used.w[w] = 0;
             uint64_t roots; bool live = true, rev_missing = false;
             if (mode == GSN_MODE_EDGE) {
