@@ -204,6 +204,36 @@ def main():
                  "max_rel_diff_vs_dense": float("%.2e" % err),
                  "note": "same step, layer inputs as integer codes (one-hot + first Linear + BN + act + scatter-add fused into a weight-row gather)"}
 
+    # Supplementary (never `value`): the same step on the dataset size of BASELINE configs[1] (ZINC-12k: 12 000 graphs,
+    # one launch sequence for the whole dataset; the working set sits in the 256 MB Infinity Cache at this size).
+    zinc12k = None
+    if world == 1 and G != 12000:
+        b2 = make_batch(12000, seed=77)
+        np2, ep2 = torch.from_numpy(b2.node_ptr).to(dev), torch.from_numpy(b2.edge_ptr).to(dev)
+        ei2 = torch.from_numpy(b2.edge_index).to(dev)
+        x2 = torch.nn.functional.one_hot(torch.from_numpy(b2.atom_type), 28).float().to(dev)
+        ef2 = torch.nn.functional.one_hot(torch.from_numpy(b2.bond_type), 4).float().to(dev)
+        deg2 = torch.zeros(b2.num_nodes, device=dev)
+        ids2 = torch.empty((b2.num_edges, plan.n_cols), dtype=torch.int64, device=dev)
+        mn2, me2 = int(np.diff(b2.node_ptr).max()), int(np.diff(b2.edge_ptr).max())
+
+        def step12k():
+            layers._CSR_CACHE.clear()
+            count_batch(plan, np2, ep2, ei2, ids_are_global=True, max_nodes=mn2, max_edges=me2, device=dev, out=ids2, check=False)
+            idf2 = layers.one_hot_identifiers(ids2, [3, 3, 3, 3], clamp=True)
+            with torch.no_grad():
+                return layer(x2, ei2, identifiers=idf2, degrees=deg2, edge_features=ef2)
+        for _ in range(max(args.warmup, 1)):
+            step12k()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(args.steps):
+            step12k()
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t2
+        zinc12k = {"graphs_per_s": round(12000 * args.steps / dt2, 1), "ms_per_step": round(dt2 / args.steps * 1e3, 4),
+                   "note": "BASELINE configs[1] dataset size: 12 000 ZINC-shaped graphs per step (N=%d, E=%d)" % (b2.num_nodes, b2.num_edges)}
+
     if rank == 0:
         kernels = {}
         merged = {}
@@ -255,6 +285,8 @@ def main():
         })
         if fused is not None:
             extra["fused_encoder_step"] = fused
+        if zinc12k is not None:
+            extra["zinc12k_step"] = zinc12k
         res = {
             "metric": "graphs/sec (orbit-count + GSN-e fwd), ZINC-shape batch; % HBM roofline",
             "value": round(world * G * args.steps / dt, 1), "unit": "graphs/s", "n_gpus": world, "steps": args.steps,
