@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""BASELINE configs[4]: counting-only throughput on synthetic Erdos-Renyi graphs G(n=128, m=1000) with the 21 connected
+five-vertex patterns (all_simple_graphs k=5: 58 vertex-orbit / 56 edge-orbit columns).  Graphs are independent units:
+every rank counts its own shard, no collective (weak scaling; barrier + max-over-ranks time only).
+
+    python scripts/bench_counting_er.py [--graphs 1024] [--mode vertex|edge]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 scripts/bench_counting_er.py"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from gsn_amd import synth  # noqa: E402
+from gsn_amd.counting import CountPlan, count_batch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--graphs", type=int, default=1024, help="graphs per launch per GPU")
+    ap.add_argument("--mode", default="vertex")
+    ap.add_argument("--induced", type=int, default=0)
+    ap.add_argument("--steps", type=int, default=5)
+    args = ap.parse_args()
+    rank, world, local = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if "RANK" in os.environ:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "orbits.npz"))
+    pats = [z["all_simple_graphs_5/%d/edges" % i].tolist() for i in range(21)]
+    plan = CountPlan.get(pats, args.mode, bool(args.induced))
+    unique = min(args.graphs, 256)
+    graphs = [synth.er_graph(128, 1000, 100000 * rank + s) for s in range(unique)]
+    graphs = [graphs[i % unique] for i in range(args.graphs)]
+    b = synth.collate(graphs)
+    node_ptr, edge_ptr = torch.from_numpy(b.node_ptr).to(dev), torch.from_numpy(b.edge_ptr).to(dev)
+    ei = torch.from_numpy(b.edge_index).to(dev)
+    rows = b.num_edges if args.mode == "edge" else b.num_nodes
+    out = torch.empty((rows, plan.n_cols), dtype=torch.int64, device=dev)
+    f = lambda: count_batch(plan, node_ptr, edge_ptr, ei, ids_are_global=True, max_nodes=128, max_edges=int(np.diff(b.edge_ptr).max()),
+                            device=dev, out=out, check=False)
+    f()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        f()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        total = int(out.sum().item())
+        print(json.dumps({"workload": "ER G(128,1000) x%d graphs/GPU, 21 five-vertex patterns, %s mode, induced=%d" % (args.graphs, args.mode, args.induced),
+                          "n_gpus": world, "graphs_per_s": round(world * args.graphs * args.steps / dt, 1),
+                          "ms_per_launch": round(dt / args.steps * 1e3, 3), "columns": plan.n_cols,
+                          "occurrence_positions_per_s": round(world * total * args.steps / dt, 1), "scaling": "weak"}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
