@@ -194,19 +194,72 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(int64_t m_rows, int n_co
     }
 }
 
-// adjoint: gT_c[code[r][c]] += g_out[r][...]; meta holds the GRADIENT table pointers.  fp32 atomics (rows collide).
-__global__ __launch_bounds__(256) void embed_bwd_kernel(int64_t m_rows, int n_cols, int d, int concat, const int64_t *codes,
-                                                        const int64_t *meta, const float *gout) {
-    const int64_t total = m_rows * n_cols * d;
+// adjoint: gT_c[code[r][c]] += g_out[r][...]; meta holds the GRADIENT table pointers.
+// Tables are tiny (a handful of rows for recoded counts or bond types) while M is the number of edges, so global float
+// atomics would serialise on a few hundred addresses (measured: 4.6 ms per call at 2*10^5 rows x 300).  A workgroup owns
+// (row chunk, 64-column slice, code column), accumulates its slice of the table in LDS (a wave covers the 64 columns of
+// one input row, so its lanes never collide) and flushes rows_c x 64 sums with one global atomic each.
+constexpr int EMB_DCH = 64;           // columns of the embedding handled by one workgroup
+constexpr int EMB_ROWS = 2048;        // input rows per workgroup
+constexpr int EMB_LDS_TABLE_ROWS = 256;
+
+__global__ __launch_bounds__(256) void embed_bwd_lds_kernel(int64_t m_rows, int n_cols, int d, int concat, const int64_t *codes,
+                                                            const int64_t *meta, const float *gout, int col0) {
+    extern __shared__ float acc[];                               // [rows_c][EMB_DCH]
+    const int c = col0 + blockIdx.z, j0 = blockIdx.y * EMB_DCH;
+    const int rows_c = (int)meta[n_cols + c];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = j0 + lane;
+    for (int i = threadIdx.x; i < rows_c * EMB_DCH; i += 256) acc[i] = 0.f;
+    __syncthreads();
     const int gw = concat ? n_cols * d : d;
+    const int64_t r0 = (int64_t)blockIdx.x * EMB_ROWS;
+    const int64_t r1 = r0 + EMB_ROWS < m_rows ? r0 + EMB_ROWS : m_rows;
+    if (j < d) {
+        for (int64_t r = r0 + wave; r < r1; r += 4) {
+            const int64_t code = codes[r * n_cols + c];
+            if (code < 0 || code >= rows_c) continue;
+            atomicAdd(&acc[(int)code * EMB_DCH + lane], gout[r * gw + (concat ? c * d + j : j)]);
+        }
+    }
+    __syncthreads();
+    float *tab = reinterpret_cast<float *>(meta[c]);
+    for (int i = threadIdx.x; i < rows_c * EMB_DCH; i += 256) {
+        const int row = i / EMB_DCH, jj = j0 + (i - row * EMB_DCH);
+        const float v = acc[i];
+        if (jj < d && v != 0.f) atomicAdd(tab + (int64_t)row * d + jj, v);
+    }
+}
+
+// large tables (> EMB_LDS_TABLE_ROWS rows): collisions are rare, plain global atomics
+__global__ __launch_bounds__(256) void embed_bwd_kernel(int64_t m_rows, int n_cols, int d, int concat, const int64_t *codes,
+                                                        const int64_t *meta, const float *gout, int only_col) {
+    const int64_t total = m_rows * d;
+    const int gw = concat ? n_cols * d : d;
+    const int c = only_col;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int64_t r = i / (n_cols * d);
-        const int rem = (int)(i - r * (n_cols * d));
-        const int c = rem / d, j = rem - c * d;
+        const int64_t r = i / d;
+        const int j = (int)(i - r * d);
         const int64_t code = codes[r * n_cols + c];
         if (code < 0 || code >= meta[n_cols + c]) continue;
-        const float g = gout[r * gw + (concat ? c * d + j : j)];
-        atomicAdd(reinterpret_cast<float *>(meta[c]) + code * d + j, g);
+        atomicAdd(reinterpret_cast<float *>(meta[c]) + code * d + j, gout[r * gw + (concat ? c * d + j : j)]);
+    }
+}
+
+// y = act((h - mean) * scale + shift) per column: the BatchNorm + activation of a stage whose pre-BN rows were
+// materialised together with their batch statistics (train mode, shapes outside the fused chain).  In place allowed.
+__global__ __launch_bounds__(256) void bn_act_kernel(int64_t total, int n_cols, const float *h, const float *mean,
+                                                     const float *scale, const float *shift, int act, float *out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % n_cols);
+        float y = (h[i] - (mean ? mean[c] : 0.f)) * (scale ? scale[c] : 1.f) + (shift ? shift[c] : 0.f);
+        switch (act) {
+            case 1: y = y > 0.f ? y : 0.f; break;
+            case 2: y = y > 0.f ? y : expm1f(y); break;
+            case 3: y = tanhf(y); break;
+            default: break;
+        }
+        out[i] = y;
     }
 }
 
@@ -271,12 +324,38 @@ extern "C" int gsn_embed_fwd_hip(int64_t m_rows, int n_cols, int d, int concat, 
 }
 
 extern "C" int gsn_embed_bwd_hip(int64_t m_rows, int n_cols, int d, int concat, const int64_t *codes, const int64_t *grad_meta,
-                                 const float *grad_out, void *stream) {
-    if (n_cols < 1 || d < 1 || !grad_meta || (m_rows > 0 && (!codes || !grad_out)))
+                                 const int64_t *table_rows, const float *grad_out, void *stream) {
+    if (n_cols < 1 || d < 1 || !grad_meta || !table_rows || (m_rows > 0 && (!codes || !grad_out)))
         return set_error(GSN_E_INVALID, "gsn_embed_bwd_hip: bad arguments");
     if (m_rows <= 0) return GSN_OK;
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for(m_rows * n_cols * d)), dim3(256), 0,
-                       reinterpret_cast<hipStream_t>(stream), m_rows, n_cols, d, concat, codes, grad_meta, grad_out);
-    GSN_LAUNCH_CHECK("embed_bwd_kernel");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    // consecutive columns with small tables share one launch (grid.z); a large table gets the plain-atomics kernel
+    int c = 0;
+    while (c < n_cols) {
+        if (table_rows[c] > EMB_LDS_TABLE_ROWS) {
+            hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for(m_rows * d)), dim3(256), 0, s, m_rows, n_cols, d, concat, codes,
+                               grad_meta, grad_out, c);
+            ++c;
+            continue;
+        }
+        int c1 = c;
+        int64_t max_rows = 0;
+        while (c1 < n_cols && table_rows[c1] <= EMB_LDS_TABLE_ROWS) { max_rows = table_rows[c1] > max_rows ? table_rows[c1] : max_rows; ++c1; }
+        const dim3 grid((unsigned)((m_rows + EMB_ROWS - 1) / EMB_ROWS), (unsigned)((d + EMB_DCH - 1) / EMB_DCH), (unsigned)(c1 - c));
+        hipLaunchKernelGGL(embed_bwd_lds_kernel, grid, dim3(256), (size_t)max_rows * EMB_DCH * sizeof(float), s, m_rows, n_cols, d,
+                           concat, codes, grad_meta, grad_out, c);
+        c = c1;
+    }
+    GSN_LAUNCH_CHECK("embed_bwd kernels");
+    return GSN_OK;
+}
+
+extern "C" int gsn_bn_act_hip(int64_t m_rows, int64_t n_cols, const float *h, const float *mean, const float *scale,
+                              const float *shift, int act, float *out, void *stream) {
+    if (n_cols < 1 || act < 0 || act > 3 || (m_rows > 0 && (!h || !out))) return set_error(GSN_E_INVALID, "gsn_bn_act_hip: bad arguments");
+    if (m_rows <= 0) return GSN_OK;
+    hipLaunchKernelGGL(bn_act_kernel, dim3(grid_for(m_rows * n_cols)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       m_rows * n_cols, (int)n_cols, h, mean, scale, shift, act, out);
+    GSN_LAUNCH_CHECK("bn_act_kernel");
     return GSN_OK;
 }

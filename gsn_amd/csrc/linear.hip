@@ -269,6 +269,7 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_kernel(LinArgs a, int k_pad
                         const float h = acc[i][j][r] + e_bias[j];
                         st_sum[j] += (double)h;
                         st_sq[j] += (double)h * (double)h;
+                        if (a.out) op[(int64_t)dr * a.n_out] = h;      // statistics AND the raw pre-BN rows in one pass
                     } else {
                         op[(int64_t)dr * a.n_out] = apply_act(fmaf(acc[i][j][r], e_scale[j], e_c0[j]), a.act);
                     }

@@ -208,9 +208,10 @@ class _EmbedFn(torch.autograd.Function):
         grads = [torch.zeros(s, dtype=torch.float32, device=dev) for s in ctx.shapes]
         meta = _table_meta(grads, dev)
         g = gout.to(torch.float32).contiguous()
+        rows = np.ascontiguousarray([s[0] for s in ctx.shapes], dtype=np.int64)
         with _abi.device_guard(dev):
             rc = _abi.lib().gsn_embed_bwd_hip(M, C, d, int(ctx.concat), codes.data_ptr() if M else None, meta.data_ptr(),
-                                              g.data_ptr() if M else None, _abi.current_stream())
+                                              _abi.ptr(rows), g.data_ptr() if M else None, _abi.current_stream())
         _abi.check(rc, "gsn_embed_bwd_hip")
         return (None, None) + tuple(grads)
 

@@ -473,6 +473,9 @@ def run_stages(stages, m_rows, training, csr=None):
     (returns None, before touching any BatchNorm state, if the stages do not fit one fused launch)."""
     if csr is not None and not _chain_fits(stages):
         return None
+    needs_stats = any(st.bn is not None and (training or st.bn.running_mean is None) for st in stages)
+    if csr is None and needs_stats and not _chain_fits(stages):
+        return _run_stages_materialised(stages, m_rows, training)
     for i, st in enumerate(stages):
         if st.bn is not None:
             def stats_fn(i=i):
@@ -483,6 +486,36 @@ def run_stages(stages, m_rows, training, csr=None):
                 return stats
             _bn_resolve(st, stats_fn, m_rows, training)
     return _launch_stages(stages, m_rows, csr=csr)
+
+
+def _bn_act_hip(h, bn_params, act):
+    """act(bn(h)) in place on materialised pre-BN rows (gsn_bn_act_hip)."""
+    vecs = [None if v is None else _f32c(v) for v in (bn_params or (None, None, None))]
+    with _abi.device_guard(h.device), _timed("bn_act", 8.0 * h.numel()):
+        rc = _abi.lib().gsn_bn_act_hip(h.shape[0], h.shape[1], h.data_ptr(), _abi.ptr(vecs[0]), _abi.ptr(vecs[1]), _abi.ptr(vecs[2]),
+                                       _ACT_CODE[act], h.data_ptr(), _abi.current_stream())
+    _abi.check(rc, "gsn_bn_act_hip")
+    return h
+
+
+def _run_stages_materialised(stages, m_rows, training):
+    """Train-mode stages outside the fused chain (e.g. d = 300): every BatchNorm stage writes its pre-BN rows AND their
+    column statistics in ONE pass of the linear kernel, then BatchNorm + activation are applied in place -- instead of a
+    statistics pass that recomputes the whole prefix (5 GEMM passes for Linear-BN-act-Linear-BN become 2)."""
+    y = None
+    for st in stages:
+        blks = st.blocks + ([(y, None)] if y is not None else [])
+        if st.bn is not None and (training or st.bn.running_mean is None):
+            n_out = st.weight.shape[0]
+            stats = torch.zeros((2, n_out), dtype=torch.float64, device=st.weight.device)
+            h = _linear_hip(blks, st.weight, st.bias, None, None, None, 0, m_rows, out=True, stats=stats)
+            _bn_resolve(st, lambda: stats, m_rows, training)
+            y = _bn_act_hip(h, st.bn_params, st.act)
+        else:
+            _bn_resolve(st, None, m_rows, training)
+            bp = st.bn_params or (None, None, None)
+            y = _linear_hip(blks, st.weight, st.bias, bp[0], bp[1], bp[2], _ACT_CODE[st.act], m_rows)
+    return y
 
 
 CODE_STATUS_CHECK = True   # read the out-of-range flag back after every code-gather launch (one host sync)

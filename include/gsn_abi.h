@@ -156,7 +156,8 @@ int gsn_propagate_bwd_hip(int kind, int64_t n_nodes, int64_t n_edges, const int6
  *   row_perm int32 [M] or NULL: output row r is computed from logical input row row_perm[r]
  *   out   [M][n_out] fp32, or NULL when only statistics are wanted
  *   stats double [2][n_out] or NULL: if given (train-mode BatchNorm1d, first pass) the kernel ADDS per-column sum and
- *         sum of squares of the PRE-BN values h = X W^T + bias into it (caller zeroes it) and skips bn / act / out
+ *         sum of squares of the PRE-BN values h = X W^T + bias into it (caller zeroes it) and skips bn / act; with
+ *         `out` also given the same pass writes those raw h rows to it (then apply gsn_bn_act_hip)
  * ---------------------------------------------------------------------------------------------------------------- */
 typedef struct {
     const float *data;     /* [rows][width] fp32, row stride = width */
@@ -239,12 +240,13 @@ int gsn_column_ranks_hip(int64_t m_rows, int n_cols, const int64_t *values, cons
  * [rows_c][d] row-major.  meta (device int64 [2C]) = table base addresses then rows_c.  concat != 0: out [M][C*d] is the
  * concatenation, else out [M][d] the sum over columns.  status (device int32, caller-zeroed) is raised to
  * GSN_ST_BAD_INDEX when a code is outside its table.  bwd accumulates grad_out into the gradient tables named by
- * grad_meta with fp32 atomics (caller zero-fills them).
+ * grad_meta (caller zero-fills them); table_rows = the row counts again as a HOST array [C] (they pick the kernel:
+ * tables of <= 256 rows are accumulated in LDS per workgroup, larger ones with global fp32 atomics).
  * ---------------------------------------------------------------------------------------------------------------- */
 int gsn_embed_fwd_hip(int64_t m_rows, int n_cols, int d, int concat, const int64_t *codes, const int64_t *meta,
                       float *out, int32_t *status, void *stream);
 int gsn_embed_bwd_hip(int64_t m_rows, int n_cols, int d, int concat, const int64_t *codes, const int64_t *grad_meta,
-                      const float *grad_out, void *stream);
+                      const int64_t *table_rows, const float *grad_out, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * First Linear of msg_fn over one-hot encoded inputs as a weight-row gather with fused bias / BatchNorm / activation
@@ -275,6 +277,14 @@ int gsn_code_stage_fwd_hip(int64_t m_rows, int n_slots, const gsn_code_slot *slo
                            const float *bias, int64_t n_out, const float *bn_mean, const float *bn_scale,
                            const float *bn_shift, int act, const int32_t *seg_target, float *out, double *stats,
                            int32_t *status, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * BatchNorm + activation applied to materialised pre-BN rows (device): y = act((h - mean) * scale + shift) per column,
+ * models_misc.mlp.forward (:52-59) for a train-mode stage whose statistics were taken in the same pass that wrote h
+ * (gsn_linear_fwd_hip with both `out` and `stats`).  h, out fp32 [M][C] row-major (may alias); vectors may be NULL.
+ * ---------------------------------------------------------------------------------------------------------------- */
+int gsn_bn_act_hip(int64_t m_rows, int64_t n_cols, const float *h, const float *mean, const float *scale,
+                   const float *shift, int act, float *out, void *stream);
 
 #ifdef __cplusplus
 }

@@ -326,3 +326,33 @@ def test_fused_scatter_add_vs_torch(N, E, hub):
     ref = torch.zeros(N, 96, dtype=torch.float64, device=dev).index_add_(0, tgt, msg)
     assert rel_err(out.double(), ref) < TOL
     assert (out[torch.bincount(tgt, minlength=N) == 0] == 0).all()
+
+
+@pytest.mark.parametrize("act", ["relu", "elu", "tanh"])
+def test_wide_mlp_train_mode_materialised_path(act):
+    """Shapes outside the fused chain (n_out > 128) in train mode: pre-BN rows + statistics in one linear pass, then
+    gsn_bn_act_hip -- against nn.Sequential of the same parameters, incl. the running statistics and a fused post-BN."""
+    from gsn_amd import layers
+    torch.manual_seed(3)
+    m = layers.mlp(70, 150, [200], 0, act, True).cuda().train()
+    post = torch.nn.BatchNorm1d(150).cuda().train()
+    ref = torch.nn.Sequential(torch.nn.Linear(70, 200), torch.nn.BatchNorm1d(200), layers.choose_activation(act) if act != "identity" else torch.nn.Identity(),
+                              torch.nn.Linear(200, 150), torch.nn.BatchNorm1d(150), torch.nn.ReLU()).cuda().train()
+    ref[0].load_state_dict(m.fc[0].state_dict()); ref[1].load_state_dict(m.bn[0].state_dict())
+    ref[3].load_state_dict(m.fc[1].state_dict()); ref[4].load_state_dict(post.state_dict())
+    x = torch.randn(777, 70, device="cuda")
+    called = []
+    orig = layers._run_stages_materialised
+    layers._run_stages_materialised = lambda *a, **k: (called.append(1), orig(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            y = m(x, post=(post, "relu"))
+            want = ref(x)
+    finally:
+        layers._run_stages_materialised = orig
+    assert called, "wide train-mode stages must take the materialised path"
+    assert float((y - want).abs().max()) <= 2e-5 * max(float(want.abs().max()), 1.0)
+    for a, b in ((m.bn[0], ref[1]), (post, ref[4])):
+        assert torch.allclose(a.running_mean, b.running_mean, rtol=1e-5, atol=1e-6)
+        assert torch.allclose(a.running_var, b.running_var, rtol=1e-4, atol=1e-6)
+        assert int(a.num_batches_tracked) == 1
