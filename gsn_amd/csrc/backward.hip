@@ -1,0 +1,259 @@
+// Backward of a dense models_misc.mlp stage on gfx950 (the adjoint of linear.hip / chain.hip for inputs that are plain
+// row-major blocks):   H = X W^T + b ,  Z = (H - mean) * scale + shift ,  Y = act(Z)        (models_misc.py:52-59)
+//
+//   gZ = gY * act'(Y)                                   (relu / elu / tanh / identity: all derivable from Y)
+//   train-mode BatchNorm1d (batch statistics over the M rows):  xh = (H - mean) * invstd
+//        g_beta = sum_r gZ ,  g_gamma = sum_r gZ * xh ,  gH = gamma * invstd * (gZ - g_beta / M - xh * g_gamma / M)
+//   eval-mode / no BN:  gH = gZ * scale
+//   gX = gH W   (gsn_linear_fwd_hip with W^T as the weight) ,   gW = gH^T X ,   gb = sum_r gH
+//
+// Kernels here: the two elementwise / column-reduction passes of the BN + activation adjoint (HBM-bound, fp64 column
+// sums) and the weight-gradient GEMM  gW[n_out][K] = gH^T X  on v_mfma_f32_32x32x2_f32, where the contraction runs over
+// the M rows: every MFMA consumes two rows (A[i][k] = gH[row k][col i], B[k][j] = X[row k][col j]), a workgroup owns one
+// 128 x 128 tile of gW and one slab of rows, accumulates in registers and adds its partial tile with float atomics.
+#include <hip/hip_runtime.h>
+
+#include "gsn_internal.h"
+
+namespace gsn {
+
+__device__ __forceinline__ float act_grad_from_y(float y, int act) {
+    switch (act) {
+        case 1: return y > 0.f ? 1.f : 0.f;
+        case 2: return y > 0.f ? 1.f : y + 1.f;          // elu: d/dz (e^z - 1) = y + 1 for z <= 0
+        case 3: return 1.f - y * y;                      // tanh
+        default: return 1.f;
+    }
+}
+
+// pass 1: column sums of gZ and gZ * xh (fp64 [2][C], caller zero-fills).  grid (blocks_x, ceil(C/64)); a wave covers 64
+// adjacent columns of one row, waves stride over rows.
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(int64_t m_rows, int n_cols, const float *gy, const float *y,
+                                                                const float *h, const float *mean, const float *invstd,
+                                                                int act, double *sums) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + lane;
+    const bool cok = c < n_cols;
+    const float mu = (cok && mean) ? mean[c] : 0.f, is = (cok && invstd) ? invstd[c] : 1.f;
+    double s1 = 0.0, s2 = 0.0;
+    if (cok) {
+        for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < m_rows; r += (int64_t)gridDim.x * 4) {
+            const int64_t i = r * n_cols + c;
+            const float gz = gy[i] * act_grad_from_y(y[i], act);
+            s1 += (double)gz;
+            s2 += (double)gz * (double)((h[i] - mu) * is);
+        }
+    }
+    __shared__ double red[2][4][64];
+    red[0][wave][lane] = s1;
+    red[1][wave][lane] = s2;
+    __syncthreads();
+    if (wave == 0 && cok) {
+        double a = 0.0, b = 0.0;
+        for (int w = 0; w < 4; ++w) { a += red[0][w][lane]; b += red[1][w][lane]; }
+        atomicAdd(&sums[c], a);
+        atomicAdd(&sums[n_cols + c], b);
+    }
+}
+
+// pass 2: gH (may alias gy).  train: coef = gamma * invstd, m1 = sums[0]/M, m2 = sums[1]/M;  otherwise gH = gZ * coef.
+// Also the column sums of gH (fp64 [C], caller zero-fills) = the bias gradient.
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(int64_t m_rows, int n_cols, const float *gy, const float *y,
+                                                               const float *h, const float *mean, const float *invstd,
+                                                               const float *coef, const double *sums, int act, float *gh,
+                                                               double *gbias) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + lane;
+    const bool cok = c < n_cols;
+    const float mu = (cok && mean) ? mean[c] : 0.f, is = (cok && invstd) ? invstd[c] : 1.f;
+    const float cf = (cok && coef) ? coef[c] : 1.f;
+    const float m1 = (cok && sums) ? (float)(sums[c] / (double)m_rows) : 0.f;
+    const float m2 = (cok && sums) ? (float)(sums[n_cols + c] / (double)m_rows) : 0.f;
+    double sb = 0.0;
+    if (cok) {
+        for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < m_rows; r += (int64_t)gridDim.x * 4) {
+            const int64_t i = r * n_cols + c;
+            const float gz = gy[i] * act_grad_from_y(y[i], act);
+            float g = gz;
+            if (sums) g = gz - m1 - (h[i] - mu) * is * m2;
+            g *= cf;
+            gh[i] = g;
+            sb += (double)g;
+        }
+    }
+    if (gbias) {
+        __shared__ double red[4][64];
+        red[wave][lane] = sb;
+        __syncthreads();
+        if (wave == 0 && cok) atomicAdd(&gbias[c], red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// weight gradient
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int WG_T = 128;          // gW tile edge
+constexpr int WG_RB = 16;          // rows per LDS chunk (2 x 2 x 16 x 132 floats = 33 KB of static LDS)
+constexpr int WG_PITCH = WG_T + 4; // LDS row pitch: the two row halves of a fragment read land 4 banks apart
+constexpr int WG_MAXB = 5;
+
+struct WgradArgs {
+    int64_t m_rows, rows_per_wg;
+    int n_out, k_total, n_blocks;
+    const float *gh;
+    const float *bdata[WG_MAXB];
+    int bwidth[WG_MAXB];
+    float *gw;
+};
+
+typedef float f32x16b __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
+    __shared__ float ta[2][WG_RB][WG_PITCH];      // gH rows x 128 output channels of this tile
+    __shared__ float tb[2][WG_RB][WG_PITCH];      // X rows  x 128 input columns of this tile
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w >> 1, wn = w & 1;            // the wave's 64 x 64 quadrant of the tile
+    const int li = lane & 31, lh = lane >> 5;
+    const int n0 = blockIdx.y * WG_T, k0 = blockIdx.z * WG_T;
+    const int64_t r_begin = (int64_t)blockIdx.x * a.rows_per_wg;
+    int64_t r_end = r_begin + a.rows_per_wg;
+    if (r_end > a.m_rows) r_end = a.m_rows;
+
+    // staging map: thread -> column (tid & 127) of the tile, rows (tid >> 7) + 2 i  (16 rows per thread per chunk)
+    const int sc = tid & 127, sr0 = tid >> 7;
+    const int ca = n0 + sc;
+    const bool ca_ok = ca < a.n_out;
+    const int kb = k0 + sc;
+    const bool kb_ok = kb < a.k_total;
+    const float *xb = a.bdata[0];
+    int xw = a.bwidth[0];
+    {
+        int blk = 0, col = kb_ok ? kb : 0;
+#pragma unroll
+        for (int b = 0; b < WG_MAXB - 1; ++b)
+            if (b < a.n_blocks - 1 && blk == b && col >= a.bwidth[b]) { col -= a.bwidth[b]; blk = b + 1; }
+#pragma unroll
+        for (int b = 1; b < WG_MAXB; ++b)
+            if (blk == b) { xb = a.bdata[b]; xw = a.bwidth[b]; }
+        xb += col;
+    }
+    const float *ga = a.gh + (ca_ok ? ca : 0);
+
+    f32x16b acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float pa[WG_RB / 2], pb[WG_RB / 2];
+    auto fetch = [&](int64_t row0) {
+#pragma unroll
+        for (int i = 0; i < WG_RB / 2; ++i) {
+            const int64_t r = row0 + sr0 + 2 * i;
+            const int64_t rc = r < r_end ? r : r_begin;            // clamped: masked to zero when stored
+            pa[i] = ga[rc * a.n_out];
+            pb[i] = xb[rc * xw];
+        }
+    };
+    auto store = [&](int buf, int64_t row0) {
+#pragma unroll
+        for (int i = 0; i < WG_RB / 2; ++i) {
+            const bool ok = row0 + sr0 + 2 * i < r_end;
+            ta[buf][sr0 + 2 * i][sc] = (ok && ca_ok) ? pa[i] : 0.f;
+            tb[buf][sr0 + 2 * i][sc] = (ok && kb_ok) ? pb[i] : 0.f;
+        }
+    };
+    if (r_begin >= r_end) return;                 // (block-uniform)
+    fetch(r_begin);
+    store(0, r_begin);
+    __syncthreads();
+    int buf = 0;
+    for (int64_t row0 = r_begin; row0 < r_end; row0 += WG_RB) {
+        const bool has_next = row0 + WG_RB < r_end;
+        if (has_next) fetch(row0 + WG_RB);
+        const float *pa0 = &ta[buf][lh][wm * 64 + li];
+        const float *pb0 = &tb[buf][lh][wn * 64 + li];
+#pragma unroll
+        for (int p = 0; p < WG_RB / 2; ++p) {
+            const float a0 = pa0[2 * p * WG_PITCH], a1 = pa0[2 * p * WG_PITCH + 32];
+            const float b0 = pb0[2 * p * WG_PITCH], b1 = pb0[2 * p * WG_PITCH + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (has_next) store(buf ^ 1, row0 + WG_RB);
+        __syncthreads();
+        buf ^= 1;
+    }
+    // C layout of a 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); rows = output channels
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int kcol = k0 + wn * 64 + j * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int nrow = n0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (nrow < a.n_out && kcol < a.k_total) atomicAdd(a.gw + (int64_t)nrow * a.k_total + kcol, acc[i][j][r]);
+            }
+        }
+}
+
+static int bgrid(int64_t m_rows) {
+    int64_t b = (m_rows + 3) / 4;
+    return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+}
+
+}  // namespace gsn
+
+using namespace gsn;
+
+extern "C" int gsn_bn_act_bwd_hip(int64_t m_rows, int64_t n_cols, const float *grad_y, const float *y, const float *h,
+                                  const float *mean, const float *invstd, const float *coef, int train_bn, int act,
+                                  double *sums, float *grad_h, double *grad_bias, void *stream) {
+    if (n_cols < 1 || act < 0 || act > 3 || (m_rows > 0 && (!grad_y || !y || !grad_h)) || (train_bn && (!h || !sums)))
+        return set_error(GSN_E_INVALID, "gsn_bn_act_bwd_hip: bad arguments");
+    if (m_rows <= 0) return GSN_OK;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid(bgrid(m_rows), (unsigned)((n_cols + 63) / 64));
+    if (train_bn)
+        hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, grid, dim3(256), 0, s, m_rows, (int)n_cols, grad_y, y, h, mean, invstd, act, sums);
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, grid, dim3(256), 0, s, m_rows, (int)n_cols, grad_y, y, train_bn ? h : y, mean,
+                       invstd, coef, train_bn ? sums : nullptr, act, grad_h, grad_bias);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(GSN_E_HIP, "bn_act_bwd kernels: %s", hipGetErrorString(e));
+    return GSN_OK;
+}
+
+extern "C" int gsn_wgrad_hip(int64_t m_rows, int64_t n_out, const float *grad_h, int n_blocks, const gsn_block *blocks,
+                             float *grad_w, void *stream) {
+    if (n_out < 1 || n_blocks < 1 || n_blocks > WG_MAXB || !blocks || !grad_w || (m_rows > 0 && !grad_h))
+        return set_error(GSN_E_INVALID, "gsn_wgrad_hip: bad arguments");
+    WgradArgs a{};
+    a.m_rows = m_rows; a.n_out = (int)n_out; a.gh = grad_h; a.gw = grad_w; a.n_blocks = n_blocks;
+    int k = 0;
+    for (int b = 0; b < n_blocks; ++b) {
+        if (!blocks[b].data || blocks[b].width <= 0) return set_error(GSN_E_INVALID, "gsn_wgrad_hip: block %d is empty", b);
+        if (blocks[b].idx || blocks[b].idx32) return set_error(GSN_E_UNSUPPORTED, "gsn_wgrad_hip: gathered blocks are not supported");
+        a.bdata[b] = blocks[b].data; a.bwidth[b] = (int)blocks[b].width;
+        k += (int)blocks[b].width;
+    }
+    a.k_total = k;
+    if (m_rows <= 0) return GSN_OK;
+    const int tn = (int)((n_out + WG_T - 1) / WG_T), tk = (k + WG_T - 1) / WG_T;
+    // enough row slabs to fill the chip, but slabs of at least 256 rows (each one ends with 128 x 128 atomics)
+    int64_t slabs = (2048 + tn * tk - 1) / (tn * tk);
+    int64_t rows_per = (m_rows + slabs - 1) / slabs;
+    if (rows_per < 256) rows_per = 256;
+    rows_per = (rows_per + WG_RB - 1) / WG_RB * WG_RB;
+    a.rows_per_wg = rows_per;
+    slabs = (m_rows + rows_per - 1) / rows_per;
+    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)slabs, (unsigned)tn, (unsigned)tk), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(GSN_E_HIP, "wgrad_kernel: %s", hipGetErrorString(e));
+    return GSN_OK;
+}

@@ -518,6 +518,173 @@ def _run_stages_materialised(stages, m_rows, training):
     return y
 
 
+
+# ------------------------------------------------------------------------------------------------------------------
+# native backward of dense stage lists (inputs = plain row-major blocks): gsn_bn_act_bwd_hip, gsn_wgrad_hip and the
+# forward linear kernel on W^T for the input gradient
+# ------------------------------------------------------------------------------------------------------------------
+NATIVE_DENSE_BACKWARD = True      # False: every mlp backward goes through the PyTorch twin (for comparison)
+
+
+def _transposed(w):
+    return w.detach().to(torch.float32).t().contiguous()
+
+
+class _DenseStagesFn(torch.autograd.Function):
+    """Forward: stage by stage on the linear kernel, keeping what the adjoint needs (stage outputs; pre-BN rows and batch
+    statistics of train-mode BatchNorm stages).  Backward: per stage  gY -> gH (BN + activation adjoint) -> gW, gb, gX."""
+
+    @staticmethod
+    def forward(ctx, spec, *tensors):
+        # spec: list of dicts {n_blocks, has_bias, bn (module or None), act};  tensors: blocks of stage 0, then per stage
+        # weight, [bias], [gamma, beta]
+        it = iter(tensors)
+        blocks0 = [next(it) for _ in range(spec[0]["n_blocks"])]
+        m_rows = blocks0[0].shape[0]
+        saved, meta = [], []
+        y = None
+        for si, sp in enumerate(spec):
+            w = next(it)
+            b = next(it) if sp["has_bias"] else None
+            bn = sp["bn"]
+            gamma = beta = None
+            if bn is not None and bn.affine:
+                gamma, beta = next(it), next(it)
+            blks = [(t, None) for t in blocks0] if si == 0 else [(y, None)]
+            n_out = w.shape[0]
+            if bn is not None:      # train-mode batch statistics (the caller routes eval-mode BN with grads to the twin)
+                stats = torch.zeros((2, n_out), dtype=torch.float64, device=w.device)
+                h = _linear_hip(blks, w, b, None, None, None, 0, m_rows, out=True, stats=stats)
+                st = _Stage(w, b, bn, sp["act"])
+                _bn_resolve(st, lambda: stats, m_rows, True)
+                mean32, scale, shift = st.bn_params
+                yy = torch.empty_like(h)
+                vecs = [_f32c(v) for v in (mean32, scale, shift)]
+                with _abi.device_guard(h.device), _timed("bn_act", 8.0 * h.numel()):
+                    _abi.check(_abi.lib().gsn_bn_act_hip(m_rows, n_out, h.data_ptr(), vecs[0].data_ptr(), vecs[1].data_ptr(),
+                                                         vecs[2].data_ptr(), _ACT_CODE[sp["act"]], yy.data_ptr(),
+                                                         _abi.current_stream()), "gsn_bn_act_hip")
+                invstd = scale / gamma.detach() if gamma is not None else scale
+                if gamma is not None:   # gamma may hold zeros: take invstd from the statistics instead of dividing
+                    mean64 = stats[0] / m_rows
+                    var = (stats[1] / m_rows - mean64 * mean64).clamp_min_(0.0)
+                    invstd = torch.rsqrt(var + bn.eps).to(torch.float32)
+                saved += [h, yy, vecs[0], invstd.contiguous(), vecs[1]]
+                meta.append(("bn", len(saved) - 5))
+                y = yy
+            else:
+                y = _linear_hip(blks, w, b, None, None, None, _ACT_CODE[sp["act"]], m_rows)
+                saved += [y]
+                meta.append(("plain", len(saved) - 1))
+        ctx.spec, ctx.meta, ctx.m_rows = spec, meta, m_rows
+        ctx.n_saved = len(saved)
+        ctx.save_for_backward(*saved, *tensors)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        spec, meta, m_rows = ctx.spec, ctx.meta, ctx.m_rows
+        allt = ctx.saved_tensors
+        saved, tensors = allt[:ctx.n_saved], allt[ctx.n_saved:]
+        L = _abi.lib()
+        # locate the per-stage tensors again
+        pos = spec[0]["n_blocks"]
+        blocks0 = list(tensors[:pos])
+        per = []
+        for sp in spec:
+            ent = {"w": tensors[pos], "w_i": pos}
+            pos += 1
+            if sp["has_bias"]:
+                ent["b_i"] = pos; pos += 1
+            if sp["bn"] is not None and sp["bn"].affine:
+                ent["g"] = tensors[pos]; ent["g_i"] = pos; ent["beta_i"] = pos + 1; pos += 2
+            per.append(ent)
+        grads = [None] * len(tensors)
+        dev = gy.device
+        g = gy.to(torch.float32).contiguous()
+        for si in range(len(spec) - 1, -1, -1):
+            sp, ent = spec[si], per[si]
+            kind, off = meta[si]
+            w = ent["w"]
+            n_out, k_total = w.shape
+            gbias = torch.zeros(n_out, dtype=torch.float64, device=dev)
+            gh = torch.empty((m_rows, n_out), dtype=torch.float32, device=dev)
+            act = _ACT_CODE[sp["act"]]
+            with _abi.device_guard(dev), _timed("bn_act_bwd", 16.0 * m_rows * n_out):
+                if kind == "bn":
+                    h, y, mean32, invstd, scale = saved[off:off + 5]
+                    sums = torch.zeros((2, n_out), dtype=torch.float64, device=dev)
+                    rc = L.gsn_bn_act_bwd_hip(m_rows, n_out, g.data_ptr(), y.data_ptr(), h.data_ptr(), mean32.data_ptr(),
+                                              invstd.data_ptr(), scale.data_ptr(), 1, act, sums.data_ptr(), gh.data_ptr(),
+                                              gbias.data_ptr(), _abi.current_stream())
+                else:
+                    y = saved[off]
+                    sums = None
+                    rc = L.gsn_bn_act_bwd_hip(m_rows, n_out, g.data_ptr(), y.data_ptr(), None, None, None, None, 0, act, None,
+                                              gh.data_ptr(), gbias.data_ptr(), _abi.current_stream())
+            _abi.check(rc, "gsn_bn_act_bwd_hip")
+            if kind == "bn" and "g_i" in ent:
+                grads[ent["g_i"]] = sums[1].to(torch.float32)
+                grads[ent["beta_i"]] = sums[0].to(torch.float32)
+            if "b_i" in ent:
+                grads[ent["b_i"]] = gbias.to(torch.float32)
+            # weight gradient
+            xin = blocks0 if si == 0 else [saved[meta[si - 1][1] + (1 if meta[si - 1][0] == "bn" else 0)]]
+            if ctx.needs_input_grad[1 + ent["w_i"]]:
+                gw = torch.zeros((n_out, k_total), dtype=torch.float32, device=dev)
+                arr = (_abi.gsn_block * len(xin))()
+                keep = []
+                for bi, t in enumerate(xin):
+                    t = _f32c(t); keep.append(t)
+                    arr[bi].data = t.data_ptr(); arr[bi].idx = None; arr[bi].idx32 = None; arr[bi].width = t.shape[1]
+                with _abi.device_guard(dev), _timed("wgrad", 2.0 * m_rows * n_out * k_total):
+                    _abi.check(L.gsn_wgrad_hip(m_rows, n_out, gh.data_ptr(), len(xin), arr, gw.data_ptr(), _abi.current_stream()),
+                               "gsn_wgrad_hip")
+                grads[ent["w_i"]] = gw
+            # input gradient
+            need_x = si > 0 or any(ctx.needs_input_grad[1 + bi] for bi in range(len(blocks0)))
+            if need_x:
+                gx = _linear_hip([(gh, None)], _transposed(w), None, None, None, None, 0, m_rows)
+                if si > 0:
+                    g = gx
+                else:
+                    o = 0
+                    for bi, t in enumerate(blocks0):
+                        wd = t.shape[1]
+                        if ctx.needs_input_grad[1 + bi]:
+                            grads[bi] = gx[:, o:o + wd]
+                        o += wd
+        return (None,) + tuple(grads)
+
+
+def _dense_native_ok(stages, training):
+    """Native backward covers: plain (un-gathered) blocks, BatchNorm only with batch statistics, <= 5 blocks."""
+    if not NATIVE_DENSE_BACKWARD or not stages or len(stages[0].blocks) > 5:
+        return False
+    for i, st in enumerate(stages):
+        if any(idx is not None for _, idx in st.blocks) or (i > 0 and st.blocks):
+            return False
+        if st.bn is not None and not (training or st.bn.running_mean is None):
+            return False
+        if st.bias is None and False:
+            return False
+    return True
+
+
+def run_stages_autograd(stages, m_rows, training):
+    """Differentiable evaluation of a dense stage list with the native adjoint."""
+    spec, tensors = [], []
+    tensors += [d for d, _ in stages[0].blocks]
+    for i, st in enumerate(stages):
+        spec.append({"n_blocks": len(st.blocks) if i == 0 else 0, "has_bias": st.bias is not None, "bn": st.bn, "act": st.act})
+        tensors.append(st.weight)
+        if st.bias is not None:
+            tensors.append(st.bias)
+        if st.bn is not None and st.bn.affine:
+            tensors += [st.bn.weight, st.bn.bias]
+    return _DenseStagesFn.apply(spec, *tensors)
+
+
 CODE_STATUS_CHECK = True   # read the out-of-range flag back after every code-gather launch (one host sync)
 
 
@@ -646,6 +813,10 @@ class mlp(nn.Module):
 
     def forward(self, x, post=None):
         _need_cuda(x, "mlp input")
+        if torch.is_grad_enabled():
+            stages = self.stages([(x, None)], post=post)
+            if _dense_native_ok(stages, self.training):
+                return run_stages_autograd(stages, x.shape[0], self.training)
         extra = list(post[0].parameters()) if (post is not None and post[0] is not None) else []
         return _run(self, lambda: self.hip_forward([(x, None)], x.shape[0], post=post),
                     lambda x_: self.torch_forward(x_, post=post), [x], extra_params=extra)
@@ -840,6 +1011,9 @@ class _SparseLayer(nn.Module):
             ts = list(ts)
             return tuple(None if t is None else (t.dense() if isinstance(t, Codes) else ts.pop(0)) for t in given)
 
+        if torch.is_grad_enabled() and NATIVE_DENSE_BACKWARD and (self.ogb or self.msg_kind == "gin"):
+            # gin / ogb: propagate (own HIP adjoint) -> axpy -> update_fn (native dense adjoint): no PyTorch twin needed
+            return self._twin(edge_index, _dense(x), _dense(ids), _dense(ef), post=post, native=True)
         extra = list(post[0].parameters()) if (post is not None and post[0] is not None) else []
         return _run(self, lambda: self._hip(edge_index, x, ids, ef, post), lambda *ts: self._twin(edge_index, *unpack(ts), post=post), inputs,
                     extra_params=extra)
@@ -953,18 +1127,20 @@ class _SparseLayer(nn.Module):
         return w_first
 
     # -- differentiable twin (PyTorch ops + the HIP propagate with its own adjoint) ---------------------------------
-    def _twin(self, edge_index, x, ids, ef, post=None):
+    def _twin(self, edge_index, x, ids, ef, post=None, native=False):
         n = x.shape[0]
         sel = self._sel()
         if self.ogb:
             per_node = self.has_ids and self.id_scope == "global"
             agg = propagate(1, edge_index, sel, n, a=x, b=ids if self.has_ids else None, c=ef, b_per_node=per_node)
             self_msg = x + ids if per_node else x
-            return self.update_fn.torch_forward((1 + self.eps) * self_msg + agg, post=post)
+            xin = (1 + self.eps) * self_msg + agg
+            return self.update_fn(xin, post=post) if native else self.update_fn.torch_forward(xin, post=post)
         if self.msg_kind == "gin":
             self_parts, ids_nb, ef_nb, per_node = self._gin_parts(x, ids, ef, n)
             agg = propagate(0, edge_index, sel, n, a=x, b=ids_nb, c=ef_nb, b_per_node=per_node)
-            return self.update_fn.torch_forward((1 + self.eps) * torch.cat(self_parts, -1) + agg, post=post)
+            xin = (1 + self.eps) * torch.cat(self_parts, -1) + agg
+            return self.update_fn(xin, post=post) if native else self.update_fn.torch_forward(xin, post=post)
         idx_i, idx_j = edge_index[sel], edge_index[1 - sel]
         parts = [x[idx_i], x[idx_j]]
         if self.has_ids:

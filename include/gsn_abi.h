@@ -286,6 +286,23 @@ int gsn_code_stage_fwd_hip(int64_t m_rows, int n_slots, const gsn_code_slot *slo
 int gsn_bn_act_hip(int64_t m_rows, int64_t n_cols, const float *h, const float *mean, const float *scale,
                    const float *shift, int act, float *out, void *stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Backward of a dense mlp stage  H = X W^T + b, Z = bn(H), Y = act(Z)  (models_misc.py:52-59) for inputs that are plain
+ * row-major blocks (device).  What PyTorch autograd does for the reference's nn.Linear / BatchNorm1d / activation.
+ *   gsn_bn_act_bwd_hip : grad_h = d/dH from grad_y.  y = the stage output (activation derivative is taken from it);
+ *       train_bn != 0: batch-statistics BatchNorm -- h = pre-BN rows, mean / invstd = the batch statistics, coef =
+ *       gamma * invstd, sums = fp64 [2][C] scratch (zero-filled) that receives sum(gZ) = grad beta and sum(gZ * xhat) =
+ *       grad gamma;  train_bn == 0: grad_h = gZ * coef (coef NULL = 1; h, mean, invstd, sums unused).
+ *       grad_bias (fp64 [C], zero-filled, may be NULL) receives the column sums of grad_h.  grad_h may alias grad_y.
+ *   gsn_wgrad_hip : grad_w[n_out][K] += grad_h^T X  with X the concatenation of `blocks` (no gathers); caller zero-fills.
+ *   The input gradient is gsn_linear_fwd_hip(grad_h, weight = W^T).
+ * ---------------------------------------------------------------------------------------------------------------- */
+int gsn_bn_act_bwd_hip(int64_t m_rows, int64_t n_cols, const float *grad_y, const float *y, const float *h,
+                       const float *mean, const float *invstd, const float *coef, int train_bn, int act, double *sums,
+                       float *grad_h, double *grad_bias, void *stream);
+int gsn_wgrad_hip(int64_t m_rows, int64_t n_out, const float *grad_h, int n_blocks, const gsn_block *blocks, float *grad_w,
+                  void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -356,3 +356,47 @@ def test_wide_mlp_train_mode_materialised_path(act):
         assert torch.allclose(a.running_mean, b.running_mean, rtol=1e-5, atol=1e-6)
         assert torch.allclose(a.running_var, b.running_var, rtol=1e-4, atol=1e-6)
         assert int(a.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("shape", [(333, 70, [200], 150), (1000, 16, [24], 8), (257, 130, [64, 96], 33), (64, 5, [], 7)])
+@pytest.mark.parametrize("act,bn,post", [("relu", True, True), ("elu", True, False), ("tanh", False, True), ("relu", False, False)])
+def test_mlp_native_backward_matches_autograd(shape, act, bn, post):
+    """gsn_bn_act_bwd_hip + gsn_wgrad_hip + the forward kernel on W^T against PyTorch autograd on the same parameters
+    (train mode: batch-statistics BatchNorm)."""
+    from gsn_amd import layers
+    m_rows, d_in, d_h, d_out = shape
+    torch.manual_seed(5)
+    m = layers.mlp(d_in, d_out, list(d_h), 0, act, bn).cuda().train()
+    pbn = torch.nn.BatchNorm1d(d_out).cuda().train() if post else None
+    pst = (pbn, "relu") if post else None
+    for mod in list(m.bn) + ([pbn] if post else []):
+        torch.nn.init.uniform_(mod.weight, 0.5, 1.5)
+        torch.nn.init.normal_(mod.bias, 0.0, 0.2)
+    x = torch.randn(m_rows, d_in, device="cuda", requires_grad=True)
+    gy = torch.randn(m_rows, d_out, device="cuda")
+    params = list(m.parameters()) + (list(pbn.parameters()) if post else [])
+    state = [b.clone() for b in m.buffers()] + ([b.clone() for b in pbn.buffers()] if post else [])
+
+    def run(native):
+        layers.NATIVE_DENSE_BACKWARD = native
+        for b, s0 in zip(list(m.buffers()) + (list(pbn.buffers()) if post else []), state):
+            b.copy_(s0)
+        for p in params + [x]:
+            p.grad = None
+        y = m(x, post=pst)
+        (y * gy).sum().backward()
+        return y.detach().clone(), [p.grad.clone() for p in params], x.grad.clone(), [b.clone() for b in m.buffers()]
+    try:
+        y1, g1, gx1, b1 = run(True)
+        y0, g0, gx0, b0 = run(False)
+    finally:
+        layers.NATIVE_DENSE_BACKWARD = True
+    scale = lambda t: max(float(t.abs().max()), 1e-6)
+    assert float((y1 - y0).abs().max()) <= 2e-5 * scale(y0)
+    gmax = max(scale(t) for t in g0)
+    for a, b_ in zip(g1, g0):
+        # (biases in front of a train-mode BatchNorm have zero gradient analytically: compare on the scale of the largest one)
+        assert float((a - b_).abs().max()) <= 2e-4 * max(scale(b_), 1e-2 * gmax), (a.shape, float((a - b_).abs().max()), scale(b_))
+    assert float((gx1 - gx0).abs().max()) <= 2e-4 * scale(gx0)
+    for a, b_ in zip(b1, b0):
+        assert torch.allclose(a.float(), b_.float(), rtol=1e-4, atol=1e-6)
