@@ -194,44 +194,11 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(int64_t m_rows, int n_co
     }
 }
 
-// adjoint: gT_c[code[r][c]] += g_out[r][...]; meta holds the GRADIENT table pointers.
-// Tables are tiny (a handful of rows for recoded counts or bond types) while M is the number of edges, so global float
-// atomics would serialise on a few hundred addresses (measured: 4.6 ms per call at 2*10^5 rows x 300).  A workgroup owns
-// (row chunk, 64-column slice, code column), accumulates its slice of the table in LDS (a wave covers the 64 columns of
-// one input row, so its lanes never collide) and flushes rows_c x 64 sums with one global atomic each.
 constexpr int EMB_DCH = 64;           // columns of the embedding handled by one workgroup
 constexpr int EMB_ROWS = 2048;        // input rows per workgroup
-constexpr int EMB_LDS_TABLE_ROWS = 256;
 
-__global__ __launch_bounds__(256) void embed_bwd_lds_kernel(int64_t m_rows, int n_cols, int d, int concat, const int64_t *codes,
-                                                            const int64_t *meta, const float *gout, int col0) {
-    extern __shared__ float acc[];                               // [rows_c][EMB_DCH]
-    const int c = col0 + blockIdx.z, j0 = blockIdx.y * EMB_DCH;
-    const int rows_c = (int)meta[n_cols + c];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int j = j0 + lane;
-    for (int i = threadIdx.x; i < rows_c * EMB_DCH; i += 256) acc[i] = 0.f;
-    __syncthreads();
-    const int gw = concat ? n_cols * d : d;
-    const int64_t r0 = (int64_t)blockIdx.x * EMB_ROWS;
-    const int64_t r1 = r0 + EMB_ROWS < m_rows ? r0 + EMB_ROWS : m_rows;
-    if (j < d) {
-        for (int64_t r = r0 + wave; r < r1; r += 4) {
-            const int64_t code = codes[r * n_cols + c];
-            if (code < 0 || code >= rows_c) continue;
-            atomicAdd(&acc[(int)code * EMB_DCH + lane], gout[r * gw + (concat ? c * d + j : j)]);
-        }
-    }
-    __syncthreads();
-    float *tab = reinterpret_cast<float *>(meta[c]);
-    for (int i = threadIdx.x; i < rows_c * EMB_DCH; i += 256) {
-        const int row = i / EMB_DCH, jj = j0 + (i - row * EMB_DCH);
-        const float v = acc[i];
-        if (jj < d && v != 0.f) atomicAdd(tab + (int64_t)row * d + jj, v);
-    }
-}
-
-// large tables (> EMB_LDS_TABLE_ROWS rows): collisions are rare, plain global atomics
+// adjoint for tables too large for the LDS path below: gT_c[code[r][c]] += g_out[r][...] with global fp32 atomics
+// (collisions are rare on large tables); meta holds the GRADIENT table pointers
 __global__ __launch_bounds__(256) void embed_bwd_kernel(int64_t m_rows, int n_cols, int d, int concat, const int64_t *codes,
                                                         const int64_t *meta, const float *gout, int only_col) {
     const int64_t total = m_rows * d;
@@ -261,6 +228,147 @@ __global__ __launch_bounds__(256) void bn_act_kernel(int64_t total, int n_cols, 
         }
         out[i] = y;
     }
+}
+
+// Small-table path of both directions (sum of table rows over all columns <= EMB_LDS_SUM_ROWS): a workgroup owns
+// (row chunk, 64-wide slice of the embedding) for ALL code columns: the table slices [sum rows][64] live in LDS, a wave
+// covers the 64 slice columns of one input row, eight rows per step so that their loads are in flight together.
+//   forward : out[r] = sum_c / concat_c  T_c[code_c][slice]                (tables copied to LDS once per workgroup)
+//   backward: gT_c[code_c][slice] += g[r]  in LDS (a wave's lanes never collide), one global atomic per entry at the end
+constexpr int EMB_LDS_SUM_ROWS = 448;      // 448 x 64 floats = 112 KiB
+constexpr int EMB_MAXC = 16;
+
+struct EmbArgs {
+    int64_t m_rows;
+    int n_cols, d, concat;
+    const int64_t *codes;
+    const int64_t *meta;          // table pointers, then row counts (device)
+    int row_off[EMB_MAXC + 1];    // prefix sums of the row counts (host copy)
+    const float *gout;            // backward
+    float *out;                   // forward
+    int32_t *status;              // forward
+};
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void embed_lds_kernel(EmbArgs a) {
+    extern __shared__ float tab[];                               // [sum rows][EMB_DCH]  (BWD: one copy per wave)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nwv = blockDim.x >> 6;
+    const int j0 = blockIdx.y * EMB_DCH, j = j0 + lane;
+    const int total_rows = a.row_off[a.n_cols];
+    // BWD: every wave accumulates into its OWN copy with plain read-modify-write (its lanes own distinct columns and a
+    // wave executes in order).  LDS float atomics were measured at ~0.7 us per instruction here.
+    float *mine = tab + (BWD ? wave * total_rows * EMB_DCH : 0);
+    if (BWD) {
+        for (int i = threadIdx.x; i < nwv * total_rows * EMB_DCH; i += blockDim.x) tab[i] = 0.f;
+    } else {
+        for (int c = 0; c < a.n_cols; ++c) {
+            const float *t = reinterpret_cast<const float *>(a.meta[c]);
+            const int rows_c = a.row_off[c + 1] - a.row_off[c];
+            for (int i = threadIdx.x; i < rows_c * EMB_DCH; i += 256) {
+                const int row = i / EMB_DCH, jj = j0 + (i - row * EMB_DCH);
+                tab[(a.row_off[c] + row) * EMB_DCH + (i - row * EMB_DCH)] = jj < a.d ? t[(int64_t)row * a.d + jj] : 0.f;
+            }
+        }
+    }
+    __syncthreads();
+    const int64_t r0 = (int64_t)blockIdx.x * EMB_ROWS;
+    const int64_t r1 = r0 + EMB_ROWS < a.m_rows ? r0 + EMB_ROWS : a.m_rows;
+    const int gw = a.concat ? a.n_cols * a.d : a.d;
+    if (j < a.d) {
+        for (int64_t rb = r0 + wave * 8; rb < r1; rb += 8 * nwv) {
+            if (BWD && !a.concat) {
+                float g[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) g[u] = a.gout[(rb + u < r1 ? rb + u : r1 - 1) * gw + j];
+                for (int c = 0; c < a.n_cols; ++c) {
+                    const int rows_c = a.row_off[c + 1] - a.row_off[c];
+                    int64_t code[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) code[u] = a.codes[(rb + u < r1 ? rb + u : r1 - 1) * a.n_cols + c];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (rb + u < r1 && code[u] >= 0 && code[u] < rows_c)
+                            mine[(a.row_off[c] + (int)code[u]) * EMB_DCH + lane] += g[u];
+                }
+            } else if (BWD) {
+                for (int c = 0; c < a.n_cols; ++c) {
+                    const int rows_c = a.row_off[c + 1] - a.row_off[c];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        if (rb + u >= r1) break;
+                        const int64_t code = a.codes[(rb + u) * a.n_cols + c];
+                        if (code >= 0 && code < rows_c)
+                            mine[(a.row_off[c] + (int)code) * EMB_DCH + lane] += a.gout[(rb + u) * gw + c * a.d + j];
+                    }
+                }
+            } else {
+                float acc[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+                for (int c = 0; c < a.n_cols; ++c) {
+                    const int rows_c = a.row_off[c + 1] - a.row_off[c];
+                    int64_t code[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) code[u] = a.codes[(rb + u < r1 ? rb + u : r1 - 1) * a.n_cols + c];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        float v = 0.f;
+                        if (code[u] >= 0 && code[u] < rows_c) v = tab[(a.row_off[c] + (int)code[u]) * EMB_DCH + lane];
+                        else atomicMax(a.status, GSN_ST_BAD_INDEX);
+                        if (a.concat) { if (rb + u < r1) a.out[(rb + u) * gw + c * a.d + j] = v; }
+                        else acc[u] += v;
+                    }
+                }
+                if (!a.concat) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (rb + u < r1) a.out[(rb + u) * gw + j] = acc[u];
+                }
+            }
+        }
+    }
+    if (BWD) {
+        __syncthreads();
+        for (int c = 0; c < a.n_cols; ++c) {
+            float *t = reinterpret_cast<float *>(a.meta[c]);
+            const int rows_c = a.row_off[c + 1] - a.row_off[c];
+            for (int i = threadIdx.x; i < rows_c * EMB_DCH; i += blockDim.x) {
+                const int row = i / EMB_DCH, jj = j0 + (i - row * EMB_DCH);
+                float v = 0.f;
+                for (int wv = 0; wv < nwv; ++wv) v += tab[(wv * total_rows + a.row_off[c] + row) * EMB_DCH + (i - row * EMB_DCH)];
+                if (jj < a.d && v != 0.f) atomicAdd(t + (int64_t)row * a.d + jj, v);
+            }
+        }
+    }
+}
+
+template <bool BWD>
+static int launch_embed_lds(EmbArgs &a, const int64_t *table_rows, hipStream_t s) {
+    a.row_off[0] = 0;
+    for (int c = 0; c < a.n_cols; ++c) a.row_off[c + 1] = a.row_off[c] + (int)table_rows[c];
+    // backward keeps one table copy per wave: 4 waves while that fits, else a single wave per workgroup
+    const int nwv = (!BWD || 4 * a.row_off[a.n_cols] <= EMB_LDS_SUM_ROWS) ? 4 : 1;
+    const size_t lds = (size_t)(BWD ? nwv : 1) * a.row_off[a.n_cols] * EMB_DCH * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&embed_lds_kernel<BWD>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                EMB_LDS_SUM_ROWS * EMB_DCH * (int)sizeof(float)) != hipSuccess)
+            return set_error(GSN_E_HIP, "embed_lds_kernel: cannot raise the LDS limit");
+        attr_set = true;
+    }
+    const dim3 grid((unsigned)((a.m_rows + EMB_ROWS - 1) / EMB_ROWS), (unsigned)((a.d + EMB_DCH - 1) / EMB_DCH));
+    hipLaunchKernelGGL(embed_lds_kernel<BWD>, grid, dim3(64 * nwv), lds, s, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(GSN_E_HIP, "embed_lds_kernel: %s", hipGetErrorString(e));
+    return GSN_OK;
+}
+
+static bool embed_lds_fits(int n_cols, const int64_t *table_rows) {
+    if (!table_rows || n_cols > EMB_MAXC) return false;
+    int64_t sum = 0;
+    for (int c = 0; c < n_cols; ++c) sum += table_rows[c];
+    return sum <= EMB_LDS_SUM_ROWS;
 }
 
 static int grid_for(int64_t items) {
@@ -312,10 +420,15 @@ extern "C" int gsn_column_ranks_hip(int64_t m_rows, int n_cols, const int64_t *v
 }
 
 extern "C" int gsn_embed_fwd_hip(int64_t m_rows, int n_cols, int d, int concat, const int64_t *codes, const int64_t *meta,
-                                 float *out, int32_t *status, void *stream) {
+                                 const int64_t *table_rows, float *out, int32_t *status, void *stream) {
     if (n_cols < 1 || d < 1 || !meta || !status || (m_rows > 0 && (!codes || !out)))
         return set_error(GSN_E_INVALID, "gsn_embed_fwd_hip: bad arguments");
     if (m_rows <= 0) return GSN_OK;
+    if (embed_lds_fits(n_cols, table_rows)) {
+        EmbArgs a{};
+        a.m_rows = m_rows; a.n_cols = n_cols; a.d = d; a.concat = concat; a.codes = codes; a.meta = meta; a.out = out; a.status = status;
+        return launch_embed_lds<false>(a, table_rows, reinterpret_cast<hipStream_t>(stream));
+    }
     const int64_t total = m_rows * (concat ? (int64_t)n_cols * d : d);
     hipLaunchKernelGGL(embed_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), m_rows,
                        n_cols, d, concat, codes, meta, out, status);
@@ -328,24 +441,15 @@ extern "C" int gsn_embed_bwd_hip(int64_t m_rows, int n_cols, int d, int concat, 
     if (n_cols < 1 || d < 1 || !grad_meta || !table_rows || (m_rows > 0 && (!codes || !grad_out)))
         return set_error(GSN_E_INVALID, "gsn_embed_bwd_hip: bad arguments");
     if (m_rows <= 0) return GSN_OK;
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    // consecutive columns with small tables share one launch (grid.z); a large table gets the plain-atomics kernel
-    int c = 0;
-    while (c < n_cols) {
-        if (table_rows[c] > EMB_LDS_TABLE_ROWS) {
-            hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for(m_rows * d)), dim3(256), 0, s, m_rows, n_cols, d, concat, codes,
-                               grad_meta, grad_out, c);
-            ++c;
-            continue;
-        }
-        int c1 = c;
-        int64_t max_rows = 0;
-        while (c1 < n_cols && table_rows[c1] <= EMB_LDS_TABLE_ROWS) { max_rows = table_rows[c1] > max_rows ? table_rows[c1] : max_rows; ++c1; }
-        const dim3 grid((unsigned)((m_rows + EMB_ROWS - 1) / EMB_ROWS), (unsigned)((d + EMB_DCH - 1) / EMB_DCH), (unsigned)(c1 - c));
-        hipLaunchKernelGGL(embed_bwd_lds_kernel, grid, dim3(256), (size_t)max_rows * EMB_DCH * sizeof(float), s, m_rows, n_cols, d,
-                           concat, codes, grad_meta, grad_out, c);
-        c = c1;
+    if (embed_lds_fits(n_cols, table_rows)) {
+        EmbArgs a{};
+        a.m_rows = m_rows; a.n_cols = n_cols; a.d = d; a.concat = concat; a.codes = codes; a.meta = grad_meta; a.gout = grad_out;
+        return launch_embed_lds<true>(a, table_rows, reinterpret_cast<hipStream_t>(stream));
     }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    for (int c = 0; c < n_cols; ++c)
+        hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for(m_rows * d)), dim3(256), 0, s, m_rows, n_cols, d, concat, codes, grad_meta,
+                           grad_out, c);
     GSN_LAUNCH_CHECK("embed_bwd kernels");
     return GSN_OK;
 }

@@ -189,9 +189,11 @@ class _EmbedFn(torch.autograd.Function):
         meta = _table_meta(tabs, dev)
         out = torch.empty((M, C * d if concat else d), dtype=torch.float32, device=dev)
         status = torch.zeros(1, dtype=torch.int32, device=dev)
+        rows = np.ascontiguousarray([t.shape[0] for t in tabs], dtype=np.int64)
         with _abi.device_guard(dev):
             rc = _abi.lib().gsn_embed_fwd_hip(M, C, d, int(concat), codes.data_ptr() if M else None, meta.data_ptr(),
-                                              out.data_ptr() if M else None, status.data_ptr(), _abi.current_stream())
+                                              _abi.ptr(rows), out.data_ptr() if M else None, status.data_ptr(),
+                                              _abi.current_stream())
         _abi.check(rc, "gsn_embed_fwd_hip")
         if int(status.item()) != 0:
             raise IndexError("index out of range in embedding table")

@@ -240,11 +240,12 @@ int gsn_column_ranks_hip(int64_t m_rows, int n_cols, const int64_t *values, cons
  * [rows_c][d] row-major.  meta (device int64 [2C]) = table base addresses then rows_c.  concat != 0: out [M][C*d] is the
  * concatenation, else out [M][d] the sum over columns.  status (device int32, caller-zeroed) is raised to
  * GSN_ST_BAD_INDEX when a code is outside its table.  bwd accumulates grad_out into the gradient tables named by
- * grad_meta (caller zero-fills them); table_rows = the row counts again as a HOST array [C] (they pick the kernel:
- * tables of <= 256 rows are accumulated in LDS per workgroup, larger ones with global fp32 atomics).
+ * grad_meta (caller zero-fills them).  table_rows = the row counts again as a HOST array [C] (NULL allowed in fwd): they
+ * pick the kernel -- tables that together have <= 448 rows are held in LDS per workgroup (64-wide slices), larger ones
+ * are read / accumulated in HBM.
  * ---------------------------------------------------------------------------------------------------------------- */
 int gsn_embed_fwd_hip(int64_t m_rows, int n_cols, int d, int concat, const int64_t *codes, const int64_t *meta,
-                      float *out, int32_t *status, void *stream);
+                      const int64_t *table_rows, float *out, int32_t *status, void *stream);
 int gsn_embed_bwd_hip(int64_t m_rows, int n_cols, int d, int concat, const int64_t *codes, const int64_t *grad_meta,
                       const int64_t *table_rows, const float *grad_out, void *stream);
 
