@@ -463,3 +463,50 @@ extern "C" int gsn_bn_act_hip(int64_t m_rows, int64_t n_cols, const float *h, co
     GSN_LAUNCH_CHECK("bn_act_kernel");
     return GSN_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// torch.cat((x[idx_0], x[idx_1], ids, e), -1) materialised (device): the training path of the `general` layers keeps the
+// assembled edge rows for the weight gradient (the inference path never builds them: chain.hip gathers on the fly).
+// ---------------------------------------------------------------------------------------------------------------------
+namespace gsn {
+constexpr int GC_MAXB = 6;
+struct GatherCatArgs {
+    int64_t m_rows;
+    int n_blocks, k_total;
+    const float *data[GC_MAXB];
+    const int64_t *idx[GC_MAXB];
+    const int32_t *idx32[GC_MAXB];
+    int width[GC_MAXB], off[GC_MAXB + 1];
+    float *out;
+};
+
+__global__ __launch_bounds__(256) void gather_cat_kernel(GatherCatArgs a) {
+    const int64_t total = a.m_rows * a.k_total;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / a.k_total;
+        const int k = (int)(i - r * a.k_total);
+        int b = 0;
+#pragma unroll
+        for (int q = 1; q < GC_MAXB; ++q)
+            if (q < a.n_blocks && k >= a.off[q]) b = q;
+        const int64_t src = a.idx32[b] ? (int64_t)a.idx32[b][r] : (a.idx[b] ? a.idx[b][r] : r);
+        a.out[i] = a.data[b][src * a.width[b] + (k - a.off[b])];
+    }
+}
+}  // namespace gsn
+
+extern "C" int gsn_gather_cat_hip(int64_t m_rows, int n_blocks, const gsn_block *blocks, float *out, void *stream) {
+    if (n_blocks < 1 || n_blocks > GC_MAXB || !blocks || (m_rows > 0 && !out)) return set_error(GSN_E_INVALID, "gsn_gather_cat_hip: bad arguments");
+    GatherCatArgs a{};
+    a.m_rows = m_rows; a.n_blocks = n_blocks; a.out = out; a.off[0] = 0;
+    for (int b = 0; b < n_blocks; ++b) {
+        if (!blocks[b].data || blocks[b].width <= 0) return set_error(GSN_E_INVALID, "gsn_gather_cat_hip: block %d is empty", b);
+        a.data[b] = blocks[b].data; a.idx[b] = blocks[b].idx; a.idx32[b] = blocks[b].idx32; a.width[b] = (int)blocks[b].width;
+        a.off[b + 1] = a.off[b] + a.width[b];
+    }
+    a.k_total = a.off[n_blocks];
+    if (m_rows <= 0) return GSN_OK;
+    hipLaunchKernelGGL(gather_cat_kernel, dim3(grid_for(m_rows * a.k_total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    GSN_LAUNCH_CHECK("gather_cat_kernel");
+    return GSN_OK;
+}

@@ -749,6 +749,46 @@ def _code_stage_segsum(mf, cblocks, csr, m_rows):
     return out
 
 
+
+class _GatherCatFn(torch.autograd.Function):
+    """cat(x[idx_i], x[idx_j], ids.., e) for the training path (gsn_gather_cat_hip); the adjoint of a gathered block is the
+    scatter-add over its index = the propagate kernel on the cached CSR of that edge_index row."""
+
+    @staticmethod
+    def forward(ctx, edge_index, n_nodes, modes, *tensors):
+        # modes[b]: 0 / 1 = rows gathered through edge_index[0] / edge_index[1], None = one row per edge
+        E = edge_index.shape[1]
+        ts = [_f32c(t) for t in tensors]
+        arr = (_abi.gsn_block * len(ts))()
+        keep = []
+        for b, (t, m) in enumerate(zip(ts, modes)):
+            arr[b].data = t.data_ptr(); arr[b].width = t.shape[1]; arr[b].idx32 = None; arr[b].idx = None
+            if m is not None:
+                idx = edge_index[m].contiguous(); keep.append(idx)
+                arr[b].idx = idx.data_ptr()
+        k_total = sum(t.shape[1] for t in ts)
+        out = torch.empty((E, k_total), dtype=torch.float32, device=edge_index.device)
+        with _abi.device_guard(out.device), _timed("gather_cat", 8.0 * out.numel()):
+            _abi.check(_abi.lib().gsn_gather_cat_hip(E, len(ts), arr, out.data_ptr() if E else None, _abi.current_stream()),
+                       "gsn_gather_cat_hip")
+        ctx.edge_index, ctx.n_nodes, ctx.modes = edge_index, n_nodes, modes
+        ctx.widths = [t.shape[1] for t in ts]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        grads, o = [], 0
+        for b, (w, m) in enumerate(zip(ctx.widths, ctx.modes)):
+            if not ctx.needs_input_grad[3 + b]:
+                grads.append(None)
+            else:
+                gb = g[:, o:o + w].contiguous()
+                # rows gathered through edge_index[m]: sum the per-edge gradients per vertex of that row
+                grads.append(gb if m is None else propagate(0, ctx.edge_index, m, ctx.n_nodes, b=gb))
+            o += w
+        return (None, None, None) + tuple(grads)
+
+
 class mlp(nn.Module):
     """models_misc.mlp (models_misc.py:18-59): Linear -> [BatchNorm1d] -> activation ... -> Linear, same attribute
     names (``fc``, ``bn``) so state dicts are interchangeable; forward runs on the HIP dense stages."""
@@ -1011,9 +1051,12 @@ class _SparseLayer(nn.Module):
             ts = list(ts)
             return tuple(None if t is None else (t.dense() if isinstance(t, Codes) else ts.pop(0)) for t in given)
 
-        if torch.is_grad_enabled() and NATIVE_DENSE_BACKWARD and (self.ogb or self.msg_kind == "gin"):
-            # gin / ogb: propagate (own HIP adjoint) -> axpy -> update_fn (native dense adjoint): no PyTorch twin needed
-            return self._twin(edge_index, _dense(x), _dense(ids), _dense(ef), post=post, native=True)
+        if torch.is_grad_enabled() and NATIVE_DENSE_BACKWARD:
+            # training: compositions of kernels that each have a HIP adjoint -- no PyTorch twin
+            if self.ogb or self.msg_kind == "gin":   # propagate -> axpy -> update_fn
+                return self._twin(edge_index, _dense(x), _dense(ids), _dense(ef), post=post, native=True)
+            if self._general_native_ok():
+                return self._general_train(edge_index, _dense(x), _dense(ids), _dense(ef), post)
         extra = list(post[0].parameters()) if (post is not None and post[0] is not None) else []
         return _run(self, lambda: self._hip(edge_index, x, ids, ef, post), lambda *ts: self._twin(edge_index, *unpack(ts), post=post), inputs,
                     extra_params=extra)
@@ -1108,6 +1151,40 @@ class _SparseLayer(nn.Module):
         msgs = mf.hip_forward(blocks, E)
         agg = propagate(0, edge_index, sel, n, b=msgs)
         return uf.hip_forward([(x, None), (agg, None)], n, post=post)
+
+
+    # -- differentiable `general` path on native adjoints ------------------------------------------------------------------
+    def _general_native_ok(self):
+        bns = list(self.msg_fn.bn) + list(self.update_fn.bn)
+        return len(self.msg_fn.fc) >= 2 and all(b.training or b.running_mean is None for b in bns) and self.training
+
+    def _general_train(self, edge_index, x, ids, ef, post):
+        """msg_fn's hidden stages on materialised edge rows -> sum per target -> [x | S | deg] through update_fn with the
+        folded first weight (the fold itself is three tiny PyTorch matrix products, so it stays differentiable)."""
+        n, sel = x.shape[0], self._sel()
+        E = edge_index.shape[1]
+        tensors, modes = [x, x], [sel, 1 - sel]
+        if self.has_ids:
+            if self.id_scope == "local":
+                tensors.append(ids); modes.append(None)
+            else:
+                tensors += [ids, ids]; modes += [sel, 1 - sel]
+        if self.has_ef:
+            tensors.append(ef); modes.append(None)
+        mf, uf = self.msg_fn, self.update_fn
+        if E > 0:
+            xe = _GatherCatFn.apply(edge_index, n, tuple(modes), *tensors)
+            r = run_stages_autograd(mf.stages([(xe, None)], upto=len(mf.fc) - 1), E, True)
+            s_agg = propagate(0, edge_index, sel, n, b=r)
+        else:
+            s_agg = torch.zeros((n, mf.fc[-2].weight.shape[0]), device=x.device)
+        csr = _csr_for(edge_index, sel, n)
+        last, w3 = mf.fc[-1], uf.fc[0].weight
+        d_x = x.shape[1]
+        w3x, w3a = w3[:, :d_x], w3[:, d_x:]
+        w_first = torch.cat([w3x, w3a @ last.weight, (w3a @ last.bias).unsqueeze(1)], 1)
+        stages = uf.stages([(x, None), (s_agg, None), (csr.deg, None)], first_weight=w_first, post=post)
+        return run_stages_autograd(stages, n, True)
 
     def _folded_first_weight(self, d_x):
         """[W3x | W3a W2 | W3a b2] (see _hip); recomputed only when one of the three parameters changed."""

@@ -304,6 +304,13 @@ int gsn_bn_act_bwd_hip(int64_t m_rows, int64_t n_cols, const float *grad_y, cons
 int gsn_wgrad_hip(int64_t m_rows, int64_t n_out, const float *grad_h, int n_blocks, const gsn_block *blocks, float *grad_w,
                   void *stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * out[r] = concat_b blocks[b].data[idx_b[r]]  (device): torch.cat((x_i, x_j, identifiers, edge_features), -1) of
+ * GSN_sparse.py:166-171 / GSN_edge_sparse.py:160-165 materialised as fp32 [M][sum widths].  Only the training path uses
+ * it (the assembled rows feed the weight gradient); inference gathers on the fly inside the dense kernels.
+ * ---------------------------------------------------------------------------------------------------------------- */
+int gsn_gather_cat_hip(int64_t m_rows, int n_blocks, const gsn_block *blocks, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
