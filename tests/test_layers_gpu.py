@@ -400,3 +400,40 @@ def test_mlp_native_backward_matches_autograd(shape, act, bn, post):
     assert float((gx1 - gx0).abs().max()) <= 2e-4 * scale(gx0)
     for a, b_ in zip(b1, b0):
         assert torch.allclose(a.float(), b_.float(), rtol=1e-4, atol=1e-6)
+
+
+def test_training_paths_use_native_adjoints():
+    """In train mode no layer kind falls back to the PyTorch twin: general -> _general_train, gin / ogb -> propagate +
+    native mlp; gradients reach every parameter and the inputs."""
+    from gsn_amd import layers, synth
+    b = synth.zinc_shape_batch(6, seed=3)
+    ei = torch.from_numpy(b.edge_index).cuda()
+    n, E = b.num_nodes, b.num_edges
+    base = dict(d_degree=1, degree_as_tag=False, retain_features=True, seed=0, activation_name="relu", bn=True, flow="source_to_target")
+    cases = [layers.GSN_edge_sparse(d_in=8, d_ef=3, d_id=5, id_scope="local", d_msg=16, d_up=16, d_h=[16], msg_kind="general", **base),
+             layers.GSN_sparse(d_in=8, d_id=5, id_scope="global", d_msg=None, d_up=16, d_h=[16], msg_kind="gin", train_eps=True,
+                               id_embedding="one_hot_encoder", extend_dims=True, **base),
+             layers.GSN_edge_sparse_ogb(d_in=8, d_ef=8, d_id=8, id_scope="local", d_msg=None, d_up=8, d_h=[16], msg_kind="ogb",
+                                        train_eps=True, **base)]
+    twin_calls = []
+    orig = layers._HipWithTorchBackward.apply
+    layers._HipWithTorchBackward.apply = staticmethod(lambda *a, **k: (twin_calls.append(1), orig(*a, **k))[1])
+    try:
+        for layer in cases:
+            layer = layer.cuda().train()
+            x = torch.randn(n, 8, device="cuda", requires_grad=True)
+            kw = {"degrees": torch.zeros(n, device="cuda")}
+            if isinstance(layer, layers.GSN_sparse):
+                kw["identifiers"] = torch.randn(n, 5, device="cuda")
+            elif isinstance(layer, layers.GSN_edge_sparse_ogb):
+                kw["identifiers"] = torch.randn(E, 8, device="cuda"); kw["edge_features"] = torch.randn(E, 8, device="cuda")
+            else:
+                kw["identifiers"] = torch.randn(E, 5, device="cuda"); kw["edge_features"] = torch.randn(E, 3, device="cuda")
+            y = layer(x, ei, **kw)
+            y.square().sum().backward()
+            assert x.grad is not None and torch.isfinite(x.grad).all()
+            missing = [k for k, p in layer.named_parameters() if p.grad is None]
+            assert not missing, missing
+    finally:
+        layers._HipWithTorchBackward.apply = orig
+    assert not twin_calls, "a training-mode layer went through the PyTorch twin"
