@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--graphs", type=int, default=65536, help="graphs per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the supplementary measurements (profiling runs: only the headline launches)")
     args = ap.parse_args()
 
     import torch
@@ -178,7 +179,7 @@ def main():
     # Supplementary (never `value`): the same step with the layer fed the integer codes instead of their dense one-hot
     # encodings (layers.Codes -> weight-row-gather edge stage); same parameters, same output to 1e-5.
     fused = None
-    if world == 1:
+    if world == 1 and not args.no_extras:
         xc = layers.Codes(torch.from_numpy(b.atom_type).to(dev), [28])
         efc = layers.Codes(torch.from_numpy(b.bond_type).to(dev), [4])
         layers.CODE_STATUS_CHECK = False          # atom / bond codes are in range by construction, counts are clamped
@@ -207,7 +208,7 @@ def main():
     # Supplementary (never `value`): the same step on the dataset size of BASELINE configs[1] (ZINC-12k: 12 000 graphs,
     # one launch sequence for the whole dataset; the working set sits in the 256 MB Infinity Cache at this size).
     zinc12k = None
-    if world == 1 and G != 12000:
+    if world == 1 and G != 12000 and not args.no_extras:
         b2 = make_batch(12000, seed=77)
         np2, ep2 = torch.from_numpy(b2.node_ptr).to(dev), torch.from_numpy(b2.edge_ptr).to(dev)
         ei2 = torch.from_numpy(b2.edge_index).to(dev)

@@ -10,8 +10,8 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
-SHORT="python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+BENCH="python $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras"
+SHORT="python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o r -- $BENCH > "$OUT/r.log" 2>&1 </dev/null
 timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS \
     --kernel-trace --output-format csv -d "$OUT" -o p -- $SHORT > "$OUT/p.log" 2>&1 </dev/null
