@@ -13,6 +13,8 @@
 // searches and writes both.  HBM traffic = read edge_index once (16 B/column) + write the int64 rows once.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "count_core.h"
 
 namespace gsn {
@@ -42,8 +44,9 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
     uint64_t *valid = reinterpret_cast<uint64_t *>(smem + a.off_valid);
     uint64_t *stack = reinterpret_cast<uint64_t *>(smem + a.off_stack);
     uint32_t *plan = reinterpret_cast<uint32_t *>(smem + a.off_plan);
-    uint8_t *eu = smem + a.off_eu;
-    uint8_t *ev = smem + a.off_ev;
+    typedef typename std::conditional<(W <= 4), uint8_t, uint16_t>::type vid_t;   // column endpoints
+    vid_t *eu = reinterpret_cast<vid_t *>(smem + a.off_eu);
+    vid_t *ev = reinterpret_cast<vid_t *>(smem + a.off_ev);
     int *rowstart = reinterpret_cast<int *>(smem + a.off_rowstart);
     int *last = reinterpret_cast<int *>(smem + a.off_last);
     uint64_t *out_lds = reinterpret_cast<uint64_t *>(smem + a.off_out);
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
             continue;
         }
         const int u = (int)u64, v = (int)v64;
-        if (edge_mode) { eu[c] = (uint8_t)u; ev[c] = (uint8_t)v; }
+        if (edge_mode) { eu[c] = (vid_t)u; ev[c] = (vid_t)v; }
         atomicMax(&misc[1], (u > v ? u : v) + 1);  // graph-tool creates vertices 0..max id, self-loop columns included
         if (u != v) {
             atomicOr(reinterpret_cast<unsigned long long *>(&A[u * W + (v >> 6)]), 1ull << (v & 63));
@@ -144,13 +147,13 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
     const uint64_t lane_lt = (1ull << lane) - 1ull;
 
     Lane<W> s;
-    s.l = -1; s.cnt = 0; s.k = 0; s.nfix = 0; s.fvec = 0; s.plan = plans;
+    s.l = -1; s.cnt = 0; s.k = 0; s.nfix = 0; s.fvec = fv_roots<W>(0, 0); s.plan = plans;
     s.balls = balls; s.ball_n = a.n_cap;
 #pragma unroll
     for (int w = 0; w < W; ++w) s.used.w[w] = 0ull;
     bool has_task = false, exhausted = false;
     int t_row = 0, t_col = 0, p_i = 0, p_e = 0;
-    uint64_t roots = 0;
+    FVec<W> roots = fv_roots<W>(0, 0);
     bool rev_missing = false;
     int mirror_row = -1;
 
@@ -194,10 +197,10 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
                             }
                         }
                         if (!live) p_i = p_e;
-                        roots = (uint64_t)u | ((uint64_t)v << 8);
+                        roots = fv_roots<W>(u, v);
                     } else {
                         if (t_row >= n_active) p_i = p_e;  // vertex beyond the largest id: not a vertex of the matched graph
-                        roots = (uint64_t)t_row;
+                        roots = fv_roots<W>(t_row, 0);
                     }
                 } else {
                     exhausted = true;
@@ -267,8 +270,8 @@ extern "C" int gsn_count_hip(const uint32_t *plan_host, const uint32_t *plan_dev
     if (!node_ptr || !edge_ptr || !out || !status) return set_error(GSN_E_INVALID, "gsn_count_hip: null pointer argument");
     if (!graph_ids) n_items = n_graphs;
     if (n_items <= 0) return GSN_OK;
-    if (max_nodes > 256)
-        return set_error(GSN_E_UNSUPPORTED, "graphs with more than 256 vertices (%lld) are outside this build", (long long)max_nodes);
+    if (max_nodes > 768)
+        return set_error(GSN_E_UNSUPPORTED, "graphs with more than 768 vertices (%lld) are outside this build", (long long)max_nodes);
     if (max_nodes < 1) max_nodes = 1;
     if (max_edges < 0) max_edges = 0;
 
@@ -283,10 +286,12 @@ extern "C" int gsn_count_hip(const uint32_t *plan_host, const uint32_t *plan_dev
     a.out = out; a.status = status;
     if (max_edges > 0 && !edge_index) return set_error(GSN_E_INVALID, "gsn_count_hip: edge_index is null");
 
-    const int W = max_nodes <= 64 ? 1 : (max_nodes <= 128 ? 2 : 4);
+    const int W = max_nodes <= 64 ? 1 : (max_nodes <= 128 ? 2 : (max_nodes <= 256 ? 4 : (max_nodes <= 512 ? 8 : 12)));
     const bool edge_mode = a.mode == GSN_MODE_EDGE;
     const int64_t rows_cap = edge_mode ? max_edges : max_nodes;
-    const int T = rows_cap * a.n_cols <= 512 ? 64 : 256;
+    // large graphs (W > 4: 16-bit vertex ids, adjacency up to 72 KiB) keep one wave per workgroup so that the candidate
+    // stack stays small; their parallelism comes from `split` workgroups per graph
+    const int T = (rows_cap * a.n_cols <= 512 || W > 4) ? 64 : 256;
     a.n_cap = (int)max_nodes; a.e_cap = (int)max_edges;
 
     int o = align_up((int)max_nodes * W * 8, 16);
@@ -294,8 +299,9 @@ extern "C" int gsn_count_hip(const uint32_t *plan_host, const uint32_t *plan_dev
     const int depth = a.kmax > 1 ? a.kmax - 1 : 1;
     a.off_stack = o; o += depth * W * T * 8;
     a.off_plan = o; o += align_up((int)plan_words * 4, 16);
-    a.off_eu = o; o += edge_mode ? align_up((int)max_edges, 16) : 0;
-    a.off_ev = o; o += edge_mode ? align_up((int)max_edges, 16) : 0;
+    const int vid_bytes = W > 4 ? 2 : 1;
+    a.off_eu = o; o += edge_mode ? align_up((int)max_edges * vid_bytes, 16) : 0;
+    a.off_ev = o; o += edge_mode ? align_up((int)max_edges * vid_bytes, 16) : 0;
     a.off_rowstart = o; o += edge_mode ? align_up(((int)max_nodes + 1) * 4, 16) : 0;
     a.off_last = o; o += edge_mode ? align_up((int)max_edges * 4, 16) : 0;
     a.off_misc = o; o += 16;
@@ -333,6 +339,8 @@ extern "C" int gsn_count_hip(const uint32_t *plan_host, const uint32_t *plan_dev
     if (W == 1) return launch<1, 256>(a, items, (size_t)o, st);
     if (W == 2 && T == 64) return launch<2, 64>(a, items, (size_t)o, st);
     if (W == 2) return launch<2, 256>(a, items, (size_t)o, st);
-    if (T == 64) return launch<4, 64>(a, items, (size_t)o, st);
-    return launch<4, 256>(a, items, (size_t)o, st);
+    if (W == 4 && T == 64) return launch<4, 64>(a, items, (size_t)o, st);
+    if (W == 4) return launch<4, 256>(a, items, (size_t)o, st);
+    if (W == 8) return launch<8, 64>(a, items, (size_t)o, st);
+    return launch<12, 64>(a, items, (size_t)o, st);
 }

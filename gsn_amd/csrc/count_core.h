@@ -6,7 +6,7 @@
 //
 // A "lane" owns one rooted search at a time:
 //   * the target graph is a bit matrix A[n][W] of 64-bit words (LDS on device),
-//   * the partial map f is packed 8 bits per level into one 64-bit register (n <= 256),
+//   * the partial map f is packed 8 bits per level into one 64-bit register (n <= 256; 16 bits / two registers above),
 //   * a frame per level holds the not-yet-tried candidates of that level (LDS stack on device, lane-interleaved),
 //   * one call to lane_step() pops one candidate, and either descends one level or -- at the last-but-one
 //     level -- adds popcount(candidates of the last level) to the lane's counter (the last level is never
@@ -60,6 +60,37 @@ GSN_HD int popc(const Bits<W> &b) {
     return c;
 }
 
+// Packed partial map: the image of level l sits at bits [VB*l, VB*l + VB) with VB = 8 for graphs of <= 256 vertices
+// (W <= 4: one 64-bit register for k <= 8) and VB = 16 above (two registers).
+template <int W>
+struct FVec {
+    static constexpr int VB = W <= 4 ? 8 : 16;
+    uint64_t lo, hi;   // hi is dead code for VB == 8
+};
+template <int W>
+GSN_HD int fv_get(const FVec<W> &f, int l) {
+    if (FVec<W>::VB == 8) return (int)((f.lo >> (8 * l)) & 0xffu);
+    const uint64_t w = l < 4 ? f.lo : f.hi;
+    return (int)((w >> (16 * (l & 3))) & 0xffffu);
+}
+template <int W>
+GSN_HD void fv_set(FVec<W> &f, int l, int v) {
+    if (FVec<W>::VB == 8) {
+        f.lo = (f.lo & ~(0xffull << (8 * l))) | ((uint64_t)v << (8 * l));
+    } else {
+        const int sh = 16 * (l & 3);
+        if (l < 4) f.lo = (f.lo & ~(0xffffull << sh)) | ((uint64_t)v << sh);
+        else f.hi = (f.hi & ~(0xffffull << sh)) | ((uint64_t)v << sh);
+    }
+}
+template <int W>
+GSN_HD FVec<W> fv_roots(int a, int b) {
+    FVec<W> f;
+    f.lo = (uint64_t)a | ((uint64_t)b << FVec<W>::VB);
+    f.hi = 0;
+    return f;
+}
+
 // Candidate set of level l given the packed partial map fvec (levels 0..l-1 assigned) and the set `used` of their images.
 //   desc = adj_mask | nonadj_mask<<8 | gt_mask<<16 | lt_mask<<24  (bit j <-> earlier level j)
 //   adj    : candidate must be a neighbour of f_j          (pattern edge)
@@ -70,12 +101,12 @@ GSN_HD int popc(const Bits<W> &b) {
 // `ball` = j | r<<3 (r = 0: none) with `balls` = the r-hop balls of the target graph, radius 2 at balls[v*W], radius 3 at
 // balls[(ball_n + v)*W] (nullptr: pruning off -- it never changes the result, only the work).
 template <int W>
-GSN_HD void candidates(Bits<W> &C, uint32_t desc, uint32_t ball, uint64_t fvec, const Bits<W> &used, const uint64_t *A,
+GSN_HD void candidates(Bits<W> &C, uint32_t desc, uint32_t ball, const FVec<W> &fvec, const Bits<W> &used, const uint64_t *A,
                        const uint64_t *valid, const uint64_t *balls, int ball_n) {
 #pragma unroll
     for (int w = 0; w < W; ++w) C.w[w] = valid[w] & ~used.w[w];
     if (balls && (ball >> 3)) {
-        const int fj = (int)((fvec >> (8 * (ball & 7u))) & 0xffu);
+        const int fj = fv_get<W>(fvec, (int)(ball & 7u));
         const uint64_t *row = balls + (size_t)(((ball >> 3) == 3 ? ball_n : 0) + fj) * W;
 #pragma unroll
         for (int w = 0; w < W; ++w) C.w[w] &= row[w];
@@ -84,7 +115,7 @@ GSN_HD void candidates(Bits<W> &C, uint32_t desc, uint32_t ball, uint64_t fvec, 
     while (m) {
         const int j = ctz64(m);
         m &= m - 1u;
-        const uint64_t *row = A + (int)((fvec >> (8 * j)) & 0xffu) * W;
+        const uint64_t *row = A + fv_get<W>(fvec, j) * W;
 #pragma unroll
         for (int w = 0; w < W; ++w) C.w[w] &= row[w];
     }
@@ -92,7 +123,7 @@ GSN_HD void candidates(Bits<W> &C, uint32_t desc, uint32_t ball, uint64_t fvec, 
     while (m) {
         const int j = ctz64(m);
         m &= m - 1u;
-        const uint64_t *row = A + (int)((fvec >> (8 * j)) & 0xffu) * W;
+        const uint64_t *row = A + fv_get<W>(fvec, j) * W;
 #pragma unroll
         for (int w = 0; w < W; ++w) C.w[w] &= ~row[w];
     }
@@ -101,7 +132,7 @@ GSN_HD void candidates(Bits<W> &C, uint32_t desc, uint32_t ball, uint64_t fvec, 
         const int jj = ctz64(m);
         m &= m - 1u;
         const bool lt = jj >= 8;
-        const int fj = (int)((fvec >> (8 * (jj & 7))) & 0xffu);
+        const int fj = fv_get<W>(fvec, jj & 7);
 #pragma unroll
         for (int w = 0; w < W; ++w) {
             const uint64_t bl = below_word(fj, w);                       // ids < fj
@@ -135,7 +166,7 @@ template <int W>
 struct Lane {
     int l;          // level whose frame is being consumed; < 0: no search in progress
     int k, nfix;
-    uint64_t fvec;  // partial map, 8 bits per level
+    FVec<W> fvec;   // partial map, VB bits per level
     uint64_t cnt;   // matches found so far for the current task (accumulates over the task's plans)
     Bits<W> used;   // images of levels 0 .. l-1
     const uint32_t *plan;
@@ -170,7 +201,7 @@ GSN_HD void frame_load(const uint64_t *stack, int sstride, int tid, int l, Bits<
 
 // Start the rooted search of `plan` with the root levels already in fvec.  May finish immediately (s.l < 0).
 template <int W>
-GSN_HD void lane_begin(Lane<W> &s, const uint32_t *plan, uint64_t fvec_roots, const uint64_t *A, const uint64_t *valid,
+GSN_HD void lane_begin(Lane<W> &s, const uint32_t *plan, const FVec<W> &fvec_roots, const uint64_t *A, const uint64_t *valid,
                        uint64_t *stack, int sstride, int tid) {
     const uint32_t h = plan[0];
     s.k = (int)(h & 0xffu);
@@ -180,8 +211,8 @@ GSN_HD void lane_begin(Lane<W> &s, const uint32_t *plan, uint64_t fvec_roots, co
     s.l = -1;
 #pragma unroll
     for (int w = 0; w < W; ++w) s.used.w[w] = 0ull;
-    bit_set<W>(s.used, (int)(fvec_roots & 0xffu));
-    if (s.nfix > 1) bit_set<W>(s.used, (int)((fvec_roots >> 8) & 0xffu));
+    bit_set<W>(s.used, fv_get<W>(fvec_roots, 0));
+    if (s.nfix > 1) bit_set<W>(s.used, fv_get<W>(fvec_roots, 1));
     if (s.nfix == s.k) { s.cnt += 1; return; }
     Bits<W> C;
     candidates<W>(C, plan[2 + s.nfix], plan_ball(plan, s.nfix), s.fvec, s.used, A, valid, s.balls, s.ball_n);
@@ -213,7 +244,7 @@ GSN_HD void lane_step(Lane<W> &s, const uint64_t *A, const uint64_t *valid, uint
     for (int w = 0; w < W; ++w) empty = empty && (M.w[w] == 0ull);
     // v >= 0 always: a frame is only ever stored non-empty or left through the `empty` path below
     const int l = s.l;
-    s.fvec = (s.fvec & ~(0xffull << (8 * l))) | ((uint64_t)v << (8 * l));
+    fv_set<W>(s.fvec, l, v);
     const int nl = l + 1;
     Bits<W> used2 = s.used;
     bit_set<W>(used2, v);
@@ -242,7 +273,7 @@ GSN_HD void lane_step(Lane<W> &s, const uint64_t *A, const uint64_t *valid, uint
     // this level is exhausted: climb to the nearest level that still has candidates
     int cl = l - 1;
     while (cl >= s.nfix) {
-        bit_clear<W>(s.used, (int)((s.fvec >> (8 * cl)) & 0xffu));
+        bit_clear<W>(s.used, fv_get<W>(s.fvec, cl));
         Bits<W> P;
         frame_load<W>(stack, sstride, tid, cl, P);
         bool pe = true;

@@ -45,17 +45,17 @@ static int run(const uint32_t *plan, int64_t n, int64_t E, const int64_t *src, c
     int status = 0;
     for (int col = 0; col < n_cols; ++col)
         for (int64_t row = 0; row < rows; ++row) {
-            Lane<W> s; s.l = -1; s.cnt = 0; s.k = 0; s.nfix = 0; s.fvec = 0; s.plan = plans;
+            Lane<W> s; s.l = -1; s.cnt = 0; s.k = 0; s.nfix = 0; s.fvec = fv_roots<W>(0, 0); s.plan = plans;
             s.balls = prune ? balls.data() : nullptr; s.ball_n = nb;
             for (int w = 0; w < W; ++w) s.used.w[w] = 0;
-            uint64_t roots; bool live = true, rev_missing = false;
+            FVec<W> roots = fv_roots<W>(0, 0); bool live = true, rev_missing = false;
             if (mode == GSN_MODE_EDGE) {
                 int u = (int)src[row], v = (int)dst[row];
                 live = u != v && last[(size_t)u * n + v] == row;
                 rev_missing = u != v && last[(size_t)v * n + u] < 0;
-                roots = (uint64_t)u | ((uint64_t)v << 8);
+                roots = fv_roots<W>(u, v);
             } else {
-                live = row < n_active; roots = (uint64_t)row;
+                live = row < n_active; roots = fv_roots<W>((int)row, 0);
             }
             if (live)
                 for (uint32_t p = col_ptr[col]; p < col_ptr[col + 1]; ++p) {
@@ -72,5 +72,7 @@ extern "C" int harness_count(const uint32_t *plan, int64_t n, int64_t E, const i
     if (n <= 64) return run<1>(plan, n, E, src, dst, out);
     if (n <= 128) return run<2>(plan, n, E, src, dst, out);
     if (n <= 256) return run<4>(plan, n, E, src, dst, out);
+    if (n <= 512) return run<8>(plan, n, E, src, dst, out);
+    if (n <= 768) return run<12>(plan, n, E, src, dst, out);
     return -1;
 }

@@ -138,3 +138,26 @@ def test_state_dict_keys_and_seeded_init_match_reference():
         keys = {k[3:] for k in c if k.startswith("sd/")}
         assert set(layer.state_dict().keys()) == keys, name
         layer.load_state_dict({k: torch.from_numpy(c["sd/" + k]) for k in keys})
+
+
+@pytest.mark.parametrize("n,mode", [(300, "vertex"), (620, "edge"), (768, "vertex")])
+def test_search_core_with_16_bit_vertex_ids_on_host(lib, harness, n, mode):
+    """Graphs beyond 256 vertices pack the partial map 16 bits per level (W = 8 / 12): plan + search core on the host vs
+    the oracle."""
+    import networkx as nx
+    from gsn_amd import synth
+    from gsn_amd.counting import CountPlan
+    from oracle import oracle
+    rng = np.random.default_rng(n)
+    nn, ei = synth.zinc_shape_graph(rng, mean_n=n, sd_n=0.0, n_min=n, n_max=n, ring_rate=n / 12.0)
+    pats = [list(nx.cycle_graph(k).edges) for k in (3, 4, 5, 6)] + [list(nx.star_graph(3).edges)]
+    plan = CountPlan(pats, mode, False, False)
+    E = ei.shape[1]
+    I64P, U32P = ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_uint32)
+    src, dst = np.ascontiguousarray(ei[0]), np.ascontiguousarray(ei[1])
+    out = np.zeros((E if mode == "edge" else nn, plan.n_cols), dtype=np.int64)
+    st = harness.harness_count(plan.table.ctypes.data_as(U32P), ctypes.c_int64(nn), ctypes.c_int64(E),
+                               src.ctypes.data_as(I64P), dst.ctypes.data_as(I64P), out.ctypes.data_as(I64P))
+    assert st == 0
+    ref = oracle.counts2ids(mode, False, np.array([0, nn]), np.array([0, E]), ei, pats, n_threads=4)
+    assert np.array_equal(out, ref) and out.sum() > 0

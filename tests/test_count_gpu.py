@@ -182,3 +182,48 @@ def test_errors():
             assert torch.equal(part[rows], full[rows])
         else:
             assert (part[rows] == -7).all()
+
+
+def _large_graphs():
+    """Graphs beyond 256 vertices (16-bit vertex ids, W = 8 / 12 words per adjacency row): PROTEINS-like sparse chains with
+    rings (max 620 vertices in the TU dataset), a COLLAB-like union of cliques, and one mixed batch with small graphs."""
+    from gsn_amd import synth
+    rng = np.random.default_rng(17)
+    out = []
+    for n in (300, 620, 768):
+        g = synth.zinc_shape_graph(rng, mean_n=n, sd_n=0.0, n_min=n, n_max=n, ring_rate=n / 14.0)
+        out.append(g)
+    n = 420
+    und = set()
+    for _ in range(9):
+        size = int(rng.integers(8, 22))
+        mem = rng.choice(n, size=size, replace=False)
+        for i in range(size):
+            for j in range(i + 1, size):
+                und.add((int(min(mem[i], mem[j])), int(max(mem[i], mem[j]))))
+    out.append((n, synth.undirected_to_edge_index(n, sorted(und))))
+    out.append(synth.er_graph(40, 90, 5))
+    return out
+
+
+@pytest.mark.parametrize("mode,pats,induced", [("vertex", "cycles", False), ("vertex", "cliques", False), ("edge", "cycles", True),
+                                               ("vertex", "cycles", True), ("edge", "cliques", False)])
+def test_large_graphs_vs_oracle(mode, pats, induced):
+    from gsn_amd import synth
+    from gsn_amd.counting import counts2ids_batch
+    from oracle import oracle
+    plist = _cycles(range(3, 7)) if pats == "cycles" else [list(nx.complete_graph(k).edges) for k in (3, 4, 5)]
+    b = synth.collate(_large_graphs())
+    got = counts2ids_batch(b, plist, mode, induced).cpu().numpy()
+    local = b.edge_index - np.repeat(b.node_ptr[:-1], np.diff(b.edge_ptr))[None, :]
+    ref = oracle.counts2ids(mode, induced, b.node_ptr, b.edge_ptr, local, plist, n_threads=8)
+    assert np.array_equal(got, ref)
+    assert got.sum() > 0
+
+
+def test_too_large_graph_is_refused():
+    from gsn_amd import _abi, synth
+    from gsn_amd.counting import counts2ids_batch
+    b = synth.collate([synth.er_graph(800, 1000, 1)])
+    with pytest.raises(_abi.GsnError, match="768"):
+        counts2ids_batch(b, _cycles([3]), "vertex", False)
