@@ -227,3 +227,48 @@ def test_too_large_graph_is_refused():
     b = synth.collate([synth.er_graph(800, 1000, 1)])
     with pytest.raises(_abi.GsnError, match="768"):
         counts2ids_batch(b, _cycles([3]), "vertex", False)
+
+
+@pytest.mark.parametrize("mode", ["vertex", "edge"])
+@pytest.mark.parametrize("induced", [False, True])
+def test_all_six_vertex_patterns_vs_oracle(mode, induced):
+    """--id_type all_simple_graphs --k 6: the 112 connected six-vertex patterns (their orbit tables are pinned to the
+    reference in orbits.npz) counted on small random graphs, against the oracle."""
+    from gsn_amd import synth
+    from gsn_amd.counting import counts2ids_batch
+    from oracle import oracle
+    z = load("orbits")
+    pats = [z["all_simple_graphs_6/%d/edges" % i].tolist() for i in range(112)]
+    graphs = [synth.er_graph(14, 30, 1), synth.er_graph(18, 40, 2), synth.er_graph(12, 40, 3), synth.er_graph(20, 30, 4)]
+    b = synth.collate(graphs)
+    got = counts2ids_batch(b, pats, mode, induced).cpu().numpy()
+    local = b.edge_index - np.repeat(b.node_ptr[:-1], np.diff(b.edge_ptr))[None, :]
+    ref = oracle.counts2ids(mode, induced, b.node_ptr, b.edge_ptr, local, pats, n_threads=8)
+    assert got.shape == ref.shape and got.shape[1] > 300
+    assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("k", [7, 8])
+def test_sampled_seven_and_eight_vertex_patterns_vs_oracle(k):
+    """k = 7 (a sample of the 853 connected atlas graphs) and k = 8 (random connected graphs): plan compiler incl.
+    symmetry breaking, distance constraints and 8-level searches, vertex and edge mode."""
+    from gsn_amd import synth
+    from gsn_amd.counting import counts2ids_batch
+    from oracle import oracle
+    rng = np.random.default_rng(k)
+    if k == 7:
+        from networkx.generators.atlas import graph_atlas_g
+        pool = [g for g in graph_atlas_g() if g.number_of_nodes() == 7 and nx.is_connected(g)]
+        pats = [list(pool[i].edges) for i in rng.choice(len(pool), size=40, replace=False)]
+    else:
+        pats = []
+        while len(pats) < 16:
+            g = nx.gnm_random_graph(8, int(rng.integers(7, 18)), seed=int(rng.integers(1 << 30)))
+            if nx.is_connected(g):
+                pats.append(list(g.edges))
+    b = synth.collate([synth.er_graph(13, 30, 11), synth.er_graph(16, 34, 12)])
+    local = b.edge_index - np.repeat(b.node_ptr[:-1], np.diff(b.edge_ptr))[None, :]
+    for mode in ("vertex", "edge"):
+        got = counts2ids_batch(b, pats, mode, False).cpu().numpy()
+        ref = oracle.counts2ids(mode, False, b.node_ptr, b.edge_ptr, local, pats, n_threads=8)
+        assert np.array_equal(got, ref), mode
