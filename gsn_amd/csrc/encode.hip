@@ -510,3 +510,41 @@ extern "C" int gsn_gather_cat_hip(int64_t m_rows, int n_blocks, const gsn_block 
     GSN_LAUNCH_CHECK("gather_cat_kernel");
     return GSN_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// BatchNorm1d bookkeeping of a train-mode stage in ONE launch (nn.BatchNorm1d semantics): from the fp64 column sums of the
+// pre-BN rows -> batch mean, biased variance, invstd, the epilogue vectors scale = gamma * invstd and shift = beta, and the
+// running statistics update (momentum, unbiased variance).  Replaces ~10 tiny PyTorch launches per BatchNorm stage.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace gsn {
+__global__ __launch_bounds__(256) void bn_finalize_kernel(int n_cols, double m_rows, double eps, double momentum, const double *stats,
+                                                          const float *gamma, const float *beta, float *running_mean,
+                                                          float *running_var, float *mean, float *invstd, float *scale, float *shift) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n_cols) return;
+    const double mu = stats[c] / m_rows;
+    double var = stats[n_cols + c] / m_rows - mu * mu;
+    var = var > 0.0 ? var : 0.0;
+    const float is = (float)(1.0 / sqrt(var + eps));
+    mean[c] = (float)mu;
+    invstd[c] = is;
+    scale[c] = gamma ? is * gamma[c] : is;
+    shift[c] = beta ? beta[c] : 0.f;
+    if (running_mean) {
+        const double unbiased = var * (m_rows / (m_rows > 1.0 ? m_rows - 1.0 : 1.0));
+        running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * (double)(float)mu);
+        running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * (double)(float)unbiased);
+    }
+}
+}  // namespace gsn
+
+extern "C" int gsn_bn_finalize_hip(int64_t n_cols, int64_t m_rows, double eps, double momentum, const double *stats,
+                                   const float *gamma, const float *beta, float *running_mean, float *running_var, float *mean,
+                                   float *invstd, float *scale, float *shift, void *stream) {
+    if (n_cols < 1 || m_rows < 1 || !stats || !mean || !invstd || !scale || !shift || ((running_mean != nullptr) != (running_var != nullptr)))
+        return set_error(GSN_E_INVALID, "gsn_bn_finalize_hip: bad arguments");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       (int)n_cols, (double)m_rows, eps, momentum, stats, gamma, beta, running_mean, running_var, mean, invstd, scale, shift);
+    GSN_LAUNCH_CHECK("bn_finalize_kernel");
+    return GSN_OK;
+}

@@ -319,11 +319,12 @@ def _linear_hip(blocks, weight, bias, bn_mean, bn_scale, bn_shift, act, m_rows, 
 
 class _Stage:
     """One Linear (+BatchNorm1d) (+activation) stage: ``act(bn([blocks | previous output] W^T + b))``."""
-    __slots__ = ("blocks", "weight", "bias", "bn", "act", "bn_params")
+    __slots__ = ("blocks", "weight", "bias", "bn", "act", "bn_params", "bn_invstd")
 
     def __init__(self, weight, bias, bn=None, act="identity", blocks=()):
         self.blocks, self.weight, self.bias, self.bn, self.act = list(blocks), weight, bias, bn, act
         self.bn_params = None  # (mean, scale, shift) once resolved
+        self.bn_invstd = None  # batch invstd of a train-mode stage (for the adjoint)
 
 
 def _launch_stages(stages, m_rows, stats=None, csr=None):
@@ -436,17 +437,25 @@ def _bn_resolve(stage, stats_fn, m_rows, training):
         return
     if training or bn.running_mean is None:
         stats = stats_fn()
-        mean = stats[0] / m_rows
-        var = (stats[1] / m_rows - mean * mean).clamp_min_(0.0)
-        if training and bn.track_running_stats and bn.running_mean is not None:
-            with torch.no_grad():
-                bn.num_batches_tracked += 1
-                mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-                unbiased = var * (m_rows / max(m_rows - 1, 1))
-                bn.running_mean.mul_(1 - mom).add_(mean.to(torch.float32) * mom)
-                bn.running_var.mul_(1 - mom).add_(unbiased.to(torch.float32) * mom)
-        mean32 = mean.to(torch.float32)
-        invstd = torch.rsqrt(var + bn.eps).to(torch.float32)
+        n_out = stats.shape[1]
+        dev = stats.device
+        vec = torch.empty((4, n_out), dtype=torch.float32, device=dev)       # mean, invstd, scale, shift
+        track = training and bn.track_running_stats and bn.running_mean is not None
+        mom = 0.0
+        if track:
+            bn.num_batches_tracked += 1
+            mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+        gamma = _f32c(bn.weight) if bn.affine else None
+        beta = _f32c(bn.bias) if bn.affine else None
+        with _abi.device_guard(dev):
+            rc = _abi.lib().gsn_bn_finalize_hip(n_out, m_rows, float(bn.eps), float(mom), stats.data_ptr(), _abi.ptr(gamma), _abi.ptr(beta),
+                                                bn.running_mean.data_ptr() if track else None, bn.running_var.data_ptr() if track else None,
+                                                vec[0].data_ptr(), vec[1].data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(),
+                                                _abi.current_stream())
+        _abi.check(rc, "gsn_bn_finalize_hip")
+        stage.bn_params = (vec[0], vec[2], vec[3])
+        stage.bn_invstd = vec[1]
+        return
     else:
         # eval mode: the three vectors depend only on the module's buffers / parameters -> cached on their versions
         key = (bn.running_mean._version, bn.running_var._version, bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
@@ -564,11 +573,7 @@ class _DenseStagesFn(torch.autograd.Function):
                     _abi.check(_abi.lib().gsn_bn_act_hip(m_rows, n_out, h.data_ptr(), vecs[0].data_ptr(), vecs[1].data_ptr(),
                                                          vecs[2].data_ptr(), _ACT_CODE[sp["act"]], yy.data_ptr(),
                                                          _abi.current_stream()), "gsn_bn_act_hip")
-                invstd = scale / gamma.detach() if gamma is not None else scale
-                if gamma is not None:   # gamma may hold zeros: take invstd from the statistics instead of dividing
-                    mean64 = stats[0] / m_rows
-                    var = (stats[1] / m_rows - mean64 * mean64).clamp_min_(0.0)
-                    invstd = torch.rsqrt(var + bn.eps).to(torch.float32)
+                invstd = st.bn_invstd
                 saved += [h, yy, vecs[0], invstd.contiguous(), vecs[1]]
                 meta.append(("bn", len(saved) - 5))
                 y = yy

@@ -311,6 +311,16 @@ int gsn_wgrad_hip(int64_t m_rows, int64_t n_out, const float *grad_h, int n_bloc
  * ---------------------------------------------------------------------------------------------------------------- */
 int gsn_gather_cat_hip(int64_t m_rows, int n_blocks, const gsn_block *blocks, float *out, void *stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Train-mode BatchNorm1d bookkeeping (device), what nn.BatchNorm1d does around the normalisation (models_misc.py:41-45):
+ * stats fp64 [2][C] = column sum and sum of squares of the M pre-BN rows ->  mean, invstd = 1/sqrt(biased var + eps),
+ * scale = gamma * invstd, shift = beta (gamma / beta NULL: 1 / 0), and running_mean / running_var (both or neither)
+ * updated with `momentum` and the unbiased variance.  All vectors fp32 [C], one launch.
+ * ---------------------------------------------------------------------------------------------------------------- */
+int gsn_bn_finalize_hip(int64_t n_cols, int64_t m_rows, double eps, double momentum, const double *stats, const float *gamma,
+                        const float *beta, float *running_mean, float *running_var, float *mean, float *invstd, float *scale,
+                        float *shift, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
