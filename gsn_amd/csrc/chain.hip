@@ -309,7 +309,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
                         for (int r = 0; r < SEG_ROWS; ++r) {
                             const int t = tg[rb + r];
                             if (t != curt) {
-                                if (curt >= 0) {
+                                if (curt >= 0 && !(a.dbg & 8)) {
                                     if (straddle) atomicAdd(op + (int64_t)curt * st.n_out, sum);
                                     else op[(int64_t)curt * st.n_out] = sum;
                                 }
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
                             }
                             sum += yp[r * pitch];
                         }
-                        if (curt >= 0) {
+                        if (curt >= 0 && !(a.dbg & 8)) {
                             if (straddle || curt == next_t) atomicAdd(op + (int64_t)curt * st.n_out, sum);
                             else op[(int64_t)curt * st.n_out] = sum;
                         }

@@ -32,7 +32,7 @@ struct ChainArgs {
     float *out;                 // [m_rows][n_out], or [n_seg][n_out] segment sums when seg_target is given
     double *stats;              // statistics of the LAST stage's pre-BN values instead of an output
     int pitch;                  // LDS row pitch in floats (odd)
-    int dbg;                    // ablation switches for profiling (env GSN_CHAIN_DBG): 1 no prefetch loads, 2 no MFMA, 4 no output
+    int dbg;                    // ablation switches for profiling (env GSN_CHAIN_DBG): 2 no MFMA, 4 no output, 8 no stores of the fused scatter-add
 };
 
 constexpr int RS_STRIDE = (CMAX_BLOCKS + 1) * CBM + 2;  // per slot: row sources per block, row targets, prev / next target
