@@ -56,9 +56,8 @@ __global__ __launch_bounds__(256) void code_stage_kernel(CodeStageArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int g = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pitch = (a.n_out + 3) & ~3;
-    const int row_bytes = pitch * 4;
     const int j0 = lane * CPL;                             // first column of this lane
-    const int jb = (j0 < pitch ? j0 : 0) * 4;              // LDS byte offset of it (lanes beyond the row read column 0)
+    const int jb = j0 < pitch ? j0 : 0;                    // LDS column of it (lanes beyond the row read column 0)
     for (int i = tid; i < (a.k_total + 1) * pitch; i += 256) {
         const int r = i / pitch, c = i - r * pitch;
         wt[i] = (r < a.k_total && c < a.n_out) ? a.wt[r * a.n_out + c] : 0.f;
@@ -98,8 +97,9 @@ __global__ __launch_bounds__(256) void code_stage_kernel(CodeStageArgs a) {
     const int n_slots = a.n_slots;
     const int my_slot = lane & 7;
     const float act_floor = a.act == 1 ? 0.f : -INFINITY;   // identity / relu as one max
-    const int zero_off = a.k_total * row_bytes;
-    const char *wtb = reinterpret_cast<const char *>(wt);
+    // row offsets are kept in FLOATS and every access goes through `wt` itself: a char* view of the LDS array loses its
+    // address space and turns the gathers into FLAT loads
+    const int zero_off = a.k_total * pitch;
 
     auto flush = [&](int target, bool atomic) {
         float *o = a.out + (int64_t)target * a.n_out + j0;
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void code_stage_kernel(CodeStageArgs a) {
                         if (d.clamp) code = code < 0 ? 0 : d.n_classes - 1;
                         else { atomicMax(a.status, GSN_ST_BAD_INDEX); code = 0; }
                     }
-                    off = (d.w_off + (int)code) * row_bytes;
+                    off = (d.w_off + (int)code) * pitch;
                 }
                 kv[u][p] = off;
             }
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void code_stage_kernel(CodeStageArgs a) {
 #pragma unroll
                 for (int s = 0; s < NSLOT; ++s) {
                     const int base = __builtin_amdgcn_readlane(kv[u][s >> 3], t * 8 + (s & 7));
-                    hv[s] = *reinterpret_cast<const vec_t *>(wtb + base + jb);
+                    hv[s] = *reinterpret_cast<const vec_t *>(&wt[base + jb]);
                 }
                 vec_t h = hv[0];
 #pragma unroll
