@@ -6,14 +6,18 @@ GSN_edge_sparse_ogb.py, MPNN_edge_sparse_ogb.py and models_misc.mlp of the refer
 (`load_state_dict`) and ``models_graph_classification.py`` can instantiate them unchanged.
 
 Forward pass = libgsn_hip.so kernels only:
-  * gsn_csr_build_hip      target-sorted CSR of the batch (cached per edge_index)
-  * gsn_linear_fwd_hip     every Linear(+BatchNorm1d)(+activation) stage, input rows gathered / concatenated on the fly
-  * gsn_propagate_fwd_hip  the scatter-add (and the gin / ogb message assembly)
+  * gsn_csr_build_hip        target-sorted CSR of the batch (cached per edge_index)
+  * gsn_mlp_chain_fwd_hip    one or two fused Linear(+BatchNorm1d)(+activation) stages, input rows gathered / concatenated on
+                             the fly, optionally with the scatter-add fused into the epilogue (gsn_segsum_prepare_hip)
+  * gsn_linear_fwd_hip       the same stage for shapes outside the fused kernel (any K / n_out, elu / tanh)
+  * gsn_propagate_fwd_hip    the stand-alone scatter-add (and the gin / ogb message assembly)
+  * gsn_code_stage_fwd_hip   first Linear over integer-coded inputs as a weight-row gather (``Codes``)
 Restructuring that only changes fp32 rounding order (tolerance 1e-5, tests/test_layers_gpu.py): for
 ``msg_kind='general'`` the last Linear of ``msg_fn`` is applied after the sum aggregation,
 ``sum_e (W r_e + b) = W (sum_e r_e) + deg * b`` (SURVEY.md 7 "design notes for the MP kernels").
-Backward: the scatter-add has its own HIP adjoint (gsn_propagate_bwd_hip); the dense stages are re-computed through
-PyTorch autograd on the GPU (rocBLAS) -- see DESIGN.md "what is not native yet".
+Backward (training) = kernels with their own adjoints composed under autograd: gsn_propagate_bwd_hip (scatter-add),
+gsn_bn_act_bwd_hip + gsn_wgrad_hip + the forward kernel on W^T (dense stages), gsn_gather_cat_hip (edge rows of the
+general layers).  A PyTorch re-computation remains only for gradients with BatchNorm in eval mode.
 There is no CPU path: calling a layer on CPU tensors raises.
 """
 from __future__ import annotations
