@@ -862,7 +862,7 @@ class mlp(nn.Module):
 
     def forward(self, x, post=None):
         _need_cuda(x, "mlp input")
-        if torch.is_grad_enabled():
+        if torch.is_grad_enabled() and self.training:     # (eval mode keeps the fused forward; its rare gradients use the twin)
             stages = self.stages([(x, None)], post=post)
             if _dense_native_ok(stages, self.training):
                 return run_stages_autograd(stages, x.shape[0], self.training)
@@ -1060,7 +1060,7 @@ class _SparseLayer(nn.Module):
             ts = list(ts)
             return tuple(None if t is None else (t.dense() if isinstance(t, Codes) else ts.pop(0)) for t in given)
 
-        if torch.is_grad_enabled() and NATIVE_DENSE_BACKWARD:
+        if torch.is_grad_enabled() and NATIVE_DENSE_BACKWARD and self.training:
             # training: compositions of kernels that each have a HIP adjoint -- no PyTorch twin
             if self.ogb or self.msg_kind == "gin":   # propagate -> axpy -> update_fn
                 return self._twin(edge_index, _dense(x), _dense(ids), _dense(ef), post=post, native=True)
