@@ -35,6 +35,8 @@ struct CountArgs {
     // LDS byte offsets
     int off_valid, off_stack, off_plan, off_eu, off_ev, off_rowstart, off_last, off_out, off_misc;
     int off_ball;              // distance-pruning tables (radius 2, radius 3: n_cap rows each) or -1
+    int off_core;              // d-cores of the graph, d = 0 .. CORE_MAX (W words each)
+    int core_mask;             // bit d: some plan needs the d-core
 };
 
 template <int W, int T>
@@ -52,6 +54,7 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
     uint64_t *out_lds = reinterpret_cast<uint64_t *>(smem + a.off_out);
     int *misc = reinterpret_cast<int *>(smem + a.off_misc);  // [0] next task  [1] n_active  [2] status
     uint64_t *balls = a.off_ball >= 0 ? reinterpret_cast<uint64_t *>(smem + a.off_ball) : nullptr;
+    uint64_t *cores = reinterpret_cast<uint64_t *>(smem + a.off_core);   // [CORE_MAX + 1][W]
 
     const int tid = threadIdx.x;
     const int item = (int)blockIdx.x / a.split, part = (int)blockIdx.x - item * a.split;
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
     // ---- phase 0: clear LDS state, copy the plan table ------------------------------------------------------------
     for (int i = tid; i < n * W; i += T) A[i] = 0ull;
     for (int i = tid; i < a.plan_words; i += T) plan[i] = a.plan[i];
-    if (tid < 3) misc[tid] = 0;
+    if (tid < 4) misc[tid] = 0;
     __syncthreads();
 
     // ---- phase 1: adjacency bit matrix from the columns -----------------------------------------------------------
@@ -99,6 +102,48 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
     __syncthreads();
     const int n_active = misc[1];
     if (tid < W) valid[tid] = below_word(n_active, tid);
+    // d-cores: every image of a pattern with minimum degree d lies in the d-core of the graph (its >= d pattern neighbours
+    // are images too), so the plan's candidate universe is that core instead of all vertices -- on molecules the 2-core
+    // (ring systems and what connects them) is a fraction of the graph and rooted searches from the rest end at once.
+    __syncthreads();
+    for (int d = 0; d <= CORE_MAX; ++d) {
+        if (tid < W) cores[d * W + tid] = valid[tid];
+    }
+    __syncthreads();
+    for (int d = 1; d <= CORE_MAX; ++d) {
+        if (!((a.core_mask >> d) & 1)) continue;
+        uint64_t *core = cores + d * W;
+        if (W == 1 && T == 64) {                    // one wave, one vertex per lane: peel with ballots, no LDS round trips
+            uint64_t cur = core[0];
+            for (;;) {
+                const bool in = (cur >> tid) & 1ull;
+                const bool keep = in && tid < n && popc64(A[tid] & cur) >= d;
+                const uint64_t nxt = __ballot(keep);
+                if (nxt == cur) break;
+                cur = nxt;
+            }
+            __syncthreads();
+            if (tid == 0) core[0] = cur;
+        } else {
+            for (;;) {                               // Jacobi peeling: decide on a snapshot, then remove
+                __syncthreads();
+                if (tid == 0) misc[3] = 0;
+                __syncthreads();
+                uint32_t dropm = 0;                  // vertices tid + i*T, i < 12 (n <= 768, T >= 64)
+                for (int v = tid, i = 0; v < n; v += T, ++i) {
+                    const bool in = (core[v >> 6] >> (v & 63)) & 1ull;
+                    if (in && !core_keeps<W>(A, core, v, d)) dropm |= 1u << i;
+                }
+                __syncthreads();
+                for (int v = tid, i = 0; v < n; v += T, ++i)
+                    if ((dropm >> i) & 1u) atomicAnd(reinterpret_cast<unsigned long long *>(&core[v >> 6]), ~(1ull << (v & 63)));
+                if (dropm) misc[3] = 1;
+                __syncthreads();
+                if (misc[3] == 0) break;
+            }
+        }
+    }
+    __syncthreads();
     // distance pruning tables: vertices within 2 / 3 hops (count_core.h, candidates())
     if (balls) {
         for (int v = tid; v < n; v += T) ball_expand<W>(A, nullptr, v, balls);
@@ -156,6 +201,7 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
     FVec<W> roots = fv_roots<W>(0, 0);
     bool rev_missing = false;
     int mirror_row = -1;
+    const uint64_t *lane_valid = valid;     // candidate universe of the lane's current plan (a core of the graph)
 
     for (;;) {
         const bool need = !has_task && !exhausted;
@@ -211,7 +257,8 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
         if (has_task) {
             if (s.l < 0) {
                 if (p_i < p_e) {
-                    lane_begin<W>(s, plans + p_i * PLAN_STRIDE_WORDS, roots, A, valid, stack, T, tid);
+                    lane_valid = cores + plan_core(plans + p_i * PLAN_STRIDE_WORDS) * W;
+                    lane_begin<W>(s, plans + p_i * PLAN_STRIDE_WORDS, roots, A, lane_valid, stack, T, tid);
                     ++p_i;
                 } else {
                     // cell finished
@@ -225,7 +272,7 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
                     has_task = false;
                 }
             } else {
-                lane_step<W>(s, A, valid, stack, T, tid);
+                lane_step<W>(s, A, lane_valid, stack, T, tid);
             }
         }
     }
@@ -305,6 +352,9 @@ extern "C" int gsn_count_hip(const uint32_t *plan_host, const uint32_t *plan_dev
     a.off_rowstart = o; o += edge_mode ? align_up(((int)max_nodes + 1) * 4, 16) : 0;
     a.off_last = o; o += edge_mode ? align_up((int)max_edges * 4, 16) : 0;
     a.off_misc = o; o += 16;
+    a.off_core = o; o += align_up((CORE_MAX + 1) * W * 8, 16);
+    a.core_mask = 0;
+    for (int p = 0; p < a.n_plans; ++p) a.core_mask |= 1 << plan_core(plan_host + a.plans_off + p * PLAN_STRIDE_WORDS);
     // pruning tables only for graphs of <= 64 vertices (molecules): on larger, denser targets the balls are (nearly)
     // everything and the extra AND per step costs more than it saves (measured: ER G(128,1000) +8 %)
     a.off_ball = -1;

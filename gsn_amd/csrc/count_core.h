@@ -162,6 +162,15 @@ GSN_HD void ball_expand(const uint64_t *A, const uint64_t *from /* [n][W] or nul
     for (int w = 0; w < W; ++w) out[v * W + w] = acc.w[w];
 }
 
+// One peeling round of the d-core: does vertex v (a member of `core`) keep at least d neighbours inside `core`?
+template <int W>
+GSN_HD bool core_keeps(const uint64_t *A, const uint64_t *core, int v, int d) {
+    int c = 0;
+#pragma unroll
+    for (int w = 0; w < W; ++w) c += popc64(A[v * W + w] & core[w]);
+    return c >= d;
+}
+
 template <int W>
 struct Lane {
     int l;          // level whose frame is being consumed; < 0: no search in progress
@@ -174,6 +183,13 @@ struct Lane {
     int ball_n;              // vertex capacity of one table
 };
 
+// core index of a plan: images must lie in the min-degree(H) core of the target; cores 0..CORE_MAX are tabulated
+// (core d for d > CORE_MAX uses core CORE_MAX, a superset)
+constexpr int CORE_MAX = 4;
+GSN_HD int plan_core(const uint32_t *plan) {
+    const int d = (int)((plan[1] >> 20) & 0xfu);
+    return d > CORE_MAX ? CORE_MAX : d;
+}
 GSN_HD uint32_t plan_ball(const uint32_t *plan, int l) { return (plan[2 + GSN_KMAX + (l >> 2)] >> (8 * (l & 3))) & 0xffu; }
 
 template <int W>
@@ -213,6 +229,12 @@ GSN_HD void lane_begin(Lane<W> &s, const uint32_t *plan, const FVec<W> &fvec_roo
     for (int w = 0; w < W; ++w) s.used.w[w] = 0ull;
     bit_set<W>(s.used, fv_get<W>(fvec_roots, 0));
     if (s.nfix > 1) bit_set<W>(s.used, fv_get<W>(fvec_roots, 1));
+    {   // a root outside the plan's core cannot be the image of anything
+        const int ra = fv_get<W>(fvec_roots, 0);
+        bool in = (valid[ra >> 6] >> (ra & 63)) & 1ull;
+        if (s.nfix > 1) { const int rb = fv_get<W>(fvec_roots, 1); in = in && ((valid[rb >> 6] >> (rb & 63)) & 1ull); }
+        if (!in) return;
+    }
     if (s.nfix == s.k) { s.cnt += 1; return; }
     Bits<W> C;
     candidates<W>(C, plan[2 + s.nfix], plan_ball(plan, s.nfix), s.fvec, s.used, A, valid, s.balls, s.ball_n);

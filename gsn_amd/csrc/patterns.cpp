@@ -94,7 +94,7 @@ static int analyse(int64_t n_edges, const int64_t *edges, int directed_orbits, P
 // ---- plan compilation -----------------------------------------------------------------------------------------
 
 struct Plan {
-    int k, n_fixed, out_col, pattern, root_a, root_b;
+    int k, n_fixed, out_col, pattern, root_a, root_b, min_degree;
     uint32_t level[GSN_KMAX];
     uint8_t ball[GSN_KMAX];
 };
@@ -149,6 +149,13 @@ static Plan make_plan(const Pattern &P, int pattern_id, const int *fixed, int n_
     Plan pl{};
     pl.k = P.k; pl.n_fixed = n_fixed; pl.out_col = out_col; pl.pattern = pattern_id;
     pl.root_a = fixed[0]; pl.root_b = n_fixed > 1 ? fixed[1] : 0;
+    // every image has at least min-degree(H) neighbours among the images, so all images lie in that core of the target
+    pl.min_degree = GSN_KMAX;
+    for (int v = 0; v < P.k; ++v) {
+        int dv = 0;
+        for (int u = 0; u < P.k; ++u) dv += (u != v && has(P, v, u)) ? 1 : 0;
+        pl.min_degree = std::min(pl.min_degree, dv);
+    }
     int order[GSN_KMAX], pos[GSN_KMAX];
     matching_order(P, fixed, n_fixed, order);
     for (int l = 0; l < P.k; ++l) pos[order[l]] = l;
@@ -278,7 +285,7 @@ extern "C" int gsn_count_plan_build(int mode, int induced, int directed_orbits, 
         uint32_t *w = plan + plans_off + i * PLAN_STRIDE_WORDS;
         const Plan &pl = plans[i];
         w[0] = (uint32_t)pl.k | ((uint32_t)pl.n_fixed << 8) | ((uint32_t)pl.out_col << 16);
-        w[1] = (uint32_t)pl.pattern | ((uint32_t)pl.root_a << 16) | ((uint32_t)pl.root_b << 24);
+        w[1] = (uint32_t)pl.pattern | ((uint32_t)pl.root_a << 16) | ((uint32_t)pl.min_degree << 20) | ((uint32_t)pl.root_b << 24);
         for (int l = 0; l < GSN_KMAX; ++l) w[2 + l] = pl.level[l];
         for (int l = 0; l < GSN_KMAX / 4; ++l) w[2 + GSN_KMAX + l] = 0;
         for (int l = 0; l < GSN_KMAX; ++l) w[2 + GSN_KMAX + l / 4] |= (uint32_t)pl.ball[l] << (8 * (l % 4));

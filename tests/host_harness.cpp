@@ -39,6 +39,19 @@ static int run(const uint32_t *plan, int64_t n, int64_t E, const int64_t *src, c
     for (int v = 0; v < (int)n; ++v) ball_expand<W>(A.data(), nullptr, v, balls.data());
     for (int v = 0; v < (int)n; ++v) ball_expand<W>(A.data(), balls.data(), v, balls.data() + (size_t)nb * W);
     const bool prune = getenv("GSN_HARNESS_NO_PRUNE") == nullptr;
+    // d-cores, d = 0 .. CORE_MAX (plan_core): candidate universe of a plan
+    std::vector<uint64_t> cores((size_t)(CORE_MAX + 1) * W, 0);
+    for (int d = 0; d <= CORE_MAX; ++d) {
+        uint64_t *core = cores.data() + (size_t)d * W;
+        for (int w = 0; w < W; ++w) core[w] = valid[w];
+        for (bool changed = prune && d > 0; changed;) {
+            changed = false;
+            std::vector<int> drop;
+            for (int v = 0; v < (int)n; ++v)
+                if (((core[v >> 6] >> (v & 63)) & 1ull) && !core_keeps<W>(A.data(), core, v, d)) drop.push_back(v);
+            for (int v : drop) { core[v >> 6] &= ~(1ull << (v & 63)); changed = true; }
+        }
+    }
     std::vector<int64_t> last((size_t)(n * n ? n * n : 1), -1);
     for (int64_t c = 0; c < E; ++c) last[(size_t)src[c] * n + dst[c]] = c;
     const int64_t rows = mode == GSN_MODE_EDGE ? E : n;
@@ -59,8 +72,9 @@ static int run(const uint32_t *plan, int64_t n, int64_t E, const int64_t *src, c
             }
             if (live)
                 for (uint32_t p = col_ptr[col]; p < col_ptr[col + 1]; ++p) {
-                    lane_begin<W>(s, plans + p * PLAN_STRIDE_WORDS, roots, A.data(), valid, stack.data(), 1, 0);
-                    while (s.l >= 0) lane_step<W>(s, A.data(), valid, stack.data(), 1, 0);
+                    const uint64_t *pv = cores.data() + (size_t)plan_core(plans + p * PLAN_STRIDE_WORDS) * W;
+                    lane_begin<W>(s, plans + p * PLAN_STRIDE_WORDS, roots, A.data(), pv, stack.data(), 1, 0);
+                    while (s.l >= 0) lane_step<W>(s, A.data(), pv, stack.data(), 1, 0);
                 }
             out[row * n_cols + col] = (int64_t)s.cnt;
             if (rev_missing && s.cnt) status = 1;
