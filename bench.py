@@ -160,6 +160,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    for _ in range(5):          # untimed: first-launch costs and GPU clock ramp after the host-side data generation
+        step()
     for _ in range(args.warmup):
         step()
     sync()
@@ -224,15 +226,18 @@ def main():
             idf2 = layers.one_hot_identifiers(ids2, [3, 3, 3, 3], clamp=True)
             with torch.no_grad():
                 return layer(x2, ei2, identifiers=idf2, degrees=deg2, edge_features=ef2)
-        for _ in range(max(args.warmup, 1)):
+        # the batch above was generated on the host while the GPU idled: warm up long enough for the clocks to come back
+        # (a 0.6 ms step measured right after an idle phase reads anywhere between 0.6 and 2.5 ms)
+        n12 = max(args.steps, 100)
+        for _ in range(100):
             step12k()
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(n12):
             step12k()
         torch.cuda.synchronize()
         dt2 = time.perf_counter() - t2
-        zinc12k = {"graphs_per_s": round(12000 * args.steps / dt2, 1), "ms_per_step": round(dt2 / args.steps * 1e3, 4),
+        zinc12k = {"graphs_per_s": round(12000 * n12 / dt2, 1), "ms_per_step": round(dt2 / n12 * 1e3, 4), "steps": n12,
                    "note": "BASELINE configs[1] dataset size: 12 000 ZINC-shaped graphs per step (N=%d, E=%d)" % (b2.num_nodes, b2.num_edges)}
 
     if rank == 0:
