@@ -145,12 +145,23 @@ def main():
     torch.manual_seed(0)
     layer = layers.GSN_edge_sparse(**CTOR).to(dev).eval()
 
+    side = torch.cuda.Stream(device=dev)
+    sel = layer._sel()
+
     def step():
         layers._CSR_CACHE.clear()             # the CSR of a fresh batch is part of the forward pass
+        main = torch.cuda.current_stream(dev)
+        # The layer's target-sorted CSR depends only on edge_index, the counting only on the graphs: the CSR build (small
+        # memory-bound kernels) runs on a second HIP stream under the VALU-bound counting kernel.  The side stream first
+        # waits for the main stream so that CSR buffers recycled by the allocator are no longer read by the previous step.
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            layers._csr_for(ei, sel, N)
         with layers._timed("count", 16.0 * E + 8.0 * E * plan.n_cols):
             count_batch(plan, node_ptr, edge_ptr, ei, ids_are_global=True, max_nodes=max_nodes, max_edges=max_edges,
                         device=dev, out=ids_out, check=False)
         idf = layers.one_hot_identifiers(ids_out, [3, 3, 3, 3], clamp=True)   # [E, 12] fp32 (gsn_one_hot_hip)
+        main.wait_stream(side)
         with torch.no_grad():
             return layer(x, ei, identifiers=idf, degrees=degrees, edge_features=ef)
 
