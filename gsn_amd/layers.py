@@ -675,8 +675,6 @@ def _dense_native_ok(stages, training):
             return False
         if st.bn is not None and not (training or st.bn.running_mean is None):
             return False
-        if st.bias is None and False:
-            return False
     return True
 
 

@@ -437,3 +437,37 @@ def test_training_paths_use_native_adjoints():
     finally:
         layers._HipWithTorchBackward.apply = orig
     assert not twin_calls, "a training-mode layer went through the PyTorch twin"
+
+
+def test_full_size_properties_of_the_headline_layer():
+    """BASELINE full size (65 536 ZINC-shaped graphs, E = 3.1 M): properties that need no reference.
+    (i) a batch is a disjoint union: the forward of the first 1000 graphs alone equals those rows of the full forward;
+    (ii) edge order is irrelevant: permuting the columns of edge_index (and the per-edge inputs with them) leaves the
+    output unchanged up to fp32 summation order;  (iii) the integer-coded inputs give the same result."""
+    import bench
+    from gsn_amd import layers
+    b = bench.make_batch(65536, 3)
+    dev = "cuda"
+    N, E = b.num_nodes, b.num_edges
+    ei = torch.from_numpy(b.edge_index).to(dev)
+    xc = layers.Codes(torch.from_numpy(b.atom_type).to(dev), [28])
+    ec = layers.Codes(torch.from_numpy(b.bond_type).to(dev), [4])
+    ic = layers.Codes(torch.randint(0, 3, (E, 4), device=dev), [3, 3, 3, 3])
+    x, idf, ef = xc.dense(), ic.dense(), ec.dense()
+    deg = torch.zeros(N, device=dev)
+    torch.manual_seed(0)
+    layer = layers.GSN_edge_sparse(**bench.CTOR).to(dev).eval()
+    with torch.no_grad():
+        y = layer(x, ei, identifiers=idf, degrees=deg, edge_features=ef)
+        n1, e1 = int(b.node_ptr[1000]), int(b.edge_ptr[1000])
+        y1 = layer(x[:n1].contiguous(), ei[:, :e1].contiguous(), identifiers=idf[:e1].contiguous(), degrees=deg[:n1],
+                   edge_features=ef[:e1].contiguous())
+        perm = torch.randperm(E, device=dev)
+        yp = layer(x, ei[:, perm].contiguous(), identifiers=idf[perm].contiguous(), degrees=deg, edge_features=ef[perm].contiguous())
+        layers.CODE_STATUS_CHECK = True
+        yc = layer(xc, ei, identifiers=ic, degrees=deg, edge_features=ec)
+    scale = float(y.abs().max())
+    assert torch.isfinite(y).all() and y.shape == (N, 128)
+    assert float((y[:n1] - y1).abs().max()) <= 1e-5 * scale
+    assert float((yp - y).abs().max()) <= 1e-5 * scale
+    assert float((yc - y).abs().max()) <= 1e-5 * scale
