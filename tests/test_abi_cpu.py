@@ -161,3 +161,13 @@ def test_search_core_with_16_bit_vertex_ids_on_host(lib, harness, n, mode):
     assert st == 0
     ref = oracle.counts2ids(mode, False, np.array([0, nn]), np.array([0, E]), ei, pats, n_threads=4)
     assert np.array_equal(out, ref) and out.sum() > 0
+
+
+def test_abi_header_is_plain_c():
+    """include/gsn_abi.h is the drop-in boundary: it must compile as C99 and as C++ on its own (no torch / HIP types)."""
+    hdr = os.path.join(REPO, "include", "gsn_abi.h")
+    subprocess.check_call(["gcc", "-fsyntax-only", "-x", "c", "-std=c99", "-Wall", "-Werror", hdr])
+    subprocess.check_call(["g++", "-fsyntax-only", "-x", "c++", "-std=c++17", "-Wall", "-Werror", hdr])
+    import re
+    code = re.sub(r"/\*.*?\*/", "", open(hdr).read(), flags=re.S)      # declarations only (comments cite torch calls)
+    assert "torch" not in code.lower() and "hipStream_t" not in code and "#include <hip" not in code
