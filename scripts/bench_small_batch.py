@@ -53,8 +53,34 @@ def main():
         t_enq = time.perf_counter() - t0
         torch.cuda.synchronize()
         t_all = time.perf_counter() - t0
-        out.append({"graphs": G, "N": N, "E": E, "us_per_step": round(t_all / reps * 1e6, 1), "host_enqueue_us": round(t_enq / reps * 1e6, 1),
-                    "graphs_per_s": round(G * reps / t_all, 1)})
+        rec = {"graphs": G, "N": N, "E": E, "us_per_step": round(t_all / reps * 1e6, 1), "host_enqueue_us": round(t_enq / reps * 1e6, 1),
+               "graphs_per_s": round(G * reps / t_all, 1)}
+        # the same step captured once into a HIP graph (fixed shapes: e.g. serving, or the SR isomorphism test) and replayed
+        try:
+            g = torch.cuda.CUDAGraph()
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for _ in range(3):
+                    step()
+            torch.cuda.current_stream().wait_stream(s)
+            with torch.cuda.graph(g):
+                y_static = step()
+            for _ in range(20):
+                g.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                g.replay()
+            torch.cuda.synchronize()
+            t_g = time.perf_counter() - t0
+            y_ref = step()
+            torch.cuda.synchronize()
+            rec["hip_graph_us_per_step"] = round(t_g / reps * 1e6, 1)
+            rec["hip_graph_matches"] = bool(torch.equal(y_static, y_ref))
+        except Exception as e:       # capture is best effort: report why it failed
+            rec["hip_graph_error"] = str(e)[:200]
+        out.append(rec)
         if prof and G == 128:
             pr = cProfile.Profile()
             pr.enable()
