@@ -471,6 +471,10 @@ extern "C" int gsn_mlp_chain_fwd_hip(int64_t m_rows, int n_stages, const gsn_cha
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (n_stages == 2 && a.st[1].k_total > 8 * CHK)
         return set_error(GSN_E_UNSUPPORTED, "gsn_mlp_chain_fwd_hip: second stage wider than 128 inputs");
+    if (n_stages == 2) {   // plain two-stage chains: stage-pipelined kernel (chain_pipe.hip) where it covers the shape
+        const int rc = launch_chain2_pipe(a, maxch, st);
+        if (rc != 1) return rc;
+    }
     if (maxch == 5) {
         if (n_stages == 1) return launch_chain<1, 5, 0>(a, st);
         return launch_chain<2, 5, 8>(a, st);

@@ -152,6 +152,9 @@ __device__ __forceinline__ void rs_store(int *dst, const RowSrcThread<NP> &t, co
     }
 }
 
+// chain_pipe.hip: stage-pipelined launch of two-stage chains with plain output; returns 1 when the shape is not covered
+int launch_chain2_pipe(const ChainArgs &a, int maxch, hipStream_t st);
+
 constexpr int SEG_ROWS = GSN_SEG_RANGE_ROWS;  // rows per reduction range of the segmented-sum epilogue
 
 }  // namespace gsn
