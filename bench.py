@@ -266,7 +266,7 @@ def main():
         kd = kernels[dom]
         if dom in ("linear_fwd", "mlp_chain"):
             ach = kd["work_per_step"] / (kd["ms_per_step"] * 1e-3) / 1e12
-            roof = {"kernel": {"linear_fwd": "linear_fwd_kernel", "mlp_chain": "mlp_chain_kernel"}[dom], "bound": "mfma",
+            roof = {"kernel": {"linear_fwd": "linear_fwd_kernel", "mlp_chain": "mlp_chain_kernel + mlp_chain2_pipe_kernel"}[dom], "bound": "mfma",
                     "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TF,
                     "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TF, 4), "traffic": None}
         else:
@@ -279,7 +279,8 @@ def main():
         try:
             import csv
             pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_bench_pmc.csv")
-            rows = [r for r in csv.DictReader(open(pmc)) if roof["kernel"] in r["kernel"]]
+            key = {"mlp_chain": "gsn::mlp_chain"}.get(dom, roof["kernel"])   # both kernels of the chain family
+            rows = [r for r in csv.DictReader(open(pmc)) if key in r["kernel"]]
             if rows and G == 65536:
                 tot = sum((2.0 * float(r["FETCH_SIZE_per_dispatch"]) + float(r["WRITE_SIZE_per_dispatch"])) * 1024.0 for r in rows)
                 roof["traffic"] = round(tot / len(rows))
