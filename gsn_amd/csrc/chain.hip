@@ -474,6 +474,9 @@ extern "C" int gsn_mlp_chain_fwd_hip(int64_t m_rows, int n_stages, const gsn_cha
     if (n_stages == 2) {   // plain two-stage chains: stage-pipelined kernel (chain_pipe.hip) where it covers the shape
         const int rc = launch_chain2_pipe(a, maxch, st);
         if (rc != 1) return rc;
+    } else if (a.seg_target) {   // edge stage with the fused scatter-add: role-pipelined kernel (chain_seg.hip)
+        const int rc = launch_chain1_seg(a, maxch, st);
+        if (rc != 1) return rc;
     }
     if (maxch == 5) {
         if (n_stages == 1) return launch_chain<1, 5, 0>(a, st);
