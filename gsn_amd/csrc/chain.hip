@@ -475,7 +475,9 @@ extern "C" int gsn_mlp_chain_fwd_hip(int64_t m_rows, int n_stages, const gsn_cha
         const int rc = launch_chain2_pipe(a, maxch, st);
         if (rc != 1) return rc;
     } else if (a.seg_target) {   // edge stage with the fused scatter-add: role-pipelined kernel (chain_seg.hip)
-        const int rc = launch_chain1_seg(a, maxch, st);
+        int rc = launch_chain1_seg_bf16(a, maxch, st);
+        if (rc != 1) return rc;
+        rc = launch_chain1_seg(a, maxch, st);
         if (rc != 1) return rc;
     }
     if (maxch == 5) {

@@ -156,6 +156,8 @@ __device__ __forceinline__ void rs_store(int *dst, const RowSrcThread<NP> &t, co
 int launch_chain2_pipe(const ChainArgs &a, int maxch, hipStream_t st);
 // chain_seg.hip: role-pipelined launch of single-stage chains with the fused scatter-add; returns 1 when not covered
 int launch_chain1_seg(const ChainArgs &a, int maxch, hipStream_t st);
+// chain_seg_bf16.hip: the same on bf16 MFMAs with exactly split operands (6 plane products); returns 1 when not covered
+int launch_chain1_seg_bf16(const ChainArgs &a, int maxch, hipStream_t st);
 
 constexpr int SEG_ROWS = GSN_SEG_RANGE_ROWS;  // rows per reduction range of the segmented-sum epilogue
 
