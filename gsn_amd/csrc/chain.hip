@@ -472,7 +472,9 @@ extern "C" int gsn_mlp_chain_fwd_hip(int64_t m_rows, int n_stages, const gsn_cha
     if (n_stages == 2 && a.st[1].k_total > 8 * CHK)
         return set_error(GSN_E_UNSUPPORTED, "gsn_mlp_chain_fwd_hip: second stage wider than 128 inputs");
     if (n_stages == 2) {   // plain two-stage chains: stage-pipelined kernel (chain_pipe.hip) where it covers the shape
-        const int rc = launch_chain2_pipe(a, maxch, st);
+        int rc = launch_chain2_pipe_bf16(a, maxch, st);
+        if (rc != 1) return rc;
+        rc = launch_chain2_pipe(a, maxch, st);
         if (rc != 1) return rc;
     } else if (a.seg_target) {   // edge stage with the fused scatter-add: role-pipelined kernel (chain_seg.hip)
         int rc = launch_chain1_seg_bf16(a, maxch, st);

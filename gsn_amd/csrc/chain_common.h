@@ -154,6 +154,8 @@ __device__ __forceinline__ void rs_store(int *dst, const RowSrcThread<NP> &t, co
 
 // chain_pipe.hip: stage-pipelined launch of two-stage chains with plain output; returns 1 when the shape is not covered
 int launch_chain2_pipe(const ChainArgs &a, int maxch, hipStream_t st);
+// chain_pipe_bf16.hip: the same on bf16 MFMAs with exactly split operands (6 plane products); returns 1 when not covered
+int launch_chain2_pipe_bf16(const ChainArgs &a, int maxch, hipStream_t st);
 // chain_seg.hip: role-pipelined launch of single-stage chains with the fused scatter-add; returns 1 when not covered
 int launch_chain1_seg(const ChainArgs &a, int maxch, hipStream_t st);
 // chain_seg_bf16.hip: the same on bf16 MFMAs with exactly split operands (6 plane products); returns 1 when not covered

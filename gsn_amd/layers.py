@@ -133,7 +133,7 @@ def _dense(v):
 # CSR of the aggregation index (cached per edge_index tensor)
 # ------------------------------------------------------------------------------------------------------------------
 class _CSR:
-    __slots__ = ("seg_ptr", "perm", "deg", "tgt", "src")
+    __slots__ = ("seg_ptr", "perm", "deg", "deg4", "tgt", "src")
 
 
 _CSR_CACHE = {}
@@ -179,6 +179,8 @@ def _csr_for(edge_index, row, n_nodes):
     c = _CSR()
     c.seg_ptr, c.perm, c.tgt, c.src = build_csr(edge_index[row], n_nodes, with_targets=True, other=edge_index[1 - row])
     c.deg = (c.seg_ptr[1:] - c.seg_ptr[:-1]).to(torch.float32).unsqueeze(1).contiguous()
+    # the same column padded to 4 floats per row (zeros): keeps the node chain's input blocks float4-gatherable
+    c.deg4 = torch.nn.functional.pad(c.deg, (0, 3))
     _CSR_CACHE[key] = (weakref.ref(edge_index), edge_index._version, c)
     return c
 
@@ -1154,7 +1156,7 @@ class _SparseLayer(nn.Module):
                 r = mf.hip_forward(blocks, E, upto=len(mf.fc) - 1)
                 s_agg = propagate(0, edge_index, sel, n, b=r)
             w_first = self._folded_first_weight(x.shape[1])
-            return uf.hip_forward([(x, None), (s_agg, None), (csr.deg, None)], n, first_weight=w_first, post=post)
+            return uf.hip_forward([(x, None), (s_agg, None), (csr.deg4, None)], n, first_weight=w_first, post=post)
         msgs = mf.hip_forward(blocks, E)
         agg = propagate(0, edge_index, sel, n, b=msgs)
         return uf.hip_forward([(x, None), (agg, None)], n, post=post)
@@ -1206,7 +1208,8 @@ class _SparseLayer(nn.Module):
         w2t = last.weight.detach().t().contiguous()                       # [d_h_msg, d_msg]: rows = input index
         w_fold = _linear_hip([(w3a, None)], w2t, None, None, None, None, 0, w3a.shape[0])   # = W3a @ W2
         b_fold = _linear_hip([(w3a, None)], last.bias.detach().unsqueeze(0).contiguous(), None, None, None, None, 0, w3a.shape[0])
-        w_first = torch.cat([w3x, w_fold, b_fold], 1).contiguous()
+        # three zero columns after the degree column: the degree block is passed 4 floats wide (csr.deg4)
+        w_first = torch.cat([w3x, w_fold, b_fold, torch.zeros_like(b_fold).expand(-1, 3)], 1).contiguous()
         self._fold_cache = (key, w_first)
         return w_first
 
