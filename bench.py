@@ -182,6 +182,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         y = step()
+    t_enq = time.perf_counter() - t0          # host time to enqueue the K steps (the GPU runs behind it)
     sync()
     dt = time.perf_counter() - t0
     timer, layers.KERNEL_TIMER = layers.KERNEL_TIMER, None
@@ -313,6 +314,7 @@ def main():
             "count_graphs_per_s": round(G / (ck["ms_per_step"] * 1e-3), 1),
             "count_hbm_GBs": round(ck["work_per_step"] / (ck["ms_per_step"] * 1e-3) / 1e9, 1),
             "ms_per_step_by_kernel": per_launch,
+            "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 4),
         })
         if fused is not None:
             extra["fused_encoder_step"] = fused

@@ -23,6 +23,7 @@
 // stage s >= 1 at most 64 columns; anything else goes through linear.hip.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 
 #include "chain_common.h"
@@ -374,6 +375,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
     }
 }
 
+void chain_trace(const char *kernel, const ChainArgs &a) {
+    static const bool on = [] { const char *d = getenv("GSN_CHAIN_TRACE"); return d && atoi(d) != 0; }();
+    if (on) fprintf(stderr, "gsn_chain_launch %s m_rows=%lld k0=%d n_out=%d stages=%d\n", kernel, (long long)a.m_rows, a.st[0].k_total, a.st[a.n_stages - 1].n_out, a.n_stages);
+}
+
 template <int NST, int CH0, int CH1, bool STATS, bool SEG>
 static int launch_chain_impl(const ChainArgs &a, hipStream_t st) {
     constexpr bool SMALL = (NST == 1 && CH0 == 5);
@@ -392,6 +398,7 @@ static int launch_chain_impl(const ChainArgs &a, hipStream_t st) {
     { const char *d = getenv("GSN_CHAIN_PERCU"); if (d) per_cu = atoi(d); }
     int64_t gx = 256 * per_cu;
     if (gx > n_tiles) gx = n_tiles;
+    chain_trace(STATS ? "mlp_chain_kernel(stats)" : (SEG ? "mlp_chain_kernel(seg)" : "mlp_chain_kernel"), a);
     hipLaunchKernelGGL((mlp_chain_kernel<NST, CH0, CH1, STATS, WPE, SEG, NW>), dim3((unsigned)gx), dim3(64 * NW), lds, st, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(GSN_E_HIP, "mlp_chain_kernel: %s", hipGetErrorString(e));

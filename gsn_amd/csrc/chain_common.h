@@ -161,6 +161,9 @@ int launch_chain1_seg(const ChainArgs &a, int maxch, hipStream_t st);
 // chain_seg_bf16.hip: the same on bf16 MFMAs with exactly split operands (6 plane products); returns 1 when not covered
 int launch_chain1_seg_bf16(const ChainArgs &a, int maxch, hipStream_t st);
 
+// GSN_CHAIN_TRACE=1: one stderr line per chain launch naming the kernel variant (used by the parity tests' coverage check)
+void chain_trace(const char *kernel, const ChainArgs &a);
+
 constexpr int SEG_ROWS = GSN_SEG_RANGE_ROWS;  // rows per reduction range of the segmented-sum epilogue
 
 }  // namespace gsn

@@ -235,6 +235,7 @@ static int launch_pipe_impl(const ChainArgs &a, int pin, int pmid, size_t lds, h
     const int64_t n_tiles = (a.m_rows + CBM - 1) / CBM;
     int64_t gx = 256;
     if (gx > n_tiles) gx = n_tiles;
+    chain_trace("mlp_chain2_pipe_kernel", a);
     hipLaunchKernelGGL((mlp_chain2_pipe_kernel<CH0, CH1>), dim3((unsigned)gx), dim3(512), lds, st, a, pin, pmid);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(GSN_E_HIP, "mlp_chain2_pipe_kernel: %s", hipGetErrorString(e));

@@ -324,6 +324,7 @@ static int launch_pipe_bf_impl(const ChainArgs &a, hipStream_t st) {
     const int64_t n_tiles = (a.m_rows + 31) / 32;
     int64_t gx = 256;
     if (gx > n_tiles) gx = n_tiles;
+    chain_trace("mlp_chain2_pipe_bf16_kernel", a);
     hipLaunchKernelGGL((mlp_chain2_pipe_bf16_kernel<NK0, NK1, VEC4, PROF>), dim3((unsigned)gx), dim3(512), lds, st, a, prof);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(GSN_E_HIP, "mlp_chain2_pipe_bf16_kernel: %s", hipGetErrorString(e));

@@ -324,6 +324,7 @@ static int launch_seg_impl(const ChainArgs &a, hipStream_t st) {
     const int64_t n_tiles = (a.m_rows + TBM - 1) / TBM;
     int64_t gx = 256 * (lds <= 78 * 1024 ? 2 : 1);
     if (gx > n_tiles) gx = n_tiles;
+    chain_trace("mlp_chain1_seg_kernel", a);
     hipLaunchKernelGGL((mlp_chain1_seg_kernel<NKS, TBM, PROF, VEC4>), dim3((unsigned)gx), dim3(TBM * 16), lds, st, a, pin, py, prof, prio);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(GSN_E_HIP, "mlp_chain1_seg_kernel: %s", hipGetErrorString(e));

@@ -396,6 +396,7 @@ static int launch_bf_impl(const ChainArgs &a, hipStream_t st) {
     const int64_t n_tiles = (a.m_rows + TBM - 1) / TBM;
     int64_t gx = 256 * (lds <= 78 * 1024 ? 2 : 1);
     if (gx > n_tiles) gx = n_tiles;
+    chain_trace("mlp_chain1_seg_bf16_kernel", a);
     hipLaunchKernelGGL((mlp_chain1_seg_bf16_kernel<NK16, TBM, PROF>), dim3((unsigned)gx), dim3(TBM * 12), lds, st, a, py, prof, prio);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(GSN_E_HIP, "mlp_chain1_seg_bf16_kernel: %s", hipGetErrorString(e));

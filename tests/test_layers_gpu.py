@@ -258,6 +258,11 @@ def test_csr_cache_is_not_fooled_by_address_reuse():
     (64, [16], [16, 8], False, True, "relu"),           # one exact tile
     (65, [3], [5], True, False, "identity"),            # tiny everything, tail row
     (4096, [160], [128, 96], False, True, "relu"),      # K0 at the limit
+    (3000, [28, 128, 4], [128, 128], False, True, "relu"),   # bf16x6 node chain: float4 staging, NK0 = 10, NK1 = 8
+    (2001, [32, 16], [64, 40], False, True, "relu"),    # bf16x6 node chain: K0 = 48 (NK0 = 5 planes padded), k1 = 64 (NK1 = 4)
+    (1500, [28, 44], [100, 128], False, False, "identity"),  # bf16x6: K0 = 72, k1 = 100 (padded MID columns), no bn
+    (999, [30, 50], [128, 128], False, True, "relu"),   # bf16x6 node chain, widths not multiples of 4: dword staging
+    (31, [8], [16, 16], False, True, "relu"),           # less than one 32-row tile
 ])
 def test_chain_kernel_shapes_vs_torch(shape):
     """gsn_mlp_chain_fwd_hip across its shape classes (kernel variants, tails, inactive waves) against fp64 torch."""
@@ -305,9 +310,15 @@ def test_chain_kernel_shapes_vs_torch(shape):
     assert torch.allclose(stats[1], (hl * hl).sum(0), rtol=1e-5, atol=1e-5 * M)
 
 
-@pytest.mark.parametrize("N,E,hub", [(500, 4000, 0), (300, 5000, 700), (2000, 1500, 40), (64, 64, 64)])
-def test_fused_scatter_add_vs_torch(N, E, hub):
-    """The segmented-sum epilogue: empty segments, segments longer than one reduction range (atomics), tile tails."""
+@pytest.mark.parametrize("wx,we,n_out", [(20, 7, 96),      # K = 47: fp32 role-split kernel (blocks not float4-gatherable)
+                                         (20, 8, 96),      # K = 48: bf16x6 kernel, NK16 = 3, partial second column half
+                                         (28, 16, 128),    # K = 72: bf16x6, NK16 = 5, the predicate-free fast path
+                                         (32, 0, 40),      # K = 64: bf16x6, NK16 = 4, fewer than 64 output columns
+                                         (36, 8, 128)])    # K = 80: bf16x6 at its K limit
+@pytest.mark.parametrize("N,E,hub", [(500, 4000, 0), (300, 5000, 700), (2000, 1500, 40), (64, 64, 64), (50, 17, 0)])
+def test_fused_scatter_add_vs_torch(N, E, hub, wx, we, n_out):
+    """The segmented-sum epilogue: empty segments, segments longer than one reduction range (atomics), tile tails -- on the
+    fp32 and the bf16x6 edge-stage kernels."""
     from gsn_amd.layers import _Stage, run_stages, _csr_for
     torch.manual_seed(N + E)
     dev = "cuda"
@@ -316,14 +327,17 @@ def test_fused_scatter_add_vs_torch(N, E, hub):
         tgt[:hub] = 3                                  # one target with a very long segment
     src = torch.randint(0, N, (E,), device=dev)
     ei = torch.stack([src, tgt], 0)
-    x = torch.randn(N, 20, device=dev); ef = torch.randn(E, 7, device=dev)
+    x = torch.randn(N, wx, device=dev); ef = torch.randn(E, max(we, 1), device=dev)
     csr = _csr_for(ei, 1, N)
-    W = torch.randn(96, 47, device=dev) / 7.0; b = torch.randn(96, device=dev)
-    st = _Stage(W, b, None, "relu", [(x, csr.tgt), (x, csr.src), (ef, csr.perm)])
+    K = 2 * wx + we
+    W = torch.randn(n_out, K, device=dev) / K ** 0.5; b = torch.randn(n_out, device=dev)
+    blocks = [(x, csr.tgt), (x, csr.src)] + ([(ef, csr.perm)] if we else [])
+    st = _Stage(W, b, None, "relu", blocks)
     out = run_stages([st], E, False, csr=csr)
-    assert out is not None and out.shape == (N, 96)
-    msg = torch.relu(torch.cat([x[tgt], x[src], ef], 1).double() @ W.double().T + b.double())
-    ref = torch.zeros(N, 96, dtype=torch.float64, device=dev).index_add_(0, tgt, msg)
+    assert out is not None and out.shape == (N, n_out)
+    cat = [x[tgt], x[src]] + ([ef] if we else [])
+    msg = torch.relu(torch.cat(cat, 1).double() @ W.double().T + b.double())
+    ref = torch.zeros(N, n_out, dtype=torch.float64, device=dev).index_add_(0, tgt, msg)
     assert rel_err(out.double(), ref) < TOL
     assert (out[torch.bincount(tgt, minlength=N) == 0] == 0).all()
 
@@ -471,3 +485,18 @@ def test_full_size_properties_of_the_headline_layer():
     assert float((y[:n1] - y1).abs().max()) <= 1e-5 * scale
     assert float((yp - y).abs().max()) <= 1e-5 * scale
     assert float((yc - y).abs().max()) <= 1e-5 * scale
+
+
+def test_chain_shape_cases_reach_every_kernel_variant():
+    """The shape cases above are only worth something if each of them runs on the kernel it names: run them in a child process
+    with GSN_CHAIN_TRACE=1 and check that all six chain kernels (fp32 generic / role-split / stage-pipelined, their bf16x6
+    twins) and the statistics pass were launched."""
+    import os, subprocess, sys
+    env = dict(os.environ, GSN_CHAIN_TRACE="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-s", "-m", "gpu", "-k", "chain_kernel_shapes or fused_scatter"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    seen = {line.split()[1] for line in (r.stdout + r.stderr).splitlines() if line.startswith("gsn_chain_launch ")}
+    for kernel in ("mlp_chain_kernel", "mlp_chain_kernel(stats)", "mlp_chain1_seg_kernel", "mlp_chain1_seg_bf16_kernel",
+                   "mlp_chain2_pipe_kernel", "mlp_chain2_pipe_bf16_kernel"):
+        assert kernel in seen, (kernel, sorted(seen))
