@@ -147,7 +147,9 @@ def main():
     torch.manual_seed(0)
     layer = layers.GSN_edge_sparse(**CTOR).to(dev).eval()
 
-    side = torch.cuda.Stream(device=dev)
+    # high priority: the CSR kernels are short and memory-bound; at equal priority their workgroups queue behind the
+    # counting kernel's and the build (0.13 ms alone) stretches past the end of the counting (GSN_SIDE_PRIO=0 to compare)
+    side = torch.cuda.Stream(device=dev, priority=-1 if os.environ.get("GSN_SIDE_PRIO", "1") != "0" else 0)
     sel = layer._sel()
 
     def step():

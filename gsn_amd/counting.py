@@ -102,7 +102,8 @@ def count_batch(plan: CountPlan, node_ptr, edge_ptr, edge_index, ids_are_global=
         # rows follow the pointers the kernel uses, not the tensor length (one host read; pass `out` to avoid it)
         rows_total = int((edge_ptr_d if plan.mode == "edge" else node_ptr_d)[-1].item()) if n_graphs > 0 else 0
         out = torch.empty((rows_total, plan.n_cols), dtype=torch.int64, device=device)
-    status = torch.zeros(max(n_graphs, 1), dtype=torch.int32, device=device)
+    # (the library zeroes the status words of the graphs it counts; with a subset the others must read OK as well)
+    status = (torch.zeros if graph_ids is not None or n_graphs == 0 else torch.empty)(max(n_graphs, 1), dtype=torch.int32, device=device)
     gid = None
     n_items = n_graphs
     if graph_ids is not None:
