@@ -70,6 +70,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     constexpr int K0 = NK0 * 16, KP0 = K0 + 8, PL0 = TBM * KP0 / 2;      // plane sizes in floats
     constexpr int K1 = NK1 * 16, KP1 = K1 + 8, PL1 = TBM * KP1 / 2;
     constexpr int PF0_J = (K0 + 31) / 32;
+    constexpr int JB = (PF0_J * 3 + 2) / 5;                                // input column groups staged by group B; the rest by group A
     constexpr int RSTEP = GT / 32, NROW = TBM / RSTEP;                    // 8, 4
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // buffers as offsets into `lds` (a pointer picked from an array of buffer pointers loses its LDS address space)
@@ -101,12 +102,82 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (cok && st.bn_scale) { scale = st.bn_scale[col]; c0 = (bias - st.bn_mean[col]) * scale + st.bn_shift[col]; }
         u32x4 Bh[NK0], Bm[NK0], Bl[NK0];
         load_weight_planes<NK0>(st, col, cok, lh, scale, Bh, Bm, Bl);
+        // this group's share of the input staging: 32-column groups j >= JB (see group B)
+        // staging map.  Scalar: thread -> column kc0 (+32j) of rows r0 + 8 i.  VEC4 (every block width a multiple of 4 floats,
+        // 16-byte aligned): thread -> columns kc0 .. kc0 + 3 (+32j) of ONE row: a quarter of the loads and address arithmetic,
+        // and the planes are written 4 bf16 at a time.
+        const int kc0 = VEC4 ? 4 * (t & 7) : (t & 31), r0 = VEC4 ? (t >> 3) : (t >> 5);
+        ColMap cm0[PF0_J];
+    #pragma unroll
+        for (int j = JB; j < PF0_J; ++j) {
+            cm0[j] = col_map(a, 0, kc0 + 32 * j);
+        }
+        float pf0[PF0_J][NROW];
+        // Direct rows only (no row indices, no permutation: the launcher sends anything else to chain_pipe.hip): the source row of
+        // tile row r is the row itself, so staging needs no row-source table, and this group -- which has stores in flight --
+        // never consumes a value loaded a tile earlier (that would put a wait for the previous tile's stores at the top of
+        // every tile).
+        const int m_rows = (int)a.m_rows, last_row = m_rows - 1;
+        const int gstep = (int)gridDim.x * TBM;
+        auto clampr = [&](int row) { return row < last_row ? row : last_row; };
+        auto prefetch_j = [&](int row0, int j) {
+            if (VEC4) {
+                if (kc0 + 32 * j >= K0) return;
+                const float4 v = *reinterpret_cast<const float4 *>(cm0[j].base + (int64_t)clampr(row0 + r0) * cm0[j].bw);
+                pf0[j][0] = v.x; pf0[j][1] = v.y; pf0[j][2] = v.z; pf0[j][3] = v.w;
+                return;
+            }
+    #pragma unroll
+            for (int i = 0; i < NROW; ++i) {
+                pf0[j][i] = cm0[j].base[(int64_t)clampr(row0 + r0 + RSTEP * i) * cm0[j].bw];
+            }
+        };
+        // prefetched rows -> three bf16 planes.  Padded columns (k >= K) hold a finite clamped-address value and meet zero weights.
+        auto stage_in = [&](float *dst) {
+            unsigned short *d16 = reinterpret_cast<unsigned short *>(dst);
+    #pragma unroll
+            for (int j = JB; j < PF0_J; ++j) {
+                if (VEC4) {
+                    const int k = kc0 + 32 * j;
+                    if (k < K0) {
+                        unsigned h[4], m[4], l[4];
+    #pragma unroll
+                        for (int e = 0; e < 4; ++e) split3p(pf0[j][e], h[e], m[e], l[e]);
+                        float *p = dst + (r0 * KP0 + k) / 2;
+                        u32x2 vh, vm, vl;
+                        vh[0] = pack_hi2(h[0], h[1]); vh[1] = pack_hi2(h[2], h[3]);
+                        vm[0] = pack_hi2(m[0], m[1]); vm[1] = pack_hi2(m[2], m[3]);
+                        vl[0] = pack_hi2(l[0], l[1]); vl[1] = pack_hi2(l[2], l[3]);
+                        *reinterpret_cast<u32x2 *>(p) = vh;
+                        *reinterpret_cast<u32x2 *>(p + PL0) = vm;
+                        *reinterpret_cast<u32x2 *>(p + 2 * PL0) = vl;
+                    }
+                } else if (kc0 + 32 * j < K0) {
+    #pragma unroll
+                    for (int i = 0; i < NROW; ++i) {
+                        unsigned h, m, l;
+                        split3p(pf0[j][i], h, m, l);
+                        const int o = (r0 + RSTEP * i) * KP0 + kc0 + 32 * j;
+                        d16[o] = (unsigned short)(h >> 16);
+                        d16[o + 2 * PL0] = (unsigned short)(m >> 16);
+                        d16[o + 4 * PL0] = (unsigned short)(l >> 16);
+                    }
+                }
+            }
+        };
         lds_barrier();
+        if (n_iter > 0) {
+#pragma unroll
+            for (int j = JB; j < PF0_J; ++j) prefetch_j((int)first * TBM, j);
+            stage_in(in_tile(0));
+        }
         lds_barrier();
         for (int64_t i = 0; i <= n_iter; ++i) {
             const unsigned long long t0 = clk();
             unsigned long long t1 = t0, t2 = t0;
             if (i < n_iter) {
+#pragma unroll
+                for (int j = JB; j < PF0_J; ++j) prefetch_j((int)(first + i * gridDim.x) * TBM + gstep, j);
                 f32x16 acc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = c0;
@@ -143,6 +214,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         m16[o + 4 * PL1] = (unsigned short)(l >> 16);
                     }
                 }
+                stage_in(in_tile(i + 1));                                   // (waits for this group's gathers; it has no stores)
                 t2 = clk();
             }
             lds_barrier();
@@ -167,15 +239,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (cok && st.bn_scale) { scale = st.bn_scale[col]; c0 = (bias - st.bn_mean[col]) * scale + st.bn_shift[col]; }
     u32x4 Bh[NK1], Bm[NK1], Bl[NK1];
     load_weight_planes<NK1>(st, col, cok, lh, scale, Bh, Bm, Bl);
-    // This group also stages the input tiles (row sources, gathers, split into planes): its matrix stage is the shorter one
-    // (K1 <= 128 against K0 <= 160) and its epilogue has no split, so the two groups' instruction streams are about even.
+    // This group stages the 32-column groups j < JB of the input tiles (gathers, split into planes), group A the rest: with
+    // the split at 3 : 2 the two groups' instruction streams per tile are about even (in-kernel profile, GSN_PIPE_PROF=1).
     // staging map.  Scalar: thread -> column kc0 (+32j) of rows r0 + 8 i.  VEC4 (every block width a multiple of 4 floats,
     // 16-byte aligned): thread -> columns kc0 .. kc0 + 3 (+32j) of ONE row: a quarter of the loads and address arithmetic,
     // and the planes are written 4 bf16 at a time.
     const int kc0 = VEC4 ? 4 * (t & 7) : (t & 31), r0 = VEC4 ? (t >> 3) : (t >> 5);
     ColMap cm0[PF0_J];
 #pragma unroll
-    for (int j = 0; j < PF0_J; ++j) {
+    for (int j = 0; j < JB; ++j) {
         cm0[j] = col_map(a, 0, kc0 + 32 * j);
     }
     float pf0[PF0_J][NROW];
@@ -202,7 +274,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     auto stage_in = [&](float *dst) {
         unsigned short *d16 = reinterpret_cast<unsigned short *>(dst);
 #pragma unroll
-        for (int j = 0; j < PF0_J; ++j) {
+        for (int j = 0; j < JB; ++j) {
             if (VEC4) {
                 const int k = kc0 + 32 * j;
                 if (k < K0) {
@@ -231,21 +303,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         }
     };
+    // Schedule of this group per tile:  staged rows of tile i+1 -> LDS (their loads were issued before the previous tile's
+    // stores, so the wait counts past those stores instead of draining them)  |  stage-1 MFMAs of tile i-1  |  loads of
+    // tile i+2  |  stores of tile i-1.  The staging runs while group A is in its matrix phase and this group's matrix
+    // phase follows A's, so the matrix pipe stays busy from the top of the tile until this group's stores.
     lds_barrier();
     if (n_iter > 0) {
 #pragma unroll
-        for (int j = 0; j < PF0_J; ++j) prefetch_j((int)first * TBM, j);
+        for (int j = 0; j < JB; ++j) prefetch_j((int)first * TBM, j);
         stage_in(in_tile(0));
+#pragma unroll
+        for (int j = 0; j < JB; ++j) prefetch_j((int)first * TBM + gstep, j);
     }
     lds_barrier();
     for (int64_t i = 0; i <= n_iter; ++i) {
         const unsigned long long t0 = clk();
         unsigned long long t1 = t0, t2 = t0, t3 = t0, t4 = t0;
-        const int row1 = (int)(first + i * gridDim.x) * TBM + gstep;           // first row of the next tile
-        if (i < n_iter) {
-#pragma unroll
-            for (int j = 0; j < PF0_J; ++j) prefetch_j(row1, j);   // next tile's gathers: a matrix phase to land
-        }
+        const int row2 = (int)(first + i * gridDim.x) * TBM + 2 * gstep;       // first row of the tile after next
+        if (i < n_iter) stage_in(in_tile(i + 1));
         t1 = clk();
         if (i > 0) {
             const int64_t row0 = (first + (i - 1) * gridDim.x) * TBM;
@@ -270,8 +345,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
             }
             if (PROF) { asm volatile("" :: "v"(acc[0])); t2 = clk(); }
-            if (i < n_iter) {   // (the one vmcnt wait of the tile: before this tile's stores are issued)
-                stage_in(in_tile(i + 1));
+            if (i < n_iter) {
+#pragma unroll
+                for (int j = 0; j < JB; ++j) prefetch_j(row2, j);       // issued BEFORE the stores below
             }
             t3 = clk();
             float *tile_out = a.out + row0 * st.n_out;                  // wave-uniform base
@@ -294,7 +370,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (st.act == 1) emit([](float y) { return y > 0.f ? y : 0.f; });
             else emit([](float y) { return y; });
         } else if (i < n_iter) {
-            stage_in(in_tile(i + 1));
+#pragma unroll
+            for (int j = 0; j < JB; ++j) prefetch_j(row2, j);
         }
         t4 = clk();
         lds_barrier();
@@ -338,7 +415,7 @@ static int launch_pipe_bf_impl(const ChainArgs &a, hipStream_t st) {
             for (int w = 0; w < 4; ++w) {
                 const unsigned long long *o = h + w * 6, *q = h + (4 + w) * 6;
                 if (o[5] && q[5])
-                    fprintf(stderr, "pipeprof(bf16x6) A%d tiles %llu: mfma %llu epilogue %llu barrier %llu | B%d: issue %llu mfma %llu stage %llu stores %llu barrier %llu (cycles per tile)\n",
+                    fprintf(stderr, "pipeprof(bf16x6) A%d tiles %llu: mfma %llu epilogue %llu barrier %llu | B%d: stage %llu mfma %llu issue %llu stores %llu barrier %llu (cycles per tile)\n",
                             w, o[5], o[0] / o[5], o[1] / o[5], o[2] / o[5], w, q[0] / q[5], q[1] / q[5], q[2] / q[5], q[3] / q[5], q[4] / q[5]);
             }
     }
