@@ -343,7 +343,7 @@ __global__ __launch_bounds__(TBM * 12) __attribute__((amdgpu_waves_per_eu(3, 3))
                 float s0 = 0.f, s1 = 0.f;
                 auto flush = [&](bool atomic) {
                     if (!FAST && curt < 0) return;
-                    float *rowp = a.out + (unsigned)curt * (unsigned)st.n_out;   // < 2^32 elements (launcher); uniform base
+                    float *rowp = a.out + (int64_t)curt * st.n_out;                // uniform base; the lane adds its columns
                     if (atomic) {
                         if (FAST || cok0) atomicAdd(rowp + c, s0);
                         if (FAST || cok1) atomicAdd(rowp + c + 64, s1);
@@ -429,7 +429,6 @@ static int launch_bf_k(const ChainArgs &a, hipStream_t st) {
 int launch_chain1_seg_bf16(const ChainArgs &a, int maxch, hipStream_t st) {
     if (a.n_stages != 1 || a.stats || !a.seg_target || maxch != 5) return 1;
     if (a.m_rows > (int64_t)2000000000) return 1;                       // 32-bit row arithmetic
-    if (a.m_rows * (int64_t)a.st[0].n_out >= ((int64_t)1 << 32)) return 1;   // (targets < m_rows is not known here; segments <= rows)
     for (int b = 0; b < a.n_blocks; ++b) {
         if (a.bidx[b] && !a.bidx32[b]) return 1;                        // int64 row indices: chain.hip's kernel
         if ((a.bwidth[b] & 3) || (reinterpret_cast<uintptr_t>(a.bdata[b]) & 15)) return 1;   // float4 gathers only
