@@ -8,8 +8,9 @@
 // This is the any-shape kernel (any K, any n_out via column tiles, elu / tanh epilogues, statistics pass); the common
 // small shapes (K <= 160, n_out <= 128, identity / relu) run on the fused weights-in-registers kernel of chain.hip.
 //
-// fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32 (exact f32, 64 FLOP/clk/SIMD = the chip's 157 TF fp32 peak;
-// gfx950 has no TF32, and the 1e-5 parity tolerance rules out bf16).  Tiling for 64-wide waves:
+// Two kernels: linear_fwd_bf16_kernel (default; every fp32 product as six exact bf16 plane products, see further down) and
+// linear_fwd_kernel: fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32 (exact f32, 64 FLOP/clk/SIMD = the chip's 157 TF fp32
+// peak; gfx950 has no TF32, and a single bf16 product misses the 1e-5 parity tolerance).  Tiling of the fp32 kernel:
 //   workgroup = 4 waves = 128 x 128 output tile; each wave owns 64 x 64 = 2 x 2 MFMA tiles (64 accumulator registers);
 //   K is walked in 32-wide slices of the CONCATENATED input row; A slices [128][32] and W^T slices [32][128] go through
 //   registers into double-buffered LDS tiles with +1 padding (pitch 33 / 129 words: staging writes and the per-lane
@@ -21,6 +22,9 @@
 //   (__syncthreads would drain the prefetch), epilogue constants live in registers, and the train-mode BatchNorm
 //   statistics pass keeps per-column fp64 partial sums in registers (one atomic per column per workgroup).
 #include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdlib>
 
 #include "gsn_internal.h"
 
@@ -293,6 +297,282 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_kernel(LinArgs a, int k_pad
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// bf16x6 twin of linear_fwd_kernel: the same tiling idea on v_mfma_f32_32x32x16_bf16 with both operands split exactly
+// into three bf16 planes by truncation while they are staged into LDS, six plane products per fp32 product (see
+// chain_seg_bf16.hip / scripts/micro/bf16x6_check.hip: fp32-equivalent error).  Why: fp32 MFMAs block every other wave of
+// their SIMD (profiles/r01_coissue.json) and run at 1/16 of the bf16 rate.
+//   workgroup = 8 waves (two per SIMD, so that one wave's staging / splitting runs next to the other's MFMAs) = 128 x 128
+//   output tile; wave w owns rows 64 (w >> 2) .. + 64 and columns 32 (w & 3) .. + 32 (two accumulator tiles);
+//   per 32-wide K slice: A planes [3][128][40] and W planes [3][128 output columns][40] of bf16 (row pitch 80 bytes = an odd
+//   multiple of 16: conflict-free ds_read_b128 of a lane's 8 consecutive k), double-buffered: 120 KiB, one workgroup per CU.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef unsigned u32x4l __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8l __attribute__((ext_vector_type(8)));
+constexpr int BKP = BK + 8;                       // bf16 row pitch of a plane
+constexpr int BPLANE = BM * BKP / 2;              // floats per plane (BM == BN)
+constexpr int NPRE8 = BM / 16;                    // staged elements per thread per slice with 512 threads
+
+__device__ __forceinline__ void split3l(float x, unsigned &h, unsigned &m, unsigned &l) {
+    h = __float_as_uint(x);
+    const float r1 = x - __uint_as_float(h & 0xffff0000u);
+    m = __float_as_uint(r1);
+    l = __float_as_uint(r1 - __uint_as_float(m & 0xffff0000u));
+}
+
+template <bool STATS, bool VEC4, int D>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void linear_fwd_bf16_kernel(LinArgs a, int k_pad) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    // [2 buffers][A planes 3 | W planes 3][BPLANE floats], then the row-source tables [2][MAX_BLOCKS][BM]
+    auto a_planes = [&](int buf) { return lds + buf * 6 * BPLANE; };
+    auto w_planes = [&](int buf) { return lds + buf * 6 * BPLANE + 3 * BPLANE; };
+    int *rsrc = reinterpret_cast<int *>(lds + 12 * BPLANE);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int li = lane & 31, lh = lane >> 5;
+    // staging.  Scalar: column kc, rows / output columns r0 + 16 i (8 each).  VEC4 (block widths, K and all bases multiples
+    // of 4 floats): columns kc .. kc + 3 of rows / output columns r0, r0 + 64 -- a quarter of the loads and LDS writes.
+    const int kc = VEC4 ? 4 * (tid & 7) : (tid & 31), r0 = VEC4 ? (tid >> 3) : (tid >> 5);
+    const int n0 = blockIdx.y * BN;
+    const int64_t n_tiles = (a.m_rows + BM - 1) / BM;
+    const int n_slices = k_pad / BK;
+
+    for (int i = tid; i < 12 * BPLANE; i += 512) lds[i] = 0.f;
+
+    const int rs_r = tid & (BM - 1);
+    const int32_t *rp32[2];
+    const int64_t *rp64[2];
+    bool ron[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int b = (tid >> 7) + 4 * h;
+        ron[h] = b < a.n_blocks;
+        rp32[h] = nullptr; rp64[h] = nullptr;
+#pragma unroll
+        for (int q = 0; q < MAX_BLOCKS; ++q)
+            if (q == b) { rp32[h] = a.bidx32[q]; rp64[h] = a.bidx[q]; }
+    }
+    auto rs_fetch = [&](int64_t row0, int *rs) {
+        const int64_t grow = row0 + rs_r;
+        const bool ok = grow < a.m_rows;
+        int64_t logical = 0;
+        if (ok) logical = a.row_perm ? (int64_t)a.row_perm[grow] : grow;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int r = 0;   // rows past the end read row 0 (never emitted)
+            if (ron[h] && ok) r = rp32[h] ? rp32[h][logical] : (rp64[h] ? (int)rp64[h][logical] : (int)logical);
+            rs[h] = r;
+        }
+    };
+    auto rs_store = [&](int *dst, const int *rs) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            if (ron[h]) dst[((tid >> 7) + 4 * h) * BM + rs_r] = rs[h];
+    };
+
+    const int col = n0 + wn * 32 + li;
+    const bool cok = col < a.n_out;
+    const float e_bias = (cok && a.bias) ? a.bias[col] : 0.f;
+    float e_scale = 1.f, e_c0 = e_bias;
+    if (cok && a.bn_scale) { e_scale = a.bn_scale[col]; e_c0 = (e_bias - a.bn_mean[col]) * e_scale + a.bn_shift[col]; }
+
+    double st_sum = 0.0, st_sq = 0.0;
+    // D register sets of staged values: the global loads of slice g + D are issued while slice g computes
+    float preAs[D][NPRE8], preWs[D][NPRE8];
+    auto fetch = [&](float *preA, float *preW, const int *rs, int c) {
+        const ColMapL cm = col_map_l(a, c * BK + kc);
+        const int *rp = rs + cm.rsoff + r0;
+        const int kg = c * BK + kc;
+        const int kk = kg < a.k_total ? kg : 0;
+        if (VEC4) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float4 v = *reinterpret_cast<const float4 *>(cm.base + (int64_t)rp[64 * i] * cm.bw);
+                preA[4 * i] = v.x; preA[4 * i + 1] = v.y; preA[4 * i + 2] = v.z; preA[4 * i + 3] = v.w;
+                int j = n0 + r0 + 64 * i;
+                j = j < a.n_out ? j : 0;
+                const float4 u = *reinterpret_cast<const float4 *>(a.W + (int64_t)j * a.k_total + kk);
+                preW[4 * i] = u.x; preW[4 * i + 1] = u.y; preW[4 * i + 2] = u.z; preW[4 * i + 3] = u.w;
+            }
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < NPRE8; ++i) preA[i] = cm.base[(int64_t)rp[16 * i] * cm.bw];
+#pragma unroll
+        for (int i = 0; i < NPRE8; ++i) {
+            int j = n0 + r0 + 16 * i;
+            j = j < a.n_out ? j : 0;
+            preW[i] = a.W[(int64_t)j * a.k_total + kk];
+        }
+    };
+    // registers -> three bf16 planes.  Rows of W^T past K / columns past n_out are zeroed by a 0/1 factor applied to values
+    // that were loaded one slice earlier (no select on fresh loads); A columns past K hold a finite clamped-address value.
+    auto pack2 = [](unsigned lo, unsigned hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); };
+    auto stage = [&](const float *preA, const float *preW, int buf, int c) {
+        const float km = (c * BK + kc < a.k_total) ? 1.f : 0.f;
+        if (VEC4) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float jm = (n0 + r0 + 64 * i < a.n_out) ? km : 0.f;
+                unsigned h[4], m[4], l[4], wh[4], wm_[4], wl[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { split3l(preA[4 * i + e], h[e], m[e], l[e]); split3l(preW[4 * i + e] * jm, wh[e], wm_[e], wl[e]); }
+                const int o = ((r0 + 64 * i) * BKP + kc) / 2;
+                float *pa = a_planes(buf) + o, *pw = w_planes(buf) + o;
+                typedef unsigned u32x2l __attribute__((ext_vector_type(2)));
+                u32x2l v;
+                v[0] = pack2(h[0], h[1]); v[1] = pack2(h[2], h[3]); *reinterpret_cast<u32x2l *>(pa) = v;
+                v[0] = pack2(m[0], m[1]); v[1] = pack2(m[2], m[3]); *reinterpret_cast<u32x2l *>(pa + BPLANE) = v;
+                v[0] = pack2(l[0], l[1]); v[1] = pack2(l[2], l[3]); *reinterpret_cast<u32x2l *>(pa + 2 * BPLANE) = v;
+                v[0] = pack2(wh[0], wh[1]); v[1] = pack2(wh[2], wh[3]); *reinterpret_cast<u32x2l *>(pw) = v;
+                v[0] = pack2(wm_[0], wm_[1]); v[1] = pack2(wm_[2], wm_[3]); *reinterpret_cast<u32x2l *>(pw + BPLANE) = v;
+                v[0] = pack2(wl[0], wl[1]); v[1] = pack2(wl[2], wl[3]); *reinterpret_cast<u32x2l *>(pw + 2 * BPLANE) = v;
+            }
+            return;
+        }
+        unsigned short *pa = reinterpret_cast<unsigned short *>(a_planes(buf)) + r0 * BKP + kc;
+        unsigned short *pw = reinterpret_cast<unsigned short *>(w_planes(buf)) + r0 * BKP + kc;
+#pragma unroll
+        for (int i = 0; i < NPRE8; ++i) {
+            unsigned h, m, l;
+            split3l(preA[i], h, m, l);
+            pa[16 * i * BKP] = (unsigned short)(h >> 16);
+            pa[16 * i * BKP + 2 * BPLANE] = (unsigned short)(m >> 16);
+            pa[16 * i * BKP + 4 * BPLANE] = (unsigned short)(l >> 16);
+            const float jm = (n0 + r0 + 16 * i < a.n_out) ? km : 0.f;
+            split3l(preW[i] * jm, h, m, l);
+            pw[16 * i * BKP] = (unsigned short)(h >> 16);
+            pw[16 * i * BKP + 2 * BPLANE] = (unsigned short)(m >> 16);
+            pw[16 * i * BKP + 4 * BPLANE] = (unsigned short)(l >> 16);
+        }
+    };
+
+    // One flat loop over the slices of all tiles of this workgroup (g = running slice number, set g % D holds its staged
+    // values): stage slice g | barrier | issue the loads of slice g + D | MFMAs of slice g | (last slice of a tile) epilogue.
+    // The row-source table of the next tile is loaded at the start of a tile and stored D slices before its end.
+    const int64_t tile0 = blockIdx.x;
+    const int64_t n_mine = tile0 < n_tiles ? (n_tiles - tile0 + gridDim.x - 1) / gridDim.x : 0;
+    int rs_next[2];
+    rs_fetch(tile0 * BM, rs_next);
+    rs_store(rsrc, rs_next);
+    __syncthreads();
+    if (n_mine > 0) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) fetch(preAs[d], preWs[d], rsrc, d);      // (D <= n_slices: both in the first tile)
+    }
+    int slot = 0, cur = 0, c = 0;
+    int64_t ti = 0;                                                     // ordinal of the current tile among this workgroup's
+    f32x16 acc[2];
+
+#define GSN_MFL(acc, x, y) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8l, x), __builtin_bit_cast(bf16x8l, y), acc, 0, 0, 0)
+    auto body = [&](float *preA, float *preW) {
+        const int64_t tile = tile0 + ti * gridDim.x;
+        const bool has_next = ti + 1 < n_mine;
+        if (c == 0) {
+            rs_fetch((tile + gridDim.x) * BM, rs_next);                 // lands while this tile computes
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        }
+        stage(preA, preW, cur, c);
+        if (c == n_slices - D && has_next) rs_store(rsrc + (slot ^ 1) * (MAX_BLOCKS * BM), rs_next);
+        lds_barrier_l();
+        {   // loads of the slice D ahead, into the register set just consumed
+            const int c2 = c + D;
+            if (c2 < n_slices) fetch(preA, preW, rsrc + slot * (MAX_BLOCKS * BM), c2);
+            else if (has_next) fetch(preA, preW, rsrc + (slot ^ 1) * (MAX_BLOCKS * BM), c2 - n_slices);
+        }
+        const float *ap = a_planes(cur) + ((wm * 64 + li) * BKP + 8 * lh) / 2;
+        const float *bp = w_planes(cur) + ((wn * 32 + li) * BKP + 8 * lh) / 2;
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+            const u32x4l bh = *reinterpret_cast<const u32x4l *>(bp + 8 * s);
+            const u32x4l bm = *reinterpret_cast<const u32x4l *>(bp + 8 * s + BPLANE);
+            const u32x4l bl = *reinterpret_cast<const u32x4l *>(bp + 8 * s + 2 * BPLANE);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float *api = ap + i * (32 * BKP / 2);
+                const u32x4l ah = *reinterpret_cast<const u32x4l *>(api + 8 * s);
+                const u32x4l am = *reinterpret_cast<const u32x4l *>(api + 8 * s + BPLANE);
+                const u32x4l al = *reinterpret_cast<const u32x4l *>(api + 8 * s + 2 * BPLANE);
+                GSN_MFL(acc[i], al, bh); GSN_MFL(acc[i], ah, bl); GSN_MFL(acc[i], am, bm);     // small terms first
+                GSN_MFL(acc[i], ah, bm); GSN_MFL(acc[i], am, bh); GSN_MFL(acc[i], ah, bh);
+            }
+        }
+        cur ^= 1;
+        if (++c < n_slices) return;
+        // epilogue.  C layout of a 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+        const int64_t row0 = tile * BM;
+        const bool full = (row0 + BM <= a.m_rows) && (n0 + BN <= a.n_out);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int64_t rbase = row0 + wm * 64 + i * 32 + 4 * lh;
+            float *op = a.out + rbase * a.n_out + col;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int dr = (r & 3) + 8 * (r >> 2);
+                if (!full && (!cok || rbase + dr >= a.m_rows)) continue;
+                if (STATS) {
+                    const float h = acc[i][r] + e_bias;
+                    st_sum += (double)h;
+                    st_sq += (double)h * (double)h;
+                    if (a.out) op[(int64_t)dr * a.n_out] = h;          // statistics AND the raw pre-BN rows in one pass
+                } else {
+                    op[(int64_t)dr * a.n_out] = apply_act(fmaf(acc[i][r], e_scale, e_c0), a.act);
+                }
+            }
+        }
+        c = 0; slot ^= 1; ++ti;
+    };
+    const int64_t total = n_mine * n_slices;
+    for (int64_t g = 0; g < total; g += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+            if (g + d < total) body(preAs[d], preWs[d]);
+    }
+#undef GSN_MFL
+
+    if (STATS) {
+        double s = st_sum, q = st_sq;
+        s += __shfl_xor(s, 32);
+        q += __shfl_xor(q, 32);
+        if (lh == 0 && cok) {
+            atomicAdd(&a.stats[col], s);
+            atomicAdd(&a.stats[a.n_out + col], q);
+        }
+    }
+}
+
+template <bool STATS, bool VEC4, int D>
+static int launch_linear_bf16_impl(const LinArgs &a, int k_pad, int64_t n_tiles, int col_tiles, hipStream_t st) {
+    const size_t lds = ((size_t)12 * BPLANE + (size_t)2 * MAX_BLOCKS * BM) * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_fwd_bf16_kernel<STATS, VEC4, D>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e0 != hipSuccess) return set_error(GSN_E_HIP, "hipFuncSetAttribute(linear_fwd_bf16_kernel): %s", hipGetErrorString(e0));
+        attr_set = true;
+    }
+    int64_t gx = 256 / col_tiles;   // persistent: one workgroup per CU in total
+    if (gx < 1) gx = 1;
+    if (gx > n_tiles) gx = n_tiles;
+    hipLaunchKernelGGL((linear_fwd_bf16_kernel<STATS, VEC4, D>), dim3((unsigned)gx, (unsigned)col_tiles), dim3(512), lds, st, a, k_pad);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(GSN_E_HIP, "linear_fwd_bf16_kernel: %s", hipGetErrorString(e));
+    return GSN_OK;
+}
+
+template <bool STATS, bool VEC4>
+static int launch_linear_bf16(const LinArgs &a, int k_pad, int64_t n_tiles, int col_tiles, hipStream_t st) {
+    // (D = 2, loads two slices ahead, was measured at the same speed: the kernel is bound by its lock-step phases --
+    // staging, barrier, matrix phase -- not by the gathers' latency; a loader / matrix role split is the next step)
+    return launch_linear_bf16_impl<STATS, VEC4, 1>(a, k_pad, n_tiles, col_tiles, st);
+}
+
 template <bool STATS, bool WRES>
 static int launch_linear(const LinArgs &a, int k_pad, size_t lds, int64_t gx, int col_tiles, hipStream_t st) {
     static bool attr_set = false;
@@ -338,6 +618,15 @@ extern "C" int gsn_linear_fwd_hip(int64_t m_rows, int n_blocks, const gsn_block 
     const int col_tiles = (int)((n_out + BN - 1) / BN);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int k_pad = (k_total + BK - 1) / BK * BK;
+    {   // default: the bf16x6 kernel (GSN_LINEAR_BF16X6=0 selects the fp32-MFMA kernel below for A/B measurements)
+        static const bool bf16x6 = [] { const char *d = getenv("GSN_LINEAR_BF16X6"); return !(d && atoi(d) == 0); }();
+        bool vec4 = (k_total & 3) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0;   // float4 staging of A and W
+        for (int b = 0; b < n_blocks; ++b)
+            if ((a.bwidth[b] & 3) || (reinterpret_cast<uintptr_t>(a.bdata[b]) & 15)) vec4 = false;
+        { const char *d = getenv("GSN_LINEAR_VEC4"); if (d && atoi(d) == 0) vec4 = false; }
+        if (bf16x6 && vec4) return stats ? launch_linear_bf16<true, true>(a, k_pad, n_tiles, col_tiles, st) : launch_linear_bf16<false, true>(a, k_pad, n_tiles, col_tiles, st);
+        if (bf16x6) return stats ? launch_linear_bf16<true, false>(a, k_pad, n_tiles, col_tiles, st) : launch_linear_bf16<false, false>(a, k_pad, n_tiles, col_tiles, st);
+    }
     const size_t common = (size_t)2 * BM * APITCH * 4 + 2 * MAX_BLOCKS * BM * 4;
     const size_t lds_res = (size_t)k_pad * WPITCH * 4 + common;
     const size_t lds_str = (size_t)2 * BK * WPITCH * 4 + common;
