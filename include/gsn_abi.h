@@ -144,7 +144,9 @@ int gsn_propagate_bwd_hip(int kind, int64_t n_nodes, int64_t n_edges, const int6
                           const float *g_out, float *g_a, float *g_b, float *g_c, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
- * HP-2  fused dense stage (device, fp32 MFMA v_mfma_f32_32x32x2_f32).  One models_misc.mlp layer
+ * HP-2  fused dense stage (device; fp32 in / fp32 out; matrix products run as six exact bf16 plane products per fp32
+ * product on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- fp32-equivalent error -- or, with GSN_LINEAR_BF16X6=0,
+ * on v_mfma_f32_32x32x2_f32).  One models_misc.mlp layer
  * (models_misc.py:52-58)   Y = act( bn( X W^T + bias ) )   over M rows, where the rows of X are assembled on the fly
  * as a concatenation of up to five blocks, each either direct ([M][w]) or gathered through an int64 index
  * ([R][w] rows picked by idx[M]) -- this is torch.cat((x_i, x_j, identifiers.., edge_features), -1) feeding msg_fn
@@ -172,8 +174,9 @@ int gsn_linear_fwd_hip(int64_t m_rows, int n_blocks, const gsn_block *blocks, co
                        const int32_t *row_perm, float *out, double *stats, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
- * HP-2  fused MLP chain (device, fp32 MFMA).  One or two dependent stages of models_misc.mlp (models_misc.py:52-58)
- * evaluated per 64-row tile without writing the intermediates to HBM:
+ * HP-2  fused MLP chain (device; fp32 in / fp32 out; matrix products as in gsn_linear_fwd_hip: bf16x6 by default,
+ * GSN_CHAIN_BF16X6=0 for the fp32-MFMA kernels).  One or two dependent stages of models_misc.mlp (models_misc.py:52-58)
+ * evaluated per 32- or 64-row tile without writing the intermediates to HBM:
  *     Y_s = act_s( bn_s( [ blocks_s | Y_{s-1} ] W_s^T + bias_s ) ),   out = Y_last   ([M][n_out_last])
  * i.e. the input of stage s > 0 is the concatenation of its own HBM blocks (e.g. x in update_fn's cat((x, agg)),
  * GSN_sparse.py:114 / GSN_edge_sparse.py:112) followed by the previous stage's output.  Weights are held in registers,
