@@ -28,8 +28,12 @@ __global__ void csr_hist(const int64_t *__restrict__ index, int64_t n_edges, int
         atomicAdd(&cnt[index[e]], 1);
 }
 
-constexpr int SCAN_T = 256;
-constexpr int SCAN_ITEMS = 4;
+// One-wave workgroups throughout the CSR build: it usually runs on a second stream next to the counting kernel, whose
+// one-wave workgroups refill every freed wave slot at once -- a 256-thread workgroup needs four free slots on one CU at the
+// same moment and starves until the counting kernel drains (measured: csr_hist 254 us instead of 30).
+constexpr int CSR_T = 64;
+constexpr int SCAN_T = 64;
+constexpr int SCAN_ITEMS = 16;
 constexpr int SCAN_TILE = SCAN_T * SCAN_ITEMS;
 
 // per-tile sums
@@ -52,29 +56,20 @@ __global__ __launch_bounds__(SCAN_T) void scan_tile_sums(const int32_t *__restri
     }
 }
 
-// exclusive scan of the tile sums by one workgroup (n_tiles is small: n / 1024)
-__global__ __launch_bounds__(1024) void scan_tile_offsets(int32_t *tile_sums, int64_t n_tiles) {
-    __shared__ int32_t buf[1024];
-    __shared__ int32_t carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (int64_t base = 0; base < n_tiles; base += 1024) {
-        const int64_t j = base + threadIdx.x;
+// exclusive scan of the tile sums by one wave (n_tiles is small: n / 1024)
+__global__ __launch_bounds__(64) void scan_tile_offsets(int32_t *tile_sums, int64_t n_tiles) {
+    const int lane = threadIdx.x;
+    int32_t carry = 0;
+    for (int64_t base = 0; base < n_tiles; base += 64) {
+        const int64_t j = base + lane;
         const int32_t v = j < n_tiles ? tile_sums[j] : 0;
-        buf[threadIdx.x] = v;
-        __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {
-            const int32_t t = threadIdx.x >= o ? buf[threadIdx.x - o] : 0;
-            __syncthreads();
-            buf[threadIdx.x] += t;
-            __syncthreads();
+        int32_t incl = v;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int32_t t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
         }
-        const int32_t incl = buf[threadIdx.x];
-        const int32_t c = carry;
-        __syncthreads();
-        if (j < n_tiles) tile_sums[j] = c + incl - v;
-        if (threadIdx.x == 1023) carry = c + incl;
-        __syncthreads();
+        if (j < n_tiles) tile_sums[j] = carry + incl - v;
+        carry += __shfl(incl, 63);
     }
 }
 
@@ -436,20 +431,20 @@ extern "C" int gsn_csr_build_hip(int64_t n_nodes, int64_t n_edges, const int64_t
     int32_t *cnt = scratch;                 // [n1] histogram, later the fill cursor
     int32_t *tiles = scratch + n1;          // [n_tiles]
     const int64_t n_tiles = (n1 + SCAN_TILE - 1) / SCAN_TILE;
-    hipLaunchKernelGGL(csr_zero, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, st, cnt, n1);
+    hipLaunchKernelGGL(csr_zero, dim3((unsigned)((n1 + CSR_T - 1) / CSR_T)), dim3(CSR_T), 0, st, cnt, n1);
     if (n_edges > 0) {
-        int64_t blocks = (n_edges + 255) / 256;
-        if (blocks > 8192) blocks = 8192;
-        hipLaunchKernelGGL(csr_hist, dim3((unsigned)blocks), dim3(256), 0, st, index, n_edges, cnt);
+        int64_t blocks = (n_edges + CSR_T - 1) / CSR_T;
+        if (blocks > 32768) blocks = 32768;
+        hipLaunchKernelGGL(csr_hist, dim3((unsigned)blocks), dim3(CSR_T), 0, st, index, n_edges, cnt);
     }
     hipLaunchKernelGGL(scan_tile_sums, dim3((unsigned)n_tiles), dim3(SCAN_T), 0, st, cnt, n1, tiles);
-    hipLaunchKernelGGL(scan_tile_offsets, dim3(1), dim3(1024), 0, st, tiles, n_tiles);
+    hipLaunchKernelGGL(scan_tile_offsets, dim3(1), dim3(64), 0, st, tiles, n_tiles);
     hipLaunchKernelGGL(scan_apply, dim3((unsigned)n_tiles), dim3(SCAN_T), 0, st, cnt, n1, tiles, seg_ptr, cnt);
     if (n_edges > 0) {
-        int64_t blocks = (n_edges + 255) / 256;
-        if (blocks > 8192) blocks = 8192;
-        hipLaunchKernelGGL(csr_fill, dim3((unsigned)blocks), dim3(256), 0, st, index, n_edges, cnt, perm);
-        hipLaunchKernelGGL(csr_sort_segments, dim3((unsigned)((n_nodes + 255) / 256)), dim3(256), 0, st, seg_ptr, n_nodes, perm, sorted_target, other, sorted_other);
+        int64_t blocks = (n_edges + CSR_T - 1) / CSR_T;
+        if (blocks > 32768) blocks = 32768;
+        hipLaunchKernelGGL(csr_fill, dim3((unsigned)blocks), dim3(CSR_T), 0, st, index, n_edges, cnt, perm);
+        hipLaunchKernelGGL(csr_sort_segments, dim3((unsigned)((n_nodes + CSR_T - 1) / CSR_T)), dim3(CSR_T), 0, st, seg_ptr, n_nodes, perm, sorted_target, other, sorted_other);
     }
     return hip_check("gsn_csr_build_hip");
 }
