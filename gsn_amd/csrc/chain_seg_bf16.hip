@@ -325,7 +325,11 @@ __global__ __launch_bounds__(TBM * 12) __attribute__((amdgpu_waves_per_eu(3, 3))
             float y0[SEG_ROWS], y1[SEG_ROWS];
 #pragma unroll
             for (int r = 0; r < SEG_ROWS; ++r) { y0[r] = yp[r * py]; y1[r] = yp[r * py + 64]; }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the LDS reads (and last tile's target loads) are in
+            // The LDS values are consumed (an empty asm the compiler must satisfy with its own lgkmcnt wait) BEFORE the next
+            // tile's target loads are issued: SMEM shares lgkmcnt with LDS and returns out of order, so a wait placed after
+            // the scalar loads would be lgkmcnt(0), i.e. the scalar loads' full latency in front of the walk.
+#pragma unroll
+            for (int r = 0; r < SEG_ROWS; ++r) asm volatile("" :: "v"(y0[r]), "v"(y1[r]));
             if (PROF) u1 = clkb();
             int cv[SEG_ROWS];
 #pragma unroll
