@@ -8,6 +8,8 @@
 // category indices on the host first, utils_encoding.py:37-59).
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
+
 #include "gsn_internal.h"
 
 namespace gsn {
@@ -43,6 +45,33 @@ __global__ __launch_bounds__(256) void one_hot_kernel(OneHotArgs a) {
     }
 }
 
+// Row-per-thread variant for the common narrow case (<= 4 identifier columns, encoded width a multiple of 4 and <= 64, output
+// 16-byte aligned): the row's values are read once, the floats leave as float4 stores (the element-per-thread kernel above
+// pays a 64-bit division, two LDS look-ups and an 8-byte load per output float).
+template <int NC>
+__global__ __launch_bounds__(256) void one_hot_rows_kernel(OneHotArgs a) {
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= a.m_rows) return;
+    int hot[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        int64_t v = a.values[row * NC + c];
+        const int ncls = a.cls_ptr[c + 1] - a.cls_ptr[c];
+        if (a.clamp) v = v < 0 ? 0 : (v >= ncls ? ncls - 1 : v);
+        hot[c] = (v >= 0 && v < ncls) ? a.cls_ptr[c] + (int)v : -1;      // position of the 1 in the encoded row, or none
+    }
+    float4 *dst = reinterpret_cast<float4 *>(a.out + row * a.width);
+    for (int k = 0; k < a.width; k += 4) {
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int d = hot[c] - k;
+            o.x = d == 0 ? 1.f : o.x; o.y = d == 1 ? 1.f : o.y; o.z = d == 2 ? 1.f : o.z; o.w = d == 3 ? 1.f : o.w;
+        }
+        dst[k >> 2] = o;
+    }
+}
+
 }  // namespace gsn
 
 using namespace gsn;
@@ -61,6 +90,17 @@ extern "C" int gsn_one_hot_hip(int64_t m_rows, int n_cols, const int64_t *values
     a.width = a.cls_ptr[n_cols];
     if (a.width > 1024) return set_error(GSN_E_UNSUPPORTED, "gsn_one_hot_hip: encoded width %d > 1024", a.width);
     if (m_rows <= 0) return GSN_OK;
+    if (n_cols <= 4 && (a.width & 3) == 0 && a.width <= 64 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+        const dim3 grid((unsigned)((m_rows + 255) / 256)), block(256);
+        hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+        if (n_cols == 1) hipLaunchKernelGGL(one_hot_rows_kernel<1>, grid, block, 0, st, a);
+        else if (n_cols == 2) hipLaunchKernelGGL(one_hot_rows_kernel<2>, grid, block, 0, st, a);
+        else if (n_cols == 3) hipLaunchKernelGGL(one_hot_rows_kernel<3>, grid, block, 0, st, a);
+        else hipLaunchKernelGGL(one_hot_rows_kernel<4>, grid, block, 0, st, a);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return set_error(GSN_E_HIP, "one_hot_rows_kernel: %s", hipGetErrorString(e));
+        return GSN_OK;
+    }
     int64_t blocks = (m_rows * a.width + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(one_hot_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
