@@ -54,6 +54,10 @@ __global__ __launch_bounds__(TBM * 12) __attribute__((amdgpu_waves_per_eu(3, 3))
     auto in_tile = [&](int64_t i) { return lds + (int)(i & 1) * in_sz; };
     auto y_tile = [&](int64_t i) { return lds + 2 * in_sz + (int)(i & 1) * y_sz; };
     int *rsrc = reinterpret_cast<int *>(lds + 2 * in_sz + 2 * y_sz);     // [NSLOT][RSS]
+    // exact_flag[b] == ordinal of the tile in input buffer b  <=>  that tile has a non-zero bit in its middle or low plane.
+    // One-hot / small-integer inputs (layer 0 of the reference models: atom, bond and identifier encodings) are exact in bf16:
+    // their m and l planes are all zero and the three plane products that read them contribute exactly nothing.
+    int *exact_flag = rsrc + NSLOT * RSS;                                 // [2]
 
     const int tid = threadIdx.x;
     const bool grp_b = tid >= GT;                   // wave-uniform
@@ -64,6 +68,7 @@ __global__ __launch_bounds__(TBM * 12) __attribute__((amdgpu_waves_per_eu(3, 3))
     const ChainStage &st = a.st[0];
 
     for (int i = tid; i < 2 * in_sz + 2 * y_sz; i += GT + GB) lds[i] = 0.f;      // padded columns must hold finite values
+    if (tid < 2) exact_flag[tid] = -1;
     __syncthreads();
 
     if (!grp_b) {
@@ -154,14 +159,15 @@ __global__ __launch_bounds__(TBM * 12) __attribute__((amdgpu_waves_per_eu(3, 3))
                 pf0[j][i] = cm0[j].base[(int64_t)(sr < 0 ? 0 : sr) * cm0[j].bw];
             }
         };
-        auto stage_in = [&](float *dst) {
+        auto stage_in = [&](float *dst, int64_t ordinal) {
+            unsigned low_bits = 0;
 #pragma unroll
             for (int j = 0; j < PF0_J; ++j) {
                 const int k = kc0 + 32 * j;
                 if (k < KIN) {
                     unsigned h[4], m[4], l[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) split3(pf0[j][e], h[e], m[e], l[e]);
+                    for (int e = 0; e < 4; ++e) { split3(pf0[j][e], h[e], m[e], l[e]); low_bits |= m[e] | l[e]; }
                     float *p = dst + (r0 * KP + k) / 2;
                     u32x2 vh, vm, vl;
                     vh[0] = pack_hi(h[0], h[1]); vh[1] = pack_hi(h[2], h[3]);
@@ -172,6 +178,7 @@ __global__ __launch_bounds__(TBM * 12) __attribute__((amdgpu_waves_per_eu(3, 3))
                     *reinterpret_cast<u32x2 *>(p + 2 * PLANE) = vl;
                 }
             }
+            if (low_bits & 0xffff0000u) exact_flag[ordinal & 1] = (int)ordinal;      // (every writer stores the same value)
         };
         {
             const int row0 = (int)first * TBM;
@@ -185,7 +192,7 @@ __global__ __launch_bounds__(TBM * 12) __attribute__((amdgpu_waves_per_eu(3, 3))
         if (n_iter > 0) {
 #pragma unroll
             for (int j = 0; j < PF0_J; ++j) prefetch_j(rsrc, j);
-            stage_in(in_tile(0));
+            stage_in(in_tile(0), 0);
         }
         lds_barrier();
         unsigned long long pc[6] = {0, 0, 0, 0, 0, 0};
@@ -217,13 +224,21 @@ __global__ __launch_bounds__(TBM * 12) __attribute__((amdgpu_waves_per_eu(3, 3))
                 if (active && !(a.dbg & 2)) {
                     const float *ap = in + ((32 * rh + li) * KP + 8 * lh) / 2;
 #define GSN_MF(x, y) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, y), acc, 0, 0, 0)
+                    if (exact_flag[i & 1] == (int)i) {              // (wave-uniform; decided once per tile, not between MFMAs)
 #pragma unroll
-                    for (int s16 = 0; s16 < NK16; ++s16) {
-                        const u32x4 ah = *reinterpret_cast<const u32x4 *>(ap + 8 * s16);
-                        const u32x4 am = *reinterpret_cast<const u32x4 *>(ap + 8 * s16 + PLANE);
-                        const u32x4 al = *reinterpret_cast<const u32x4 *>(ap + 8 * s16 + 2 * PLANE);
-                        GSN_MF(al, Bh[s16]); GSN_MF(ah, Bl[s16]); GSN_MF(am, Bm[s16]);     // small terms first
-                        GSN_MF(ah, Bm[s16]); GSN_MF(am, Bh[s16]); GSN_MF(ah, Bh[s16]);
+                        for (int s16 = 0; s16 < NK16; ++s16) {
+                            const u32x4 ah = *reinterpret_cast<const u32x4 *>(ap + 8 * s16);
+                            const u32x4 am = *reinterpret_cast<const u32x4 *>(ap + 8 * s16 + PLANE);
+                            const u32x4 al = *reinterpret_cast<const u32x4 *>(ap + 8 * s16 + 2 * PLANE);
+                            GSN_MF(al, Bh[s16]); GSN_MF(ah, Bl[s16]); GSN_MF(am, Bm[s16]);     // small terms first
+                            GSN_MF(ah, Bm[s16]); GSN_MF(am, Bh[s16]); GSN_MF(ah, Bh[s16]);
+                        }
+                    } else {                                        // bf16-exact tile: x = x_h, three products
+#pragma unroll
+                        for (int s16 = 0; s16 < NK16; ++s16) {
+                            const u32x4 ah = *reinterpret_cast<const u32x4 *>(ap + 8 * s16);
+                            GSN_MF(ah, Bl[s16]); GSN_MF(ah, Bm[s16]); GSN_MF(ah, Bh[s16]);
+                        }
                     }
 #undef GSN_MF
                 }
@@ -241,7 +256,7 @@ __global__ __launch_bounds__(TBM * 12) __attribute__((amdgpu_waves_per_eu(3, 3))
                     }
                 }
                 t3 = clk();
-                stage_in(in_tile(i + 1));                                   // (waits for the gathers; no stores in this group)
+                stage_in(in_tile(i + 1), i + 1);                            // (waits for the gathers; no stores in this group)
                 if (rs_wave) rs_commit(rsrc + (int)((i + 2) & (NSLOT - 1)) * RSS, row2);
                 t4 = clk();
             }
@@ -391,7 +406,7 @@ static int launch_bf_impl(const ChainArgs &a, hipStream_t st) {
     }
     int py = a.st[0].n_out | 1;
     if (py == a.st[0].n_out) py += 2;
-    const size_t lds = ((size_t)2 * 3 * (TBM * (NK16 * 16 + 8) / 2) + (size_t)2 * TBM * py + (size_t)4 * CMAX_BLOCKS * TBM) * 4;
+    const size_t lds = ((size_t)2 * 3 * (TBM * (NK16 * 16 + 8) / 2) + (size_t)2 * TBM * py + (size_t)4 * CMAX_BLOCKS * TBM + 2) * 4;
     if (lds > 160 * 1024) return 1;
     unsigned long long *prof = nullptr;
     int prio = 0;

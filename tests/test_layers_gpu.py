@@ -500,3 +500,29 @@ def test_chain_shape_cases_reach_every_kernel_variant():
     for kernel in ("mlp_chain_kernel", "mlp_chain_kernel(stats)", "mlp_chain1_seg_kernel", "mlp_chain1_seg_bf16_kernel",
                    "mlp_chain2_pipe_kernel", "mlp_chain2_pipe_bf16_kernel"):
         assert kernel in seen, (kernel, sorted(seen))
+
+
+@pytest.mark.parametrize("mix", ["exact", "mixed"])
+def test_fused_scatter_add_with_bf16_exact_inputs(mix):
+    """One-hot / small-integer inputs are exact in bf16: the bf16x6 edge stage then skips the plane products that read the
+    (all-zero) middle and low planes of a tile.  'mixed': only part of the edge rows carry inexact values, so exact and
+    inexact tiles alternate inside one launch."""
+    from gsn_amd.layers import _Stage, run_stages, _csr_for
+    torch.manual_seed(5)
+    dev = "cuda"
+    N, E = 900, 7000
+    tgt = torch.randint(0, N, (E,), device=dev); src = torch.randint(0, N, (E,), device=dev)
+    ei = torch.stack([src, tgt], 0)
+    x = torch.nn.functional.one_hot(torch.randint(0, 28, (N,), device=dev), 28).float()
+    ids = torch.randint(0, 5, (E, 12), device=dev).float()                 # small integers: exact as well
+    ef = torch.nn.functional.one_hot(torch.randint(0, 4, (E,), device=dev), 4).float()
+    if mix == "mixed":
+        ef = ef.clone(); ef[tgt < N // 3] = torch.randn(int((tgt < N // 3).sum()), 4, device=dev)
+    csr = _csr_for(ei, 1, N)
+    K = 28 + 28 + 12 + 4
+    W = torch.randn(128, K, device=dev) / K ** 0.5; b = torch.randn(128, device=dev)
+    st = _Stage(W, b, None, "relu", [(x, csr.tgt), (x, csr.src), (ids, csr.perm), (ef, csr.perm)])
+    out = run_stages([st], E, False, csr=csr)
+    msg = torch.relu(torch.cat([x[tgt], x[src], ids, ef], 1).double() @ W.double().T + b.double())
+    ref = torch.zeros(N, 128, dtype=torch.float64, device=dev).index_add_(0, tgt, msg)
+    assert rel_err(out.double(), ref) < TOL
