@@ -115,7 +115,9 @@ __global__ __launch_bounds__(TBM * 12) __attribute__((amdgpu_waves_per_eu(3, 3))
             cm0[j] = col_map(a, 0, kc0 + 32 * j);
             cm0[j].rsoff = cm0[j].rsoff / CBM * TBM;
         }
-        float pf0[PF0_J][NROW];
+        // two register sets: the gathers of tile t go to set t & 1, two tiles before the tile is computed (one tile of bf16
+        // MFMAs is shorter than a gather's latency)
+        float pfs[2][PF0_J][NROW];
         // Row sources: thread t resolves tile row t % TBM of input block t / TBM.  Every load below is unconditional from a
         // valid address and its value stays RAW in a register until the end of the tile (any select / sign extension on a
         // just-loaded value makes the compiler wait for it on the spot: a full memory latency at the top of every tile), and
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(TBM * 12) __attribute__((amdgpu_waves_per_eu(3, 3))
             const bool ok = row0 + rs_r < m_rows;
             if (rs_on) dst[rs_b * TBM + rs_r] = ok ? (rs_idx ? raw_idx : rs_lg) : -1;
         };
-        auto prefetch_j = [&](const int *rs, int j) {
+        auto prefetch_j = [&](float (*pf0)[NROW], const int *rs, int j) {
             if (VEC4) {
                 if (kc0 + 32 * j >= KIN) return;
                 const int sr = rs[cm0[j].rsoff + r0];
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(TBM * 12) __attribute__((amdgpu_waves_per_eu(3, 3))
                 pf0[j][i] = cm0[j].base[(int64_t)(sr < 0 ? 0 : sr) * cm0[j].bw];
             }
         };
-        auto stage_in = [&](float *dst, int64_t ordinal) {
+        auto stage_in = [&](float (*pf0)[NROW], float *dst, int64_t ordinal) {
             unsigned low_bits = 0;
 #pragma unroll
             for (int j = 0; j < PF0_J; ++j) {
@@ -180,19 +182,23 @@ __global__ __launch_bounds__(TBM * 12) __attribute__((amdgpu_waves_per_eu(3, 3))
             }
             if (low_bits & 0xffff0000u) exact_flag[ordinal & 1] = (int)ordinal;      // (every writer stores the same value)
         };
-        {
+        {   // row sources of this workgroup's first three tiles; the permutation entry of the fourth in flight
             const int row0 = (int)first * TBM;
             rs_issue(row0, permp[clampr(row0 + rs_r)]);
             rs_commit(rsrc, row0);
             rs_issue(row0 + gstep, permp[clampr(row0 + gstep + rs_r)]);
             rs_commit(rsrc + RSS, row0 + gstep);
-            raw_perm = permp[clampr(row0 + 2 * gstep + rs_r)];
+            rs_issue(row0 + 2 * gstep, permp[clampr(row0 + 2 * gstep + rs_r)]);
+            rs_commit(rsrc + 2 * RSS, row0 + 2 * gstep);
+            raw_perm = permp[clampr(row0 + 3 * gstep + rs_r)];
         }
         lds_barrier();
         if (n_iter > 0) {
 #pragma unroll
-            for (int j = 0; j < PF0_J; ++j) prefetch_j(rsrc, j);
-            stage_in(in_tile(0), 0);
+            for (int j = 0; j < PF0_J; ++j) prefetch_j(pfs[0], rsrc, j);
+            stage_in(pfs[0], in_tile(0), 0);
+#pragma unroll
+            for (int j = 0; j < PF0_J; ++j) prefetch_j(pfs[1], rsrc + RSS, j);            // tile 1 -> set 1
         }
         lds_barrier();
         unsigned long long pc[6] = {0, 0, 0, 0, 0, 0};
@@ -203,13 +209,14 @@ __global__ __launch_bounds__(TBM * 12) __attribute__((amdgpu_waves_per_eu(3, 3))
             __builtin_amdgcn_sched_barrier(0);
             return v;
         };
-        for (int64_t i = 0; i <= n_iter; ++i) {
+        // pf_load: the set that receives the gathers of tile i + 2 (it held tile i, staged a tile ago); pf_stage: tile i + 1
+        auto body = [&](int64_t i, float (*pf_load)[NROW], float (*pf_stage)[NROW]) {
             const unsigned long long t0 = clk();
             unsigned long long t1 = t0, t2 = t0, t3 = t0, t4 = t0;
             if (i < n_iter) {
                 const int64_t tile = first + i * gridDim.x;
-                const int *rs_next = rsrc + (int)((i + 1) & (NSLOT - 1)) * RSS;
-                const int row2 = (int)tile * TBM + 2 * gstep;               // the tile after next
+                const int *rs_next = rsrc + (int)((i + 2) & (NSLOT - 1)) * RSS;
+                const int row2 = (int)tile * TBM + 3 * gstep;               // the tile three ahead (row sources)
                 if (rs_wave) {
                     rs_issue(row2, raw_perm);
                     raw_perm = permp[clampr(row2 + gstep + rs_r)];
@@ -220,7 +227,7 @@ __global__ __launch_bounds__(TBM * 12) __attribute__((amdgpu_waves_per_eu(3, 3))
                 for (int r = 0; r < 16; ++r) acc[r] = c0;
                 t1 = clk();
 #pragma unroll
-                for (int j = 0; j < PF0_J; ++j) prefetch_j(rs_next, j);   // next tile's gathers: the whole matrix phase to land
+                for (int j = 0; j < PF0_J; ++j) prefetch_j(pf_load, rs_next, j);   // gathers of tile i + 2: a whole tile to land
                 if (active && !(a.dbg & 2)) {
                     const float *ap = in + ((32 * rh + li) * KP + 8 * lh) / 2;
 #define GSN_MF(x, y) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, y), acc, 0, 0, 0)
@@ -256,8 +263,8 @@ __global__ __launch_bounds__(TBM * 12) __attribute__((amdgpu_waves_per_eu(3, 3))
                     }
                 }
                 t3 = clk();
-                stage_in(in_tile(i + 1), i + 1);                            // (waits for the gathers; no stores in this group)
-                if (rs_wave) rs_commit(rsrc + (int)((i + 2) & (NSLOT - 1)) * RSS, row2);
+                stage_in(pf_stage, in_tile(i + 1), i + 1);                  // (gathered a tile ago; no stores in this group)
+                if (rs_wave) rs_commit(rsrc + (int)((i + 3) & (NSLOT - 1)) * RSS, row2);
                 t4 = clk();
             }
             lds_barrier();
@@ -266,6 +273,10 @@ __global__ __launch_bounds__(TBM * 12) __attribute__((amdgpu_waves_per_eu(3, 3))
                 const unsigned long long t5 = clk();
                 pc[0] += t1 - t0; pc[1] += t2 - t1; pc[2] += t3 - t2; pc[3] += t4 - t3; pc[4] += t5 - t4; pc[5] += 1;
             }
+        };
+        for (int64_t i = 0; i <= n_iter; i += 2) {
+            body(i, pfs[0], pfs[1]);
+            if (i + 1 <= n_iter) body(i + 1, pfs[1], pfs[0]);
         }
         if (PROF && prof && lane == 0 && blockIdx.x == 0) {
             unsigned long long *o = prof + w8 * 6;
