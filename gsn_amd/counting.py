@@ -181,7 +181,19 @@ def subgraph_isomorphism_edge_counts(edge_index, **kwargs):
     plan = CountPlan.get([sg.edge_list], "edge", induced, sg.directed_orbits)
     ei, n, E = _single_graph(edge_index, 0)
     out, _ = count_batch(plan, [0, max(n, 1)], [0, E], ei, ids_are_global=False, max_nodes=max(n, 1), max_edges=E)
+    if getattr(sg, "line_graph_orbits", False):
+        _line_graph_orbits_keyerror(sg, out)
+        return torch.zeros((E, len(subgraph_dict["orbit_partition"])), dtype=torch.float64)
     return out.cpu().to(torch.float64)
+
+
+def _line_graph_orbits_keyerror(sg, counts):
+    """Orbits from edge_automorphism_orbits (--edge_automorphism line_graph, deprecated) have ONE membership entry per
+    undirected pattern edge (utils_graph_processing.py:241-243), but the reference's edge counter looks the membership up by
+    position in the DIRECTED edge list (:161-173): the first match raises KeyError(m) at i = m.  Same behaviour here: a
+    graph with at least one match raises, a graph without matches gets its all-zero rows."""
+    if bool((counts != 0).any().item()):
+        raise KeyError(len(sg.get_edges()))
 
 
 def subgraph_counts2ids(count_fn, data, subgraph_dicts, subgraph_params):
@@ -210,6 +222,17 @@ def subgraph_counts2ids(count_fn, data, subgraph_dicts, subgraph_params):
     e_cpu, n, E = _single_graph(edge_index, num_nodes)
     out, _ = count_batch(plan, [0, n], [0, E], e_cpu, ids_are_global=False, max_nodes=n, max_edges=E)
     ids = out[:num_nodes] if mode == "vertex" else out
+    if mode == "edge" and any(getattr(p, "line_graph_orbits", False) for p in pats):
+        cols, blocks = 0, []
+        for p, d in zip(pats, subgraph_dicts):        # per pattern, as the reference's loop would reach it
+            w = CountPlan.get([p.edge_list], mode, subgraph_params["induced"], dirorb).n_cols
+            if p.line_graph_orbits:
+                _line_graph_orbits_keyerror(p, out[:, cols:cols + w])
+                blocks.append(torch.zeros((out.shape[0], len(d["orbit_partition"])), dtype=torch.int64, device=out.device))
+            else:
+                blocks.append(out[:, cols:cols + w])
+            cols += w
+        ids = torch.cat(blocks, 1)
     setattr(data, "edge_index", edge_index)
     setattr(data, "identifiers", ids.cpu().long())
     return data

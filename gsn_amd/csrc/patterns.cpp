@@ -234,6 +234,83 @@ extern "C" int gsn_pattern_orbits(int64_t n_edges, const int64_t *edges, int dir
     return GSN_OK;
 }
 
+// ---- vertex orbits of a graph with up to 64 vertices (line graphs of patterns: utils_graph_processing.py:205-231) ----------
+namespace {
+struct OrbitSearch {
+    int n;
+    uint64_t adj[64];
+    int deg[64];
+    int order[64];      // assignment order: the forced vertex first, then breadth-first from it, then the rest
+    int img[64];
+    // extend sigma over order[l..]; sigma must map edges to edges and non-edges to non-edges among assigned vertices
+    bool extend(int l, uint64_t used) {
+        if (l == n) return true;
+        const int x = order[l];
+        for (int y = 0; y < n; ++y) {
+            if (((used >> y) & 1) || deg[y] != deg[x]) continue;
+            bool ok = true;
+            for (int j = 0; j < l && ok; ++j) {
+                const int a = order[j];
+                if (((adj[x] >> a) & 1) != ((adj[y] >> img[a]) & 1)) ok = false;
+            }
+            if (!ok) continue;
+            img[x] = y;
+            if (extend(l + 1, used | (1ull << y))) return true;
+        }
+        return false;
+    }
+    bool maps(int u, int v) {   // is there an automorphism with sigma(u) = v
+        if (deg[u] != deg[v]) return false;
+        bool seen[64] = {false};
+        int cnt = 0;
+        auto bfs = [&](int s) {
+            int head = cnt;
+            order[cnt++] = s; seen[s] = true;
+            while (head < cnt) {
+                const int a = order[head++];
+                for (int b = 0; b < n; ++b)
+                    if (((adj[a] >> b) & 1) && !seen[b]) { seen[b] = true; order[cnt++] = b; }
+            }
+        };
+        bfs(u);
+        for (int s = 0; s < n; ++s)
+            if (!seen[s]) bfs(s);
+        img[u] = v;
+        return extend(1, 1ull << v);
+    }
+};
+}  // namespace
+
+extern "C" int gsn_graph_vertex_orbits(int64_t n_vertices, int64_t n_edges, const int64_t *edges, int64_t *out_orbit,
+                                       int64_t *out_n_orbits) {
+    if (n_vertices < 0 || n_vertices > 64) return set_error(GSN_E_UNSUPPORTED, "gsn_graph_vertex_orbits: %lld vertices; this build handles <= 64", (long long)n_vertices);
+    if (n_edges > 0 && !edges) return set_error(GSN_E_INVALID, "gsn_graph_vertex_orbits: no edge array");
+    OrbitSearch S;
+    S.n = (int)n_vertices;
+    for (int v = 0; v < S.n; ++v) S.adj[v] = 0;
+    for (int64_t i = 0; i < n_edges; ++i) {
+        const int64_t u = edges[2 * i], v = edges[2 * i + 1];
+        if (u < 0 || v < 0 || u >= n_vertices || v >= n_vertices) return set_error(GSN_E_INVALID, "gsn_graph_vertex_orbits: vertex id out of range");
+        if (u == v) continue;
+        S.adj[u] |= 1ull << v;
+        S.adj[v] |= 1ull << u;
+    }
+    for (int v = 0; v < S.n; ++v) S.deg[v] = __builtin_popcountll(S.adj[v]);
+    // minrep[v] = smallest vertex of v's orbit: vertices in ascending order try the earlier orbit minima only
+    int minrep[64];
+    std::vector<int> reps;
+    for (int v = 0; v < S.n; ++v) {
+        minrep[v] = v;
+        for (int r : reps)
+            if (S.maps(r, v)) { minrep[v] = r; break; }
+        if (minrep[v] == v) reps.push_back(v);
+    }
+    if (out_orbit)
+        for (int v = 0; v < S.n; ++v) out_orbit[v] = (int64_t)(std::lower_bound(reps.begin(), reps.end(), minrep[v]) - reps.begin());
+    if (out_n_orbits) *out_n_orbits = (int64_t)reps.size();
+    return GSN_OK;
+}
+
 extern "C" int gsn_count_plan_build(int mode, int induced, int directed_orbits, int64_t n_patterns, const int64_t *pat_ptr,
                                     const int64_t *pat_edges, uint32_t *plan, int64_t capacity, int64_t *out_words,
                                     int64_t *out_n_cols) {

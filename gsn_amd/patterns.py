@@ -23,9 +23,12 @@ class PatternGraph:
     """Stand-in for the ``gt.Graph`` stored under ``subgraph_dict['subgraph']``: the pattern's edge list plus what
     the counting kernel needs to rebuild its plan (``directed_orbits``).  Picklable (joblib workers)."""
 
-    def __init__(self, edge_list, directed_orbits=False):
+    def __init__(self, edge_list, directed_orbits=False, line_graph_orbits=False):
         self.edge_list = [(int(u), int(v)) for u, v in edge_list]
         self.directed_orbits = bool(directed_orbits)
+        # produced by edge_automorphism_orbits (the deprecated line-graph variant): its membership dict has one entry per
+        # undirected edge, which the reference's edge counter indexes by directed-edge position (see counting.py)
+        self.line_graph_orbits = bool(line_graph_orbits)
 
     def get_edges(self):
         """Simple undirected edges in insertion order, like ``gt.Graph.get_edges()`` after
@@ -105,9 +108,48 @@ def induced_edge_automorphism_orbits(edge_list, **kwargs):
     return PatternGraph(edge_list, directed_orbits), edge_orbit_partition, edge_orbit_membership, info["aut_count"]
 
 
+def graph_vertex_orbits(n_vertices, edges):
+    """Vertex orbits of Aut(G) for a graph with <= 64 vertices -> (orbit id per vertex, number of orbits); orbit id =
+    rank of the orbit's smallest vertex (gsn_graph_vertex_orbits, host C++)."""
+    e = np.ascontiguousarray(np.asarray(list(edges), dtype=np.int64).reshape(-1, 2))
+    orb = np.zeros(max(int(n_vertices), 1), dtype=np.int64)
+    n_orb = ctypes.c_int64()
+    rc = _abi.lib().gsn_graph_vertex_orbits(int(n_vertices), len(e), _abi.ptr(e) if len(e) else None, _abi.ptr(orb),
+                                            ctypes.addressof(n_orb))
+    _abi.check(rc, "gsn_graph_vertex_orbits")
+    return orb[:int(n_vertices)].copy(), int(n_orb.value)
+
+
 def edge_automorphism_orbits(edge_list, **kwargs):
-    """Deprecated in the reference itself (utils_graph_processing.py:185 "line graph edge automorphism: deprecated",
-    only reachable with --edge_automorphism line_graph, used by no README / BASELINE config).  Kept for the import in
-    utils.py:2; not implemented on the HIP path."""
-    raise NotImplementedError("edge_automorphism='line_graph' (deprecated in the reference) is not implemented; "
-                              "use the default --edge_automorphism induced")
+    """Edge orbits from the vertex orbits of the pattern's LINE graph -- the reference's deprecated
+    ``--edge_automorphism line_graph`` variant (utils_graph_processing.py:189-251).  Returns ``(graph, orbit_partition,
+    orbit_membership, aut_count)``: ``orbit_partition[orbit]`` lists the pattern edges as the line graph's node tuples,
+    ``orbit_membership[i]`` is indexed by position in ``graph.get_edges()`` (:241-243), ``aut_count`` = |Aut(H)| of the
+    pattern itself (:201-202).  The line graph and its node order come from networkx, the reference's own dependency for
+    this step (:193, :206-210); graph-tool's automorphism enumeration of it (:214-224) is replaced by
+    ``gsn_graph_vertex_orbits``.  Like the reference, a line-graph node that touches no line-graph edge (a pattern
+    component with a single edge) is not a vertex of the graph whose orbits are taken, and raises KeyError."""
+    import networkx as nx
+    if kwargs.get("directed", False):
+        raise NotImplementedError("directed patterns are not supported")
+    info = analyse(edge_list, False)
+    graph = PatternGraph(edge_list, False, line_graph_orbits=True)
+    line = nx.line_graph(nx.from_edgelist(edge_list))
+    mapping = {node: i for i, node in enumerate(line.nodes)}
+    inverse_mapping = {i: node for node, i in mapping.items()}
+    line_edges = [(mapping[a], mapping[b]) for a, b in line.edges]
+    n_line = max((max(a, b) for a, b in line_edges), default=-1) + 1     # gt.Graph.add_edge_list: vertices 0..max id
+    orbit, _ = graph_vertex_orbits(n_line, line_edges)
+    orbit_membership = {v: int(orbit[v]) for v in range(n_line)}
+    orbit_partition = {}
+    for vertex, orb in orbit_membership.items():
+        orbit_partition.setdefault(orb, []).append(inverse_mapping[vertex])
+    orbit_membership_new = {}
+    for i, edge in enumerate(graph.get_edges().tolist()):
+        edge = tuple(edge)
+        mapped_edge = mapping[edge] if edge in mapping else mapping[(edge[1], edge[0])]
+        orbit_membership_new[i] = orbit_membership[mapped_edge]
+    print("Edge orbit partition of given substructure: {}".format(orbit_partition))
+    print("Number of edge orbits: {}".format(len(orbit_partition)))
+    print("Graph (vertex) automorphism count: {}".format(info["aut_count"]))
+    return graph, orbit_partition, orbit_membership_new, info["aut_count"]

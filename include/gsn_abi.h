@@ -68,6 +68,18 @@ int gsn_pattern_orbits(int64_t n_edges, const int64_t *edges, int directed_orbit
                        int64_t *out_aut_count);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * HP-1  vertex orbits of an arbitrary small graph (host).  The automorphism part of the reference's deprecated
+ * edge_automorphism_orbits (utils_graph_processing.py:189-251, --edge_automorphism line_graph): there the graph is the
+ * LINE graph of the pattern and graph-tool enumerates its automorphisms (:214-224); here orbits come from
+ * "is there an automorphism with sigma(u) = v" searches, numbered like np.unique(..., return_inverse) numbers the
+ * per-vertex orbit minima (:231): orbit id = rank of the orbit's smallest vertex.
+ *   edges      [n_edges][2] int64, vertices 0..n_vertices-1 (n_vertices <= 64); self loops / duplicates dropped
+ *   out_orbit  [n_vertices]
+ * ---------------------------------------------------------------------------------------------------------------- */
+int gsn_graph_vertex_orbits(int64_t n_vertices, int64_t n_edges, const int64_t *edges, int64_t *out_orbit,
+                            int64_t *out_n_orbits);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * HP-1  counting plan (host).  Compiles a list of patterns (the reference's `subgraph_dicts`,
  * utils_data_gen.py:31-42) into the packed table the kernel executes: one rooted search per (pattern, vertex orbit)
  * [vertex mode] or per (pattern, directed-edge orbit) [edge mode], with symmetry-breaking order constraints for the

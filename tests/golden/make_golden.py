@@ -271,10 +271,15 @@ def gen_orbits(ref, out):
                     alle = sorted(e for edges in seen.values() for e in edges)
                     rec[key + "/e_list" + sfx] = np.asarray(alle, dtype=np.int64).reshape(-1, 2)
                 # deprecated line-graph variant (utils_graph_processing.py:189) for a few small patterns
-                if fam in ("cycle_graph", "path_graph", "star_graph", "diamond_graph", "all_simple_graphs_4") and len(el) > 1:
+                if fam in ("cycle_graph", "complete_graph", "path_graph", "star_graph", "binomial_tree", "diamond_graph",
+                           "nonisomorphic_trees", "all_simple_graphs_3", "all_simple_graphs_4", "all_simple_graphs_5") and len(el) > 1:
                     _, lpart, lmemb, aut3 = ugp.edge_automorphism_orbits(edge_list=el, directed=False)
+                    assert aut3 == aut
                     rec[key + "/line_membership"] = np.asarray([lmemb[i] for i in range(len(lmemb))], dtype=np.int64)
                     rec[key + "/line_n_orbits"] = np.int64(len(lpart))
+                    # the partition as rows (orbit, u, v): the line graph's node tuples in the order the reference lists them
+                    rec[key + "/line_partition"] = np.asarray([(o, e[0], e[1]) for o in sorted(lpart) for e in lpart[o]],
+                                                              dtype=np.int64).reshape(-1, 3)
     rec["names"] = np.asarray(names)
     np.savez_compressed(os.path.join(out, "orbits.npz"), **rec)
     print("orbits: %d patterns" % len(names))

@@ -65,8 +65,45 @@ def test_reference_style_return_values(lib, capsys):
     assert ememb == {0: 0, 1: 0, 2: 1, 3: 1, 4: 0, 5: 0}
     import pickle
     assert pickle.loads(pickle.dumps(g)).edge_list == g.edge_list   # joblib workers pickle subgraph_dicts
-    with pytest.raises(NotImplementedError):
-        patterns.edge_automorphism_orbits(edge_list=[(0, 1), (1, 2)])
+    g, lpart, lmemb, aut = patterns.edge_automorphism_orbits(edge_list=[(0, 1), (1, 2), (2, 3)])
+    assert lpart == {0: [(0, 1), (2, 3)], 1: [(1, 2)]} and lmemb == {0: 0, 1: 1, 2: 0} and aut == 2
+    with pytest.raises(KeyError):       # single edge: its line graph has no edges, hence no graph-tool vertices (:211-212)
+        patterns.edge_automorphism_orbits(edge_list=[(0, 1)])
+
+
+def _line_cases():
+    z = load("orbits")
+    return [str(n) for n in z["names"] if (str(n) + "/line_membership") in z.files]
+
+
+@pytest.mark.parametrize("name", _line_cases())
+def test_line_graph_edge_orbits_match_reference(lib, name, capsys):
+    """a3: the deprecated --edge_automorphism line_graph variant (utils_graph_processing.py:189-251) against what the
+    reference's own function returned for 62 patterns (incl. K4 / diamond, where Aut(L(H)) is larger than Aut(H))."""
+    from gsn_amd import patterns
+    z = load("orbits")
+    edges = [tuple(e) for e in z[name + "/edges"].tolist()]
+    g, part, memb, aut = patterns.edge_automorphism_orbits(edge_list=edges, directed=False)
+    assert [memb[i] for i in range(len(memb))] == z[name + "/line_membership"].tolist()
+    assert len(part) == int(z[name + "/line_n_orbits"])
+    assert [(o, e[0], e[1]) for o in sorted(part) for e in part[o]] == [tuple(r) for r in z[name + "/line_partition"].tolist()]
+    assert aut == int(z[name + "/aut_count"])
+    assert "Number of edge orbits: %d" % len(part) in capsys.readouterr().out
+
+
+def test_graph_vertex_orbits_generic(lib):
+    from gsn_amd import patterns
+    import networkx as nx
+    orb, n = patterns.graph_vertex_orbits(10, list(nx.petersen_graph().edges))          # vertex-transitive
+    assert n == 1 and orb.tolist() == [0] * 10
+    orb, n = patterns.graph_vertex_orbits(28, list(nx.relabel_nodes(nx.line_graph(nx.complete_graph(8)), {e: i for i, e in enumerate(nx.line_graph(nx.complete_graph(8)).nodes)}).edges))
+    assert n == 1                                                                        # L(K8): 28 vertices, one orbit
+    orb, n = patterns.graph_vertex_orbits(5, [(0, 1), (1, 2), (2, 3), (3, 4)])
+    assert orb.tolist() == [0, 1, 2, 1, 0] and n == 3
+    orb, n = patterns.graph_vertex_orbits(4, [(0, 1)])                                   # isolated vertices form an orbit
+    assert orb.tolist() == [0, 0, 1, 1]
+    with pytest.raises(Exception):
+        patterns.graph_vertex_orbits(65, [(0, 1)])
 
 
 @pytest.fixture(scope="module")

@@ -184,6 +184,24 @@ def test_errors():
             assert (part[rows] == -7).all()
 
 
+def test_line_graph_orbits_in_the_edge_counter():
+    """--edge_automorphism line_graph (deprecated): the reference's edge counter indexes the per-edge membership of
+    edge_automorphism_orbits by directed-edge position and raises KeyError(m) on the first match
+    (utils_graph_processing.py:161-173 with :241-243); graphs without a match get zero rows."""
+    from gsn_amd import patterns
+    from gsn_amd.counting import subgraph_isomorphism_edge_counts
+    tri = [(0, 1), (1, 2), (2, 0)]
+    g, part, memb, aut = patterns.edge_automorphism_orbits(edge_list=tri)
+    d = {"subgraph": g, "orbit_partition": part, "orbit_membership": memb, "aut_count": aut}
+    path = torch.tensor([[0, 1, 1, 2], [1, 0, 2, 1]])
+    out = subgraph_isomorphism_edge_counts(path, subgraph_dict=d, induced=False)
+    assert out.shape == (4, 1) and out.dtype == torch.float64 and float(out.abs().sum()) == 0.0
+    tri_ei = torch.tensor([[0, 1, 1, 2, 2, 0], [1, 0, 2, 1, 0, 2]])
+    with pytest.raises(KeyError) as e:
+        subgraph_isomorphism_edge_counts(tri_ei, subgraph_dict=d, induced=False)
+    assert e.value.args[0] == 3
+
+
 def _large_graphs():
     """Graphs beyond 256 vertices (16-bit vertex ids, W = 8 / 12 words per adjacency row): PROTEINS-like sparse chains with
     rings (max 620 vertices in the TU dataset), a COLLAB-like union of cliques, and one mixed batch with small graphs."""
