@@ -33,70 +33,131 @@ BF16X6 = os.environ.get("GSN_CHAIN_BF16X6", "64") != "0"   # chain kernels: 6 bf
 
 
 def make_batch(n_graphs, seed):
-    """n_graphs ZINC-shaped graphs: `unique` distinct seeded graphs tiled to size (generation is Python-side and not timed)."""
+    """n_graphs distinct seeded ZINC-shaped graphs (generation is Python-side and not timed: ~0.16 ms per graph)."""
     from gsn_amd import synth
-    unique = min(n_graphs, 4096)
-    base = synth.zinc_shape_batch(unique, seed=seed)
-    reps = (n_graphs + unique - 1) // unique
-    if reps == 1:
-        return base
-    node_ptr = [base.node_ptr]
-    edge_ptr = [base.edge_ptr]
-    eis, at, bt = [base.edge_index], [base.atom_type], [base.bond_type]
-    for r in range(1, reps):
-        node_ptr.append(base.node_ptr[1:] + r * base.num_nodes)
-        edge_ptr.append(base.edge_ptr[1:] + r * base.num_edges)
-        eis.append(base.edge_index + r * base.num_nodes)
-        at.append(base.atom_type)
-        bt.append(base.bond_type)
-    b = synth.Batch(np.concatenate(node_ptr)[:n_graphs + 1], np.concatenate(edge_ptr)[:n_graphs + 1], np.concatenate(eis, axis=1))
-    E, N = int(b.edge_ptr[-1]), int(b.node_ptr[-1])
-    b.edge_index = np.ascontiguousarray(b.edge_index[:, :E])
-    b.num_edges, b.num_nodes = E, N
-    b.atom_type = np.concatenate(at)[:N]
-    b.bond_type = np.concatenate(bt)[:E]
-    return b
+    return synth.zinc_shape_batch(n_graphs, seed=seed)
 
 
 CTOR = dict(d_in=28, d_ef=4, d_id=12, d_degree=1, degree_as_tag=False, retain_features=True, id_scope="local", d_msg=128,
             d_up=128, d_h=[128], seed=0, activation_name="relu", bn=True, msg_kind="general", flow="source_to_target")
 
 
-def cpu_baseline(n_graphs, seed):
-    """The oracle (CPU port of the reference path) timed on this box's host cores on a bounded sample of the same workload."""
+def cpu_baseline(seed):
+    """The oracle (CPU port of the reference path: oracle/count_oracle.c + plain PyTorch fp32 layer) timed on this box's host
+    cores on bounded samples of the same workload: at 1 thread (the reference's default --num_threads 1, main.py:519-520),
+    at all host cores, and at 32 threads (where this port peaks: the PyTorch CPU layer slows down beyond that on batches of
+    small graphs).  `value` / `cores` are the all-cores run; the other two ride along."""
     import torch
     import networkx as nx
-    from gsn_amd import synth
+    from gsn_amd import synth, layers
     from oracle import oracle
-    # more threads than this only slow the PyTorch CPU layer down on small graphs batches (measured on the 256-thread GPU
-    # host: 8 threads 28k graphs/s, 32 threads 26k, 64 threads 20k, 128 threads 16k) -- use what the baseline is best at
-    cores = min(os.cpu_count() or 1, 32)
-    b = synth.zinc_shape_batch(n_graphs, seed=seed)
     pats = [list(nx.cycle_graph(k).edges) for k in range(3, 7)]
-    local = b.edge_index - np.repeat(b.node_ptr[:-1], np.diff(b.edge_ptr))[None, :]
-    torch.set_num_threads(cores)
     torch.manual_seed(0)
-    from gsn_amd import layers
     layer = layers.GSN_edge_sparse(**CTOR).eval()
     sd = {k: v.clone() for k, v in layer.state_dict().items()}
-    x = torch.nn.functional.one_hot(torch.from_numpy(b.atom_type), 28).float()
-    ef = torch.nn.functional.one_hot(torch.from_numpy(b.bond_type), 4).float()
-    ei = torch.from_numpy(b.edge_index)
+
+    def run(n_graphs, threads, budget_s):
+        b = synth.zinc_shape_batch(n_graphs, seed=seed)
+        local = b.edge_index - np.repeat(b.node_ptr[:-1], np.diff(b.edge_ptr))[None, :]
+        x = torch.nn.functional.one_hot(torch.from_numpy(b.atom_type), 28).float()
+        ef = torch.nn.functional.one_hot(torch.from_numpy(b.bond_type), 4).float()
+        ei = torch.from_numpy(b.edge_index)
+        torch.set_num_threads(threads)
+        t0 = time.perf_counter()
+        reps = 0
+        while True:
+            ids = oracle.counts2ids("edge", False, b.node_ptr, b.edge_ptr, local, pats, n_threads=threads)
+            idt = torch.from_numpy(ids).clamp(max=2)
+            idf = torch.nn.functional.one_hot(idt, 3).reshape(idt.shape[0], 12).float()
+            with torch.no_grad():
+                oracle.layer_forward("GSN_edge_sparse", CTOR, sd, x, ei, identifiers=idf, degrees=None, edge_features=ef)
+            reps += 1
+            dt = time.perf_counter() - t0
+            if dt > budget_s:
+                break
+        return {"value": round(reps * n_graphs / dt, 1), "unit": "graphs/s", "cores": threads,
+                "sample": "%d passes over %d ZINC-shaped graphs, %d thread%s, %.1f s" % (reps, n_graphs, threads, "" if threads == 1 else "s", dt)}
+    ncpu = os.cpu_count() or 1
+    one = run(1024, 1, 6.0)
+    full = run(8192, ncpu, 8.0)
+    res = dict(full, kind="port", host_cpu_count=ncpu, one_thread=one,
+               what="oracle/count_oracle.c (OpenMP over graphs) + plain PyTorch fp32 layer forward; value/cores = all host cores")
+    if ncpu > 32:
+        res["threads_32"] = run(8192, 32, 6.0)
+    return res
+
+
+def verify_tile(plan, b, ids_out, y, layer, n_check):
+    """After the timed region: the counts and the layer output of the first `n_check` graphs of the timed batch against the
+    oracle (the timed step itself never checks)."""
+    import torch
+    import networkx as nx
+    from oracle import oracle
+    g = min(n_check, b.num_graphs)
+    n1, e1 = int(b.node_ptr[g]), int(b.edge_ptr[g])
+    pats = [list(nx.cycle_graph(k).edges) for k in range(3, 7)]
+    local = b.edge_index[:, :e1] - np.repeat(b.node_ptr[:g], np.diff(b.edge_ptr[:g + 1]))[None, :]
+    ref = oracle.counts2ids("edge", False, b.node_ptr[:g + 1], b.edge_ptr[:g + 1], local, pats, n_threads=min(os.cpu_count() or 1, 32))
+    got = ids_out[:e1].cpu().numpy()
+    counts_ok = bool(np.array_equal(got, ref))
+    sd = {k: v.detach().cpu().clone() for k, v in layer.state_dict().items()}
+    x = torch.nn.functional.one_hot(torch.from_numpy(b.atom_type[:n1]), 28).float()
+    ef = torch.nn.functional.one_hot(torch.from_numpy(b.bond_type[:e1]), 4).float()
+    idf = torch.nn.functional.one_hot(torch.from_numpy(ref).clamp(max=2), 3).reshape(e1, 12).float()
+    with torch.no_grad():
+        yref = oracle.layer_forward("GSN_edge_sparse", CTOR, sd, x, torch.from_numpy(b.edge_index[:, :e1]), identifiers=idf, degrees=None, edge_features=ef)
+    ygot = y[:n1].cpu()
+    err_max = float((ygot - yref).abs().max() / yref.abs().max())
+    # element-wise: |got - ref| <= 1e-5 |ref| + 1e-5 * (row scale): the floor is 1e-5 of the row's largest |value|
+    floor = 1e-5 * yref.abs().amax(dim=1, keepdim=True)
+    elem_ok = bool(((ygot - yref).abs() <= 1e-5 * yref.abs() + floor).all())
+    return {"graphs": g, "counts_bit_exact": counts_ok, "layer_max_err_over_max": float("%.3g" % err_max),
+            "layer_elementwise_1e-5_rel_plus_1e-5_rowmax": elem_ok}
+
+
+def work_figures(plan_patterns, ids_out):
+    """SURVEY 8(d) counting work figures derivable from the output alone: occurrences x positions = sum of all counts;
+    maps = sum_p aut_p * (sum of pattern p's columns) / (2 |E(H_p)|)  (edge mode)."""
+    from gsn_amd import patterns
+    col_sums = ids_out.sum(dim=0).cpu().numpy().astype(np.float64)
+    maps, c0 = 0.0, 0
+    for el in plan_patterns:
+        info = patterns.analyse(el, False)
+        w = info["n_edge_orbits"]
+        maps += info["aut_count"] * col_sums[c0:c0 + w].sum() / float(len(info["arcs"]))
+        c0 += w
+    return float(col_sums.sum()), float(maps)
+
+
+def dry_run(args):
+    """--dry-run: everything around the kernels (rank launch, process group, barrier-bracketed timing, MAX over ranks, one
+    JSON line from rank 0) with an empty step, so the N > 1 entry point is testable on a box without GPUs (gloo)."""
+    import torch
+    from gsn_amd import dist as gdist
+    rank, world, _, dist = gdist.init_from_env(args.backend, None)
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks" % (args.gpus, world))
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+    for _ in range(args.warmup):
+        pass
+    sync()
     t0 = time.perf_counter()
-    reps = 0
-    while True:
-        ids = oracle.counts2ids("edge", False, b.node_ptr, b.edge_ptr, local, pats, n_threads=cores)
-        idt = torch.from_numpy(ids).clamp(max=2)
-        idf = torch.nn.functional.one_hot(idt, 3).reshape(idt.shape[0], 12).float()
-        with torch.no_grad():
-            oracle.layer_forward("GSN_edge_sparse", CTOR, sd, x, ei, identifiers=idf, degrees=None, edge_features=ef)
-        reps += 1
-        dt = time.perf_counter() - t0
-        if dt > 12.0:
-            break
-    return {"value": round(reps * n_graphs / dt, 1), "unit": "graphs/s", "cores": cores, "kind": "port",
-            "sample": "%d passes over %d ZINC-shaped graphs: oracle/count_oracle.c (OpenMP over graphs) + plain PyTorch fp32 "
-                      "layer forward, %d threads, %.1f s" % (reps, n_graphs, cores, dt)}
+    for _ in range(args.steps):
+        time.sleep(0.001 * (1 + rank))          # ranks differ: the reported time must be the slowest rank's
+    sync()
+    dt = gdist.max_over_ranks(time.perf_counter() - t0)
+    if rank == 0:
+        print(json.dumps({"metric": "graphs/sec (orbit-count + GSN-e fwd), ZINC-shape batch; % HBM roofline", "value": None,
+                          "unit": "graphs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dry_run": True, "backend": args.backend,
+                          "config": {"workload": "none (plumbing check: empty step)", "parallelism": "graph-shard x%d" % world}}))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
@@ -108,28 +169,34 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the supplementary measurements (profiling runs: only the headline launches)")
     ap.add_argument("--no-graph", action="store_true", help="skip the HIP-graph replay of the timed steps (eager launches only)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend (nccl = RCCL; gloo only with --dry-run)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="plumbing check without a GPU: launch, rendezvous, barrier, max-over-ranks and the JSON line run for real, "
+                         "the step is an empty stub (the line carries dry_run=true and no throughput claim)")
     args = ap.parse_args()
 
+    from gsn_amd import dist as gdist
+    if args.gpus > 1 and not gdist.under_launcher():
+        # `python bench.py --gpus N`: start the N ranks ourselves (one per GPU, torch.distributed.run, rendezvous on
+        # 127.0.0.1); under the driver's own `python -m torch.distributed.run ... bench.py --gpus N` this is skipped.
+        raise SystemExit(gdist.launch_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
+
     import torch
+    if args.dry_run:
+        return dry_run(args)
     import networkx as nx
     from gsn_amd import layers
     from gsn_amd.counting import CountPlan, count_batch
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path is HIP-only; there is no CPU fallback)")
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1 or "RANK" in os.environ:   # launched by torch.distributed.run (also with one process): RCCL barrier + max-reduce
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    # launched by torch.distributed.run (also with one process): RCCL is used for the barrier and the max-over-ranks only
+    rank, world, local_rank, dist = gdist.init_from_env("nccl", dev)
     if args.gpus != world:
-        if rank == 0:
-            print("note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks" % (args.gpus, world))
 
     G = args.graphs
     b = make_batch(G, seed=1000 + rank)       # every rank owns a different shard of graphs
@@ -191,11 +258,11 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     timer, layers.KERNEL_TIMER = layers.KERNEL_TIMER, None
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = gdist.max_over_ranks(dt, dev)
     assert torch.isfinite(y).all()
+    # (outside the timed region) the timed batch's own results against the oracle, and the counting work figures
+    checked = verify_tile(plan, b, ids_out, y, layer, 4096) if rank == 0 else None
+    occ_pos, n_maps = work_figures([list(nx.cycle_graph(k).edges) for k in range(3, 7)], ids_out)
 
     # The same K steps once more, replayed from ONE captured HIP graph of the step (same kernels, same streams, same inputs):
     # eager launches cost the host ~0.3 ms of Python per step, which is normally hidden behind the GPU but, on a busy host
@@ -231,10 +298,7 @@ def main():
                 gobj.replay()
             sync()
             dt_graph = time.perf_counter() - t0
-            if dist is not None:
-                t = torch.tensor([dt_graph], device=dev, dtype=torch.float64)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                dt_graph = float(t.item())
+            dt_graph = gdist.max_over_ranks(dt_graph, dev)
     dt_eager = dt
     if dt_graph is not None and dt_graph < dt:
         dt = dt_graph
@@ -381,6 +445,10 @@ def main():
             extra["propagate_hbm_frac"] = round(pk["work_per_step"] / (pk["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         extra.update({
             "count_graphs_per_s": round(G / (ck["ms_per_step"] * 1e-3), 1),
+            # SURVEY 8(d) work figures, from the output alone: occurrence-positions = sum of all counts; maps = sum_p
+            # aut_p * (pattern p's column sums) / (2 |E(H_p)|)
+            "count_occurrence_positions_per_s": round(occ_pos / (ck["ms_per_step"] * 1e-3), 1),
+            "count_maps_per_s": round(n_maps / (ck["ms_per_step"] * 1e-3), 1),
             "count_hbm_GBs": round(ck["work_per_step"] / (ck["ms_per_step"] * 1e-3) / 1e9, 1),
             "ms_per_step_by_kernel": per_launch,
             "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 4),
@@ -403,9 +471,13 @@ def main():
                                    "+ GSN_edge_sparse layer-0 forward (general, d_in=28, d_ef=4, d_id=12, d=128, bn, eval)" % (G, N, E),
                        "graphs_per_step_per_gpu": G, "parallelism": "graph-shard x%d, no data-path collective" % world},
             "roofline": roof, "kernels": extra,
+            "counts_checked": bool(checked["counts_bit_exact"]), "checked": checked,
+            "tolerance": "counts bit-exact (int64); layer output vs the fp32 oracle: |got-ref| <= 1e-5 |ref| + 1e-5 max|ref row| element-wise",
         }
+        assert checked["counts_bit_exact"], "timed counts differ from the oracle"
+        assert checked["layer_elementwise_1e-5_rel_plus_1e-5_rowmax"], "timed layer output differs from the oracle: %r" % (checked,)
         if not args.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline(8192, seed=1000)
+            res["cpu_baseline"] = cpu_baseline(seed=1000)
         print(json.dumps(res))
     if dist is not None:
         dist.barrier()

@@ -60,7 +60,10 @@ def prepare_graphs(graphs, subgraph_dicts, subgraph_params, regression, dataset_
     span = (0, len(graphs))
     if shard is not None:
         rank, world = shard
-        cost = np.array([float(g.edge_mat.shape[1]) ** 1.5 + 1.0 for g in graphs])
+        # sum_v deg(v)^(k-1) per graph, k = the largest pattern (self loops / duplicates included: a proxy)
+        kmax = max(p.num_vertices() for p in pats)
+        cost = np.array([float(dist.counting_cost(g.edge_mat.reshape(2, -1).numpy(), [0, g.edge_mat.reshape(2, -1).shape[1]], kmax)[0])
+                         for g in graphs])
         bounds = dist.shard_by_cost(cost, world)
         span = (int(bounds[rank]), int(bounds[rank + 1]))
         graphs = graphs[span[0]:span[1]]

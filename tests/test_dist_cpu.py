@@ -20,9 +20,17 @@ def _worker(rank, world, port, q):
     torch.manual_seed(0)
     model = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ReLU(), torch.nn.Linear(7, 3))
     x = torch.arange(1001 * 5, dtype=torch.float32).reshape(1001, 5) / 1000.0
-    model(x[lo:hi]).pow(2).sum().backward()           # every rank: its own shard of "graphs"
+    extra = torch.nn.Parameter(torch.ones(4))         # used by rank 0 only: rank 1's .grad stays None
+    loss = model(x[lo:hi]).pow(2).sum()
+    if rank == 0:
+        loss = loss + (extra * torch.arange(4.0)).sum()
+    loss.backward()                                   # every rank: its own shard of "graphs"
     local = [p.grad.clone() for p in model.parameters()]
-    allreduce_gradients(model.parameters(), average=True)
+    allreduce_gradients(list(model.parameters()) + [extra], average=True)
+    assert extra.grad is not None and torch.allclose(extra.grad, torch.arange(4.0) / 2)   # zeros from the rank that had none
+    allreduce_gradients(list(model.parameters()) + [extra], average=False)               # reuses the bucket
+    for p in model.parameters():
+        p.grad /= 2
     q.put((rank, lo, hi, [g.numpy() for g in local], [p.grad.numpy().copy() for p in model.parameters()]))
     dist.barrier()
     dist.destroy_process_group()
@@ -51,3 +59,50 @@ def test_shard_by_cost():
     b = shard_by_cost([1, 1, 1, 1, 100, 1, 1, 1], 2)
     assert b[0] == 0 and b[-1] == 8 and b == sorted(b)
     assert [shard_range(10, r, 3) for r in range(3)] == [(0, 4), (4, 7), (7, 10)]
+
+
+def _last_json(out):
+    import json
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert lines, out
+    return json.loads(lines[-1])
+
+
+def test_bench_spawns_its_own_ranks_gloo_dry_run():
+    """`python bench.py --gpus 2` starts two ranks itself (torch.distributed.run underneath) and rank 0 prints ONE line with
+    n_gpus = 2; the driver's explicit torchrun form runs the same code.  --dry-run --backend gloo: everything but the kernels."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bench = os.path.join(repo, "bench.py")
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "4", "--warmup", "1", "--dry-run", "--backend", "gloo"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _last_json(r.stdout)
+    assert line["n_gpus"] == 2 and line["steps"] == 4 and line["dry_run"] is True and line["scaling"] == "weak"
+    assert line["ms_per_step"] >= 1.9          # rank 1 sleeps 2 ms per step: the line carries the MAX over ranks
+    assert sum(1 for l in r.stdout.splitlines() if l.startswith("{")) == 1
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), bench, "--gpus", "2", "--steps", "3", "--warmup", "0", "--dry-run", "--backend", "gloo"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert _last_json(r.stdout)["n_gpus"] == 2
+    # a launcher / flag mismatch is refused instead of silently reporting the wrong n_gpus
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), bench, "--gpus", "4", "--dry-run", "--backend", "gloo"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0
+
+
+def test_counting_cost_proxy():
+    import numpy as np
+    from gsn_amd import dist as gdist, synth
+    b = synth.zinc_shape_batch(6, seed=3)
+    c = gdist.counting_cost(b.edge_index, b.edge_ptr, 5)
+    for g in range(6):
+        n, ei = b.graph(g)
+        deg = np.bincount(ei[0], minlength=n).astype(np.float64)
+        assert abs((deg ** 4).sum() + 1 - c[g]) < 1e-6
