@@ -1,0 +1,789 @@
+// One `general` message-passing layer in ONE launch (GSN_sparse.py:93-176 / GSN_edge_sparse.py:82-170 and the MPNN twins):
+//
+//     r_e  = act_e( bn_e( cat(x_i, x_j, ids.., e) W1^T + b1 ) )              per edge      (edge stage, K_e <= 80)
+//     S_v  = sum_{e -> v} r_e                                                per node      (torch.sparse.sum, :140-143)
+//     h_v  = act_0( bn_0( [x_v | S_v | deg_v] W0'^T + b0 ) )                 per node      (W0' = [W3x | W3a W2 | W3a b2], layers.py)
+//     out_v = act_1( bn_1( h_v W1'^T + b1' ) )                               per node
+//
+// r_e, S_v and h_v never touch HBM: every input is read once, the output written once (B_alg).
+//
+// Work decomposition.  A PyG batch is a disjoint union and the rows of the target-sorted CSR (gsn_csr_build_hip) are
+// node-contiguous, so a workgroup owns a contiguous NODE range and walks it in tiles of <= 32 nodes whose in-edges it
+// processes in chunks of <= 64 rows (the tile takes as many nodes as fit a whole number of chunks: ZINC-shaped graphs give
+// ~31 nodes / 64 edges per tile, one chunk; a hub or a dense graph gives several chunks per tile).  All waves run the same
+// tile iterator over seg_ptr (one 33-entry window load per tile, fetched a tile ahead), so every scheduling decision is a
+// wave-uniform scalar and no descriptor is communicated.
+//
+// Roles (12 waves, 3 per SIMD; a wave keeps ONE stage's weights in registers for the whole kernel):
+//   group E  (waves 0-3):  edge stage of chunk i          -> Y   [64][132] fp32 in LDS
+//   group S0 (waves 4-7):  node stage 0 of the tile before -> H   [32][132] fp32 in LDS
+//   group S1 (waves 8-11): node stage 1 of the tile before that -> out rows (global stores)
+// Every step has a matrix phase (alpha) and a staging phase (beta), one LDS-only barrier after each; all LDS buffers are
+// single: alpha reads the operand planes and writes fp32 tiles, beta reads fp32 tiles and writes operand planes.
+//   beta, E : gathered rows (float4 global loads issued a step earlier) -> fp16 planes IN_E of chunk i+1
+//   beta, S0: per node  sum of its Y rows in row order (deterministic, no atomics; partial sums of multi-chunk tiles in
+//             S_acc) ; on the tile's last chunk  [x | S | deg] -> fp16 planes IN_N
+//   beta, S1: H -> fp16 planes MID
+//
+// Matrix arithmetic: fp16x3.  Both operands are split into two fp16 planes (x = x_h + x_l, 11 + 11 significant bits, round
+// to nearest) after an exact power-of-two scaling that puts the largest magnitude of every A row (and of each stage's weight
+// matrix) into [2^14, 2^15); x w ~ x_h w_h + x_h w_l + x_l w_h with fp32 accumulation inside v_mfma_f32_32x32x16_f16; the
+// dropped x_l w_l is < 2^-22 |x w|.  scripts/micro/bf16x6_check.hip: max error vs fp64 2.0e-7 of max|C| at K = 160 (an fp32
+// FMA loop: 3.1e-7; the six bf16 plane products of chain_*_bf16.hip: 2.9e-7) at HALF the matrix work of the bf16 scheme.
+// The accumulator is un-scaled in the epilogue (one fma with the row's inverse scale).  Rows that are exactly representable
+// in fp16 without scaling (one-hot / small-integer encodings: every layer-0 input of the reference models) need no row
+// maximum and no low plane: a chunk made only of such rows runs two products instead of three.
+// Non-finite inputs: a row containing Inf or NaN yields NaN in that row's outputs (an fp32 product would keep a signed Inf).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+
+#include "chain_common.h"
+
+namespace gsn {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 lf_h2 __attribute__((ext_vector_type(2)));
+typedef float lf_f2 __attribute__((ext_vector_type(2)));
+typedef unsigned lf_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned lf_u2 __attribute__((ext_vector_type(2)));
+
+constexpr int LF_TE = 64;     // edge rows per chunk
+constexpr int LF_TN = 32;     // nodes per tile
+constexpr int LF_MAXB = 6;    // edge-stage input blocks
+constexpr int LF_PY = 132;    // fp32 row pitch of Y / S_acc / H in floats (rows 16-byte aligned, banks staggered by 4)
+constexpr int LF_SEGW = 36;   // ints per seg-window slot (33 used)
+constexpr int LF_NSLOT = 8;   // seg-window slots: tiles between formation (three chunks ahead) and the node stage's staging
+constexpr int LF_NXJ = 2;     // [x | deg] float4 chunks a stager thread may own (d_x <= 60)
+
+struct LfStage {
+    const float *W, *bias, *bn_mean, *bn_scale, *bn_shift;
+    int k_total, n_out, act;
+};
+
+struct LfArgs {
+    int n_nodes, n_edges;
+    const int32_t *seg_ptr;                 // [n_nodes + 1] target-sorted CSR
+    int e_nblocks;
+    const float *e_data[LF_MAXB];           // edge-stage blocks, row r of the sorted order reads row e_idx[b][r] of e_data[b]
+    const int32_t *e_idx[LF_MAXB];
+    int e_width[LF_MAXB];
+    LfStage e, s0, s1;
+    const float *x;                         // [n_nodes][d_x] first block of the node stage
+    int d_x;
+    float *out;                             // [n_nodes][s1.n_out]
+};
+
+struct LfDesc {                             // one chunk of one tile; every field wave-uniform
+    int valid, m0, nn, e0, ne, first, last, slot;
+};
+
+struct LfIter {
+    const int32_t *seg;
+    int n_nodes, m_next, m_end;
+    int m0, nn, eb, ee, ec, pending, slot;
+    int win;                                // lane l: seg_ptr[m_next + l] (prefetched window of the NEXT tile)
+};
+
+__device__ __forceinline__ void lf_iter_load(LfIter &it, int lane) {
+    int idx = it.m_next + lane;
+    idx = idx < it.n_nodes ? idx : it.n_nodes;
+    it.win = it.seg[idx];
+}
+
+// next chunk in node order; forms a new tile from the prefetched window when the current one is exhausted
+__device__ __forceinline__ LfDesc lf_iter_next(LfIter &it, int lane, int *segl, bool writer) {
+    LfDesc d;
+    d.valid = 0; d.m0 = 0; d.nn = 0; d.e0 = 0; d.ne = 0; d.first = 0; d.last = 0; d.slot = 0;
+    if (!(it.pending || it.ec < it.ee)) {
+        if (it.m_next >= it.m_end) return d;
+        int nmax = it.m_end - it.m_next;
+        nmax = nmax < LF_TN ? nmax : LF_TN;
+        const int w0 = __builtin_amdgcn_readfirstlane(it.win);
+        const int cnt = it.win - w0;                                    // lane l: in-edges of the tile's first l nodes
+        const int ne_all = __builtin_amdgcn_readlane(cnt, nmax);
+        int nn = nmax;
+        if (ne_all > LF_TE) {
+            const int cap = ne_all / LF_TE * LF_TE;                     // a whole number of chunks
+            const unsigned long long ok = __ballot(lane <= nmax && cnt <= cap);
+            nn = __popcll(ok) - 1;                                      // cnt is monotone in the lane; lane 0 always passes
+            nn = nn < 1 ? 1 : nn;                                       // a single node with more than `cap` edges
+        }
+        nn = __builtin_amdgcn_readfirstlane(nn);
+        it.m0 = it.m_next; it.nn = nn; it.eb = w0; it.ee = __builtin_amdgcn_readlane(it.win, nn);
+        it.ec = it.eb; it.pending = 1; it.slot = (it.slot + 1) & (LF_NSLOT - 1);
+        if (writer && lane <= LF_TN) segl[it.slot * LF_SEGW + lane] = it.win;
+        it.m_next += nn;
+        lf_iter_load(it, lane);
+    }
+    d.valid = 1; d.m0 = it.m0; d.nn = it.nn; d.e0 = it.ec;
+    const int left = it.ee - it.ec;
+    d.ne = left < LF_TE ? left : LF_TE;
+    d.first = it.ec == it.eb; d.last = it.ec + LF_TE >= it.ee; d.slot = it.slot;
+    it.ec += LF_TE; it.pending = 0;
+    return d;
+}
+
+// power-of-two scale that puts a magnitude with these (sign-less) float bits into [2^14, 2^15), and its inverse.  The
+// biased exponent is clamped to [15, 254] so that both factors stay normal floats.
+__device__ __forceinline__ void lf_scale(unsigned maxbits, float &scale, float &inv) {
+    int e = (int)(maxbits >> 23);
+    e = e < 15 ? 15 : (e > 254 ? 254 : e);
+    scale = __uint_as_float((unsigned)(268 - e) << 23);
+    inv = __uint_as_float((unsigned)(e - 14) << 23);
+}
+
+// two floats -> packed fp16 high parts, packed fp16 low parts (round to nearest), and the fp32 residual bits
+__device__ __forceinline__ void lf_split2(lf_f2 v, unsigned &hi, unsigned &lo, unsigned &resbits) {
+    const lf_h2 h = __builtin_convertvector(v, lf_h2);
+    const lf_f2 r = v - __builtin_convertvector(h, lf_f2);
+    const lf_h2 l = __builtin_convertvector(r, lf_h2);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+    resbits = __float_as_uint(r.x) | __float_as_uint(r.y);
+}
+
+__device__ __forceinline__ unsigned lf_absmax4(unsigned m, float4 v) {
+    const unsigned a = __float_as_uint(v.x) & 0x7fffffffu, b = __float_as_uint(v.y) & 0x7fffffffu;
+    const unsigned c = __float_as_uint(v.z) & 0x7fffffffu, d = __float_as_uint(v.w) & 0x7fffffffu;
+    m = max(max(m, a), b);
+    return max(max(m, c), d);
+}
+
+// reductions over the 8 consecutive lanes that share one staged row
+__device__ __forceinline__ unsigned lf_or8(unsigned v) {
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);    // quad_perm [1,0,3,2]
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);    // quad_perm [2,3,0,1]
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true);   // row_half_mirror
+    return v;
+}
+__device__ __forceinline__ unsigned lf_max8(unsigned v) {
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true));
+    return v;
+}
+
+// row of NCH float4 chunks held by 8 lanes -> scaled fp16 planes at `dst` (+ plane stride); chunk j is stored only where
+// wr[j] (a per-lane predicate on the store alone: the arithmetic is branch-free).  Returns the inverse row scale.
+template <int NCH>
+__device__ __forceinline__ float lf_split_row_scaled(const float4 (&v)[NCH], const bool (&wr)[NCH], _Float16 *dst, int plane_halfs, const int (&koff)[NCH]) {
+    unsigned m = 0;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) m = lf_absmax4(m, v[j]);
+    m = lf_max8(m);
+    float rs, inv;
+    lf_scale(m, rs, inv);
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        unsigned h0, l0, h1, l1, rb;
+        lf_split2(lf_f2{v[j].x * rs, v[j].y * rs}, h0, l0, rb);
+        lf_split2(lf_f2{v[j].z * rs, v[j].w * rs}, h1, l1, rb);
+        if (wr[j]) {
+            *reinterpret_cast<lf_u2 *>(dst + koff[j]) = lf_u2{h0, h1};
+            *reinterpret_cast<lf_u2 *>(dst + plane_halfs + koff[j]) = lf_u2{l0, l1};
+        }
+    }
+    return inv;
+}
+
+// weights of one lane (output column `col`, plane column k' = 16 s + 8 lh + e), BN scale folded in, times the stage's
+// power-of-two scale.  Plane column k' holds original weight column  k' < h1 ? dx + k' : (k' < h1 + dx ? k' - h1 : k')
+// (node stage 0 keeps its input planes as [S | x | deg]; h1 = dx = 0: identity).
+template <int NK>
+__device__ __forceinline__ void lf_weight_planes(const LfStage &st, int col, bool cok, int lh, float bnscale, float wscale, int h1, int dx, lf_u4 *Bh, lf_u4 *Bl) {
+#pragma unroll
+    for (int s = 0; s < NK; ++s) {
+        unsigned h[4], l[4], rb;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float wv[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int kp = 16 * s + 8 * lh + 2 * q + e;
+                const int k = kp < h1 ? dx + kp : (kp < h1 + dx ? kp - h1 : kp);
+                const bool ok = kp < st.k_total && cok;
+                const float w0 = st.W[ok ? (int64_t)col * st.k_total + k : 0];
+                wv[e] = ok ? w0 * bnscale * wscale : 0.f;
+            }
+            lf_split2(lf_f2{wv[0], wv[1]}, h[q], l[q], rb);
+        }
+        Bh[s] = lf_u4{h[0], h[1], h[2], h[3]};
+        Bl[s] = lf_u4{l[0], l[1], l[2], l[3]};
+    }
+}
+
+// largest |W[col][k] * bnscale| of this lane's column
+__device__ __forceinline__ unsigned lf_weight_absmax(const LfStage &st, int col, bool cok, float bnscale) {
+    unsigned m = 0;
+    if (cok)
+        for (int k = 0; k < st.k_total; ++k) m = max(m, __float_as_uint(st.W[(int64_t)col * st.k_total + k] * bnscale) & 0x7fffffffu);
+    return m;
+}
+
+#define LF_MF(A, B) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B), acc, 0, 0, 0)
+
+// acc[32 x 32] = A[32 rows][16 NK] (planes at ap, ap + plane) x this wave's weight planes, three plane products per k-step.
+// Two independent accumulator chains over the two halves of K, issued alternately: a dependent MFMA that does not follow its
+// predecessor back to back loses the forwarding path (~40 cycles, scripts/micro/valu_rates.hip), and with the LDS reads of the
+// next fragments in between it never does; with two chains no MFMA waits for the one issued just before it.
+template <int NK>
+__device__ __forceinline__ f32x16 lf_mma_k2(const _Float16 *ap, int plane, const lf_u4 *Bh, const lf_u4 *Bl) {
+    static_assert(NK % 2 == 0, "two chains over the halves of K");
+    constexpr int H = NK / 2;
+    f32x16 acc, acb;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acb[r] = 0.f; }
+    lf_u4 ha[2], la[2], hb[2], lb[2];
+    ha[0] = *reinterpret_cast<const lf_u4 *>(ap);
+    la[0] = *reinterpret_cast<const lf_u4 *>(ap + plane);
+    hb[0] = *reinterpret_cast<const lf_u4 *>(ap + 16 * H);
+    lb[0] = *reinterpret_cast<const lf_u4 *>(ap + plane + 16 * H);
+#pragma unroll
+    for (int s = 0; s < H; ++s) {
+        const int c = s & 1, n = c ^ 1;
+        if (s + 1 < H) {
+            ha[n] = *reinterpret_cast<const lf_u4 *>(ap + 16 * (s + 1));
+            la[n] = *reinterpret_cast<const lf_u4 *>(ap + plane + 16 * (s + 1));
+            hb[n] = *reinterpret_cast<const lf_u4 *>(ap + 16 * (s + 1 + H));
+            lb[n] = *reinterpret_cast<const lf_u4 *>(ap + plane + 16 * (s + 1 + H));
+        }
+        LF_MF(la[c], Bh[s]);
+        acb = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, lb[c]), __builtin_bit_cast(f16x8, Bh[s + H]), acb, 0, 0, 0);
+        LF_MF(ha[c], Bl[s]);
+        acb = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, hb[c]), __builtin_bit_cast(f16x8, Bl[s + H]), acb, 0, 0, 0);
+        LF_MF(ha[c], Bh[s]);
+        acb = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, hb[c]), __builtin_bit_cast(f16x8, Bh[s + H]), acb, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += acb[r];
+    return acc;
+}
+
+// the edge stage's two 32-row halves of a chunk as two interleaved chains (same weights, two A tiles)
+template <int NK, bool THREE>
+__device__ __forceinline__ void lf_mma_2tiles(const _Float16 *ap0, const _Float16 *ap1, int plane, const lf_u4 *Bh, const lf_u4 *Bl, f32x16 &acc, f32x16 &acb) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acb[r] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < NK; ++s) {
+        const lf_u4 ha = *reinterpret_cast<const lf_u4 *>(ap0 + 16 * s), hb = *reinterpret_cast<const lf_u4 *>(ap1 + 16 * s);
+        if (THREE) {
+            const lf_u4 la = *reinterpret_cast<const lf_u4 *>(ap0 + plane + 16 * s), lb = *reinterpret_cast<const lf_u4 *>(ap1 + plane + 16 * s);
+            LF_MF(la, Bh[s]);
+            acb = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, lb), __builtin_bit_cast(f16x8, Bh[s]), acb, 0, 0, 0);
+        }
+        LF_MF(ha, Bl[s]);
+        acb = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, hb), __builtin_bit_cast(f16x8, Bl[s]), acb, 0, 0, 0);
+        LF_MF(ha, Bh[s]);
+        acb = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, hb), __builtin_bit_cast(f16x8, Bh[s]), acb, 0, 0, 0);
+    }
+}
+
+// epilogue of a 32 x 32 accumulator tile: y = max(acc * comb[row] + c0, lo) for this lane's 16 rows; f(r, y) with r the row
+// inside the 32-row tile.  comb: this tile's 32 inverse scales (LDS).
+template <typename F>
+__device__ __forceinline__ void lf_epilogue(const f32x16 &acc, const float *comb, int lh, float c0, float lo, F f) {
+    const float *cp = comb + 4 * lh;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 cm = *reinterpret_cast<const float4 *>(cp + 8 * g);
+        const float cv[4] = {cm.x, cm.y, cm.z, cm.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) f(4 * lh + 8 * g + r, __builtin_amdgcn_fmed3f(fmaf(acc[4 * g + r], cv[r], c0), lo, INFINITY));   // = max(., lo)
+    }
+}
+
+template <int NKE, int NK0, int NK1, bool PROF>
+__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void layer_fused_kernel(LfArgs a, unsigned long long *prof) {
+    auto clk = [&]() -> unsigned long long {
+        if (!PROF) return 0;
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long v = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_sched_barrier(0);
+        return v;
+    };
+    unsigned long long pc[6] = {0, 0, 0, 0, 0, 0};     // alpha work, barrier 1, beta work, barrier 2, bookkeeping, steps
+    constexpr int KE = 16 * NKE, KPE = KE + 8, PLE = LF_TE * KPE;        // halfs
+    constexpr int K0 = 16 * NK0, KP0 = K0 + 8, PL0 = LF_TN * KP0;
+    constexpr int K1 = 16 * NK1, KP1 = K1 + 8, PL1 = LF_TN * KP1;
+    constexpr int NCHE = (KE / 4 + 7) / 8;                               // float4 chunks per stager thread and row
+    constexpr int NCH1 = K1 / 32;
+    constexpr int NJS = 4, NJX = LF_NXJ, NCH0 = NJS + NJX;               // node rows: <= 4 chunks of S and <= LF_NXJ of [x | deg] per thread
+    static_assert(K1 % 32 == 0, "stage-1 input planes in whole 32-column groups");
+    constexpr int OFF_INE = 0, SZ_INE = 2 * PLE * 2;
+    constexpr int OFF_Y = OFF_INE + SZ_INE, SZ_Y = LF_TE * LF_PY * 4;
+    constexpr int OFF_SACC = OFF_Y + SZ_Y, SZ_SACC = 2 * LF_TN * LF_PY * 4;   // per-node sums of two tiles (parity of the tile's slot)
+    constexpr int OFF_INN = OFF_SACC + SZ_SACC, SZ_INN = 2 * PL0 * 2;
+    constexpr int OFF_H = OFF_INN + SZ_INN, SZ_H = LF_TN * LF_PY * 4;
+    constexpr int OFF_MID = OFF_H + SZ_H, SZ_MID = 2 * PL1 * 2;
+    constexpr int OFF_TAB = OFF_MID + SZ_MID;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    _Float16 *in_e = reinterpret_cast<_Float16 *>(smem + OFF_INE);
+    float *ytile = reinterpret_cast<float *>(smem + OFF_Y);
+    float *sacc = reinterpret_cast<float *>(smem + OFF_SACC);
+    _Float16 *in_n = reinterpret_cast<_Float16 *>(smem + OFF_INN);
+    float *htile = reinterpret_cast<float *>(smem + OFF_H);
+    _Float16 *mid = reinterpret_cast<_Float16 *>(smem + OFF_MID);
+    int *rsrc = reinterpret_cast<int *>(smem + OFF_TAB);                 // [LF_MAXB][LF_TE]
+    float *comb_e = reinterpret_cast<float *>(rsrc + LF_MAXB * LF_TE);   // [LF_TE]  inverse row scale x inverse weight scale
+    float *comb_n = comb_e + LF_TE;                                      // [LF_TN]
+    float *comb_h = comb_n + LF_TN;                                      // [LF_TN]
+    int *segl = reinterpret_cast<int *>(comb_h + LF_TN);                 // [LF_NSLOT][LF_SEGW] seg_ptr windows of the tiles in flight
+    int *flag_e = segl + LF_NSLOT * LF_SEGW;                                    // [4]  flag_e[0] == ordinal of a chunk with a scaled row
+    unsigned *wmax = reinterpret_cast<unsigned *>(flag_e + 4);           // [12] per-wave weight maxima (prologue)
+    int *pub = reinterpret_cast<int *>(wmax + 12);                        // [4]  tile bookkeeping published to group S1 every step
+
+    const int tid = threadIdx.x;
+    const int grp = __builtin_amdgcn_readfirstlane(tid >> 8);            // 0: E, 1: S0, 2: S1
+    const int t = tid & 255;
+    const int lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int q8 = t & 7, r8 = t >> 3;                                    // stager map: 8 lanes per row, 32 rows per pass
+
+    for (int i = tid; i < OFF_TAB / 4; i += 768) reinterpret_cast<float *>(smem)[i] = 0.f;   // padded columns stay zero
+    if (tid < 4) flag_e[tid] = -1;
+
+    // ---- this wave's stage: folded BatchNorm, weight scale ------------------------------------------------------------
+    const LfStage &st = grp == 0 ? a.e : (grp == 1 ? a.s0 : a.s1);
+    const int col = 32 * w + li;
+    const bool cok = col < st.n_out;
+    const bool active = 32 * w < st.n_out;
+    const float bias = (cok && st.bias) ? st.bias[col] : 0.f;
+    float bnscale = 1.f, c0 = bias;
+    if (cok && st.bn_scale) { bnscale = st.bn_scale[col]; c0 = (bias - st.bn_mean[col]) * bnscale + st.bn_shift[col]; }
+    {
+        unsigned m = lf_weight_absmax(st, col, cok, bnscale);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+        if (lane == 0) wmax[4 * grp + w] = m;
+    }
+    __syncthreads();
+    float wscale, inv_w;
+    lf_scale(max(max(wmax[4 * grp], wmax[4 * grp + 1]), max(wmax[4 * grp + 2], wmax[4 * grp + 3])), wscale, inv_w);
+    wscale = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(wscale)));       // (wave-uniform: scalar registers)
+    inv_w = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(inv_w)));
+    const float act_lo = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(st.act == 1 ? 0.f : -INFINITY)));   // relu / identity as one max
+
+    // ---- node range of this workgroup, tile iterator (identical in every wave of groups E and S0) -----------------------
+    LfIter it;
+    it.seg = a.seg_ptr; it.n_nodes = a.n_nodes;
+    it.m_next = (int)((int64_t)a.n_nodes * blockIdx.x / gridDim.x);
+    it.m_end = (int)((int64_t)a.n_nodes * (blockIdx.x + 1) / gridDim.x);
+    it.m0 = 0; it.nn = 0; it.eb = 0; it.ee = 0; it.ec = 0; it.pending = 0; it.slot = 0;
+    const bool seg_writer = tid < 64;
+    LfDesc d0, d1, d2;                                                    // chunks i, i+1, i+2 of step i
+    d0.valid = 0; d0.m0 = 0; d0.nn = 0; d0.e0 = 0; d0.ne = 0; d0.first = 0; d0.last = 0; d0.slot = 0;
+    d1 = d0; d2 = d0;
+    if (grp != 2) {
+        lf_iter_load(it, lane);
+        d2 = lf_iter_next(it, lane, segl, seg_writer);
+    }
+    int ts_valid = 0, ts_m0 = 0, ts_nn = 0, ts_slot = 0;                  // tile whose per-node sums are complete (S buffer of its slot parity)
+    int ta_valid = 0, ta_m0 = 0, ta_nn = 0;                               // tile whose planes IN_N are staged
+    int tb_valid = 0, tb_m0 = 0, tb_nn = 0;                               // tile whose planes MID are staged
+    int step = -2;
+
+    if (grp == 0) {
+        // =============================================================================================================
+        // group E
+        // =============================================================================================================
+        lf_u4 Bh[NKE], Bl[NKE];
+        lf_weight_planes<NKE>(st, col, cok, lh, bnscale, wscale, 0, 0, Bh, Bl);
+        // staging map: thread -> rows r8 and r8 + 32, float4 chunks q8 + 8 j of each
+        const float *gbase[NCHE];
+        int gbw[NCHE], gblk[NCHE], gk[NCHE];
+        bool gon[NCHE], gwr[NCHE];
+#pragma unroll
+        for (int j = 0; j < NCHE; ++j) {
+            const int kc = 4 * (q8 + 8 * j);
+            gon[j] = kc < a.e.k_total;                                    // a real input column: loaded
+            gwr[j] = kc < KE;                                             // inside the plane row: stored (zeros beyond k_total)
+            int blk = 0, c = kc;
+#pragma unroll
+            for (int b = 0; b < LF_MAXB - 1; ++b)
+                if (blk == b && b + 1 < a.e_nblocks && c >= a.e_width[b]) { c -= a.e_width[b]; blk = b + 1; }
+            if (!gon[j]) { blk = 0; c = 0; }
+            const float *bd = a.e_data[0];
+            int bw = a.e_width[0];
+#pragma unroll
+            for (int b = 1; b < LF_MAXB; ++b)
+                if (blk == b) { bd = a.e_data[b]; bw = a.e_width[b]; }
+            gbase[j] = bd + c; gbw[j] = bw; gblk[j] = blk * LF_TE; gk[j] = kc;
+        }
+        // row sources: thread -> tile row t & 63 of block t >> 6 (and of block 4 + (t >> 6))
+        const int rs_r = lane, rs_b = w;                                 // (the block is wave-uniform: its index pointer lives in scalar registers)
+        const int32_t *rs_p0 = a.e_idx[0], *rs_p1 = a.e_idx[0];
+#pragma unroll
+        for (int b = 0; b < LF_MAXB; ++b) {
+            if (b == rs_b && b < a.e_nblocks) rs_p0 = a.e_idx[b];
+            if (b == rs_b + 4 && b < a.e_nblocks) rs_p1 = a.e_idx[b];
+        }
+        const bool rs_on0 = rs_b < a.e_nblocks, rs_on1 = rs_b + 4 < a.e_nblocks;
+        const int e_last = a.n_edges > 0 ? a.n_edges - 1 : 0;
+        const int njs = a.e.n_out >> 5;                                   // 32-column groups of the activated rows
+        int raw0 = 0, raw1 = 0;
+        float4 pf[2][NCHE];
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int j = 0; j < NCHE; ++j) pf[rr][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        while (d0.valid | d1.valid | d2.valid | ts_valid | ta_valid | tb_valid | (step < 0)) {
+            const unsigned long long c_0 = clk();
+            const LfDesc dn = lf_iter_next(it, lane, segl, seg_writer);  // chunk i + 3 (its window arrived a step ago)
+            // ---------------- alpha ----------------
+            if (tid == 0) {                                               // what group S1 needs to follow the tiles (it never loads seg_ptr:
+                pub[0] = ts_valid; pub[1] = ts_m0; pub[2] = ts_nn;        // a wait for such a load would drain its output stores)
+                pub[3] = d1.valid | (d0.valid && d0.last);
+            }
+            if (d2.valid && a.n_edges > 0) {                              // row sources of chunk i + 2 (consumed in beta)
+                int er = d2.e0 + (rs_r < d2.ne ? rs_r : (d2.ne > 0 ? d2.ne - 1 : 0));
+                er = er < e_last ? er : e_last;
+                if (rs_on0) raw0 = rs_p0[er];
+                if (rs_on1) raw1 = rs_p1[er];
+            }
+            if (d1.valid && d1.ne > 0) {                                  // gathers of chunk i + 1 (consumed in beta)
+                int sr[2][NCHE];
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                    for (int j = 0; j < NCHE; ++j) sr[rr][j] = rsrc[gblk[j] + r8 + 32 * rr];
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                    for (int j = 0; j < NCHE; ++j) {                      // (a chunk past k_total reads a valid address and is zeroed)
+                        const float4 g = *reinterpret_cast<const float4 *>(gbase[j] + (int64_t)sr[rr][j] * gbw[j]);
+                        pf[rr][j] = gon[j] ? g : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+            }
+            if (d0.valid && d0.ne > 0 && active) {
+                const _Float16 *ap0 = in_e + li * KPE + 8 * lh, *ap1 = ap0 + 32 * KPE;
+                f32x16 acc, acb;
+                if (flag_e[0] == step) lf_mma_2tiles<NKE, true>(ap0, ap1, PLE, Bh, Bl, acc, acb);
+                else lf_mma_2tiles<NKE, false>(ap0, ap1, PLE, Bh, Bl, acc, acb);
+                float *yp = ytile + col;
+                if (cok) {
+                    lf_epilogue(acc, comb_e, lh, c0, act_lo, [&](int r, float y) { yp[r * LF_PY] = y; });
+                    lf_epilogue(acb, comb_e + 32, lh, c0, act_lo, [&](int r, float y) { yp[(32 + r) * LF_PY] = y; });
+                }
+            }
+            const unsigned long long c_1 = clk();
+            lds_barrier();
+            const unsigned long long c_2 = clk();
+            // ---------------- beta ----------------
+            if (d2.valid) {
+                if (rs_on0) rsrc[rs_b * LF_TE + rs_r] = raw0;
+                if (rs_on1) rsrc[(rs_b + 4) * LF_TE + rs_r] = raw1;
+            }
+            if (d1.valid && d1.ne > 0) {
+                bool scaled_any = false;
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr) {
+                    const int row = r8 + 32 * rr;
+                    _Float16 *dst = in_e + row * KPE;
+                    unsigned hi[NCHE][2], lo[NCHE][2], bits = 0;
+#pragma unroll
+                    for (int j = 0; j < NCHE; ++j) {
+                        unsigned rb0, rb1;
+                        lf_split2(lf_f2{pf[rr][j].x, pf[rr][j].y}, hi[j][0], lo[j][0], rb0);
+                        lf_split2(lf_f2{pf[rr][j].z, pf[rr][j].w}, hi[j][1], lo[j][1], rb1);
+                        bits |= rb0 | rb1;
+                    }
+                    bits = lf_or8(bits);
+                    float comb = inv_w;
+                    if (bits == 0) {                                      // the whole row is exact in fp16: no scale, low plane zero
+#pragma unroll
+                        for (int j = 0; j < NCHE; ++j)
+                            if (gwr[j]) {
+                                *reinterpret_cast<lf_u2 *>(dst + gk[j]) = lf_u2{hi[j][0], hi[j][1]};
+                                *reinterpret_cast<lf_u2 *>(dst + PLE + gk[j]) = lf_u2{0u, 0u};
+                            }
+                    } else {
+                        comb = lf_split_row_scaled<NCHE>(pf[rr], gwr, dst, PLE, gk) * inv_w;
+                        scaled_any = true;
+                    }
+                    if (q8 == 0) comb_e[row] = comb;
+                }
+                if (scaled_any) flag_e[0] = step + 1;                     // (every writer stores the same value)
+            }
+            if (d0.valid) {
+                // per-node sums of this chunk's activated rows, in row order (deterministic, no atomics): thread -> node r8,
+                // columns 4 (q8 + 8 j); a tile's sums live in the S buffer of its slot parity until group S0 stages them a step later
+                const int *sw = segl + d0.slot * LF_SEGW + r8;
+                int a0 = 0, a1 = 0;
+                if (r8 < d0.nn) { a0 = sw[0]; a1 = sw[1]; }
+                const int lo = (a0 > d0.e0 ? a0 : d0.e0) - d0.e0, hi = (a1 < d0.e0 + LF_TE ? a1 : d0.e0 + LF_TE) - d0.e0;
+                float *sp = sacc + (d0.slot & 1) * (LF_TN * LF_PY) + r8 * LF_PY + 4 * q8;
+                float4 v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!d0.first) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (j < njs) v[j] = *reinterpret_cast<const float4 *>(sp + 32 * j);
+                }
+                for (int r = lo; r < hi; ++r) {
+                    const float *y0 = ytile + r * LF_PY + 4 * q8;
+                    float4 ya[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (j < njs) ya[j] = *reinterpret_cast<const float4 *>(y0 + 32 * j);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (j < njs) { v[j].x += ya[j].x; v[j].y += ya[j].y; v[j].z += ya[j].z; v[j].w += ya[j].w; }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (j < njs) *reinterpret_cast<float4 *>(sp + 32 * j) = v[j];
+            }
+            const unsigned long long c_3 = clk();
+            lds_barrier();
+            const unsigned long long c_4 = clk();
+            tb_valid = ta_valid; tb_m0 = ta_m0; tb_nn = ta_nn;
+            ta_valid = ts_valid; ta_m0 = ts_m0; ta_nn = ts_nn;
+            ts_valid = d0.valid && d0.last; ts_m0 = d0.m0; ts_nn = d0.nn; ts_slot = d0.slot;
+            d0 = d1; d1 = d2; d2 = dn;
+            ++step;
+            if (PROF) { const unsigned long long c_5 = clk(); pc[0] += c_1 - c_0; pc[1] += c_2 - c_1; pc[2] += c_3 - c_2; pc[3] += c_4 - c_3; pc[4] += c_5 - c_4; pc[5] += 1; }
+        }
+        if (PROF && prof && lane == 0 && blockIdx.x == 0)
+            for (int q = 0; q < 6; ++q) prof[(tid >> 6) * 6 + q] = pc[q];
+        return;
+    }
+
+    if (grp == 1) {
+        // =============================================================================================================
+        // group S0.  Input planes of a node row: [S (h1 columns) | x (d_x) | deg, 0, 0, 0]; the weight planes follow that order.
+        // Thread -> row r8, S chunks q8 + 8 j (j < njs) and chunks q8 + 8 j of the [x | deg] part (j < njx).
+        // =============================================================================================================
+        const int h1 = a.e.n_out, cs = h1 >> 2, cx = a.d_x >> 2;
+        const int njs = cs >> 3, njx = (cx + 1 + 7) >> 3;                 // (h1 is a multiple of 32)
+        lf_u4 Bh[NK0], Bl[NK0];
+        lf_weight_planes<NK0>(st, col, cok, lh, bnscale, wscale, h1, a.d_x, Bh, Bl);
+        int koff[NCH0];
+        bool wr[NCH0], isx[NJX], isdeg[NJX];
+#pragma unroll
+        for (int j = 0; j < NJS; ++j) { koff[j] = 4 * (q8 + 8 * j); wr[j] = j < njs; }
+#pragma unroll
+        for (int j = 0; j < NJX; ++j) {
+            const int c = q8 + 8 * j;
+            koff[NJS + j] = h1 + 4 * c;
+            isx[j] = c < cx; isdeg[j] = c == cx;
+            wr[NJS + j] = c <= cx;
+        }
+        float4 xr[NJX];
+#pragma unroll
+        for (int j = 0; j < NJX; ++j) xr[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        while (d0.valid | d1.valid | d2.valid | ts_valid | ta_valid | tb_valid | (step < 0)) {
+            const unsigned long long c_0 = clk();
+            const LfDesc dn = lf_iter_next(it, lane, segl, seg_writer);
+            // ---------------- alpha ----------------
+            if (ts_valid) {                                               // x rows of the tile staged in this step's beta
+#pragma unroll
+                for (int j = 0; j < NJX; ++j) {
+                    xr[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (j < njx && isx[j] && r8 < ts_nn)
+                        xr[j] = *reinterpret_cast<const float4 *>(a.x + (int64_t)(ts_m0 + r8) * a.d_x + 4 * (q8 + 8 * j));
+                }
+            }
+            if (ta_valid && active) {
+                const f32x16 acc = lf_mma_k2<NK0>(in_n + li * KP0 + 8 * lh, PL0, Bh, Bl);
+                float *hp = htile + col;
+                if (cok) lf_epilogue(acc, comb_n, lh, c0, act_lo, [&](int r, float y) { hp[r * LF_PY] = y; });
+            }
+            const unsigned long long c_1 = clk();
+            lds_barrier();
+            const unsigned long long c_2 = clk();
+            // ---------------- beta ----------------
+            if (ts_valid) {                                               // [S | x | deg] of the tile whose sums group E finished a step ago
+                const int *sw = segl + ts_slot * LF_SEGW + r8;
+                int a0 = 0, a1 = 0;
+                if (r8 < ts_nn) { a0 = sw[0]; a1 = sw[1]; }
+                const float *sp = sacc + (ts_slot & 1) * (LF_TN * LF_PY) + r8 * LF_PY;
+                float4 v[NCH0];
+#pragma unroll
+                for (int j = 0; j < NJS; ++j) {
+                    v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (j < njs) v[j] = *reinterpret_cast<const float4 *>(sp + koff[j]);
+                }
+                const float degf = (float)(a1 - a0);
+#pragma unroll
+                for (int j = 0; j < NJX; ++j) {
+                    v[NJS + j] = xr[j];                                    // (zero where this lane has no x chunk)
+                    if (isdeg[j]) v[NJS + j] = make_float4(degf, 0.f, 0.f, 0.f);
+                }
+                const float inv = lf_split_row_scaled<NCH0>(v, wr, in_n + r8 * KP0, PL0, koff);
+                if (q8 == 0) comb_n[r8] = inv * inv_w;
+            }
+            const unsigned long long c_3 = clk();
+            lds_barrier();
+            const unsigned long long c_4 = clk();
+            tb_valid = ta_valid; tb_m0 = ta_m0; tb_nn = ta_nn;
+            ta_valid = ts_valid; ta_m0 = ts_m0; ta_nn = ts_nn;
+            ts_valid = d0.valid && d0.last; ts_m0 = d0.m0; ts_nn = d0.nn; ts_slot = d0.slot;
+            d0 = d1; d1 = d2; d2 = dn;
+            ++step;
+            if (PROF) { const unsigned long long c_5 = clk(); pc[0] += c_1 - c_0; pc[1] += c_2 - c_1; pc[2] += c_3 - c_2; pc[3] += c_4 - c_3; pc[4] += c_5 - c_4; pc[5] += 1; }
+        }
+        if (PROF && prof && lane == 0 && blockIdx.x == 0)
+            for (int q = 0; q < 6; ++q) prof[(tid >> 6) * 6 + q] = pc[q];
+        return;
+    }
+
+    // =================================================================================================================
+    // group S1
+    // =================================================================================================================
+    lf_u4 Bh[NK1], Bl[NK1];
+    lf_weight_planes<NK1>(st, col, cok, lh, bnscale, wscale, 0, 0, Bh, Bl);
+    const int njh = a.s0.n_out >> 5;                                      // 32-column groups of H that carry data (n_out multiple of 32)
+    int koff[NCH1];
+    bool wr[NCH1];
+#pragma unroll
+    for (int j = 0; j < NCH1; ++j) { wr[j] = j < njh; koff[j] = 4 * (q8 + 8 * j); }
+    // This group follows the tiles through the record group E publishes every step instead of running the iterator: its
+    // only global memory operations are the output stores, and it never waits for them.
+    int more = 1;
+    while (more | ta_valid | tb_valid | (step < 0)) {
+        const unsigned long long c_0 = clk();
+        // ---------------- alpha ----------------
+        if (tb_valid && active) {
+            const f32x16 acc = lf_mma_k2<NK1>(mid + li * KP1 + 8 * lh, PL1, Bh, Bl);
+            float *op = a.out + (int64_t)tb_m0 * st.n_out + col;          // wave-uniform base + the lane's column
+            const int n_out = st.n_out, nn = tb_nn;
+            if (cok) {
+                if (nn == LF_TN) lf_epilogue(acc, comb_h, lh, c0, act_lo, [&](int r, float y) { op[r * n_out] = y; });
+                else lf_epilogue(acc, comb_h, lh, c0, act_lo, [&](int r, float y) { if (r < nn) op[r * n_out] = y; });
+            }
+        }
+        const unsigned long long c_1 = clk();
+        lds_barrier();
+        const unsigned long long c_2 = clk();
+        // ---------------- beta ----------------
+        const int nta_valid = __builtin_amdgcn_readfirstlane(pub[0]), nta_m0 = __builtin_amdgcn_readfirstlane(pub[1]);
+        const int nta_nn = __builtin_amdgcn_readfirstlane(pub[2]);
+        more = __builtin_amdgcn_readfirstlane(pub[3]);
+        if (ta_valid) {                                                   // H of that tile was written in this step's alpha
+            float4 v[NCH1];
+#pragma unroll
+            for (int j = 0; j < NCH1; ++j) {
+                v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (j < njh) v[j] = *reinterpret_cast<const float4 *>(htile + r8 * LF_PY + koff[j]);
+            }
+            const float inv = lf_split_row_scaled<NCH1>(v, wr, mid + r8 * KP1, PL1, koff);
+            if (q8 == 0) comb_h[r8] = inv * inv_w;
+        }
+        const unsigned long long c_3 = clk();
+        lds_barrier();
+        const unsigned long long c_4 = clk();
+        tb_valid = ta_valid; tb_m0 = ta_m0; tb_nn = ta_nn;
+        ta_valid = nta_valid; ta_m0 = nta_m0; ta_nn = nta_nn;
+        ++step;
+        if (PROF) { const unsigned long long c_5 = clk(); pc[0] += c_1 - c_0; pc[1] += c_2 - c_1; pc[2] += c_3 - c_2; pc[3] += c_4 - c_3; pc[4] += c_5 - c_4; pc[5] += 1; }
+    }
+    if (PROF && prof && lane == 0 && blockIdx.x == 0)
+        for (int q = 0; q < 6; ++q) prof[(tid >> 6) * 6 + q] = pc[q];
+}
+
+#undef LF_MF
+
+template <int NKE, int NK0, int NK1, bool PROF = false>
+static int lf_launch(const LfArgs &a, hipStream_t st) {
+    constexpr size_t lds = (size_t)2 * LF_TE * (16 * NKE + 8) * 2 + (size_t)LF_TE * LF_PY * 4 + (size_t)2 * LF_TN * LF_PY * 4 +
+                           (size_t)2 * LF_TN * (16 * NK0 + 8) * 2 + (size_t)LF_TN * LF_PY * 4 + (size_t)2 * LF_TN * (16 * NK1 + 8) * 2 +
+                           ((size_t)LF_MAXB * LF_TE + LF_TE + 2 * LF_TN + LF_NSLOT * LF_SEGW + 4 + 12 + 4) * 4;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    const void *fn = reinterpret_cast<const void *>(&layer_fused_kernel<NKE, NK0, NK1, PROF>);
+    hipError_t e0 = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   // (per device: set on every launch)
+    if (e0 != hipSuccess) return set_error(GSN_E_HIP, "hipFuncSetAttribute(layer_fused_kernel): %s", hipGetErrorString(e0));
+    int64_t gx = 256;
+    { const char *d = getenv("GSN_FUSED_GRID"); if (d && atoi(d) > 0) gx = atoi(d); }
+    const int64_t n_tiles = ((int64_t)a.n_nodes + LF_TN - 1) / LF_TN;
+    if (gx > n_tiles) gx = n_tiles;
+    if (getenv("GSN_CHAIN_TRACE")) fprintf(stderr, "gsn chain: layer_fused_kernel<%d,%d,%d> nodes %d edges %d grid %lld\n", NKE, NK0, NK1, a.n_nodes, a.n_edges, (long long)gx);
+    unsigned long long *prof = nullptr;
+    if (PROF) { (void)hipMalloc(&prof, 12 * 6 * 8); (void)hipMemset(prof, 0, 12 * 6 * 8); }
+    hipLaunchKernelGGL((layer_fused_kernel<NKE, NK0, NK1, PROF>), dim3((unsigned)gx), dim3(768), lds, st, a, prof);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(GSN_E_HIP, "layer_fused_kernel: %s", hipGetErrorString(e));
+    if (PROF) {
+        unsigned long long h[12 * 6];
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(h, prof, sizeof(h), hipMemcpyDeviceToHost);
+        (void)hipFree(prof);
+        static int shown = 0;
+        if (shown++ % 8 == 7)
+            for (int w = 0; w < 12; ++w) {
+                const unsigned long long *o = h + w * 6;
+                if (o[5]) fprintf(stderr, "fusedprof %s%d steps %llu: alpha %llu barrier %llu beta %llu barrier %llu bookkeeping %llu (cycles per step)\n",
+                                  w < 4 ? "E" : (w < 8 ? "S0-" : "S1-"), w & 3, o[5], o[0] / o[5], o[1] / o[5], o[2] / o[5], o[3] / o[5], o[4] / o[5]);
+            }
+    }
+    return GSN_OK;
+}
+
+static bool lf_stage_ok(const gsn_chain_stage &g) {
+    if (!g.W || g.n_out < 1 || g.n_out > 128 || (g.n_out & 3)) return false;
+    if (g.act != 0 && g.act != 1) return false;
+    if ((g.bn_scale != nullptr) != (g.bn_shift != nullptr) || (g.bn_scale != nullptr) != (g.bn_mean != nullptr)) return false;
+    return true;
+}
+
+}  // namespace gsn
+
+using namespace gsn;
+
+extern "C" int gsn_layer_fused_supported(const gsn_chain_stage *edge, int64_t d_x, const gsn_chain_stage *node0,
+                                         const gsn_chain_stage *node1) {
+    if (!edge || !node0 || !node1) return 0;
+    if (!lf_stage_ok(*edge) || !lf_stage_ok(*node0) || !lf_stage_ok(*node1)) return 0;
+    if ((edge->n_out & 31) || (node0->n_out & 31)) return 0;           // the stagers own whole 32-column groups of S and H
+    if (edge->n_blocks < 1 || edge->n_blocks > LF_MAXB || !edge->blocks) return 0;
+    int64_t ke = 0;
+    for (int b = 0; b < edge->n_blocks; ++b) {
+        const gsn_block &bl = edge->blocks[b];
+        if (!bl.data || !bl.idx32 || bl.idx || bl.width <= 0 || (bl.width & 3)) return 0;   // int32 row sources, float4 gathers
+        if (reinterpret_cast<uintptr_t>(bl.data) & 15) return 0;
+        ke += bl.width;
+    }
+    if (ke > 80) return 0;
+    if (d_x < 4 || (d_x & 3) || d_x + 4 > 32 * LF_NXJ) return 0;
+    const int64_t k0 = d_x + edge->n_out + 4;
+    if (k0 > 160) return 0;
+    if (node0->n_blocks != 0 || node1->n_blocks != 0) return 0;
+    return 1;
+}
+
+extern "C" int gsn_layer_fused_fwd_hip(int64_t n_nodes, int64_t n_edges, const int32_t *seg_ptr, const gsn_chain_stage *edge,
+                                       const float *x, int64_t d_x, const gsn_chain_stage *node0, const gsn_chain_stage *node1,
+                                       float *out, void *stream) {
+    if (!gsn_layer_fused_supported(edge, d_x, node0, node1))
+        return set_error(GSN_E_UNSUPPORTED, "gsn_layer_fused_fwd_hip: shape outside the fused layer kernel (edge K <= 80, d_x + n_msg + 4 <= 160, "
+                                            "widths <= 128 and multiples of 4, int32 row sources, identity / relu)");
+    if (!seg_ptr || !x || !out) return set_error(GSN_E_INVALID, "gsn_layer_fused_fwd_hip: null seg_ptr / x / out");
+    if (reinterpret_cast<uintptr_t>(x) & 15) return set_error(GSN_E_INVALID, "gsn_layer_fused_fwd_hip: x must be 16-byte aligned");
+    if (n_nodes > (int64_t)2000000000 || n_edges > (int64_t)2000000000) return set_error(GSN_E_UNSUPPORTED, "gsn_layer_fused_fwd_hip: 32-bit row arithmetic");
+    if (n_nodes <= 0) return GSN_OK;
+    LfArgs a{};
+    a.n_nodes = (int)n_nodes; a.n_edges = (int)n_edges; a.seg_ptr = seg_ptr;
+    a.e_nblocks = edge->n_blocks;
+    int ke = 0;
+    for (int b = 0; b < edge->n_blocks; ++b) {
+        a.e_data[b] = edge->blocks[b].data; a.e_idx[b] = edge->blocks[b].idx32; a.e_width[b] = (int)edge->blocks[b].width;
+        ke += a.e_width[b];
+    }
+    auto fill = [](LfStage &s, const gsn_chain_stage &g, int k) {
+        s.W = g.W; s.bias = g.bias; s.bn_mean = g.bn_mean; s.bn_scale = g.bn_scale; s.bn_shift = g.bn_shift;
+        s.k_total = k; s.n_out = (int)g.n_out; s.act = g.act;
+    };
+    fill(a.e, *edge, ke);
+    fill(a.s0, *node0, (int)(d_x + edge->n_out + 4));
+    fill(a.s1, *node1, (int)node0->n_out);
+    a.x = x; a.d_x = (int)d_x; a.out = out;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int k0 = a.s0.k_total, k1 = a.s1.k_total;
+    { const char *d = getenv("GSN_FUSED_PROF"); if (d && atoi(d) && k0 > 96 && k1 > 64) return lf_launch<5, 10, 8, true>(a, st); }
+    if (k0 <= 96) return k1 <= 64 ? lf_launch<5, 6, 4>(a, st) : lf_launch<5, 6, 8>(a, st);
+    return k1 <= 64 ? lf_launch<5, 10, 4>(a, st) : lf_launch<5, 10, 8>(a, st);
+}

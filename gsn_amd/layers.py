@@ -23,6 +23,7 @@ There is no CPU path: calling a layer on CPU tensors raises.
 from __future__ import annotations
 
 import ctypes
+import os
 import weakref
 
 import torch
@@ -432,6 +433,71 @@ def _chain_fits(stages):
         arr[j].blocks = barr; arr[j].n_blocks = len(st.blocks)
         arr[j].W = 1; arr[j].n_out = st.weight.shape[0]; arr[j].act = _ACT_CODE[st.act]
     return bool(_abi.lib().gsn_mlp_chain_supported(n, arr))
+
+
+FUSED_LAYER = os.environ.get("GSN_LAYER_FUSED", "1") != "0"   # one-launch `general` layer (gsn_layer_fused_fwd_hip) where it fits
+
+
+def _stage_struct(st, blocks, keep):
+    """gsn_chain_stage of a resolved _Stage (BN parameters already in st.bn_params)."""
+    g = _abi.gsn_chain_stage()
+    barr = (_abi.gsn_block * max(len(blocks), 1))()
+    for b, (d, idx) in enumerate(blocks):
+        d = _f32c(d); keep.append(d)
+        barr[b].data = d.data_ptr(); barr[b].width = d.shape[1]
+        barr[b].idx = None; barr[b].idx32 = None
+        if idx is not None:
+            idx = idx.contiguous(); keep.append(idx)
+            if idx.dtype == torch.int32:
+                barr[b].idx32 = idx.data_ptr()
+            else:
+                barr[b].idx = idx.data_ptr()
+    keep.append(barr)
+    w = _f32c(st.weight); keep.append(w)
+    g.blocks = barr; g.n_blocks = len(blocks)
+    g.W = w.data_ptr(); g.n_out = w.shape[0]
+    vecs = [None if v is None else _f32c(v) for v in ((st.bias,) + (st.bn_params or (None, None, None)))]
+    keep.extend(vecs)
+    g.bias, g.bn_mean, g.bn_scale, g.bn_shift = [_abi.ptr(v) for v in vecs]
+    g.act = _ACT_CODE[st.act]
+    return g
+
+
+def _layer_fused(x, csr, edge_stages, node_stages, training):
+    """edge stage + per-target sum + two node stages in ONE launch (gsn_layer_fused_fwd_hip); None if the layer does not
+    fit (shape, activation, or a BatchNorm1d that needs batch statistics)."""
+    if not FUSED_LAYER or len(edge_stages) != 1 or len(node_stages) != 2:
+        return None
+    stages = edge_stages + node_stages
+    for st in stages:
+        if st.act not in ("identity", "relu"):
+            return None
+        if st.bn is not None and (training or st.bn.running_mean is None):
+            return None
+    if len(node_stages[0].blocks) != 1 or node_stages[1].blocks:     # ([x | S | deg]: S and deg are produced inside the kernel)
+        return None
+    for st in stages:
+        _bn_resolve(st, None, 0, False)
+    keep = []
+    ge = _stage_struct(edge_stages[0], edge_stages[0].blocks, keep)
+    g0 = _stage_struct(node_stages[0], [], keep)
+    g1 = _stage_struct(node_stages[1], [], keep)
+    L = _abi.lib()
+    d_x = x.shape[1]
+    if node_stages[0].weight.shape[1] != d_x + edge_stages[0].weight.shape[0] + 4:
+        return None
+    if not L.gsn_layer_fused_supported(ctypes.byref(ge), d_x, ctypes.byref(g0), ctypes.byref(g1)):
+        return None
+    n = x.shape[0]
+    E = csr.tgt.numel()
+    out = torch.empty((n, node_stages[1].weight.shape[0]), dtype=torch.float32, device=x.device)
+    flops = 2.0 * E * edge_stages[0].weight.shape[1] * edge_stages[0].weight.shape[0]
+    flops += 2.0 * n * (node_stages[0].weight.shape[1] * node_stages[0].weight.shape[0] + node_stages[1].weight.shape[1] * node_stages[1].weight.shape[0])
+    with _abi.device_guard(x.device), _timed("layer_fused", flops):
+        rc = L.gsn_layer_fused_fwd_hip(n, E, csr.seg_ptr.data_ptr(), ctypes.byref(ge), x.data_ptr(), d_x, ctypes.byref(g0),
+                                       ctypes.byref(g1), out.data_ptr(), _abi.current_stream())
+    _abi.check(rc, "gsn_layer_fused_fwd_hip")
+    return out
 
 
 def _bn_resolve(stage, stats_fn, m_rows, training):
@@ -1151,6 +1217,13 @@ class _SparseLayer(nn.Module):
                     sblocks += [(ids, csr.perm)] if self.id_scope == "local" else [(ids, csr.tgt), (ids, csr.src)]
                 if self.has_ef:
                     sblocks.append((ef, csr.perm))
+                # the whole layer in one launch where it fits (eval-mode BatchNorm, K_edge <= 80, widths <= 128)
+                if post is None or post[0] is None or post[0].training == uf.training:
+                    y = _layer_fused(x, csr, mf.stages(sblocks, upto=len(mf.fc) - 1),
+                                     uf.stages([(x, None)], first_weight=self._folded_first_weight(x.shape[1]), post=post),
+                                     self.training)
+                    if y is not None:
+                        return y
                 s_agg = mf.hip_forward(sblocks, E, upto=len(mf.fc) - 1, csr=csr)
             if s_agg is None:
                 r = mf.hip_forward(blocks, E, upto=len(mf.fc) - 1)

@@ -218,6 +218,32 @@ typedef struct {
 int gsn_mlp_chain_supported(int n_stages, const gsn_chain_stage *stages);
 int gsn_mlp_chain_fwd_hip(int64_t m_rows, int n_stages, const gsn_chain_stage *stages, const int32_t *row_perm,
                           const int32_t *seg_target, float *out, double *stats, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * HP-2  one whole `general` layer in ONE launch (device; fp32 in / fp32 out): GSN_sparse.forward / propagate / message
+ * (GSN_sparse.py:93-176), GSN_edge_sparse (GSN_edge_sparse.py:82-170) and the MPNN twins with msg_kind='general':
+ *     r_e   = act_e( bn_e( cat(edge blocks) We^T + be ) )                          per edge, rows in target-sorted order
+ *     S_v   = sum_{e -> v} r_e                                                     torch.sparse.sum (:140-143)
+ *     out_v = act_1( bn_1( act_0( bn_0( [x_v | S_v | deg_v,0,0,0] W0^T + b0 ) ) W1^T + b1 ) )
+ * where the caller has folded msg_fn's last Linear into update_fn's first (W0 = [W3x | W3a W2 | W3a b2 | 0 0 0], layers.py)
+ * and deg_v = seg_ptr[v+1] - seg_ptr[v].  r_e, S_v and the hidden rows stay in LDS: every input is read once and the
+ * output written once.  Matrix products: both operands split into two fp16 planes after exact power-of-two row / matrix
+ * scaling, three plane products on v_mfma_f32_32x32x16_f16 with fp32 accumulation (error vs fp64 as an fp32 FMA loop's;
+ * two products for rows that are exact in fp16, e.g. one-hot encodings).  Summation order of S_v = row order.
+ *   seg_ptr  int32 [n_nodes+1]  target-sorted CSR of gsn_csr_build_hip
+ *   edge     stage with 1..6 blocks, every block gathered through an int32 index in sorted-row order (sorted_target,
+ *            sorted_source or perm of gsn_csr_build_hip), widths multiples of 4, sum <= 80; n_out <= 128
+ *   x        [n_nodes][d_x], d_x multiple of 4; d_x + edge.n_out + 4 <= 160
+ *   node0    W [n0][d_x + edge.n_out + 4], no blocks;  node1  W [n1][n0], no blocks;  n0, n1 <= 128, multiples of 4
+ *   act 0 identity / 1 relu; bn_* as in gsn_linear_fwd_hip (eval-mode / resolved statistics)
+ * gsn_layer_fused_supported() says whether the shapes fit; otherwise compose gsn_mlp_chain_fwd_hip launches.
+ * ---------------------------------------------------------------------------------------------------------------- */
+int gsn_layer_fused_supported(const gsn_chain_stage *edge, int64_t d_x, const gsn_chain_stage *node0,
+                              const gsn_chain_stage *node1);
+int gsn_layer_fused_fwd_hip(int64_t n_nodes, int64_t n_edges, const int32_t *seg_ptr, const gsn_chain_stage *edge,
+                            const float *x, int64_t d_x, const gsn_chain_stage *node0, const gsn_chain_stage *node1,
+                            float *out, void *stream);
+
 int gsn_segsum_prepare_hip(int64_t n_seg, int64_t n_rows, const int32_t *seg_ptr, const int32_t *row_target,
                            int64_t n_out, float *out, void *stream);
 

@@ -1,0 +1,193 @@
+"""The one-launch `general` layer (gsn_layer_fused_fwd_hip, csrc/layer_fused.hip) on a real MI355X: against the oracle's
+plain fp32 restatement of the reference layers, against the multi-launch path of the same package, on shapes that exercise
+every branch of the tile iterator (one chunk per tile, several chunks per tile, hubs, isolated nodes, tiny batches) and both
+operand paths (rows exact in fp16 / rows that need the power-of-two row scale)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CTOR = dict(d_in=28, d_ef=4, d_id=12, d_degree=1, degree_as_tag=False, retain_features=True, id_scope="local", d_msg=128,
+            d_up=128, d_h=[128], seed=0, activation_name="relu", bn=True, msg_kind="general", flow="source_to_target")
+
+
+def _elementwise_ok(got, ref, rtol=1e-5):
+    """|got - ref| <= rtol |ref| + rtol * max|ref row|: element-wise relative with an absolute floor per row"""
+    floor = rtol * ref.abs().amax(dim=1, keepdim=True)
+    return bool(((got - ref).abs() <= rtol * ref.abs() + floor).all())
+
+
+def _randomise_bn(layer, seed):
+    g = torch.Generator().manual_seed(seed)
+    for m in layer.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.copy_(torch.rand(m.running_mean.shape, generator=g) * 0.6 - 0.3)
+            m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+            m.weight.data.copy_(torch.rand(m.weight.shape, generator=g) + 0.5)
+            m.bias.data.copy_(torch.rand(m.bias.shape, generator=g) * 0.6 - 0.3)
+
+
+def _run(cls, ctor, x, ei, ids, ef, seed=0, expect_fused=True, capfd=None):
+    from gsn_amd import layers
+    from oracle import oracle
+    torch.manual_seed(seed)
+    layer = getattr(layers, cls)(**ctor)
+    _randomise_bn(layer, seed + 1)
+    layer.eval()
+    sd = {k: v.clone() for k, v in layer.state_dict().items()}
+    kw = dict(identifiers=ids, degrees=None)
+    if ef is not None:
+        kw["edge_features"] = ef
+    ref = oracle.layer_forward(cls, ctor, sd, x, ei, training=False, **kw)
+    layer.cuda()
+    kwg = dict(identifiers=None if ids is None else ids.cuda(), degrees=torch.zeros(x.shape[0], device="cuda"))
+    if ef is not None:
+        kwg["edge_features"] = ef.cuda()
+    import os
+    os.environ["GSN_CHAIN_TRACE"] = "1"
+    try:
+        with torch.no_grad():
+            layers._CSR_CACHE.clear()
+            y = layer(x.cuda(), ei.cuda(), **kwg)
+            torch.cuda.synchronize()
+    finally:
+        os.environ.pop("GSN_CHAIN_TRACE", None)
+    if capfd is not None:
+        err = capfd.readouterr().err
+        assert ("layer_fused_kernel" in err) == expect_fused, err[-500:]
+    was = layers.FUSED_LAYER
+    layers.FUSED_LAYER = False
+    try:
+        with torch.no_grad():
+            y2 = layer(x.cuda(), ei.cuda(), **kwg)
+    finally:
+        layers.FUSED_LAYER = was
+    return y.cpu(), y2.cpu(), ref
+
+
+def _zinc(n_graphs, seed):
+    from gsn_amd import synth
+    b = synth.zinc_shape_batch(n_graphs, seed=seed)
+    x = torch.nn.functional.one_hot(torch.from_numpy(b.atom_type), 28).float()
+    ef = torch.nn.functional.one_hot(torch.from_numpy(b.bond_type), 4).float()
+    return b, x, ef, torch.from_numpy(b.edge_index)
+
+
+@pytest.mark.parametrize("n_graphs", [1, 3, 64, 4096])
+def test_fused_layer_zinc_shape_exact_rows(n_graphs, capfd):
+    """layer 0 of BASELINE config 2: one-hot inputs (rows exact in fp16: two plane products in the edge stage)"""
+    b, x, ef, ei = _zinc(n_graphs, seed=20 + n_graphs)
+    ids = (torch.rand(b.num_edges, 12, generator=torch.Generator().manual_seed(1)) < 0.2).float()
+    y, y2, ref = _run("GSN_edge_sparse", CTOR, x, ei, ids, ef, seed=3, capfd=capfd)
+    assert _elementwise_ok(y, ref), float((y - ref).abs().max() / ref.abs().max())
+    assert _elementwise_ok(y, y2)
+
+
+def test_fused_layer_general_float_inputs(capfd):
+    """real-valued inputs of mixed magnitude: every row takes the scaled path (three plane products)"""
+    b, x, ef, ei = _zinc(512, seed=5)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(b.num_nodes, 28, generator=g) * torch.logspace(-3, 2, 28)
+    ef = torch.randn(b.num_edges, 4, generator=g) * 30.0
+    ids = torch.randn(b.num_edges, 12, generator=g).abs() * 1e-3
+    y, y2, ref = _run("GSN_edge_sparse", CTOR, x, ei, ids, ef, seed=4, capfd=capfd)
+    assert _elementwise_ok(y, ref), float((y - ref).abs().max() / ref.abs().max())
+    assert _elementwise_ok(y, y2)
+
+
+def test_fused_layer_mixed_rows(capfd):
+    """some rows exact, some not, inside one chunk"""
+    b, x, ef, ei = _zinc(256, seed=6)
+    g = torch.Generator().manual_seed(8)
+    ids = (torch.rand(b.num_edges, 12, generator=g) < 0.2).float()
+    noisy = torch.rand(b.num_edges, generator=g) < 0.3
+    ids[noisy] += torch.randn(int(noisy.sum()), 12, generator=g) * 0.01
+    y, y2, ref = _run("GSN_edge_sparse", CTOR, x, ei, ids, ef, seed=5, capfd=capfd)
+    assert _elementwise_ok(y, ref), float((y - ref).abs().max() / ref.abs().max())
+
+
+def _graph_batch(graphs):
+    from gsn_amd import synth
+    return synth.collate(graphs)
+
+
+def test_fused_layer_dense_hub_isolated(capfd):
+    """tiles with several chunks (dense graphs), a hub with hundreds of in-edges, runs of isolated nodes, an edge-less
+    graph at the start / end, duplicate edges"""
+    from gsn_amd import synth
+    rng = np.random.default_rng(3)
+    graphs = []
+    graphs.append((5, np.zeros((2, 0), dtype=np.int64)))                              # no edges at all
+    graphs.append(synth.er_graph(40, 300, 1))                                          # mean degree 15
+    star = np.stack([np.zeros(300, dtype=np.int64), np.arange(1, 301)])
+    graphs.append((400, np.concatenate([star, star[::-1]], axis=1)))                   # hub with 300 in-edges, 99 isolated nodes
+    graphs.append(synth.zinc_shape_graph(rng))
+    dup = np.array([[0, 1, 0, 1, 2, 1], [1, 0, 1, 0, 1, 2]], dtype=np.int64)
+    graphs.append((3, dup))                                                            # duplicate columns are summed twice
+    graphs.append(synth.er_graph(128, 1000, 2))
+    graphs.append((70, np.zeros((2, 0), dtype=np.int64)))
+    b = _graph_batch(graphs)
+    g = torch.Generator().manual_seed(9)
+    N, E = b.num_nodes, b.num_edges
+    x = torch.nn.functional.one_hot(torch.randint(0, 28, (N,), generator=g), 28).float()
+    ef = torch.nn.functional.one_hot(torch.randint(0, 4, (E,), generator=g), 4).float()
+    ids = torch.randint(0, 3, (E, 12), generator=g).float()
+    ei = torch.from_numpy(b.edge_index)
+    for flow in ("source_to_target", "target_to_source"):
+        ctor = dict(CTOR, flow=flow)
+        y, y2, ref = _run("GSN_edge_sparse", ctor, x, ei, ids, ef, seed=6, capfd=capfd)
+        assert _elementwise_ok(y, ref), (flow, float((y - ref).abs().max() / ref.abs().max()))
+        assert _elementwise_ok(y, y2)
+
+
+@pytest.mark.parametrize("cls,ctor_kw,d_x,d_id,d_ef", [
+    ("GSN_sparse", dict(d_in=1, d_id=67, d_msg=64, d_up=64, d_h=[64]), 1, 67, 0),                  # SR25 config: d_x = 1 (not a multiple of 4): multi-launch path
+    ("GSN_edge_sparse", dict(d_in=28, d_ef=4, d_id=12, d_msg=64, d_up=64, d_h=[64]), 28, 12, 4),   # ZINC-100K script: d = 64
+    ("GSN_sparse", dict(d_in=16, d_id=8, d_msg=128, d_up=96, d_h=[128], id_scope="global"), 16, 8, 0),   # GSN-v: ids gathered at both ends
+    ("MPNN_edge_sparse", dict(d_in=32, d_ef=8, d_msg=128, d_up=128, d_h=[64]), 32, 0, 8),
+    ("MPNN_sparse", dict(d_in=24, d_msg=48, d_up=32, d_h=[128], bn=False, activation_name="identity"), 24, 0, 0),
+])
+def test_fused_layer_other_classes_and_widths(cls, ctor_kw, d_x, d_id, d_ef, capfd):
+    b, _, _, ei = _zinc(300, seed=31)
+    base = dict(d_degree=1, degree_as_tag=False, retain_features=True, seed=0, activation_name="relu", bn=True, msg_kind="general",
+                flow="source_to_target")
+    if "GSN" in cls:
+        base["id_scope"] = "local"
+    ctor = dict(base, **ctor_kw)
+    g = torch.Generator().manual_seed(12)
+    N, E = b.num_nodes, b.num_edges
+    x = torch.randn(N, d_x, generator=g)
+    ids = None
+    if d_id:
+        ids = torch.randn(N if ctor.get("id_scope") == "global" else E, d_id, generator=g)
+    ef = torch.randn(E, d_ef, generator=g) if d_ef else None
+    fits = d_x % 4 == 0 and (2 * d_x + (2 * d_id if ctor.get("id_scope") == "global" else d_id) + d_ef) <= 80
+    y, y2, ref = _run(cls, ctor, x, ei, ids, ef, seed=8, expect_fused=fits, capfd=capfd)
+    assert _elementwise_ok(y, ref), float((y - ref).abs().max() / ref.abs().max())
+
+
+def test_fused_layer_full_size_properties():
+    """65 536 ZINC-shaped graphs (the bench shape): the fused layer equals the multi-launch path element-wise, and the batch
+    is a disjoint union -- the first 1000 graphs alone give the same rows."""
+    from gsn_amd import layers
+    b, x, ef, ei = _zinc(65536, seed=77)
+    ids = torch.nn.functional.one_hot(torch.randint(0, 3, (b.num_edges, 4), generator=torch.Generator().manual_seed(2)), 3).reshape(-1, 12).float()
+    torch.manual_seed(0)
+    layer = layers.GSN_edge_sparse(**CTOR)
+    _randomise_bn(layer, 5)
+    layer.eval().cuda()
+    xg, eig, idg, efg = x.cuda(), ei.cuda(), ids.cuda(), ef.cuda()
+    deg = torch.zeros(b.num_nodes, device="cuda")
+    with torch.no_grad():
+        y = layer(xg, eig, identifiers=idg, degrees=deg, edge_features=efg)
+        layers.FUSED_LAYER = False
+        try:
+            y2 = layer(xg, eig, identifiers=idg, degrees=deg, edge_features=efg)
+        finally:
+            layers.FUSED_LAYER = True
+        n1, e1 = int(b.node_ptr[1000]), int(b.edge_ptr[1000])
+        y3 = layer(xg[:n1].contiguous(), eig[:, :e1].contiguous(), identifiers=idg[:e1].contiguous(), degrees=deg[:n1], edge_features=efg[:e1].contiguous())
+    assert torch.isfinite(y).all()
+    assert _elementwise_ok(y.cpu(), y2.cpu())
+    assert _elementwise_ok(y3.cpu(), y[:n1].cpu(), rtol=2e-6)
