@@ -36,3 +36,11 @@ extern "C" int gsn_device_count(void) {
     }
     return good;
 }
+
+namespace gsn {
+int current_device() {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    return dev;
+}
+}  // namespace gsn

@@ -387,11 +387,12 @@ static int launch_chain_impl(const ChainArgs &a, hipStream_t st) {
     constexpr int WPE = NST == 1 ? (SMALL ? 4 : 2) : 1;
     const void *fn = reinterpret_cast<const void *>(&mlp_chain_kernel<NST, CH0, CH1, STATS, WPE, SEG, NW>);
     const size_t lds = (size_t)2 * CBM * a.pitch * 4 + 3 * RS_STRIDE * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_set;
+    const int attr_dev = current_device();
+    if (!attr_set.done(attr_dev)) {
         hipError_t e0 = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e0 != hipSuccess) return set_error(GSN_E_HIP, "hipFuncSetAttribute(mlp_chain_kernel): %s", hipGetErrorString(e0));
-        attr_set = true;
+        attr_set.mark(attr_dev);
     }
     const int64_t n_tiles = (a.m_rows + CBM - 1) / CBM;
     int per_cu = (SMALL && lds <= 76 * 1024) ? 2 : 1;

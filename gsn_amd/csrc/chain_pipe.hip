@@ -225,12 +225,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 template <int CH0, int CH1>
 static int launch_pipe_impl(const ChainArgs &a, int pin, int pmid, size_t lds, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_set;
+    const int attr_dev = current_device();
+    if (!attr_set.done(attr_dev)) {
         hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_chain2_pipe_kernel<CH0, CH1>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e0 != hipSuccess) return set_error(GSN_E_HIP, "hipFuncSetAttribute(mlp_chain2_pipe_kernel): %s", hipGetErrorString(e0));
-        attr_set = true;
+        attr_set.mark(attr_dev);
     }
     const int64_t n_tiles = (a.m_rows + CBM - 1) / CBM;
     int64_t gx = 256;

@@ -389,12 +389,13 @@ template <int NK0, int NK1, bool VEC4, bool PROF = false>
 static int launch_pipe_bf_impl(const ChainArgs &a, hipStream_t st) {
     constexpr size_t lds = ((size_t)6 * (32 * (NK0 * 16 + 8) / 2) + (size_t)6 * (32 * (NK1 * 16 + 8) / 2)) * 4;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_set;
+    const int attr_dev = current_device();
+    if (!attr_set.done(attr_dev)) {
         hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void *>(&mlp_chain2_pipe_bf16_kernel<NK0, NK1, VEC4, PROF>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e0 != hipSuccess) return set_error(GSN_E_HIP, "hipFuncSetAttribute(mlp_chain2_pipe_bf16_kernel): %s", hipGetErrorString(e0));
-        attr_set = true;
+        attr_set.mark(attr_dev);
     }
     unsigned long long *prof = nullptr;
     if (PROF) { (void)hipMalloc(&prof, 8 * 6 * 8); (void)hipMemset(prof, 0, 8 * 6 * 8); }

@@ -306,11 +306,12 @@ __global__ __launch_bounds__(TBM * 16) __attribute__((amdgpu_waves_per_eu(4, 4))
 template <int NKS, int TBM, bool PROF, bool VEC4>
 static int launch_seg_impl(const ChainArgs &a, hipStream_t st) {
     const void *fn = reinterpret_cast<const void *>(&mlp_chain1_seg_kernel<NKS, TBM, PROF, VEC4>);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_set;
+    const int attr_dev = current_device();
+    if (!attr_set.done(attr_dev)) {
         hipError_t e0 = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e0 != hipSuccess) return set_error(GSN_E_HIP, "hipFuncSetAttribute(mlp_chain1_seg_kernel): %s", hipGetErrorString(e0));
-        attr_set = true;
+        attr_set.mark(attr_dev);
     }
     const int pin = (((NKS * 2 + 31) / 32) * 32) | 1;
     int py = a.st[0].n_out | 1;

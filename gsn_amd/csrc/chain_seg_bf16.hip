@@ -409,11 +409,12 @@ __global__ __launch_bounds__(TBM * 12) __attribute__((amdgpu_waves_per_eu(3, 3))
 template <int NK16, int TBM, bool PROF>
 static int launch_bf_impl(const ChainArgs &a, hipStream_t st) {
     const void *fn = reinterpret_cast<const void *>(&mlp_chain1_seg_bf16_kernel<NK16, TBM, PROF>);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_set;
+    const int attr_dev = current_device();
+    if (!attr_set.done(attr_dev)) {
         hipError_t e0 = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e0 != hipSuccess) return set_error(GSN_E_HIP, "hipFuncSetAttribute(mlp_chain1_seg_bf16_kernel): %s", hipGetErrorString(e0));
-        attr_set = true;
+        attr_set.mark(attr_dev);
     }
     int py = a.st[0].n_out | 1;
     if (py == a.st[0].n_out) py += 2;

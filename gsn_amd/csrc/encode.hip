@@ -390,12 +390,13 @@ static int launch_embed_lds(EmbArgs &a, const int64_t *table_rows, hipStream_t s
     // backward keeps one table copy per wave: 4 waves while that fits, else a single wave per workgroup
     const int nwv = (!BWD || 4 * a.row_off[a.n_cols] <= EMB_LDS_SUM_ROWS) ? 4 : 1;
     const size_t lds = (size_t)(BWD ? nwv : 1) * a.row_off[a.n_cols] * EMB_DCH * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_set;
+    const int attr_dev = current_device();
+    if (!attr_set.done(attr_dev)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&embed_lds_kernel<BWD>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 EMB_LDS_SUM_ROWS * EMB_DCH * (int)sizeof(float)) != hipSuccess)
             return set_error(GSN_E_HIP, "embed_lds_kernel: cannot raise the LDS limit");
-        attr_set = true;
+        attr_set.mark(attr_dev);
     }
     const dim3 grid((unsigned)((a.m_rows + EMB_ROWS - 1) / EMB_ROWS), (unsigned)((a.d + EMB_DCH - 1) / EMB_DCH));
     hipLaunchKernelGGL(embed_lds_kernel<BWD>, grid, dim3(64 * nwv), lds, s, a);

@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <atomic>
 
 #include "../../include/gsn_abi.h"
 
@@ -21,5 +22,14 @@ constexpr int PLAN_HEADER_WORDS = 8;
 constexpr int PLAN_STRIDE_WORDS = 2 + GSN_KMAX + GSN_KMAX / 4;
 
 int set_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
+// "done once per DEVICE" flag for per-device kernel attributes (hipFuncSetAttribute applies to the current device only; a
+// process may drive several GPUs).  Lock-free: a racing second setter merely repeats the idempotent call.
+struct DeviceOnce {
+    std::atomic<unsigned long long> mask{0};
+    bool done(int dev) const { return dev >= 0 && dev < 64 && ((mask.load(std::memory_order_acquire) >> dev) & 1ull); }
+    void mark(int dev) { if (dev >= 0 && dev < 64) mask.fetch_or(1ull << dev, std::memory_order_release); }
+};
+int current_device();   // hipGetDevice, -1 on error (abi.cpp)
 
 }  // namespace gsn

@@ -12,18 +12,18 @@
 // processes in chunks of <= 64 rows (the tile takes as many nodes as fit a whole number of chunks: ZINC-shaped graphs give
 // ~31 nodes / 64 edges per tile, one chunk; a hub or a dense graph gives several chunks per tile).  All waves run the same
 // tile iterator over seg_ptr (one 33-entry window load per tile, fetched a tile ahead), so every scheduling decision is a
-// wave-uniform scalar and no descriptor is communicated.
+// wave-uniform scalar; only group S1, which must never wait for a load behind its output stores, follows a four-word record.
 //
-// Roles (12 waves, 3 per SIMD; a wave keeps ONE stage's weights in registers for the whole kernel):
-//   group E  (waves 0-3):  edge stage of chunk i          -> Y   [64][132] fp32 in LDS
-//   group S0 (waves 4-7):  node stage 0 of the tile before -> H   [32][132] fp32 in LDS
-//   group S1 (waves 8-11): node stage 1 of the tile before that -> out rows (global stores)
-// Every step has a matrix phase (alpha) and a staging phase (beta), one LDS-only barrier after each; all LDS buffers are
-// single: alpha reads the operand planes and writes fp32 tiles, beta reads fp32 tiles and writes operand planes.
-//   beta, E : gathered rows (float4 global loads issued a step earlier) -> fp16 planes IN_E of chunk i+1
-//   beta, S0: per node  sum of its Y rows in row order (deterministic, no atomics; partial sums of multi-chunk tiles in
-//             S_acc) ; on the tile's last chunk  [x | S | deg] -> fp16 planes IN_N
-//   beta, S1: H -> fp16 planes MID
+// Roles (12 waves, 3 per SIMD; a wave keeps ONE stage's weights in registers for the whole kernel).  Every step has two
+// phases with one LDS-only barrier after each, and every group alternates a matrix phase with a staging phase, so that the
+// matrix pipe and the vector pipe are both busy in both phases; every LDS buffer is written in one phase and read in the other
+// (only H, which crosses from phase 2 to the next step's phase 2, is double):
+//                 phase 1                                              phase 2
+//   group E  (waves 0-3)   edge stage of chunk i: IN_E -> Y (fp32)      gathered rows -> planes IN_E of chunk i + 1;  per node, sum of its
+//                          (+ issues the gathers of chunk i + 1)        Y rows in row order -> S (deterministic, no atomics)
+//   group S0 (waves 4-7)   [S | x | deg] of the finished tile -> IN_N    node stage 0: IN_N -> H[i & 1] (fp32)
+//   group S1 (waves 8-11)  node stage 1 of the tile staged last step:   H[(i - 1) & 1] -> planes MID
+//                          MID -> out rows (global stores)
 //
 // Matrix arithmetic: fp16x3.  Both operands are split into two fp16 planes (x = x_h + x_l, 11 + 11 significant bits, round
 // to nearest) after an exact power-of-two scaling that puts the largest magnitude of every A row (and of each stage's weight
@@ -33,7 +33,9 @@
 // The accumulator is un-scaled in the epilogue (one fma with the row's inverse scale).  Rows that are exactly representable
 // in fp16 without scaling (one-hot / small-integer encodings: every layer-0 input of the reference models) need no row
 // maximum and no low plane: a chunk made only of such rows runs two products instead of three.
-// Non-finite inputs: a row containing Inf or NaN yields NaN in that row's outputs (an fp32 product would keep a signed Inf).
+// Non-finite values: an edge row, node row or hidden row that holds an Inf or a NaN gives NaN in ALL of that row's outputs
+// (and so, through the per-node sums, in the rows that aggregate it); fp32 arithmetic would keep a signed Inf where no Inf - Inf
+// or 0 * Inf occurs.  An Inf / NaN weight or folded BatchNorm factor makes every output row NaN.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -167,15 +169,17 @@ __device__ __forceinline__ unsigned lf_max8(unsigned v) {
 }
 
 // row of NCH float4 chunks held by 8 lanes -> scaled fp16 planes at `dst` (+ plane stride); chunk j is stored only where
-// wr[j] (a per-lane predicate on the store alone: the arithmetic is branch-free).  Returns the inverse row scale.
+// wr[j] (a per-lane predicate on the store alone: the arithmetic is branch-free).  Returns the inverse row scale -- NaN, with
+// `nonfinite` set, when the row holds an Inf or a NaN: the epilogue of that tile then writes NaN rows (see lf_epilogue).
 template <int NCH>
-__device__ __forceinline__ float lf_split_row_scaled(const float4 (&v)[NCH], const bool (&wr)[NCH], _Float16 *dst, int plane_halfs, const int (&koff)[NCH]) {
+__device__ __forceinline__ float lf_split_row_scaled(const float4 (&v)[NCH], const bool (&wr)[NCH], _Float16 *dst, int plane_halfs, const int (&koff)[NCH], bool &nonfinite) {
     unsigned m = 0;
 #pragma unroll
     for (int j = 0; j < NCH; ++j) m = lf_absmax4(m, v[j]);
     m = lf_max8(m);
     float rs, inv;
     lf_scale(m, rs, inv);
+    if (m >= 0x7f800000u) { inv = __uint_as_float(0x7fc00000u); nonfinite = true; }   // Inf / NaN in the row: its outputs become NaN
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
         unsigned h0, l0, h1, l1, rb;
@@ -191,9 +195,10 @@ __device__ __forceinline__ float lf_split_row_scaled(const float4 (&v)[NCH], con
 
 // weights of one lane (output column `col`, plane column k' = 16 s + 8 lh + e), BN scale folded in, times the stage's
 // power-of-two scale.  Plane column k' holds original weight column  k' < h1 ? dx + k' : (k' < h1 + dx ? k' - h1 : k')
-// (node stage 0 keeps its input planes as [S | x | deg]; h1 = dx = 0: identity).
+// (node stage 0 keeps its input planes as [S | x | deg]; h1 = dx = 0: identity); the first h1 plane columns are multiplied by
+// sfac (the S rows arrive times the edge stage's weight scale).
 template <int NK>
-__device__ __forceinline__ void lf_weight_planes(const LfStage &st, int col, bool cok, int lh, float bnscale, float wscale, int h1, int dx, lf_u4 *Bh, lf_u4 *Bl) {
+__device__ __forceinline__ void lf_weight_planes(const LfStage &st, int col, bool cok, int lh, float bnscale, float wscale, int h1, int dx, float sfac, lf_u4 *Bh, lf_u4 *Bl) {
 #pragma unroll
     for (int s = 0; s < NK; ++s) {
         unsigned h[4], l[4], rb;
@@ -206,7 +211,7 @@ __device__ __forceinline__ void lf_weight_planes(const LfStage &st, int col, boo
                 const int k = kp < h1 ? dx + kp : (kp < h1 + dx ? kp - h1 : kp);
                 const bool ok = kp < st.k_total && cok;
                 const float w0 = st.W[ok ? (int64_t)col * st.k_total + k : 0];
-                wv[e] = ok ? w0 * bnscale * wscale : 0.f;
+                wv[e] = ok ? w0 * bnscale * wscale * (kp < h1 ? sfac : 1.f) : 0.f;     // (sfac: exact power of two)
             }
             lf_split2(lf_f2{wv[0], wv[1]}, h[q], l[q], rb);
         }
@@ -262,29 +267,34 @@ __device__ __forceinline__ f32x16 lf_mma_k2(const _Float16 *ap, int plane, const
     return acc;
 }
 
-// the edge stage's two 32-row halves of a chunk as two interleaved chains (same weights, two A tiles)
+// one 32-row tile of the edge stage: a single accumulator chain (the edge group's register budget also holds the gathered
+// rows of the next chunk), fragments of k-step s + 1 read before the products of step s are issued
 template <int NK, bool THREE>
-__device__ __forceinline__ void lf_mma_2tiles(const _Float16 *ap0, const _Float16 *ap1, int plane, const lf_u4 *Bh, const lf_u4 *Bl, f32x16 &acc, f32x16 &acb) {
+__device__ __forceinline__ f32x16 lf_mma_tile(const _Float16 *ap, int plane, const lf_u4 *Bh, const lf_u4 *Bl, float init) {
+    f32x16 acc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acb[r] = 0.f; }
+    for (int r = 0; r < 16; ++r) acc[r] = init;
+    lf_u4 ha[2], la[2];
+    ha[0] = *reinterpret_cast<const lf_u4 *>(ap);
+    la[0] = THREE ? *reinterpret_cast<const lf_u4 *>(ap + plane) : ha[0];
 #pragma unroll
     for (int s = 0; s < NK; ++s) {
-        const lf_u4 ha = *reinterpret_cast<const lf_u4 *>(ap0 + 16 * s), hb = *reinterpret_cast<const lf_u4 *>(ap1 + 16 * s);
-        if (THREE) {
-            const lf_u4 la = *reinterpret_cast<const lf_u4 *>(ap0 + plane + 16 * s), lb = *reinterpret_cast<const lf_u4 *>(ap1 + plane + 16 * s);
-            LF_MF(la, Bh[s]);
-            acb = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, lb), __builtin_bit_cast(f16x8, Bh[s]), acb, 0, 0, 0);
+        const int c = s & 1, n = c ^ 1;
+        if (s + 1 < NK) {
+            ha[n] = *reinterpret_cast<const lf_u4 *>(ap + 16 * (s + 1));
+            la[n] = THREE ? *reinterpret_cast<const lf_u4 *>(ap + plane + 16 * (s + 1)) : ha[n];
         }
-        LF_MF(ha, Bl[s]);
-        acb = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, hb), __builtin_bit_cast(f16x8, Bl[s]), acb, 0, 0, 0);
-        LF_MF(ha, Bh[s]);
-        acb = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, hb), __builtin_bit_cast(f16x8, Bh[s]), acb, 0, 0, 0);
+        if (THREE) LF_MF(la[c], Bh[s]);
+        LF_MF(ha[c], Bl[s]);
+        LF_MF(ha[c], Bh[s]);
     }
+    return acc;
 }
 
 // epilogue of a 32 x 32 accumulator tile: y = max(acc * comb[row] + c0, lo) for this lane's 16 rows; f(r, y) with r the row
-// inside the 32-row tile.  comb: this tile's 32 inverse scales (LDS).
-template <typename F>
+// inside the 32-row tile.  comb: this tile's 32 inverse scales (LDS).  NANROWS (tiles whose stager met a non-finite value,
+// rare): rows whose inverse scale is NaN come out as NaN -- the plain max would drop the NaN (IEEE maxNum semantics).
+template <bool NANROWS, typename F>
 __device__ __forceinline__ void lf_epilogue(const f32x16 &acc, const float *comb, int lh, float c0, float lo, F f) {
     const float *cp = comb + 4 * lh;
 #pragma unroll
@@ -292,7 +302,11 @@ __device__ __forceinline__ void lf_epilogue(const f32x16 &acc, const float *comb
         const float4 cm = *reinterpret_cast<const float4 *>(cp + 8 * g);
         const float cv[4] = {cm.x, cm.y, cm.z, cm.w};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) f(4 * lh + 8 * g + r, __builtin_amdgcn_fmed3f(fmaf(acc[4 * g + r], cv[r], c0), lo, INFINITY));   // = max(., lo)
+        for (int r = 0; r < 4; ++r) {
+            float y = __builtin_amdgcn_fmed3f(fmaf(acc[4 * g + r], cv[r], c0), lo, INFINITY);   // = max(., lo)
+            if (NANROWS) y = cv[r] != cv[r] ? cv[r] : y;
+            f(4 * lh + 8 * g + r, y);
+        }
     }
 }
 
@@ -305,7 +319,8 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         __builtin_amdgcn_sched_barrier(0);
         return v;
     };
-    unsigned long long pc[6] = {0, 0, 0, 0, 0, 0};     // alpha work, barrier 1, beta work, barrier 2, bookkeeping, steps
+    unsigned long long pc[6] = {0, 0, 0, 0, 0, 0};     // phase-1 work, barrier 1, phase-2 work, barrier 2, bookkeeping, steps
+    unsigned long long pe[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // group E only: iterator + publish, row sources + gathers, matrix + epilogue | row-source table, split, sums
     constexpr int KE = 16 * NKE, KPE = KE + 8, PLE = LF_TE * KPE;        // halfs
     constexpr int K0 = 16 * NK0, KP0 = K0 + 8, PL0 = LF_TN * KP0;
     constexpr int K1 = 16 * NK1, KP1 = K1 + 8, PL1 = LF_TN * KP1;
@@ -315,9 +330,9 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     static_assert(K1 % 32 == 0, "stage-1 input planes in whole 32-column groups");
     constexpr int OFF_INE = 0, SZ_INE = 2 * PLE * 2;
     constexpr int OFF_Y = OFF_INE + SZ_INE, SZ_Y = LF_TE * LF_PY * 4;
-    constexpr int OFF_SACC = OFF_Y + SZ_Y, SZ_SACC = 2 * LF_TN * LF_PY * 4;   // per-node sums of two tiles (parity of the tile's slot)
+    constexpr int OFF_SACC = OFF_Y + SZ_Y, SZ_SACC = LF_TN * LF_PY * 4;       // per-node sums of the tile being reduced
     constexpr int OFF_INN = OFF_SACC + SZ_SACC, SZ_INN = 2 * PL0 * 2;
-    constexpr int OFF_H = OFF_INN + SZ_INN, SZ_H = LF_TN * LF_PY * 4;
+    constexpr int OFF_H = OFF_INN + SZ_INN, SZ_H = 2 * LF_TN * LF_PY * 4;       // hidden rows of two tiles (step parity)
     constexpr int OFF_MID = OFF_H + SZ_H, SZ_MID = 2 * PL1 * 2;
     constexpr int OFF_TAB = OFF_MID + SZ_MID;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -332,7 +347,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     float *comb_n = comb_e + LF_TE;                                      // [LF_TN]
     float *comb_h = comb_n + LF_TN;                                      // [LF_TN]
     int *segl = reinterpret_cast<int *>(comb_h + LF_TN);                 // [LF_NSLOT][LF_SEGW] seg_ptr windows of the tiles in flight
-    int *flag_e = segl + LF_NSLOT * LF_SEGW;                                    // [4]  flag_e[0] == ordinal of a chunk with a scaled row
+    int *flag_e = segl + LF_NSLOT * LF_SEGW;                             // [4]  ordinals of: a chunk with a scaled row; a chunk / node tile / hidden tile with a non-finite row
     unsigned *wmax = reinterpret_cast<unsigned *>(flag_e + 4);           // [12] per-wave weight maxima (prologue)
     int *pub = reinterpret_cast<int *>(wmax + 12);                        // [4]  tile bookkeeping published to group S1 every step
 
@@ -366,6 +381,9 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     wscale = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(wscale)));       // (wave-uniform: scalar registers)
     inv_w = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(inv_w)));
     const float act_lo = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(st.act == 1 ? 0.f : -INFINITY)));   // relu / identity as one max
+    // an Inf / NaN weight (or folded BatchNorm factor): every output row of this stage is NaN, through the same path as a non-finite input row
+    const bool w_bad = __builtin_amdgcn_readfirstlane((int)(max(max(wmax[4 * grp], wmax[4 * grp + 1]), max(wmax[4 * grp + 2], wmax[4 * grp + 3])) >= 0x7f800000u)) != 0;
+    if (w_bad) inv_w = __uint_as_float(0x7fc00000u);
 
     // ---- node range of this workgroup, tile iterator (identical in every wave of groups E and S0) -----------------------
     LfIter it;
@@ -381,9 +399,11 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         lf_iter_load(it, lane);
         d2 = lf_iter_next(it, lane, segl, seg_writer);
     }
-    int ts_valid = 0, ts_m0 = 0, ts_nn = 0, ts_slot = 0;                  // tile whose per-node sums are complete (S buffer of its slot parity)
-    int ta_valid = 0, ta_m0 = 0, ta_nn = 0;                               // tile whose planes IN_N are staged
-    int tb_valid = 0, tb_m0 = 0, tb_nn = 0;                               // tile whose planes MID are staged
+    // tiles in the node pipeline at step i:  ts: sums complete, group S0 stages it in phase 1 and multiplies it in phase 2 -> H[i & 1];
+    // th: its H was written in step i - 1, group S1 splits it in phase 2 -> MID;  tm: MID staged in step i - 1, S1 multiplies it in phase 1
+    int ts_valid = 0, ts_m0 = 0, ts_nn = 0, ts_slot = 0;
+    int th_valid = 0, th_m0 = 0, th_nn = 0;
+    int tm_valid = 0, tm_m0 = 0, tm_nn = 0;
     int step = -2;
 
     if (grp == 0) {
@@ -391,16 +411,17 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         // group E
         // =============================================================================================================
         lf_u4 Bh[NKE], Bl[NKE];
-        lf_weight_planes<NKE>(st, col, cok, lh, bnscale, wscale, 0, 0, Bh, Bl);
+        lf_weight_planes<NKE>(st, col, cok, lh, bnscale, wscale, 0, 0, 1.f, Bh, Bl);
         // staging map: thread -> rows r8 and r8 + 32, float4 chunks q8 + 8 j of each
         const float *gbase[NCHE];
         int gbw[NCHE], gblk[NCHE], gk[NCHE];
-        bool gon[NCHE], gwr[NCHE];
+        bool gon[NCHE];
+        unsigned gmask[NCHE];
 #pragma unroll
         for (int j = 0; j < NCHE; ++j) {
             const int kc = 4 * (q8 + 8 * j);
             gon[j] = kc < a.e.k_total;                                    // a real input column: loaded
-            gwr[j] = kc < KE;                                             // inside the plane row: stored (zeros beyond k_total)
+            gmask[j] = gon[j] ? 0xffffffffu : 0u;
             int blk = 0, c = kc;
 #pragma unroll
             for (int b = 0; b < LF_MAXB - 1; ++b)
@@ -424,20 +445,22 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const bool rs_on0 = rs_b < a.e_nblocks, rs_on1 = rs_b + 4 < a.e_nblocks;
         const int e_last = a.n_edges > 0 ? a.n_edges - 1 : 0;
         const int njs = a.e.n_out >> 5;                                   // 32-column groups of the activated rows
+        const float c0w = c0 * wscale;                                    // the accumulators' start value in a chunk of exact rows
         int raw0 = 0, raw1 = 0;
         float4 pf[2][NCHE];
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
             for (int j = 0; j < NCHE; ++j) pf[rr][j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        while (d0.valid | d1.valid | d2.valid | ts_valid | ta_valid | tb_valid | (step < 0)) {
+        while (d0.valid | d1.valid | d2.valid | ts_valid | th_valid | tm_valid | (step < 0)) {
             const unsigned long long c_0 = clk();
             const LfDesc dn = lf_iter_next(it, lane, segl, seg_writer);  // chunk i + 3 (its window arrived a step ago)
-            // ---------------- alpha ----------------
+            // ---------------- phase 1 ----------------
             if (tid == 0) {                                               // what group S1 needs to follow the tiles (it never loads seg_ptr:
                 pub[0] = ts_valid; pub[1] = ts_m0; pub[2] = ts_nn;        // a wait for such a load would drain its output stores)
                 pub[3] = d1.valid | (d0.valid && d0.last);
             }
+            const unsigned long long e_1 = clk();
             if (d2.valid && a.n_edges > 0) {                              // row sources of chunk i + 2 (consumed in beta)
                 int er = d2.e0 + (rs_r < d2.ne ? rs_r : (d2.ne > 0 ? d2.ne - 1 : 0));
                 er = er < e_last ? er : e_last;
@@ -453,69 +476,90 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
                 for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
-                    for (int j = 0; j < NCHE; ++j) {                      // (a chunk past k_total reads a valid address and is zeroed)
-                        const float4 g = *reinterpret_cast<const float4 *>(gbase[j] + (int64_t)sr[rr][j] * gbw[j]);
-                        pf[rr][j] = gon[j] ? g : make_float4(0.f, 0.f, 0.f, 0.f);
-                    }
+                    for (int j = 0; j < NCHE; ++j)                        // (a chunk past k_total reads a valid address; it is masked when the
+                        pf[rr][j] = *reinterpret_cast<const float4 *>(gbase[j] + (int64_t)sr[rr][j] * gbw[j]);   // row is staged: any use here would wait for the data)
             }
+            const unsigned long long e_2 = clk();
             if (d0.valid && d0.ne > 0 && active) {
                 const _Float16 *ap0 = in_e + li * KPE + 8 * lh, *ap1 = ap0 + 32 * KPE;
-                f32x16 acc, acb;
-                if (flag_e[0] == step) lf_mma_2tiles<NKE, true>(ap0, ap1, PLE, Bh, Bl, acc, acb);
-                else lf_mma_2tiles<NKE, false>(ap0, ap1, PLE, Bh, Bl, acc, acb);
+                // The activated rows are kept TIMES the weight scale (Y' = ws * Y, an exact power of two that the per-node sums divide
+                // out again): a chunk whose rows are all exact in fp16 starts its accumulators at ws * c0 and needs no multiply at all.
                 float *yp = ytile + col;
-                if (cok) {
-                    lf_epilogue(acc, comb_e, lh, c0, act_lo, [&](int r, float y) { yp[r * LF_PY] = y; });
-                    lf_epilogue(acb, comb_e + 32, lh, c0, act_lo, [&](int r, float y) { yp[(32 + r) * LF_PY] = y; });
+                const bool nanrows = flag_e[1] == step || w_bad;
+                const bool three = flag_e[0] == step || nanrows;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    if (h == 1 && d0.ne <= 32) break;
+                    const _Float16 *ap = h ? ap1 : ap0;
+                    float *y0 = yp + (32 * h + 4 * lh) * LF_PY;
+                    if (three) {
+                        const f32x16 acc = lf_mma_tile<NKE, true>(ap, PLE, Bh, Bl, 0.f);
+                        if (cok) {
+                            if (nanrows) lf_epilogue<true>(acc, comb_e + 32 * h, lh, c0w, act_lo, [&](int r, float y) { yp[(32 * h + r) * LF_PY] = y; });
+                            else lf_epilogue<false>(acc, comb_e + 32 * h, lh, c0w, act_lo, [&](int r, float y) { yp[(32 * h + r) * LF_PY] = y; });
+                        }
+                    } else {
+                        const f32x16 acc = lf_mma_tile<NKE, false>(ap, PLE, Bh, Bl, c0w);
+                        if (cok) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) y0[((r & 3) + 8 * (r >> 2)) * LF_PY] = __builtin_amdgcn_fmed3f(acc[r], act_lo, INFINITY);
+                        }
+                    }
                 }
             }
             const unsigned long long c_1 = clk();
             lds_barrier();
             const unsigned long long c_2 = clk();
-            // ---------------- beta ----------------
+            // ---------------- phase 2 ----------------
             if (d2.valid) {
                 if (rs_on0) rsrc[rs_b * LF_TE + rs_r] = raw0;
                 if (rs_on1) rsrc[(rs_b + 4) * LF_TE + rs_r] = raw1;
             }
+            const unsigned long long e_3 = clk();
             if (d1.valid && d1.ne > 0) {
-                bool scaled_any = false;
+                bool scaled_any = false, nf_any = false;
 #pragma unroll
                 for (int rr = 0; rr < 2; ++rr) {
                     const int row = r8 + 32 * rr;
                     _Float16 *dst = in_e + row * KPE;
-                    unsigned hi[NCHE][2], lo[NCHE][2], bits = 0;
+                    unsigned hi[NCHE][2], bits = 0;
 #pragma unroll
                     for (int j = 0; j < NCHE; ++j) {
-                        unsigned rb0, rb1;
-                        lf_split2(lf_f2{pf[rr][j].x, pf[rr][j].y}, hi[j][0], lo[j][0], rb0);
-                        lf_split2(lf_f2{pf[rr][j].z, pf[rr][j].w}, hi[j][1], lo[j][1], rb1);
-                        bits |= rb0 | rb1;
+                        unsigned rb0, rb1, lo0, lo1;
+                        lf_split2(lf_f2{pf[rr][j].x, pf[rr][j].y}, hi[j][0], lo0, rb0);
+                        lf_split2(lf_f2{pf[rr][j].z, pf[rr][j].w}, hi[j][1], lo1, rb1);
+                        bits |= (rb0 | rb1) & gmask[j];                   // (columns past k_total hold whatever the clamped address had)
                     }
                     bits = lf_or8(bits);
-                    float comb = inv_w;
+                    float comb = 1.f;
                     if (bits == 0) {                                      // the whole row is exact in fp16: no scale, low plane zero
 #pragma unroll
                         for (int j = 0; j < NCHE; ++j)
-                            if (gwr[j]) {
+                            if (gon[j]) {                                 // (columns k_total .. KE are never written: they stay zero)
                                 *reinterpret_cast<lf_u2 *>(dst + gk[j]) = lf_u2{hi[j][0], hi[j][1]};
                                 *reinterpret_cast<lf_u2 *>(dst + PLE + gk[j]) = lf_u2{0u, 0u};
                             }
                     } else {
-                        comb = lf_split_row_scaled<NCHE>(pf[rr], gwr, dst, PLE, gk) * inv_w;
+                        float4 pz[NCHE];
+#pragma unroll
+                        for (int j = 0; j < NCHE; ++j) pz[j] = gon[j] ? pf[rr][j] : make_float4(0.f, 0.f, 0.f, 0.f);
+                        comb = lf_split_row_scaled<NCHE>(pz, gon, dst, PLE, gk, nf_any);
                         scaled_any = true;
                     }
-                    if (q8 == 0) comb_e[row] = comb;
+                    if (q8 == 0) comb_e[row] = w_bad ? inv_w : comb;
                 }
                 if (scaled_any) flag_e[0] = step + 1;                     // (every writer stores the same value)
+                if (nf_any) flag_e[1] = step + 1;
             }
+            const unsigned long long e_4 = clk();
             if (d0.valid) {
                 // per-node sums of this chunk's activated rows, in row order (deterministic, no atomics): thread -> node r8,
-                // columns 4 (q8 + 8 j); a tile's sums live in the S buffer of its slot parity until group S0 stages them a step later
+                // columns 4 (q8 + 8 j); group S0 stages a finished tile's sums in phase 1 of the next step, before they are overwritten
                 const int *sw = segl + d0.slot * LF_SEGW + r8;
                 int a0 = 0, a1 = 0;
                 if (r8 < d0.nn) { a0 = sw[0]; a1 = sw[1]; }
                 const int lo = (a0 > d0.e0 ? a0 : d0.e0) - d0.e0, hi = (a1 < d0.e0 + LF_TE ? a1 : d0.e0 + LF_TE) - d0.e0;
-                float *sp = sacc + (d0.slot & 1) * (LF_TN * LF_PY) + r8 * LF_PY + 4 * q8;
+                float *sp = sacc + r8 * LF_PY + 4 * q8;
                 float4 v[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -534,6 +578,10 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     for (int j = 0; j < 4; ++j)
                         if (j < njs) { v[j].x += ya[j].x; v[j].y += ya[j].y; v[j].z += ya[j].z; v[j].w += ya[j].w; }
                 }
+                if (d0.last) {                                            // (Y rows carry the weight scale: divide it out once per node)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { v[j].x *= inv_w; v[j].y *= inv_w; v[j].z *= inv_w; v[j].w *= inv_w; }
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (j < njs) *reinterpret_cast<float4 *>(sp + 32 * j) = v[j];
@@ -541,15 +589,18 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             const unsigned long long c_3 = clk();
             lds_barrier();
             const unsigned long long c_4 = clk();
-            tb_valid = ta_valid; tb_m0 = ta_m0; tb_nn = ta_nn;
-            ta_valid = ts_valid; ta_m0 = ts_m0; ta_nn = ts_nn;
+            tm_valid = th_valid; tm_m0 = th_m0; tm_nn = th_nn;
+            th_valid = ts_valid; th_m0 = ts_m0; th_nn = ts_nn;
             ts_valid = d0.valid && d0.last; ts_m0 = d0.m0; ts_nn = d0.nn; ts_slot = d0.slot;
             d0 = d1; d1 = d2; d2 = dn;
             ++step;
-            if (PROF) { const unsigned long long c_5 = clk(); pc[0] += c_1 - c_0; pc[1] += c_2 - c_1; pc[2] += c_3 - c_2; pc[3] += c_4 - c_3; pc[4] += c_5 - c_4; pc[5] += 1; }
+            if (PROF) { const unsigned long long c_5 = clk(); pc[0] += c_1 - c_0; pc[1] += c_2 - c_1; pc[2] += c_3 - c_2; pc[3] += c_4 - c_3; pc[4] += c_5 - c_4; pc[5] += 1;
+                        pe[0] += e_1 - c_0; pe[1] += e_2 - e_1; pe[2] += c_1 - e_2; pe[3] += e_3 - c_2; pe[4] += e_4 - e_3; pe[5] += c_3 - e_4; }
         }
-        if (PROF && prof && lane == 0 && blockIdx.x == 0)
+        if (PROF && prof && lane == 0 && blockIdx.x == 0) {
             for (int q = 0; q < 6; ++q) prof[(tid >> 6) * 6 + q] = pc[q];
+            for (int q = 0; q < 6; ++q) prof[72 + (tid >> 6) * 6 + q] = pe[q];
+        }
         return;
     }
 
@@ -561,7 +612,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const int h1 = a.e.n_out, cs = h1 >> 2, cx = a.d_x >> 2;
         const int njs = cs >> 3, njx = (cx + 1 + 7) >> 3;                 // (h1 is a multiple of 32)
         lf_u4 Bh[NK0], Bl[NK0];
-        lf_weight_planes<NK0>(st, col, cok, lh, bnscale, wscale, h1, a.d_x, Bh, Bl);
+        lf_weight_planes<NK0>(st, col, cok, lh, bnscale, wscale, h1, a.d_x, 1.f, Bh, Bl);
         int koff[NCH0];
         bool wr[NCH0], isx[NJX], isdeg[NJX];
 #pragma unroll
@@ -576,32 +627,15 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         float4 xr[NJX];
 #pragma unroll
         for (int j = 0; j < NJX; ++j) xr[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        while (d0.valid | d1.valid | d2.valid | ts_valid | ta_valid | tb_valid | (step < 0)) {
+        while (d0.valid | d1.valid | d2.valid | ts_valid | th_valid | tm_valid | (step < 0)) {
             const unsigned long long c_0 = clk();
             const LfDesc dn = lf_iter_next(it, lane, segl, seg_writer);
-            // ---------------- alpha ----------------
-            if (ts_valid) {                                               // x rows of the tile staged in this step's beta
-#pragma unroll
-                for (int j = 0; j < NJX; ++j) {
-                    xr[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (j < njx && isx[j] && r8 < ts_nn)
-                        xr[j] = *reinterpret_cast<const float4 *>(a.x + (int64_t)(ts_m0 + r8) * a.d_x + 4 * (q8 + 8 * j));
-                }
-            }
-            if (ta_valid && active) {
-                const f32x16 acc = lf_mma_k2<NK0>(in_n + li * KP0 + 8 * lh, PL0, Bh, Bl);
-                float *hp = htile + col;
-                if (cok) lf_epilogue(acc, comb_n, lh, c0, act_lo, [&](int r, float y) { hp[r * LF_PY] = y; });
-            }
-            const unsigned long long c_1 = clk();
-            lds_barrier();
-            const unsigned long long c_2 = clk();
-            // ---------------- beta ----------------
-            if (ts_valid) {                                               // [S | x | deg] of the tile whose sums group E finished a step ago
+            // ---------------- phase 1 ----------------
+            if (ts_valid) {                                               // [S | x | deg] of the tile whose sums group E finished in the last step
                 const int *sw = segl + ts_slot * LF_SEGW + r8;
                 int a0 = 0, a1 = 0;
                 if (r8 < ts_nn) { a0 = sw[0]; a1 = sw[1]; }
-                const float *sp = sacc + (ts_slot & 1) * (LF_TN * LF_PY) + r8 * LF_PY;
+                const float *sp = sacc + r8 * LF_PY;
                 float4 v[NCH0];
 #pragma unroll
                 for (int j = 0; j < NJS; ++j) {
@@ -611,17 +645,39 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 const float degf = (float)(a1 - a0);
 #pragma unroll
                 for (int j = 0; j < NJX; ++j) {
-                    v[NJS + j] = xr[j];                                    // (zero where this lane has no x chunk)
+                    v[NJS + j] = xr[j];                                    // (loaded a step ago; zero where this lane has no x chunk)
                     if (isdeg[j]) v[NJS + j] = make_float4(degf, 0.f, 0.f, 0.f);
                 }
-                const float inv = lf_split_row_scaled<NCH0>(v, wr, in_n + r8 * KP0, PL0, koff);
+                bool nf = false;
+                const float inv = lf_split_row_scaled<NCH0>(v, wr, in_n + r8 * KP0, PL0, koff, nf);
                 if (q8 == 0) comb_n[r8] = inv * inv_w;
+                if (nf) flag_e[2] = step;
+            }
+            if (d0.valid && d0.last) {                                    // x rows of the tile that completes in this step (staged in the next)
+#pragma unroll
+                for (int j = 0; j < NJX; ++j) {
+                    xr[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (j < njx && isx[j] && r8 < d0.nn)
+                        xr[j] = *reinterpret_cast<const float4 *>(a.x + (int64_t)(d0.m0 + r8) * a.d_x + 4 * (q8 + 8 * j));
+                }
+            }
+            const unsigned long long c_1 = clk();
+            lds_barrier();
+            const unsigned long long c_2 = clk();
+            // ---------------- phase 2 ----------------
+            if (ts_valid && active) {
+                const f32x16 acc = lf_mma_k2<NK0>(in_n + li * KP0 + 8 * lh, PL0, Bh, Bl);
+                float *hp = htile + (step & 1) * (LF_TN * LF_PY) + col;
+                if (cok) {
+                    if (flag_e[2] == step || w_bad) lf_epilogue<true>(acc, comb_n, lh, c0, act_lo, [&](int r, float y) { hp[r * LF_PY] = y; });
+                    else lf_epilogue<false>(acc, comb_n, lh, c0, act_lo, [&](int r, float y) { hp[r * LF_PY] = y; });
+                }
             }
             const unsigned long long c_3 = clk();
             lds_barrier();
             const unsigned long long c_4 = clk();
-            tb_valid = ta_valid; tb_m0 = ta_m0; tb_nn = ta_nn;
-            ta_valid = ts_valid; ta_m0 = ts_m0; ta_nn = ts_nn;
+            tm_valid = th_valid; tm_m0 = th_m0; tm_nn = th_nn;
+            th_valid = ts_valid; th_m0 = ts_m0; th_nn = ts_nn;
             ts_valid = d0.valid && d0.last; ts_m0 = d0.m0; ts_nn = d0.nn; ts_slot = d0.slot;
             d0 = d1; d1 = d2; d2 = dn;
             ++step;
@@ -636,7 +692,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     // group S1
     // =================================================================================================================
     lf_u4 Bh[NK1], Bl[NK1];
-    lf_weight_planes<NK1>(st, col, cok, lh, bnscale, wscale, 0, 0, Bh, Bl);
+    lf_weight_planes<NK1>(st, col, cok, lh, bnscale, wscale, 0, 0, 1.f, Bh, Bl);
     const int njh = a.s0.n_out >> 5;                                      // 32-column groups of H that carry data (n_out multiple of 32)
     int koff[NCH1];
     bool wr[NCH1];
@@ -645,40 +701,44 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     // This group follows the tiles through the record group E publishes every step instead of running the iterator: its
     // only global memory operations are the output stores, and it never waits for them.
     int more = 1;
-    while (more | ta_valid | tb_valid | (step < 0)) {
+    while (more | th_valid | tm_valid | (step < 0)) {
         const unsigned long long c_0 = clk();
-        // ---------------- alpha ----------------
-        if (tb_valid && active) {
+        // ---------------- phase 1 ----------------
+        if (tm_valid && active) {
             const f32x16 acc = lf_mma_k2<NK1>(mid + li * KP1 + 8 * lh, PL1, Bh, Bl);
-            float *op = a.out + (int64_t)tb_m0 * st.n_out + col;          // wave-uniform base + the lane's column
-            const int n_out = st.n_out, nn = tb_nn;
+            float *op = a.out + (int64_t)tm_m0 * st.n_out + col;          // wave-uniform base + the lane's column
+            const int n_out = st.n_out, nn = tm_nn;
             if (cok) {
-                if (nn == LF_TN) lf_epilogue(acc, comb_h, lh, c0, act_lo, [&](int r, float y) { op[r * n_out] = y; });
-                else lf_epilogue(acc, comb_h, lh, c0, act_lo, [&](int r, float y) { if (r < nn) op[r * n_out] = y; });
+                if (flag_e[3] == step || w_bad) lf_epilogue<true>(acc, comb_h, lh, c0, act_lo, [&](int r, float y) { if (r < nn) op[r * n_out] = y; });
+                else if (nn == LF_TN) lf_epilogue<false>(acc, comb_h, lh, c0, act_lo, [&](int r, float y) { op[r * n_out] = y; });
+                else lf_epilogue<false>(acc, comb_h, lh, c0, act_lo, [&](int r, float y) { if (r < nn) op[r * n_out] = y; });
             }
         }
         const unsigned long long c_1 = clk();
         lds_barrier();
         const unsigned long long c_2 = clk();
-        // ---------------- beta ----------------
-        const int nta_valid = __builtin_amdgcn_readfirstlane(pub[0]), nta_m0 = __builtin_amdgcn_readfirstlane(pub[1]);
-        const int nta_nn = __builtin_amdgcn_readfirstlane(pub[2]);
+        // ---------------- phase 2 ----------------
+        const int nts_valid = __builtin_amdgcn_readfirstlane(pub[0]), nts_m0 = __builtin_amdgcn_readfirstlane(pub[1]);
+        const int nts_nn = __builtin_amdgcn_readfirstlane(pub[2]);
         more = __builtin_amdgcn_readfirstlane(pub[3]);
-        if (ta_valid) {                                                   // H of that tile was written in this step's alpha
+        if (th_valid) {                                                   // H of that tile was written in the last step's phase 2
+            const float *hp = htile + ((step - 1) & 1) * (LF_TN * LF_PY) + r8 * LF_PY;
             float4 v[NCH1];
 #pragma unroll
             for (int j = 0; j < NCH1; ++j) {
                 v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (j < njh) v[j] = *reinterpret_cast<const float4 *>(htile + r8 * LF_PY + koff[j]);
+                if (j < njh) v[j] = *reinterpret_cast<const float4 *>(hp + koff[j]);
             }
-            const float inv = lf_split_row_scaled<NCH1>(v, wr, mid + r8 * KP1, PL1, koff);
+            bool nf = false;
+            const float inv = lf_split_row_scaled<NCH1>(v, wr, mid + r8 * KP1, PL1, koff, nf);
             if (q8 == 0) comb_h[r8] = inv * inv_w;
+            if (nf) flag_e[3] = step + 1;
         }
         const unsigned long long c_3 = clk();
         lds_barrier();
         const unsigned long long c_4 = clk();
-        tb_valid = ta_valid; tb_m0 = ta_m0; tb_nn = ta_nn;
-        ta_valid = nta_valid; ta_m0 = nta_m0; ta_nn = nta_nn;
+        tm_valid = th_valid; tm_m0 = th_m0; tm_nn = th_nn;
+        th_valid = nts_valid; th_m0 = nts_m0; th_nn = nts_nn;
         ++step;
         if (PROF) { const unsigned long long c_5 = clk(); pc[0] += c_1 - c_0; pc[1] += c_2 - c_1; pc[2] += c_3 - c_2; pc[3] += c_4 - c_3; pc[4] += c_5 - c_4; pc[5] += 1; }
     }
@@ -690,25 +750,30 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 
 template <int NKE, int NK0, int NK1, bool PROF = false>
 static int lf_launch(const LfArgs &a, hipStream_t st) {
-    constexpr size_t lds = (size_t)2 * LF_TE * (16 * NKE + 8) * 2 + (size_t)LF_TE * LF_PY * 4 + (size_t)2 * LF_TN * LF_PY * 4 +
-                           (size_t)2 * LF_TN * (16 * NK0 + 8) * 2 + (size_t)LF_TN * LF_PY * 4 + (size_t)2 * LF_TN * (16 * NK1 + 8) * 2 +
+    constexpr size_t lds = (size_t)2 * LF_TE * (16 * NKE + 8) * 2 + (size_t)LF_TE * LF_PY * 4 + (size_t)LF_TN * LF_PY * 4 +
+                           (size_t)2 * LF_TN * (16 * NK0 + 8) * 2 + (size_t)2 * LF_TN * LF_PY * 4 + (size_t)2 * LF_TN * (16 * NK1 + 8) * 2 +
                            ((size_t)LF_MAXB * LF_TE + LF_TE + 2 * LF_TN + LF_NSLOT * LF_SEGW + 4 + 12 + 4) * 4;
     static_assert(lds <= 160 * 1024, "LDS budget");
     const void *fn = reinterpret_cast<const void *>(&layer_fused_kernel<NKE, NK0, NK1, PROF>);
-    hipError_t e0 = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   // (per device: set on every launch)
-    if (e0 != hipSuccess) return set_error(GSN_E_HIP, "hipFuncSetAttribute(layer_fused_kernel): %s", hipGetErrorString(e0));
+    static DeviceOnce attr_set;                                        // (the attribute is per device)
+    const int attr_dev = current_device();
+    if (!attr_set.done(attr_dev)) {
+        hipError_t e0 = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e0 != hipSuccess) return set_error(GSN_E_HIP, "hipFuncSetAttribute(layer_fused_kernel): %s", hipGetErrorString(e0));
+        attr_set.mark(attr_dev);
+    }
     int64_t gx = 256;
     { const char *d = getenv("GSN_FUSED_GRID"); if (d && atoi(d) > 0) gx = atoi(d); }
     const int64_t n_tiles = ((int64_t)a.n_nodes + LF_TN - 1) / LF_TN;
     if (gx > n_tiles) gx = n_tiles;
     if (getenv("GSN_CHAIN_TRACE")) fprintf(stderr, "gsn chain: layer_fused_kernel<%d,%d,%d> nodes %d edges %d grid %lld\n", NKE, NK0, NK1, a.n_nodes, a.n_edges, (long long)gx);
     unsigned long long *prof = nullptr;
-    if (PROF) { (void)hipMalloc(&prof, 12 * 6 * 8); (void)hipMemset(prof, 0, 12 * 6 * 8); }
+    if (PROF) { (void)hipMalloc(&prof, 16 * 6 * 8); (void)hipMemset(prof, 0, 16 * 6 * 8); }
     hipLaunchKernelGGL((layer_fused_kernel<NKE, NK0, NK1, PROF>), dim3((unsigned)gx), dim3(768), lds, st, a, prof);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(GSN_E_HIP, "layer_fused_kernel: %s", hipGetErrorString(e));
     if (PROF) {
-        unsigned long long h[12 * 6];
+        unsigned long long h[16 * 6];
         (void)hipDeviceSynchronize();
         (void)hipMemcpy(h, prof, sizeof(h), hipMemcpyDeviceToHost);
         (void)hipFree(prof);
@@ -716,8 +781,13 @@ static int lf_launch(const LfArgs &a, hipStream_t st) {
         if (shown++ % 8 == 7)
             for (int w = 0; w < 12; ++w) {
                 const unsigned long long *o = h + w * 6;
-                if (o[5]) fprintf(stderr, "fusedprof %s%d steps %llu: alpha %llu barrier %llu beta %llu barrier %llu bookkeeping %llu (cycles per step)\n",
+                if (o[5]) fprintf(stderr, "fusedprof %s%d steps %llu: phase1 %llu barrier %llu phase2 %llu barrier %llu bookkeeping %llu (cycles per step)\n",
                                   w < 4 ? "E" : (w < 8 ? "S0-" : "S1-"), w & 3, o[5], o[0] / o[5], o[1] / o[5], o[2] / o[5], o[3] / o[5], o[4] / o[5]);
+                if (w < 4 && o[5]) {
+                    const unsigned long long *e = h + 72 + w * 6;
+                    fprintf(stderr, "fusedprof E%d detail: iterator+publish %llu sources+gathers %llu matrix+epilogue %llu | table %llu split %llu sums %llu\n", w,
+                            e[0] / o[5], e[1] / o[5], e[2] / o[5], e[3] / o[5], e[4] / o[5], e[5] / o[5]);
+                }
             }
     }
     return GSN_OK;

@@ -550,12 +550,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 template <bool STATS, bool VEC4, int D>
 static int launch_linear_bf16_impl(const LinArgs &a, int k_pad, int64_t n_tiles, int col_tiles, hipStream_t st) {
     const size_t lds = ((size_t)12 * BPLANE + (size_t)2 * MAX_BLOCKS * BM) * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_set;
+    const int attr_dev = current_device();
+    if (!attr_set.done(attr_dev)) {
         hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_fwd_bf16_kernel<STATS, VEC4, D>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e0 != hipSuccess) return set_error(GSN_E_HIP, "hipFuncSetAttribute(linear_fwd_bf16_kernel): %s", hipGetErrorString(e0));
-        attr_set = true;
+        attr_set.mark(attr_dev);
     }
     int64_t gx = 256 / col_tiles;   // persistent: one workgroup per CU in total
     if (gx < 1) gx = 1;
@@ -575,12 +576,13 @@ static int launch_linear_bf16(const LinArgs &a, int k_pad, int64_t n_tiles, int 
 
 template <bool STATS, bool WRES>
 static int launch_linear(const LinArgs &a, int k_pad, size_t lds, int64_t gx, int col_tiles, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_set;
+    const int attr_dev = current_device();
+    if (!attr_set.done(attr_dev)) {
         hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_fwd_kernel<STATS, WRES>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e0 != hipSuccess) return set_error(GSN_E_HIP, "hipFuncSetAttribute(linear_fwd_kernel): %s", hipGetErrorString(e0));
-        attr_set = true;
+        attr_set.mark(attr_dev);
     }
     hipLaunchKernelGGL((linear_fwd_kernel<STATS, WRES>), dim3((unsigned)gx, (unsigned)col_tiles), dim3(256), lds, st, a, k_pad);
     hipError_t e = hipGetLastError();

@@ -416,12 +416,13 @@ extern "C" int gsn_csr_build_hip(int64_t n_nodes, int64_t n_edges, const int64_t
         return set_error(GSN_E_UNSUPPORTED, "gsn_csr_build_hip: more than 2^31 edges or vertices");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (n_nodes <= CSR_SMALL_NODES && n_edges <= CSR_SMALL_EDGES) {
-        static bool lds_set = false;
-        if (!lds_set) {   // up to 2 x 48 KiB of dynamic LDS
+        static DeviceOnce lds_set;
+        const int lds_dev = current_device();
+        if (!lds_set.done(lds_dev)) {   // up to 2 x 48 KiB of dynamic LDS
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(&csr_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     2 * (CSR_SMALL_NODES + 1) * (int)sizeof(int32_t)) != hipSuccess)
                 return set_error(GSN_E_HIP, "gsn_csr_build_hip: cannot raise the LDS limit of csr_small_kernel");
-            lds_set = true;
+            lds_set.mark(lds_dev);
         }
         hipLaunchKernelGGL(csr_small_kernel, dim3(1), dim3(1024), (size_t)(2 * (n_nodes + 1)) * sizeof(int32_t), st, index, n_edges,
                            (int)n_nodes, seg_ptr, perm, sorted_target, other, sorted_other);

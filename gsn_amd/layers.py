@@ -34,7 +34,7 @@ from . import _abi
 
 __all__ = ["mlp", "central_encoder", "GSN_sparse", "GSN_edge_sparse", "MPNN_sparse", "MPNN_edge_sparse",
            "GSN_edge_sparse_ogb", "MPNN_edge_sparse_ogb", "build_csr", "propagate", "run_stages", "one_hot_identifiers",
-           "global_add_pool_sparse", "global_mean_pool_sparse", "Codes", "run_linear_module"]
+           "global_add_pool_sparse", "global_mean_pool_sparse", "Codes", "run_linear_module", "invalidate_caches"]
 
 _ACT_CODE = {"identity": 0, "relu": 1, "elu": 2, "tanh": 3}
 _MAX_BLOCKS = 5
@@ -134,7 +134,22 @@ def _dense(v):
 # CSR of the aggregation index (cached per edge_index tensor)
 # ------------------------------------------------------------------------------------------------------------------
 class _CSR:
-    __slots__ = ("seg_ptr", "perm", "deg", "deg4", "tgt", "src")
+    """Target-sorted CSR of one aggregation index.  ``deg`` / ``deg4`` (in-degree as a float column, and the same padded to
+    four columns) are only needed by the multi-launch path of the `general` layers and are built on first use: the one-launch
+    layer kernel takes the degrees from ``seg_ptr`` itself."""
+    __slots__ = ("seg_ptr", "perm", "tgt", "src", "_deg", "_deg4")
+
+    @property
+    def deg(self):
+        if self._deg is None:
+            self._deg = (self.seg_ptr[1:] - self.seg_ptr[:-1]).to(torch.float32).unsqueeze(1).contiguous()
+        return self._deg
+
+    @property
+    def deg4(self):
+        if self._deg4 is None:
+            self._deg4 = torch.nn.functional.pad(self.deg, (0, 3))
+        return self._deg4
 
 
 _CSR_CACHE = {}
@@ -165,35 +180,54 @@ def build_csr(index, n_nodes, with_targets=False, other=None):
     return seg_ptr, perm[:E]
 
 
+def _cache_put(key, owner, value):
+    """_CSR_CACHE entry that disappears with the tensor it belongs to (weak-reference callback), so batches that are
+    dropped do not leave E-sized index tensors behind."""
+    def _gone(_ref, key=key):
+        hit = _CSR_CACHE.get(key)
+        if hit is not None and hit[0] is _ref:
+            del _CSR_CACHE[key]
+    ref = weakref.ref(owner, _gone)
+    _CSR_CACHE[key] = (ref, owner._version, value)
+
+
+def _cache_get(key, owner):
+    hit = _CSR_CACHE.get(key)
+    if hit is not None:
+        ref, version, value = hit
+        if ref() is owner and version == owner._version:
+            return value
+    return None
+
+
 def _csr_for(edge_index, row, n_nodes):
     """CSR of ``edge_index[row]`` cached on the tensor OBJECT (weak reference + version counter): a freed tensor's address
     is reused by the caching allocator, so (data_ptr, shape) alone would return a stale CSR for a different graph of the
     same size (e.g. the 15 SR(25,12,5,6) graphs all have E = 300)."""
     key = (id(edge_index), row, n_nodes)
-    hit = _CSR_CACHE.get(key)
-    if hit is not None:
-        ref, version, csr = hit
-        if ref() is edge_index and version == edge_index._version:
-            return csr
-    if len(_CSR_CACHE) > 64:
-        _CSR_CACHE.clear()
+    c = _cache_get(key, edge_index)
+    if c is not None:
+        return c
     c = _CSR()
     c.seg_ptr, c.perm, c.tgt, c.src = build_csr(edge_index[row], n_nodes, with_targets=True, other=edge_index[1 - row])
-    c.deg = (c.seg_ptr[1:] - c.seg_ptr[:-1]).to(torch.float32).unsqueeze(1).contiguous()
-    # the same column padded to 4 floats per row (zeros): keeps the node chain's input blocks float4-gatherable
-    c.deg4 = torch.nn.functional.pad(c.deg, (0, 3))
-    _CSR_CACHE[key] = (weakref.ref(edge_index), edge_index._version, c)
+    c._deg = c._deg4 = None
+    _cache_put(key, edge_index, c)
     return c
 
 
 def global_add_pool_sparse(x, batch, num_graphs=None):
     """Sum readout (utils_graph_learning.py:23-29: COO [G, N, d] + torch.sparse.sum) as a segmented sum keyed by the
-    ``batch`` vector, on the propagate kernel."""
+    ``batch`` vector, on the propagate kernel.  The (row id, graph id) index pair is cached on the
+    ``batch`` tensor, so repeated readouts of one batch (every layer of a jumping-knowledge model) build its CSR once."""
     _need_cuda(x, "x")
     n_rows = x.shape[0]
     g = int(batch.max().item()) + 1 if num_graphs is None else int(num_graphs)
-    # rows are "edges" whose target is their graph id; the message is the row itself
-    ei = torch.stack([torch.arange(n_rows, device=x.device, dtype=torch.int64), batch.to(torch.int64)], 0)
+    key = (id(batch), "pool", n_rows)
+    ei = _cache_get(key, batch)
+    if ei is None:
+        # rows are "edges" whose target is their graph id; the message is the row itself
+        ei = torch.stack([torch.arange(n_rows, device=x.device, dtype=torch.int64), batch.to(torch.int64)], 0)
+        _cache_put(key, batch, ei)
     return propagate(0, ei, 1, g, b=x)
 
 
@@ -435,6 +469,23 @@ def _chain_fits(stages):
     return bool(_abi.lib().gsn_mlp_chain_supported(n, arr))
 
 
+def invalidate_caches(module=None):
+    """Drop the derived tensors this module keeps per parameter VERSION (folded first weight of the `general` layers,
+    eval-mode BatchNorm scale / shift vectors, transposed weights) -- needed only after writing a parameter or buffer
+    through ``.data`` (``p.data.copy_`` / ``fill_``), which PyTorch does not count as a new version; optimizers,
+    ``load_state_dict`` and ordinary in-place ops do bump the version and need no call.  ``module=None``: also the CSR cache."""
+    if module is None:
+        _CSR_CACHE.clear()
+        return
+    for m in module.modules():
+        for attr in ("_fold_cache", "_gsn_eval_cache", "_gsn_wt"):
+            if hasattr(m, attr):
+                try:
+                    delattr(m, attr)
+                except AttributeError:
+                    pass
+
+
 FUSED_LAYER = os.environ.get("GSN_LAYER_FUSED", "1") != "0"   # one-launch `general` layer (gsn_layer_fused_fwd_hip) where it fits
 
 
@@ -508,6 +559,8 @@ def _bn_resolve(stage, stats_fn, m_rows, training):
         stage.bn_params = None
         return
     if training or bn.running_mean is None:
+        if training and m_rows == 1:
+            raise ValueError("Expected more than 1 value per channel when training, got input size torch.Size([1, %d])" % bn.num_features)
         stats = stats_fn()
         n_out = stats.shape[1]
         dev = stats.device
