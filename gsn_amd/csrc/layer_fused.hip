@@ -10,19 +10,21 @@
 // Work decomposition.  A PyG batch is a disjoint union and the rows of the target-sorted CSR (gsn_csr_build_hip) are
 // node-contiguous, so a workgroup owns a contiguous NODE range and walks it in tiles of <= 32 nodes whose in-edges it
 // processes in chunks of <= 64 rows (the tile takes as many nodes as fit a whole number of chunks: ZINC-shaped graphs give
-// ~31 nodes / 64 edges per tile, one chunk; a hub or a dense graph gives several chunks per tile).  All waves run the same
-// tile iterator over seg_ptr (one 33-entry window load per tile, fetched a tile ahead), so every scheduling decision is a
-// wave-uniform scalar; only group S1, which must never wait for a load behind its output stores, follows a four-word record.
+// ~31 nodes / 64 edges per tile, one chunk; a hub or a dense graph gives several chunks per tile).  Group S0 runs the tile
+// iterator over seg_ptr (one 33-entry window load per tile, fetched a tile ahead) and publishes every chunk descriptor four
+// steps ahead through LDS, so every scheduling decision is a wave-uniform scalar read; group S1, which must never wait for a
+// load behind its output stores, follows a ten-word record per step.
 //
 // Roles (12 waves, 3 per SIMD; a wave keeps ONE stage's weights in registers for the whole kernel).  Every step has two
 // phases with one LDS-only barrier after each, and every group alternates a matrix phase with a staging phase, so that the
 // matrix pipe and the vector pipe are both busy in both phases; every LDS buffer is written in one phase and read in the other
 // (only H, which crosses from phase 2 to the next step's phase 2, is double):
 //                 phase 1                                              phase 2
-//   group E  (waves 0-3)   edge stage of chunk i: IN_E -> Y (fp32)      gathered rows -> planes IN_E of chunk i + 1;  per node, sum of its
-//                          (+ issues the gathers of chunk i + 1)        Y rows in row order -> S (deterministic, no atomics)
-//   group S0 (waves 4-7)   [S | x | deg] of the finished tile -> IN_N    node stage 0: IN_N -> H[i & 1] (fp32)
-//   group S1 (waves 8-11)  node stage 1 of the tile staged last step:   H[(i - 1) & 1] -> planes MID
+//   group E  (waves 0-3)   edge stage of chunk i: IN_E -> Y (fp32)      gathered rows -> planes IN_E of chunk i + 1
+//                          (+ issues the gathers of chunk i + 1)
+//   group S0 (waves 4-7)   tile iterator; [S | x | deg] of the         node stage 0: IN_N -> H[i & 1] (fp32);  per node 0..15 of the
+//                          finished tile -> IN_N                        tile, sum of its Y rows in row order -> S (no atomics)
+//   group S1 (waves 8-11)  node stage 1 of the tile staged last step:   H[(i - 1) & 1] -> planes MID;  the sums of nodes 16..31
 //                          MID -> out rows (global stores)
 //
 // Matrix arithmetic: fp16x3.  Both operands are split into two fp16 planes (x = x_h + x_l, 11 + 11 significant bits, round
@@ -310,6 +312,51 @@ __device__ __forceinline__ void lf_epilogue(const f32x16 &acc, const float *comb
     }
 }
 
+// Per-node sums of a chunk's activated rows (group E left them in Y times its weight scale), in row order: deterministic, no
+// atomics.  256 threads handle 16 nodes (node_base ..): 16 lanes per node, float4 chunks l16 and l16 + 16 of the row.  A tile's
+// sums accumulate in S over its chunks; the last chunk divides the weight scale out.
+__device__ __forceinline__ void lf_node_sums(const float *ytile, float *sacc, const int *seg_win, int node_base, int u, int cs, int nn, int e0,
+                                             bool first, bool last, float inv_w_e) {
+    const int node = node_base + (u >> 4), l16 = u & 15;
+    int a0 = 0, a1 = 0;
+    if (node < nn) { a0 = seg_win[node]; a1 = seg_win[node + 1]; }
+    const int lo = (a0 > e0 ? a0 : e0) - e0, hi = (a1 < e0 + LF_TE ? a1 : e0 + LF_TE) - e0;
+    const bool on0 = l16 < cs, on1 = l16 + 16 < cs;
+    float *sp = sacc + node * LF_PY + 4 * l16;
+    float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+    if (!first) {
+        if (on0) v0 = *reinterpret_cast<const float4 *>(sp);
+        if (on1) v1 = *reinterpret_cast<const float4 *>(sp + 64);
+    }
+    for (int r = lo; r < hi; ++r) {
+        const float *y = ytile + r * LF_PY + 4 * l16;
+        float4 y0 = make_float4(0.f, 0.f, 0.f, 0.f), y1 = y0;
+        if (on0) y0 = *reinterpret_cast<const float4 *>(y);
+        if (on1) y1 = *reinterpret_cast<const float4 *>(y + 64);
+        v0.x += y0.x; v0.y += y0.y; v0.z += y0.z; v0.w += y0.w;
+        v1.x += y1.x; v1.y += y1.y; v1.z += y1.z; v1.w += y1.w;
+    }
+    if (last) {
+        v0.x *= inv_w_e; v0.y *= inv_w_e; v0.z *= inv_w_e; v0.w *= inv_w_e;
+        v1.x *= inv_w_e; v1.y *= inv_w_e; v1.z *= inv_w_e; v1.w *= inv_w_e;
+    }
+    if (on0) *reinterpret_cast<float4 *>(sp) = v0;
+    if (on1) *reinterpret_cast<float4 *>(sp + 64) = v1;
+}
+
+// a chunk descriptor through LDS (group S0 runs the tile iterator and publishes every chunk four steps ahead)
+__device__ __forceinline__ void lf_desc_put(int *ring, const LfDesc &d) {
+    ring[0] = d.valid; ring[1] = d.m0; ring[2] = d.nn; ring[3] = d.e0; ring[4] = d.ne; ring[5] = d.first; ring[6] = d.last; ring[7] = d.slot;
+}
+__device__ __forceinline__ LfDesc lf_desc_get(const int *ring) {
+    LfDesc d;
+    d.valid = __builtin_amdgcn_readfirstlane(ring[0]); d.m0 = __builtin_amdgcn_readfirstlane(ring[1]);
+    d.nn = __builtin_amdgcn_readfirstlane(ring[2]); d.e0 = __builtin_amdgcn_readfirstlane(ring[3]);
+    d.ne = __builtin_amdgcn_readfirstlane(ring[4]); d.first = __builtin_amdgcn_readfirstlane(ring[5]);
+    d.last = __builtin_amdgcn_readfirstlane(ring[6]); d.slot = __builtin_amdgcn_readfirstlane(ring[7]);
+    return d;
+}
+
 template <int NKE, int NK0, int NK1, bool PROF>
 __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void layer_fused_kernel(LfArgs a, unsigned long long *prof) {
     auto clk = [&]() -> unsigned long long {
@@ -349,7 +396,8 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     int *segl = reinterpret_cast<int *>(comb_h + LF_TN);                 // [LF_NSLOT][LF_SEGW] seg_ptr windows of the tiles in flight
     int *flag_e = segl + LF_NSLOT * LF_SEGW;                             // [4]  ordinals of: a chunk with a scaled row; a chunk / node tile / hidden tile with a non-finite row
     unsigned *wmax = reinterpret_cast<unsigned *>(flag_e + 4);           // [12] per-wave weight maxima (prologue)
-    int *pub = reinterpret_cast<int *>(wmax + 12);                        // [4]  tile bookkeeping published to group S1 every step
+    int *pub = reinterpret_cast<int *>(wmax + 12);                        // [12] step record for group S1 (published by group S0 every step)
+    int *dring = pub + 12;                                                // [8][8] chunk descriptors, published four steps ahead
 
     const int tid = threadIdx.x;
     const int grp = __builtin_amdgcn_readfirstlane(tid >> 8);            // 0: E, 1: S0, 2: S1
@@ -369,6 +417,23 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const float bias = (cok && st.bias) ? st.bias[col] : 0.f;
     float bnscale = 1.f, c0 = bias;
     if (cok && st.bn_scale) { bnscale = st.bn_scale[col]; c0 = (bias - st.bn_mean[col]) * bnscale + st.bn_shift[col]; }
+    // ---- node range of this workgroup; group S0 runs the tile iterator (identical in its four waves) and publishes every chunk
+    //      four steps ahead through LDS: chunks 0 and 1 here, before the prologue's barrier
+    LfIter it;
+    it.seg = a.seg_ptr; it.n_nodes = a.n_nodes;
+    it.m_next = (int)((int64_t)a.n_nodes * blockIdx.x / gridDim.x);
+    it.m_end = (int)((int64_t)a.n_nodes * (blockIdx.x + 1) / gridDim.x);
+    it.m0 = 0; it.nn = 0; it.eb = 0; it.ee = 0; it.ec = 0; it.pending = 0; it.slot = 0; it.win = 0;
+    const bool seg_writer = tid >= 256 && tid < 320;
+    LfDesc d3;                                                            // (group S0 only) chunk i + 3
+    d3.valid = 0; d3.m0 = 0; d3.nn = 0; d3.e0 = 0; d3.ne = 0; d3.first = 0; d3.last = 0; d3.slot = 0;
+    LfDesc dc0 = d3;
+    if (grp == 1) {
+        lf_iter_load(it, lane);
+        dc0 = lf_iter_next(it, lane, segl, seg_writer);
+        d3 = lf_iter_next(it, lane, segl, seg_writer);
+        if (tid == 256) { lf_desc_put(dring, dc0); lf_desc_put(dring + 8, d3); }
+    }
     {
         unsigned m = lf_weight_absmax(st, col, cok, bnscale);
 #pragma unroll
@@ -385,20 +450,18 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const bool w_bad = __builtin_amdgcn_readfirstlane((int)(max(max(wmax[4 * grp], wmax[4 * grp + 1]), max(wmax[4 * grp + 2], wmax[4 * grp + 3])) >= 0x7f800000u)) != 0;
     if (w_bad) inv_w = __uint_as_float(0x7fc00000u);
 
-    // ---- node range of this workgroup, tile iterator (identical in every wave of groups E and S0) -----------------------
-    LfIter it;
-    it.seg = a.seg_ptr; it.n_nodes = a.n_nodes;
-    it.m_next = (int)((int64_t)a.n_nodes * blockIdx.x / gridDim.x);
-    it.m_end = (int)((int64_t)a.n_nodes * (blockIdx.x + 1) / gridDim.x);
-    it.m0 = 0; it.nn = 0; it.eb = 0; it.ee = 0; it.ec = 0; it.pending = 0; it.slot = 0;
-    const bool seg_writer = tid < 64;
+    // ---- step bookkeeping (the tile iterator itself lives in group S0, see below) ------------------------------------------
     LfDesc d0, d1, d2;                                                    // chunks i, i+1, i+2 of step i
     d0.valid = 0; d0.m0 = 0; d0.nn = 0; d0.e0 = 0; d0.ne = 0; d0.first = 0; d0.last = 0; d0.slot = 0;
     d1 = d0; d2 = d0;
-    if (grp != 2) {
-        lf_iter_load(it, lane);
-        d2 = lf_iter_next(it, lane, segl, seg_writer);
-    }
+    if (grp == 0) d2 = lf_desc_get(dring);                                // chunk 0 (published before the prologue's barrier)
+    if (grp == 1) d2 = dc0;
+    // the edge stage's weight scale: its activated rows carry it until the per-node sums (groups S0 and S1) divide it out
+    float ws_e_unused, inv_w_e;
+    lf_scale(max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3])), ws_e_unused, inv_w_e);
+    if (max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3])) >= 0x7f800000u) inv_w_e = __uint_as_float(0x7fc00000u);
+    inv_w_e = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(inv_w_e)));
+    const int cs_e = a.e.n_out >> 2;                                       // float4 chunks of an activated row
     // tiles in the node pipeline at step i:  ts: sums complete, group S0 stages it in phase 1 and multiplies it in phase 2 -> H[i & 1];
     // th: its H was written in step i - 1, group S1 splits it in phase 2 -> MID;  tm: MID staged in step i - 1, S1 multiplies it in phase 1
     int ts_valid = 0, ts_m0 = 0, ts_nn = 0, ts_slot = 0;
@@ -444,7 +507,6 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         }
         const bool rs_on0 = rs_b < a.e_nblocks, rs_on1 = rs_b + 4 < a.e_nblocks;
         const int e_last = a.n_edges > 0 ? a.n_edges - 1 : 0;
-        const int njs = a.e.n_out >> 5;                                   // 32-column groups of the activated rows
         const float c0w = c0 * wscale;                                    // the accumulators' start value in a chunk of exact rows
         int raw0 = 0, raw1 = 0;
         float4 pf[2][NCHE];
@@ -454,12 +516,8 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             for (int j = 0; j < NCHE; ++j) pf[rr][j] = make_float4(0.f, 0.f, 0.f, 0.f);
         while (d0.valid | d1.valid | d2.valid | ts_valid | th_valid | tm_valid | (step < 0)) {
             const unsigned long long c_0 = clk();
-            const LfDesc dn = lf_iter_next(it, lane, segl, seg_writer);  // chunk i + 3 (its window arrived a step ago)
+            const LfDesc dn = lf_desc_get(dring + 8 * ((step + 3) & 7));  // chunk i + 3 (group S0 published it a step ago)
             // ---------------- phase 1 ----------------
-            if (tid == 0) {                                               // what group S1 needs to follow the tiles (it never loads seg_ptr:
-                pub[0] = ts_valid; pub[1] = ts_m0; pub[2] = ts_nn;        // a wait for such a load would drain its output stores)
-                pub[3] = d1.valid | (d0.valid && d0.last);
-            }
             const unsigned long long e_1 = clk();
             if (d2.valid && a.n_edges > 0) {                              // row sources of chunk i + 2 (consumed in beta)
                 int er = d2.e0 + (rs_r < d2.ne ? rs_r : (d2.ne > 0 ? d2.ne - 1 : 0));
@@ -552,40 +610,6 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 if (nf_any) flag_e[1] = step + 1;
             }
             const unsigned long long e_4 = clk();
-            if (d0.valid) {
-                // per-node sums of this chunk's activated rows, in row order (deterministic, no atomics): thread -> node r8,
-                // columns 4 (q8 + 8 j); group S0 stages a finished tile's sums in phase 1 of the next step, before they are overwritten
-                const int *sw = segl + d0.slot * LF_SEGW + r8;
-                int a0 = 0, a1 = 0;
-                if (r8 < d0.nn) { a0 = sw[0]; a1 = sw[1]; }
-                const int lo = (a0 > d0.e0 ? a0 : d0.e0) - d0.e0, hi = (a1 < d0.e0 + LF_TE ? a1 : d0.e0 + LF_TE) - d0.e0;
-                float *sp = sacc + r8 * LF_PY + 4 * q8;
-                float4 v[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (!d0.first) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (j < njs) v[j] = *reinterpret_cast<const float4 *>(sp + 32 * j);
-                }
-                for (int r = lo; r < hi; ++r) {
-                    const float *y0 = ytile + r * LF_PY + 4 * q8;
-                    float4 ya[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (j < njs) ya[j] = *reinterpret_cast<const float4 *>(y0 + 32 * j);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (j < njs) { v[j].x += ya[j].x; v[j].y += ya[j].y; v[j].z += ya[j].z; v[j].w += ya[j].w; }
-                }
-                if (d0.last) {                                            // (Y rows carry the weight scale: divide it out once per node)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { v[j].x *= inv_w; v[j].y *= inv_w; v[j].z *= inv_w; v[j].w *= inv_w; }
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (j < njs) *reinterpret_cast<float4 *>(sp + 32 * j) = v[j];
-            }
             const unsigned long long c_3 = clk();
             lds_barrier();
             const unsigned long long c_4 = clk();
@@ -629,9 +653,16 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         for (int j = 0; j < NJX; ++j) xr[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         while (d0.valid | d1.valid | d2.valid | ts_valid | th_valid | tm_valid | (step < 0)) {
             const unsigned long long c_0 = clk();
-            const LfDesc dn = lf_iter_next(it, lane, segl, seg_writer);
+            const LfDesc dn = lf_iter_next(it, lane, segl, seg_writer);  // chunk i + 4 (its window arrived a step ago)
             // ---------------- phase 1 ----------------
-            if (ts_valid) {                                               // [S | x | deg] of the tile whose sums group E finished in the last step
+            if (tid == 256) {
+                lf_desc_put(dring + 8 * ((step + 4) & 7), dn);            // group E reads it at the top of the next step
+                // what group S1 needs to follow the tiles and to sum its half of this chunk's nodes (it never loads seg_ptr: a
+                // wait for such a load would drain its output stores)
+                pub[0] = ts_valid; pub[1] = ts_m0; pub[2] = ts_nn; pub[3] = d1.valid | (d0.valid && d0.last);
+                pub[4] = d0.valid; pub[5] = d0.e0; pub[6] = d0.nn; pub[7] = d0.first; pub[8] = d0.last; pub[9] = d0.slot;
+            }
+            if (ts_valid) {                                               // [S | x | deg] of the tile whose sums were finished in the last step
                 const int *sw = segl + ts_slot * LF_SEGW + r8;
                 int a0 = 0, a1 = 0;
                 if (r8 < ts_nn) { a0 = sw[0]; a1 = sw[1]; }
@@ -673,13 +704,15 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     else lf_epilogue<false>(acc, comb_n, lh, c0, act_lo, [&](int r, float y) { hp[r * LF_PY] = y; });
                 }
             }
+            if (d0.valid)                                                 // nodes 0 .. 15 of this chunk's tile (group S1: 16 .. 31)
+                lf_node_sums(ytile, sacc, segl + d0.slot * LF_SEGW, 0, t, cs_e, d0.nn, d0.e0, d0.first, d0.last, inv_w_e);
             const unsigned long long c_3 = clk();
             lds_barrier();
             const unsigned long long c_4 = clk();
             tm_valid = th_valid; tm_m0 = th_m0; tm_nn = th_nn;
             th_valid = ts_valid; th_m0 = ts_m0; th_nn = ts_nn;
             ts_valid = d0.valid && d0.last; ts_m0 = d0.m0; ts_nn = d0.nn; ts_slot = d0.slot;
-            d0 = d1; d1 = d2; d2 = dn;
+            d0 = d1; d1 = d2; d2 = d3; d3 = dn;
             ++step;
             if (PROF) { const unsigned long long c_5 = clk(); pc[0] += c_1 - c_0; pc[1] += c_2 - c_1; pc[2] += c_3 - c_2; pc[3] += c_4 - c_3; pc[4] += c_5 - c_4; pc[5] += 1; }
         }
@@ -721,6 +754,8 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const int nts_valid = __builtin_amdgcn_readfirstlane(pub[0]), nts_m0 = __builtin_amdgcn_readfirstlane(pub[1]);
         const int nts_nn = __builtin_amdgcn_readfirstlane(pub[2]);
         more = __builtin_amdgcn_readfirstlane(pub[3]);
+        const int c_valid = __builtin_amdgcn_readfirstlane(pub[4]), c_e0 = __builtin_amdgcn_readfirstlane(pub[5]), c_nn = __builtin_amdgcn_readfirstlane(pub[6]);
+        const int c_first = __builtin_amdgcn_readfirstlane(pub[7]), c_last = __builtin_amdgcn_readfirstlane(pub[8]), c_slot = __builtin_amdgcn_readfirstlane(pub[9]);
         if (th_valid) {                                                   // H of that tile was written in the last step's phase 2
             const float *hp = htile + ((step - 1) & 1) * (LF_TN * LF_PY) + r8 * LF_PY;
             float4 v[NCH1];
@@ -734,6 +769,8 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             if (q8 == 0) comb_h[r8] = inv * inv_w;
             if (nf) flag_e[3] = step + 1;
         }
+        if (c_valid)                                                      // nodes 16 .. 31 of this chunk's tile (group S0: 0 .. 15)
+            lf_node_sums(ytile, sacc, segl + c_slot * LF_SEGW, 16, t, cs_e, c_nn, c_e0, c_first != 0, c_last != 0, inv_w_e);
         const unsigned long long c_3 = clk();
         lds_barrier();
         const unsigned long long c_4 = clk();
@@ -752,7 +789,7 @@ template <int NKE, int NK0, int NK1, bool PROF = false>
 static int lf_launch(const LfArgs &a, hipStream_t st) {
     constexpr size_t lds = (size_t)2 * LF_TE * (16 * NKE + 8) * 2 + (size_t)LF_TE * LF_PY * 4 + (size_t)LF_TN * LF_PY * 4 +
                            (size_t)2 * LF_TN * (16 * NK0 + 8) * 2 + (size_t)2 * LF_TN * LF_PY * 4 + (size_t)2 * LF_TN * (16 * NK1 + 8) * 2 +
-                           ((size_t)LF_MAXB * LF_TE + LF_TE + 2 * LF_TN + LF_NSLOT * LF_SEGW + 4 + 12 + 4) * 4;
+                           ((size_t)LF_MAXB * LF_TE + LF_TE + 2 * LF_TN + LF_NSLOT * LF_SEGW + 4 + 12 + 12 + 64) * 4;
     static_assert(lds <= 160 * 1024, "LDS budget");
     const void *fn = reinterpret_cast<const void *>(&layer_fused_kernel<NKE, NK0, NK1, PROF>);
     static DeviceOnce attr_set;                                        // (the attribute is per device)
