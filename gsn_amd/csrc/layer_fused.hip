@@ -509,6 +509,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const int e_last = a.n_edges > 0 ? a.n_edges - 1 : 0;
         const float c0w = c0 * wscale;                                    // the accumulators' start value in a chunk of exact rows
         int raw0 = 0, raw1 = 0;
+        bool lo_dirty[2] = {false, false};                                // (LDS starts zeroed; a thread always stages the same two tile rows)
         float4 pf[2][NCHE];
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr)
@@ -595,9 +596,12 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                         for (int j = 0; j < NCHE; ++j)
                             if (gon[j]) {                                 // (columns k_total .. KE are never written: they stay zero)
                                 *reinterpret_cast<lf_u2 *>(dst + gk[j]) = lf_u2{hi[j][0], hi[j][1]};
-                                *reinterpret_cast<lf_u2 *>(dst + PLE + gk[j]) = lf_u2{0u, 0u};
+                                // the low plane of this row is zero already unless this thread staged a scaled row here last time
+                                if (lo_dirty[rr]) *reinterpret_cast<lf_u2 *>(dst + PLE + gk[j]) = lf_u2{0u, 0u};
                             }
+                        lo_dirty[rr] = false;
                     } else {
+                        lo_dirty[rr] = true;
                         float4 pz[NCHE];
 #pragma unroll
                         for (int j = 0; j < NCHE; ++j) pz[j] = gon[j] ? pf[rr][j] : make_float4(0.f, 0.f, 0.f, 0.f);
