@@ -30,10 +30,11 @@ _PLAN_CACHE = {}
 class CountPlan:
     """Compiled search plans for a list of patterns (built on the host by gsn_count_plan_build, cached per device)."""
 
-    def __init__(self, pattern_edge_lists, mode, induced, directed_orbits=False):
+    def __init__(self, pattern_edge_lists, mode, induced, directed_orbits=False, directed=False):
         self.mode = mode
         self.induced = bool(induced)
         self.directed_orbits = bool(directed_orbits)
+        self.directed = bool(directed)           # digraph patterns and targets (main.py --directed); vertex mode only
         pats = [np.asarray(list(el), dtype=np.int64).reshape(-1, 2) for el in pattern_edge_lists]
         if not pats:
             raise ValueError("no patterns given")
@@ -41,7 +42,8 @@ class CountPlan:
         pat_edges = np.ascontiguousarray(np.concatenate(pats, axis=0))
         L = _abi.lib()
         words, ncols = ctypes.c_int64(), ctypes.c_int64()
-        args = (_MODE[mode], int(self.induced), int(self.directed_orbits), len(pats), _abi.ptr(pat_ptr), _abi.ptr(pat_edges))
+        args = (_MODE[mode], int(self.induced), int(self.directed_orbits) | (2 if self.directed else 0), len(pats),
+                _abi.ptr(pat_ptr), _abi.ptr(pat_edges))
         _abi.check(L.gsn_count_plan_build(*args, None, 0, ctypes.addressof(words), ctypes.addressof(ncols)),
                    "gsn_count_plan_build")
         self.table = np.zeros(words.value, dtype=np.uint32)
@@ -53,11 +55,11 @@ class CountPlan:
         self._dev = {}
 
     @staticmethod
-    def get(pattern_edge_lists, mode, induced, directed_orbits=False):
+    def get(pattern_edge_lists, mode, induced, directed_orbits=False, directed=False):
         key = (tuple(tuple((int(u), int(v)) for u, v in el) for el in pattern_edge_lists), mode, bool(induced),
-               bool(directed_orbits))
+               bool(directed_orbits), bool(directed))
         if key not in _PLAN_CACHE:
-            _PLAN_CACHE[key] = CountPlan(pattern_edge_lists, mode, induced, directed_orbits)
+            _PLAN_CACHE[key] = CountPlan(pattern_edge_lists, mode, induced, directed_orbits, directed)
         return _PLAN_CACHE[key]
 
     def device_table(self, device):
@@ -129,10 +131,10 @@ def count_batch(plan: CountPlan, node_ptr, edge_ptr, edge_index, ids_are_global=
     return out, status
 
 
-def counts2ids_batch(batch, pattern_edge_lists, mode, induced, directed_orbits=False, device=None):
+def counts2ids_batch(batch, pattern_edge_lists, mode, induced, directed_orbits=False, device=None, directed=False):
     """Batched ``subgraph_counts2ids`` over a :class:`gsn_amd.synth.Batch`-like object (node_ptr, edge_ptr, edge_index
     with batch-global ids, self loops already stripped).  -> int64 device tensor [rows_total, sum orbits]."""
-    plan = CountPlan.get(pattern_edge_lists, mode, induced, directed_orbits)
+    plan = CountPlan.get(pattern_edge_lists, mode, induced, directed_orbits, directed)
     out, _ = count_batch(plan, batch.node_ptr, batch.edge_ptr, batch.edge_index, ids_are_global=True, device=device)
     return out
 
@@ -148,6 +150,16 @@ def _pattern_of(subgraph_dict):
     return sg
 
 
+def _directed_of(pats, directed):
+    """The reference builds pattern and target with the same ``directed`` flag (utils_data_gen.py:38, utils_ids.py:23);
+    a pattern analysed under the other flag has other orbits, so a mismatch is refused instead of counted."""
+    directed = bool(directed)
+    for p in pats:
+        if bool(getattr(p, "directed", False)) != directed:
+            raise ValueError("directed=%s, but the pattern %r was analysed with directed=%s" % (directed, p, not directed))
+    return directed
+
+
 def _single_graph(edge_index, num_nodes):
     ei = edge_index if isinstance(edge_index, torch.Tensor) else torch.as_tensor(np.asarray(edge_index))
     ei = ei.to(torch.int64)
@@ -160,12 +172,13 @@ def _single_graph(edge_index, num_nodes):
 
 def subgraph_isomorphism_vertex_counts(edge_index, **kwargs):
     """GSN-v identifiers of one graph and one pattern (utils_graph_processing.py:103-131): CPU float64 tensor
-    [num_nodes, n_orbits], counts[v, o] = number of occurrences containing v at a position of orbit o."""
+    [num_nodes, n_orbits], counts[v, o] = number of occurrences containing v at a position of orbit o.
+    ``directed=True`` (:108-110): the columns of edge_index are arcs and the pattern (from
+    ``automorphism_orbits(..., directed=True)``) is a digraph."""
     subgraph_dict, induced, num_nodes = kwargs["subgraph_dict"], kwargs["induced"], kwargs["num_nodes"]
-    if kwargs.get("directed", False):
-        raise NotImplementedError("directed=True is not supported")
     sg = _pattern_of(subgraph_dict)
-    plan = CountPlan.get([sg.edge_list], "vertex", induced, False)
+    directed = _directed_of([sg], kwargs.get("directed", False))
+    plan = CountPlan.get([sg.edge_list], "vertex", induced, False, directed)
     ei, n, E = _single_graph(edge_index, num_nodes)
     out, _ = count_batch(plan, [0, n], [0, E], ei, ids_are_global=False, max_nodes=n, max_edges=E)
     return out[:int(num_nodes)].cpu().to(torch.float64)
@@ -207,8 +220,6 @@ def subgraph_counts2ids(count_fn, data, subgraph_dicts, subgraph_params):
         setattr(data, "edge_features", data.edge_features[mask])
     edge_index = ei[:, mask]
     num_nodes = data.x.shape[0]
-    if subgraph_params.get("directed", False):
-        raise NotImplementedError("directed=True is not supported")
     name = getattr(count_fn, "__name__", "")
     if name == "subgraph_isomorphism_edge_counts":
         mode = "edge"
@@ -217,8 +228,11 @@ def subgraph_counts2ids(count_fn, data, subgraph_dicts, subgraph_params):
     else:
         raise TypeError("count_fn must be subgraph_isomorphism_vertex_counts or subgraph_isomorphism_edge_counts")
     pats = [_pattern_of(d) for d in subgraph_dicts]
+    directed = _directed_of(pats, subgraph_params.get("directed", False))
+    if directed and mode == "edge":
+        raise NotImplementedError("directed=True is not supported (NameError in the reference, utils_graph_processing.py:164)")
     dirorb = any(p.directed_orbits for p in pats) if mode == "edge" else False
-    plan = CountPlan.get([p.edge_list for p in pats], mode, subgraph_params["induced"], dirorb)
+    plan = CountPlan.get([p.edge_list for p in pats], mode, subgraph_params["induced"], dirorb, directed)
     e_cpu, n, E = _single_graph(edge_index, num_nodes)
     out, _ = count_batch(plan, [0, n], [0, E], e_cpu, ids_are_global=False, max_nodes=n, max_edges=E)
     ids = out[:num_nodes] if mode == "vertex" else out

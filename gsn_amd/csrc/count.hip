@@ -2,7 +2,8 @@
 //
 // One workgroup = one graph.  The graph lives in LDS for the whole kernel:
 //   * adjacency bit matrix A[n][W] (W = ceil(n/64) 64-bit words per row), built from the edge_index columns with
-//     LDS atomic-or (self loops dropped, parallel edges merged -> the simple undirected graph graph-tool matches on),
+//     LDS atomic-or (self loops dropped, parallel edges merged -> the simple undirected graph graph-tool matches on);
+//     directed plans (main.py --directed, vertex mode): A holds the out-neighbour rows and a second matrix the in-neighbour rows,
 //   * edge mode: the column endpoints (u8), a CSR rank  slot(u,v) = rowstart[u] + popcount(A[u] & below(v))  and
 //     last[slot] = highest column holding (u,v)  ("last duplicate wins", utils_graph_processing.py:142-144),
 //   * the packed plan table, a lane-interleaved candidate stack, and (if it fits) a staging copy of the output rows.
@@ -37,9 +38,11 @@ struct CountArgs {
     int off_ball;              // distance-pruning tables (radius 2, radius 3: n_cap rows each) or -1
     int off_core;              // d-cores of the graph, d = 0 .. CORE_MAX (W words each)
     int core_mask;             // bit d: some plan needs the d-core
+    int off_ain;               // directed plans: the in-neighbour bit matrix
+    int stride;                // words per plan (plan_stride)
 };
 
-template <int W, int T>
+template <int W, int T, bool DIR>
 __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t *A = reinterpret_cast<uint64_t *>(smem);
@@ -55,6 +58,7 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
     int *misc = reinterpret_cast<int *>(smem + a.off_misc);  // [0] next task  [1] n_active  [2] status
     uint64_t *balls = a.off_ball >= 0 ? reinterpret_cast<uint64_t *>(smem + a.off_ball) : nullptr;
     uint64_t *cores = reinterpret_cast<uint64_t *>(smem + a.off_core);   // [CORE_MAX + 1][W]
+    uint64_t *A_in = DIR ? reinterpret_cast<uint64_t *>(smem + a.off_ain) : nullptr;
 
     const int tid = threadIdx.x;
     const int item = (int)blockIdx.x / a.split, part = (int)blockIdx.x - item * a.split;
@@ -78,6 +82,8 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
 
     // ---- phase 0: clear LDS state, copy the plan table ------------------------------------------------------------
     for (int i = tid; i < n * W; i += T) A[i] = 0ull;
+    if (DIR)
+        for (int i = tid; i < n * W; i += T) A_in[i] = 0ull;
     for (int i = tid; i < a.plan_words; i += T) plan[i] = a.plan[i];
     if (tid < 4) misc[tid] = 0;
     __syncthreads();
@@ -96,7 +102,7 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
         atomicMax(&misc[1], (u > v ? u : v) + 1);  // graph-tool creates vertices 0..max id, self-loop columns included
         if (u != v) {
             atomicOr(reinterpret_cast<unsigned long long *>(&A[u * W + (v >> 6)]), 1ull << (v & 63));
-            atomicOr(reinterpret_cast<unsigned long long *>(&A[v * W + (u >> 6)]), 1ull << (u & 63));
+            atomicOr(reinterpret_cast<unsigned long long *>(&(DIR ? A_in : A)[v * W + (u >> 6)]), 1ull << (u & 63));
         }
     }
     __syncthreads();
@@ -257,8 +263,9 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
         if (has_task) {
             if (s.l < 0) {
                 if (p_i < p_e) {
-                    lane_valid = cores + plan_core(plans + p_i * PLAN_STRIDE_WORDS) * W;
-                    lane_begin<W>(s, plans + p_i * PLAN_STRIDE_WORDS, roots, A, lane_valid, stack, T, tid);
+                    const uint32_t *pl = plans + p_i * (DIR ? PLAN_STRIDE_DIRECTED : PLAN_STRIDE_WORDS);
+                    lane_valid = cores + plan_core(pl) * W;
+                    lane_begin<W, DIR>(s, pl, roots, A, lane_valid, stack, T, tid, A_in);
                     ++p_i;
                 } else {
                     // cell finished
@@ -272,7 +279,7 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
                     has_task = false;
                 }
             } else {
-                lane_step<W>(s, A, lane_valid, stack, T, tid);
+                lane_step<W, DIR>(s, A, lane_valid, stack, T, tid, A_in);
             }
         }
     }
@@ -293,15 +300,19 @@ __global__ void status_zero_kernel(const int32_t *graph_ids, int n, int32_t *sta
 
 static inline int align_up(int x, int a) { return (x + a - 1) / a * a; }
 
-template <int W, int T>
-static int launch(CountArgs &a, int n_items, size_t lds, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&count_kernel<W, T>),
+template <int W, int T, bool DIR>
+static int launch_d(CountArgs &a, int n_items, size_t lds, hipStream_t stream) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&count_kernel<W, T, DIR>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return set_error(GSN_E_HIP, "hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
-    hipLaunchKernelGGL((count_kernel<W, T>), dim3((unsigned)n_items), dim3(T), lds, stream, a);
+    hipLaunchKernelGGL((count_kernel<W, T, DIR>), dim3((unsigned)n_items), dim3(T), lds, stream, a);
     e = hipGetLastError();
     if (e != hipSuccess) return set_error(GSN_E_HIP, "count_kernel launch: %s", hipGetErrorString(e));
     return GSN_OK;
+}
+template <int W, int T>
+static int launch(CountArgs &a, int n_items, size_t lds, hipStream_t stream) {
+    return a.off_ain >= 0 ? launch_d<W, T, true>(a, n_items, lds, stream) : launch_d<W, T, false>(a, n_items, lds, stream);
 }
 
 }  // namespace gsn
@@ -326,7 +337,10 @@ extern "C" int gsn_count_hip(const uint32_t *plan_host, const uint32_t *plan_dev
     a.plan = plan_dev; a.plan_words = (int)plan_words;
     a.mode = (int)plan_host[1]; a.n_plans = (int)plan_host[3]; a.n_cols = (int)plan_host[4]; a.kmax = (int)plan_host[5];
     a.plans_off = (int)plan_host[7];
-    a.sym = (a.mode == GSN_MODE_EDGE && plan_host[6] == 0) ? 1 : 0;
+    a.sym = (a.mode == GSN_MODE_EDGE && (plan_host[6] & 1u) == 0) ? 1 : 0;
+    const bool directed = (plan_host[6] & 2u) != 0;
+    a.stride = plan_stride(plan_host[6]);
+    if (directed && a.mode != GSN_MODE_VERTEX) return set_error(GSN_E_UNSUPPORTED, "gsn_count_hip: directed plans are vertex-mode plans");
     a.node_ptr = node_ptr; a.edge_ptr = edge_ptr;
     a.src = edge_index; a.dst = edge_index ? edge_index + edge_row_stride : nullptr;
     a.ids_are_global = ids_are_global; a.graph_ids = graph_ids;
@@ -342,6 +356,8 @@ extern "C" int gsn_count_hip(const uint32_t *plan_host, const uint32_t *plan_dev
     a.n_cap = (int)max_nodes; a.e_cap = (int)max_edges;
 
     int o = align_up((int)max_nodes * W * 8, 16);
+    a.off_ain = -1;
+    if (directed) { a.off_ain = o; o += align_up((int)max_nodes * W * 8, 16); }
     a.off_valid = o; o += align_up(W * 8, 16);
     const int depth = a.kmax > 1 ? a.kmax - 1 : 1;
     a.off_stack = o; o += depth * W * T * 8;
@@ -354,11 +370,11 @@ extern "C" int gsn_count_hip(const uint32_t *plan_host, const uint32_t *plan_dev
     a.off_misc = o; o += 16;
     a.off_core = o; o += align_up((CORE_MAX + 1) * W * 8, 16);
     a.core_mask = 0;
-    for (int p = 0; p < a.n_plans; ++p) a.core_mask |= 1 << plan_core(plan_host + a.plans_off + p * PLAN_STRIDE_WORDS);
+    for (int p = 0; p < a.n_plans; ++p) a.core_mask |= 1 << plan_core(plan_host + a.plans_off + p * a.stride);
     // pruning tables only for graphs of <= 64 vertices (molecules): on larger, denser targets the balls are (nearly)
     // everything and the extra AND per step costs more than it saves (measured: ER G(128,1000) +8 %)
     a.off_ball = -1;
-    if (W == 1 && a.kmax >= 4) { a.off_ball = o; o += align_up(2 * (int)max_nodes * W * 8, 16); }
+    if (W == 1 && a.kmax >= 4 && !directed) { a.off_ball = o; o += align_up(2 * (int)max_nodes * W * 8, 16); }
     a.off_out = o;
     const int64_t stage_bytes = rows_cap * a.n_cols * 8;
     // Stage the output rows in LDS (coalesced final write) only while that keeps the workgroup small: the search is

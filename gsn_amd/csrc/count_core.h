@@ -100,9 +100,11 @@ GSN_HD FVec<W> fv_roots(int a, int b) {
 // `valid & ~used` -- the kernel is VALU-issue bound, so the per-step instruction count is what matters.
 // `ball` = j | r<<3 (r = 0: none) with `balls` = the r-hop balls of the target graph, radius 2 at balls[v*W], radius 3 at
 // balls[(ball_n + v)*W] (nullptr: pruning off -- it never changes the result, only the work).
-template <int W>
+// DIR (digraph patterns and targets): A holds the OUT-neighbour rows, A_in the IN-neighbour rows, and desc_in =
+// in_adj_mask | in_nonadj_mask<<8 names the earlier levels whose image the candidate must (not) have an arc TO.
+template <int W, bool DIR = false>
 GSN_HD void candidates(Bits<W> &C, uint32_t desc, uint32_t ball, const FVec<W> &fvec, const Bits<W> &used, const uint64_t *A,
-                       const uint64_t *valid, const uint64_t *balls, int ball_n) {
+                       const uint64_t *valid, const uint64_t *balls, int ball_n, uint32_t desc_in = 0, const uint64_t *A_in = nullptr) {
 #pragma unroll
     for (int w = 0; w < W; ++w) C.w[w] = valid[w] & ~used.w[w];
     if (balls && (ball >> 3)) {
@@ -126,6 +128,24 @@ GSN_HD void candidates(Bits<W> &C, uint32_t desc, uint32_t ball, const FVec<W> &
         const uint64_t *row = A + fv_get<W>(fvec, j) * W;
 #pragma unroll
         for (int w = 0; w < W; ++w) C.w[w] &= ~row[w];
+    }
+    if (DIR) {
+        m = desc_in & 0xffu;
+        while (m) {
+            const int j = ctz64(m);
+            m &= m - 1u;
+            const uint64_t *row = A_in + fv_get<W>(fvec, j) * W;
+#pragma unroll
+            for (int w = 0; w < W; ++w) C.w[w] &= row[w];
+        }
+        m = (desc_in >> 8) & 0xffu;
+        while (m) {
+            const int j = ctz64(m);
+            m &= m - 1u;
+            const uint64_t *row = A_in + fv_get<W>(fvec, j) * W;
+#pragma unroll
+            for (int w = 0; w < W; ++w) C.w[w] &= ~row[w];
+        }
     }
     m = desc >> 16;
     while (m) {
@@ -216,9 +236,9 @@ GSN_HD void frame_load(const uint64_t *stack, int sstride, int tid, int l, Bits<
 }
 
 // Start the rooted search of `plan` with the root levels already in fvec.  May finish immediately (s.l < 0).
-template <int W>
+template <int W, bool DIR = false>
 GSN_HD void lane_begin(Lane<W> &s, const uint32_t *plan, const FVec<W> &fvec_roots, const uint64_t *A, const uint64_t *valid,
-                       uint64_t *stack, int sstride, int tid) {
+                       uint64_t *stack, int sstride, int tid, const uint64_t *A_in = nullptr) {
     const uint32_t h = plan[0];
     s.k = (int)(h & 0xffu);
     s.nfix = (int)((h >> 8) & 0xffu);
@@ -237,7 +257,8 @@ GSN_HD void lane_begin(Lane<W> &s, const uint32_t *plan, const FVec<W> &fvec_roo
     }
     if (s.nfix == s.k) { s.cnt += 1; return; }
     Bits<W> C;
-    candidates<W>(C, plan[2 + s.nfix], plan_ball(plan, s.nfix), s.fvec, s.used, A, valid, s.balls, s.ball_n);
+    candidates<W, DIR>(C, plan[2 + s.nfix], plan_ball(plan, s.nfix), s.fvec, s.used, A, valid, s.balls, s.ball_n,
+                       DIR ? plan[PLAN_STRIDE_WORDS + s.nfix] : 0u, A_in);
     if (s.nfix == s.k - 1) { s.cnt += (uint64_t)popc<W>(C); return; }
     bool cempty = true;
 #pragma unroll
@@ -249,8 +270,9 @@ GSN_HD void lane_begin(Lane<W> &s, const uint32_t *plan, const FVec<W> &fvec_roo
 
 // One search step.  Precondition: s.l >= 0.  Pops one candidate of the current level; at the last-but-one level the
 // whole last level is counted by popcount.  A level that runs empty backtracks in the same step (no wasted iteration).
-template <int W>
-GSN_HD void lane_step(Lane<W> &s, const uint64_t *A, const uint64_t *valid, uint64_t *stack, int sstride, int tid) {
+template <int W, bool DIR = false>
+GSN_HD void lane_step(Lane<W> &s, const uint64_t *A, const uint64_t *valid, uint64_t *stack, int sstride, int tid,
+                      const uint64_t *A_in = nullptr) {
     Bits<W> M;
     frame_load<W>(stack, sstride, tid, s.l, M);
     int v = -1;
@@ -271,7 +293,8 @@ GSN_HD void lane_step(Lane<W> &s, const uint64_t *A, const uint64_t *valid, uint
     Bits<W> used2 = s.used;
     bit_set<W>(used2, v);
     Bits<W> C;
-    candidates<W>(C, s.plan[2 + nl], plan_ball(s.plan, nl), s.fvec, used2, A, valid, s.balls, s.ball_n);
+    candidates<W, DIR>(C, s.plan[2 + nl], plan_ball(s.plan, nl), s.fvec, used2, A, valid, s.balls, s.ball_n,
+                       DIR ? s.plan[PLAN_STRIDE_WORDS + nl] : 0u, A_in);
     bool descend = false;
     if (nl == s.k - 1) {
         s.cnt += (uint64_t)popc<W>(C);

@@ -11,15 +11,19 @@
 namespace gsn {
 
 // packed counting-plan table (uint32 words) -- written by gsn_count_plan_build, read by the kernel
-//   header : [0] magic  [1] mode  [2] induced  [3] n_plans  [4] n_cols  [5] kmax  [6] directed_orbits  [7] plans_off
+//   header : [0] magic  [1] mode  [2] induced  [3] n_plans  [4] n_cols  [5] kmax  [6] directed_orbits | directed<<1  [7] plans_off
 //   col_ptr: [8 .. 8+n_cols]  plans col_ptr[c]..col_ptr[c+1] all write output column c (plans are sorted by column)
-//   plan p : at plans_off + p*PLAN_STRIDE_WORDS: [0] k | n_fixed<<8 | out_col<<16     [1] pattern | root_a<<16 | min_degree<<20 | root_b<<24
+//   plan p : at plans_off + p*plan_stride(header[6]): [0] k | n_fixed<<8 | out_col<<16     [1] pattern | root_a<<16 | min_degree<<20 | root_b<<24
 //            [2+l] level l: adj_mask | nonadj_mask<<8 | gt_mask<<16 | lt_mask<<24   (bit j = earlier level j)
 //            [2+KMAX + l/4] byte l%4: distance constraint of level l:  j | r<<3  (r = 0 none, 2 or 3): the image of level
 //                         l must lie within r hops of the image of level j (r = their distance in the pattern)
 constexpr uint32_t PLAN_MAGIC = 0x47534e31u;  // 'GSN1'
 constexpr int PLAN_HEADER_WORDS = 8;
+//            directed patterns only: [PLAN_STRIDE_WORDS + l] level l: in_adj_mask | in_nonadj_mask<<8 -- the image must (not) be
+//                         an IN-neighbour of f_j (pattern arc level l -> level j); [2+l] then speaks of OUT-neighbours of f_j
 constexpr int PLAN_STRIDE_WORDS = 2 + GSN_KMAX + GSN_KMAX / 4;
+constexpr int PLAN_STRIDE_DIRECTED = PLAN_STRIDE_WORDS + GSN_KMAX;
+inline int plan_stride(uint32_t flags) { return (flags & 2u) ? PLAN_STRIDE_DIRECTED : PLAN_STRIDE_WORDS; }
 
 int set_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 

@@ -358,7 +358,7 @@ __device__ __forceinline__ LfDesc lf_desc_get(const int *ring) {
 }
 
 template <int NKE, int NK0, int NK1, bool PROF>
-__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void layer_fused_kernel(LfArgs a, unsigned long long *prof) {
+__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void layer_fused_kernel(LfArgs a, unsigned long long *prof, int prio) {
     auto clk = [&]() -> unsigned long long {
         if (!PROF) return 0;
         __builtin_amdgcn_sched_barrier(0);
@@ -539,6 +539,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                         pf[rr][j] = *reinterpret_cast<const float4 *>(gbase[j] + (int64_t)sr[rr][j] * gbw[j]);   // row is staged: any use here would wait for the data)
             }
             const unsigned long long e_2 = clk();
+            if (prio) __builtin_amdgcn_s_setprio(2);
             if (d0.valid && d0.ne > 0 && active) {
                 const _Float16 *ap0 = in_e + li * KPE + 8 * lh, *ap1 = ap0 + 32 * KPE;
                 // The activated rows are kept TIMES the weight scale (Y' = ws * Y, an exact power of two that the per-node sums divide
@@ -566,6 +567,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     }
                 }
             }
+            if (prio) __builtin_amdgcn_s_setprio(0);
             const unsigned long long c_1 = clk();
             lds_barrier();
             const unsigned long long c_2 = clk();
@@ -700,6 +702,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             lds_barrier();
             const unsigned long long c_2 = clk();
             // ---------------- phase 2 ----------------
+            if (prio) __builtin_amdgcn_s_setprio(2);
             if (ts_valid && active) {
                 const f32x16 acc = lf_mma_k2<NK0>(in_n + li * KP0 + 8 * lh, PL0, Bh, Bl);
                 float *hp = htile + (step & 1) * (LF_TN * LF_PY) + col;
@@ -708,6 +711,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     else lf_epilogue<false>(acc, comb_n, lh, c0, act_lo, [&](int r, float y) { hp[r * LF_PY] = y; });
                 }
             }
+            if (prio) __builtin_amdgcn_s_setprio(0);
             if (d0.valid)                                                 // nodes 0 .. 15 of this chunk's tile (group S1: 16 .. 31)
                 lf_node_sums(ytile, sacc, segl + d0.slot * LF_SEGW, 0, t, cs_e, d0.nn, d0.e0, d0.first, d0.last, inv_w_e);
             const unsigned long long c_3 = clk();
@@ -741,6 +745,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     while (more | th_valid | tm_valid | (step < 0)) {
         const unsigned long long c_0 = clk();
         // ---------------- phase 1 ----------------
+        if (prio) __builtin_amdgcn_s_setprio(2);
         if (tm_valid && active) {
             const f32x16 acc = lf_mma_k2<NK1>(mid + li * KP1 + 8 * lh, PL1, Bh, Bl);
             float *op = a.out + (int64_t)tm_m0 * st.n_out + col;          // wave-uniform base + the lane's column
@@ -751,6 +756,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 else lf_epilogue<false>(acc, comb_h, lh, c0, act_lo, [&](int r, float y) { if (r < nn) op[r * n_out] = y; });
             }
         }
+        if (prio) __builtin_amdgcn_s_setprio(0);
         const unsigned long long c_1 = clk();
         lds_barrier();
         const unsigned long long c_2 = clk();
@@ -810,7 +816,8 @@ static int lf_launch(const LfArgs &a, hipStream_t st) {
     if (getenv("GSN_CHAIN_TRACE")) fprintf(stderr, "gsn chain: layer_fused_kernel<%d,%d,%d> nodes %d edges %d grid %lld\n", NKE, NK0, NK1, a.n_nodes, a.n_edges, (long long)gx);
     unsigned long long *prof = nullptr;
     if (PROF) { (void)hipMalloc(&prof, 16 * 6 * 8); (void)hipMemset(prof, 0, 16 * 6 * 8); }
-    hipLaunchKernelGGL((layer_fused_kernel<NKE, NK0, NK1, PROF>), dim3((unsigned)gx), dim3(768), lds, st, a, prof);
+    static const int prio = [] { const char *d = getenv("GSN_FUSED_PRIO"); return d ? atoi(d) : 1; }();   // matrix phases at raised wave priority (~1 %)
+    hipLaunchKernelGGL((layer_fused_kernel<NKE, NK0, NK1, PROF>), dim3((unsigned)gx), dim3(768), lds, st, a, prof, prio);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(GSN_E_HIP, "layer_fused_kernel: %s", hipGetErrorString(e));
     if (PROF) {

@@ -22,7 +22,8 @@ namespace gsn {
 
 struct Pattern {
     int k = 0;
-    uint8_t adj[GSN_KMAX] = {0};                 // adj[i] bit j
+    bool directed = false;                       // main.py --directed: the rows of the edge list are arcs
+    uint8_t adj[GSN_KMAX] = {0};                 // adj[i] bit j: edge {i,j} (both rows) or, directed, arc i -> j
     std::vector<std::array<uint8_t, GSN_KMAX>> aut;  // all automorphisms sigma: sigma[i] = image of i
     int vorbit[GSN_KMAX] = {0};
     int n_vorbits = 0;
@@ -32,8 +33,9 @@ struct Pattern {
 };
 
 static bool has(const Pattern &P, int i, int j) { return (P.adj[i] >> j) & 1; }
+static bool linked(const Pattern &P, int i, int j) { return has(P, i, j) || has(P, j, i); }   // adjacent in the underlying graph
 
-// all edge-preserving bijections V(H)->V(H)  (= non-induced self-monomorphisms, which for equal edge counts are automorphisms)
+// all edge- (arc-) preserving bijections V(H)->V(H)  (= non-induced self-monomorphisms, which for equal edge counts are automorphisms)
 static void enum_aut(const Pattern &P, int l, std::array<uint8_t, GSN_KMAX> &sigma, unsigned used,
                      std::vector<std::array<uint8_t, GSN_KMAX>> &out) {
     if (l == P.k) { out.push_back(sigma); return; }
@@ -41,14 +43,17 @@ static void enum_aut(const Pattern &P, int l, std::array<uint8_t, GSN_KMAX> &sig
         if ((used >> v) & 1) continue;
         bool ok = true;
         for (int j = 0; j < l && ok; ++j)
-            if (has(P, l, j) && !has(P, v, sigma[j])) ok = false;
+            if ((has(P, l, j) && !has(P, v, sigma[j])) || (has(P, j, l) && !has(P, sigma[j], v))) ok = false;
         if (!ok) continue;
         sigma[l] = (uint8_t)v;
         enum_aut(P, l + 1, sigma, used | (1u << v), out);
     }
 }
 
-static int analyse(int64_t n_edges, const int64_t *edges, int directed_orbits, Pattern &P) {
+// flags: bit 0 = directed_orbits (edge classes keep the order of the two vertex orbits), bit 1 = directed (digraph pattern)
+static int analyse(int64_t n_edges, const int64_t *edges, int flags, Pattern &P) {
+    const int directed_orbits = flags & 1;
+    P.directed = (flags & 2) != 0;
     int64_t mx = -1;
     for (int64_t i = 0; i < 2 * n_edges; ++i) {
         if (edges[i] < 0) return set_error(GSN_E_INVALID, "pattern vertex id < 0");
@@ -61,7 +66,7 @@ static int analyse(int64_t n_edges, const int64_t *edges, int directed_orbits, P
         int u = (int)edges[2 * i], v = (int)edges[2 * i + 1];
         if (u == v) continue;  // gt.stats.remove_self_loops
         P.adj[u] |= (uint8_t)(1u << v);
-        P.adj[v] |= (uint8_t)(1u << u);
+        if (!P.directed) P.adj[v] |= (uint8_t)(1u << u);
     }
     std::array<uint8_t, GSN_KMAX> sigma{};
     enum_aut(P, 0, sigma, 0, P.aut);
@@ -96,6 +101,7 @@ static int analyse(int64_t n_edges, const int64_t *edges, int directed_orbits, P
 struct Plan {
     int k, n_fixed, out_col, pattern, root_a, root_b, min_degree;
     uint32_t level[GSN_KMAX];
+    uint32_t level_in[GSN_KMAX];     // directed patterns: the constraints through arcs that LEAVE the level's vertex
     uint8_t ball[GSN_KMAX];
 };
 
@@ -109,8 +115,9 @@ static void matching_order(const Pattern &P, const int *fixed, int n_fixed, int 
         for (int v = 0; v < P.k; ++v) {
             if (placed[v]) continue;
             int conn = 0;
-            for (int j = 0; j < l; ++j) conn += has(P, v, order[j]);
-            int deg = __builtin_popcount(P.adj[v]);
+            for (int j = 0; j < l; ++j) conn += linked(P, v, order[j]);
+            int deg = 0;
+            for (int u = 0; u < P.k; ++u) deg += (u != v && linked(P, v, u)) ? 1 : 0;
             if (conn > best_conn || (conn == best_conn && deg > best_deg)) { best = v; best_conn = conn; best_deg = deg; }
         }
         order[l] = best; placed[best] = true;
@@ -156,6 +163,7 @@ static Plan make_plan(const Pattern &P, int pattern_id, const int *fixed, int n_
         for (int u = 0; u < P.k; ++u) dv += (u != v && has(P, v, u)) ? 1 : 0;
         pl.min_degree = std::min(pl.min_degree, dv);
     }
+    if (P.directed) pl.min_degree = 0;   // (core and distance pruning are defined on undirected targets only)
     int order[GSN_KMAX], pos[GSN_KMAX];
     matching_order(P, fixed, n_fixed, order);
     for (int l = 0; l < P.k; ++l) pos[order[l]] = l;
@@ -163,10 +171,17 @@ static Plan make_plan(const Pattern &P, int pattern_id, const int *fixed, int n_
     symmetry_constraints(P, fixed, n_fixed, order, less);
     for (int l = 0; l < P.k; ++l) {
         uint32_t adj = 0, nonadj = 0, gt = 0, lt = 0;
+        // bit j of adj: the image must be an (out-)neighbour of f_j -- pattern edge, or arc order[j] -> order[l]
+        uint32_t adj_in = 0, nonadj_in = 0;
         for (int j = 0; j < l; ++j) {
-            if (has(P, order[l], order[j])) adj |= 1u << j;
+            if (has(P, order[j], order[l])) adj |= 1u << j;
             else if (induced) nonadj |= 1u << j;
+            if (P.directed) {        // arc order[l] -> order[j]: the image must be an in-neighbour of f_j
+                if (has(P, order[l], order[j])) adj_in |= 1u << j;
+                else if (induced) nonadj_in |= 1u << j;
+            }
         }
+        pl.level_in[l] = adj_in | (nonadj_in << 8);
         for (auto &c : less) {
             // f(c.first) < f(c.second)
             if (c.second == order[l] && pos[c.first] < l) gt |= 1u << pos[c.first];   // f_l > f_j
@@ -184,7 +199,7 @@ static Plan make_plan(const Pattern &P, int pattern_id, const int *fixed, int n_
         for (int a = 0; a < P.k; ++a)
             for (int b = 0; b < P.k; ++b) dist[a][b] = std::min(dist[a][b], dist[a][m] + dist[m][b]);
     for (int l = 0; l < GSN_KMAX; ++l) pl.ball[l] = 0;
-    for (int l = n_fixed; l < P.k; ++l) {
+    for (int l = n_fixed; l < P.k && !P.directed; ++l) {
         int best_j = -1, best_r = 99;
         for (int j = 0; j < l; ++j) {
             const int d = dist[order[l]][order[j]];
@@ -316,6 +331,10 @@ extern "C" int gsn_count_plan_build(int mode, int induced, int directed_orbits, 
                                     int64_t *out_n_cols) {
     if (mode != GSN_MODE_VERTEX && mode != GSN_MODE_EDGE) return set_error(GSN_E_INVALID, "mode must be 0 (vertex) or 1 (edge)");
     if (n_patterns <= 0 || !pat_ptr || !pat_edges) return set_error(GSN_E_INVALID, "no patterns");
+    const bool directed = (directed_orbits & 2) != 0;
+    if (directed && mode == GSN_MODE_EDGE)
+        return set_error(GSN_E_UNSUPPORTED, "directed patterns: vertex counts only (the reference's directed edge counter fails on an unbound name, utils_graph_processing.py:146 vs :164)");
+    const int stride = plan_stride((uint32_t)directed_orbits);
     std::vector<Plan> plans;
     int col0 = 0, kmax = 0;
     for (int64_t p = 0; p < n_patterns; ++p) {
@@ -343,13 +362,13 @@ extern "C" int gsn_count_plan_build(int mode, int induced, int directed_orbits, 
     // group the plans of one output column together: a kernel task is (column, row) and runs that column's plans
     std::stable_sort(plans.begin(), plans.end(), [](const Plan &a, const Plan &b) { return a.out_col < b.out_col; });
     const int64_t plans_off = PLAN_HEADER_WORDS + (col0 + 1);
-    int64_t words = plans_off + (int64_t)plans.size() * PLAN_STRIDE_WORDS;
+    int64_t words = plans_off + (int64_t)plans.size() * stride;
     if (out_words) *out_words = words;
     if (out_n_cols) *out_n_cols = col0;
     if (!plan) return GSN_OK;
     if (capacity < words) return set_error(GSN_E_NOSPACE, "plan buffer too small: need %lld words", (long long)words);
     plan[0] = PLAN_MAGIC; plan[1] = (uint32_t)mode; plan[2] = (uint32_t)(induced != 0); plan[3] = (uint32_t)plans.size();
-    plan[4] = (uint32_t)col0; plan[5] = (uint32_t)kmax; plan[6] = (uint32_t)(directed_orbits != 0); plan[7] = (uint32_t)plans_off;
+    plan[4] = (uint32_t)col0; plan[5] = (uint32_t)kmax; plan[6] = (uint32_t)((directed_orbits & 1) | (directed ? 2 : 0)); plan[7] = (uint32_t)plans_off;
     {   // col_ptr[c] .. col_ptr[c+1]: plan indices of column c
         uint32_t *cp = plan + PLAN_HEADER_WORDS;
         size_t i = 0;
@@ -359,13 +378,15 @@ extern "C" int gsn_count_plan_build(int mode, int induced, int directed_orbits, 
         }
     }
     for (size_t i = 0; i < plans.size(); ++i) {
-        uint32_t *w = plan + plans_off + i * PLAN_STRIDE_WORDS;
+        uint32_t *w = plan + plans_off + i * stride;
         const Plan &pl = plans[i];
         w[0] = (uint32_t)pl.k | ((uint32_t)pl.n_fixed << 8) | ((uint32_t)pl.out_col << 16);
         w[1] = (uint32_t)pl.pattern | ((uint32_t)pl.root_a << 16) | ((uint32_t)pl.min_degree << 20) | ((uint32_t)pl.root_b << 24);
         for (int l = 0; l < GSN_KMAX; ++l) w[2 + l] = pl.level[l];
         for (int l = 0; l < GSN_KMAX / 4; ++l) w[2 + GSN_KMAX + l] = 0;
         for (int l = 0; l < GSN_KMAX; ++l) w[2 + GSN_KMAX + l / 4] |= (uint32_t)pl.ball[l] << (8 * (l % 4));
+        if (directed)
+            for (int l = 0; l < GSN_KMAX; ++l) w[PLAN_STRIDE_WORDS + l] = pl.level_in[l];
     }
     return GSN_OK;
 }

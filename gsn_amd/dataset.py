@@ -43,10 +43,12 @@ def prepare_graphs(graphs, subgraph_dicts, subgraph_params, regression, dataset_
 
     Two deviations, both where the reference raises by accident: a zero-edge graph in edge mode gets the empty
     ``[0, sum orbits]`` identifier matrix the reference intends (its line :104 dies on an undefined name), and
-    ``directed=True`` is refused up front."""
+    ``directed=True`` with the EDGE counter is refused up front (NameError in the reference,
+    utils_graph_processing.py:146 vs :164); ``directed=True`` vertex counts treat every column of ``edge_mat`` as an arc."""
     mode = _mode_of(count_fn)
-    if subgraph_params.get("directed", False):
-        raise NotImplementedError("directed=True is not supported")
+    directed = bool(subgraph_params.get("directed", False))
+    if directed and mode == "edge":
+        raise NotImplementedError("directed=True is not supported by the edge counter")
     data_cls = data_cls or gdata.Data
     pats = []
     for d in subgraph_dicts:
@@ -55,7 +57,8 @@ def prepare_graphs(graphs, subgraph_dicts, subgraph_params, regression, dataset_
             raise TypeError("subgraph_dicts must come from gsn_amd's automorphism functions")
         pats.append(sg)
     dirorb = any(p.directed_orbits for p in pats) if mode == "edge" else False
-    plan = counting.CountPlan.get([p.edge_list for p in pats], mode, subgraph_params["induced"], dirorb)
+    directed = counting._directed_of(pats, directed)
+    plan = counting.CountPlan.get([p.edge_list for p in pats], mode, subgraph_params["induced"], dirorb, directed)
 
     span = (0, len(graphs))
     if shard is not None:

@@ -23,19 +23,20 @@ class PatternGraph:
     """Stand-in for the ``gt.Graph`` stored under ``subgraph_dict['subgraph']``: the pattern's edge list plus what
     the counting kernel needs to rebuild its plan (``directed_orbits``).  Picklable (joblib workers)."""
 
-    def __init__(self, edge_list, directed_orbits=False, line_graph_orbits=False):
+    def __init__(self, edge_list, directed_orbits=False, line_graph_orbits=False, directed=False):
         self.edge_list = [(int(u), int(v)) for u, v in edge_list]
         self.directed_orbits = bool(directed_orbits)
+        self.directed = bool(directed)            # gt.Graph(directed=True): the rows of edge_list are arcs
         # produced by edge_automorphism_orbits (the deprecated line-graph variant): its membership dict has one entry per
         # undirected edge, which the reference's edge counter indexes by directed-edge position (see counting.py)
         self.line_graph_orbits = bool(line_graph_orbits)
 
     def get_edges(self):
-        """Simple undirected edges in insertion order, like ``gt.Graph.get_edges()`` after
+        """Simple undirected edges (directed: arcs) in insertion order, like ``gt.Graph.get_edges()`` after
         remove_self_loops / remove_parallel_edges."""
         seen, out = set(), []
         for u, v in self.edge_list:
-            key = (min(u, v), max(u, v))
+            key = (u, v) if getattr(self, "directed", False) else (min(u, v), max(u, v))
             if u != v and key not in seen:
                 seen.add(key)
                 out.append([u, v])
@@ -54,15 +55,16 @@ class PatternGraph:
         return "PatternGraph(%r)" % (self.edge_list,)
 
 
-def analyse(edge_list, directed_orbits=False):
-    """-> dict(k, vertex_orbit[k], n_vertex_orbits, arcs[2m,2], arc_orbit[2m], n_edge_orbits, aut_count)."""
+def analyse(edge_list, directed_orbits=False, directed=False):
+    """-> dict(k, vertex_orbit[k], n_vertex_orbits, arcs[2m,2], arc_orbit[2m], n_edge_orbits, aut_count).
+    ``directed``: the rows of edge_list are arcs (the reference's ``directed=True``, utils_graph_processing.py:14-16)."""
     e = np.ascontiguousarray(np.asarray(list(edge_list), dtype=np.int64).reshape(-1, 2))
     L = _abi.lib()
     k, nvo, na, neo, aut = (ctypes.c_int64() for _ in range(5))
     vorb = np.zeros(8, dtype=np.int64)
     arcs = np.zeros((64, 2), dtype=np.int64)
     aorb = np.zeros(64, dtype=np.int64)
-    rc = L.gsn_pattern_orbits(len(e), _abi.ptr(e), int(bool(directed_orbits)), ctypes.addressof(k), _abi.ptr(vorb),
+    rc = L.gsn_pattern_orbits(len(e), _abi.ptr(e), int(bool(directed_orbits)) | (2 if directed else 0), ctypes.addressof(k), _abi.ptr(vorb),
                               ctypes.addressof(nvo), _abi.ptr(arcs), _abi.ptr(aorb), ctypes.addressof(na),
                               ctypes.addressof(neo), ctypes.addressof(aut))
     _abi.check(rc, "gsn_pattern_orbits")
@@ -74,11 +76,10 @@ def analyse(edge_list, directed_orbits=False):
 def automorphism_orbits(edge_list, print_msgs=True, **kwargs):
     """Vertex automorphism orbits.  Returns ``(graph, orbit_partition, orbit_membership, aut_count)`` exactly as
     utils_graph_processing.py:10-56: ``orbit_membership[v]`` = rank of the smallest vertex of v's orbit,
-    ``orbit_partition[orbit]`` = vertices in ascending order."""
-    if kwargs.get("directed", False):
-        raise NotImplementedError("directed patterns are not supported (the reference's directed edge path is broken "
-                                  "too: utils_graph_processing.py:146 vs :164)")
-    info = analyse(edge_list, False)
+    ``orbit_partition[orbit]`` = vertices in ascending order.  ``directed=True`` (:14): the rows of ``edge_list`` are
+    arcs and the automorphisms are those of the digraph."""
+    directed = bool(kwargs.get("directed", False))
+    info = analyse(edge_list, False, directed)
     orbit_membership = {v: int(info["vertex_orbit"][v]) for v in range(info["k"])}
     orbit_partition = {}
     for v, o in orbit_membership.items():
@@ -87,7 +88,7 @@ def automorphism_orbits(edge_list, print_msgs=True, **kwargs):
         print("Orbit partition of given substructure: {}".format(orbit_partition))
         print("Number of orbits: {}".format(len(orbit_partition)))
         print("Automorphism count: {}".format(info["aut_count"]))
-    return PatternGraph(edge_list, False), orbit_partition, orbit_membership, info["aut_count"]
+    return PatternGraph(edge_list, False, directed=directed), orbit_partition, orbit_membership, info["aut_count"]
 
 
 def induced_edge_automorphism_orbits(edge_list, **kwargs):
@@ -95,7 +96,8 @@ def induced_edge_automorphism_orbits(edge_list, **kwargs):
     aut_count)`` as utils_graph_processing.py:58-100: membership is indexed by position in the pattern's sorted
     bidirectional edge list; orbit ids in first-seen order of {orbit(u), orbit(v)} (ordered iff directed_orbits)."""
     if kwargs.get("directed", False):
-        raise NotImplementedError("directed patterns are not supported")
+        raise NotImplementedError("directed edge orbits feed the reference's directed edge counter, which fails on an unbound "
+                                  "name (utils_graph_processing.py:146 vs :164); directed patterns are vertex-count only")
     directed_orbits = bool(kwargs.get("directed_orbits", False))
     info = analyse(edge_list, directed_orbits)
     edge_orbit_partition, edge_orbit_membership = {}, {}

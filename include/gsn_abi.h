@@ -58,10 +58,15 @@ int gsn_device_count(void);
  * induced_edge_automorphism_orbits (:58-100): vertex orbits of Aut(H) numbered by rank of the orbit's smallest
  * vertex; the pattern's directed edges sorted by (u,v); edge-orbit ids in first-seen order of the key
  * {orbit(u),orbit(v)} (ordered pair iff directed_orbits); |Aut(H)|.
+ *   directed_orbits  bit 0 (GSN_FLAG_DIRECTED_ORBITS): the reference's `directed_orbits`;  bit 1 (GSN_FLAG_DIRECTED): the
+ *                    reference's `directed` (main.py:558, utils_graph_processing.py:14-16) -- every row (u,v) of `edges` is the
+ *                    ARC u -> v, automorphisms preserve arcs, out_arcs lists the arcs themselves
  *   edges            [n_edges][2] int64, vertices 0..k-1; self loops / duplicates are dropped like the reference does
  *   out_vertex_orbit [GSN_KMAX]
  *   out_arcs         [k*(k-1)][2]  sorted directed edge list;  out_arc_orbit [k*(k-1)]
  * ---------------------------------------------------------------------------------------------------------------- */
+#define GSN_FLAG_DIRECTED_ORBITS 1
+#define GSN_FLAG_DIRECTED 2
 int gsn_pattern_orbits(int64_t n_edges, const int64_t *edges, int directed_orbits, int64_t *out_k,
                        int64_t *out_vertex_orbit, int64_t *out_n_vertex_orbits, int64_t *out_arcs,
                        int64_t *out_arc_orbit, int64_t *out_n_arcs, int64_t *out_n_edge_orbits,
@@ -84,6 +89,10 @@ int gsn_graph_vertex_orbits(int64_t n_vertices, int64_t n_edges, const int64_t *
  * utils_data_gen.py:31-42) into the packed table the kernel executes: one rooted search per (pattern, vertex orbit)
  * [vertex mode] or per (pattern, directed-edge orbit) [edge mode], with symmetry-breaking order constraints for the
  * root's stabiliser.  Output columns follow utils_ids.py:19-25: patterns in the given order, orbit ids ascending.
+ *   directed_orbits  flag bits as for gsn_pattern_orbits.  GSN_FLAG_DIRECTED (vertex mode only; edge mode ->
+ *           GSN_E_UNSUPPORTED, the reference's directed edge counter dies on an unbound name, utils_graph_processing.py:146 vs
+ *           :164): patterns AND the graphs later counted with this plan are digraphs (gt.Graph(directed=True), :108-113) -- a
+ *           column (u,v) of edge_index is the arc u -> v, matches preserve arcs and, induced, non-arcs in each direction
  *   pat_ptr [n_patterns+1] into pat_edges [.][2]
  *   plan    caller buffer of `capacity` uint32 words (call with plan=NULL to get *out_words)
  * ---------------------------------------------------------------------------------------------------------------- */

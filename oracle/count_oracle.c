@@ -34,11 +34,13 @@
 typedef struct {
     int n;          /* vertices 0..n-1 (n = max id + 1 over all columns, as gt.Graph.add_edge_list does) */
     int words;      /* 64-bit words per adjacency row */
-    uint64_t *adj;  /* n * words */
+    uint64_t *adj;  /* n * words; bit v of row u = edge {u,v} (undirected: both rows) or arc u -> v (directed) */
+    int directed;   /* gt.Graph(directed=...) -- main.py --directed (utils_graph_processing.py:14-16 / :108-110) */
 } or_graph;
 
 static int or_graph_init(or_graph *g, int n) {
     g->n = n;
+    g->directed = 0;
     g->words = (n + 63) / 64;
     if (g->words == 0) g->words = 1;
     g->adj = (uint64_t *)calloc((size_t)(n > 0 ? n : 1) * g->words, sizeof(uint64_t));
@@ -48,19 +50,22 @@ static void or_graph_free(or_graph *g) { free(g->adj); g->adj = NULL; }
 static inline void or_set(or_graph *g, int u, int v) { g->adj[(size_t)u * g->words + (v >> 6)] |= 1ull << (v & 63); }
 static inline int or_has(const or_graph *g, int u, int v) { return (int)((g->adj[(size_t)u * g->words + (v >> 6)] >> (v & 63)) & 1); }
 
-/* simple undirected graph from an edge list: self loops dropped, parallel edges merged
- * (utils_graph_processing.py:16-19 / :110-113 / :150-153) */
-static int or_build(or_graph *g, const int64_t *src, const int64_t *dst, int64_t m) {
+/* simple graph from an edge list: self loops dropped, parallel edges merged
+ * (utils_graph_processing.py:16-19 / :110-113 / :150-153); directed: every row (u, v) is the arc u -> v and only
+ * repeated arcs of the same direction are parallel */
+static int or_build_d(or_graph *g, const int64_t *src, const int64_t *dst, int64_t m, int directed) {
     int64_t mx = -1;
     for (int64_t i = 0; i < m; ++i) { if (src[i] > mx) mx = src[i]; if (dst[i] > mx) mx = dst[i]; }
     if (or_graph_init(g, (int)(mx + 1))) return -1;
+    g->directed = directed;
     for (int64_t i = 0; i < m; ++i) {
         if (src[i] == dst[i]) continue;
         or_set(g, (int)src[i], (int)dst[i]);
-        or_set(g, (int)dst[i], (int)src[i]);
+        if (!directed) or_set(g, (int)dst[i], (int)src[i]);
     }
     return 0;
 }
+static int or_build(or_graph *g, const int64_t *src, const int64_t *dst, int64_t m) { return or_build_d(g, src, dst, m, 0); }
 
 /* ---- generic "all maps" enumerator: pattern vertices assigned in order 0..k-1 ------------------ */
 typedef void (*or_visit)(const int *f, void *ctx);
@@ -83,6 +88,11 @@ static int or_feasible(const or_enum *e, int l, int v) {
         int he = or_has(e->H, p, q), ge = or_has(e->G, v, e->f[q]);
         if (he && !ge) return 0;               /* pattern edge must be a target edge            */
         if (e->induced && !he && ge) return 0; /* induced: pattern non-edge must be a non-edge  */
+        if (e->H->directed) {                  /* digraphs: the same two rules for the arc q -> p */
+            he = or_has(e->H, q, p); ge = or_has(e->G, e->f[q], v);
+            if (he && !ge) return 0;
+            if (e->induced && !he && ge) return 0;
+        }
     }
     return 1;
 }
@@ -92,7 +102,7 @@ static void or_rec(or_enum *e, int l) {
     int p = e->order[l];
     /* candidate generation: neighbours of the image of an already-matched pattern neighbour, else all */
     int anchor = -1;
-    for (int j = 0; j < l; ++j) if (or_has(e->H, p, e->order[j])) { anchor = e->f[e->order[j]]; break; }
+    for (int j = 0; j < l; ++j) if (or_has(e->H, e->order[j], p)) { anchor = e->f[e->order[j]]; break; }   /* (arc q -> p: out-neighbours of f(q)) */
     if (anchor >= 0) {
         const uint64_t *row = e->G->adj + (size_t)anchor * e->G->words;
         for (int w = 0; w < e->G->words; ++w) {
@@ -126,7 +136,7 @@ static int64_t or_enumerate(const or_graph *H, const or_graph *G, int induced, o
         int pick = -1;
         for (int p = 0; p < H->n && pick < 0; ++p) {
             if (placed[p]) continue;
-            for (int j = 0; j < l; ++j) if (or_has(H, p, e.order[j])) { pick = p; break; }
+            for (int j = 0; j < l; ++j) if (or_has(H, p, e.order[j]) || or_has(H, e.order[j], p)) { pick = p; break; }
         }
         if (pick < 0) for (int p = 0; p < H->n; ++p) if (!placed[p]) { pick = p; break; }
         e.order[l] = pick; placed[pick] = 1;
@@ -151,12 +161,12 @@ static void or_orbit_visit(const int *f, void *ctx_) {
 
 /* out_membership[k]: contiguous orbit id per pattern vertex (np.unique(..., return_inverse), :40);
  * returns k (number of pattern vertices) or <0 */
-int oracle_automorphism_orbits(const int64_t *edges /* [m][2] */, int64_t m, int64_t *out_membership,
-                               int64_t *out_n_orbits, int64_t *out_aut_count) {
+static int or_automorphism_orbits(const int64_t *edges /* [m][2] */, int64_t m, int directed, int64_t *out_membership,
+                                  int64_t *out_n_orbits, int64_t *out_aut_count) {
     or_graph H;
     int64_t *s = (int64_t *)malloc(sizeof(int64_t) * (size_t)(m ? m : 1)), *d = (int64_t *)malloc(sizeof(int64_t) * (size_t)(m ? m : 1));
     for (int64_t i = 0; i < m; ++i) { s[i] = edges[2 * i]; d[i] = edges[2 * i + 1]; }
-    if (or_build(&H, s, d, m)) { free(s); free(d); return -1; }
+    if (or_build_d(&H, s, d, m, directed)) { free(s); free(d); return -1; }
     free(s); free(d);
     if (H.n > OR_KMAX) { or_graph_free(&H); return -2; }
     or_orbit_ctx c; c.k = H.n;
@@ -183,6 +193,13 @@ int oracle_automorphism_orbits(const int64_t *edges /* [m][2] */, int64_t m, int
     int k = H.n;
     or_graph_free(&H);
     return k;
+}
+int oracle_automorphism_orbits(const int64_t *edges, int64_t m, int64_t *out_membership, int64_t *out_n_orbits, int64_t *out_aut_count) {
+    return or_automorphism_orbits(edges, m, 0, out_membership, out_n_orbits, out_aut_count);
+}
+/* directed=True (:14): the pattern is the digraph whose arcs are the rows of edge_list */
+int oracle_automorphism_orbits_directed(const int64_t *edges, int64_t m, int64_t *out_membership, int64_t *out_n_orbits, int64_t *out_aut_count) {
+    return or_automorphism_orbits(edges, m, 1, out_membership, out_n_orbits, out_aut_count);
 }
 
 /* sorted bidirectional edge list of the simple pattern graph: to_undirected(get_edges()) = concat both
@@ -234,16 +251,16 @@ static void or_vc_visit(const int *f, void *ctx_) {
 
 /* edge_index given as two int64 rows (src[E], dst[E]); out [num_nodes][n_orbits] int64.
  * returns 0, or <0 on error (-3: a count is not divisible by aut_count -> restatement bug) */
-int oracle_vertex_counts(const int64_t *src, const int64_t *dst, int64_t E, int64_t num_nodes,
-                         const int64_t *pat_edges, int64_t pat_m, int induced, int64_t *out, int64_t out_stride) {
+static int or_vertex_counts(const int64_t *src, const int64_t *dst, int64_t E, int64_t num_nodes, const int64_t *pat_edges,
+                            int64_t pat_m, int induced, int directed, int64_t *out, int64_t out_stride) {
     int64_t memb[OR_KMAX], n_orb, aut;
-    int k = oracle_automorphism_orbits(pat_edges, pat_m, memb, &n_orb, &aut);
+    int k = or_automorphism_orbits(pat_edges, pat_m, directed, memb, &n_orb, &aut);
     if (k < 0) return k;
     or_graph H, G;
     int64_t *s = (int64_t *)malloc(sizeof(int64_t) * (size_t)(pat_m ? pat_m : 1)), *d = (int64_t *)malloc(sizeof(int64_t) * (size_t)(pat_m ? pat_m : 1));
     for (int64_t i = 0; i < pat_m; ++i) { s[i] = pat_edges[2 * i]; d[i] = pat_edges[2 * i + 1]; }
-    or_build(&H, s, d, pat_m); free(s); free(d);
-    or_build(&G, src, dst, E);                                                       /* :110-113 */
+    or_build_d(&H, s, d, pat_m, directed); free(s); free(d);
+    or_build_d(&G, src, dst, E, directed);                                           /* :110-113 */
     int64_t rows = num_nodes > G.n ? num_nodes : G.n;
     int64_t *cnt = (int64_t *)calloc((size_t)(rows ? rows : 1) * n_orb, sizeof(int64_t)); /* :122 */
     or_vc_ctx c; c.k = k; c.n_orb = (int)n_orb; c.memb = memb; c.counts = cnt;
@@ -257,6 +274,15 @@ int oracle_vertex_counts(const int64_t *src, const int64_t *dst, int64_t E, int6
         }
     free(cnt); or_graph_free(&H); or_graph_free(&G);
     return rc;
+}
+int oracle_vertex_counts(const int64_t *src, const int64_t *dst, int64_t E, int64_t num_nodes,
+                         const int64_t *pat_edges, int64_t pat_m, int induced, int64_t *out, int64_t out_stride) {
+    return or_vertex_counts(src, dst, E, num_nodes, pat_edges, pat_m, induced, 0, out, out_stride);
+}
+/* directed=True (:108): pattern and target are digraphs; a match preserves arcs (induced: and non-arcs, per direction) */
+int oracle_vertex_counts_directed(const int64_t *src, const int64_t *dst, int64_t E, int64_t num_nodes,
+                                  const int64_t *pat_edges, int64_t pat_m, int induced, int64_t *out, int64_t out_stride) {
+    return or_vertex_counts(src, dst, E, num_nodes, pat_edges, pat_m, induced, 1, out, out_stride);
 }
 
 /* ---- edge counts (utils_graph_processing.py:134-179) --------------------------------------------- */
@@ -319,13 +345,18 @@ int oracle_counts2ids(int mode /*0 vertex, 1 edge*/, int induced, int directed_o
                       const int64_t *node_ptr, const int64_t *edge_ptr, const int64_t *src, const int64_t *dst,
                       int64_t n_patterns, const int64_t *pat_ptr, const int64_t *pat_edges,
                       int64_t *out, int64_t cols_total, int n_threads) {
+    /* bit 1 of directed_orbits = main.py --directed (digraph patterns and targets; vertex mode only: the reference's
+     * directed edge counter dies on an unbound name, utils_graph_processing.py:146 vs :164) */
+    const int directed = (directed_orbits >> 1) & 1;
+    directed_orbits &= 1;
+    if (directed && mode != 0) return -6;
     int64_t *col_off = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n_patterns + 1));
     col_off[0] = 0;
     for (int64_t p = 0; p < n_patterns; ++p) {
         int64_t n_orb, aut;
         const int64_t *pe = pat_edges + 2 * pat_ptr[p];
         int64_t pm = pat_ptr[p + 1] - pat_ptr[p];
-        if (mode == 0) { int64_t memb[OR_KMAX]; if (oracle_automorphism_orbits(pe, pm, memb, &n_orb, &aut) < 0) { free(col_off); return -2; } }
+        if (mode == 0) { int64_t memb[OR_KMAX]; if (or_automorphism_orbits(pe, pm, directed, memb, &n_orb, &aut) < 0) { free(col_off); return -2; } }
         else { int64_t arcs[2 * OR_KMAX * OR_KMAX], am[OR_KMAX * OR_KMAX]; if (oracle_induced_edge_orbits(pe, pm, directed_orbits, arcs, am, &n_orb, &aut) < 0) { free(col_off); return -2; } }
         col_off[p + 1] = col_off[p] + n_orb;
     }
@@ -343,8 +374,8 @@ int oracle_counts2ids(int mode /*0 vertex, 1 edge*/, int induced, int directed_o
             int64_t pm = pat_ptr[p + 1] - pat_ptr[p];
             int rc;
             if (mode == 0)
-                rc = oracle_vertex_counts(src + e0, dst + e0, E, nn, pe, pm, induced,
-                                          out + node_ptr[g] * cols_total + col_off[p], cols_total);
+                rc = or_vertex_counts(src + e0, dst + e0, E, nn, pe, pm, induced, directed,
+                                      out + node_ptr[g] * cols_total + col_off[p], cols_total);
             else
                 rc = oracle_edge_counts(src + e0, dst + e0, E, pe, pm, induced, directed_orbits,
                                         out + e0 * cols_total + col_off[p], cols_total);

@@ -1020,6 +1020,62 @@ def gen_model(ref, out):
     print("model: %d arrays" % len(rec))
 
 
+def gen_directed(ref, out):
+    """directed=True (main.py --directed): patterns and targets are digraphs, vertex counts only (the reference's directed edge
+    counter dies on an unbound name, utils_graph_processing.py:146 vs :164).  automorphism_orbits(directed=True) +
+    subgraph_isomorphism_vertex_counts(directed=True) of the reference over networkx's DiGraphMatcher."""
+    import io
+    import contextlib
+    ugp = ref["utils_graph_processing"]
+    rec = {"names": []}
+    pats = [[(0, 1), (1, 2), (2, 0)], [(0, 1), (0, 2), (1, 2)], [(0, 1), (1, 2)], [(0, 1), (1, 0), (1, 2)], [(0, 1), (0, 2), (0, 3)],
+            [(1, 0), (2, 0), (3, 0)], [(0, 1), (1, 2), (2, 3), (3, 0)], [(0, 1), (1, 2), (2, 3), (0, 3)], list(nx.cycle_graph(4).edges),
+            list(nx.complete_graph(4).edges), [(0, 1), (1, 0), (1, 2), (2, 1)], [(0, 1), (1, 2), (2, 3), (3, 4), (4, 0)],
+            [(0, 1), (1, 2), (2, 0), (2, 3), (3, 4)], list(nx.path_graph(5).edges)]
+    rng = np.random.default_rng(5)
+
+    def digraph(n, m, loops=0, dups=0):
+        src = rng.integers(0, n, size=m); dst = rng.integers(0, n, size=m)
+        keep = src != dst
+        ei = np.stack([src[keep], dst[keep]]).astype(np.int64)
+        if dups:
+            ei = np.concatenate([ei, ei[:, :dups]], axis=1)
+        if loops:
+            lv = rng.integers(0, n, size=loops)
+            ei = np.concatenate([ei[:, :3], np.stack([lv, lv]), ei[:, 3:]], axis=1)
+        return n, ei
+    zb = synth.zinc_shape_batch(4, seed=3)
+    graphs = [digraph(10, 30), digraph(16, 70), digraph(24, 110, loops=3, dups=5), digraph(40, 90), zb.graph(0), zb.graph(1),
+              (7, np.zeros((2, 0), dtype=np.int64))]
+    nn = [10, 16, 24, 43, graphs[4][0], graphs[5][0], 7]
+    # orbits of the directed patterns
+    for pi, el in enumerate(pats):
+        with contextlib.redirect_stdout(io.StringIO()):
+            _, part, memb, aut = ugp.automorphism_orbits(edge_list=el, print_msgs=False, directed=True, directed_orbits=False)
+        rec["pattern/%d/edges" % pi] = np.asarray(el, dtype=np.int64).reshape(-1, 2)
+        rec["pattern/%d/v_membership" % pi] = np.asarray([memb[v] for v in range(len(memb))], dtype=np.int64)
+        rec["pattern/%d/aut_count" % pi] = np.int64(aut)
+    rec["n_patterns"] = np.int64(len(pats))
+    for induced in (False, True):
+        dicts = []
+        with contextlib.redirect_stdout(io.StringIO()):
+            for el in pats:
+                sg, part, memb, aut = ugp.automorphism_orbits(edge_list=el, print_msgs=False, directed=True, directed_orbits=False)
+                dicts.append({"subgraph": sg, "orbit_partition": part, "orbit_membership": memb, "aut_count": aut})
+        outs = []
+        for gi, (n, ei) in enumerate(graphs):
+            ids = None
+            for d in dicts:
+                c = ugp.subgraph_isomorphism_vertex_counts(torch.from_numpy(ei), subgraph_dict=d, induced=induced, num_nodes=nn[gi], directed=True)
+                ids = c if ids is None else torch.cat((ids, c), 1)
+            outs.append(ids.long().numpy())
+        name = "digraphs_%s_vertex" % ("induced" if induced else "mono")
+        save_case(rec, name, graphs, pats, "vertex", induced, outs, num_nodes=nn)
+    rec["names"] = np.asarray(rec["names"])
+    np.savez_compressed(os.path.join(out, "counts_directed.npz"), **rec)
+    print("directed: %d cases, %d patterns" % (len(rec["names"]), len(pats)))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="orbits,counts,layers")
@@ -1037,6 +1093,8 @@ def main():
         gen_dataset(ref, args.out)
     if "model" in only:
         gen_model(ref, args.out)
+    if "directed" in only:
+        gen_directed(ref, args.out)
 
 
 if __name__ == "__main__":

@@ -24,12 +24,20 @@ def pattern_lists(z, case):
     return [flat[ptr[i]:ptr[i + 1]].tolist() for i in range(len(ptr) - 1)]
 
 
-def count_case(case):
-    z = load("counts")
+def count_case(case, fixture="counts"):
+    z = load(fixture)
     return dict(
         node_ptr=z[case + "/node_ptr"], edge_ptr=z[case + "/edge_ptr"], edge_index_local=z[case + "/edge_index_local"],
         patterns=pattern_lists(z, case), mode=str(z[case + "/mode"]), induced=bool(z[case + "/induced"]),
         directed_orbits=bool(z[case + "/directed_orbits"]), counts=z[case + "/counts"])
+
+
+def directed_patterns():
+    """[(edge list, vertex membership, aut_count)] of the digraph patterns in counts_directed.npz (reference:
+    automorphism_orbits(directed=True))."""
+    z = load("counts_directed")
+    return [(z["pattern/%d/edges" % i].tolist(), z["pattern/%d/v_membership" % i].tolist(), int(z["pattern/%d/aut_count" % i]))
+            for i in range(int(z["n_patterns"]))]
 
 
 def layer_case(case):

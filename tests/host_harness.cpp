@@ -19,9 +19,11 @@ int set_error(int code, const char *fmt, ...) {
 }
 using namespace gsn;
 
-template <int W>
+template <int W, bool DIR>
 static int run(const uint32_t *plan, int64_t n, int64_t E, const int64_t *src, const int64_t *dst, int64_t *out) {
     const int mode = (int)plan[1], n_cols = (int)plan[4], kmax = (int)plan[5], plans_off = (int)plan[7];
+    const int stride = plan_stride(plan[6]);
+    std::vector<uint64_t> A_in(DIR ? (size_t)(n ? n : 1) * W : 1, 0);
     const uint32_t *col_ptr = plan + PLAN_HEADER_WORDS, *plans = plan + plans_off;
     std::vector<uint64_t> A((size_t)(n ? n : 1) * W, 0), stack((size_t)kmax * W, 0);
     int n_active = 0;
@@ -30,7 +32,7 @@ static int run(const uint32_t *plan, int64_t n, int64_t E, const int64_t *src, c
         n_active = std::max(n_active, std::max(u, v) + 1);
         if (u == v) continue;
         A[(size_t)u * W + (v >> 6)] |= 1ull << (v & 63);
-        A[(size_t)v * W + (u >> 6)] |= 1ull << (u & 63);
+        (DIR ? A_in : A)[(size_t)v * W + (u >> 6)] |= 1ull << (u & 63);
     }
     uint64_t valid[W];
     for (int w = 0; w < W; ++w) valid[w] = below_word(n_active, w);
@@ -38,7 +40,7 @@ static int run(const uint32_t *plan, int64_t n, int64_t E, const int64_t *src, c
     std::vector<uint64_t> balls((size_t)2 * nb * W, 0);           // radius 2, then radius 3
     for (int v = 0; v < (int)n; ++v) ball_expand<W>(A.data(), nullptr, v, balls.data());
     for (int v = 0; v < (int)n; ++v) ball_expand<W>(A.data(), balls.data(), v, balls.data() + (size_t)nb * W);
-    const bool prune = getenv("GSN_HARNESS_NO_PRUNE") == nullptr;
+    const bool prune = getenv("GSN_HARNESS_NO_PRUNE") == nullptr && !DIR;
     // d-cores, d = 0 .. CORE_MAX (plan_core): candidate universe of a plan
     std::vector<uint64_t> cores((size_t)(CORE_MAX + 1) * W, 0);
     for (int d = 0; d <= CORE_MAX; ++d) {
@@ -72,9 +74,9 @@ static int run(const uint32_t *plan, int64_t n, int64_t E, const int64_t *src, c
             }
             if (live)
                 for (uint32_t p = col_ptr[col]; p < col_ptr[col + 1]; ++p) {
-                    const uint64_t *pv = cores.data() + (size_t)plan_core(plans + p * PLAN_STRIDE_WORDS) * W;
-                    lane_begin<W>(s, plans + p * PLAN_STRIDE_WORDS, roots, A.data(), pv, stack.data(), 1, 0);
-                    while (s.l >= 0) lane_step<W>(s, A.data(), pv, stack.data(), 1, 0);
+                    const uint64_t *pv = cores.data() + (size_t)plan_core(plans + p * stride) * W;
+                    lane_begin<W, DIR>(s, plans + p * stride, roots, A.data(), pv, stack.data(), 1, 0, A_in.data());
+                    while (s.l >= 0) lane_step<W, DIR>(s, A.data(), pv, stack.data(), 1, 0, A_in.data());
                 }
             out[row * n_cols + col] = (int64_t)s.cnt;
             if (rev_missing && s.cnt) status = 1;
@@ -82,11 +84,16 @@ static int run(const uint32_t *plan, int64_t n, int64_t E, const int64_t *src, c
     return status;
 }
 
-extern "C" int harness_count(const uint32_t *plan, int64_t n, int64_t E, const int64_t *src, const int64_t *dst, int64_t *out) {
-    if (n <= 64) return run<1>(plan, n, E, src, dst, out);
-    if (n <= 128) return run<2>(plan, n, E, src, dst, out);
-    if (n <= 256) return run<4>(plan, n, E, src, dst, out);
-    if (n <= 512) return run<8>(plan, n, E, src, dst, out);
-    if (n <= 768) return run<12>(plan, n, E, src, dst, out);
+template <bool DIR>
+static int run_w(const uint32_t *plan, int64_t n, int64_t E, const int64_t *src, const int64_t *dst, int64_t *out) {
+    if (n <= 64) return run<1, DIR>(plan, n, E, src, dst, out);
+    if (n <= 128) return run<2, DIR>(plan, n, E, src, dst, out);
+    if (n <= 256) return run<4, DIR>(plan, n, E, src, dst, out);
+    if (n <= 512) return run<8, DIR>(plan, n, E, src, dst, out);
+    if (n <= 768) return run<12, DIR>(plan, n, E, src, dst, out);
     return -1;
+}
+
+extern "C" int harness_count(const uint32_t *plan, int64_t n, int64_t E, const int64_t *src, const int64_t *dst, int64_t *out) {
+    return (plan[6] & 2u) ? run_w<true>(plan, n, E, src, dst, out) : run_w<false>(plan, n, E, src, dst, out);
 }

@@ -139,6 +139,42 @@ def test_plans_and_search_core_on_host(lib, harness, name):
     assert np.array_equal(got, c["counts"])
 
 
+def test_directed_patterns_orbits_and_search_core_on_host(lib, harness):
+    """directed=True: gsn_pattern_orbits with GSN_FLAG_DIRECTED against the reference's orbits, and the directed plans + the
+    DIR search core on the host against the reference's directed vertex counts."""
+    from gsn_amd import patterns
+    from gsn_amd.counting import CountPlan
+    from helpers import directed_patterns
+    for el, memb, aut in directed_patterns():
+        g, part, om, a = patterns.automorphism_orbits(edge_list=el, print_msgs=False, directed=True)
+        assert [om[v] for v in range(len(memb))] == memb and a == aut and g.directed
+        assert {o: sorted(vs) for o, vs in part.items()} == {o: [v for v in range(len(memb)) if memb[v] == o] for o in set(memb)}
+    I64P, U32P = ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_uint32)
+    for name in case_names("counts_directed"):
+        c = count_case(name, "counts_directed")
+        plan = CountPlan(c["patterns"], "vertex", c["induced"], False, directed=True)
+        assert int(plan.table[6]) == 2
+        npt, ept, ei = c["node_ptr"], c["edge_ptr"], c["edge_index_local"]
+        outs = []
+        for g in range(len(npt) - 1):
+            n, E = int(npt[g + 1] - npt[g]), int(ept[g + 1] - ept[g])
+            src = np.ascontiguousarray(ei[0, ept[g]:ept[g + 1]])
+            dst = np.ascontiguousarray(ei[1, ept[g]:ept[g + 1]])
+            out = np.zeros((n, plan.n_cols), dtype=np.int64)
+            st = harness.harness_count(plan.table.ctypes.data_as(U32P), ctypes.c_int64(n), ctypes.c_int64(E),
+                                       src.ctypes.data_as(I64P), dst.ctypes.data_as(I64P), out.ctypes.data_as(I64P))
+            assert st == 0
+            outs.append(out)
+        assert np.array_equal(np.concatenate(outs, axis=0), c["counts"])
+    with pytest.raises(RuntimeError):                      # the reference's directed edge counter is broken: refused
+        CountPlan([[(0, 1), (1, 2)]], "edge", False, False, directed=True)
+    # an undirected pattern handed to a directed count (or the reverse) is refused, not silently mis-counted
+    from gsn_amd import counting
+    g_und = patterns.PatternGraph([(0, 1), (1, 2)])
+    with pytest.raises(ValueError):
+        counting._directed_of([g_und], True)
+
+
 def test_no_cpu_fallback(lib):
     if torch.cuda.is_available():
         pytest.skip("GPU present")

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import load, case_names, count_case, layer_case
+from helpers import load, case_names, count_case, layer_case, directed_patterns
 from oracle import oracle
 
 
@@ -29,6 +29,20 @@ def test_counts(name):
                             directed_orbits=c["directed_orbits"], n_threads=4)
     assert got.shape == c["counts"].shape
     assert np.array_equal(got, c["counts"])
+
+
+def test_directed_orbits_and_counts():
+    """directed=True (main.py --directed): digraph patterns and targets, vertex counts (counts_directed.npz = the reference's
+    automorphism_orbits / subgraph_isomorphism_vertex_counts with directed=True over networkx's DiGraphMatcher)."""
+    for el, memb, aut in directed_patterns():
+        m, n_orb, a = oracle.automorphism_orbits(el, directed=True)
+        assert m.tolist() == memb and a == aut and n_orb == len(set(memb))
+    for name in case_names("counts_directed"):
+        c = count_case(name, "counts_directed")
+        got = oracle.counts2ids("vertex", c["induced"], c["node_ptr"], c["edge_ptr"], c["edge_index_local"], c["patterns"], directed=True)
+        assert np.array_equal(got, c["counts"]) and got.sum() > 0
+    with pytest.raises(NotImplementedError):
+        oracle.counts2ids("edge", False, [0, 3], [0, 2], np.array([[0, 1], [1, 2]]), [[(0, 1), (1, 2)]], directed=True)
 
 
 def test_srg_closed_forms():
