@@ -80,9 +80,20 @@ struct LfArgs {
     float *out;                             // [n_nodes][s1.n_out]
 };
 
-struct LfDesc {                             // one chunk of one tile; every field wave-uniform
-    int valid, m0, nn, e0, ne, first, last, slot;
+// One chunk of one tile; every field wave-uniform.  Packed into three words (the descriptors of four chunks in flight, the
+// three tiles of the node pipeline and the iterator all live in scalar registers: unpacked they spill into vector lanes).
+struct LfDesc {
+    int m0, e0, pk;                         // pk: valid | first << 1 | last << 2 | slot << 3 | nn << 6 | ne << 12
+    __device__ __forceinline__ int valid() const { return pk & 1; }
+    __device__ __forceinline__ int first() const { return (pk >> 1) & 1; }
+    __device__ __forceinline__ int last() const { return (pk >> 2) & 1; }
+    __device__ __forceinline__ int slot() const { return (pk >> 3) & 7; }
+    __device__ __forceinline__ int nn() const { return (pk >> 6) & 63; }
+    __device__ __forceinline__ int ne() const { return (pk >> 12) & 127; }
+    __device__ __forceinline__ int completes() const { return (pk & 5) == 5; }        // valid && last: the tile's sums are finished in this step
 };
+__device__ __forceinline__ LfDesc lf_desc_none() { LfDesc d; d.m0 = 0; d.e0 = 0; d.pk = 0; return d; }
+static_assert(LF_TN < 64 && LF_TE < 128 && LF_NSLOT <= 8, "descriptor field widths");
 
 struct LfIter {
     const int32_t *seg;
@@ -99,8 +110,7 @@ __device__ __forceinline__ void lf_iter_load(LfIter &it, int lane) {
 
 // next chunk in node order; forms a new tile from the prefetched window when the current one is exhausted
 __device__ __forceinline__ LfDesc lf_iter_next(LfIter &it, int lane, int *segl, bool writer) {
-    LfDesc d;
-    d.valid = 0; d.m0 = 0; d.nn = 0; d.e0 = 0; d.ne = 0; d.first = 0; d.last = 0; d.slot = 0;
+    LfDesc d = lf_desc_none();
     if (!(it.pending || it.ec < it.ee)) {
         if (it.m_next >= it.m_end) return d;
         int nmax = it.m_end - it.m_next;
@@ -122,10 +132,10 @@ __device__ __forceinline__ LfDesc lf_iter_next(LfIter &it, int lane, int *segl, 
         it.m_next += nn;
         lf_iter_load(it, lane);
     }
-    d.valid = 1; d.m0 = it.m0; d.nn = it.nn; d.e0 = it.ec;
+    d.m0 = it.m0; d.e0 = it.ec;
     const int left = it.ee - it.ec;
-    d.ne = left < LF_TE ? left : LF_TE;
-    d.first = it.ec == it.eb; d.last = it.ec + LF_TE >= it.ee; d.slot = it.slot;
+    const int ne = left < LF_TE ? left : LF_TE;
+    d.pk = 1 | ((it.ec == it.eb) << 1) | ((it.ec + LF_TE >= it.ee) << 2) | (it.slot << 3) | (it.nn << 6) | (ne << 12);
     it.ec += LF_TE; it.pending = 0;
     return d;
 }
@@ -243,22 +253,24 @@ __device__ __forceinline__ f32x16 lf_mma_k2(const _Float16 *ap, int plane, const
     f32x16 acc, acb;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acb[r] = 0.f; }
-    lf_u4 ha[2], la[2], hb[2], lb[2];
+    // The low-plane fragments feed ONE product each, issued first: their registers are reloaded for the next k-step right after
+    // it (the five other products of the step cover the LDS latency); only the high-plane fragments are double-buffered.
+    lf_u4 ha[2], hb[2], la, lb;
     ha[0] = *reinterpret_cast<const lf_u4 *>(ap);
-    la[0] = *reinterpret_cast<const lf_u4 *>(ap + plane);
+    la = *reinterpret_cast<const lf_u4 *>(ap + plane);
     hb[0] = *reinterpret_cast<const lf_u4 *>(ap + 16 * H);
-    lb[0] = *reinterpret_cast<const lf_u4 *>(ap + plane + 16 * H);
+    lb = *reinterpret_cast<const lf_u4 *>(ap + plane + 16 * H);
 #pragma unroll
     for (int s = 0; s < H; ++s) {
         const int c = s & 1, n = c ^ 1;
+        LF_MF(la, Bh[s]);
+        acb = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, lb), __builtin_bit_cast(f16x8, Bh[s + H]), acb, 0, 0, 0);
         if (s + 1 < H) {
+            la = *reinterpret_cast<const lf_u4 *>(ap + plane + 16 * (s + 1));
+            lb = *reinterpret_cast<const lf_u4 *>(ap + plane + 16 * (s + 1 + H));
             ha[n] = *reinterpret_cast<const lf_u4 *>(ap + 16 * (s + 1));
-            la[n] = *reinterpret_cast<const lf_u4 *>(ap + plane + 16 * (s + 1));
             hb[n] = *reinterpret_cast<const lf_u4 *>(ap + 16 * (s + 1 + H));
-            lb[n] = *reinterpret_cast<const lf_u4 *>(ap + plane + 16 * (s + 1 + H));
         }
-        LF_MF(la[c], Bh[s]);
-        acb = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, lb[c]), __builtin_bit_cast(f16x8, Bh[s + H]), acb, 0, 0, 0);
         LF_MF(ha[c], Bl[s]);
         acb = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, hb[c]), __builtin_bit_cast(f16x8, Bl[s + H]), acb, 0, 0, 0);
         LF_MF(ha[c], Bh[s]);
@@ -293,8 +305,8 @@ __device__ __forceinline__ f32x16 lf_mma_tile(const _Float16 *ap, int plane, con
     return acc;
 }
 
-// epilogue of a 32 x 32 accumulator tile: y = max(acc * comb[row] + c0, lo) for this lane's 16 rows; f(r, y) with r the row
-// inside the 32-row tile.  comb: this tile's 32 inverse scales (LDS).  NANROWS (tiles whose stager met a non-finite value,
+// epilogue of a 32 x 32 accumulator tile: y = max(acc * comb[row] + c0, lo) for this lane's 16 rows; f(g, r, y) for row
+// 4 lh + 8 g + r of the 32-row tile.  comb: this tile's 32 inverse scales (LDS).  NANROWS (tiles whose stager met a non-finite value,
 // rare): rows whose inverse scale is NaN come out as NaN -- the plain max would drop the NaN (IEEE maxNum semantics).
 template <bool NANROWS, typename F>
 __device__ __forceinline__ void lf_epilogue(const f32x16 &acc, const float *comb, int lh, float c0, float lo, F f) {
@@ -307,7 +319,7 @@ __device__ __forceinline__ void lf_epilogue(const f32x16 &acc, const float *comb
         for (int r = 0; r < 4; ++r) {
             float y = __builtin_amdgcn_fmed3f(fmaf(acc[4 * g + r], cv[r], c0), lo, INFINITY);   // = max(., lo)
             if (NANROWS) y = cv[r] != cv[r] ? cv[r] : y;
-            f(4 * lh + 8 * g + r, y);
+            f(g, r, y);
         }
     }
 }
@@ -315,8 +327,10 @@ __device__ __forceinline__ void lf_epilogue(const f32x16 &acc, const float *comb
 // Per-node sums of a chunk's activated rows (group E left them in Y times its weight scale), in row order: deterministic, no
 // atomics.  256 threads handle 16 nodes (node_base ..): 16 lanes per node, float4 chunks l16 and l16 + 16 of the row.  A tile's
 // sums accumulate in S over its chunks; the last chunk divides the weight scale out.
-__device__ __forceinline__ void lf_node_sums(const float *ytile, float *sacc, const int *seg_win, int node_base, int u, int cs, int nn, int e0,
+template <int WG>
+__device__ __forceinline__ void lf_node_sums(const float *ytile, float *sacc, const int *seg_win, int node_base, int u, int cs_rt, int nn, int e0,
                                              bool first, bool last, float inv_w_e) {
+    const int cs = WG ? 8 * WG : cs_rt;
     const int node = node_base + (u >> 4), l16 = u & 15;
     int a0 = 0, a1 = 0;
     if (node < nn) { a0 = seg_win[node]; a1 = seg_win[node + 1]; }
@@ -346,18 +360,18 @@ __device__ __forceinline__ void lf_node_sums(const float *ytile, float *sacc, co
 
 // a chunk descriptor through LDS (group S0 runs the tile iterator and publishes every chunk four steps ahead)
 __device__ __forceinline__ void lf_desc_put(int *ring, const LfDesc &d) {
-    ring[0] = d.valid; ring[1] = d.m0; ring[2] = d.nn; ring[3] = d.e0; ring[4] = d.ne; ring[5] = d.first; ring[6] = d.last; ring[7] = d.slot;
+    *reinterpret_cast<int4 *>(ring) = make_int4(d.m0, d.e0, d.pk, 0);
 }
 __device__ __forceinline__ LfDesc lf_desc_get(const int *ring) {
+    const int4 v = *reinterpret_cast<const int4 *>(ring);
     LfDesc d;
-    d.valid = __builtin_amdgcn_readfirstlane(ring[0]); d.m0 = __builtin_amdgcn_readfirstlane(ring[1]);
-    d.nn = __builtin_amdgcn_readfirstlane(ring[2]); d.e0 = __builtin_amdgcn_readfirstlane(ring[3]);
-    d.ne = __builtin_amdgcn_readfirstlane(ring[4]); d.first = __builtin_amdgcn_readfirstlane(ring[5]);
-    d.last = __builtin_amdgcn_readfirstlane(ring[6]); d.slot = __builtin_amdgcn_readfirstlane(ring[7]);
+    d.m0 = __builtin_amdgcn_readfirstlane(v.x); d.e0 = __builtin_amdgcn_readfirstlane(v.y); d.pk = __builtin_amdgcn_readfirstlane(v.z);
     return d;
 }
 
-template <int NKE, int NK0, int NK1, bool PROF>
+// WG > 0: all three widths (edge stage, node stage 0, node stage 1) are 32 WG, known at compile time -- the shape of every
+// reference configuration (d = 64, 128); WG = 0: widths read from the arguments (any multiple of 32 / 4).
+template <int NKE, int NK0, int NK1, int WG, bool PROF>
 __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void layer_fused_kernel(LfArgs a, unsigned long long *prof, int prio) {
     auto clk = [&]() -> unsigned long long {
         if (!PROF) return 0;
@@ -367,21 +381,23 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         return v;
     };
     unsigned long long pc[6] = {0, 0, 0, 0, 0, 0};     // phase-1 work, barrier 1, phase-2 work, barrier 2, bookkeeping, steps
-    unsigned long long pe[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // group E only: iterator + publish, row sources + gathers, matrix + epilogue | row-source table, split, sums
+    unsigned long long pe[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // per-group detail, see lf_launch
     constexpr int KE = 16 * NKE, KPE = KE + 8, PLE = LF_TE * KPE;        // halfs
     constexpr int K0 = 16 * NK0, KP0 = K0 + 8, PL0 = LF_TN * KP0;
     constexpr int K1 = 16 * NK1, KP1 = K1 + 8, PL1 = LF_TN * KP1;
     constexpr int NCHE = (KE / 4 + 7) / 8;                               // float4 chunks per stager thread and row
     constexpr int NCH1 = K1 / 32;
-    constexpr int NJS = 4, NJX = LF_NXJ, NCH0 = NJS + NJX;               // node rows: <= 4 chunks of S and <= LF_NXJ of [x | deg] per thread
+    constexpr int NJS = WG ? WG : 4, NJX = LF_NXJ, NCH0 = NJS + NJX;     // node rows: <= 4 chunks of S and <= LF_NXJ of [x | deg] per thread
     static_assert(K1 % 32 == 0, "stage-1 input planes in whole 32-column groups");
+    static_assert(WG == 0 || (2 * WG == NK1 && 2 * WG < NK0), "compile-time widths: K1 = 32 WG, K0 > 32 WG");
     constexpr int OFF_INE = 0, SZ_INE = 2 * PLE * 2;
     constexpr int OFF_Y = OFF_INE + SZ_INE, SZ_Y = LF_TE * LF_PY * 4;
     constexpr int OFF_SACC = OFF_Y + SZ_Y, SZ_SACC = LF_TN * LF_PY * 4;       // per-node sums of the tile being reduced
     constexpr int OFF_INN = OFF_SACC + SZ_SACC, SZ_INN = 2 * PL0 * 2;
     constexpr int OFF_H = OFF_INN + SZ_INN, SZ_H = 2 * LF_TN * LF_PY * 4;       // hidden rows of two tiles (step parity)
     constexpr int OFF_MID = OFF_H + SZ_H, SZ_MID = 2 * PL1 * 2;
-    constexpr int OFF_TAB = OFF_MID + SZ_MID;
+    constexpr int OFF_XR = OFF_MID + SZ_MID, SZ_XR = LF_NXJ * LF_TN * 32 * 4;  // raw x rows of the tile whose sums complete in this step
+    constexpr int OFF_TAB = OFF_XR + SZ_XR;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     _Float16 *in_e = reinterpret_cast<_Float16 *>(smem + OFF_INE);
     float *ytile = reinterpret_cast<float *>(smem + OFF_Y);
@@ -389,6 +405,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     _Float16 *in_n = reinterpret_cast<_Float16 *>(smem + OFF_INN);
     float *htile = reinterpret_cast<float *>(smem + OFF_H);
     _Float16 *mid = reinterpret_cast<_Float16 *>(smem + OFF_MID);
+    float *xrl = reinterpret_cast<float *>(smem + OFF_XR);                // [LF_NXJ][LF_TN][32]: chunk q8 + 8 j of row r8 at ((j * LF_TN + r8) * 8 + q8) * 4
     int *rsrc = reinterpret_cast<int *>(smem + OFF_TAB);                 // [LF_MAXB][LF_TE]
     float *comb_e = reinterpret_cast<float *>(rsrc + LF_MAXB * LF_TE);   // [LF_TE]  inverse row scale x inverse weight scale
     float *comb_n = comb_e + LF_TE;                                      // [LF_TN]
@@ -396,8 +413,11 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     int *segl = reinterpret_cast<int *>(comb_h + LF_TN);                 // [LF_NSLOT][LF_SEGW] seg_ptr windows of the tiles in flight
     int *flag_e = segl + LF_NSLOT * LF_SEGW;                             // [4]  ordinals of: a chunk with a scaled row; a chunk / node tile / hidden tile with a non-finite row
     unsigned *wmax = reinterpret_cast<unsigned *>(flag_e + 4);           // [12] per-wave weight maxima (prologue)
-    int *pub = reinterpret_cast<int *>(wmax + 12);                        // [12] step record for group S1 (published by group S0 every step)
-    int *dring = pub + 12;                                                // [8][8] chunk descriptors, published four steps ahead
+    int *pub = reinterpret_cast<int *>(wmax + 12);                        // [4 (+8)] step record for group S1 (published by group S0 every step)
+    int *dring = pub + 12;                                                // [8][4] chunk descriptors, published four steps ahead
+    float *wtab = reinterpret_cast<float *>(dring + 64);                   // [4] inverse weight scales of groups E, S0, S1 (NaN: non-finite weights).  Read
+                                                                          // back into a scalar register at every use: held in a vector register over the
+                                                                          // whole loop they get spilled, and a reload waits for every load / store in flight
 
     const int tid = threadIdx.x;
     const int grp = __builtin_amdgcn_readfirstlane(tid >> 8);            // 0: E, 1: S0, 2: S1
@@ -411,9 +431,11 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 
     // ---- this wave's stage: folded BatchNorm, weight scale ------------------------------------------------------------
     const LfStage &st = grp == 0 ? a.e : (grp == 1 ? a.s0 : a.s1);
+    const int st_n_out = WG ? 32 * WG : st.n_out;
+    const int h1 = WG ? 32 * WG : a.e.n_out;                              // width of the activated edge rows = of the per-node sums
     const int col = 32 * w + li;
-    const bool cok = col < st.n_out;
-    const bool active = 32 * w < st.n_out;
+    const bool cok = col < st_n_out;
+    const bool active = 32 * w < st_n_out;
     const float bias = (cok && st.bias) ? st.bias[col] : 0.f;
     float bnscale = 1.f, c0 = bias;
     if (cok && st.bn_scale) { bnscale = st.bn_scale[col]; c0 = (bias - st.bn_mean[col]) * bnscale + st.bn_shift[col]; }
@@ -425,14 +447,13 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     it.m_end = (int)((int64_t)a.n_nodes * (blockIdx.x + 1) / gridDim.x);
     it.m0 = 0; it.nn = 0; it.eb = 0; it.ee = 0; it.ec = 0; it.pending = 0; it.slot = 0; it.win = 0;
     const bool seg_writer = tid >= 256 && tid < 320;
-    LfDesc d3;                                                            // (group S0 only) chunk i + 3
-    d3.valid = 0; d3.m0 = 0; d3.nn = 0; d3.e0 = 0; d3.ne = 0; d3.first = 0; d3.last = 0; d3.slot = 0;
+    LfDesc d3 = lf_desc_none();                                           // (group S0 only) chunk i + 3
     LfDesc dc0 = d3;
     if (grp == 1) {
         lf_iter_load(it, lane);
         dc0 = lf_iter_next(it, lane, segl, seg_writer);
         d3 = lf_iter_next(it, lane, segl, seg_writer);
-        if (tid == 256) { lf_desc_put(dring, dc0); lf_desc_put(dring + 8, d3); }
+        if (tid == 256) { lf_desc_put(dring, dc0); lf_desc_put(dring + 4, d3); }
     }
     {
         unsigned m = lf_weight_absmax(st, col, cok, bnscale);
@@ -449,24 +470,27 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     // an Inf / NaN weight (or folded BatchNorm factor): every output row of this stage is NaN, through the same path as a non-finite input row
     const bool w_bad = __builtin_amdgcn_readfirstlane((int)(max(max(wmax[4 * grp], wmax[4 * grp + 1]), max(wmax[4 * grp + 2], wmax[4 * grp + 3])) >= 0x7f800000u)) != 0;
     if (w_bad) inv_w = __uint_as_float(0x7fc00000u);
+    if (t == 0) wtab[grp] = inv_w;                                         // (visible after the first barrier of the loop; first used after it)
+    auto uniform_lds = [](const float *p) -> float { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(*p))); };
 
     // ---- step bookkeeping (the tile iterator itself lives in group S0, see below) ------------------------------------------
-    LfDesc d0, d1, d2;                                                    // chunks i, i+1, i+2 of step i
-    d0.valid = 0; d0.m0 = 0; d0.nn = 0; d0.e0 = 0; d0.ne = 0; d0.first = 0; d0.last = 0; d0.slot = 0;
-    d1 = d0; d2 = d0;
+    LfDesc d0 = lf_desc_none(), d1 = d0, d2 = d0;                         // chunks i, i+1, i+2 of step i
     if (grp == 0) d2 = lf_desc_get(dring);                                // chunk 0 (published before the prologue's barrier)
     if (grp == 1) d2 = dc0;
     // the edge stage's weight scale: its activated rows carry it until the per-node sums (groups S0 and S1) divide it out
-    float ws_e_unused, inv_w_e;
-    lf_scale(max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3])), ws_e_unused, inv_w_e);
-    if (max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3])) >= 0x7f800000u) inv_w_e = __uint_as_float(0x7fc00000u);
-    inv_w_e = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(inv_w_e)));
-    const int cs_e = a.e.n_out >> 2;                                       // float4 chunks of an activated row
-    // tiles in the node pipeline at step i:  ts: sums complete, group S0 stages it in phase 1 and multiplies it in phase 2 -> H[i & 1];
-    // th: its H was written in step i - 1, group S1 splits it in phase 2 -> MID;  tm: MID staged in step i - 1, S1 multiplies it in phase 1
-    int ts_valid = 0, ts_m0 = 0, ts_nn = 0, ts_slot = 0;
-    int th_valid = 0, th_m0 = 0, th_nn = 0;
-    int tm_valid = 0, tm_m0 = 0, tm_nn = 0;
+    {
+        float ws_e_unused, inv_w_e;
+        lf_scale(max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3])), ws_e_unused, inv_w_e);
+        if (max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3])) >= 0x7f800000u) inv_w_e = __uint_as_float(0x7fc00000u);
+        if (tid == 0) wtab[3] = inv_w_e;
+    }
+    const int cs_e = h1 >> 2;                                              // float4 chunks of an activated row
+    // tiles in the node pipeline at step i (m0 + the descriptor word of the chunk that completed the tile; pk = 0: none):
+    //   ts: sums complete, group S0 stages it in phase 1 and multiplies it in phase 2 -> H[i & 1];
+    //   th: its H was written in step i - 1, group S1 splits it in phase 2 -> MID;  tm: MID staged in step i - 1, S1 multiplies it in phase 1
+    int ts_pk = 0, ts_m0 = 0, th_pk = 0, th_m0 = 0, tm_pk = 0, tm_m0 = 0;
+    auto pk_nn = [](int pk) { return (pk >> 6) & 63; };
+    auto pk_slot = [](int pk) { return (pk >> 3) & 7; };
     int step = -2;
 
     if (grp == 0) {
@@ -515,18 +539,29 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
             for (int j = 0; j < NCHE; ++j) pf[rr][j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        while (d0.valid | d1.valid | d2.valid | ts_valid | th_valid | tm_valid | (step < 0)) {
+        // The x rows of the node stage travel through this group as well (group S0 keeps 80 registers of weights and must not hold
+        // loads in flight over its matrix phase): loaded in phase 1 of the step that completes the tile's sums, parked raw in LDS in
+        // phase 2, staged by group S0 in the next step's phase 1.  Thread -> row r8, chunks q8 + 8 j.
+        const int cx_e = a.d_x >> 2, njx_e = (cx_e + 1 + 7) >> 3;
+        float4 xq[NJX];
+#pragma unroll
+        for (int j = 0; j < NJX; ++j) xq[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        (void)xq;
+        float *const yp_lane = ytile + col + 4 * lh * LF_PY;              // this lane's column, row 4 lh of the tile (MFMA row map: 4 lh + 8 g + r)
+        while (d0.valid() | d1.valid() | d2.valid() | ts_pk | th_pk | tm_pk | (step < 0)) {
             const unsigned long long c_0 = clk();
-            const LfDesc dn = lf_desc_get(dring + 8 * ((step + 3) & 7));  // chunk i + 3 (group S0 published it a step ago)
+            const LfDesc dn = lf_desc_get(dring + 4 * ((step + 3) & 7));  // chunk i + 3 (group S0 published it a step ago)
             // ---------------- phase 1 ----------------
             const unsigned long long e_1 = clk();
-            if (d2.valid && a.n_edges > 0) {                              // row sources of chunk i + 2 (consumed in beta)
-                int er = d2.e0 + (rs_r < d2.ne ? rs_r : (d2.ne > 0 ? d2.ne - 1 : 0));
+            if (d2.valid() && a.n_edges > 0) {                            // row sources of chunk i + 2 (consumed in phase 2)
+                const int ne2 = d2.ne();
+                int er = d2.e0 + (rs_r < ne2 ? rs_r : (ne2 > 0 ? ne2 - 1 : 0));
                 er = er < e_last ? er : e_last;
                 if (rs_on0) raw0 = rs_p0[er];
                 if (rs_on1) raw1 = rs_p1[er];
             }
-            if (d1.valid && d1.ne > 0) {                                  // gathers of chunk i + 1 (consumed in beta)
+            const bool e1_on = d1.valid() && d1.ne() > 0;
+            if (e1_on) {                                                  // gathers of chunk i + 1 (consumed in phase 2)
                 int sr[2][NCHE];
 #pragma unroll
                 for (int rr = 0; rr < 2; ++rr)
@@ -538,25 +573,34 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     for (int j = 0; j < NCHE; ++j)                        // (a chunk past k_total reads a valid address; it is masked when the
                         pf[rr][j] = *reinterpret_cast<const float4 *>(gbase[j] + (int64_t)sr[rr][j] * gbw[j]);   // row is staged: any use here would wait for the data)
             }
+            const bool xon = d0.completes() != 0;
+            const int d0nn = d0.nn();
+            if (xon) {                                                    // (clamped addresses, masked when parked: a select or a zero written to
+#pragma unroll                                                            //  these registers here would wait for the gathers just issued)
+                for (int j = 0; j < NJX; ++j) {
+                    const int xrow = d0.m0 + (r8 < d0nn ? r8 : d0nn - 1), xc = q8 + 8 * j < cx_e ? q8 + 8 * j : cx_e - 1;
+                    if (j < njx_e) xq[j] = *reinterpret_cast<const float4 *>(a.x + (int64_t)xrow * a.d_x + 4 * xc);
+                }
+            }
             const unsigned long long e_2 = clk();
             if (prio) __builtin_amdgcn_s_setprio(2);
-            if (d0.valid && d0.ne > 0 && active) {
+            const int d0ne = d0.ne();
+            if (d0.valid() && d0ne > 0 && active) {
                 const _Float16 *ap0 = in_e + li * KPE + 8 * lh, *ap1 = ap0 + 32 * KPE;
                 // The activated rows are kept TIMES the weight scale (Y' = ws * Y, an exact power of two that the per-node sums divide
                 // out again): a chunk whose rows are all exact in fp16 starts its accumulators at ws * c0 and needs no multiply at all.
-                float *yp = ytile + col;
                 const bool nanrows = flag_e[1] == step || w_bad;
                 const bool three = flag_e[0] == step || nanrows;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    if (h == 1 && d0.ne <= 32) break;
+                    if (h == 1 && d0ne <= 32) break;
                     const _Float16 *ap = h ? ap1 : ap0;
-                    float *y0 = yp + (32 * h + 4 * lh) * LF_PY;
+                    float *y0 = yp_lane + 32 * h * LF_PY;
                     if (three) {
                         const f32x16 acc = lf_mma_tile<NKE, true>(ap, PLE, Bh, Bl, 0.f);
                         if (cok) {
-                            if (nanrows) lf_epilogue<true>(acc, comb_e + 32 * h, lh, c0w, act_lo, [&](int r, float y) { yp[(32 * h + r) * LF_PY] = y; });
-                            else lf_epilogue<false>(acc, comb_e + 32 * h, lh, c0w, act_lo, [&](int r, float y) { yp[(32 * h + r) * LF_PY] = y; });
+                            if (nanrows) lf_epilogue<true>(acc, comb_e + 32 * h, lh, c0w, act_lo, [&](int g, int r, float y) { y0[(8 * g + r) * LF_PY] = y; });
+                            else lf_epilogue<false>(acc, comb_e + 32 * h, lh, c0w, act_lo, [&](int g, int r, float y) { y0[(8 * g + r) * LF_PY] = y; });
                         }
                     } else {
                         const f32x16 acc = lf_mma_tile<NKE, false>(ap, PLE, Bh, Bl, c0w);
@@ -572,12 +616,12 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             lds_barrier();
             const unsigned long long c_2 = clk();
             // ---------------- phase 2 ----------------
-            if (d2.valid) {
+            if (d2.valid()) {
                 if (rs_on0) rsrc[rs_b * LF_TE + rs_r] = raw0;
                 if (rs_on1) rsrc[(rs_b + 4) * LF_TE + rs_r] = raw1;
             }
             const unsigned long long e_3 = clk();
-            if (d1.valid && d1.ne > 0) {
+            if (e1_on) {
                 bool scaled_any = false, nf_any = false;
 #pragma unroll
                 for (int rr = 0; rr < 2; ++rr) {
@@ -610,18 +654,26 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                         comb = lf_split_row_scaled<NCHE>(pz, gon, dst, PLE, gk, nf_any);
                         scaled_any = true;
                     }
-                    if (q8 == 0) comb_e[row] = w_bad ? inv_w : comb;
+                    if (q8 == 0) comb_e[row] = w_bad ? __uint_as_float(0x7fc00000u) : comb;
                 }
                 if (scaled_any) flag_e[0] = step + 1;                     // (every writer stores the same value)
                 if (nf_any) flag_e[1] = step + 1;
+            }
+            if (xon) {
+#pragma unroll
+                for (int j = 0; j < NJX; ++j)
+                    if (j < njx_e) {
+                        const bool on = q8 + 8 * j < cx_e && r8 < d0nn;
+                        *reinterpret_cast<float4 *>(xrl + ((j * LF_TN + r8) * 8 + q8) * 4) = on ? xq[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
             }
             const unsigned long long e_4 = clk();
             const unsigned long long c_3 = clk();
             lds_barrier();
             const unsigned long long c_4 = clk();
-            tm_valid = th_valid; tm_m0 = th_m0; tm_nn = th_nn;
-            th_valid = ts_valid; th_m0 = ts_m0; th_nn = ts_nn;
-            ts_valid = d0.valid && d0.last; ts_m0 = d0.m0; ts_nn = d0.nn; ts_slot = d0.slot;
+            tm_pk = th_pk; tm_m0 = th_m0;
+            th_pk = ts_pk; th_m0 = ts_m0;
+            ts_pk = d0.completes() ? d0.pk : 0; ts_m0 = d0.m0;
             d0 = d1; d1 = d2; d2 = dn;
             ++step;
             if (PROF) { const unsigned long long c_5 = clk(); pc[0] += c_1 - c_0; pc[1] += c_2 - c_1; pc[2] += c_3 - c_2; pc[3] += c_4 - c_3; pc[4] += c_5 - c_4; pc[5] += 1;
@@ -639,37 +691,38 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         // group S0.  Input planes of a node row: [S (h1 columns) | x (d_x) | deg, 0, 0, 0]; the weight planes follow that order.
         // Thread -> row r8, S chunks q8 + 8 j (j < njs) and chunks q8 + 8 j of the [x | deg] part (j < njx).
         // =============================================================================================================
-        const int h1 = a.e.n_out, cs = h1 >> 2, cx = a.d_x >> 2;
-        const int njs = cs >> 3, njx = (cx + 1 + 7) >> 3;                 // (h1 is a multiple of 32)
+        const int cs = h1 >> 2, cx = a.d_x >> 2;
+        const int njs = WG ? WG : cs >> 3, njx = (cx + 1 + 7) >> 3;      // (h1 is a multiple of 32)
         lf_u4 Bh[NK0], Bl[NK0];
         lf_weight_planes<NK0>(st, col, cok, lh, bnscale, wscale, h1, a.d_x, 1.f, Bh, Bl);
         int koff[NCH0];
-        bool wr[NCH0], isx[NJX], isdeg[NJX];
+        bool wr[NCH0], isdeg[NJX];
 #pragma unroll
         for (int j = 0; j < NJS; ++j) { koff[j] = 4 * (q8 + 8 * j); wr[j] = j < njs; }
 #pragma unroll
         for (int j = 0; j < NJX; ++j) {
             const int c = q8 + 8 * j;
             koff[NJS + j] = h1 + 4 * c;
-            isx[j] = c < cx; isdeg[j] = c == cx;
+            isdeg[j] = c == cx;
             wr[NJS + j] = c <= cx;
         }
-        float4 xr[NJX];
-#pragma unroll
-        for (int j = 0; j < NJX; ++j) xr[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        while (d0.valid | d1.valid | d2.valid | ts_valid | th_valid | tm_valid | (step < 0)) {
+        float *const hp_lane = htile + col + 4 * lh * LF_PY;
+        while (d0.valid() | d1.valid() | d2.valid() | ts_pk | th_pk | tm_pk | (step < 0)) {
             const unsigned long long c_0 = clk();
             const LfDesc dn = lf_iter_next(it, lane, segl, seg_writer);  // chunk i + 4 (its window arrived a step ago)
             // ---------------- phase 1 ----------------
+            const unsigned long long e_1 = clk();
             if (tid == 256) {
-                lf_desc_put(dring + 8 * ((step + 4) & 7), dn);            // group E reads it at the top of the next step
+                lf_desc_put(dring + 4 * ((step + 4) & 7), dn);            // group E reads it at the top of the next step
                 // what group S1 needs to follow the tiles and to sum its half of this chunk's nodes (it never loads seg_ptr: a
-                // wait for such a load would drain its output stores)
-                pub[0] = ts_valid; pub[1] = ts_m0; pub[2] = ts_nn; pub[3] = d1.valid | (d0.valid && d0.last);
-                pub[4] = d0.valid; pub[5] = d0.e0; pub[6] = d0.nn; pub[7] = d0.first; pub[8] = d0.last; pub[9] = d0.slot;
+                // wait for such a load would drain its output stores): the tile staged now, "more steps follow", the current chunk
+                const int more = d1.valid() | d0.completes();
+                *reinterpret_cast<int4 *>(pub) = make_int4(ts_pk, ts_m0, d0.pk | (more << 20), d0.e0);
             }
-            if (ts_valid) {                                               // [S | x | deg] of the tile whose sums were finished in the last step
-                const int *sw = segl + ts_slot * LF_SEGW + r8;
+            const unsigned long long e_2 = clk();
+            if (ts_pk) {                                                  // [S | x | deg] of the tile whose sums were finished in the last step
+                const int ts_nn = pk_nn(ts_pk);
+                const int *sw = segl + pk_slot(ts_pk) * LF_SEGW + r8;
                 int a0 = 0, a1 = 0;
                 if (r8 < ts_nn) { a0 = sw[0]; a1 = sw[1]; }
                 const float *sp = sacc + r8 * LF_PY;
@@ -682,50 +735,48 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 const float degf = (float)(a1 - a0);
 #pragma unroll
                 for (int j = 0; j < NJX; ++j) {
-                    v[NJS + j] = xr[j];                                    // (loaded a step ago; zero where this lane has no x chunk)
+                    v[NJS + j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (j < njx) v[NJS + j] = *reinterpret_cast<const float4 *>(xrl + ((j * LF_TN + r8) * 8 + q8) * 4);   // (group E parked it; zero past d_x)
                     if (isdeg[j]) v[NJS + j] = make_float4(degf, 0.f, 0.f, 0.f);
                 }
                 bool nf = false;
                 const float inv = lf_split_row_scaled<NCH0>(v, wr, in_n + r8 * KP0, PL0, koff, nf);
-                if (q8 == 0) comb_n[r8] = inv * inv_w;
+                if (q8 == 0) comb_n[r8] = inv * uniform_lds(wtab + 1);
                 if (nf) flag_e[2] = step;
             }
-            if (d0.valid && d0.last) {                                    // x rows of the tile that completes in this step (staged in the next)
-#pragma unroll
-                for (int j = 0; j < NJX; ++j) {
-                    xr[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (j < njx && isx[j] && r8 < d0.nn)
-                        xr[j] = *reinterpret_cast<const float4 *>(a.x + (int64_t)(d0.m0 + r8) * a.d_x + 4 * (q8 + 8 * j));
-                }
-            }
+            const unsigned long long e_3 = clk();
             const unsigned long long c_1 = clk();
             lds_barrier();
             const unsigned long long c_2 = clk();
             // ---------------- phase 2 ----------------
             if (prio) __builtin_amdgcn_s_setprio(2);
-            if (ts_valid && active) {
+            if (ts_pk && active) {
                 const f32x16 acc = lf_mma_k2<NK0>(in_n + li * KP0 + 8 * lh, PL0, Bh, Bl);
-                float *hp = htile + (step & 1) * (LF_TN * LF_PY) + col;
+                float *hp = hp_lane + (step & 1) * (LF_TN * LF_PY);
                 if (cok) {
-                    if (flag_e[2] == step || w_bad) lf_epilogue<true>(acc, comb_n, lh, c0, act_lo, [&](int r, float y) { hp[r * LF_PY] = y; });
-                    else lf_epilogue<false>(acc, comb_n, lh, c0, act_lo, [&](int r, float y) { hp[r * LF_PY] = y; });
+                    if (flag_e[2] == step || w_bad) lf_epilogue<true>(acc, comb_n, lh, c0, act_lo, [&](int g, int r, float y) { hp[(8 * g + r) * LF_PY] = y; });
+                    else lf_epilogue<false>(acc, comb_n, lh, c0, act_lo, [&](int g, int r, float y) { hp[(8 * g + r) * LF_PY] = y; });
                 }
             }
             if (prio) __builtin_amdgcn_s_setprio(0);
-            if (d0.valid)                                                 // nodes 0 .. 15 of this chunk's tile (group S1: 16 .. 31)
-                lf_node_sums(ytile, sacc, segl + d0.slot * LF_SEGW, 0, t, cs_e, d0.nn, d0.e0, d0.first, d0.last, inv_w_e);
+            const unsigned long long e_4 = clk();
+            if (d0.valid())                                               // nodes 0 .. 15 of this chunk's tile (group S1: 16 .. 31)
+                lf_node_sums<WG>(ytile, sacc, segl + d0.slot() * LF_SEGW, 0, t, cs_e, d0.nn(), d0.e0, d0.first() != 0, d0.last() != 0, uniform_lds(wtab + 3));
             const unsigned long long c_3 = clk();
             lds_barrier();
             const unsigned long long c_4 = clk();
-            tm_valid = th_valid; tm_m0 = th_m0; tm_nn = th_nn;
-            th_valid = ts_valid; th_m0 = ts_m0; th_nn = ts_nn;
-            ts_valid = d0.valid && d0.last; ts_m0 = d0.m0; ts_nn = d0.nn; ts_slot = d0.slot;
+            tm_pk = th_pk; tm_m0 = th_m0;
+            th_pk = ts_pk; th_m0 = ts_m0;
+            ts_pk = d0.completes() ? d0.pk : 0; ts_m0 = d0.m0;
             d0 = d1; d1 = d2; d2 = d3; d3 = dn;
             ++step;
-            if (PROF) { const unsigned long long c_5 = clk(); pc[0] += c_1 - c_0; pc[1] += c_2 - c_1; pc[2] += c_3 - c_2; pc[3] += c_4 - c_3; pc[4] += c_5 - c_4; pc[5] += 1; }
+            if (PROF) { const unsigned long long c_5 = clk(); pc[0] += c_1 - c_0; pc[1] += c_2 - c_1; pc[2] += c_3 - c_2; pc[3] += c_4 - c_3; pc[4] += c_5 - c_4; pc[5] += 1;
+                        pe[0] += e_1 - c_0; pe[1] += e_2 - e_1; pe[2] += e_3 - e_2; pe[3] += c_1 - e_3; pe[4] += e_4 - c_2; pe[5] += c_3 - e_4; }
         }
-        if (PROF && prof && lane == 0 && blockIdx.x == 0)
+        if (PROF && prof && lane == 0 && blockIdx.x == 0) {
             for (int q = 0; q < 6; ++q) prof[(tid >> 6) * 6 + q] = pc[q];
+            for (int q = 0; q < 6; ++q) prof[72 + (tid >> 6) * 6 + q] = pe[q];
+        }
         return;
     }
 
@@ -734,26 +785,34 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     // =================================================================================================================
     lf_u4 Bh[NK1], Bl[NK1];
     lf_weight_planes<NK1>(st, col, cok, lh, bnscale, wscale, 0, 0, 1.f, Bh, Bl);
-    const int njh = a.s0.n_out >> 5;                                      // 32-column groups of H that carry data (n_out multiple of 32)
+    const int njh = WG ? WG : a.s0.n_out >> 5;                            // 32-column groups of H that carry data (n_out multiple of 32)
     int koff[NCH1];
     bool wr[NCH1];
 #pragma unroll
     for (int j = 0; j < NCH1; ++j) { wr[j] = j < njh; koff[j] = 4 * (q8 + 8 * j); }
-    // This group follows the tiles through the record group E publishes every step instead of running the iterator: its
+    // Output rows leave through a buffer resource per tile (base = the tile's first row, extent = its nn rows): the rows past nn
+    // of a short tile are dropped by the hardware's range check instead of one compare + exec mask per store, and the address of
+    // a store is one per-lane byte offset fixed before the loop plus an immediate.
+    const int rstride = st_n_out * 4;                                     // bytes per output row
+    int voff[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) voff[g] = ((8 * g + 4 * lh) * st_n_out + col) * 4;
+    // This group follows the tiles through the record group S0 publishes every step instead of running the iterator: its
     // only global memory operations are the output stores, and it never waits for them.
     int more = 1;
-    while (more | th_valid | tm_valid | (step < 0)) {
+    while (more | th_pk | tm_pk | (step < 0)) {
         const unsigned long long c_0 = clk();
         // ---------------- phase 1 ----------------
         if (prio) __builtin_amdgcn_s_setprio(2);
-        if (tm_valid && active) {
+        unsigned long long e_1 = c_0;
+        if (tm_pk && active) {
             const f32x16 acc = lf_mma_k2<NK1>(mid + li * KP1 + 8 * lh, PL1, Bh, Bl);
-            float *op = a.out + (int64_t)tm_m0 * st.n_out + col;          // wave-uniform base + the lane's column
-            const int n_out = st.n_out, nn = tm_nn;
+            if (PROF) { pe[5] += (unsigned long long)(acc[0] != 12345.f); e_1 = clk(); }   // (forces the products to finish before the reading)
+            const __amdgpu_buffer_rsrc_t orow = __builtin_amdgcn_make_buffer_rsrc(a.out + (int64_t)tm_m0 * st_n_out, 0, pk_nn(tm_pk) * rstride, 0x00020000);
             if (cok) {
-                if (flag_e[3] == step || w_bad) lf_epilogue<true>(acc, comb_h, lh, c0, act_lo, [&](int r, float y) { if (r < nn) op[r * n_out] = y; });
-                else if (nn == LF_TN) lf_epilogue<false>(acc, comb_h, lh, c0, act_lo, [&](int r, float y) { op[r * n_out] = y; });
-                else lf_epilogue<false>(acc, comb_h, lh, c0, act_lo, [&](int r, float y) { if (r < nn) op[r * n_out] = y; });
+                auto put = [&](int g, int r, float y) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), orow, voff[g] + r * rstride, 0, 0); };
+                if (flag_e[3] == step || w_bad) lf_epilogue<true>(acc, comb_h, lh, c0, act_lo, put);
+                else lf_epilogue<false>(acc, comb_h, lh, c0, act_lo, put);
             }
         }
         if (prio) __builtin_amdgcn_s_setprio(0);
@@ -761,12 +820,12 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         lds_barrier();
         const unsigned long long c_2 = clk();
         // ---------------- phase 2 ----------------
-        const int nts_valid = __builtin_amdgcn_readfirstlane(pub[0]), nts_m0 = __builtin_amdgcn_readfirstlane(pub[1]);
-        const int nts_nn = __builtin_amdgcn_readfirstlane(pub[2]);
-        more = __builtin_amdgcn_readfirstlane(pub[3]);
-        const int c_valid = __builtin_amdgcn_readfirstlane(pub[4]), c_e0 = __builtin_amdgcn_readfirstlane(pub[5]), c_nn = __builtin_amdgcn_readfirstlane(pub[6]);
-        const int c_first = __builtin_amdgcn_readfirstlane(pub[7]), c_last = __builtin_amdgcn_readfirstlane(pub[8]), c_slot = __builtin_amdgcn_readfirstlane(pub[9]);
-        if (th_valid) {                                                   // H of that tile was written in the last step's phase 2
+        const int4 rec = *reinterpret_cast<const int4 *>(pub);
+        const int nts_pk = __builtin_amdgcn_readfirstlane(rec.x), nts_m0 = __builtin_amdgcn_readfirstlane(rec.y);
+        const int c_pk = __builtin_amdgcn_readfirstlane(rec.z), c_e0 = __builtin_amdgcn_readfirstlane(rec.w);
+        more = (c_pk >> 20) & 1;
+        const unsigned long long e_3 = clk();
+        if (th_pk) {                                                      // H of that tile was written in the last step's phase 2
             const float *hp = htile + ((step - 1) & 1) * (LF_TN * LF_PY) + r8 * LF_PY;
             float4 v[NCH1];
 #pragma unroll
@@ -776,32 +835,37 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             }
             bool nf = false;
             const float inv = lf_split_row_scaled<NCH1>(v, wr, mid + r8 * KP1, PL1, koff, nf);
-            if (q8 == 0) comb_h[r8] = inv * inv_w;
+            if (q8 == 0) comb_h[r8] = inv * uniform_lds(wtab + 2);
             if (nf) flag_e[3] = step + 1;
         }
-        if (c_valid)                                                      // nodes 16 .. 31 of this chunk's tile (group S0: 0 .. 15)
-            lf_node_sums(ytile, sacc, segl + c_slot * LF_SEGW, 16, t, cs_e, c_nn, c_e0, c_first != 0, c_last != 0, inv_w_e);
+        const unsigned long long e_4 = clk();
+        if (c_pk & 1)                                                     // nodes 16 .. 31 of this chunk's tile (group S0: 0 .. 15)
+            lf_node_sums<WG>(ytile, sacc, segl + pk_slot(c_pk) * LF_SEGW, 16, t, cs_e, pk_nn(c_pk), c_e0, ((c_pk >> 1) & 1) != 0, ((c_pk >> 2) & 1) != 0, uniform_lds(wtab + 3));
         const unsigned long long c_3 = clk();
         lds_barrier();
         const unsigned long long c_4 = clk();
-        tm_valid = th_valid; tm_m0 = th_m0; tm_nn = th_nn;
-        th_valid = nts_valid; th_m0 = nts_m0; th_nn = nts_nn;
+        tm_pk = th_pk; tm_m0 = th_m0;
+        th_pk = nts_pk; th_m0 = nts_m0;
         ++step;
-        if (PROF) { const unsigned long long c_5 = clk(); pc[0] += c_1 - c_0; pc[1] += c_2 - c_1; pc[2] += c_3 - c_2; pc[3] += c_4 - c_3; pc[4] += c_5 - c_4; pc[5] += 1; }
+        if (PROF) { const unsigned long long c_5 = clk(); pc[0] += c_1 - c_0; pc[1] += c_2 - c_1; pc[2] += c_3 - c_2; pc[3] += c_4 - c_3; pc[4] += c_5 - c_4; pc[5] += 1;
+                    pe[0] += e_1 - c_0; pe[1] += c_1 - e_1; pe[2] += e_3 - c_2; pe[3] += e_4 - e_3; pe[4] += c_3 - e_4; }
     }
-    if (PROF && prof && lane == 0 && blockIdx.x == 0)
+    if (PROF && prof && lane == 0 && blockIdx.x == 0) {
         for (int q = 0; q < 6; ++q) prof[(tid >> 6) * 6 + q] = pc[q];
+        for (int q = 0; q < 5; ++q) prof[72 + (tid >> 6) * 6 + q] = pe[q];
+    }
 }
 
 #undef LF_MF
 
-template <int NKE, int NK0, int NK1, bool PROF = false>
+template <int NKE, int NK0, int NK1, int WG = 0, bool PROF = false>
 static int lf_launch(const LfArgs &a, hipStream_t st) {
     constexpr size_t lds = (size_t)2 * LF_TE * (16 * NKE + 8) * 2 + (size_t)LF_TE * LF_PY * 4 + (size_t)LF_TN * LF_PY * 4 +
                            (size_t)2 * LF_TN * (16 * NK0 + 8) * 2 + (size_t)2 * LF_TN * LF_PY * 4 + (size_t)2 * LF_TN * (16 * NK1 + 8) * 2 +
-                           ((size_t)LF_MAXB * LF_TE + LF_TE + 2 * LF_TN + LF_NSLOT * LF_SEGW + 4 + 12 + 12 + 64) * 4;
+                           (size_t)LF_NXJ * LF_TN * 32 * 4 +
+                           ((size_t)LF_MAXB * LF_TE + LF_TE + 2 * LF_TN + LF_NSLOT * LF_SEGW + 4 + 12 + 12 + 64 + 4) * 4;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    const void *fn = reinterpret_cast<const void *>(&layer_fused_kernel<NKE, NK0, NK1, PROF>);
+    const void *fn = reinterpret_cast<const void *>(&layer_fused_kernel<NKE, NK0, NK1, WG, PROF>);
     static DeviceOnce attr_set;                                        // (the attribute is per device)
     const int attr_dev = current_device();
     if (!attr_set.done(attr_dev)) {
@@ -813,15 +877,15 @@ static int lf_launch(const LfArgs &a, hipStream_t st) {
     { const char *d = getenv("GSN_FUSED_GRID"); if (d && atoi(d) > 0) gx = atoi(d); }
     const int64_t n_tiles = ((int64_t)a.n_nodes + LF_TN - 1) / LF_TN;
     if (gx > n_tiles) gx = n_tiles;
-    if (getenv("GSN_CHAIN_TRACE")) fprintf(stderr, "gsn chain: layer_fused_kernel<%d,%d,%d> nodes %d edges %d grid %lld\n", NKE, NK0, NK1, a.n_nodes, a.n_edges, (long long)gx);
+    if (getenv("GSN_CHAIN_TRACE")) fprintf(stderr, "gsn chain: layer_fused_kernel<%d,%d,%d,%d> nodes %d edges %d grid %lld\n", NKE, NK0, NK1, WG, a.n_nodes, a.n_edges, (long long)gx);
     unsigned long long *prof = nullptr;
-    if (PROF) { (void)hipMalloc(&prof, 16 * 6 * 8); (void)hipMemset(prof, 0, 16 * 6 * 8); }
+    if (PROF) { (void)hipMalloc(&prof, 24 * 6 * 8); (void)hipMemset(prof, 0, 24 * 6 * 8); }
     static const int prio = [] { const char *d = getenv("GSN_FUSED_PRIO"); return d ? atoi(d) : 1; }();   // matrix phases at raised wave priority (~1 %)
-    hipLaunchKernelGGL((layer_fused_kernel<NKE, NK0, NK1, PROF>), dim3((unsigned)gx), dim3(768), lds, st, a, prof, prio);
+    hipLaunchKernelGGL((layer_fused_kernel<NKE, NK0, NK1, WG, PROF>), dim3((unsigned)gx), dim3(768), lds, st, a, prof, prio);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(GSN_E_HIP, "layer_fused_kernel: %s", hipGetErrorString(e));
     if (PROF) {
-        unsigned long long h[16 * 6];
+        unsigned long long h[24 * 6];
         (void)hipDeviceSynchronize();
         (void)hipMemcpy(h, prof, sizeof(h), hipMemcpyDeviceToHost);
         (void)hipFree(prof);
@@ -831,11 +895,16 @@ static int lf_launch(const LfArgs &a, hipStream_t st) {
                 const unsigned long long *o = h + w * 6;
                 if (o[5]) fprintf(stderr, "fusedprof %s%d steps %llu: phase1 %llu barrier %llu phase2 %llu barrier %llu bookkeeping %llu (cycles per step)\n",
                                   w < 4 ? "E" : (w < 8 ? "S0-" : "S1-"), w & 3, o[5], o[0] / o[5], o[1] / o[5], o[2] / o[5], o[3] / o[5], o[4] / o[5]);
-                if (w < 4 && o[5]) {
-                    const unsigned long long *e = h + 72 + w * 6;
+                const unsigned long long *e = h + 72 + w * 6;
+                if (w < 4 && o[5])
                     fprintf(stderr, "fusedprof E%d detail: iterator+publish %llu sources+gathers %llu matrix+epilogue %llu | table %llu split %llu sums %llu\n", w,
                             e[0] / o[5], e[1] / o[5], e[2] / o[5], e[3] / o[5], e[4] / o[5], e[5] / o[5]);
-                }
+                else if (w < 8 && o[5])
+                    fprintf(stderr, "fusedprof S0-%d detail: iterator %llu publish %llu staging %llu x-loads %llu | matrix+epilogue %llu sums %llu\n", w & 3,
+                            e[0] / o[5], e[1] / o[5], e[2] / o[5], e[3] / o[5], e[4] / o[5], e[5] / o[5]);
+                else if (o[5])
+                    fprintf(stderr, "fusedprof S1-%d detail: matrix %llu epilogue+stores %llu | record %llu split %llu sums %llu\n", w & 3,
+                            e[0] / o[5], e[1] / o[5], e[2] / o[5], e[3] / o[5], e[4] / o[5]);
             }
     }
     return GSN_OK;
@@ -901,7 +970,13 @@ extern "C" int gsn_layer_fused_fwd_hip(int64_t n_nodes, int64_t n_edges, const i
     a.x = x; a.d_x = (int)d_x; a.out = out;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int k0 = a.s0.k_total, k1 = a.s1.k_total;
-    { const char *d = getenv("GSN_FUSED_PROF"); if (d && atoi(d) && k0 > 96 && k1 > 64) return lf_launch<5, 10, 8, true>(a, st); }
+    // every width 128 (or 64): the reference's d = 128 / 64 layers -- widths as compile-time constants
+    const bool generic = getenv("GSN_FUSED_GENERIC") != nullptr;
+    const bool w128 = !generic && a.e.n_out == 128 && a.s0.n_out == 128 && a.s1.n_out == 128 && k0 <= 160;
+    const bool w64 = !generic && a.e.n_out == 64 && a.s0.n_out == 64 && a.s1.n_out == 64 && k0 <= 96;
+    { const char *d = getenv("GSN_FUSED_PROF"); if (d && atoi(d) && w128) return lf_launch<5, 10, 8, 4, true>(a, st); }
+    if (w128) return lf_launch<5, 10, 8, 4>(a, st);
+    if (w64) return lf_launch<5, 6, 4, 2>(a, st);
     if (k0 <= 96) return k1 <= 64 ? lf_launch<5, 6, 4>(a, st) : lf_launch<5, 6, 8>(a, st);
     return k1 <= 64 ? lf_launch<5, 10, 4>(a, st) : lf_launch<5, 10, 8>(a, st);
 }
