@@ -2,10 +2,11 @@
 """Benchmark of the hot path named by BASELINE.json: orbit counting + GSN-e forward on ZINC-shaped batches.
 
 One "step" = one pass over one batch of G synthetic ZINC-shaped graphs resident in HBM:
-    (1) gsn_count_hip           cycle_graph k = 3..6, id_scope=local (GSN-e), non-induced  -> int64 [E, 4]
-    (2) gsn_one_hot_hip          per-column one-hot of min(count, 2)  -> float [E, 12]   (the reference does this in
-                                 DiscreteEmbedding('one_hot_encoder'), utils_graph_learning.py:78 / :170-187)
-    (3) GSN_edge_sparse forward  layer 0 of BASELINE config 2: msg_kind=general, d_in=28, d_ef=4, d_id=12, d_h=d_msg=d_up=128,
+    (1) gsn_count_encode_hip    cycle_graph k = 3..6, id_scope=local (GSN-e), non-induced; the counts [E, 4] leave the kernel
+                                 as the per-column one-hot of min(count, 2) -> float [E, 12] (the reference: int64 identifiers,
+                                 then DiscreteEmbedding('one_hot_encoder'), utils_graph_learning.py:78 / :170-187); after the
+                                 timed region the int64 counts of the same batch are produced by gsn_count_hip and checked
+    (2) GSN_edge_sparse forward  layer 0 of BASELINE config 2: msg_kind=general, d_in=28, d_ef=4, d_id=12, d_h=d_msg=d_up=128,
                                  bn=True, eval mode; includes building the target-sorted CSR (cache cleared every step)
 Prints ONE JSON line (rank 0).  Multi-GPU: one process per GPU (torch.distributed / RCCL only for the barrier and the
 max-over-ranks timing); graphs are sharded across ranks, the data path has no collective ("weak" scaling: G per GPU fixed).
@@ -216,6 +217,7 @@ def main():
     plan = CountPlan.get([list(nx.cycle_graph(k).edges) for k in range(3, 7)], "edge", False)
     plan.device_table(dev)
     ids_out = torch.empty((E, plan.n_cols), dtype=torch.int64, device=dev)
+    idf_out = torch.empty((E, 12), dtype=torch.float32, device=dev)    # the encoded identifiers the layer reads
     torch.manual_seed(0)
     layer = layers.GSN_edge_sparse(**CTOR).to(dev).eval()
 
@@ -233,13 +235,14 @@ def main():
         side.wait_stream(main)
         with torch.cuda.stream(side):
             layers._csr_for(ei, sel, N)
-        with layers._timed("count", 16.0 * E + 8.0 * E * plan.n_cols):
+        # gsn_count_encode_hip: the counts leave the kernel as the one-hot rows of min(count, 2) the layer consumes (the reference:
+        # int64 identifiers, then DiscreteEmbedding('one_hot_encoder'), utils_graph_learning.py:78 / :170-187) -- no int64 round trip
+        with layers._timed("count", 16.0 * E + 4.0 * E * 12):
             count_batch(plan, node_ptr, edge_ptr, ei, ids_are_global=True, max_nodes=max_nodes, max_edges=max_edges,
-                        device=dev, out=ids_out, check=False)
-        idf = layers.one_hot_identifiers(ids_out, [3, 3, 3, 3], clamp=True)   # [E, 12] fp32 (gsn_one_hot_hip)
+                        device=dev, check=False, encode=([3, 3, 3, 3], True), counts=False, encoded_out=idf_out)
         main.wait_stream(side)
         with torch.no_grad():
-            return layer(x, ei, identifiers=idf, degrees=degrees, edge_features=ef)
+            return layer(x, ei, identifiers=idf_out, degrees=degrees, edge_features=ef)
 
     def sync():
         torch.cuda.synchronize()
@@ -264,8 +267,14 @@ def main():
     timer, layers.KERNEL_TIMER = layers.KERNEL_TIMER, None
     dt = gdist.max_over_ranks(dt, dev)
     assert torch.isfinite(y).all()
-    # (outside the timed region) the timed batch's own results against the oracle, and the counting work figures
+    # (outside the timed region) the timed batch's own results against the oracle, and the counting work figures: the int64
+    # counts of the same batch (one more launch), the timed step's encoded rows against their one-hot, a tile against the oracle
+    count_batch(plan, node_ptr, edge_ptr, ei, ids_are_global=True, max_nodes=max_nodes, max_edges=max_edges, device=dev, out=ids_out, check=False)
+    enc_ok = bool(torch.equal(idf_out, torch.nn.functional.one_hot(ids_out.clamp(max=2), 3).reshape(E, 12).float()))
+    assert enc_ok, "encoded identifiers of the timed step differ from one_hot(min(count, 2))"
     checked = verify_tile(plan, b, ids_out, y, layer, 4096) if rank == 0 else None
+    if checked is not None:
+        checked["encoded_rows_equal_one_hot_of_counts"] = enc_ok
     occ_pos, n_maps = work_figures([list(nx.cycle_graph(k).edges) for k in range(3, 7)], ids_out)
 
     # Diagnostic (never `value`): the same K steps replayed from ONE captured HIP graph of the step (same kernels, same inputs).

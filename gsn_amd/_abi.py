@@ -48,6 +48,8 @@ SIGNATURES = {
     "gsn_count_plan_build": (c_int, [c_int, c_int, c_int, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
     "gsn_count_hip": (c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_i64, c_i64,
                               c_vp, c_vp, c_vp]),
+    "gsn_count_encode_hip": (c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_i64, c_i64,
+                                     c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
     "gsn_csr_scratch_elems": (c_i64, [c_i64]),
     "gsn_csr_build_hip": (c_int, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "gsn_segsum_prepare_hip": (c_int, [c_i64, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp]),

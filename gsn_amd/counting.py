@@ -76,8 +76,14 @@ def _as_dev_i64(x, device):
 
 
 def count_batch(plan: CountPlan, node_ptr, edge_ptr, edge_index, ids_are_global=True, max_nodes=None, max_edges=None,
-                device=None, graph_ids=None, out=None, check=True):
+                device=None, graph_ids=None, out=None, check=True, encode=None, counts=True, encoded_out=None):
     """Run the counting kernel over a batch.
+
+    ``encode=(n_classes, clamp)`` also returns the one-hot encoded identifiers the GSN layers consume (the reference's
+    ``DiscreteEmbedding('one_hot_encoder')`` over the counts, utils_graph_learning.py:170-187) straight from the kernel
+    (``gsn_count_encode_hip``): the result becomes ``(out, status, encoded)`` with ``encoded`` fp32
+    [rows_total, sum(n_classes)] (``encoded_out`` to reuse a buffer); with ``counts=False`` the int64 rows are not written at
+    all (``out`` is None).
 
     node_ptr / edge_ptr: int64 [G+1] (host or device); edge_index: int64 [2, E_total].  Returns
     ``(out, status)``: ``out`` int64 device tensor [rows_total, plan.n_cols] (rows = vertices in vertex mode, columns
@@ -100,9 +106,26 @@ def count_batch(plan: CountPlan, node_ptr, edge_ptr, edge_index, ids_are_global=
         raise ValueError("edge_index must be [2, E]")
     n_graphs = node_ptr_d.numel() - 1
     E_total = ei.shape[1]
-    if out is None:
-        # rows follow the pointers the kernel uses, not the tensor length (one host read; pass `out` to avoid it)
-        rows_total = int((edge_ptr_d if plan.mode == "edge" else node_ptr_d)[-1].item()) if n_graphs > 0 else 0
+    enc = enc_tab = None
+    rows_total = None
+    if encode is not None or out is None:
+        # rows follow the pointers the kernel uses, not the tensor length (one host read; pass `out` / `encoded_out` to avoid it)
+        if out is not None:
+            rows_total = out.shape[0]
+        elif encoded_out is not None:
+            rows_total = encoded_out.shape[0]
+        else:
+            rows_total = int((edge_ptr_d if plan.mode == "edge" else node_ptr_d)[-1].item()) if n_graphs > 0 else 0
+    if encode is not None:
+        n_classes, clamp = encode
+        n_classes = [int(c) for c in n_classes]
+        if len(n_classes) != plan.n_cols or min(n_classes) < 1:
+            raise ValueError("encode: one n_classes >= 1 per output column (%d columns)" % plan.n_cols)
+        enc_tab = np.asarray(n_classes, dtype=np.int32)
+        enc = encoded_out if encoded_out is not None else torch.empty((rows_total, sum(n_classes)), dtype=torch.float32, device=device)
+        if enc.shape != (rows_total, sum(n_classes)) or enc.dtype != torch.float32 or not enc.is_contiguous():
+            raise ValueError("encoded_out must be a contiguous fp32 [rows, sum(n_classes)] tensor")
+    if out is None and (counts or encode is None):
         out = torch.empty((rows_total, plan.n_cols), dtype=torch.int64, device=device)
     # (the library zeroes the status words of the graphs it counts; with a subset the others must read OK as well)
     status = (torch.zeros if graph_ids is not None or n_graphs == 0 else torch.empty)(max(n_graphs, 1), dtype=torch.int32, device=device)
@@ -113,13 +136,15 @@ def count_batch(plan: CountPlan, node_ptr, edge_ptr, edge_index, ids_are_global=
         n_items = gid.numel()
     if n_graphs > 0 and n_items > 0:
         tab = plan.device_table(device)
+        common = (_abi.ptr(plan.table), tab.data_ptr(), len(plan.table), n_graphs, node_ptr_d.data_ptr(), edge_ptr_d.data_ptr(),
+                  ei.data_ptr() if E_total else None, ei.stride(0), int(bool(ids_are_global)), None if gid is None else gid.data_ptr(),
+                  n_items, int(max_nodes), int(max_edges), None if out is None else out.data_ptr(), status.data_ptr())
         with _abi.device_guard(device):
-            rc = _abi.lib().gsn_count_hip(_abi.ptr(plan.table), tab.data_ptr(), len(plan.table), n_graphs,
-                                          node_ptr_d.data_ptr(), edge_ptr_d.data_ptr(), ei.data_ptr() if E_total else None,
-                                          ei.stride(0), int(bool(ids_are_global)), None if gid is None else gid.data_ptr(),
-                                          n_items, int(max_nodes), int(max_edges), out.data_ptr(), status.data_ptr(),
-                                          _abi.current_stream())
-        _abi.check(rc, "gsn_count_hip")
+            if enc is None:
+                rc = _abi.lib().gsn_count_hip(*common, _abi.current_stream())
+            else:
+                rc = _abi.lib().gsn_count_encode_hip(*common, _abi.ptr(enc_tab), int(bool(encode[1])), enc.data_ptr(), _abi.current_stream())
+        _abi.check(rc, "gsn_count_hip" if enc is None else "gsn_count_encode_hip")
     if check:
         st = status.cpu().numpy()
         if (st == 1).any():
@@ -128,6 +153,8 @@ def count_batch(plan: CountPlan, node_ptr, edge_ptr, edge_index, ids_are_global=
         bad = np.nonzero(st > 1)[0]
         if len(bad):
             raise ValueError("graph %d: %s" % (int(bad[0]), _STATUS_MSG.get(int(st[bad[0]]), "status %d" % st[bad[0]])))
+    if encode is not None:
+        return out, status, enc
     return out, status
 
 

@@ -20,6 +20,8 @@
 
 namespace gsn {
 
+constexpr int GSN_ENC_MAX_COLS = 64;
+
 struct CountArgs {
     const uint32_t *plan;      // device
     int plan_words;
@@ -40,6 +42,14 @@ struct CountArgs {
     int core_mask;             // bit d: some plan needs the d-core
     int off_ain;               // directed plans: the in-neighbour bit matrix
     int stride;                // words per plan (plan_stride)
+    // fused identifier encoding (gsn_count_encode_hip): column c of a finished cell also / instead leaves as n_classes[c] floats
+    // with a single 1 (utils_graph_learning.one_hot_encoder, :170-187) -- the int64 round trip through HBM and the one-hot launch go
+    unsigned short enc_n[GSN_ENC_MAX_COLS];   // n_classes per output column (blocks in column order)
+    float *enc_out;            // [rows_total][enc_width] or null
+    int enc_width, enc_clamp, off_enc;
+    int enc_stage;             // 1: cells leave their class index in an LDS byte array, the rows are expanded and written coalesced at the end
+    int off_encst;             // that array: [rows_cap][n_cols] bytes, 0xff = no class (count out of range, unclamped)
+    uint32_t enc_magic;        // floor(2^32 / enc_width) + 1: row = mulhi(i, magic) for i < rows_cap * enc_width
 };
 
 template <int W, int T, bool DIR>
@@ -59,6 +69,7 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
     uint64_t *balls = a.off_ball >= 0 ? reinterpret_cast<uint64_t *>(smem + a.off_ball) : nullptr;
     uint64_t *cores = reinterpret_cast<uint64_t *>(smem + a.off_core);   // [CORE_MAX + 1][W]
     uint64_t *A_in = DIR ? reinterpret_cast<uint64_t *>(smem + a.off_ain) : nullptr;
+    const int *enc = reinterpret_cast<const int *>(smem + a.off_enc);   // [2 * n_cols] (encoded output only)
 
     const int tid = threadIdx.x;
     const int item = (int)blockIdx.x / a.split, part = (int)blockIdx.x - item * a.split;
@@ -73,7 +84,8 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
     if (n64 > a.n_cap || E64 > a.e_cap || n64 > W * 64) {
         // caller under-declared max_nodes / max_edges: report, leave zeros
         if (part == 0) {
-            for (int64_t i = tid; i < rows64 * n_cols; i += T) a.out[row0 * n_cols + i] = 0;
+            if (a.out) for (int64_t i = tid; i < rows64 * n_cols; i += T) a.out[row0 * n_cols + i] = 0;
+            if (a.enc_out) for (int64_t i = tid; i < rows64 * a.enc_width; i += T) a.enc_out[row0 * a.enc_width + i] = 0.f;
             if (tid == 0) atomicMax(&a.status[g], (int)GSN_ST_TOO_LARGE);
         }
         return;
@@ -85,6 +97,13 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
     if (DIR)
         for (int i = tid; i < n * W; i += T) A_in[i] = 0ull;
     for (int i = tid; i < a.plan_words; i += T) plan[i] = a.plan[i];
+    if (a.enc_out)                                      // (first float, n_classes) per column
+        for (int c = tid; c < n_cols; c += T) {
+            int o = 0;
+            for (int x = 0; x < c; ++x) o += a.enc_n[x];
+            reinterpret_cast<int *>(smem + a.off_enc)[2 * c] = o;
+            reinterpret_cast<int *>(smem + a.off_enc)[2 * c + 1] = a.enc_n[c];
+        }
     if (tid < 4) misc[tid] = 0;
     __syncthreads();
 
@@ -181,7 +200,8 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
     __syncthreads();
     if (misc[2] != 0) {  // bad index: zeros + status
         if (part == 0) {
-            for (int i = tid; i < rows * n_cols; i += T) a.out[row0 * n_cols + i] = 0;
+            if (a.out) for (int i = tid; i < rows * n_cols; i += T) a.out[row0 * n_cols + i] = 0;
+            if (a.enc_out) for (int i = tid; i < rows * a.enc_width; i += T) a.enc_out[row0 * a.enc_width + i] = 0.f;
             if (tid == 0) atomicMax(&a.status[g], misc[2]);
         }
         return;
@@ -270,10 +290,30 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
                 } else {
                     // cell finished
                     if (a.stage_out) out_lds[t_row * n_cols + t_col] = s.cnt;
-                    else a.out[(row0 + t_row) * n_cols + t_col] = (int64_t)s.cnt;
+                    else if (a.out) a.out[(row0 + t_row) * n_cols + t_col] = (int64_t)s.cnt;
                     if (mirror_row >= 0) {
                         if (a.stage_out) out_lds[mirror_row * n_cols + t_col] = s.cnt;
-                        else a.out[(row0 + mirror_row) * n_cols + t_col] = (int64_t)s.cnt;
+                        else if (a.out) a.out[(row0 + mirror_row) * n_cols + t_col] = (int64_t)s.cnt;
+                    }
+                    if (a.enc_out && a.enc_stage) {
+                        const int ncls = enc[2 * t_col + 1];
+                        uint64_t v = s.cnt;
+                        if (a.enc_clamp && v >= (uint64_t)ncls) v = (uint64_t)(ncls - 1);
+                        const unsigned char code = v < (uint64_t)ncls ? (unsigned char)v : (unsigned char)0xff;
+                        unsigned char *est = smem + a.off_encst;
+                        est[t_row * n_cols + t_col] = code;
+                        if (mirror_row >= 0) est[mirror_row * n_cols + t_col] = code;
+                    } else if (a.enc_out) {
+                        const int eo = enc[2 * t_col], ncls = enc[2 * t_col + 1];
+                        uint64_t v = s.cnt;
+                        if (a.enc_clamp && v >= (uint64_t)ncls) v = (uint64_t)(ncls - 1);
+                        float *d0 = a.enc_out + (row0 + t_row) * a.enc_width + eo;
+                        float *d1 = a.enc_out + (row0 + (mirror_row >= 0 ? mirror_row : t_row)) * a.enc_width + eo;
+                        for (int j = 0; j < ncls; ++j) {
+                            const float one = (uint64_t)j == v ? 1.f : 0.f;
+                            d0[j] = one;
+                            if (mirror_row >= 0) d1[j] = one;
+                        }
                     }
                     if (edge_mode && rev_missing && s.cnt != 0) atomicMax(&misc[2], (int)GSN_ST_KEYERROR);
                     has_task = false;
@@ -289,6 +329,41 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
     if (a.stage_out) {   // (only with split == 1)
         int64_t *dst = a.out + row0 * n_cols;
         for (int i = tid; i < n_tasks; i += T) dst[i] = (int64_t)out_lds[i];
+    }
+    // ---- phase 4': encoded rows from the staged class indices, one float per thread and trip, consecutive addresses ----------
+    if (a.enc_out && a.enc_stage) {
+        const unsigned char *est = smem + a.off_encst;
+        float *dst = a.enc_out + row0 * a.enc_width;
+        const int total = rows * a.enc_width;
+        if (n_cols == 4 && (a.enc_width & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+            // four identifier columns (the cycle / clique families of the reference's configurations): a thread owns a row, reads
+            // its four class indices as one word and writes the row as float4s
+            int hot0 = enc[0], hot1 = enc[2], hot2 = enc[4], hot3 = enc[6];
+            for (int r = tid; r < rows; r += T) {
+                const unsigned cw = *reinterpret_cast<const unsigned *>(est + 4 * r);
+                const int c0 = (int)(cw & 0xffu), c1 = (int)((cw >> 8) & 0xffu), c2 = (int)((cw >> 16) & 0xffu), c3 = (int)(cw >> 24);
+                const int h0 = c0 == 0xff ? -1 : hot0 + c0, h1 = c1 == 0xff ? -1 : hot1 + c1;
+                const int h2 = c2 == 0xff ? -1 : hot2 + c2, h3 = c3 == 0xff ? -1 : hot3 + c3;
+                float4 *d4 = reinterpret_cast<float4 *>(dst + r * a.enc_width);
+                for (int k = 0; k < a.enc_width; k += 4) {
+                    float4 o;
+                    o.x = (h0 == k || h1 == k || h2 == k || h3 == k) ? 1.f : 0.f;
+                    o.y = (h0 == k + 1 || h1 == k + 1 || h2 == k + 1 || h3 == k + 1) ? 1.f : 0.f;
+                    o.z = (h0 == k + 2 || h1 == k + 2 || h2 == k + 2 || h3 == k + 2) ? 1.f : 0.f;
+                    o.w = (h0 == k + 3 || h1 == k + 3 || h2 == k + 3 || h3 == k + 3) ? 1.f : 0.f;
+                    d4[k >> 2] = o;
+                }
+            }
+        } else
+        // column c owns floats enc[2c] .. enc[2c] + enc[2c + 1] of a row; the table is short: a linear scan per float
+        for (int i = tid; i < total; i += T) {
+            const int r = (int)__umulhi((unsigned)i, a.enc_magic);
+            const int j = i - r * a.enc_width;
+            int c = 0;
+            while (c + 1 < n_cols && enc[2 * (c + 1)] <= j) ++c;
+            const int k = j - enc[2 * c];
+            dst[i] = (k < enc[2 * c + 1] && (int)est[r * n_cols + c] == k) ? 1.f : 0.f;
+        }
     }
     if (tid == 0 && misc[2] != 0) atomicMax(&a.status[g], misc[2]);   // status[] is zeroed by the launcher
 }
@@ -319,13 +394,15 @@ static int launch(CountArgs &a, int n_items, size_t lds, hipStream_t stream) {
 
 using namespace gsn;
 
-extern "C" int gsn_count_hip(const uint32_t *plan_host, const uint32_t *plan_dev, int64_t plan_words, int64_t n_graphs,
-                             const int64_t *node_ptr, const int64_t *edge_ptr, const int64_t *edge_index,
-                             int64_t edge_row_stride, int ids_are_global, const int32_t *graph_ids, int64_t n_items,
-                             int64_t max_nodes, int64_t max_edges, int64_t *out, int32_t *status, void *stream) {
+static int count_launch(const uint32_t *plan_host, const uint32_t *plan_dev, int64_t plan_words, int64_t n_graphs,
+                        const int64_t *node_ptr, const int64_t *edge_ptr, const int64_t *edge_index,
+                        int64_t edge_row_stride, int ids_are_global, const int32_t *graph_ids, int64_t n_items,
+                        int64_t max_nodes, int64_t max_edges, int64_t *out, int32_t *status, const int32_t *n_classes,
+                        int enc_clamp, float *enc_out, void *stream) {
     if (!plan_host || !plan_dev || plan_words < PLAN_HEADER_WORDS || plan_host[0] != PLAN_MAGIC)
         return set_error(GSN_E_INVALID, "gsn_count_hip: not a plan table (build it with gsn_count_plan_build)");
-    if (!node_ptr || !edge_ptr || !out || !status) return set_error(GSN_E_INVALID, "gsn_count_hip: null pointer argument");
+    if (!node_ptr || !edge_ptr || (!out && !enc_out) || !status) return set_error(GSN_E_INVALID, "gsn_count_hip: null pointer argument");
+    if (enc_out && !n_classes) return set_error(GSN_E_INVALID, "gsn_count_encode_hip: n_classes is null");
     if (!graph_ids) n_items = n_graphs;
     if (n_items <= 0) return GSN_OK;
     if (max_nodes > 768)
@@ -345,6 +422,20 @@ extern "C" int gsn_count_hip(const uint32_t *plan_host, const uint32_t *plan_dev
     a.src = edge_index; a.dst = edge_index ? edge_index + edge_row_stride : nullptr;
     a.ids_are_global = ids_are_global; a.graph_ids = graph_ids;
     a.out = out; a.status = status;
+    a.enc_out = enc_out; a.enc_width = 0; a.enc_clamp = enc_clamp;
+    int64_t enc_width = 0;
+    bool enc_bytes = true;                              // every class index fits a byte (0xff = none)
+    if (enc_out) {
+        if (a.n_cols > GSN_ENC_MAX_COLS)
+            return set_error(GSN_E_UNSUPPORTED, "gsn_count_encode_hip: %d output columns; the fused encoding handles <= %d", a.n_cols, GSN_ENC_MAX_COLS);
+        for (int c = 0; c < a.n_cols; ++c) {
+            if (n_classes[c] < 1 || n_classes[c] > 65535) return set_error(GSN_E_INVALID, "gsn_count_encode_hip: n_classes[%d] = %d", c, n_classes[c]);
+            a.enc_n[c] = (unsigned short)n_classes[c];
+            enc_width += n_classes[c];
+            enc_bytes = enc_bytes && n_classes[c] <= 255;
+        }
+        a.enc_width = (int)enc_width;
+    }
     if (max_edges > 0 && !edge_index) return set_error(GSN_E_INVALID, "gsn_count_hip: edge_index is null");
 
     const int W = max_nodes <= 64 ? 1 : (max_nodes <= 128 ? 2 : (max_nodes <= 256 ? 4 : (max_nodes <= 512 ? 8 : 12)));
@@ -368,6 +459,7 @@ extern "C" int gsn_count_hip(const uint32_t *plan_host, const uint32_t *plan_dev
     a.off_rowstart = o; o += edge_mode ? align_up(((int)max_nodes + 1) * 4, 16) : 0;
     a.off_last = o; o += edge_mode ? align_up((int)max_edges * 4, 16) : 0;
     a.off_misc = o; o += 16;
+    a.off_enc = o; o += enc_out ? align_up(2 * a.n_cols * 4, 16) : 0;
     a.off_core = o; o += align_up((CORE_MAX + 1) * W * 8, 16);
     a.core_mask = 0;
     for (int p = 0; p < a.n_plans; ++p) a.core_mask |= 1 << plan_core(plan_host + a.plans_off + p * a.stride);
@@ -381,7 +473,7 @@ extern "C" int gsn_count_hip(const uint32_t *plan_host, const uint32_t *plan_dev
     // latency-bound on dependent LDS reads, so heavy graphs want as many co-resident workgroups per CU as possible
     // (>= 8 waves per SIMD) and write their cells straight to HBM instead.
     const int64_t lds_budget = (T == 64 ? 160 * 1024 / 32 : 160 * 1024 / 8);
-    a.stage_out = (o + stage_bytes <= lds_budget) ? 1 : 0;
+    a.stage_out = (out && o + stage_bytes <= lds_budget) ? 1 : 0;
     // few heavy graphs: several workgroups per graph so that every CU gets >= 8 of them
     a.split = 1;
     const int64_t tasks_cap = rows_cap * a.n_cols;
@@ -392,6 +484,14 @@ extern "C" int gsn_count_hip(const uint32_t *plan_host, const uint32_t *plan_dev
         if (sp > 1) { a.split = (int)sp; a.stage_out = 0; }
     }
     if (a.stage_out) o += (int)stage_bytes;
+    // class indices of the encoded rows: staged whenever one workgroup owns the whole graph and the indices fit a byte; else
+    // every cell writes its floats itself
+    a.enc_stage = 0; a.off_encst = o; a.enc_magic = 0;
+    if (enc_out && a.split == 1 && enc_bytes && rows_cap * enc_width < (int64_t)1 << 24 && o + rows_cap * a.n_cols <= 150 * 1024) {
+        a.enc_stage = 1;
+        a.enc_magic = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)enc_width + 1);
+        o += align_up((int)(rows_cap * a.n_cols), 16);     // (16-byte aligned: with four columns a row's indices are read as one word)
+    }
     if (o > 160 * 1024) return set_error(GSN_E_UNSUPPORTED, "graph too large for LDS (%d B needed)", o);
 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -409,4 +509,23 @@ extern "C" int gsn_count_hip(const uint32_t *plan_host, const uint32_t *plan_dev
     if (W == 4) return launch<4, 256>(a, items, (size_t)o, st);
     if (W == 8) return launch<8, 64>(a, items, (size_t)o, st);
     return launch<12, 64>(a, items, (size_t)o, st);
+}
+
+extern "C" int gsn_count_hip(const uint32_t *plan_host, const uint32_t *plan_dev, int64_t plan_words, int64_t n_graphs,
+                             const int64_t *node_ptr, const int64_t *edge_ptr, const int64_t *edge_index,
+                             int64_t edge_row_stride, int ids_are_global, const int32_t *graph_ids, int64_t n_items,
+                             int64_t max_nodes, int64_t max_edges, int64_t *out, int32_t *status, void *stream) {
+    if (!out) return set_error(GSN_E_INVALID, "gsn_count_hip: null pointer argument");
+    return count_launch(plan_host, plan_dev, plan_words, n_graphs, node_ptr, edge_ptr, edge_index, edge_row_stride, ids_are_global,
+                        graph_ids, n_items, max_nodes, max_edges, out, status, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int gsn_count_encode_hip(const uint32_t *plan_host, const uint32_t *plan_dev, int64_t plan_words, int64_t n_graphs,
+                                    const int64_t *node_ptr, const int64_t *edge_ptr, const int64_t *edge_index,
+                                    int64_t edge_row_stride, int ids_are_global, const int32_t *graph_ids, int64_t n_items,
+                                    int64_t max_nodes, int64_t max_edges, int64_t *out, int32_t *status,
+                                    const int32_t *n_classes, int clamp, float *enc_out, void *stream) {
+    if (!enc_out) return set_error(GSN_E_INVALID, "gsn_count_encode_hip: enc_out is null");
+    return count_launch(plan_host, plan_dev, plan_words, n_graphs, node_ptr, edge_ptr, edge_index, edge_row_stride, ids_are_global,
+                        graph_ids, n_items, max_nodes, max_edges, out, status, n_classes, clamp, enc_out, stream);
 }

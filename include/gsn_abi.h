@@ -121,6 +121,21 @@ int gsn_count_hip(const uint32_t *plan_host, const uint32_t *plan_dev, int64_t p
                   int64_t edge_row_stride, int ids_are_global, const int32_t *graph_ids, int64_t n_items,
                   int64_t max_nodes, int64_t max_edges, int64_t *out, int32_t *status, void *stream);
 
+/* Counting with the identifier encoding fused into the kernel's output: what the reference does in two steps -- int64 counts
+ * (utils_ids.py:7-29), then DiscreteEmbedding('one_hot_encoder') on them in front of every GSN layer
+ * (utils_graph_learning.py:78 / :170-187, models_graph_classification.py:222) -- in one launch, without the int64 rows going
+ * to HBM and back and without the gsn_one_hot_hip launch.  Arguments as gsn_count_hip, plus
+ *   n_classes  HOST int32 [n_cols] (as gsn_one_hot_hip; n_cols <= 64): column c becomes n_classes[c] floats, blocks in column order
+ *   clamp      != 0: counts above n_classes[c] - 1 go to the last class (as gsn_one_hot_hip)
+ *   enc_out    fp32 device [rows_total][sum n_classes]: per column a single 1 at the count (all 0 when the count is out of
+ *              range and clamp == 0); fully overwritten for the processed graphs
+ *   out        the int64 rows as well, or NULL (then only the encoded rows are written) */
+int gsn_count_encode_hip(const uint32_t *plan_host, const uint32_t *plan_dev, int64_t plan_words, int64_t n_graphs,
+                         const int64_t *node_ptr, const int64_t *edge_ptr, const int64_t *edge_index,
+                         int64_t edge_row_stride, int ids_are_global, const int32_t *graph_ids, int64_t n_items,
+                         int64_t max_nodes, int64_t max_edges, int64_t *out, int32_t *status, const int32_t *n_classes,
+                         int clamp, float *enc_out, void *stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * HP-2  aggregation target index (device).  The scatter-add of the layers,
  *   torch.sparse.FloatTensor(edge_index, msgs, [N,N,d]) + torch.sparse.sum(msgs, aggr_dim).to_dense()

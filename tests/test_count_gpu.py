@@ -290,3 +290,34 @@ def test_sampled_seven_and_eight_vertex_patterns_vs_oracle(k):
         got = counts2ids_batch(b, pats, mode, False).cpu().numpy()
         ref = oracle.counts2ids(mode, False, b.node_ptr, b.edge_ptr, local, pats, n_threads=8)
         assert np.array_equal(got, ref), mode
+
+
+@pytest.mark.parametrize("mode", ["vertex", "edge"])
+def test_count_with_fused_encoding(mode):
+    """gsn_count_encode_hip: the one-hot rows written by the counting kernel equal gsn_one_hot_hip / torch one_hot of the int64
+    counts -- clamped and unclamped, mixed class counts, with and without the int64 rows, graph subsets, a refused graph."""
+    from gsn_amd import synth, layers
+    from gsn_amd.counting import CountPlan, count_batch
+    b = synth.zinc_shape_batch(2000, seed=21)
+    pats = _cycles(range(3, 7))
+    plan = CountPlan.get(pats, mode, False)
+    ref, _ = count_batch(plan, b.node_ptr, b.edge_ptr, b.edge_index)
+    for n_classes, clamp in (([3, 3, 3, 3], True), ([2, 5, 1, 4], True), ([2, 2, 3, 2], False)):
+        want = layers.one_hot_identifiers(ref, n_classes, clamp=clamp)
+        out, st, enc = count_batch(plan, b.node_ptr, b.edge_ptr, b.edge_index, encode=(n_classes, clamp))
+        assert torch.equal(out, ref) and torch.equal(enc, want) and enc.dtype == torch.float32
+        out2, st, enc2 = count_batch(plan, b.node_ptr, b.edge_ptr, b.edge_index, encode=(n_classes, clamp), counts=False)
+        assert out2 is None and torch.equal(enc2, want)
+    # a subset of the graphs into a reused buffer: the other rows are left alone
+    buf = torch.full((ref.shape[0], 12), -5.0, device="cuda")
+    count_batch(plan, b.node_ptr, b.edge_ptr, b.edge_index, graph_ids=[3, 1000], encode=([3, 3, 3, 3], True), counts=False, encoded_out=buf)
+    want = layers.one_hot_identifiers(ref, [3, 3, 3, 3], clamp=True)
+    ptr = b.edge_ptr if mode == "edge" else b.node_ptr
+    for g in (2, 3, 999, 1000, 1001):
+        rows = slice(int(ptr[g]), int(ptr[g + 1]))
+        assert torch.equal(buf[rows], want[rows]) if g in (3, 1000) else bool((buf[rows] == -5.0).all())
+    # a graph beyond the declared sizes: zero rows + status, like the int64 path
+    with pytest.raises(ValueError):
+        count_batch(plan, b.node_ptr, b.edge_ptr, b.edge_index, max_nodes=8, max_edges=200, encode=([3, 3, 3, 3], True))
+    with pytest.raises(ValueError):
+        count_batch(plan, b.node_ptr, b.edge_ptr, b.edge_index, encode=([3, 3, 3], True))
