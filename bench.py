@@ -225,6 +225,10 @@ def main():
     # counting kernel's and the build (0.13 ms alone) stretches past the end of the counting (GSN_SIDE_PRIO=0 to compare)
     side = torch.cuda.Stream(device=dev, priority=-1 if os.environ.get("GSN_SIDE_PRIO", "1") != "0" else 0)
     sel = layer._sel()
+    # the batch's graph boundaries (the pointers the counting kernel takes as well): the layer's target-sorted CSR is then built by
+    # ONE launch, every graph sorted in LDS (gsn_csr_build_graphs_hip), instead of the generic seven
+    if os.environ.get("GSN_BENCH_GENERIC_CSR", "0") == "0":
+        layers.set_graph_partition(ei, node_ptr, edge_ptr, max_nodes, max_edges, check=False)
 
     def step():
         layers._CSR_CACHE.clear()             # the CSR of a fresh batch is part of the forward pass

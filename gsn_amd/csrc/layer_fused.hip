@@ -328,12 +328,12 @@ __device__ __forceinline__ void lf_epilogue(const f32x16 &acc, const float *comb
 // atomics.  256 threads handle 16 nodes (node_base ..): 16 lanes per node, float4 chunks l16 and l16 + 16 of the row.  A tile's
 // sums accumulate in S over its chunks; the last chunk divides the weight scale out.
 template <int WG>
-__device__ __forceinline__ void lf_node_sums(const float *ytile, float *sacc, const int *seg_win, int node_base, int u, int cs_rt, int nn, int e0,
+__device__ __forceinline__ void lf_node_sums(const float *ytile, float *sacc, int w0, int w1, int node_base, int u, int cs_rt, int nn, int e0,
                                              bool first, bool last, float inv_w_e) {
     const int cs = WG ? 8 * WG : cs_rt;
     const int node = node_base + (u >> 4), l16 = u & 15;
     int a0 = 0, a1 = 0;
-    if (node < nn) { a0 = seg_win[node]; a1 = seg_win[node + 1]; }
+    if (node < nn) { a0 = w0; a1 = w1; }          // w0, w1 = seg window entries node, node + 1 (read by the caller, early)
     const int lo = (a0 > e0 ? a0 : e0) - e0, hi = (a1 < e0 + LF_TE ? a1 : e0 + LF_TE) - e0;
     const bool on0 = l16 < cs, on1 = l16 + 16 < cs;
     float *sp = sacc + node * LF_PY + 4 * l16;
@@ -380,6 +380,10 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         __builtin_amdgcn_sched_barrier(0);
         return v;
     };
+    // diagnostic build only: bits 8.. of `prio` switch parts of the work off (GSN_FUSED_ABLATE; results are then garbage) to see
+    // what the step time is sensitive to
+    const int abl = PROF ? (prio >> 8) : 0;
+    prio &= 0xff;
     unsigned long long pc[6] = {0, 0, 0, 0, 0, 0};     // phase-1 work, barrier 1, phase-2 work, barrier 2, bookkeeping, steps
     unsigned long long pe[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // per-group detail, see lf_launch
     constexpr int KE = 16 * NKE, KPE = KE + 8, PLE = LF_TE * KPE;        // halfs
@@ -560,7 +564,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 if (rs_on0) raw0 = rs_p0[er];
                 if (rs_on1) raw1 = rs_p1[er];
             }
-            const bool e1_on = d1.valid() && d1.ne() > 0;
+            const bool e1_on = d1.valid() && d1.ne() > 0 && !(abl & 128);
             if (e1_on) {                                                  // gathers of chunk i + 1 (consumed in phase 2)
                 int sr[2][NCHE];
 #pragma unroll
@@ -585,7 +589,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             const unsigned long long e_2 = clk();
             if (prio) __builtin_amdgcn_s_setprio(2);
             const int d0ne = d0.ne();
-            if (d0.valid() && d0ne > 0 && active) {
+            if (d0.valid() && d0ne > 0 && active && !(abl & 1)) {
                 const _Float16 *ap0 = in_e + li * KPE + 8 * lh, *ap1 = ap0 + 32 * KPE;
                 // The activated rows are kept TIMES the weight scale (Y' = ws * Y, an exact power of two that the per-node sums divide
                 // out again): a chunk whose rows are all exact in fp16 starts its accumulators at ws * c0 and needs no multiply at all.
@@ -621,7 +625,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 if (rs_on1) rsrc[(rs_b + 4) * LF_TE + rs_r] = raw1;
             }
             const unsigned long long e_3 = clk();
-            if (e1_on) {
+            if (e1_on && !(abl & 2)) {
                 bool scaled_any = false, nf_any = false;
 #pragma unroll
                 for (int rr = 0; rr < 2; ++rr) {
@@ -720,7 +724,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 *reinterpret_cast<int4 *>(pub) = make_int4(ts_pk, ts_m0, d0.pk | (more << 20), d0.e0);
             }
             const unsigned long long e_2 = clk();
-            if (ts_pk) {                                                  // [S | x | deg] of the tile whose sums were finished in the last step
+            if (ts_pk && !(abl & 4)) {                                    // [S | x | deg] of the tile whose sums were finished in the last step
                 const int ts_nn = pk_nn(ts_pk);
                 const int *sw = segl + pk_slot(ts_pk) * LF_SEGW + r8;
                 int a0 = 0, a1 = 0;
@@ -749,8 +753,11 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             lds_barrier();
             const unsigned long long c_2 = clk();
             // ---------------- phase 2 ----------------
+            // (this chunk's segment bounds for the per-node sums below: read now, under the matrix products)
+            const int *swp = segl + d0.slot() * LF_SEGW + (t >> 4);
+            const int sw0 = swp[0], sw1 = swp[1];
             if (prio) __builtin_amdgcn_s_setprio(2);
-            if (ts_pk && active) {
+            if (ts_pk && active && !(abl & 8)) {
                 const f32x16 acc = lf_mma_k2<NK0>(in_n + li * KP0 + 8 * lh, PL0, Bh, Bl);
                 float *hp = hp_lane + (step & 1) * (LF_TN * LF_PY);
                 if (cok) {
@@ -760,8 +767,8 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             }
             if (prio) __builtin_amdgcn_s_setprio(0);
             const unsigned long long e_4 = clk();
-            if (d0.valid())                                               // nodes 0 .. 15 of this chunk's tile (group S1: 16 .. 31)
-                lf_node_sums<WG>(ytile, sacc, segl + d0.slot() * LF_SEGW, 0, t, cs_e, d0.nn(), d0.e0, d0.first() != 0, d0.last() != 0, uniform_lds(wtab + 3));
+            if (d0.valid() && !(abl & 16))                                // nodes 0 .. 15 of this chunk's tile (group S1: 16 .. 31)
+                lf_node_sums<WG>(ytile, sacc, sw0, sw1, 0, t, cs_e, d0.nn(), d0.e0, d0.first() != 0, d0.last() != 0, uniform_lds(wtab + 3));
             const unsigned long long c_3 = clk();
             lds_barrier();
             const unsigned long long c_4 = clk();
@@ -805,7 +812,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         // ---------------- phase 1 ----------------
         if (prio) __builtin_amdgcn_s_setprio(2);
         unsigned long long e_1 = c_0;
-        if (tm_pk && active) {
+        if (tm_pk && active && !(abl & 32)) {
             const f32x16 acc = lf_mma_k2<NK1>(mid + li * KP1 + 8 * lh, PL1, Bh, Bl);
             if (PROF) { pe[5] += (unsigned long long)(acc[0] != 12345.f); e_1 = clk(); }   // (forces the products to finish before the reading)
             const __amdgpu_buffer_rsrc_t orow = __builtin_amdgcn_make_buffer_rsrc(a.out + (int64_t)tm_m0 * st_n_out, 0, pk_nn(tm_pk) * rstride, 0x00020000);
@@ -824,8 +831,10 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const int nts_pk = __builtin_amdgcn_readfirstlane(rec.x), nts_m0 = __builtin_amdgcn_readfirstlane(rec.y);
         const int c_pk = __builtin_amdgcn_readfirstlane(rec.z), c_e0 = __builtin_amdgcn_readfirstlane(rec.w);
         more = (c_pk >> 20) & 1;
+        const int *swp = segl + pk_slot(c_pk) * LF_SEGW + 16 + (t >> 4);   // segment bounds of this group's nodes (16 ..) of the current chunk
+        const int sw0 = swp[0], sw1 = swp[1];
         const unsigned long long e_3 = clk();
-        if (th_pk) {                                                      // H of that tile was written in the last step's phase 2
+        if (th_pk && !(abl & 64)) {                                       // H of that tile was written in the last step's phase 2
             const float *hp = htile + ((step - 1) & 1) * (LF_TN * LF_PY) + r8 * LF_PY;
             float4 v[NCH1];
 #pragma unroll
@@ -839,8 +848,8 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             if (nf) flag_e[3] = step + 1;
         }
         const unsigned long long e_4 = clk();
-        if (c_pk & 1)                                                     // nodes 16 .. 31 of this chunk's tile (group S0: 0 .. 15)
-            lf_node_sums<WG>(ytile, sacc, segl + pk_slot(c_pk) * LF_SEGW, 16, t, cs_e, pk_nn(c_pk), c_e0, ((c_pk >> 1) & 1) != 0, ((c_pk >> 2) & 1) != 0, uniform_lds(wtab + 3));
+        if ((c_pk & 1) && !(abl & 16))                                    // nodes 16 .. 31 of this chunk's tile (group S0: 0 .. 15)
+            lf_node_sums<WG>(ytile, sacc, sw0, sw1, 16, t, cs_e, pk_nn(c_pk), c_e0, ((c_pk >> 1) & 1) != 0, ((c_pk >> 2) & 1) != 0, uniform_lds(wtab + 3));
         const unsigned long long c_3 = clk();
         lds_barrier();
         const unsigned long long c_4 = clk();
@@ -880,7 +889,9 @@ static int lf_launch(const LfArgs &a, hipStream_t st) {
     if (getenv("GSN_CHAIN_TRACE")) fprintf(stderr, "gsn chain: layer_fused_kernel<%d,%d,%d,%d> nodes %d edges %d grid %lld\n", NKE, NK0, NK1, WG, a.n_nodes, a.n_edges, (long long)gx);
     unsigned long long *prof = nullptr;
     if (PROF) { (void)hipMalloc(&prof, 24 * 6 * 8); (void)hipMemset(prof, 0, 24 * 6 * 8); }
-    static const int prio = [] { const char *d = getenv("GSN_FUSED_PRIO"); return d ? atoi(d) : 1; }();   // matrix phases at raised wave priority (~1 %)
+    static const int prio_env = [] { const char *d = getenv("GSN_FUSED_PRIO"); return d ? atoi(d) : 1; }();   // matrix phases at raised wave priority (~1 %)
+    int prio = prio_env & 0xff;
+    if (PROF) { const char *d = getenv("GSN_FUSED_ABLATE"); if (d) prio |= atoi(d) << 8; }
     hipLaunchKernelGGL((layer_fused_kernel<NKE, NK0, NK1, WG, PROF>), dim3((unsigned)gx), dim3(768), lds, st, a, prof, prio);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(GSN_E_HIP, "layer_fused_kernel: %s", hipGetErrorString(e));

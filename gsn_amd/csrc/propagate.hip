@@ -391,6 +391,86 @@ static int launch_fwd(const PropArgs &p, hipStream_t st) {
     return hip_check("propagate_fwd_kernel");
 }
 
+
+// ----------------------------------------------------------------------------------------------------------------
+// CSR build of a PyG batch, one wave per GRAPH.  A collated batch is a disjoint union: graph g owns the consecutive
+// columns edge_ptr[g] .. edge_ptr[g+1] of edge_index and the consecutive vertices node_ptr[g] .. node_ptr[g+1], so its
+// columns keep that range in the target-sorted order as well and the whole stable counting sort of a graph -- histogram,
+// scan, placement, order restore -- runs in LDS: one launch, no global atomics, no global scan, every input column read
+// once and every output written once (the generic build above: seven launches over the same data).
+// ----------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void csr_graphs_kernel(const int64_t *__restrict__ node_ptr, const int64_t *__restrict__ edge_ptr, int n_graphs,
+                                                        int64_t n_nodes, int64_t n_edges, int n_cap, int e_cap,
+                                                        const int64_t *__restrict__ index, const int64_t *__restrict__ other,
+                                                        int32_t *seg_ptr, int32_t *perm, int32_t *sorted_target, int32_t *sorted_other,
+                                                        int32_t *status) {
+    extern __shared__ int32_t csr_lds[];
+    int32_t *start = csr_lds;                  // [n_cap + 1] histogram -> exclusive scan
+    int32_t *cur = start + (n_cap + 1);        // [n_cap + 1] placement cursors
+    int32_t *tloc = cur + (n_cap + 1);         // [e_cap] graph-local target of every column
+    int32_t *pl = tloc + e_cap;                // [e_cap] graph-local column ids in target order
+    const int g = blockIdx.x, lane = threadIdx.x;
+    const int64_t n0 = node_ptr[g], e0 = edge_ptr[g];
+    const int64_t n64 = node_ptr[g + 1] - n0, E64 = edge_ptr[g + 1] - e0;
+    if (g == n_graphs - 1)                     // vertices behind the last graph (none in a collated batch) own no columns
+        for (int64_t v = node_ptr[n_graphs] + lane; v <= n_nodes; v += 64) seg_ptr[v] = (int32_t)n_edges;
+    if (g == 0)
+        for (int64_t v = lane; v < n0; v += 64) seg_ptr[v] = 0;
+    if (n64 < 0 || E64 < 0 || n64 > n_cap || E64 > e_cap) {
+        if (lane == 0) atomicMax(status, (int)GSN_ST_TOO_LARGE);
+        return;
+    }
+    const int n = (int)n64, E = (int)E64;
+    for (int v = lane; v <= n; v += 64) start[v] = 0;
+    __syncthreads();
+    bool bad = false;
+    for (int e = lane; e < E; e += 64) {
+        const int64_t t = index[e0 + e] - n0;
+        const bool ok = t >= 0 && t < n;
+        bad = bad || !ok;
+        const int tl = ok ? (int)t : 0;
+        tloc[e] = tl;
+        atomicAdd(&start[tl], 1);
+    }
+    if (bad) atomicMax(status, (int)GSN_ST_BAD_INDEX);      // a column whose target lies outside its graph: not a collated batch
+    __syncthreads();
+    // exclusive scan of the n + 1 counters (start[n] = 0 becomes E), 64 at a time
+    int carry = 0;
+    for (int base = 0; base <= n; base += 64) {
+        const int v = base + lane;
+        const int c = v <= n ? start[v] : 0;
+        int incl = c;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        const int ex = carry + incl - c;
+        if (v <= n) { start[v] = ex; cur[v] = ex; }
+        if (v < n) seg_ptr[n0 + v] = (int32_t)(e0 + ex);
+        carry += __shfl(incl, 63);
+    }
+    __syncthreads();
+    for (int e = lane; e < E; e += 64) pl[atomicAdd(&cur[tloc[e]], 1)] = e;
+    __syncthreads();
+    // restore column order inside every segment (the cursor hands out slots in arbitrary order)
+    for (int v = lane; v < n; v += 64) {
+        const int lo = start[v], hi = start[v + 1];
+        for (int i = lo + 1; i < hi; ++i) {
+            const int x = pl[i];
+            int j = i - 1;
+            while (j >= lo && pl[j] > x) { pl[j + 1] = pl[j]; --j; }
+            pl[j + 1] = x;
+        }
+    }
+    __syncthreads();
+    for (int i = lane; i < E; i += 64) {
+        const int le = pl[i];
+        perm[e0 + i] = (int32_t)(e0 + le);
+        if (sorted_target) sorted_target[e0 + i] = (int32_t)(n0 + tloc[le]);
+        if (sorted_other) sorted_other[e0 + i] = (int32_t)other[e0 + le];
+    }
+}
+
 }  // namespace gsn
 
 using namespace gsn;
@@ -526,4 +606,32 @@ extern "C" int gsn_propagate_bwd_hip(int kind, int64_t n_nodes, int64_t n_edges,
         hipLaunchKernelGGL(propagate_bwd_node_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
     }
     return hip_check("gsn_propagate_bwd_hip");
+}
+
+extern "C" int gsn_csr_build_graphs_hip(int64_t n_graphs, const int64_t *node_ptr, const int64_t *edge_ptr, int64_t n_nodes,
+                                        int64_t n_edges, int64_t max_nodes, int64_t max_edges, const int64_t *index,
+                                        const int64_t *other, int32_t *seg_ptr, int32_t *perm, int32_t *sorted_target,
+                                        int32_t *sorted_other, int32_t *status, void *stream) {
+    if (sorted_other && !other) return set_error(GSN_E_INVALID, "gsn_csr_build_graphs_hip: sorted_other needs `other`");
+    if (n_graphs < 1 || !node_ptr || !edge_ptr || n_nodes < 0 || n_edges < 0 || !seg_ptr || !status || (n_edges > 0 && (!index || !perm)))
+        return set_error(GSN_E_INVALID, "gsn_csr_build_graphs_hip: bad argument");
+    if (n_edges >= (int64_t)1 << 31 || n_nodes >= ((int64_t)1 << 31) - 1 || n_graphs >= (int64_t)1 << 31)
+        return set_error(GSN_E_UNSUPPORTED, "gsn_csr_build_graphs_hip: more than 2^31 edges, vertices or graphs");
+    if (max_nodes < 1) max_nodes = 1;
+    if (max_edges < 1) max_edges = 1;
+    const int64_t lds = (2 * (max_nodes + 1) + 2 * max_edges) * (int64_t)sizeof(int32_t);
+    if (lds > 64 * 1024)
+        return set_error(GSN_E_UNSUPPORTED, "gsn_csr_build_graphs_hip: graphs of up to %lld vertices / %lld columns need %lld B of LDS (limit 64 KiB); use gsn_csr_build_hip",
+                         (long long)max_nodes, (long long)max_edges, (long long)lds);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    static DeviceOnce lds_set;
+    const int lds_dev = current_device();
+    if (!lds_set.done(lds_dev)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&csr_graphs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess)
+            return set_error(GSN_E_HIP, "gsn_csr_build_graphs_hip: cannot raise the LDS limit of csr_graphs_kernel");
+        lds_set.mark(lds_dev);
+    }
+    hipLaunchKernelGGL(csr_graphs_kernel, dim3((unsigned)n_graphs), dim3(64), (size_t)lds, st, node_ptr, edge_ptr, (int)n_graphs, n_nodes, n_edges,
+                       (int)max_nodes, (int)max_edges, index, other, seg_ptr, perm, sorted_target, sorted_other, status);
+    return hip_check("gsn_csr_build_graphs_hip");
 }

@@ -34,7 +34,7 @@ from . import _abi
 
 __all__ = ["mlp", "central_encoder", "GSN_sparse", "GSN_edge_sparse", "MPNN_sparse", "MPNN_edge_sparse",
            "GSN_edge_sparse_ogb", "MPNN_edge_sparse_ogb", "build_csr", "propagate", "run_stages", "one_hot_identifiers",
-           "global_add_pool_sparse", "global_mean_pool_sparse", "Codes", "run_linear_module", "invalidate_caches"]
+           "global_add_pool_sparse", "global_mean_pool_sparse", "Codes", "run_linear_module", "invalidate_caches", "set_graph_partition", "build_csr_graphs"]
 
 _ACT_CODE = {"identity": 0, "relu": 1, "elu": 2, "tanh": 3}
 _MAX_BLOCKS = 5
@@ -180,6 +180,65 @@ def build_csr(index, n_nodes, with_targets=False, other=None):
     return seg_ptr, perm[:E]
 
 
+def build_csr_graphs(index, n_nodes, node_ptr, edge_ptr, max_nodes, max_edges, other=None, check=True):
+    """:func:`build_csr` (with targets) for a collated batch whose graph boundaries are known: ONE launch, every graph sorted in
+    LDS (gsn_csr_build_graphs_hip).  ``node_ptr`` / ``edge_ptr``: int64 device [G + 1].  ``check``: read the status word back
+    (a column that leaves its graph's vertex range means the pointers do not describe this batch -> ValueError)."""
+    _need_cuda(index, "edge_index")
+    index = index.contiguous()
+    E = index.numel()
+    dev = index.device
+    seg_ptr = torch.empty(n_nodes + 1, dtype=torch.int32, device=dev)
+    perm = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+    tgt = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+    src = torch.empty(max(E, 1), dtype=torch.int32, device=dev) if other is not None else None
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    if other is not None:
+        other = other.contiguous()
+    G = node_ptr.numel() - 1
+    with _abi.device_guard(dev), _timed("csr_build", 28.0 * E + 4.0 * n_nodes):
+        _abi.check(_abi.lib().gsn_csr_build_graphs_hip(G, node_ptr.data_ptr(), edge_ptr.data_ptr(), n_nodes, E, int(max_nodes), int(max_edges),
+                                                       index.data_ptr() if E else None, other.data_ptr() if (other is not None and E) else None,
+                                                       seg_ptr.data_ptr(), perm.data_ptr(), tgt.data_ptr(), _abi.ptr(src) if E else None,
+                                                       status.data_ptr(), _abi.current_stream()), "gsn_csr_build_graphs_hip")
+    if check:
+        st = int(status.item())
+        if st:
+            raise ValueError("build_csr_graphs: node_ptr / edge_ptr do not describe this edge_index (status %d)" % st)
+    return seg_ptr, perm[:E], tgt[:E], (src[:E] if src is not None else None)
+
+
+_PARTITION = {}
+_CSR_GRAPHS_LDS = 64 * 1024
+
+
+def set_graph_partition(edge_index, node_ptr, edge_ptr, max_nodes, max_edges, check=True):
+    """Tell the layers that ``edge_index`` (the tensor object later passed to ``forward``) is a collated batch with these graph
+    boundaries (int64 device [G + 1]; what torch_geometric's ``Batch.ptr`` and the counting kernel's pointers hold): its
+    aggregation index is then built by one launch per batch instead of the generic seven (the reference has no counterpart:
+    it re-sorts a COO tensor in every layer, GSN_sparse.py:140-143).  Without this call nothing changes."""
+    _need_cuda(edge_index, "edge_index")
+    if (2 * (int(max_nodes) + 1) + 2 * int(max_edges)) * 4 > _CSR_GRAPHS_LDS:
+        return False                       # graphs too large for the per-graph kernel: the generic build is used
+    key = id(edge_index)
+
+    def _gone(_ref, key=key):
+        hit = _PARTITION.get(key)
+        if hit is not None and hit[0] is _ref:
+            del _PARTITION[key]
+    _PARTITION[key] = (weakref.ref(edge_index, _gone), edge_index._version,
+                       (node_ptr.to(device=edge_index.device, dtype=torch.int64).contiguous(),
+                        edge_ptr.to(device=edge_index.device, dtype=torch.int64).contiguous(), int(max_nodes), int(max_edges), bool(check)))
+    return True
+
+
+def _partition_of(edge_index):
+    hit = _PARTITION.get(id(edge_index))
+    if hit is not None and hit[0]() is edge_index and hit[1] == edge_index._version:
+        return hit[2]
+    return None
+
+
 def _cache_put(key, owner, value):
     """_CSR_CACHE entry that disappears with the tensor it belongs to (weak-reference callback), so batches that are
     dropped do not leave E-sized index tensors behind."""
@@ -209,7 +268,12 @@ def _csr_for(edge_index, row, n_nodes):
     if c is not None:
         return c
     c = _CSR()
-    c.seg_ptr, c.perm, c.tgt, c.src = build_csr(edge_index[row], n_nodes, with_targets=True, other=edge_index[1 - row])
+    part = _partition_of(edge_index)
+    if part is not None:
+        c.seg_ptr, c.perm, c.tgt, c.src = build_csr_graphs(edge_index[row], n_nodes, part[0], part[1], part[2], part[3],
+                                                           other=edge_index[1 - row], check=part[4])
+    else:
+        c.seg_ptr, c.perm, c.tgt, c.src = build_csr(edge_index[row], n_nodes, with_targets=True, other=edge_index[1 - row])
     c._deg = c._deg4 = None
     _cache_put(key, edge_index, c)
     return c

@@ -20,6 +20,15 @@ from .layers import (GSN_edge_sparse, GSN_edge_sparse_ogb, GSN_sparse, MPNN_edge
                      choose_activation, global_add_pool_sparse, global_mean_pool_sparse, mlp, run_linear_module)
 
 
+def _register_partition(data, edge_index):
+    """A batch object may carry ``graph_partition = (node_ptr, edge_ptr, max_nodes, max_edges)`` (int64 [G + 1] pointers of the
+    collated graphs): the layers then build their aggregation index with one launch per batch (layers.set_graph_partition)."""
+    part = getattr(data, "graph_partition", None)
+    if part is not None and edge_index.is_cuda:
+        from . import layers as _layers
+        _layers.set_graph_partition(edge_index, part[0], part[1], part[2], part[3])
+
+
 class GNNSubstructures(nn.Module):
     def __init__(self, in_features, out_features, encoder_ids, d_in_id, in_edge_features=None, d_in_node_encoder=None,
                  d_in_edge_encoder=None, encoder_degrees=None, d_degree=None, **kwargs):
@@ -110,6 +119,7 @@ class GNNSubstructures(nn.Module):
     def forward(self, data, print_flag=False, return_intermediate=False):
         kwargs = {"degrees": self.degree_encoder(data.degrees)}
         edge_index = data.edge_index
+        _register_partition(data, edge_index)
         x = self.input_node_encoder(data.x)
         if self.random_features:
             r = torch.rand(size=(x.shape[0], self.r_d_out), device=x.device).float()

@@ -268,6 +268,22 @@ int gsn_layer_fused_fwd_hip(int64_t n_nodes, int64_t n_edges, const int32_t *seg
                             const float *x, int64_t d_x, const gsn_chain_stage *node0, const gsn_chain_stage *node1,
                             float *out, void *stream);
 
+/* The same CSR for a PyG-collated batch, one launch.  A batch is a disjoint union (torch_geometric's Batch / the reference's
+ * DataLoader, main.py:19, utils_data_prep.py:35-60): graph g owns the consecutive columns edge_ptr[g] .. edge_ptr[g+1] of
+ * edge_index and the consecutive vertices node_ptr[g] .. node_ptr[g+1], so every graph is sorted on its own in LDS (one wave
+ * per graph) -- no global atomics, no global scan, same stable result as gsn_csr_build_hip.
+ *   node_ptr, edge_ptr  int64 device [n_graphs + 1] (the arrays gsn_count_hip takes)
+ *   max_nodes, max_edges  upper bounds over the graphs (size LDS: (2 (max_nodes + 1) + 2 max_edges) * 4 B <= 64 KiB, else
+ *                       GSN_E_UNSUPPORTED -> use gsn_csr_build_hip)
+ *   index, other, seg_ptr, perm, sorted_target, sorted_other   as gsn_csr_build_hip
+ *   status              int32 device [1], zeroed by the caller: raised to GSN_ST_BAD_INDEX when a column's `index` entry lies
+ *                       outside its graph's vertex range (the arrays do not describe a collated batch; outputs are then
+ *                       unspecified), GSN_ST_TOO_LARGE when a graph exceeds max_nodes / max_edges */
+int gsn_csr_build_graphs_hip(int64_t n_graphs, const int64_t *node_ptr, const int64_t *edge_ptr, int64_t n_nodes,
+                             int64_t n_edges, int64_t max_nodes, int64_t max_edges, const int64_t *index,
+                             const int64_t *other, int32_t *seg_ptr, int32_t *perm, int32_t *sorted_target,
+                             int32_t *sorted_other, int32_t *status, void *stream);
+
 int gsn_segsum_prepare_hip(int64_t n_seg, int64_t n_rows, const int32_t *seg_ptr, const int32_t *row_target,
                            int64_t n_out, float *out, void *stream);
 

@@ -28,7 +28,7 @@ def main():
             w.writerow(head)
             w.writerows(body)
     acc = defaultdict(lambda: defaultdict(list))
-    for stem in ("p_counter_collection.csv", "f_counter_collection.csv", "w_counter_collection.csv"):
+    for stem in ("p_counter_collection.csv", "q_counter_collection.csv", "f_counter_collection.csv", "w_counter_collection.csv"):
         p = find(src, stem)
         if not p:
             continue

@@ -536,3 +536,48 @@ def test_fused_scatter_add_with_bf16_exact_inputs(mix):
     msg = torch.relu(torch.cat([x[tgt], x[src], ids, ef], 1).double() @ W.double().T + b.double())
     ref = torch.zeros(N, 128, dtype=torch.float64, device=dev).index_add_(0, tgt, msg)
     assert rel_err(out.double(), ref) < TOL
+
+
+def test_csr_of_a_collated_batch_in_one_launch():
+    """gsn_csr_build_graphs_hip (one wave per graph, sorted in LDS) against the generic gsn_csr_build_hip: identical seg_ptr,
+    perm, sorted targets and sources for both rows of edge_index; duplicates, self loops, empty graphs, vertices without
+    columns; pointers that do not describe the batch are reported; graphs beyond the LDS bound fall back."""
+    import numpy as np
+    from gsn_amd import layers, synth
+    rng = np.random.default_rng(3)
+    graphs = [synth.zinc_shape_graph(rng) for _ in range(700)]
+    graphs[5] = (4, np.zeros((2, 0), np.int64))                                    # no columns
+    graphs[9] = (6, np.array([[0, 1, 1, 1, 2, 2, 5, 5], [1, 0, 0, 1, 2, 1, 0, 0]]))   # duplicates, self loops
+    graphs[40] = synth.er_graph(300, 2500, 1)
+    b = synth.collate(graphs)
+    dev = torch.device("cuda")
+    ei = torch.from_numpy(b.edge_index).to(dev)
+    npt, ept = torch.from_numpy(b.node_ptr).to(dev), torch.from_numpy(b.edge_ptr).to(dev)
+    mn, me = int(np.diff(b.node_ptr).max()), int(np.diff(b.edge_ptr).max())
+    N = b.num_nodes
+    for row in (0, 1):
+        want = layers.build_csr(ei[row], N, with_targets=True, other=ei[1 - row])
+        got = layers.build_csr_graphs(ei[row], N, npt, ept, mn, me, other=ei[1 - row])
+        for a, c in zip(want, got):
+            assert torch.equal(a, c)
+    # wrong pointers: a column leaves its graph -> reported
+    bad = ept.clone()
+    bad[3] += 2
+    with pytest.raises(ValueError):
+        layers.build_csr_graphs(ei[1], N, npt, bad, mn, me + 2, other=ei[0])
+    with pytest.raises(ValueError):                                   # under-declared bound
+        layers.build_csr_graphs(ei[1], N, npt, ept, mn, 100, other=ei[0])
+    assert layers.set_graph_partition(ei, npt, ept, 40000, 100000) is False      # beyond the LDS bound: generic build
+    # a layer forward is the same with and without the partition
+    torch.manual_seed(0)
+    layer = layers.GSN_edge_sparse(d_in=8, d_ef=4, d_id=4, d_degree=1, degree_as_tag=False, retain_features=True, id_scope="local", d_msg=32,
+                                   d_up=32, d_h=[32], seed=0, activation_name="relu", bn=False, msg_kind="general", flow="source_to_target").to(dev).eval()
+    g = torch.Generator().manual_seed(1)
+    x, ids, ef = torch.randn(N, 8, generator=g).to(dev), torch.randn(b.num_edges, 4, generator=g).to(dev), torch.randn(b.num_edges, 4, generator=g).to(dev)
+    with torch.no_grad():
+        y0 = layer(x, ei, identifiers=ids, degrees=torch.zeros(N, device=dev), edge_features=ef)
+        layers._CSR_CACHE.clear()
+        assert layers.set_graph_partition(ei, npt, ept, mn, me) is True
+        y1 = layer(x, ei, identifiers=ids, degrees=torch.zeros(N, device=dev), edge_features=ef)
+    assert torch.equal(y0, y1)
+    layers._PARTITION.clear()
