@@ -37,6 +37,7 @@ struct CountArgs {
     int32_t *status;
     // LDS byte offsets
     int off_valid, off_stack, off_plan, off_eu, off_ev, off_rowstart, off_last, off_out, off_misc;
+    int off_prim, off_revof;   // edge mode: the rows that run searches, in column order; per column the last column of the reverse pair
     int off_ball;              // distance-pruning tables (radius 2, radius 3: n_cap rows each) or -1
     int off_core;              // d-cores of the graph, d = 0 .. CORE_MAX (W words each)
     int core_mask;             // bit d: some plan needs the d-core
@@ -64,6 +65,8 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
     vid_t *ev = reinterpret_cast<vid_t *>(smem + a.off_ev);
     int *rowstart = reinterpret_cast<int *>(smem + a.off_rowstart);
     int *last = reinterpret_cast<int *>(smem + a.off_last);
+    int *prim = reinterpret_cast<int *>(smem + a.off_prim);
+    int *revof = reinterpret_cast<int *>(smem + a.off_revof);
     uint64_t *out_lds = reinterpret_cast<uint64_t *>(smem + a.off_out);
     int *misc = reinterpret_cast<int *>(smem + a.off_misc);  // [0] next task  [1] n_active  [2] status
     uint64_t *balls = a.off_ball >= 0 ? reinterpret_cast<uint64_t *>(smem + a.off_ball) : nullptr;
@@ -91,6 +94,24 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
         return;
     }
     const int n = (int)n64, E = (int)E64, rows = (int)rows64;
+
+    // one finished cell (row, column) = cnt: the int64 row (staged or direct), the staged class index or the encoded floats
+    auto emit_cell = [&](int row, int col, uint64_t cnt) {
+        if (a.stage_out) out_lds[row * n_cols + col] = cnt;
+        else if (a.out) a.out[(row0 + row) * n_cols + col] = (int64_t)cnt;
+        if (a.enc_out) {
+            const int *enc_t = reinterpret_cast<const int *>(smem + a.off_enc);
+            const int eo = enc_t[2 * col], ncls = enc_t[2 * col + 1];
+            uint64_t v = cnt;
+            if (a.enc_clamp && v >= (uint64_t)ncls) v = (uint64_t)(ncls - 1);
+            if (a.enc_stage) {
+                (smem + a.off_encst)[row * n_cols + col] = v < (uint64_t)ncls ? (unsigned char)v : (unsigned char)0xff;
+            } else {
+                float *d0 = a.enc_out + (row0 + row) * a.enc_width + eo;
+                for (int j = 0; j < ncls; ++j) d0[j] = (uint64_t)j == v ? 1.f : 0.f;
+            }
+        }
+    };
 
     // ---- phase 0: clear LDS state, copy the plan table ------------------------------------------------------------
     for (int i = tid; i < n * W; i += T) A[i] = 0ull;
@@ -176,15 +197,27 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
         for (int v = tid; v < n; v += T) ball_expand<W>(A, balls, v, balls + a.n_cap * W);
     }
 
-    // ---- phase 2 (edge mode): CSR rank of every directed pair, last-duplicate-wins column -------------------------
+    // ---- phase 2 (edge mode): CSR rank of every directed pair, last-duplicate-wins column, the rows that search ---------
     if (edge_mode) {
-        for (int u = tid; u <= n; u += T) {
-            int s = 0;
-            for (int x = 0; x < u; ++x) {
+        if (W == 1 && T == 64) {                 // one wave, n <= 64: the row starts are a wave prefix sum of the degrees
+            const int d = tid < n ? popc64(A[tid]) : 0;
+            int incl = d;
 #pragma unroll
-                for (int w = 0; w < W; ++w) s += popc64(A[x * W + w]);
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(incl, o);
+                if (tid >= o) incl += t;
             }
-            rowstart[u] = s;
+            if (tid <= n) rowstart[tid] = incl - d;
+            if (tid == 63 && n == 64) rowstart[64] = incl;
+        } else {
+            for (int u = tid; u <= n; u += T) {
+                int s = 0;
+                for (int x = 0; x < u; ++x) {
+#pragma unroll
+                    for (int w = 0; w < W; ++w) s += popc64(A[x * W + w]);
+                }
+                rowstart[u] = s;
+            }
         }
         for (int i = tid; i < E; i += T) last[i] = -1;
         __syncthreads();
@@ -194,7 +227,42 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
             int r = rowstart[u];
 #pragma unroll
             for (int w = 0; w < W; ++w) r += popc64(A[u * W + w] & below_word(v, w));
+            revof[c] = r;                        // (its slot, until the pass below replaces it)
             atomicMax(&last[r], c);
+        }
+        __syncthreads();
+        // Per column, once (not per task): is it the column that carries the counts of its pair (the last duplicate,
+        // utils_graph_processing.py:142-144), which column carries the reverse pair, and does it search at all?  Undirected orbit
+        // classes: every map that puts a pattern edge (a,b) on (u,v) puts (b,a), same class, on (v,u), so the two rows are equal
+        // -- the u < v row searches and writes both.  Rows that carry nothing (self loops, earlier duplicates) get their zeros
+        // here.  The searching rows are compacted IN COLUMN ORDER by one wave: every workgroup of a split graph enumerates the
+        // same task list.
+        if (tid < 64) {
+            int n_prim = 0;
+            for (int c0 = 0; c0 < E; c0 += 64) {
+                const int c = c0 + tid;
+                bool primary = false;
+                if (c < E) {
+                    const int u = eu[c], v = ev[c];
+                    bool live = false;
+                    int rev = -1;
+                    if (u != v) {
+                        live = last[revof[c]] == c;
+                        int rr = rowstart[v];
+#pragma unroll
+                        for (int w = 0; w < W; ++w) rr += popc64(A[v * W + w] & below_word(u, w));
+                        rev = last[rr];
+                    }
+                    revof[c] = rev;
+                    primary = live && !(a.sym && rev >= 0 && u > v);
+                    if (!live && part == 0)
+                        for (int col = 0; col < n_cols; ++col) emit_cell(c, col, 0ull);
+                }
+                const uint64_t pm = __ballot(primary);
+                if (primary) prim[n_prim + __popcll(pm & ((1ull << tid) - 1ull))] = c;
+                n_prim += __popcll(pm);
+            }
+            if (tid == 0) misc[3] = n_prim;
         }
     }
     __syncthreads();
@@ -210,8 +278,11 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
     // ---- phase 3: task pool -- (column, row) cells, pulled by lanes as they go idle --------------------------------
     // this workgroup takes the tasks  part, part + split, part + 2*split, ...  (strided, so the heavy columns of a
     // pattern family are spread over all the workgroups of a graph); n_tasks = how many of them
-    const int n_tasks_all = rows * n_cols;
+    const int n_div = edge_mode ? misc[3] : rows;            // rows that run searches
+    const int n_tasks_all = n_div * n_cols;
     const int n_tasks = n_tasks_all > part ? (n_tasks_all - part + a.split - 1) / a.split : 0;
+    const float div_rcp = n_div > 0 ? 1.0f / (float)n_div : 0.f;
+    const bool div_float = n_tasks_all < (1 << 22);        // task index exact in fp32: quotient by one multiply + one correction
     const uint32_t *col_ptr = plan + PLAN_HEADER_WORDS;
     const uint32_t *plans = plan + a.plans_off;
     const int lane = tid & 63;
@@ -241,36 +312,29 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
                 const int t = base + __popcll(m & lane_lt);
                 if (t < n_tasks) {
                     const int tt = part + t * a.split;
-                    t_col = tt / rows;
-                    t_row = tt - t_col * rows;
+                    int t_idx;
+                    if (div_float) {
+                        t_col = (int)((float)tt * div_rcp);
+                        t_idx = tt - t_col * n_div;
+                        if (t_idx < 0) { --t_col; t_idx += n_div; }
+                        if (t_idx >= n_div) { ++t_col; t_idx -= n_div; }
+                    } else {
+                        t_col = tt / n_div;
+                        t_idx = tt - t_col * n_div;
+                    }
                     has_task = true;
                     s.cnt = 0; s.l = -1;
                     p_i = (int)col_ptr[t_col]; p_e = (int)col_ptr[t_col + 1];
                     rev_missing = false;
                     mirror_row = -1;
                     if (edge_mode) {
-                        const int u = eu[t_row], v = ev[t_row];
-                        bool live = u != v;
-                        if (live) {
-                            int r = rowstart[u];
-#pragma unroll
-                            for (int w = 0; w < W; ++w) r += popc64(A[u * W + w] & below_word(v, w));
-                            live = last[r] == t_row;  // earlier duplicates of (u,v) keep 0 (utils_graph_processing.py:142-144)
-                            int rr = rowstart[v];
-#pragma unroll
-                            for (int w = 0; w < W; ++w) rr += popc64(A[v * W + w] & below_word(u, w));
-                            const int rev = last[rr];
-                            rev_missing = rev < 0;
-                            // Undirected orbit classes: every map that puts a pattern edge (a,b) on (u,v) puts (b,a), same
-                            // class, on (v,u), so the two rows are equal.  The u < v row searches and writes both cells.
-                            if (live && a.sym && rev >= 0) {
-                                if (u > v) has_task = false;
-                                else mirror_row = rev;
-                            }
-                        }
-                        if (!live) p_i = p_e;
-                        roots = fv_roots<W>(u, v);
+                        t_row = prim[t_idx];
+                        const int rev = revof[t_row];
+                        rev_missing = rev < 0;
+                        if (a.sym && rev >= 0) mirror_row = rev;
+                        roots = fv_roots<W>(eu[t_row], ev[t_row]);
                     } else {
+                        t_row = t_idx;
                         if (t_row >= n_active) p_i = p_e;  // vertex beyond the largest id: not a vertex of the matched graph
                         roots = fv_roots<W>(t_row, 0);
                     }
@@ -289,32 +353,8 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
                     ++p_i;
                 } else {
                     // cell finished
-                    if (a.stage_out) out_lds[t_row * n_cols + t_col] = s.cnt;
-                    else if (a.out) a.out[(row0 + t_row) * n_cols + t_col] = (int64_t)s.cnt;
-                    if (mirror_row >= 0) {
-                        if (a.stage_out) out_lds[mirror_row * n_cols + t_col] = s.cnt;
-                        else if (a.out) a.out[(row0 + mirror_row) * n_cols + t_col] = (int64_t)s.cnt;
-                    }
-                    if (a.enc_out && a.enc_stage) {
-                        const int ncls = enc[2 * t_col + 1];
-                        uint64_t v = s.cnt;
-                        if (a.enc_clamp && v >= (uint64_t)ncls) v = (uint64_t)(ncls - 1);
-                        const unsigned char code = v < (uint64_t)ncls ? (unsigned char)v : (unsigned char)0xff;
-                        unsigned char *est = smem + a.off_encst;
-                        est[t_row * n_cols + t_col] = code;
-                        if (mirror_row >= 0) est[mirror_row * n_cols + t_col] = code;
-                    } else if (a.enc_out) {
-                        const int eo = enc[2 * t_col], ncls = enc[2 * t_col + 1];
-                        uint64_t v = s.cnt;
-                        if (a.enc_clamp && v >= (uint64_t)ncls) v = (uint64_t)(ncls - 1);
-                        float *d0 = a.enc_out + (row0 + t_row) * a.enc_width + eo;
-                        float *d1 = a.enc_out + (row0 + (mirror_row >= 0 ? mirror_row : t_row)) * a.enc_width + eo;
-                        for (int j = 0; j < ncls; ++j) {
-                            const float one = (uint64_t)j == v ? 1.f : 0.f;
-                            d0[j] = one;
-                            if (mirror_row >= 0) d1[j] = one;
-                        }
-                    }
+                    emit_cell(t_row, t_col, s.cnt);
+                    if (mirror_row >= 0) emit_cell(mirror_row, t_col, s.cnt);
                     if (edge_mode && rev_missing && s.cnt != 0) atomicMax(&misc[2], (int)GSN_ST_KEYERROR);
                     has_task = false;
                 }
@@ -328,7 +368,7 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
     // ---- phase 4: coalesced write of the staged rows --------------------------------------------------------------
     if (a.stage_out) {   // (only with split == 1)
         int64_t *dst = a.out + row0 * n_cols;
-        for (int i = tid; i < n_tasks; i += T) dst[i] = (int64_t)out_lds[i];
+        for (int i = tid; i < rows * n_cols; i += T) dst[i] = (int64_t)out_lds[i];
     }
     // ---- phase 4': encoded rows from the staged class indices, one float per thread and trip, consecutive addresses ----------
     if (a.enc_out && a.enc_stage) {
@@ -458,6 +498,8 @@ static int count_launch(const uint32_t *plan_host, const uint32_t *plan_dev, int
     a.off_ev = o; o += edge_mode ? align_up((int)max_edges * vid_bytes, 16) : 0;
     a.off_rowstart = o; o += edge_mode ? align_up(((int)max_nodes + 1) * 4, 16) : 0;
     a.off_last = o; o += edge_mode ? align_up((int)max_edges * 4, 16) : 0;
+    a.off_prim = o; o += edge_mode ? align_up((int)max_edges * 4, 16) : 0;
+    a.off_revof = o; o += edge_mode ? align_up((int)max_edges * 4, 16) : 0;
     a.off_misc = o; o += 16;
     a.off_enc = o; o += enc_out ? align_up(2 * a.n_cols * 4, 16) : 0;
     a.off_core = o; o += align_up((CORE_MAX + 1) * W * 8, 16);
