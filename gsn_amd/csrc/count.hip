@@ -284,6 +284,7 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
     const float div_rcp = n_div > 0 ? 1.0f / (float)n_div : 0.f;
     const bool div_float = n_tasks_all < (1 << 22);        // task index exact in fp32: quotient by one multiply + one correction
     const uint32_t *col_ptr = plan + PLAN_HEADER_WORDS;
+    const uint32_t *col_order = col_ptr + n_cols + 1;
     const uint32_t *plans = plan + a.plans_off;
     const int lane = tid & 63;
     const uint64_t lane_lt = (1ull << lane) - 1ull;
@@ -322,6 +323,9 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
                         t_col = tt / n_div;
                         t_idx = tt - t_col * n_div;
                     }
+                    // columns in the plan compiler's order of falling estimated cost: the lanes that go idle at the end of the pool
+                    // should be left with the short searches, not with the long ones
+                    t_col = (int)col_order[t_col];
                     has_task = true;
                     s.cnt = 0; s.l = -1;
                     p_i = (int)col_ptr[t_col]; p_e = (int)col_ptr[t_col + 1];

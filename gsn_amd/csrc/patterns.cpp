@@ -361,7 +361,7 @@ extern "C" int gsn_count_plan_build(int mode, int induced, int directed_orbits, 
     }
     // group the plans of one output column together: a kernel task is (column, row) and runs that column's plans
     std::stable_sort(plans.begin(), plans.end(), [](const Plan &a, const Plan &b) { return a.out_col < b.out_col; });
-    const int64_t plans_off = PLAN_HEADER_WORDS + (col0 + 1);
+    const int64_t plans_off = PLAN_HEADER_WORDS + (col0 + 1) + col0;
     int64_t words = plans_off + (int64_t)plans.size() * stride;
     if (out_words) *out_words = words;
     if (out_n_cols) *out_n_cols = col0;
@@ -376,6 +376,29 @@ extern "C" int gsn_count_plan_build(int mode, int induced, int directed_orbits, 
             while (i < plans.size() && plans[i].out_col < c) ++i;
             cp[c] = (uint32_t)i;
         }
+    }
+    {   // col_order: the columns by falling estimated search cost.  The kernel hands out the (column, row) cells of a graph in this
+        // column order, so the lanes that go idle at the end of the pool are left with the short searches.  Estimate per plan:
+        // product over the enumerated levels (the last one is counted by popcount) of a branching factor -- the whole graph for
+        // a level without an adjacency constraint, an assumed degree shrinking with every further adjacency / order constraint.
+        std::vector<double> cost((size_t)col0, 0.0);
+        for (const Plan &pl : plans) {
+            double c = 1.0;
+            for (int l = pl.n_fixed; l + 1 < pl.k; ++l) {
+                const uint32_t d = pl.level[l], din = pl.level_in[l];
+                const int n_adj = __builtin_popcount(d & 0xffu) + __builtin_popcount(din & 0xffu);
+                const int n_ord = __builtin_popcount(d >> 16);
+                double b = n_adj == 0 ? 24.0 : 4.0 / n_adj;
+                if (n_ord) b *= 0.5;
+                c *= b < 1.0 ? 1.0 : b;
+            }
+            cost[(size_t)pl.out_col] += c;
+        }
+        std::vector<int> order((size_t)col0);
+        for (int c = 0; c < col0; ++c) order[(size_t)c] = c;
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return cost[(size_t)x] > cost[(size_t)y]; });
+        uint32_t *co = plan + PLAN_HEADER_WORDS + (col0 + 1);
+        for (int c = 0; c < col0; ++c) co[c] = (uint32_t)order[(size_t)c];
     }
     for (size_t i = 0; i < plans.size(); ++i) {
         uint32_t *w = plan + plans_off + i * stride;
