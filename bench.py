@@ -134,6 +134,52 @@ def work_figures(plan_patterns, ids_out):
     return float(col_sums.sum()), float(maps)
 
 
+def full_model_closure(dev, gm, batch=None):
+    """count + the FULL model of BASELINE configs[1] (GNNSubstructures, 4 layers: layer 0 is GSN_edge_sparse, layers 1-3
+    MPNN_edge_sparse with K = 260 edge rows -- the any-shape dense kernels; one-hot encoders, jk, sum readout, eval) over `gm`
+    ZINC-shaped graphs -> (step function, gm).  Also used by scripts/profile_full_model.py."""
+    import types
+    import networkx as nx
+    import torch
+    from gsn_amd import layers, models
+    from gsn_amd.counting import CountPlan, count_batch
+    if batch is None:
+        b = make_batch(gm, seed=1000)
+        node_ptr = torch.from_numpy(b.node_ptr).to(dev)
+        edge_ptr = torch.from_numpy(b.edge_ptr).to(dev)
+        ei = torch.from_numpy(b.edge_index).to(dev)
+        plan = CountPlan.get([list(nx.cycle_graph(k).edges) for k in range(3, 7)], "edge", False)
+        max_nodes, max_edges = int(np.diff(b.node_ptr).max()), int(np.diff(b.edge_ptr).max())
+    else:
+        b, node_ptr, edge_ptr, ei, plan, max_nodes, max_edges = batch
+    L4, d4 = 4, 128
+    kw = dict(seed=0, model_name="GSN_edge_sparse", readout="sum", dropout_features=[0.0] * (L4 + 1), bn=[True] * L4,
+              final_projection=[False] * L4 + [True], inject_ids=False, inject_edge_features=True, random_features=False,
+              id_scope="local", d_msg=[d4] * L4, d_out=[d4] * L4, d_h=[[d4]] * L4, aggr="add", flow="source_to_target",
+              msg_kind="general", train_eps=[False] * L4, activation_mlp="relu", bn_mlp=True, jk_mlp=True, degree_embedding="None",
+              degree_as_tag=[False] * L4, retain_features=[True] * L4, multi_embedding_aggr="sum", input_node_encoder="one_hot_encoder",
+              d_out_node_encoder=d4, edge_encoder="one_hot_encoder", d_out_edge_encoder=[d4] * L4, id_embedding="one_hot_encoder",
+              d_out_id_embedding=d4, d_out_degree_embedding=d4, extend_dims=True, activation="relu")
+    torch.manual_seed(0)
+    n4, e4 = int(b.node_ptr[gm]), int(b.edge_ptr[gm])
+    model = models.GNNSubstructures(1, 1, None, [3, 3, 3, 3], 1, [28], [4], None, None, **kw).to(dev).eval()
+    np4, ep4 = node_ptr[:gm + 1].contiguous(), edge_ptr[:gm + 1].contiguous()
+    ei4 = ei[:, :e4].contiguous()
+    ids4 = torch.empty((e4, plan.n_cols), dtype=torch.int64, device=dev)
+    data4 = types.SimpleNamespace(x=torch.from_numpy(b.atom_type[:n4]).unsqueeze(1).to(dev), edge_index=ei4,
+                                  edge_features=torch.from_numpy(b.bond_type[:e4]).unsqueeze(1).to(dev), identifiers=None,
+                                  batch=torch.from_numpy(np.asarray(b.batch)[:n4].astype(np.int64)).to(dev), degrees=torch.zeros(n4, device=dev),
+                                  graph_partition=(np4, ep4, max_nodes, max_edges))
+
+    def step_model():
+        layers._CSR_CACHE.clear()
+        count_batch(plan, np4, ep4, ei4, ids_are_global=True, max_nodes=max_nodes, max_edges=max_edges, device=dev, out=ids4, check=False)
+        data4.identifiers = ids4.clamp(max=2)
+        with torch.no_grad():
+            return model(data4)
+    return step_model, gm
+
+
 def dry_run(args):
     """--dry-run: everything around the kernels (rank launch, process group, barrier-bracketed timing, MAX over ranks, one
     JSON line from rank 0) with an empty step, so the N > 1 entry point is testable on a box without GPUs (gloo)."""
@@ -350,33 +396,8 @@ def main():
     # readout, eval) on the same batch.
     model4 = None
     if world == 1 and not args.no_extras:
-        import types
-        from gsn_amd import models
-        L4, d4 = 4, 128
-        kw = dict(seed=0, model_name="GSN_edge_sparse", readout="sum", dropout_features=[0.0] * (L4 + 1), bn=[True] * L4,
-                  final_projection=[False] * L4 + [True], inject_ids=False, inject_edge_features=True, random_features=False,
-                  id_scope="local", d_msg=[d4] * L4, d_out=[d4] * L4, d_h=[[d4]] * L4, aggr="add", flow="source_to_target",
-                  msg_kind="general", train_eps=[False] * L4, activation_mlp="relu", bn_mlp=True, jk_mlp=True, degree_embedding="None",
-                  degree_as_tag=[False] * L4, retain_features=[True] * L4, multi_embedding_aggr="sum", input_node_encoder="one_hot_encoder",
-                  d_out_node_encoder=d4, edge_encoder="one_hot_encoder", d_out_edge_encoder=[d4] * L4, id_embedding="one_hot_encoder",
-                  d_out_id_embedding=d4, d_out_degree_embedding=d4, extend_dims=True, activation="relu")
-        torch.manual_seed(0)
-        gm = min(G, 16384)
-        n4, e4 = int(b.node_ptr[gm]), int(b.edge_ptr[gm])
-        model = models.GNNSubstructures(1, 1, None, [3, 3, 3, 3], 1, [28], [4], None, None, **kw).to(dev).eval()
-        np4, ep4 = node_ptr[:gm + 1].contiguous(), edge_ptr[:gm + 1].contiguous()
-        ei4 = ei[:, :e4].contiguous()
-        ids4 = torch.empty((e4, plan.n_cols), dtype=torch.int64, device=dev)
-        data4 = types.SimpleNamespace(x=torch.from_numpy(b.atom_type[:n4]).unsqueeze(1).to(dev), edge_index=ei4,
-                                      edge_features=torch.from_numpy(b.bond_type[:e4]).unsqueeze(1).to(dev), identifiers=None,
-                                      batch=torch.from_numpy(np.asarray(b.batch)[:n4].astype(np.int64)).to(dev), degrees=torch.zeros(n4, device=dev))
-
-        def step_model():
-            count_batch(plan, np4, ep4, ei4, ids_are_global=True, max_nodes=max_nodes, max_edges=max_edges, device=dev, out=ids4, check=False)
-            data4.identifiers = ids4.clamp(max=2)
-            with torch.no_grad():
-                return model(data4)
         try:
+            step_model, gm = full_model_closure(dev, min(G, 16384), batch=(b, node_ptr, edge_ptr, ei, plan, max_nodes, max_edges))
             for _ in range(3):
                 ym = step_model()
             torch.cuda.synchronize()
@@ -388,9 +409,9 @@ def main():
             model4 = {"graphs_per_s": round(gm * args.steps / dt3, 1), "ms_per_step": round(dt3 / args.steps * 1e3, 4), "graphs_per_step": gm,
                       "finite": bool(torch.isfinite(ym).all()),
                       "note": "count + GNNSubstructures eval forward (4 layers d=128, one-hot encoders, jk, sum readout) on %d graphs" % gm}
+            del step_model
         except Exception as ex:      # supplementary: never fails the headline
             model4 = {"error": str(ex)[:200]}
-        del model, data4, ids4
 
     # Supplementary (never `value`): the same step on the dataset size of BASELINE configs[1] (ZINC-12k: 12 000 graphs,
     # one launch sequence for the whole dataset; the working set sits in the 256 MB Infinity Cache at this size).
