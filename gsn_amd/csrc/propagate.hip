@@ -393,6 +393,94 @@ static int launch_fwd(const PropArgs &p, hipStream_t st) {
 
 
 // ----------------------------------------------------------------------------------------------------------------
+// Edge stage of a `general` layer with the node part of its Linear taken out of the edge loop.  The first Linear of msg_fn acts
+// on cat(x_i, x_j, z_e) (GSN_sparse.py:166-171, GSN_edge_sparse.py:160-165, MPNN twins), and
+//     cat(x_i, x_j, z_e) W^T = x_i W_i^T + x_j W_j^T + z_e W_z^T,
+// so the two node terms are ONE product per NODE (P = x [W_i | W_j]^T, N rows instead of E, gsn_linear_fwd_hip) and what is left
+// per edge is a gather-add:   S[t] = sum_{e -> t} act( P_i[t] + P_j[src_e] + z_e W_z^T )   (bias and the eval-mode BatchNorm are
+// folded into P_i and the weights by the caller).  HBM-bound: one 4 d-byte row gather per edge + the z_e row, one read and one
+// write per node; z_e W_z^T (d_z <= 16 columns) is done in registers.  One row group of LPR lanes per target, float4 columns.
+// ----------------------------------------------------------------------------------------------------------------
+struct SplitSumArgs {
+    int64_t n_nodes;
+    const int32_t *seg_ptr, *sorted_src, *perm;
+    const float *tb, *a;            // P_i and P_j: rows of `pitch` floats
+    int64_t pitch;
+    const float *z0, *z1;           // per-edge blocks (rows addressed through perm) or null
+    int w0, w1;                     // their widths (multiples of 4)
+    const float *wz;                // [w0 + w1][d] = W_z^T
+    int d, act;
+    float *out;
+};
+
+template <int MAXC, int NZ4>
+__global__ __launch_bounds__(256) void edge_split_sum_kernel(SplitSumArgs p) {
+    constexpr int LPR = 32, RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / LPR, li = lane % LPR;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    // this lane's columns of W_z^T
+    float4 wz[NZ4 > 0 ? NZ4 * 4 : 1][MAXC];
+#pragma unroll
+    for (int k = 0; k < NZ4 * 4; ++k)
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int col = (i * LPR + li) * 4;
+            wz[k][i] = (k < p.w0 + p.w1 && col < p.d) ? *reinterpret_cast<const float4 *>(p.wz + (int64_t)k * p.d + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    const int nz0 = p.w0 >> 2, nz = (p.w0 + p.w1) >> 2;
+    for (int64_t t0 = wave * RPW; t0 < p.n_nodes; t0 += n_waves * RPW) {
+        const int64_t t = t0 + sub;
+        if (t >= p.n_nodes) continue;
+        float4 m0[MAXC], acc[MAXC];
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int col = (i * LPR + li) * 4;
+            vzero(acc[i]); vzero(m0[i]);
+            if (col < p.d) m0[i] = *reinterpret_cast<const float4 *>(p.tb + t * p.pitch + col);
+        }
+        const int32_t lo = p.seg_ptr[t], hi = p.seg_ptr[t + 1];
+        for (int32_t q = lo; q < hi; ++q) {
+            const int64_t sv = p.sorted_src[q];
+            float4 m[MAXC];
+#pragma unroll
+            for (int i = 0; i < MAXC; ++i) {
+                const int col = (i * LPR + li) * 4;
+                m[i] = m0[i];
+                if (col < p.d) m[i] = vadd(m[i], *reinterpret_cast<const float4 *>(p.a + sv * p.pitch + col));
+            }
+            if (NZ4 > 0) {
+                const int64_t e = p.perm[q];
+#pragma unroll
+                for (int k4 = 0; k4 < NZ4; ++k4) {
+                    if (k4 < nz) {
+                        const float4 z = k4 < nz0 ? *reinterpret_cast<const float4 *>(p.z0 + e * p.w0 + 4 * k4)
+                                                  : *reinterpret_cast<const float4 *>(p.z1 + e * p.w1 + 4 * (k4 - nz0));
+                        const float zz[4] = {z.x, z.y, z.z, z.w};
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+#pragma unroll
+                            for (int i = 0; i < MAXC; ++i) {
+                                const float4 w = wz[4 * k4 + r][i];
+                                m[i].x = fmaf(zz[r], w.x, m[i].x); m[i].y = fmaf(zz[r], w.y, m[i].y);
+                                m[i].z = fmaf(zz[r], w.z, m[i].z); m[i].w = fmaf(zz[r], w.w, m[i].w);
+                            }
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < MAXC; ++i) acc[i] = vadd(acc[i], p.act ? vrelu(m[i]) : m[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int col = (i * LPR + li) * 4;
+            if (col < p.d) *reinterpret_cast<float4 *>(p.out + t * p.d + col) = acc[i];
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
 // CSR build of a PyG batch, one wave per GRAPH.  A collated batch is a disjoint union: graph g owns the consecutive
 // columns edge_ptr[g] .. edge_ptr[g+1] of edge_index and the consecutive vertices node_ptr[g] .. node_ptr[g+1], so its
 // columns keep that range in the target-sorted order as well and the whole stable counting sort of a graph -- histogram,
@@ -634,4 +722,51 @@ extern "C" int gsn_csr_build_graphs_hip(int64_t n_graphs, const int64_t *node_pt
     hipLaunchKernelGGL(csr_graphs_kernel, dim3((unsigned)n_graphs), dim3(64), (size_t)lds, st, node_ptr, edge_ptr, (int)n_graphs, n_nodes, n_edges,
                        (int)max_nodes, (int)max_edges, index, other, seg_ptr, perm, sorted_target, sorted_other, status);
     return hip_check("gsn_csr_build_graphs_hip");
+}
+
+template <int MAXC, int NZ4>
+static int launch_split_sum(const SplitSumArgs &p, hipStream_t st) {
+    int64_t blocks = ((p.n_nodes + 1) / 2 + 3) / 4;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL((edge_split_sum_kernel<MAXC, NZ4>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+    return hip_check("edge_split_sum_kernel");
+}
+
+extern "C" int gsn_edge_split_sum_hip(int64_t n_nodes, int64_t n_edges, const int32_t *seg_ptr, const int32_t *sorted_src,
+                                      const int32_t *perm, const float *p_i, const float *p_j, int64_t pitch, const float *z0,
+                                      int64_t w0, const float *z1, int64_t w1, const float *wz_t, int64_t d, int act, float *out,
+                                      void *stream) {
+    if (n_nodes < 0 || n_edges < 0 || !seg_ptr || !p_i || !p_j || !out || (n_edges > 0 && !sorted_src))
+        return set_error(GSN_E_INVALID, "gsn_edge_split_sum_hip: bad argument");
+    if (d < 4 || (d & 3) || d > 256 || pitch < d || (pitch & 3)) return set_error(GSN_E_UNSUPPORTED, "gsn_edge_split_sum_hip: d must be a multiple of 4 up to 256 (pitch a multiple of 4)");
+    if (w0 < 0 || w1 < 0 || (w0 & 3) || (w1 & 3) || w0 + w1 > 16 || (w0 > 0 && !z0) || (w1 > 0 && !z1) || (w0 == 0 && w1 > 0))
+        return set_error(GSN_E_UNSUPPORTED, "gsn_edge_split_sum_hip: per-edge blocks must be multiples of 4 wide, 16 columns in total at most");
+    if (w0 + w1 > 0 && (!wz_t || !perm)) return set_error(GSN_E_INVALID, "gsn_edge_split_sum_hip: per-edge blocks need W_z^T and perm");
+    if (act != 0 && act != 1) return set_error(GSN_E_UNSUPPORTED, "gsn_edge_split_sum_hip: identity / relu only");
+    if ((reinterpret_cast<uintptr_t>(p_i) | reinterpret_cast<uintptr_t>(p_j) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(wz_t) |
+         reinterpret_cast<uintptr_t>(z0) | reinterpret_cast<uintptr_t>(z1)) & 15)
+        return set_error(GSN_E_INVALID, "gsn_edge_split_sum_hip: pointers must be 16-byte aligned");
+    if (n_nodes == 0) return GSN_OK;
+    SplitSumArgs p{};
+    p.n_nodes = n_nodes; p.seg_ptr = seg_ptr; p.sorted_src = sorted_src; p.perm = perm; p.tb = p_i; p.a = p_j; p.pitch = pitch;
+    p.z0 = z0; p.z1 = z1; p.w0 = (int)w0; p.w1 = (int)w1; p.wz = wz_t; p.d = (int)d; p.act = act; p.out = out;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int nz4 = (int)((w0 + w1) >> 2);
+    const bool wide = d > 128;
+    if (wide && nz4 > 2) return set_error(GSN_E_UNSUPPORTED, "gsn_edge_split_sum_hip: d > 128 with more than 8 per-edge columns");
+    if (!wide) {
+        switch (nz4) {
+            case 0: return launch_split_sum<1, 0>(p, st);
+            case 1: return launch_split_sum<1, 1>(p, st);
+            case 2: return launch_split_sum<1, 2>(p, st);
+            case 3: return launch_split_sum<1, 3>(p, st);
+            default: return launch_split_sum<1, 4>(p, st);
+        }
+    }
+    switch (nz4) {
+        case 0: return launch_split_sum<2, 0>(p, st);
+        case 1: return launch_split_sum<2, 1>(p, st);
+        default: return launch_split_sum<2, 2>(p, st);
+    }
 }

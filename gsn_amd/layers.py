@@ -542,7 +542,7 @@ def invalidate_caches(module=None):
         _CSR_CACHE.clear()
         return
     for m in module.modules():
-        for attr in ("_fold_cache", "_gsn_eval_cache", "_gsn_wt"):
+        for attr in ("_fold_cache", "_split_cache", "_gsn_eval_cache", "_gsn_wt"):
             if hasattr(m, attr):
                 try:
                     delattr(m, attr)
@@ -550,6 +550,8 @@ def invalidate_caches(module=None):
                     pass
 
 
+SPLIT_EDGE_STAGE = os.environ.get("GSN_SPLIT_EDGE", "1") != "0"        # node part of a wide edge Linear once per node (K > SPLIT_EDGE_MIN_K)
+SPLIT_EDGE_MIN_K = int(os.environ.get("GSN_SPLIT_EDGE_MIN_K", "160"))
 FUSED_LAYER = os.environ.get("GSN_LAYER_FUSED", "1") != "0"   # one-launch `general` layer (gsn_layer_fused_fwd_hip) where it fits
 
 
@@ -1341,7 +1343,11 @@ class _SparseLayer(nn.Module):
                                      self.training)
                     if y is not None:
                         return y
-                s_agg = mf.hip_forward(sblocks, E, upto=len(mf.fc) - 1, csr=csr)
+                # wide edge rows (K > 160: layers 1.. of a d = 128 model, K = 260): the node part of the Linear once per NODE,
+                # the rest as a gather-add inside the scatter kernel
+                s_agg = self._split_edge_stage(x, ids, ef, csr, n, E)
+                if s_agg is None:
+                    s_agg = mf.hip_forward(sblocks, E, upto=len(mf.fc) - 1, csr=csr)
             if s_agg is None:
                 r = mf.hip_forward(blocks, E, upto=len(mf.fc) - 1)
                 s_agg = propagate(0, edge_index, sel, n, b=r)
@@ -1384,6 +1390,69 @@ class _SparseLayer(nn.Module):
         w_first = torch.cat([w3x, w3a @ last.weight, (w3a @ last.bias).unsqueeze(1)], 1)
         stages = uf.stages([(x, None), (s_agg, None), (csr.deg, None)], first_weight=w_first, post=post)
         return run_stages_autograd(stages, n, True)
+
+    def _split_edge_stage(self, x, ids, ef, csr, n, E):
+        """S[t] = sum_{e -> t} act(bn(cat(x_i, x_j, z_e) W1^T + b1)) with the node columns of W1 applied once per node:
+        P = x [W_i | W_j]^T (gsn_linear_fwd_hip, N rows), then gsn_edge_split_sum_hip gathers P_i[t] + P_j[src] and adds
+        z_e W_z^T per edge.  Eval-mode / no BatchNorm, one hidden edge stage, identity / relu, per-edge blocks of
+        <= 16 columns; used when the concatenated row is wider than the fused chain kernels take (K > SPLIT_EDGE_MIN_K).
+        Returns None when the shape is outside that."""
+        mf = self.msg_fn
+        if not SPLIT_EDGE_STAGE or len(mf.fc) != 2 or self.training or E == 0:
+            return None
+        st = mf.stages([], upto=1)[0]
+        act = {"identity": 0, "relu": 1}.get(st.act)
+        if act is None or (st.bn is not None and (st.bn.training or st.bn.running_mean is None)):
+            return None
+        d_x, d_h = x.shape[1], st.weight.shape[0]
+        node_blocks, edge_blocks = [x], []
+        if self.has_ids:
+            (edge_blocks if self.id_scope == "local" else node_blocks).append(ids)
+        if self.has_ef:
+            edge_blocks.append(ef)
+        d_n = sum(b.shape[1] for b in node_blocks)
+        d_r = sum(b.shape[1] for b in edge_blocks)
+        if 2 * d_n + d_r <= SPLIT_EDGE_MIN_K or d_h % 4 or d_h > 256 or any(b.shape[1] % 4 for b in edge_blocks) \
+                or d_r > (16 if d_h <= 128 else 8) or len(edge_blocks) > 2:
+            return None
+        _bn_resolve(st, None, E, False)
+        w1, b1 = mf.fc[0].weight, mf.fc[0].bias
+        bn_key = None if st.bn is None else tuple(t._version for t in (st.bn.running_mean, st.bn.running_var)) + \
+            ((st.bn.weight._version, st.bn.bias._version) if st.bn.affine else ())
+        key = (w1._version, w1.data_ptr(), None if b1 is None else b1._version, bn_key, d_x, d_n, d_r)
+        cache = getattr(self, "_split_cache", None)
+        if cache is None or cache[0] != key:
+            w = w1.detach()
+            scale = None
+            bias = b1.detach() if b1 is not None else torch.zeros(d_h, device=w.device)
+            if st.bn_params is not None:
+                mean, scale, shift = st.bn_params
+                bias = (bias - mean) * scale + shift
+            # column layout of W1: x_i, x_j, then ids_i, ids_j (global scope) or ids (local), then edge features
+            cols_i, cols_j, off = [w[:, :d_x]], [w[:, d_x:2 * d_x]], 2 * d_x
+            if self.has_ids and self.id_scope != "local":
+                d_id = ids.shape[1]
+                cols_i.append(w[:, off:off + d_id]); cols_j.append(w[:, off + d_id:off + 2 * d_id]); off += 2 * d_id
+            w_i, w_j, w_z = torch.cat(cols_i, 1), torch.cat(cols_j, 1), w[:, off:]
+            if scale is not None:
+                w_i, w_j, w_z = w_i * scale[:, None], w_j * scale[:, None], w_z * scale[:, None]
+            w_n = torch.cat([w_i, w_j], 0).contiguous()                                   # [2 d_h, d_n]
+            bias_n = torch.cat([bias, torch.zeros_like(bias)]).contiguous()               # the target half carries bias + BN shift
+            wz_t = w_z.t().contiguous() if d_r else None                                  # [d_r, d_h]
+            cache = (key, w_n, bias_n, wz_t)
+            self._split_cache = cache
+        _, w_n, bias_n, wz_t = cache
+        P = _linear_hip([(b, None) for b in node_blocks], w_n, bias_n, None, None, None, 0, n)          # [N, 2 d_h]
+        zs = [_f32c(b) for b in edge_blocks]
+        out = torch.empty((n, d_h), dtype=torch.float32, device=x.device)
+        with _abi.device_guard(x.device), _timed("edge_split_sum", 4.0 * (E * (d_h + d_r) + 2.0 * n * d_h)):
+            rc = _abi.lib().gsn_edge_split_sum_hip(n, E, csr.seg_ptr.data_ptr(), csr.src.data_ptr(), csr.perm.data_ptr(),
+                                                   P.data_ptr(), P.data_ptr() + 4 * d_h, 2 * d_h,
+                                                   zs[0].data_ptr() if zs else None, zs[0].shape[1] if zs else 0,
+                                                   zs[1].data_ptr() if len(zs) > 1 else None, zs[1].shape[1] if len(zs) > 1 else 0,
+                                                   _abi.ptr(wz_t), d_h, act, out.data_ptr(), _abi.current_stream())
+        _abi.check(rc, "gsn_edge_split_sum_hip")
+        return out
 
     def _folded_first_weight(self, d_x):
         """[W3x | W3a W2 | W3a b2] (see _hip); recomputed only when one of the three parameters changed."""

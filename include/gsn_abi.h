@@ -268,6 +268,22 @@ int gsn_layer_fused_fwd_hip(int64_t n_nodes, int64_t n_edges, const int32_t *seg
                             const float *x, int64_t d_x, const gsn_chain_stage *node0, const gsn_chain_stage *node1,
                             float *out, void *stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * HP-2  edge stage of a `general` layer with the node part of its Linear taken out of the edge loop (device, fp32).
+ * msg_fn's first Linear acts on cat(x_i, x_j, z_e) (GSN_sparse.py:166-171, GSN_edge_sparse.py:160-165, MPNN twins);
+ * cat(x_i, x_j, z_e) W^T = x_i W_i^T + x_j W_j^T + z_e W_z^T, so the caller computes P = x [W_i | W_j]^T once per NODE
+ * (gsn_linear_fwd_hip, N rows instead of E; bias and eval-mode BatchNorm folded into P_i and the weights) and this entry does
+ *     out[t] = sum_{e : tgt(e) = t} act( P_i[t] + P_j[src(e)] + z_e W_z^T )            (GSN_edge_sparse.py:136-139 scatter-add)
+ *   seg_ptr, sorted_src, perm   the target-sorted CSR of gsn_csr_build_hip / gsn_csr_build_graphs_hip
+ *   p_i, p_j   fp32 device rows of `pitch` floats (two column ranges of one [N][2 d] matrix, or two matrices), d columns used
+ *   z0, z1     per-edge blocks [E][w0], [E][w1] (identifiers / edge features; widths multiples of 4, w0 + w1 <= 16) or NULL
+ *   wz_t       [w0 + w1][d] = W_z^T;   act 0 identity / 1 relu;   out [N][d] fully overwritten;  d multiple of 4, <= 256
+ * ---------------------------------------------------------------------------------------------------------------- */
+int gsn_edge_split_sum_hip(int64_t n_nodes, int64_t n_edges, const int32_t *seg_ptr, const int32_t *sorted_src,
+                           const int32_t *perm, const float *p_i, const float *p_j, int64_t pitch, const float *z0,
+                           int64_t w0, const float *z1, int64_t w1, const float *wz_t, int64_t d, int act, float *out,
+                           void *stream);
+
 /* The same CSR for a PyG-collated batch, one launch.  A batch is a disjoint union (torch_geometric's Batch / the reference's
  * DataLoader, main.py:19, utils_data_prep.py:35-60): graph g owns the consecutive columns edge_ptr[g] .. edge_ptr[g+1] of
  * edge_index and the consecutive vertices node_ptr[g] .. node_ptr[g+1], so every graph is sorted on its own in LDS (one wave

@@ -581,3 +581,53 @@ def test_csr_of_a_collated_batch_in_one_launch():
         y1 = layer(x, ei, identifiers=ids, degrees=torch.zeros(N, device=dev), edge_features=ef)
     assert torch.equal(y0, y1)
     layers._PARTITION.clear()
+
+
+@pytest.mark.parametrize("cls,scope,bn,d", [("MPNN_edge_sparse", None, True, 128), ("GSN_edge_sparse", "local", True, 128),
+                                             ("GSN_edge_sparse", "global", False, 96), ("GSN_sparse", "global", True, 128),
+                                             ("MPNN_sparse", None, True, 200)])
+def test_wide_edge_stage_split_into_node_product_and_gather_sum(cls, scope, bn, d, monkeypatch):
+    """Layers 1.. of a d = 128 model (edge rows K = 260): cat(x_i, x_j, z) W^T = x_i W_i^T + x_j W_j^T + z W_z^T -- node
+    product + gsn_edge_split_sum_hip -- against the fp32 oracle at 1e-5 element-wise, and against the E-row product path."""
+    from gsn_amd import layers, synth
+    from oracle import oracle
+    b = synth.zinc_shape_batch(300, seed=31)
+    N, E = b.num_nodes, b.num_edges
+    ctor = dict(d_in=d, d_degree=1, degree_as_tag=False, retain_features=True, d_msg=d, d_up=d, d_h=[d], seed=0,
+                activation_name="relu", bn=bn, msg_kind="general", flow="source_to_target")
+    if "edge" in cls:
+        ctor["d_ef"] = 4
+    if cls.startswith("GSN"):
+        ctor.update(d_id=8, id_scope=scope)
+    torch.manual_seed(3)
+    layer = getattr(layers, cls)(**ctor)
+    g = torch.Generator().manual_seed(4)
+    for mod in layer.modules():
+        if isinstance(mod, torch.nn.BatchNorm1d):
+            mod.running_mean.copy_(torch.rand(mod.running_mean.shape, generator=g) * 0.4 - 0.2)
+            mod.running_var.copy_(torch.rand(mod.running_var.shape, generator=g) + 0.5)
+    layer.eval()
+    x = torch.randn(N, d, generator=g)
+    ids = torch.randn(N if scope == "global" else E, 8, generator=g) if cls.startswith("GSN") else None
+    ef = torch.randn(E, 4, generator=g) if "edge" in cls else None
+    ei = torch.from_numpy(b.edge_index)
+    sd = {k: v.clone() for k, v in layer.state_dict().items()}
+    ref = oracle.layer_forward(cls, ctor, sd, x, ei, identifiers=ids, degrees=None, edge_features=ef, training=False)
+    layer.cuda()
+    kw = dict(identifiers=None if ids is None else ids.cuda(), degrees=torch.zeros(N, device="cuda"), edge_features=None if ef is None else ef.cuda())
+    calls = []
+    orig = layers._SparseLayer._split_edge_stage
+
+    def spy(self, *a, **k):
+        r = orig(self, *a, **k)
+        calls.append(r is not None)
+        return r
+    monkeypatch.setattr(layers._SparseLayer, "_split_edge_stage", spy)
+    with torch.no_grad():
+        y = layer(x.cuda(), ei.cuda(), **kw).cpu()
+        assert calls == [True]
+        monkeypatch.setattr(layers, "SPLIT_EDGE_STAGE", False)
+        layers._CSR_CACHE.clear()
+        y_old = layer(x.cuda(), ei.cuda(), **kw).cpu()
+    assert elementwise_ok(y, ref), float((y - ref).abs().max() / ref.abs().max())
+    assert elementwise_ok(y, y_old)
