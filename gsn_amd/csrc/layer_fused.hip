@@ -12,20 +12,24 @@
 // processes in chunks of <= 64 rows (the tile takes as many nodes as fit a whole number of chunks: ZINC-shaped graphs give
 // ~31 nodes / 64 edges per tile, one chunk; a hub or a dense graph gives several chunks per tile).  Group S0 runs the tile
 // iterator over seg_ptr (one 33-entry window load per tile, fetched a tile ahead) and publishes every chunk descriptor four
-// steps ahead through LDS, so every scheduling decision is a wave-uniform scalar read; group S1, which must never wait for a
-// load behind its output stores, follows a ten-word record per step.
+// steps ahead through LDS (three packed words each), so every scheduling decision is a wave-uniform scalar read; group S1, which
+// must never wait for a load behind its output stores, follows a four-word record per step.
 //
 // Roles (12 waves, 3 per SIMD; a wave keeps ONE stage's weights in registers for the whole kernel).  Every step has two
 // phases with one LDS-only barrier after each, and every group alternates a matrix phase with a staging phase, so that the
 // matrix pipe and the vector pipe are both busy in both phases; every LDS buffer is written in one phase and read in the other
 // (only H, which crosses from phase 2 to the next step's phase 2, is double):
 //                 phase 1                                              phase 2
-//   group E  (waves 0-3)   edge stage of chunk i: IN_E -> Y (fp32)      gathered rows -> planes IN_E of chunk i + 1
-//                          (+ issues the gathers of chunk i + 1)
+//   group E  (waves 0-3)   edge stage of chunk i: IN_E -> Y (fp32)      gathered rows -> planes IN_E of chunk i + 1;
+//                          (+ issues the gathers of chunk i + 1 and     the x rows -> XR (raw; group S0 stages them next step)
+//                          the x-row loads of a completing tile)
 //   group S0 (waves 4-7)   tile iterator; [S | x | deg] of the         node stage 0: IN_N -> H[i & 1] (fp32);  per node 0..15 of the
 //                          finished tile -> IN_N                        tile, sum of its Y rows in row order -> S (no atomics)
 //   group S1 (waves 8-11)  node stage 1 of the tile staged last step:   H[(i - 1) & 1] -> planes MID;  the sums of nodes 16..31
-//                          MID -> out rows (global stores)
+//                          MID -> out rows (range-checked buffer stores)
+// No register spill inside the loops (a scratch reload waits, in order, behind every load / store in flight): uniform scale
+// factors are read back from an LDS table at the point of use, group S0 holds no load over its matrix phase (group E fetches the
+// x rows), descriptors are packed.  WG > 0 instantiations know the three widths at compile time (d = 128 / 64).
 //
 // Matrix arithmetic: fp16x3.  Both operands are split into two fp16 planes (x = x_h + x_l, 11 + 11 significant bits, round
 // to nearest) after an exact power-of-two scaling that puts the largest magnitude of every A row (and of each stage's weight

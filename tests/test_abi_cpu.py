@@ -175,6 +175,25 @@ def test_directed_patterns_orbits_and_search_core_on_host(lib, harness):
         counting._directed_of([g_und], True)
 
 
+def test_plan_table_column_order(lib):
+    """The plan table carries the order in which the kernel hands out a graph's (column, row) cells: a permutation of the columns,
+    larger cycles before smaller ones (estimated search cost), tree-like five-vertex patterns before dense ones."""
+    import networkx as nx
+    from gsn_amd.counting import CountPlan
+    plan = CountPlan([list(nx.cycle_graph(k).edges) for k in range(3, 9)], "edge", False)
+    n = plan.n_cols
+    order = plan.table[8 + n + 1: 8 + 2 * n + 1].tolist()
+    assert sorted(order) == list(range(n)) and order == list(range(n - 1, -1, -1))
+    assert int(plan.table[7]) == 8 + 2 * n + 1
+    pats = [list(nx.path_graph(5).edges), list(nx.complete_graph(5).edges), list(nx.star_graph(4).edges)]
+    plan = CountPlan(pats, "vertex", False)
+    order = plan.table[8 + plan.n_cols + 1: 8 + 2 * plan.n_cols + 1].tolist()
+    assert sorted(order) == list(range(plan.n_cols))
+    k5_col = plan.n_cols - 3          # columns: path (3 orbits), K5 (1), star (2)
+    assert order.index(3) > order.index(0), order      # the clique's column comes after the path's
+    del k5_col
+
+
 def test_no_cpu_fallback(lib):
     if torch.cuda.is_available():
         pytest.skip("GPU present")
