@@ -389,6 +389,32 @@ def propagate(kind, edge_index, sel, n_nodes, a=None, b=None, c=None, b_per_node
 # ------------------------------------------------------------------------------------------------------------------
 # fused Linear (+BN) (+activation) stage
 # ------------------------------------------------------------------------------------------------------------------
+LINEAR_F16X3 = os.environ.get("GSN_LINEAR_F16X3", "1") != "0"     # direct-row dense stages on the fp16x3 kernel (else bf16x6 / fp32)
+LINEAR_F16X3_MIN_N = int(os.environ.get("GSN_LINEAR_F16X3_MIN_N", "128"))
+
+
+def _f16x3_weights(weight, w32):
+    """fp16 planes + inverse column scales of a weight matrix for gsn_linear_f16x3_fwd_hip, made once per weight VERSION and kept
+    on the tensor object (parameters, folded weights and the cached derived matrices all live across calls)."""
+    key = (weight._version, w32.data_ptr(), tuple(w32.shape))
+    hit = getattr(weight, "_gsn_f16x3", None)
+    if hit is not None and hit[0] == key:
+        return hit[1], hit[2]
+    n_out, k = w32.shape
+    L = _abi.lib()
+    kpad = int(L.gsn_linear_f16x3_kpad(k))
+    planes = torch.empty(2 * n_out * kpad, dtype=torch.float16, device=w32.device)
+    col_inv = torch.empty(n_out, dtype=torch.float32, device=w32.device)
+    with _abi.device_guard(w32.device):
+        _abi.check(L.gsn_linear_f16x3_prepare_hip(w32.data_ptr(), n_out, k, planes.data_ptr(), col_inv.data_ptr(), _abi.current_stream()),
+                   "gsn_linear_f16x3_prepare_hip")
+    try:
+        weight._gsn_f16x3 = (key, planes, col_inv)
+    except (AttributeError, RuntimeError):
+        pass
+    return planes, col_inv
+
+
 def _linear_hip(blocks, weight, bias, bn_mean, bn_scale, bn_shift, act, m_rows, out=True, stats=None):
     """blocks: list of (data [R,w] fp32 cuda, idx int64 [M] or None)."""
     if len(blocks) > _MAX_BLOCKS:
@@ -414,6 +440,19 @@ def _linear_hip(blocks, weight, bias, bn_mean, bn_scale, bn_shift, act, m_rows, 
     y = torch.empty((m_rows, n_out), dtype=torch.float32, device=dev) if out else None
     w = _f32c(weight)
     vecs = [None if v is None else _f32c(v) for v in (bias, bn_mean, bn_scale, bn_shift)]
+    # direct rows (node-level stages): the fp16x3 kernel with the weights split once per weight version
+    # (from two column tiles on: the pre-pass over the rows that finds their scales is then amortised -- at n_out <= 128 the
+    #  bf16x6 kernel, which reads the rows once, is faster: 99 vs 90 TF/s at K = 260)
+    if (LINEAR_F16X3 and out and stats is None and m_rows > 0 and n_out > LINEAR_F16X3_MIN_N and all(idx is None for _, idx in blocks)
+            and all(d.shape[1] % 4 == 0 and d.data_ptr() % 16 == 0 for d in keep)):
+        planes, col_inv = _f16x3_weights(weight, w)
+        scratch = torch.empty(2 * m_rows, dtype=torch.float32, device=dev)
+        with _abi.device_guard(dev), _timed("linear_fwd", 2.0 * m_rows * w.shape[1] * n_out):
+            rc = _abi.lib().gsn_linear_f16x3_fwd_hip(m_rows, len(blocks), arr, planes.data_ptr(), col_inv.data_ptr(), _abi.ptr(vecs[0]), n_out,
+                                                     _abi.ptr(vecs[1]), _abi.ptr(vecs[2]), _abi.ptr(vecs[3]), act, scratch.data_ptr(),
+                                                     y.data_ptr(), _abi.current_stream())
+        _abi.check(rc, "gsn_linear_f16x3_fwd_hip")
+        return y
     with _abi.device_guard(dev), _timed("linear_fwd", 2.0 * m_rows * w.shape[1] * n_out):
         rc = _abi.lib().gsn_linear_fwd_hip(m_rows, len(blocks), arr, w.data_ptr(), _abi.ptr(vecs[0]), n_out, _abi.ptr(vecs[1]),
                                            _abi.ptr(vecs[2]), _abi.ptr(vecs[3]), act, None, _abi.ptr(y), _abi.ptr(stats),
@@ -548,6 +587,9 @@ def invalidate_caches(module=None):
                     delattr(m, attr)
                 except AttributeError:
                     pass
+        for prm in m.parameters(recurse=False):          # fp16 planes of the weights (gsn_linear_f16x3_prepare_hip)
+            if hasattr(prm, "_gsn_f16x3"):
+                del prm._gsn_f16x3
 
 
 SPLIT_EDGE_STAGE = os.environ.get("GSN_SPLIT_EDGE", "1") != "0"        # node part of a wide edge Linear once per node (K > SPLIT_EDGE_MIN_K)

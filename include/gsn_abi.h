@@ -269,6 +269,26 @@ int gsn_layer_fused_fwd_hip(int64_t n_nodes, int64_t n_edges, const int32_t *seg
                             float *out, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * HP-2  dense stage on DIRECT rows with fp16x3 matrix arithmetic (device): the same operation as gsn_linear_fwd_hip
+ *     out[m, :] = act( bn( cat(blocks[0][m], blocks[1][m], ..) W^T + b ) )          (models_misc.py:52-58)
+ * for blocks without a row index (node-level stages: the node product of a wide layer, its K = 260 node stage, jk projections,
+ * the d = 300 ogb stages).  Two fp16 planes per operand after an exact power-of-two scaling (every input row by its largest
+ * magnitude -- a pre-pass inside the call --, every output column of W by its largest entry), three plane products per fp32
+ * product on the 16-bit matrix pipe, fp32 accumulation: the error of an fp32 FMA loop at half the matrix work of the bf16x6
+ * kernel, over the whole fp32 exponent range; a row with an Inf / NaN comes out NaN.
+ *   gsn_linear_f16x3_kpad(K)          K rounded up to two of the kernel's K slices (64)
+ *   gsn_linear_f16x3_prepare_hip      splits W [n_out][K] once: planes = 2 * n_out * kpad(K) fp16 values, col_inv = n_out floats
+ *                                     (device buffers of the caller; valid until W changes)
+ *   gsn_linear_f16x3_fwd_hip          blocks: data + width only (idx / idx32 must be NULL), widths multiples of 4, 16-byte
+ *                                     aligned; row_scratch: 2 * m_rows floats; bias / bn_* / act as gsn_linear_fwd_hip
+ * ---------------------------------------------------------------------------------------------------------------- */
+int64_t gsn_linear_f16x3_kpad(int64_t k_total);
+int gsn_linear_f16x3_prepare_hip(const float *W, int64_t n_out, int64_t k_total, void *planes, float *col_inv, void *stream);
+int gsn_linear_f16x3_fwd_hip(int64_t m_rows, int n_blocks, const gsn_block *blocks, const void *planes, const float *col_inv,
+                             const float *bias, int64_t n_out, const float *bn_mean, const float *bn_scale, const float *bn_shift,
+                             int act, float *row_scratch, float *out, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * HP-2  edge stage of a `general` layer with the node part of its Linear taken out of the edge loop (device, fp32).
  * msg_fn's first Linear acts on cat(x_i, x_j, z_e) (GSN_sparse.py:166-171, GSN_edge_sparse.py:160-165, MPNN twins);
  * cat(x_i, x_j, z_e) W^T = x_i W_i^T + x_j W_j^T + z_e W_z^T, so the caller computes P = x [W_i | W_j]^T once per NODE

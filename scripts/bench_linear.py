@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """gsn_linear_fwd_hip alone (the any-shape dense stage): fp32-equivalent TFLOP/s at the shapes of the d = 300 ogb layers and
-of the K = 260 message stage of the ZINC model's later layers.  GSN_LINEAR_BF16X6=0 selects the fp32-MFMA kernel."""
+of the K = 260 message stage of the ZINC model's later layers.  Direct rows run the fp16x3 kernel (gsn_linear_f16x3_fwd_hip);
+GSN_LINEAR_F16X3=0 selects the bf16x6 kernel, with GSN_LINEAR_BF16X6=0 the fp32-MFMA kernel."""
 import json
 import os
 import sys
@@ -15,7 +16,7 @@ from gsn_amd import layers  # noqa: E402
 def main():
     dev = torch.device("cuda")
     out = []
-    for M, K, N in ((196608, 300, 600), (196608, 600, 300), (1 << 20, 260, 128), (1 << 20, 128, 128)):
+    for M, K, N in ((196608, 300, 600), (196608, 600, 300), (1 << 20, 260, 128), (1 << 20, 128, 128), (380000, 128, 256)):
         x = torch.randn(M, K, device=dev)
         W = torch.randn(N, K, device=dev) / K ** 0.5
         b = torch.randn(N, device=dev)
@@ -34,7 +35,8 @@ def main():
         err = float((y[:4096].double() - ref).abs().max() / ref.abs().max())
         out.append({"M": M, "K": K, "N": N, "ms": round(dt * 1e3, 3), "fp32_equivalent_TFLOPs": round(2.0 * M * K * N / dt / 1e12, 1),
                     "max_rel_err_vs_fp64": err})
-    print(json.dumps({"kernel": "bf16x6" if os.environ.get("GSN_LINEAR_BF16X6", "1") != "0" else "fp32 mfma", "cases": out}))
+    kern = "fp16x3" if layers.LINEAR_F16X3 else ("bf16x6" if os.environ.get("GSN_LINEAR_BF16X6", "1") != "0" else "fp32 mfma")
+    print(json.dumps({"kernel": kern, "cases": out}))
 
 
 if __name__ == "__main__":

@@ -100,3 +100,43 @@ def test_random_chain_shapes_vs_fp64(seed):
         out, ref, what = _case(rng, dev)
         assert out.shape == ref.shape, what
         assert rel_err(out.double(), ref) < TOL, what
+
+
+@pytest.mark.parametrize("m,widths,n,act,bn", [(1000, [132], 256, "relu", True), (4097, [128, 128, 4], 384, "identity", False),
+                                                (130, [300], 600, "relu", False), (777, [64, 200], 130, "tanh", True),
+                                                (50000, [128], 256, "relu", True)])
+def test_direct_rows_on_the_fp16x3_linear_kernel(m, widths, n, act, bn, capfd):
+    """gsn_linear_f16x3_fwd_hip (direct rows, n_out > 128): several input blocks, K not a multiple of the slice, a ragged last
+    row tile and column tile, every epilogue -- against fp64, element-wise, with the product's own condition scale as floor."""
+    import os
+    from gsn_amd import layers
+    g = torch.Generator().manual_seed(m + n)
+    xs = [torch.randn(m, w, generator=g) * (10.0 ** i) for i, w in enumerate(widths)]
+    k = sum(widths)
+    w = torch.randn(n, k, generator=g) / k ** 0.5
+    w[3] *= 1e-12; w[7] *= 1e9                                  # column scales far apart
+    b = torch.randn(n, generator=g)
+    bnm = None
+    if bn:
+        bnm = torch.nn.BatchNorm1d(n)
+        bnm.running_mean.copy_(torch.rand(n, generator=g) - 0.5); bnm.running_var.copy_(torch.rand(n, generator=g) + 0.5)
+        bnm.weight.data.copy_(torch.rand(n, generator=g) + 0.5); bnm.bias.data.copy_(torch.rand(n, generator=g) - 0.5)
+        bnm.eval().cuda()
+    st = layers._Stage(w.cuda(), b.cuda(), bnm, act, [(x.cuda(), None) for x in xs])
+    os.environ["GSN_CHAIN_TRACE"] = "1"
+    try:
+        y = layers.run_stages([st], m, False).cpu()
+        torch.cuda.synchronize()
+    finally:
+        os.environ.pop("GSN_CHAIN_TRACE", None)
+    assert "linear_f16x3_kernel" in capfd.readouterr().err
+    x = torch.cat(xs, 1).double()
+    pre = x @ w.double().t() + b.double()
+    scale = x.abs() @ w.double().abs().t() + b.double().abs()
+    if bn:
+        s_ = (bnm.weight.double().cpu() / torch.sqrt(bnm.running_var.double().cpu() + bnm.eps))
+        pre = (pre - bnm.running_mean.double().cpu()) * s_ + bnm.bias.double().cpu()
+        scale = scale * s_.abs() + bnm.bias.double().cpu().abs() + (bnm.running_mean.double().cpu() * s_).abs()
+    ref = {"relu": torch.relu, "identity": lambda t: t, "tanh": torch.tanh}[act](pre)
+    err = (y.double() - ref).abs()
+    assert bool((err <= 1e-5 * ref.abs() + 2e-6 * scale).all()), float((err / (1e-5 * ref.abs() + 2e-6 * scale)).max())
