@@ -79,8 +79,11 @@ SIGNATURES = {
     "gsn_bn_finalize_hip": (c_int, [c_i64, c_i64, ctypes.c_double, ctypes.c_double, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "gsn_mlp_chain_supported": (c_int, [c_int, ctypes.POINTER(gsn_chain_stage)]),
     "gsn_layer_fused_supported": (c_int, [ctypes.POINTER(gsn_chain_stage), c_i64, ctypes.POINTER(gsn_chain_stage), ctypes.POINTER(gsn_chain_stage)]),
+    "gsn_layer_fused_prepared_bytes": (c_i64, [ctypes.POINTER(gsn_chain_stage), c_i64, ctypes.POINTER(gsn_chain_stage), ctypes.POINTER(gsn_chain_stage)]),
+    "gsn_layer_fused_prepare_hip": (c_int, [ctypes.POINTER(gsn_chain_stage), c_i64, ctypes.POINTER(gsn_chain_stage), ctypes.POINTER(gsn_chain_stage),
+                                            c_vp, c_vp]),
     "gsn_layer_fused_fwd_hip": (c_int, [c_i64, c_i64, c_vp, ctypes.POINTER(gsn_chain_stage), c_vp, c_i64, ctypes.POINTER(gsn_chain_stage),
-                                        ctypes.POINTER(gsn_chain_stage), c_vp, c_vp]),
+                                        ctypes.POINTER(gsn_chain_stage), c_vp, c_vp, c_vp]),
     "gsn_mlp_chain_fwd_hip": (c_int, [c_i64, c_int, ctypes.POINTER(gsn_chain_stage), c_vp, c_vp, c_vp, c_vp, c_vp]),
 }
 

@@ -82,7 +82,11 @@ struct LfArgs {
     const float *x;                         // [n_nodes][d_x] first block of the node stage
     int d_x;
     float *out;                             // [n_nodes][s1.n_out]
+    // the three stages' weights as this kernel's register fragments (gsn_layer_fused_prepare_hip): [0..11] per-wave maxima of
+    // |W * bn_scale| (the stage scales), then per stage [wave][k-step][plane h, l][lane] 16-byte fragments
+    const unsigned *prep;
 };
+constexpr int LF_PREP_HDR = 16;             // words in front of the fragments
 
 // One chunk of one tile; every field wave-uniform.  Packed into three words (the descriptors of four chunks in flight, the
 // three tiles of the node pipeline and the iterator all live in scalar registers: unpacked they spill into vector lanes).
@@ -434,6 +438,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const int li = lane & 31, lh = lane >> 5;
     const int q8 = t & 7, r8 = t >> 3;                                    // stager map: 8 lanes per row, 32 rows per pass
 
+    const unsigned long long t_entry = clk();
     for (int i = tid; i < OFF_TAB / 4; i += 768) reinterpret_cast<float *>(smem)[i] = 0.f;   // padded columns stay zero
     if (tid < 4) flag_e[tid] = -1;
 
@@ -463,13 +468,9 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         d3 = lf_iter_next(it, lane, segl, seg_writer);
         if (tid == 256) { lf_desc_put(dring, dc0); lf_desc_put(dring + 4, d3); }
     }
-    {
-        unsigned m = lf_weight_absmax(st, col, cok, bnscale);
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
-        if (lane == 0) wmax[4 * grp + w] = m;
-    }
+    if (tid < 12) wmax[tid] = a.prep[tid];                                // per-wave weight maxima (prepared once per weight version)
     __syncthreads();
+    const unsigned long long t_max = clk();
     float wscale, inv_w;
     lf_scale(max(max(wmax[4 * grp], wmax[4 * grp + 1]), max(wmax[4 * grp + 2], wmax[4 * grp + 3])), wscale, inv_w);
     wscale = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(wscale)));       // (wave-uniform: scalar registers)
@@ -480,6 +481,10 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     if (w_bad) inv_w = __uint_as_float(0x7fc00000u);
     if (t == 0) wtab[grp] = inv_w;                                         // (visible after the first barrier of the loop; first used after it)
     auto uniform_lds = [](const float *p) -> float { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(*p))); };
+    // this wave's weight fragments: consecutive lanes read consecutive 16 bytes (the in-kernel split read 64 different rows per
+    // instruction from every workgroup at once: 50 - 400 k cycles of prologue under load)
+    const lf_u4 *pfrag = reinterpret_cast<const lf_u4 *>(a.prep + LF_PREP_HDR) +
+                         ((grp == 0 ? 0 : (grp == 1 ? 4 * NKE : 4 * (NKE + NK0))) * 2 + (grp == 0 ? NKE : (grp == 1 ? NK0 : NK1)) * 2 * w) * 64 + lane;
 
     // ---- step bookkeeping (the tile iterator itself lives in group S0, see below) ------------------------------------------
     LfDesc d0 = lf_desc_none(), d1 = d0, d2 = d0;                         // chunks i, i+1, i+2 of step i
@@ -506,7 +511,8 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         // group E
         // =============================================================================================================
         lf_u4 Bh[NKE], Bl[NKE];
-        lf_weight_planes<NKE>(st, col, cok, lh, bnscale, wscale, 0, 0, 1.f, Bh, Bl);
+#pragma unroll
+        for (int q = 0; q < NKE; ++q) { Bh[q] = pfrag[(2 * q) * 64]; Bl[q] = pfrag[(2 * q + 1) * 64]; }
         // staging map: thread -> rows r8 and r8 + 32, float4 chunks q8 + 8 j of each
         const float *gbase[NCHE];
         int gbw[NCHE], gblk[NCHE], gk[NCHE];
@@ -702,7 +708,9 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const int cs = h1 >> 2, cx = a.d_x >> 2;
         const int njs = WG ? WG : cs >> 3, njx = (cx + 1 + 7) >> 3;      // (h1 is a multiple of 32)
         lf_u4 Bh[NK0], Bl[NK0];
-        lf_weight_planes<NK0>(st, col, cok, lh, bnscale, wscale, h1, a.d_x, 1.f, Bh, Bl);
+#pragma unroll
+        for (int q = 0; q < NK0; ++q) { Bh[q] = pfrag[(2 * q) * 64]; Bl[q] = pfrag[(2 * q + 1) * 64]; }
+        const unsigned long long t_planes = PROF ? (unsigned long long)(Bh[0][0] != 0x12345u) + clk() : 0ull;
         int koff[NCH0];
         bool wr[NCH0], isdeg[NJX];
 #pragma unroll
@@ -787,7 +795,11 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         if (PROF && prof && lane == 0 && blockIdx.x == 0) {
             for (int q = 0; q < 6; ++q) prof[(tid >> 6) * 6 + q] = pc[q];
             for (int q = 0; q < 6; ++q) prof[72 + (tid >> 6) * 6 + q] = pe[q];
+            if (tid == 256) { prof[140] = t_max - t_entry; prof[141] = t_planes - t_max; prof[142] = clk() - t_planes; }
         }
+        if (PROF && prof && tid == 256 && blockIdx.x == 128) { prof[136] = t_max - t_entry; prof[137] = t_planes - t_max; prof[138] = clk() - t_planes; prof[139] = t_entry; }
+        if (PROF && prof && tid == 256 && blockIdx.x == 0) prof[143] = t_entry;
+        if (PROF && prof && tid == 256) { prof[144 + 2 * blockIdx.x] = t_entry; prof[145 + 2 * blockIdx.x] = clk(); }   // entry / exit time of every workgroup
         return;
     }
 
@@ -795,7 +807,8 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     // group S1
     // =================================================================================================================
     lf_u4 Bh[NK1], Bl[NK1];
-    lf_weight_planes<NK1>(st, col, cok, lh, bnscale, wscale, 0, 0, 1.f, Bh, Bl);
+#pragma unroll
+    for (int q = 0; q < NK1; ++q) { Bh[q] = pfrag[(2 * q) * 64]; Bl[q] = pfrag[(2 * q + 1) * 64]; }
     const int njh = WG ? WG : a.s0.n_out >> 5;                            // 32-column groups of H that carry data (n_out multiple of 32)
     int koff[NCH1];
     bool wr[NCH1];
@@ -869,6 +882,50 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
 }
 
+// The weights of the three stages in the form the layer kernel keeps them in registers, made ONCE per weight version by one
+// workgroup: per wave the largest |W * bn_scale| of its 32 columns (-> the stage's power-of-two scale), then every wave's fp16
+// plane fragments.  Layout: see LfArgs::prep.
+template <int NKE, int NK0, int NK1>
+__global__ __launch_bounds__(768) void layer_fused_prepare_kernel(LfArgs a, unsigned *prep) {
+    __shared__ unsigned wmax[12];
+    const int tid = threadIdx.x;
+    const int grp = tid >> 8, t = tid & 255, lane = t & 63, w = t >> 6, li = lane & 31, lh = lane >> 5;
+    const LfStage &st = grp == 0 ? a.e : (grp == 1 ? a.s0 : a.s1);
+    const int col = 32 * w + li;
+    const bool cok = col < st.n_out;
+    float bnscale = 1.f;
+    if (cok && st.bn_scale) bnscale = st.bn_scale[col];
+    {
+        unsigned m = lf_weight_absmax(st, col, cok, bnscale);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+        if (lane == 0) { wmax[4 * grp + w] = m; prep[4 * grp + w] = m; }
+    }
+    __syncthreads();
+    float wscale, inv_w;
+    lf_scale(max(max(wmax[4 * grp], wmax[4 * grp + 1]), max(wmax[4 * grp + 2], wmax[4 * grp + 3])), wscale, inv_w);
+    lf_u4 *frag = reinterpret_cast<lf_u4 *>(prep + LF_PREP_HDR);
+    if (grp == 0) {
+        lf_u4 Bh[NKE], Bl[NKE];
+        lf_weight_planes<NKE>(st, col, cok, lh, bnscale, wscale, 0, 0, 1.f, Bh, Bl);
+        lf_u4 *f = frag + (NKE * 2 * w) * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < NKE; ++q) { f[(2 * q) * 64] = Bh[q]; f[(2 * q + 1) * 64] = Bl[q]; }
+    } else if (grp == 1) {
+        lf_u4 Bh[NK0], Bl[NK0];
+        lf_weight_planes<NK0>(st, col, cok, lh, bnscale, wscale, a.e.n_out, a.d_x, 1.f, Bh, Bl);
+        lf_u4 *f = frag + (4 * NKE * 2 + NK0 * 2 * w) * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < NK0; ++q) { f[(2 * q) * 64] = Bh[q]; f[(2 * q + 1) * 64] = Bl[q]; }
+    } else {
+        lf_u4 Bh[NK1], Bl[NK1];
+        lf_weight_planes<NK1>(st, col, cok, lh, bnscale, wscale, 0, 0, 1.f, Bh, Bl);
+        lf_u4 *f = frag + (4 * (NKE + NK0) * 2 + NK1 * 2 * w) * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < NK1; ++q) { f[(2 * q) * 64] = Bh[q]; f[(2 * q + 1) * 64] = Bl[q]; }
+    }
+}
+
 #undef LF_MF
 
 template <int NKE, int NK0, int NK1, int WG = 0, bool PROF = false>
@@ -892,7 +949,7 @@ static int lf_launch(const LfArgs &a, hipStream_t st) {
     if (gx > n_tiles) gx = n_tiles;
     if (getenv("GSN_CHAIN_TRACE")) fprintf(stderr, "gsn chain: layer_fused_kernel<%d,%d,%d,%d> nodes %d edges %d grid %lld\n", NKE, NK0, NK1, WG, a.n_nodes, a.n_edges, (long long)gx);
     unsigned long long *prof = nullptr;
-    if (PROF) { (void)hipMalloc(&prof, 24 * 6 * 8); (void)hipMemset(prof, 0, 24 * 6 * 8); }
+    if (PROF) { (void)hipMalloc(&prof, (24 * 6 + 512) * 8); (void)hipMemset(prof, 0, (24 * 6 + 512) * 8); }
     static const int prio_env = [] { const char *d = getenv("GSN_FUSED_PRIO"); return d ? atoi(d) : 1; }();   // matrix phases at raised wave priority (~1 %)
     int prio = prio_env & 0xff;
     if (PROF) { const char *d = getenv("GSN_FUSED_ABLATE"); if (d) prio |= atoi(d) << 8; }
@@ -900,11 +957,23 @@ static int lf_launch(const LfArgs &a, hipStream_t st) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(GSN_E_HIP, "layer_fused_kernel: %s", hipGetErrorString(e));
     if (PROF) {
-        unsigned long long h[24 * 6];
+        unsigned long long h[24 * 6 + 512];
         (void)hipDeviceSynchronize();
         (void)hipMemcpy(h, prof, sizeof(h), hipMemcpyDeviceToHost);
         (void)hipFree(prof);
         static int shown = 0;
+        if (shown % 8 == 7 && gx == 256) {           // when did the workgroups enter and leave (relative to the first entry)?
+            unsigned long long t0 = ~0ull;
+            for (int b = 0; b < 256; ++b) if (h[144 + 2 * b] && h[144 + 2 * b] < t0) t0 = h[144 + 2 * b];
+            fprintf(stderr, "fusedprof workgroup entry / exit (cycles after the first entry):");
+            for (int b = 0; b < 256; b += 15) fprintf(stderr, " [%d] %lld / %lld", b, (long long)(h[144 + 2 * b] - t0), (long long)(h[145 + 2 * b] - t0));
+            long long emax = 0, xmin = 1ll << 62, xmax = 0;
+            for (int b = 0; b < 256; ++b) {
+                const long long e = (long long)(h[144 + 2 * b] - t0), x = (long long)(h[145 + 2 * b] - t0);
+                emax = e > emax ? e : emax; xmin = x < xmin ? x : xmin; xmax = x > xmax ? x : xmax;
+            }
+            fprintf(stderr, "\nfusedprof last entry %lld, first exit %lld, last exit %lld\n", emax, xmin, xmax);
+        }
         if (shown++ % 8 == 7)
             for (int w = 0; w < 12; ++w) {
                 const unsigned long long *o = h + w * 6;
@@ -917,7 +986,9 @@ static int lf_launch(const LfArgs &a, hipStream_t st) {
                 else if (w < 8 && o[5])
                     fprintf(stderr, "fusedprof S0-%d detail: iterator %llu publish %llu staging %llu x-loads %llu | matrix+epilogue %llu sums %llu\n", w & 3,
                             e[0] / o[5], e[1] / o[5], e[2] / o[5], e[3] / o[5], e[4] / o[5], e[5] / o[5]);
-                else if (o[5])
+                if (w == 4) fprintf(stderr, "fusedprof prologue (S0-0): zero LDS + weight maxima %llu, weight planes %llu, loop %llu cycles | workgroup 128: %llu %llu %llu, entered %lld cycles after workgroup 0\n",
+                                    h[140], h[141], h[142], h[136], h[137], h[138], (long long)(h[139] - h[143]));
+                if (w >= 8 && o[5])
                     fprintf(stderr, "fusedprof S1-%d detail: matrix %llu epilogue+stores %llu | record %llu split %llu sums %llu\n", w & 3,
                             e[0] / o[5], e[1] / o[5], e[2] / o[5], e[3] / o[5], e[4] / o[5]);
             }
@@ -957,18 +1028,8 @@ extern "C" int gsn_layer_fused_supported(const gsn_chain_stage *edge, int64_t d_
     return 1;
 }
 
-extern "C" int gsn_layer_fused_fwd_hip(int64_t n_nodes, int64_t n_edges, const int32_t *seg_ptr, const gsn_chain_stage *edge,
-                                       const float *x, int64_t d_x, const gsn_chain_stage *node0, const gsn_chain_stage *node1,
-                                       float *out, void *stream) {
-    if (!gsn_layer_fused_supported(edge, d_x, node0, node1))
-        return set_error(GSN_E_UNSUPPORTED, "gsn_layer_fused_fwd_hip: shape outside the fused layer kernel (edge K <= 80, d_x + n_msg + 4 <= 160, "
-                                            "widths <= 128 and multiples of 4, int32 row sources, identity / relu)");
-    if (!seg_ptr || !x || !out) return set_error(GSN_E_INVALID, "gsn_layer_fused_fwd_hip: null seg_ptr / x / out");
-    if (reinterpret_cast<uintptr_t>(x) & 15) return set_error(GSN_E_INVALID, "gsn_layer_fused_fwd_hip: x must be 16-byte aligned");
-    if (n_nodes > (int64_t)2000000000 || n_edges > (int64_t)2000000000) return set_error(GSN_E_UNSUPPORTED, "gsn_layer_fused_fwd_hip: 32-bit row arithmetic");
-    if (n_nodes <= 0) return GSN_OK;
-    LfArgs a{};
-    a.n_nodes = (int)n_nodes; a.n_edges = (int)n_edges; a.seg_ptr = seg_ptr;
+// shared by the prepare and the forward entry: the stage descriptions of the kernel and its (NK0, NK1) instantiation
+static void lf_fill_stages(LfArgs &a, const gsn_chain_stage *edge, int64_t d_x, const gsn_chain_stage *node0, const gsn_chain_stage *node1) {
     a.e_nblocks = edge->n_blocks;
     int ke = 0;
     for (int b = 0; b < edge->n_blocks; ++b) {
@@ -982,12 +1043,57 @@ extern "C" int gsn_layer_fused_fwd_hip(int64_t n_nodes, int64_t n_edges, const i
     fill(a.e, *edge, ke);
     fill(a.s0, *node0, (int)(d_x + edge->n_out + 4));
     fill(a.s1, *node1, (int)node0->n_out);
-    a.x = x; a.d_x = (int)d_x; a.out = out;
+    a.d_x = (int)d_x;
+}
+static int lf_nk0(const LfArgs &a) { return a.s0.k_total <= 96 ? 6 : 10; }
+static int lf_nk1(const LfArgs &a) { return a.s1.k_total <= 64 ? 4 : 8; }
+
+extern "C" int64_t gsn_layer_fused_prepared_bytes(const gsn_chain_stage *edge, int64_t d_x, const gsn_chain_stage *node0,
+                                                  const gsn_chain_stage *node1) {
+    if (!gsn_layer_fused_supported(edge, d_x, node0, node1)) return 0;
+    LfArgs a{};
+    lf_fill_stages(a, edge, d_x, node0, node1);
+    return (int64_t)(LF_PREP_HDR + 4 * (5 + lf_nk0(a) + lf_nk1(a)) * 2 * 64 * 4) * 4;
+}
+
+extern "C" int gsn_layer_fused_prepare_hip(const gsn_chain_stage *edge, int64_t d_x, const gsn_chain_stage *node0,
+                                           const gsn_chain_stage *node1, void *prepared, void *stream) {
+    if (!gsn_layer_fused_supported(edge, d_x, node0, node1))
+        return set_error(GSN_E_UNSUPPORTED, "gsn_layer_fused_prepare_hip: shape outside the fused layer kernel");
+    if (!prepared || (reinterpret_cast<uintptr_t>(prepared) & 15)) return set_error(GSN_E_INVALID, "gsn_layer_fused_prepare_hip: prepared must be a 16-byte aligned device buffer");
+    LfArgs a{};
+    lf_fill_stages(a, edge, d_x, node0, node1);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    unsigned *pp = reinterpret_cast<unsigned *>(prepared);
+    const int nk0 = lf_nk0(a), nk1 = lf_nk1(a);
+    if (nk0 == 6 && nk1 == 4) hipLaunchKernelGGL((layer_fused_prepare_kernel<5, 6, 4>), dim3(1), dim3(768), 0, st, a, pp);
+    else if (nk0 == 6) hipLaunchKernelGGL((layer_fused_prepare_kernel<5, 6, 8>), dim3(1), dim3(768), 0, st, a, pp);
+    else if (nk1 == 4) hipLaunchKernelGGL((layer_fused_prepare_kernel<5, 10, 4>), dim3(1), dim3(768), 0, st, a, pp);
+    else hipLaunchKernelGGL((layer_fused_prepare_kernel<5, 10, 8>), dim3(1), dim3(768), 0, st, a, pp);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(GSN_E_HIP, "layer_fused_prepare_kernel: %s", hipGetErrorString(e));
+    return GSN_OK;
+}
+
+extern "C" int gsn_layer_fused_fwd_hip(int64_t n_nodes, int64_t n_edges, const int32_t *seg_ptr, const gsn_chain_stage *edge,
+                                       const float *x, int64_t d_x, const gsn_chain_stage *node0, const gsn_chain_stage *node1,
+                                       const void *prepared, float *out, void *stream) {
+    if (!gsn_layer_fused_supported(edge, d_x, node0, node1))
+        return set_error(GSN_E_UNSUPPORTED, "gsn_layer_fused_fwd_hip: shape outside the fused layer kernel (edge K <= 80, d_x + n_msg + 4 <= 160, "
+                                            "widths <= 128 and multiples of 4, int32 row sources, identity / relu)");
+    if (!seg_ptr || !x || !out || !prepared) return set_error(GSN_E_INVALID, "gsn_layer_fused_fwd_hip: null seg_ptr / x / out / prepared (gsn_layer_fused_prepare_hip)");
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(prepared)) & 15) return set_error(GSN_E_INVALID, "gsn_layer_fused_fwd_hip: x and prepared must be 16-byte aligned");
+    if (n_nodes > (int64_t)2000000000 || n_edges > (int64_t)2000000000) return set_error(GSN_E_UNSUPPORTED, "gsn_layer_fused_fwd_hip: 32-bit row arithmetic");
+    if (n_nodes <= 0) return GSN_OK;
+    LfArgs a{};
+    a.n_nodes = (int)n_nodes; a.n_edges = (int)n_edges; a.seg_ptr = seg_ptr;
+    lf_fill_stages(a, edge, d_x, node0, node1);
+    a.x = x; a.out = out; a.prep = reinterpret_cast<const unsigned *>(prepared);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int k0 = a.s0.k_total, k1 = a.s1.k_total;
     // every width 128 (or 64): the reference's d = 128 / 64 layers -- widths as compile-time constants
     const bool generic = getenv("GSN_FUSED_GENERIC") != nullptr;
-    const bool w128 = !generic && a.e.n_out == 128 && a.s0.n_out == 128 && a.s1.n_out == 128 && k0 <= 160;
+    const bool w128 = !generic && a.e.n_out == 128 && a.s0.n_out == 128 && a.s1.n_out == 128 && k0 <= 160 && k0 > 96 && k1 > 64;
     const bool w64 = !generic && a.e.n_out == 64 && a.s0.n_out == 64 && a.s1.n_out == 64 && k0 <= 96;
     { const char *d = getenv("GSN_FUSED_PROF"); if (d && atoi(d) && w128) return lf_launch<5, 10, 8, 4, true>(a, st); }
     if (w128) return lf_launch<5, 10, 8, 4>(a, st);

@@ -581,7 +581,7 @@ def invalidate_caches(module=None):
         _CSR_CACHE.clear()
         return
     for m in module.modules():
-        for attr in ("_fold_cache", "_split_cache", "_gsn_eval_cache", "_gsn_wt"):
+        for attr in ("_fold_cache", "_split_cache", "_fused_prep", "_gsn_eval_cache", "_gsn_wt"):
             if hasattr(m, attr):
                 try:
                     delattr(m, attr)
@@ -622,7 +622,16 @@ def _stage_struct(st, blocks, keep):
     return g
 
 
-def _layer_fused(x, csr, edge_stages, node_stages, training):
+def _prep_key(st):
+    bn = st.bn
+    bk = None
+    if bn is not None:
+        bk = (bn.running_mean._version, bn.running_var._version, bn.running_mean.data_ptr(),
+              (bn.weight._version, bn.bias._version) if bn.affine else None)
+    return (st.weight.data_ptr(), st.weight._version, tuple(st.weight.shape), bk)
+
+
+def _layer_fused(x, csr, edge_stages, node_stages, training, owner=None, gen=0):
     """edge stage + per-target sum + two node stages in ONE launch (gsn_layer_fused_fwd_hip); None if the layer does not
     fit (shape, activation, or a BatchNorm1d that needs batch statistics)."""
     if not FUSED_LAYER or len(edge_stages) != 1 or len(node_stages) != 2:
@@ -652,9 +661,22 @@ def _layer_fused(x, csr, edge_stages, node_stages, training):
     out = torch.empty((n, node_stages[1].weight.shape[0]), dtype=torch.float32, device=x.device)
     flops = 2.0 * E * edge_stages[0].weight.shape[1] * edge_stages[0].weight.shape[0]
     flops += 2.0 * n * (node_stages[0].weight.shape[1] * node_stages[0].weight.shape[0] + node_stages[1].weight.shape[1] * node_stages[1].weight.shape[0])
+    # the weights as the kernel's register fragments: once per weight version (kept on the layer module)
+    key = (tuple(_prep_key(st) for st in stages), d_x, gen)
+    hit = getattr(owner, "_fused_prep", None) if owner is not None else None
+    if hit is not None and hit[0] == key:
+        prep = hit[1]
+    else:
+        nbytes = int(L.gsn_layer_fused_prepared_bytes(ctypes.byref(ge), d_x, ctypes.byref(g0), ctypes.byref(g1)))
+        prep = torch.empty(nbytes // 4, dtype=torch.int32, device=x.device)
+        with _abi.device_guard(x.device):
+            _abi.check(L.gsn_layer_fused_prepare_hip(ctypes.byref(ge), d_x, ctypes.byref(g0), ctypes.byref(g1), prep.data_ptr(),
+                                                     _abi.current_stream()), "gsn_layer_fused_prepare_hip")
+        if owner is not None:
+            owner._fused_prep = (key, prep)
     with _abi.device_guard(x.device), _timed("layer_fused", flops):
         rc = L.gsn_layer_fused_fwd_hip(n, E, csr.seg_ptr.data_ptr(), ctypes.byref(ge), x.data_ptr(), d_x, ctypes.byref(g0),
-                                       ctypes.byref(g1), out.data_ptr(), _abi.current_stream())
+                                       ctypes.byref(g1), prep.data_ptr(), out.data_ptr(), _abi.current_stream())
     _abi.check(rc, "gsn_layer_fused_fwd_hip")
     return out
 
@@ -1382,7 +1404,7 @@ class _SparseLayer(nn.Module):
                 if post is None or post[0] is None or post[0].training == uf.training:
                     y = _layer_fused(x, csr, mf.stages(sblocks, upto=len(mf.fc) - 1),
                                      uf.stages([(x, None)], first_weight=self._folded_first_weight(x.shape[1]), post=post),
-                                     self.training)
+                                     self.training, owner=self, gen=getattr(self, "_fold_gen", 0))
                     if y is not None:
                         return y
                 # wide edge rows (K > 160: layers 1.. of a d = 128 model, K = 260): the node part of the Linear once per NODE,
@@ -1512,6 +1534,7 @@ class _SparseLayer(nn.Module):
         # three zero columns after the degree column: the degree block is passed 4 floats wide (csr.deg4)
         w_first = torch.cat([w3x, w_fold, b_fold, torch.zeros_like(b_fold).expand(-1, 3)], 1).contiguous()
         self._fold_cache = (key, w_first)
+        self._fold_gen = getattr(self, "_fold_gen", 0) + 1        # (a new tensor may reuse the old one's address)
         return w_first
 
     # -- differentiable twin (PyTorch ops + the HIP propagate with its own adjoint) ---------------------------------

@@ -264,9 +264,18 @@ int gsn_mlp_chain_fwd_hip(int64_t m_rows, int n_stages, const gsn_chain_stage *s
  * ---------------------------------------------------------------------------------------------------------------- */
 int gsn_layer_fused_supported(const gsn_chain_stage *edge, int64_t d_x, const gsn_chain_stage *node0,
                               const gsn_chain_stage *node1);
+/* The weights in the form the kernel keeps them in registers (per stage a power-of-two scale from max |W * bn_scale|, fp16
+ * plane fragments per wave and K step) are made ONCE per weight version by gsn_layer_fused_prepare_hip into a device buffer of
+ * gsn_layer_fused_prepared_bytes() bytes (16-byte aligned) and handed to every forward call as `prepared`; re-run it when W,
+ * bias-independent: bn_scale or W of a stage changed.  (Split inside the forward kernel, every workgroup re-read every weight
+ * row at the same moment: 50 - 400 k cycles of prologue per launch under load.) */
+int64_t gsn_layer_fused_prepared_bytes(const gsn_chain_stage *edge, int64_t d_x, const gsn_chain_stage *node0,
+                                       const gsn_chain_stage *node1);
+int gsn_layer_fused_prepare_hip(const gsn_chain_stage *edge, int64_t d_x, const gsn_chain_stage *node0,
+                                const gsn_chain_stage *node1, void *prepared, void *stream);
 int gsn_layer_fused_fwd_hip(int64_t n_nodes, int64_t n_edges, const int32_t *seg_ptr, const gsn_chain_stage *edge,
                             const float *x, int64_t d_x, const gsn_chain_stage *node0, const gsn_chain_stage *node1,
-                            float *out, void *stream);
+                            const void *prepared, float *out, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * HP-2  dense stage on DIRECT rows with fp16x3 matrix arithmetic (device): the same operation as gsn_linear_fwd_hip
