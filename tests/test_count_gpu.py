@@ -321,3 +321,25 @@ def test_count_with_fused_encoding(mode):
         count_batch(plan, b.node_ptr, b.edge_ptr, b.edge_index, max_nodes=8, max_edges=200, encode=([3, 3, 3, 3], True))
     with pytest.raises(ValueError):
         count_batch(plan, b.node_ptr, b.edge_ptr, b.edge_index, encode=([3, 3, 3], True))
+
+
+@pytest.mark.parametrize("mode", ["vertex", "edge"])
+def test_fused_encoding_on_split_graphs(mode):
+    """Few heavy graphs: several workgroups share one graph's cells (split > 1), so the class indices cannot be staged per graph
+    and every cell writes its floats itself; duplicates and self loops in the columns."""
+    from gsn_amd import synth, layers
+    from gsn_amd.counting import CountPlan, count_batch
+    graphs = [synth.er_graph(128, 900, s) for s in (5, 6, 7)]
+    n0, e0 = graphs[0]
+    graphs[0] = (n0, np.concatenate([e0, e0[:, :7], np.array([[3, 9], [3, 9]])], axis=1))      # repeated columns + self loops
+    b = synth.collate(graphs)
+    plan = CountPlan.get(_cycles(range(3, 6)), mode, False)
+    ref, _ = count_batch(plan, b.node_ptr, b.edge_ptr, b.edge_index)
+    n_classes = [4, 7, 250]
+    for clamp in (True, False):
+        want = layers.one_hot_identifiers(ref, n_classes, clamp=clamp)
+        out, _, enc = count_batch(plan, b.node_ptr, b.edge_ptr, b.edge_index, encode=(n_classes, clamp))
+        assert torch.equal(out, ref) and torch.equal(enc, want)
+        _, _, enc2 = count_batch(plan, b.node_ptr, b.edge_ptr, b.edge_index, encode=(n_classes, clamp), counts=False)
+        assert torch.equal(enc2, want)
+    assert int(ref.max()) > 7          # (the clamp matters)
