@@ -513,6 +513,8 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         lf_u4 Bh[NKE], Bl[NKE];
 #pragma unroll
         for (int q = 0; q < NKE; ++q) { Bh[q] = pfrag[(2 * q) * 64]; Bl[q] = pfrag[(2 * q + 1) * 64]; }
+        __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the fragments are HERE -- left "in flight" into the loop, their first uses get
+                                                 // a wait in every iteration, and in this group's loop that wait covers the gathers as well
         // staging map: thread -> rows r8 and r8 + 32, float4 chunks q8 + 8 j of each
         const float *gbase[NCHE];
         int gbw[NCHE], gblk[NCHE], gk[NCHE];
@@ -710,6 +712,8 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         lf_u4 Bh[NK0], Bl[NK0];
 #pragma unroll
         for (int q = 0; q < NK0; ++q) { Bh[q] = pfrag[(2 * q) * 64]; Bl[q] = pfrag[(2 * q + 1) * 64]; }
+        __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the fragments are HERE -- left "in flight" into the loop, their first uses get
+                                                 // a wait in every iteration, and in this group's loop that wait covers the gathers as well
         const unsigned long long t_planes = PROF ? (unsigned long long)(Bh[0][0] != 0x12345u) + clk() : 0ull;
         int koff[NCH0];
         bool wr[NCH0], isdeg[NJX];
@@ -809,6 +813,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     lf_u4 Bh[NK1], Bl[NK1];
 #pragma unroll
     for (int q = 0; q < NK1; ++q) { Bh[q] = pfrag[(2 * q) * 64]; Bl[q] = pfrag[(2 * q + 1) * 64]; }
+    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0), see group E
     const int njh = WG ? WG : a.s0.n_out >> 5;                            // 32-column groups of H that carry data (n_out multiple of 32)
     int koff[NCH1];
     bool wr[NCH1];
