@@ -969,11 +969,12 @@ static int lf_launch(const LfArgs &a, hipStream_t st) {
         static int shown = 0;
         if (shown % 8 == 7 && gx == 256) {           // when did the workgroups enter and leave (relative to the first entry)?
             unsigned long long t0 = ~0ull;
-            for (int b = 0; b < 256; ++b) if (h[144 + 2 * b] && h[144 + 2 * b] < t0) t0 = h[144 + 2 * b];
-            fprintf(stderr, "fusedprof workgroup entry / exit (cycles after the first entry):");
-            for (int b = 0; b < 256; b += 15) fprintf(stderr, " [%d] %lld / %lld", b, (long long)(h[144 + 2 * b] - t0), (long long)(h[145 + 2 * b] - t0));
+            // (s_memtime counters are per XCD: only the workgroups of one XCD, blockIdx % 8 == 0, are comparable)
+            for (int b = 0; b < 256; b += 8) if (h[144 + 2 * b] && h[144 + 2 * b] < t0) t0 = h[144 + 2 * b];
+            fprintf(stderr, "fusedprof workgroup entry / exit on XCD 0 (cycles after its first entry):");
+            for (int b = 0; b < 256; b += 40) fprintf(stderr, " [%d] %lld / %lld", b, (long long)(h[144 + 2 * b] - t0), (long long)(h[145 + 2 * b] - t0));
             long long emax = 0, xmin = 1ll << 62, xmax = 0;
-            for (int b = 0; b < 256; ++b) {
+            for (int b = 0; b < 256; b += 8) {
                 const long long e = (long long)(h[144 + 2 * b] - t0), x = (long long)(h[145 + 2 * b] - t0);
                 emax = e > emax ? e : emax; xmin = x < xmin ? x : xmin; xmax = x > xmax ? x : xmax;
             }
@@ -991,8 +992,8 @@ static int lf_launch(const LfArgs &a, hipStream_t st) {
                 else if (w < 8 && o[5])
                     fprintf(stderr, "fusedprof S0-%d detail: iterator %llu publish %llu staging %llu x-loads %llu | matrix+epilogue %llu sums %llu\n", w & 3,
                             e[0] / o[5], e[1] / o[5], e[2] / o[5], e[3] / o[5], e[4] / o[5], e[5] / o[5]);
-                if (w == 4) fprintf(stderr, "fusedprof prologue (S0-0): zero LDS + weight maxima %llu, weight planes %llu, loop %llu cycles | workgroup 128: %llu %llu %llu, entered %lld cycles after workgroup 0\n",
-                                    h[140], h[141], h[142], h[136], h[137], h[138], (long long)(h[139] - h[143]));
+                if (w == 4) fprintf(stderr, "fusedprof prologue of workgroup 0 / 128 (wave S0-0): LDS clear + tables %llu / %llu, weight fragments %llu / %llu cycles\n",
+                                    h[140], h[136], h[141], h[137]);
                 if (w >= 8 && o[5])
                     fprintf(stderr, "fusedprof S1-%d detail: matrix %llu epilogue+stores %llu | record %llu split %llu sums %llu\n", w & 3,
                             e[0] / o[5], e[1] / o[5], e[2] / o[5], e[3] / o[5], e[4] / o[5]);
