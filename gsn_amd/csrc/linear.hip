@@ -38,6 +38,11 @@ constexpr int NPRE = BM / 8;  // staged elements per thread per slice (A); a W^T
 struct LinArgs {
     int64_t m_rows;
     int n_blocks;
+    // the same five blocks as named fields (cb*, cw*): the per-lane block choice of col_map_l among ARRAY elements of the argument
+    // block is compiled into a vector load of the pointer from the argument segment -- a dependent load and a wait in front of every
+    // slice's fetch; selects among named fields stay in registers
+    const float *cb0, *cb1, *cb2, *cb3, *cb4;
+    int cw0, cw1, cw2, cw3, cw4;
     const float *bdata[MAX_BLOCKS];
     const int64_t *bidx[MAX_BLOCKS];
     const int32_t *bidx32[MAX_BLOCKS];
@@ -69,19 +74,14 @@ struct ColMapL {
 };
 
 __device__ __forceinline__ ColMapL col_map_l(const LinArgs &a, int kg) {
-    int blk = 0, col = kg;
-#pragma unroll
-    for (int b = 0; b < MAX_BLOCKS - 1; ++b) {
-        if (b < a.n_blocks - 1 && blk == b && col >= a.bwidth[b]) { col -= a.bwidth[b]; blk = b + 1; }
-    }
-    if (kg >= a.k_total) { blk = 0; col = 0; }
-    const float *bd = a.bdata[0];
-    int bw = a.bwidth[0];
-#pragma unroll
-    for (int b = 1; b < MAX_BLOCKS; ++b)
-        if (blk == b) { bd = a.bdata[b]; bw = a.bwidth[b]; }
+    const int p1 = a.cw0, p2 = p1 + a.cw1, p3 = p2 + a.cw2, p4 = p3 + a.cw3;        // first column of blocks 1 .. 4 (uniform; past K when absent)
+    if (kg >= a.k_total) kg = 0;                                                     // (a valid address; its W row is 0)
     ColMapL m;
-    m.base = bd + col; m.bw = bw; m.rsoff = blk * BM;
+    m.base = a.cb0 + kg; m.bw = a.cw0; m.rsoff = 0;
+    if (kg >= p1) { m.base = a.cb1 + (kg - p1); m.bw = a.cw1; m.rsoff = BM; }
+    if (kg >= p2) { m.base = a.cb2 + (kg - p2); m.bw = a.cw2; m.rsoff = 2 * BM; }
+    if (kg >= p3) { m.base = a.cb3 + (kg - p3); m.bw = a.cw3; m.rsoff = 3 * BM; }
+    if (kg >= p4) { m.base = a.cb4 + (kg - p4); m.bw = a.cw4; m.rsoff = 4 * BM; }
     return m;
 }
 
@@ -614,6 +614,12 @@ extern "C" int gsn_linear_fwd_hip(int64_t m_rows, int n_blocks, const gsn_block 
         k_total += (int)blocks[b].width;
     }
     a.k_total = k_total; a.n_out = (int)n_out; a.act = act;
+    {
+        const float *cb[MAX_BLOCKS]; int cw[MAX_BLOCKS];
+        for (int b = 0; b < MAX_BLOCKS; ++b) { cb[b] = b < n_blocks ? a.bdata[b] : a.bdata[0]; cw[b] = b < n_blocks ? a.bwidth[b] : (1 << 27); }
+        a.cb0 = cb[0]; a.cb1 = cb[1]; a.cb2 = cb[2]; a.cb3 = cb[3]; a.cb4 = cb[4];
+        a.cw0 = cw[0]; a.cw1 = cw[1]; a.cw2 = cw[2]; a.cw3 = cw[3]; a.cw4 = cw[4];
+    }
     a.W = W; a.bias = bias; a.bn_mean = bn_mean; a.bn_scale = bn_scale; a.bn_shift = bn_shift;
     a.row_perm = row_perm; a.out = out; a.stats = stats;
     const int64_t n_tiles = (m_rows + BM - 1) / BM;
