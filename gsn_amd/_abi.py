@@ -53,6 +53,7 @@ SIGNATURES = {
     "gsn_csr_scratch_elems": (c_i64, [c_i64]),
     "gsn_csr_build_hip": (c_int, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "gsn_linear_f16x3_kpad": (c_i64, [c_i64]),
+    "gsn_linear_f16x3_scratch_bytes": (c_i64, [c_i64, c_i64]),
     "gsn_linear_f16x3_prepare_hip": (c_int, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp]),
     "gsn_linear_f16x3_fwd_hip": (c_int, [c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),
     "gsn_edge_split_sum_hip": (c_int, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_vp]),

@@ -7,20 +7,22 @@
 // workgroup) handled at 85-100 TF/s fp32-equivalent.  Differences:
 //   * two fp16 planes per operand after an exact power-of-two scaling, three plane products per fp32 product: half the matrix
 //     work of bf16x6 at the same error (scripts/micro/bf16x6_check.hip);
-//   * the weights are split ONCE (gsn_linear_f16x3_prepare_hip: per output column a power-of-two scale from its largest entry,
-//     planes [2][n_out][K_pad] of fp16 in a caller buffer that lives as long as the weights do) instead of in every K slice of
-//     every row tile: the kernel stages them with plain 8-byte copies;
-//   * every input row gets its scale from a pre-pass over the row (lin16_rowscale_kernel: largest magnitude over ALL its
-//     columns, so one accumulator serves the whole K loop); the epilogue multiplies the row's and the column's inverse scales
-//     back in (exact), then bias / BatchNorm / activation as in linear.hip.
-// Tiling as linear_fwd_bf16_kernel: persistent workgroups of 8 waves on 128 x 128 output tiles, 32-wide K slices, planes
-// double-buffered in LDS (row pitch 80 bytes: conflict-free ds_read_b128), wave w = rows 64 (w >> 2).., columns 32 (w & 3)..
+//   * BOTH operands reach the matrix kernel as fp16 planes: the weights are split once per weight version
+//     (gsn_linear_f16x3_prepare_hip: per output column a power-of-two scale from its largest entry), the rows once per call by a
+//     pre-pass (lin16_split_rows_kernel: per row a scale from its largest magnitude over ALL its columns, so one accumulator
+//     serves the whole K loop) -- not per K slice by every column tile; the epilogue multiplies the row's and the column's
+//     inverse scales back in (exact), then bias / BatchNorm / activation as in linear.hip;
+//   * plane layout in memory [row][K slice][high | low][32 halfs]: the 128 bytes one (row, 32-wide K slice) needs are ONE cache
+//     line.  scripts/micro/l1_stream.hip: a CU pulls 51 bytes per clock through its vector L1 when every wave instruction reads
+//     whole lines, 16 when it reads 64-byte halves of 16 lines (what [plane][row][K] gives) -- and that rate, not the matrix
+//     pipe, is what bounds a kernel of this shape.
 // Rows with an Inf / NaN come out NaN in all columns (documented deviation of the split-operand kernels).
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "gsn_internal.h"
 
@@ -28,9 +30,8 @@ namespace gsn {
 
 namespace {
 
-constexpr int L_BM = 128, L_BN = 128, L_BK = 32;
-constexpr int L_BKP = L_BK + 8;                    // fp16 row pitch of a plane
-constexpr int L_PLANE = L_BM * L_BKP / 2;          // 32-bit words per plane
+constexpr int L_BK = 32;                           // K slice
+constexpr int L_LINE = 4 * L_BK;                   // bytes of one (row, slice): 32 high halfs, 32 low halfs
 constexpr int L_MAXB = 5;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -47,12 +48,17 @@ struct L16Args {
     //  the argument segment, and the wait for that pointer drains every prefetch in flight)
     const float *b0, *b1, *b2, *b3, *b4;
     int w0, w1, w2, w3, w4;        // widths (0 past n_blocks)
-    const _Float16 *wplanes;       // [2][n_out][k_pad]
+    const unsigned char *wplanes;  // [n_out][k_pad / 32][2][32] halfs
     const float *colinv;           // [n_out] inverse column scales
     const float *bias, *bn_mean, *bn_scale, *bn_shift;
     int k_total, k_pad, n_out, act;
-    float *rowscale;               // [2][m_rows]: scale, inverse
     float *out;
+    float *rowinv;                 // [m_pad] inverse row scales (0 past m_rows)
+    unsigned char *aplanes;        // [m_rows][k_pad / 32][2][32] halfs
+    int64_t m_pad;
+    int col_tiles, groups;         // column tiles of the output, row groups per XCD
+    int dbg;                       // diagnostic build: 1 no stores, 2 no products, 4 no loads, 8 no LDS writes
+    unsigned long long *prof;      // diagnostic build: cycles per phase of workgroup 0, wave 0
 };
 
 __device__ __forceinline__ void l16_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -81,6 +87,8 @@ __device__ __forceinline__ float l16_act(float y, int act) {
         default: return y;
     }
 }
+
+__device__ __noinline__ float l16_act_slow(float y, int act) { return l16_act(y, act); }
 
 // concatenated column kg -> (block base + column, block width); clamped to a valid address past K
 struct L16Col {
@@ -111,193 +119,320 @@ __global__ __launch_bounds__(64) void lin16_prepare_kernel(const float *__restri
     float s, inv;
     l16_scale(m, s, inv);
     if (m >= 0x7f800000u) inv = __uint_as_float(0x7fc00000u);        // a non-finite weight: the whole output column is NaN
-    _Float16 *ph = planes + (int64_t)j * k_pad, *pl = planes + ((int64_t)n_out + j) * k_pad;
+    _Float16 *row = planes + (int64_t)j * k_pad * 2;
     for (int k = lane; k < k_pad; k += 64) {
         const float v = k < k_total ? w[k] * s : 0.f;
         const _Float16 h = (_Float16)v;
-        ph[k] = h;
-        pl[k] = (_Float16)(v - (float)h);
+        _Float16 *line = row + (k >> 5) * 64 + (k & 31);
+        line[0] = h;
+        line[32] = (_Float16)(v - (float)h);
     }
     if (lane == 0) colinv[j] = inv;
 }
 
-// ---- rows: 8 lanes per row, float4 chunks over the concatenated blocks ---------------------------------------------------------
-__global__ __launch_bounds__(256) void lin16_rowscale_kernel(L16Args a) {
-    const int64_t row = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
+// ---- rows split ONCE per call: scale + two fp16 planes -----------------------------------------------------------------------------
+// 8 lanes per row, float4 chunks over the concatenated blocks.  The chunks of a row up to K = 320 stay in registers between the
+// pass that finds the row's largest magnitude and the pass that writes its planes; wider rows are read again (from L2).
+constexpr int L_RC = 10;
+__global__ __launch_bounds__(256) void lin16_split_rows_kernel(L16Args a) {
+    const int64_t row = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);     // < m_pad
     const int q8 = threadIdx.x & 7;
+    const bool on = row < a.m_rows;
+    const int64_t rr = on ? row : a.m_rows - 1;
+    const int nch = a.k_total >> 2, nchp = a.k_pad >> 2;
+    float4 v[L_RC];
     unsigned m = 0;
-    if (row < a.m_rows) {
-        for (int c = q8; 4 * c < a.k_total; c += 8) {
+    auto amax = [&](const float4 &x) {
+        m = max(max(m, __float_as_uint(x.x) & 0x7fffffffu), __float_as_uint(x.y) & 0x7fffffffu);
+        m = max(max(m, __float_as_uint(x.z) & 0x7fffffffu), __float_as_uint(x.w) & 0x7fffffffu);
+    };
+#pragma unroll
+    for (int i = 0; i < L_RC; ++i) {
+        const int c = q8 + 8 * i;
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < nch) {
             const L16Col cm = l16_col(a, 4 * c);
-            const float4 v = *reinterpret_cast<const float4 *>(cm.base + row * cm.bw);
-            m = max(max(m, __float_as_uint(v.x) & 0x7fffffffu), __float_as_uint(v.y) & 0x7fffffffu);
-            m = max(max(m, __float_as_uint(v.z) & 0x7fffffffu), __float_as_uint(v.w) & 0x7fffffffu);
+            v[i] = *reinterpret_cast<const float4 *>(cm.base + rr * cm.bw);
+            amax(v[i]);
         }
+    }
+    for (int c = q8 + 8 * L_RC; c < nch; c += 8) {
+        const L16Col cm = l16_col(a, 4 * c);
+        amax(*reinterpret_cast<const float4 *>(cm.base + rr * cm.bw));
     }
     m = max(m, (unsigned)__shfl_xor((int)m, 1));
     m = max(m, (unsigned)__shfl_xor((int)m, 2));
     m = max(m, (unsigned)__shfl_xor((int)m, 4));
-    if (row < a.m_rows && q8 == 0) {
-        float s, inv;
-        l16_scale(m, s, inv);
-        if (m >= 0x7f800000u) inv = __uint_as_float(0x7fc00000u);    // Inf / NaN in the row: its outputs become NaN
-        a.rowscale[row] = s;
-        a.rowscale[a.m_rows + row] = inv;
+    float s, inv;
+    l16_scale(m, s, inv);
+    if (m >= 0x7f800000u) inv = __uint_as_float(0x7fc00000u);            // Inf / NaN in the row: its outputs become NaN
+    if (q8 == 0) a.rowinv[row] = on ? inv : 0.f;
+    if (!on) return;
+    unsigned char *prow = a.aplanes + row * a.k_pad * 4;                 // (4 bytes per column: a high and a low half)
+    auto put = [&](int c, const float4 &x) {                              // chunk c = columns 4c .. 4c + 3: slice c >> 3, piece c & 7
+        unsigned h0, l0, h1, l1;
+        l16_split2(fl2{x.x * s, x.y * s}, h0, l0);
+        l16_split2(fl2{x.z * s, x.w * s}, h1, l1);
+        unsigned char *line = prow + (c >> 3) * L_LINE + (c & 7) * 8;     // (the 8 lanes of a row write one whole line per trip)
+        *reinterpret_cast<un2 *>(line) = un2{h0, h1};
+        *reinterpret_cast<un2 *>(line + 64) = un2{l0, l1};
+    };
+#pragma unroll
+    for (int i = 0; i < L_RC; ++i) {
+        const int c = q8 + 8 * i;
+        if (c < nchp) put(c, v[i]);                                        // (zero past K: the padding columns)
+    }
+    for (int c = q8 + 8 * L_RC; c < nchp; c += 8) {
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < nch) {
+            const L16Col cm = l16_col(a, 4 * c);
+            x = *reinterpret_cast<const float4 *>(cm.base + row * cm.bw);
+        }
+        put(c, x);
     }
 }
 
-// ---- the product ------------------------------------------------------------------------------------------------------------------
-// TWO workgroups per CU (exactly 80 KiB of LDS each, <= 128 registers): the staging phase of one runs under the matrix phase of
-// the other -- inside one workgroup the slices are lock-step (stage | barrier | products).
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void linear_f16x3_kernel(L16Args a) {
+// ---- the product on pre-split rows ---------------------------------------------------------------------------------------------------
+// A plain fp16 matrix kernel with three plane products per k-step: both operands arrive as fp16 planes and are staged with 16-byte
+// copies (no arithmetic between the load and LDS).  2 WM waves on a (64 WM) x (64 NJ) output tile, wave w = rows 64 (w >> 1)..,
+// columns 32 NJ (w & 1)..; the lines of two K slices in LDS (row pitch 144 bytes = 64 high + 64 low + 16: 16-byte fragment reads
+// and 128-byte row writes are both conflict-free), the next slice travels through registers while the current one is
+// multiplied; ONE barrier per slice.  <4, 4>: 256 x 256 tiles, one workgroup per CU; <2, 2>: 128 x 128 tiles, two per CU.
+// Workgroup -> (XCD, column tile, row group): the column tiles of one row tile run on the same XCD at the same time, its rows
+// leave HBM once.  The output tile leaves in 16-byte stores through a buffer resource per tile (rows past M and columns past N
+// are dropped by the range check).
+constexpr int P_PITCH = L_LINE + 16;               // bytes per row in LDS
+template <int WM, int NJ, bool PROF, bool VEC>
+__global__ __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(2, 2))) void linear_f16x3_planes_kernel(L16Args a) {
+    const int dbg = PROF ? a.dbg : 0;
+    constexpr int P_BM = 64 * WM, BN = 64 * NJ;                            // output rows / columns per tile
+    constexpr int NT = 128 * WM;                                           // threads
+    constexpr int RP = 16 * WM;                                            // rows one staging pass of the workgroup covers
+    constexpr int NWP = BN / RP;                                           // passes over the weight rows
+    constexpr int A_RG = P_BM * P_PITCH, W_RG = BN * P_PITCH, BUF = A_RG + W_RG;
     extern __shared__ __attribute__((aligned(16))) unsigned l16_lds[];
-    // [2 buffers][A planes h, l | W planes h, l][L_PLANE words].  The row tables (scale, inverse scale of the tile's 128 rows, two
-    // slots) live in the 16 padding bytes behind row r of the first plane: words 16 .. 19 of the row = scale0, inv0, scale1, inv1.
-    auto a_planes = [&](int buf) { return l16_lds + buf * 4 * L_PLANE; };
-    auto w_planes = [&](int buf) { return l16_lds + buf * 4 * L_PLANE + 2 * L_PLANE; };
-    auto rtab = [&](int slot, int which, int r) -> float & { return reinterpret_cast<float *>(l16_lds)[r * (L_BKP / 2) + L_BK / 2 + 2 * slot + which]; };
+    unsigned char *const lds = reinterpret_cast<unsigned char *>(l16_lds);
+    auto a_rows = [&](int buf) { return lds + buf * BUF; };
+    auto w_rows = [&](int buf) { return lds + buf * BUF + A_RG; };
+    // inverse row scales of a tile: two slots in the padding behind row r of buffer 0 (bytes 128 .. 135 of the row)
+    auto rtab = [&](int slot, int r) -> float & { return *reinterpret_cast<float *>(lds + r * P_PITCH + L_LINE + 4 * slot); };
+    auto clk = [&]() -> unsigned long long {
+        if (!PROF) return 0ull;
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long v = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_sched_barrier(0);
+        return v;
+    };
+    unsigned long long pq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
-    const int kc = 4 * (tid & 7), r0 = tid >> 3;                          // staging: columns kc .. kc + 3 of rows / output columns r0, r0 + 64
-    const int n0 = blockIdx.y * L_BN;
-    const int64_t n_tiles = (a.m_rows + L_BM - 1) / L_BM;
+    // staging: 8 lanes = the 128-byte line of one (row, slice); a wave instruction moves 8 whole lines.  Thread -> piece sp of rows
+    // (output columns) sr, sr + RP, ..
+    const int sr = 8 * wave + (lane >> 3), sp = lane & 7;
+    const int xcd = blockIdx.x & 7, slot_in_xcd = blockIdx.x >> 3;
+    const int ct = slot_in_xcd % a.col_tiles, grp = slot_in_xcd / a.col_tiles;
+    const int n0 = ct * BN;
+    const int64_t n_tiles = (a.m_rows + P_BM - 1) / P_BM;
+    const int64_t tile0 = (int64_t)xcd * a.groups + grp, tstride = 8 * (int64_t)a.groups;
+    const int64_t n_mine = tile0 < n_tiles ? (n_tiles - tile0 + tstride - 1) / tstride : 0;
     const int n_slices = a.k_pad / L_BK;
+    const int row_bytes = n_slices * L_LINE;                              // one row of planes in memory
 
-    for (int i = tid; i < 8 * L_PLANE; i += 512) l16_lds[i] = 0u;
-
-    const int col = n0 + wn * 32 + li;
-    const bool cok = col < a.n_out;
-    const float e_bias = (cok && a.bias) ? a.bias[col] : 0.f;
-    float e_scale = cok ? a.colinv[col] : 0.f, e_c0 = e_bias;
-    if (cok && a.bn_scale) { e_c0 = (e_bias - a.bn_mean[col]) * a.bn_scale[col] + a.bn_shift[col]; e_scale *= a.bn_scale[col]; }
-
-    const int64_t tile0 = blockIdx.x;
-    const int64_t n_mine = tile0 < n_tiles ? (n_tiles - tile0 + gridDim.x - 1) / gridDim.x : 0;
-    // row tables of a tile: thread t < 128 owns row t (scale), 128 <= t < 256 row t - 128 (inverse)
-    auto rt_fetch = [&](int64_t row0) -> float {                        // (every thread loads: a clamped address, no branch)
-        int64_t r = row0 + (tid & 127);
-        r = r < a.m_rows ? r : a.m_rows - 1;
-        return a.rowscale[((tid >> 7) & 1) * a.m_rows + r];
-    };
-    float rt_next = rt_fetch(tile0 * L_BM);
-    __syncthreads();                                                     // (the zero fill above also covers the padding)
-    if (tid < 256) rtab(0, tid >> 7, tid & 127) = rt_next;
-    __syncthreads();
-
-    // TWO register sets of staged values (A, B): the loads of slice c + 2 are issued while slice c computes -- one slice of
-    // products does not cover the latency of an HBM / L2 miss, and inside a workgroup the slices are lock-step.  K is padded to a
-    // multiple of 64, so a tile has an even number of slices and the sets keep their roles across tiles (compile-time names: a
-    // run-time choice between the sets would make every stage wait for all loads in flight).
-    float4 preA_a[2], preA_b[2];
-    un2 preWh_a[2], preWl_a[2], preWh_b[2], preWl_b[2];
-    auto fetch = [&](float4 *pA, un2 *pWh, un2 *pWl, int64_t row0, int c) {
-        const L16Col cm = l16_col(a, c * L_BK + kc);
+    float e_scale[NJ], e_c0[NJ];
+    int cbyte[NJ];                                                         // byte offset of this lane's column j in an output row; past the tile's extent when the column does not exist
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int64_t r = row0 + r0 + 64 * i;
-            r = r < a.m_rows ? r : a.m_rows - 1;                        // rows past the end read the last row (never emitted)
-            pA[i] = *reinterpret_cast<const float4 *>(cm.base + r * cm.bw);
-            int j = n0 + r0 + 64 * i;
-            j = j < a.n_out ? j : 0;                                    // (its output column is never emitted)
-            const _Float16 *wp = a.wplanes + (int64_t)j * a.k_pad + c * L_BK + kc;
-            pWh[i] = *reinterpret_cast<const un2 *>(wp);
-            pWl[i] = *reinterpret_cast<const un2 *>(wp + (int64_t)a.n_out * a.k_pad);
-        }
-    };
-    auto stage = [&](const float4 *pA, const un2 *pWh, const un2 *pWl, int buf, int slot) {
+    for (int j = 0; j < NJ; ++j) {
+        const int col = n0 + wn * 32 * NJ + 32 * j + li;
+        const bool cok = col < a.n_out;
+        const float e_bias = (cok && a.bias) ? a.bias[col] : 0.f;
+        e_scale[j] = cok ? a.colinv[col] : 0.f;
+        e_c0[j] = e_bias;
+        if (cok && a.bn_scale) { e_c0[j] = (e_bias - a.bn_mean[col]) * a.bn_scale[col] + a.bn_shift[col]; e_scale[j] *= a.bn_scale[col]; }
+        cbyte[j] = cok ? col * 4 : 0x7f000000;
+    }
+    const int rstride = a.n_out * 4;                                      // bytes per output row
+    int vcol[NJ];                                                          // 16-byte stores: byte offset of (row idx / (8 NJ) of a piece, 4 columns) for piece read k
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const float s = rtab(slot, 0, r0 + 64 * i);
-            unsigned h0, l0, h1, l1;
-            l16_split2(fl2{pA[i].x * s, pA[i].y * s}, h0, l0);
-            l16_split2(fl2{pA[i].z * s, pA[i].w * s}, h1, l1);
-            const int o = ((r0 + 64 * i) * L_BKP + kc) / 2;
-            *reinterpret_cast<un2 *>(a_planes(buf) + o) = un2{h0, h1};
-            *reinterpret_cast<un2 *>(a_planes(buf) + L_PLANE + o) = un2{l0, l1};
-            *reinterpret_cast<un2 *>(w_planes(buf) + o) = pWh[i];
-            *reinterpret_cast<un2 *>(w_planes(buf) + L_PLANE + o) = pWl[i];
-        }
+    for (int k = 0; k < NJ; ++k) {
+        const int idx = 64 * k + lane, c4 = idx % (8 * NJ), col = n0 + wn * 32 * NJ + 4 * c4;
+        vcol[k] = col < a.n_out ? ((idx / (8 * NJ)) - (64 * k) / (8 * NJ)) * rstride + col * 4 : 0x7f000000;
+    }
+    unsigned wofs[NWP];                                                     // weight rows of this workgroup's column tile (fixed): byte offsets (the planes of W stay below 4 GiB)
+#pragma unroll
+    for (int i = 0; i < NWP; ++i) {
+        int j = n0 + sr + RP * i;
+        j = j < a.n_out ? j : 0;                                            // (its output column is never emitted)
+        wofs[i] = (unsigned)j * (unsigned)row_bytes + 16u * sp;
+    }
+    auto rt_fetch = [&](int64_t row0) -> float {                          // (every thread loads: rowinv is padded to whole tiles)
+        const int64_t r = row0 + (tid & (P_BM - 1));
+        return a.rowinv[r < a.m_pad ? r : a.m_pad - 1];
     };
-    f32x16 acc[2];
+    float rt_next = rt_fetch(tile0 * P_BM);
+    if (tid < P_BM) rtab(0, tid) = rt_next;
+
+    un4 pA[4], pW[NWP];                                                     // the slice in flight
+    auto fetch = [&](const unsigned char *abase, const unsigned *aofs, int c) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pA[i] = *reinterpret_cast<const un4 *>(abase + aofs[i] + c * L_LINE);
+#pragma unroll
+        for (int i = 0; i < NWP; ++i) pW[i] = *reinterpret_cast<const un4 *>(a.wplanes + wofs[i] + c * L_LINE);
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<un4 *>(a_rows(buf) + (sr + RP * i) * P_PITCH + 16 * sp) = pA[i];
+#pragma unroll
+        for (int i = 0; i < NWP; ++i) *reinterpret_cast<un4 *>(w_rows(buf) + (sr + RP * i) * P_PITCH + 16 * sp) = pW[i];
+    };
+    f32x16 acc[2][NJ];
 #define L16_MF(acc, x, y) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, x), __builtin_bit_cast(h16x8, y), acc, 0, 0, 0)
     auto products = [&](int buf) {
-        const unsigned *ap = a_planes(buf) + ((wm * 64 + li) * L_BKP + 8 * lh) / 2;
-        const unsigned *bp = w_planes(buf) + ((wn * 32 + li) * L_BKP + 8 * lh) / 2;
-        un4 bh[2], bl[2], ah[2][2], al[2][2];
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {                                     // all twelve fragments first: the products then run back to back
-            bh[s] = *reinterpret_cast<const un4 *>(bp + 8 * s);
-            bl[s] = *reinterpret_cast<const un4 *>(bp + 8 * s + L_PLANE);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                ah[s][i] = *reinterpret_cast<const un4 *>(ap + i * (32 * L_BKP / 2) + 8 * s);
-                al[s][i] = *reinterpret_cast<const un4 *>(ap + i * (32 * L_BKP / 2) + 8 * s + L_PLANE);
-            }
-        }
+        const unsigned char *ap = a_rows(buf) + (wm * 64 + li) * P_PITCH + 16 * lh, *bp = w_rows(buf) + (wn * 32 * NJ + li) * P_PITCH + 16 * lh;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            L16_MF(acc[0], al[s][0], bh[s]); L16_MF(acc[1], al[s][1], bh[s]);     // small terms first; the two tiles alternate
-            L16_MF(acc[0], ah[s][0], bl[s]); L16_MF(acc[1], ah[s][1], bl[s]);
-            L16_MF(acc[0], ah[s][0], bh[s]); L16_MF(acc[1], ah[s][1], bh[s]);
+            un4 ah[2], al[2], bh[NJ], bl[NJ];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ah[i] = *reinterpret_cast<const un4 *>(ap + i * (32 * P_PITCH) + 32 * s);
+                al[i] = *reinterpret_cast<const un4 *>(ap + i * (32 * P_PITCH) + 32 * s + 64);
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                bh[j] = *reinterpret_cast<const un4 *>(bp + j * (32 * P_PITCH) + 32 * s);
+                bl[j] = *reinterpret_cast<const un4 *>(bp + j * (32 * P_PITCH) + 32 * s + 64);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) L16_MF(acc[i][j], al[i], bh[j]);                      // small terms first
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) L16_MF(acc[i][j], ah[i], bl[j]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) L16_MF(acc[i][j], ah[i], bh[j]);
         }
     };
-    static_assert(L_BK == 32, "two k-steps per slice");
+    // rows of a tile: byte offsets from the tile's first row (rows past the end read the last row; never emitted)
+    auto row_ofs = [&](int64_t row0, unsigned *aofs) {
+        const int64_t left = a.m_rows - row0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int r = sr + RP * i;
+            r = r < left ? r : (int)(left > 0 ? left - 1 : 0);
+            aofs[i] = (unsigned)r * (unsigned)row_bytes + 16u * sp;
+        }
+    };
+    auto tile_base = [&](int64_t row0) { return a.aplanes + (row0 < a.m_rows ? row0 : 0) * row_bytes; };
+    unsigned aofs[4], aofs_next[4];
+    row_ofs(tile0 * P_BM, aofs);
+    const unsigned char *abase = tile_base(tile0 * P_BM), *abase_next = abase;
     if (n_mine > 0) {
-        fetch(preA_a, preWh_a, preWl_a, tile0 * L_BM, 0);
-        fetch(preA_b, preWh_b, preWl_b, tile0 * L_BM, 1);
+        fetch(abase, aofs, 0);
+        stage(0);
     }
-    int slot = 0;
+    l16_barrier();
+    int slot = 0, buf = 0;
     for (int64_t ti = 0; ti < n_mine; ++ti) {
-        const int64_t tile = tile0 + ti * gridDim.x;
-        const int64_t row0 = tile * L_BM, row_next = (tile + gridDim.x) * L_BM;
+        const int64_t tile = tile0 + ti * tstride;
+        const int64_t row0 = tile * P_BM, row_next = (tile + tstride) * P_BM;
         const bool has_next = ti + 1 < n_mine;
         rt_next = rt_fetch(row_next);                                      // lands while this tile computes
+        row_ofs(has_next ? row_next : row0, aofs_next);
+        abase_next = tile_base(has_next ? row_next : row0);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-        for (int c = 0; c < n_slices; c += 2) {
-            const bool last = c + 2 >= n_slices;
-            // what the two sets fetch next: slices c + 2, c + 3 of this tile, or slices 0, 1 of the next one (of this one again when
-            // there is none: every slice issues the SAME number of loads, so the waits can be counted -- a conditional load in
-            // between turns every wait into "all loads in flight")
-            const int64_t row_f = last ? (has_next ? row_next : row0) : row0;
-            const int c_f = last ? 0 : c + 2;
-            // slice c: set A, buffer 0
-            stage(preA_a, preWh_a, preWl_a, 0, slot);
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int c = 0; c < n_slices; ++c) {
+            // in flight during the products of slice c: slice c + 1 of this tile, or slice 0 of the next one (of this one again when
+            // there is none: every slice issues the same loads)
+            const bool last = c + 1 >= n_slices;
+            const unsigned long long q0 = clk();
+            if (!(dbg & 4)) fetch(last ? abase_next : abase, last ? aofs_next : aofs, last ? 0 : c + 1);
+            const unsigned long long q1 = clk();
+            if (!(dbg & 2)) products(buf);
+            const unsigned long long q2 = clk();
+            if (!(dbg & 8)) stage(buf ^ 1);
+            if (last && tid < P_BM) rtab(slot ^ 1, tid) = rt_next;          // (read by the next tile's epilogue)
+            const unsigned long long q3 = clk();
             l16_barrier();
-            fetch(preA_a, preWh_a, preWl_a, row_f, c_f);
-            products(0);
-            // slice c + 1: set B, buffer 1
-            stage(preA_b, preWh_b, preWl_b, 1, slot);
-            l16_barrier();
-            if (last && tid < 256) rtab(slot ^ 1, tid >> 7, tid & 127) = rt_next;   // (read by the next tile after its first barrier)
-            fetch(preA_b, preWh_b, preWl_b, row_f, c_f + 1);
-            products(1);
+            buf ^= 1;
+            if (PROF) { const unsigned long long q4 = clk(); pq[0] += q1 - q0; pq[1] += q2 - q1; pq[2] += q3 - q2; pq[3] += q4 - q3; pq[5] += 1; }
         }
-        // epilogue.  C layout of a 32x32 tile: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
-        const bool full = (row0 + L_BM <= a.m_rows) && (n0 + L_BN <= a.n_out);
+        const unsigned long long qe0 = clk();
+        // epilogue.  C layout of a 32x32 tile: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).  A CU retires
+        // about one store instruction per ~65 cycles whatever its width (measured: 4-byte stores of a 256 x 256 tile took longer
+        // than its whole K loop), so the tile leaves in 16-byte stores: every wave turns 8 rows x 32 NJ columns at a time through a
+        // private piece of the plane buffer that was multiplied last (free until the next tile's second slice is staged).
+        const int64_t rows_left = a.m_rows - row0;
+        const int nrows = rows_left < P_BM ? (int)rows_left : P_BM;
+        const __amdgpu_buffer_rsrc_t orow = __builtin_amdgcn_make_buffer_rsrc(a.out + row0 * a.n_out, 0, nrows * rstride, 0x00020000);
+        const float act_lo = a.act == 1 ? 0.f : -INFINITY;
+        constexpr int SP = 32 * NJ * 4 + 16;                               // bytes per row of a wave's 8-row piece
+        unsigned char *const scr = w_rows(buf ^ 1) + wave * (8 * SP);
+        auto emit = [&](auto simple) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int rl = wm * 64 + i * 32 + 4 * lh;                    // first of this lane's rows inside the tile
-            const int64_t rbase = row0 + rl;
-            float *op = a.out + rbase * a.n_out + col;
+            for (int i = 0; i < 2; ++i) {
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const float ivv[4] = {rtab(slot, 1, rl + 8 * gq), rtab(slot, 1, rl + 8 * gq + 1), rtab(slot, 1, rl + 8 * gq + 2), rtab(slot, 1, rl + 8 * gq + 3)};
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int rl = wm * 64 + i * 32 + 8 * gq;            // first tile row of this piece
+                    const float ivv[4] = {rtab(slot, rl + 4 * lh), rtab(slot, rl + 4 * lh + 1), rtab(slot, rl + 4 * lh + 2), rtab(slot, rl + 4 * lh + 3)};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int dr = r + 8 * gq;
-                    if (!full && (!cok || rbase + dr >= a.m_rows)) continue;
-                    op[(int64_t)dr * a.n_out] = l16_act(fmaf(acc[i][4 * gq + r], ivv[r] * e_scale, e_c0), a.act);
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) {
+                            float y = fmaf(acc[i][j][4 * gq + r], ivv[r] * e_scale[j], e_c0[j]);
+                            if (decltype(simple)::value) y = y < act_lo ? act_lo : y;           // (a NaN stays a NaN)
+                            else y = l16_act_slow(y, a.act);
+                            *reinterpret_cast<float *>(scr + (r + 4 * lh) * SP + (li + 32 * j) * 4) = y;
+                        }
+                    if ((dbg & 1) && acc[i][0][4 * gq] != 12345.f) continue;
+#pragma unroll
+                    for (int k = 0; k < NJ; ++k) {
+                        const int idx = 64 * k + lane, row = idx / (8 * NJ), c4 = idx % (8 * NJ);
+                        const un4 v = *reinterpret_cast<const un4 *>(scr + row * SP + 16 * c4);
+                        __builtin_amdgcn_raw_buffer_store_b128(v, orow, vcol[k], (rl + (64 * k) / (8 * NJ)) * rstride, 0);
+                    }
+                }
+            }
+        };
+        if (VEC) {
+            if (a.act <= 1) emit(std::true_type{});
+            else emit(std::false_type{});
+        } else {
+#pragma unroll 1
+            for (int i = 0; i < 2; ++i) {
+                const int rl = wm * 64 + i * 32 + 4 * lh;                // first of this lane's rows inside the tile
+#pragma unroll 1
+                for (int gq = 0; gq < 4; ++gq) {
+                    const float ivv[4] = {rtab(slot, rl + 8 * gq), rtab(slot, rl + 8 * gq + 1), rtab(slot, rl + 8 * gq + 2), rtab(slot, rl + 8 * gq + 3)};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) {
+                            const float y = l16_act_slow(fmaf(i ? acc[1][j][4 * gq + r] : acc[0][j][4 * gq + r], ivv[r] * e_scale[j], e_c0[j]), a.act);
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), orow, cbyte[j] + 4 * lh * rstride, (wm * 64 + i * 32 + 8 * gq + r) * rstride, 0);
+                        }
                 }
             }
         }
+        l16_barrier();                                                     // (the pieces are overwritten by the next tile's staging)
+        if (PROF) { pq[4] += clk() - qe0; pq[6] += 1; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) aofs[i] = aofs_next[i];
+        abase = abase_next;
         slot ^= 1;
     }
+    if (PROF && a.prof && blockIdx.x == 0 && tid == 0)
+        for (int q = 0; q < 8; ++q) a.prof[q] = pq[q];
 #undef L16_MF
 }
 
@@ -307,12 +442,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
 using namespace gsn;
 
-extern "C" int64_t gsn_linear_f16x3_kpad(int64_t k_total) { return (k_total + 2 * L_BK - 1) / (2 * L_BK) * (2 * L_BK); }
+extern "C" int64_t gsn_linear_f16x3_kpad(int64_t k_total) { return (k_total + L_BK - 1) / L_BK * L_BK; }
+
+extern "C" int64_t gsn_linear_f16x3_scratch_bytes(int64_t m_rows, int64_t k_total) {
+    if (m_rows <= 0 || k_total <= 0) return 0;
+    const int64_t m_pad = (m_rows + 255) / 256 * 256, k_pad = gsn_linear_f16x3_kpad(k_total);
+    return m_pad * 4 + m_rows * k_pad * 4;                                // inverse row scales | the rows' planes
+}
 
 extern "C" int gsn_linear_f16x3_prepare_hip(const float *W, int64_t n_out, int64_t k_total, void *planes, float *col_inv, void *stream) {
     if (!W || !planes || !col_inv || n_out <= 0 || k_total <= 0 || n_out > (1 << 24) || k_total > (1 << 20))
         return set_error(GSN_E_INVALID, "gsn_linear_f16x3_prepare_hip: bad argument");
     const int k_pad = (int)gsn_linear_f16x3_kpad(k_total);
+    if (n_out * (int64_t)k_pad * 4 >= ((int64_t)1 << 31))
+        return set_error(GSN_E_UNSUPPORTED, "gsn_linear_f16x3_prepare_hip: weight planes of 2 GiB and more are not supported");
     hipLaunchKernelGGL(lin16_prepare_kernel, dim3((unsigned)n_out), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), W, (int)n_out, (int)k_total,
                        k_pad, reinterpret_cast<_Float16 *>(planes), col_inv);
     hipError_t e = hipGetLastError();
@@ -328,6 +471,7 @@ extern "C" int gsn_linear_f16x3_fwd_hip(int64_t m_rows, int n_blocks, const gsn_
     if ((bn_scale != nullptr) != (bn_shift != nullptr) || (bn_scale != nullptr) != (bn_mean != nullptr))
         return set_error(GSN_E_INVALID, "gsn_linear_f16x3_fwd_hip: bn_mean, bn_scale and bn_shift go together");
     if (act < 0 || act > 3) return set_error(GSN_E_INVALID, "gsn_linear_f16x3_fwd_hip: act must be 0..3");
+    if ((reinterpret_cast<uintptr_t>(row_scratch) & 15) != 0) return set_error(GSN_E_INVALID, "gsn_linear_f16x3_fwd_hip: row_scratch must be 16-byte aligned");
     if (m_rows <= 0) return GSN_OK;
     L16Args a{};
     a.m_rows = m_rows; a.n_blocks = n_blocks;
@@ -345,31 +489,69 @@ extern "C" int gsn_linear_f16x3_fwd_hip(int64_t m_rows, int n_blocks, const gsn_
     a.b0 = bd[0]; a.b1 = bd[1]; a.b2 = bd[2]; a.b3 = bd[3]; a.b4 = bd[4];
     a.w0 = bw[0]; a.w1 = bw[1]; a.w2 = bw[2]; a.w3 = bw[3]; a.w4 = bw[4];
     a.k_total = k_total; a.k_pad = (int)gsn_linear_f16x3_kpad(k_total); a.n_out = (int)n_out; a.act = act;
-    a.wplanes = reinterpret_cast<const _Float16 *>(planes); a.colinv = col_inv;
+    if (n_out * (int64_t)a.k_pad * 4 >= ((int64_t)1 << 31) || n_out >= (1 << 24))
+        return set_error(GSN_E_UNSUPPORTED, "gsn_linear_f16x3_fwd_hip: weight planes of 2 GiB and more are not supported");
+    a.wplanes = reinterpret_cast<const unsigned char *>(planes); a.colinv = col_inv;
     a.bias = bias; a.bn_mean = bn_mean; a.bn_scale = bn_scale; a.bn_shift = bn_shift;
-    a.rowscale = row_scratch; a.out = out;
+    a.out = out;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(lin16_rowscale_kernel, dim3((unsigned)((m_rows + 31) / 32)), dim3(256), 0, st, a);
-    const size_t lds = (size_t)8 * L_PLANE * 4;
-    static DeviceOnce attr_set;
+    // scratch: [m_pad] inverse row scales | [m_rows][k_pad / 32] lines of the rows' planes
+    a.m_pad = (m_rows + 255) / 256 * 256;
+    a.rowinv = row_scratch;
+    a.aplanes = reinterpret_cast<unsigned char *>(row_scratch + a.m_pad);
+    hipLaunchKernelGGL(lin16_split_rows_kernel, dim3((unsigned)(a.m_pad / 32)), dim3(256), 0, st, a);
+    // tile shape: 256 x 256 (one workgroup of 8 waves per CU) or 128 x 128 (two workgroups of 4 waves per CU)
+    static const int force_wm = getenv("GSN_L16_WM") ? atoi(getenv("GSN_L16_WM")) : 0;
+    const int wm = force_wm ? force_wm : 2;
+    const int nj = wm;
+    const int bm = 64 * wm, bn = 64 * nj;
+    const int64_t n_tiles = (m_rows + bm - 1) / bm;
+    const int col_tiles = (int)((n_out + bn - 1) / bn);
+    const int slots = wm == 4 ? 32 : 64;                                    // workgroups per XCD
+    int groups = slots / col_tiles;
+    if (groups < 1) groups = 1;
+    const int64_t need = (n_tiles + 7) / 8;
+    if (groups > need) groups = (int)need;
+    a.col_tiles = col_tiles; a.groups = groups;
+    a.dbg = getenv("GSN_L16_DBG") ? atoi(getenv("GSN_L16_DBG")) : 0;
+    static const bool want_prof = getenv("GSN_L16_PROF") != nullptr;
+    a.prof = nullptr;
+    if (want_prof && hipMalloc(reinterpret_cast<void **>(&a.prof), 64) != hipSuccess) a.prof = nullptr;
+    const size_t lds = (size_t)2 * (bm + bn) * P_PITCH;
+    if (getenv("GSN_CHAIN_TRACE"))
+        fprintf(stderr, "gsn linear: linear_f16x3_kernel (%d x %d tiles) M %lld K %d N %d grid 8 x %d x %d\n", bm, bn, (long long)m_rows, k_total, (int)n_out,
+                groups, col_tiles);
+    const dim3 grid((unsigned)(8 * groups * col_tiles));
+    const bool vec = n_out % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;      // 16-byte output stores
+    static DeviceOnce attr_set[6];
     const int attr_dev = current_device();
-    if (!attr_set.done(attr_dev)) {
-        hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_f16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e0 != hipSuccess) return set_error(GSN_E_HIP, "hipFuncSetAttribute(linear_f16x3_kernel): %s", hipGetErrorString(e0));
-        attr_set.mark(attr_dev);
+    hipError_t e0 = hipSuccess;
+    auto launch = [&](auto kern, int which) {
+        if (!attr_set[which].done(attr_dev)) {
+            e0 = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e0 != hipSuccess) return;
+            attr_set[which].mark(attr_dev);
+        }
+        hipLaunchKernelGGL(kern, grid, dim3(128 * wm), lds, st, a);
+    };
+    if (want_prof || a.dbg) {                                               // diagnostic builds
+        if (wm == 4) launch(linear_f16x3_planes_kernel<4, 4, true, true>, 0);
+        else launch(linear_f16x3_planes_kernel<2, 2, true, true>, 1);
+    } else if (!vec) {
+        if (wm == 4) launch(linear_f16x3_planes_kernel<4, 4, false, false>, 2);
+        else launch(linear_f16x3_planes_kernel<2, 2, false, false>, 3);
+    } else if (wm == 4) launch(linear_f16x3_planes_kernel<4, 4, false, true>, 4);
+    else launch(linear_f16x3_planes_kernel<2, 2, false, true>, 5);
+    if (e0 != hipSuccess) return set_error(GSN_E_HIP, "hipFuncSetAttribute(linear_f16x3_kernel): %s", hipGetErrorString(e0));
+    if (a.prof) {
+        unsigned long long h[8];
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(h, a.prof, 64, hipMemcpyDeviceToHost);
+        (void)hipFree(a.prof);
+        const double n = h[5] ? (double)h[5] : 1.0, nt = h[6] ? (double)h[6] : 1.0;
+        fprintf(stderr, "l16prof: per slice: fetch issue %.0f products %.0f stage(+load wait) %.0f barrier %.0f | epilogue %.0f per tile (%llu slices, %llu tiles)\n",
+                h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / nt, h[5], h[6]);
     }
-    const int64_t n_tiles = (m_rows + L_BM - 1) / L_BM;
-    const int col_tiles = (int)((n_out + L_BN - 1) / L_BN);
-    int64_t gx = 512 / col_tiles;                                            // persistent: two workgroups per CU in total
-    if (gx < 1) gx = 1;
-    if (gx > n_tiles) gx = n_tiles;
-    if (getenv("GSN_CHAIN_TRACE")) {
-        int nb = -1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, linear_f16x3_kernel, 512, lds);
-        fprintf(stderr, "gsn linear: linear_f16x3_kernel M %lld K %d N %d grid %lld x %d, %d workgroup(s) per CU\n", (long long)m_rows, k_total, (int)n_out,
-                (long long)gx, col_tiles, nb);
-    }
-    hipLaunchKernelGGL(linear_f16x3_kernel, dim3((unsigned)gx, (unsigned)col_tiles), dim3(512), lds, st, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(GSN_E_HIP, "linear_f16x3_kernel: %s", hipGetErrorString(e));
     return GSN_OK;

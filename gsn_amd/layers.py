@@ -446,7 +446,7 @@ def _linear_hip(blocks, weight, bias, bn_mean, bn_scale, bn_shift, act, m_rows, 
     if (LINEAR_F16X3 and out and stats is None and m_rows > 0 and n_out > LINEAR_F16X3_MIN_N and all(idx is None for _, idx in blocks)
             and all(d.shape[1] % 4 == 0 and d.data_ptr() % 16 == 0 for d in keep)):
         planes, col_inv = _f16x3_weights(weight, w)
-        scratch = torch.empty(2 * m_rows, dtype=torch.float32, device=dev)
+        scratch = torch.empty(int(_abi.lib().gsn_linear_f16x3_scratch_bytes(m_rows, w.shape[1])), dtype=torch.uint8, device=dev)
         with _abi.device_guard(dev), _timed("linear_fwd", 2.0 * m_rows * w.shape[1] * n_out):
             rc = _abi.lib().gsn_linear_f16x3_fwd_hip(m_rows, len(blocks), arr, planes.data_ptr(), col_inv.data_ptr(), _abi.ptr(vecs[0]), n_out,
                                                      _abi.ptr(vecs[1]), _abi.ptr(vecs[2]), _abi.ptr(vecs[3]), act, scratch.data_ptr(),

@@ -288,10 +288,14 @@ int gsn_layer_fused_fwd_hip(int64_t n_nodes, int64_t n_edges, const int32_t *seg
  *   gsn_linear_f16x3_kpad(K)          K rounded up to two of the kernel's K slices (64)
  *   gsn_linear_f16x3_prepare_hip      splits W [n_out][K] once: planes = 2 * n_out * kpad(K) fp16 values, col_inv = n_out floats
  *                                     (device buffers of the caller; valid until W changes)
+ *   gsn_linear_f16x3_scratch_bytes    size of row_scratch for m_rows rows of K columns: the rows' inverse scales and their two
+ *                                     fp16 planes (split once per call by a pre-pass, read by every column tile)
  *   gsn_linear_f16x3_fwd_hip          blocks: data + width only (idx / idx32 must be NULL), widths multiples of 4, 16-byte
- *                                     aligned; row_scratch: 2 * m_rows floats; bias / bn_* / act as gsn_linear_fwd_hip
+ *                                     aligned; row_scratch: gsn_linear_f16x3_scratch_bytes(m_rows, K) bytes, 16-byte aligned;
+ *                                     bias / bn_* / act as gsn_linear_fwd_hip
  * ---------------------------------------------------------------------------------------------------------------- */
 int64_t gsn_linear_f16x3_kpad(int64_t k_total);
+int64_t gsn_linear_f16x3_scratch_bytes(int64_t m_rows, int64_t k_total);
 int gsn_linear_f16x3_prepare_hip(const float *W, int64_t n_out, int64_t k_total, void *planes, float *col_inv, void *stream);
 int gsn_linear_f16x3_fwd_hip(int64_t m_rows, int n_blocks, const gsn_block *blocks, const void *planes, const float *col_inv,
                              const float *bias, int64_t n_out, const float *bn_mean, const float *bn_scale, const float *bn_shift,

@@ -16,7 +16,10 @@ from gsn_amd import layers  # noqa: E402
 def main():
     dev = torch.device("cuda")
     out = []
-    for M, K, N in ((196608, 300, 600), (196608, 600, 300), (1 << 20, 260, 128), (1 << 20, 128, 128), (380000, 128, 256)):
+    shapes = ((196608, 300, 600), (196608, 600, 300), (1 << 20, 260, 128), (1 << 20, 128, 128), (380000, 128, 256))
+    if os.environ.get("GSN_L16_SHAPES"):                      # (scripts/micro/l16_ablate.sh: one shape per run; or M:K:N)
+        shapes = [tuple(int(v) for v in i.split(":")) if ":" in i else shapes[int(i)] for i in os.environ["GSN_L16_SHAPES"].split(",")]
+    for M, K, N in shapes:
         x = torch.randn(M, K, device=dev)
         W = torch.randn(N, K, device=dev) / K ** 0.5
         b = torch.randn(N, device=dev)

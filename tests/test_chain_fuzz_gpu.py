@@ -104,10 +104,12 @@ def test_random_chain_shapes_vs_fp64(seed):
 
 @pytest.mark.parametrize("m,widths,n,act,bn", [(1000, [132], 256, "relu", True), (4097, [128, 128, 4], 384, "identity", False),
                                                 (130, [300], 600, "relu", False), (777, [64, 200], 130, "tanh", True),
-                                                (50000, [128], 256, "relu", True)])
+                                                (50000, [128], 256, "relu", True), (3000, [400, 240], 200, "elu", True),
+                                                (257, [36], 131, "relu", False), (70000, [64], 1028, "identity", False)])
 def test_direct_rows_on_the_fp16x3_linear_kernel(m, widths, n, act, bn, capfd):
-    """gsn_linear_f16x3_fwd_hip (direct rows, n_out > 128): several input blocks, K not a multiple of the slice, a ragged last
-    row tile and column tile, every epilogue -- against fp64, element-wise, with the product's own condition scale as floor."""
+    """gsn_linear_f16x3_fwd_hip (direct rows, n_out > 128): several input blocks, K not a multiple of the slice and wider than the
+    pre-pass keeps in registers, a ragged last row tile and column tile, n_out not a multiple of 4 (4-byte output stores), more
+    row tiles than workgroups, every epilogue -- against fp64, element-wise, with the product's own condition scale as floor."""
     import os
     from gsn_amd import layers
     g = torch.Generator().manual_seed(m + n)
@@ -137,6 +139,6 @@ def test_direct_rows_on_the_fp16x3_linear_kernel(m, widths, n, act, bn, capfd):
         s_ = (bnm.weight.double().cpu() / torch.sqrt(bnm.running_var.double().cpu() + bnm.eps))
         pre = (pre - bnm.running_mean.double().cpu()) * s_ + bnm.bias.double().cpu()
         scale = scale * s_.abs() + bnm.bias.double().cpu().abs() + (bnm.running_mean.double().cpu() * s_).abs()
-    ref = {"relu": torch.relu, "identity": lambda t: t, "tanh": torch.tanh}[act](pre)
+    ref = {"relu": torch.relu, "identity": lambda t: t, "tanh": torch.tanh, "elu": torch.nn.functional.elu}[act](pre)
     err = (y.double() - ref).abs()
     assert bool((err <= 1e-5 * ref.abs() + 2e-6 * scale).all()), float((err / (1e-5 * ref.abs() + 2e-6 * scale)).max())
