@@ -196,8 +196,10 @@ __global__ __launch_bounds__(256) void lin16_split_rows_kernel(L16Args a) {
 // A plain fp16 matrix kernel with three plane products per k-step: both operands arrive as fp16 planes and are staged with 16-byte
 // copies (no arithmetic between the load and LDS).  2 WM waves on a (64 WM) x (64 NJ) output tile, wave w = rows 64 (w >> 1)..,
 // columns 32 NJ (w & 1)..; the lines of two K slices in LDS (row pitch 144 bytes = 64 high + 64 low + 16: 16-byte fragment reads
-// and 128-byte row writes are both conflict-free), the next slice travels through registers while the current one is
-// multiplied; ONE barrier per slice.  <4, 4>: 256 x 256 tiles, one workgroup per CU; <2, 2>: 128 x 128 tiles, two per CU.
+// and 128-byte row writes are both conflict-free), the next TWO slices travel through two named register sets while the
+// current one is multiplied; ONE barrier per slice.  Instantiated as <2, 2>: 128 x 128 tiles, 4 waves, two workgroups per CU whose staging and
+// matrix phases interleave (256 x 256 tiles with 8 waves, one per CU, leave no registers for the second set of loads in flight
+// and measured 3-5 % slower).
 // Workgroup -> (XCD, column tile, row group): the column tiles of one row tile run on the same XCD at the same time, its rows
 // leave HBM once.  The output tile leaves in 16-byte stores through a buffer resource per tile (rows past M and columns past N
 // are dropped by the range check).
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(2, 2))
     unsigned long long pq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform, and the compiler should know)
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
     // staging: 8 lanes = the 128-byte line of one (row, slice); a wave instruction moves 8 whole lines.  Thread -> piece sp of rows
@@ -241,24 +243,28 @@ __global__ __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int n_slices = a.k_pad / L_BK;
     const int row_bytes = n_slices * L_LINE;                              // one row of planes in memory
 
-    float e_scale[NJ], e_c0[NJ];
-    int cbyte[NJ];                                                         // byte offset of this lane's column j in an output row; past the tile's extent when the column does not exist
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int col = n0 + wn * 32 * NJ + 32 * j + li;
+    // per-column epilogue constants and per-lane store offsets live in LDS behind the slice buffers: held in registers across the K
+    // loop they are spilled, and a spill reload in the epilogue waits for every store issued before it
+    float *const ecol = reinterpret_cast<float *>(lds + 2 * BUF);         // [BN] scale | [BN] constant
+    int *const vtab = reinterpret_cast<int *>(lds + 2 * BUF + 8 * BN);    // [2][NJ][64] byte offsets of the 16-byte stores | [2][NJ][32] of the 4-byte ones
+    for (int cidx = tid; cidx < BN; cidx += NT) {
+        const int col = n0 + cidx;
         const bool cok = col < a.n_out;
         const float e_bias = (cok && a.bias) ? a.bias[col] : 0.f;
-        e_scale[j] = cok ? a.colinv[col] : 0.f;
-        e_c0[j] = e_bias;
-        if (cok && a.bn_scale) { e_c0[j] = (e_bias - a.bn_mean[col]) * a.bn_scale[col] + a.bn_shift[col]; e_scale[j] *= a.bn_scale[col]; }
-        cbyte[j] = cok ? col * 4 : 0x7f000000;
+        float es = cok ? a.colinv[col] : 0.f, ec = e_bias;
+        if (cok && a.bn_scale) { ec = (e_bias - a.bn_mean[col]) * a.bn_scale[col] + a.bn_shift[col]; es *= a.bn_scale[col]; }
+        ecol[cidx] = es; ecol[BN + cidx] = ec;
     }
     const int rstride = a.n_out * 4;                                      // bytes per output row
-    int vcol[NJ];                                                          // 16-byte stores: byte offset of (row idx / (8 NJ) of a piece, 4 columns) for piece read k
-#pragma unroll
-    for (int k = 0; k < NJ; ++k) {
-        const int idx = 64 * k + lane, c4 = idx % (8 * NJ), col = n0 + wn * 32 * NJ + 4 * c4;
-        vcol[k] = col < a.n_out ? ((idx / (8 * NJ)) - (64 * k) / (8 * NJ)) * rstride + col * 4 : 0x7f000000;
+    for (int q = tid; q < 2 * NJ * 64; q += NT) {                         // piece read k of lane l in a wave with column half w: (row idx / (8 NJ) of the piece, 4 columns)
+        const int l = q & 63, k = (q >> 6) % NJ, w = q / (64 * NJ);
+        const int idx = 64 * k + l, c4 = idx % (8 * NJ), col = n0 + w * 32 * NJ + 4 * c4;
+        vtab[q] = col < a.n_out ? ((idx / (8 * NJ)) - (64 * k) / (8 * NJ)) * rstride + col * 4 : 0x7f000000;
+    }
+    for (int q = tid; q < 2 * NJ * 32; q += NT) {                         // 4-byte stores: column j of lane li; past the tile's extent when the column does not exist
+        const int l = q & 31, j = (q >> 5) % NJ, w = q / (32 * NJ);
+        const int col = n0 + w * 32 * NJ + 32 * j + l;
+        vtab[2 * NJ * 64 + q] = col < a.n_out ? col * 4 : 0x7f000000;
     }
     unsigned wofs[NWP];                                                     // weight rows of this workgroup's column tile (fixed): byte offsets (the planes of W stay below 4 GiB)
 #pragma unroll
@@ -271,17 +277,18 @@ __global__ __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(2, 2))
         const int64_t r = row0 + (tid & (P_BM - 1));
         return a.rowinv[r < a.m_pad ? r : a.m_pad - 1];
     };
-    float rt_next = rt_fetch(tile0 * P_BM);
-    if (tid < P_BM) rtab(0, tid) = rt_next;
 
-    un4 pA[4], pW[NWP];                                                     // the slice in flight
-    auto fetch = [&](const unsigned char *abase, const unsigned *aofs, int c) {
+    // TWO named register sets: the loads of slice c + 2 are issued while slice c is multiplied (one slice of products does not
+    // cover a load's latency when the other workgroup of the CU keeps the memory pipeline busy).  Every slice issues the same
+    // number of loads, so the waits are counted.
+    un4 pA_a[4], pW_a[NWP], pA_b[4], pW_b[NWP];
+    auto fetch = [&](un4 (&pA)[4], un4 (&pW)[NWP], const unsigned char *abase, const unsigned *aofs, int c) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) pA[i] = *reinterpret_cast<const un4 *>(abase + aofs[i] + c * L_LINE);
 #pragma unroll
         for (int i = 0; i < NWP; ++i) pW[i] = *reinterpret_cast<const un4 *>(a.wplanes + wofs[i] + c * L_LINE);
     };
-    auto stage = [&](int buf) {
+    auto stage = [&](const un4 (&pA)[4], const un4 (&pW)[NWP], int buf) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) *reinterpret_cast<un4 *>(a_rows(buf) + (sr + RP * i) * P_PITCH + 16 * sp) = pA[i];
 #pragma unroll
@@ -330,44 +337,44 @@ __global__ __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(2, 2))
     };
     auto tile_base = [&](int64_t row0) { return a.aplanes + (row0 < a.m_rows ? row0 : 0) * row_bytes; };
     unsigned aofs[4], aofs_next[4];
-    row_ofs(tile0 * P_BM, aofs);
-    const unsigned char *abase = tile_base(tile0 * P_BM), *abase_next = abase;
-    if (n_mine > 0) {
-        fetch(abase, aofs, 0);
-        stage(0);
-    }
-    l16_barrier();
-    int slot = 0, buf = 0;
-    for (int64_t ti = 0; ti < n_mine; ++ti) {
-        const int64_t tile = tile0 + ti * tstride;
-        const int64_t row0 = tile * P_BM, row_next = (tile + tstride) * P_BM;
-        const bool has_next = ti + 1 < n_mine;
-        rt_next = rt_fetch(row_next);                                      // lands while this tile computes
-        row_ofs(has_next ? row_next : row0, aofs_next);
-        abase_next = tile_base(has_next ? row_next : row0);
+    const unsigned char *abase, *abase_next;
+    int64_t ti = 0;                                                        // this workgroup's tile counter
+    int c = 0, slot = 0;                                                   // slice inside the tile; row-scale slot of the tile
+    float rt_next;
+    // what a tile needs besides its slices: the rows of the NEXT tile (its first two slices are fetched during this tile's last
+    // two) and that tile's inverse row scales; when there is no next tile the current one is read again (every slice issues the
+    // same loads)
+    auto begin_tile = [&]() {
+        const int64_t row0 = (tile0 + ti * tstride) * P_BM, row_next = ti + 1 < n_mine ? row0 + tstride * P_BM : row0;
+        rt_next = rt_fetch(row_next);
+        row_ofs(row_next, aofs_next);
+        abase_next = tile_base(row_next);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        for (int c = 0; c < n_slices; ++c) {
-            // in flight during the products of slice c: slice c + 1 of this tile, or slice 0 of the next one (of this one again when
-            // there is none: every slice issues the same loads)
-            const bool last = c + 1 >= n_slices;
-            const unsigned long long q0 = clk();
-            if (!(dbg & 4)) fetch(last ? abase_next : abase, last ? aofs_next : aofs, last ? 0 : c + 1);
-            const unsigned long long q1 = clk();
-            if (!(dbg & 2)) products(buf);
-            const unsigned long long q2 = clk();
-            if (!(dbg & 8)) stage(buf ^ 1);
-            if (last && tid < P_BM) rtab(slot ^ 1, tid) = rt_next;          // (read by the next tile's epilogue)
-            const unsigned long long q3 = clk();
-            l16_barrier();
-            buf ^= 1;
-            if (PROF) { const unsigned long long q4 = clk(); pq[0] += q1 - q0; pq[1] += q2 - q1; pq[2] += q3 - q2; pq[3] += q4 - q3; pq[5] += 1; }
-        }
+    };
+    // One slice: stage its register set, barrier, refill the set with the slice two ahead, multiply; after a tile's last slice its
+    // epilogue.  Slices alternate between the two register sets / LDS buffers across tile boundaries too (a tile may have an odd
+    // number of slices), so the epilogue is compiled behind both halves of the loop below -- the sets keep compile-time names.
+    auto step = [&](un4 (&pA)[4], un4 (&pW)[NWP], const int bufx) -> bool {
+        const unsigned long long q0 = clk();
+        if (!(dbg & 8)) stage(pA, pW, bufx);
+        if (c + 1 >= n_slices && tid < P_BM) rtab(slot ^ 1, tid) = rt_next;           // (read by the next tile's epilogue)
+        const unsigned long long q1 = clk();
+        l16_barrier();
+        const unsigned long long q2 = clk();
+        const int c2 = c + 2;
+        const bool wrap = c2 >= n_slices;
+        if (!(dbg & 4)) fetch(pA, pW, wrap ? abase_next : abase, wrap ? aofs_next : aofs, wrap ? c2 - n_slices : c2);
+        const unsigned long long q3 = clk();
+        if (!(dbg & 2)) products(bufx);
+        if (PROF) { const unsigned long long q4 = clk(); pq[0] += q3 - q2; pq[1] += q4 - q3; pq[2] += q1 - q0; pq[3] += q2 - q1; pq[5] += 1; }
+        if (++c < n_slices) return false;
         const unsigned long long qe0 = clk();
+        const int64_t row0 = (tile0 + ti * tstride) * P_BM;
         // epilogue.  C layout of a 32x32 tile: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).  A CU retires
         // about one store instruction per ~65 cycles whatever its width (measured: 4-byte stores of a 256 x 256 tile took longer
         // than its whole K loop), so the tile leaves in 16-byte stores: every wave turns 8 rows x 32 NJ columns at a time through a
@@ -377,7 +384,10 @@ __global__ __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(2, 2))
         const __amdgpu_buffer_rsrc_t orow = __builtin_amdgcn_make_buffer_rsrc(a.out + row0 * a.n_out, 0, nrows * rstride, 0x00020000);
         const float act_lo = a.act == 1 ? 0.f : -INFINITY;
         constexpr int SP = 32 * NJ * 4 + 16;                               // bytes per row of a wave's 8-row piece
-        unsigned char *const scr = w_rows(buf ^ 1) + wave * (8 * SP);
+        unsigned char *const scr = w_rows(bufx ^ 1) + wave * (8 * SP);
+        float es[NJ], ec[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) { es[j] = ecol[wn * 32 * NJ + 32 * j + li]; ec[j] = ecol[BN + wn * 32 * NJ + 32 * j + li]; }
         auto emit = [&](auto simple) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -389,7 +399,7 @@ __global__ __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(2, 2))
                     for (int r = 0; r < 4; ++r)
 #pragma unroll
                         for (int j = 0; j < NJ; ++j) {
-                            float y = fmaf(acc[i][j][4 * gq + r], ivv[r] * e_scale[j], e_c0[j]);
+                            float y = fmaf(acc[i][j][4 * gq + r], ivv[r] * es[j], ec[j]);
                             if (decltype(simple)::value) y = y < act_lo ? act_lo : y;           // (a NaN stays a NaN)
                             else y = l16_act_slow(y, a.act);
                             *reinterpret_cast<float *>(scr + (r + 4 * lh) * SP + (li + 32 * j) * 4) = y;
@@ -399,7 +409,7 @@ __global__ __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(2, 2))
                     for (int k = 0; k < NJ; ++k) {
                         const int idx = 64 * k + lane, row = idx / (8 * NJ), c4 = idx % (8 * NJ);
                         const un4 v = *reinterpret_cast<const un4 *>(scr + row * SP + 16 * c4);
-                        __builtin_amdgcn_raw_buffer_store_b128(v, orow, vcol[k], (rl + (64 * k) / (8 * NJ)) * rstride, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(v, orow, vtab[(wn * NJ + k) * 64 + lane], (rl + (64 * k) / (8 * NJ)) * rstride, 0);
                     }
                 }
             }
@@ -418,18 +428,33 @@ __global__ __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(2, 2))
                     for (int r = 0; r < 4; ++r)
 #pragma unroll
                         for (int j = 0; j < NJ; ++j) {
-                            const float y = l16_act_slow(fmaf(i ? acc[1][j][4 * gq + r] : acc[0][j][4 * gq + r], ivv[r] * e_scale[j], e_c0[j]), a.act);
-                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), orow, cbyte[j] + 4 * lh * rstride, (wm * 64 + i * 32 + 8 * gq + r) * rstride, 0);
+                            const float y = l16_act_slow(fmaf(i ? acc[1][j][4 * gq + r] : acc[0][j][4 * gq + r], ivv[r] * es[j], ec[j]), a.act);
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), orow, vtab[2 * NJ * 64 + (wn * NJ + j) * 32 + li] + 4 * lh * rstride, (wm * 64 + i * 32 + 8 * gq + r) * rstride, 0);
                         }
                 }
             }
         }
-        l16_barrier();                                                     // (the pieces are overwritten by the next tile's staging)
+        l16_barrier();                                                     // (the pieces are overwritten by the next slice's staging)
         if (PROF) { pq[4] += clk() - qe0; pq[6] += 1; }
+        c = 0; slot ^= 1; ++ti;
 #pragma unroll
         for (int i = 0; i < 4; ++i) aofs[i] = aofs_next[i];
         abase = abase_next;
-        slot ^= 1;
+        if (ti >= n_mine) return true;
+        begin_tile();
+        return false;
+    };
+    if (n_mine > 0) {                                                      // (K is padded to two slices at least)
+        row_ofs(tile0 * P_BM, aofs);
+        abase = tile_base(tile0 * P_BM);
+        fetch(pA_a, pW_a, abase, aofs, 0);
+        fetch(pA_b, pW_b, abase, aofs, 1);
+        if (tid < P_BM) rtab(0, tid) = rt_fetch(tile0 * P_BM);
+        begin_tile();
+        for (;;) {
+            if (step(pA_a, pW_a, 0)) break;
+            if (step(pA_b, pW_b, 1)) break;
+        }
     }
     if (PROF && a.prof && blockIdx.x == 0 && tid == 0)
         for (int q = 0; q < 8; ++q) a.prof[q] = pq[q];
@@ -442,7 +467,10 @@ __global__ __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(2, 2))
 
 using namespace gsn;
 
-extern "C" int64_t gsn_linear_f16x3_kpad(int64_t k_total) { return (k_total + L_BK - 1) / L_BK * L_BK; }
+extern "C" int64_t gsn_linear_f16x3_kpad(int64_t k_total) {
+    const int64_t k = (k_total + L_BK - 1) / L_BK * L_BK;
+    return k < 2 * L_BK ? 2 * L_BK : k;                                   // (the kernel keeps two slices in flight)
+}
 
 extern "C" int64_t gsn_linear_f16x3_scratch_bytes(int64_t m_rows, int64_t k_total) {
     if (m_rows <= 0 || k_total <= 0) return 0;
@@ -500,14 +528,13 @@ extern "C" int gsn_linear_f16x3_fwd_hip(int64_t m_rows, int n_blocks, const gsn_
     a.rowinv = row_scratch;
     a.aplanes = reinterpret_cast<unsigned char *>(row_scratch + a.m_pad);
     hipLaunchKernelGGL(lin16_split_rows_kernel, dim3((unsigned)(a.m_pad / 32)), dim3(256), 0, st, a);
-    // tile shape: 256 x 256 (one workgroup of 8 waves per CU) or 128 x 128 (two workgroups of 4 waves per CU)
-    static const int force_wm = getenv("GSN_L16_WM") ? atoi(getenv("GSN_L16_WM")) : 0;
-    const int wm = force_wm ? force_wm : 2;
-    const int nj = wm;
+    // 128 x 128 tiles, two workgroups of 4 waves per CU (256 x 256 tiles with 8 waves measured 3-5 % slower: no registers left
+    // for the second set of loads in flight)
+    const int wm = 2, nj = 2;
     const int bm = 64 * wm, bn = 64 * nj;
     const int64_t n_tiles = (m_rows + bm - 1) / bm;
     const int col_tiles = (int)((n_out + bn - 1) / bn);
-    const int slots = wm == 4 ? 32 : 64;                                    // workgroups per XCD
+    const int slots = 64;                                                   // workgroups per XCD
     int groups = slots / col_tiles;
     if (groups < 1) groups = 1;
     const int64_t need = (n_tiles + 7) / 8;
@@ -517,13 +544,13 @@ extern "C" int gsn_linear_f16x3_fwd_hip(int64_t m_rows, int n_blocks, const gsn_
     static const bool want_prof = getenv("GSN_L16_PROF") != nullptr;
     a.prof = nullptr;
     if (want_prof && hipMalloc(reinterpret_cast<void **>(&a.prof), 64) != hipSuccess) a.prof = nullptr;
-    const size_t lds = (size_t)2 * (bm + bn) * P_PITCH;
+    const size_t lds = (size_t)2 * (bm + bn) * P_PITCH + 8 * bn + 4 * (2 * nj * 64 + 2 * nj * 32);   // slice buffers | epilogue tables
     if (getenv("GSN_CHAIN_TRACE"))
         fprintf(stderr, "gsn linear: linear_f16x3_kernel (%d x %d tiles) M %lld K %d N %d grid 8 x %d x %d\n", bm, bn, (long long)m_rows, k_total, (int)n_out,
                 groups, col_tiles);
     const dim3 grid((unsigned)(8 * groups * col_tiles));
     const bool vec = n_out % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;      // 16-byte output stores
-    static DeviceOnce attr_set[6];
+    static DeviceOnce attr_set[3];
     const int attr_dev = current_device();
     hipError_t e0 = hipSuccess;
     auto launch = [&](auto kern, int which) {
@@ -534,14 +561,9 @@ extern "C" int gsn_linear_f16x3_fwd_hip(int64_t m_rows, int n_blocks, const gsn_
         }
         hipLaunchKernelGGL(kern, grid, dim3(128 * wm), lds, st, a);
     };
-    if (want_prof || a.dbg) {                                               // diagnostic builds
-        if (wm == 4) launch(linear_f16x3_planes_kernel<4, 4, true, true>, 0);
-        else launch(linear_f16x3_planes_kernel<2, 2, true, true>, 1);
-    } else if (!vec) {
-        if (wm == 4) launch(linear_f16x3_planes_kernel<4, 4, false, false>, 2);
-        else launch(linear_f16x3_planes_kernel<2, 2, false, false>, 3);
-    } else if (wm == 4) launch(linear_f16x3_planes_kernel<4, 4, false, true>, 4);
-    else launch(linear_f16x3_planes_kernel<2, 2, false, true>, 5);
+    if (want_prof || a.dbg) launch(linear_f16x3_planes_kernel<2, 2, true, true>, 0);       // diagnostic build
+    else if (!vec) launch(linear_f16x3_planes_kernel<2, 2, false, false>, 1);
+    else launch(linear_f16x3_planes_kernel<2, 2, false, true>, 2);
     if (e0 != hipSuccess) return set_error(GSN_E_HIP, "hipFuncSetAttribute(linear_f16x3_kernel): %s", hipGetErrorString(e0));
     if (a.prof) {
         unsigned long long h[8];

@@ -239,6 +239,30 @@ def _partition_of(edge_index):
     return None
 
 
+_BATCH_PTR = {}
+
+
+def set_batch_partition(batch, node_ptr):
+    """Tell the readout that ``batch`` (the tensor object later passed to the pooling functions) is the SORTED graph-id vector of
+    a collated batch with these boundaries (int64 [G + 1]: ``Batch.ptr``): its rows are already grouped by graph, so the
+    segmented sum needs no index build at all (the generic build sorts the N row ids by graph id with seven launches)."""
+    _need_cuda(batch, "batch")
+    key = id(batch)
+
+    def _gone(_ref, key=key):
+        hit = _BATCH_PTR.get(key)
+        if hit is not None and hit[0] is _ref:
+            del _BATCH_PTR[key]
+    _BATCH_PTR[key] = (weakref.ref(batch, _gone), batch._version, node_ptr.to(device=batch.device, dtype=torch.int32).contiguous())
+
+
+def _batch_ptr_of(batch):
+    hit = _BATCH_PTR.get(id(batch))
+    if hit is not None and hit[0]() is batch and hit[1] == batch._version:
+        return hit[2]
+    return None
+
+
 def _cache_put(key, owner, value):
     """_CSR_CACHE entry that disappears with the tensor it belongs to (weak-reference callback), so batches that are
     dropped do not leave E-sized index tensors behind."""
@@ -292,6 +316,15 @@ def global_add_pool_sparse(x, batch, num_graphs=None):
         # rows are "edges" whose target is their graph id; the message is the row itself
         ei = torch.stack([torch.arange(n_rows, device=x.device, dtype=torch.int64), batch.to(torch.int64)], 0)
         _cache_put(key, batch, ei)
+    ptr = _batch_ptr_of(batch)
+    if ptr is not None and ptr.numel() == g + 1 and _cache_get((id(ei), 1, g), ei) is None:
+        # rows grouped by graph already: segment g = rows ptr[g] .. ptr[g + 1], in place
+        c = _CSR()
+        c.seg_ptr = ptr
+        c.perm = torch.arange(n_rows, device=x.device, dtype=torch.int32)
+        c.tgt, c.src = batch.to(torch.int32), c.perm
+        c._deg = c._deg4 = None
+        _cache_put((id(ei), 1, g), ei, c)
     return propagate(0, ei, 1, g, b=x)
 
 
