@@ -105,11 +105,13 @@ def test_random_chain_shapes_vs_fp64(seed):
 @pytest.mark.parametrize("m,widths,n,act,bn", [(1000, [132], 256, "relu", True), (4097, [128, 128, 4], 384, "identity", False),
                                                 (130, [300], 600, "relu", False), (777, [64, 200], 130, "tanh", True),
                                                 (50000, [128], 256, "relu", True), (3000, [400, 240], 200, "elu", True),
-                                                (257, [36], 131, "relu", False), (70000, [64], 1028, "identity", False)])
+                                                (257, [36], 131, "relu", False), (70000, [64], 1028, "identity", False),
+                                                (20000, [352], 300, "relu", False), (60000, [600], 256, "relu", True)])
 def test_direct_rows_on_the_fp16x3_linear_kernel(m, widths, n, act, bn, capfd):
     """gsn_linear_f16x3_fwd_hip (direct rows, n_out > 128): several input blocks, K not a multiple of the slice and wider than the
     pre-pass keeps in registers, a ragged last row tile and column tile, n_out not a multiple of 4 (4-byte output stores), more
-    row tiles than workgroups, every epilogue -- against fp64, element-wise, with the product's own condition scale as floor."""
+    row tiles than workgroups with an odd number of K slices (the shapes on which a 16-byte store's data register was once
+    overwritten behind the store), every epilogue -- against fp64, element-wise, with the product's own condition scale as floor."""
     import os
     from gsn_amd import layers
     g = torch.Generator().manual_seed(m + n)
