@@ -465,6 +465,231 @@ __global__ __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(2, 2))
 #undef L16_MF
 }
 
+
+// ---- the same product with LDS-DMA staging -------------------------------------------------------------------------------------------
+// global_load_lds_dwordx4 moves a slice's lines straight into LDS (destination: a wave-uniform base + 16 bytes per lane, so the LDS
+// image of a wave instruction is its 8 lines back to back: row pitch 128 bytes, no padding): no staging registers, no ds_write pass,
+// no wait between a load and its LDS write.  Bank conflicts of the fragment reads are avoided by a swizzle instead of a pad: the
+// 16-byte piece p of row r sits at slot p ^ ((r >> 1) & 7) -- applied on the SOURCE side (lane -> which piece it fetches) and on
+// the fragment reads.  Two slice buffers; slice c + 1 is in flight while slice c is multiplied; one barrier per slice.
+constexpr int D_BM = 128, D_BN = 128, D_NT = 256;
+constexpr int D_BUF = (D_BM + D_BN) * L_LINE;          // bytes per slice buffer
+template <bool PROF, bool VEC>
+__global__ __launch_bounds__(D_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void linear_f16x3_dma_kernel(L16Args a) {
+    constexpr int NJ = 2;
+    const int dbg = PROF ? a.dbg : 0;
+    extern __shared__ __attribute__((aligned(16))) unsigned l16_lds[];
+    unsigned char *const lds = reinterpret_cast<unsigned char *>(l16_lds);
+    float *const rtabp = reinterpret_cast<float *>(lds + 2 * D_BUF);      // [2][D_BM] inverse row scales of the current / next tile
+    float *const ecol = rtabp + 2 * D_BM;                                  // [D_BN] scale | [D_BN] constant
+    int *const vtab = reinterpret_cast<int *>(ecol + 2 * D_BN);            // [2][NJ][64] offsets of the 16-byte stores | [2][NJ][32] of the 4-byte ones
+    auto clk = [&]() -> unsigned long long {
+        if (!PROF) return 0ull;
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long v = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_sched_barrier(0);
+        return v;
+    };
+    unsigned long long pq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int xcd = blockIdx.x & 7, slot_in_xcd = blockIdx.x >> 3;
+    const int ct = slot_in_xcd % a.col_tiles, grp = slot_in_xcd / a.col_tiles;
+    const int n0 = ct * D_BN;
+    const int64_t n_tiles = (a.m_rows + D_BM - 1) / D_BM;
+    const int64_t tile0 = (int64_t)xcd * a.groups + grp, tstride = 8 * (int64_t)a.groups;
+    const int64_t n_mine = tile0 < n_tiles ? (n_tiles - tile0 + tstride - 1) / tstride : 0;
+    const int n_slices = a.k_pad / L_BK;
+    const int row_bytes = n_slices * L_LINE;
+    const int rstride = a.n_out * 4;
+
+    for (int cidx = tid; cidx < D_BN; cidx += D_NT) {
+        const int col = n0 + cidx;
+        const bool cok = col < a.n_out;
+        const float e_bias = (cok && a.bias) ? a.bias[col] : 0.f;
+        float es = cok ? a.colinv[col] : 0.f, ec = e_bias;
+        if (cok && a.bn_scale) { ec = (e_bias - a.bn_mean[col]) * a.bn_scale[col] + a.bn_shift[col]; es *= a.bn_scale[col]; }
+        ecol[cidx] = es; ecol[D_BN + cidx] = ec;
+    }
+    for (int q = tid; q < 2 * NJ * 64; q += D_NT) {
+        const int l = q & 63, k = (q >> 6) % NJ, w = q / (64 * NJ);
+        const int idx = 64 * k + l, c4 = idx % (8 * NJ), col = n0 + w * 32 * NJ + 4 * c4;
+        vtab[q] = col < a.n_out ? ((idx / (8 * NJ)) - (64 * k) / (8 * NJ)) * rstride + col * 4 : 0x7f000000;
+    }
+    for (int q = tid; q < 2 * NJ * 32; q += D_NT) {
+        const int l = q & 31, j = (q >> 5) % NJ, w = q / (32 * NJ);
+        const int col = n0 + w * 32 * NJ + 32 * j + l;
+        vtab[2 * NJ * 64 + q] = col < a.n_out ? col * 4 : 0x7f000000;
+    }
+    // staging: wave w moves rows (output columns) 32 w + 8 i .. + 7 with instruction i; lane -> row 8 i + (lane >> 3), slot lane & 7,
+    // i.e. piece (lane & 7) ^ swizzle(row)
+    const int s_r8 = lane >> 3, s_q = lane & 7;
+    unsigned wofs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = 32 * wave + 8 * i + s_r8;
+        int j = n0 + r;
+        j = j < a.n_out ? j : 0;
+        wofs[i] = (unsigned)j * (unsigned)row_bytes + 16u * (unsigned)(s_q ^ ((r >> 1) & 7));
+    }
+    auto row_ofs = [&](int64_t row0, unsigned *aofs) {
+        const int64_t left = a.m_rows - row0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 32 * wave + 8 * i + s_r8;
+            const int rc = r < left ? r : (int)(left > 0 ? left - 1 : 0);
+            aofs[i] = (unsigned)rc * (unsigned)row_bytes + 16u * (unsigned)(s_q ^ ((r >> 1) & 7));
+        }
+    };
+    auto tile_base = [&](int64_t row0) { return a.aplanes + (row0 < a.m_rows ? row0 : 0) * row_bytes; };
+    typedef const __attribute__((address_space(1))) void *gptr_t;
+    typedef __attribute__((address_space(3))) void *lptr_t;
+    auto fetch = [&](const unsigned char *abase, const unsigned *aofs, int c, int buf) {
+        unsigned char *const da = lds + buf * D_BUF + (32 * wave) * L_LINE, *const dw = da + D_BM * L_LINE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(abase + aofs[i] + c * L_LINE), (lptr_t)(da + 8 * i * L_LINE), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(a.wplanes + wofs[i] + c * L_LINE), (lptr_t)(dw + 8 * i * L_LINE), 16, 0, 0);
+    };
+    // fragment reads: piece 4 plane + 2 s + lh of row (.. + li): slot = piece ^ ((li >> 1) & 7) (the tile offsets of a row are multiples of 16)
+    const int swz = (li >> 1) & 7;
+    int fo[2][2];                                                           // [plane][k-step] byte offset inside the row
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int st = 0; st < 2; ++st) fo[pl][st] = 16 * ((4 * pl + 2 * st + lh) ^ swz);
+    f32x16 acc[2][NJ];
+#define L16_MF(acc, x, y) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, x), __builtin_bit_cast(h16x8, y), acc, 0, 0, 0)
+    auto products = [&](int buf) {
+        const unsigned char *ap = lds + buf * D_BUF + (wm * 64 + li) * L_LINE, *bp = lds + buf * D_BUF + (D_BM + wn * 32 * NJ + li) * L_LINE;
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            un4 ah[2], al[2], bh[NJ], bl[NJ];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ah[i] = *reinterpret_cast<const un4 *>(ap + i * (32 * L_LINE) + fo[0][st]);
+                al[i] = *reinterpret_cast<const un4 *>(ap + i * (32 * L_LINE) + fo[1][st]);
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                bh[j] = *reinterpret_cast<const un4 *>(bp + j * (32 * L_LINE) + fo[0][st]);
+                bl[j] = *reinterpret_cast<const un4 *>(bp + j * (32 * L_LINE) + fo[1][st]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) L16_MF(acc[i][j], al[i], bh[j]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) L16_MF(acc[i][j], ah[i], bl[j]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) L16_MF(acc[i][j], ah[i], bh[j]);
+        }
+    };
+    if (n_mine > 0) {
+        unsigned aofs[4], aofs_next[4];
+        const unsigned char *abase = tile_base(tile0 * D_BM), *abase_next = abase;
+        row_ofs(tile0 * D_BM, aofs);
+        fetch(abase, aofs, 0, 0);
+        if (tid < D_BM) { const int64_t r = tile0 * D_BM + tid; rtabp[tid] = a.rowinv[r < a.m_pad ? r : a.m_pad - 1]; }
+        int buf = 0, slot = 0;
+        for (int64_t ti = 0; ti < n_mine; ++ti) {
+            const int64_t row0 = (tile0 + ti * tstride) * D_BM, row_next = ti + 1 < n_mine ? row0 + tstride * D_BM : row0;
+            float rt_next = 0.f;
+            if (tid < D_BM) { const int64_t r = row_next + tid; rt_next = a.rowinv[r < a.m_pad ? r : a.m_pad - 1]; }
+            row_ofs(row_next, aofs_next);
+            abase_next = tile_base(row_next);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int c = 0; c < n_slices; ++c) {
+                const unsigned long long q0 = clk();
+                // slice c has landed (this wave's share; the barrier makes that true for all of them) and nobody reads the other buffer
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                l16_barrier();
+                const unsigned long long q1 = clk();
+                const bool wrap = c + 1 >= n_slices;
+                if (!(dbg & 4)) fetch(wrap ? abase_next : abase, wrap ? aofs_next : aofs, wrap ? 0 : c + 1, buf ^ 1);
+                const unsigned long long q2 = clk();
+                if (!(dbg & 2)) products(buf);
+                buf ^= 1;
+                if (PROF) { const unsigned long long q3 = clk(); pq[0] += q2 - q1; pq[1] += q3 - q2; pq[3] += q1 - q0; pq[5] += 1; }
+            }
+            const unsigned long long qe0 = clk();
+            if (tid < D_BM) rtabp[(slot ^ 1) * D_BM + tid] = rt_next;
+            l16_barrier();                                                 // every wave is done with the last slice's buffer: it is the epilogue's scratch
+            const int64_t rows_left = a.m_rows - row0;
+            const int nrows = rows_left < D_BM ? (int)rows_left : D_BM;
+            const __amdgpu_buffer_rsrc_t orow = __builtin_amdgcn_make_buffer_rsrc(a.out + row0 * a.n_out, 0, nrows * rstride, 0x00020000);
+            const float act_lo = a.act == 1 ? 0.f : -INFINITY;
+            constexpr int SP = 32 * NJ * 4 + 16;
+            unsigned char *const scr = lds + (buf ^ 1) * D_BUF + wave * (8 * SP);
+            const float *const rt = rtabp + slot * D_BM;
+            float es[NJ], ec[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) { es[j] = ecol[wn * 32 * NJ + 32 * j + li]; ec[j] = ecol[D_BN + wn * 32 * NJ + 32 * j + li]; }
+            auto emit = [&](auto simple) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const int rl = wm * 64 + i * 32 + 8 * gq;
+                        const float ivv[4] = {rt[rl + 4 * lh], rt[rl + 4 * lh + 1], rt[rl + 4 * lh + 2], rt[rl + 4 * lh + 3]};
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+#pragma unroll
+                            for (int j = 0; j < NJ; ++j) {
+                                float y = fmaf(acc[i][j][4 * gq + r], ivv[r] * es[j], ec[j]);
+                                if (decltype(simple)::value) y = y < act_lo ? act_lo : y;       // (a NaN stays a NaN)
+                                else y = l16_act_slow(y, a.act);
+                                *reinterpret_cast<float *>(scr + (r + 4 * lh) * SP + (li + 32 * j) * 4) = y;
+                            }
+                        if ((dbg & 1) && acc[i][0][4 * gq] != 12345.f) continue;
+                        if (VEC) {
+#pragma unroll
+                            for (int k = 0; k < NJ; ++k) {
+                                const int idx = 64 * k + lane, row = idx / (8 * NJ), c4 = idx % (8 * NJ);
+                                const un4 v = *reinterpret_cast<const un4 *>(scr + row * SP + 16 * c4);
+                                // (row offset in the vector offset, s_nop behind the store: see linear_f16x3_planes_kernel)
+                                __builtin_amdgcn_raw_buffer_store_b128(v, orow, vtab[(wn * NJ + k) * 64 + lane] + (rl + (64 * k) / (8 * NJ)) * rstride, 0, 0);
+                                asm volatile("s_nop 1" ::: "memory");
+                            }
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                                for (int j = 0; j < NJ; ++j) {
+                                    const unsigned y = *reinterpret_cast<const unsigned *>(scr + (r + 4 * lh) * SP + (li + 32 * j) * 4);
+                                    __builtin_amdgcn_raw_buffer_store_b32(y, orow, vtab[2 * NJ * 64 + (wn * NJ + j) * 32 + li] + (rl + r + 4 * lh) * rstride, 0, 0);
+                                }
+                        }
+                    }
+                }
+            };
+            if (a.act <= 1) emit(std::true_type{});
+            else emit(std::false_type{});
+            if (PROF) { pq[4] += clk() - qe0; pq[6] += 1; }
+            slot ^= 1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) aofs[i] = aofs_next[i];
+            abase = abase_next;
+        }
+    }
+    if (PROF && a.prof && blockIdx.x == 0 && tid == 0)
+        for (int q = 0; q < 8; ++q) a.prof[q] = pq[q];
+#undef L16_MF
+}
+
 }  // namespace
 
 }  // namespace gsn
@@ -548,13 +773,13 @@ extern "C" int gsn_linear_f16x3_fwd_hip(int64_t m_rows, int n_blocks, const gsn_
     static const bool want_prof = getenv("GSN_L16_PROF") != nullptr;
     a.prof = nullptr;
     if (want_prof && hipMalloc(reinterpret_cast<void **>(&a.prof), 64) != hipSuccess) a.prof = nullptr;
-    const size_t lds = (size_t)2 * (bm + bn) * P_PITCH + 8 * bn + 4 * (2 * nj * 64 + 2 * nj * 32);   // slice buffers | epilogue tables
+    size_t lds = (size_t)2 * (bm + bn) * P_PITCH + 8 * bn + 4 * (2 * nj * 64 + 2 * nj * 32);   // slice buffers | epilogue tables
     if (getenv("GSN_CHAIN_TRACE"))
         fprintf(stderr, "gsn linear: linear_f16x3_kernel (%d x %d tiles) M %lld K %d N %d grid 8 x %d x %d\n", bm, bn, (long long)m_rows, k_total, (int)n_out,
                 groups, col_tiles);
     const dim3 grid((unsigned)(8 * groups * col_tiles));
     const bool vec = n_out % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;      // 16-byte output stores
-    static DeviceOnce attr_set[3];
+    static DeviceOnce attr_set[6];
     const int attr_dev = current_device();
     hipError_t e0 = hipSuccess;
     auto launch = [&](auto kern, int which) {
@@ -565,9 +790,17 @@ extern "C" int gsn_linear_f16x3_fwd_hip(int64_t m_rows, int n_blocks, const gsn_
         }
         hipLaunchKernelGGL(kern, grid, dim3(128 * wm), lds, st, a);
     };
-    if (want_prof || a.dbg) launch(linear_f16x3_planes_kernel<2, 2, true, true>, 0);       // diagnostic build
-    else if (!vec) launch(linear_f16x3_planes_kernel<2, 2, false, false>, 1);
-    else launch(linear_f16x3_planes_kernel<2, 2, false, true>, 2);
+    static const bool reg_stage = getenv("GSN_L16_REGSTAGE") != nullptr;  // (A/B: slices staged through registers)
+    if (reg_stage) {
+        if (want_prof || a.dbg) launch(linear_f16x3_planes_kernel<2, 2, true, true>, 0);       // diagnostic build
+        else if (!vec) launch(linear_f16x3_planes_kernel<2, 2, false, false>, 1);
+        else launch(linear_f16x3_planes_kernel<2, 2, false, true>, 2);
+    } else {
+        lds = (size_t)2 * D_BUF + 4 * (2 * D_BM + 2 * D_BN) + 4 * (2 * 2 * 64 + 2 * 2 * 32);
+        if (want_prof || a.dbg) launch(linear_f16x3_dma_kernel<true, true>, 3);
+        else if (!vec) launch(linear_f16x3_dma_kernel<false, false>, 4);
+        else launch(linear_f16x3_dma_kernel<false, true>, 5);
+    }
     if (e0 != hipSuccess) return set_error(GSN_E_HIP, "hipFuncSetAttribute(linear_f16x3_kernel): %s", hipGetErrorString(e0));
     if (a.prof) {
         unsigned long long h[8];
