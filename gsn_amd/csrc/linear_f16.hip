@@ -169,13 +169,16 @@ __global__ __launch_bounds__(256) void lin16_split_rows_kernel(L16Args a) {
     if (q8 == 0) a.rowinv[row] = on ? inv : 0.f;
     if (!on) return;
     unsigned char *prow = a.aplanes + row * a.k_pad * 4;                 // (4 bytes per column: a high and a low half)
-    auto put = [&](int c, const float4 &x) {                              // chunk c = columns 4c .. 4c + 3: slice c >> 3, piece c & 7
+    // chunk c = columns 4c .. 4c + 3 of slice c >> 3.  Lane pairs trade halves so that every lane stores 16 bytes: the even lane
+    // the high halfs of both chunks, the odd lane the low halfs -- the 8 lanes of a row write one whole line with one instruction
+    const bool even = (q8 & 1) == 0;
+    auto put = [&](int c, const float4 &x) {
         unsigned h0, l0, h1, l1;
         l16_split2(fl2{x.x * s, x.y * s}, h0, l0);
         l16_split2(fl2{x.z * s, x.w * s}, h1, l1);
-        unsigned char *line = prow + (c >> 3) * L_LINE + (c & 7) * 8;     // (the 8 lanes of a row write one whole line per trip)
-        *reinterpret_cast<un2 *>(line) = un2{h0, h1};
-        *reinterpret_cast<un2 *>(line + 64) = un2{l0, l1};
+        const unsigned r0 = (unsigned)__shfl_xor((int)(even ? l0 : h0), 1), r1 = (unsigned)__shfl_xor((int)(even ? l1 : h1), 1);
+        unsigned char *line = prow + (c >> 3) * L_LINE + (even ? 0 : 64) + ((c & 7) >> 1) * 16;
+        *reinterpret_cast<un4 *>(line) = even ? un4{h0, h1, r0, r1} : un4{r0, r1, l0, l1};
     };
 #pragma unroll
     for (int i = 0; i < L_RC; ++i) {
@@ -602,8 +605,8 @@ __global__ __launch_bounds__(D_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
         int buf = 0, slot = 0;
         for (int64_t ti = 0; ti < n_mine; ++ti) {
             const int64_t row0 = (tile0 + ti * tstride) * D_BM, row_next = ti + 1 < n_mine ? row0 + tstride * D_BM : row0;
-            float rt_next = 0.f;
-            if (tid < D_BM) { const int64_t r = row_next + tid; rt_next = a.rowinv[r < a.m_pad ? r : a.m_pad - 1]; }
+            float rt_next;                                                  // (every wave issues this load: the counted wait below relies on it)
+            { const int64_t r = row_next + (tid & (D_BM - 1)); rt_next = a.rowinv[r < a.m_pad ? r : a.m_pad - 1]; }
             row_ofs(row_next, aofs_next);
             abase_next = tile_base(row_next);
 #pragma unroll
@@ -615,8 +618,15 @@ __global__ __launch_bounds__(D_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
             for (int c = 0; c < n_slices; ++c) {
                 const unsigned long long q0 = clk();
                 // slice c has landed (this wave's share; the barrier makes that true for all of them) and nobody reads the other buffer
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // (first slice of a later tile: the 16 output stores of the previous tile and the row-scale load below were issued
+                //  AFTER this slice's loads -- memory operations complete in order, so "all but the newest 17" covers the slice
+                //  without waiting for the stores)
+                if (VEC && !PROF && c == 0 && ti > 0) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 l16_barrier();
+                // (the next tile's row scales go to LDS here, where nothing is in flight: consumed at the end of the tile, the
+                //  compiler's wait for this load would also wait for the next tile's first slice)
+                if (c == 1 && tid < D_BM) rtabp[(slot ^ 1) * D_BM + tid] = rt_next;
                 const unsigned long long q1 = clk();
                 const bool wrap = c + 1 >= n_slices;
                 if (!(dbg & 4)) fetch(wrap ? abase_next : abase, wrap ? aofs_next : aofs, wrap ? 0 : c + 1, buf ^ 1);
@@ -626,7 +636,6 @@ __global__ __launch_bounds__(D_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
                 if (PROF) { const unsigned long long q3 = clk(); pq[0] += q2 - q1; pq[1] += q3 - q2; pq[3] += q1 - q0; pq[5] += 1; }
             }
             const unsigned long long qe0 = clk();
-            if (tid < D_BM) rtabp[(slot ^ 1) * D_BM + tid] = rt_next;
             l16_barrier();                                                 // every wave is done with the last slice's buffer: it is the epilogue's scratch
             const int64_t rows_left = a.m_rows - row0;
             const int nrows = rows_left < D_BM ? (int)rows_left : D_BM;

@@ -13,7 +13,7 @@ import csv, sys
 out = []
 for r in csv.DictReader(open(sys.argv[1])):
     n = r["Name"]
-    for key in ("planes_kernel", "split_rows", "prepare_kernel", "linear_fwd_bf16"):
+    for key in ("dma_kernel", "planes_kernel", "split_rows", "prepare_kernel", "linear_fwd_bf16"):
         if key in n:
             out.append("%s avg %.1f min %.1f max %.1f us x%s" % (key, float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Calls"]))
 print("dbg %s: %s" % (sys.argv[2], "  ".join(out)))

@@ -11,8 +11,8 @@ import csv, sys, collections
 acc = collections.defaultdict(lambda: [0.0, 0])
 for r in csv.DictReader(open(sys.argv[1])):
     k = r["Kernel_Name"]
-    if "planes_kernel" in k or "split_rows" in k or "linear_f16x3_kernel" in k:
-        name = "planes" if "planes_kernel" in k else ("split" if "split_rows" in k else "inkernel")
+    if "planes_kernel" in k or "dma_kernel" in k or "split_rows" in k:
+        name = "split" if "split_rows" in k else "matrix"
         a = acc[(name, r["Counter_Name"])]
         a[0] += float(r["Counter_Value"]); a[1] += 1
 for (n, c), (v, k) in sorted(acc.items()):
