@@ -285,8 +285,9 @@ int gsn_layer_fused_fwd_hip(int64_t n_nodes, int64_t n_edges, const int32_t *seg
  * magnitude -- a pre-pass inside the call --, every output column of W by its largest entry), three plane products per fp32
  * product on the 16-bit matrix pipe, fp32 accumulation: the error of an fp32 FMA loop at half the matrix work of the bf16x6
  * kernel, over the whole fp32 exponent range; a row with an Inf / NaN comes out NaN.
- *   gsn_linear_f16x3_kpad(K)          K rounded up to two of the kernel's K slices (64)
- *   gsn_linear_f16x3_prepare_hip      splits W [n_out][K] once: planes = 2 * n_out * kpad(K) fp16 values, col_inv = n_out floats
+ *   gsn_linear_f16x3_kpad(K)          K rounded up to whole K slices of 32 columns (two at least)
+ *   gsn_linear_f16x3_prepare_hip      splits W [n_out][K] once: planes = 2 * n_out * kpad(K) fp16 values (laid out
+ *                                     [n_out][kpad / 32][high | low][32]: one cache line per row and slice), col_inv = n_out floats
  *                                     (device buffers of the caller; valid until W changes)
  *   gsn_linear_f16x3_scratch_bytes    size of row_scratch for m_rows rows of K columns: the rows' inverse scales and their two
  *                                     fp16 planes (split once per call by a pre-pass, read by every column tile)
