@@ -106,7 +106,8 @@ def test_random_chain_shapes_vs_fp64(seed):
                                                 (130, [300], 600, "relu", False), (777, [64, 200], 130, "tanh", True),
                                                 (50000, [128], 256, "relu", True), (3000, [400, 240], 200, "elu", True),
                                                 (257, [36], 131, "relu", False), (70000, [64], 1028, "identity", False),
-                                                (20000, [352], 300, "relu", False), (60000, [600], 256, "relu", True)])
+                                                (20000, [352], 300, "relu", False), (60000, [600], 256, "relu", True),
+                                                (1, [4], 132, "relu", False), (5, [8, 4], 200, "identity", True), (129, [32], 129, "relu", True)])
 def test_direct_rows_on_the_fp16x3_linear_kernel(m, widths, n, act, bn, capfd):
     """gsn_linear_f16x3_fwd_hip (direct rows, n_out > 128): several input blocks, K not a multiple of the slice and wider than the
     pre-pass keeps in registers, a ragged last row tile and column tile, n_out not a multiple of 4 (4-byte output stores), more
