@@ -104,7 +104,7 @@ def main():
                           "n_gpus": world, "graphs_per_s": round(world * args.batch * args.steps / dt, 1),
                           "ms_per_step": round(dt / args.steps * 1e3, 3), "parameters": n_params,
                           "grad_bucket_MB": round(n_params * 4 / 1e6, 2), "loss": float(loss.item()),
-                          "note": "forward on HIP kernels; backward of the dense stages through PyTorch autograd (DESIGN.md 8)"}))
+                          "note": "forward and backward on HIP kernels (native adjoints of every stage, DESIGN.md 4); SGD update and glue in PyTorch"}))
     if dist is not None:
         dist.destroy_process_group()
 
