@@ -215,6 +215,14 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
                         }
                     }
                 }
+            } else if (s == 0) {
+                // a wave without output columns (n_out <= 96: wave 3, n_out <= 64: waves 2 and 3) multiplies nothing but still owns
+                // its share of the next tile's rows: without these loads its rows of the next tile kept what the buffer held --
+                // the rows of the tile this workgroup handled before (wrong output rows from the second tile of a workgroup on,
+                // i.e. past 128 x gridDim rows)
+#pragma unroll
+                for (int ch = 0; ch < CH0; ++ch)
+                    if (ch < nch[0] && ch < PF0_J) prefetch_j(rs_next_tab, ch);
             }
             // epilogue.  C layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).  Straight-line for full tiles
             // (activation switch hoisted out of the 32-element loops) so the stores / LDS writes issue back to back.

@@ -145,3 +145,25 @@ def test_direct_rows_on_the_fp16x3_linear_kernel(m, widths, n, act, bn, capfd):
     ref = {"relu": torch.relu, "identity": lambda t: t, "tanh": torch.tanh, "elu": torch.nn.functional.elu}[act](pre)
     err = (y.double() - ref).abs()
     assert bool((err <= 1e-5 * ref.abs() + 2e-6 * scale).all()), float((err / (1e-5 * ref.abs() + 2e-6 * scale)).max())
+
+
+@pytest.mark.parametrize("m,k,widths", [(70000, 132, [96]), (70000, 128, [64]), (50000, 36, [32]), (70000, 100, [64, 64]), (40000, 160, [128, 96]),
+                                          (70000, 260, [64]), (70000, 132, [128])])
+def test_narrow_stages_over_many_row_tiles(m, k, widths):
+    """Stages with fewer than 128 output columns over more rows than one pass of the persistent workgroups covers (regression: see
+    test_narrow_layers_on_a_big_batch_vs_oracle), one and two stages, against fp64 element-wise."""
+    from gsn_amd import layers
+    g = torch.Generator().manual_seed(m + k + sum(widths))
+    x = torch.randn(m, k, generator=g)
+    stages, cur, ref = [], k, x.double()
+    for i, n in enumerate(widths):
+        w = torch.randn(n, cur, generator=g) / cur ** 0.5
+        b = torch.randn(n, generator=g)
+        stages.append(layers._Stage(w.cuda(), b.cuda(), None, "relu", [(x.cuda(), None)] if i == 0 else []))
+        ref = torch.relu(ref @ w.double().t() + b.double())
+        cur = n
+    y = layers.run_stages(stages, m, False).cpu()
+    assert y.shape == ref.shape
+    err = (y.double() - ref).abs()
+    bad = err > 1e-5 * ref.abs().max()
+    assert not bool(bad.any()), "rows %s" % bad.any(1).nonzero().flatten()[:8].tolist()

@@ -207,6 +207,48 @@ def test_layer_vs_oracle_big_batch():
     assert elementwise_ok(y.cpu(), ref)
 
 
+@pytest.mark.parametrize("cls,kind", [("GSN_edge_sparse", "general"), ("GSN_sparse", "gin"), ("MPNN_edge_sparse", "general")])
+def test_narrow_layers_on_a_big_batch_vs_oracle(cls, kind):
+    """d = 64 (BASELINE config 3's width) on 4096 graphs: 95 k vertices / 195 k edge rows, i.e. every persistent workgroup of the
+    dense kernels handles several row tiles, with stages that have fewer output columns than a workgroup has column waves
+    (regression: the waves without output columns of mlp_chain_kernel skipped their share of the next tile's loads -- rows
+    past the first 128 x gridDim were computed from the previous tile's inputs; the small-batch goldens never got there)."""
+    from gsn_amd import layers, synth
+    from oracle import oracle
+    torch.manual_seed(8)
+    b = synth.zinc_shape_batch(4096, seed=12)
+    N, E = b.num_nodes, b.num_edges
+    ctor = dict(d_in=28, d_ef=4, d_id=12, d_degree=1, degree_as_tag=False, retain_features=True, id_scope="local", d_msg=64,
+                d_up=64, d_h=[64], seed=0, activation_name="relu", bn=True, flow="source_to_target")
+    if cls == "GSN_sparse":
+        ctor.update(id_scope="global", msg_kind="gin", aggr="add", train_eps=False)
+        ctor.pop("d_ef")
+    else:
+        ctor["msg_kind"] = kind
+    layer = getattr(layers, cls)(**ctor)
+    for m in layer.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.uniform_(-0.3, 0.3); m.running_var.uniform_(0.5, 1.5); m.weight.data.uniform_(0.5, 1.5); m.bias.data.uniform_(-0.3, 0.3)
+    layer.eval()
+    x = torch.nn.functional.one_hot(torch.from_numpy(b.atom_type), 28).float()
+    ef = torch.nn.functional.one_hot(torch.from_numpy(b.bond_type), 4).float()
+    ei = torch.from_numpy(b.edge_index)
+    ids = (torch.rand(N if cls == "GSN_sparse" else E, 12) < 0.2).float()
+    sd = {k: v.clone() for k, v in layer.state_dict().items()}
+    kw = dict(identifiers=ids, degrees=None, training=False)
+    if cls != "GSN_sparse":
+        kw["edge_features"] = ef
+    ref = oracle.layer_forward(cls, ctor, sd, x, ei, **kw)
+    layer.cuda()
+    with torch.no_grad():
+        kw2 = dict(identifiers=ids.cuda(), degrees=torch.zeros(N, device="cuda"))
+        if cls != "GSN_sparse":
+            kw2["edge_features"] = ef.cuda()
+        y = layer(x.cuda(), ei.cuda(), **kw2)
+    assert rel_err(y.cpu(), ref) < TOL
+    assert elementwise_ok(y.cpu(), ref)
+
+
 def test_one_hot_identifiers_vs_torch():
     from gsn_amd.layers import one_hot_identifiers
     torch.manual_seed(3)
