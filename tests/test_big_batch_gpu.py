@@ -1,0 +1,85 @@
+"""Every layer class at several widths on a batch large enough that each persistent workgroup of the dense kernels walks several
+row tiles (2048 graphs: 47 k vertices, 97 k edge rows), eval and train-mode forward, against the oracle's fp32 torch restatement
+(oracle/oracle.py::layer_forward, itself pinned to the reference's layers by tests/golden/layers.npz).  The reference-generated
+goldens are small batches: they cover every code path of the layers but never a second tile of a workgroup -- which is where the
+missing loads of mlp_chain_kernel's idle waves (widths 64 and 96) went unnoticed."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def rel_err(a, b, floor=1e-30):
+    return (a - b).abs().max().item() / max(b.abs().max().item(), floor)
+
+
+def elementwise_ok(got, ref, rtol=TOL):
+    """|got - ref| <= rtol |ref| + rtol * max|ref row|, every element"""
+    got, ref = got.reshape(ref.shape[0], -1), ref.reshape(ref.shape[0], -1)
+    return bool(((got - ref).abs() <= rtol * ref.abs() + rtol * ref.abs().amax(dim=1, keepdim=True)).all())
+
+BASE = dict(d_degree=1, degree_as_tag=False, retain_features=True, seed=0, activation_name="relu", bn=True, flow="source_to_target",
+            aggr="add", eps=0, extend_dims=True, id_embedding="one_hot_encoder", edge_embedding="one_hot_encoder")
+
+
+def _case(cls, d, kind):
+    ctor = dict(BASE)
+    if cls.endswith("_ogb"):
+        ctor.update(d_in=d, d_id=d, id_scope="local", d_msg=None, d_up=d, d_h=[2 * d], msg_kind="ogb", train_eps=True)
+        if "edge" in cls:
+            ctor["d_ef"] = d
+        return ctor, d, d, d
+    if kind == "gin":
+        ctor.update(d_in=d, d_id=12, id_scope="global" if "GSN" in cls else "local", d_msg=None, d_up=d, d_h=[d], msg_kind="gin", train_eps=True)
+        if "edge" in cls:
+            ctor["d_ef"] = 4
+        return ctor, d, 12, 4
+    ctor.update(d_in=28, d_id=12, id_scope="local", d_msg=d, d_up=d, d_h=[d], msg_kind="general", train_eps=False)
+    if "edge" in cls:
+        ctor["d_ef"] = 4
+    return ctor, 28, 12, 4
+
+
+CASES = [(c, d, k) for c in ("GSN_sparse", "GSN_edge_sparse", "MPNN_sparse", "MPNN_edge_sparse") for d in (32, 64, 96) for k in ("general", "gin")]
+CASES += [(c, d, "ogb") for c in ("GSN_edge_sparse_ogb", "MPNN_edge_sparse_ogb") for d in (64, 300)]
+
+
+@pytest.mark.parametrize("cls,d,kind", CASES)
+@pytest.mark.parametrize("training", [False, True])
+def test_layer_classes_at_several_widths_on_many_row_tiles(cls, d, kind, training):
+    from gsn_amd import layers, synth
+    from oracle import oracle
+    if training and d == 300:
+        pytest.skip("covered by the config-4 golden and the training-step scripts; the oracle's CPU pass at d = 300 takes minutes")
+    torch.manual_seed(d + len(cls))
+    b = synth.zinc_shape_batch(2048, seed=21)
+    N, E = b.num_nodes, b.num_edges
+    ctor, d_x, d_id, d_ef = _case(cls, d, kind)
+    layer = getattr(layers, cls)(**ctor)
+    for m in layer.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.uniform_(-0.3, 0.3); m.running_var.uniform_(0.5, 1.5); m.weight.data.uniform_(0.5, 1.5); m.bias.data.uniform_(-0.3, 0.3)
+    layer.train(training)
+    x = torch.randn(N, d_x) if d_x != 28 else torch.nn.functional.one_hot(torch.from_numpy(b.atom_type), 28).float()
+    ei = torch.from_numpy(b.edge_index)
+    has_ids, has_ef = cls.startswith("GSN"), "edge" in cls
+    per_node_ids = ctor["id_scope"] == "global"
+    ids = torch.randn(N if per_node_ids else E, d_id) * 0.5 if has_ids else None
+    ef = torch.randn(E, d_ef) * 0.5 if has_ef else None
+    sd = {k: v.clone() for k, v in layer.state_dict().items()}
+    ref = oracle.layer_forward(cls, ctor, sd, x, ei, identifiers=ids, degrees=None, edge_features=ef, training=training)
+    layer.cuda()
+    kw = dict(degrees=torch.zeros(N, device="cuda"))
+    if has_ids:
+        kw["identifiers"] = ids.cuda()
+    elif cls.endswith("_ogb"):
+        kw["identifiers"] = None                 # (the ogb classes take the keyword whether they use it or not, MPNN_edge_sparse_ogb.py:63)
+    if has_ef:
+        kw["edge_features"] = ef.cuda()
+    with torch.no_grad():
+        y = layer(x.cuda(), ei.cuda(), **kw)
+    assert y.shape == ref.shape
+    assert rel_err(y.cpu(), ref) < TOL
+    assert elementwise_ok(y.cpu(), ref)
