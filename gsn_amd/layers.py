@@ -1334,6 +1334,15 @@ class _SparseLayer(nn.Module):
             post = (kwargs.get("post_bn"), kwargs.get("post_act") or "identity")
         x, ids, ef = self._prepare(x, kwargs)
         _need_cuda(x, "x")
+        # Row counts of the per-edge / per-vertex inputs: the reference fails in torch.cat / indexing when they do not fit
+        # (GSN_sparse.py:118-132); the kernels would read past the tensors instead.
+        n_rows, n_cols_e = x.shape[0], edge_index.shape[1]
+        ids_per_edge = self.has_ids and (self.id_scope == "local")
+        if ids is not None and ids.shape[0] != (n_cols_e if ids_per_edge else n_rows):
+            raise RuntimeError("identifiers: %d rows, expected %d (id_scope %r: one row per %s)" % (
+                ids.shape[0], n_cols_e if ids_per_edge else n_rows, self.id_scope, "edge" if ids_per_edge else "vertex"))
+        if ef is not None and ef.shape[0] != n_cols_e:
+            raise RuntimeError("edge_features: %d rows, expected one per edge (%d)" % (ef.shape[0], n_cols_e))
         _need_cuda(edge_index, "edge_index")
         given = [x, ids, ef]
         inputs = [t for t in given if t is not None and not isinstance(t, Codes)]

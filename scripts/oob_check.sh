@@ -1,0 +1,13 @@
+#!/bin/bash
+# Out-of-bounds detector for the GPU suite: with PyTorch's caching allocator off every tensor is its own hipMalloc mapping, so a
+# kernel that reads or writes past a tensor faults ("Memory access fault by GPU") instead of silently touching a neighbour inside
+# the allocator's block.  One pytest process per file (a fault kills the process).  Run on the GPU box: scripts/oob_check.sh
+export PYTORCH_NO_CUDA_MEMORY_CACHING=1
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+rc=0
+for f in tests/test_*gpu*.py; do
+  r=$(timeout 900 python -m pytest "$f" -q -m gpu 2>&1 | grep -v amdgpu.ids | tail -1 | cut -c1-120)
+  echo "$f: $r"
+  case "$r" in *passed*) ;; *) rc=1 ;; esac
+done
+exit $rc

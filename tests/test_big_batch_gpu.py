@@ -3,6 +3,8 @@ row tiles (2048 graphs: 47 k vertices, 97 k edge rows), eval and train-mode forw
 (oracle/oracle.py::layer_forward, itself pinned to the reference's layers by tests/golden/layers.npz).  The reference-generated
 goldens are small batches: they cover every code path of the layers but never a second tile of a workgroup -- which is where the
 missing loads of mlp_chain_kernel's idle waves (widths 64 and 96) went unnoticed."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -150,3 +152,96 @@ def test_train_mode_backward_on_many_row_tiles(cls, d, kind):
             assert rel_err(p.grad.cpu(), grads[k], FL) < BT, k
             n_checked += 1
     assert n_checked >= 4
+
+
+def _model_kwargs(model_name, n_layers, d, msg_kind, id_scope, readout, activation, jk_mlp, enc):
+    return dict(seed=0, model_name=model_name, readout=readout, dropout_features=[0.0] * (n_layers + 1), bn=[True] * n_layers,
+                final_projection=[True] * (n_layers + 1), inject_ids=False, inject_edge_features=True, random_features=False,
+                id_scope=id_scope, d_msg=[d] * n_layers, d_out=[d] * n_layers, d_h=[[d]] * n_layers, aggr="add",
+                flow="source_to_target", msg_kind=msg_kind, train_eps=[False] * n_layers, activation_mlp="relu", bn_mlp=True,
+                jk_mlp=jk_mlp, degree_embedding="None", degree_as_tag=[False] * n_layers, retain_features=[True] * n_layers,
+                multi_embedding_aggr="sum", input_node_encoder=enc, d_out_node_encoder=d, edge_encoder=enc,
+                d_out_edge_encoder=[d] * n_layers, id_embedding=enc, d_out_id_embedding=d, d_out_degree_embedding=d,
+                extend_dims=True, activation=activation)
+
+
+@pytest.mark.parametrize("model_name,d,msg_kind,id_scope,readout,enc,partition",
+                         [("GSN_edge_sparse", 128, "general", "local", "sum", "one_hot_encoder", True),
+                          ("GSN_edge_sparse", 64, "general", "local", "mean", "embedding", False),
+                          ("GSN_sparse", 64, "gin", "global", "sum", "embedding", True),
+                          ("GSN_sparse", 32, "general", "local", "sum", "one_hot_encoder", False)])
+def test_whole_model_is_independent_of_the_batch_size(model_name, d, msg_kind, id_scope, readout, enc, partition):
+    """Eval-mode prediction of every graph must not depend on which batch it is in: one 2048-graph batch (every kernel on several
+    row tiles per workgroup, per-graph CSR build and pointer-segment readout when the partition is registered) against the same
+    graphs in eight batches of 256 -- the size the reference-generated model goldens pin to the reference.  Three-layer models
+    of config 2's and config 3's kinds; identifiers = real cycle counts from the counting kernel."""
+    import types
+    import networkx as nx
+    from gsn_amd import models, synth
+    from gsn_amd.counting import CountPlan, count_batch
+    G, CH = 2048, 256
+    b = synth.zinc_shape_batch(G, seed=31)
+    edge_ids = id_scope == "local"                            # (local scope: one identifier row per edge, GSN_sparse.py:118)
+    plan = CountPlan.get([list(nx.cycle_graph(k).edges) for k in range(3, 7)], "edge" if edge_ids else "vertex", False)
+    node_ptr, edge_ptr = torch.from_numpy(b.node_ptr).cuda(), torch.from_numpy(b.edge_ptr).cuda()
+    ei = torch.from_numpy(b.edge_index).cuda()
+    ids, st = count_batch(plan, node_ptr, edge_ptr, ei, ids_are_global=True)
+    assert int(st.max()) == 0
+    ids = ids.clamp(max=2)
+    has_ef = "edge" in model_name
+    args = (1, 1, None, [3] * plan.n_cols, 1, [28], [4]) if has_ef else (1, 1, None, [3] * plan.n_cols, None, [28])
+    torch.manual_seed(1)
+    kw = _model_kwargs(model_name, 3, d, msg_kind, id_scope, readout, "relu", True, enc)
+    if not has_ef:
+        kw["edge_encoder"] = "None"
+    model = models.GNNSubstructures(*args, **kw).cuda().eval()
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.uniform_(-0.3, 0.3); m.running_var.uniform_(0.5, 1.5)
+    atom = torch.from_numpy(b.atom_type).unsqueeze(1).cuda()
+    bond = torch.from_numpy(b.bond_type).unsqueeze(1).cuda()
+    batch = torch.from_numpy(np.asarray(b.batch).astype(np.int64)).cuda()
+
+    def run(g0, g1, register):
+        n0, n1, e0, e1 = int(b.node_ptr[g0]), int(b.node_ptr[g1]), int(b.edge_ptr[g0]), int(b.edge_ptr[g1])
+        d_ = types.SimpleNamespace(x=atom[n0:n1], edge_index=(ei[:, e0:e1] - n0).contiguous(), batch=(batch[n0:n1] - g0).contiguous(),
+                                   degrees=torch.zeros(n1 - n0, device="cuda"),
+                                   identifiers=(ids[e0:e1] if edge_ids else ids[n0:n1]).contiguous())
+        if has_ef:
+            d_.edge_features = bond[e0:e1]
+        if register:
+            d_.graph_partition = ((node_ptr[g0:g1 + 1] - n0).contiguous(), (edge_ptr[g0:g1 + 1] - e0).contiguous(),
+                                  int(np.diff(b.node_ptr).max()), int(np.diff(b.edge_ptr).max()))
+        with torch.no_grad():
+            return model(d_)
+    big = run(0, G, partition)
+    small = torch.cat([run(g, g + CH, False) for g in range(0, G, CH)], 0)
+    assert big.shape == small.shape == (G, 1)
+    badg = ((big - small).abs() > 1e-4 * float(small.abs().max())).flatten().nonzero().flatten()
+    assert badg.numel() == 0, "graphs %s ... (%d), first vertex %d" % (badg[:6].tolist(), badg.numel(), int(b.node_ptr[int(badg[0])]))
+    assert rel_err(big, small) < TOL
+    assert bool(((big - small).abs() <= TOL * small.abs() + TOL * float(small.abs().max())).all())
+
+
+def test_row_counts_of_the_inputs_are_checked():
+    """identifiers / edge_features with the wrong number of rows (per vertex instead of per edge, ..) raise as they do in the
+    reference (torch.cat / indexing there) instead of being read past their end by the kernels."""
+    from gsn_amd import layers, synth
+    b = synth.zinc_shape_batch(8, seed=2)
+    N, E = b.num_nodes, b.num_edges
+    ctor, d_x, d_id, d_ef = _case("GSN_edge_sparse", 32, "general")
+    layer = layers.GSN_edge_sparse(**ctor).cuda().eval()
+    x = torch.randn(N, d_x, device="cuda"); ei = torch.from_numpy(b.edge_index).cuda()
+    good = dict(identifiers=torch.randn(E, d_id, device="cuda"), edge_features=torch.randn(E, d_ef, device="cuda"), degrees=torch.zeros(N, device="cuda"))
+    with torch.no_grad():
+        layer(x, ei, **good)
+        with pytest.raises(RuntimeError):
+            layer(x, ei, **dict(good, identifiers=torch.randn(N, d_id, device="cuda")))
+        with pytest.raises(RuntimeError):
+            layer(x, ei, **dict(good, edge_features=torch.randn(E - 1, d_ef, device="cuda")))
+    ctor, d_x, d_id, _ = _case("GSN_sparse", 32, "gin")          # global scope: one row per vertex
+    layer = layers.GSN_sparse(**ctor).cuda().eval()
+    with torch.no_grad():
+        layer(torch.randn(N, d_x, device="cuda"), ei, identifiers=torch.randn(N, d_id, device="cuda"), degrees=torch.zeros(N, device="cuda"))
+        with pytest.raises(RuntimeError):
+            layer(torch.randn(N, d_x, device="cuda"), ei, identifiers=torch.randn(E, d_id, device="cuda"), degrees=torch.zeros(N, device="cuda"))
