@@ -10,4 +10,11 @@ for f in tests/test_*gpu*.py; do
   echo "$f: $r"
   case "$r" in *passed*) ;; *) rc=1 ;; esac
 done
+# the benchmark's launches (headline + supplementary steps; --no-graph: stream capture cannot free memory without the cache) and smoke()
+r=$(timeout 1200 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph 2>&1 | grep -v amdgpu.ids | tail -1 | cut -c1-60)
+echo "bench.py: $r"
+case "$r" in '{"metric"'*) ;; *) rc=1 ;; esac
+r=$(python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1)
+echo "smoke: $r"
+case "$r" in "smoke ok") ;; *) rc=1 ;; esac
 exit $rc
