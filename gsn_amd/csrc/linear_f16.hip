@@ -699,275 +699,6 @@ __global__ __launch_bounds__(D_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
 #undef L16_MF
 }
 
-// ---- n_out <= 128: rows split inside the matrix kernel -------------------------------------------------------------------------------
-// With one column tile every row is used once, so a pre-pass that writes its planes costs more than it saves.  Same tiles, LDS
-// layout, fragment reads and epilogue as linear_f16x3_dma_kernel; the weight lines arrive by LDS-DMA, the rows as fp32 straight
-// from their blocks (8 lanes = one 128-byte line), are scaled, split into planes in registers and written to the swizzled lines.
-// The row scales (largest magnitude over ALL columns of the row) come from a first pass over the tile's rows that the same
-// workgroup makes right before the tile (the rows are read again, from L2, by the K loop).
-template <bool PROF, bool VEC>
-__global__ __launch_bounds__(D_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void linear_f16x3_inline_kernel(L16Args a) {
-    constexpr int NJ = 2;
-    const int dbg = PROF ? a.dbg : 0;
-    extern __shared__ __attribute__((aligned(16))) unsigned l16_lds[];
-    unsigned char *const lds = reinterpret_cast<unsigned char *>(l16_lds);
-    float *const rtabp = reinterpret_cast<float *>(lds + 2 * D_BUF);      // [D_BM] scale | [D_BM] inverse scale of the current tile's rows
-    float *const ecol = rtabp + 2 * D_BM;                                  // [D_BN] scale | [D_BN] constant
-    int *const vtab = reinterpret_cast<int *>(ecol + 2 * D_BN);            // [2][NJ][64] offsets of the 16-byte stores | [2][NJ][32] of the 4-byte ones
-    auto clk = [&]() -> unsigned long long {
-        if (!PROF) return 0ull;
-        __builtin_amdgcn_sched_barrier(0);
-        const unsigned long long v = __builtin_amdgcn_s_memtime();
-        __builtin_amdgcn_sched_barrier(0);
-        return v;
-    };
-    unsigned long long pq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int li = lane & 31, lh = lane >> 5;
-    const int xcd = blockIdx.x & 7, slot_in_xcd = blockIdx.x >> 3;
-    const int ct = slot_in_xcd % a.col_tiles, grp = slot_in_xcd / a.col_tiles;
-    const int n0 = ct * D_BN;
-    const int64_t n_tiles = (a.m_rows + D_BM - 1) / D_BM;
-    const int64_t tile0 = (int64_t)xcd * a.groups + grp, tstride = 8 * (int64_t)a.groups;
-    const int64_t n_mine = tile0 < n_tiles ? (n_tiles - tile0 + tstride - 1) / tstride : 0;
-    const int n_slices = a.k_pad / L_BK;
-    const int row_bytes = n_slices * L_LINE;
-    const int rstride = a.n_out * 4;
-
-    for (int cidx = tid; cidx < D_BN; cidx += D_NT) {
-        const int col = n0 + cidx;
-        const bool cok = col < a.n_out;
-        const float e_bias = (cok && a.bias) ? a.bias[col] : 0.f;
-        float es = cok ? a.colinv[col] : 0.f, ec = e_bias;
-        if (cok && a.bn_scale) { ec = (e_bias - a.bn_mean[col]) * a.bn_scale[col] + a.bn_shift[col]; es *= a.bn_scale[col]; }
-        ecol[cidx] = es; ecol[D_BN + cidx] = ec;
-    }
-    for (int q = tid; q < 2 * NJ * 64; q += D_NT) {
-        const int l = q & 63, k = (q >> 6) % NJ, w = q / (64 * NJ);
-        const int idx = 64 * k + l, c4 = idx % (8 * NJ), col = n0 + w * 32 * NJ + 4 * c4;
-        vtab[q] = col < a.n_out ? ((idx / (8 * NJ)) - (64 * k) / (8 * NJ)) * rstride + col * 4 : 0x7f000000;
-    }
-    for (int q = tid; q < 2 * NJ * 32; q += D_NT) {
-        const int l = q & 31, j = (q >> 5) % NJ, w = q / (32 * NJ);
-        const int col = n0 + w * 32 * NJ + 32 * j + l;
-        vtab[2 * NJ * 64 + q] = col < a.n_out ? col * 4 : 0x7f000000;
-    }
-    // staging: wave w moves rows (output columns) 32 w + 8 i .. + 7 with instruction i; lane -> row 8 i + (lane >> 3) and
-    //   weights: slot lane & 7 = piece (lane & 7) ^ swizzle(row) of the row's line, by LDS-DMA;
-    //   rows:    columns 4 (lane & 7) .. + 3 of the slice as fp32 from their block (8 lanes = one 128-byte line), scaled by the
-    //            row's power of two, split into two fp16 planes in registers and written to the swizzled line in LDS.
-    const int s_r8 = lane >> 3, s_q = lane & 7;
-    unsigned wofs[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = 32 * wave + 8 * i + s_r8;
-        int j = n0 + r;
-        j = j < a.n_out ? j : 0;
-        wofs[i] = (unsigned)j * (unsigned)row_bytes + 16u * (unsigned)(s_q ^ ((r >> 1) & 7));
-    }
-    typedef const __attribute__((address_space(1))) void *gptr_t;
-    typedef __attribute__((address_space(3))) void *lptr_t;
-    auto fetch_w = [&](int c, int buf) {
-        unsigned char *const dw = lds + buf * D_BUF + (D_BM + 32 * wave) * L_LINE;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(a.wplanes + wofs[i] + c * L_LINE), (lptr_t)(dw + 8 * i * L_LINE), 16, 0, 0);
-    };
-    int64_t arow[4];                                                       // this thread's rows of the current tile (clamped to the last row)
-    auto set_rows = [&](int64_t row0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int64_t r = row0 + 32 * wave + 8 * i + s_r8;
-            arow[i] = r < a.m_rows ? r : a.m_rows - 1;
-        }
-    };
-    float4 pa[4];                                                          // the slice of rows in flight
-    auto fetch_a = [&](int c) {
-        const int kg = c * L_BK + 4 * s_q;
-        const L16Col cm = l16_col(a, kg);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) pa[i] = *reinterpret_cast<const float4 *>(cm.base + arow[i] * cm.bw);
-    };
-    auto stage_a = [&](int c, int buf) {
-        const bool real = c * L_BK + 4 * s_q < a.k_total;                  // (columns past K: zero)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = 32 * wave + 8 * i + s_r8;
-            const float sc = real ? rtabp[r] : 0.f;
-            unsigned h0, l0, h1, l1;
-            l16_split2(fl2{pa[i].x * sc, pa[i].y * sc}, h0, l0);
-            l16_split2(fl2{pa[i].z * sc, pa[i].w * sc}, h1, l1);
-            // columns 4 q .. 4 q + 3 = half (q & 1) of piece q >> 1 of the high plane, of piece 4 + (q >> 1) of the low plane
-            unsigned char *const rowp = lds + buf * D_BUF + r * L_LINE + 8 * (s_q & 1);
-            const int sw = (r >> 1) & 7;
-            *reinterpret_cast<un2 *>(rowp + 16 * ((s_q >> 1) ^ sw)) = un2{h0, h1};
-            *reinterpret_cast<un2 *>(rowp + 16 * ((4 + (s_q >> 1)) ^ sw)) = un2{l0, l1};
-        }
-    };
-    // largest magnitude of every row of the tile over all its columns -> scale, inverse scale (a row with an Inf / NaN: inverse NaN)
-    auto row_scales = [&]() {
-        unsigned mx[4] = {0u, 0u, 0u, 0u};
-#pragma unroll 3
-        for (int c = 0; c < n_slices; ++c) {
-            const int kg = c * L_BK + 4 * s_q;
-            if (kg < a.k_total) {
-                const L16Col cm = l16_col(a, kg);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float4 v = *reinterpret_cast<const float4 *>(cm.base + arow[i] * cm.bw);
-                    mx[i] = max(max(mx[i], __float_as_uint(v.x) & 0x7fffffffu), __float_as_uint(v.y) & 0x7fffffffu);
-                    mx[i] = max(max(mx[i], __float_as_uint(v.z) & 0x7fffffffu), __float_as_uint(v.w) & 0x7fffffffu);
-                }
-            }
-        }
-        l16_barrier();                                                     // (every wave has left the previous tile's epilogue, which reads the table)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            unsigned m = mx[i];
-            m = max(m, (unsigned)__shfl_xor((int)m, 1));
-            m = max(m, (unsigned)__shfl_xor((int)m, 2));
-            m = max(m, (unsigned)__shfl_xor((int)m, 4));
-            float sc, inv;
-            l16_scale(m, sc, inv);
-            if (m >= 0x7f800000u) inv = __uint_as_float(0x7fc00000u);
-            if (s_q == 0) { const int r = 32 * wave + 8 * i + s_r8; rtabp[r] = sc; rtabp[D_BM + r] = inv; }
-        }
-    };
-    // fragment reads: piece 4 plane + 2 s + lh of row (.. + li): slot = piece ^ ((li >> 1) & 7) (the tile offsets of a row are multiples of 16)
-    const int swz = (li >> 1) & 7;
-    int fo[2][2];                                                           // [plane][k-step] byte offset inside the row
-#pragma unroll
-    for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-        for (int st = 0; st < 2; ++st) fo[pl][st] = 16 * ((4 * pl + 2 * st + lh) ^ swz);
-    f32x16 acc[2][NJ];
-#define L16_MF(acc, x, y) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, x), __builtin_bit_cast(h16x8, y), acc, 0, 0, 0)
-    auto products = [&](int buf) {
-        const unsigned char *ap = lds + buf * D_BUF + (wm * 64 + li) * L_LINE, *bp = lds + buf * D_BUF + (D_BM + wn * 32 * NJ + li) * L_LINE;
-#pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            un4 ah[2], al[2], bh[NJ], bl[NJ];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                ah[i] = *reinterpret_cast<const un4 *>(ap + i * (32 * L_LINE) + fo[0][st]);
-                al[i] = *reinterpret_cast<const un4 *>(ap + i * (32 * L_LINE) + fo[1][st]);
-            }
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                bh[j] = *reinterpret_cast<const un4 *>(bp + j * (32 * L_LINE) + fo[0][st]);
-                bl[j] = *reinterpret_cast<const un4 *>(bp + j * (32 * L_LINE) + fo[1][st]);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) L16_MF(acc[i][j], al[i], bh[j]);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) L16_MF(acc[i][j], ah[i], bl[j]);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) L16_MF(acc[i][j], ah[i], bh[j]);
-        }
-    };
-    if (n_mine > 0) {
-        int buf = 0;
-        fetch_w(0, 0);
-        for (int64_t ti = 0; ti < n_mine; ++ti) {
-            const int64_t row0 = (tile0 + ti * tstride) * D_BM;
-            set_rows(row0);
-            row_scales();
-            fetch_a(0);
-            l16_barrier();                                                 // the scales are in LDS
-            stage_a(0, buf);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-            for (int c = 0; c < n_slices; ++c) {
-                const unsigned long long q0 = clk();
-                // slice c is in LDS: the weights by DMA (this wave's share has landed; the barrier makes that true for all), the rows by
-                // the ds_writes before the barrier; nobody reads the other buffer any more
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                l16_barrier();
-                const unsigned long long q1 = clk();
-                const bool more = c + 1 < n_slices;
-                if (!(dbg & 4)) {
-                    if (more) fetch_a(c + 1);
-                    fetch_w(more ? c + 1 : 0, buf ^ 1);                    // (after the last slice: slice 0 of the next tile -- of this one again when there is none)
-                }
-                const unsigned long long q2 = clk();
-                if (!(dbg & 2)) products(buf);
-                const unsigned long long q3 = clk();
-                if (more && !(dbg & 8)) stage_a(c + 1, buf ^ 1);
-                buf ^= 1;
-                if (PROF) { const unsigned long long q4 = clk(); pq[0] += q2 - q1; pq[1] += q3 - q2; pq[2] += q4 - q3; pq[3] += q1 - q0; pq[5] += 1; }
-            }
-            const unsigned long long qe0 = clk();
-            l16_barrier();                                                 // every wave is done with the last slice's buffer: its ROW part is the epilogue's scratch
-            const int64_t rows_left = a.m_rows - row0;
-            const int nrows = rows_left < D_BM ? (int)rows_left : D_BM;
-            const __amdgpu_buffer_rsrc_t orow = __builtin_amdgcn_make_buffer_rsrc(a.out + row0 * a.n_out, 0, nrows * rstride, 0x00020000);
-            const float act_lo = a.act == 1 ? 0.f : -INFINITY;
-            constexpr int SP = 32 * NJ * 4 + 16;
-            unsigned char *const scr = lds + (buf ^ 1) * D_BUF + wave * (8 * SP);   // (the weight part of that buffer holds the next tile's slice 0)
-            const float *const rt = rtabp + D_BM;
-            float es[NJ], ec[NJ];
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) { es[j] = ecol[wn * 32 * NJ + 32 * j + li]; ec[j] = ecol[D_BN + wn * 32 * NJ + 32 * j + li]; }
-            auto emit = [&](auto simple) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-#pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) {
-                        const int rl = wm * 64 + i * 32 + 8 * gq;
-                        const float ivv[4] = {rt[rl + 4 * lh], rt[rl + 4 * lh + 1], rt[rl + 4 * lh + 2], rt[rl + 4 * lh + 3]};
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-#pragma unroll
-                            for (int j = 0; j < NJ; ++j) {
-                                float y = fmaf(acc[i][j][4 * gq + r], ivv[r] * es[j], ec[j]);
-                                if (decltype(simple)::value) y = y < act_lo ? act_lo : y;       // (a NaN stays a NaN)
-                                else y = l16_act_slow(y, a.act);
-                                *reinterpret_cast<float *>(scr + (r + 4 * lh) * SP + (li + 32 * j) * 4) = y;
-                            }
-                        if ((dbg & 1) && acc[i][0][4 * gq] != 12345.f) continue;
-                        if (VEC) {
-#pragma unroll
-                            for (int k = 0; k < NJ; ++k) {
-                                const int idx = 64 * k + lane, row = idx / (8 * NJ), c4 = idx % (8 * NJ);
-                                const un4 v = *reinterpret_cast<const un4 *>(scr + row * SP + 16 * c4);
-                                // (row offset in the vector offset, s_nop behind the store: see linear_f16x3_planes_kernel)
-                                __builtin_amdgcn_raw_buffer_store_b128(v, orow, vtab[(wn * NJ + k) * 64 + lane] + (rl + (64 * k) / (8 * NJ)) * rstride, 0, 0);
-                                asm volatile("s_nop 1" ::: "memory");
-                            }
-                        } else {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                                for (int j = 0; j < NJ; ++j) {
-                                    const unsigned y = *reinterpret_cast<const unsigned *>(scr + (r + 4 * lh) * SP + (li + 32 * j) * 4);
-                                    __builtin_amdgcn_raw_buffer_store_b32(y, orow, vtab[2 * NJ * 64 + (wn * NJ + j) * 32 + li] + (rl + r + 4 * lh) * rstride, 0, 0);
-                                }
-                        }
-                    }
-                }
-            };
-            if (a.act <= 1) emit(std::true_type{});
-            else emit(std::false_type{});
-            if (PROF) { pq[4] += clk() - qe0; pq[6] += 1; }
-        }
-    }
-    if (PROF && a.prof && blockIdx.x == 0 && tid == 0)
-        for (int q = 0; q < 8; ++q) a.prof[q] = pq[q];
-#undef L16_MF
-}
-
 }  // namespace
 
 }  // namespace gsn
@@ -1001,12 +732,12 @@ extern "C" int gsn_linear_f16x3_prepare_hip(const float *W, int64_t n_out, int64
 extern "C" int gsn_linear_f16x3_fwd_hip(int64_t m_rows, int n_blocks, const gsn_block *blocks, const void *planes, const float *col_inv,
                                         const float *bias, int64_t n_out, const float *bn_mean, const float *bn_scale, const float *bn_shift,
                                         int act, float *row_scratch, float *out, void *stream) {
-    if (n_blocks < 1 || n_blocks > L_MAXB || !blocks || !planes || !col_inv || (!row_scratch && n_out > D_BN) || !out || n_out <= 0)
-        return set_error(GSN_E_INVALID, "gsn_linear_f16x3_fwd_hip: need 1..%d input blocks, the weight planes, scratch (n_out > 128) and out", L_MAXB);
+    if (n_blocks < 1 || n_blocks > L_MAXB || !blocks || !planes || !col_inv || !row_scratch || !out || n_out <= 0)
+        return set_error(GSN_E_INVALID, "gsn_linear_f16x3_fwd_hip: need 1..%d input blocks, the weight planes, scratch and out", L_MAXB);
     if ((bn_scale != nullptr) != (bn_shift != nullptr) || (bn_scale != nullptr) != (bn_mean != nullptr))
         return set_error(GSN_E_INVALID, "gsn_linear_f16x3_fwd_hip: bn_mean, bn_scale and bn_shift go together");
     if (act < 0 || act > 3) return set_error(GSN_E_INVALID, "gsn_linear_f16x3_fwd_hip: act must be 0..3");
-    if (row_scratch && (reinterpret_cast<uintptr_t>(row_scratch) & 15) != 0) return set_error(GSN_E_INVALID, "gsn_linear_f16x3_fwd_hip: row_scratch must be 16-byte aligned");
+    if ((reinterpret_cast<uintptr_t>(row_scratch) & 15) != 0) return set_error(GSN_E_INVALID, "gsn_linear_f16x3_fwd_hip: row_scratch must be 16-byte aligned");
     if (m_rows <= 0) return GSN_OK;
     L16Args a{};
     a.m_rows = m_rows; a.n_blocks = n_blocks;
@@ -1034,9 +765,7 @@ extern "C" int gsn_linear_f16x3_fwd_hip(int64_t m_rows, int n_blocks, const gsn_
     a.m_pad = (m_rows + 255) / 256 * 256;
     a.rowinv = row_scratch;
     a.aplanes = reinterpret_cast<unsigned char *>(row_scratch + a.m_pad);
-    static const bool no_inline = getenv("GSN_L16_NOINLINE") != nullptr;   // (A/B)
-    const bool inline_split = n_out <= D_BN && !no_inline;                 // one column tile: the rows are split inside the matrix kernel
-    if (!inline_split) hipLaunchKernelGGL(lin16_split_rows_kernel, dim3((unsigned)(a.m_pad / 32)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(lin16_split_rows_kernel, dim3((unsigned)(a.m_pad / 32)), dim3(256), 0, st, a);
     // 128 x 128 tiles, two workgroups of 4 waves per CU (256 x 256 tiles with 8 waves measured 3-5 % slower: no registers left
     // for the second set of loads in flight)
     const int wm = 2, nj = 2;
@@ -1059,7 +788,7 @@ extern "C" int gsn_linear_f16x3_fwd_hip(int64_t m_rows, int n_blocks, const gsn_
                 groups, col_tiles);
     const dim3 grid((unsigned)(8 * groups * col_tiles));
     const bool vec = n_out % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && !getenv("GSN_L16_NOVEC");      // 16-byte output stores
-    static DeviceOnce attr_set[9];
+    static DeviceOnce attr_set[6];
     const int attr_dev = current_device();
     hipError_t e0 = hipSuccess;
     auto launch = [&](auto kern, int which) {
@@ -1071,12 +800,7 @@ extern "C" int gsn_linear_f16x3_fwd_hip(int64_t m_rows, int n_blocks, const gsn_
         hipLaunchKernelGGL(kern, grid, dim3(128 * wm), lds, st, a);
     };
     static const bool reg_stage = getenv("GSN_L16_REGSTAGE") != nullptr;  // (A/B: slices staged through registers)
-    if (inline_split) {
-        lds = (size_t)2 * D_BUF + 4 * (2 * D_BM + 2 * D_BN) + 4 * (2 * 2 * 64 + 2 * 2 * 32);
-        if (want_prof || a.dbg) launch(linear_f16x3_inline_kernel<true, true>, 6);
-        else if (!vec) launch(linear_f16x3_inline_kernel<false, false>, 7);
-        else launch(linear_f16x3_inline_kernel<false, true>, 8);
-    } else if (reg_stage) {
+    if (reg_stage) {
         if (want_prof || a.dbg) launch(linear_f16x3_planes_kernel<2, 2, true, true>, 0);       // diagnostic build
         else if (!vec) launch(linear_f16x3_planes_kernel<2, 2, false, false>, 1);
         else launch(linear_f16x3_planes_kernel<2, 2, false, true>, 2);
