@@ -504,7 +504,7 @@ def main():
         try:
             import csv
             pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_bench_pmc.csv")
-            key = {"layer_fused": "gsn::layer_fused", "mlp_chain": "gsn::mlp_chain"}.get(dom, roof["kernel"])
+            key = {"layer_fused": "gsn::layer_fused_kernel", "mlp_chain": "gsn::mlp_chain"}.get(dom, roof["kernel"])   # (not layer_fused_prepare_kernel)
             rows = [r for r in csv.DictReader(open(pmc)) if key in r["kernel"]]
             if rows and G == 65536:
                 tot = sum((2.0 * float(r["FETCH_SIZE_per_dispatch"]) + float(r["WRITE_SIZE_per_dispatch"])) * 1024.0 for r in rows)
