@@ -309,6 +309,8 @@ def global_add_pool_sparse(x, batch, num_graphs=None):
     ``batch`` tensor, so repeated readouts of one batch (every layer of a jumping-knowledge model) build its CSR once."""
     _need_cuda(x, "x")
     n_rows = x.shape[0]
+    if batch.numel() != n_rows:
+        raise RuntimeError("global_add_pool_sparse: %d rows but %d batch entries" % (n_rows, batch.numel()))
     g = int(batch.max().item()) + 1 if num_graphs is None else int(num_graphs)
     key = (id(batch), "pool", n_rows)
     ei = _cache_get(key, batch)
