@@ -480,7 +480,10 @@ extern "C" int gsn_mlp_chain_fwd_hip(int64_t m_rows, int n_stages, const gsn_cha
     // LDS row pitch: the staging writes cover whole 32-column groups of stage 0; a later stage's input tile holds the
     // previous stage's n_out columns; the segmented-sum epilogue stages n_out_last columns.  +1 / odd: conflict-free.
     int cols = (maxch * CHK + 31) / 32 * 32;
-    for (int s = 1; s < n_stages; ++s) cols = a.st[s].k_total > cols ? a.st[s].k_total : cols;
+    for (int s = 1; s < n_stages; ++s) {                       // (whole CHK-column chunks are read: see chain_pipe.hip)
+        const int kp = (a.st[s].k_total + CHK - 1) / CHK * CHK;
+        cols = kp > cols ? kp : cols;
+    }
     if (a.seg_target && a.st[n_stages - 1].n_out > cols) cols = a.st[n_stages - 1].n_out;
     a.pitch = cols | 1;
     if (a.pitch == cols) a.pitch += 2;

@@ -248,8 +248,11 @@ int launch_chain2_pipe(const ChainArgs &a, int maxch, hipStream_t st) {
     if (a.n_stages != 2 || a.stats || a.seg_target) return 1;
     { const char *d = getenv("GSN_CHAIN_PIPE"); if (d && atoi(d) == 0) return 1; }
     const int pin = ((maxch * CHK + 31) / 32 * 32) | 1;
-    int pmid = a.st[1].k_total | 1;
-    if (pmid == a.st[1].k_total) pmid += 2;
+    // (the matrix loop reads whole CHK-column chunks: a pitch below the padded width lets the last row of a tile read past the
+    //  tile -- into the row-source table behind the second MID tile, whose -1 entries are NaNs as floats: NaN x 0 weights)
+    const int k1_pad = (a.st[1].k_total + CHK - 1) / CHK * CHK;
+    int pmid = k1_pad | 1;
+    if (pmid == k1_pad) pmid += 2;
     const size_t lds = ((size_t)2 * CBM * pin + (size_t)2 * CBM * pmid + (size_t)3 * RS_STRIDE) * 4;
     if (lds > 160 * 1024) return 1;
     if (maxch == 5) return launch_pipe_impl<5, 8>(a, pin, pmid, lds, st);

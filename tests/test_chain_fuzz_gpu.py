@@ -13,7 +13,7 @@ def rel_err(a, b, floor=1e-30):
     return (a - b).abs().max().item() / max(b.abs().max().item(), floor)
 
 
-def _case(rng, dev):
+def _case(rng, dev, large=False):
     from gsn_amd.layers import _Stage, _launch_stages, _chain_fits, run_stages, _csr_for
     two = rng.random() < 0.5
     seg = (not two) and rng.random() < 0.6
@@ -40,9 +40,12 @@ def _case(rng, dev):
     act = "relu" if rng.random() < 0.7 else "identity"
     if seg:
         N = int(rng.integers(3, 400)); E = int(rng.integers(1, 3000))
+        if large:
+            N = int(rng.integers(5000, 30000)); E = int(rng.integers(30000, 90000))
         tgt = torch.from_numpy(rng.integers(0, N, E)).to(dev); src = torch.from_numpy(rng.integers(0, N, E)).to(dev)
         if rng.random() < 0.3:
-            tgt[: E // 3] = int(rng.integers(0, N))                       # a long segment (atomics across ranges)
+            tgt[: min(E // 3, 2000)] = int(rng.integers(0, N))            # a long segment (atomics across ranges; an fp32 sum of
+                                                                          # more terms than that leaves the 1e-5 bar by rounding alone)
         ei = torch.stack([src, tgt], 0)
         csr = _csr_for(ei, 1, N)
         blocks, cols = [], []
@@ -66,6 +69,8 @@ def _case(rng, dev):
         out = run_stages([st], E, False, csr=csr)
         return out, ref, ("seg", widths, n1, E, N)
     M = int(rng.choice([1, 31, 32, 33, 63, 64, 65, 500, 2047, 4100]))
+    if large:
+        M = int(rng.choice([20000, 33000, 50001, 70000]))
     gathered = rng.random() < 0.4
     blocks, cols = [], []
     for i, w in enumerate(widths):
@@ -90,6 +95,20 @@ def _case(rng, dev):
         stages.append(st); k = n_out
     assert _chain_fits(stages)
     return _launch_stages(stages, M), ref, ("chain", widths, hidden, M, gathered)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_chain_shapes_over_many_row_tiles_vs_fp64(seed):
+    """The same random shapes with 20-90 k rows: every persistent workgroup walks several row tiles (the small cases above
+    never leave a workgroup's first tile)."""
+    rng = np.random.default_rng(7000 + seed)
+    dev = torch.device("cuda")
+    for _ in range(14):
+        out, ref, what = _case(rng, dev, large=True)
+        assert out.shape == ref.shape, what
+        assert rel_err(out.double(), ref) < TOL, what
+        err = (out.double() - ref).abs()
+        assert not bool((err > 1e-4 * ref.abs().max()).any()), what
 
 
 @pytest.mark.parametrize("seed", range(6))
