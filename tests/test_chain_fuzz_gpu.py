@@ -186,3 +186,51 @@ def test_narrow_stages_over_many_row_tiles(m, k, widths):
     err = (y.double() - ref).abs()
     bad = err > 1e-5 * ref.abs().max()
     assert not bool(bad.any()), "rows %s" % bad.any(1).nonzero().flatten()[:8].tolist()
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_random_wide_linear_shapes_over_many_row_tiles_vs_fp64(seed):
+    """gsn_linear_fwd_hip / gsn_linear_f16x3_fwd_hip (layers._linear_hip: the stages too wide for the chain kernels) with random
+    block lists (direct and gathered rows), K 164-700, n_out 40-600, 20-70 k rows, with and without the train-mode column sums:
+    output and fp64 column sums / sums of squares against fp64."""
+    from gsn_amd import layers
+    rng = np.random.default_rng(9000 + seed)
+    dev = torch.device("cuda")
+    for _ in range(8):
+        M = int(rng.choice([20000, 33001, 50001, 70000]))
+        n_blocks = int(rng.integers(1, 5))
+        K = int(rng.integers(41, 176)) * 4
+        cuts = sorted(set(int(c) * 4 for c in rng.integers(1, K // 4, n_blocks - 1))) if n_blocks > 1 else []
+        widths = [b - a for a, b in zip([0] + cuts, cuts + [K])]
+        N = int(rng.choice([40, 128, 132, 300, 600]))
+        gathered = rng.random() < 0.5
+        blocks, cols = [], []
+        for i, w in enumerate(widths):
+            if gathered and i % 2 == 0:
+                d = torch.randn(997, w, device=dev)
+                idx = torch.from_numpy(rng.integers(0, 997, M)).to(dev).to(torch.int32 if i % 4 == 0 else torch.int64)
+                blocks.append((d, idx)); cols.append(d[idx.long()])
+            else:
+                d = torch.randn(M, w, device=dev); blocks.append((d, None)); cols.append(d)
+        x = torch.cat(cols, 1).double()
+        W = torch.randn(N, K, device=dev) / K ** 0.5
+        b = torch.randn(N, device=dev)
+        act = int(rng.integers(0, 2))
+        want_stats = rng.random() < 0.4
+        what = (M, widths, N, gathered, act, want_stats)
+        if want_stats:                                  # train-mode first pass: pre-activation rows + their column sums
+            stats = torch.zeros(2 * N, dtype=torch.float64, device=dev)
+            y = layers._linear_hip(blocks, W, b, None, None, None, 0, M, stats=stats)
+            ref = x @ W.double().T + b.double()
+            s_ref = torch.cat([ref.sum(0), (ref * ref).sum(0)])
+            # (the kernel sums its rounded fp32 outputs in fp64: against the exact sums the error is a random walk of M roundings,
+            #  to be measured against the column's mass, not against a first moment that may cancel to ~0)
+            mass = torch.cat([ref.abs().sum(0), (ref * ref).sum(0)])
+            assert float(((stats - s_ref).abs() / mass).max()) < 1e-6, what
+        else:
+            y = layers._linear_hip(blocks, W, b, None, None, None, act, M)
+            ref = x @ W.double().T + b.double()
+            if act == 1:
+                ref = torch.relu(ref)
+        err = (y.double() - ref).abs()
+        assert not bool((torch.isnan(err) | (err > 1e-5 * ref.abs().max())).any()), what
