@@ -55,9 +55,19 @@ def _make(case, seed):
 @pytest.mark.parametrize("train", [False, True], ids=["eval", "train"])
 @pytest.mark.parametrize("case", CASES, ids=["%s-%s-%d-%s" % (c[0], c[1], c[5], c[6]) for c in CASES])
 def test_codes_equal_dense(case, train):
+    _codes_equal_dense(case, train, 40)
+
+
+@pytest.mark.parametrize("case", CASES, ids=["%s-%s-%d-%s" % (c[0], c[1], c[5], c[6]) for c in CASES])
+def test_codes_equal_dense_on_many_row_tiles(case):
+    """The same on 2048 graphs (97 k edge rows: several row tiles per persistent workgroup of the weight-row-gather stage)."""
+    _codes_equal_dense(case, False, 2048)
+
+
+def _codes_equal_dense(case, train, n_graphs):
     cls, scope, xc, ic, ec, d, act, bn, flow = case
     rng = np.random.default_rng(3)
-    ei, n = _graph(40, 5)
+    ei, n = _graph(n_graphs, 5)
     E = ei.shape[1]
     layer = _make(case, 1)
     layer.train(train)
