@@ -49,7 +49,7 @@ def test_encode_without_encoders_keeps_data(gold):
     assert all(torch.equal(a.identifiers, b) for a, b in zip(graphs, before))
 
 
-@pytest.mark.parametrize("shape", [(1, 1), (5, 3), (4097, 7), (70000, 2)])
+@pytest.mark.parametrize("shape", [(1, 1), (5, 3), (4097, 7), (70000, 2), (3000001, 4)])
 def test_unique_codes_random(shape):
     rng = np.random.default_rng(shape[0])
     vals = rng.integers(-5, [3 + 40 * c * c for c in range(shape[1])], size=shape)
