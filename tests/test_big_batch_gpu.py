@@ -250,3 +250,57 @@ def test_row_counts_of_the_inputs_are_checked():
         layer(torch.randn(N, d_x, device="cuda"), ei, identifiers=torch.randn(N, d_id, device="cuda"), degrees=torch.zeros(N, device="cuda"))
         with pytest.raises(RuntimeError):
             layer(torch.randn(N, d_x, device="cuda"), ei, identifiers=torch.randn(E, d_id, device="cuda"), degrees=torch.zeros(N, device="cuda"))
+
+
+@pytest.mark.parametrize("vn,residual,d", [(True, False, 300), (True, True, 64), (False, False, 96)])
+def test_ogb_model_is_independent_of_the_batch_size(vn, residual, d):
+    """The virtual-node model of BASELINE config 4 (models_graph_classification_ogb_original.py; GSN_edge_sparse_ogb layers,
+    embedding encoders of several feature columns, per-layer virtual-node pooling, mean readout), eval mode: 2048 graphs in one
+    batch against eight batches of 256 (the reference-generated fixture is one small batch)."""
+    import types
+    import networkx as nx
+    from gsn_amd import models, synth
+    from gsn_amd.counting import CountPlan, count_batch
+    G, CH, L = 2048, 256, 3
+    b = synth.zinc_shape_batch(G, seed=33)
+    plan = CountPlan.get([list(nx.cycle_graph(k).edges) for k in range(3, 7)], "edge", False)
+    node_ptr, edge_ptr = torch.from_numpy(b.node_ptr).cuda(), torch.from_numpy(b.edge_ptr).cuda()
+    ei = torch.from_numpy(b.edge_index).cuda()
+    ids, st = count_batch(plan, node_ptr, edge_ptr, ei, ids_are_global=True)
+    assert int(st.max()) == 0
+    ids = ids.clamp(max=2)
+    atom_dims, bond_dims, id_dims = [28, 3, 4], [4, 2], [3] * plan.n_cols
+    kw = dict(seed=0, model_name="GSN_edge_sparse_ogb", readout="mean", dropout_features=[0.0] * (L + 1), bn=[True] * L,
+              final_projection=[False] * L + [True], residual=residual, inject_ids=True, vn=vn, id_scope="local",
+              d_msg=[d] * L, d_out=[d] * L, d_h=[[2 * d]] * L, aggr="add", flow="source_to_target", msg_kind="ogb",
+              train_eps=[True] * L, activation_mlp="relu", bn_mlp=True, jk_mlp=False, degree_embedding="None",
+              degree_as_tag=[False] * L, retain_features=[True] * L, multi_embedding_aggr="sum", features_scope="full",
+              input_node_encoder="embedding", d_out_node_encoder=d, input_vn_encoder="embedding", d_out_vn_encoder=d,
+              edge_encoder="embedding", d_out_edge_encoder=[d] * L, id_embedding="embedding", d_out_id_embedding=d,
+              d_out_degree_embedding=d, d_out_vn=[d] * (L - 1), vn_pooling="sum", extend_dims=True, activation="relu")
+    torch.manual_seed(2)
+    model = models.GNN_OGB(3, 2, None, id_dims, 2, atom_dims, bond_dims, None, None, **kw).cuda().eval()
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.uniform_(-0.3, 0.3); m.running_var.uniform_(0.5, 1.5)
+    g = torch.Generator().manual_seed(4)
+    atom = torch.stack([torch.from_numpy(b.atom_type)] + [torch.randint(0, n, (b.num_nodes,), generator=g) for n in atom_dims[1:]], 1).cuda()
+    bond = torch.stack([torch.from_numpy(b.bond_type)] + [torch.randint(0, n, (b.num_edges,), generator=g) for n in bond_dims[1:]], 1).cuda()
+    batch = torch.from_numpy(np.asarray(b.batch).astype(np.int64)).cuda()
+
+    def run(g0, g1, register):
+        n0, n1, e0, e1 = int(b.node_ptr[g0]), int(b.node_ptr[g1]), int(b.edge_ptr[g0]), int(b.edge_ptr[g1])
+        d_ = types.SimpleNamespace(x=atom[n0:n1], edge_index=(ei[:, e0:e1] - n0).contiguous(), batch=(batch[n0:n1] - g0).contiguous(),
+                                   degrees=torch.zeros(n1 - n0, device="cuda"), identifiers=ids[e0:e1].contiguous(), edge_features=bond[e0:e1],
+                                   num_graphs=g1 - g0)
+        if register:
+            d_.graph_partition = ((node_ptr[g0:g1 + 1] - n0).contiguous(), (edge_ptr[g0:g1 + 1] - e0).contiguous(),
+                                  int(np.diff(b.node_ptr).max()), int(np.diff(b.edge_ptr).max()))
+        with torch.no_grad():
+            return model(d_)
+    big = run(0, G, True)
+    small = torch.cat([run(g_, g_ + CH, False) for g_ in range(0, G, CH)], 0)
+    assert big.shape == small.shape == (G, 2)
+    badg = ((big - small).abs() > 1e-4 * float(small.abs().max())).any(1).nonzero().flatten()
+    assert badg.numel() == 0, "graphs %s ... (%d)" % (badg[:6].tolist(), badg.numel())
+    assert rel_err(big, small) < 2e-5
