@@ -549,15 +549,19 @@ __global__ __launch_bounds__(D_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
     auto tile_base = [&](int64_t row0) { return a.aplanes + (row0 < a.m_rows ? row0 : 0) * row_bytes; };
     typedef const __attribute__((address_space(1))) void *gptr_t;
     typedef __attribute__((address_space(3))) void *lptr_t;
-    auto fetch = [&](const unsigned char *abase, const unsigned *aofs, int c, int buf) {
-        unsigned char *const da = lds + buf * D_BUF + (32 * wave) * L_LINE, *const dw = da + D_BM * L_LINE;
+    auto fetch_rows = [&](const unsigned char *abase, const unsigned *aofs, int c, int buf) {
+        unsigned char *const da = lds + buf * D_BUF + (32 * wave) * L_LINE;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             __builtin_amdgcn_global_load_lds((gptr_t)(abase + aofs[i] + c * L_LINE), (lptr_t)(da + 8 * i * L_LINE), 16, 0, 0);
+    };
+    auto fetch_weights = [&](int c, int buf) {
+        unsigned char *const dw = lds + buf * D_BUF + (D_BM + 32 * wave) * L_LINE;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             __builtin_amdgcn_global_load_lds((gptr_t)(a.wplanes + wofs[i] + c * L_LINE), (lptr_t)(dw + 8 * i * L_LINE), 16, 0, 0);
     };
+    auto fetch = [&](const unsigned char *abase, const unsigned *aofs, int c, int buf) { fetch_rows(abase, aofs, c, buf); fetch_weights(c, buf); };
     // fragment reads: piece 4 plane + 2 s + lh of row (.. + li): slot = piece ^ ((li >> 1) & 7) (the tile offsets of a row are multiples of 16)
     const int swz = (li >> 1) & 7;
     int fo[2][2];                                                           // [plane][k-step] byte offset inside the row
@@ -567,10 +571,11 @@ __global__ __launch_bounds__(D_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
         for (int st = 0; st < 2; ++st) fo[pl][st] = 16 * ((4 * pl + 2 * st + lh) ^ swz);
     f32x16 acc[2][NJ];
 #define L16_MF(acc, x, y) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, x), __builtin_bit_cast(h16x8, y), acc, 0, 0, 0)
-    auto products = [&](int buf) {
+    auto products = [&](int buf, auto between) {
         const unsigned char *ap = lds + buf * D_BUF + (wm * 64 + li) * L_LINE, *bp = lds + buf * D_BUF + (D_BM + wn * 32 * NJ + li) * L_LINE;
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
+            if (st == 1) between();
             un4 ah[2], al[2], bh[NJ], bl[NJ];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -629,9 +634,15 @@ __global__ __launch_bounds__(D_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
                 if (c == 1 && tid < D_BM) rtabp[(slot ^ 1) * D_BM + tid] = rt_next;
                 const unsigned long long q1 = clk();
                 const bool wrap = c + 1 >= n_slices;
-                if (!(dbg & 4)) fetch(wrap ? abase_next : abase, wrap ? aofs_next : aofs, wrap ? 0 : c + 1, buf ^ 1);
+                // the next slice's rows are issued in front of the products, its weights between the two k-steps: the wave's matrix
+                // chain starts after four DMA instructions instead of eight (their issue waits for the memory pipeline)
+                const unsigned char *const nb = wrap ? abase_next : abase;
+                const unsigned *const no = wrap ? aofs_next : aofs;
+                const int nc = wrap ? 0 : c + 1;
+                if (!(dbg & 4)) fetch_rows(nb, no, nc, buf ^ 1);
                 const unsigned long long q2 = clk();
-                if (!(dbg & 2)) products(buf);
+                if (!(dbg & 2)) products(buf, [&]() { if (!(dbg & 4)) fetch_weights(nc, buf ^ 1); });
+                else if (!(dbg & 4)) fetch_weights(nc, buf ^ 1);
                 buf ^= 1;
                 if (PROF) { const unsigned long long q3 = clk(); pq[0] += q2 - q1; pq[1] += q3 - q2; pq[3] += q1 - q0; pq[5] += 1; }
             }
