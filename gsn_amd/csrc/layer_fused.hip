@@ -49,6 +49,7 @@
 #include <cstdlib>
 
 #include "chain_common.h"
+#include "layer_rr.h"
 
 namespace gsn {
 
@@ -1053,13 +1054,15 @@ static void lf_fill_stages(LfArgs &a, const gsn_chain_stage *edge, int64_t d_x, 
 }
 static int lf_nk0(const LfArgs &a) { return a.s0.k_total <= 96 ? 6 : 10; }
 static int lf_nk1(const LfArgs &a) { return a.s1.k_total <= 64 ? 4 : 8; }
+// the prepared buffer: this file's fragments, then (where the shape fits) those of the register-resident kernel (layer_rr.hip)
+static int64_t lf_prep_bytes_own(const LfArgs &a) { return (((int64_t)(LF_PREP_HDR + 4 * (5 + lf_nk0(a) + lf_nk1(a)) * 2 * 64 * 4) * 4) + 255) / 256 * 256; }
 
 extern "C" int64_t gsn_layer_fused_prepared_bytes(const gsn_chain_stage *edge, int64_t d_x, const gsn_chain_stage *node0,
                                                   const gsn_chain_stage *node1) {
     if (!gsn_layer_fused_supported(edge, d_x, node0, node1)) return 0;
     LfArgs a{};
     lf_fill_stages(a, edge, d_x, node0, node1);
-    return (int64_t)(LF_PREP_HDR + 4 * (5 + lf_nk0(a) + lf_nk1(a)) * 2 * 64 * 4) * 4;
+    return lf_prep_bytes_own(a) + rr_prepared_bytes(edge, d_x, node0, node1);
 }
 
 extern "C" int gsn_layer_fused_prepare_hip(const gsn_chain_stage *edge, int64_t d_x, const gsn_chain_stage *node0,
@@ -1078,6 +1081,8 @@ extern "C" int gsn_layer_fused_prepare_hip(const gsn_chain_stage *edge, int64_t 
     else hipLaunchKernelGGL((layer_fused_prepare_kernel<5, 10, 8>), dim3(1), dim3(768), 0, st, a, pp);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(GSN_E_HIP, "layer_fused_prepare_kernel: %s", hipGetErrorString(e));
+    if (rr_supported(edge, d_x, node0, node1))
+        return rr_prepare(edge, d_x, node0, node1, reinterpret_cast<unsigned char *>(prepared) + lf_prep_bytes_own(a), st);
     return GSN_OK;
 }
 
@@ -1096,6 +1101,11 @@ extern "C" int gsn_layer_fused_fwd_hip(int64_t n_nodes, int64_t n_edges, const i
     lf_fill_stages(a, edge, d_x, node0, node1);
     a.x = x; a.out = out; a.prep = reinterpret_cast<const unsigned *>(prepared);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    // every stage 128 wide, d_x + 4 <= 32: the register-resident kernel (layer_rr.hip; GSN_FUSED_RR=0 keeps this file's kernel)
+    if (rr_supported(edge, d_x, node0, node1)) {
+        const int rc = rr_forward(n_nodes, n_edges, seg_ptr, edge, x, d_x, node0, node1, reinterpret_cast<const unsigned char *>(prepared) + lf_prep_bytes_own(a), out, st);
+        if (rc != 1) return rc;
+    }
     const int k0 = a.s0.k_total, k1 = a.s1.k_total;
     // every width 128 (or 64): the reference's d = 128 / 64 layers -- widths as compile-time constants
     const bool generic = getenv("GSN_FUSED_GENERIC") != nullptr;
