@@ -11,7 +11,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgsn_hip.so")
+LIB_PATH = os.environ.get("GSN_LIB_PATH") or os.path.join(_HERE, "lib", "libgsn_hip.so")   # (GSN_LIB_PATH: A/B builds of the same ABI)
 _lib = None
 
 c_i64 = ctypes.c_int64

@@ -40,6 +40,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "chain_common.h"
 #include "layer_rr.h"
@@ -183,13 +184,20 @@ __device__ __forceinline__ void rr_idx_load(const RrArgs &a, const RrDesc &d, in
 // block holds them (table in LDS: base, row stride and index role per slot and lane half).  Always issued -- with the row indices
 // of an earlier block when there is no next one -- so that the destination registers are dead between their last use and here.
 __device__ __forceinline__ void rr_gather_issue(const rr_u4 *slot_tab, int lh, const int (&r)[RR_MAXROLE], rr_f4 (&g)[RR_NSLOT]) {
+    rr_u4 ent[RR_NSLOT];
+#pragma unroll
+    for (int s = 0; s < RR_NSLOT; ++s) ent[s] = slot_tab[2 * s + lh];           // (all table reads first: one LDS latency, not ten)
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < RR_NSLOT; ++s) {
-        const rr_u4 ent = slot_tab[2 * s + lh];
-        const unsigned m1 = 0u - (unsigned)(ent.w == 1u), m2 = 0u - (unsigned)(ent.w == 2u);      // (a select chain became divergent branches)
+        const unsigned m1 = 0u - (unsigned)(ent[s].w == 1u), m2 = 0u - (unsigned)(ent[s].w == 2u);      // (a select chain became divergent branches)
         const unsigned row = ((unsigned)r[0] & ~(m1 | m2)) | ((unsigned)r[1] & m1) | ((unsigned)r[2] & m2);
-        const unsigned long long addr = ((unsigned long long)ent.y << 32 | ent.x) + (unsigned long long)row * ent.z;
+        const unsigned long long addr = ((unsigned long long)ent[s].y << 32 | ent[s].x) + (unsigned long long)row * ent[s].z;
+#ifdef RR_ABL_NOGATHER
+        g[s] = rr_f4{(float)(addr & 1), 0.f, 1.f, 0.f};
+#else
         g[s] = *reinterpret_cast<const __attribute__((address_space(1))) rr_f4 *>(addr);
+#endif
     }
 }
 
@@ -197,17 +205,29 @@ __device__ __forceinline__ unsigned rr_pack_h2(float a, float b) { return __buil
 __device__ __forceinline__ rr_f2 rr_unpack_h2(unsigned p) { return __builtin_convertvector(__builtin_bit_cast(rr_h2, p), rr_f2); }
 __device__ __forceinline__ unsigned rr_pack_b2(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector(rr_f2{a, b}, rr_b2)); }
 
+// fp32 - (one half of a packed fp16 pair), one instruction: the compiler converts the pair back (two v_cvt) and subtracts packed
+__device__ __forceinline__ float rr_res_lo(float a, unsigned pair) { float r; asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(a), "v"(pair)); return r; }
+__device__ __forceinline__ float rr_res_hi(float a, unsigned pair) { float r; asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(a), "v"(pair)); return r; }
+// a * s - half of the pair (one rounding)
+__device__ __forceinline__ float rr_res_lo_s(float a, float s, unsigned pair) { float r; asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(a), "v"(s), "v"(pair)); return r; }
+__device__ __forceinline__ float rr_res_hi_s(float a, float s, unsigned pair) { float r; asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(a), "v"(s), "v"(pair)); return r; }
+// max(x, lo) with lo in a scalar register, one instruction (fmaxf / fmed3 on an MFMA result get a canonicalising v_max in front)
+__device__ __forceinline__ float rr_max(float x, float lo) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "s"(lo)); return r; }
+
 // (a, b) -> packed fp16 high parts and low parts (round to nearest)
 __device__ __forceinline__ void rr_split2(float a, float b, unsigned &hi, unsigned &lo) {
     hi = rr_pack_h2(a, b);
-    const rr_f2 hf = rr_unpack_h2(hi);
-    lo = rr_pack_h2(a - hf.x, b - hf.y);
+    lo = rr_pack_h2(rr_res_lo(a, hi), rr_res_hi(b, hi));
+}
+// the same of (a s, b s)
+__device__ __forceinline__ void rr_split2s(float a, float b, float s, unsigned &hi, unsigned &lo) {
+    hi = rr_pack_h2(a * s, b * s);
+    lo = rr_pack_h2(rr_res_lo_s(a, s, hi), rr_res_hi_s(b, s, hi));
 }
 // the same, also returning the OR of the residuals' bits (zero: both exact in fp16)
 __device__ __forceinline__ void rr_split2r(float a, float b, unsigned &hi, unsigned &res) {
     hi = rr_pack_h2(a, b);
-    const rr_f2 hf = rr_unpack_h2(hi);
-    res |= __float_as_uint(a - hf.x) | __float_as_uint(b - hf.y);
+    res |= __float_as_uint(rr_res_lo(a, hi)) | __float_as_uint(rr_res_hi(b, hi));
 }
 // (a, b) -> three packed bf16 planes, a + b exactly (8 + 8 + 8 bits, round to nearest each)
 __device__ __forceinline__ void rr_split3b(float a, float b, unsigned &p1, unsigned &p2, unsigned &p3) {
@@ -238,10 +258,29 @@ typedef const __attribute__((address_space(3))) rr_u4 *rr_ldsp;
 __device__ __forceinline__ const void *rr_lds_generic(unsigned lds_addr) { return (const void *)reinterpret_cast<const __attribute__((address_space(3))) unsigned char *>(lds_addr); }
 __device__ __forceinline__ rr_u4 rr_lds_frag(const unsigned (&base)[3], int f) {
     const int byte = f * 1024;
+#ifdef RR_ABL_NOLDS
+    return rr_u4{base[0], (unsigned)f, base[1], 0x3c003c00u};
+#else
     return *reinterpret_cast<rr_ldsp>(base[byte >> 16] + (unsigned)(byte & 0xffff));
+#endif
 }
 
+// scheduling fence between the unrolled groups of products (the compiler otherwise hoists every fragment read of a stage to its top)
+#ifdef RR_NOSB
+#define RR_SB()
+#else
+#define RR_SB() __builtin_amdgcn_sched_barrier(0)
+#endif
+#ifndef RR_PD
+#define RR_PD 4
+#endif
+// diagnostic builds (scripts/rr_variant.sh): RR_ABL_NOMFMA / NOLDS / NOSTREAM / NOGATHER / NOSTORE switch one kind of work off (results are
+// then garbage) to see what the kernel's time is sensitive to
+#ifdef RR_ABL_NOMFMA
+#define RR_MFH(A, B, C) asm volatile("" :: "v"(A), "v"(B))
+#else
 #define RR_MFH(A, B, C) C = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rr_h8, A), __builtin_bit_cast(rr_h8, B), C, 0, 0, 0)
+#endif
 #define RR_MFB(A, B, C) C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(rr_b8, A), __builtin_bit_cast(rr_b8, B), C, 0, 0, 0)
 
 // the incidence operand of one 32-row edge block: lane (t, h), k-slot s of chunk cc <-> block row 16 cc + 8 (s >> 2) + 4 h + (s & 3);
@@ -269,8 +308,17 @@ __device__ __forceinline__ void rr_incidence(unsigned bm, int lh, rr_u4 (&M)[2])
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
-template <int WB, int NKX>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void layer_fused_kernel_rr(RrArgs a) {
+template <int WB, int NKX, bool PROF>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void layer_fused_kernel_rr(RrArgs a, unsigned long long *prof) {
+    // diagnostic build (GSN_FUSED_PROF=1): cycles per phase of wave 0 of workgroup 0 and of one wave in the middle of the grid
+    auto clk = [&]() -> unsigned {
+        if (!PROF) return 0u;
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned v = (unsigned)__builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_sched_barrier(0);
+        return v;
+    };
+    unsigned pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // wait+convert, issue, edge, stage 0, split, stage 1, blocks, tiles
     using SH = RrShape<WB, NKX>;
     constexpr int NKS = SH::NKS, NK0 = SH::NK0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -336,7 +384,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     unsigned badt = 0;                                 // this lane's target saw a non-finite edge row
     const int cx = a.d_x >> 2;
 
+    const unsigned t_start = clk();
     while (cur.valid()) {
+        const unsigned t0 = clk();
         // (every LDS read below is loop-invariant to the compiler, which hoists what it likes out of the loop and then spills it: the
         //  bases are made opaque once per block)
         asm volatile("" : "+v"(ldsb[0]), "+v"(ldsb[1]), "+v"(ldsb[2]));
@@ -363,7 +413,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     xq[c][j] = *reinterpret_cast<const float4 *>(a.x + (int64_t)xrow * a.d_x + 4 * q);
                 }
         };
-        load_x();
         // =========================================================================================================================
         // the gathered rows as fp16 fragments; are they all exact (and < 2)?  Then the next block's gathers take their registers.
         // =========================================================================================================================
@@ -383,6 +432,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             Al[c] = Ah[c];
         }
         const bool inexact = ((res & 0x7fffffffu) | (big & 0x40000000u)) != 0;
+        // k-slot 79 (chunk 4, upper lane half, last slot) carries the constant 1 whose weights are the folded bias: the accumulators of
+        // the short path start at zero (an inline constant of the first product instead of sixteen moves per 32 x 32 tile)
+        Ah[RR_NKE - 1][3] = lh ? (Ah[RR_NKE - 1][3] & 0xffffu) | 0x3c000000u : Ah[RR_NKE - 1][3];
         const bool exact_blk = ne == 0 || __builtin_amdgcn_ballot_w64(inexact) == 0ull;
         float inv_e = 1.f;
         bool bad_e = false;
@@ -408,14 +460,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const rr_f4 v = g[2 * c + j];
-                    rr_split2(v.x * rs, v.y * rs, h[2 * j], l[2 * j]);
-                    rr_split2(v.z * rs, v.w * rs, h[2 * j + 1], l[2 * j + 1]);
+                    rr_split2s(v.x, v.y, rs, h[2 * j], l[2 * j]);
+                    rr_split2s(v.z, v.w, rs, h[2 * j + 1], l[2 * j + 1]);
                 }
                 Ah[c] = rr_u4{h[0], h[1], h[2], h[3]};
                 Al[c] = rr_u4{l[0], l[1], l[2], l[3]};
             }
+            // (scaled rows: no constant column -- the row scale has no fp16 value; the bias enters in the epilogue)
+            Ah[RR_NKE - 1][3] = lh ? Ah[RR_NKE - 1][3] & 0xffffu : Ah[RR_NKE - 1][3];
+            Al[RR_NKE - 1][3] = lh ? Al[RR_NKE - 1][3] & 0xffffu : Al[RR_NKE - 1][3];
         }
 #endif
+        const unsigned t1 = clk();
         // ---- next block: its gathers, the descriptor after it, that one's row indices.  Inside a tile right here (they fly under this
         //      block's edge stage); behind the tile's last block after node stage 0, whose accumulators need the registers ------------
         int npt = 0, npt1 = 0;
@@ -428,6 +484,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         };
         if (!cur.last() && exact_blk) advance();       // (scaled rows: behind the edge stage, which then needs the registers itself)
 
+        const unsigned t2 = clk();
         // =========================================================================================================================
         // edge stage + per-node sums of this block
         // =========================================================================================================================
@@ -439,32 +496,46 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (exact_blk)
 #endif
             {
-                // ---- exact rows: two plane products, Y'' = se Y bounded by 2^15, two fp16 planes into the incidence product -------
+                // ---- exact rows: two plane products, Y'' = se Y bounded by 2^15, two fp16 planes into the incidence product.
+                //      Two feature blocks at a time = two accumulator chains issued alternately: an MFMA that waits for the accumulator of
+                //      the one issued just before it, with anything in between, costs ~75 cycles instead of 32 (guide: +43 for the first
+                //      extra issue slot).  Weight fragments of step c + 1 are read before the products of step c.
 #pragma unroll
-                for (int fb = 0; fb < WB; ++fb) {
-                    f32x16 acc;
-                    const float c00 = tab[32 * fb + li];
+                for (int fp = 0; fp < WB; fp += 2) {
+                    f32x16 acc0, acc1;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[r] = c00;
+                    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+                    rr_u4 f0h = rr_lds_frag(ldsb, SH::F_WE + 2 * (fp * RR_NKE)), f0l = rr_lds_frag(ldsb, SH::F_WE + 2 * (fp * RR_NKE) + 1);
+                    rr_u4 f1h = rr_lds_frag(ldsb, SH::F_WE + 2 * ((fp + 1) * RR_NKE)), f1l = rr_lds_frag(ldsb, SH::F_WE + 2 * ((fp + 1) * RR_NKE) + 1);
 #pragma unroll
                     for (int c = 0; c < RR_NKE; ++c) {
-                        const rr_u4 bh = rr_lds_frag(ldsb, SH::F_WE + ((fb * RR_NKE + c) * 2)), bl = rr_lds_frag(ldsb, SH::F_WE + ((fb * RR_NKE + c) * 2 + 1));
-                        RR_MFH(Ah[c], bl, acc);
-                        RR_MFH(Ah[c], bh, acc);
-                        __builtin_amdgcn_sched_barrier(0);
+                        rr_u4 n0h = f0h, n0l = f0l, n1h = f1h, n1l = f1l;
+                        if (c + 1 < RR_NKE) {
+                            n0h = rr_lds_frag(ldsb, SH::F_WE + 2 * (fp * RR_NKE + c + 1)); n0l = rr_lds_frag(ldsb, SH::F_WE + 2 * (fp * RR_NKE + c + 1) + 1);
+                            n1h = rr_lds_frag(ldsb, SH::F_WE + 2 * ((fp + 1) * RR_NKE + c + 1)); n1l = rr_lds_frag(ldsb, SH::F_WE + 2 * ((fp + 1) * RR_NKE + c + 1) + 1);
+                        }
+                        RR_MFH(Ah[c], f0l, acc0);
+                        RR_MFH(Ah[c], f1l, acc1);
+                        RR_MFH(Ah[c], f0h, acc0);
+                        RR_MFH(Ah[c], f1h, acc1);
+                        RR_SB();
+                        f0h = n0h; f0l = n0l; f1h = n1h; f1l = n1l;
                     }
-                    unsigned yh[8], yl[8];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q)
-                        rr_split2(fmaxf(acc[2 * q], lo_e), fmaxf(acc[2 * q + 1], lo_e), yh[q], yl[q]);
+                    for (int u = 0; u < 2; ++u) {
+                        const f32x16 &acc = u ? acc1 : acc0;
+                        unsigned yh[8], yl[8];
 #pragma unroll
-                    for (int cc = 0; cc < 2; ++cc) {
-                        const rr_u4 ph = rr_u4{yh[4 * cc], yh[4 * cc + 1], yh[4 * cc + 2], yh[4 * cc + 3]};
-                        const rr_u4 pl = rr_u4{yl[4 * cc], yl[4 * cc + 1], yl[4 * cc + 2], yl[4 * cc + 3]};
-                        RR_MFH(pl, M[cc], sacc[fb]);
-                        RR_MFH(ph, M[cc], sacc[fb]);
+                        for (int q = 0; q < 8; ++q) rr_split2(rr_max(acc[2 * q], lo_e), rr_max(acc[2 * q + 1], lo_e), yh[q], yl[q]);
+                        // (four products on one accumulator: low planes first, the other chain's split in between)
+                        const rr_u4 pl0 = rr_u4{yl[0], yl[1], yl[2], yl[3]}, pl1 = rr_u4{yl[4], yl[5], yl[6], yl[7]};
+                        const rr_u4 ph0 = rr_u4{yh[0], yh[1], yh[2], yh[3]}, ph1 = rr_u4{yh[4], yh[5], yh[6], yh[7]};
+                        RR_MFH(pl0, M[0], sacc[fp + u]);
+                        RR_MFH(pl1, M[1], sacc[fp + u]);
+                        RR_MFH(ph0, M[0], sacc[fp + u]);
+                        RR_MFH(ph1, M[1], sacc[fp + u]);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
+                    RR_SB();
                 }
             }
 #ifndef RR_EXP_NOSLOW
@@ -486,7 +557,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         RR_MFH(Al[c], bh, acc);
                         RR_MFH(Ah[c], bl, acc);
                         RR_MFH(Ah[c], bh, acc);
-                        __builtin_amdgcn_sched_barrier(0);
+                        RR_SB();
                     }
                     // (eight rows at a time: the inverse row scale travels to the accumulator's REGISTER -- row rr_crow(r, h) of the block)
 #pragma unroll
@@ -505,7 +576,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         RR_MFB(p3, M[cc], sacc[fb]);
                         RR_MFB(p2, M[cc], sacc[fb]);
                         RR_MFB(p1, M[cc], sacc[fb]);
-                        __builtin_amdgcn_sched_barrier(0);
+                        RR_SB();
                     }
                 }
             }
@@ -513,12 +584,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
 
         if (!cur.last() && !exact_blk) advance();
+        const unsigned t3 = clk();
+        if (PROF) { pc[0] += t1 - t0; pc[1] += t2 - t1; pc[2] += t3 - t2; pc[6] += 1; }
 
+        unsigned t4g = 0, t5g = 0;
         if (cur.last()) {
             // =====================================================================================================================
             // node stage 0 (transposed): H^T = W0 [S | x | deg]^T
             // =====================================================================================================================
             f32x16 hacc[WB];
+            load_x();                                                   // (rows this tile's edge blocks have just gathered: cache hits)
             // ---- row scale from max(|S|, |x|, deg) in true units (sacc = 2 se S) ------------------------------------------------
             float ms = 0.f;
 #pragma unroll
@@ -560,8 +635,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 unsigned h[4], l[4];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    rr_split2(xv[c][j].x * rs, xv[c][j].y * rs, h[2 * j], l[2 * j]);
-                    rr_split2(xv[c][j].z * rs, xv[c][j].w * rs, h[2 * j + 1], l[2 * j + 1]);
+                    rr_split2s(xv[c][j].x, xv[c][j].y, rs, h[2 * j], l[2 * j]);
+                    rr_split2s(xv[c][j].z, xv[c][j].w, rs, h[2 * j + 1], l[2 * j + 1]);
                 }
                 Xh[c] = rr_u4{h[0], h[1], h[2], h[3]};
                 Xl[c] = rr_u4{l[0], l[1], l[2], l[3]};
@@ -574,46 +649,83 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     const float4 cv = *reinterpret_cast<const float4 *>(tab + 32 * WB + 32 * fbo + 8 * i + 4 * lh);
                     hacc[fbo][4 * i] = cv.x * sc; hacc[fbo][4 * i + 1] = cv.y * sc; hacc[fbo][4 * i + 2] = cv.z * sc; hacc[fbo][4 * i + 3] = cv.w * sc;
                 }
-            // ---- [x | deg] part first (its fragments' registers are free for the rest of the stage) --------------------------------
+            // ---- [x | deg] part first (its fragments' registers are free for the rest of the stage).  Everywhere in this stage: hidden
+            //      feature blocks in pairs = two accumulator chains issued alternately (see the edge stage), fragments one step ahead ----
+            {
+                auto fr = [&](int i, rr_u4 &h0, rr_u4 &l0, rr_u4 &h1, rr_u4 &l1) {          // step i = (cq, pair)
+                    const int cq = i / (WB / 2), fa = 2 * (i % (WB / 2));
+                    h0 = rr_lds_frag(ldsb, SH::F_W0H + fa * NK0 + NKS + cq); l0 = rr_lds_frag(ldsb, SH::F_W0XL + fa * NKX + cq);
+                    h1 = rr_lds_frag(ldsb, SH::F_W0H + (fa + 1) * NK0 + NKS + cq); l1 = rr_lds_frag(ldsb, SH::F_W0XL + (fa + 1) * NKX + cq);
+                };
+                rr_u4 a0h, a0l, a1h, a1l;
+                fr(0, a0h, a0l, a1h, a1l);
 #pragma unroll
-            for (int cq = 0; cq < NKX; ++cq) {
-                const int c = NKS + cq;
-#pragma unroll
-                for (int fbo = 0; fbo < WB; ++fbo) {
-                    const rr_u4 ah = rr_lds_frag(ldsb, SH::F_W0H + fbo * NK0 + c), al = rr_lds_frag(ldsb, SH::F_W0XL + fbo * NKX + cq);
-                    RR_MFH(ah, Xl[cq], hacc[fbo]);
-                    RR_MFH(al, Xh[cq], hacc[fbo]);
-                    RR_MFH(ah, Xh[cq], hacc[fbo]);
+                for (int i = 0; i < NKX * (WB / 2); ++i) {
+                    const int cq = i / (WB / 2), fa = 2 * (i % (WB / 2));
+                    rr_u4 n0h = a0h, n0l = a0l, n1h = a1h, n1l = a1l;
+                    if (i + 1 < NKX * (WB / 2)) fr(i + 1, n0h, n0l, n1h, n1l);
+                    RR_MFH(a0h, Xl[cq], hacc[fa]);
+                    RR_MFH(a1h, Xl[cq], hacc[fa + 1]);
+                    RR_MFH(a0l, Xh[cq], hacc[fa]);
+                    RR_MFH(a1l, Xh[cq], hacc[fa + 1]);
+                    RR_MFH(a0h, Xh[cq], hacc[fa]);
+                    RR_MFH(a1h, Xh[cq], hacc[fa + 1]);
+                    RR_SB();
+                    a0h = n0h; a0l = n0l; a1h = n1h; a1l = n1l;
                 }
-                __builtin_amdgcn_sched_barrier(0);
             }
             // ---- S part: the S^T tiles become operand fragments, 16 features at a time; the weights' low planes arrive from L2, PD
-            //      fragments ahead (nothing else of this wave is in flight here: the next block's gathers are issued behind this stage)
-            constexpr int PD = 4, NSL = NKS * WB;
+            //      fragments ahead (nothing else of this wave is in flight here: the next block's gathers are issued behind this stage);
+            //      the high planes one step ahead from LDS; the split of chunk c + 1 is spread under the products of chunk c
+#ifdef RR_ABL_NOSTREAM
+#define RR_STREAM(I) rr_u4{(unsigned)(I), (unsigned)lane, 0x3c003c00u, 0u}
+#else
+#define RR_STREAM(I) __builtin_bit_cast(rr_u4, __builtin_amdgcn_raw_buffer_load_b128(wstream, 16 * lane, (I) * 1024, 0))
+#endif
+            constexpr int PD = RR_PD, NSL = NKS * WB;
+            static_assert(PD % 2 == 0, "the stream is consumed two fragments per step");
             rr_u4 ql[PD];
 #pragma unroll
-            for (int i = 0; i < PD; ++i) ql[i] = __builtin_bit_cast(rr_u4, __builtin_amdgcn_raw_buffer_load_b128(wstream, 16 * lane, i * 1024, 0));
+            for (int i = 0; i < PD; ++i) ql[i] = RR_STREAM(i);
+            {
+                rr_u4 a0h = rr_lds_frag(ldsb, SH::F_W0H), a1h = rr_lds_frag(ldsb, SH::F_W0H + NK0);
+                unsigned ph[4], pl[4], nph[4], npl[4];
 #pragma unroll
-            for (int fb = 0; fb < WB; ++fb)
+                for (int q = 0; q < 4; ++q) rr_split2s(sacc[0][2 * q], sacc[0][2 * q + 1], fs, ph[q], pl[q]);
 #pragma unroll
-                for (int cc = 0; cc < 2; ++cc) {
-                    unsigned h[4], l[4];
+                for (int c = 0; c < NKS; ++c) {
+                    const rr_u4 bh = rr_u4{ph[0], ph[1], ph[2], ph[3]}, bl = rr_u4{pl[0], pl[1], pl[2], pl[3]};
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) rr_split2(sacc[fb][8 * cc + 2 * q] * fs, sacc[fb][8 * cc + 2 * q + 1] * fs, h[q], l[q]);
-                    const rr_u4 bh = rr_u4{h[0], h[1], h[2], h[3]}, bl = rr_u4{l[0], l[1], l[2], l[3]};
-                    const int c = 2 * fb + cc;
-#pragma unroll
-                    for (int fbo = 0; fbo < WB; ++fbo) {
-                        const int i = c * WB + fbo;
-                        const rr_u4 ah = rr_lds_frag(ldsb, SH::F_W0H + fbo * NK0 + c);
-                        const rr_u4 al = ql[i % PD];
-                        RR_MFH(ah, bl, hacc[fbo]);
-                        RR_MFH(al, bh, hacc[fbo]);
-                        RR_MFH(ah, bh, hacc[fbo]);
-                        if (i + PD < NSL) ql[i % PD] = __builtin_bit_cast(rr_u4, __builtin_amdgcn_raw_buffer_load_b128(wstream, 16 * lane, (i + PD) * 1024, 0));
-                        __builtin_amdgcn_sched_barrier(0);
+                    for (int fa = 0; fa < WB; fa += 2) {
+                        const int i = c * WB + fa;                 // stream position of (c, fa); (c, fa + 1) follows
+                        rr_u4 n0h = a0h, n1h = a1h;
+                        if (i + 2 < NSL) {
+                            const int c1 = (i + 2) / WB, f1 = (i + 2) % WB;
+                            n0h = rr_lds_frag(ldsb, SH::F_W0H + f1 * NK0 + c1); n1h = rr_lds_frag(ldsb, SH::F_W0H + (f1 + 1) * NK0 + c1);
+                        }
+                        const rr_u4 a0l = ql[i % PD], a1l = ql[(i + 1) % PD];
+                        RR_MFH(a0h, bl, hacc[fa]);
+                        RR_MFH(a1h, bl, hacc[fa + 1]);
+                        RR_MFH(a0l, bh, hacc[fa]);
+                        RR_MFH(a1l, bh, hacc[fa + 1]);
+                        RR_MFH(a0h, bh, hacc[fa]);
+                        RR_MFH(a1h, bh, hacc[fa + 1]);
+                        if (i + PD < NSL) {
+                            ql[i % PD] = RR_STREAM(i + PD);
+                            ql[(i + 1) % PD] = RR_STREAM(i + 1 + PD);
+                        }
+                        if (c + 1 < NKS) {                         // half of the next chunk's planes
+                            const int c1 = c + 1, fb1 = c1 >> 1, cc1 = c1 & 1;
+                            rr_split2s(sacc[fb1][8 * cc1 + 2 * fa], sacc[fb1][8 * cc1 + 2 * fa + 1], fs, nph[fa], npl[fa]);
+                            rr_split2s(sacc[fb1][8 * cc1 + 2 * fa + 2], sacc[fb1][8 * cc1 + 2 * fa + 3], fs, nph[fa + 1], npl[fa + 1]);
+                        }
+                        RR_SB();
+                        a0h = n0h; a1h = n1h;
                     }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { ph[q] = nph[q]; pl[q] = npl[q]; }
                 }
+            }
             // (the sums are consumed: zero for the next tile HERE, not under a condition at the top of the loop -- the compiler cannot
             //  know that a tile's last block is followed by a first one and would keep the 64 registers alive through node stage 1)
 #pragma unroll
@@ -621,6 +733,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sacc[fb][r] = 0.f;
             badt = 0;
+            const unsigned t4 = clk(); t4g = t4;
             // =====================================================================================================================
             // node stage 1: OUT = H W1^T, rows leave as 128-byte row segments
             // =====================================================================================================================
@@ -629,7 +742,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int fbo = 0; fbo < WB; ++fbo)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) hacc[fbo][r] = fmaxf(hacc[fbo][r], lo_0);
+                for (int r = 0; r < 16; ++r) hacc[fbo][r] = rr_max(hacc[fbo][r], lo_0);
 #pragma unroll
             for (int fbo = 0; fbo < WB; ++fbo)
 #pragma unroll
@@ -648,41 +761,70 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int cc = 0; cc < 2; ++cc) {
                     unsigned h[4], l[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) rr_split2(hacc[fbo][8 * cc + 2 * q] * f2, hacc[fbo][8 * cc + 2 * q + 1] * f2, h[q], l[q]);
+                    for (int q = 0; q < 4; ++q) rr_split2s(hacc[fbo][8 * cc + 2 * q], hacc[fbo][8 * cc + 2 * q + 1], f2, h[q], l[q]);
                     Hh[2 * fbo + cc] = rr_u4{h[0], h[1], h[2], h[3]};
                     Hl[2 * fbo + cc] = rr_u4{l[0], l[1], l[2], l[3]};
                 }
             float invr[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) invr[r] = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * rr_crow(r, lh), __float_as_int(inv2)));
+            const unsigned t5 = clk(); t5g = t5;
             advance();                                                  // (the hidden rows are fp16 fragments now: room for the next block's gathers)
             const int voff_lane = (4 * lh * 32 * WB + li) * 4;          // byte offset of (row 4 h, column li) in an output tile
             const __amdgpu_buffer_rsrc_t orow = __builtin_amdgcn_make_buffer_rsrc(a.out + (int64_t)cur.m0 * (32 * WB), 0, nn * (32 * WB * 4), 0x00020000);
 #pragma unroll
-            for (int fb = 0; fb < WB; ++fb) {
-                f32x16 o;
+            for (int fp = 0; fp < WB; fp += 2) {
+                // two output feature blocks = two accumulator chains issued alternately; weight fragments one step ahead
+                f32x16 o0, o1;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[r] = 0.f;
+                for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+                rr_u4 b0h = rr_lds_frag(ldsb, SH::F_W1 + 2 * (fp * NKS)), b0l = rr_lds_frag(ldsb, SH::F_W1 + 2 * (fp * NKS) + 1);
+                rr_u4 b1h = rr_lds_frag(ldsb, SH::F_W1 + 2 * ((fp + 1) * NKS)), b1l = rr_lds_frag(ldsb, SH::F_W1 + 2 * ((fp + 1) * NKS) + 1);
 #pragma unroll
                 for (int c = 0; c < NKS; ++c) {
-                    const rr_u4 bh = rr_lds_frag(ldsb, SH::F_W1 + (fb * NKS + c) * 2), bl = rr_lds_frag(ldsb, SH::F_W1 + (fb * NKS + c) * 2 + 1);
-                    RR_MFH(Hl[c], bh, o);
-                    RR_MFH(Hh[c], bl, o);
-                    RR_MFH(Hh[c], bh, o);
-                    __builtin_amdgcn_sched_barrier(0);
+                    rr_u4 n0h = b0h, n0l = b0l, n1h = b1h, n1l = b1l;
+                    if (c + 1 < NKS) {
+                        n0h = rr_lds_frag(ldsb, SH::F_W1 + 2 * (fp * NKS + c + 1)); n0l = rr_lds_frag(ldsb, SH::F_W1 + 2 * (fp * NKS + c + 1) + 1);
+                        n1h = rr_lds_frag(ldsb, SH::F_W1 + 2 * ((fp + 1) * NKS + c + 1)); n1l = rr_lds_frag(ldsb, SH::F_W1 + 2 * ((fp + 1) * NKS + c + 1) + 1);
+                    }
+                    RR_MFH(Hl[c], b0h, o0);
+                    RR_MFH(Hl[c], b1h, o1);
+                    RR_MFH(Hh[c], b0l, o0);
+                    RR_MFH(Hh[c], b1l, o1);
+                    RR_MFH(Hh[c], b0h, o0);
+                    RR_MFH(Hh[c], b1h, o1);
+                    RR_SB();
+                    b0h = n0h; b0l = n0l; b1h = n1h; b1l = n1l;
                 }
-                const float cb = tab[2 * 32 * WB + 32 * fb + li];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float y = fmaxf(fmaf(o[r], invr[r], cb), lo_1);
-                    if (anybad) y = invr[r] != invr[r] ? invr[r] : y;
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), orow, voff_lane + ((r & 3) + 8 * (r >> 2)) * (32 * WB * 4) + 32 * fb * 4, 0, 0);
+                for (int u = 0; u < 2; ++u) {
+                    const f32x16 &o = u ? o1 : o0;
+                    const float cb = tab[2 * 32 * WB + 32 * (fp + u) + li];
+                    auto put = [&](auto nanrows) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            float y = rr_max(fmaf(o[r], invr[r], cb), lo_1);
+                            if (decltype(nanrows)::value) y = invr[r] != invr[r] ? invr[r] : y;     // (the max drops a NaN)
+#ifdef RR_ABL_NOSTORE
+                            asm volatile("" :: "v"(y));
+                            if (false)
+#endif
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), orow, voff_lane + ((r & 3) + 8 * (r >> 2)) * (32 * WB * 4) + 32 * (fp + u) * 4, 0, 0);
+                        }
+                    };
+                    if (anybad) put(std::true_type{}); else put(std::false_type{});
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                RR_SB();
             }
         }
+        if (PROF && cur.last()) { const unsigned t6 = clk(); pc[7] += 1; pc[5] += t6 - t5g; pc[3] += t4g - t3; pc[4] += t5g - t4g; }
         cur = nxt; nxt = nn2;
         pt = npt; pt1 = npt1;
+    }
+    if (PROF && prof && lane0 == 0 && (range == 0 || range == a.n_ranges / 2)) {
+        unsigned long long *o = prof + (range == 0 ? 0 : 16);
+        for (int q = 0; q < 8; ++q) o[q] = pc[q];
+        o[8] = clk() - t_start;
     }
 }
 
@@ -762,7 +904,7 @@ __global__ __launch_bounds__(1024) void layer_rr_prepare_kernel(RrPrepArgs p, un
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             int k;
-            if (st == 0) { k = 16 * c + 8 * h + s; k = k < p.k_total[0] ? k : -1; }
+            if (st == 0) { k = 16 * c + 8 * h + s; k = k < p.k_total[0] ? k : (k == 16 * RR_NKE - 1 ? -2 : -1); }
             else if (st == 1) {
                 if (c < NKS) k = p.d_x + rr_kslot_feature(c, h, s);
                 else {
@@ -770,7 +912,7 @@ __global__ __launch_bounds__(1024) void layer_rr_prepare_kernel(RrPrepArgs p, un
                     k = j < p.d_x ? j : (j < p.d_x + 4 ? p.d_x + Wd + (j - p.d_x) : -1);
                 }
             } else k = rr_kslot_feature(c, h, s);
-            wv[s] = k >= 0 ? p.W[st][(int64_t)row * p.k_total[st] + k] * sc : 0.f;
+            wv[s] = k >= 0 ? p.W[st][(int64_t)row * p.k_total[st] + k] * sc : (k == -2 ? rr_prep_c0(p, 0, row) * rr_pow2(Ee + 127) : 0.f);
         }
         unsigned o[4];
 #pragma unroll
@@ -820,7 +962,7 @@ int rr_supported(const gsn_chain_stage *edge, int64_t d_x, const gsn_chain_stage
         for (int q = 0; q < nroles; ++q) seen = seen || roles[q] == bl.idx32;
         if (!seen) { if (nroles == RR_MAXROLE) return 0; roles[nroles++] = bl.idx32; }
     }
-    if (ke > 16 * RR_NKE) return 0;
+    if (ke > 16 * RR_NKE - 4) return 0;                // (the last k-slot is the bias column)
     if (d_x < 4 || (d_x & 3) || d_x + 4 > 32) return 0;
     if (node0->n_blocks != 0 || node1->n_blocks != 0) return 0;
     return 1;
@@ -888,7 +1030,8 @@ int rr_forward(int64_t n_nodes, int64_t n_edges, const int32_t *seg_ptr, const g
     if (ranges > n_tiles) ranges = n_tiles;
     if (gx > ranges) gx = ranges;
     a.n_ranges = (int)ranges;
-    const void *fn = reinterpret_cast<const void *>(&layer_fused_kernel_rr<4, 2>);
+    static const bool prof_on = [] { const char *d = getenv("GSN_FUSED_PROF"); return d && atoi(d) != 0; }();
+    const void *fn = prof_on ? reinterpret_cast<const void *>(&layer_fused_kernel_rr<4, 2, true>) : reinterpret_cast<const void *>(&layer_fused_kernel_rr<4, 2, false>);
     static DeviceOnce attr_set;
     const int attr_dev = current_device();
     if (!attr_set.done(attr_dev)) {
@@ -898,7 +1041,25 @@ int rr_forward(int64_t n_nodes, int64_t n_edges, const int32_t *seg_ptr, const g
     }
     static_assert(SH::LDS_BYTES <= 160 * 1024, "LDS budget");
     if (getenv("GSN_CHAIN_TRACE")) fprintf(stderr, "gsn chain: layer_fused_kernel_rr<4,2> nodes %d edges %d grid %lld ranges %d\n", a.n_nodes, a.n_edges, (long long)gx, a.n_ranges);
-    hipLaunchKernelGGL((layer_fused_kernel_rr<4, 2>), dim3((unsigned)gx), dim3(512), SH::LDS_BYTES, st, a);
+    if (prof_on) {
+        unsigned long long *prof = nullptr;
+        (void)hipMalloc(&prof, 32 * 8); (void)hipMemsetAsync(prof, 0, 32 * 8, st);
+        hipLaunchKernelGGL((layer_fused_kernel_rr<4, 2, true>), dim3((unsigned)gx), dim3(512), SH::LDS_BYTES, st, a, prof);
+        unsigned long long h[32];
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(h, prof, sizeof(h), hipMemcpyDeviceToHost);
+        (void)hipFree(prof);
+        static int shown = 0;
+        if (shown++ % 8 == 7)
+            for (int w = 0; w < 2; ++w) {
+                const unsigned long long *o = h + 16 * w;
+                const double nb = o[6] ? (double)o[6] : 1.0, nt = o[7] ? (double)o[7] : 1.0;
+                fprintf(stderr, "rrprof range %s: blocks %llu tiles %llu total %llu cycles | per block: wait+convert %.0f issue %.0f edge %.0f | per tile: stage0 %.0f split %.0f stage1 %.0f\n",
+                        w ? "mid" : "0", o[6], o[7], o[8], o[0] / nb, o[1] / nb, o[2] / nb, o[3] / nt, o[4] / nt, o[5] / nt);
+            }
+    } else {
+        hipLaunchKernelGGL((layer_fused_kernel_rr<4, 2, false>), dim3((unsigned)gx), dim3(512), SH::LDS_BYTES, st, a, (unsigned long long *)nullptr);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(GSN_E_HIP, "layer_fused_kernel_rr: %s", hipGetErrorString(e));
     return GSN_OK;
