@@ -214,6 +214,15 @@ __device__ __forceinline__ float rr_res_hi_s(float a, float s, unsigned pair) { 
 // max(x, lo) with lo in a scalar register, one instruction (fmaxf / fmed3 on an MFMA result get a canonicalising v_max in front)
 __device__ __forceinline__ float rr_max(float x, float lo) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "s"(lo)); return r; }
 
+// The helpers above are opaque to the compiler's hazard recogniser: it pads an MFMA result -> VALU read with the wait states the
+// hardware needs (it has no interlock there) only for instructions it knows.  Where such a helper is the FIRST reader of an
+// accumulator, this goes between the last product and the read (8-pass MFMA: 12 states; fences keep both sides in place).
+__device__ __forceinline__ void rr_mfma_settle() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 15\n\ts_nop 1" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // (a, b) -> packed fp16 high parts and low parts (round to nearest)
 __device__ __forceinline__ void rr_split2(float a, float b, unsigned &hi, unsigned &lo) {
     hi = rr_pack_h2(a, b);
@@ -319,6 +328,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         return v;
     };
     unsigned pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // wait+convert, issue, edge, stage 0, split, stage 1, blocks, tiles
+    unsigned pw[4] = {0, 0, 0, 0};               // explicit waits (diagnostic build): gathers at the block top, x rows, everything in flight before advance(), LDS at the top of stage 1
+    auto wait_all = [&](int which) { if (PROF) { const unsigned a0 = clk(); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); pw[which] += clk() - a0; } };
     using SH = RrShape<WB, NKX>;
     constexpr int NKS = SH::NKS, NK0 = SH::NK0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -384,6 +395,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     unsigned badt = 0;                                 // this lane's target saw a non-finite edge row
     const int cx = a.d_x >> 2;
 
+#ifdef RR_STAGGER
+    // the second wave of every SIMD starts half a tile late: while one is in its edge stage (vector-heavy) the other is in the node
+    // stages (matrix-heavy)
+    if (wave >= 4) { for (int q = 0; q < RR_STAGGER; ++q) __builtin_amdgcn_s_sleep(127); }
+#endif
     const unsigned t_start = clk();
     while (cur.valid()) {
         const unsigned t0 = clk();
@@ -416,6 +432,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // =========================================================================================================================
         // the gathered rows as fp16 fragments; are they all exact (and < 2)?  Then the next block's gathers take their registers.
         // =========================================================================================================================
+        wait_all(0);
         rr_u4 Ah[RR_NKE], Al[RR_NKE];
         unsigned res = 0, big = 0;
 #pragma unroll
@@ -477,6 +494,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         int npt = 0, npt1 = 0;
         RrDesc nn2; nn2.m0 = 0; nn2.e0 = 0; nn2.pk = 0;
         auto advance = [&]() {
+            wait_all(2);
             rr_gather_issue(slot_tab, lh, ixn.r, g);
             npt = ixn.pt; npt1 = ixn.pt1;
             nn2 = rr_iter_next(it, lane);
@@ -521,6 +539,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         RR_SB();
                         f0h = n0h; f0l = n0l; f1h = n1h; f1l = n1l;
                     }
+                    rr_mfma_settle();
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
                         const f32x16 &acc = u ? acc1 : acc0;
@@ -594,6 +613,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             // =====================================================================================================================
             f32x16 hacc[WB];
             load_x();                                                   // (rows this tile's edge blocks have just gathered: cache hits)
+            wait_all(1);
             // ---- row scale from max(|S|, |x|, deg) in true units (sacc = 2 se S) ------------------------------------------------
             float ms = 0.f;
 #pragma unroll
@@ -739,6 +759,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             // =====================================================================================================================
             // ---- activation, row scale of H, fragments ----------------------------------------------------------------------------
             float m2 = 0.f;
+            rr_mfma_settle();
 #pragma unroll
             for (int fbo = 0; fbo < WB; ++fbo)
 #pragma unroll
@@ -825,6 +846,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         unsigned long long *o = prof + (range == 0 ? 0 : 16);
         for (int q = 0; q < 8; ++q) o[q] = pc[q];
         o[8] = clk() - t_start;
+        for (int q = 0; q < 4; ++q) o[9 + q] = pw[q];
     }
 }
 
@@ -1054,8 +1076,8 @@ int rr_forward(int64_t n_nodes, int64_t n_edges, const int32_t *seg_ptr, const g
             for (int w = 0; w < 2; ++w) {
                 const unsigned long long *o = h + 16 * w;
                 const double nb = o[6] ? (double)o[6] : 1.0, nt = o[7] ? (double)o[7] : 1.0;
-                fprintf(stderr, "rrprof range %s: blocks %llu tiles %llu total %llu cycles | per block: wait+convert %.0f issue %.0f edge %.0f | per tile: stage0 %.0f split %.0f stage1 %.0f\n",
-                        w ? "mid" : "0", o[6], o[7], o[8], o[0] / nb, o[1] / nb, o[2] / nb, o[3] / nt, o[4] / nt, o[5] / nt);
+                fprintf(stderr, "rrprof range %s: blocks %llu tiles %llu total %llu cycles | per block: wait+convert %.0f issue %.0f edge %.0f | per tile: stage0 %.0f split %.0f stage1 %.0f | waits per block: gathers %.0f, before advance %.0f; per tile: x rows %.0f\n",
+                        w ? "mid" : "0", o[6], o[7], o[8], o[0] / nb, o[1] / nb, o[2] / nb, o[3] / nt, o[4] / nt, o[5] / nt, o[9] / nb, o[11] / nb, o[10] / nt);
             }
     } else {
         hipLaunchKernelGGL((layer_fused_kernel_rr<4, 2, false>), dim3((unsigned)gx), dim3(512), SH::LDS_BYTES, st, a, (unsigned long long *)nullptr);
