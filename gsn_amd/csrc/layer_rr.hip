@@ -283,6 +283,14 @@ __device__ __forceinline__ rr_u4 rr_lds_frag(const unsigned (&base)[3], int f) {
 #ifndef RR_PD
 #define RR_PD 4
 #endif
+// prescribes the issue order inside one fenced group: NM x (one MFMA, then NV vector instructions).  A wave issues in order, and an
+// MFMA behind an MFMA waits 32 cycles for the pipe: only vector work placed BETWEEN two MFMAs runs under the first one
+// (scripts/micro/issue_mix.hip: MFMA + 4 v_fma = 34 cycles, + 8 = 52; a second wave's vector stream beside an MFMA stream: both ~1.6x slower).
+#ifdef RR_NOMIX
+#define RR_MIX(NM, NV)
+#else
+#define RR_MIX(NM, NV) _Pragma("unroll") for (int mix_q = 0; mix_q < (NM); ++mix_q) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, (NV), 0); }
+#endif
 // diagnostic builds (scripts/rr_variant.sh): RR_ABL_NOMFMA / NOLDS / NOSTREAM / NOGATHER / NOSTORE switch one kind of work off (results are
 // then garbage) to see what the kernel's time is sensitive to
 #ifdef RR_ABL_NOMFMA
@@ -775,17 +783,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             float inv2 = rr_pow2(e2 - 14 - E1);                          // 1 / (row scale x matrix scale of stage 1)
             if (m2b >= 0x7f800000u || badrow) { f2 = __uint_as_float(0x7fc00000u); inv2 = f2; badrow = true; }
             const bool anybad = __builtin_amdgcn_ballot_w64(badrow) != 0ull;
+            // (the fp16 planes of H are made 16 hidden features at a time UNDER the first products of node stage 1, below)
             rr_u4 Hh[NKS], Hl[NKS];
+            auto hsplit = [&](int c) {
+                const int fbo = c >> 1, cc = c & 1;
+                unsigned h[4], l[4];
 #pragma unroll
-            for (int fbo = 0; fbo < WB; ++fbo)
-#pragma unroll
-                for (int cc = 0; cc < 2; ++cc) {
-                    unsigned h[4], l[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) rr_split2s(hacc[fbo][8 * cc + 2 * q], hacc[fbo][8 * cc + 2 * q + 1], f2, h[q], l[q]);
-                    Hh[2 * fbo + cc] = rr_u4{h[0], h[1], h[2], h[3]};
-                    Hl[2 * fbo + cc] = rr_u4{l[0], l[1], l[2], l[3]};
-                }
+                for (int q = 0; q < 4; ++q) rr_split2s(hacc[fbo][8 * cc + 2 * q], hacc[fbo][8 * cc + 2 * q + 1], f2, h[q], l[q]);
+                Hh[c] = rr_u4{h[0], h[1], h[2], h[3]};
+                Hl[c] = rr_u4{l[0], l[1], l[2], l[3]};
+            };
+            hsplit(0);
             float invr[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) invr[r] = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * rr_crow(r, lh), __float_as_int(inv2)));
@@ -814,6 +822,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     RR_MFH(Hh[c], b1l, o1);
                     RR_MFH(Hh[c], b0h, o0);
                     RR_MFH(Hh[c], b1h, o1);
+                    if (fp == 0 && c + 1 < NKS) { hsplit(c + 1); RR_MIX(6, 4) }       // the planes of the next 16 hidden features, under the products
                     RR_SB();
                     b0h = n0h; b0l = n0l; b1h = n1h; b1l = n1l;
                 }
