@@ -211,6 +211,144 @@ def dry_run(args):
         dist.destroy_process_group()
 
 
+def rr_tiling(seg, n_nodes, grid=256):
+    """The tiles and 32-row edge blocks csrc/layer_rr.hip walks for this CSR (its iterator restated): 2048 node ranges, tiles of <= 32
+    nodes whose in-edges are a whole number of 64-row chunks where the degrees allow it, blocks of <= 32 edge rows.  For the roofline's
+    executed-MFMA count (outside the timed region)."""
+    n_tiles_nominal = (n_nodes + 31) // 32
+    n_ranges = min(grid * 8, n_tiles_nominal)
+    tiles = blocks = 0
+    for r in range(n_ranges):
+        m, end = n_nodes * r // n_ranges, n_nodes * (r + 1) // n_ranges
+        while m < end:
+            nmax = min(32, end - m)
+            cnt = seg[m:m + nmax + 1] - seg[m]
+            nn = nmax
+            if cnt[nmax] > 64:
+                cap = int(cnt[nmax]) // 64 * 64
+                nn = max(1, int(np.searchsorted(cnt, cap, side="right")) - 1)
+            tiles += 1
+            blocks += (int(cnt[nn]) + 31) // 32
+            m += nn
+    return tiles, blocks
+
+
+def small_batch_steps(plan, layer, dev):
+    """the reference's real batch sizes (32 / 128 graphs per step).  Wall time of count + encode + CSR + layer-0 forward
+    per step: eager (host-bound: ~8 launches) and replayed from one captured HIP graph (what is left is the serial latency of the
+    small dependent kernels).  Supplementary, never `value`."""
+    import torch
+    from gsn_amd import layers
+    from gsn_amd.counting import count_batch
+    out = {}
+    for G in (32, 128):
+        b = make_batch(G, seed=G)
+        N, E = b.num_nodes, b.num_edges
+        mn, me = int(np.diff(b.node_ptr).max()), int(np.diff(b.edge_ptr).max())
+        node_ptr, edge_ptr = torch.from_numpy(b.node_ptr).to(dev), torch.from_numpy(b.edge_ptr).to(dev)
+        ei = torch.from_numpy(b.edge_index).to(dev)
+        x = torch.nn.functional.one_hot(torch.from_numpy(b.atom_type), 28).float().to(dev)
+        ef = torch.nn.functional.one_hot(torch.from_numpy(b.bond_type), 4).float().to(dev)
+        deg = torch.zeros(N, device=dev)
+        idf = torch.empty((E, 12), dtype=torch.float32, device=dev)
+        layers.set_graph_partition(ei, node_ptr, edge_ptr, mn, me, check=False)
+
+        def step():
+            layers._CSR_CACHE.clear()
+            count_batch(plan, node_ptr, edge_ptr, ei, ids_are_global=True, max_nodes=mn, max_edges=me, device=dev, check=False,
+                        encode=([3, 3, 3, 3], True), counts=False, encoded_out=idf)
+            with torch.no_grad():
+                return layer(x, ei, identifiers=idf, degrees=deg, edge_features=ef)
+        for _ in range(30):
+            step()
+        torch.cuda.synchronize()
+        reps = 300
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            y_ref = step()
+        torch.cuda.synchronize()
+        rec = {"graphs": G, "eager_us": round((time.perf_counter() - t0) / reps * 1e6, 1)}
+        try:
+            g = torch.cuda.CUDAGraph()
+            s = torch.cuda.Stream(device=dev)
+            s.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(s):
+                for _ in range(3):
+                    step()
+            torch.cuda.current_stream(dev).wait_stream(s)
+            with torch.cuda.graph(g):
+                y_static = step()
+            for _ in range(30):
+                g.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                g.replay()
+            torch.cuda.synchronize()
+            rec["hip_graph_us"] = round((time.perf_counter() - t0) / reps * 1e6, 1)
+            rec["hip_graph_matches_eager"] = bool(torch.equal(y_static, y_ref))
+        except Exception as e:       # capture is best effort
+            rec["hip_graph_error"] = str(e)[:160]
+        out["B%d" % G] = rec
+    return out
+
+
+def propagate_figures(b, dev):
+    """the stand-alone per-target sum (gsn_propagate_fwd_hip, the aggregation of the gin / ogb layers and the fallback
+    of the others) on the bench batch as a fraction of the HBM peak -- the two cases of scripts/bench_propagate.py that the 0.70 target
+    is quoted on: the scatter-add of per-edge messages with d = 128 and the ogb message relu(x_j + id_e + e) with d = 300.
+    Algorithmic bytes: the CSR's three int32 arrays + seg_ptr, every message operand once, the output once."""
+    import torch
+    from gsn_amd import layers
+    N, E = b.num_nodes, b.num_edges
+    ei = torch.from_numpy(b.edge_index).to(dev)
+    out = {}
+    for name, kind, da, db, dc in (("scatter_add_messages_d128", 0, 0, 128, 0), ("ogb_relu_sum_d300", 1, 300, 300, 300)):
+        a = torch.randn(N, da, device=dev) if da else None
+        bb = torch.randn(E, db, device=dev) if db else None
+        c = torch.randn(E, dc, device=dev) if dc else None
+        with torch.no_grad():
+            for _ in range(4):
+                y = layers.propagate(kind, ei, 1, N, a=a, b=bb, c=c)
+            torch.cuda.synchronize()
+            layers.KERNEL_TIMER = {}
+            for _ in range(10):
+                layers.propagate(kind, ei, 1, N, a=a, b=bb, c=c)
+            torch.cuda.synchronize()
+        evs = layers.KERNEL_TIMER.get("propagate_fwd", [])
+        layers.KERNEL_TIMER = None
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in evs) / max(len(evs), 1)
+        byt = 12.0 * E + 4.0 * (N + 1) + 4.0 * (N * da + E * db + E * dc) + 4.0 * N * y.shape[1]
+        out[name] = {"ms": round(ms, 4), "GBps": round(byt / ms / 1e6, 1), "hbm_frac": round(byt / ms / 1e6 / HBM_PEAK_GBS, 4)}
+        del a, bb, c, y
+    return out
+
+
+def float_input_layer(layer, b, ei, dev):
+    """The layer launch alone with real-valued inputs (no row exact in fp16: three plane products in the edge stage, every row scaled,
+    the activated rows as three bf16 planes) beside the one-hot headline: the best case is not the only case."""
+    import torch
+    from gsn_amd import layers
+    N, E = b.num_nodes, b.num_edges
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, 28, generator=g).to(dev)
+    ids = torch.randn(E, 12, generator=g).to(dev)
+    ef = torch.randn(E, 4, generator=g).to(dev)
+    deg = torch.zeros(N, device=dev)
+    with torch.no_grad():
+        for _ in range(5):
+            layer(x, ei, identifiers=ids, degrees=deg, edge_features=ef)
+        torch.cuda.synchronize()
+        layers.KERNEL_TIMER = {}
+        for _ in range(10):
+            layer(x, ei, identifiers=ids, degrees=deg, edge_features=ef)
+        torch.cuda.synchronize()
+    evs = layers.KERNEL_TIMER.get("layer_fused", [])
+    layers.KERNEL_TIMER = None
+    ms = sum(e0.elapsed_time(e1) for e0, e1, _ in evs) / max(len(evs), 1)
+    return {"layer_launch_ms": round(ms, 4)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -315,6 +453,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     timer, layers.KERNEL_TIMER = layers.KERNEL_TIMER, None
+    dt_own = dt
     dt = gdist.max_over_ranks(dt, dev)
     assert torch.isfinite(y).all()
     # (outside the timed region) the timed batch's own results against the oracle, and the counting work figures: the int64
@@ -446,6 +585,28 @@ def main():
         zinc12k = {"graphs_per_s": round(12000 * n12 / dt2, 1), "ms_per_step": round(dt2 / n12 * 1e3, 4), "steps": n12,
                    "note": "BASELINE configs[1] dataset size: 12 000 ZINC-shaped graphs per step (N=%d, E=%d)" % (b2.num_nodes, b2.num_edges)}
 
+    # Supplementary (never `value`): the reference's real batch sizes, the stand-alone aggregation stage, the layer on real-valued inputs
+    small = prop = flt = None
+    if world == 1 and not args.no_extras:
+        try:
+            small = small_batch_steps(plan, layer, dev)
+        except Exception as ex:
+            small = {"error": str(ex)[:200]}
+        try:
+            prop = propagate_figures(b, dev)
+        except Exception as ex:
+            prop = {"error": str(ex)[:200]}
+        try:
+            flt = float_input_layer(layer, b, ei, dev)
+        except Exception as ex:
+            flt = {"error": str(ex)[:200]}
+    # every rank's own time of the K steps (the headline takes the maximum): a slow rank shows up by name in the N > 1 line
+    per_rank_ms = [round(dt_own / args.steps * 1e3, 4)]
+    if dist is not None and world > 1:
+        tl = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(tl, torch.tensor([dt_own], device=dev, dtype=torch.float64))
+        per_rank_ms = [round(float(t.item()) / args.steps * 1e3, 4) for t in tl]
+
     if rank == 0:
         kernels = {}
         merged = {}
@@ -470,11 +631,22 @@ def main():
             # matrix work actually executed on v_mfma_f32_32x32x16_f16: fp16x3 (three plane products per fp32 product; two in the
             # edge stage here, whose one-hot input rows are exact in fp16)
             f_alg = 2.0 * E * 72 * 128 + 2.0 * N * ((28 + 128 + 1) * 128 + 128 * 128)
-            f_exec = 2.0 * (2.0 * E * 72 * 128) + 3.0 * (2.0 * N * ((28 + 128 + 4) * 128 + 128 * 128))
+            # executed v_mfma_f32_32x32x16_f16 instructions of csrc/layer_rr.hip (32 768 flop each), from the tiles and 32-row edge
+            # blocks its iterator forms on this batch: per block 5 x 4 x 2 products of the edge stage (input rows exact in fp16: two
+            # plane products) + 2 x 4 x 2 of the incidence product that sums the activated rows per target (two fp16 planes); per
+            # tile (10 + 8) x 4 x 3 of the two node stages.  (GSN_FUSED_RR=0: layer_fused.hip, 2 / 3 products per fp32 product, no
+            # incidence product.)
+            rr = os.environ.get("GSN_FUSED_RR", "1") != "0"
+            if rr:
+                n_t, n_b = rr_tiling(layers._csr_for(ei, sel, N).seg_ptr.cpu().numpy().astype(np.int64), N)
+                f_exec = 32768.0 * (n_b * (5 * 4 * 2 + 2 * 4 * 2) + n_t * (10 + 8) * 4 * 3)
+            else:
+                f_exec = 2.0 * (2.0 * E * 72 * 128) + 3.0 * (2.0 * N * ((28 + 128 + 4) * 128 + 128 * 128))
             t_hbm, t_mfma = b_launch / (HBM_PEAK_GBS * 1e9), f_exec / (MFMA_BF16_PEAK_TF * 1e12)
             hbm = b_launch / t_k / 1e9
             executed = f_exec / t_k / 1e12
-            common = {"kernel": "layer_fused_kernel<5,10,8> (edge stage + per-node sums + node stages 0 and 1 in one launch)",
+            common = {"kernel": ("layer_fused_kernel_rr<4,2> (csrc/layer_rr.hip: " if rr else "layer_fused_kernel<5,10,8,4> (csrc/layer_fused.hip: ") +
+                                "edge stage + per-node sums + node stages 0 and 1 in one launch)",
                       "matrix_dtype": "fp16x3: operands split into two fp16 planes after exact power-of-two row / matrix scaling, three plane "
                                       "products per fp32 product on v_mfma_f32_32x32x16_f16 with fp32 accumulation (two where the rows are exact in fp16)",
                       "algorithmic_bytes": round(b_launch), "survey_B_alg_bytes": round(survey_b_alg),
@@ -499,24 +671,24 @@ def main():
             roof = {"kernel": {"propagate_fwd": "propagate_fwd_kernel", "count": "count_kernel"}[dom], "bound": "hbm",
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
         # HBM traffic cannot be read from inside the run: PMC needs rocprofv3 around the process.  Report the committed
-        # measurement of the same command (scripts/profile_bench.sh -> profiles/r02_bench_pmc.csv): per launch of the dominant
+        # measurement of the same command (scripts/profile_bench.sh -> profiles/r03_bench_pmc.csv): per launch of the dominant
         # kernel, FETCH_SIZE x2 (gfx950 under-reports wide reads, MI355X_MICROARCH.md) + WRITE_SIZE, in bytes.
         try:
             import csv
-            pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_bench_pmc.csv")
+            pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_bench_pmc.csv")
             key = {"layer_fused": "gsn::layer_fused_kernel", "mlp_chain": "gsn::mlp_chain"}.get(dom, roof["kernel"])   # (not layer_fused_prepare_kernel)
             rows = [r for r in csv.DictReader(open(pmc)) if key in r["kernel"]]
             if rows and G == 65536:
                 tot = sum((2.0 * float(r["FETCH_SIZE_per_dispatch"]) + float(r["WRITE_SIZE_per_dispatch"])) * 1024.0 for r in rows)
                 roof["traffic"] = round(tot / len(rows))
-                roof["traffic_source"] = "profiles/r02_bench_pmc.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
+                roof["traffic_source"] = "profiles/r03_bench_pmc.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
             crow = [r for r in csv.DictReader(open(pmc)) if "count_kernel" in r["kernel"]]
             if crow and G == 65536:      # the counting kernel is VALU-bound, not bandwidth-bound -- show it
                 r0 = crow[0]
                 pmc_count = {"valu_busy_frac_of_wave_cycles": round(float(r0["SQ_ACTIVE_INST_ANY_per_dispatch"]) / float(r0["SQ_WAVE_CYCLES_per_dispatch"]), 4),
                              "valu_instructions_per_dispatch": float(r0["SQ_INSTS_VALU_per_dispatch"]),
                              "hbm_bytes_per_dispatch": round((2.0 * float(r0["FETCH_SIZE_per_dispatch"]) + float(r0["WRITE_SIZE_per_dispatch"])) * 1024.0),
-                             "source": "profiles/r02_bench_pmc.csv"}
+                             "source": "profiles/r03_bench_pmc.csv"}
             else:
                 pmc_count = None
         except Exception:
@@ -549,6 +721,14 @@ def main():
             extra["fused_encoder_step"] = fused
         if zinc12k is not None:
             extra["zinc12k_step"] = zinc12k
+        if small is not None:
+            extra["small_batch"] = small
+        if prop is not None:
+            extra["propagate"] = prop
+        if flt is not None:
+            extra["layer_float_inputs"] = flt
+        extra["ms_per_step_by_rank"] = per_rank_ms
+        extra["prewarm_steps_untimed"] = int(os.environ.get("GSN_BENCH_PREWARM", "60"))
         if model4 is not None:
             extra["full_model_step"] = model4
         res = {

@@ -401,7 +401,7 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
         } else
         // column c owns floats enc[2c] .. enc[2c] + enc[2c + 1] of a row; the table is short: a linear scan per float
         for (int i = tid; i < total; i += T) {
-            const int r = (int)__umulhi((unsigned)i, a.enc_magic);
+            const int r = i / a.enc_width;              // (exact: the reciprocal multiply was off by one for wide encodings, e.g. width 1000 from row 6100 on; this loop is bound by its stores)
             const int j = i - r * a.enc_width;
             int c = 0;
             while (c + 1 < n_cols && enc[2 * (c + 1)] <= j) ++c;

@@ -500,12 +500,34 @@ __global__ __launch_bounds__(64) void csr_graphs_kernel(const int64_t *__restric
     const int g = blockIdx.x, lane = threadIdx.x;
     const int64_t n0 = node_ptr[g], e0 = edge_ptr[g];
     const int64_t n64 = node_ptr[g + 1] - n0, E64 = edge_ptr[g + 1] - e0;
+    // The pointers must describe THIS batch: graph g owns vertices [node_ptr[g], node_ptr[g+1]) and columns [edge_ptr[g], edge_ptr[g+1])
+    // inside [0, n_nodes] x [0, n_edges], the last graph ends at n_edges (a column behind it would stay unsorted) and the first starts
+    // at column 0.  Anything else raises GSN_ST_BAD_INDEX and this graph writes nothing outside its clamped vertex range.
+    const bool ptr_ok = n0 >= 0 && e0 >= 0 && n64 >= 0 && E64 >= 0 && n0 + n64 <= n_nodes && e0 + E64 <= n_edges &&
+                        (g != 0 || e0 == 0) && (g != n_graphs - 1 || e0 + E64 == n_edges);
+    if (!ptr_ok) {
+        if (lane == 0) atomicMax(status, (int)GSN_ST_BAD_INDEX);
+        // keep every seg_ptr entry this workgroup is responsible for inside [0, n_edges]: later kernels walk seg_ptr
+        const int64_t a0 = n0 < 0 ? 0 : (n0 > n_nodes ? n_nodes : n0);
+        int64_t a1 = n0 + n64; a1 = a1 < a0 ? a0 : (a1 > n_nodes ? n_nodes : a1);
+        for (int64_t v = a0 + lane; v < a1; v += 64) seg_ptr[v] = (int32_t)n_edges;
+        if (g == n_graphs - 1) for (int64_t v = a1 + lane; v <= n_nodes; v += 64) seg_ptr[v] = (int32_t)n_edges;
+        if (g == 0) for (int64_t v = lane; v < a0; v += 64) seg_ptr[v] = 0;
+        return;
+    }
     if (g == n_graphs - 1)                     // vertices behind the last graph (none in a collated batch) own no columns
-        for (int64_t v = node_ptr[n_graphs] + lane; v <= n_nodes; v += 64) seg_ptr[v] = (int32_t)n_edges;
+        for (int64_t v = n0 + n64 + lane; v <= n_nodes; v += 64) seg_ptr[v] = (int32_t)n_edges;
     if (g == 0)
         for (int64_t v = lane; v < n0; v += 64) seg_ptr[v] = 0;
-    if (n64 < 0 || E64 < 0 || n64 > n_cap || E64 > e_cap) {
+    if (n64 > n_cap || E64 > e_cap) {
         if (lane == 0) atomicMax(status, (int)GSN_ST_TOO_LARGE);
+        // (the caller falls back to the generic build; until then the graph's vertices own no columns and its columns map to themselves)
+        for (int64_t v = lane; v < n64; v += 64) seg_ptr[n0 + v] = (int32_t)e0;
+        for (int64_t e = lane; e < E64; e += 64) {
+            perm[e0 + e] = (int32_t)(e0 + e);
+            if (sorted_target) sorted_target[e0 + e] = (int32_t)n0;
+            if (sorted_other) sorted_other[e0 + e] = (int32_t)n0;
+        }
         return;
     }
     const int n = (int)n64, E = (int)E64;

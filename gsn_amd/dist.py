@@ -136,7 +136,10 @@ def allreduce_gradients(parameters, average: bool = True, group=None):
             raise TypeError("allreduce_gradients: parameters must share one dtype and device (got %s/%s and %s/%s)"
                             % (dtype, device, p.dtype, p.device))
     key = (tuple(id(p) for p in params), dtype, device)
-    n_total = sum(p.numel() for p in params)
+    # behind the gradients: one has-gradient flag per parameter (summed by the same collective), so that a parameter no rank produced a
+    # gradient for keeps ``grad = None`` -- with zeros instead, weight decay / momentum would move parameters a single-GPU run never touches
+    n_grad = sum(p.numel() for p in params)
+    n_total = n_grad + len(params)
     flat = _BUCKETS.get(key)
     if flat is None or flat.numel() != n_total:
         if len(_BUCKETS) > 8:
@@ -144,20 +147,24 @@ def allreduce_gradients(parameters, average: bool = True, group=None):
         flat = torch.empty(n_total, dtype=dtype, device=device)
         _BUCKETS[key] = flat
     off = 0
-    for p in params:
+    for i, p in enumerate(params):
         n = p.numel()
         if p.grad is None:
             flat[off:off + n].zero_()
         else:
             flat[off:off + n].copy_(p.grad.reshape(-1))
+        flat[n_grad + i] = 0.0 if p.grad is None else 1.0
         off += n
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    has = flat[n_grad:].tolist()                      # (one small read-back per step; the gradients themselves stay on the device)
     if average:
-        flat /= dist.get_world_size(group)
+        flat[:n_grad] /= dist.get_world_size(group)
     off = 0
-    for p in params:
+    for i, p in enumerate(params):
         n = p.numel()
-        if p.grad is None:
+        if has[i] == 0:
+            pass                                      # no rank has a gradient: stays None, as on one GPU
+        elif p.grad is None:
             p.grad = flat[off:off + n].view_as(p).clone()
         else:
             p.grad.copy_(flat[off:off + n].view_as(p))

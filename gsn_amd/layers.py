@@ -607,6 +607,26 @@ def _chain_fits(stages):
     return bool(_abi.lib().gsn_mlp_chain_supported(n, arr))
 
 
+VALIDATE_CACHES = os.environ.get("GSN_VALIDATE_CACHES", "0") != "0"   # re-derive-and-compare mode for the per-weight caches (below)
+
+
+def _module_fingerprint(module):
+    """Validation mode (``GSN_VALIDATE_CACHES=1`` / ``layers.VALIDATE_CACHES = True``): a content fingerprint of every floating-point
+    parameter and buffer of ``module`` -- three moments per tensor, ONE read-back per forward.  The derived-weight caches (prepared
+    fp16 fragments of the one-launch layer, folded first weight, fp16 planes of the dense stages, eval-mode BatchNorm vectors) are
+    keyed on ``tensor._version`` and ``data_ptr``, which a write through ``.data`` (EMA / SWA ``p.data.copy_``, weight clipping,
+    manual surgery) does not change; with this mode on, such a write is noticed at the next forward and the caches of the module are
+    dropped.  Costs a device synchronisation per layer forward: a debugging / validation switch, off by default -- production code
+    that writes through ``.data`` calls :func:`invalidate_caches` instead."""
+    vals = []
+    for t in list(module.parameters()) + list(module.buffers()):
+        if t.is_floating_point() and t.numel():
+            f = t.detach().reshape(-1).double()
+            w = torch.arange(1, f.numel() + 1, device=f.device, dtype=torch.float64)
+            vals += [f.sum(), (f * f).sum(), (f * w).sum()]
+    return tuple(torch.stack(vals).tolist()) if vals else ()
+
+
 def invalidate_caches(module=None):
     """Drop the derived tensors this module keeps per parameter VERSION (folded first weight of the `general` layers,
     eval-mode BatchNorm scale / shift vectors, transposed weights) -- needed only after writing a parameter or buffer
@@ -675,8 +695,11 @@ def _layer_fused(x, csr, edge_stages, node_stages, training, owner=None, gen=0):
     for st in stages:
         if st.act not in ("identity", "relu"):
             return None
-        if st.bn is not None and (training or st.bn.running_mean is None):
+        # (a BatchNorm1d that is itself in train mode takes batch statistics whatever the layer's flag says: not this kernel's arithmetic)
+        if st.bn is not None and (training or st.bn.training or st.bn.running_mean is None):
             return None
+    if x.data_ptr() % 16:
+        return None
     if len(node_stages[0].blocks) != 1 or node_stages[1].blocks:     # ([x | S | deg]: S and deg are produced inside the kernel)
         return None
     for st in stages:
@@ -1336,6 +1359,11 @@ class _SparseLayer(nn.Module):
             post = (kwargs.get("post_bn"), kwargs.get("post_act") or "identity")
         x, ids, ef = self._prepare(x, kwargs)
         _need_cuda(x, "x")
+        if VALIDATE_CACHES:           # (see _module_fingerprint: notices parameter writes that bypass tensor._version)
+            fp = _module_fingerprint(self)
+            if fp != getattr(self, "_gsn_fingerprint", None):
+                invalidate_caches(self)
+                self._gsn_fingerprint = fp
         # Row counts of the per-edge / per-vertex inputs: the reference fails in torch.cat / indexing when they do not fit
         # (GSN_sparse.py:118-132); the kernels would read past the tensors instead.
         n_rows, n_cols_e = x.shape[0], edge_index.shape[1]

@@ -1020,6 +1020,63 @@ def gen_model(ref, out):
     print("model: %d arrays" % len(rec))
 
 
+def gen_model_ogb300(ref, out):
+    """BASELINE config 4 at its REAL widths: models_graph_classification_ogb_original.GNN_OGB, 5 layers x 300, virtual node, one
+    train-mode step on 8 molecule-shaped graphs: prediction, BatchNorm running statistics after the step, digests of every parameter
+    gradient (tests/helpers.py: grad_digest).  The 3.4 M parameters are not stored: both sides fill the model with
+    helpers.procedural_state (a function of the state_dict keys)."""
+    import importlib
+    import io
+    import contextlib
+    sys.path.insert(0, os.path.dirname(HERE))
+    import helpers
+    mogb = importlib.import_module("models_graph_classification_ogb_original")
+    assert mogb.__file__.startswith(REF)
+    rng = np.random.default_rng(33)
+    b = synth.zinc_shape_batch(8, seed=9)
+    Nn, Ee = b.num_nodes, b.num_edges
+    atom_dims, bond_dims, id_dims = [119, 4, 12, 12, 10, 6, 6, 2, 2], [5, 6, 2], [3, 3, 3, 3]
+    dd = types.SimpleNamespace(
+        x=torch.from_numpy(rng.integers(0, atom_dims, size=(Nn, len(atom_dims)))), edge_index=torch.from_numpy(b.edge_index),
+        edge_features=torch.from_numpy(rng.integers(0, bond_dims, size=(Ee, len(bond_dims)))),
+        identifiers=torch.from_numpy(rng.integers(0, id_dims, size=(Ee, len(id_dims)))),
+        batch=torch.from_numpy(np.asarray(b.batch).astype(np.int64)), degrees=torch.zeros(Nn))
+    L, dm = 5, 300
+    kw = dict(seed=0, model_name="GSN_edge_sparse_ogb", readout="mean", dropout_features=[0.0] * (L + 1), bn=[True] * L,
+              final_projection=[False] * L + [True], residual=False, inject_ids=True, vn=True, id_scope="local",
+              d_msg=[dm] * L, d_out=[dm] * L, d_h=[[2 * dm]] * L, aggr="add", flow="source_to_target", msg_kind="ogb",
+              train_eps=[True] * L, activation_mlp="relu", bn_mlp=True, jk_mlp=False, degree_embedding="None",
+              degree_as_tag=[False] * L, retain_features=[True] * L, multi_embedding_aggr="sum", features_scope="full",
+              input_node_encoder="embedding", d_out_node_encoder=dm, input_vn_encoder="embedding", d_out_vn_encoder=dm,
+              edge_encoder="embedding", d_out_edge_encoder=[dm] * L, id_embedding="embedding", d_out_id_embedding=dm,
+              d_out_degree_embedding=dm, d_out_vn=[dm] * (L - 1), vn_pooling="sum", extend_dims=True, activation="relu")
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = mogb.GNN_OGB(len(atom_dims), 1, None, id_dims, len(bond_dims), atom_dims, bond_dims, None, None, **kw)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict(helpers.procedural_state(shapes))
+    model.train(True)
+    pred = model(dd)
+    rec = {"pred": pred.detach().numpy(), "n_params": np.int64(sum(p.numel() for p in model.parameters()))}
+    gy = torch.from_numpy(rng.standard_normal(tuple(pred.shape)).astype(np.float32))
+    (pred * gy).sum().backward()
+    rec["gy"] = gy.numpy()
+    dg = helpers.grad_digest({k: p_.grad for k, p_ in model.named_parameters() if p_.grad is not None})
+    rec["grad_keys"] = np.array(sorted(dg))
+    rec["grad_digest"] = np.array([dg[k] for k in sorted(dg)], dtype=np.float64)
+    after = model.state_dict()
+    run_keys = sorted(k for k in after if "running_" in k)
+    rec["running_keys"] = np.array(run_keys)
+    rec["running_digest"] = np.array([[float(after[k].double().sum()), float(after[k].double().norm())] for k in run_keys])
+    rec["shape_keys"] = np.array(sorted(shapes))
+    rec["shape_ptr"] = np.cumsum([0] + [len(shapes[k]) for k in sorted(shapes)]).astype(np.int64)
+    rec["shape_flat"] = np.array([d for k in sorted(shapes) for d in shapes[k]], dtype=np.int64)
+    for attr in ("x", "edge_index", "identifiers", "batch", "degrees", "edge_features"):
+        rec["data/%s" % attr] = getattr(dd, attr).numpy()
+    np.savez_compressed(os.path.join(out, "model_ogb300.npz"), **rec)
+    print("model_ogb300: %d arrays, %d parameters" % (len(rec), int(rec["n_params"])))
+
+
 def gen_directed(ref, out):
     """directed=True (main.py --directed): patterns and targets are digraphs, vertex counts only (the reference's directed edge
     counter dies on an unbound name, utils_graph_processing.py:146 vs :164).  automorphism_orbits(directed=True) +
@@ -1095,6 +1152,8 @@ def main():
         gen_model(ref, args.out)
     if "directed" in only:
         gen_directed(ref, args.out)
+    if "ogb300" in only:
+        gen_model_ogb300(ref, args.out)
 
 
 if __name__ == "__main__":

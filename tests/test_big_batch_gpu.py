@@ -58,10 +58,10 @@ def test_layer_classes_at_several_widths_on_many_row_tiles(cls, d, kind, trainin
     from oracle import oracle
     if training and d in (16, 48, 100, 160, 200) and not (cls == "GSN_edge_sparse" and kind == "general"):
         pytest.skip("train-mode forward at the odd widths: one class is enough (same dense kernels)")
-    if training and d == 300:
-        pytest.skip("covered by the config-4 golden and the training-step scripts; the oracle's CPU pass at d = 300 takes minutes")
     torch.manual_seed(d + len(cls))
-    b = synth.zinc_shape_batch(2048, seed=21)
+    # (d = 300, BASELINE config 4's width: 256 graphs -- 6 k vertices, 12 k edge rows, still several row tiles of the dense kernels --
+    #  keep the oracle's CPU pass at seconds, in eval AND in train mode)
+    b = synth.zinc_shape_batch(256 if d == 300 else 2048, seed=21)
     N, E = b.num_nodes, b.num_edges
     ctor, d_x, d_id, d_ef = _case(cls, d, kind)
     layer = getattr(layers, cls)(**ctor)
@@ -93,7 +93,8 @@ def test_layer_classes_at_several_widths_on_many_row_tiles(cls, d, kind, trainin
 
 
 @pytest.mark.parametrize("cls,d,kind", [("GSN_edge_sparse", 64, "general"), ("GSN_edge_sparse", 128, "general"), ("GSN_sparse", 64, "gin"),
-                                        ("MPNN_edge_sparse", 96, "general"), ("GSN_edge_sparse_ogb", 64, "ogb"), ("GSN_edge_sparse", 32, "gin")])
+                                        ("MPNN_edge_sparse", 96, "general"), ("GSN_edge_sparse_ogb", 64, "ogb"), ("GSN_edge_sparse", 32, "gin"),
+                                        ("GSN_edge_sparse_ogb", 300, "ogb"), ("MPNN_edge_sparse_ogb", 300, "ogb")])
 def test_train_mode_backward_on_many_row_tiles(cls, d, kind):
     """Forward + backward in training mode (batch-statistics BatchNorm) on the multi-tile batch: gradients of the inputs and of
     every parameter against PyTorch autograd over the oracle's restatement (the goldens' backward cases are small graphs).
@@ -103,7 +104,7 @@ def test_train_mode_backward_on_many_row_tiles(cls, d, kind):
     from gsn_amd import layers, synth
     from oracle import oracle
     torch.manual_seed(d + len(cls) + 1)
-    b = synth.zinc_shape_batch(2048, seed=22)
+    b = synth.zinc_shape_batch(256 if d == 300 else 2048, seed=22)     # (d = 300: config 4's width on linear_f16x3 + wgrad, oracle pass in seconds)
     N, E = b.num_nodes, b.num_edges
     ctor, d_x, d_id, d_ef = _case(cls, d, kind)
     if not cls.endswith("_ogb"):
@@ -131,15 +132,26 @@ def test_train_mode_backward_on_many_row_tiles(cls, d, kind):
     idg = efg = None
     if has_ids:
         idg = ids.cuda().requires_grad_(True); kw["identifiers"] = idg
+    elif cls.endswith("_ogb"):
+        kw["identifiers"] = None                 # (the ogb classes take the keyword whether they use it or not, MPNN_edge_sparse_ogb.py:63)
     if has_ef:
         efg = ef.cuda().requires_grad_(True); kw["edge_features"] = efg
     y = layer(xg, ei.cuda(), **kw)
     assert rel_err(y.detach().cpu(), ref.detach()) < TOL
     (y * w_out.cuda()).sum().backward()
-    BT = 5e-5
+    BT = 2e-5
     grads = {k: v.grad for k, v in sd.items() if v.requires_grad and v.grad is not None}
     FL = 0.02 * max([float(g.abs().max()) for g in grads.values()] + [0.5])
-    assert rel_err(xg.grad.cpu(), xr.grad, FL) < BT
+    if cls.endswith("_ogb") and d == 300:
+        # The ogb layers are relu by definition (message relu(x_j + ..), *_ogb.py:100; hidden layer of update_fn): no C1 variant.  With
+        # 3.6 M relu units in this pass a pre-activation within rounding distance of zero is likely, and two correct implementations then
+        # put that unit on different sides of the kink.  Behind a train-mode BatchNorm one flipped unit moves the batch statistics of its
+        # feature, i.e. the gradient of EVERY row in that column by ~1 / rows: 1.6e-4 on this 6 k-row batch (seen: 2.3e-4), 2e-5 on the
+        # 47 k-row batches of the other cases, which keep the sharp bar.
+        BT = 5e-4
+        assert rel_err(xg.grad.cpu(), xr.grad, FL) < BT
+    else:
+        assert rel_err(xg.grad.cpu(), xr.grad, FL) < BT
     if idg is not None:
         assert rel_err(idg.grad.cpu(), idr.grad, FL) < BT
     if efg is not None:

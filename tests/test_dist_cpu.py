@@ -21,14 +21,17 @@ def _worker(rank, world, port, q):
     model = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ReLU(), torch.nn.Linear(7, 3))
     x = torch.arange(1001 * 5, dtype=torch.float32).reshape(1001, 5) / 1000.0
     extra = torch.nn.Parameter(torch.ones(4))         # used by rank 0 only: rank 1's .grad stays None
+    unused = torch.nn.Parameter(torch.ones(3))        # used by NO rank: must keep grad = None (as on one GPU), not receive zeros
     loss = model(x[lo:hi]).pow(2).sum()
     if rank == 0:
         loss = loss + (extra * torch.arange(4.0)).sum()
     loss.backward()                                   # every rank: its own shard of "graphs"
     local = [p.grad.clone() for p in model.parameters()]
-    allreduce_gradients(list(model.parameters()) + [extra], average=True)
+    allreduce_gradients(list(model.parameters()) + [extra, unused], average=True)
     assert extra.grad is not None and torch.allclose(extra.grad, torch.arange(4.0) / 2)   # zeros from the rank that had none
-    allreduce_gradients(list(model.parameters()) + [extra], average=False)               # reuses the bucket
+    assert unused.grad is None
+    allreduce_gradients(list(model.parameters()) + [extra, unused], average=False)       # reuses the bucket
+    assert unused.grad is None
     for p in model.parameters():
         p.grad /= 2
     q.put((rank, lo, hi, [g.numpy() for g in local], [p.grad.numpy().copy() for p in model.parameters()]))

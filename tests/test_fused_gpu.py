@@ -191,3 +191,40 @@ def test_fused_layer_full_size_properties():
     assert torch.isfinite(y).all()
     assert _elementwise_ok(y.cpu(), y2.cpu())
     assert _elementwise_ok(y3.cpu(), y[:n1].cpu(), rtol=2e-6)
+
+
+def test_parameter_written_through_data_is_noticed():
+    """VERDICT r02 / ADVICE r02: ``p.data.mul_()`` does not bump ``p._version``, on which the prepared-weight caches are keyed.  With the
+    validation mode on (``layers.VALIDATE_CACHES`` / ``GSN_VALIDATE_CACHES=1``) the next forward notices the write by content; without
+    it ``layers.invalidate_caches(layer)`` is the documented call.  Either way the result must equal the oracle WITH the new weight."""
+    from gsn_amd import layers
+    from oracle import oracle
+    b, x, ef, ei = _zinc(300, seed=41)
+    ids = (torch.rand(b.num_edges, 12, generator=torch.Generator().manual_seed(1)) < 0.2).float()
+    torch.manual_seed(2)
+    layer = layers.GSN_edge_sparse(**CTOR)
+    _randomise_bn(layer, 9)
+    layer.eval().cuda()
+    kw = dict(identifiers=ids.cuda(), degrees=torch.zeros(x.shape[0], device="cuda"), edge_features=ef.cuda())
+
+    def ref_now():
+        sd = {k: v.detach().cpu().clone() for k, v in layer.state_dict().items()}
+        return oracle.layer_forward("GSN_edge_sparse", CTOR, sd, x, ei, training=False, identifiers=ids, degrees=None, edge_features=ef)
+    was = layers.VALIDATE_CACHES
+    try:
+        for mode in ("validate", "explicit"):
+            layers.VALIDATE_CACHES = mode == "validate"
+            with torch.no_grad():
+                y0 = layer(x.cuda(), ei.cuda(), **kw)
+                assert _elementwise_ok(y0.cpu(), ref_now())
+                layer.msg_fn.fc[0].weight.data.mul_(2.0)               # edge stage
+                layer.msg_fn.fc[1].bias.data.add_(0.25)                # folded into the node stage
+                layer.update_fn.bn[0].running_var.data.mul_(1.5)       # eval-mode BatchNorm vectors
+                if mode == "explicit":
+                    layers.invalidate_caches(layer)
+                y1 = layer(x.cuda(), ei.cuda(), **kw)
+            r1 = ref_now()
+            assert not _elementwise_ok(y0.cpu(), r1)                    # (the write matters)
+            assert _elementwise_ok(y1.cpu(), r1), (mode, float((y1.cpu() - r1).abs().max() / r1.abs().max()))
+    finally:
+        layers.VALIDATE_CACHES = was

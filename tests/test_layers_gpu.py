@@ -165,7 +165,7 @@ def test_layer_backward_golden(name):
     y = layer(x, ei, **kw)
     assert rel_err(y.detach(), torch.from_numpy(c["y"]).cuda()) < TOL
     (y * torch.from_numpy(c["w"]).cuda()).sum().backward()
-    BT = 5e-5  # gradients go through train-mode BN statistics twice; a little looser than the forward bar
+    BT = 2e-5  # gradients go through train-mode BN statistics twice; a little looser than the forward bar (1e-5)
     # a bias in front of a train-mode BatchNorm has an exactly-zero gradient: both sides hold only rounding noise there,
     # whose size follows the layer's overall gradient scale -> floor the denominator at 2% of the largest parameter gradient
     FL = 0.02 * max([float(np.abs(c[k]).max()) for k in c if k.startswith("gp/")] + [0.5])
@@ -641,6 +641,26 @@ def test_csr_of_a_collated_batch_in_one_launch():
         layers.build_csr_graphs(ei[1], N, npt, bad, mn, me + 2, other=ei[0])
     with pytest.raises(ValueError):                                   # under-declared bound
         layers.build_csr_graphs(ei[1], N, npt, ept, mn, 100, other=ei[0])
+    # pointers that leave the batch: reported, and nothing is written outside the arrays -- every seg_ptr entry stays in
+    # [0, E] also when the status word is not read (check=False, what bench.py does)
+    E = b.num_edges
+    for which, delta in (("node_end", 7), ("edge_end", 5), ("edge_short", -3), ("edge_start", 2), ("node_back", None)):
+        np2, ep2 = npt.clone(), ept.clone()
+        if which == "node_end":
+            np2[-1] += delta
+        elif which == "edge_end":
+            ep2[-1] += delta
+        elif which == "edge_short":
+            ep2[-1] += delta
+        elif which == "edge_start":
+            ep2[0] += delta
+        else:
+            np2[10] = np2[9] - 3                                       # not monotone
+        with pytest.raises(ValueError):
+            layers.build_csr_graphs(ei[1], N, np2, ep2, mn + 8, me + 8, other=ei[0])
+        out = layers.build_csr_graphs(ei[1], N, np2, ep2, mn + 8, me + 8, other=ei[0], check=False)
+        torch.cuda.synchronize()
+        assert int(out[0].min()) >= 0 and int(out[0].max()) <= E, which
     assert layers.set_graph_partition(ei, npt, ept, 40000, 100000) is False      # beyond the LDS bound: generic build
     # a layer forward is the same with and without the partition
     torch.manual_seed(0)
