@@ -50,6 +50,7 @@
 
 #include "chain_common.h"
 #include "layer_rr.h"
+#include "layer_w.h"
 
 namespace gsn {
 
@@ -1017,6 +1018,7 @@ using namespace gsn;
 extern "C" int gsn_layer_fused_supported(const gsn_chain_stage *edge, int64_t d_x, const gsn_chain_stage *node0,
                                          const gsn_chain_stage *node1) {
     if (!edge || !node0 || !node1) return 0;
+    if (w_supported(edge, d_x, node0, node1)) return 1;                // d_x = 128 (layer_w.hip)
     if (!lf_stage_ok(*edge) || !lf_stage_ok(*node0) || !lf_stage_ok(*node1)) return 0;
     if ((edge->n_out & 31) || (node0->n_out & 31)) return 0;           // the stagers own whole 32-column groups of S and H
     if (edge->n_blocks < 1 || edge->n_blocks > LF_MAXB || !edge->blocks) return 0;
@@ -1060,6 +1062,7 @@ static int64_t lf_prep_bytes_own(const LfArgs &a) { return (((int64_t)(LF_PREP_H
 extern "C" int64_t gsn_layer_fused_prepared_bytes(const gsn_chain_stage *edge, int64_t d_x, const gsn_chain_stage *node0,
                                                   const gsn_chain_stage *node1) {
     if (!gsn_layer_fused_supported(edge, d_x, node0, node1)) return 0;
+    if (w_supported(edge, d_x, node0, node1)) return w_prepared_bytes(edge, d_x, node0, node1);
     LfArgs a{};
     lf_fill_stages(a, edge, d_x, node0, node1);
     return lf_prep_bytes_own(a) + rr_prepared_bytes(edge, d_x, node0, node1);
@@ -1070,6 +1073,7 @@ extern "C" int gsn_layer_fused_prepare_hip(const gsn_chain_stage *edge, int64_t 
     if (!gsn_layer_fused_supported(edge, d_x, node0, node1))
         return set_error(GSN_E_UNSUPPORTED, "gsn_layer_fused_prepare_hip: shape outside the fused layer kernel");
     if (!prepared || (reinterpret_cast<uintptr_t>(prepared) & 15)) return set_error(GSN_E_INVALID, "gsn_layer_fused_prepare_hip: prepared must be a 16-byte aligned device buffer");
+    if (w_supported(edge, d_x, node0, node1)) return w_prepare(edge, d_x, node0, node1, prepared, reinterpret_cast<hipStream_t>(stream));
     LfArgs a{};
     lf_fill_stages(a, edge, d_x, node0, node1);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -1096,6 +1100,8 @@ extern "C" int gsn_layer_fused_fwd_hip(int64_t n_nodes, int64_t n_edges, const i
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(prepared)) & 15) return set_error(GSN_E_INVALID, "gsn_layer_fused_fwd_hip: x and prepared must be 16-byte aligned");
     if (n_nodes > (int64_t)2000000000 || n_edges > (int64_t)2000000000) return set_error(GSN_E_UNSUPPORTED, "gsn_layer_fused_fwd_hip: 32-bit row arithmetic");
     if (n_nodes <= 0) return GSN_OK;
+    if (w_supported(edge, d_x, node0, node1))
+        return w_forward(n_nodes, n_edges, seg_ptr, edge, x, d_x, node0, node1, prepared, out, reinterpret_cast<hipStream_t>(stream));
     LfArgs a{};
     a.n_nodes = (int)n_nodes; a.n_edges = (int)n_edges; a.seg_ptr = seg_ptr;
     lf_fill_stages(a, edge, d_x, node0, node1);

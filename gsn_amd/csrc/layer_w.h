@@ -1,0 +1,20 @@
+// The one-launch `general` layer for WIDE node rows (d_x = 128: the hidden layers of a d = 128 model, edge rows of K = 256 + <= 16
+// columns), layer_w.hip.  Selected inside the gsn_layer_fused_* entry points of layer_fused.hip.  Not part of the ABI.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "gsn_internal.h"
+
+namespace gsn {
+
+// 1 when the shapes fit the wide kernel
+int w_supported(const gsn_chain_stage *edge, int64_t d_x, const gsn_chain_stage *node0, const gsn_chain_stage *node1);
+// bytes of its prepared-weights buffer (0 when unsupported); 16-byte aligned
+int64_t w_prepared_bytes(const gsn_chain_stage *edge, int64_t d_x, const gsn_chain_stage *node0, const gsn_chain_stage *node1);
+int w_prepare(const gsn_chain_stage *edge, int64_t d_x, const gsn_chain_stage *node0, const gsn_chain_stage *node1, void *prepared, hipStream_t st);
+// forward; GSN_OK or an error (GSN_E_UNSUPPORTED when this call's arguments are outside the kernel after all)
+int w_forward(int64_t n_nodes, int64_t n_edges, const int32_t *seg_ptr, const gsn_chain_stage *edge, const float *x, int64_t d_x,
+              const gsn_chain_stage *node0, const gsn_chain_stage *node1, const void *prepared, float *out, hipStream_t st);
+
+}  // namespace gsn

@@ -735,6 +735,8 @@ def _layer_fused(x, csr, edge_stages, node_stages, training, owner=None, gen=0):
     with _abi.device_guard(x.device), _timed("layer_fused", flops):
         rc = L.gsn_layer_fused_fwd_hip(n, E, csr.seg_ptr.data_ptr(), ctypes.byref(ge), x.data_ptr(), d_x, ctypes.byref(g0),
                                        ctypes.byref(g1), prep.data_ptr(), out.data_ptr(), _abi.current_stream())
+    if rc == -2:           # GSN_E_UNSUPPORTED: this call's arguments are outside the kernel after all (e.g. stream capture on the wide kernel)
+        return None
     _abi.check(rc, "gsn_layer_fused_fwd_hip")
     return out
 

@@ -112,6 +112,54 @@ def test_vertex_edge_consistency_at_full_size():
     assert torch.equal(e[order], e[rorder])
 
 
+def test_er128_full_size_vertex_edge_orbit_sums_agree():
+    """Size-independent property at the ER size of BASELINE config 4 (G(128, 1000), the 21 connected five-vertex patterns) on
+    10 240 graphs: every vertex-orbit column of a pattern sums to #occurrences * |orbit| and every edge-orbit column to
+    #occurrences * (arcs in the class), so each column yields the same integer occurrence total per pattern -- per GRAPH, not only
+    in the grand total; repeated runs are identical and the tail graphs equal a batch of their own (oracle-checked there)."""
+    from gsn_amd import synth, patterns
+    from gsn_amd.counting import counts2ids_batch
+    from oracle import oracle
+    z = load("orbits")
+    pats = [z["all_simple_graphs_5/%d/edges" % i].tolist() for i in range(21)]
+    n_graphs = 10240
+    graphs = [synth.er_graph(128, 1000, s) for s in range(n_graphs)]
+    b = synth.collate(graphs)
+    v = counts2ids_batch(b, pats, "vertex", False)
+    e = counts2ids_batch(b, pats, "edge", False)
+    assert v.shape == (128 * n_graphs, 58) and e.shape == (2000 * n_graphs, 56)
+    assert torch.equal(v, counts2ids_batch(b, pats, "vertex", False))
+    vg = v.view(n_graphs, 128, 58).sum(1)                 # per graph column sums
+    eg = e.view(n_graphs, 2000, 56).sum(1)
+    cv = ce = 0
+    nonzero = 0
+    for el in pats:
+        _, vpart, _, _ = patterns.automorphism_orbits(edge_list=el, print_msgs=False)
+        _, epart, _, _ = patterns.induced_edge_automorphism_orbits(edge_list=el)
+        occ = None
+        for o in sorted(vpart):
+            col = vg[:, cv]
+            assert bool((col % len(vpart[o]) == 0).all())
+            q = col // len(vpart[o])
+            assert occ is None or torch.equal(q, occ)
+            occ = q
+            cv += 1
+        for o in sorted(epart):
+            col = eg[:, ce]
+            assert bool((col % len(epart[o]) == 0).all())
+            assert torch.equal(col // len(epart[o]), occ)
+            ce += 1
+        nonzero += int(occ.sum() > 0)
+    assert cv == 58 and ce == 56 and nonzero == 21
+    # the last three graphs as a batch of their own, against the oracle
+    tail = synth.collate(graphs[-3:])
+    tv = counts2ids_batch(tail, pats, "vertex", False)
+    assert torch.equal(tv, v[-3 * 128:])
+    local = tail.edge_index - np.repeat(tail.node_ptr[:-1], np.diff(tail.edge_ptr))[None, :]
+    ref = oracle.counts2ids("vertex", False, tail.node_ptr, tail.edge_ptr, local, pats, n_threads=8)
+    assert np.array_equal(tv.cpu().numpy(), ref)
+
+
 def test_reference_signatures_and_counts2ids():
     from gsn_amd import patterns, counting
     z = load("counts2ids")

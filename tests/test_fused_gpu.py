@@ -167,6 +167,81 @@ def test_fused_layer_other_classes_and_widths(cls, ctor_kw, d_x, d_id, d_ef, cap
     assert _elementwise_ok(y, ref), float((y - ref).abs().max() / ref.abs().max())
 
 
+WIDE = [
+    ("GSN_edge_sparse", dict(d_in=128, d_ef=4, d_id=12, d_msg=128, d_up=128, d_h=[128]), 12, 4),     # K = 272: hidden layer of BASELINE config 2 with ids
+    ("MPNN_edge_sparse", dict(d_in=128, d_ef=4, d_msg=128, d_up=128, d_h=[128]), 0, 4),             # K = 260
+    ("GSN_sparse", dict(d_in=128, d_id=8, d_msg=128, d_up=128, d_h=[128]), 8, 0),                    # K = 264, no edge features
+    ("MPNN_sparse", dict(d_in=128, d_msg=128, d_up=128, d_h=[128]), 0, 0),                           # K = 256: no per-edge columns at all
+]
+
+
+def _wide_ctor(cls, ctor_kw, **over):
+    base = dict(d_degree=1, degree_as_tag=False, retain_features=True, seed=0, activation_name="relu", bn=True, msg_kind="general",
+                flow="source_to_target")
+    if "GSN" in cls:
+        base["id_scope"] = "local"
+    return dict(base, **ctor_kw, **over)
+
+
+@pytest.mark.parametrize("cls,ctor_kw,d_id,d_ef", WIDE)
+@pytest.mark.parametrize("n_graphs", [1, 300])
+def test_fused_layer_wide_rows(cls, ctor_kw, d_id, d_ef, n_graphs, capfd):
+    """d_x = 128 (the hidden layers of a d = 128 model): csrc/layer_w.hip, one launch behind the row-exponent pass"""
+    b, _, _, ei = _zinc(n_graphs, seed=41 + n_graphs)
+    g = torch.Generator().manual_seed(13)
+    N, E = b.num_nodes, b.num_edges
+    x = torch.randn(N, 128, generator=g).relu()
+    ids = torch.randn(E, d_id, generator=g).abs() if d_id else None
+    ef = torch.randn(E, d_ef, generator=g) if d_ef else None
+    y, y2, ref = _run(cls, _wide_ctor(cls, ctor_kw), x, ei, ids, ef, seed=9, capfd=capfd)
+    assert _elementwise_ok(y, ref), float((y - ref).abs().max() / ref.abs().max())
+    assert _elementwise_ok(y, y2)
+
+
+def test_fused_layer_wide_rows_mixed_magnitudes_hubs(capfd):
+    """rows whose magnitudes span 2^-20 .. 2^20 (every edge row gets its own power-of-two scale from the two node rows and the
+    per-edge columns), hubs with hundreds of in-edges (several 64-row units per tile), isolated nodes, edge-less graphs"""
+    from gsn_amd import synth
+    rng = np.random.default_rng(5)
+    graphs = [(5, np.zeros((2, 0), dtype=np.int64)), synth.er_graph(40, 300, 1)]
+    star = np.stack([np.zeros(300, dtype=np.int64), np.arange(1, 301)])
+    graphs.append((400, np.concatenate([star, star[::-1]], axis=1)))
+    graphs += [synth.zinc_shape_graph(rng) for _ in range(40)]
+    graphs.append(synth.er_graph(128, 1000, 2))
+    graphs.append((70, np.zeros((2, 0), dtype=np.int64)))
+    b = _graph_batch(graphs)
+    g = torch.Generator().manual_seed(19)
+    N, E = b.num_nodes, b.num_edges
+    x = torch.randn(N, 128, generator=g) * torch.exp2(torch.randint(-20, 21, (N, 1), generator=g).float())
+    x[::7] *= torch.logspace(-4, 0, 128)
+    ef = torch.randn(E, 4, generator=g) * torch.exp2(torch.randint(-10, 11, (E, 1), generator=g).float())
+    ids = torch.randint(0, 3, (E, 12), generator=g).float()
+    ei = torch.from_numpy(b.edge_index)
+    cls, ctor_kw = WIDE[0][0], WIDE[0][1]
+    for flow in ("source_to_target", "target_to_source"):
+        y, y2, ref = _run(cls, _wide_ctor(cls, ctor_kw, flow=flow), x, ei, ids, ef, seed=10, capfd=capfd)
+        assert _elementwise_ok(y, ref), (flow, float((y - ref).abs().max() / ref.abs().max()))
+
+
+def test_fused_layer_wide_rows_non_finite():
+    """an Inf in one node row and a NaN in one edge's features make exactly the output rows that see them NaN"""
+    b, _, _, ei = _zinc(40, seed=77)
+    g = torch.Generator().manual_seed(23)
+    N, E = b.num_nodes, b.num_edges
+    x = torch.randn(N, 128, generator=g)
+    ef = torch.randn(E, 4, generator=g)
+    ids = torch.randn(E, 12, generator=g)
+    x[17, 5] = float("inf")
+    ef[33, 2] = float("nan")
+    cls, ctor_kw = WIDE[0][0], WIDE[0][1]
+    y, y2, ref = _run(cls, _wide_ctor(cls, ctor_kw), x, ei, ids, ef, seed=11)
+    bad_ref = ~torch.isfinite(ref).all(dim=1)
+    bad = ~torch.isfinite(y).all(dim=1)
+    assert torch.equal(bad, bad_ref) and bool(bad.any()) and not bool(bad.all())
+    assert bool(torch.isnan(y[bad]).all())
+    assert _elementwise_ok(y[~bad], ref[~bad])
+
+
 def test_fused_layer_full_size_properties():
     """65 536 ZINC-shaped graphs (the bench shape): the fused layer equals the multi-launch path element-wise, and the batch
     is a disjoint union -- the first 1000 graphs alone give the same rows."""
