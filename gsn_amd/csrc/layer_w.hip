@@ -47,8 +47,11 @@ constexpr int W_NST = 2 * W_NXC + 1;   // chunk steps of the edge stage: the per
 constexpr int W_MAXROLE = 3;
 constexpr int W_HDR = 32;
 constexpr unsigned W_MAGIC = 0x57573031u;
-constexpr int W_PDG = 3;           // gathered chunks in flight ahead of the one being converted
-constexpr int W_Q = 16;            // streamed weight fragments in flight (two chunk steps of a node stage)
+#ifndef W_SD_N
+#define W_SD_N 5
+#endif
+constexpr int W_SD = W_SD_N;       // chunk steps a wave's share of the node-stage fragments is requested ahead of its write to the ring
+constexpr int W_PDG = 2;           // gathered chunks in flight ahead of the one being converted
 
 enum { WH_MAGIC = 0, WH_EE = 1, WH_E0 = 2, WH_E1 = 3, WH_EMIN = 4, WH_BAD = 5, WH_ACT = 6 };
 
@@ -60,10 +63,11 @@ struct WShape {
     static constexpr int F_LDS = F_WE + W_NST * WB * 2;
     static constexpr int F_W0 = F_LDS;                       // node stage 0 [c][fbo][plane], c < NK0             (streamed)
     static constexpr int F_W1 = F_W0 + NK0 * WB * 2;         // node stage 1 [c][fb][plane]                       (streamed)
-    static constexpr int F_ALL = F_W1 + NKS * WB * 2;
-    static constexpr int N_STREAM = F_ALL - F_LDS;
+    static constexpr int F_WB = F_W1 + NKS * WB * 2;         // node stage 0's (c0, deg column) as bf16 planes [fbo]   (read per tile)
+    static constexpr int F_ALL = F_WB + WB;
+    static constexpr int N_STREAM = F_WB - F_LDS;
     static constexpr int TAB_WORDS = 4 * 32 * WB;            // c0 of the edge stage (matrix units), c0 of node stage 0, its deg column, c0 of node stage 1
-    static constexpr int LDS_BYTES = F_LDS * 1024 + TAB_WORDS * 4;
+    static constexpr int LDS_BYTES = F_LDS * 1024 + 3 * 8192;     // the edge stage's fragments + a three-slot ring of node-stage chunk steps
     static constexpr int PREP_WORDS = W_HDR + F_ALL * 256 + TAB_WORDS;
 };
 
@@ -163,6 +167,25 @@ __device__ __forceinline__ void w_idx_load(const WArgs &a, const WDesc &d, int l
 
 typedef const __attribute__((address_space(1))) rr_f4 *w_gptr;
 
+// issue order inside one chunk step: NM x (one MFMA, then -- while there are any -- one LDS read and one global load, then NV vector
+// instructions).  A wave issues in order; a ds_read_b128 holds the issue port ~16-20 cycles (scripts/micro/lds_frag_stream.hip), an MFMA 4
+// of the 32 its pipe is busy: the eight fragment reads of a step cost 160 cycles in front of the products and nothing between them.
+#ifdef RR_NOMIX
+#define W_MIX(NM, ND, NG, NV)
+#else
+#define W_MIX(NM, ND, NG, NV) _Pragma("unroll") for (int mix_q = 0; mix_q < (NM); ++mix_q) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); \
+    if (mix_q < (ND)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); if (mix_q < (NG)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
+    __builtin_amdgcn_sched_group_barrier(0x002, (NV), 0); }
+#endif
+// the edge stage's step: a feature block's two fragments are replaced behind its six products (reads behind products 6, 7, 12, 13, ...)
+#ifdef RR_NOMIX
+#define W_MIX_EDGE()
+#else
+#define W_MIX_EDGE() _Pragma("unroll") for (int mix_q = 0; mix_q < 24; ++mix_q) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); \
+    if (mix_q >= 5 && (mix_q - 5) % 6 < 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); if (mix_q < 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
+    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); }
+#endif
+
 // ------------------------------------------------------------------------------------------------------------------------------
 template <bool PROF>
 __global__ __launch_bounds__(256) void layer_fused_kernel_w(WArgs a, unsigned long long *prof) {
@@ -173,27 +196,31 @@ __global__ __launch_bounds__(256) void layer_fused_kernel_w(WArgs a, unsigned lo
         __builtin_amdgcn_sched_barrier(0);
         return v;
     };
-    unsigned pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // scales, edge loop, edge epilogue, advance, stage 0, stage 1, units, tiles
+    unsigned pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // scales, edge loop, edge epilogue + prefetch, rendezvous, stage 0, stage 1, units, tiles
+    unsigned pd[4] = {0, 0, 0, 0};               // inside `stage 1`: between the stages, its eight steps, advance, stores
     using SH = WShape;
     constexpr int WB = SH::WB, NKS = SH::NKS, NK0 = SH::NK0;
+    constexpr int NSTEP = NK0 + NKS;              // chunk steps of the two node stages (8 streamed fragments each)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
     const int lane0 = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li0 = lane0 & 31, lh0 = lane0 >> 5;
-    unsigned ldsb[3];
-    ldsb[0] = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem + 16u * (unsigned)lane0;
-    ldsb[1] = ldsb[0] + 0x10000u; ldsb[2] = ldsb[0] + 0x20000u;
-    asm volatile("" : "+v"(ldsb[1]), "+v"(ldsb[2]));
+    // LDS address of this lane's 16 bytes inside fragment 0; the bases 64 and 128 KiB further (16-bit immediate offsets) are made where
+    // they are used, opaque to the compiler (layer_rr_inl.h: rr_lds_frag)
+    const unsigned ldsb0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem + 16u * (unsigned)lane0;
+    auto lds_bases = [&](unsigned (&b)[3]) {
+        b[0] = ldsb0;
+        asm volatile("" : "+v"(b[0]));
+        b[1] = b[0] + 0x10000u; b[2] = b[0] + 0x20000u;
+        asm volatile("" : "+v"(b[1]), "+v"(b[2]));
+    };
 
-    // ---- prologue: edge-stage fragments and the bias tables -> LDS --------------------------------------------------------------
+    // ---- prologue: edge-stage fragments -> LDS ----------------------------------------------------------------------------------
     {
         const rr_u4 *src = reinterpret_cast<const rr_u4 *>(a.prep + W_HDR);
         rr_u4 *dst = reinterpret_cast<rr_u4 *>(smem);
         for (int i = tid; i < SH::F_LDS * 64; i += 256) dst[i] = src[i];
-        const float *tsrc = reinterpret_cast<const float *>(a.prep + W_HDR + SH::F_ALL * 256);
-        float *tdst = reinterpret_cast<float *>(smem + SH::F_LDS * 1024);
-        for (int i = tid; i < SH::TAB_WORDS; i += 256) tdst[i] = tsrc[i];
     }
     __syncthreads();
     const int Ee = (int)a.prep[WH_EE], E0 = (int)a.prep[WH_E0], E1 = (int)a.prep[WH_E1], e_min = (int)a.prep[WH_EMIN];
@@ -201,15 +228,15 @@ __global__ __launch_bounds__(256) void layer_fused_kernel_w(WArgs a, unsigned lo
     const unsigned acts = a.prep[WH_ACT];
     auto sgpr = [](float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); };
     const float lo_e = sgpr((acts & 1) ? 0.f : -3.0e38f), lo_0 = sgpr((acts & 2) ? 0.f : -INFINITY), lo_1 = sgpr((acts & 4) ? 0.f : -INFINITY);
-    const __amdgpu_buffer_rsrc_t wstream = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(a.prep) + W_HDR + SH::F_W0 * 256, 0, SH::N_STREAM * 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wstream = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(a.prep) + W_HDR + SH::F_W0 * 256, 0, (SH::F_ALL - SH::F_W0) * 1024, 0x00020000);
+    const float *tab0 = reinterpret_cast<const float *>(a.prep + W_HDR + SH::F_ALL * 256);     // (folded biases: global memory, cache hits)
 
-    // ---- this wave's node range -----------------------------------------------------------------------------------------------
+    // ---- this wave's node range (an empty one still walks through the workgroup's rendezvous) -------------------------------------
     const int range = wave * (int)gridDim.x + (int)blockIdx.x;
-    if (range >= a.n_ranges) return;
     WIter it;
     it.seg = a.seg_ptr; it.n_nodes = a.n_nodes;
-    it.m_next = (int)((int64_t)a.n_nodes * range / a.n_ranges);
-    it.m_end = (int)((int64_t)a.n_nodes * (range + 1) / a.n_ranges);
+    it.m_next = range < a.n_ranges ? (int)((int64_t)a.n_nodes * range / a.n_ranges) : 0;
+    it.m_end = range < a.n_ranges ? (int)((int64_t)a.n_nodes * (range + 1) / a.n_ranges) : 0;
     it.m0 = 0; it.nn = 0; it.eb = 0; it.ee = 0; it.ec = 0; it.pending = 0; it.win = 0;
     w_iter_load(it, lane0);
     WDesc cur = w_iter_next(it, lane0);
@@ -259,334 +286,412 @@ __global__ __launch_bounds__(256) void layer_fused_kernel_w(WArgs a, unsigned lo
     };
     Pre pre;
     pre_issue(ixc, lh0, pre);
-    int pt = ixc.pt, pt1 = ixc.pt1, xet = ixc.xet;
 
-    f32x16 sacc[WB];                                   // S^T tiles: row = feature in block, column = target
-#pragma unroll
-    for (int fb = 0; fb < WB; ++fb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sacc[fb][r] = 0.f;
-    unsigned badt = 0;
 
-#define W_STREAM(I) __builtin_bit_cast(rr_u4, __builtin_amdgcn_raw_buffer_load_b128(wstream, 16 * lane, (I) * 1024, 0))
+    // The fragments of the two node stages stream from L2 once per WORKGROUP and tile round (a CU's path to L2 carries ~30 bytes per
+    // cycle: four private streams of 192 KiB per tile cost more than the products they feed): wave w loads fragments 2 w, 2 w + 1
+    // of every chunk step five steps ahead into registers, writes them to a three-slot ring in LDS two steps ahead, and all four
+    // waves read the step's eight fragments from there.  One barrier per step.
+#define W_SHARE(K, J) __builtin_bit_cast(rr_u4, __builtin_amdgcn_raw_buffer_load_b128(wstream, 16 * lane, (8 * (K) + (J)) * 1024 + wave * 2048, 0))
+    constexpr unsigned RING = SH::F_LDS * 1024 - 0x20000;       // byte offset of the ring behind ldsb[2]
+    typedef __attribute__((address_space(3))) rr_u4 *w_ldsw;
 
     const unsigned t_start = clk();
-    while (cur.valid()) {
-        const unsigned t0 = clk();
-        asm volatile("" : "+v"(ldsb[0]), "+v"(ldsb[1]), "+v"(ldsb[2]));
+    while (true) {
         int li = li0, lh = lh0;
         asm volatile("" : "+v"(li), "+v"(lh));
         const int lane = li + 32 * lh;
-        const float *tab = reinterpret_cast<const float *>(rr_lds_generic(ldsb[0] - 16u * (unsigned)lane + SH::F_LDS * 1024));
-        const int nn = cur.nn(), ne = cur.ne();
-        if (li >= nn) { pt = 0; pt1 = 0; }
-        const bool last = cur.last() != 0;
-
-
-        float inv[2] = {1.f, 1.f};
-        bool bad_e[2] = {false, false};
-        f32x16 acc[2][WB];
-        if (ne > 0) {
-            // =====================================================================================================================
-            // row scales of the unit's edge rows: exponent fields of x_i, x_j (side array) and of the per-edge columns
-            // =====================================================================================================================
-            float rs[2];
-            rr_u4 Ah[2], Al[2];
+        const float *tab = tab0;
+        asm volatile("" : "+s"(tab));                    // (loop-invariant loads: hoisted out of the tile loop and spilled otherwise)
+        // ---- this wave's tile: its units through the edge stage ----------------------------------------------------------------------
+        f32x16 sacc[WB];                               // S^T tiles: row = feature in block, column = target
 #pragma unroll
-            for (int sb = 0; sb < 2; ++sb) {
-                unsigned m = 0;
+        for (int fb = 0; fb < WB; ++fb)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const rr_f4 v = pre.z[sb][j];
-                    m = max(max(m, __float_as_uint(v.x) & 0x7fffffffu), __float_as_uint(v.y) & 0x7fffffffu);
-                    m = max(max(m, __float_as_uint(v.z) & 0x7fffffffu), __float_as_uint(v.w) & 0x7fffffffu);
-                }
-                m = rr_xhalf_max(m);
-                int e = max(max((int)(m >> 23), pre.xf[sb][0]), pre.xf[sb][1]);
-                bad_e[sb] = e >= 255;
-                e = e < 15 ? 15 : (e > 254 ? 254 : e);
-                rs[sb] = __uint_as_float((unsigned)(268 - e) << 23);
-                inv[sb] = __uint_as_float((unsigned)(e - 14) << 23);
-                unsigned h[4], l[4];
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const rr_f4 v = pre.z[sb][j];
-                    rr_split2s(v.x, v.y, rs[sb], h[2 * j], l[2 * j]);
-                    rr_split2s(v.z, v.w, rs[sb], h[2 * j + 1], l[2 * j + 1]);
-                }
-                Ah[sb] = rr_u4{h[0], h[1], h[2], h[3]};
-                Al[sb] = rr_u4{l[0], l[1], l[2], l[3]};
-            }
-            const unsigned t1 = clk();
-            // =====================================================================================================================
-            // edge stage: 17 chunk steps x (2 sub-blocks x 4 feature blocks x 3 plane products)
-            // =====================================================================================================================
-#pragma unroll
-            for (int sb = 0; sb < 2; ++sb)
-#pragma unroll
-                for (int fb = 0; fb < WB; ++fb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[sb][fb][r] = 0.f;
-            rr_u4 fr[8], nf[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) fr[q] = rr_lds_frag(ldsb, SH::F_WE + q);
-            auto issue = [&](int c) {                  // chunk c of the gathered node rows: c < 8 from x_i, else x_j
-#pragma unroll
-                for (int sb = 0; sb < 2; ++sb)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        raw[c % (W_PDG + 1)][sb][j] = *reinterpret_cast<w_gptr>(pre.rowp[sb][c >> 3] + 64 * (c & 7) + 16 * j);
-            };
-            rr_u4 Nh[2], Nl[2];
-            auto convert = [&](int c) {
-#pragma unroll
-                for (int sb = 0; sb < 2; ++sb) {
-                    unsigned h[4], l[4];
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const rr_f4 v = raw[c % (W_PDG + 1)][sb][j];
-                        rr_split2s(v.x, v.y, rs[sb], h[2 * j], l[2 * j]);
-                        rr_split2s(v.z, v.w, rs[sb], h[2 * j + 1], l[2 * j + 1]);
-                    }
-                    Nh[sb] = rr_u4{h[0], h[1], h[2], h[3]};
-                    Nl[sb] = rr_u4{l[0], l[1], l[2], l[3]};
-                }
-            };
-#pragma unroll
-            for (int s = 0; s < W_NST; ++s) {
-                // step s multiplies chunk s - 1 of the node rows (s = 0: the per-edge chunk); chunk s is converted under it, chunk s + W_PDG issued
-                if (s + W_PDG < 2 * W_NXC) issue(s + W_PDG);
-                if (s + 1 < W_NST) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) nf[q] = rr_lds_frag(ldsb, SH::F_WE + 8 * (s + 1) + q);
-                }
-#pragma unroll
-                for (int fb = 0; fb < WB; ++fb)
-#pragma unroll
-                    for (int sb = 0; sb < 2; ++sb) RR_MFH(Al[sb], fr[2 * fb], acc[sb][fb]);
-#pragma unroll
-                for (int fb = 0; fb < WB; ++fb)
-#pragma unroll
-                    for (int sb = 0; sb < 2; ++sb) RR_MFH(Ah[sb], fr[2 * fb + 1], acc[sb][fb]);
-#pragma unroll
-                for (int fb = 0; fb < WB; ++fb)
-#pragma unroll
-                    for (int sb = 0; sb < 2; ++sb) RR_MFH(Ah[sb], fr[2 * fb], acc[sb][fb]);
-                if (s + 1 < W_NST) convert(s);
-                RR_MIX(24, 2)
-                RR_SB();
-#pragma unroll
-                for (int sb = 0; sb < 2; ++sb) { Ah[sb] = Nh[sb]; Al[sb] = Nl[sb]; }
-#pragma unroll
-                for (int q = 0; q < 8; ++q) fr[q] = nf[q];
-            }
-            const unsigned t2 = clk();
-            if (PROF) { pc[0] += t1 - t0; pc[1] += t2 - t1; }
-        }
-        const unsigned t2b = clk();
-        if (ne > 0) {
-            // =====================================================================================================================
-            // activation + per-node sums: the activated rows as three bf16 planes into the incidence product
-            // =====================================================================================================================
-#pragma unroll
-            for (int sb = 0; sb < 2; ++sb) {
-                const unsigned bm = rr_edge_mask(pt, pt1, cur.e0 + 32 * sb);
-                rr_u4 M[2];
-                rr_incidence(bm, lh, M);
-                const unsigned badrows = (unsigned)__builtin_amdgcn_ballot_w64(bad_e[sb]);
-                if (badrows & bm) badt = 1;
-                float iv = inv[sb];
-                if (bad_e[sb]) iv = 0.f;               // (its products are NaN; the clamp below makes them finite, its target is marked)
-                float invr[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) invr[r] = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * rr_crow(r, lh), __float_as_int(iv)));
-#pragma unroll
-                for (int fb = 0; fb < WB; ++fb) {
-                    const float cb = tab[32 * fb + li];
-#pragma unroll
-                    for (int cc = 0; cc < 2; ++cc) {
-                        unsigned y1[4], y2[4], y3[4];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int r0 = 8 * cc + 2 * q;
-                            const float ya = __builtin_amdgcn_fmed3f(fmaf(acc[sb][fb][r0], invr[r0], cb), lo_e, 3.0e38f);
-                            const float yb = __builtin_amdgcn_fmed3f(fmaf(acc[sb][fb][r0 + 1], invr[r0 + 1], cb), lo_e, 3.0e38f);
-                            rr_split3b(ya, yb, y1[q], y2[q], y3[q]);
-                        }
-                        const rr_u4 p1 = rr_u4{y1[0], y1[1], y1[2], y1[3]}, p2 = rr_u4{y2[0], y2[1], y2[2], y2[3]}, p3 = rr_u4{y3[0], y3[1], y3[2], y3[3]};
-                        RR_MFB(p3, M[cc], sacc[fb]);
-                        RR_MFB(p2, M[cc], sacc[fb]);
-                        RR_MFB(p1, M[cc], sacc[fb]);
-                    }
-                }
-            }
-        }
-        const unsigned t3 = clk();
-        if (PROF) { pc[2] += t3 - t2b; pc[6] += 1; }
-        // ---- next unit: everything its edge stage needs before the first product, the descriptor after it, that one's row indices.
-        //      Behind a tile's last unit the gathers are issued in front of node stage 1 (registers), otherwise here ----------------------
+            for (int r = 0; r < 16; ++r) sacc[fb][r] = 0.f;
+        unsigned badt = 0;
+        const bool tile_valid = cur.valid() != 0;
+        const int t_m0 = cur.m0, t_nn = tile_valid ? cur.nn() : 0;
+        int pt = ixc.pt, pt1 = ixc.pt1;
+        const int xet = ixc.xet;
+        if (li >= t_nn) { pt = 0; pt1 = 0; }
         Pre pren;
-        int npt = 0, npt1 = 0, nxet = 0;
+        WIdx ixu = ixn;
         WDesc nn2; nn2.m0 = 0; nn2.e0 = 0; nn2.pk = 0;
+        // the next unit: everything its edge stage needs before the first product, the descriptor after it, that one's row indices
         auto advance = [&]() {
-            pre_issue(ixn, lh, pren);
-            npt = ixn.pt; npt1 = ixn.pt1; nxet = ixn.xet;
+            int lhu = lh;
+            asm volatile("" : "+v"(lhu));                // (else the quad selections are hoisted out of every loop and spilled)
+            pre_issue(ixn, lhu, pren);
+            ixu = ixn;                                   // (pt, pt1, xet of the next unit's tile)
             nn2 = w_iter_next(it, lane);
             w_idx_load(a, nn2, li, ixn);
         };
-        if (!last) advance();
-
-        if (last) {
+        auto rotate = [&]() { cur = nxt; nxt = nn2; ixc = ixu; pre = pren; };
+        bool more = tile_valid;
+        while (more) {
+            const unsigned t0 = clk();
+            const int ne = cur.ne();
+            const bool last = cur.last() != 0;
+            float inv[2] = {1.f, 1.f};
+            bool bad_e[2] = {false, false};
+            f32x16 acc[2][WB];
+            if (ne > 0) {
+                // =================================================================================================================
+                // row scales of the unit's edge rows: exponent fields of x_i, x_j (side array) and of the per-edge columns
+                // =================================================================================================================
+                float rs[2];
+                rr_u4 Ah[2], Al[2];
+#pragma unroll
+                for (int sb = 0; sb < 2; ++sb) {
+                    unsigned m = 0;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const rr_f4 v = pre.z[sb][j];
+                        m = max(max(m, __float_as_uint(v.x) & 0x7fffffffu), __float_as_uint(v.y) & 0x7fffffffu);
+                        m = max(max(m, __float_as_uint(v.z) & 0x7fffffffu), __float_as_uint(v.w) & 0x7fffffffu);
+                    }
+                    m = rr_xhalf_max(m);
+                    int e = max(max((int)(m >> 23), pre.xf[sb][0]), pre.xf[sb][1]);
+                    bad_e[sb] = e >= 255;
+                    e = e < 15 ? 15 : (e > 254 ? 254 : e);
+                    rs[sb] = __uint_as_float((unsigned)(268 - e) << 23);
+                    inv[sb] = __uint_as_float((unsigned)(e - 14) << 23);
+                    unsigned h[4], l[4];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const rr_f4 v = pre.z[sb][j];
+                        rr_split2s(v.x, v.y, rs[sb], h[2 * j], l[2 * j]);
+                        rr_split2s(v.z, v.w, rs[sb], h[2 * j + 1], l[2 * j + 1]);
+                    }
+                    Ah[sb] = rr_u4{h[0], h[1], h[2], h[3]};
+                    Al[sb] = rr_u4{l[0], l[1], l[2], l[3]};
+                }
+                const unsigned t1 = clk();
+                // =================================================================================================================
+                // edge stage: 17 chunk steps x (2 sub-blocks x 4 feature blocks x 3 plane products)
+                // =================================================================================================================
+#pragma unroll
+                for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                    for (int fb = 0; fb < WB; ++fb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[sb][fb][r] = 0.f;
+                unsigned ldsb[3];
+                lds_bases(ldsb);
+                rr_u4 fr[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) fr[q] = rr_lds_frag(ldsb, SH::F_WE + q);
+                auto issue = [&](int c) {                  // chunk c of the gathered node rows: c < 8 from x_i, else x_j
+#pragma unroll
+                    for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            raw[c % (W_PDG + 1)][sb][j] = *reinterpret_cast<w_gptr>(pre.rowp[sb][c >> 3] + 64 * (c & 7) + 16 * j);
+                };
+                rr_u4 Nh[2], Nl[2];
+                auto convert = [&](int c) {
+#pragma unroll
+                    for (int sb = 0; sb < 2; ++sb) {
+                        unsigned h[4], l[4];
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const rr_f4 v = raw[c % (W_PDG + 1)][sb][j];
+                            rr_split2s(v.x, v.y, rs[sb], h[2 * j], l[2 * j]);
+                            rr_split2s(v.z, v.w, rs[sb], h[2 * j + 1], l[2 * j + 1]);
+                        }
+                        Nh[sb] = rr_u4{h[0], h[1], h[2], h[3]};
+                        Nl[sb] = rr_u4{l[0], l[1], l[2], l[3]};
+                    }
+                };
+#pragma unroll
+                for (int s = 0; s < W_NST; ++s) {
+                    // step s multiplies chunk s - 1 of the node rows (s = 0: the per-edge chunk); chunk s is converted under it, chunk s + W_PDG issued
+                    if (s + W_PDG < 2 * W_NXC) issue(s + W_PDG);
+                    // (feature block by feature block, the two sub-blocks' accumulators alternately; a block's two fragments are replaced by
+                    //  the next step's as soon as its six products are issued: ten fragments in registers instead of sixteen)
+#pragma unroll
+                    for (int fb = 0; fb < WB; ++fb) {
+                        RR_MFH(Al[0], fr[2 * fb], acc[0][fb]);
+                        RR_MFH(Al[1], fr[2 * fb], acc[1][fb]);
+                        RR_MFH(Ah[0], fr[2 * fb + 1], acc[0][fb]);
+                        RR_MFH(Ah[1], fr[2 * fb + 1], acc[1][fb]);
+                        RR_MFH(Ah[0], fr[2 * fb], acc[0][fb]);
+                        RR_MFH(Ah[1], fr[2 * fb], acc[1][fb]);
+                        if (s + 1 < W_NST) {
+                            fr[2 * fb] = rr_lds_frag(ldsb, SH::F_WE + 8 * (s + 1) + 2 * fb);
+                            fr[2 * fb + 1] = rr_lds_frag(ldsb, SH::F_WE + 8 * (s + 1) + 2 * fb + 1);
+                        }
+                    }
+                    if (s + 1 < W_NST) convert(s);
+                    W_MIX_EDGE()
+                    RR_SB();
+#pragma unroll
+                    for (int sb = 0; sb < 2; ++sb) { Ah[sb] = Nh[sb]; Al[sb] = Nl[sb]; }
+                }
+                const unsigned t2 = clk();
+                if (PROF) { pc[0] += t1 - t0; pc[1] += t2 - t1; }
+            }
+            const unsigned t2b = clk();
+            // ---- inside a tile the next unit's gathers fly under this one's activation (the ring of gathered chunks is free now); behind
+            //      the tile's last unit they are issued behind the node stages (registers)
+            float cbe[WB];
+#pragma unroll
+            for (int fb = 0; fb < WB; ++fb) cbe[fb] = tab[32 * fb + li0];
+            if (!last) advance();
+            if (ne > 0) {
+                // =================================================================================================================
+                // activation + per-node sums: the activated rows as three bf16 planes into the incidence product
+                // =================================================================================================================
+                int li = li0, lh = lh0;                   // (made here: everything computed from the lane index is otherwise hoisted in front of
+                asm volatile("" : "+v"(li), "+v"(lh));    //  the edge stage and spilled across it)
+#pragma unroll
+                for (int sb = 0; sb < 2; ++sb) {
+                    const unsigned bm = rr_edge_mask(pt, pt1, cur.e0 + 32 * sb);
+                    rr_u4 M[2];
+                    rr_incidence(bm, lh, M);
+                    const unsigned badrows = (unsigned)__builtin_amdgcn_ballot_w64(bad_e[sb]);
+                    if (badrows & bm) badt = 1;
+                    float iv = inv[sb];
+                    if (bad_e[sb]) iv = 0.f;               // (its products are NaN; the clamp below makes them finite, its target is marked)
+                    float invr[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) invr[r] = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * rr_crow(r, lh), __float_as_int(iv)));
+#pragma unroll
+                    for (int fb = 0; fb < WB; ++fb) {
+                        const float cb = cbe[fb];
+#pragma unroll
+                        for (int cc = 0; cc < 2; ++cc) {
+                            unsigned y1[4], y2[4], y3[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const int r0 = 8 * cc + 2 * q;
+                                const float ya = __builtin_amdgcn_fmed3f(fmaf(acc[sb][fb][r0], invr[r0], cb), lo_e, 3.0e38f);
+                                const float yb = __builtin_amdgcn_fmed3f(fmaf(acc[sb][fb][r0 + 1], invr[r0 + 1], cb), lo_e, 3.0e38f);
+                                rr_split3b(ya, yb, y1[q], y2[q], y3[q]);
+                            }
+                            const rr_u4 p1 = rr_u4{y1[0], y1[1], y1[2], y1[3]}, p2 = rr_u4{y2[0], y2[1], y2[2], y2[3]}, p3 = rr_u4{y3[0], y3[1], y3[2], y3[3]};
+                            RR_MFB(p3, M[cc], sacc[fb]);
+                            RR_MFB(p2, M[cc], sacc[fb]);
+                            RR_MFB(p1, M[cc], sacc[fb]);
+                        }
+                    }
+                }
+            }
+            if (PROF) { pc[2] += clk() - t2b; pc[6] += 1; }
+            if (last) break;
+            rotate();
+        }
+        // ---- this wave's share of the first five node-stage steps (a wave without a tile still carries its share for the others); the row
+        //      scale of node stage 0 and the accumulators' start values are made while they fly --------------------------------------------
+        rr_u4 sq[W_SD][2];                             // share of steps k + 2 .. k + 1 + W_SD (registers), slot = step % W_SD
+        rr_u4 s01[2][2];                               // share of steps 0 and 1 (written to the ring at the rendezvous)
+        f32x16 hacc[WB];
+        asm volatile("" : "+v"(li), "+v"(lh));
+        // (a wave's loads return in order: what is needed first is requested first)
+        rr_u4 bfr[WB];
+#pragma unroll
+        for (int fbo = 0; fbo < WB; ++fbo) bfr[fbo] = __builtin_bit_cast(rr_u4, __builtin_amdgcn_raw_buffer_load_b128(wstream, 16 * lane, (SH::N_STREAM + fbo) * 1024, 0));
+        float cb1[WB];
+#pragma unroll
+        for (int fb = 0; fb < WB; ++fb) cb1[fb] = tab[3 * 32 * WB + 32 * fb + li];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            s01[0][j] = W_SHARE(0, j); s01[1][j] = W_SHARE(1, j);
+#pragma unroll
+            for (int k = 2; k < 2 + W_SD; ++k) sq[k % W_SD][j] = W_SHARE(k, j);
+        }
+        // ---- row scale from max(|S|, |x|, deg) in true units (sacc = 2 se S) ------------------------------------------------
+        float ms = 0.f;
+#pragma unroll
+        for (int fb = 0; fb < WB; ++fb)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) ms = fmaxf(fmaxf(fabsf(sacc[fb][r]), fabsf(sacc[fb][r + 1])), ms);
+        const float degf = (float)(pt1 - pt);
+        const unsigned msb = __float_as_uint(ms);
+        int es = (int)(msb >> 23) - 1 - Ee;
+        es = msb == 0 ? 0 : es;
+        unsigned fld = (unsigned)max(max(max(es, xet), (int)(__float_as_uint(degf) >> 23)), 0);
+        fld = rr_xhalf_max(fld);
+        bool badrow = msb >= 0x7f800000u || xet >= 255 || badt != 0 || w_bad;
+        badrow = rr_xhalf_or(badrow ? 1u : 0u) != 0;
+        int e_t = (int)fld;
+        e_t = e_t < e_min ? e_min : (e_t > 254 ? 254 : e_t);
+        const float rs0 = __uint_as_float((unsigned)(268 - e_t) << 23);
+        float fs = rr_pow2(267 - e_t - Ee);
+        if (badrow) fs = __uint_as_float(0x7fc00000u);
+        // ---- accumulators start at (c0 + deg w_deg) s0 rs0: ONE bf16 product per feature block.  The prepared fragment holds three bf16
+        //      planes of c0 2^E0 in k-slots 0..2 and of w_deg 2^E0 in 3..5 and 6..8; this lane's operand rs0 (a power of two: exact in
+        //      bf16 at any exponent) in 0..2, the upper 8 bits of deg times rs0 in 3..5, the lower in 6..8 (exact for deg < 65536)
+        {
+            const float dh = __uint_as_float(__float_as_uint(degf) & 0xffff0000u), dl = degf - dh;
+            const unsigned rsb = __float_as_uint(rs0) >> 16, dhb = __float_as_uint(dh * rs0) >> 16, dlb = __float_as_uint(dl * rs0) >> 16;
+            const rr_u4 bv = lh ? rr_u4{dlb, 0u, 0u, 0u} : rr_u4{rsb | (rsb << 16), rsb | (dhb << 16), dhb | (dhb << 16), dlb | (dlb << 16)};
+#pragma unroll
+            for (int fbo = 0; fbo < WB; ++fbo) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) hacc[fbo][r] = 0.f;
+                RR_MFB(bfr[fbo], bv, hacc[fbo]);
+            }
+        }
+        // ---- rendezvous of the workgroup's four waves: is there a tile at all?  (votes in the first words of the ring) ------------------
+        const unsigned tr0 = clk();
+        {
+            unsigned *vote = reinterpret_cast<unsigned *>(smem + SH::F_LDS * 1024);
+            if (lane == 0) vote[wave] = tile_valid ? 1u : 0u;
+            lds_barrier();
+            const unsigned any = vote[0] | vote[1] | vote[2] | vote[3];
+            lds_barrier();
+            if (__builtin_amdgcn_readfirstlane(any) == 0) break;
+        }
+        unsigned ldsb[3];
+        lds_bases(ldsb);
+        const unsigned wbase = ldsb[2] + RING + (unsigned)wave * 2048u;       // this wave's two fragments inside a ring slot
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) *reinterpret_cast<w_ldsw>(wbase + 8192u * k + 1024u * j) = s01[k][j];
+        lds_barrier();
+        const unsigned tr1 = clk();
+        {
+            const int nn = t_nn;
             // =====================================================================================================================
             // node stage 0 (transposed): H^T = W0 [S | x]^T, deg with the bias
             // =====================================================================================================================
-            rr_u4 wq[W_Q];
-#pragma unroll
-            for (int i = 0; i < W_Q; ++i) wq[i] = W_STREAM(i);
-            f32x16 hacc[WB];
-            rr_f4 xr[4][2];                               // ring of the x row's chunks (lane (t, h): columns 16 c + 8 h ..+8)
-            const int xrow = cur.m0 + (li < nn ? li : nn - 1);
+            f32x16 oacc[WB];
+            rr_f4 xr[3][2];                               // ring of the x row's chunks (lane (t, h): columns 16 c + 8 h ..+8)
+            int xrow = t_m0 + (li < nn ? li : nn - 1);
+            xrow = nn > 0 ? xrow : 0;
             const unsigned long long xp = reinterpret_cast<unsigned long long>(a.x) + (unsigned long long)xrow * (W_DX * 4) + (unsigned long long)(32 * lh);
             auto xissue = [&](int c) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j) xr[c % 4][j] = *reinterpret_cast<w_gptr>(xp + 64 * c + 16 * j);
+                for (int j = 0; j < 2; ++j) xr[c % 3][j] = *reinterpret_cast<w_gptr>(xp + 64 * c + 16 * j);
             };
-            // ---- row scale from max(|S|, |x|, deg) in true units (sacc = 2 se S) ------------------------------------------------
-            float ms = 0.f;
+            rr_u4 fr[8], nf[8];
 #pragma unroll
-            for (int fb = 0; fb < WB; ++fb)
+            for (int q = 0; q < 8; ++q) fr[q] = *reinterpret_cast<rr_ldsp>(ldsb[2] + RING + 1024u * q);
+            // per chunk step k of the two stages: this wave's share of step k + 2 goes from registers to the ring, its share of step k + 5
+            // is requested, the eight fragments of step k + 1 are read, the twelve products of step k issued; one barrier
+            unsigned ph[4], pl[4], nph[4], npl[4];
+            float f2 = 0.f, inv2 = 0.f;
+            bool anybad = false;
 #pragma unroll
-                for (int r = 0; r < 16; r += 2) ms = fmaxf(fmaxf(fabsf(sacc[fb][r]), fabsf(sacc[fb][r + 1])), ms);
-            const float degf = (float)(pt1 - pt);
-            const unsigned msb = __float_as_uint(ms);
-            int es = (int)(msb >> 23) - 1 - Ee;
-            es = msb == 0 ? 0 : es;
-            unsigned fld = (unsigned)max(max(max(es, xet), (int)(__float_as_uint(degf) >> 23)), 0);
-            fld = rr_xhalf_max(fld);
-            bool badrow = msb >= 0x7f800000u || xet >= 255 || badt != 0 || w_bad;
-            badrow = rr_xhalf_or(badrow ? 1u : 0u) != 0;
-            int e_t = (int)fld;
-            e_t = e_t < e_min ? e_min : (e_t > 254 ? 254 : e_t);
-            const float rs0 = __uint_as_float((unsigned)(268 - e_t) << 23);
-            float fs = rr_pow2(267 - e_t - Ee);
-            const float sc = rr_pow2(E0 + 268 - e_t);
-            if (badrow) fs = __uint_as_float(0x7fc00000u);
-            // ---- accumulators start at (c0 + deg w_deg) in accumulator units ----------------------------------------------------------
+            for (int q = 0; q < 4; ++q) rr_split2s(sacc[0][2 * q], sacc[0][2 * q + 1], fs, ph[q], pl[q]);
+            unsigned t5 = 0, t5a = 0;
 #pragma unroll
-            for (int fbo = 0; fbo < WB; ++fbo)
+            for (int k = 0; k < NSTEP; ++k) {
+#ifndef W_ABL_NORINGWRITE
+                if (k + 2 < NSTEP)
+#else
+                if (false)
+#endif
+                {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float4 cv = *reinterpret_cast<const float4 *>(tab + 32 * WB + 32 * fbo + 8 * i + 4 * lh);
-                    const float4 wd = *reinterpret_cast<const float4 *>(tab + 2 * 32 * WB + 32 * fbo + 8 * i + 4 * lh);
-                    hacc[fbo][4 * i] = fmaf(degf, wd.x, cv.x) * sc; hacc[fbo][4 * i + 1] = fmaf(degf, wd.y, cv.y) * sc;
-                    hacc[fbo][4 * i + 2] = fmaf(degf, wd.z, cv.z) * sc; hacc[fbo][4 * i + 3] = fmaf(degf, wd.w, cv.w) * sc;
+                    for (int j = 0; j < 2; ++j) *reinterpret_cast<w_ldsw>(wbase + 8192u * ((k + 2) % 3) + 1024u * j) = sq[(k + 2) % W_SD][j];
                 }
-            // ---- 16 chunks: S (the S^T tiles become operand fragments, 16 features at a time), then x (chunk cx is issued at step
-            //      cx + 4 and converted under step cx + 7); weight fragments from the stream --------------------------------------------
-            {
-                unsigned ph[4], pl[4], nph[4], npl[4];
+                if (k + 2 + W_SD < NSTEP) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) rr_split2s(sacc[0][2 * q], sacc[0][2 * q + 1], fs, ph[q], pl[q]);
+                    for (int j = 0; j < 2; ++j) sq[(k + 2) % W_SD][j] = W_SHARE(k + 2 + W_SD, j);
+                }
+#ifdef W_ABL_NORINGREAD
 #pragma unroll
-                for (int c = 0; c < NK0; ++c) {
-                    const rr_u4 bh = rr_u4{ph[0], ph[1], ph[2], ph[3]}, bl = rr_u4{pl[0], pl[1], pl[2], pl[3]};
-                    const int i0 = 8 * c;
-                    if (c >= 4 && c - 4 < W_NXC) xissue(c - 4);
+                for (int q = 0; q < 8; ++q) nf[q] = fr[q];                                 // (diagnostic build: wrong results)
+#else
+                if (k + 1 < NSTEP) {
 #pragma unroll
-                    for (int fbo = 0; fbo < WB; ++fbo) RR_MFH(wq[(i0 + 2 * fbo) % W_Q], bl, hacc[fbo]);
+                    for (int q = 0; q < 8; ++q) nf[q] = *reinterpret_cast<rr_ldsp>(ldsb[2] + RING + 8192u * ((k + 1) % 3) + 1024u * q);
+                }
+#endif
+                const rr_u4 bh = rr_u4{ph[0], ph[1], ph[2], ph[3]}, bl = rr_u4{pl[0], pl[1], pl[2], pl[3]};
+                if (k < NK0) {
+                    // ---- node stage 0, chunk k: S (the S^T tiles as operand fragments, 16 features at a time), then x (chunk cx is
+                    //      requested at step cx + 5 and converted under step cx + 7) -------------------------------------------------
+                    if (k >= 5 && k - 5 < W_NXC) xissue(k - 5);
 #pragma unroll
-                    for (int fbo = 0; fbo < WB; ++fbo) RR_MFH(wq[(i0 + 2 * fbo + 1) % W_Q], bh, hacc[fbo]);
+                    for (int fbo = 0; fbo < WB; ++fbo) RR_MFH(fr[2 * fbo], bl, hacc[fbo]);
 #pragma unroll
-                    for (int fbo = 0; fbo < WB; ++fbo) RR_MFH(wq[(i0 + 2 * fbo) % W_Q], bh, hacc[fbo]);
-                    if (c + 1 < NKS) {
-                        const int c1 = c + 1, fb1 = c1 >> 1, cc1 = c1 & 1;
+                    for (int fbo = 0; fbo < WB; ++fbo) RR_MFH(fr[2 * fbo + 1], bh, hacc[fbo]);
+#pragma unroll
+                    for (int fbo = 0; fbo < WB; ++fbo) RR_MFH(fr[2 * fbo], bh, hacc[fbo]);
+                    if (k + 1 < NKS) {
+                        const int c1 = k + 1, fb1 = c1 >> 1, cc1 = c1 & 1;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) rr_split2s(sacc[fb1][8 * cc1 + 2 * q], sacc[fb1][8 * cc1 + 2 * q + 1], fs, nph[q], npl[q]);
-                    } else if (c + 1 < NK0) {
-                        const int cx = c + 1 - NKS;
+                    } else if (k + 1 < NK0) {
+                        const int cx = k + 1 - NKS;
 #pragma unroll
                         for (int j = 0; j < 2; ++j) {
-                            rr_split2s(xr[cx % 4][j].x, xr[cx % 4][j].y, rs0, nph[2 * j], npl[2 * j]);
-                            rr_split2s(xr[cx % 4][j].z, xr[cx % 4][j].w, rs0, nph[2 * j + 1], npl[2 * j + 1]);
+                            rr_split2s(xr[cx % 3][j].x, xr[cx % 3][j].y, rs0, nph[2 * j], npl[2 * j]);
+                            rr_split2s(xr[cx % 3][j].z, xr[cx % 3][j].w, rs0, nph[2 * j + 1], npl[2 * j + 1]);
                         }
                     }
-                    RR_MIX(12, 2)
+                    W_MIX(12, 8, 2, 2)
                     RR_SB();
+                    if (k + 1 == NK0) {
+                        // ---- between the stages: activation, row scale of H, the first 16 hidden features as fragments --------------------
+                        t5 = clk();
+                        float m2 = 0.f;
+                        rr_mfma_settle();
 #pragma unroll
-                    for (int q = 0; q < 8; ++q)
-                        if (i0 + q + W_Q < SH::N_STREAM) wq[(i0 + q) % W_Q] = W_STREAM(i0 + q + W_Q);
+                        for (int fbo = 0; fbo < WB; ++fbo)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { ph[q] = nph[q]; pl[q] = npl[q]; }
-                }
-            }
+                            for (int r = 0; r < 16; ++r) hacc[fbo][r] = rr_max(hacc[fbo][r], lo_0);
 #pragma unroll
-            for (int fb = 0; fb < WB; ++fb)
+                        for (int fbo = 0; fbo < WB; ++fbo)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) sacc[fb][r] = 0.f;
-            badt = 0;
-            const unsigned t5 = clk();
-            // =====================================================================================================================
-            // node stage 1: OUT = H W1^T (8 chunks of the hidden rows x 4 output blocks), rows leave as 128-byte row segments
-            // =====================================================================================================================
-            float m2 = 0.f;
-            rr_mfma_settle();
+                            for (int r = 0; r < 16; r += 2) m2 = fmaxf(fmaxf(fabsf(hacc[fbo][r]), fabsf(hacc[fbo][r + 1])), m2);
+                        const unsigned m2b = rr_xhalf_max(__float_as_uint(m2));
+                        int e2 = (int)(m2b >> 23) + (e_t - 141 - E0);
+                        e2 = e2 < 15 ? 15 : (e2 > 254 ? 254 : e2);
+                        f2 = rr_pow2(e_t - e2 - E0 + 127);
+                        inv2 = rr_pow2(e2 - 14 - E1);
+                        if (m2b >= 0x7f800000u || badrow) { f2 = __uint_as_float(0x7fc00000u); inv2 = f2; badrow = true; }
+                        anybad = __builtin_amdgcn_ballot_w64(badrow) != 0ull;
 #pragma unroll
-            for (int fbo = 0; fbo < WB; ++fbo)
+                        for (int q = 0; q < 4; ++q) rr_split2s(hacc[0][2 * q], hacc[0][2 * q + 1], f2, nph[q], npl[q]);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) hacc[fbo][r] = rr_max(hacc[fbo][r], lo_0);
+                        for (int fb = 0; fb < WB; ++fb)
 #pragma unroll
-            for (int fbo = 0; fbo < WB; ++fbo)
+                            for (int r = 0; r < 16; ++r) oacc[fb][r] = 0.f;
+                        t5a = clk();
+                    }
+                } else {
+                    // ---- node stage 1, chunk c of the hidden rows: OUT = H W1^T ---------------------------------------------------------
+                    const int c = k - NK0;
 #pragma unroll
-                for (int r = 0; r < 16; r += 2) m2 = fmaxf(fmaxf(fabsf(hacc[fbo][r]), fabsf(hacc[fbo][r + 1])), m2);
-            const unsigned m2b = rr_xhalf_max(__float_as_uint(m2));
-            int e2 = (int)(m2b >> 23) + (e_t - 141 - E0);
-            e2 = e2 < 15 ? 15 : (e2 > 254 ? 254 : e2);
-            float f2 = rr_pow2(e_t - e2 - E0 + 127);
-            float inv2 = rr_pow2(e2 - 14 - E1);
-            if (m2b >= 0x7f800000u || badrow) { f2 = __uint_as_float(0x7fc00000u); inv2 = f2; badrow = true; }
-            const bool anybad = __builtin_amdgcn_ballot_w64(badrow) != 0ull;
-            advance();                                  // (the next unit's gathers fly under this stage)
-            f32x16 oacc[WB];
+                    for (int fb = 0; fb < WB; ++fb) RR_MFH(bl, fr[2 * fb], oacc[fb]);
 #pragma unroll
-            for (int fb = 0; fb < WB; ++fb)
+                    for (int fb = 0; fb < WB; ++fb) RR_MFH(bh, fr[2 * fb + 1], oacc[fb]);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[fb][r] = 0.f;
-            {
-                unsigned ph[4], pl[4], nph[4], npl[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) rr_split2s(hacc[0][2 * q], hacc[0][2 * q + 1], f2, ph[q], pl[q]);
-#pragma unroll
-                for (int c = 0; c < NKS; ++c) {
-                    const rr_u4 ah = rr_u4{ph[0], ph[1], ph[2], ph[3]}, al = rr_u4{pl[0], pl[1], pl[2], pl[3]};
-                    const int i0 = NK0 * WB * 2 + 8 * c;
-#pragma unroll
-                    for (int fb = 0; fb < WB; ++fb) RR_MFH(al, wq[(i0 + 2 * fb) % W_Q], oacc[fb]);
-#pragma unroll
-                    for (int fb = 0; fb < WB; ++fb) RR_MFH(ah, wq[(i0 + 2 * fb + 1) % W_Q], oacc[fb]);
-#pragma unroll
-                    for (int fb = 0; fb < WB; ++fb) RR_MFH(ah, wq[(i0 + 2 * fb) % W_Q], oacc[fb]);
+                    for (int fb = 0; fb < WB; ++fb) RR_MFH(bh, fr[2 * fb], oacc[fb]);
                     if (c + 1 < NKS) {
                         const int c1 = c + 1, fb1 = c1 >> 1, cc1 = c1 & 1;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) rr_split2s(hacc[fb1][8 * cc1 + 2 * q], hacc[fb1][8 * cc1 + 2 * q + 1], f2, nph[q], npl[q]);
                     }
-                    RR_MIX(12, 2)
+                    W_MIX(12, 8, 2, 2)
                     RR_SB();
-#pragma unroll
-                    for (int q = 0; q < 8; ++q)
-                        if (i0 + q + W_Q < SH::N_STREAM) wq[(i0 + q) % W_Q] = W_STREAM(i0 + q + W_Q);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) { ph[q] = nph[q]; pl[q] = npl[q]; }
                 }
+                lds_barrier();
+#pragma unroll
+                for (int q = 0; q < 8; ++q) fr[q] = nf[q];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { ph[q] = nph[q]; pl[q] = npl[q]; }
             }
+            const unsigned t5b = clk();
+            advance();                                  // (the next tile's first gathers fly under the stores)
+            const unsigned t5c = clk();
+            int li = li0, lh = lh0;
+            asm volatile("" : "+v"(li), "+v"(lh));
+            // ---- rows leave as 128-byte row segments ---------------------------------------------------------------------------------
             float invr[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) invr[r] = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * rr_crow(r, lh), __float_as_int(inv2)));
             const int voff_lane = (4 * lh * 32 * WB + li) * 4;
-            const __amdgpu_buffer_rsrc_t orow = __builtin_amdgcn_make_buffer_rsrc(a.out + (int64_t)cur.m0 * (32 * WB), 0, nn * (32 * WB * 4), 0x00020000);
+            const __amdgpu_buffer_rsrc_t orow = __builtin_amdgcn_make_buffer_rsrc(a.out + (int64_t)t_m0 * (32 * WB), 0, nn * (32 * WB * 4), 0x00020000);
 #pragma unroll
             for (int fb = 0; fb < WB; ++fb) {
-                const float cb = tab[3 * 32 * WB + 32 * fb + li];
+                const float cb = cb1[fb];
                 auto put = [&](auto nanrows) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
@@ -597,16 +702,15 @@ __global__ __launch_bounds__(256) void layer_fused_kernel_w(WArgs a, unsigned lo
                 };
                 if (anybad) put(std::true_type{}); else put(std::false_type{});
             }
-            if (PROF) { const unsigned t6 = clk(); pc[7] += 1; pc[4] += t5 - t3; pc[5] += t6 - t5; }
+            if (PROF) { const unsigned t6 = clk(); pc[7] += tile_valid ? 1 : 0; pc[3] += tr1 - tr0; pc[4] += t5 - tr1; pc[5] += t6 - t5; pd[0] += t5a - t5; pd[1] += t5b - t5a; pd[2] += t5c - t5b; pd[3] += t6 - t5c; }
+            rotate();
         }
-        cur = nxt; nxt = nn2;
-        pt = npt; pt1 = npt1; xet = nxet;
-        pre = pren;
     }
     if (PROF && prof && lane0 == 0 && (range == 0 || range == a.n_ranges / 2)) {
         unsigned long long *o = prof + (range == 0 ? 0 : 16);
         for (int q = 0; q < 8; ++q) o[q] = pc[q];
         o[8] = clk() - t_start;
+        for (int q = 0; q < 4; ++q) o[9 + q] = pd[q];
     }
 }
 
@@ -687,6 +791,18 @@ __global__ __launch_bounds__(1024) void layer_w_prepare_kernel(WPrepArgs p, unsi
     for (int i = tid; i < SH::F_ALL * 64; i += 1024) {
         const int f = i >> 6, lane = i & 63, l31 = lane & 31, h = lane >> 5;
         int st, blk, c, plane;
+        if (f >= SH::F_WB) {
+            // (c0, deg column) of node stage 0 in matrix units as bf16 planes: lane (g, h), k-slot 8 h + s -> 0..2 planes of c0, 3..5 and 6..8 planes of w_deg
+            const int row = 32 * (f - SH::F_WB) + l31;
+            const float s0 = rr_pow2(E0 + 127);
+            const float cv = w_prep_c0(p, 1, row) * s0, wd = p.W[1][(int64_t)row * p.k_total[1] + W_DX + Wd] * w_prep_bn(p, 1, row) * s0;
+            unsigned c1, c2, c3, d1, d2, d3;
+            rr_split3b(cv, 0.f, c1, c2, c3);
+            rr_split3b(wd, 0.f, d1, d2, d3);
+            c1 &= 0xffffu; c2 &= 0xffffu; c3 &= 0xffffu; d1 &= 0xffffu; d2 &= 0xffffu; d3 &= 0xffffu;
+            frag[i] = h ? rr_u4{d3, 0u, 0u, 0u} : rr_u4{c1 | (c2 << 16), c3 | (d1 << 16), d2 | (d3 << 16), d1 | (d2 << 16)};
+            continue;
+        }
         if (f < SH::F_W0) { st = 0; const int q = f - SH::F_WE; plane = q & 1; blk = (q >> 1) % WB; c = (q >> 1) / WB; }          // c = chunk step
         else if (f < SH::F_W1) { st = 1; const int q = f - SH::F_W0; plane = q & 1; blk = (q >> 1) % WB; c = (q >> 1) / WB; }
         else { st = 2; const int q = f - SH::F_W1; plane = q & 1; blk = (q >> 1) % WB; c = (q >> 1) / WB; }
@@ -862,8 +978,8 @@ int w_forward(int64_t n_nodes, int64_t n_edges, const int32_t *seg_ptr, const gs
             for (int w = 0; w < 2; ++w) {
                 const unsigned long long *o = h + 16 * w;
                 const double nu = o[6] ? (double)o[6] : 1.0, nt = o[7] ? (double)o[7] : 1.0;
-                fprintf(stderr, "wprof range %s: units %llu tiles %llu total %llu cycles | per unit: scales %.0f edge loop %.0f epilogue %.0f advance %.0f | per tile: stage0 %.0f stage1 %.0f\n",
-                        w ? "mid" : "0", o[6], o[7], o[8], o[0] / nu, o[1] / nu, o[2] / nu, o[3] / nu, o[4] / nt, o[5] / nt);
+                fprintf(stderr, "wprof range %s: units %llu tiles %llu total %llu cycles | per unit: scales %.0f edge loop %.0f epilogue %.0f rendezvous %.0f | per tile: stage0 %.0f stage1 %.0f (between the stages %.0f, steps %.0f, advance %.0f, stores %.0f)\n",
+                        w ? "mid" : "0", o[6], o[7], o[8], o[0] / nu, o[1] / nu, o[2] / nu, o[3] / nu, o[4] / nt, o[5] / nt, o[9] / nt, o[10] / nt, o[11] / nt, o[12] / nt);
             }
     } else {
         hipLaunchKernelGGL((layer_fused_kernel_w<false>), dim3((unsigned)gx), dim3(256), SH::LDS_BYTES, st, a, (unsigned long long *)nullptr);

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--graphs", type=int, default=65536)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--float-inputs", action="store_true", help="real-valued inputs (no row is exact in fp16)")
+    ap.add_argument("--wide", action="store_true", help="a hidden layer of the d = 128 model: d_in = 128, K = 272 edge rows (csrc/layer_w.hip)")
     args = ap.parse_args()
     b = synth.zinc_shape_batch(args.graphs, seed=1000)
     N, E = b.num_nodes, b.num_edges
@@ -29,12 +30,16 @@ def main():
     ids = torch.nn.functional.one_hot(torch.randint(0, 3, (E, 4)), 3).reshape(E, 12).float().to(dev)
     if args.float_inputs:
         x, ef, ids = torch.randn_like(x), torch.randn_like(ef), torch.randn_like(ids)
+    d_in = 28
+    if args.wide:
+        d_in = 128
+        x = torch.randn(N, 128, device=dev).relu()
     ei = torch.from_numpy(b.edge_index).to(dev)
     deg = torch.zeros(N, device=dev)
     torch.manual_seed(0)
-    layer = layers.GSN_edge_sparse(**CTOR).to(dev).eval()
-    b_alg = 16.0 * E + 4.0 * (N * 28 + E * 12 + E * 4 + N * 128)
-    f_alg = 2.0 * E * (72 * 128 + 128 * 128) + 2.0 * N * ((28 + 128) * 128 + 128 * 128)
+    layer = layers.GSN_edge_sparse(**dict(CTOR, d_in=d_in)).to(dev).eval()
+    b_alg = 16.0 * E + 4.0 * (N * d_in + E * 12 + E * 4 + N * 128)
+    f_alg = 2.0 * E * ((2 * d_in + 16) * 128 + 128 * 128) + 2.0 * N * ((d_in + 128) * 128 + 128 * 128)
     res = {"graphs": args.graphs, "N": N, "E": E, "B_alg_bytes": b_alg, "F_alg_flops": f_alg}
     ys = {}
     for name, fused in (("fused", True), ("multi_launch", False)):
