@@ -211,12 +211,12 @@ def dry_run(args):
         dist.destroy_process_group()
 
 
-def rr_tiling(seg, n_nodes, grid=256):
+def rr_tiling(seg, n_nodes, grid=256, unit=32):
     """The tiles and 32-row edge blocks csrc/layer_rr.hip walks for this CSR (its iterator restated): 2048 node ranges, tiles of <= 32
     nodes whose in-edges are a whole number of 64-row chunks where the degrees allow it, blocks of <= 32 edge rows.  For the roofline's
     executed-MFMA count (outside the timed region)."""
     n_tiles_nominal = (n_nodes + 31) // 32
-    n_ranges = min(grid * 8, n_tiles_nominal)
+    n_ranges = min(grid * 8, n_tiles_nominal)            # (layer_w.hip: 256 workgroups x 4 waves = the same 1024 with grid = 128)
     tiles = blocks = 0
     for r in range(n_ranges):
         m, end = n_nodes * r // n_ranges, n_nodes * (r + 1) // n_ranges
@@ -228,7 +228,7 @@ def rr_tiling(seg, n_nodes, grid=256):
                 cap = int(cnt[nmax]) // 64 * 64
                 nn = max(1, int(np.searchsorted(cnt, cap, side="right")) - 1)
             tiles += 1
-            blocks += (int(cnt[nn]) + 31) // 32
+            blocks += (int(cnt[nn]) + unit - 1) // unit
             m += nn
     return tiles, blocks
 
@@ -347,6 +347,44 @@ def float_input_layer(layer, b, ei, dev):
     layers.KERNEL_TIMER = None
     ms = sum(e0.elapsed_time(e1) for e0, e1, _ in evs) / max(len(evs), 1)
     return {"layer_launch_ms": round(ms, 4)}
+
+
+def wide_layer(b, ei, dev):
+    """A hidden layer of the d = 128 model on the bench batch (GSN_edge_sparse, d_in = 128, K = 272 edge rows: csrc/layer_w.hip, one
+    launch behind the row-exponent pass).  Executed MFMA flops per launch: one tile of <= 32 nodes / one unit of <= 64 in-edges =
+    744 products of 32 x 32 x 16 (408 edge stage + 48 incidence + 192 + 96 node stages)."""
+    import torch
+    from gsn_amd import layers
+    N, E = b.num_nodes, b.num_edges
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(N, 128, generator=g).relu().to(dev)
+    ids = torch.randn(E, 12, generator=g).abs().to(dev)
+    ef = torch.randn(E, 4, generator=g).to(dev)
+    deg = torch.zeros(N, device=dev)
+    torch.manual_seed(0)
+    ctor = dict(d_in=128, d_ef=4, d_id=12, d_degree=1, degree_as_tag=False, retain_features=True, id_scope="local", d_msg=128, d_up=128,
+                d_h=[128], seed=0, activation_name="relu", bn=True, msg_kind="general", flow="source_to_target")
+    layer = layers.GSN_edge_sparse(**ctor).to(dev).eval()
+    with torch.no_grad():
+        for _ in range(5):
+            layer(x, ei, identifiers=ids, degrees=deg, edge_features=ef)
+        torch.cuda.synchronize()
+        layers.KERNEL_TIMER = {}
+        for _ in range(10):
+            layer(x, ei, identifiers=ids, degrees=deg, edge_features=ef)
+        torch.cuda.synchronize()
+    evs = layers.KERNEL_TIMER.get("layer_fused", [])
+    layers.KERNEL_TIMER = None
+    if not evs:
+        return {"error": "the layer did not take the one-launch path"}
+    ms = sum(e0.elapsed_time(e1) for e0, e1, _ in evs) / len(evs)
+    b_alg = 16.0 * E + 4.0 * (N * 128 + E * 16 + N * 128)
+    seg = np.concatenate([[0], np.cumsum(np.bincount(b.edge_index[1], minlength=N))])
+    n_t, n_b = rr_tiling(seg, N, grid=128, unit=64)
+    f_exec = 32768.0 * (n_b * 456 + n_t * 288)
+    return {"ms": round(ms, 4), "algorithmic_bytes": int(b_alg), "hbm_GBs": round(b_alg / ms / 1e6, 1), "hbm_frac": round(b_alg / ms / 1e6 / 8000.0, 4),
+            "mfma_executed_TFLOPs": round(f_exec / ms / 1e9, 1), "mfma_frac": round(f_exec / ms / 1e9 / 2500.0, 4), "units": int(n_b), "tiles": int(n_t),
+            "note": "row-exponent pass + layer_fused_kernel_w, HIP events around both"}
 
 
 def main():
@@ -586,7 +624,7 @@ def main():
                    "note": "BASELINE configs[1] dataset size: 12 000 ZINC-shaped graphs per step (N=%d, E=%d)" % (b2.num_nodes, b2.num_edges)}
 
     # Supplementary (never `value`): the reference's real batch sizes, the stand-alone aggregation stage, the layer on real-valued inputs
-    small = prop = flt = None
+    small = prop = flt = wide = None
     if world == 1 and not args.no_extras:
         try:
             small = small_batch_steps(plan, layer, dev)
@@ -600,6 +638,10 @@ def main():
             flt = float_input_layer(layer, b, ei, dev)
         except Exception as ex:
             flt = {"error": str(ex)[:200]}
+        try:
+            wide = wide_layer(b, ei, dev)
+        except Exception as ex:
+            wide = {"error": str(ex)[:200]}
     # every rank's own time of the K steps (the headline takes the maximum): a slow rank shows up by name in the N > 1 line
     per_rank_ms = [round(dt_own / args.steps * 1e3, 4)]
     if dist is not None and world > 1:
@@ -727,6 +769,8 @@ def main():
             extra["propagate"] = prop
         if flt is not None:
             extra["layer_float_inputs"] = flt
+        if wide is not None:
+            extra["layer_wide_d128"] = wide
         extra["ms_per_step_by_rank"] = per_rank_ms
         extra["prewarm_steps_untimed"] = int(os.environ.get("GSN_BENCH_PREWARM", "60"))
         if model4 is not None:

@@ -14,6 +14,8 @@
 // searches and writes both.  HBM traffic = read edge_index once (16 B/column) + write the int64 rows once.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 
 #include "count_core.h"
@@ -30,6 +32,10 @@ struct CountArgs {
     int ids_are_global;
     const int32_t *graph_ids;  // or null
     int n_cap, e_cap;          // LDS capacities (rows of A, columns)
+    int n_decl, e_decl;        // the caller's max_nodes / max_edges: a single graph beyond them is reported (GSN_ST_TOO_LARGE)
+    int stack_skip;            // frames of the candidate stack that are never addressed (the smallest n_fixed of the plans)
+    int pair;                  // 1: a workgroup takes the graphs 2 i, 2 i + 1 -- as ONE graph, their disjoint union, when that fits n_cap / e_cap
+    int n_graphs;
     int stage_out;             // 1: output rows staged in LDS then written coalesced
     int sym;                   // edge mode with undirected orbit classes: rows (u,v) and (v,u) are equal -> search once
     int split;                 // workgroups per graph (each takes a contiguous slice of the (column,row) task space)
@@ -53,12 +59,30 @@ struct CountArgs {
     uint32_t enc_magic;        // floor(2^32 / enc_width) + 1: row = mulhi(i, magic) for i < rows_cap * enc_width
 };
 
+// diagnostic build (-DCOUNT_PROF, scripts/rr_variant.sh with RR_VARIANT_SRC=count): cycles of thread 0 per phase, summed over the workgroups
+#ifdef COUNT_PROF
+__device__ unsigned long long *g_count_prof;   // [items][8], set by the launcher
+#define COUNT_T(I) do { __syncthreads(); if (threadIdx.x == 0 && g_count_prof) { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); g_count_prof[(size_t)blockIdx.x * 8 + (I)] = t_now - t_prev; t_prev = t_now; } } while (0)
+#else
+#define COUNT_T(I)
+#endif
+
+// One pass of a workgroup over `ng` consecutive graphs g .. g + ng - 1 taken as ONE graph, their disjoint union (ng = 2 only for plans
+// whose patterns are connected: an image of a connected pattern lies inside one component, so every rooted count of the union is the
+// count in the root's own graph; vertex ids of the second graph follow the first's, rows and columns are contiguous in the batch
+// anyway).  Two ZINC-sized graphs fill the 64 lanes of the wave that had one before: the set-up phases (adjacency, cores, distance
+// tables, edge ranks: latency of dependent LDS round trips, half of a workgroup's life) are paid once per pair, and the task pool
+// keeps 64 lanes busy twice as long.  report = false (a pair): nothing is reported, a pair that does not fit or holds an error
+// returns 1 and the caller redoes its graphs one by one.
 template <int W, int T, bool DIR>
-__global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *smem, const int item, const int part, const int g, const int ng, const bool report) {
+#ifdef COUNT_PROF
+    unsigned long long t_prev = __builtin_amdgcn_s_memtime();
+#endif
+    __syncthreads();                                    // (a pass before this one has finished with LDS)
     uint64_t *A = reinterpret_cast<uint64_t *>(smem);
     uint64_t *valid = reinterpret_cast<uint64_t *>(smem + a.off_valid);
-    uint64_t *stack = reinterpret_cast<uint64_t *>(smem + a.off_stack);
+    uint64_t *stack = reinterpret_cast<uint64_t *>(smem + a.off_stack) - (size_t)a.stack_skip * W * T;   // (frame l at stack + l W T: see the launcher)
     uint32_t *plan = reinterpret_cast<uint32_t *>(smem + a.off_plan);
     typedef typename std::conditional<(W <= 4), uint8_t, uint16_t>::type vid_t;   // column endpoints
     vid_t *eu = reinterpret_cast<vid_t *>(smem + a.off_eu);
@@ -75,25 +99,27 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
     const int *enc = reinterpret_cast<const int *>(smem + a.off_enc);   // [2 * n_cols] (encoded output only)
 
     const int tid = threadIdx.x;
-    const int item = (int)blockIdx.x / a.split, part = (int)blockIdx.x - item * a.split;
-    const int g = a.graph_ids ? a.graph_ids[item] : item;
+    (void)item;
     const int64_t n0 = a.node_ptr[g], e0 = a.edge_ptr[g];
-    const int64_t n64 = a.node_ptr[g + 1] - n0, E64 = a.edge_ptr[g + 1] - e0;
+    const int64_t n64 = a.node_ptr[g + ng] - n0, E64 = a.edge_ptr[g + ng] - e0;
+    const int64_t nA64 = a.node_ptr[g + 1] - n0, EA64 = a.edge_ptr[g + 1] - e0;      // the first graph's share (ng = 1: everything)
     const bool edge_mode = a.mode == GSN_MODE_EDGE;
     const int64_t rows64 = edge_mode ? E64 : n64;
     const int64_t row0 = edge_mode ? e0 : n0;
     const int n_cols = a.n_cols;
 
-    if (n64 > a.n_cap || E64 > a.e_cap || n64 > W * 64) {
+    if (ng > 1 && (n64 > a.n_cap || E64 > a.e_cap || n64 > W * 64)) return 1;
+    if (ng == 1 && (n64 > a.n_decl || E64 > a.e_decl || n64 > W * 64)) {
         // caller under-declared max_nodes / max_edges: report, leave zeros
         if (part == 0) {
             if (a.out) for (int64_t i = tid; i < rows64 * n_cols; i += T) a.out[row0 * n_cols + i] = 0;
             if (a.enc_out) for (int64_t i = tid; i < rows64 * a.enc_width; i += T) a.enc_out[row0 * a.enc_width + i] = 0.f;
             if (tid == 0) atomicMax(&a.status[g], (int)GSN_ST_TOO_LARGE);
         }
-        return;
+        return 0;
     }
     const int n = (int)n64, E = (int)E64, rows = (int)rows64;
+    const int nA = (int)nA64, EA = (int)EA64;
 
     // one finished cell (row, column) = cnt: the int64 row (staged or direct), the staged class index or the encoded floats
     auto emit_cell = [&](int row, int col, uint64_t cnt) {
@@ -125,29 +151,33 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
             reinterpret_cast<int *>(smem + a.off_enc)[2 * c] = o;
             reinterpret_cast<int *>(smem + a.off_enc)[2 * c + 1] = a.enc_n[c];
         }
-    if (tid < 4) misc[tid] = 0;
+    if (tid < 8) misc[tid] = 0;
     __syncthreads();
 
+    COUNT_T(0);
     // ---- phase 1: adjacency bit matrix from the columns -----------------------------------------------------------
-    const int64_t off = a.ids_are_global ? n0 : 0;
     for (int c = tid; c < E; c += T) {
+        const bool second = c >= EA;                    // (a column of the pair's second graph: its vertices are nA .. n - 1)
+        const int64_t off = a.ids_are_global ? n0 : (second ? -(int64_t)nA : 0);
         const int64_t u64 = a.src[e0 + c] - off, v64 = a.dst[e0 + c] - off;
-        if (u64 < 0 || v64 < 0 || u64 >= n || v64 >= n) {
+        const int64_t lo = second ? nA : 0, hi = second ? n : nA;
+        if (u64 < lo || v64 < lo || u64 >= hi || v64 >= hi) {
             atomicMax(&misc[2], (int)GSN_ST_BAD_INDEX);
             if (edge_mode) { eu[c] = 0; ev[c] = 0; }
             continue;
         }
         const int u = (int)u64, v = (int)v64;
         if (edge_mode) { eu[c] = (vid_t)u; ev[c] = (vid_t)v; }
-        atomicMax(&misc[1], (u > v ? u : v) + 1);  // graph-tool creates vertices 0..max id, self-loop columns included
+        atomicMax(&misc[second ? 5 : 1], (u > v ? u : v) + 1);  // graph-tool creates vertices 0..max id, self-loop columns included
         if (u != v) {
             atomicOr(reinterpret_cast<unsigned long long *>(&A[u * W + (v >> 6)]), 1ull << (v & 63));
             atomicOr(reinterpret_cast<unsigned long long *>(&(DIR ? A_in : A)[v * W + (u >> 6)]), 1ull << (u & 63));
         }
     }
     __syncthreads();
-    const int n_active = misc[1];
-    if (tid < W) valid[tid] = below_word(n_active, tid);
+    COUNT_T(1);
+    // the vertices that exist: 0 .. largest id of the first graph, nA .. largest id of the second
+    if (tid < W) valid[tid] = below_word(misc[1], tid) | (below_word(misc[5], tid) & ~below_word(nA, tid));
     // d-cores: every image of a pattern with minimum degree d lies in the d-core of the graph (its >= d pattern neighbours
     // are images too), so the plan's candidate universe is that core instead of all vertices -- on molecules the 2-core
     // (ring systems and what connects them) is a fraction of the graph and rooted searches from the rest end at once.
@@ -190,6 +220,7 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
         }
     }
     __syncthreads();
+    COUNT_T(2);
     // distance pruning tables: vertices within 2 / 3 hops (count_core.h, candidates())
     if (balls) {
         for (int v = tid; v < n; v += T) ball_expand<W>(A, nullptr, v, balls);
@@ -197,6 +228,7 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
         for (int v = tid; v < n; v += T) ball_expand<W>(A, balls, v, balls + a.n_cap * W);
     }
 
+    COUNT_T(3);
     // ---- phase 2 (edge mode): CSR rank of every directed pair, last-duplicate-wins column, the rows that search ---------
     if (edge_mode) {
         if (W == 1 && T == 64) {                 // one wave, n <= 64: the row starts are a wave prefix sum of the degrees
@@ -267,14 +299,16 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
     }
     __syncthreads();
     if (misc[2] != 0) {  // bad index: zeros + status
+        if (!report) return 1;
         if (part == 0) {
             if (a.out) for (int i = tid; i < rows * n_cols; i += T) a.out[row0 * n_cols + i] = 0;
             if (a.enc_out) for (int i = tid; i < rows * a.enc_width; i += T) a.enc_out[row0 * a.enc_width + i] = 0.f;
             if (tid == 0) atomicMax(&a.status[g], misc[2]);
         }
-        return;
+        return 0;
     }
 
+    COUNT_T(4);
     // ---- phase 3: task pool -- (column, row) cells, pulled by lanes as they go idle --------------------------------
     // this workgroup takes the tasks  part, part + split, part + 2*split, ...  (strided, so the heavy columns of a
     // pattern family are spread over all the workgroups of a graph); n_tasks = how many of them
@@ -339,7 +373,7 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
                         roots = fv_roots<W>(eu[t_row], ev[t_row]);
                     } else {
                         t_row = t_idx;
-                        if (t_row >= n_active) p_i = p_e;  // vertex beyond the largest id: not a vertex of the matched graph
+                        if (!((valid[t_row >> 6] >> (t_row & 63)) & 1ull)) p_i = p_e;  // vertex beyond the largest id: not a vertex of the matched graph
                         roots = fv_roots<W>(t_row, 0);
                     }
                 } else {
@@ -369,6 +403,7 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
     }
     __syncthreads();
 
+    COUNT_T(5);
     // ---- phase 4: coalesced write of the staged rows --------------------------------------------------------------
     if (a.stage_out) {   // (only with split == 1)
         int64_t *dst = a.out + row0 * n_cols;
@@ -409,7 +444,28 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
             dst[i] = (k < enc[2 * c + 1] && (int)est[r * n_cols + c] == k) ? 1.f : 0.f;
         }
     }
-    if (tid == 0 && misc[2] != 0) atomicMax(&a.status[g], misc[2]);   // status[] is zeroed by the launcher
+    COUNT_T(6);
+    if (misc[2] != 0) {
+        if (!report) return 1;
+        if (tid == 0) atomicMax(&a.status[g], misc[2]);   // status[] is zeroed by the launcher
+    }
+    return 0;
+}
+
+template <int W, int T, bool DIR>
+__global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int item = (int)blockIdx.x / a.split, part = (int)blockIdx.x - item * a.split;
+    // one call site (the body is inlined once): pass 0 = the graph, or the pair 2 i, 2 i + 1 as one; passes 1, 2 = the pair's graphs one by
+    // one when it did not fit or held an error
+    const int g0 = a.pair ? 2 * item : (a.graph_ids ? a.graph_ids[item] : item);
+    const bool two = a.pair && g0 + 1 < a.n_graphs;
+    for (int pass = 0; pass < 3; ++pass) {
+        const int g = pass == 2 ? g0 + 1 : g0;
+        const int ng = (pass == 0 && two) ? 2 : 1;
+        const int rc = count_body<W, T, DIR>(a, smem, item, a.pair ? 0 : part, g, ng, ng == 1);
+        if (!two || (pass == 0 && rc == 0)) break;
+    }
 }
 
 __global__ void status_zero_kernel(const int32_t *graph_ids, int n, int32_t *status) {
@@ -427,6 +483,30 @@ static int launch_d(CountArgs &a, int n_items, size_t lds, hipStream_t stream) {
     hipLaunchKernelGGL((count_kernel<W, T, DIR>), dim3((unsigned)n_items), dim3(T), lds, stream, a);
     e = hipGetLastError();
     if (e != hipSuccess) return set_error(GSN_E_HIP, "count_kernel launch: %s", hipGetErrorString(e));
+#ifdef COUNT_PROF
+    {
+        (void)hipStreamSynchronize(stream);
+        static int shown = 0;
+        if (shown++ % 16 == 15) {
+            unsigned long long *buf = nullptr;
+            (void)hipMalloc(&buf, (size_t)n_items * 64);
+            (void)hipMemset(buf, 0, (size_t)n_items * 64);
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_count_prof), &buf, sizeof(buf));
+            hipLaunchKernelGGL((count_kernel<W, T, DIR>), dim3((unsigned)n_items), dim3(T), lds, stream, a);
+            (void)hipStreamSynchronize(stream);
+            unsigned long long *h = new unsigned long long[(size_t)n_items * 8];
+            (void)hipMemcpy(h, buf, (size_t)n_items * 64, hipMemcpyDeviceToHost);
+            double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int i = 0; i < n_items; ++i) for (int q = 0; q < 8; ++q) s[q] += (double)h[(size_t)i * 8 + q];
+            fprintf(stderr, "countprof W %d T %d items %d: cycles per workgroup: clear+plan %.0f adjacency %.0f cores %.0f balls %.0f edge ranks %.0f task pool %.0f write %.0f\n", W, T, n_items,
+                    s[0] / n_items, s[1] / n_items, s[2] / n_items, s[3] / n_items, s[4] / n_items, s[5] / n_items, s[6] / n_items);
+            delete[] h;
+            unsigned long long *nul = nullptr;
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_count_prof), &nul, sizeof(nul));
+            (void)hipFree(buf);
+        }
+    }
+#endif
     return GSN_OK;
 }
 template <int W, int T>
@@ -488,13 +568,40 @@ static int count_launch(const uint32_t *plan_host, const uint32_t *plan_dev, int
     // large graphs (W > 4: 16-bit vertex ids, adjacency up to 72 KiB) keep one wave per workgroup so that the candidate
     // stack stays small; their parallelism comes from `split` workgroups per graph
     const int T = (rows_cap * a.n_cols <= 512 || W > 4) ? 64 : 256;
+    a.n_decl = (int)max_nodes; a.e_decl = (int)max_edges;
+    a.n_graphs = (int)n_graphs;
+    // Two consecutive graphs per workgroup, as one graph (count_body): whole batches of small graphs whose plans hold connected patterns
+    // only (every enumerated level of every plan has an adjacency constraint); GSN_COUNT_PAIR=0 switches it off.
+    const int64_t tasks_cap1 = rows_cap * a.n_cols;
+    bool pair = !graph_ids && n_graphs >= 2 && W == 1 && T == 64 && !(n_items < 2048 && tasks_cap1 >= 1024);
+    if (pair) { const char *d = getenv("GSN_COUNT_PAIR"); if (d && atoi(d) == 0) pair = false; }
+    for (int p = 0; pair && p < a.n_plans; ++p) {
+        const uint32_t *w = plan_host + a.plans_off + (int64_t)p * a.stride;
+        const int k = (int)(w[0] & 0xffu), nfix = (int)((w[0] >> 8) & 0xffu);
+        for (int l = nfix; l < k; ++l) {
+            const uint32_t adj = (w[2 + l] & 0xffu) | (directed ? (w[PLAN_STRIDE_WORDS + l] & 0xffu) : 0u);
+            if (adj == 0) pair = false;
+        }
+    }
+    a.pair = pair ? 1 : 0;
+    if (pair) {
+        max_nodes = 2 * max_nodes < 64 ? 2 * max_nodes : 64;
+        max_edges = 2 * max_edges;
+    }
+    const int64_t rows_cap_u = edge_mode ? max_edges : max_nodes;      // (of what a workgroup holds: a graph, or the union of two)
     a.n_cap = (int)max_nodes; a.e_cap = (int)max_edges;
 
     int o = align_up((int)max_nodes * W * 8, 16);
     a.off_ain = -1;
     if (directed) { a.off_ain = o; o += align_up((int)max_nodes * W * 8, 16); }
     a.off_valid = o; o += align_up(W * 8, 16);
-    const int depth = a.kmax > 1 ? a.kmax - 1 : 1;
+    // candidate stack: one frame per enumerated level below the last (levels n_fixed .. k - 2); the frames of the root levels are
+    // never touched, so the array starts at the smallest n_fixed of the plans (stack_skip frames in front of it do not exist)
+    int nfix_min = 255;
+    for (int p = 0; p < a.n_plans; ++p) { const int nf = (int)((plan_host[a.plans_off + (int64_t)p * a.stride] >> 8) & 0xffu); nfix_min = nf < nfix_min ? nf : nfix_min; }
+    if (nfix_min > a.kmax - 1 || a.n_plans == 0) nfix_min = 0;
+    a.stack_skip = nfix_min;
+    const int depth = a.kmax - 1 - nfix_min > 1 ? a.kmax - 1 - nfix_min : 1;
     a.off_stack = o; o += depth * W * T * 8;
     a.off_plan = o; o += align_up((int)plan_words * 4, 16);
     const int vid_bytes = W > 4 ? 2 : 1;
@@ -504,7 +611,7 @@ static int count_launch(const uint32_t *plan_host, const uint32_t *plan_dev, int
     a.off_last = o; o += edge_mode ? align_up((int)max_edges * 4, 16) : 0;
     a.off_prim = o; o += edge_mode ? align_up((int)max_edges * 4, 16) : 0;
     a.off_revof = o; o += edge_mode ? align_up((int)max_edges * 4, 16) : 0;
-    a.off_misc = o; o += 16;
+    a.off_misc = o; o += 32;
     a.off_enc = o; o += enc_out ? align_up(2 * a.n_cols * 4, 16) : 0;
     a.off_core = o; o += align_up((CORE_MAX + 1) * W * 8, 16);
     a.core_mask = 0;
@@ -514,16 +621,16 @@ static int count_launch(const uint32_t *plan_host, const uint32_t *plan_dev, int
     a.off_ball = -1;
     if (W == 1 && a.kmax >= 4 && !directed) { a.off_ball = o; o += align_up(2 * (int)max_nodes * W * 8, 16); }
     a.off_out = o;
-    const int64_t stage_bytes = rows_cap * a.n_cols * 8;
+    const int64_t stage_bytes = rows_cap_u * a.n_cols * 8;
     // Stage the output rows in LDS (coalesced final write) only while that keeps the workgroup small: the search is
     // latency-bound on dependent LDS reads, so heavy graphs want as many co-resident workgroups per CU as possible
     // (>= 8 waves per SIMD) and write their cells straight to HBM instead.
-    const int64_t lds_budget = (T == 64 ? 160 * 1024 / 32 : 160 * 1024 / 8);
+    const int64_t lds_budget = (T == 64 ? (pair ? 160 * 1024 / 16 : 160 * 1024 / 32) : 160 * 1024 / 8);
     a.stage_out = (out && o + stage_bytes <= lds_budget) ? 1 : 0;
     // few heavy graphs: several workgroups per graph so that every CU gets >= 8 of them
     a.split = 1;
     const int64_t tasks_cap = rows_cap * a.n_cols;
-    if (n_items < 2048 && tasks_cap >= 1024) {
+    if (!pair && n_items < 2048 && tasks_cap >= 1024) {
         int64_t sp = (2048 + n_items - 1) / n_items;
         if (sp > 32) sp = 32;
         if (sp > tasks_cap / 256) sp = tasks_cap / 256;
@@ -533,10 +640,10 @@ static int count_launch(const uint32_t *plan_host, const uint32_t *plan_dev, int
     // class indices of the encoded rows: staged whenever one workgroup owns the whole graph and the indices fit a byte; else
     // every cell writes its floats itself
     a.enc_stage = 0; a.off_encst = o; a.enc_magic = 0;
-    if (enc_out && a.split == 1 && enc_bytes && rows_cap * enc_width < (int64_t)1 << 24 && o + rows_cap * a.n_cols <= 150 * 1024) {
+    if (enc_out && a.split == 1 && enc_bytes && rows_cap_u * enc_width < (int64_t)1 << 24 && o + rows_cap_u * a.n_cols <= 150 * 1024) {
         a.enc_stage = 1;
         a.enc_magic = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)enc_width + 1);
-        o += align_up((int)(rows_cap * a.n_cols), 16);     // (16-byte aligned: with four columns a row's indices are read as one word)
+        o += align_up((int)(rows_cap_u * a.n_cols), 16);     // (16-byte aligned: with four columns a row's indices are read as one word)
     }
     if (o > 160 * 1024) return set_error(GSN_E_UNSUPPORTED, "graph too large for LDS (%d B needed)", o);
 
@@ -546,7 +653,7 @@ static int count_launch(const uint32_t *plan_host, const uint32_t *plan_dev, int
         if (graph_ids) hipLaunchKernelGGL(status_zero_kernel, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, st, graph_ids, (int)n_items, status);
         if (e != hipSuccess) return set_error(GSN_E_HIP, "hipMemsetAsync(status): %s", hipGetErrorString(e));
     }
-    const int items = (int)n_items * a.split;
+    const int items = pair ? (int)((n_graphs + 1) / 2) : (int)n_items * a.split;
     if (W == 1 && T == 64) return launch<1, 64>(a, items, (size_t)o, st);
     if (W == 1) return launch<1, 256>(a, items, (size_t)o, st);
     if (W == 2 && T == 64) return launch<2, 64>(a, items, (size_t)o, st);

@@ -190,8 +190,11 @@ __device__ __forceinline__ void rr_gather_issue(const rr_u4 *slot_tab, int lh, c
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
+#ifndef RR_NW
+#define RR_NW 8            // waves per workgroup (one workgroup per CU): 8 = two per SIMD, 256 registers each
+#endif
 template <int WB, int NKX, bool PROF>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void layer_fused_kernel_rr(RrArgs a, unsigned long long *prof) {
+__global__ __launch_bounds__(64 * RR_NW) __attribute__((amdgpu_waves_per_eu(RR_NW / 4, RR_NW / 4))) void layer_fused_kernel_rr(RrArgs a, unsigned long long *prof) {
     // diagnostic build (GSN_FUSED_PROF=1): cycles per phase of wave 0 of workgroup 0 and of one wave in the middle of the grid
     auto clk = [&]() -> unsigned {
         if (!PROF) return 0u;
@@ -220,10 +223,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     {
         const rr_u4 *src = reinterpret_cast<const rr_u4 *>(a.prep + RR_HDR);
         rr_u4 *dst = reinterpret_cast<rr_u4 *>(smem);
-        for (int i = tid; i < SH::F_LDS * 64; i += 512) dst[i] = src[i];
+        for (int i = tid; i < SH::F_LDS * 64; i += 64 * RR_NW) dst[i] = src[i];
         const float *tsrc = reinterpret_cast<const float *>(a.prep + RR_HDR + SH::F_ALL * 256);
         float *tdst = reinterpret_cast<float *>(smem + SH::F_LDS * 1024);
-        for (int i = tid; i < SH::TAB_WORDS; i += 512) tdst[i] = tsrc[i];
+        for (int i = tid; i < SH::TAB_WORDS; i += 64 * RR_NW) tdst[i] = tsrc[i];
         if (tid < RR_NSLOT * 2) {
             const RrSlotHalf &sh = a.slot[tid >> 1][tid & 1];
             slot_tab0[tid] = rr_u4{(unsigned)sh.base, (unsigned)(sh.base >> 32), sh.stride, sh.role};
@@ -922,7 +925,7 @@ int rr_forward(int64_t n_nodes, int64_t n_edges, const int32_t *seg_ptr, const g
     const int64_t n_tiles = (n_nodes + RR_TN - 1) / RR_TN;
     int64_t gx = 256;
     { const char *d = getenv("GSN_FUSED_GRID"); if (d && atoi(d) > 0) gx = atoi(d); }
-    int64_t ranges = gx * 8;
+    int64_t ranges = gx * RR_NW;
     if (ranges > n_tiles) ranges = n_tiles;
     if (gx > ranges) gx = ranges;
     a.n_ranges = (int)ranges;
@@ -940,7 +943,7 @@ int rr_forward(int64_t n_nodes, int64_t n_edges, const int32_t *seg_ptr, const g
     if (prof_on) {
         unsigned long long *prof = nullptr;
         (void)hipMalloc(&prof, 32 * 8); (void)hipMemsetAsync(prof, 0, 32 * 8, st);
-        hipLaunchKernelGGL((layer_fused_kernel_rr<4, 2, true>), dim3((unsigned)gx), dim3(512), SH::LDS_BYTES, st, a, prof);
+        hipLaunchKernelGGL((layer_fused_kernel_rr<4, 2, true>), dim3((unsigned)gx), dim3(64 * RR_NW), SH::LDS_BYTES, st, a, prof);
         unsigned long long h[32];
         (void)hipStreamSynchronize(st);
         (void)hipMemcpy(h, prof, sizeof(h), hipMemcpyDeviceToHost);
@@ -954,7 +957,7 @@ int rr_forward(int64_t n_nodes, int64_t n_edges, const int32_t *seg_ptr, const g
                         w ? "mid" : "0", o[6], o[7], o[8], o[0] / nb, o[1] / nb, o[2] / nb, o[3] / nt, o[4] / nt, o[5] / nt, o[9] / nb, o[11] / nb, o[10] / nt);
             }
     } else {
-        hipLaunchKernelGGL((layer_fused_kernel_rr<4, 2, false>), dim3((unsigned)gx), dim3(512), SH::LDS_BYTES, st, a, (unsigned long long *)nullptr);
+        hipLaunchKernelGGL((layer_fused_kernel_rr<4, 2, false>), dim3((unsigned)gx), dim3(64 * RR_NW), SH::LDS_BYTES, st, a, (unsigned long long *)nullptr);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(GSN_E_HIP, "layer_fused_kernel_rr: %s", hipGetErrorString(e));

@@ -8,19 +8,28 @@
 //     out_v = act_1( bn_1( h_v W1'^T + b1' ) )                               per node
 //
 // Same data flow as layer_rr.hip (every wave owns a range of nodes and takes tiles of <= 32 nodes through all stages; accumulator
-// tiles turn into operand fragments in place; per-node sums through an incidence product; no barrier after the prologue), other
-// budget: 328 KiB of fp16 plane fragments instead of 184, and 2.3x the products per tile.  So
-//   * ONE wave per SIMD (256 threads per workgroup, one workgroup per CU): 512 registers per lane.  The edge stage keeps the
-//     accumulators of a UNIT of 64 edge rows (two 32-row sub-blocks x four feature blocks = 128 registers) and walks the 17
-//     16-column chunks of the rows once: per chunk 24 products that share 8 weight fragments (the LDS read per product halves),
-//     with the NEXT chunk's gathered fp32 values converted to scaled fp16 planes and the gathers three chunks ahead issued in
-//     between -- a wave issues in order, and vector work placed between two MFMAs runs under them (scripts/micro/issue_mix.hip:
-//     MFMA + 4 vector instructions = 34 cycles; scripts/micro/wide_edge_loop.hip: this loop at 850-880 cycles per chunk of 768).
-//   * the edge stage's fragments (136 KiB) live in LDS; those of the two node stages (192 KiB) stream from L2 in the order of
-//     use, two chunk steps ahead, through a ring of 16 fragments in registers.
+// tiles turn into operand fragments in place; per-node sums through an incidence product), other budget: 332 KiB of fp16 plane
+// fragments instead of 184, and 2.2x the products per tile.  So
+//   * ONE wave per SIMD (256 threads per workgroup, one workgroup per CU): 512 registers per lane (256 of them accumulator
+//     registers).  The edge stage keeps the accumulators of a UNIT of 64 edge rows (two 32-row sub-blocks x four feature blocks =
+//     128 registers) and walks the 17 16-column chunks of the rows once: per chunk 24 products that share 8 weight fragments, with
+//     the NEXT chunk's gathered fp32 values converted to scaled fp16 planes, the fragment reads of the next step and the gathers
+//     two chunks ahead issued in between -- a wave issues in order, and what is placed between two MFMAs runs under them
+//     (scripts/micro/issue_mix.hip: MFMA + 4 vector instructions = 34 cycles; scripts/micro/wide_edge_loop.hip: this loop at
+//     850-880 cycles per chunk of 768).  With one wave per SIMD nothing else hides anything: the order of issue is prescribed
+//     (W_MIX / W_MIX_EDGE), and a single register spill costs a tile ~4 000 cycles (its reload waits for every gather in flight).
+//   * the edge stage's fragments (136 KiB) live in LDS.  Those of the two node stages (192 KiB) cannot, and a CU's path to L2
+//     carries only ~30 bytes per cycle (measured: four private streams per CU were the bound, at any depth of prefetch and with
+//     half the CUs idle alike): they stream ONCE PER WORKGROUP.  After its tile's edge stage a wave meets the other three; then for
+//     each of the 24 chunk steps of the node stages wave w loads fragments 2 w, 2 w + 1 of the step four steps ahead into
+//     registers, writes them into a three-slot ring in LDS two steps ahead, and all four waves read the step's eight fragments
+//     from there.  One barrier per step; a wave whose range is exhausted keeps carrying its share until every range is.
 //   * the power-of-two row scale of an edge row must be known before its first chunk is converted, and the row is 1 KiB: it is
 //     made from the row exponents of the two node rows (a side array of one int per node, written by a small pass over x in
-//     front of this kernel) and the per-edge columns (gathered first).
+//     front of this kernel: layer_w_row_exp_kernel) and the per-edge columns (gathered first).
+//   * node stage 0's bias and deg column enter as ONE bf16 product per feature block (three bf16 planes of c0 and w_deg against
+//     the lane's row scale and deg x row scale -- powers of two and small integers are exact in bf16 at any exponent) instead of
+//     128 values per lane that would have to be loaded and held.
 //
 // Matrix arithmetic: fp16x3 everywhere (two fp16 planes per operand after exact power-of-two row / matrix scaling, three plane
 // products, fp32 accumulation); the activated edge rows enter the incidence product as three bf16 planes (exact at any magnitude).

@@ -172,6 +172,7 @@ WIDE = [
     ("MPNN_edge_sparse", dict(d_in=128, d_ef=4, d_msg=128, d_up=128, d_h=[128]), 0, 4),             # K = 260
     ("GSN_sparse", dict(d_in=128, d_id=8, d_msg=128, d_up=128, d_h=[128]), 8, 0),                    # K = 264, no edge features
     ("MPNN_sparse", dict(d_in=128, d_msg=128, d_up=128, d_h=[128]), 0, 0),                           # K = 256: no per-edge columns at all
+    ("GSN_sparse", dict(d_in=128, d_id=8, d_msg=128, d_up=128, d_h=[128], id_scope="global"), 8, 0),  # K = 272: ids of both end points (per-NODE rows in the last chunk)
 ]
 
 
@@ -180,7 +181,9 @@ def _wide_ctor(cls, ctor_kw, **over):
                 flow="source_to_target")
     if "GSN" in cls:
         base["id_scope"] = "local"
-    return dict(base, **ctor_kw, **over)
+    base.update(ctor_kw)
+    base.update(over)
+    return base
 
 
 @pytest.mark.parametrize("cls,ctor_kw,d_id,d_ef", WIDE)
@@ -191,9 +194,10 @@ def test_fused_layer_wide_rows(cls, ctor_kw, d_id, d_ef, n_graphs, capfd):
     g = torch.Generator().manual_seed(13)
     N, E = b.num_nodes, b.num_edges
     x = torch.randn(N, 128, generator=g).relu()
-    ids = torch.randn(E, d_id, generator=g).abs() if d_id else None
+    ctor = _wide_ctor(cls, ctor_kw)
+    ids = torch.randn(N if ctor.get("id_scope") == "global" else E, d_id, generator=g).abs() if d_id else None
     ef = torch.randn(E, d_ef, generator=g) if d_ef else None
-    y, y2, ref = _run(cls, _wide_ctor(cls, ctor_kw), x, ei, ids, ef, seed=9, capfd=capfd)
+    y, y2, ref = _run(cls, ctor, x, ei, ids, ef, seed=9, capfd=capfd)
     assert _elementwise_ok(y, ref), float((y - ref).abs().max() / ref.abs().max())
     assert _elementwise_ok(y, y2)
 
