@@ -654,6 +654,7 @@ static int count_launch(const uint32_t *plan_host, const uint32_t *plan_dev, int
         if (e != hipSuccess) return set_error(GSN_E_HIP, "hipMemsetAsync(status): %s", hipGetErrorString(e));
     }
     const int items = pair ? (int)((n_graphs + 1) / 2) : (int)n_items * a.split;
+    if (getenv("GSN_CHAIN_TRACE")) fprintf(stderr, "gsn count: count_kernel<%d,%d> workgroups %d pair %d split %d lds %d\n", W, T, items, a.pair, a.split, o);
     if (W == 1 && T == 64) return launch<1, 64>(a, items, (size_t)o, st);
     if (W == 1) return launch<1, 256>(a, items, (size_t)o, st);
     if (W == 2 && T == 64) return launch<2, 64>(a, items, (size_t)o, st);

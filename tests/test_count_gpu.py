@@ -160,6 +160,75 @@ def test_er128_full_size_vertex_edge_orbit_sums_agree():
     assert np.array_equal(tv.cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize("mode", ["vertex", "edge"])
+@pytest.mark.parametrize("global_ids", [True, False])
+def test_two_graphs_per_workgroup(mode, global_ids, capfd):
+    """Batches of small graphs are counted two graphs per workgroup, as one disjoint union (csrc/count.hip): pairs that fit 64
+    vertices, pairs that do not (redone one by one), an odd graph at the end, trailing isolated vertices in the FIRST graph of a pair
+    (they are not vertices of the matched graph, utils_graph_processing.py:103-110), graphs without edges, duplicate columns and self
+    loops, ids local to the graph and global; a bad index in the second graph of a pair is reported for that graph alone; a plan with
+    a disconnected pattern takes the one-graph path.  Bit-exact against the oracle, and equal to the run with pairing off."""
+    import os
+    from gsn_amd import synth
+    from gsn_amd.counting import CountPlan, count_batch
+    from oracle import oracle
+    rng = np.random.default_rng(11)
+    graphs = [synth.zinc_shape_graph(rng) for _ in range(7)]
+    graphs.append(synth.er_graph(40, 45, 3)); graphs.append(synth.er_graph(40, 40, 4))           # 80 vertices: the pair does not fit
+    graphs.append((30, np.array([[0, 1, 1, 2, 2, 0, 3, 3], [1, 0, 2, 1, 0, 2, 3, 4]], dtype=np.int64)))   # triangle + self loop + an arc without its reverse; vertices 5..29 do not exist
+    graphs.append(synth.zinc_shape_graph(rng))
+    graphs.append((4, np.zeros((2, 0), dtype=np.int64))); graphs.append((3, np.zeros((2, 0), dtype=np.int64)))
+    graphs.append(synth.er_graph(20, 45, 5))
+    dup = np.array([[0, 1, 0, 1, 2, 1, 2, 0], [1, 0, 1, 0, 1, 2, 0, 2]], dtype=np.int64)
+    graphs.append((3, dup))
+    b = synth.collate(graphs)
+    assert len(graphs) % 2 == 1
+    pats = [list(nx.cycle_graph(k).edges) for k in (3, 4, 5)] + [list(nx.path_graph(3).edges), list(nx.star_graph(3).edges)]
+    local = b.edge_index - np.repeat(b.node_ptr[:-1], np.diff(b.edge_ptr))[None, :]
+    ei = b.edge_index if global_ids else local
+    plan = CountPlan.get(pats, mode, False)
+
+    def run(check=True, edge_index=ei):
+        out, status = count_batch(plan, b.node_ptr, b.edge_ptr, torch.from_numpy(edge_index).cuda(), ids_are_global=global_ids, check=check)
+        return out.cpu().numpy(), status.cpu().numpy()
+    os.environ["GSN_CHAIN_TRACE"] = "1"
+    try:
+        got, st = run()
+    finally:
+        os.environ.pop("GSN_CHAIN_TRACE")
+    assert "pair 1" in capfd.readouterr().err
+    ref = oracle.counts2ids(mode, False, b.node_ptr, b.edge_ptr, local, pats, n_threads=4)
+    assert np.array_equal(got, ref)
+    assert not st.any()
+    os.environ["GSN_COUNT_PAIR"] = "0"
+    try:
+        got1, _ = run()
+    finally:
+        os.environ.pop("GSN_COUNT_PAIR")
+    assert np.array_equal(got, got1)
+    # a bad index in the SECOND graph of the first pair: that graph's rows are zero and its status is raised, its neighbour's rows stay
+    bad = ei.copy()
+    c = int(b.edge_ptr[1])
+    bad[0, c] = (b.node_ptr[2] if global_ids else b.node_ptr[2] - b.node_ptr[1]) + 5
+    gotb, stb = run(check=False, edge_index=bad)
+    rows = b.edge_ptr if mode == "edge" else b.node_ptr
+    assert stb[1] != 0 and not stb[0] and not stb[2:].any()
+    assert not gotb[rows[1]:rows[2]].any()
+    assert np.array_equal(gotb[:rows[1]], ref[:rows[1]]) and np.array_equal(gotb[rows[2]:], ref[rows[2]:])
+    # two triangles side by side: a disconnected pattern sees BOTH graphs of a union, so such a plan keeps one graph per workgroup
+    if mode == "vertex":
+        two = [(0, 1), (1, 2), (2, 0), (3, 4), (4, 5), (5, 3)]
+        plan2 = CountPlan.get([two], mode, False)
+        os.environ["GSN_CHAIN_TRACE"] = "1"
+        try:
+            out2, _ = count_batch(plan2, b.node_ptr, b.edge_ptr, torch.from_numpy(ei).cuda(), ids_are_global=global_ids)
+        finally:
+            os.environ.pop("GSN_CHAIN_TRACE")
+        assert "pair 0" in capfd.readouterr().err
+        ref2 = oracle.counts2ids(mode, False, b.node_ptr, b.edge_ptr, local, [two], n_threads=4)
+        assert np.array_equal(out2.cpu().numpy(), ref2)
+
+
 def test_reference_signatures_and_counts2ids():
     from gsn_amd import patterns, counting
     z = load("counts2ids")
