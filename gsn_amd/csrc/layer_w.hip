@@ -57,7 +57,7 @@ constexpr int W_MAXROLE = 3;
 constexpr int W_HDR = 32;
 constexpr unsigned W_MAGIC = 0x57573031u;
 #ifndef W_SD_N
-#define W_SD_N 5
+#define W_SD_N 4
 #endif
 constexpr int W_SD = W_SD_N;       // chunk steps a wave's share of the node-stage fragments is requested ahead of its write to the ring
 constexpr int W_PDG = 2;           // gathered chunks in flight ahead of the one being converted
