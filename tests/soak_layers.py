@@ -4,7 +4,7 @@ pytest): random class, message kind, identifier scope, flow, widths (any integer
 widths, BatchNorm on / off, activation, eval / train-mode forward, 1-700 graphs per batch (so that single-tile and multi-tile
 launches both occur).  Tolerance 1e-5 of the largest output (element-wise with the row-max floor of test_layers_gpu.py).
 
-    python tests/soak_layers.py [first_seed] [n_seeds]"""
+    python tests/soak_layers.py [first_seed] [n_seeds] [--wide]     (--wide: the `general` cases take the d = 128 shape of csrc/layer_w.hip)"""
 import os
 import sys
 
@@ -15,6 +15,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from gsn_amd import layers, synth  # noqa: E402
 from oracle import oracle  # noqa: E402
+
+
+WIDE = "--wide" in sys.argv
+if WIDE:
+    sys.argv.remove("--wide")
 
 
 def main():
@@ -28,6 +33,8 @@ def main():
         ogb = cls.endswith("_ogb")
         has_ids, has_ef = cls.startswith("GSN"), "edge" in cls
         kind = "ogb" if ogb else str(rng.choice(["general", "gin"]))
+        if WIDE and not ogb:
+            kind = "general"
         d = int(rng.choice([int(rng.integers(3, 40)), int(rng.integers(8, 50)) * 4, 64, 128])) if not ogb else int(rng.choice([int(rng.integers(4, 80)) * 4, 64, 300]))
         scope = str(rng.choice(["local", "global"]))
         flow = str(rng.choice(["source_to_target", "target_to_source"]))
@@ -41,6 +48,19 @@ def main():
             ctor.update(d_in=d, d_id=d, id_scope=scope if has_ids else "local", d_msg=None, d_up=d, d_h=[2 * d], msg_kind="ogb")
             if has_ef:
                 ctor["d_ef"] = d
+        elif kind == "general" and WIDE:
+            # the d = 128 hidden-layer shape of csrc/layer_w.hip (all widths 128, <= 16 per-edge / per-end-point columns in multiples of 4), eval
+            d = d_x = 128
+            d_id, d_ef = int(rng.choice([4, 8, 12] if scope == "local" or not has_ef else [4])), 4
+            if scope == "global" and has_ef:
+                d_id, d_ef = 4, 8
+            if scope == "global" and not has_ef:
+                d_id = int(rng.choice([4, 8]))
+            act = str(rng.choice(["relu", "identity"]))
+            training = False
+            ctor.update(activation_name=act, d_in=128, d_id=d_id, id_scope=scope, d_msg=128, d_up=128, d_h=[128], msg_kind="general")
+            if has_ef:
+                ctor["d_ef"] = d_ef
         else:
             d_x, d_id, d_ef = int(rng.integers(1, 40)), int(rng.integers(1, 20)), int(rng.integers(1, 9))
             if kind == "gin":
@@ -62,6 +82,8 @@ def main():
                 m.running_mean.uniform_(-0.3, 0.3); m.running_var.uniform_(0.5, 1.5); m.weight.data.uniform_(0.5, 1.5); m.bias.data.uniform_(-0.3, 0.3)
         layer.train(training)
         x = torch.randn(N, d_x)
+        if WIDE:                                                  # rows of very different magnitude: every edge row has its own scale
+            x = x * torch.exp2(torch.randint(-12, 13, (N, 1)).float())
         ei = torch.from_numpy(b.edge_index)
         ids_scope = ctor["id_scope"]
         ids = torch.randn(E if ids_scope == "local" else N, d_id) * 0.5 if has_ids else None
