@@ -33,6 +33,27 @@ def _register_partition(data, edge_index):
             _layers.set_batch_partition(batch, part[0])           # the readout's rows are grouped by graph already
 
 
+_PARAMETER_FREE_ENCODERS = ("one_hot_encoder", "atom_one_hot_encoder", "bond_one_hot_encoder")
+
+
+def _encode_once(memo, enc, x, training):
+    """The reference encodes ``data.identifiers`` / ``data.edge_features`` once per LAYER (models_graph_classification.py:213-223); the
+    one-hot encoders have no parameters, so every layer's encoder returns the same rows: they are made once per forward.  An encoder
+    with parameters is re-used only for the SAME module in eval mode (in train mode its BatchNorm statistics move with every call, as in
+    the reference).  ``memo``: a dict that lives for one forward."""
+    name = getattr(enc, "encoder_name", None)
+    if name in _PARAMETER_FREE_ENCODERS:
+        key = (name, tuple(enc.encoder.d_in), id(x))
+    elif not training:
+        key = (id(enc), id(x))
+    else:
+        return enc(x)
+    hit = memo.get(key)
+    if hit is None:
+        hit = memo[key] = enc(x)
+    return hit
+
+
 class GNNSubstructures(nn.Module):
     def __init__(self, in_features, out_features, encoder_ids, d_in_id, in_edge_features=None, d_in_node_encoder=None,
                  d_in_edge_encoder=None, encoder_degrees=None, d_degree=None, **kwargs):
@@ -122,6 +143,7 @@ class GNNSubstructures(nn.Module):
 
     def forward(self, data, print_flag=False, return_intermediate=False):
         kwargs = {"degrees": self.degree_encoder(data.degrees)}
+        memo = {}
         edge_index = data.edge_index
         _register_partition(data, edge_index)
         x = self.input_node_encoder(data.x)
@@ -130,9 +152,9 @@ class GNNSubstructures(nn.Module):
             x = torch.cat((x, r), 1)
         x_interm = [x]
         for i in range(len(self.conv)):
-            kwargs["identifiers"] = (self.id_encoder[i] if self.inject_ids else self.id_encoder[0])(data.identifiers)
+            kwargs["identifiers"] = _encode_once(memo, self.id_encoder[i] if self.inject_ids else self.id_encoder[0], data.identifiers, self.training)
             if hasattr(data, "edge_features"):
-                kwargs["edge_features"] = (self.edge_encoder[i] if self.inject_edge_features else self.edge_encoder[0])(data.edge_features)
+                kwargs["edge_features"] = _encode_once(memo, self.edge_encoder[i] if self.inject_edge_features else self.edge_encoder[0], data.edge_features, self.training)
             else:
                 kwargs["edge_features"] = None
             # BatchNorm1d + activation of models_graph_classification.py:226-228 ride in the layer's last epilogue
@@ -245,6 +267,7 @@ class GNN_OGB(nn.Module):
 
     def forward(self, data, return_intermediate=False):
         kwargs = {"degrees": self.degree_encoder(data.degrees)}
+        memo = {}
         edge_index = data.edge_index
         if self.vn:
             n_graphs = int(data.batch[-1].item()) + 1
@@ -253,8 +276,8 @@ class GNN_OGB(nn.Module):
         x_interm = [x]
         n_layers = len(self.conv)
         for i in range(n_layers):
-            kwargs["identifiers"] = (self.id_encoder[i] if self.inject_ids else self.id_encoder[0])(data.identifiers)
-            kwargs["edge_features"] = self.edge_encoder[i](data.edge_features) if hasattr(data, "edge_features") else None
+            kwargs["identifiers"] = _encode_once(memo, self.id_encoder[i] if self.inject_ids else self.id_encoder[0], data.identifiers, self.training)
+            kwargs["edge_features"] = _encode_once(memo, self.edge_encoder[i], data.edge_features, self.training) if hasattr(data, "edge_features") else None
             if self.vn:
                 x_interm[i] = x_interm[i] + vn_embedding[data.batch]
             last = i == n_layers - 1

@@ -260,6 +260,12 @@ int gsn_mlp_chain_fwd_hip(int64_t m_rows, int n_stages, const gsn_chain_stage *s
  *   x        [n_nodes][d_x], d_x multiple of 4; d_x + edge.n_out + 4 <= 160
  *   node0    W [n0][d_x + edge.n_out + 4], no blocks;  node1  W [n1][n0], no blocks;  n0, n1 <= 128, multiples of 4
  *   act 0 identity / 1 relu; bn_* as in gsn_linear_fwd_hip (eval-mode / resolved statistics)
+ * and, the hidden layers of a d = 128 model (GSN_edge_sparse.py:82-170 with K = 260 / 272 edge rows, MPNN_edge_sparse.py:110-151;
+ * csrc/layer_w.hip): d_x = 128, every stage 128 wide, edge blocks = x through one index, x through another, then <= 16 further
+ * columns (widths multiples of 4, each gathered through one of those two indices or a third).  For this shape the forward call
+ * runs a small pass over x in front of the layer kernel (one int per node: the exponent of the row's largest |value|, stream-
+ * ordered scratch from hipMallocAsync) and returns GSN_E_UNSUPPORTED when the stream is being captured into a graph or the first two
+ * edge blocks are not `x` itself; the caller then composes the layer from the other entry points.
  * gsn_layer_fused_supported() says whether the shapes fit; otherwise compose gsn_mlp_chain_fwd_hip launches.
  * ---------------------------------------------------------------------------------------------------------------- */
 int gsn_layer_fused_supported(const gsn_chain_stage *edge, int64_t d_x, const gsn_chain_stage *node0,
