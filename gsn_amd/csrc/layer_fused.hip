@@ -1090,9 +1090,31 @@ extern "C" int gsn_layer_fused_prepare_hip(const gsn_chain_stage *edge, int64_t 
     return GSN_OK;
 }
 
+extern "C" int64_t gsn_layer_fused_workspace_bytes(int64_t n_nodes, const gsn_chain_stage *edge, int64_t d_x, const gsn_chain_stage *node0,
+                                                   const gsn_chain_stage *node1) {
+    if (n_nodes <= 0 || !w_supported(edge, d_x, node0, node1)) return 0;
+    return n_nodes * 4;                                  // the row exponents of x (layer_w.hip)
+}
+
+static int lf_forward(int64_t n_nodes, int64_t n_edges, const int32_t *seg_ptr, const gsn_chain_stage *edge,
+                      const float *x, int64_t d_x, const gsn_chain_stage *node0, const gsn_chain_stage *node1,
+                      const void *prepared, float *out, void *workspace, int64_t workspace_bytes, void *stream);
+
 extern "C" int gsn_layer_fused_fwd_hip(int64_t n_nodes, int64_t n_edges, const int32_t *seg_ptr, const gsn_chain_stage *edge,
                                        const float *x, int64_t d_x, const gsn_chain_stage *node0, const gsn_chain_stage *node1,
                                        const void *prepared, float *out, void *stream) {
+    return lf_forward(n_nodes, n_edges, seg_ptr, edge, x, d_x, node0, node1, prepared, out, nullptr, 0, stream);
+}
+
+extern "C" int gsn_layer_fused_fwd_ws_hip(int64_t n_nodes, int64_t n_edges, const int32_t *seg_ptr, const gsn_chain_stage *edge,
+                                          const float *x, int64_t d_x, const gsn_chain_stage *node0, const gsn_chain_stage *node1,
+                                          const void *prepared, float *out, void *workspace, int64_t workspace_bytes, void *stream) {
+    return lf_forward(n_nodes, n_edges, seg_ptr, edge, x, d_x, node0, node1, prepared, out, workspace, workspace_bytes, stream);
+}
+
+static int lf_forward(int64_t n_nodes, int64_t n_edges, const int32_t *seg_ptr, const gsn_chain_stage *edge,
+                      const float *x, int64_t d_x, const gsn_chain_stage *node0, const gsn_chain_stage *node1,
+                      const void *prepared, float *out, void *workspace, int64_t workspace_bytes, void *stream) {
     if (!gsn_layer_fused_supported(edge, d_x, node0, node1))
         return set_error(GSN_E_UNSUPPORTED, "gsn_layer_fused_fwd_hip: shape outside the fused layer kernel (edge K <= 80, d_x + n_msg + 4 <= 160, "
                                             "widths <= 128 and multiples of 4, int32 row sources, identity / relu)");
@@ -1100,8 +1122,11 @@ extern "C" int gsn_layer_fused_fwd_hip(int64_t n_nodes, int64_t n_edges, const i
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(prepared)) & 15) return set_error(GSN_E_INVALID, "gsn_layer_fused_fwd_hip: x and prepared must be 16-byte aligned");
     if (n_nodes > (int64_t)2000000000 || n_edges > (int64_t)2000000000) return set_error(GSN_E_UNSUPPORTED, "gsn_layer_fused_fwd_hip: 32-bit row arithmetic");
     if (n_nodes <= 0) return GSN_OK;
-    if (w_supported(edge, d_x, node0, node1))
-        return w_forward(n_nodes, n_edges, seg_ptr, edge, x, d_x, node0, node1, prepared, out, reinterpret_cast<hipStream_t>(stream));
+    if (w_supported(edge, d_x, node0, node1)) {
+        if (workspace && (workspace_bytes < n_nodes * 4 || (reinterpret_cast<uintptr_t>(workspace) & 3)))
+            return set_error(GSN_E_INVALID, "gsn_layer_fused_fwd_ws_hip: workspace smaller than gsn_layer_fused_workspace_bytes() or misaligned");
+        return w_forward(n_nodes, n_edges, seg_ptr, edge, x, d_x, node0, node1, prepared, out, reinterpret_cast<int32_t *>(workspace), reinterpret_cast<hipStream_t>(stream));
+    }
     LfArgs a{};
     a.n_nodes = (int)n_nodes; a.n_edges = (int)n_edges; a.seg_ptr = seg_ptr;
     lf_fill_stages(a, edge, d_x, node0, node1);

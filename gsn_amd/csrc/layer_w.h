@@ -14,7 +14,8 @@ int w_supported(const gsn_chain_stage *edge, int64_t d_x, const gsn_chain_stage 
 int64_t w_prepared_bytes(const gsn_chain_stage *edge, int64_t d_x, const gsn_chain_stage *node0, const gsn_chain_stage *node1);
 int w_prepare(const gsn_chain_stage *edge, int64_t d_x, const gsn_chain_stage *node0, const gsn_chain_stage *node1, void *prepared, hipStream_t st);
 // forward; GSN_OK or an error (GSN_E_UNSUPPORTED when this call's arguments are outside the kernel after all)
+// `row_exp`: n_nodes ints of caller-owned scratch for the row exponents of x, or null (stream-ordered allocation per call; not under capture)
 int w_forward(int64_t n_nodes, int64_t n_edges, const int32_t *seg_ptr, const gsn_chain_stage *edge, const float *x, int64_t d_x,
-              const gsn_chain_stage *node0, const gsn_chain_stage *node1, const void *prepared, float *out, hipStream_t st);
+              const gsn_chain_stage *node0, const gsn_chain_stage *node1, const void *prepared, float *out, int32_t *row_exp, hipStream_t st);
 
 }  // namespace gsn

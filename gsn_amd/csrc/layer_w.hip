@@ -912,13 +912,15 @@ int w_prepare(const gsn_chain_stage *edge, int64_t d_x, const gsn_chain_stage *n
 }
 
 int w_forward(int64_t n_nodes, int64_t n_edges, const int32_t *seg_ptr, const gsn_chain_stage *edge, const float *x, int64_t d_x,
-              const gsn_chain_stage *node0, const gsn_chain_stage *node1, const void *prepared, float *out, hipStream_t st) {
+              const gsn_chain_stage *node0, const gsn_chain_stage *node1, const void *prepared, float *out, int32_t *row_exp, hipStream_t st) {
     using SH = WShape;
     (void)d_x; (void)node0; (void)node1;
     if (edge->blocks[0].data != x) return set_error(GSN_E_UNSUPPORTED, "gsn_layer_fused_fwd_hip: the wide kernel takes x itself as its first two edge blocks");
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
-        return set_error(GSN_E_UNSUPPORTED, "gsn_layer_fused_fwd_hip: the wide kernel allocates its row-exponent array per call (no stream capture)");
+    if (!row_exp) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+            return set_error(GSN_E_UNSUPPORTED, "gsn_layer_fused_fwd_hip: without a workspace the d = 128 kernel allocates its row-exponent array per call (no stream capture): gsn_layer_fused_fwd_ws_hip");
+    }
     WArgs a{};
     a.n_nodes = (int)n_nodes; a.n_edges = (int)n_edges; a.seg_ptr = seg_ptr;
     a.x = x; a.out = out; a.prep = reinterpret_cast<const unsigned *>(prepared);
@@ -962,9 +964,11 @@ int w_forward(int64_t n_nodes, int64_t n_edges, const int32_t *seg_ptr, const gs
     }
     static_assert(SH::LDS_BYTES <= 160 * 1024, "LDS budget");
     // the row exponents of x: one int per node, stream-ordered scratch
-    int32_t *xe = nullptr;
-    hipError_t em = hipMallocAsync(reinterpret_cast<void **>(&xe), (size_t)n_nodes * 4, st);
-    if (em != hipSuccess) return set_error(GSN_E_HIP, "hipMallocAsync(row exponents): %s", hipGetErrorString(em));
+    int32_t *xe = row_exp;
+    if (!xe) {
+        hipError_t em = hipMallocAsync(reinterpret_cast<void **>(&xe), (size_t)n_nodes * 4, st);
+        if (em != hipSuccess) return set_error(GSN_E_HIP, "hipMallocAsync(row exponents): %s", hipGetErrorString(em));
+    }
     a.xe = xe;
     const bool trace = getenv("GSN_CHAIN_TRACE") != nullptr;
     {
@@ -994,7 +998,7 @@ int w_forward(int64_t n_nodes, int64_t n_edges, const int32_t *seg_ptr, const gs
         hipLaunchKernelGGL((layer_fused_kernel_w<false>), dim3((unsigned)gx), dim3(256), SH::LDS_BYTES, st, a, (unsigned long long *)nullptr);
     }
     hipError_t e = hipGetLastError();
-    (void)hipFreeAsync(xe, st);
+    if (!row_exp) (void)hipFreeAsync(xe, st);
     if (e != hipSuccess) return set_error(GSN_E_HIP, "layer_fused_kernel_w: %s", hipGetErrorString(e));
     return GSN_OK;
 }

@@ -732,9 +732,11 @@ def _layer_fused(x, csr, edge_stages, node_stages, training, owner=None, gen=0):
                                                      _abi.current_stream()), "gsn_layer_fused_prepare_hip")
         if owner is not None:
             owner._fused_prep = (key, prep)
+    ws_bytes = int(L.gsn_layer_fused_workspace_bytes(n, ctypes.byref(ge), d_x, ctypes.byref(g0), ctypes.byref(g1)))
+    ws = torch.empty(ws_bytes // 4, dtype=torch.int32, device=x.device) if ws_bytes else None      # (the caching allocator: capture-safe)
     with _abi.device_guard(x.device), _timed("layer_fused", flops):
-        rc = L.gsn_layer_fused_fwd_hip(n, E, csr.seg_ptr.data_ptr(), ctypes.byref(ge), x.data_ptr(), d_x, ctypes.byref(g0),
-                                       ctypes.byref(g1), prep.data_ptr(), out.data_ptr(), _abi.current_stream())
+        rc = L.gsn_layer_fused_fwd_ws_hip(n, E, csr.seg_ptr.data_ptr(), ctypes.byref(ge), x.data_ptr(), d_x, ctypes.byref(g0),
+                                          ctypes.byref(g1), prep.data_ptr(), out.data_ptr(), _abi.ptr(ws), ws_bytes, _abi.current_stream())
     if rc == -2:           # GSN_E_UNSUPPORTED: this call's arguments are outside the kernel after all (e.g. stream capture on the wide kernel)
         return None
     _abi.check(rc, "gsn_layer_fused_fwd_hip")

@@ -264,8 +264,9 @@ int gsn_mlp_chain_fwd_hip(int64_t m_rows, int n_stages, const gsn_chain_stage *s
  * csrc/layer_w.hip): d_x = 128, every stage 128 wide, edge blocks = x through one index, x through another, then <= 16 further
  * columns (widths multiples of 4, each gathered through one of those two indices or a third).  For this shape the forward call
  * runs a small pass over x in front of the layer kernel (one int per node: the exponent of the row's largest |value|, stream-
- * ordered scratch from hipMallocAsync) and returns GSN_E_UNSUPPORTED when the stream is being captured into a graph or the first two
- * edge blocks are not `x` itself; the caller then composes the layer from the other entry points.
+ * ordered scratch from hipMallocAsync unless the caller brings it: gsn_layer_fused_fwd_ws_hip) and returns GSN_E_UNSUPPORTED when it would
+ * have to allocate while the stream is being captured into a graph, or when the first two edge blocks are not `x` itself; the caller
+ * then composes the layer from the other entry points.
  * gsn_layer_fused_supported() says whether the shapes fit; otherwise compose gsn_mlp_chain_fwd_hip launches.
  * ---------------------------------------------------------------------------------------------------------------- */
 int gsn_layer_fused_supported(const gsn_chain_stage *edge, int64_t d_x, const gsn_chain_stage *node0,
@@ -282,6 +283,14 @@ int gsn_layer_fused_prepare_hip(const gsn_chain_stage *edge, int64_t d_x, const 
 int gsn_layer_fused_fwd_hip(int64_t n_nodes, int64_t n_edges, const int32_t *seg_ptr, const gsn_chain_stage *edge,
                             const float *x, int64_t d_x, const gsn_chain_stage *node0, const gsn_chain_stage *node1,
                             const void *prepared, float *out, void *stream);
+/* The same with caller-owned scratch: gsn_layer_fused_workspace_bytes() device bytes (0 for shapes that need none; today the d = 128
+ * shape: 4 bytes per node), 4-byte aligned, contents undefined before and after.  With it the call allocates nothing and can be
+ * captured into a HIP graph; `workspace` may be null when the size is 0. */
+int64_t gsn_layer_fused_workspace_bytes(int64_t n_nodes, const gsn_chain_stage *edge, int64_t d_x, const gsn_chain_stage *node0,
+                                        const gsn_chain_stage *node1);
+int gsn_layer_fused_fwd_ws_hip(int64_t n_nodes, int64_t n_edges, const int32_t *seg_ptr, const gsn_chain_stage *edge,
+                               const float *x, int64_t d_x, const gsn_chain_stage *node0, const gsn_chain_stage *node1,
+                               const void *prepared, float *out, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * HP-2  dense stage on DIRECT rows with fp16x3 matrix arithmetic (device): the same operation as gsn_linear_fwd_hip
