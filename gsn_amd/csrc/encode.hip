@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(int64_t m_rows, int n_co
 }
 
 constexpr int EMB_DCH = 64;           // columns of the embedding handled by one workgroup
-constexpr int EMB_ROWS = 2048;        // input rows per workgroup
+constexpr int EMB_ROWS = 2048;        // input rows per workgroup at most (the launcher shrinks it until the grid fills the chip: EmbArgs::rows_per_wg)
 
 // adjoint for tables too large for the LDS path below: gT_c[code[r][c]] += g_out[r][...] with global fp32 atomics
 // (collisions are rare on large tables); meta holds the GRADIENT table pointers
@@ -287,6 +287,7 @@ struct EmbArgs {
     const float *gout;            // backward
     float *out;                   // forward
     int32_t *status;              // forward
+    int rows_per_wg;              // input rows per workgroup (multiple of 32, <= EMB_ROWS)
 };
 
 template <bool BWD>
@@ -312,8 +313,8 @@ __global__ __launch_bounds__(256) void embed_lds_kernel(EmbArgs a) {
         }
     }
     __syncthreads();
-    const int64_t r0 = (int64_t)blockIdx.x * EMB_ROWS;
-    const int64_t r1 = r0 + EMB_ROWS < a.m_rows ? r0 + EMB_ROWS : a.m_rows;
+    const int64_t r0 = (int64_t)blockIdx.x * a.rows_per_wg;
+    const int64_t r1 = r0 + a.rows_per_wg < a.m_rows ? r0 + a.rows_per_wg : a.m_rows;
     const int gw = a.concat ? a.n_cols * a.d : a.d;
     if (j < a.d) {
         for (int64_t rb = r0 + wave * 8; rb < r1; rb += 8 * nwv) {
@@ -398,7 +399,14 @@ static int launch_embed_lds(EmbArgs &a, const int64_t *table_rows, hipStream_t s
             return set_error(GSN_E_HIP, "embed_lds_kernel: cannot raise the LDS limit");
         attr_set.mark(attr_dev);
     }
-    const dim3 grid((unsigned)((a.m_rows + EMB_ROWS - 1) / EMB_ROWS), (unsigned)((a.d + EMB_DCH - 1) / EMB_DCH));
+    // rows per workgroup: 2048 at most (the table slices are copied to / flushed from LDS once per workgroup), fewer until there are ~8
+    // workgroups per CU -- at 2048 a molhiv-sized batch (214 k edge rows, d = 300) gave every CU two workgroups and 0.9 TB/s
+    const int64_t n_slices = (a.d + EMB_DCH - 1) / EMB_DCH;
+    int64_t rpw = (a.m_rows * n_slices + 2047) / 2048;
+    rpw = (rpw + 31) / 32 * 32;
+    rpw = rpw < 128 ? 128 : (rpw > EMB_ROWS ? EMB_ROWS : rpw);
+    a.rows_per_wg = (int)rpw;
+    const dim3 grid((unsigned)((a.m_rows + rpw - 1) / rpw), (unsigned)n_slices);
     hipLaunchKernelGGL(embed_lds_kernel<BWD>, grid, dim3(64 * nwv), lds, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(GSN_E_HIP, "embed_lds_kernel: %s", hipGetErrorString(e));
