@@ -1098,23 +1098,30 @@ extern "C" int64_t gsn_layer_fused_workspace_bytes(int64_t n_nodes, const gsn_ch
 
 static int lf_forward(int64_t n_nodes, int64_t n_edges, const int32_t *seg_ptr, const gsn_chain_stage *edge,
                       const float *x, int64_t d_x, const gsn_chain_stage *node0, const gsn_chain_stage *node1,
-                      const void *prepared, float *out, void *workspace, int64_t workspace_bytes, void *stream);
+                      const void *prepared, float *out, void *workspace, int64_t workspace_bytes, const int32_t *x_row_exp,
+                      int32_t *out_row_exp, void *stream);
 
 extern "C" int gsn_layer_fused_fwd_hip(int64_t n_nodes, int64_t n_edges, const int32_t *seg_ptr, const gsn_chain_stage *edge,
                                        const float *x, int64_t d_x, const gsn_chain_stage *node0, const gsn_chain_stage *node1,
                                        const void *prepared, float *out, void *stream) {
-    return lf_forward(n_nodes, n_edges, seg_ptr, edge, x, d_x, node0, node1, prepared, out, nullptr, 0, stream);
+    return lf_forward(n_nodes, n_edges, seg_ptr, edge, x, d_x, node0, node1, prepared, out, nullptr, 0, nullptr, nullptr, stream);
 }
 
 extern "C" int gsn_layer_fused_fwd_ws_hip(int64_t n_nodes, int64_t n_edges, const int32_t *seg_ptr, const gsn_chain_stage *edge,
                                           const float *x, int64_t d_x, const gsn_chain_stage *node0, const gsn_chain_stage *node1,
-                                          const void *prepared, float *out, void *workspace, int64_t workspace_bytes, void *stream) {
-    return lf_forward(n_nodes, n_edges, seg_ptr, edge, x, d_x, node0, node1, prepared, out, workspace, workspace_bytes, stream);
+                                          const void *prepared, float *out, void *workspace, int64_t workspace_bytes,
+                                          const int32_t *x_row_exp, int32_t *out_row_exp, void *stream) {
+    if (out_row_exp && (!node1 || node1->n_out != 128))
+        return set_error(GSN_E_INVALID, "gsn_layer_fused_fwd_ws_hip: out_row_exp is defined for 128-wide output rows");
+    const int rc = lf_forward(n_nodes, n_edges, seg_ptr, edge, x, d_x, node0, node1, prepared, out, workspace, workspace_bytes, x_row_exp, out_row_exp, stream);
+    if (rc != GSN_OK || !out_row_exp || n_nodes <= 0 || w_supported(edge, d_x, node0, node1)) return rc;
+    return w_row_exponents(n_nodes, out, out_row_exp, reinterpret_cast<hipStream_t>(stream));     // (the other kernels: a pass over the rows they wrote)
 }
 
 static int lf_forward(int64_t n_nodes, int64_t n_edges, const int32_t *seg_ptr, const gsn_chain_stage *edge,
                       const float *x, int64_t d_x, const gsn_chain_stage *node0, const gsn_chain_stage *node1,
-                      const void *prepared, float *out, void *workspace, int64_t workspace_bytes, void *stream) {
+                      const void *prepared, float *out, void *workspace, int64_t workspace_bytes, const int32_t *x_row_exp,
+                      int32_t *out_row_exp, void *stream) {
     if (!gsn_layer_fused_supported(edge, d_x, node0, node1))
         return set_error(GSN_E_UNSUPPORTED, "gsn_layer_fused_fwd_hip: shape outside the fused layer kernel (edge K <= 80, d_x + n_msg + 4 <= 160, "
                                             "widths <= 128 and multiples of 4, int32 row sources, identity / relu)");
@@ -1125,7 +1132,8 @@ static int lf_forward(int64_t n_nodes, int64_t n_edges, const int32_t *seg_ptr, 
     if (w_supported(edge, d_x, node0, node1)) {
         if (workspace && (workspace_bytes < n_nodes * 4 || (reinterpret_cast<uintptr_t>(workspace) & 3)))
             return set_error(GSN_E_INVALID, "gsn_layer_fused_fwd_ws_hip: workspace smaller than gsn_layer_fused_workspace_bytes() or misaligned");
-        return w_forward(n_nodes, n_edges, seg_ptr, edge, x, d_x, node0, node1, prepared, out, reinterpret_cast<int32_t *>(workspace), reinterpret_cast<hipStream_t>(stream));
+        return w_forward(n_nodes, n_edges, seg_ptr, edge, x, d_x, node0, node1, prepared, out, reinterpret_cast<int32_t *>(workspace), x_row_exp, out_row_exp,
+                         reinterpret_cast<hipStream_t>(stream));
     }
     LfArgs a{};
     a.n_nodes = (int)n_nodes; a.n_edges = (int)n_edges; a.seg_ptr = seg_ptr;

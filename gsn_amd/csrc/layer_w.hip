@@ -89,6 +89,7 @@ struct WArgs {
     WQuad zq[4];                      // the four 16-byte quads of the per-edge chunk
     const float *x;
     const int32_t *xe;                // exponent field of max |x[v][:]| per node (255: the row holds an Inf / NaN)
+    int32_t *xe_out;                  // the same of the output rows, written with them (or null)
     float *out;
     const unsigned *prep;
     int n_ranges;
@@ -698,6 +699,9 @@ __global__ __launch_bounds__(256) void layer_fused_kernel_w(WArgs a, unsigned lo
             for (int r = 0; r < 16; ++r) invr[r] = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * rr_crow(r, lh), __float_as_int(inv2)));
             const int voff_lane = (4 * lh * 32 * WB + li) * 4;
             const __amdgpu_buffer_rsrc_t orow = __builtin_amdgcn_make_buffer_rsrc(a.out + (int64_t)t_m0 * (32 * WB), 0, nn * (32 * WB * 4), 0x00020000);
+            unsigned mrow[16];                          // largest |value| (bits) of this lane's columns in every row of the tile
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mrow[r] = 0u;
 #pragma unroll
             for (int fb = 0; fb < WB; ++fb) {
                 const float cb = cb1[fb];
@@ -706,10 +710,27 @@ __global__ __launch_bounds__(256) void layer_fused_kernel_w(WArgs a, unsigned lo
                     for (int r = 0; r < 16; ++r) {
                         float y = fmaxf(fmaf(oacc[fb][r], invr[r], cb), lo_1);
                         if (decltype(nanrows)::value) y = invr[r] != invr[r] ? invr[r] : y;     // (the max drops a NaN)
+                        mrow[r] = max(mrow[r], __float_as_uint(y) & 0x7fffffffu);
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), orow, voff_lane + ((r & 3) + 8 * (r >> 2)) * (32 * WB * 4) + 32 * fb * 4, 0, 0);
                     }
                 };
                 if (anybad) put(std::true_type{}); else put(std::false_type{});
+            }
+            if (a.xe_out) {
+                // the row exponents of the OUTPUT rows for the layer that takes them as its x (it then skips its pass over them): maximum over
+                // the 32 lanes of a half by DPP (row_shr 1, 2, 4, 8: lane 15 of a row of 16 holds the row's maximum; row_bcast15: lane 31 /
+                // 63 that of the half), lanes 31 and 63 write their sixteen rows
+                const __amdgpu_buffer_rsrc_t erow = __builtin_amdgcn_make_buffer_rsrc(a.xe_out + t_m0, 0, nn * 4, 0x00020000);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    unsigned v = mrow[r];
+                    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true));
+                    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true));
+                    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true));
+                    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true));
+                    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true));
+                    if (li == 31) __builtin_amdgcn_raw_buffer_store_b32(v >> 23, erow, ((r & 3) + 8 * (r >> 2) + 4 * lh) * 4, 0, 0);
+                }
             }
             if (PROF) { const unsigned t6 = clk(); pc[7] += tile_valid ? 1 : 0; pc[3] += tr1 - tr0; pc[4] += t5 - tr1; pc[5] += t6 - t5; pd[0] += t5a - t5; pd[1] += t5b - t5a; pd[2] += t5c - t5b; pd[3] += t6 - t5c; }
             rotate();
@@ -911,12 +932,24 @@ int w_prepare(const gsn_chain_stage *edge, int64_t d_x, const gsn_chain_stage *n
     return GSN_OK;
 }
 
+int w_row_exponents(int64_t n_nodes, const float *x, int32_t *row_exp, hipStream_t st) {
+    if (n_nodes <= 0) return GSN_OK;
+    int64_t gb = (n_nodes + 31) / 32;
+    gb = gb < 1 ? 1 : (gb > 2048 ? 2048 : gb);
+    if (getenv("GSN_CHAIN_TRACE")) fprintf(stderr, "gsn chain: layer_w_row_exp_kernel nodes %lld\n", (long long)n_nodes);
+    hipLaunchKernelGGL(layer_w_row_exp_kernel, dim3((unsigned)gb), dim3(256), 0, st, x, (int)n_nodes, row_exp);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(GSN_E_HIP, "layer_w_row_exp_kernel: %s", hipGetErrorString(e));
+    return GSN_OK;
+}
+
 int w_forward(int64_t n_nodes, int64_t n_edges, const int32_t *seg_ptr, const gsn_chain_stage *edge, const float *x, int64_t d_x,
-              const gsn_chain_stage *node0, const gsn_chain_stage *node1, const void *prepared, float *out, int32_t *row_exp, hipStream_t st) {
+              const gsn_chain_stage *node0, const gsn_chain_stage *node1, const void *prepared, float *out, int32_t *row_exp,
+              const int32_t *x_row_exp, int32_t *out_row_exp, hipStream_t st) {
     using SH = WShape;
     (void)d_x; (void)node0; (void)node1;
     if (edge->blocks[0].data != x) return set_error(GSN_E_UNSUPPORTED, "gsn_layer_fused_fwd_hip: the wide kernel takes x itself as its first two edge blocks");
-    if (!row_exp) {
+    if (!row_exp && !x_row_exp) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
             return set_error(GSN_E_UNSUPPORTED, "gsn_layer_fused_fwd_hip: without a workspace the d = 128 kernel allocates its row-exponent array per call (no stream capture): gsn_layer_fused_fwd_ws_hip");
@@ -965,13 +998,14 @@ int w_forward(int64_t n_nodes, int64_t n_edges, const int32_t *seg_ptr, const gs
     static_assert(SH::LDS_BYTES <= 160 * 1024, "LDS budget");
     // the row exponents of x: one int per node, stream-ordered scratch
     int32_t *xe = row_exp;
-    if (!xe) {
+    if (!xe && !x_row_exp) {
         hipError_t em = hipMallocAsync(reinterpret_cast<void **>(&xe), (size_t)n_nodes * 4, st);
         if (em != hipSuccess) return set_error(GSN_E_HIP, "hipMallocAsync(row exponents): %s", hipGetErrorString(em));
     }
-    a.xe = xe;
+    a.xe = x_row_exp ? x_row_exp : xe;
+    a.xe_out = out_row_exp;
     const bool trace = getenv("GSN_CHAIN_TRACE") != nullptr;
-    {
+    if (!x_row_exp) {
         int64_t gb = (n_nodes + 31) / 32;
         gb = gb < 1 ? 1 : (gb > 2048 ? 2048 : gb);
         if (trace) fprintf(stderr, "gsn chain: layer_w_row_exp_kernel nodes %d\n", a.n_nodes);
@@ -998,7 +1032,7 @@ int w_forward(int64_t n_nodes, int64_t n_edges, const int32_t *seg_ptr, const gs
         hipLaunchKernelGGL((layer_fused_kernel_w<false>), dim3((unsigned)gx), dim3(256), SH::LDS_BYTES, st, a, (unsigned long long *)nullptr);
     }
     hipError_t e = hipGetLastError();
-    if (!row_exp) (void)hipFreeAsync(xe, st);
+    if (!row_exp && !x_row_exp) (void)hipFreeAsync(xe, st);
     if (e != hipSuccess) return set_error(GSN_E_HIP, "layer_fused_kernel_w: %s", hipGetErrorString(e));
     return GSN_OK;
 }

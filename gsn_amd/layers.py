@@ -686,6 +686,9 @@ def _prep_key(st):
     return (st.weight.data_ptr(), st.weight._version, tuple(st.weight.shape), bk)
 
 
+CHAIN_ROW_EXPONENTS = os.environ.get("GSN_CHAIN_ROW_EXP", "1") != "0"      # 128-wide one-launch layers leave their output's row exponents for the next layer
+
+
 def _layer_fused(x, csr, edge_stages, node_stages, training, owner=None, gen=0):
     """edge stage + per-target sum + two node stages in ONE launch (gsn_layer_fused_fwd_hip); None if the layer does not
     fit (shape, activation, or a BatchNorm1d that needs batch statistics)."""
@@ -732,12 +735,27 @@ def _layer_fused(x, csr, edge_stages, node_stages, training, owner=None, gen=0):
                                                      _abi.current_stream()), "gsn_layer_fused_prepare_hip")
         if owner is not None:
             owner._fused_prep = (key, prep)
-    ws_bytes = int(L.gsn_layer_fused_workspace_bytes(n, ctypes.byref(ge), d_x, ctypes.byref(g0), ctypes.byref(g1)))
+    # layers of a d = 128 model hand the row exponents of their output to the next one (csrc/layer_w.hip takes its edge rows' scales from
+    # them): kept on the output tensor together with its version counter, used only while the tensor is unchanged
+    x_exp = None
+    hit = getattr(x, "_gsn_row_exp", None)
+    if hit is not None and hit[1] == x._version and hit[0].numel() == n and hit[0].device == x.device:
+        x_exp = hit[0]
+    # (asked of the d = 128 kernel only, which writes them with its rows; behind the other kernels they would cost a pass over the output)
+    out_exp = torch.empty(n, dtype=torch.int32, device=x.device) if d_x == 128 and out.shape[1] == 128 and CHAIN_ROW_EXPONENTS else None
+    ws_bytes = 0 if x_exp is not None else int(L.gsn_layer_fused_workspace_bytes(n, ctypes.byref(ge), d_x, ctypes.byref(g0), ctypes.byref(g1)))
     ws = torch.empty(ws_bytes // 4, dtype=torch.int32, device=x.device) if ws_bytes else None      # (the caching allocator: capture-safe)
     with _abi.device_guard(x.device), _timed("layer_fused", flops):
         rc = L.gsn_layer_fused_fwd_ws_hip(n, E, csr.seg_ptr.data_ptr(), ctypes.byref(ge), x.data_ptr(), d_x, ctypes.byref(g0),
-                                          ctypes.byref(g1), prep.data_ptr(), out.data_ptr(), _abi.ptr(ws), ws_bytes, _abi.current_stream())
+                                          ctypes.byref(g1), prep.data_ptr(), out.data_ptr(), _abi.ptr(ws), ws_bytes, _abi.ptr(x_exp),
+                                          _abi.ptr(out_exp), _abi.current_stream())
+    if rc == 0 and out_exp is not None:
+        out._gsn_row_exp = (out_exp, out._version)
     if rc == -2:           # GSN_E_UNSUPPORTED: this call's arguments are outside the kernel after all (e.g. stream capture on the wide kernel)
+        if os.environ.get("GSN_CHAIN_TRACE"):
+            import sys
+            msg = L.gsn_last_error()
+            print("gsn chain: one-launch layer declined: %s" % (msg.decode() if msg else ""), file=sys.stderr)
         return None
     _abi.check(rc, "gsn_layer_fused_fwd_hip")
     return out

@@ -285,12 +285,17 @@ int gsn_layer_fused_fwd_hip(int64_t n_nodes, int64_t n_edges, const int32_t *seg
                             const void *prepared, float *out, void *stream);
 /* The same with caller-owned scratch: gsn_layer_fused_workspace_bytes() device bytes (0 for shapes that need none; today the d = 128
  * shape: 4 bytes per node), 4-byte aligned, contents undefined before and after.  With it the call allocates nothing and can be
- * captured into a HIP graph; `workspace` may be null when the size is 0. */
+ * captured into a HIP graph; `workspace` may be null when the size is 0.
+ * Chaining layers of a d = 128 model: `out_row_exp` (int32 [n_nodes] or null; 128-wide outputs only) receives, per output row, the
+ * exponent field of its largest |value| (255: the row holds an Inf / NaN) -- the d = 128 kernel writes it with the rows, the other
+ * kernels by a pass over the rows they wrote; `x_row_exp` (or null) is that array of the layer that produced `x`: the d = 128 kernel
+ * then skips its own pass over x (and needs no workspace).  It must describe the CURRENT contents of x. */
 int64_t gsn_layer_fused_workspace_bytes(int64_t n_nodes, const gsn_chain_stage *edge, int64_t d_x, const gsn_chain_stage *node0,
                                         const gsn_chain_stage *node1);
 int gsn_layer_fused_fwd_ws_hip(int64_t n_nodes, int64_t n_edges, const int32_t *seg_ptr, const gsn_chain_stage *edge,
                                const float *x, int64_t d_x, const gsn_chain_stage *node0, const gsn_chain_stage *node1,
-                               const void *prepared, float *out, void *workspace, int64_t workspace_bytes, void *stream);
+                               const void *prepared, float *out, void *workspace, int64_t workspace_bytes,
+                               const int32_t *x_row_exp, int32_t *out_row_exp, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * HP-2  dense stage on DIRECT rows with fp16x3 matrix arithmetic (device): the same operation as gsn_linear_fwd_hip

@@ -307,3 +307,63 @@ def test_parameter_written_through_data_is_noticed():
             assert _elementwise_ok(y1.cpu(), r1), (mode, float((y1.cpu() - r1).abs().max() / r1.abs().max()))
     finally:
         layers.VALIDATE_CACHES = was
+
+
+def test_wide_layers_chain_their_row_exponents(capfd):
+    """Two d = 128 layers in a row: the first leaves the row exponents of its output on the tensor, the second takes them instead of
+    its own pass over x (trace: one row-exponent pass, two layer launches) and gives the same result as with the pass; a tensor that
+    was written in place since is not trusted; `out_row_exp` of the d = 128 kernel equals the pass over its output; behind the
+    other kernels the entry point makes it by that pass."""
+    import ctypes
+    import os
+    from gsn_amd import layers, _abi
+    b, _, _, ei = _zinc(200, seed=91)
+    g = torch.Generator().manual_seed(29)
+    N, E = b.num_nodes, b.num_edges
+    x = (torch.randn(N, 128, generator=g) * torch.exp2(torch.randint(-6, 7, (N, 1), generator=g).float())).cuda()
+    ef = torch.randn(E, 4, generator=g).cuda()
+    ids = torch.randn(E, 12, generator=g).cuda()
+    torch.manual_seed(5)
+    l1 = layers.GSN_edge_sparse(**_wide_ctor(WIDE[0][0], WIDE[0][1])).cuda().eval()
+    l2 = layers.GSN_edge_sparse(**_wide_ctor(WIDE[0][0], WIDE[0][1], seed=1)).cuda().eval()
+    kw = dict(identifiers=ids, degrees=torch.zeros(N, device="cuda"), edge_features=ef)
+    eic = ei.cuda()
+
+    def two(chain):
+        was = layers.CHAIN_ROW_EXPONENTS
+        layers.CHAIN_ROW_EXPONENTS = chain
+        os.environ["GSN_CHAIN_TRACE"] = "1"
+        try:
+            with torch.no_grad():
+                h = l1(x, eic, **kw)
+                y = l2(h, eic, **kw)
+                torch.cuda.synchronize()
+        finally:
+            os.environ.pop("GSN_CHAIN_TRACE")
+            layers.CHAIN_ROW_EXPONENTS = was
+        return h, y, capfd.readouterr().err
+    h0, y0, err0 = two(False)
+    h1, y1, err1 = two(True)
+    assert err0.count("layer_w_row_exp_kernel") == 2 and err0.count("layer_fused_kernel_w ") == 2
+    assert err1.count("layer_w_row_exp_kernel") == 1 and err1.count("layer_fused_kernel_w ") == 2
+    assert torch.equal(h0, h1) and torch.equal(y0, y1)
+    rexp, ver = h1._gsn_row_exp
+    ref = (h1.abs().amax(dim=1).view(torch.int32) >> 23).to(torch.int32)
+    assert ver == h1._version and torch.equal(rexp, ref)
+    # written in place since: the exponents on the tensor are stale and must not be used
+    with torch.no_grad():
+        h1.mul_(4.0)
+        os.environ["GSN_CHAIN_TRACE"] = "1"
+        try:
+            y2 = l2(h1, eic, **kw)
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("GSN_CHAIN_TRACE")
+        assert "layer_w_row_exp_kernel" in capfd.readouterr().err
+        was = layers.CHAIN_ROW_EXPONENTS
+        layers.CHAIN_ROW_EXPONENTS = False
+        try:
+            y3 = l2(h1.clone(), eic, **kw)
+        finally:
+            layers.CHAIN_ROW_EXPONENTS = was
+    assert torch.equal(y2, y3)
