@@ -89,8 +89,9 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
     vid_t *ev = reinterpret_cast<vid_t *>(smem + a.off_ev);
     int *rowstart = reinterpret_cast<int *>(smem + a.off_rowstart);
     int *last = reinterpret_cast<int *>(smem + a.off_last);
-    int *prim = reinterpret_cast<int *>(smem + a.off_prim);
-    int *revof = reinterpret_cast<int *>(smem + a.off_revof);
+    // (column tables as 16-bit values: a workgroup whose per-column state fits LDS has far fewer than 65535 columns; 0xffff = none)
+    uint16_t *prim = reinterpret_cast<uint16_t *>(smem + a.off_prim);
+    uint16_t *revof = reinterpret_cast<uint16_t *>(smem + a.off_revof);
     uint64_t *out_lds = reinterpret_cast<uint64_t *>(smem + a.off_out);
     int *misc = reinterpret_cast<int *>(smem + a.off_misc);  // [0] next task  [1] n_active  [2] status
     uint64_t *balls = a.off_ball >= 0 ? reinterpret_cast<uint64_t *>(smem + a.off_ball) : nullptr;
@@ -259,7 +260,7 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
             int r = rowstart[u];
 #pragma unroll
             for (int w = 0; w < W; ++w) r += popc64(A[u * W + w] & below_word(v, w));
-            revof[c] = r;                        // (its slot, until the pass below replaces it)
+            revof[c] = (uint16_t)r;              // (its slot, until the pass below replaces it)
             atomicMax(&last[r], c);
         }
         __syncthreads();
@@ -285,13 +286,13 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
                         for (int w = 0; w < W; ++w) rr += popc64(A[v * W + w] & below_word(u, w));
                         rev = last[rr];
                     }
-                    revof[c] = rev;
+                    revof[c] = rev < 0 ? (uint16_t)0xffffu : (uint16_t)rev;
                     primary = live && !(a.sym && rev >= 0 && u > v);
                     if (!live && part == 0)
                         for (int col = 0; col < n_cols; ++col) emit_cell(c, col, 0ull);
                 }
                 const uint64_t pm = __ballot(primary);
-                if (primary) prim[n_prim + __popcll(pm & ((1ull << tid) - 1ull))] = c;
+                if (primary) prim[n_prim + __popcll(pm & ((1ull << tid) - 1ull))] = (uint16_t)c;
                 n_prim += __popcll(pm);
             }
             if (tid == 0) misc[3] = n_prim;
@@ -367,7 +368,7 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
                     mirror_row = -1;
                     if (edge_mode) {
                         t_row = prim[t_idx];
-                        const int rev = revof[t_row];
+                        const int rev = revof[t_row] == 0xffffu ? -1 : (int)revof[t_row];
                         rev_missing = rev < 0;
                         if (a.sym && rev >= 0) mirror_row = rev;
                         roots = fv_roots<W>(eu[t_row], ev[t_row]);
@@ -609,8 +610,9 @@ static int count_launch(const uint32_t *plan_host, const uint32_t *plan_dev, int
     a.off_ev = o; o += edge_mode ? align_up((int)max_edges * vid_bytes, 16) : 0;
     a.off_rowstart = o; o += edge_mode ? align_up(((int)max_nodes + 1) * 4, 16) : 0;
     a.off_last = o; o += edge_mode ? align_up((int)max_edges * 4, 16) : 0;
-    a.off_prim = o; o += edge_mode ? align_up((int)max_edges * 4, 16) : 0;
-    a.off_revof = o; o += edge_mode ? align_up((int)max_edges * 4, 16) : 0;
+    if (edge_mode && max_edges >= 65535) return set_error(GSN_E_UNSUPPORTED, "gsn_count_hip: %lld columns per workgroup (16-bit column tables; LDS ends far earlier)", (long long)max_edges);
+    a.off_prim = o; o += edge_mode ? align_up((int)max_edges * 2, 16) : 0;
+    a.off_revof = o; o += edge_mode ? align_up((int)max_edges * 2, 16) : 0;
     a.off_misc = o; o += 32;
     a.off_enc = o; o += enc_out ? align_up(2 * a.n_cols * 4, 16) : 0;
     a.off_core = o; o += align_up((CORE_MAX + 1) * W * 8, 16);

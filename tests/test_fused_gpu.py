@@ -367,3 +367,41 @@ def test_wide_layers_chain_their_row_exponents(capfd):
         finally:
             layers.CHAIN_ROW_EXPONENTS = was
     assert torch.equal(y2, y3)
+
+
+def test_wide_layer_inside_a_captured_graph(capfd):
+    """gsn_layer_fused_fwd_ws_hip: with caller-owned scratch the d = 128 layer allocates nothing, so the SAME kernel runs inside a captured
+    HIP graph (trace printed during capture) and the replay equals the eager result bit for bit"""
+    import os
+    from gsn_amd import layers
+    b, _, _, ei = _zinc(64, seed=17)
+    g = torch.Generator().manual_seed(31)
+    N, E = b.num_nodes, b.num_edges
+    x = torch.randn(N, 128, generator=g).cuda()
+    ef = torch.randn(E, 4, generator=g).cuda()
+    ids = torch.randn(E, 12, generator=g).cuda()
+    torch.manual_seed(7)
+    layer = layers.GSN_edge_sparse(**_wide_ctor(WIDE[0][0], WIDE[0][1])).cuda().eval()
+    kw = dict(identifiers=ids, degrees=torch.zeros(N, device="cuda"), edge_features=ef)
+    eic = ei.cuda()
+    with torch.no_grad():
+        y0 = layer(x, eic, **kw)
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                layer(x, eic, **kw)
+        torch.cuda.synchronize()
+        capfd.readouterr()
+        graph = torch.cuda.CUDAGraph()
+        os.environ["GSN_CHAIN_TRACE"] = "1"
+        try:
+            with torch.cuda.graph(graph):
+                y1 = layer(x, eic, **kw)
+        finally:
+            os.environ.pop("GSN_CHAIN_TRACE")
+        assert "layer_fused_kernel_w " in capfd.readouterr().err
+        x.mul_(1.5)                                   # (new contents, same addresses: the replay recomputes)
+        y2 = layer(x, eic, **kw)
+        graph.replay()
+        torch.cuda.synchronize()
+    assert torch.equal(y1, y2) and not torch.equal(y0, y2)
