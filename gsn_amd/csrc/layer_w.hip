@@ -188,12 +188,15 @@ typedef const __attribute__((address_space(1))) rr_f4 *w_gptr;
     __builtin_amdgcn_sched_group_barrier(0x002, (NV), 0); }
 #endif
 // the edge stage's step: a feature block's two fragments are replaced behind its six products (reads behind products 6, 7, 12, 13, ...)
+#ifndef W_MIXV
+#define W_MIXV 2
+#endif
 #ifdef RR_NOMIX
 #define W_MIX_EDGE()
 #else
 #define W_MIX_EDGE() _Pragma("unroll") for (int mix_q = 0; mix_q < 24; ++mix_q) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); \
     if (mix_q >= 5 && (mix_q - 5) % 6 < 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); if (mix_q < 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
-    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); }
+    __builtin_amdgcn_sched_group_barrier(0x002, W_MIXV, 0); }
 #endif
 
 // ------------------------------------------------------------------------------------------------------------------------------
