@@ -739,7 +739,9 @@ def _layer_fused(x, csr, edge_stages, node_stages, training, owner=None, gen=0):
     # them): kept on the output tensor together with its version counter, used only while the tensor is unchanged
     x_exp = None
     hit = getattr(x, "_gsn_row_exp", None)
-    if hit is not None and hit[1] == x._version and hit[0].numel() == n and hit[0].device == x.device:
+    # (a write through `.data` does not move the version counter -- the caveat of every per-tensor cache here, INTEGRATION.md: the
+    #  validation mode does not trust the tensor's exponents and lets the kernel make them again)
+    if hit is not None and hit[1] == x._version and hit[0].numel() == n and hit[0].device == x.device and not VALIDATE_CACHES:
         x_exp = hit[0]
     # (asked of the d = 128 kernel only, which writes them with its rows; behind the other kernels they would cost a pass over the output)
     out_exp = torch.empty(n, dtype=torch.int32, device=x.device) if d_x == 128 and out.shape[1] == 128 and CHAIN_ROW_EXPONENTS else None
