@@ -290,25 +290,29 @@ struct EmbArgs {
     int rows_per_wg;              // input rows per workgroup (multiple of 32, <= EMB_ROWS)
 };
 
-template <bool BWD>
+// NSUB: 64-column sub-slices per workgroup (slice = 64 NSUB columns of the embedding).  When the tables are small enough a workgroup
+// takes WHOLE rows (NSUB = ceil(d / 64)): consecutive rows of the output are then written as one contiguous run instead of five
+// 256-byte pieces per row by five workgroups at different times (d = 300: pieces that straddle cache lines).
+template <bool BWD, int NSUB>
 __global__ __launch_bounds__(256) void embed_lds_kernel(EmbArgs a) {
-    extern __shared__ float tab[];                               // [sum rows][EMB_DCH]  (BWD: one copy per wave)
+    constexpr int DCH = EMB_DCH * NSUB;
+    extern __shared__ float tab[];                               // [sum rows][DCH]  (BWD: one copy per wave)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nwv = blockDim.x >> 6;
-    const int j0 = blockIdx.y * EMB_DCH, j = j0 + lane;
+    const int j0 = blockIdx.y * DCH;
     const int total_rows = a.row_off[a.n_cols];
     // BWD: every wave accumulates into its OWN copy with plain read-modify-write (its lanes own distinct columns and a
     // wave executes in order).  LDS float atomics were measured at ~0.7 us per instruction here.
-    float *mine = tab + (BWD ? wave * total_rows * EMB_DCH : 0);
+    float *mine = tab + (BWD ? wave * total_rows * DCH : 0);
     if (BWD) {
-        for (int i = threadIdx.x; i < nwv * total_rows * EMB_DCH; i += blockDim.x) tab[i] = 0.f;
+        for (int i = threadIdx.x; i < nwv * total_rows * DCH; i += blockDim.x) tab[i] = 0.f;
     } else {
         for (int c = 0; c < a.n_cols; ++c) {
             const float *t = reinterpret_cast<const float *>(a.meta[c]);
             const int rows_c = a.row_off[c + 1] - a.row_off[c];
-            for (int i = threadIdx.x; i < rows_c * EMB_DCH; i += 256) {
-                const int row = i / EMB_DCH, jj = j0 + (i - row * EMB_DCH);
-                tab[(a.row_off[c] + row) * EMB_DCH + (i - row * EMB_DCH)] = jj < a.d ? t[(int64_t)row * a.d + jj] : 0.f;
+            for (int i = threadIdx.x; i < rows_c * DCH; i += blockDim.x) {
+                const int row = i / DCH, jj = j0 + (i - row * DCH);
+                tab[(a.row_off[c] + row) * DCH + (i - row * DCH)] = jj < a.d ? t[(int64_t)row * a.d + jj] : 0.f;
             }
         }
     }
@@ -316,12 +320,17 @@ __global__ __launch_bounds__(256) void embed_lds_kernel(EmbArgs a) {
     const int64_t r0 = (int64_t)blockIdx.x * a.rows_per_wg;
     const int64_t r1 = r0 + a.rows_per_wg < a.m_rows ? r0 + a.rows_per_wg : a.m_rows;
     const int gw = a.concat ? a.n_cols * a.d : a.d;
-    if (j < a.d) {
+    if (j0 + lane < a.d) {
         for (int64_t rb = r0 + wave * 8; rb < r1; rb += 8 * nwv) {
             if (BWD && !a.concat) {
-                float g[8];
+                float g[8][NSUB];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) g[u] = a.gout[(rb + u < r1 ? rb + u : r1 - 1) * gw + j];
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int sb = 0; sb < NSUB; ++sb) {
+                        const int j = j0 + EMB_DCH * sb + lane;
+                        g[u][sb] = j < a.d ? a.gout[(rb + u < r1 ? rb + u : r1 - 1) * gw + j] : 0.f;
+                    }
                 for (int c = 0; c < a.n_cols; ++c) {
                     const int rows_c = a.row_off[c + 1] - a.row_off[c];
                     int64_t code[8];
@@ -329,8 +338,10 @@ __global__ __launch_bounds__(256) void embed_lds_kernel(EmbArgs a) {
                     for (int u = 0; u < 8; ++u) code[u] = a.codes[(rb + u < r1 ? rb + u : r1 - 1) * a.n_cols + c];
 #pragma unroll
                     for (int u = 0; u < 8; ++u)
-                        if (rb + u < r1 && code[u] >= 0 && code[u] < rows_c)
-                            mine[(a.row_off[c] + (int)code[u]) * EMB_DCH + lane] += g[u];
+                        if (rb + u < r1 && code[u] >= 0 && code[u] < rows_c) {
+#pragma unroll
+                            for (int sb = 0; sb < NSUB; ++sb) mine[(a.row_off[c] + (int)code[u]) * DCH + EMB_DCH * sb + lane] += g[u][sb];
+                        }
                 }
             } else if (BWD) {
                 for (int c = 0; c < a.n_cols; ++c) {
@@ -339,14 +350,21 @@ __global__ __launch_bounds__(256) void embed_lds_kernel(EmbArgs a) {
                     for (int u = 0; u < 8; ++u) {
                         if (rb + u >= r1) break;
                         const int64_t code = a.codes[(rb + u) * a.n_cols + c];
-                        if (code >= 0 && code < rows_c)
-                            mine[(a.row_off[c] + (int)code) * EMB_DCH + lane] += a.gout[(rb + u) * gw + c * a.d + j];
+                        if (code >= 0 && code < rows_c) {
+#pragma unroll
+                            for (int sb = 0; sb < NSUB; ++sb) {
+                                const int j = j0 + EMB_DCH * sb + lane;
+                                if (j < a.d) mine[(a.row_off[c] + (int)code) * DCH + EMB_DCH * sb + lane] += a.gout[(rb + u) * gw + c * a.d + j];
+                            }
+                        }
                     }
                 }
             } else {
-                float acc[8];
+                float acc[8][NSUB];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int sb = 0; sb < NSUB; ++sb) acc[u][sb] = 0.f;
                 for (int c = 0; c < a.n_cols; ++c) {
                     const int rows_c = a.row_off[c + 1] - a.row_off[c];
                     int64_t code[8];
@@ -354,17 +372,25 @@ __global__ __launch_bounds__(256) void embed_lds_kernel(EmbArgs a) {
                     for (int u = 0; u < 8; ++u) code[u] = a.codes[(rb + u < r1 ? rb + u : r1 - 1) * a.n_cols + c];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
-                        float v = 0.f;
-                        if (code[u] >= 0 && code[u] < rows_c) v = tab[(a.row_off[c] + (int)code[u]) * EMB_DCH + lane];
-                        else atomicMax(a.status, GSN_ST_BAD_INDEX);
-                        if (a.concat) { if (rb + u < r1) a.out[(rb + u) * gw + c * a.d + j] = v; }
-                        else acc[u] += v;
+                        const bool ok = code[u] >= 0 && code[u] < rows_c;
+                        if (!ok) atomicMax(a.status, GSN_ST_BAD_INDEX);
+#pragma unroll
+                        for (int sb = 0; sb < NSUB; ++sb) {
+                            const int j = j0 + EMB_DCH * sb + lane;
+                            const float v = ok ? tab[(a.row_off[c] + (int)code[u]) * DCH + EMB_DCH * sb + lane] : 0.f;
+                            if (a.concat) { if (rb + u < r1 && j < a.d) a.out[(rb + u) * gw + c * a.d + j] = v; }
+                            else acc[u][sb] += v;
+                        }
                     }
                 }
                 if (!a.concat) {
 #pragma unroll
                     for (int u = 0; u < 8; ++u)
-                        if (rb + u < r1) a.out[(rb + u) * gw + j] = acc[u];
+#pragma unroll
+                        for (int sb = 0; sb < NSUB; ++sb) {
+                            const int j = j0 + EMB_DCH * sb + lane;
+                            if (rb + u < r1 && j < a.d) a.out[(rb + u) * gw + j] = acc[u][sb];
+                        }
                 }
             }
         }
@@ -374,43 +400,65 @@ __global__ __launch_bounds__(256) void embed_lds_kernel(EmbArgs a) {
         for (int c = 0; c < a.n_cols; ++c) {
             float *t = reinterpret_cast<float *>(a.meta[c]);
             const int rows_c = a.row_off[c + 1] - a.row_off[c];
-            for (int i = threadIdx.x; i < rows_c * EMB_DCH; i += blockDim.x) {
-                const int row = i / EMB_DCH, jj = j0 + (i - row * EMB_DCH);
+            for (int i = threadIdx.x; i < rows_c * DCH; i += blockDim.x) {
+                const int row = i / DCH, jj = j0 + (i - row * DCH);
                 float v = 0.f;
-                for (int wv = 0; wv < nwv; ++wv) v += tab[(wv * total_rows + a.row_off[c] + row) * EMB_DCH + (i - row * EMB_DCH)];
+                for (int wv = 0; wv < nwv; ++wv) v += tab[(wv * total_rows + a.row_off[c] + row) * DCH + (i - row * DCH)];
                 if (jj < a.d && v != 0.f) atomicAdd(t + (int64_t)row * a.d + jj, v);
             }
         }
     }
 }
 
-template <bool BWD>
-static int launch_embed_lds(EmbArgs &a, const int64_t *table_rows, hipStream_t s) {
-    a.row_off[0] = 0;
-    for (int c = 0; c < a.n_cols; ++c) a.row_off[c + 1] = a.row_off[c] + (int)table_rows[c];
-    // backward keeps one table copy per wave: 4 waves while that fits, else a single wave per workgroup
-    const int nwv = (!BWD || 4 * a.row_off[a.n_cols] <= EMB_LDS_SUM_ROWS) ? 4 : 1;
-    const size_t lds = (size_t)(BWD ? nwv : 1) * a.row_off[a.n_cols] * EMB_DCH * sizeof(float);
+template <bool BWD, int NSUB>
+static int launch_embed_lds_n(EmbArgs &a, int nwv, hipStream_t s) {
+    constexpr int DCH = EMB_DCH * NSUB;
+    const size_t lds = (size_t)(BWD ? nwv : 1) * a.row_off[a.n_cols] * DCH * sizeof(float);
     static DeviceOnce attr_set;
     const int attr_dev = current_device();
     if (!attr_set.done(attr_dev)) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&embed_lds_kernel<BWD>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&embed_lds_kernel<BWD, NSUB>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 EMB_LDS_SUM_ROWS * EMB_DCH * (int)sizeof(float)) != hipSuccess)
             return set_error(GSN_E_HIP, "embed_lds_kernel: cannot raise the LDS limit");
         attr_set.mark(attr_dev);
     }
     // rows per workgroup: 2048 at most (the table slices are copied to / flushed from LDS once per workgroup), fewer until there are ~8
     // workgroups per CU -- at 2048 a molhiv-sized batch (214 k edge rows, d = 300) gave every CU two workgroups and 0.9 TB/s
-    const int64_t n_slices = (a.d + EMB_DCH - 1) / EMB_DCH;
+    const int64_t n_slices = (a.d + DCH - 1) / DCH;
     int64_t rpw = (a.m_rows * n_slices + 2047) / 2048;
     rpw = (rpw + 31) / 32 * 32;
     rpw = rpw < 128 ? 128 : (rpw > EMB_ROWS ? EMB_ROWS : rpw);
     a.rows_per_wg = (int)rpw;
     const dim3 grid((unsigned)((a.m_rows + rpw - 1) / rpw), (unsigned)n_slices);
-    hipLaunchKernelGGL(embed_lds_kernel<BWD>, grid, dim3(64 * nwv), lds, s, a);
+    hipLaunchKernelGGL((embed_lds_kernel<BWD, NSUB>), grid, dim3(64 * nwv), lds, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(GSN_E_HIP, "embed_lds_kernel: %s", hipGetErrorString(e));
     return GSN_OK;
+}
+
+template <bool BWD>
+static int launch_embed_lds(EmbArgs &a, const int64_t *table_rows, hipStream_t s) {
+    a.row_off[0] = 0;
+    for (int c = 0; c < a.n_cols; ++c) a.row_off[c + 1] = a.row_off[c] + (int)table_rows[c];
+    const int rows = a.row_off[a.n_cols];
+    // backward keeps one table copy per wave: 4 waves while that fits, else a single wave per workgroup
+    // whole rows per workgroup (summed embeddings of width <= 320) while the tables (x the wave copies of the backward pass) stay under
+    // 48 KiB of LDS: three workgroups and more per CU
+    const int nsub = (a.d + EMB_DCH - 1) / EMB_DCH;
+    const int64_t one_copy = (int64_t)rows * nsub * EMB_DCH * 4;
+    int wv = 4;                                                  // (backward: four wave copies, or two, of the tables)
+    if (BWD && 4 * one_copy > 48 * 1024) wv = 2;
+    const bool whole = !a.concat && nsub >= 2 && nsub <= 5 && (BWD ? wv : 1) * one_copy <= 48 * 1024;
+    if (whole) {
+        switch (nsub) {
+            case 2: return launch_embed_lds_n<BWD, 2>(a, wv, s);
+            case 3: return launch_embed_lds_n<BWD, 3>(a, wv, s);
+            case 4: return launch_embed_lds_n<BWD, 4>(a, wv, s);
+            default: return launch_embed_lds_n<BWD, 5>(a, wv, s);
+        }
+    }
+    const int nwv = (!BWD || 4 * rows <= EMB_LDS_SUM_ROWS) ? 4 : 1;
+    return launch_embed_lds_n<BWD, 1>(a, nwv, s);
 }
 
 static bool embed_lds_fits(int n_cols, const int64_t *table_rows) {
@@ -510,6 +558,36 @@ extern "C" int gsn_bn_act_hip(int64_t m_rows, int64_t n_cols, const float *h, co
     hipLaunchKernelGGL(bn_act_kernel, dim3(grid_for(m_rows * n_cols)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        m_rows * n_cols, (int)n_cols, h, mean, scale, shift, act, out);
     GSN_LAUNCH_CHECK("bn_act_kernel");
+    return GSN_OK;
+}
+
+// per-column sum and sum of squares of materialised rows, added to stats[2][n_cols] (fp64): a workgroup takes a band of rows, a thread
+// the columns tid, tid + 256, ... (consecutive threads read consecutive floats), one fp64 atomic per column and workgroup at the end
+namespace gsn {
+constexpr int CS_ROWS = 128;
+__global__ __launch_bounds__(256) void column_stats_kernel(int64_t m_rows, int n_cols, const float *h, double *stats) {
+    const int64_t r0 = (int64_t)blockIdx.x * CS_ROWS;
+    const int64_t r1 = r0 + CS_ROWS < m_rows ? r0 + CS_ROWS : m_rows;
+    for (int c = threadIdx.x; c < n_cols; c += 256) {
+        double s = 0.0, q = 0.0;
+        const float *p = h + r0 * n_cols + c;
+        for (int64_t r = r0; r < r1; ++r, p += n_cols) {
+            const double v = (double)*p;
+            s += v; q += v * v;
+        }
+        atomicAdd(stats + c, s);
+        atomicAdd(stats + n_cols + c, q);
+    }
+}
+}  // namespace gsn
+
+extern "C" int gsn_column_stats_hip(int64_t m_rows, int64_t n_cols, const float *h, double *stats, void *stream) {
+    if (n_cols < 1 || n_cols > (1 << 20) || !stats || (m_rows > 0 && !h)) return set_error(GSN_E_INVALID, "gsn_column_stats_hip: bad arguments");
+    if (m_rows <= 0) return GSN_OK;
+    const int64_t blocks = (m_rows + gsn::CS_ROWS - 1) / gsn::CS_ROWS;
+    if (blocks > 0x7fffffff) return set_error(GSN_E_UNSUPPORTED, "gsn_column_stats_hip: too many rows");
+    hipLaunchKernelGGL(gsn::column_stats_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), m_rows, (int)n_cols, h, stats);
+    GSN_LAUNCH_CHECK("column_stats_kernel");
     return GSN_OK;
 }
 

@@ -437,6 +437,10 @@ int gsn_code_stage_fwd_hip(int64_t m_rows, int n_slots, const gsn_code_slot *slo
  * ---------------------------------------------------------------------------------------------------------------- */
 int gsn_bn_act_hip(int64_t m_rows, int64_t n_cols, const float *h, const float *mean, const float *scale,
                    const float *shift, int act, float *out, void *stream);
+/* The statistics of materialised pre-BN rows (device): ADDS per-column sum and sum of squares of h [M][C] into stats double [2][C]
+ * (caller zeroes it) -- what gsn_linear_fwd_hip's `stats` argument takes inside its product, for rows that another kernel wrote
+ * (the fp16x3 dense kernel of a train-mode stage, models_misc.py:52-59 with nn.BatchNorm1d in training mode). */
+int gsn_column_stats_hip(int64_t m_rows, int64_t n_cols, const float *h, double *stats, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Backward of a dense mlp stage  H = X W^T + b, Z = bn(H), Y = act(Z)  (models_misc.py:52-59) for inputs that are plain
