@@ -33,6 +33,10 @@ class gsn_chain_stage(ctypes.Structure):
                 ("bn_mean", c_vp), ("bn_scale", c_vp), ("bn_shift", c_vp), ("act", c_int)]
 
 
+class gsn_self_block(ctypes.Structure):
+    _fields_ = [("data", c_vp), ("width", c_i64), ("row_stride", c_i64)]
+
+
 # name -> (restype, argtypes); kept in one place so tests can check it against include/gsn_abi.h
 class gsn_code_slot(ctypes.Structure):
     _fields_ = [("codes", ctypes.c_void_p), ("idx", ctypes.c_void_p), ("stride", ctypes.c_int32), ("col", ctypes.c_int32),
@@ -63,6 +67,10 @@ SIGNATURES = {
                                       c_i64, c_vp, c_vp]),
     "gsn_propagate_bwd_hip": (c_int, [c_int, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_int,
                                       c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "gsn_propagate_self_fwd_hip": (c_int, [c_int, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_vp,
+                                           c_i64, c_i64, c_i64, c_int, ctypes.POINTER(gsn_self_block), c_vp, c_vp, c_vp]),
+    "gsn_propagate_pad_bwd_hip": (c_int, [c_int, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_int,
+                                          c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "gsn_linear_fwd_hip": (c_int, [c_i64, c_int, ctypes.POINTER(gsn_block), c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_int,
                                    c_vp, c_vp, c_vp, c_vp]),
     "gsn_one_hot_hip": (c_int, [c_i64, c_int, c_vp, c_vp, c_int, c_vp, c_vp]),

@@ -4,7 +4,8 @@
 //   gZ = gY * act'(Y)                                   (relu / elu / tanh / identity: all derivable from Y)
 //   train-mode BatchNorm1d (batch statistics over the M rows):  xh = (H - mean) * invstd
 //        g_beta = sum_r gZ ,  g_gamma = sum_r gZ * xh ,  gH = gamma * invstd * (gZ - g_beta / M - xh * g_gamma / M)
-//   eval-mode / no BN:  gH = gZ * scale
+//   eval-mode / no BN:  gH = gZ * scale   (train_bn == 2: eval-mode BatchNorm whose gamma / beta want gradients -- the same two
+//        column sums with xh from the running statistics, gH = gZ * gamma * invstd)
 //   gX = gH W   (gsn_linear_fwd_hip with W^T as the weight) ,   gW = gH^T X ,   gb = sum_r gH
 //
 // Kernels here: the two elementwise / column-reduction passes of the BN + activation adjoint (HBM-bound, fp64 column
@@ -219,10 +220,12 @@ extern "C" int gsn_bn_act_bwd_hip(int64_t m_rows, int64_t n_cols, const float *g
     if (m_rows <= 0) return GSN_OK;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid(bgrid(m_rows), (unsigned)((n_cols + 63) / 64));
+    // train_bn == 2: BatchNorm on its RUNNING statistics (eval mode) with gradients wanted for gamma / beta: the same column sums
+    // (xhat from the running mean / invstd), but grad_h = gZ * coef -- the statistics are constants of the rows
     if (train_bn)
         hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, grid, dim3(256), 0, s, m_rows, (int)n_cols, grad_y, y, h, mean, invstd, act, sums);
-    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, grid, dim3(256), 0, s, m_rows, (int)n_cols, grad_y, y, train_bn ? h : y, mean,
-                       invstd, coef, train_bn ? sums : nullptr, act, grad_h, grad_bias);
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, grid, dim3(256), 0, s, m_rows, (int)n_cols, grad_y, y, train_bn == 1 ? h : y, mean,
+                       invstd, coef, train_bn == 1 ? sums : nullptr, act, grad_h, grad_bias);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(GSN_E_HIP, "bn_act_bwd kernels: %s", hipGetErrorString(e));
     return GSN_OK;

@@ -231,6 +231,15 @@ struct PropArgs {
     int da, db, dc, d_out;
     int b_per_node;
     float *out;
+    // r03: the layer's own term and the central encoders' column padding inside the same pass (GSN_sparse.py:157-163,
+    // GSN_edge_sparse_ogb.py:103-106:  (1 + eps) * self + sum of messages;  utils_graph_learning.py:240-246: a zero column in front
+    // of the neighbours' one-hot block).  CAT: the self blocks are concatenated, RELU_SUM: added; row_stride 0 = one row for every node.
+    int pad_b, pad_c;
+    int n_self;
+    const float *self_data[3];
+    int self_w[3];
+    int64_t self_stride[3];
+    const float *eps;
 };
 
 template <int VEC>
@@ -260,6 +269,8 @@ __device__ __forceinline__ void vstore_once(float4 *p, float4 v) {
 }
 __device__ __forceinline__ float vadd(float x, float y) { return x + y; }
 __device__ __forceinline__ float4 vadd(float4 x, float4 y) { return make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w); }
+__device__ __forceinline__ float vfma(float s, float x, float y) { return s * x + y; }     // (1 + eps) * self + sum: two roundings, as the reference's two ops
+__device__ __forceinline__ float4 vfma(float s, float4 x, float4 y) { return make_float4(s * x.x + y.x, s * x.y + y.y, s * x.z + y.z, s * x.w + y.w); }
 __device__ __forceinline__ float vrelu(float x) { return x > 0.f ? x : 0.f; }
 __device__ __forceinline__ float4 vrelu(float4 x) { return make_float4(vrelu(x.x), vrelu(x.y), vrelu(x.z), vrelu(x.w)); }
 __device__ __forceinline__ void vzero(float &x) { x = 0.f; }
@@ -293,10 +304,14 @@ __global__ __launch_bounds__(256) void propagate_fwd_kernel(PropArgs p) {
                 if (col < p.d_out) {
                     V m;
                     if (p.kind == GSN_MSG_CAT) {
-                        if (col < p.da) m = *reinterpret_cast<const V *>(p.a + s * p.da + col);
-                        else if (col < p.da + p.db)
-                            m = p.b_per_node ? *reinterpret_cast<const V *>(p.b + s * p.db + (col - p.da)) : vload_once(reinterpret_cast<const V *>(p.b + e * p.db + (col - p.da)));
-                        else m = vload_once(reinterpret_cast<const V *>(p.c + e * p.dc + (col - p.da - p.db)));
+                        // column layout: a | pad_b zeros | b | pad_c zeros | c      (pads only on the scalar path, VEC == 1)
+                        int o = col - p.da;
+                        if (o < 0) m = *reinterpret_cast<const V *>(p.a + s * p.da + col);
+                        else if (VEC == 1 && o < p.pad_b) vzero(m);
+                        else if ((o -= (VEC == 1 ? p.pad_b : 0)) < p.db)
+                            m = p.b_per_node ? *reinterpret_cast<const V *>(p.b + s * p.db + o) : vload_once(reinterpret_cast<const V *>(p.b + e * p.db + o));
+                        else if (VEC == 1 && (o - p.db) < p.pad_c) vzero(m);
+                        else m = vload_once(reinterpret_cast<const V *>(p.c + e * p.dc + (o - p.db - (VEC == 1 ? p.pad_c : 0))));
                     } else {
                         vzero(m);
                         if (p.a) m = vadd(m, *reinterpret_cast<const V *>(p.a + s * p.d_out + col));
@@ -306,6 +321,30 @@ __global__ __launch_bounds__(256) void propagate_fwd_kernel(PropArgs p) {
                         m = vrelu(m);
                     }
                     acc[i] = vadd(acc[i], m);
+                }
+            }
+        }
+        if (p.n_self) {
+            const float sc = 1.f + (p.eps ? *p.eps : 0.f);
+#pragma unroll
+            for (int i = 0; i < MAXC; ++i) {
+                const int col = (i * LPR + li) * VEC;
+                if (col < p.d_out) {
+                    V sv;
+                    vzero(sv);
+                    int o = col;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        if (k < p.n_self) {
+                            if (p.kind == GSN_MSG_CAT) {
+                                if (o >= 0 && o < p.self_w[k]) sv = *reinterpret_cast<const V *>(p.self_data[k] + t * p.self_stride[k] + o);
+                                o -= p.self_w[k];
+                            } else {
+                                sv = vadd(sv, *reinterpret_cast<const V *>(p.self_data[k] + t * p.self_stride[k] + col));
+                            }
+                        }
+                    }
+                    acc[i] = vfma(sc, sv, acc[i]);
                 }
             }
         }
@@ -328,6 +367,7 @@ struct PropBwdArgs {
     const float *a, *b, *c, *g_out;
     int da, db, dc, d_out;
     int b_per_node;
+    int pad_b, pad_c;         // CAT: zero columns in front of b / c (no gradient)
     float *g_a, *g_b, *g_c;
 };
 
@@ -340,10 +380,11 @@ __global__ __launch_bounds__(256) void propagate_bwd_edge_kernel(PropBwdArgs p) 
         const int64_t t = p.tgt[e];
         float g = p.g_out[t * p.d_out + col];
         if (p.kind == GSN_MSG_CAT) {
-            if (col >= p.da && col < p.da + p.db) {
-                if (!p.b_per_node && p.g_b) p.g_b[e * p.db + (col - p.da)] = g;
-            } else if (col >= p.da + p.db) {
-                if (p.g_c) p.g_c[e * p.dc + (col - p.da - p.db)] = g;
+            const int ob = col - p.da - p.pad_b, oc = ob - p.db - p.pad_c;
+            if (ob >= 0 && ob < p.db) {
+                if (!p.b_per_node && p.g_b) p.g_b[e * p.db + ob] = g;
+            } else if (oc >= 0) {
+                if (p.g_c) p.g_c[e * p.dc + oc] = g;
             }
         } else {
             const int64_t s = p.src[e];
@@ -662,30 +703,66 @@ extern "C" int gsn_csr_build_hip(int64_t n_nodes, int64_t n_edges, const int64_t
 extern "C" int gsn_propagate_fwd_hip(int kind, int64_t n_nodes, int64_t n_edges, const int64_t *src, const int32_t *seg_ptr,
                                      const int32_t *perm, const int32_t *sorted_src, const float *a, int64_t da, const float *b, int64_t db,
                                      int b_per_node, const float *c, int64_t dc, float *out, void *stream) {
+    return gsn_propagate_self_fwd_hip(kind, n_nodes, n_edges, src, seg_ptr, perm, sorted_src, a, da, b, db, b_per_node, c, dc, 0, 0, 0,
+                                      nullptr, nullptr, out, stream);
+}
+
+extern "C" int gsn_propagate_self_fwd_hip(int kind, int64_t n_nodes, int64_t n_edges, const int64_t *src, const int32_t *seg_ptr,
+                                          const int32_t *perm, const int32_t *sorted_src, const float *a, int64_t da, const float *b,
+                                          int64_t db, int b_per_node, const float *c, int64_t dc, int64_t pad_b, int64_t pad_c,
+                                          int n_self, const gsn_self_block *self_blocks, const float *eps, float *out, void *stream) {
     if (kind != GSN_MSG_CAT && kind != GSN_MSG_RELU_SUM) return set_error(GSN_E_INVALID, "gsn_propagate_fwd_hip: unknown kind %d", kind);
+    if (pad_b < 0 || pad_c < 0 || n_self < 0 || n_self > 3 || (n_self > 0 && !self_blocks))
+        return set_error(GSN_E_INVALID, "gsn_propagate_self_fwd_hip: bad pads / self blocks");
+    if ((pad_b || pad_c) && (kind != GSN_MSG_CAT || (pad_b && b_per_node)))
+        return set_error(GSN_E_INVALID, "gsn_propagate_self_fwd_hip: zero columns only in front of the per-edge blocks of a concatenation");
     if (!seg_ptr || !out || (n_edges > 0 && !src)) return set_error(GSN_E_INVALID, "gsn_propagate_fwd_hip: null pointer");
     // widths are authoritative; a null pointer is only legal for a block that is never dereferenced
     if ((da > 0 && !a && n_edges > 0) || (db > 0 && !b && n_edges > 0) || (dc > 0 && !c && n_edges > 0))
         return set_error(GSN_E_INVALID, "gsn_propagate_fwd_hip: a block has width > 0 but no data");
     if (da < 0 || db < 0 || dc < 0) return set_error(GSN_E_INVALID, "gsn_propagate_fwd_hip: negative width");
     int64_t d_out;
-    if (kind == GSN_MSG_CAT) d_out = da + db + dc;
+    if (kind == GSN_MSG_CAT) d_out = da + (db ? pad_b + db : 0) + (dc ? pad_c + dc : 0);
     else {
         d_out = da > db ? da : db;
         d_out = d_out > dc ? d_out : dc;
         if ((da && da != d_out) || (db && db != d_out) || (dc && dc != d_out))
             return set_error(GSN_E_INVALID, "gsn_propagate_fwd_hip: relu-sum blocks must share one width");
     }
+    if ((pad_b && !db) || (pad_c && !dc)) return set_error(GSN_E_INVALID, "gsn_propagate_self_fwd_hip: padding in front of an empty block");
+    uintptr_t self_align = 0;
+    int64_t self_or = 0, self_sum = 0;
+    for (int k = 0; k < n_self; ++k) {
+        if (!self_blocks[k].data || self_blocks[k].width <= 0 || self_blocks[k].row_stride < 0)
+            return set_error(GSN_E_INVALID, "gsn_propagate_self_fwd_hip: self block %d is empty", k);
+        if (kind == GSN_MSG_RELU_SUM && self_blocks[k].width != d_out)
+            return set_error(GSN_E_INVALID, "gsn_propagate_self_fwd_hip: self block %d: width %lld, expected %lld", k,
+                             (long long)self_blocks[k].width, (long long)d_out);
+        self_align |= (uintptr_t)self_blocks[k].data;
+        self_or |= self_blocks[k].width | self_blocks[k].row_stride;
+        self_sum += self_blocks[k].width;
+    }
+    if (n_self && kind == GSN_MSG_CAT) {
+        if (d_out == 0) d_out = self_sum;      // (no edges' worth of blocks: the self term alone)
+        if (self_sum != d_out)
+            return set_error(GSN_E_INVALID, "gsn_propagate_self_fwd_hip: self blocks are %lld columns wide, messages %lld",
+                             (long long)self_sum, (long long)d_out);
+    }
     if (d_out <= 0 || n_nodes <= 0) return GSN_OK;
     if (d_out > 1024) return set_error(GSN_E_UNSUPPORTED, "gsn_propagate_fwd_hip: message width %lld > 1024", (long long)d_out);
     PropArgs p{};
+    p.pad_b = db ? (int)pad_b : 0; p.pad_c = dc ? (int)pad_c : 0; p.n_self = n_self; p.eps = eps;
+    for (int k = 0; k < n_self; ++k) {
+        p.self_data[k] = self_blocks[k].data; p.self_w[k] = (int)self_blocks[k].width; p.self_stride[k] = self_blocks[k].row_stride;
+    }
     p.kind = kind; p.n_nodes = n_nodes; p.n_edges = n_edges; p.src = src; p.seg_ptr = seg_ptr; p.perm = perm;
     p.sorted_src = sorted_src;
     p.a = da ? a : nullptr; p.b = db ? b : nullptr; p.c = dc ? c : nullptr;
     p.da = (int)da; p.db = (int)db; p.dc = (int)dc; p.d_out = (int)d_out;
     p.b_per_node = b_per_node; p.out = out;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const bool aligned = ((da | db | dc) % 4 == 0) && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)out) % 16 == 0);
+    const bool aligned = ((da | db | dc | pad_b | pad_c | self_or) % 4 == 0) && pad_b == 0 && pad_c == 0 &&
+                         (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)out | self_align) % 16 == 0);
     if (aligned) {
         const int64_t q = d_out / 4;  // float4 per row
         if (q <= 8) return launch_fwd<4, 8, 1>(p, st);
@@ -706,10 +783,22 @@ extern "C" int gsn_propagate_bwd_hip(int kind, int64_t n_nodes, int64_t n_edges,
                                      const int32_t *seg_ptr_src, const int32_t *perm_src, const float *a, int64_t da,
                                      const float *b, int64_t db, int b_per_node, const float *c, int64_t dc,
                                      const float *g_out, float *g_a, float *g_b, float *g_c, void *stream) {
+    return gsn_propagate_pad_bwd_hip(kind, n_nodes, n_edges, src, tgt, seg_ptr_src, perm_src, a, da, b, db, b_per_node, c, dc, 0, 0, g_out,
+                                     g_a, g_b, g_c, stream);
+}
+
+extern "C" int gsn_propagate_pad_bwd_hip(int kind, int64_t n_nodes, int64_t n_edges, const int64_t *src, const int64_t *tgt,
+                                         const int32_t *seg_ptr_src, const int32_t *perm_src, const float *a, int64_t da,
+                                         const float *b, int64_t db, int b_per_node, const float *c, int64_t dc, int64_t pad_b,
+                                         int64_t pad_c, const float *g_out, float *g_a, float *g_b, float *g_c, void *stream) {
     if (kind != GSN_MSG_CAT && kind != GSN_MSG_RELU_SUM) return set_error(GSN_E_INVALID, "gsn_propagate_bwd_hip: unknown kind %d", kind);
     if (!g_out || (n_edges > 0 && (!src || !tgt))) return set_error(GSN_E_INVALID, "gsn_propagate_bwd_hip: null pointer");
+    if (pad_b < 0 || pad_c < 0 || ((pad_b || pad_c) && (kind != GSN_MSG_CAT || (pad_b && b_per_node))))
+        return set_error(GSN_E_INVALID, "gsn_propagate_pad_bwd_hip: zero columns only in front of the per-edge blocks of a concatenation");
+    if (!db) pad_b = 0;
+    if (!dc) pad_c = 0;
     int64_t d_out;
-    if (kind == GSN_MSG_CAT) d_out = da + db + dc;
+    if (kind == GSN_MSG_CAT) d_out = da + pad_b + db + pad_c + dc;
     else { d_out = da > db ? da : db; d_out = d_out > dc ? d_out : dc; }
     if (d_out <= 0 || n_nodes <= 0) return GSN_OK;
     if (kind == GSN_MSG_RELU_SUM && ((da && !a) || (db && !b) || (dc && !c)))
@@ -719,6 +808,7 @@ extern "C" int gsn_propagate_bwd_hip(int kind, int64_t n_nodes, int64_t n_edges,
     p.seg_ptr_src = seg_ptr_src; p.perm_src = perm_src;
     p.a = da ? a : nullptr; p.b = db ? b : nullptr; p.c = dc ? c : nullptr; p.g_out = g_out;
     p.da = (int)da; p.db = (int)db; p.dc = (int)dc; p.d_out = (int)d_out; p.b_per_node = b_per_node;
+    p.pad_b = (int)pad_b; p.pad_c = (int)pad_c;
     p.g_a = g_a; p.g_b = g_b; p.g_c = g_c;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const bool need_edge = (g_b && !b_per_node && db) || (g_c && dc);

@@ -360,34 +360,50 @@ def one_hot_identifiers(values, n_classes, clamp=False):
 # ------------------------------------------------------------------------------------------------------------------
 class _PropagateFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, kind, edge_index, sel, n_nodes, b_per_node, a, b, c):
+    def forward(ctx, kind, edge_index, sel, n_nodes, b_per_node, a, b, c, pads, eps, *selfs):
+        # selfs: the layer's own term -- blocks [N][w] or [1][w] (one row for every vertex); pads: zero columns in front of b / c
         tgt_row, src_row = sel, 1 - sel
         csr_t = _csr_for(edge_index, tgt_row, n_nodes)
         src = edge_index[src_row].contiguous()
         E = src.numel()
         ts = [None if t is None else _f32c(t) for t in (a, b, c)]
         widths = [0 if t is None else t.shape[1] for t in ts]
-        d_out = sum(widths) if kind == 0 else max(widths)
+        pad_b, pad_c = (pads[0] if widths[1] else 0), (pads[1] if widths[2] else 0)
+        ss = [_f32c(t) for t in selfs]
+        d_out = (sum(widths) + pad_b + pad_c) if kind == 0 else max(widths)
+        if ss and kind == 0 and sum(t.shape[1] for t in ss) != d_out:
+            raise RuntimeError("propagate: the self blocks are %d columns wide, the messages %d" % (sum(t.shape[1] for t in ss), d_out))
         out = torch.empty((n_nodes, d_out), dtype=torch.float32, device=edge_index.device)
         # algorithmic bytes: src (8) + perm (4) per edge, every message element read once, output written once
         per_edge = (0 if ts[0] is None else widths[0]) + (0 if (ts[1] is None or b_per_node) else widths[1]) + (0 if ts[2] is None else widths[2])
-        bytes_alg = 12.0 * E + 4.0 * n_nodes + 4.0 * (E * per_edge + n_nodes * d_out)
+        bytes_alg = 12.0 * E + 4.0 * n_nodes + 4.0 * (E * per_edge + n_nodes * d_out) + 4.0 * sum(t.numel() for t in ss)
+        arr = (_abi.gsn_self_block * max(1, len(ss)))()
+        for k, t in enumerate(ss):
+            if t.shape[0] not in (1, n_nodes):
+                raise RuntimeError("propagate: self block %d has %d rows (1 or %d expected)" % (k, t.shape[0], n_nodes))
+            arr[k].data = t.data_ptr(); arr[k].width = t.shape[1]; arr[k].row_stride = 0 if (t.shape[0] == 1 and n_nodes != 1) else t.shape[1]
+        eps32 = None if eps is None else _f32c(eps.reshape(-1))
         with _abi.device_guard(edge_index.device), _timed("propagate_fwd", bytes_alg):
-            rc = _abi.lib().gsn_propagate_fwd_hip(kind, n_nodes, E, src.data_ptr() if E else None, csr_t.seg_ptr.data_ptr(),
-                                                  csr_t.perm.data_ptr() if E else None,
-                                                  csr_t.src.data_ptr() if (E and csr_t.src is not None) else None,
-                                                  _abi.ptr(ts[0]), widths[0], _abi.ptr(ts[1]), widths[1], int(b_per_node),
-                                                  _abi.ptr(ts[2]), widths[2], out.data_ptr(), _abi.current_stream())
-        _abi.check(rc, "gsn_propagate_fwd_hip")
+            rc = _abi.lib().gsn_propagate_self_fwd_hip(kind, n_nodes, E, src.data_ptr() if E else None, csr_t.seg_ptr.data_ptr(),
+                                                       csr_t.perm.data_ptr() if E else None,
+                                                       csr_t.src.data_ptr() if (E and csr_t.src is not None) else None,
+                                                       _abi.ptr(ts[0]), widths[0], _abi.ptr(ts[1]), widths[1], int(b_per_node),
+                                                       _abi.ptr(ts[2]), widths[2], pad_b, pad_c, len(ss), arr, _abi.ptr(eps32),
+                                                       out.data_ptr(), _abi.current_stream())
+        _abi.check(rc, "gsn_propagate_self_fwd_hip")
         ctx.kind, ctx.sel, ctx.n_nodes, ctx.b_per_node = kind, sel, n_nodes, b_per_node
         ctx.edge_index = edge_index
-        ctx.widths = widths
-        ctx.save_for_backward(*[t if t is not None else torch.empty(0, device=edge_index.device) for t in ts])
+        ctx.widths, ctx.pads, ctx.n_self, ctx.has_eps = widths, (pad_b, pad_c), len(ss), eps is not None
+        ctx.eps_shape = None if eps is None else eps.shape
+        empty = torch.empty(0, device=edge_index.device)
+        ctx.save_for_backward(*[t if t is not None else empty for t in ts], eps32 if eps is not None else empty, *ss)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
-        a, b, c = [t if t.numel() else None for t in ctx.saved_tensors]
+        saved = ctx.saved_tensors
+        a, b, c = [t if t.numel() else None for t in saved[:3]]
+        eps32, ss = saved[3], saved[4:]
         ei, sel, n = ctx.edge_index, ctx.sel, ctx.n_nodes
         src = ei[1 - sel].contiguous()
         tgt = ei[sel].contiguous()
@@ -404,21 +420,45 @@ class _PropagateFn(torch.autograd.Function):
         if need[1] and wb:
             g_b = torch.zeros((n if ctx.b_per_node else E, wb), dtype=torch.float32, device=dev)
         g_c = torch.zeros((E, wc), dtype=torch.float32, device=dev) if (need[2] and wc) else None
-        with _abi.device_guard(dev):
-            rc = _abi.lib().gsn_propagate_bwd_hip(ctx.kind, n, E, src.data_ptr() if E else None, tgt.data_ptr() if E else None,
-                                                  csr_s.seg_ptr.data_ptr() if csr_s is not None else None,
-                                                  csr_s.perm.data_ptr() if (csr_s is not None and E) else None,
-                                                  _abi.ptr(a), wa, _abi.ptr(b), wb, int(ctx.b_per_node), _abi.ptr(c), wc,
-                                                  g_out.data_ptr(), _abi.ptr(g_a), _abi.ptr(g_b), _abi.ptr(g_c),
-                                                  _abi.current_stream())
-        _abi.check(rc, "gsn_propagate_bwd_hip")
-        return None, None, None, None, None, g_a, g_b, g_c
+        if g_a is not None or g_b is not None or g_c is not None:
+            with _abi.device_guard(dev):
+                rc = _abi.lib().gsn_propagate_pad_bwd_hip(ctx.kind, n, E, src.data_ptr() if E else None, tgt.data_ptr() if E else None,
+                                                          csr_s.seg_ptr.data_ptr() if csr_s is not None else None,
+                                                          csr_s.perm.data_ptr() if (csr_s is not None and E) else None,
+                                                          _abi.ptr(a), wa, _abi.ptr(b), wb, int(ctx.b_per_node), _abi.ptr(c), wc,
+                                                          ctx.pads[0], ctx.pads[1], g_out.data_ptr(), _abi.ptr(g_a), _abi.ptr(g_b),
+                                                          _abi.ptr(g_c), _abi.current_stream())
+            _abi.check(rc, "gsn_propagate_pad_bwd_hip")
+        # the self term (1 + eps) * self: a column slice of g_out per block (a few elementwise ops over N rows, backward only)
+        g_eps, g_selfs = None, []
+        if ctx.n_self:
+            sc = (1.0 + eps32[0]) if ctx.has_eps else 1.0
+            want_eps = ctx.has_eps and ctx.needs_input_grad[9]
+            acc, o = None, 0
+            for k, t in enumerate(ss):
+                w = t.shape[1]
+                gk = g_out[:, o:o + w] if ctx.kind == 0 else g_out
+                if ctx.needs_input_grad[10 + k]:
+                    gs = gk * sc
+                    g_selfs.append(gs.sum(0, keepdim=True) if (t.shape[0] == 1 and n != 1) else gs)
+                else:
+                    g_selfs.append(None)
+                if want_eps:
+                    term = (gk.to(torch.float64) * t).sum()
+                    acc = term if acc is None else acc + term
+                if ctx.kind == 0:
+                    o += w
+            if want_eps:
+                g_eps = acc.to(torch.float32).reshape(ctx.eps_shape)
+        return (None, None, None, None, None, g_a, g_b, g_c, None, g_eps) + tuple(g_selfs)
 
 
-def propagate(kind, edge_index, sel, n_nodes, a=None, b=None, c=None, b_per_node=False):
-    """out[t] = sum_{e: edge_index[sel, e] = t} msg_e  with msg_e = cat(a[src_e], b, c) (kind 0) or
-    relu(a[src_e] + b + c) (kind 1); b is per edge, or per node gathered at src if ``b_per_node``."""
-    return _PropagateFn.apply(kind, edge_index, sel, n_nodes, bool(b_per_node), a, b, c)
+def propagate(kind, edge_index, sel, n_nodes, a=None, b=None, c=None, b_per_node=False, selfs=(), eps=None, pads=(0, 0)):
+    """out[t] = [(1 + eps) * self[t] +] sum_{e: edge_index[sel, e] = t} msg_e  with msg_e = cat(a[src_e], 0.., b, 0.., c) (kind 0; ``pads``
+    zero columns in front of b and c) or relu(a[src_e] + b + c) (kind 1); b is per edge, or per node gathered at src if ``b_per_node``.
+    ``selfs``: blocks of the layer's own term, concatenated (kind 0) or added (kind 1), each [N][w] or [1][w] (the same row for every
+    vertex); ``eps`` a 0-dim / 1-element tensor (GSN_sparse.py:157-163, GSN_edge_sparse_ogb.py:103-106)."""
+    return _PropagateFn.apply(kind, edge_index, sel, n_nodes, bool(b_per_node), a, b, c, (int(pads[0]), int(pads[1])), eps, *selfs)
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -808,13 +848,15 @@ def _bn_resolve(stage, stats_fn, m_rows, training):
         hit = getattr(bn, "_gsn_eval_cache", None)
         if hit is not None and hit[0] == key:
             stage.bn_params = hit[1]
+            stage.bn_invstd = hit[2]
             return
         mean32 = bn.running_mean
         invstd = torch.rsqrt(bn.running_var.to(torch.float64) + bn.eps).to(torch.float32)
         scale = invstd * bn.weight.detach() if bn.affine else invstd
         shift = bn.bias.detach() if bn.affine else torch.zeros_like(invstd)
         stage.bn_params = (mean32.contiguous(), scale.contiguous(), shift.contiguous())
-        bn._gsn_eval_cache = (key, stage.bn_params)
+        stage.bn_invstd = invstd.contiguous()
+        bn._gsn_eval_cache = (key, stage.bn_params, stage.bn_invstd)
         return
     scale = invstd * bn.weight.detach() if bn.affine else invstd
     shift = bn.bias.detach() if bn.affine else torch.zeros_like(invstd)
@@ -906,11 +948,26 @@ class _DenseStagesFn(torch.autograd.Function):
                 gamma, beta = next(it), next(it)
             blks = [(t, None) for t in blocks0] if si == 0 else [(y, None)]
             n_out = w.shape[0]
-            if bn is not None:      # train-mode batch statistics (the caller routes eval-mode BN with grads to the twin)
-                stats = torch.zeros((2, n_out), dtype=torch.float64, device=w.device)
-                h = _linear_hip(blks, w, b, None, None, None, 0, m_rows, out=True, stats=stats)
+            bn_train = bn is not None and (bn.training or bn.running_mean is None)
+            bn_affine_grad = bn is not None and bn.affine and (bn.weight.requires_grad or bn.bias.requires_grad)
+            if bn is not None and not bn_train and not bn_affine_grad:
+                # BatchNorm on its running statistics, gamma / beta frozen: a per-column affine map in the epilogue of the product
                 st = _Stage(w, b, bn, sp["act"])
-                _bn_resolve(st, lambda: stats, m_rows, True)
+                _bn_resolve(st, None, m_rows, False)
+                mean32, scale, shift = st.bn_params
+                y = _linear_hip(blks, w, b, mean32, scale, shift, _ACT_CODE[sp["act"]], m_rows)
+                saved += [y, _f32c(scale)]
+                meta.append(("affine", len(saved) - 2))
+            elif bn is not None:
+                # batch statistics (train mode), or running statistics with gradients for gamma / beta: pre-BN rows materialised
+                st = _Stage(w, b, bn, sp["act"])
+                if bn_train:
+                    stats = torch.zeros((2, n_out), dtype=torch.float64, device=w.device)
+                    h = _linear_hip(blks, w, b, None, None, None, 0, m_rows, out=True, stats=stats)
+                    _bn_resolve(st, lambda: stats, m_rows, True)
+                else:
+                    h = _linear_hip(blks, w, b, None, None, None, 0, m_rows, out=True)
+                    _bn_resolve(st, None, m_rows, False)
                 mean32, scale, shift = st.bn_params
                 yy = torch.empty_like(h)
                 vecs = [_f32c(v) for v in (mean32, scale, shift)]
@@ -920,7 +977,7 @@ class _DenseStagesFn(torch.autograd.Function):
                                                          _abi.current_stream()), "gsn_bn_act_hip")
                 invstd = st.bn_invstd
                 saved += [h, yy, vecs[0], invstd.contiguous(), vecs[1]]
-                meta.append(("bn", len(saved) - 5))
+                meta.append(("bn" if bn_train else "bn_eval", len(saved) - 5))
                 y = yy
             else:
                 y = _linear_hip(blks, w, b, None, None, None, _ACT_CODE[sp["act"]], m_rows)
@@ -961,25 +1018,30 @@ class _DenseStagesFn(torch.autograd.Function):
             gh = torch.empty((m_rows, n_out), dtype=torch.float32, device=dev)
             act = _ACT_CODE[sp["act"]]
             with _abi.device_guard(dev), _timed("bn_act_bwd", 16.0 * m_rows * n_out):
-                if kind == "bn":
+                if kind in ("bn", "bn_eval"):
                     h, y, mean32, invstd, scale = saved[off:off + 5]
                     sums = torch.zeros((2, n_out), dtype=torch.float64, device=dev)
                     rc = L.gsn_bn_act_bwd_hip(m_rows, n_out, g.data_ptr(), y.data_ptr(), h.data_ptr(), mean32.data_ptr(),
-                                              invstd.data_ptr(), scale.data_ptr(), 1, act, sums.data_ptr(), gh.data_ptr(),
-                                              gbias.data_ptr(), _abi.current_stream())
+                                              invstd.data_ptr(), scale.data_ptr(), 1 if kind == "bn" else 2, act, sums.data_ptr(),
+                                              gh.data_ptr(), gbias.data_ptr(), _abi.current_stream())
+                elif kind == "affine":
+                    y, scale = saved[off:off + 2]
+                    sums = None
+                    rc = L.gsn_bn_act_bwd_hip(m_rows, n_out, g.data_ptr(), y.data_ptr(), None, None, None, scale.data_ptr(), 0, act, None,
+                                              gh.data_ptr(), gbias.data_ptr(), _abi.current_stream())
                 else:
                     y = saved[off]
                     sums = None
                     rc = L.gsn_bn_act_bwd_hip(m_rows, n_out, g.data_ptr(), y.data_ptr(), None, None, None, None, 0, act, None,
                                               gh.data_ptr(), gbias.data_ptr(), _abi.current_stream())
             _abi.check(rc, "gsn_bn_act_bwd_hip")
-            if kind == "bn" and "g_i" in ent:
+            if kind in ("bn", "bn_eval") and "g_i" in ent:
                 grads[ent["g_i"]] = sums[1].to(torch.float32)
                 grads[ent["beta_i"]] = sums[0].to(torch.float32)
             if "b_i" in ent:
                 grads[ent["b_i"]] = gbias.to(torch.float32)
             # weight gradient
-            xin = blocks0 if si == 0 else [saved[meta[si - 1][1] + (1 if meta[si - 1][0] == "bn" else 0)]]
+            xin = blocks0 if si == 0 else [saved[meta[si - 1][1] + (1 if meta[si - 1][0] in ("bn", "bn_eval") else 0)]]
             if ctx.needs_input_grad[1 + ent["w_i"]]:
                 gw = torch.zeros((n_out, k_total), dtype=torch.float32, device=dev)
                 arr = (_abi.gsn_block * len(xin))()
@@ -1007,14 +1069,13 @@ class _DenseStagesFn(torch.autograd.Function):
         return (None,) + tuple(grads)
 
 
-def _dense_native_ok(stages, training):
-    """Native backward covers: plain (un-gathered) blocks, BatchNorm only with batch statistics, <= 5 blocks."""
+def _dense_native_ok(stages, training=None):
+    """Native backward covers: plain (un-gathered) blocks, <= 5 of them; BatchNorm on batch statistics or (r03) on its running
+    statistics -- each BatchNorm1d module's own ``training`` flag decides, as in the reference (models_misc.py:41-45)."""
     if not NATIVE_DENSE_BACKWARD or not stages or len(stages[0].blocks) > 5:
         return False
     for i, st in enumerate(stages):
         if any(idx is not None for _, idx in st.blocks) or (i > 0 and st.blocks):
-            return False
-        if st.bn is not None and not (training or st.bn.running_mean is None):
             return False
     return True
 
@@ -1201,17 +1262,21 @@ class mlp(nn.Module):
 
     def forward(self, x, post=None):
         _need_cuda(x, "mlp input")
-        if torch.is_grad_enabled() and self.training:     # (eval mode keeps the fused forward; its rare gradients use the twin)
-            stages = self.stages([(x, None)], post=post)
-            if _dense_native_ok(stages, self.training):
-                return run_stages_autograd(stages, x.shape[0], self.training)
+        native = _dense_native_ok(self.stages([(x, None)], post=post))
+        if torch.is_grad_enabled() and self.training and native:
+            return run_stages_autograd(self.stages([(x, None)], post=post), x.shape[0], self.training)
+        # eval mode: the fused forward; if a gradient is asked for after all, the stages are re-run on the kernels that keep what
+        # their HIP adjoints need (no PyTorch twin: BatchNorm on running statistics is a per-column affine map there)
         extra = list(post[0].parameters()) if (post is not None and post[0] is not None) else []
-        return _run(self, lambda: self.hip_forward([(x, None)], x.shape[0], post=post),
-                    lambda x_: self.torch_forward(x_, post=post), [x], extra_params=extra)
+        again = (lambda x_: run_stages_autograd(self.stages([(x_, None)], post=post), x_.shape[0], self.training)) if native and not self.training \
+            else (lambda x_: self.torch_forward(x_, post=post))
+        return _run(self, lambda: self.hip_forward([(x, None)], x.shape[0], post=post), again, [x], extra_params=extra,
+                    native=native and not self.training)
 
 
 class _HipWithTorchBackward(torch.autograd.Function):
-    """y = hip_fn() in forward; gradients by re-running the differentiable twin under autograd."""
+    """y = hip_fn() in forward; gradients by re-running a differentiable evaluation of the same function under autograd: the PyTorch
+    twin here, a composition of kernels that each have a HIP adjoint in the subclass below (same mechanics)."""
 
     @staticmethod
     def forward(ctx, hip_fn, torch_fn, n_inputs, *tensors):
@@ -1239,7 +1304,12 @@ class _HipWithTorchBackward(torch.autograd.Function):
         return tuple(out)
 
 
-def _run(module, hip_fn, torch_fn, inputs, extra_params=()):
+class _HipWithNativeBackward(_HipWithTorchBackward):
+    """Same, with ``torch_fn`` a composition of HIP kernels with HIP adjoints (eval-mode gradients: the fused forward keeps nothing,
+    the backward re-runs the stages materialised and walks their adjoints -- gsn_bn_act_bwd_hip, gsn_wgrad_hip, gsn_propagate_bwd_hip)."""
+
+
+def _run(module, hip_fn, torch_fn, inputs, extra_params=(), native=False):
     if not torch.is_grad_enabled():
         return hip_fn()
     params = [p for p in module.parameters()] + list(extra_params)
@@ -1247,13 +1317,17 @@ def _run(module, hip_fn, torch_fn, inputs, extra_params=()):
     if not need_grad:
         with torch.no_grad():
             return hip_fn()
-    return _HipWithTorchBackward.apply(hip_fn, torch_fn, len(inputs), *inputs, *params)
+    fn = _HipWithNativeBackward if (native and NATIVE_DENSE_BACKWARD) else _HipWithTorchBackward
+    return fn.apply(hip_fn, torch_fn, len(inputs), *inputs, *params)
 
 
 def run_linear_module(lin, x):
     """A lone ``nn.Linear`` on the HIP dense stage (DiscreteEmbedding('linear'), utils_graph_learning.py:63-65)."""
     _need_cuda(x, "linear input")
     stage = lambda: run_stages([_Stage(lin.weight, lin.bias, None, "identity", [(x, None)])], x.shape[0], False)
+    if NATIVE_DENSE_BACKWARD:
+        again = lambda x_: run_stages_autograd([_Stage(lin.weight, lin.bias, None, "identity", [(x_, None)])], x_.shape[0], False)
+        return _run(lin, stage, again, [x], native=True)
     return _run(lin, stage, lambda x_: F.linear(x_, lin.weight, lin.bias), [x])
 
 
@@ -1298,6 +1372,20 @@ class central_encoder(nn.Module):
         else:
             x_central = torch.zeros((num_nodes, self.d_out), device=x_nb.device)
         return x_central, x_nb
+
+    def central_row(self, device):
+        """(the central value as ONE row [1][d_out], zero columns to put in front of the neighbours' block): what ``forward`` expands to
+        num_nodes rows and concatenates -- gsn_propagate_self_fwd_hip takes it as a row stride of 0 and a column offset instead."""
+        if (not self.one_hot) and self.extend:
+            return self.encoder.encoder.encoder[0].weight[0:1], 0
+        key = str(device)
+        cache = self.__dict__.setdefault("_gsn_rows", {})
+        if key not in cache:
+            row = torch.zeros((1, self.d_out), device=device)
+            if self.one_hot and self.extend:
+                row[0, 0] = 1.0
+            cache[key] = row
+        return cache[key], (1 if (self.one_hot and self.extend) else 0)
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -1420,6 +1508,14 @@ class _SparseLayer(nn.Module):
             if self._general_native_ok():
                 return self._general_train(edge_index, _dense(x), _dense(ids), _dense(ef), post)
         extra = list(post[0].parameters()) if (post is not None and post[0] is not None) else []
+        if NATIVE_DENSE_BACKWARD and not self.training:
+            # eval mode: the fused forward keeps nothing; a gradient asked for after all re-runs the layer as the composition of kernels
+            # that have HIP adjoints (the train-mode paths above; every BatchNorm1d in eval mode is an affine map there) -- no twin
+            if self.ogb or self.msg_kind == "gin":
+                again = lambda *ts: self._twin(edge_index, *unpack(ts), post=post, native=True)
+            else:
+                again = lambda *ts: self._general_train(edge_index, *unpack(ts), post)
+            return _run(self, lambda: self._hip(edge_index, x, ids, ef, post), again, inputs, extra_params=extra, native=True)
         return _run(self, lambda: self._hip(edge_index, x, ids, ef, post), lambda *ts: self._twin(edge_index, *unpack(ts), post=post), inputs,
                     extra_params=extra)
 
@@ -1443,6 +1539,30 @@ class _SparseLayer(nn.Module):
             self_parts.append(c)
         return self_parts, ids_nb, ef_nb, ids_per_node
 
+    def _self_plus_messages(self, edge_index, x, ids, ef):
+        """(1 + eps) * self + sum of messages of the gin / ogb layers in ONE pass of the propagate kernel (forward: no elementwise
+        tensor op, no concatenation; GSN_sparse.py:157-163, GSN_edge_sparse.py:95-109, GSN_edge_sparse_ogb.py:63-84 / :103-106)."""
+        n, sel = x.shape[0], self._sel()
+        if self.ogb:
+            per_node = self.has_ids and self.id_scope == "global"
+            return propagate(1, edge_index, sel, n, a=x, b=ids if self.has_ids else None, c=ef, b_per_node=per_node,
+                             selfs=[x, ids] if per_node else [x], eps=self.eps)
+        selfs, ids_nb, ef_nb, per_node, pads = [x], None, None, False, [0, 0]
+        if self.has_ids:
+            if self.id_scope == "global":
+                selfs.append(ids); ids_nb, per_node = ids, True
+            else:
+                row, pads[0] = self.central_node_id_encoder.central_row(x.device)
+                selfs.append(row); ids_nb = ids
+        if self.has_ef:
+            row, pad = self.central_node_edge_encoder.central_row(x.device)
+            selfs.append(row); ef_nb = ef
+            if ids_nb is None:      # (the edge features are then the kernel's block b)
+                ids_nb, ef_nb, pads[0] = ef, None, pad
+            else:
+                pads[1] = pad
+        return propagate(0, edge_index, sel, n, a=x, b=ids_nb, c=ef_nb, b_per_node=per_node, selfs=selfs, eps=self.eps, pads=pads)
+
     # -- HIP forward ---------------------------------------------------------------------------------------------
     def _hip(self, edge_index, x, ids, ef, post=None):
         n = x.shape[0]
@@ -1454,16 +1574,8 @@ class _SparseLayer(nn.Module):
         x = _f32c(_dense(x))
         if not use_codes:
             ids, ef = _dense(ids), _dense(ef)
-        if self.ogb:
-            per_node = self.has_ids and self.id_scope == "global"
-            agg = propagate(1, edge_index, sel, n, a=x, b=ids if self.has_ids else None, c=ef, b_per_node=per_node)
-            self_msg = x + ids if per_node else x
-            xin = (1 + self.eps) * self_msg + agg
-            return self.update_fn.hip_forward([(xin, None)], n, post=post)
-        if self.msg_kind == "gin":
-            self_parts, ids_nb, ef_nb, per_node = self._gin_parts(x, ids, ef, n)
-            agg = propagate(0, edge_index, sel, n, a=x, b=ids_nb, c=ef_nb, b_per_node=per_node)
-            xin = (1 + self.eps) * torch.cat(self_parts, -1) + agg
+        if self.ogb or self.msg_kind == "gin":
+            xin = self._self_plus_messages(edge_index, x, ids, ef)
             return self.update_fn.hip_forward([(xin, None)], n, post=post)
         # general
         idx_i, idx_j = edge_index[sel].contiguous(), edge_index[1 - sel].contiguous()
@@ -1528,8 +1640,7 @@ class _SparseLayer(nn.Module):
 
     # -- differentiable `general` path on native adjoints ------------------------------------------------------------------
     def _general_native_ok(self):
-        bns = list(self.msg_fn.bn) + list(self.update_fn.bn)
-        return len(self.msg_fn.fc) >= 2 and all(b.training or b.running_mean is None for b in bns) and self.training
+        return self.training
 
     def _general_train(self, edge_index, x, ids, ef, post):
         """msg_fn's hidden stages on materialised edge rows -> sum per target -> [x | S | deg] through update_fn with the
@@ -1545,6 +1656,14 @@ class _SparseLayer(nn.Module):
         if self.has_ef:
             tensors.append(ef); modes.append(None)
         mf, uf = self.msg_fn, self.update_fn
+        if len(mf.fc) < 2:      # a single Linear as msg_fn: nothing to fold (GSN_sparse.py:166-171 with d_h = [])
+            if E > 0:
+                xe = _GatherCatFn.apply(edge_index, n, tuple(modes), *tensors)
+                msgs = run_stages_autograd(mf.stages([(xe, None)]), E, True)
+                agg = propagate(0, edge_index, sel, n, b=msgs)
+            else:
+                agg = torch.zeros((n, mf.fc[-1].weight.shape[0]), device=x.device)
+            return run_stages_autograd(uf.stages([(x, None), (agg, None)], post=post), n, True)
         if E > 0:
             xe = _GatherCatFn.apply(edge_index, n, tuple(modes), *tensors)
             r = run_stages_autograd(mf.stages([(xe, None)], upto=len(mf.fc) - 1), E, True)
@@ -1645,6 +1764,8 @@ class _SparseLayer(nn.Module):
     def _twin(self, edge_index, x, ids, ef, post=None, native=False):
         n = x.shape[0]
         sel = self._sel()
+        if native and (self.ogb or self.msg_kind == "gin"):
+            return self.update_fn(self._self_plus_messages(edge_index, x, ids, ef), post=post)
         if self.ogb:
             per_node = self.has_ids and self.id_scope == "global"
             agg = propagate(1, edge_index, sel, n, a=x, b=ids if self.has_ids else None, c=ef, b_per_node=per_node)

@@ -179,6 +179,34 @@ int gsn_propagate_bwd_hip(int kind, int64_t n_nodes, int64_t n_edges, const int6
                           const float *b, int64_t db, int b_per_node, const float *c, int64_t dc,
                           const float *g_out, float *g_a, float *g_b, float *g_c, void *stream);
 
+/* The same pass with the layer's own term and the central encoders' column padding inside it (r03; what the reference does with
+ * three elementwise tensor ops and two concatenations per layer):
+ *     out[t] = (1 + *eps) * self[t] + sum_{e -> t} msg_e
+ *   GSN_sparse.py:157-163 / GSN_edge_sparse.py:95-109 (gin):   self = cat(x, identifiers or their central value, central edge value);
+ *   GSN_edge_sparse_ogb.py:63-84, :103-106 (ogb):              self = x (+ identifiers, global scope).
+ * self_blocks: up to three blocks, concatenated (CAT: their widths add up to d_out) or added (RELU_SUM: each d_out wide); row_stride
+ * in floats, 0 = ONE row for every vertex (central_encoder's constant value, utils_graph_learning.py:232-260).  eps: device pointer
+ * to the layer's eps (parameter or buffer), NULL = 0.  pad_b / pad_c: zero columns in front of the per-edge blocks b / c of a
+ * concatenation (utils_graph_learning.py:240-242: the extra first column of an extended one-hot encoding), so that
+ * d_out = da + pad_b + db + pad_c + dc.  gsn_propagate_pad_bwd_hip: the adjoint with the same column layout (the self term's adjoint is
+ * a column slice of g_out times (1 + eps): host side).
+ */
+typedef struct gsn_self_block {
+    const float *data;
+    int64_t width;
+    int64_t row_stride;
+} gsn_self_block;
+
+int gsn_propagate_self_fwd_hip(int kind, int64_t n_nodes, int64_t n_edges, const int64_t *src, const int32_t *seg_ptr,
+                               const int32_t *perm, const int32_t *sorted_src, const float *a, int64_t da, const float *b, int64_t db,
+                               int b_per_node, const float *c, int64_t dc, int64_t pad_b, int64_t pad_c, int n_self,
+                               const gsn_self_block *self_blocks, const float *eps, float *out, void *stream);
+
+int gsn_propagate_pad_bwd_hip(int kind, int64_t n_nodes, int64_t n_edges, const int64_t *src, const int64_t *tgt,
+                              const int32_t *seg_ptr_src, const int32_t *perm_src, const float *a, int64_t da,
+                              const float *b, int64_t db, int b_per_node, const float *c, int64_t dc, int64_t pad_b, int64_t pad_c,
+                              const float *g_out, float *g_a, float *g_b, float *g_c, void *stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * HP-2  fused dense stage (device; fp32 in / fp32 out; matrix products run as six exact bf16 plane products per fp32
  * product on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- fp32-equivalent error -- or, with GSN_LINEAR_BF16X6=0,
@@ -448,7 +476,9 @@ int gsn_column_stats_hip(int64_t m_rows, int64_t n_cols, const float *h, double 
  *   gsn_bn_act_bwd_hip : grad_h = d/dH from grad_y.  y = the stage output (activation derivative is taken from it);
  *       train_bn != 0: batch-statistics BatchNorm -- h = pre-BN rows, mean / invstd = the batch statistics, coef =
  *       gamma * invstd, sums = fp64 [2][C] scratch (zero-filled) that receives sum(gZ) = grad beta and sum(gZ * xhat) =
- *       grad gamma;  train_bn == 0: grad_h = gZ * coef (coef NULL = 1; h, mean, invstd, sums unused).
+ *       grad gamma;  train_bn == 0: grad_h = gZ * coef (coef NULL = 1; h, mean, invstd, sums unused);  train_bn == 2: BatchNorm
+ *       on its running statistics (module in eval mode, models_misc.py:41-45 under model.eval()) with gradients for gamma / beta:
+ *       h = pre-BN rows, mean / invstd = the running statistics, sums as above, grad_h = gZ * coef.
  *       grad_bias (fp64 [C], zero-filled, may be NULL) receives the column sums of grad_h.  grad_h may alias grad_y.
  *   gsn_wgrad_hip : grad_w[n_out][K] += grad_h^T X  with X the concatenation of `blocks` (no gathers); caller zero-fills.
  *   The input gradient is gsn_linear_fwd_hip(grad_h, weight = W^T).
