@@ -14,6 +14,8 @@
 // 128 x 128 tile of gW and one slab of rows, accumulates in registers and adds its partial tile with float atomics.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "gsn_internal.h"
 
 namespace gsn {
@@ -101,6 +103,7 @@ constexpr int WG_MAXB = 5;
 struct WgradArgs {
     int64_t m_rows, rows_per_wg;
     int n_out, k_total, n_blocks;
+    int tn, tk;                    // tiles along n_out / K (wgrad_bf16_kernel's own workgroup map)
     const float *gh;
     const float *bdata[WG_MAXB];
     int bwidth[WG_MAXB];
@@ -203,6 +206,148 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// weight gradient on the bf16 matrix pipe (r03): the same tile / slab / atomics skeleton, the products as six exact bf16 plane
+// products on v_mfma_f32_32x32x16_bf16 (both operands split by truncation into 8 + 8 + 8 mantissa bits; hh, hm, mh, mm, hl, lh --
+// the arithmetic of the forward bf16x6 kernels, chain_seg_bf16.hip: error of an fp32 FMA loop, any magnitude, no scales).  The
+// contraction runs over ROWS, so a lane's operand (8 consecutive k of one column) is a column segment of the row-major inputs:
+// the staging threads own one column and 8 rows, split while the values are in registers and write one 16-byte slot per plane
+// into a [column][row-half] LDS layout the MFMA lanes read back with one ds_read_b128 -- the transposition costs nothing.
+// 6 MFMAs of 8 passes per 16 rows and tile pair instead of 8 fp32 MFMAs of 16 passes: 2.7x less matrix time; LDS 48 KiB.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef unsigned wg_u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void wg_split3(float x, unsigned &h, unsigned &m, unsigned &l) {
+    h = __float_as_uint(x);
+    const float r1 = x - __uint_as_float(h & 0xffff0000u);
+    m = __float_as_uint(r1);
+    l = __float_as_uint(r1 - __uint_as_float(m & 0xffff0000u));
+}
+__device__ __forceinline__ unsigned wg_pack_hi(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+
+__global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradArgs a) {
+    __shared__ wg_u32x4 ta[2][3][WG_T][2];        // [buffer][plane][column][row half]: 8 bf16 = rows 8 h .. 8 h + 7 of the chunk
+    __shared__ wg_u32x4 tb[2][3][WG_T][2];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    // Workgroup -> (row slab, tile): the tn x tk tiles of ONE slab are consecutive workgroups of ONE XCD (the dispatcher deals
+    // workgroup ids round-robin over the 8 XCDs), so the slab's rows of gH and X -- read once per tile column / row -- come from
+    // that XCD's L2 after the first read instead of from HBM (tn = 5, tk = 3: 1.39 GB of reads -> 0.38 GB per d = 300 stage).
+    const int ntile = a.tn * a.tk;
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int tile = seq % ntile;
+    const int64_t slab = (int64_t)(seq / ntile) * 8 + xcd;
+    const int n0 = (tile / a.tk) * WG_T, k0 = (tile % a.tk) * WG_T;
+    const int64_t r_begin = slab * a.rows_per_wg;
+    int64_t r_end = r_begin + a.rows_per_wg;
+    if (r_end > a.m_rows) r_end = a.m_rows;
+    if (r_begin >= r_end) return;                 // (block-uniform)
+
+    const int sc = tid & 127, sh = tid >> 7;      // staging: column sc, rows 8 sh .. 8 sh + 7 of a 16-row chunk
+    const int ca = n0 + sc;
+    const bool ca_ok = ca < a.n_out;
+    const int kb = k0 + sc;
+    const bool kb_ok = kb < a.k_total;
+    const float *xb = a.bdata[0];
+    int xw = a.bwidth[0];
+    {
+        int blk = 0, col = kb_ok ? kb : 0;
+#pragma unroll
+        for (int b = 0; b < WG_MAXB - 1; ++b)
+            if (b < a.n_blocks - 1 && blk == b && col >= a.bwidth[b]) { col -= a.bwidth[b]; blk = b + 1; }
+#pragma unroll
+        for (int b = 1; b < WG_MAXB; ++b)
+            if (blk == b) { xb = a.bdata[b]; xw = a.bwidth[b]; }
+        xb += col;
+    }
+    const float *ga = a.gh + (ca_ok ? ca : 0);
+
+    f32x16b acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float pa[8], pb[8];
+    auto fetch = [&](int64_t row0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int64_t r = row0 + 8 * sh + i;
+            const int64_t rc = r < r_end ? r : r_begin;            // clamped: masked to zero when stored
+            pa[i] = ga[rc * a.n_out];
+            pb[i] = xb[rc * xw];
+        }
+    };
+    auto store_one = [&](wg_u32x4 (*dst)[WG_T][2], const float (&v)[8], bool col_ok, int64_t row0) {
+        unsigned h[8], m[8], l[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bool ok = col_ok && (row0 + 8 * sh + i < r_end);
+            wg_split3(ok ? v[i] : 0.f, h[i], m[i], l[i]);
+        }
+        wg_u32x4 ph, pm, pl;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ph[i] = wg_pack_hi(h[2 * i], h[2 * i + 1]);
+            pm[i] = wg_pack_hi(m[2 * i], m[2 * i + 1]);
+            pl[i] = wg_pack_hi(l[2 * i], l[2 * i + 1]);
+        }
+        dst[0][sc][sh] = ph;
+        dst[1][sc][sh] = pm;
+        dst[2][sc][sh] = pl;
+    };
+    fetch(r_begin);
+    store_one(ta[0], pa, ca_ok, r_begin);
+    store_one(tb[0], pb, kb_ok, r_begin);
+    __syncthreads();
+    int buf = 0;
+#define WG_MF(x, y, c) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wg_bf16x8, x), __builtin_bit_cast(wg_bf16x8, y), c, 0, 0, 0)
+    for (int64_t row0 = r_begin; row0 < r_end; row0 += 16) {
+        const bool has_next = row0 + 16 < r_end;
+        if (has_next) fetch(row0 + 16);
+        wg_u32x4 fa[2][3], fb[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                fa[i][pl] = ta[buf][pl][wm * 64 + i * 32 + li][lh];
+                fb[i][pl] = tb[buf][pl][wn * 64 + i * 32 + li][lh];
+            }
+        // small terms first (hl, lh, mm, hm, mh), hh last; the four accumulator tiles alternate so that no MFMA waits for its predecessor
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            const int pa_ = (t == 0) ? 0 : (t == 1) ? 2 : (t == 2) ? 1 : (t == 3) ? 0 : (t == 4) ? 1 : 0;
+            const int pb_ = (t == 0) ? 2 : (t == 1) ? 0 : (t == 2) ? 1 : (t == 3) ? 1 : (t == 4) ? 0 : 0;
+            WG_MF(fa[0][pa_], fb[0][pb_], acc[0][0]);
+            WG_MF(fa[0][pa_], fb[1][pb_], acc[0][1]);
+            WG_MF(fa[1][pa_], fb[0][pb_], acc[1][0]);
+            WG_MF(fa[1][pa_], fb[1][pb_], acc[1][1]);
+        }
+        if (has_next) {
+            store_one(ta[buf ^ 1], pa, ca_ok, row0 + 16);
+            store_one(tb[buf ^ 1], pb, kb_ok, row0 + 16);
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+#undef WG_MF
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int kcol = k0 + wn * 64 + j * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int nrow = n0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (nrow < a.n_out && kcol < a.k_total) atomicAdd(a.gw + (int64_t)nrow * a.k_total + kcol, acc[i][j][r]);
+            }
+        }
+}
+
 static int bgrid(int64_t m_rows) {
     int64_t b = (m_rows + 3) / 4;
     return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
@@ -254,8 +399,17 @@ extern "C" int gsn_wgrad_hip(int64_t m_rows, int64_t n_out, const float *grad_h,
     rows_per = (rows_per + WG_RB - 1) / WG_RB * WG_RB;
     a.rows_per_wg = rows_per;
     slabs = (m_rows + rows_per - 1) / rows_per;
-    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)slabs, (unsigned)tn, (unsigned)tk), dim3(256), 0,
-                       reinterpret_cast<hipStream_t>(stream), a);
+    // GSN_WGRAD_FP32=1: the fp32-MFMA kernel (v_mfma_f32_32x32x2_f32), for A/B runs
+    static const bool fp32_kernel = [] { const char *e = getenv("GSN_WGRAD_FP32"); return e && e[0] == '1'; }();
+    if (fp32_kernel)
+        hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)slabs, (unsigned)tn, (unsigned)tk), dim3(256), 0,
+                           reinterpret_cast<hipStream_t>(stream), a);
+    else {
+        a.tn = tn; a.tk = tk;
+        const int64_t slab_groups = (slabs + 7) / 8;
+        hipLaunchKernelGGL(wgrad_bf16_kernel, dim3((unsigned)(slab_groups * tn * tk * 8)), dim3(256), 0,
+                           reinterpret_cast<hipStream_t>(stream), a);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(GSN_E_HIP, "wgrad_kernel: %s", hipGetErrorString(e));
     return GSN_OK;
