@@ -369,6 +369,7 @@ struct PropBwdArgs {
     int b_per_node;
     int pad_b, pad_c;         // CAT: zero columns in front of b / c (no gradient)
     float *g_a, *g_b, *g_c;
+    const float *g_edge;      // RELU_SUM: the masked per-edge gradient the edge kernel has just written (g_c, or a per-edge g_b), or null
 };
 
 // per-edge gradients: g_b[e] (if per-edge) and g_c[e]; one row group per edge, scalar columns
@@ -411,14 +412,21 @@ __global__ __launch_bounds__(256) void propagate_bwd_node_kernel(PropBwdArgs p) 
             float acc = 0.f;
             for (int32_t q = lo; q < hi; ++q) {
                 const int64_t e = p.perm_src[q];
-                const int64_t t = p.tgt[e];
-                float g = p.g_out[t * p.d_out + col];
-                if (p.kind != GSN_MSG_CAT) {
-                    float pre = 0.f;
-                    if (p.a) pre += p.a[s * p.d_out + col];
-                    if (p.b) pre += p.b[(p.b_per_node ? s : e) * p.d_out + col];
-                    if (p.c) pre += p.c[e * p.d_out + col];
-                    g = pre > 0.f ? g : 0.f;
+                float g;
+                if (p.g_edge) {
+                    // relu-sum with a per-edge gradient already written by propagate_bwd_edge_kernel: that row IS relu'(pre) * g_out[t]
+                    // (one stream instead of the three forward inputs + the gathered g_out row)
+                    g = p.g_edge[e * p.d_out + col];
+                } else {
+                    const int64_t t = p.tgt[e];
+                    g = p.g_out[t * p.d_out + col];
+                    if (p.kind != GSN_MSG_CAT) {
+                        float pre = 0.f;
+                        if (p.a) pre += p.a[s * p.d_out + col];
+                        if (p.b) pre += p.b[(p.b_per_node ? s : e) * p.d_out + col];
+                        if (p.c) pre += p.c[e * p.d_out + col];
+                        g = pre > 0.f ? g : 0.f;
+                    }
                 }
                 acc += g;
             }
@@ -429,6 +437,73 @@ __global__ __launch_bounds__(256) void propagate_bwd_node_kernel(PropBwdArgs p) 
                 if (p.g_a) p.g_a[s * p.d_out + col] = acc;
                 if (p.b_per_node && p.g_b) p.g_b[s * p.d_out + col] = acc;
             }
+        }
+    }
+}
+
+// adjoint of the self term  out[t] += (1 + eps) * self[t]:  g_self_k = (1 + eps) * (columns of g_out) for per-node blocks, the column
+// sums of (1 + eps) * g_out for single-row blocks (fp64, the host slices them), g_eps = sum g_out . self (fp64).  One pass over g_out;
+// lane = column, waves stride over rows (the layout of bn_act_bwd_reduce_kernel).
+struct SelfBwdArgs {
+    int kind;
+    int64_t n_nodes;
+    int d_out, n_self;
+    const float *g_out;
+    const float *self_data[3];
+    int self_w[3];
+    int64_t self_stride[3];
+    float *g_self[3];
+    const float *eps;
+    double *g_eps, *g_colsum;
+};
+
+__global__ __launch_bounds__(256) void propagate_self_bwd_kernel(SelfBwdArgs p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + lane;
+    const bool cok = c < p.d_out;
+    const float sc = 1.f + (p.eps ? *p.eps : 0.f);
+    // CAT: the block this column belongs to and the offset inside it
+    int kb = 0, o = c;
+    if (p.kind == GSN_MSG_CAT) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            if (k < p.n_self - 1 && kb == k && o >= p.self_w[k]) { o -= p.self_w[k]; kb = k + 1; }
+    }
+    double se = 0.0, scol = 0.0;
+    if (cok) {
+        for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < p.n_nodes; t += (int64_t)gridDim.x * 4) {
+            const float g = p.g_out[t * p.d_out + c];
+            const float gs = g * sc;
+            float sv = 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                if (k < p.n_self) {
+                    if (p.kind == GSN_MSG_CAT) {
+                        if (k == kb) {
+                            sv = p.self_data[k][t * p.self_stride[k] + o];
+                            if (p.g_self[k]) p.g_self[k][t * p.self_w[k] + o] = gs;
+                        }
+                    } else {
+                        sv += p.self_data[k][t * p.self_stride[k] + c];
+                        if (p.g_self[k]) p.g_self[k][t * p.d_out + c] = gs;
+                    }
+                }
+            }
+            se += (double)g * (double)sv;
+            scol += (double)gs;
+        }
+    }
+    __shared__ double red[2][4][64];
+    red[0][wave][lane] = se;
+    red[1][wave][lane] = scol;
+    __syncthreads();
+    if (wave == 0) {
+        double a = red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane];
+        const double b = red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane];
+        if (p.g_colsum && cok) atomicAdd(&p.g_colsum[c], b);
+        if (p.g_eps) {
+            for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off);
+            if (lane == 0) atomicAdd(p.g_eps, a);
         }
     }
 }
@@ -818,6 +893,7 @@ extern "C" int gsn_propagate_pad_bwd_hip(int kind, int64_t n_nodes, int64_t n_ed
         hipLaunchKernelGGL(propagate_bwd_edge_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
     }
     const bool need_node = (g_a && da) || (g_b && b_per_node && db);
+    if (kind == GSN_MSG_RELU_SUM && need_edge && n_edges > 0) p.g_edge = (g_c && dc) ? g_c : g_b;
     if (need_node) {
         if (!seg_ptr_src || (n_edges > 0 && !perm_src)) return set_error(GSN_E_INVALID, "gsn_propagate_bwd_hip: source CSR missing");
         int64_t blocks = (n_nodes + 3) / 4;
@@ -825,6 +901,35 @@ extern "C" int gsn_propagate_pad_bwd_hip(int kind, int64_t n_nodes, int64_t n_ed
         hipLaunchKernelGGL(propagate_bwd_node_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
     }
     return hip_check("gsn_propagate_bwd_hip");
+}
+
+extern "C" int gsn_propagate_self_bwd_hip(int kind, int64_t n_nodes, int64_t d_out, const float *g_out, int n_self,
+                                          const gsn_self_block *self_blocks, float *const *g_self, const float *eps, double *g_eps,
+                                          double *g_colsum, void *stream) {
+    if (kind != GSN_MSG_CAT && kind != GSN_MSG_RELU_SUM) return set_error(GSN_E_INVALID, "gsn_propagate_self_bwd_hip: unknown kind %d", kind);
+    if (n_self < 1 || n_self > 3 || !self_blocks || !g_out || d_out < 1 || d_out > 1024)
+        return set_error(GSN_E_INVALID, "gsn_propagate_self_bwd_hip: bad arguments");
+    SelfBwdArgs p{};
+    p.kind = kind; p.n_nodes = n_nodes; p.d_out = (int)d_out; p.n_self = n_self; p.g_out = g_out; p.eps = eps; p.g_eps = g_eps; p.g_colsum = g_colsum;
+    int64_t sum = 0;
+    for (int k = 0; k < n_self; ++k) {
+        if (!self_blocks[k].data || self_blocks[k].width <= 0 || self_blocks[k].row_stride < 0)
+            return set_error(GSN_E_INVALID, "gsn_propagate_self_bwd_hip: self block %d is empty", k);
+        if (kind == GSN_MSG_RELU_SUM && self_blocks[k].width != d_out)
+            return set_error(GSN_E_INVALID, "gsn_propagate_self_bwd_hip: self block %d: width %lld, expected %lld", k,
+                             (long long)self_blocks[k].width, (long long)d_out);
+        p.self_data[k] = self_blocks[k].data; p.self_w[k] = (int)self_blocks[k].width; p.self_stride[k] = self_blocks[k].row_stride;
+        p.g_self[k] = g_self ? g_self[k] : nullptr;
+        sum += self_blocks[k].width;
+    }
+    if (kind == GSN_MSG_CAT && sum != d_out)
+        return set_error(GSN_E_INVALID, "gsn_propagate_self_bwd_hip: self blocks are %lld columns wide, g_out %lld", (long long)sum, (long long)d_out);
+    if (n_nodes <= 0) return GSN_OK;
+    int64_t bx = (n_nodes + 3) / 4;
+    if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(propagate_self_bwd_kernel, dim3((unsigned)bx, (unsigned)((d_out + 63) / 64)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), p);
+    return hip_check("propagate_self_bwd_kernel");
 }
 
 extern "C" int gsn_csr_build_graphs_hip(int64_t n_graphs, const int64_t *node_ptr, const int64_t *edge_ptr, int64_t n_nodes,

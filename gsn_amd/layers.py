@@ -415,11 +415,12 @@ class _PropagateFn(torch.autograd.Function):
         # the source-sorted CSR is only needed for per-node gradients (g_a, per-node g_b)
         need_node = (need[0] and wa) or (need[1] and wb and ctx.b_per_node)
         csr_s = _csr_for(ei, 1 - sel, n) if need_node else None
-        g_a = torch.zeros((n, wa), dtype=torch.float32, device=dev) if (need[0] and wa) else None
+        # (every element of the three is written by the kernels: no zero fill)
+        g_a = torch.empty((n, wa), dtype=torch.float32, device=dev) if (need[0] and wa) else None
         g_b = None
         if need[1] and wb:
-            g_b = torch.zeros((n if ctx.b_per_node else E, wb), dtype=torch.float32, device=dev)
-        g_c = torch.zeros((E, wc), dtype=torch.float32, device=dev) if (need[2] and wc) else None
+            g_b = torch.empty((n if ctx.b_per_node else E, wb), dtype=torch.float32, device=dev)
+        g_c = torch.empty((E, wc), dtype=torch.float32, device=dev) if (need[2] and wc) else None
         if g_a is not None or g_b is not None or g_c is not None:
             with _abi.device_guard(dev):
                 rc = _abi.lib().gsn_propagate_pad_bwd_hip(ctx.kind, n, E, src.data_ptr() if E else None, tgt.data_ptr() if E else None,
@@ -429,27 +430,36 @@ class _PropagateFn(torch.autograd.Function):
                                                           ctx.pads[0], ctx.pads[1], g_out.data_ptr(), _abi.ptr(g_a), _abi.ptr(g_b),
                                                           _abi.ptr(g_c), _abi.current_stream())
             _abi.check(rc, "gsn_propagate_pad_bwd_hip")
-        # the self term (1 + eps) * self: a column slice of g_out per block (a few elementwise ops over N rows, backward only)
-        g_eps, g_selfs = None, []
-        if ctx.n_self:
-            sc = (1.0 + eps32[0]) if ctx.has_eps else 1.0
-            want_eps = ctx.has_eps and ctx.needs_input_grad[9]
-            acc, o = None, 0
+        # the self term (1 + eps) * self: one pass over g_out (gsn_propagate_self_bwd_hip)
+        g_eps, g_selfs = None, [None] * ctx.n_self
+        want_eps = ctx.has_eps and ctx.needs_input_grad[9]
+        want_self = [bool(ctx.needs_input_grad[10 + k]) for k in range(ctx.n_self)]
+        if ctx.n_self and (want_eps or any(want_self)):
+            d_out = g_out.shape[1]
+            single = [t.shape[0] == 1 and n != 1 for t in ss]
+            arr = (_abi.gsn_self_block * ctx.n_self)()
+            gptr = (_abi.c_vp * ctx.n_self)()
+            for k, t in enumerate(ss):
+                arr[k].data = t.data_ptr(); arr[k].width = t.shape[1]; arr[k].row_stride = 0 if single[k] else t.shape[1]
+                if want_self[k] and not single[k]:
+                    g_selfs[k] = torch.empty((n, t.shape[1]), dtype=torch.float32, device=dev)
+                gptr[k] = None if g_selfs[k] is None else g_selfs[k].data_ptr()
+            need_col = any(w and sg for w, sg in zip(want_self, single))
+            acc = torch.zeros(1 + (d_out if need_col else 0), dtype=torch.float64, device=dev)
+            with _abi.device_guard(dev):
+                rc = _abi.lib().gsn_propagate_self_bwd_hip(ctx.kind, n, d_out, g_out.data_ptr(), ctx.n_self, arr, gptr,
+                                                           eps32.data_ptr() if ctx.has_eps else None, acc.data_ptr() if want_eps else None,
+                                                           acc.data_ptr() + 8 if need_col else None, _abi.current_stream())
+            _abi.check(rc, "gsn_propagate_self_bwd_hip")
+            if want_eps:
+                g_eps = acc[0].to(torch.float32).reshape(ctx.eps_shape)
+            o = 0
             for k, t in enumerate(ss):
                 w = t.shape[1]
-                gk = g_out[:, o:o + w] if ctx.kind == 0 else g_out
-                if ctx.needs_input_grad[10 + k]:
-                    gs = gk * sc
-                    g_selfs.append(gs.sum(0, keepdim=True) if (t.shape[0] == 1 and n != 1) else gs)
-                else:
-                    g_selfs.append(None)
-                if want_eps:
-                    term = (gk.to(torch.float64) * t).sum()
-                    acc = term if acc is None else acc + term
+                if want_self[k] and single[k]:
+                    g_selfs[k] = (acc[1 + o:1 + o + w] if ctx.kind == 0 else acc[1:1 + d_out]).to(torch.float32).reshape(1, w)
                 if ctx.kind == 0:
                     o += w
-            if want_eps:
-                g_eps = acc.to(torch.float32).reshape(ctx.eps_shape)
         return (None, None, None, None, None, g_a, g_b, g_c, None, g_eps) + tuple(g_selfs)
 
 

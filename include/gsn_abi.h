@@ -188,8 +188,8 @@ int gsn_propagate_bwd_hip(int kind, int64_t n_nodes, int64_t n_edges, const int6
  * in floats, 0 = ONE row for every vertex (central_encoder's constant value, utils_graph_learning.py:232-260).  eps: device pointer
  * to the layer's eps (parameter or buffer), NULL = 0.  pad_b / pad_c: zero columns in front of the per-edge blocks b / c of a
  * concatenation (utils_graph_learning.py:240-242: the extra first column of an extended one-hot encoding), so that
- * d_out = da + pad_b + db + pad_c + dc.  gsn_propagate_pad_bwd_hip: the adjoint with the same column layout (the self term's adjoint is
- * a column slice of g_out times (1 + eps): host side).
+ * d_out = da + pad_b + db + pad_c + dc.  gsn_propagate_pad_bwd_hip: the adjoint of the messages with the same column layout;
+ * gsn_propagate_self_bwd_hip: the adjoint of the self term.
  */
 typedef struct gsn_self_block {
     const float *data;
@@ -201,6 +201,13 @@ int gsn_propagate_self_fwd_hip(int kind, int64_t n_nodes, int64_t n_edges, const
                                const int32_t *perm, const int32_t *sorted_src, const float *a, int64_t da, const float *b, int64_t db,
                                int b_per_node, const float *c, int64_t dc, int64_t pad_b, int64_t pad_c, int n_self,
                                const gsn_self_block *self_blocks, const float *eps, float *out, void *stream);
+
+/* Adjoint of the self term (one pass over g_out [N][d_out]): g_self[k] (fp32 [N][width_k], NULL = not wanted / single-row block)
+ * receives (1 + eps) * the block's columns of g_out; g_colsum (fp64 [d_out], zero-filled, may be NULL) the column sums of
+ * (1 + eps) * g_out -- the gradient of a single-row block is its slice; g_eps (fp64 [1], zero-filled, may be NULL) sum g_out . self. */
+int gsn_propagate_self_bwd_hip(int kind, int64_t n_nodes, int64_t d_out, const float *g_out, int n_self,
+                               const gsn_self_block *self_blocks, float *const *g_self, const float *eps, double *g_eps,
+                               double *g_colsum, void *stream);
 
 int gsn_propagate_pad_bwd_hip(int kind, int64_t n_nodes, int64_t n_edges, const int64_t *src, const int64_t *tgt,
                               const int32_t *seg_ptr_src, const int32_t *perm_src, const float *a, int64_t da,
