@@ -69,6 +69,7 @@ SIGNATURES = {
                                       c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "gsn_propagate_self_fwd_hip": (c_int, [c_int, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_vp,
                                            c_i64, c_i64, c_i64, c_int, ctypes.POINTER(gsn_self_block), c_vp, c_vp, c_vp]),
+    "gsn_add_gathered_hip": (c_int, [c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
     "gsn_propagate_self_bwd_hip": (c_int, [c_int, c_i64, c_i64, c_vp, c_int, ctypes.POINTER(gsn_self_block), ctypes.POINTER(c_vp), c_vp, c_vp,
                                            c_vp, c_vp]),
     "gsn_propagate_pad_bwd_hip": (c_int, [c_int, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_int,

@@ -622,6 +622,48 @@ __global__ __launch_bounds__(256) void gather_cat_kernel(GatherCatArgs a) {
 }
 }  // namespace gsn
 
+// out[r] = x[r] + table[idx[r]]: the virtual node's embedding added to every vertex of its graph
+// (models_graph_classification_ogb_original.py:236: x + vn_embedding[data.batch]) -- gather and add in one pass; a row whose index
+// is outside the table comes out NaN (the reference raises an index error).
+namespace gsn {
+template <int VEC>
+__global__ __launch_bounds__(256) void add_gathered_kernel(int64_t n_rows, int d, const float *__restrict__ x, const float *__restrict__ table,
+                                                           const int64_t *__restrict__ idx, int64_t n_table, float *__restrict__ out) {
+    const int per_row = d / VEC;
+    const int64_t total = n_rows * per_row;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / per_row;
+        const int c = (int)(i - r * per_row) * VEC;
+        const int64_t g = idx[r];
+        const bool ok = g >= 0 && g < n_table;
+        if (VEC == 4) {
+            const float4 a = *reinterpret_cast<const float4 *>(x + r * d + c);
+            float4 b = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
+            if (ok) b = *reinterpret_cast<const float4 *>(table + g * d + c);
+            *reinterpret_cast<float4 *>(out + r * d + c) = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+        } else {
+            out[r * d + c] = x[r * d + c] + (ok ? table[g * d + c] : __builtin_nanf(""));
+        }
+    }
+}
+}  // namespace gsn
+
+extern "C" int gsn_add_gathered_hip(int64_t n_rows, int64_t d, const float *x, const float *table, const int64_t *idx, int64_t n_table,
+                                    float *out, void *stream) {
+    if (d < 1 || n_table < 0 || (n_rows > 0 && (!x || !table || !idx || !out))) return set_error(GSN_E_INVALID, "gsn_add_gathered_hip: bad arguments");
+    if (n_rows <= 0) return GSN_OK;
+    const bool v4 = d % 4 == 0 && (((uintptr_t)x | (uintptr_t)table | (uintptr_t)out) % 16 == 0);
+    const int64_t total = n_rows * (v4 ? d / 4 : d);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (v4) hipLaunchKernelGGL((gsn::add_gathered_kernel<4>), dim3((unsigned)blocks), dim3(256), 0, s, n_rows, (int)d, x, table, idx, n_table, out);
+    else hipLaunchKernelGGL((gsn::add_gathered_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, s, n_rows, (int)d, x, table, idx, n_table, out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(GSN_E_HIP, "add_gathered_kernel: %s", hipGetErrorString(e));
+    return GSN_OK;
+}
+
 extern "C" int gsn_gather_cat_hip(int64_t m_rows, int n_blocks, const gsn_block *blocks, float *out, void *stream) {
     if (n_blocks < 1 || n_blocks > GC_MAXB || !blocks || (m_rows > 0 && !out)) return set_error(GSN_E_INVALID, "gsn_gather_cat_hip: bad arguments");
     GatherCatArgs a{};

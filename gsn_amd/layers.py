@@ -330,6 +330,40 @@ def global_add_pool_sparse(x, batch, num_graphs=None):
     return propagate(0, ei, 1, g, b=x)
 
 
+class _AddByGraphFn(torch.autograd.Function):
+    """x + table[batch] in one pass (gsn_add_gathered_hip); adjoint: identity for x, the sum readout for the table."""
+
+    @staticmethod
+    def forward(ctx, x, table, batch):
+        xs, ts = _f32c(x), _f32c(table)
+        idx = batch.to(torch.int64).contiguous()
+        out = torch.empty_like(xs)
+        with _abi.device_guard(xs.device), _timed("add_gathered", 12.0 * xs.numel()):
+            rc = _abi.lib().gsn_add_gathered_hip(xs.shape[0], xs.shape[1], xs.data_ptr() if xs.numel() else None, _abi.ptr(ts),
+                                                 idx.data_ptr() if idx.numel() else None, ts.shape[0], out.data_ptr() if out.numel() else None,
+                                                 _abi.current_stream())
+        _abi.check(rc, "gsn_add_gathered_hip")
+        ctx.batch, ctx.n_table = batch, ts.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g_table = None
+        if ctx.needs_input_grad[1]:
+            with torch.no_grad():
+                g_table = global_add_pool_sparse(g, ctx.batch, ctx.n_table)
+        return (g if ctx.needs_input_grad[0] else None), g_table, None
+
+
+def add_by_graph(x, table, batch):
+    """``x + table[batch]`` (models_graph_classification_ogb_original.py:236: the virtual node's embedding joins every vertex of its
+    graph) as one kernel, with the readout kernel as the adjoint of the gather."""
+    _need_cuda(x, "x")
+    if x.dim() != 2 or table.dim() != 2 or x.shape[1] != table.shape[1] or batch.numel() != x.shape[0]:
+        return x + table[batch]            # (shapes the reference would broadcast or reject: its own expression)
+    return _AddByGraphFn.apply(x, table, batch)
+
+
 def global_mean_pool_sparse(x, batch, num_graphs=None):
     """Mean readout (utils_graph_learning.py:32-41): sum readout divided by the graph sizes (empty graphs divide by 1)."""
     s = global_add_pool_sparse(x, batch, num_graphs)
@@ -1019,18 +1053,26 @@ class _DenseStagesFn(torch.autograd.Function):
         grads = [None] * len(tensors)
         dev = gy.device
         g = gy.to(torch.float32).contiguous()
+        # every zero-initialised accumulator of this backward from two arenas (one fill each instead of three small fills per stage)
+        n64 = sum(3 * ent["w"].shape[0] for ent in per)
+        n32 = sum(ent["w"].numel() for si, ent in enumerate(per) if ctx.needs_input_grad[1 + ent["w_i"]])
+        z64 = torch.zeros(n64, dtype=torch.float64, device=dev)
+        z32 = torch.zeros(n32, dtype=torch.float32, device=dev)
+        o64 = o32 = 0
         for si in range(len(spec) - 1, -1, -1):
             sp, ent = spec[si], per[si]
             kind, off = meta[si]
             w = ent["w"]
             n_out, k_total = w.shape
-            gbias = torch.zeros(n_out, dtype=torch.float64, device=dev)
+            gbias = z64[o64:o64 + n_out]
+            sums_z = z64[o64 + n_out:o64 + 3 * n_out].view(2, n_out)
+            o64 += 3 * n_out
             gh = torch.empty((m_rows, n_out), dtype=torch.float32, device=dev)
             act = _ACT_CODE[sp["act"]]
             with _abi.device_guard(dev), _timed("bn_act_bwd", 16.0 * m_rows * n_out):
                 if kind in ("bn", "bn_eval"):
                     h, y, mean32, invstd, scale = saved[off:off + 5]
-                    sums = torch.zeros((2, n_out), dtype=torch.float64, device=dev)
+                    sums = sums_z
                     rc = L.gsn_bn_act_bwd_hip(m_rows, n_out, g.data_ptr(), y.data_ptr(), h.data_ptr(), mean32.data_ptr(),
                                               invstd.data_ptr(), scale.data_ptr(), 1 if kind == "bn" else 2, act, sums.data_ptr(),
                                               gh.data_ptr(), gbias.data_ptr(), _abi.current_stream())
@@ -1053,7 +1095,8 @@ class _DenseStagesFn(torch.autograd.Function):
             # weight gradient
             xin = blocks0 if si == 0 else [saved[meta[si - 1][1] + (1 if meta[si - 1][0] in ("bn", "bn_eval") else 0)]]
             if ctx.needs_input_grad[1 + ent["w_i"]]:
-                gw = torch.zeros((n_out, k_total), dtype=torch.float32, device=dev)
+                gw = z32[o32:o32 + n_out * k_total].view(n_out, k_total)
+                o32 += n_out * k_total
                 arr = (_abi.gsn_block * len(xin))()
                 keep = []
                 for bi, t in enumerate(xin):

@@ -17,7 +17,7 @@ import torch.nn.functional as F
 from . import layers
 from .encoding import DiscreteEmbedding
 from .layers import (GSN_edge_sparse, GSN_edge_sparse_ogb, GSN_sparse, MPNN_edge_sparse, MPNN_edge_sparse_ogb, MPNN_sparse,
-                     choose_activation, global_add_pool_sparse, global_mean_pool_sparse, mlp, run_linear_module)
+                     add_by_graph, choose_activation, global_add_pool_sparse, global_mean_pool_sparse, mlp, run_linear_module)
 
 
 def _register_partition(data, edge_index):
@@ -279,7 +279,7 @@ class GNN_OGB(nn.Module):
             kwargs["identifiers"] = _encode_once(memo, self.id_encoder[i] if self.inject_ids else self.id_encoder[0], data.identifiers, self.training)
             kwargs["edge_features"] = _encode_once(memo, self.edge_encoder[i], data.edge_features, self.training) if hasattr(data, "edge_features") else None
             if self.vn:
-                x_interm[i] = x_interm[i] + vn_embedding[data.batch]
+                x_interm[i] = add_by_graph(x_interm[i], vn_embedding, data.batch)
             last = i == n_layers - 1
             # BatchNorm1d (+ activation on all but the last layer) fused into the layer's last stage (:241-246)
             x = self.conv[i](x_interm[i], edge_index, post_bn=self.batch_norms[i] if self.bn[i] else None,

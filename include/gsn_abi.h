@@ -503,6 +503,12 @@ int gsn_wgrad_hip(int64_t m_rows, int64_t n_out, const float *grad_h, int n_bloc
  * ---------------------------------------------------------------------------------------------------------------- */
 int gsn_gather_cat_hip(int64_t m_rows, int n_blocks, const gsn_block *blocks, float *out, void *stream);
 
+/* out[r] = x[r] + table[idx[r]]  (device; fp32 [M][d], table [T][d], idx int64 [M]): the virtual-node embedding added to the vertices of
+ * its graph, models_graph_classification_ogb_original.py:236 `x + vn_embedding[data.batch]`, in one pass.  A row whose index lies
+ * outside [0, T) comes out NaN.  Adjoint: grad x = grad out; grad table = the sum readout of grad out (gsn_propagate_fwd_hip). */
+int gsn_add_gathered_hip(int64_t n_rows, int64_t d, const float *x, const float *table, const int64_t *idx, int64_t n_table, float *out,
+                         void *stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Train-mode BatchNorm1d bookkeeping (device), what nn.BatchNorm1d does around the normalisation (models_misc.py:41-45):
  * stats fp64 [2][C] = column sum and sum of squares of the M pre-BN rows ->  mean, invstd = 1/sqrt(biased var + eps),
