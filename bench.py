@@ -387,6 +387,41 @@ def wide_layer(b, ei, dev):
             "note": "row-exponent pass + layer_fused_kernel_w, HIP events around both"}
 
 
+def train_step_config4(dev):
+    """BASELINE configs[3] (ogbg-molhiv GSN-e TRAINING): one optimisation step of the 5 x 300 virtual-node model on 4096 molhiv-shaped
+    graphs -- forward, backward (HIP adjoints), gradient bucket, SGD (scripts/train_step_molhiv.py; supplementary, never `value`)."""
+    import importlib.util
+    import types
+    spec = importlib.util.spec_from_file_location("train_step_molhiv", os.path.join(os.path.dirname(os.path.abspath(__file__)), "scripts", "train_step_molhiv.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    r = mod.run(types.SimpleNamespace(batch=4096, steps=5, warmup=2, layers=5, d=300), dev)
+    return {"graphs": 4096, "ms_per_step": r["ms_per_step"], "graphs_per_s": r["graphs_per_s"], "parameters": r["parameters"], "workload": r["workload"]}
+
+
+def linear_d300(dev):
+    """The d = 300 node-level dense stage of the ogb layers (196 608 x 300 -> 600, gsn_linear_f16x3_fwd_hip incl. its row pre-pass) against
+    the roofs of the pipe it uses: 2.5 PF/s fp16 / 3 plane products = 833 TF/s fp32-equivalent, and 8 TB/s on its algorithmic bytes."""
+    M, K, Nn = 196608, 300, 600
+    x = torch.randn(M, K, device=dev)
+    W = torch.randn(Nn, K, device=dev) / K ** 0.5
+    bb = torch.randn(Nn, device=dev)
+    st = layers._Stage(W, bb, None, "relu", [(x, None)])
+    for _ in range(3):
+        layers._launch_stages([st], M)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        layers._launch_stages([st], M)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    tf = 2.0 * M * K * Nn / ms / 1e9
+    b_alg = 4.0 * (M * K + M * Nn + Nn * K)
+    return {"shape": [M, K, Nn], "ms": round(ms, 4), "fp32_equivalent_TFLOPs": round(tf, 1), "frac_of_fp16x3_roof_833TF": round(tf / (MFMA_BF16_PEAK_TF / 3.0), 4),
+            "algorithmic_bytes": round(b_alg), "hbm_frac": round(b_alg / (ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -624,7 +659,7 @@ def main():
                    "note": "BASELINE configs[1] dataset size: 12 000 ZINC-shaped graphs per step (N=%d, E=%d)" % (b2.num_nodes, b2.num_edges)}
 
     # Supplementary (never `value`): the reference's real batch sizes, the stand-alone aggregation stage, the layer on real-valued inputs
-    small = prop = flt = wide = None
+    small = prop = flt = wide = train4 = lin300 = None
     if world == 1 and not args.no_extras:
         try:
             small = small_batch_steps(plan, layer, dev)
@@ -642,6 +677,14 @@ def main():
             wide = wide_layer(b, ei, dev)
         except Exception as ex:
             wide = {"error": str(ex)[:200]}
+        try:
+            train4 = train_step_config4(dev)
+        except Exception as ex:
+            train4 = {"error": str(ex)[:200]}
+        try:
+            lin300 = linear_d300(dev)
+        except Exception as ex:
+            lin300 = {"error": str(ex)[:200]}
     # every rank's own time of the K steps (the headline takes the maximum): a slow rank shows up by name in the N > 1 line
     per_rank_ms = [round(dt_own / args.steps * 1e3, 4)]
     if dist is not None and world > 1:
@@ -771,6 +814,10 @@ def main():
             extra["layer_float_inputs"] = flt
         if wide is not None:
             extra["layer_wide_d128"] = wide
+        if train4 is not None:
+            extra["train_step_config4"] = train4
+        if lin300 is not None:
+            extra["linear_f16x3_d300"] = lin300
         extra["ms_per_step_by_rank"] = per_rank_ms
         extra["prewarm_steps_untimed"] = int(os.environ.get("GSN_BENCH_PREWARM", "60"))
         if model4 is not None:

@@ -58,6 +58,16 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    res = run(args, dev, dist, rank, world)
+    if rank == 0:
+        print(json.dumps(res))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def run(args, dev, dist=None, rank=0, world=1):
+    """The timed training steps; returns the result line as a dict (bench.py's supplementary `train_step_config4` calls this with
+    ``types.SimpleNamespace(batch=4096, steps=5, warmup=2, layers=5, d=300)``)."""
     data, d_id, N, E = make_data(args.batch, 100 + rank, dev)
     L, dm = args.layers, args.d
     kw = dict(seed=0, model_name="GSN_edge_sparse_ogb", readout="mean", dropout_features=[0.5] * (L + 1), bn=[True] * L,
@@ -99,14 +109,11 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    if rank == 0:
-        print(json.dumps({"workload": "molhiv-shaped GNN_OGB training step (%d layers, d=%d, vn), batch %d graphs/GPU (N=%d, E=%d)" % (L, dm, args.batch, N, E),
-                          "n_gpus": world, "graphs_per_s": round(world * args.batch * args.steps / dt, 1),
-                          "ms_per_step": round(dt / args.steps * 1e3, 3), "parameters": n_params,
-                          "grad_bucket_MB": round(n_params * 4 / 1e6, 2), "loss": float(loss.item()),
-                          "note": "forward and backward on HIP kernels (native adjoints of every stage, DESIGN.md 4); SGD update and glue in PyTorch"}))
-    if dist is not None:
-        dist.destroy_process_group()
+    return {"workload": "molhiv-shaped GNN_OGB training step (%d layers, d=%d, vn), batch %d graphs/GPU (N=%d, E=%d)" % (L, dm, args.batch, N, E),
+            "n_gpus": world, "graphs_per_s": round(world * args.batch * args.steps / dt, 1),
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "parameters": n_params,
+            "grad_bucket_MB": round(n_params * 4 / 1e6, 2), "loss": float(loss.item()),
+            "note": "forward and backward on HIP kernels (native adjoints of every stage, DESIGN.md 4); SGD update and glue in PyTorch"}
 
 
 if __name__ == "__main__":
