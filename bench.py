@@ -402,6 +402,8 @@ def train_step_config4(dev):
 def linear_d300(dev):
     """The d = 300 node-level dense stage of the ogb layers (196 608 x 300 -> 600, gsn_linear_f16x3_fwd_hip incl. its row pre-pass) against
     the roofs of the pipe it uses: 2.5 PF/s fp16 / 3 plane products = 833 TF/s fp32-equivalent, and 8 TB/s on its algorithmic bytes."""
+    import torch
+    from gsn_amd import layers
     M, K, Nn = 196608, 300, 600
     x = torch.randn(M, K, device=dev)
     W = torch.randn(Nn, K, device=dev) / K ** 0.5

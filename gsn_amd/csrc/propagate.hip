@@ -280,7 +280,8 @@ __device__ __forceinline__ void vzero(float4 &x) { x = make_float4(0.f, 0.f, 0.f
 // vertex comes from the segment-ordered copy the CSR build writes (one dependent load less than src[perm[q]]).
 // (Taking the edges of a segment four at a time with all row loads in flight together was measured and is no faster:
 // the kernel is limited by DRAM efficiency on 512-byte gathers, not by load latency.)
-template <int VEC, int LPR, int MAXC>
+// EXT: the layer's own term and / or zero columns (gsn_propagate_self_fwd_hip); the plain kernel is compiled without either
+template <int VEC, int LPR, int MAXC, bool EXT>
 __global__ __launch_bounds__(256) void propagate_fwd_kernel(PropArgs p) {
     using V = typename VecT<VEC>::type;
     constexpr int RPW = 64 / LPR;  // rows (targets) per wave
@@ -305,13 +306,14 @@ __global__ __launch_bounds__(256) void propagate_fwd_kernel(PropArgs p) {
                     V m;
                     if (p.kind == GSN_MSG_CAT) {
                         // column layout: a | pad_b zeros | b | pad_c zeros | c      (pads only on the scalar path, VEC == 1)
+                        constexpr bool PADS = EXT && VEC == 1;
                         int o = col - p.da;
                         if (o < 0) m = *reinterpret_cast<const V *>(p.a + s * p.da + col);
-                        else if (VEC == 1 && o < p.pad_b) vzero(m);
-                        else if ((o -= (VEC == 1 ? p.pad_b : 0)) < p.db)
+                        else if (PADS && o < p.pad_b) vzero(m);
+                        else if ((o -= (PADS ? p.pad_b : 0)) < p.db)
                             m = p.b_per_node ? *reinterpret_cast<const V *>(p.b + s * p.db + o) : vload_once(reinterpret_cast<const V *>(p.b + e * p.db + o));
-                        else if (VEC == 1 && (o - p.db) < p.pad_c) vzero(m);
-                        else m = vload_once(reinterpret_cast<const V *>(p.c + e * p.dc + (o - p.db - (VEC == 1 ? p.pad_c : 0))));
+                        else if (PADS && (o - p.db) < p.pad_c) vzero(m);
+                        else m = vload_once(reinterpret_cast<const V *>(p.c + e * p.dc + (o - p.db - (PADS ? p.pad_c : 0))));
                     } else {
                         vzero(m);
                         if (p.a) m = vadd(m, *reinterpret_cast<const V *>(p.a + s * p.d_out + col));
@@ -324,7 +326,7 @@ __global__ __launch_bounds__(256) void propagate_fwd_kernel(PropArgs p) {
                 }
             }
         }
-        if (p.n_self) {
+        if (EXT && p.n_self) {
             const float sc = 1.f + (p.eps ? *p.eps : 0.f);
 #pragma unroll
             for (int i = 0; i < MAXC; ++i) {
@@ -522,7 +524,8 @@ static int launch_fwd(const PropArgs &p, hipStream_t st) {
     const int64_t cap = 256 * 8 * 4;  // enough workgroups to fill 256 CUs several times; grid-stride beyond
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((propagate_fwd_kernel<VEC, LPR, MAXC>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+    if (p.n_self || p.pad_b || p.pad_c) hipLaunchKernelGGL((propagate_fwd_kernel<VEC, LPR, MAXC, true>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((propagate_fwd_kernel<VEC, LPR, MAXC, false>), dim3((unsigned)blocks), dim3(256), 0, st, p);
     return hip_check("propagate_fwd_kernel");
 }
 
