@@ -402,6 +402,36 @@ __global__ __launch_bounds__(256) void propagate_bwd_edge_kernel(PropBwdArgs p) 
     }
 }
 
+// the same for relu-sum messages whose width is a multiple of four floats (the d = 300 ogb layers): a row group of 16 lanes per edge,
+// float4 columns, the edge's two indices read once per group instead of once per element (r03: 500 -> ~330 us at E = 214 k, d = 300)
+__global__ __launch_bounds__(256) void propagate_bwd_edge_relu4_kernel(PropBwdArgs p) {
+    const int lane = threadIdx.x & 63, sub = lane >> 4, li = lane & 15;
+    const int q = p.d_out >> 2;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t e0 = wave * 4; e0 < p.n_edges; e0 += n_waves * 4) {
+        const int64_t e = e0 + sub;
+        if (e >= p.n_edges) continue;
+        const int64_t t = p.tgt[e], s = p.src[e];
+        const float4 *go = reinterpret_cast<const float4 *>(p.g_out + t * p.d_out);
+        const float4 *pa = p.a ? reinterpret_cast<const float4 *>(p.a + s * p.d_out) : nullptr;
+        const float4 *pb = p.b ? reinterpret_cast<const float4 *>(p.b + (p.b_per_node ? s : e) * p.d_out) : nullptr;
+        const float4 *pc = p.c ? reinterpret_cast<const float4 *>(p.c + e * p.d_out) : nullptr;
+        float4 *gb = (!p.b_per_node && p.g_b) ? reinterpret_cast<float4 *>(p.g_b + e * p.d_out) : nullptr;
+        float4 *gc = p.g_c ? reinterpret_cast<float4 *>(p.g_c + e * p.d_out) : nullptr;
+        for (int c4 = li; c4 < q; c4 += 16) {
+            float4 g = go[c4];
+            float4 pre = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pa) pre = vadd(pre, pa[c4]);
+            if (pb) pre = vadd(pre, p.b_per_node ? pb[c4] : vload_once(pb + c4));
+            if (pc) pre = vadd(pre, vload_once(pc + c4));
+            g.x = pre.x > 0.f ? g.x : 0.f; g.y = pre.y > 0.f ? g.y : 0.f; g.z = pre.z > 0.f ? g.z : 0.f; g.w = pre.w > 0.f ? g.w : 0.f;
+            if (gb) gb[c4] = g;
+            if (gc) gc[c4] = g;
+        }
+    }
+}
+
 // per-node gradients through the source-sorted CSR: g_a[s] (and g_b[s] if per node) = sum over edges leaving s
 __global__ __launch_bounds__(256) void propagate_bwd_node_kernel(PropBwdArgs p) {
     const int lane = threadIdx.x & 63;
@@ -891,9 +921,17 @@ extern "C" int gsn_propagate_pad_bwd_hip(int kind, int64_t n_nodes, int64_t n_ed
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const bool need_edge = (g_b && !b_per_node && db) || (g_c && dc);
     if (need_edge && n_edges > 0) {
-        int64_t blocks = (n_edges * d_out + 255) / 256;
-        if (blocks > 16384) blocks = 16384;
-        hipLaunchKernelGGL(propagate_bwd_edge_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
+        const bool vec4 = kind == GSN_MSG_RELU_SUM && d_out % 4 == 0 &&
+                          (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)g_out | (uintptr_t)g_b | (uintptr_t)g_c) % 16 == 0);
+        if (vec4) {
+            int64_t blocks = (n_edges + 15) / 16;
+            if (blocks > 16384) blocks = 16384;
+            hipLaunchKernelGGL(propagate_bwd_edge_relu4_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
+        } else {
+            int64_t blocks = (n_edges * d_out + 255) / 256;
+            if (blocks > 16384) blocks = 16384;
+            hipLaunchKernelGGL(propagate_bwd_edge_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
+        }
     }
     const bool need_node = (g_a && da) || (g_b && b_per_node && db);
     if (kind == GSN_MSG_RELU_SUM && need_edge && n_edges > 0) p.g_edge = (g_c && dc) ? g_c : g_b;

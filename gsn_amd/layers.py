@@ -455,6 +455,10 @@ class _PropagateFn(torch.autograd.Function):
         if need[1] and wb:
             g_b = torch.empty((n if ctx.b_per_node else E, wb), dtype=torch.float32, device=dev)
         g_c = torch.empty((E, wc), dtype=torch.float32, device=dev) if (need[2] and wc) else None
+        # relu-sum: the per-edge gradients of b and c are the SAME rows (relu'(a_j + b + c) g_out[t]) -- written once, handed to both
+        shared_bc = ctx.kind == 1 and g_c is not None and g_b is not None and not ctx.b_per_node
+        if shared_bc:
+            g_b = None
         if g_a is not None or g_b is not None or g_c is not None:
             with _abi.device_guard(dev):
                 rc = _abi.lib().gsn_propagate_pad_bwd_hip(ctx.kind, n, E, src.data_ptr() if E else None, tgt.data_ptr() if E else None,
@@ -464,6 +468,8 @@ class _PropagateFn(torch.autograd.Function):
                                                           ctx.pads[0], ctx.pads[1], g_out.data_ptr(), _abi.ptr(g_a), _abi.ptr(g_b),
                                                           _abi.ptr(g_c), _abi.current_stream())
             _abi.check(rc, "gsn_propagate_pad_bwd_hip")
+        if shared_bc:
+            g_b = g_c
         # the self term (1 + eps) * self: one pass over g_out (gsn_propagate_self_bwd_hip)
         g_eps, g_selfs = None, [None] * ctx.n_self
         want_eps = ctx.has_eps and ctx.needs_input_grad[9]
