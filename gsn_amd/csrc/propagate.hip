@@ -473,6 +473,51 @@ __global__ __launch_bounds__(256) void propagate_bwd_node_kernel(PropBwdArgs p) 
     }
 }
 
+// relu-sum node gradients from the masked per-edge rows (g_edge), float4 columns: a row group of 16 lanes per source vertex
+__global__ __launch_bounds__(256) void propagate_bwd_node_edge4_kernel(PropBwdArgs p) {
+    const int lane = threadIdx.x & 63, sub = lane >> 4, li = lane & 15;
+    const int q = p.d_out >> 2;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t s0 = wave * 4; s0 < p.n_nodes; s0 += n_waves * 4) {
+        const int64_t s = s0 + sub;
+        if (s >= p.n_nodes) continue;
+        const int32_t lo = p.seg_ptr_src[s], hi = p.seg_ptr_src[s + 1];
+        for (int c4 = li; c4 < q; c4 += 16) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int32_t qq = lo; qq < hi; ++qq) {
+                const int64_t e = p.perm_src[qq];
+                acc = vadd(acc, reinterpret_cast<const float4 *>(p.g_edge + e * p.d_out)[c4]);
+            }
+            if (p.g_a) reinterpret_cast<float4 *>(p.g_a + s * p.d_out)[c4] = acc;
+            if (p.b_per_node && p.g_b) reinterpret_cast<float4 *>(p.g_b + s * p.d_out)[c4] = acc;
+        }
+    }
+}
+
+// the self term's adjoint when it is ONE per-node block as wide as the messages and no single-row sums are wanted (the ogb layers with
+// per-edge identifiers): an elementwise pass over the flat [N d] arrays in float4s, eps from a block reduction
+__global__ __launch_bounds__(256) void propagate_self_bwd_flat_kernel(int64_t n4, const float4 *__restrict__ g_out, const float4 *__restrict__ self,
+                                                                      float4 *__restrict__ g_self, const float *eps, double *g_eps) {
+    const float sc = 1.f + (eps ? *eps : 0.f);
+    double se = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 g = g_out[i];
+        if (g_eps) {
+            const float4 v = self[i];
+            se += (double)g.x * v.x + (double)g.y * v.y + (double)g.z * v.z + (double)g.w * v.w;
+        }
+        if (g_self) g_self[i] = make_float4(g.x * sc, g.y * sc, g.z * sc, g.w * sc);
+    }
+    if (g_eps) {
+        for (int off = 32; off > 0; off >>= 1) se += __shfl_down(se, off);
+        __shared__ double red[4];
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = se;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(g_eps, red[0] + red[1] + red[2] + red[3]);
+    }
+}
+
 // adjoint of the self term  out[t] += (1 + eps) * self[t]:  g_self_k = (1 + eps) * (columns of g_out) for per-node blocks, the column
 // sums of (1 + eps) * g_out for single-row blocks (fp64, the host slices them), g_eps = sum g_out . self (fp64).  One pass over g_out;
 // lane = column, waves stride over rows (the layout of bn_act_bwd_reduce_kernel).
@@ -937,9 +982,17 @@ extern "C" int gsn_propagate_pad_bwd_hip(int kind, int64_t n_nodes, int64_t n_ed
     if (kind == GSN_MSG_RELU_SUM && need_edge && n_edges > 0) p.g_edge = (g_c && dc) ? g_c : g_b;
     if (need_node) {
         if (!seg_ptr_src || (n_edges > 0 && !perm_src)) return set_error(GSN_E_INVALID, "gsn_propagate_bwd_hip: source CSR missing");
-        int64_t blocks = (n_nodes + 3) / 4;
-        if (blocks > 16384) blocks = 16384;
-        hipLaunchKernelGGL(propagate_bwd_node_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
+        const bool edge4 = p.g_edge && kind == GSN_MSG_RELU_SUM && d_out % 4 == 0 &&
+                           (((uintptr_t)p.g_edge | (uintptr_t)g_a | (uintptr_t)(b_per_node ? g_b : nullptr)) % 16 == 0);
+        if (edge4) {
+            int64_t blocks = (n_nodes + 15) / 16;
+            if (blocks > 16384) blocks = 16384;
+            hipLaunchKernelGGL(propagate_bwd_node_edge4_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
+        } else {
+            int64_t blocks = (n_nodes + 3) / 4;
+            if (blocks > 16384) blocks = 16384;
+            hipLaunchKernelGGL(propagate_bwd_node_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
+        }
     }
     return hip_check("gsn_propagate_bwd_hip");
 }
@@ -966,6 +1019,16 @@ extern "C" int gsn_propagate_self_bwd_hip(int kind, int64_t n_nodes, int64_t d_o
     if (kind == GSN_MSG_CAT && sum != d_out)
         return set_error(GSN_E_INVALID, "gsn_propagate_self_bwd_hip: self blocks are %lld columns wide, g_out %lld", (long long)sum, (long long)d_out);
     if (n_nodes <= 0) return GSN_OK;
+    if (n_self == 1 && !g_colsum && self_blocks[0].width == d_out && self_blocks[0].row_stride == d_out && (n_nodes * d_out) % 4 == 0 &&
+        (((uintptr_t)g_out | (uintptr_t)self_blocks[0].data | (uintptr_t)p.g_self[0]) % 16 == 0)) {
+        const int64_t n4 = n_nodes * d_out / 4;
+        int64_t bx = (n4 + 255) / 256;
+        if (bx > 4096) bx = 4096;
+        hipLaunchKernelGGL(propagate_self_bwd_flat_kernel, dim3((unsigned)bx), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), n4,
+                           reinterpret_cast<const float4 *>(g_out), reinterpret_cast<const float4 *>(self_blocks[0].data),
+                           reinterpret_cast<float4 *>(p.g_self[0]), eps, g_eps);
+        return hip_check("propagate_self_bwd_flat_kernel");
+    }
     int64_t bx = (n_nodes + 3) / 4;
     if (bx > 1024) bx = 1024;
     hipLaunchKernelGGL(propagate_self_bwd_kernel, dim3((unsigned)bx, (unsigned)((d_out + 63) / 64)), dim3(256), 0,
