@@ -189,3 +189,50 @@ def test_propagate_self_term_and_padding_vs_torch():
     w = torch.randn_like(ref)
     for g, r in zip(torch.autograd.grad((out * w).sum(), [a, bn_, c, eps]), torch.autograd.grad((ref * w).sum(), [a, bn_, c, eps])):
         assert torch.allclose(g, r, rtol=1e-4, atol=1e-4 * max(1.0, float(r.abs().max())))
+
+
+@pytest.mark.parametrize("m_rows,n_out,widths", [(5000, 600, (300,)), (777, 70, (33, 5, 128)), (33, 300, (600,)), (100000, 128, (260,)), (17, 9, (7,))])
+def test_weight_gradient_bf16x6_vs_fp64(m_rows, n_out, widths):
+    """gsn_wgrad_hip (wgrad_bf16_kernel: six exact bf16 plane products, contraction over the rows) against an fp64 product: the error of
+    an fp32 FMA loop, at magnitudes from 1e-6 to 1e6 per column, ragged row counts, concatenated blocks, tiles past the matrix edges."""
+    import ctypes
+    from gsn_amd import _abi
+    torch.manual_seed(m_rows)
+    gh = torch.randn(m_rows, n_out, device="cuda") * torch.logspace(-6, 6, n_out, device="cuda")
+    blocks = [torch.randn(m_rows, w, device="cuda") * torch.logspace(-3, 3, w, device="cuda") for w in widths]
+    k_total = sum(widths)
+    gw = torch.zeros(n_out, k_total, device="cuda")
+    arr = (_abi.gsn_block * len(blocks))()
+    for i, t in enumerate(blocks):
+        arr[i].data = t.data_ptr(); arr[i].idx = None; arr[i].idx32 = None; arr[i].width = t.shape[1]
+    _abi.check(_abi.lib().gsn_wgrad_hip(m_rows, n_out, gh.data_ptr(), len(blocks), arr, gw.data_ptr(), _abi.current_stream()), "gsn_wgrad_hip")
+    x = torch.cat(blocks, 1)
+    ref = gh.double().t() @ x.double()
+    # element-wise against the product of the column magnitudes (what an fp32 accumulation of m_rows terms can promise)
+    bound = (gh.double().abs().t() @ x.double().abs())
+    err = ((gw.double() - ref).abs() / bound.clamp_min(1e-300)).max().item()
+    ref32 = (gh.t() @ x).double()
+    err32 = ((ref32 - ref).abs() / bound.clamp_min(1e-300)).max().item()
+    assert err <= max(2.0 * err32, 3e-7), (err, err32)
+
+
+def test_add_by_graph_vs_torch():
+    """gsn_add_gathered_hip: x + table[batch] and its adjoint (identity / sum readout), float4 and scalar widths; an index outside the
+    table gives a NaN row."""
+    from gsn_amd import layers
+    torch.manual_seed(4)
+    for n, g, d in [(1000, 37, 300), (513, 5, 7), (64, 64, 128)]:
+        batch = torch.sort(torch.randint(0, g, (n,), device="cuda")).values
+        x = torch.randn(n, d, device="cuda", requires_grad=True)
+        tab = torch.randn(g, d, device="cuda", requires_grad=True)
+        y = layers.add_by_graph(x, tab, batch)
+        ref = x + tab[batch]
+        assert torch.equal(y, ref)
+        w = torch.randn_like(ref)
+        gx, gt = torch.autograd.grad((y * w).sum(), [x, tab])
+        rx, rt = torch.autograd.grad((ref * w).sum(), [x, tab])
+        assert torch.equal(gx, rx)
+        assert torch.allclose(gt, rt, rtol=1e-5, atol=1e-5)
+    bad = torch.tensor([0, 1, 5], device="cuda")
+    y = layers.add_by_graph(torch.zeros(3, 4, device="cuda"), torch.ones(2, 4, device="cuda"), bad)
+    assert torch.isnan(y[2]).all() and torch.equal(y[:2], torch.ones(2, 4, device="cuda"))
