@@ -1732,8 +1732,11 @@ class _SparseLayer(nn.Module):
         csr = _csr_for(edge_index, sel, n)
         last, w3 = mf.fc[-1], uf.fc[0].weight
         d_x = x.shape[1]
-        w3x, w3a = w3[:, :d_x], w3[:, d_x:]
-        w_first = torch.cat([w3x, w3a @ last.weight, (w3a @ last.bias).unsqueeze(1)], 1)
+        w3x, w3a = w3[:, :d_x], w3[:, d_x:].contiguous()
+        # the fold  W3a W2 | W3a b2  as two dense stages with their own adjoints (rows = W3a; no library GEMM in the step)
+        w_fold = run_stages_autograd([_Stage(last.weight.t(), None, None, "identity", [(w3a, None)])], w3a.shape[0], True)
+        b_fold = run_stages_autograd([_Stage(last.bias.unsqueeze(0), None, None, "identity", [(w3a, None)])], w3a.shape[0], True)
+        w_first = torch.cat([w3x, w_fold, b_fold], 1)
         stages = uf.stages([(x, None), (s_agg, None), (csr.deg, None)], first_weight=w_first, post=post)
         return run_stages_autograd(stages, n, True)
 
