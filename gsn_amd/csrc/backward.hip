@@ -360,7 +360,7 @@ using namespace gsn;
 extern "C" int gsn_bn_act_bwd_hip(int64_t m_rows, int64_t n_cols, const float *grad_y, const float *y, const float *h,
                                   const float *mean, const float *invstd, const float *coef, int train_bn, int act,
                                   double *sums, float *grad_h, double *grad_bias, void *stream) {
-    if (n_cols < 1 || act < 0 || act > 3 || (m_rows > 0 && (!grad_y || !y || !grad_h)) || (train_bn && (!h || !sums)))
+    if (n_cols < 1 || act < 0 || act > 3 || (m_rows > 0 && (!grad_y || !y || !grad_h)) || (train_bn && m_rows > 0 && (!h || !sums)))
         return set_error(GSN_E_INVALID, "gsn_bn_act_bwd_hip: bad arguments");
     if (m_rows <= 0) return GSN_OK;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -384,7 +384,7 @@ extern "C" int gsn_wgrad_hip(int64_t m_rows, int64_t n_out, const float *grad_h,
     a.m_rows = m_rows; a.n_out = (int)n_out; a.gh = grad_h; a.gw = grad_w; a.n_blocks = n_blocks;
     int k = 0;
     for (int b = 0; b < n_blocks; ++b) {
-        if (!blocks[b].data || blocks[b].width <= 0) return set_error(GSN_E_INVALID, "gsn_wgrad_hip: block %d is empty", b);
+        if ((!blocks[b].data && m_rows > 0) || blocks[b].width <= 0) return set_error(GSN_E_INVALID, "gsn_wgrad_hip: block %d is empty", b);
         if (blocks[b].idx || blocks[b].idx32) return set_error(GSN_E_UNSUPPORTED, "gsn_wgrad_hip: gathered blocks are not supported");
         a.bdata[b] = blocks[b].data; a.bwidth[b] = (int)blocks[b].width;
         k += (int)blocks[b].width;

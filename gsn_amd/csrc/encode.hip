@@ -669,7 +669,8 @@ extern "C" int gsn_gather_cat_hip(int64_t m_rows, int n_blocks, const gsn_block 
     GatherCatArgs a{};
     a.m_rows = m_rows; a.n_blocks = n_blocks; a.out = out; a.off[0] = 0;
     for (int b = 0; b < n_blocks; ++b) {
-        if (!blocks[b].data || blocks[b].width <= 0) return set_error(GSN_E_INVALID, "gsn_gather_cat_hip: block %d is empty", b);
+        // (zero rows: per-edge blocks of an edge-less batch are empty tensors without a pointer)
+        if ((!blocks[b].data && m_rows > 0) || blocks[b].width <= 0) return set_error(GSN_E_INVALID, "gsn_gather_cat_hip: block %d is empty", b);
         a.data[b] = blocks[b].data; a.idx[b] = blocks[b].idx; a.idx32[b] = blocks[b].idx32; a.width[b] = (int)blocks[b].width;
         a.off[b + 1] = a.off[b] + a.width[b];
     }

@@ -954,7 +954,8 @@ extern "C" int gsn_propagate_pad_bwd_hip(int kind, int64_t n_nodes, int64_t n_ed
     if (kind == GSN_MSG_CAT) d_out = da + pad_b + db + pad_c + dc;
     else { d_out = da > db ? da : db; d_out = d_out > dc ? d_out : dc; }
     if (d_out <= 0 || n_nodes <= 0) return GSN_OK;
-    if (kind == GSN_MSG_RELU_SUM && ((da && !a) || (db && !b) || (dc && !c)))
+    // (per-edge blocks of an edge-less batch are empty tensors: no pointer to give)
+    if (kind == GSN_MSG_RELU_SUM && ((da && !a) || (db && !b && (b_per_node || n_edges > 0)) || (dc && !c && n_edges > 0)))
         return set_error(GSN_E_INVALID, "gsn_propagate_bwd_hip: relu-sum needs the forward inputs");
     PropBwdArgs p{};
     p.kind = kind; p.n_nodes = n_nodes; p.n_edges = n_edges; p.src = src; p.tgt = tgt;

@@ -566,6 +566,8 @@ def _linear_hip(blocks, weight, bias, bn_mean, bn_scale, bn_shift, act, m_rows, 
         arr[i].width = d.shape[1]
     n_out = weight.shape[0]
     y = torch.empty((m_rows, n_out), dtype=torch.float32, device=dev) if out else None
+    if m_rows == 0:
+        return y                      # (no rows: nothing to launch; `stats` keeps its zeros)
     w = _f32c(weight)
     vecs = [None if v is None else _f32c(v) for v in (bias, bn_mean, bn_scale, bn_shift)]
     # direct rows (node-level stages): the fp16x3 kernel with the weights split once per weight version
@@ -610,6 +612,12 @@ def _launch_stages(stages, m_rows, stats=None, csr=None):
     scatter-add) -> [n_nodes, n_out]; returns None if that cannot be fused (caller falls back to propagate)."""
     L = _abi.lib()
     dev = stages[0].weight.device
+    if m_rows == 0:
+        # no rows (an edge-less batch in front of an edge stage): nothing to launch -- empty output, zero sums per target
+        n_last = stages[-1].weight.shape[0]
+        if csr is not None:
+            return torch.zeros((csr.seg_ptr.numel() - 1, n_last), dtype=torch.float32, device=dev)
+        return torch.empty((0, n_last), dtype=torch.float32, device=dev) if stats is None else None
     y = None
     i = 0
     while i < len(stages):
@@ -869,8 +877,8 @@ def _bn_resolve(stage, stats_fn, m_rows, training):
         stage.bn_params = None
         return
     if training or bn.running_mean is None:
-        if training and m_rows == 1:
-            raise ValueError("Expected more than 1 value per channel when training, got input size torch.Size([1, %d])" % bn.num_features)
+        if training and m_rows <= 1:
+            raise ValueError("Expected more than 1 value per channel when training, got input size torch.Size([%d, %d])" % (m_rows, bn.num_features))
         stats = stats_fn()
         n_out = stats.shape[1]
         dev = stats.device
@@ -1715,20 +1723,15 @@ class _SparseLayer(nn.Module):
         if self.has_ef:
             tensors.append(ef); modes.append(None)
         mf, uf = self.msg_fn, self.update_fn
+        # (an edge-less batch walks the same graph with zero rows: every parameter and input then gets the ZERO gradient PyTorch gives it)
         if len(mf.fc) < 2:      # a single Linear as msg_fn: nothing to fold (GSN_sparse.py:166-171 with d_h = [])
-            if E > 0:
-                xe = _GatherCatFn.apply(edge_index, n, tuple(modes), *tensors)
-                msgs = run_stages_autograd(mf.stages([(xe, None)]), E, True)
-                agg = propagate(0, edge_index, sel, n, b=msgs)
-            else:
-                agg = torch.zeros((n, mf.fc[-1].weight.shape[0]), device=x.device)
-            return run_stages_autograd(uf.stages([(x, None), (agg, None)], post=post), n, True)
-        if E > 0:
             xe = _GatherCatFn.apply(edge_index, n, tuple(modes), *tensors)
-            r = run_stages_autograd(mf.stages([(xe, None)], upto=len(mf.fc) - 1), E, True)
-            s_agg = propagate(0, edge_index, sel, n, b=r)
-        else:
-            s_agg = torch.zeros((n, mf.fc[-2].weight.shape[0]), device=x.device)
+            msgs = run_stages_autograd(mf.stages([(xe, None)]), E, True)
+            agg = propagate(0, edge_index, sel, n, b=msgs)
+            return run_stages_autograd(uf.stages([(x, None), (agg, None)], post=post), n, True)
+        xe = _GatherCatFn.apply(edge_index, n, tuple(modes), *tensors)
+        r = run_stages_autograd(mf.stages([(xe, None)], upto=len(mf.fc) - 1), E, True)
+        s_agg = propagate(0, edge_index, sel, n, b=r)
         csr = _csr_for(edge_index, sel, n)
         last, w3 = mf.fc[-1], uf.fc[0].weight
         d_x = x.shape[1]

@@ -236,3 +236,16 @@ def test_add_by_graph_vs_torch():
     bad = torch.tensor([0, 1, 5], device="cuda")
     y = layers.add_by_graph(torch.zeros(3, 4, device="cuda"), torch.ones(2, 4, device="cuda"), bad)
     assert torch.isnan(y[2]).all() and torch.equal(y[:2], torch.ones(2, 4, device="cuda"))
+
+
+@pytest.mark.parametrize("seed", [116, 179, 207, 254, 264, 7022, 7403])
+def test_edge_less_batches_give_the_zero_gradients_pytorch_gives(seed):
+    """Regression (found by tests/soak_grads.py): a batch without a single edge -- every class / kind, train and eval mode.  The forward
+    equals the oracle, and every parameter and input that only acts through the edges gets a ZERO gradient (not None, not an error):
+    zero-row stages launch nothing, the per-edge blocks are empty tensors without a pointer."""
+    import soak_grads
+    r = soak_grads.one_case(seed)
+    assert r is not None
+    desc, bad = r
+    assert " E=0" in desc, desc
+    assert not bad, (desc, bad)
