@@ -143,12 +143,20 @@ def check(rc: int, what: str = "") -> None:
         raise GsnError("%s failed (%d): %s" % (what or "libgsn_hip", rc, msg.decode() if msg else ""))
 
 
+_GPU_SEEN = False
+
+
 def require_gpu() -> None:
-    """Device entry points need a real gfx950; refuse loudly otherwise."""
+    """Device entry points need a real gfx950; refuse loudly otherwise.  (torch.cuda.is_available() costs ~40 us a call: a GPU that
+    has been seen once stays.)"""
+    global _GPU_SEEN
+    if _GPU_SEEN:
+        return
     import torch
     if not torch.cuda.is_available():
         raise RuntimeError("gsn_amd: no GPU visible to PyTorch-ROCm; the counting / message-passing kernels are "
                            "HIP-only (gfx950) and there is no CPU fallback.")
+    _GPU_SEEN = True
 
 
 def ptr(t) -> int:

@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void rank_gather_kernel(int64_t m_rows, int n_
 // AtomEncoder / BondEncoder): out[r] = concat_c T_c[code[r][c]]  or  sum_c T_c[code[r][c]].
 // meta (device, int64): [0..C) table base pointers, [C..2C) table row counts.  One thread per output float; codes are
 // broadcast within a row, table rows are read coalesced.  status (device int32) is raised to GSN_ST_BAD_INDEX on a code
-// outside its table (the reference's nn.Embedding raises IndexError).
+// outside its table (the reference's nn.Embedding raises IndexError) and the row's values come out NaN.
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void embed_fwd_kernel(int64_t m_rows, int n_cols, int d, int concat, const int64_t *codes,
                                                         const int64_t *meta, float *out, int32_t *status) {
@@ -221,12 +221,12 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(int64_t m_rows, int n_co
         if (concat) {
             const int c = w / d, j = w - c * d;
             const int64_t code = codes[r * n_cols + c];
-            if (code < 0 || code >= meta[n_cols + c]) { atomicMax(status, GSN_ST_BAD_INDEX); continue; }
+            if (code < 0 || code >= meta[n_cols + c]) { atomicMax(status, GSN_ST_BAD_INDEX); out[i] = __builtin_nanf(""); continue; }
             acc = reinterpret_cast<const float *>(meta[c])[code * d + j];
         } else {
             for (int c = 0; c < n_cols; ++c) {
                 const int64_t code = codes[r * n_cols + c];
-                if (code < 0 || code >= meta[n_cols + c]) { atomicMax(status, GSN_ST_BAD_INDEX); continue; }
+                if (code < 0 || code >= meta[n_cols + c]) { atomicMax(status, GSN_ST_BAD_INDEX); acc = __builtin_nanf(""); continue; }
                 acc += reinterpret_cast<const float *>(meta[c])[code * d + w];
             }
         }
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void embed_lds_kernel(EmbArgs a) {
 #pragma unroll
                         for (int sb = 0; sb < NSUB; ++sb) {
                             const int j = j0 + EMB_DCH * sb + lane;
-                            const float v = ok ? tab[(a.row_off[c] + (int)code[u]) * DCH + EMB_DCH * sb + lane] : 0.f;
+                            const float v = ok ? tab[(a.row_off[c] + (int)code[u]) * DCH + EMB_DCH * sb + lane] : __builtin_nanf("");
                             if (a.concat) { if (rb + u < r1 && j < a.d) a.out[(rb + u) * gw + c * a.d + j] = v; }
                             else acc[u][sb] += v;
                         }

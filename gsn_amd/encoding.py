@@ -18,6 +18,8 @@ from __future__ import annotations
 
 import sys
 
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -174,14 +176,66 @@ class zero_encoder(nn.Module):
         return "{}({})".format(self.__class__.__name__, self.d_out)
 
 
+_META_CACHE = {}
+
+
 def _table_meta(tables, device):
-    ptrs = [t.data_ptr() for t in tables] + [int(t.shape[0]) for t in tables]
-    return torch.tensor(ptrs, dtype=torch.int64, device=device)
+    """Device array [table pointers | row counts] of an embedding launch.  Uploading it is a host-to-device copy from pageable memory
+    (the host waits for the stream): the arrays are kept per pointer tuple -- parameters keep their addresses, and the caching
+    allocator hands a step's gradient tables the addresses of the step before."""
+    ptrs = tuple([t.data_ptr() for t in tables] + [int(t.shape[0]) for t in tables])
+    key = (ptrs, str(device))
+    hit = _META_CACHE.get(key)
+    if hit is None:
+        if len(_META_CACHE) > 256:
+            _META_CACHE.clear()
+        hit = _META_CACHE[key] = torch.tensor(ptrs, dtype=torch.int64, device=device)
+    return hit
+
+
+# Out-of-range codes.  The reference's nn.Embedding raises IndexError (CPU) / a device-side assert that surfaces later (GPU).  Here the
+# kernel raises a status word and makes the row NaN; reading the word back at once would synchronise host and device at EVERY
+# embedding (twelve times per step of the ogb model).  So the word travels to pinned host memory behind the kernel and is looked at when
+# its event has completed -- at the next embedding call, in the backward, or by check_embedding_status() -- i.e. the IndexError arrives
+# one call late, like any asynchronous device error.  GSN_EMBED_STATUS_SYNC=1 checks at once.
+EMBED_STATUS_SYNC = os.environ.get("GSN_EMBED_STATUS_SYNC", "0") == "1"
+_PENDING_STATUS = []
+_STATUS_RING, _STATUS_NEXT = None, 0
+
+
+def check_embedding_status(wait=False):
+    """Raise IndexError if an embedding launch whose result has arrived saw a code outside its table (wait=True: of any launch so far)."""
+    while _PENDING_STATUS and (wait or _PENDING_STATUS[0][0].query()):
+        ev, host = _PENDING_STATUS.pop(0)
+        if wait:
+            ev.synchronize()
+        if int(host[0]) != 0:
+            _PENDING_STATUS.clear()
+            raise IndexError("index out of range in embedding table")
+
+
+def _defer_status(status):
+    if EMBED_STATUS_SYNC:
+        if int(status.item()) != 0:
+            raise IndexError("index out of range in embedding table")
+        return
+    global _STATUS_RING, _STATUS_NEXT
+    if _STATUS_RING is None:
+        _STATUS_RING = torch.zeros(128, dtype=torch.int32).pin_memory()      # (one pinned allocation: slots handed out in turn)
+    if len(_PENDING_STATUS) >= 96:
+        check_embedding_status(wait=True)
+    host = _STATUS_RING[_STATUS_NEXT:_STATUS_NEXT + 1]
+    _STATUS_NEXT = (_STATUS_NEXT + 1) % 128
+    host.copy_(status, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    _PENDING_STATUS.append((ev, host))
 
 
 class _EmbedFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, codes, concat, *tables):
+        check_embedding_status()
         dev = codes.device
         d = int(tables[0].shape[1])
         M, C = codes.shape
@@ -195,14 +249,14 @@ class _EmbedFn(torch.autograd.Function):
                                               _abi.ptr(rows), out.data_ptr() if M else None, status.data_ptr(),
                                               _abi.current_stream())
         _abi.check(rc, "gsn_embed_fwd_hip")
-        if int(status.item()) != 0:
-            raise IndexError("index out of range in embedding table")
+        _defer_status(status)
         ctx.save_for_backward(codes)
         ctx.concat, ctx.shapes = concat, [tuple(t.shape) for t in tables]
         return out
 
     @staticmethod
     def backward(ctx, gout):
+        check_embedding_status()
         (codes,) = ctx.saved_tensors
         dev = codes.device
         M, C = codes.shape

@@ -303,6 +303,20 @@ def _csr_for(edge_index, row, n_nodes):
     return c
 
 
+def num_graphs_of(batch):
+    """1 + the largest graph id of a ``batch`` vector -- ONE device read per batch tensor (cached on the tensor object with its version
+    counter; a registered partition answers without any): the reference reads it once per readout, a host synchronisation each time."""
+    ptr = _batch_ptr_of(batch)
+    if ptr is not None:
+        return int(ptr.numel()) - 1
+    key = (id(batch), "n_graphs")
+    g = _cache_get(key, batch)
+    if g is None:
+        g = int(batch.max().item()) + 1 if batch.numel() else 0
+        _cache_put(key, batch, g)
+    return g
+
+
 def global_add_pool_sparse(x, batch, num_graphs=None):
     """Sum readout (utils_graph_learning.py:23-29: COO [G, N, d] + torch.sparse.sum) as a segmented sum keyed by the
     ``batch`` vector, on the propagate kernel.  The (row id, graph id) index pair is cached on the
@@ -311,7 +325,7 @@ def global_add_pool_sparse(x, batch, num_graphs=None):
     n_rows = x.shape[0]
     if batch.numel() != n_rows:
         raise RuntimeError("global_add_pool_sparse: %d rows but %d batch entries" % (n_rows, batch.numel()))
-    g = int(batch.max().item()) + 1 if num_graphs is None else int(num_graphs)
+    g = num_graphs_of(batch) if num_graphs is None else int(num_graphs)
     key = (id(batch), "pool", n_rows)
     ei = _cache_get(key, batch)
     if ei is None:

@@ -270,7 +270,7 @@ class GNN_OGB(nn.Module):
         memo = {}
         edge_index = data.edge_index
         if self.vn:
-            n_graphs = int(data.batch[-1].item()) + 1
+            n_graphs = layers.num_graphs_of(data.batch)            # (data.batch[-1] + 1 of the reference: sorted graph ids; one read per batch)
             vn_embedding = self.vn_encoder(torch.zeros(n_graphs, dtype=edge_index.dtype, device=edge_index.device))
         x = self.input_node_encoder(data.x)
         x_interm = [x]

@@ -425,7 +425,7 @@ int gsn_column_ranks_hip(int64_t m_rows, int n_cols, const int64_t *values, cons
  * AtomEncoder / BondEncoder ('atom_encoder' / 'bond_encoder', :99-107).  codes int64 [M][C]; table c is fp32
  * [rows_c][d] row-major.  meta (device int64 [2C]) = table base addresses then rows_c.  concat != 0: out [M][C*d] is the
  * concatenation, else out [M][d] the sum over columns.  status (device int32, caller-zeroed) is raised to
- * GSN_ST_BAD_INDEX when a code is outside its table.  bwd accumulates grad_out into the gradient tables named by
+ * GSN_ST_BAD_INDEX when a code is outside its table (that row's values are NaN).  bwd accumulates grad_out into the gradient tables named by
  * grad_meta (caller zero-fills them).  table_rows = the row counts again as a HOST array [C] (NULL allowed in fwd): they
  * pick the kernel -- tables that together have <= 448 rows are held in LDS per workgroup (64-wide slices), larger ones
  * are read / accumulated in HBM.

@@ -98,9 +98,26 @@ def test_embedding_matches_reference_fwd_bwd(gold, aggr):
 
 
 def test_embedding_out_of_range_raises():
+    """A code outside its table: the row comes out NaN at once and the IndexError of the reference's nn.Embedding arrives without a
+    host synchronisation per call -- at the next embedding call whose predecessor has completed, or from check_embedding_status()."""
     m = encoding.multi_embedding([3, 3], 4, "sum").cuda()
+    for concat in ("sum", "concat"):
+        mm = encoding.multi_embedding([3, 3], 4, concat).cuda()
+        y = mm(torch.tensor([[0, 1], [0, 3]]).cuda())
+        assert torch.isfinite(y[0]).all() and torch.isnan(y[1]).any()
+        with pytest.raises(IndexError):
+            encoding.check_embedding_status(wait=True)
+    y = m(torch.tensor([[0, 3]]).cuda())
+    torch.cuda.synchronize()
     with pytest.raises(IndexError):
-        m(torch.tensor([[0, 3]]).cuda())
+        m(torch.tensor([[0, 1]]).cuda())                 # (the launch before this one has completed: its status is read here)
+    encoding.check_embedding_status(wait=True)           # (nothing pending is left behind for other tests)
+    encoding.EMBED_STATUS_SYNC = True
+    try:
+        with pytest.raises(IndexError):
+            m(torch.tensor([[0, 3]]).cuda())
+    finally:
+        encoding.EMBED_STATUS_SYNC = False
 
 
 def test_ogb_style_encoders_and_linear():
