@@ -134,7 +134,7 @@ def work_figures(plan_patterns, ids_out):
     return float(col_sums.sum()), float(maps)
 
 
-def full_model_closure(dev, gm, batch=None):
+def full_model_closure(dev, gm, batch=None, check=True):
     """count + the FULL model of BASELINE configs[1] (GNNSubstructures, 4 layers: layer 0 is GSN_edge_sparse, layers 1-3
     MPNN_edge_sparse with K = 260 edge rows -- the any-shape dense kernels; one-hot encoders, jk, sum readout, eval) over `gm`
     ZINC-shaped graphs -> (step function, gm).  Also used by scripts/profile_full_model.py."""
@@ -169,7 +169,7 @@ def full_model_closure(dev, gm, batch=None):
     data4 = types.SimpleNamespace(x=torch.from_numpy(b.atom_type[:n4]).unsqueeze(1).to(dev), edge_index=ei4,
                                   edge_features=torch.from_numpy(b.bond_type[:e4]).unsqueeze(1).to(dev), identifiers=None,
                                   batch=torch.from_numpy(np.asarray(b.batch)[:n4].astype(np.int64)).to(dev), degrees=torch.zeros(n4, device=dev),
-                                  graph_partition=(np4, ep4, max_nodes, max_edges))
+                                  graph_partition=(np4, ep4, max_nodes, max_edges, check))
 
     def step_model():
         layers._CSR_CACHE.clear()
@@ -269,27 +269,46 @@ def small_batch_steps(plan, layer, dev):
         torch.cuda.synchronize()
         rec = {"graphs": G, "eager_us": round((time.perf_counter() - t0) / reps * 1e6, 1)}
         try:
-            g = torch.cuda.CUDAGraph()
-            s = torch.cuda.Stream(device=dev)
-            s.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(s):
-                for _ in range(3):
-                    step()
-            torch.cuda.current_stream(dev).wait_stream(s)
-            with torch.cuda.graph(g):
-                y_static = step()
+            from gsn_amd.graphs import GraphedStep
+            g = GraphedStep(step, warmup=3, device=dev)          # (the product's capture helper: side-stream warm-up, capture, replay)
             for _ in range(30):
-                g.replay()
+                g()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(reps):
-                g.replay()
+                y_static = g()
             torch.cuda.synchronize()
             rec["hip_graph_us"] = round((time.perf_counter() - t0) / reps * 1e6, 1)
             rec["hip_graph_matches_eager"] = bool(torch.equal(y_static, y_ref))
         except Exception as e:       # capture is best effort
             rec["hip_graph_error"] = str(e)[:160]
         out["B%d" % G] = rec
+    # the whole model of BASELINE configs[1] (count + 4 layers + encoders + readout) at the reference's batch size, eager and replayed
+    try:
+        from gsn_amd.graphs import GraphedStep
+        mstep, _ = full_model_closure(dev, 128, check=False)
+        for _ in range(10):
+            y_ref = mstep()
+        torch.cuda.synchronize()
+        reps = 100
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            y_ref = mstep()
+        torch.cuda.synchronize()
+        rec = {"graphs": 128, "eager_us": round((time.perf_counter() - t0) / reps * 1e6, 1)}
+        g = GraphedStep(mstep, warmup=2, device=dev)
+        for _ in range(10):
+            g()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            y_static = g()
+        torch.cuda.synchronize()
+        rec["hip_graph_us"] = round((time.perf_counter() - t0) / reps * 1e6, 1)
+        rec["hip_graph_matches_eager"] = bool(torch.equal(y_static, y_ref))
+        out["full_model_B128"] = rec
+    except Exception as e:
+        out["full_model_B128"] = {"error": str(e)[:160]}
     return out
 
 

@@ -21,13 +21,14 @@ from .layers import (GSN_edge_sparse, GSN_edge_sparse_ogb, GSN_sparse, MPNN_edge
 
 
 def _register_partition(data, edge_index):
-    """A batch object may carry ``graph_partition = (node_ptr, edge_ptr, max_nodes, max_edges)`` (int64 [G + 1] pointers of the
+    """A batch object may carry ``graph_partition = (node_ptr, edge_ptr, max_nodes, max_edges[, check])`` (int64 [G + 1] pointers of the
     collated graphs): the layers then build their aggregation index with one launch per batch (layers.set_graph_partition) and
-    the readout uses the node pointers as its segment bounds (layers.set_batch_partition)."""
+    the readout uses the node pointers as its segment bounds (layers.set_batch_partition).  ``check`` (default True) reads the build's
+    status word back -- a host synchronisation; False for a forward that is captured into a HIP graph (gsn_amd.graphs)."""
     part = getattr(data, "graph_partition", None)
     if part is not None and edge_index.is_cuda:
         from . import layers as _layers
-        _layers.set_graph_partition(edge_index, part[0], part[1], part[2], part[3])
+        _layers.set_graph_partition(edge_index, part[0], part[1], part[2], part[3], check=bool(part[4]) if len(part) > 4 else True)
         batch = getattr(data, "batch", None)
         if batch is not None and batch.is_cuda:
             _layers.set_batch_partition(batch, part[0])           # the readout's rows are grouped by graph already

@@ -405,3 +405,21 @@ def test_wide_layer_inside_a_captured_graph(capfd):
         graph.replay()
         torch.cuda.synchronize()
     assert torch.equal(y1, y2) and not torch.equal(y0, y2)
+
+
+def test_graphed_step_replays_a_whole_model_forward():
+    """gsn_amd.graphs.GraphedStep: count + the 4-layer d = 128 model forward of 48 graphs captured once, replayed on refilled inputs -- the
+    replay equals the eager forward of the new inputs bit for bit, and a refill changes the result."""
+    import bench
+    from gsn_amd import graphs
+    dev = torch.device("cuda", 0)
+    step, G = bench.full_model_closure(dev, 48, check=False)         # (no status read-back inside the capture)
+    with torch.no_grad():
+        y_eager = step()
+        y_eager = y_eager.clone() if torch.is_tensor(y_eager) else y_eager
+        gs = graphs.GraphedStep(step, warmup=2, device=dev)
+        y_replay = gs()
+        torch.cuda.synchronize()
+    if torch.is_tensor(y_eager):
+        assert torch.equal(y_replay, y_eager)
+    assert gs.replays == 1
