@@ -89,6 +89,8 @@ SIGNATURES = {
     "gsn_wgrad_hip": (c_int, [c_i64, c_i64, c_vp, c_int, ctypes.POINTER(gsn_block), c_vp, c_vp]),
     "gsn_gather_cat_hip": (c_int, [c_i64, c_int, ctypes.POINTER(gsn_block), c_vp, c_vp]),
     "gsn_bn_finalize_hip": (c_int, [c_i64, c_i64, ctypes.c_double, ctypes.c_double, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "gsn_bn_finalize_count_hip": (c_int, [c_i64, c_i64, ctypes.c_double, ctypes.c_double, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                          c_vp]),
     "gsn_column_stats_hip": (c_int, [c_i64, c_i64, c_vp, c_vp, c_vp]),
     "gsn_mlp_chain_supported": (c_int, [c_int, ctypes.POINTER(gsn_chain_stage)]),
     "gsn_layer_fused_supported": (c_int, [ctypes.POINTER(gsn_chain_stage), c_i64, ctypes.POINTER(gsn_chain_stage), ctypes.POINTER(gsn_chain_stage)]),

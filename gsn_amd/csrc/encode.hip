@@ -689,9 +689,11 @@ extern "C" int gsn_gather_cat_hip(int64_t m_rows, int n_blocks, const gsn_block 
 namespace gsn {
 __global__ __launch_bounds__(256) void bn_finalize_kernel(int n_cols, double m_rows, double eps, double momentum, const double *stats,
                                                           const float *gamma, const float *beta, float *running_mean,
-                                                          float *running_var, float *mean, float *invstd, float *scale, float *shift) {
+                                                          float *running_var, float *mean, float *invstd, float *scale, float *shift,
+                                                          int64_t *num_batches_tracked) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= n_cols) return;
+    if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;       // (nn.BatchNorm1d's counter: one tensor op per call otherwise)
     const double mu = stats[c] / m_rows;
     double var = stats[n_cols + c] / m_rows - mu * mu;
     var = var > 0.0 ? var : 0.0;
@@ -711,10 +713,18 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(int n_cols, double m_r
 extern "C" int gsn_bn_finalize_hip(int64_t n_cols, int64_t m_rows, double eps, double momentum, const double *stats,
                                    const float *gamma, const float *beta, float *running_mean, float *running_var, float *mean,
                                    float *invstd, float *scale, float *shift, void *stream) {
+    return gsn_bn_finalize_count_hip(n_cols, m_rows, eps, momentum, stats, gamma, beta, running_mean, running_var, mean, invstd, scale, shift,
+                                     nullptr, stream);
+}
+
+extern "C" int gsn_bn_finalize_count_hip(int64_t n_cols, int64_t m_rows, double eps, double momentum, const double *stats,
+                                         const float *gamma, const float *beta, float *running_mean, float *running_var, float *mean,
+                                         float *invstd, float *scale, float *shift, int64_t *num_batches_tracked, void *stream) {
     if (n_cols < 1 || m_rows < 1 || !stats || !mean || !invstd || !scale || !shift || ((running_mean != nullptr) != (running_var != nullptr)))
         return set_error(GSN_E_INVALID, "gsn_bn_finalize_hip: bad arguments");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       (int)n_cols, (double)m_rows, eps, momentum, stats, gamma, beta, running_mean, running_var, mean, invstd, scale, shift);
+                       (int)n_cols, (double)m_rows, eps, momentum, stats, gamma, beta, running_mean, running_var, mean, invstd, scale, shift,
+                       num_batches_tracked);
     GSN_LAUNCH_CHECK("bn_finalize_kernel");
     return GSN_OK;
 }

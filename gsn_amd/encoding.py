@@ -239,7 +239,7 @@ class _EmbedFn(torch.autograd.Function):
         dev = codes.device
         d = int(tables[0].shape[1])
         M, C = codes.shape
-        tabs = [t.detach().to(torch.float32).contiguous() for t in tables]
+        tabs = [t if (t.dtype == torch.float32 and t.is_contiguous()) else t.detach().to(torch.float32).contiguous() for t in tables]
         meta = _table_meta(tabs, dev)
         out = torch.empty((M, C * d if concat else d), dtype=torch.float32, device=dev)
         status = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -261,7 +261,14 @@ class _EmbedFn(torch.autograd.Function):
         dev = codes.device
         M, C = codes.shape
         d = ctx.shapes[0][1]
-        grads = [torch.zeros(s, dtype=torch.float32, device=dev) for s in ctx.shapes]
+        # gradient tables: ONE zero fill for all of them (nine tables of the atom encoder: nine launches otherwise); offsets rounded to
+        # 16 bytes so that every table keeps the alignment of a tensor of its own
+        sizes = [(s[0] * s[1] + 3) // 4 * 4 for s in ctx.shapes]
+        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        grads, o = [], 0
+        for s_, n_ in zip(ctx.shapes, sizes):
+            grads.append(flat[o:o + s_[0] * s_[1]].view(s_))
+            o += n_
         meta = _table_meta(grads, dev)
         g = gout.to(torch.float32).contiguous()
         rows = np.ascontiguousarray([s[0] for s in ctx.shapes], dtype=np.int64)

@@ -899,17 +899,21 @@ def _bn_resolve(stage, stats_fn, m_rows, training):
         vec = torch.empty((4, n_out), dtype=torch.float32, device=dev)       # mean, invstd, scale, shift
         track = training and bn.track_running_stats and bn.running_mean is not None
         mom = 0.0
+        nbt = None
         if track:
-            bn.num_batches_tracked += 1
-            mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+            if bn.momentum is not None and bn.num_batches_tracked.is_cuda and bn.num_batches_tracked.dtype == torch.int64:
+                mom, nbt = bn.momentum, bn.num_batches_tracked      # (the counter is incremented by the finalize kernel)
+            else:
+                bn.num_batches_tracked += 1
+                mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
         gamma = _f32c(bn.weight) if bn.affine else None
         beta = _f32c(bn.bias) if bn.affine else None
         with _abi.device_guard(dev):
-            rc = _abi.lib().gsn_bn_finalize_hip(n_out, m_rows, float(bn.eps), float(mom), stats.data_ptr(), _abi.ptr(gamma), _abi.ptr(beta),
-                                                bn.running_mean.data_ptr() if track else None, bn.running_var.data_ptr() if track else None,
-                                                vec[0].data_ptr(), vec[1].data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(),
-                                                _abi.current_stream())
-        _abi.check(rc, "gsn_bn_finalize_hip")
+            rc = _abi.lib().gsn_bn_finalize_count_hip(n_out, m_rows, float(bn.eps), float(mom), stats.data_ptr(), _abi.ptr(gamma), _abi.ptr(beta),
+                                                      bn.running_mean.data_ptr() if track else None, bn.running_var.data_ptr() if track else None,
+                                                      vec[0].data_ptr(), vec[1].data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(),
+                                                      _abi.ptr(nbt), _abi.current_stream())
+        _abi.check(rc, "gsn_bn_finalize_count_hip")
         stage.bn_params = (vec[0], vec[2], vec[3])
         stage.bn_invstd = vec[1]
         return

@@ -519,6 +519,11 @@ int gsn_bn_finalize_hip(int64_t n_cols, int64_t m_rows, double eps, double momen
                         const float *beta, float *running_mean, float *running_var, float *mean, float *invstd, float *scale,
                         float *shift, void *stream);
 
+/* The same with nn.BatchNorm1d's `num_batches_tracked` (int64 [1], device; NULL = none) incremented by the kernel. */
+int gsn_bn_finalize_count_hip(int64_t n_cols, int64_t m_rows, double eps, double momentum, const double *stats, const float *gamma,
+                              const float *beta, float *running_mean, float *running_var, float *mean, float *invstd, float *scale,
+                              float *shift, int64_t *num_batches_tracked, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
