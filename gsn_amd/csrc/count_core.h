@@ -211,6 +211,25 @@ GSN_HD int plan_core(const uint32_t *plan) {
     return d > CORE_MAX ? CORE_MAX : d;
 }
 GSN_HD uint32_t plan_ball(const uint32_t *plan, int l) { return (plan[2 + GSN_KMAX + (l >> 2)] >> (8 * (l & 3))) & 0xffu; }
+// closed form of the last two levels (patterns.cpp: plan_tail_mode): 0 none, 1 independent candidate sets, 2 twins
+GSN_HD int plan_tail(const uint32_t *plan) { return (int)((plan[1] >> 28) & 3u); }
+
+// Number of ways to place the last two levels given C1 = the candidates of level k - 2 (levels 0 .. k - 3 are in fvec / used):
+// independent sets: |C1| |C2| - |C1 & C2| with C2 = the candidates of level k - 1 (whose constraints do not name level k - 2);
+// twins: C(|C1|, 2).
+template <int W, bool DIR>
+GSN_HD uint64_t tail_pairs(int mode, const Bits<W> &C1, const uint32_t *plan, int k, const FVec<W> &fvec, const Bits<W> &used, const uint64_t *A,
+                           const uint64_t *valid, const uint64_t *balls, int ball_n, const uint64_t *A_in) {
+    const uint64_t n1 = (uint64_t)popc<W>(C1);
+    if (mode == 2) return n1 * (n1 - (n1 ? 1ull : 0ull)) / 2ull;
+    Bits<W> C2;
+    candidates<W, DIR>(C2, plan[2 + k - 1], plan_ball(plan, k - 1), fvec, used, A, valid, balls, ball_n,
+                       DIR ? plan[PLAN_STRIDE_WORDS + k - 1] : 0u, A_in);
+    int both = 0;
+#pragma unroll
+    for (int w = 0; w < W; ++w) both += popc64(C1.w[w] & C2.w[w]);
+    return n1 * (uint64_t)popc<W>(C2) - (uint64_t)both;
+}
 
 template <int W>
 GSN_HD void bit_set(Bits<W> &b, int v) {
@@ -260,6 +279,10 @@ GSN_HD void lane_begin(Lane<W> &s, const uint32_t *plan, const FVec<W> &fvec_roo
     candidates<W, DIR>(C, plan[2 + s.nfix], plan_ball(plan, s.nfix), s.fvec, s.used, A, valid, s.balls, s.ball_n,
                        DIR ? plan[PLAN_STRIDE_WORDS + s.nfix] : 0u, A_in);
     if (s.nfix == s.k - 1) { s.cnt += (uint64_t)popc<W>(C); return; }
+    if (s.nfix == s.k - 2 && plan_tail(plan)) {
+        s.cnt += tail_pairs<W, DIR>(plan_tail(plan), C, plan, s.k, s.fvec, s.used, A, valid, s.balls, s.ball_n, A_in);
+        return;
+    }
     bool cempty = true;
 #pragma unroll
     for (int w = 0; w < W; ++w) cempty = cempty && (C.w[w] == 0ull);
@@ -298,6 +321,9 @@ GSN_HD void lane_step(Lane<W> &s, const uint64_t *A, const uint64_t *valid, uint
     bool descend = false;
     if (nl == s.k - 1) {
         s.cnt += (uint64_t)popc<W>(C);
+    } else if (nl == s.k - 2 && plan_tail(s.plan)) {
+        // the last two levels in closed form: level k - 2 is not enumerated
+        s.cnt += tail_pairs<W, DIR>(plan_tail(s.plan), C, s.plan, s.k, s.fvec, used2, A, valid, s.balls, s.ball_n, A_in);
     } else {
         bool cempty = true;
 #pragma unroll

@@ -14,7 +14,7 @@ namespace gsn {
 //   header : [0] magic  [1] mode  [2] induced  [3] n_plans  [4] n_cols  [5] kmax  [6] directed_orbits | directed<<1  [7] plans_off
 //   col_ptr: [8 .. 8+n_cols]  plans col_ptr[c]..col_ptr[c+1] all write output column c (plans are sorted by column)
 //   col_order: [9+n_cols .. 9+2 n_cols)  the columns by falling estimated search cost (the order the kernel hands cells out in)
-//   plan p : at plans_off + p*plan_stride(header[6]): [0] k | n_fixed<<8 | out_col<<16     [1] pattern | root_a<<16 | min_degree<<20 | root_b<<24
+//   plan p : at plans_off + p*plan_stride(header[6]): [0] k | n_fixed<<8 | out_col<<16     [1] pattern | root_a<<16 | min_degree<<20 | root_b<<24 | tail_mode<<28 (closed form of the last two levels: patterns.cpp)
 //            [2+l] level l: adj_mask | nonadj_mask<<8 | gt_mask<<16 | lt_mask<<24   (bit j = earlier level j)
 //            [2+KMAX + l/4] byte l%4: distance constraint of level l:  j | r<<3  (r = 0 none, 2 or 3): the image of level
 //                         l must lie within r hops of the image of level j (r = their distance in the pattern)

@@ -105,6 +105,28 @@ struct Plan {
     uint8_t ball[GSN_KMAX];
 };
 
+// Closed form for the LAST TWO levels (count_core.h, lane_step): when the last level's constraints do not name the level before it, the
+// two candidate sets C1, C2 are both known once the levels above are placed, and the number of (u, v), u in C1, v in C2, u != v, is
+// |C1| |C2| - |C1 & C2| -- the last-but-one level need not be enumerated.  Two pendant vertices of a pattern (a star's leaves, the two ends
+// of a path rooted in its middle) end a matching order this way.  When the only link is ONE symmetry-breaking order constraint and the
+// two levels are otherwise constrained alike (twins under the root's stabiliser), the count is C(|C1|, 2).
+//   0 = none, 1 = independent, 2 = twins
+static int plan_tail_mode(const Plan &pl, bool directed) {
+    if (pl.k - pl.n_fixed < 2) return 0;
+    const int a = pl.k - 2, b = pl.k - 1;
+    const uint32_t bit = 1u << a, d1 = pl.level[b], d2 = pl.level[a];
+    const bool ref_adj = (d1 & bit) != 0, ref_non = ((d1 >> 8) & bit) != 0, ref_gt = ((d1 >> 16) & bit) != 0, ref_lt = ((d1 >> 24) & bit) != 0;
+    const bool ball_ref = (pl.ball[b] >> 3) != 0 && (pl.ball[b] & 7) == a;
+    const bool in_ref = directed && ((pl.level_in[b] & bit) != 0 || ((pl.level_in[b] >> 8) & bit) != 0);
+    if (ref_adj || ref_non || ball_ref || in_ref) return 0;
+    if (!ref_gt && !ref_lt) return 1;
+    if (ref_gt != ref_lt) {
+        const uint32_t d1c = d1 & ~((bit << 16) | (bit << 24));
+        if (d1c == d2 && pl.ball[b] == pl.ball[a] && (!directed || pl.level_in[b] == pl.level_in[a])) return 2;
+    }
+    return 0;
+}
+
 // Matching order: fixed roots first, then greedily the unplaced vertex with most placed neighbours (ties: higher degree,
 // lower id) so candidate sets shrink as early as possible.
 static void matching_order(const Pattern &P, const int *fixed, int n_fixed, int *order) {
@@ -404,7 +426,8 @@ extern "C" int gsn_count_plan_build(int mode, int induced, int directed_orbits, 
         uint32_t *w = plan + plans_off + i * stride;
         const Plan &pl = plans[i];
         w[0] = (uint32_t)pl.k | ((uint32_t)pl.n_fixed << 8) | ((uint32_t)pl.out_col << 16);
-        w[1] = (uint32_t)pl.pattern | ((uint32_t)pl.root_a << 16) | ((uint32_t)pl.min_degree << 20) | ((uint32_t)pl.root_b << 24);
+        w[1] = (uint32_t)pl.pattern | ((uint32_t)pl.root_a << 16) | ((uint32_t)pl.min_degree << 20) | ((uint32_t)pl.root_b << 24) |
+               ((uint32_t)plan_tail_mode(pl, directed != 0) << 28);
         for (int l = 0; l < GSN_KMAX; ++l) w[2 + l] = pl.level[l];
         for (int l = 0; l < GSN_KMAX / 4; ++l) w[2 + GSN_KMAX + l] = 0;
         for (int l = 0; l < GSN_KMAX; ++l) w[2 + GSN_KMAX + l / 4] |= (uint32_t)pl.ball[l] << (8 * (l % 4));
