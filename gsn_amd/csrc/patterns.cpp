@@ -121,8 +121,14 @@ static int plan_tail_mode(const Plan &pl, bool directed) {
     if (ref_adj || ref_non || ball_ref || in_ref) return 0;
     if (!ref_gt && !ref_lt) return 1;
     if (ref_gt != ref_lt) {
+        // v > u (or v < u) is the only link.  The pairs are the 2-subsets of C1 iff { v : v fits level b without the link, v > u } =
+        // { v in C1 : v > u } for every u in C1: same adjacency / distance constraints, same order constraints on the other side, and on the
+        // link's side level b may omit bounds that level a has (v > u > f_j makes them hold) but not add any.
         const uint32_t d1c = d1 & ~((bit << 16) | (bit << 24));
-        if (d1c == d2 && pl.ball[b] == pl.ball[a] && (!directed || pl.level_in[b] == pl.level_in[a])) return 2;
+        const bool same_adj = (d1c & 0xffffu) == (d2 & 0xffffu);
+        const uint32_t gt1 = (d1c >> 16) & 0xffu, lt1 = d1c >> 24, gt2 = (d2 >> 16) & 0xffu, lt2 = d2 >> 24;
+        const bool order_ok = ref_gt ? ((gt1 & ~gt2) == 0 && lt1 == lt2) : ((lt1 & ~lt2) == 0 && gt1 == gt2);
+        if (same_adj && order_ok && pl.ball[b] == pl.ball[a] && (!directed || pl.level_in[b] == pl.level_in[a])) return 2;
     }
     return 0;
 }
