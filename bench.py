@@ -418,6 +418,33 @@ def train_step_config4(dev):
     return {"graphs": 4096, "ms_per_step": r["ms_per_step"], "graphs_per_s": r["graphs_per_s"], "parameters": r["parameters"], "workload": r["workload"]}
 
 
+def count_er128(dev):
+    """BASELINE configs[4]: counting only, 512 Erdos-Renyi G(128, 1000) graphs x the 21 connected five-vertex patterns (58 vertex-orbit
+    columns, non-induced), graphs per second of one launch (scripts/bench_counting_er.py is the stand-alone / multi-GPU form)."""
+    import torch
+    from gsn_amd import synth
+    from gsn_amd.counting import CountPlan, count_batch
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "orbits.npz"))
+    pats = [z["all_simple_graphs_5/%d/edges" % i].tolist() for i in range(21)]
+    plan = CountPlan.get(pats, "vertex", False)
+    G = 512
+    b = synth.collate([synth.er_graph(128, 1000, s) for s in range(G)])
+    node_ptr, edge_ptr = torch.from_numpy(b.node_ptr).to(dev), torch.from_numpy(b.edge_ptr).to(dev)
+    ei = torch.from_numpy(b.edge_index).to(dev)
+    out = torch.empty((b.num_nodes, plan.n_cols), dtype=torch.int64, device=dev)
+    f = lambda: count_batch(plan, node_ptr, edge_ptr, ei, ids_are_global=True, max_nodes=128, max_edges=int(np.diff(b.edge_ptr).max()),
+                            device=dev, out=out, check=False)
+    f()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        f()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 3
+    return {"graphs": G, "ms_per_launch": round(dt * 1e3, 3), "graphs_per_s": round(G / dt, 1), "columns": int(plan.n_cols),
+            "occurrence_positions_per_s": round(float(out.sum().item()) / dt, 1)}
+
+
 def linear_d300(dev):
     """The d = 300 node-level dense stage of the ogb layers (196 608 x 300 -> 600, gsn_linear_f16x3_fwd_hip incl. its row pre-pass) against
     the roofs of the pipe it uses: 2.5 PF/s fp16 / 3 plane products = 833 TF/s fp32-equivalent, and 8 TB/s on its algorithmic bytes."""
@@ -680,7 +707,7 @@ def main():
                    "note": "BASELINE configs[1] dataset size: 12 000 ZINC-shaped graphs per step (N=%d, E=%d)" % (b2.num_nodes, b2.num_edges)}
 
     # Supplementary (never `value`): the reference's real batch sizes, the stand-alone aggregation stage, the layer on real-valued inputs
-    small = prop = flt = wide = train4 = lin300 = None
+    small = prop = flt = wide = train4 = lin300 = er128 = None
     if world == 1 and not args.no_extras:
         try:
             small = small_batch_steps(plan, layer, dev)
@@ -706,6 +733,10 @@ def main():
             lin300 = linear_d300(dev)
         except Exception as ex:
             lin300 = {"error": str(ex)[:200]}
+        try:
+            er128 = count_er128(dev)
+        except Exception as ex:
+            er128 = {"error": str(ex)[:200]}
     # every rank's own time of the K steps (the headline takes the maximum): a slow rank shows up by name in the N > 1 line
     per_rank_ms = [round(dt_own / args.steps * 1e3, 4)]
     if dist is not None and world > 1:
@@ -839,6 +870,8 @@ def main():
             extra["train_step_config4"] = train4
         if lin300 is not None:
             extra["linear_f16x3_d300"] = lin300
+        if er128 is not None:
+            extra["count_er128_config5"] = er128
         extra["ms_per_step_by_rank"] = per_rank_ms
         extra["prewarm_steps_untimed"] = int(os.environ.get("GSN_BENCH_PREWARM", "60"))
         if model4 is not None:
