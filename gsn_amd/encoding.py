@@ -205,6 +205,8 @@ _STATUS_RING, _STATUS_NEXT = None, 0
 
 def check_embedding_status(wait=False):
     """Raise IndexError if an embedding launch whose result has arrived saw a code outside its table (wait=True: of any launch so far)."""
+    if _PENDING_STATUS and torch.cuda.is_current_stream_capturing():
+        return                              # (no event queries while a HIP graph is being captured)
     while _PENDING_STATUS and (wait or _PENDING_STATUS[0][0].query()):
         ev, host = _PENDING_STATUS.pop(0)
         if wait:
@@ -220,6 +222,8 @@ def _defer_status(status):
             raise IndexError("index out of range in embedding table")
         return
     global _STATUS_RING, _STATUS_NEXT
+    if torch.cuda.is_current_stream_capturing():
+        return                              # (a captured step cannot report: its out-of-range rows are NaN, gsn_amd.graphs)
     if _STATUS_RING is None:
         _STATUS_RING = torch.zeros(128, dtype=torch.int32).pin_memory()      # (one pinned allocation: slots handed out in turn)
     if len(_PENDING_STATUS) >= 96:

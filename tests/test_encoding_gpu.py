@@ -169,3 +169,19 @@ def test_embedding_tables_on_many_rows_fwd_bwd(rows, dims, d_out, concat):
         gref = torch.zeros(dims[c], d_out, dtype=torch.float64, device="cuda").index_add_(0, x[:, c], wc)
         err = float((t.grad.double() - gref).abs().max())
         assert err <= 2e-5 * float(gref.abs().max()), (c, err, float(gref.abs().max()))
+
+
+def test_embedding_inside_a_captured_graph():
+    """An embedding launch inside a HIP-graph capture (gsn_amd.graphs): the deferred status machinery stays out of the capture, the replay
+    equals the eager result on refilled codes."""
+    from gsn_amd import graphs
+    torch.manual_seed(1)
+    m = encoding.multi_embedding([5, 7], 8, "sum").cuda()
+    codes = torch.stack([torch.randint(0, 5, (300,)), torch.randint(0, 7, (300,))], 1).cuda()
+    with torch.no_grad():
+        step = graphs.GraphedStep(lambda: m(codes), warmup=2)
+        codes.copy_(torch.stack([torch.randint(0, 5, (300,)), torch.randint(0, 7, (300,))], 1).cuda())
+        y = step().clone()
+        want = m(codes)
+    assert torch.equal(y, want)
+    encoding.check_embedding_status(wait=True)
