@@ -45,6 +45,8 @@ struct CountArgs {
     int off_valid, off_stack, off_plan, off_eu, off_ev, off_rowstart, off_last, off_out, off_misc;
     int off_prim, off_revof;   // edge mode: the rows that run searches, in column order; per column the last column of the reverse pair
     int off_ball;              // distance-pruning tables (radius 2, radius 3: n_cap rows each) or -1
+    int off_degp;              // degree bit planes of the cores, [CORE_MAX + 1][DEG_PLANES][W] words (plans with a chain tail), or -1
+    int degp_mask;             // bit d: some chain-tail plan lives in the d-core
     int off_core;              // d-cores of the graph, d = 0 .. CORE_MAX (W words each)
     int core_mask;             // bit d: some plan needs the d-core
     int off_ain;               // directed plans: the in-neighbour bit matrix
@@ -96,6 +98,7 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
     int *misc = reinterpret_cast<int *>(smem + a.off_misc);  // [0] next task  [1] n_active  [2] status
     uint64_t *balls = a.off_ball >= 0 ? reinterpret_cast<uint64_t *>(smem + a.off_ball) : nullptr;
     uint64_t *cores = reinterpret_cast<uint64_t *>(smem + a.off_core);   // [CORE_MAX + 1][W]
+    uint64_t *degp = a.off_degp >= 0 ? reinterpret_cast<uint64_t *>(smem + a.off_degp) : nullptr;
     uint64_t *A_in = DIR ? reinterpret_cast<uint64_t *>(smem + a.off_ain) : nullptr;
     const int *enc = reinterpret_cast<const int *>(smem + a.off_enc);   // [2 * n_cols] (encoded output only)
 
@@ -221,6 +224,18 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
         }
     }
     __syncthreads();
+    // degree bit planes of the cores that hold a chain-tail plan (count_core.h: tail_pairs, mode 3)
+    if (degp) {
+        for (int i = tid; i < (CORE_MAX + 1) * DEG_PLANES * W; i += T) degp[i] = 0ull;
+        __syncthreads();
+        for (int d = 0; d <= CORE_MAX; ++d) {
+            if (!((a.degp_mask >> d) & 1)) continue;
+            for (int v = tid; v < n; v += T)
+                deg_planes_vertex<W>(A, cores + d * W, v, degp + d * DEG_PLANES * W,
+                                     [](uint64_t *wp, uint64_t bit) { atomicOr(reinterpret_cast<unsigned long long *>(wp), (unsigned long long)bit); });
+        }
+        __syncthreads();
+    }
     COUNT_T(2);
     // distance pruning tables: vertices within 2 / 3 hops (count_core.h, candidates())
     if (balls) {
@@ -326,7 +341,7 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
 
     Lane<W> s;
     s.l = -1; s.cnt = 0; s.k = 0; s.nfix = 0; s.fvec = fv_roots<W>(0, 0); s.plan = plans;
-    s.balls = balls; s.ball_n = a.n_cap;
+    s.balls = balls; s.ball_n = a.n_cap; s.degp = degp;
 #pragma unroll
     for (int w = 0; w < W; ++w) s.used.w[w] = 0ull;
     bool has_task = false, exhausted = false;
@@ -622,6 +637,13 @@ static int count_launch(const uint32_t *plan_host, const uint32_t *plan_dev, int
     // everything and the extra AND per step costs more than it saves (measured: ER G(128,1000) +8 %)
     a.off_ball = -1;
     if (W == 1 && a.kmax >= 4 && !directed) { a.off_ball = o; o += align_up(2 * (int)max_nodes * W * 8, 16); }
+    // degree planes only when a plan ends in a chain (patterns.cpp: plan_tail_mode == 3): cycles, cliques -- the molecule workloads -- do not
+    a.off_degp = -1; a.degp_mask = 0;
+    for (int p = 0; p < a.n_plans; ++p) {
+        const uint32_t *w = plan_host + a.plans_off + (int64_t)p * a.stride;
+        if (plan_tail(w) == 3) a.degp_mask |= 1 << plan_core(w);
+    }
+    if (a.degp_mask) { a.off_degp = o; o += align_up((CORE_MAX + 1) * DEG_PLANES * W * 8, 16); }
     a.off_out = o;
     const int64_t stage_bytes = rows_cap_u * a.n_cols * 8;
     // Stage the output rows in LDS (coalesced final write) only while that keeps the workgroup small: the search is

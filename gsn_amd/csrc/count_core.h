@@ -47,6 +47,10 @@ GSN_HD uint64_t below_word(int p, int wi) {
     return wi < pw ? ~0ull : (wi == pw ? ((1ull << (p & 63)) - 1ull) : 0ull);
 }
 
+// bit planes of the vertices' degrees inside each d-core: plane p of core d has bit v set iff bit p of |N(v) & core_d| is set (v in core_d);
+// layout [CORE_MAX + 1][DEG_PLANES][W] words (n <= 768 < 2^10).  sum_{v in S} deg(v) = sum_p 2^p popc(S & plane_p).
+constexpr int DEG_PLANES = 10;
+
 template <int W>
 struct Bits {
     uint64_t w[W];
@@ -191,6 +195,17 @@ GSN_HD bool core_keeps(const uint64_t *A, const uint64_t *core, int v, int d) {
     return c >= d;
 }
 
+// degree planes of ONE vertex v of core d (caller: every v of every needed core; planes zeroed before).  `orfn(word_ptr, bit)` sets a bit.
+template <int W, class OrFn>
+GSN_HD void deg_planes_vertex(const uint64_t *A, const uint64_t *core, int v, uint64_t *planes /* of this core */, OrFn orfn) {
+    if (!((core[v >> 6] >> (v & 63)) & 1ull)) return;
+    int deg = 0;
+#pragma unroll
+    for (int w = 0; w < W; ++w) deg += popc64(A[v * W + w] & core[w]);
+    for (int p = 0; p < DEG_PLANES; ++p)
+        if ((deg >> p) & 1) orfn(planes + p * W + (v >> 6), 1ull << (v & 63));
+}
+
 template <int W>
 struct Lane {
     int l;          // level whose frame is being consumed; < 0: no search in progress
@@ -201,6 +216,7 @@ struct Lane {
     const uint32_t *plan;
     const uint64_t *balls;   // distance-pruning tables of the target graph or nullptr
     int ball_n;              // vertex capacity of one table
+    const uint64_t *degp;    // degree bit planes of the cores (plans with a chain tail) or nullptr
 };
 
 // core index of a plan: images must lie in the min-degree(H) core of the target; cores 0..CORE_MAX are tabulated
@@ -211,7 +227,7 @@ GSN_HD int plan_core(const uint32_t *plan) {
     return d > CORE_MAX ? CORE_MAX : d;
 }
 GSN_HD uint32_t plan_ball(const uint32_t *plan, int l) { return (plan[2 + GSN_KMAX + (l >> 2)] >> (8 * (l & 3))) & 0xffu; }
-// closed form of the last two levels (patterns.cpp: plan_tail_mode): 0 none, 1 independent candidate sets, 2 twins
+// closed form of the last two levels (patterns.cpp: plan_tail_mode): 0 none, 1 independent candidate sets, 2 twins, 3 chain
 GSN_HD int plan_tail(const uint32_t *plan) { return (int)((plan[1] >> 28) & 3u); }
 
 // Number of ways to place the last two levels given C1 = the candidates of level k - 2 (levels 0 .. k - 3 are in fvec / used):
@@ -219,9 +235,29 @@ GSN_HD int plan_tail(const uint32_t *plan) { return (int)((plan[1] >> 28) & 3u);
 // twins: C(|C1|, 2).
 template <int W, bool DIR>
 GSN_HD uint64_t tail_pairs(int mode, const Bits<W> &C1, const uint32_t *plan, int k, const FVec<W> &fvec, const Bits<W> &used, const uint64_t *A,
-                           const uint64_t *valid, const uint64_t *balls, int ball_n, const uint64_t *A_in) {
+                           const uint64_t *valid, const uint64_t *balls, int ball_n, const uint64_t *A_in, const uint64_t *degp) {
     const uint64_t n1 = (uint64_t)popc<W>(C1);
     if (mode == 2) return n1 * (n1 - (n1 ? 1ull : 0ull)) / 2ull;
+    if (mode == 3) {
+        // chain: sum over d in C1 of |N(d) & core \ placed| -- d itself is no neighbour of d, the placed images f_0 .. f_{k-3} are
+        const uint64_t *pl = degp + (size_t)plan_core(plan) * DEG_PLANES * W;
+        uint64_t s = 0;
+#pragma unroll
+        for (int p = 0; p < DEG_PLANES; ++p) {
+            int c = 0;
+#pragma unroll
+            for (int w = 0; w < W; ++w) c += popc64(C1.w[w] & pl[p * W + w]);
+            s += (uint64_t)c << p;
+        }
+        for (int j = 0; j < k - 2; ++j) {
+            const uint64_t *row = A + fv_get<W>(fvec, j) * W;
+            int c = 0;
+#pragma unroll
+            for (int w = 0; w < W; ++w) c += popc64(C1.w[w] & row[w]);
+            s -= (uint64_t)c;
+        }
+        return s;
+    }
     Bits<W> C2;
     candidates<W, DIR>(C2, plan[2 + k - 1], plan_ball(plan, k - 1), fvec, used, A, valid, balls, ball_n,
                        DIR ? plan[PLAN_STRIDE_WORDS + k - 1] : 0u, A_in);
@@ -280,7 +316,7 @@ GSN_HD void lane_begin(Lane<W> &s, const uint32_t *plan, const FVec<W> &fvec_roo
                        DIR ? plan[PLAN_STRIDE_WORDS + s.nfix] : 0u, A_in);
     if (s.nfix == s.k - 1) { s.cnt += (uint64_t)popc<W>(C); return; }
     if (s.nfix == s.k - 2 && plan_tail(plan)) {
-        s.cnt += tail_pairs<W, DIR>(plan_tail(plan), C, plan, s.k, s.fvec, s.used, A, valid, s.balls, s.ball_n, A_in);
+        s.cnt += tail_pairs<W, DIR>(plan_tail(plan), C, plan, s.k, s.fvec, s.used, A, valid, s.balls, s.ball_n, A_in, s.degp);
         return;
     }
     bool cempty = true;
@@ -323,7 +359,7 @@ GSN_HD void lane_step(Lane<W> &s, const uint64_t *A, const uint64_t *valid, uint
         s.cnt += (uint64_t)popc<W>(C);
     } else if (nl == s.k - 2 && plan_tail(s.plan)) {
         // the last two levels in closed form: level k - 2 is not enumerated
-        s.cnt += tail_pairs<W, DIR>(plan_tail(s.plan), C, s.plan, s.k, s.fvec, used2, A, valid, s.balls, s.ball_n, A_in);
+        s.cnt += tail_pairs<W, DIR>(plan_tail(s.plan), C, s.plan, s.k, s.fvec, used2, A, valid, s.balls, s.ball_n, A_in, s.degp);
     } else {
         bool cempty = true;
 #pragma unroll

@@ -110,11 +110,16 @@ struct Plan {
 // |C1| |C2| - |C1 & C2| -- the last-but-one level need not be enumerated.  Two pendant vertices of a pattern (a star's leaves, the two ends
 // of a path rooted in its middle) end a matching order this way.  When the only link is ONE symmetry-breaking order constraint and the
 // two levels are otherwise constrained alike (twins under the root's stabiliser), the count is C(|C1|, 2).
-//   0 = none, 1 = independent, 2 = twins
+// When the last level is a pendant vertex hanging off the level before it and carries no other constraint (a path's far end, the tail of a
+// tadpole), its candidate set for the image d of level k - 2 is N(d) within the plan's core minus the images placed so far, so the
+// placements of both levels are  sum_{d in C1} deg_core(d)  -  sum_{j placed} |N(f_j) & C1|  -- a weighted popcount of C1 over the bit
+// planes of the core degrees (count_core.h: DEG_PLANES, built once per graph) and one AND + popcount per placed level.
+//   0 = none, 1 = independent, 2 = twins, 3 = chain
 static int plan_tail_mode(const Plan &pl, bool directed) {
     if (pl.k - pl.n_fixed < 2) return 0;
     const int a = pl.k - 2, b = pl.k - 1;
     const uint32_t bit = 1u << a, d1 = pl.level[b], d2 = pl.level[a];
+    if (!directed && (d1 & 0xffu) == bit && ((d1 >> 8) & 0xffu) == 0 && (d1 >> 16) == 0) return 3;
     const bool ref_adj = (d1 & bit) != 0, ref_non = ((d1 >> 8) & bit) != 0, ref_gt = ((d1 >> 16) & bit) != 0, ref_lt = ((d1 >> 24) & bit) != 0;
     const bool ball_ref = (pl.ball[b] >> 3) != 0 && (pl.ball[b] & 7) == a;
     const bool in_ref = directed && ((pl.level_in[b] & bit) != 0 || ((pl.level_in[b] >> 8) & bit) != 0);

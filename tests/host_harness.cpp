@@ -54,6 +54,12 @@ static int run(const uint32_t *plan, int64_t n, int64_t E, const int64_t *src, c
             for (int v : drop) { core[v >> 6] &= ~(1ull << (v & 63)); changed = true; }
         }
     }
+    // degree bit planes of every core (count_core.h: tail_pairs, mode 3)
+    std::vector<uint64_t> degp((size_t)(CORE_MAX + 1) * DEG_PLANES * W, 0);
+    for (int d = 0; d <= CORE_MAX; ++d)
+        for (int v = 0; v < (int)n; ++v)
+            deg_planes_vertex<W>(A.data(), cores.data() + (size_t)d * W, v, degp.data() + (size_t)d * DEG_PLANES * W,
+                                 [](uint64_t *wp, uint64_t bit) { *wp |= bit; });
     std::vector<int64_t> last((size_t)(n * n ? n * n : 1), -1);
     for (int64_t c = 0; c < E; ++c) last[(size_t)src[c] * n + dst[c]] = c;
     const int64_t rows = mode == GSN_MODE_EDGE ? E : n;
@@ -61,7 +67,7 @@ static int run(const uint32_t *plan, int64_t n, int64_t E, const int64_t *src, c
     for (int col = 0; col < n_cols; ++col)
         for (int64_t row = 0; row < rows; ++row) {
             Lane<W> s; s.l = -1; s.cnt = 0; s.k = 0; s.nfix = 0; s.fvec = fv_roots<W>(0, 0); s.plan = plans;
-            s.balls = prune ? balls.data() : nullptr; s.ball_n = nb;
+            s.balls = prune ? balls.data() : nullptr; s.ball_n = nb; s.degp = degp.data();
             for (int w = 0; w < W; ++w) s.used.w[w] = 0;
             FVec<W> roots = fv_roots<W>(0, 0); bool live = true, rev_missing = false;
             if (mode == GSN_MODE_EDGE) {
