@@ -47,6 +47,7 @@ struct CountArgs {
     int off_ball;              // distance-pruning tables (radius 2, radius 3: n_cap rows each) or -1
     int off_degp;              // degree bit planes of the cores, [CORE_MAX + 1][DEG_PLANES][W] words (plans with a chain tail), or -1
     int degp_mask;             // bit d: some chain-tail plan lives in the d-core
+    int any_tail;              // some plan ends in a closed form (plan_tail != 0)
     int off_core;              // d-cores of the graph, d = 0 .. CORE_MAX (W words each)
     int core_mask;             // bit d: some plan needs the d-core
     int off_ain;               // directed plans: the in-neighbour bit matrix
@@ -76,7 +77,7 @@ __device__ unsigned long long *g_count_prof;   // [items][8], set by the launche
 // tables, edge ranks: latency of dependent LDS round trips, half of a workgroup's life) are paid once per pair, and the task pool
 // keeps 64 lanes busy twice as long.  report = false (a pair): nothing is reported, a pair that does not fit or holds an error
 // returns 1 and the caller redoes its graphs one by one.
-template <int W, int T, bool DIR>
+template <int W, int T, bool DIR, bool TAIL>
 __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *smem, const int item, const int part, const int g, const int ng, const bool report) {
 #ifdef COUNT_PROF
     unsigned long long t_prev = __builtin_amdgcn_s_memtime();
@@ -403,7 +404,7 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
                 if (p_i < p_e) {
                     const uint32_t *pl = plans + p_i * (DIR ? PLAN_STRIDE_DIRECTED : PLAN_STRIDE_WORDS);
                     lane_valid = cores + plan_core(pl) * W;
-                    lane_begin<W, DIR>(s, pl, roots, A, lane_valid, stack, T, tid, A_in);
+                    lane_begin<W, DIR, TAIL>(s, pl, roots, A, lane_valid, stack, T, tid, A_in);
                     ++p_i;
                 } else {
                     // cell finished
@@ -413,7 +414,7 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
                     has_task = false;
                 }
             } else {
-                lane_step<W, DIR>(s, A, lane_valid, stack, T, tid, A_in);
+                lane_step<W, DIR, TAIL>(s, A, lane_valid, stack, T, tid, A_in);
             }
         }
     }
@@ -468,7 +469,7 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
     return 0;
 }
 
-template <int W, int T, bool DIR>
+template <int W, int T, bool DIR, bool TAIL>
 __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int item = (int)blockIdx.x / a.split, part = (int)blockIdx.x - item * a.split;
@@ -479,7 +480,7 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
     for (int pass = 0; pass < 3; ++pass) {
         const int g = pass == 2 ? g0 + 1 : g0;
         const int ng = (pass == 0 && two) ? 2 : 1;
-        const int rc = count_body<W, T, DIR>(a, smem, item, a.pair ? 0 : part, g, ng, ng == 1);
+        const int rc = count_body<W, T, DIR, TAIL>(a, smem, item, a.pair ? 0 : part, g, ng, ng == 1);
         if (!two || (pass == 0 && rc == 0)) break;
     }
 }
@@ -491,12 +492,12 @@ __global__ void status_zero_kernel(const int32_t *graph_ids, int n, int32_t *sta
 
 static inline int align_up(int x, int a) { return (x + a - 1) / a * a; }
 
-template <int W, int T, bool DIR>
+template <int W, int T, bool DIR, bool TAIL>
 static int launch_d(CountArgs &a, int n_items, size_t lds, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&count_kernel<W, T, DIR>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&count_kernel<W, T, DIR, TAIL>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return set_error(GSN_E_HIP, "hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
-    hipLaunchKernelGGL((count_kernel<W, T, DIR>), dim3((unsigned)n_items), dim3(T), lds, stream, a);
+    hipLaunchKernelGGL((count_kernel<W, T, DIR, TAIL>), dim3((unsigned)n_items), dim3(T), lds, stream, a);
     e = hipGetLastError();
     if (e != hipSuccess) return set_error(GSN_E_HIP, "count_kernel launch: %s", hipGetErrorString(e));
 #ifdef COUNT_PROF
@@ -508,7 +509,7 @@ static int launch_d(CountArgs &a, int n_items, size_t lds, hipStream_t stream) {
             (void)hipMalloc(&buf, (size_t)n_items * 64);
             (void)hipMemset(buf, 0, (size_t)n_items * 64);
             (void)hipMemcpyToSymbol(HIP_SYMBOL(g_count_prof), &buf, sizeof(buf));
-            hipLaunchKernelGGL((count_kernel<W, T, DIR>), dim3((unsigned)n_items), dim3(T), lds, stream, a);
+            hipLaunchKernelGGL((count_kernel<W, T, DIR, TAIL>), dim3((unsigned)n_items), dim3(T), lds, stream, a);
             (void)hipStreamSynchronize(stream);
             unsigned long long *h = new unsigned long long[(size_t)n_items * 8];
             (void)hipMemcpy(h, buf, (size_t)n_items * 64, hipMemcpyDeviceToHost);
@@ -527,7 +528,15 @@ static int launch_d(CountArgs &a, int n_items, size_t lds, hipStream_t stream) {
 }
 template <int W, int T>
 static int launch(CountArgs &a, int n_items, size_t lds, hipStream_t stream) {
-    return a.off_ain >= 0 ? launch_d<W, T, true>(a, n_items, lds, stream) : launch_d<W, T, false>(a, n_items, lds, stream);
+    // TAIL: the instantiation with the closed forms / the tight loop of the last two levels (count_core.h) -- graphs above 64 vertices, or a
+    // plan that ends in a closed form; the molecule workloads with cycle / clique patterns run the instantiation without them
+    if constexpr (W >= 2) {            // (always with the tails: no second instantiation to compile)
+        return a.off_ain >= 0 ? launch_d<W, T, true, true>(a, n_items, lds, stream) : launch_d<W, T, false, true>(a, n_items, lds, stream);
+    } else {
+        const bool tail = a.any_tail != 0;
+        if (a.off_ain >= 0) return tail ? launch_d<W, T, true, true>(a, n_items, lds, stream) : launch_d<W, T, true, false>(a, n_items, lds, stream);
+        return tail ? launch_d<W, T, false, true>(a, n_items, lds, stream) : launch_d<W, T, false, false>(a, n_items, lds, stream);
+    }
 }
 
 }  // namespace gsn
@@ -611,13 +620,15 @@ static int count_launch(const uint32_t *plan_host, const uint32_t *plan_dev, int
     a.off_ain = -1;
     if (directed) { a.off_ain = o; o += align_up((int)max_nodes * W * 8, 16); }
     a.off_valid = o; o += align_up(W * 8, 16);
-    // candidate stack: one frame per enumerated level below the last (levels n_fixed .. k - 2); the frames of the root levels are
+    // candidate stack: one frame per enumerated level below the last (levels n_fixed .. k - 2; .. k - 3 for W >= 2); the frames of the root levels are
     // never touched, so the array starts at the smallest n_fixed of the plans (stack_skip frames in front of it do not exist)
     int nfix_min = 255;
     for (int p = 0; p < a.n_plans; ++p) { const int nf = (int)((plan_host[a.plans_off + (int64_t)p * a.stride] >> 8) & 0xffu); nfix_min = nf < nfix_min ? nf : nfix_min; }
     if (nfix_min > a.kmax - 1 || a.n_plans == 0) nfix_min = 0;
     a.stack_skip = nfix_min;
-    const int depth = a.kmax - 1 - nfix_min > 1 ? a.kmax - 1 - nfix_min : 1;
+    // (W >= 2: levels k - 2 and k - 1 never get a frame -- count_core.h counts them in closed form or in tail_loop)
+    const int last_frame = W >= 2 ? a.kmax - 2 : a.kmax - 1;
+    const int depth = last_frame - nfix_min > 1 ? last_frame - nfix_min : 1;
     a.off_stack = o; o += depth * W * T * 8;
     a.off_plan = o; o += align_up((int)plan_words * 4, 16);
     const int vid_bytes = W > 4 ? 2 : 1;
@@ -638,9 +649,10 @@ static int count_launch(const uint32_t *plan_host, const uint32_t *plan_dev, int
     a.off_ball = -1;
     if (W == 1 && a.kmax >= 4 && !directed) { a.off_ball = o; o += align_up(2 * (int)max_nodes * W * 8, 16); }
     // degree planes only when a plan ends in a chain (patterns.cpp: plan_tail_mode == 3): cycles, cliques -- the molecule workloads -- do not
-    a.off_degp = -1; a.degp_mask = 0;
+    a.off_degp = -1; a.degp_mask = 0; a.any_tail = 0;
     for (int p = 0; p < a.n_plans; ++p) {
         const uint32_t *w = plan_host + a.plans_off + (int64_t)p * a.stride;
+        if (plan_tail(w)) a.any_tail = 1;
         if (plan_tail(w) == 3) a.degp_mask |= 1 << plan_core(w);
     }
     if (a.degp_mask) { a.off_degp = o; o += align_up((CORE_MAX + 1) * DEG_PLANES * W * 8, 16); }
