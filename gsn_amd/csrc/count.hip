@@ -469,8 +469,12 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
     return 0;
 }
 
+// COUNT_WAVES: waves per SIMD the register allocator must leave room for in the one-wave molecule instantiation (83 registers = 5 waves)
+#ifndef COUNT_WAVES
+#define COUNT_WAVES 5
+#endif
 template <int W, int T, bool DIR, bool TAIL>
-__global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
+__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu((W == 1 && T == 64 && !TAIL) ? COUNT_WAVES : 1))) void count_kernel(CountArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int item = (int)blockIdx.x / a.split, part = (int)blockIdx.x - item * a.split;
     // one call site (the body is inlined once): pass 0 = the graph, or the pair 2 i, 2 i + 1 as one; passes 1, 2 = the pair's graphs one by
