@@ -670,8 +670,9 @@ static int count_launch(const uint32_t *plan_host, const uint32_t *plan_dev, int
     // few heavy graphs: several workgroups per graph so that every CU gets >= 8 of them
     a.split = 1;
     const int64_t tasks_cap = rows_cap * a.n_cols;
-    if (!pair && n_items < 2048 && tasks_cap >= 1024) {
-        int64_t sp = (2048 + n_items - 1) / n_items;
+    static const int64_t split_target = [] { const char *e = getenv("GSN_COUNT_SPLIT_TARGET"); const int64_t v = e ? atoll(e) : 0; return v > 0 ? v : (int64_t)2048; }();
+    if (!pair && n_items < split_target && tasks_cap >= 1024) {
+        int64_t sp = (split_target + n_items - 1) / n_items;
         if (sp > 32) sp = 32;
         if (sp > tasks_cap / 256) sp = tasks_cap / 256;
         if (sp > 1) { a.split = (int)sp; a.stage_out = 0; }
