@@ -460,3 +460,42 @@ def test_fused_encoding_on_split_graphs(mode):
         _, _, enc2 = count_batch(plan, b.node_ptr, b.edge_ptr, b.edge_index, encode=(n_classes, clamp), counts=False)
         assert torch.equal(enc2, want)
     assert int(ref.max()) > 7          # (the clamp matters)
+
+
+PENDANT_PATTERNS = {
+    "star4": [(0, 1), (0, 2), (0, 3), (0, 4)],                       # four twin leaves
+    "path5": [(0, 1), (1, 2), (2, 3), (3, 4)],                       # chain tail from an end, independent ends from the middle
+    "fork": [(0, 1), (1, 2), (2, 3), (2, 4)],                        # two twin leaves on the far end of a path
+    "tadpole32": [(0, 1), (1, 2), (2, 0), (2, 3), (3, 4)],           # triangle with a tail of two
+    "c4_pendant": [(0, 1), (1, 2), (2, 3), (3, 0), (0, 4)],
+    "bull": [(0, 1), (1, 2), (2, 0), (0, 3), (1, 4)],                # two independent pendants on a triangle
+    "spider6": [(0, 1), (0, 2), (0, 3), (1, 4), (2, 5)],             # six vertices: pendants at different depths
+}
+
+
+@pytest.mark.parametrize("mode", ["vertex", "edge"])
+@pytest.mark.parametrize("induced", [False, True])
+def test_closed_form_tails_vs_oracle(mode, induced):
+    """The last two levels of a rooted search in closed form / in one tight loop (count_core.h: tail_pairs, tail_loop; round 3): patterns
+    with pendant vertices on molecule-sized graphs (one bit-matrix word: the TAIL instantiation of the one-wave kernel), on ER graphs
+    of 100-128 vertices (two words: closed forms + the tight loop, one frame fewer) and of 200 vertices (four words), non-induced (closed
+    forms apply) and induced (they do not: same counts through the generic levels / the loop) -- bit-exact against the oracle.  The plan
+    table of the non-induced run holds every closed-form kind."""
+    from gsn_amd import synth
+    from gsn_amd.counting import CountPlan, counts2ids_batch
+    from oracle import oracle
+    pats = [PENDANT_PATTERNS[k] for k in sorted(PENDANT_PATTERNS)]
+    if not induced:
+        plan = CountPlan.get(pats, mode, False)
+        arr = next(v for v in (getattr(plan, n) for n in dir(plan)) if isinstance(v, np.ndarray) and v.dtype == np.uint32)
+        n_plans, plans_off = int(arr[3]), int(arr[7])
+        kinds = {(int(arr[plans_off + i * 12 + 1]) >> 28) & 3 for i in range(n_plans)}
+        assert kinds == {0, 1, 2, 3}, kinds
+    batches = [synth.zinc_shape_batch(40, seed=5),
+               synth.collate([synth.er_graph(128, 700, 11), synth.er_graph(100, 420, 12), synth.er_graph(90, 200, 13), synth.er_graph(65, 64, 14)]),
+               synth.collate([synth.er_graph(200, 900, 21), synth.er_graph(150, 300, 22)])]
+    for b in batches:
+        got = counts2ids_batch(b, pats, mode, induced).cpu().numpy()
+        local = b.edge_index - np.repeat(b.node_ptr[:-1], np.diff(b.edge_ptr))[None, :]
+        ref = oracle.counts2ids(mode, induced, b.node_ptr, b.edge_ptr, local, pats, n_threads=8)
+        assert np.array_equal(got, ref), (mode, induced, b.num_nodes)
