@@ -287,3 +287,37 @@ def test_register_resident_layer_kernels_build_without_spills(tmp_path):
         hits = [(n, int(v)) for n, v in blocks if kernel in n]
         assert hits, name
         assert all(v <= allowed for _, v in hits), hits
+
+
+@pytest.mark.parametrize("mode", ["vertex", "edge"])
+@pytest.mark.parametrize("induced", [False, True])
+def test_closed_form_tails_of_the_search_core_on_host(lib, harness, mode, induced):
+    """count_core.h's closed forms of the last two levels (independent pendants, twins, chain tails through degree bit planes) and its tight
+    tail loop, run on the host by the test-only harness against the oracle: patterns with pendant vertices on molecule-shaped graphs and on
+    Erdos-Renyi graphs of 70 / 130 vertices (one / two / four-word bit rows).  (The same patterns on the GPU: test_count_gpu.py.)"""
+    from gsn_amd import synth
+    from gsn_amd.counting import CountPlan
+    from oracle import oracle
+    pats = [[(0, 1), (0, 2), (0, 3), (0, 4)], [(0, 1), (1, 2), (2, 3), (3, 4)], [(0, 1), (1, 2), (2, 3), (2, 4)],
+            [(0, 1), (1, 2), (2, 0), (2, 3), (3, 4)], [(0, 1), (1, 2), (2, 3), (3, 0), (0, 4)], [(0, 1), (1, 2), (2, 0), (0, 3), (1, 4)],
+            [(0, 1), (0, 2), (0, 3), (1, 4), (2, 5)]]
+    plan = CountPlan(pats, mode, induced, False)
+    n_plans, plans_off = int(plan.table[3]), int(plan.table[7])
+    kinds = {(int(plan.table[plans_off + i * 12 + 1]) >> 28) & 3 for i in range(n_plans)}
+    assert kinds == ({0} if induced else {0, 1, 2, 3}), kinds
+    b0 = synth.zinc_shape_batch(6, seed=3)
+    graphs = [(int(b0.node_ptr[g + 1] - b0.node_ptr[g]), b0.edge_index[:, b0.edge_ptr[g]:b0.edge_ptr[g + 1]] - b0.node_ptr[g]) for g in range(6)]
+    for n_, m_, s_ in ((70, 160, 1), (130, 300, 2), (40, 200, 3)):
+        n_g, ei_g = synth.er_graph(n_, m_, s_)
+        graphs.append((n_g, np.asarray(ei_g)))
+    I64P, U32P = ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_uint32)
+    for n, ei in graphs:
+        ei = np.ascontiguousarray(ei.astype(np.int64))
+        E = ei.shape[1]
+        src, dst = np.ascontiguousarray(ei[0]), np.ascontiguousarray(ei[1])
+        out = np.zeros((E if mode == "edge" else n, plan.n_cols), dtype=np.int64)
+        st = harness.harness_count(plan.table.ctypes.data_as(U32P), ctypes.c_int64(n), ctypes.c_int64(E),
+                                   src.ctypes.data_as(I64P), dst.ctypes.data_as(I64P), out.ctypes.data_as(I64P))
+        assert st == 0
+        ref = oracle.counts2ids(mode, induced, np.array([0, n], dtype=np.int64), np.array([0, E], dtype=np.int64), ei, pats, n_threads=4)
+        assert np.array_equal(out, ref), (mode, induced, n)
