@@ -269,6 +269,7 @@ struct Lane {
     const uint64_t *balls;   // distance-pruning tables of the target graph or nullptr
     int ball_n;              // vertex capacity of one table
     const uint64_t *degp;    // degree bit planes of the cores (plans with a chain tail) or nullptr
+    int loop;                // W == 1: the last two levels in tail_loop all the same (dense small graphs: the launcher decides)
 };
 
 // core index of a plan: images must lie in the min-degree(H) core of the target; cores 0..CORE_MAX are tabulated
@@ -369,7 +370,7 @@ GSN_HD void lane_begin(Lane<W> &s, const uint32_t *plan, const FVec<W> &fvec_roo
     candidates<W, DIR>(C, plan[2 + s.nfix], plan_ball(plan, s.nfix), s.fvec, s.used, A, valid, s.balls, s.ball_n,
                        DIR ? plan[PLAN_STRIDE_WORDS + s.nfix] : 0u, A_in);
     if (s.nfix == s.k - 1) { s.cnt += (uint64_t)popc<W>(C); return; }
-    if (TAIL && s.nfix == s.k - 2 && (TailLoop<W>::on || plan_tail(plan))) {     // the last two levels: closed form or one tight loop, no frame
+    if (TAIL && s.nfix == s.k - 2 && (TailLoop<W>::on || s.loop || plan_tail(plan))) {     // the last two levels: closed form or one tight loop, no frame
         const int tm = plan_tail(plan);
         s.cnt += tm ? tail_pairs<W, DIR>(tm, C, plan, s.k, s.fvec, s.used, A, valid, s.balls, s.ball_n, A_in, s.degp)
                     : tail_loop<W, DIR>(C, plan, s.k, s.fvec, s.used, A, valid, s.balls, s.ball_n, A_in);
@@ -413,7 +414,7 @@ GSN_HD void lane_step(Lane<W> &s, const uint64_t *A, const uint64_t *valid, uint
     bool descend = false;
     if (nl == s.k - 1) {
         s.cnt += (uint64_t)popc<W>(C);
-    } else if (TAIL && nl == s.k - 2 && (TailLoop<W>::on || plan_tail(s.plan))) {
+    } else if (TAIL && nl == s.k - 2 && (TailLoop<W>::on || s.loop || plan_tail(s.plan))) {
         // the last two levels: in closed form where the plan allows it (level k - 2 is not enumerated), else in one tight loop over its images
         const int tm = plan_tail(s.plan);
         s.cnt += tm ? tail_pairs<W, DIR>(tm, C, s.plan, s.k, s.fvec, used2, A, valid, s.balls, s.ball_n, A_in, s.degp)

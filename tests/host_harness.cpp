@@ -67,7 +67,7 @@ static int run(const uint32_t *plan, int64_t n, int64_t E, const int64_t *src, c
     for (int col = 0; col < n_cols; ++col)
         for (int64_t row = 0; row < rows; ++row) {
             Lane<W> s; s.l = -1; s.cnt = 0; s.k = 0; s.nfix = 0; s.fvec = fv_roots<W>(0, 0); s.plan = plans;
-            s.balls = prune ? balls.data() : nullptr; s.ball_n = nb; s.degp = degp.data();
+            s.balls = prune ? balls.data() : nullptr; s.ball_n = nb; s.degp = degp.data(); s.loop = getenv("GSN_HARNESS_TAIL_LOOP") ? 1 : 0;
             for (int w = 0; w < W; ++w) s.used.w[w] = 0;
             FVec<W> roots = fv_roots<W>(0, 0); bool live = true, rev_missing = false;
             if (mode == GSN_MODE_EDGE) {
