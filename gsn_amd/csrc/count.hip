@@ -100,7 +100,7 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
     int *misc = reinterpret_cast<int *>(smem + a.off_misc);  // [0] next task  [1] n_active  [2] status
     uint64_t *balls = a.off_ball >= 0 ? reinterpret_cast<uint64_t *>(smem + a.off_ball) : nullptr;
     uint64_t *cores = reinterpret_cast<uint64_t *>(smem + a.off_core);   // [CORE_MAX + 1][W]
-    uint64_t *degp = a.off_degp >= 0 ? reinterpret_cast<uint64_t *>(smem + a.off_degp) : nullptr;
+    uint64_t *degp = (TAIL && a.off_degp >= 0) ? reinterpret_cast<uint64_t *>(smem + a.off_degp) : nullptr;     // (TAIL = false: none of this exists)
     uint64_t *A_in = DIR ? reinterpret_cast<uint64_t *>(smem + a.off_ain) : nullptr;
     const int *enc = reinterpret_cast<const int *>(smem + a.off_enc);   // [2 * n_cols] (encoded output only)
 
@@ -227,7 +227,7 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
     }
     __syncthreads();
     // degree bit planes of the cores that hold a chain-tail plan (count_core.h: tail_pairs, mode 3)
-    if (degp) {
+    if (TAIL && degp) {
         for (int i = tid; i < (CORE_MAX + 1) * DEG_PLANES * W; i += T) degp[i] = 0ull;
         __syncthreads();
         for (int d = 0; d <= CORE_MAX; ++d) {
@@ -343,7 +343,8 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
 
     Lane<W> s;
     s.l = -1; s.cnt = 0; s.k = 0; s.nfix = 0; s.fvec = fv_roots<W>(0, 0); s.plan = plans;
-    s.balls = balls; s.ball_n = a.n_cap; s.degp = degp; s.loop = a.tail_loop;
+    s.balls = balls; s.ball_n = a.n_cap; s.degp = nullptr; s.loop = 0;
+    if (TAIL) { s.degp = degp; s.loop = a.tail_loop; }
 #pragma unroll
     for (int w = 0; w < W; ++w) s.used.w[w] = 0ull;
     bool has_task = false, exhausted = false;
@@ -470,12 +471,11 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
     return 0;
 }
 
-// COUNT_WAVES: waves per SIMD the register allocator must leave room for in the one-wave molecule instantiation (83 registers = 5 waves)
-#ifndef COUNT_WAVES
-#define COUNT_WAVES 5
-#endif
+// (Measured and dropped: amdgpu_waves_per_eu(6 / 7) on the molecule instantiation spills 72 / 104 bytes per lane for 1.4 / 2 % on the kernel
+//  and 0.5 % on the step; even a bound of 5 -- no tighter than what the allocator picks by itself -- changed its choices: 94 registers and
+//  36 bytes of scratch instead of 83 and none, +3 % kernel time.  No occupancy attribute.)
 template <int W, int T, bool DIR, bool TAIL>
-__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu((W == 1 && T == 64 && !TAIL) ? COUNT_WAVES : 1))) void count_kernel(CountArgs a) {
+__global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int item = (int)blockIdx.x / a.split, part = (int)blockIdx.x - item * a.split;
     // one call site (the body is inlined once): pass 0 = the graph, or the pair 2 i, 2 i + 1 as one; passes 1, 2 = the pair's graphs one by
