@@ -249,3 +249,32 @@ def test_edge_less_batches_give_the_zero_gradients_pytorch_gives(seed):
     desc, bad = r
     assert " E=0" in desc, desc
     assert not bad, (desc, bad)
+
+
+@pytest.mark.parametrize("name", ["general_local", "gin_local_embedding_extend", "ogb_local"])
+def test_eval_mode_gradients_with_frozen_batchnorm_parameters(name):
+    """Frozen-BatchNorm fine-tuning: the layer in eval mode AND gamma / beta without gradients -- the eval-mode stage is then a per-column
+    affine epilogue of the product (no pre-BatchNorm rows are kept: _DenseStagesFn's `affine` stage, gsn_bn_act_bwd_hip with train_bn = 0
+    and coef = gamma * invstd); every other gradient equals autograd over the oracle, BatchNorm's parameters get none."""
+    cls, ctor, layer, x, ei, kw = _setup(name)
+    layer.eval()
+    for m in layer.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.weight.requires_grad_(False); m.bias.requires_grad_(False)
+    yr, w, gx_ref, gkw_ref, gw_ref = _oracle_grads(cls, ctor, layer, x, ei, kw)
+    gw_ref = {k: g for k, g in gw_ref.items() if ".bn." not in k}          # (the oracle differentiates everything: BatchNorm's are not asked for here)
+    layer.cuda()
+    xg = x.cuda().requires_grad_(True)
+    kwg = {k: v.cuda().requires_grad_(True) for k, v in kw.items()}
+    y = layer(xg, ei.cuda(), degrees=torch.zeros(x.shape[0], device="cuda"), **kwg)
+    (y * w.cuda()).sum().backward()
+    assert float((y.detach().cpu() - yr).abs().max()) <= 1e-5 * float(yr.abs().max())
+    assert float((xg.grad.cpu() - gx_ref).abs().max()) <= 2e-5 * float(gx_ref.abs().max())
+    gmax = max(float(g.abs().max()) for g in gw_ref.values())
+    got = dict(layer.named_parameters())
+    for k, g in gw_ref.items():
+        assert got[k].grad is not None, k
+        assert float((got[k].grad.cpu() - g).abs().max()) <= 2e-5 * gmax, k
+    for k, p in got.items():
+        if ".bn." in k:
+            assert p.grad is None, k
