@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 
 #include "gsn_internal.h"
 
@@ -533,11 +534,199 @@ extern "C" int gsn_embed_fwd_hip(int64_t m_rows, int n_cols, int d, int concat, 
     return GSN_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Summed-embedding backward on the matrix pipe (r03).  gT_c[r][:] = sum over the rows m with code[m][c] = r of g[m][:]  is the product
+// OneHot(codes)^T g: the one-hot operand is made in registers from the codes (1.0 is exact in bf16: ONE plane), g is split exactly into
+// three bf16 planes while it is staged (the weight-gradient kernel's skeleton, backward.hip: contraction over the rows, operands
+// transposed for free in the staging registers), three products per tile pair, fp32 accumulation.  The concatenated table rows of all
+// code columns are the output rows; tiles of 128 table rows x 128 embedding columns, row slabs per workgroup, float atomics at the end.
+// Why: the LDS-accumulating kernel above keeps one table copy per wave -- tables of more than ~100 rows leave room for ONE wave per
+// workgroup (identifier codes of the ogb model: 298 us per call at 214 k x 300); this one reads g once per 128 table rows at memory speed.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace gsn {
+typedef float emb_f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned emb_u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 emb_bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int EMBM_T = 128;
+
+struct EmbMArgs {
+    int64_t m_rows, rows_per_wg;
+    int n_cols, d, rtot, tn, tk;
+    const int64_t *codes;
+    const int64_t *meta;           // gradient table pointers (device)
+    int row_off[EMB_MAXC + 1];
+    const float *gout;
+};
+
+__device__ __forceinline__ void embm_split3(float x, unsigned &h, unsigned &m, unsigned &l) {
+    h = __float_as_uint(x);
+    const float r1 = x - __uint_as_float(h & 0xffff0000u);
+    m = __float_as_uint(r1);
+    l = __float_as_uint(r1 - __uint_as_float(m & 0xffff0000u));
+}
+__device__ __forceinline__ unsigned embm_pack_hi(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+
+__global__ __launch_bounds__(256) void embed_bwd_mfma_kernel(EmbMArgs a) {
+    __shared__ emb_u32x4 tb[2][3][EMBM_T][2];           // [buffer][plane][embedding column][row half]: 8 bf16 = rows 8 h .. 8 h + 7 of the chunk
+    __shared__ emb_u32x4 tc[2][EMB_MAXC][2];            // [buffer][code column][row half]: 8 int16 codes of those rows (0xffff = none)
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int ntile = a.tn * a.tk;
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int tile = seq % ntile;
+    const int64_t slab = (int64_t)(seq / ntile) * 8 + xcd;
+    const int n0 = (tile / a.tk) * EMBM_T, k0 = (tile % a.tk) * EMBM_T;
+    const int64_t r_begin = slab * a.rows_per_wg;
+    int64_t r_end = r_begin + a.rows_per_wg;
+    if (r_end > a.m_rows) r_end = a.m_rows;
+    if (r_begin >= r_end) return;                 // (block-uniform)
+
+    // this lane's two output rows (concatenated table rows): which code column they belong to and the code that selects them
+    int my_col[2], my_code[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int i = n0 + wm * 64 + t * 32 + li;
+        int c = 0;
+        for (int q = 1; q < a.n_cols; ++q) c = i >= a.row_off[q] ? q : c;
+        my_col[t] = c;
+        my_code[t] = i < a.rtot ? i - a.row_off[c] : 0xfffe;       // (rows past the tables match nothing: codes are < 0xfffe)
+    }
+    const int sc = tid & 127, sh = tid >> 7;      // staging: embedding column sc, rows 8 sh .. 8 sh + 7 of a 16-row chunk
+    const int kb = k0 + sc;
+    const bool kb_ok = kb < a.d;
+    const float *xb = a.gout + (kb_ok ? kb : 0);
+    // codes: thread (column c = tid >> 4, row = tid & 15) for tid < 16 n_cols
+    const int cc = tid >> 4, cr = tid & 15;
+    const bool c_ok = cc < a.n_cols;
+    const int rows_cc = c_ok ? a.row_off[cc + 1] - a.row_off[cc] : 0;
+
+    emb_f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float pb[8];
+    int64_t pcode = 0;
+    auto fetch = [&](int64_t row0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int64_t r = row0 + 8 * sh + i;
+            const int64_t rc = r < r_end ? r : r_begin;
+            pb[i] = xb[rc * a.d];
+        }
+        if (c_ok) { const int64_t r = row0 + cr; pcode = a.codes[(r < r_end ? r : r_begin) * a.n_cols + cc]; }
+    };
+    auto store = [&](int buf, int64_t row0) {
+        unsigned h[8], m[8], l[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bool ok = kb_ok && (row0 + 8 * sh + i < r_end);
+            embm_split3(ok ? pb[i] : 0.f, h[i], m[i], l[i]);
+        }
+        emb_u32x4 ph, pm, pl;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ph[i] = embm_pack_hi(h[2 * i], h[2 * i + 1]);
+            pm[i] = embm_pack_hi(m[2 * i], m[2 * i + 1]);
+            pl[i] = embm_pack_hi(l[2 * i], l[2 * i + 1]);
+        }
+        tb[buf][0][sc][sh] = ph;
+        tb[buf][1][sc][sh] = pm;
+        tb[buf][2][sc][sh] = pl;
+        if (c_ok) {
+            const bool ok = row0 + cr < r_end && pcode >= 0 && pcode < rows_cc;
+            reinterpret_cast<unsigned short *>(&tc[buf][cc][0])[cr] = ok ? (unsigned short)pcode : (unsigned short)0xffffu;
+        }
+    };
+    fetch(r_begin);
+    store(0, r_begin);
+    __syncthreads();
+    int buf = 0;
+#define EMBM_MF(x, y, c) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(emb_bf16x8, x), __builtin_bit_cast(emb_bf16x8, y), c, 0, 0, 0)
+    for (int64_t row0 = r_begin; row0 < r_end; row0 += 16) {
+        const bool has_next = row0 + 16 < r_end;
+        if (has_next) fetch(row0 + 16);
+        // the one-hot operand of this lane's two output rows: 1.0 (bf16 0x3f80) where the row's code selects it
+        emb_u32x4 fa[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const emb_u32x4 cd = tc[buf][my_col[t]][lh];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned lo = cd[q] & 0xffffu, hi = cd[q] >> 16;
+                fa[t][q] = ((int)lo == my_code[t] ? 0x3f80u : 0u) | ((int)hi == my_code[t] ? 0x3f800000u : 0u);
+            }
+        }
+        emb_u32x4 fb[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) fb[i][pl] = tb[buf][pl][wn * 64 + i * 32 + li][lh];
+#pragma unroll
+        for (int pl = 2; pl >= 0; --pl) {            // low plane first
+            EMBM_MF(fa[0], fb[0][pl], acc[0][0]);
+            EMBM_MF(fa[0], fb[1][pl], acc[0][1]);
+            EMBM_MF(fa[1], fb[0][pl], acc[1][0]);
+            EMBM_MF(fa[1], fb[1][pl], acc[1][1]);
+        }
+        if (has_next) store(buf ^ 1, row0 + 16);
+        __syncthreads();
+        buf ^= 1;
+    }
+#undef EMBM_MF
+    // C layout of a 32x32 tile: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5); rows = concatenated table rows
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int nrow = n0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (nrow >= a.rtot) continue;
+            int c = 0;
+            for (int q = 1; q < a.n_cols; ++q) c = nrow >= a.row_off[q] ? q : c;
+            float *t = reinterpret_cast<float *>(a.meta[c]) + (int64_t)(nrow - a.row_off[c]) * a.d;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int kcol = k0 + wn * 64 + j * 32 + li;
+                const float v = acc[i][j][r];
+                if (kcol < a.d && v != 0.f) atomicAdd(t + kcol, v);
+            }
+        }
+}
+}  // namespace gsn
+
 extern "C" int gsn_embed_bwd_hip(int64_t m_rows, int n_cols, int d, int concat, const int64_t *codes, const int64_t *grad_meta,
                                  const int64_t *table_rows, const float *grad_out, void *stream) {
     if (n_cols < 1 || d < 1 || !grad_meta || !table_rows || (m_rows > 0 && (!codes || !grad_out)))
         return set_error(GSN_E_INVALID, "gsn_embed_bwd_hip: bad arguments");
     if (m_rows <= 0) return GSN_OK;
+    {   // summed embeddings of enough rows: the one-hot product on the matrix pipe (GSN_EMBED_BWD_LDS=1: the LDS-accumulating kernel)
+        static const bool lds_only = [] { const char *e = getenv("GSN_EMBED_BWD_LDS"); return e && e[0] == '1'; }();
+        int64_t rtot = 0;
+        bool small_tables = n_cols <= EMB_MAXC;
+        for (int c = 0; small_tables && c < n_cols; ++c) { rtot += table_rows[c]; small_tables = table_rows[c] > 0 && table_rows[c] < 0xfffe; }
+        if (!lds_only && !concat && small_tables && rtot <= 4096 && m_rows >= 4096) {
+            EmbMArgs a{};
+            a.m_rows = m_rows; a.n_cols = n_cols; a.d = d; a.rtot = (int)rtot; a.codes = codes; a.meta = grad_meta; a.gout = grad_out;
+            a.row_off[0] = 0;
+            for (int c = 0; c < n_cols; ++c) a.row_off[c + 1] = a.row_off[c] + (int)table_rows[c];
+            a.tn = (int)((rtot + EMBM_T - 1) / EMBM_T); a.tk = (d + EMBM_T - 1) / EMBM_T;
+            const int nt = a.tn * a.tk;
+            int64_t slabs = (2048 + nt - 1) / nt;
+            int64_t rows_per = (m_rows + slabs - 1) / slabs;
+            if (rows_per < 256) rows_per = 256;
+            rows_per = (rows_per + 15) / 16 * 16;
+            a.rows_per_wg = rows_per;
+            slabs = (m_rows + rows_per - 1) / rows_per;
+            const int64_t groups = (slabs + 7) / 8;
+            hipLaunchKernelGGL(embed_bwd_mfma_kernel, dim3((unsigned)(groups * nt * 8)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+            GSN_LAUNCH_CHECK("embed_bwd_mfma_kernel");
+            return GSN_OK;
+        }
+    }
     if (embed_lds_fits(n_cols, table_rows)) {
         EmbArgs a{};
         a.m_rows = m_rows; a.n_cols = n_cols; a.d = d; a.concat = concat; a.codes = codes; a.meta = grad_meta; a.gout = grad_out;

@@ -428,7 +428,8 @@ int gsn_column_ranks_hip(int64_t m_rows, int n_cols, const int64_t *values, cons
  * GSN_ST_BAD_INDEX when a code is outside its table (that row's values are NaN).  bwd accumulates grad_out into the gradient tables named by
  * grad_meta (caller zero-fills them).  table_rows = the row counts again as a HOST array [C] (NULL allowed in fwd): they
  * pick the kernel -- tables that together have <= 448 rows are held in LDS per workgroup (64-wide slices), larger ones
- * are read / accumulated in HBM.
+ * are read / accumulated in HBM; the backward of summed embeddings over >= 4096 rows is the product OneHot(codes)^T grad_out on the
+ * matrix pipe (exact bf16 planes, fp32 accumulation).
  * ---------------------------------------------------------------------------------------------------------------- */
 int gsn_embed_fwd_hip(int64_t m_rows, int n_cols, int d, int concat, const int64_t *codes, const int64_t *meta,
                       const int64_t *table_rows, float *out, int32_t *status, void *stream);

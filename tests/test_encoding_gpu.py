@@ -185,3 +185,24 @@ def test_embedding_inside_a_captured_graph():
         want = m(codes)
     assert torch.equal(y, want)
     encoding.check_embedding_status(wait=True)
+
+
+@pytest.mark.parametrize("m_rows,dims,d", [(20000, [37], 300), (9000, [5, 6, 2], 300), (12345, [119, 4, 12, 12, 10, 6, 6, 2, 2], 300),
+                                           (5000, [300, 7], 64), (4100, [3], 7), (70000, [448], 128)])
+def test_summed_embedding_backward_on_the_matrix_pipe(m_rows, dims, d):
+    """gsn_embed_bwd_hip for summed embeddings of >= 4096 rows: OneHot(codes)^T g as bf16 plane products (embed_bwd_mfma_kernel) against an
+    fp64 index_add -- tables of 2 .. 448 rows, one to nine code columns, widths that are not multiples of the tile, gradients with a wide
+    range of magnitudes; and against the LDS-accumulating kernel through the module's backward at a size below the switch."""
+    torch.manual_seed(m_rows)
+    m = encoding.multi_embedding(list(dims), d, "sum").cuda()
+    codes = torch.stack([torch.randint(0, n, (m_rows,)) for n in dims], 1).cuda()
+    if len(dims) == 1:
+        codes[: m_rows // 2, 0] = 0                     # (one heavy row: half of the batch lands on it)
+    y = m(codes)
+    g = (torch.randn(m_rows, d, device="cuda") * torch.logspace(-4, 4, d, device="cuda")).contiguous()
+    y.backward(g)
+    for c, (name, p) in enumerate(m.named_parameters()):
+        ref = torch.zeros(p.shape, dtype=torch.float64, device="cuda").index_add_(0, codes[:, c], g.double())
+        bound = torch.zeros(p.shape, dtype=torch.float64, device="cuda").index_add_(0, codes[:, c], g.double().abs())
+        err = ((p.grad.double() - ref).abs() / bound.clamp_min(1e-300)).max().item()
+        assert err <= 3e-7 * max(1.0, (m_rows / dims[c]) ** 0.5), (name, err)
