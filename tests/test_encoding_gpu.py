@@ -171,6 +171,7 @@ def test_embedding_tables_on_many_rows_fwd_bwd(rows, dims, d_out, concat):
         assert err <= 2e-5 * float(gref.abs().max()), (c, err, float(gref.abs().max()))
 
 
+@pytest.mark.skipif(os.environ.get("PYTORCH_NO_CUDA_MEMORY_CACHING") == "1", reason="stream capture cannot free memory without the caching allocator (scripts/oob_check.sh)")
 def test_embedding_inside_a_captured_graph():
     """An embedding launch inside a HIP-graph capture (gsn_amd.graphs): the deferred status machinery stays out of the capture, the replay
     equals the eager result on refilled codes."""

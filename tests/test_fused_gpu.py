@@ -3,6 +3,8 @@ plain fp32 restatement of the reference layers, against the multi-launch path of
 every branch of the tile iterator (one chunk per tile, several chunks per tile, hubs, isolated nodes, tiny batches) and both
 operand paths (rows exact in fp16 / rows that need the power-of-two row scale)."""
 import numpy as np
+import os
+
 import pytest
 import torch
 
@@ -369,6 +371,7 @@ def test_wide_layers_chain_their_row_exponents(capfd):
     assert torch.equal(y2, y3)
 
 
+@pytest.mark.skipif(os.environ.get("PYTORCH_NO_CUDA_MEMORY_CACHING") == "1", reason="stream capture cannot free memory without the caching allocator (scripts/oob_check.sh)")
 def test_wide_layer_inside_a_captured_graph(capfd):
     """gsn_layer_fused_fwd_ws_hip: with caller-owned scratch the d = 128 layer allocates nothing, so the SAME kernel runs inside a captured
     HIP graph (trace printed during capture) and the replay equals the eager result bit for bit"""
@@ -407,6 +410,7 @@ def test_wide_layer_inside_a_captured_graph(capfd):
     assert torch.equal(y1, y2) and not torch.equal(y0, y2)
 
 
+@pytest.mark.skipif(os.environ.get("PYTORCH_NO_CUDA_MEMORY_CACHING") == "1", reason="stream capture cannot free memory without the caching allocator (scripts/oob_check.sh)")
 def test_graphed_step_replays_a_whole_model_forward():
     """gsn_amd.graphs.GraphedStep: count + the 4-layer d = 128 model forward of 48 graphs captured once, replayed on refilled inputs -- the
     replay equals the eager forward of the new inputs bit for bit, and a refill changes the result."""
