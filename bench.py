@@ -233,7 +233,7 @@ def rr_tiling(seg, n_nodes, grid=256, unit=32):
     return tiles, blocks
 
 
-def small_batch_steps(plan, layer, dev):
+def small_batch_steps(plan, layer, dev, graphs=True):
     """the reference's real batch sizes (32 / 128 graphs per step).  Wall time of count + encode + CSR + layer-0 forward
     per step: eager (host-bound: ~8 launches) and replayed from one captured HIP graph (what is left is the serial latency of the
     small dependent kernels).  Supplementary, never `value`."""
@@ -268,6 +268,9 @@ def small_batch_steps(plan, layer, dev):
             y_ref = step()
         torch.cuda.synchronize()
         rec = {"graphs": G, "eager_us": round((time.perf_counter() - t0) / reps * 1e6, 1)}
+        if not graphs:                 # (--no-graph: stream capture cannot free memory without the caching allocator, scripts/oob_check.sh)
+            out["B%d" % G] = rec
+            continue
         try:
             from gsn_amd.graphs import GraphedStep
             g = GraphedStep(step, warmup=3, device=dev)          # (the product's capture helper: side-stream warm-up, capture, replay)
@@ -296,6 +299,9 @@ def small_batch_steps(plan, layer, dev):
             y_ref = mstep()
         torch.cuda.synchronize()
         rec = {"graphs": 128, "eager_us": round((time.perf_counter() - t0) / reps * 1e6, 1)}
+        if not graphs:
+            out["full_model_B128"] = rec
+            return out
         g = GraphedStep(mstep, warmup=2, device=dev)
         for _ in range(10):
             g()
@@ -710,7 +716,7 @@ def main():
     small = prop = flt = wide = train4 = lin300 = er128 = None
     if world == 1 and not args.no_extras:
         try:
-            small = small_batch_steps(plan, layer, dev)
+            small = small_batch_steps(plan, layer, dev, graphs=not args.no_graph)
         except Exception as ex:
             small = {"error": str(ex)[:200]}
         try:
