@@ -282,6 +282,8 @@ GSN_HD int plan_core(const uint32_t *plan) {
 GSN_HD uint32_t plan_ball(const uint32_t *plan, int l) { return (plan[2 + GSN_KMAX + (l >> 2)] >> (8 * (l & 3))) & 0xffu; }
 // closed form of the last two levels (patterns.cpp: plan_tail_mode): 0 none, 1 independent candidate sets, 2 twins, 3 chain
 GSN_HD int plan_tail(const uint32_t *plan) { return (int)((plan[1] >> 28) & 3u); }
+// the level at which the closed form replaces the search: k - 2, or k - r for a run of r twin levels (mode 2, r = 2 .. 5)
+GSN_HD int plan_tail_level(const uint32_t *plan, int k) { return ((plan[1] >> 28) & 3u) == 2u ? k - 2 - (int)(plan[1] >> 30) : k - 2; }
 
 // Number of ways to place the last two levels given C1 = the candidates of level k - 2 (levels 0 .. k - 3 are in fvec / used):
 // independent sets: |C1| |C2| - |C1 & C2| with C2 = the candidates of level k - 1 (whose constraints do not name level k - 2);
@@ -290,7 +292,13 @@ template <int W, bool DIR>
 GSN_HD uint64_t tail_pairs(int mode, const Bits<W> &C1, const uint32_t *plan, int k, const FVec<W> &fvec, const Bits<W> &used, const uint64_t *A,
                            const uint64_t *valid, const uint64_t *balls, int ball_n, const uint64_t *A_in, const uint64_t *degp) {
     const uint64_t n1 = (uint64_t)popc<W>(C1);
-    if (mode == 2) return n1 * (n1 - (n1 ? 1ull : 0ull)) / 2ull;
+    if (mode == 2) {                                    // C(n1, r): r twin levels
+        const int r = 2 + (int)(plan[1] >> 30);
+        if (n1 < (uint64_t)r) return 0;
+        uint64_t c = 1;
+        for (int i = 0; i < r; ++i) c = c * (n1 - (uint64_t)i) / (uint64_t)(i + 1);     // (exact at every step: i + 1 consecutive integers)
+        return c;
+    }
     if (mode == 3) {
         // chain: sum over d in C1 of |N(d) & core \ placed| -- d itself is no neighbour of d, the placed images f_0 .. f_{k-3} are
         const uint64_t *pl = degp + (size_t)plan_core(plan) * DEG_PLANES * W;
@@ -370,6 +378,10 @@ GSN_HD void lane_begin(Lane<W> &s, const uint32_t *plan, const FVec<W> &fvec_roo
     candidates<W, DIR>(C, plan[2 + s.nfix], plan_ball(plan, s.nfix), s.fvec, s.used, A, valid, s.balls, s.ball_n,
                        DIR ? plan[PLAN_STRIDE_WORDS + s.nfix] : 0u, A_in);
     if (s.nfix == s.k - 1) { s.cnt += (uint64_t)popc<W>(C); return; }
+    if (TAIL && plan_tail(plan) == 2 && s.nfix == plan_tail_level(plan, s.k)) {            // a run of twin levels: C(|C|, r)
+        s.cnt += tail_pairs<W, DIR>(2, C, plan, s.k, s.fvec, s.used, A, valid, s.balls, s.ball_n, A_in, s.degp);
+        return;
+    }
     if (TAIL && s.nfix == s.k - 2 && (TailLoop<W>::on || s.loop || plan_tail(plan))) {     // the last two levels: closed form or one tight loop, no frame
         const int tm = plan_tail(plan);
         s.cnt += tm ? tail_pairs<W, DIR>(tm, C, plan, s.k, s.fvec, s.used, A, valid, s.balls, s.ball_n, A_in, s.degp)
@@ -414,6 +426,8 @@ GSN_HD void lane_step(Lane<W> &s, const uint64_t *A, const uint64_t *valid, uint
     bool descend = false;
     if (nl == s.k - 1) {
         s.cnt += (uint64_t)popc<W>(C);
+    } else if (TAIL && plan_tail(s.plan) == 2 && nl == plan_tail_level(s.plan, s.k)) {
+        s.cnt += tail_pairs<W, DIR>(2, C, s.plan, s.k, s.fvec, used2, A, valid, s.balls, s.ball_n, A_in, s.degp);      // r twin levels: C(|C|, r)
     } else if (TAIL && nl == s.k - 2 && (TailLoop<W>::on || s.loop || plan_tail(s.plan))) {
         // the last two levels: in closed form where the plan allows it (level k - 2 is not enumerated), else in one tight loop over its images
         const int tm = plan_tail(s.plan);

@@ -115,25 +115,42 @@ struct Plan {
 // placements of both levels are  sum_{d in C1} deg_core(d)  -  sum_{j placed} |N(f_j) & C1|  -- a weighted popcount of C1 over the bit
 // planes of the core degrees (count_core.h: DEG_PLANES, built once per graph) and one AND + popcount per placed level.
 //   0 = none, 1 = independent, 2 = twins, 3 = chain
-static int plan_tail_mode(const Plan &pl, bool directed) {
+// are levels a and b = a + 1 twins: linked by exactly one order constraint, otherwise constrained alike (level b may omit bounds on the link's
+// side that level a has: v > u > f_j makes them hold)?  Returns +1 (b > a), -1 (b < a) or 0.
+static int twin_link(const Plan &pl, bool directed, int a) {
+    const int b = a + 1;
+    const uint32_t bit = 1u << a, d1 = pl.level[b], d2 = pl.level[a];
+    const bool ref_adj = (d1 & bit) != 0, ref_non = ((d1 >> 8) & bit) != 0, ref_gt = ((d1 >> 16) & bit) != 0, ref_lt = ((d1 >> 24) & bit) != 0;
+    const bool ball_ref = (pl.ball[b] >> 3) != 0 && (pl.ball[b] & 7) == a;
+    const bool in_ref = directed && ((pl.level_in[b] & bit) != 0 || ((pl.level_in[b] >> 8) & bit) != 0);
+    if (ref_adj || ref_non || ball_ref || in_ref || ref_gt == ref_lt) return 0;
+    const uint32_t d1c = d1 & ~((bit << 16) | (bit << 24));
+    const bool same_adj = (d1c & 0xffffu) == (d2 & 0xffffu);
+    const uint32_t gt1 = (d1c >> 16) & 0xffu, lt1 = d1c >> 24, gt2 = (d2 >> 16) & 0xffu, lt2 = d2 >> 24;
+    const bool order_ok = ref_gt ? ((gt1 & ~gt2) == 0 && lt1 == lt2) : ((lt1 & ~lt2) == 0 && gt1 == gt2);
+    if (!(same_adj && order_ok && pl.ball[b] == pl.ball[a] && (!directed || pl.level_in[b] == pl.level_in[a]))) return 0;
+    return ref_gt ? 1 : -1;
+}
+
+// *twin_run (mode 2 only): how many of the last levels are twins in a row (2 .. 5) -- the leaves of a star: the images of r twin levels are
+// the r-subsets of the candidate set of the first of them, C(|C1|, r), and none of the r levels is enumerated.
+static int plan_tail_mode(const Plan &pl, bool directed, int *twin_run) {
+    *twin_run = 2;
     if (pl.k - pl.n_fixed < 2) return 0;
     const int a = pl.k - 2, b = pl.k - 1;
-    const uint32_t bit = 1u << a, d1 = pl.level[b], d2 = pl.level[a];
+    const uint32_t bit = 1u << a, d1 = pl.level[b];
     if (!directed && (d1 & 0xffu) == bit && ((d1 >> 8) & 0xffu) == 0 && (d1 >> 16) == 0) return 3;
     const bool ref_adj = (d1 & bit) != 0, ref_non = ((d1 >> 8) & bit) != 0, ref_gt = ((d1 >> 16) & bit) != 0, ref_lt = ((d1 >> 24) & bit) != 0;
     const bool ball_ref = (pl.ball[b] >> 3) != 0 && (pl.ball[b] & 7) == a;
     const bool in_ref = directed && ((pl.level_in[b] & bit) != 0 || ((pl.level_in[b] >> 8) & bit) != 0);
     if (ref_adj || ref_non || ball_ref || in_ref) return 0;
     if (!ref_gt && !ref_lt) return 1;
-    if (ref_gt != ref_lt) {
-        // v > u (or v < u) is the only link.  The pairs are the 2-subsets of C1 iff { v : v fits level b without the link, v > u } =
-        // { v in C1 : v > u } for every u in C1: same adjacency / distance constraints, same order constraints on the other side, and on the
-        // link's side level b may omit bounds that level a has (v > u > f_j makes them hold) but not add any.
-        const uint32_t d1c = d1 & ~((bit << 16) | (bit << 24));
-        const bool same_adj = (d1c & 0xffffu) == (d2 & 0xffffu);
-        const uint32_t gt1 = (d1c >> 16) & 0xffu, lt1 = d1c >> 24, gt2 = (d2 >> 16) & 0xffu, lt2 = d2 >> 24;
-        const bool order_ok = ref_gt ? ((gt1 & ~gt2) == 0 && lt1 == lt2) : ((lt1 & ~lt2) == 0 && gt1 == gt2);
-        if (same_adj && order_ok && pl.ball[b] == pl.ball[a] && (!directed || pl.level_in[b] == pl.level_in[a])) return 2;
+    if (const int dir = twin_link(pl, directed, a)) {
+        // a run of twins: extend downwards while the level below is linked the same way
+        int first = a;
+        while (first - 1 >= pl.n_fixed && pl.k - (first - 1) <= 5 && twin_link(pl, directed, first - 1) == dir) --first;
+        *twin_run = pl.k - first;
+        return 2;
     }
     return 0;
 }
@@ -437,8 +454,10 @@ extern "C" int gsn_count_plan_build(int mode, int induced, int directed_orbits, 
         uint32_t *w = plan + plans_off + i * stride;
         const Plan &pl = plans[i];
         w[0] = (uint32_t)pl.k | ((uint32_t)pl.n_fixed << 8) | ((uint32_t)pl.out_col << 16);
+        int twin_run = 2;
+        const int tail_mode = plan_tail_mode(pl, directed != 0, &twin_run);
         w[1] = (uint32_t)pl.pattern | ((uint32_t)pl.root_a << 16) | ((uint32_t)pl.min_degree << 20) | ((uint32_t)pl.root_b << 24) |
-               ((uint32_t)plan_tail_mode(pl, directed != 0) << 28);
+               ((uint32_t)tail_mode << 28) | ((uint32_t)(twin_run - 2) << 30);
         for (int l = 0; l < GSN_KMAX; ++l) w[2 + l] = pl.level[l];
         for (int l = 0; l < GSN_KMAX / 4; ++l) w[2 + GSN_KMAX + l] = 0;
         for (int l = 0; l < GSN_KMAX; ++l) w[2 + GSN_KMAX + l / 4] |= (uint32_t)pl.ball[l] << (8 * (l % 4));

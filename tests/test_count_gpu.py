@@ -470,6 +470,9 @@ PENDANT_PATTERNS = {
     "c4_pendant": [(0, 1), (1, 2), (2, 3), (3, 0), (0, 4)],
     "bull": [(0, 1), (1, 2), (2, 0), (0, 3), (1, 4)],                # two independent pendants on a triangle
     "spider6": [(0, 1), (0, 2), (0, 3), (1, 4), (2, 5)],             # six vertices: pendants at different depths
+    "star5": [(0, 1), (0, 2), (0, 3), (0, 4), (0, 5)],               # runs of twin leaves: C(n, r), r up to 5
+    "star6": [(0, 1), (0, 2), (0, 3), (0, 4), (0, 5), (0, 6)],
+    "broom": [(0, 1), (1, 2), (2, 3), (2, 4), (2, 5), (2, 6)],
 }
 
 
@@ -491,9 +494,10 @@ def test_closed_form_tails_vs_oracle(mode, induced):
         n_plans, plans_off = int(arr[3]), int(arr[7])
         kinds = {(int(arr[plans_off + i * 12 + 1]) >> 28) & 3 for i in range(n_plans)}
         assert kinds == {0, 1, 2, 3}, kinds
+    # (seven-vertex stars: the oracle enumerates every map, d! / (d - 6)! per vertex of degree d -- moderate degrees)
     batches = [synth.zinc_shape_batch(40, seed=5),
-               synth.collate([synth.er_graph(128, 700, 11), synth.er_graph(100, 420, 12), synth.er_graph(90, 200, 13), synth.er_graph(65, 64, 14)]),
-               synth.collate([synth.er_graph(200, 900, 21), synth.er_graph(150, 300, 22)])]
+               synth.collate([synth.er_graph(128, 420, 11), synth.er_graph(100, 300, 12), synth.er_graph(90, 200, 13), synth.er_graph(65, 64, 14)]),
+               synth.collate([synth.er_graph(200, 600, 21), synth.er_graph(150, 300, 22)])]
     for b in batches:
         got = counts2ids_batch(b, pats, mode, induced).cpu().numpy()
         local = b.edge_index - np.repeat(b.node_ptr[:-1], np.diff(b.edge_ptr))[None, :]
