@@ -107,6 +107,8 @@ struct WgradArgs {
     const float *gh;
     const float *bdata[WG_MAXB];
     int bwidth[WG_MAXB];
+    const int64_t *bidx[WG_MAXB];  // gathered blocks (wgrad_bf16_kernel): row m of block b = bdata[b][idx[m]] -- the x_i / x_j blocks of an edge stage
+    const int32_t *bidx32[WG_MAXB];
     float *gw;
 };
 
@@ -252,6 +254,8 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradArgs a) {
     const bool kb_ok = kb < a.k_total;
     const float *xb = a.bdata[0];
     int xw = a.bwidth[0];
+    const int64_t *xi = a.bidx[0];
+    const int32_t *xi32 = a.bidx32[0];
     {
         int blk = 0, col = kb_ok ? kb : 0;
 #pragma unroll
@@ -259,7 +263,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradArgs a) {
             if (b < a.n_blocks - 1 && blk == b && col >= a.bwidth[b]) { col -= a.bwidth[b]; blk = b + 1; }
 #pragma unroll
         for (int b = 1; b < WG_MAXB; ++b)
-            if (blk == b) { xb = a.bdata[b]; xw = a.bwidth[b]; }
+            if (blk == b) { xb = a.bdata[b]; xw = a.bwidth[b]; xi = a.bidx[b]; xi32 = a.bidx32[b]; }
         xb += col;
     }
     const float *ga = a.gh + (ca_ok ? ca : 0);
@@ -279,7 +283,9 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradArgs a) {
             const int64_t r = row0 + 8 * sh + i;
             const int64_t rc = r < r_end ? r : r_begin;            // clamped: masked to zero when stored
             pa[i] = ga[rc * a.n_out];
-            pb[i] = xb[rc * xw];
+            // (a gathered block: the row index is the same for the 128 threads of a row half -- one broadcast load)
+            const int64_t rx = xi ? xi[rc] : (xi32 ? (int64_t)xi32[rc] : rc);
+            pb[i] = xb[rx * xw];
         }
     };
     auto store_one = [&](wg_u32x4 (*dst)[WG_T][2], const float (&v)[8], bool col_ok, int64_t row0) {
@@ -382,11 +388,13 @@ extern "C" int gsn_wgrad_hip(int64_t m_rows, int64_t n_out, const float *grad_h,
         return set_error(GSN_E_INVALID, "gsn_wgrad_hip: bad arguments");
     WgradArgs a{};
     a.m_rows = m_rows; a.n_out = (int)n_out; a.gh = grad_h; a.gw = grad_w; a.n_blocks = n_blocks;
+    bool gathered = false;
     int k = 0;
     for (int b = 0; b < n_blocks; ++b) {
         if ((!blocks[b].data && m_rows > 0) || blocks[b].width <= 0) return set_error(GSN_E_INVALID, "gsn_wgrad_hip: block %d is empty", b);
-        if (blocks[b].idx || blocks[b].idx32) return set_error(GSN_E_UNSUPPORTED, "gsn_wgrad_hip: gathered blocks are not supported");
         a.bdata[b] = blocks[b].data; a.bwidth[b] = (int)blocks[b].width;
+        a.bidx[b] = blocks[b].idx; a.bidx32[b] = blocks[b].idx32;
+        gathered = gathered || blocks[b].idx || blocks[b].idx32;
         k += (int)blocks[b].width;
     }
     a.k_total = k;
@@ -401,7 +409,7 @@ extern "C" int gsn_wgrad_hip(int64_t m_rows, int64_t n_out, const float *grad_h,
     slabs = (m_rows + rows_per - 1) / rows_per;
     // GSN_WGRAD_FP32=1: the fp32-MFMA kernel (v_mfma_f32_32x32x2_f32), for A/B runs
     static const bool fp32_kernel = [] { const char *e = getenv("GSN_WGRAD_FP32"); return e && e[0] == '1'; }();
-    if (fp32_kernel)
+    if (fp32_kernel && !gathered)      // (gathered blocks: the bf16 kernel only)
         hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)slabs, (unsigned)tn, (unsigned)tk), dim3(256), 0,
                            reinterpret_cast<hipStream_t>(stream), a);
     else {

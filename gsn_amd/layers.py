@@ -996,6 +996,7 @@ def _run_stages_materialised(stages, m_rows, training):
 # forward linear kernel on W^T for the input gradient
 # ------------------------------------------------------------------------------------------------------------------
 NATIVE_DENSE_BACKWARD = True      # False: every mlp backward goes through the PyTorch twin (for comparison)
+GATHER_CAT_TRAIN = os.environ.get("GSN_GATHER_CAT_TRAIN", "0") == "1"    # 1: training assembles the edge rows first (gsn_gather_cat_hip), as before r03
 
 
 def _transposed(w):
@@ -1012,7 +1013,16 @@ class _DenseStagesFn(torch.autograd.Function):
         # weight, [bias], [gamma, beta]
         it = iter(tensors)
         blocks0 = [next(it) for _ in range(spec[0]["n_blocks"])]
-        m_rows = blocks0[0].shape[0]
+        # gathered stage-0 blocks (the x_i / x_j / per-end-point blocks of an edge stage): read where they lie through edge_index[mode],
+        # by the forward product AND by the weight gradient -- no assembled [E, K] copy of the rows
+        gather = spec[0].get("gather")
+        if gather is not None:
+            g_ei, g_n, g_modes = gather
+            idx0 = [None if m is None else g_ei[m] for m in g_modes]
+            m_rows = g_ei.shape[1]
+        else:
+            idx0 = [None] * len(blocks0)
+            m_rows = blocks0[0].shape[0]
         saved, meta = [], []
         y = None
         for si, sp in enumerate(spec):
@@ -1022,7 +1032,7 @@ class _DenseStagesFn(torch.autograd.Function):
             gamma = beta = None
             if bn is not None and bn.affine:
                 gamma, beta = next(it), next(it)
-            blks = [(t, None) for t in blocks0] if si == 0 else [(y, None)]
+            blks = [(t, ix) for t, ix in zip(blocks0, idx0)] if si == 0 else [(y, None)]
             n_out = w.shape[0]
             bn_train = bn is not None and (bn.training or bn.running_mean is None)
             bn_affine_grad = bn is not None and bn.affine and (bn.weight.requires_grad or bn.bias.requires_grad)
@@ -1131,9 +1141,13 @@ class _DenseStagesFn(torch.autograd.Function):
                 o32 += n_out * k_total
                 arr = (_abi.gsn_block * len(xin))()
                 keep = []
+                gather = spec[0].get("gather") if si == 0 else None
                 for bi, t in enumerate(xin):
                     t = _f32c(t); keep.append(t)
                     arr[bi].data = t.data_ptr(); arr[bi].idx = None; arr[bi].idx32 = None; arr[bi].width = t.shape[1]
+                    if gather is not None and gather[2][bi] is not None:
+                        ix = gather[0][gather[2][bi]].contiguous(); keep.append(ix)
+                        arr[bi].idx = ix.data_ptr()
                 with _abi.device_guard(dev), _timed("wgrad", 2.0 * m_rows * n_out * k_total):
                     _abi.check(L.gsn_wgrad_hip(m_rows, n_out, gh.data_ptr(), len(xin), arr, gw.data_ptr(), _abi.current_stream()),
                                "gsn_wgrad_hip")
@@ -1145,11 +1159,17 @@ class _DenseStagesFn(torch.autograd.Function):
                 if si > 0:
                     g = gx
                 else:
+                    gather = spec[0].get("gather")
                     o = 0
                     for bi, t in enumerate(blocks0):
                         wd = t.shape[1]
                         if ctx.needs_input_grad[1 + bi]:
-                            grads[bi] = gx[:, o:o + wd]
+                            mode = None if gather is None else gather[2][bi]
+                            if mode is None:
+                                grads[bi] = gx[:, o:o + wd]
+                            else:       # rows gathered through edge_index[mode]: the per-edge gradients summed per vertex (the propagate kernel)
+                                with torch.no_grad():
+                                    grads[bi] = propagate(0, gather[0], mode, gather[1], b=gx[:, o:o + wd].contiguous())
                         o += wd
         return (None,) + tuple(grads)
 
@@ -1165,12 +1185,16 @@ def _dense_native_ok(stages, training=None):
     return True
 
 
-def run_stages_autograd(stages, m_rows, training):
-    """Differentiable evaluation of a dense stage list with the native adjoint."""
+def run_stages_autograd(stages, m_rows, training, gather=None):
+    """Differentiable evaluation of a dense stage list with the native adjoint.  ``gather = (edge_index, n_nodes, modes)``: block b of
+    the first stage is gathered through ``edge_index[modes[b]]`` (None: one row per edge) -- the edge rows cat(x_i, x_j, ..) of
+    GSN_sparse.py:166-171 are then never assembled, neither for the product nor for the weight gradient."""
     spec, tensors = [], []
     tensors += [d for d, _ in stages[0].blocks]
     for i, st in enumerate(stages):
         spec.append({"n_blocks": len(st.blocks) if i == 0 else 0, "has_bias": st.bias is not None, "bn": st.bn, "act": st.act})
+        if i == 0 and gather is not None and any(m is not None for m in gather[2]):
+            spec[0]["gather"] = gather
         tensors.append(st.weight)
         if st.bias is not None:
             tensors.append(st.bias)
@@ -1742,13 +1766,15 @@ class _SparseLayer(nn.Module):
             tensors.append(ef); modes.append(None)
         mf, uf = self.msg_fn, self.update_fn
         # (an edge-less batch walks the same graph with zero rows: every parameter and input then gets the ZERO gradient PyTorch gives it)
+        # the edge rows cat(x_i, x_j, ids.., e) are read where they lie (gathered blocks), by the product and by its weight gradient
+        eblocks, gather = [(t, None) for t in tensors], (edge_index, n, tuple(modes))
+        if GATHER_CAT_TRAIN or len(tensors) > _MAX_BLOCKS:      # (the assembled-rows form: A/B switch)
+            eblocks, gather = [(_GatherCatFn.apply(edge_index, n, tuple(modes), *tensors), None)], None
         if len(mf.fc) < 2:      # a single Linear as msg_fn: nothing to fold (GSN_sparse.py:166-171 with d_h = [])
-            xe = _GatherCatFn.apply(edge_index, n, tuple(modes), *tensors)
-            msgs = run_stages_autograd(mf.stages([(xe, None)]), E, True)
+            msgs = run_stages_autograd(mf.stages(eblocks), E, True, gather=gather)
             agg = propagate(0, edge_index, sel, n, b=msgs)
             return run_stages_autograd(uf.stages([(x, None), (agg, None)], post=post), n, True)
-        xe = _GatherCatFn.apply(edge_index, n, tuple(modes), *tensors)
-        r = run_stages_autograd(mf.stages([(xe, None)], upto=len(mf.fc) - 1), E, True)
+        r = run_stages_autograd(mf.stages(eblocks, upto=len(mf.fc) - 1), E, True, gather=gather)
         s_agg = propagate(0, edge_index, sel, n, b=r)
         csr = _csr_for(edge_index, sel, n)
         last, w3 = mf.fc[-1], uf.fc[0].weight

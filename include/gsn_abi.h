@@ -488,7 +488,8 @@ int gsn_column_stats_hip(int64_t m_rows, int64_t n_cols, const float *h, double 
  *       on its running statistics (module in eval mode, models_misc.py:41-45 under model.eval()) with gradients for gamma / beta:
  *       h = pre-BN rows, mean / invstd = the running statistics, sums as above, grad_h = gZ * coef.
  *       grad_bias (fp64 [C], zero-filled, may be NULL) receives the column sums of grad_h.  grad_h may alias grad_y.
- *   gsn_wgrad_hip : grad_w[n_out][K] += grad_h^T X  with X the concatenation of `blocks` (no gathers); caller zero-fills.
+ *   gsn_wgrad_hip : grad_w[n_out][K] += grad_h^T X  with X the concatenation of `blocks` (direct, or gathered through idx / idx32 as
+ *       in gsn_linear_fwd_hip: the x_i / x_j blocks of an edge stage are read where they lie); caller zero-fills.
  *   The input gradient is gsn_linear_fwd_hip(grad_h, weight = W^T).
  * ---------------------------------------------------------------------------------------------------------------- */
 int gsn_bn_act_bwd_hip(int64_t m_rows, int64_t n_cols, const float *grad_y, const float *y, const float *h,
