@@ -908,14 +908,16 @@ def _bn_resolve(stage, stats_fn, m_rows, training):
                 mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
         gamma = _f32c(bn.weight) if bn.affine else None
         beta = _f32c(bn.bias) if bn.affine else None
+        v0, v1, v2, v3 = vec.unbind(0)           # (the four rows: one call, and their addresses by arithmetic -- this runs per BatchNorm per step)
+        p0 = vec.data_ptr()
         with _abi.device_guard(dev):
             rc = _abi.lib().gsn_bn_finalize_count_hip(n_out, m_rows, float(bn.eps), float(mom), stats.data_ptr(), _abi.ptr(gamma), _abi.ptr(beta),
                                                       bn.running_mean.data_ptr() if track else None, bn.running_var.data_ptr() if track else None,
-                                                      vec[0].data_ptr(), vec[1].data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(),
+                                                      p0, p0 + 4 * n_out, p0 + 8 * n_out, p0 + 12 * n_out,
                                                       _abi.ptr(nbt), _abi.current_stream())
         _abi.check(rc, "gsn_bn_finalize_count_hip")
-        stage.bn_params = (vec[0], vec[2], vec[3])
-        stage.bn_invstd = vec[1]
+        stage.bn_params = (v0, v2, v3)
+        stage.bn_invstd = v1
         return
     else:
         # eval mode: the three vectors depend only on the module's buffers / parameters -> cached on their versions
