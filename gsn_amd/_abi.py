@@ -37,6 +37,10 @@ class gsn_self_block(ctypes.Structure):
     _fields_ = [("data", c_vp), ("width", c_i64), ("row_stride", c_i64)]
 
 
+class gsn_pack16(ctypes.Structure):
+    _fields_ = [("node_rows", c_vp), ("edge_rows", c_vp)]
+
+
 # name -> (restype, argtypes); kept in one place so tests can check it against include/gsn_abi.h
 class gsn_code_slot(ctypes.Structure):
     _fields_ = [("codes", ctypes.c_void_p), ("idx", ctypes.c_void_p), ("stride", ctypes.c_int32), ("col", ctypes.c_int32),
@@ -54,6 +58,9 @@ SIGNATURES = {
                               c_vp, c_vp, c_vp]),
     "gsn_count_encode_hip": (c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_i64, c_i64,
                                      c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
+    "gsn_count_encode_pack16_hip": (c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_i64, c_i64,
+                                            c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_i64, c_vp]),
+    "gsn_pack16_rows_hip": (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp]),
     "gsn_csr_scratch_elems": (c_i64, [c_i64]),
     "gsn_csr_build_hip": (c_int, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "gsn_linear_f16x3_kpad": (c_i64, [c_i64]),
@@ -99,6 +106,10 @@ SIGNATURES = {
                                             c_vp, c_vp]),
     "gsn_layer_fused_fwd_hip": (c_int, [c_i64, c_i64, c_vp, ctypes.POINTER(gsn_chain_stage), c_vp, c_i64, ctypes.POINTER(gsn_chain_stage),
                                         ctypes.POINTER(gsn_chain_stage), c_vp, c_vp, c_vp]),
+    "gsn_layer_fused_pack16_supported": (c_int, [ctypes.POINTER(gsn_chain_stage), c_i64, ctypes.POINTER(gsn_chain_stage), ctypes.POINTER(gsn_chain_stage)]),
+    "gsn_layer_fused_pack16_prepared_bytes": (c_i64, [ctypes.POINTER(gsn_chain_stage), c_i64, ctypes.POINTER(gsn_chain_stage), ctypes.POINTER(gsn_chain_stage)]),
+    "gsn_layer_fused_pack16_prepare_hip": (c_int, [ctypes.POINTER(gsn_chain_stage), c_i64, ctypes.POINTER(gsn_chain_stage), ctypes.POINTER(gsn_chain_stage), c_vp, c_vp]),
+    "gsn_layer_fused_fwd_pack16_hip": (c_int, [c_i64, c_i64, c_vp, ctypes.POINTER(gsn_chain_stage), c_vp, c_i64, ctypes.POINTER(gsn_chain_stage), ctypes.POINTER(gsn_chain_stage), c_vp, ctypes.POINTER(gsn_pack16), c_i64, c_vp, c_vp]),
     "gsn_layer_fused_workspace_bytes": (c_i64, [c_i64, ctypes.POINTER(gsn_chain_stage), c_i64, ctypes.POINTER(gsn_chain_stage), ctypes.POINTER(gsn_chain_stage)]),
     "gsn_layer_fused_fwd_ws_hip": (c_int, [c_i64, c_i64, c_vp, ctypes.POINTER(gsn_chain_stage), c_vp, c_i64, ctypes.POINTER(gsn_chain_stage),
                                            ctypes.POINTER(gsn_chain_stage), c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),

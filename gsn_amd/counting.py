@@ -16,7 +16,7 @@ import ctypes
 import numpy as np
 import torch
 
-from . import _abi
+from . import _abi, packs
 from .patterns import PatternGraph
 
 __all__ = ["CountPlan", "count_batch", "counts2ids_batch", "subgraph_isomorphism_vertex_counts",
@@ -76,14 +76,16 @@ def _as_dev_i64(x, device):
 
 
 def count_batch(plan: CountPlan, node_ptr, edge_ptr, edge_index, ids_are_global=True, max_nodes=None, max_edges=None,
-                device=None, graph_ids=None, out=None, check=True, encode=None, counts=True, encoded_out=None):
+                device=None, graph_ids=None, out=None, check=True, encode=None, counts=True, encoded_out=None, encoded_pack=None):
     """Run the counting kernel over a batch.
 
     ``encode=(n_classes, clamp)`` also returns the one-hot encoded identifiers the GSN layers consume (the reference's
     ``DiscreteEmbedding('one_hot_encoder')`` over the counts, utils_graph_learning.py:170-187) straight from the kernel
     (``gsn_count_encode_hip``): the result becomes ``(out, status, encoded)`` with ``encoded`` fp32
     [rows_total, sum(n_classes)] (``encoded_out`` to reuse a buffer); with ``counts=False`` the int64 rows are not written at
-    all (``out`` is None).
+    all (``out`` is None).  ``encoded_pack=(pack, col0)`` (with ``encode``): the kernel writes the encoded rows a second time as
+    fp16 into columns col0.. of the exact row pack ``pack`` (:mod:`gsn_amd.packs`) and ``encoded`` is tagged with it -- the first GSN
+    layer then reads the pack (csrc/layer_rp.hip) instead of converting the fp32 rows.
 
     node_ptr / edge_ptr: int64 [G+1] (host or device); edge_index: int64 [2, E_total].  Returns
     ``(out, status)``: ``out`` int64 device tensor [rows_total, plan.n_cols] (rows = vertices in vertex mode, columns
@@ -142,8 +144,22 @@ def count_batch(plan: CountPlan, node_ptr, edge_ptr, edge_index, ids_are_global=
         with _abi.device_guard(device):
             if enc is None:
                 rc = _abi.lib().gsn_count_hip(*common, _abi.current_stream())
-            else:
+            elif encoded_pack is None:
+                packs.release(enc)                  # (rewritten through its raw pointer: an earlier pack no longer describes it)
                 rc = _abi.lib().gsn_count_encode_hip(*common, _abi.ptr(enc_tab), int(bool(encode[1])), enc.data_ptr(), _abi.current_stream())
+            else:
+                pack, col0 = encoded_pack
+                if pack.dtype != torch.float16 or pack.dim() != 2 or pack.shape[0] != enc.shape[0] or not pack.is_contiguous() or pack.device != enc.device:
+                    raise ValueError("encoded_pack: a contiguous fp16 [rows, cols] tensor on the device of the encoded rows")
+                packs.release(enc)
+                rc = _abi.lib().gsn_count_encode_pack16_hip(*common, _abi.ptr(enc_tab), int(bool(encode[1])), enc.data_ptr(), pack.data_ptr(),
+                                                            pack.shape[1], int(col0), _abi.current_stream())
+                if rc == -2:                         # GSN_E_UNSUPPORTED: rows not staged in this launch configuration -> pack the fp32 rows
+                    rc = _abi.lib().gsn_count_encode_hip(*common, _abi.ptr(enc_tab), int(bool(encode[1])), enc.data_ptr(), _abi.current_stream())
+                    _abi.check(rc, "gsn_count_encode_hip")
+                    packs._pack_rows(enc, pack, int(col0), -1, False)
+                if rc == 0:
+                    packs.claim(enc, pack, int(col0))
         _abi.check(rc, "gsn_count_hip" if enc is None else "gsn_count_encode_hip")
     if check:
         st = status.cpu().numpy()

@@ -60,7 +60,8 @@ struct CountArgs {
     int enc_width, enc_clamp, off_enc;
     int enc_stage;             // 1: cells leave their class index in an LDS byte array, the rows are expanded and written coalesced at the end
     int off_encst;             // that array: [rows_cap][n_cols] bytes, 0xff = no class (count out of range, unclamped)
-    uint32_t enc_magic;        // floor(2^32 / enc_width) + 1: row = mulhi(i, magic) for i < rows_cap * enc_width
+    uint16_t *enc16;           // the same rows as fp16 into a column range of an exact row pack (gsn_count_encode_pack16_hip), or null; staged rows only
+    int enc16_stride, enc16_col0;
 };
 
 // diagnostic build (-DCOUNT_PROF, scripts/rr_variant.sh with RR_VARIANT_SRC=count): cycles of thread 0 per phase, summed over the workgroups
@@ -120,6 +121,7 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
         if (part == 0) {
             if (a.out) for (int64_t i = tid; i < rows64 * n_cols; i += T) a.out[row0 * n_cols + i] = 0;
             if (a.enc_out) for (int64_t i = tid; i < rows64 * a.enc_width; i += T) a.enc_out[row0 * a.enc_width + i] = 0.f;
+            if (a.enc16) for (int64_t i = tid; i < rows64 * a.enc_width; i += T) a.enc16[(row0 + i / a.enc_width) * a.enc16_stride + a.enc16_col0 + i % a.enc_width] = 0;
             if (tid == 0) atomicMax(&a.status[g], (int)GSN_ST_TOO_LARGE);
         }
         return 0;
@@ -433,7 +435,8 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
         const unsigned char *est = smem + a.off_encst;
         float *dst = a.enc_out + row0 * a.enc_width;
         const int total = rows * a.enc_width;
-        if (n_cols == 4 && (a.enc_width & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+        const bool pack_ok = !a.enc16 || (((a.enc16_stride | a.enc16_col0) & 3) == 0 && (reinterpret_cast<uintptr_t>(a.enc16) & 7) == 0);
+        if (n_cols == 4 && (a.enc_width & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0 && pack_ok) {
             // four identifier columns (the cycle / clique families of the reference's configurations): a thread owns a row, reads
             // its four class indices as one word and writes the row as float4s
             int hot0 = enc[0], hot1 = enc[2], hot2 = enc[4], hot3 = enc[6];
@@ -451,6 +454,15 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
                     o.w = (h0 == k + 3 || h1 == k + 3 || h2 == k + 3 || h3 == k + 3) ? 1.f : 0.f;
                     d4[k >> 2] = o;
                 }
+                if (a.enc16) {                          // the same row as fp16 (1.0 = 0x3c00) into the pack's column range, 8 bytes per store
+                    uint2 *p2 = reinterpret_cast<uint2 *>(a.enc16 + (row0 + r) * a.enc16_stride + a.enc16_col0);
+                    for (int k = 0; k < a.enc_width; k += 4) {
+                        uint2 o;
+                        o.x = ((h0 == k || h1 == k || h2 == k || h3 == k) ? 0x3c00u : 0u) | ((h0 == k + 1 || h1 == k + 1 || h2 == k + 1 || h3 == k + 1) ? 0x3c000000u : 0u);
+                        o.y = ((h0 == k + 2 || h1 == k + 2 || h2 == k + 2 || h3 == k + 2) ? 0x3c00u : 0u) | ((h0 == k + 3 || h1 == k + 3 || h2 == k + 3 || h3 == k + 3) ? 0x3c000000u : 0u);
+                        p2[k >> 2] = o;
+                    }
+                }
             }
         } else
         // column c owns floats enc[2c] .. enc[2c] + enc[2c + 1] of a row; the table is short: a linear scan per float
@@ -460,7 +472,9 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
             int c = 0;
             while (c + 1 < n_cols && enc[2 * (c + 1)] <= j) ++c;
             const int k = j - enc[2 * c];
-            dst[i] = (k < enc[2 * c + 1] && (int)est[r * n_cols + c] == k) ? 1.f : 0.f;
+            const bool hot = k < enc[2 * c + 1] && (int)est[r * n_cols + c] == k;
+            dst[i] = hot ? 1.f : 0.f;
+            if (a.enc16) a.enc16[(row0 + r) * a.enc16_stride + a.enc16_col0 + j] = hot ? (uint16_t)0x3c00 : (uint16_t)0;
         }
     }
     COUNT_T(6);
@@ -552,7 +566,7 @@ static int count_launch(const uint32_t *plan_host, const uint32_t *plan_dev, int
                         const int64_t *node_ptr, const int64_t *edge_ptr, const int64_t *edge_index,
                         int64_t edge_row_stride, int ids_are_global, const int32_t *graph_ids, int64_t n_items,
                         int64_t max_nodes, int64_t max_edges, int64_t *out, int32_t *status, const int32_t *n_classes,
-                        int enc_clamp, float *enc_out, void *stream) {
+                        int enc_clamp, float *enc_out, void *stream, uint16_t *enc16 = nullptr, int64_t enc16_stride = 0, int64_t enc16_col0 = 0) {
     if (!plan_host || !plan_dev || plan_words < PLAN_HEADER_WORDS || plan_host[0] != PLAN_MAGIC)
         return set_error(GSN_E_INVALID, "gsn_count_hip: not a plan table (build it with gsn_count_plan_build)");
     if (!node_ptr || !edge_ptr || (!out && !enc_out) || !status) return set_error(GSN_E_INVALID, "gsn_count_hip: null pointer argument");
@@ -689,13 +703,16 @@ static int count_launch(const uint32_t *plan_host, const uint32_t *plan_dev, int
     if (a.stage_out) o += (int)stage_bytes;
     // class indices of the encoded rows: staged whenever one workgroup owns the whole graph and the indices fit a byte; else
     // every cell writes its floats itself
-    a.enc_stage = 0; a.off_encst = o; a.enc_magic = 0;
+    a.enc_stage = 0; a.off_encst = o;
+    a.enc16 = enc16; a.enc16_stride = (int)enc16_stride; a.enc16_col0 = (int)enc16_col0;
     if (enc_out && a.split == 1 && enc_bytes && rows_cap_u * enc_width < (int64_t)1 << 24 && o + rows_cap_u * a.n_cols <= 150 * 1024) {
         a.enc_stage = 1;
-        a.enc_magic = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)enc_width + 1);
         o += align_up((int)(rows_cap_u * a.n_cols), 16);     // (16-byte aligned: with four columns a row's indices are read as one word)
     }
     if (o > 160 * 1024) return set_error(GSN_E_UNSUPPORTED, "graph too large for LDS (%d B needed)", o);
+    if (enc16 && !a.enc_stage)
+        return set_error(GSN_E_UNSUPPORTED, "gsn_count_encode_pack16_hip: the fp16 rows are written from the staged class indices (one workgroup per graph, "
+                                            "n_classes <= 255); pack the fp32 rows with gsn_pack16_rows_hip instead");
 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     {   // per-graph status words start at OK; workgroups raise them with atomicMax
@@ -732,4 +749,19 @@ extern "C" int gsn_count_encode_hip(const uint32_t *plan_host, const uint32_t *p
     if (!enc_out) return set_error(GSN_E_INVALID, "gsn_count_encode_hip: enc_out is null");
     return count_launch(plan_host, plan_dev, plan_words, n_graphs, node_ptr, edge_ptr, edge_index, edge_row_stride, ids_are_global,
                         graph_ids, n_items, max_nodes, max_edges, out, status, n_classes, clamp, enc_out, stream);
+}
+
+extern "C" int gsn_count_encode_pack16_hip(const uint32_t *plan_host, const uint32_t *plan_dev, int64_t plan_words, int64_t n_graphs,
+                                           const int64_t *node_ptr, const int64_t *edge_ptr, const int64_t *edge_index,
+                                           int64_t edge_row_stride, int ids_are_global, const int32_t *graph_ids, int64_t n_items,
+                                           int64_t max_nodes, int64_t max_edges, int64_t *out, int32_t *status,
+                                           const int32_t *n_classes, int clamp, float *enc_out, uint16_t *pack, int64_t pack_stride,
+                                           int64_t pack_col0, void *stream) {
+    if (!enc_out || !pack) return set_error(GSN_E_INVALID, "gsn_count_encode_pack16_hip: enc_out / pack is null");
+    int64_t w = 0;
+    if (n_classes && plan_host && plan_words >= PLAN_HEADER_WORDS) for (uint32_t c = 0; c < plan_host[4] && c < GSN_ENC_MAX_COLS; ++c) w += n_classes[c];
+    if (pack_stride <= 0 || pack_stride > 0x7fffffff || pack_col0 < 0 || pack_col0 + w > pack_stride)
+        return set_error(GSN_E_INVALID, "gsn_count_encode_pack16_hip: columns %lld .. %lld outside a pack row of %lld", (long long)pack_col0, (long long)(pack_col0 + w), (long long)pack_stride);
+    return count_launch(plan_host, plan_dev, plan_words, n_graphs, node_ptr, edge_ptr, edge_index, edge_row_stride, ids_are_global,
+                        graph_ids, n_items, max_nodes, max_edges, out, status, n_classes, clamp, enc_out, stream, pack, pack_stride, pack_col0);
 }

@@ -1156,3 +1156,38 @@ static int lf_forward(int64_t n_nodes, int64_t n_edges, const int32_t *seg_ptr, 
     if (k0 <= 96) return k1 <= 64 ? lf_launch<5, 6, 4>(a, st) : lf_launch<5, 6, 8>(a, st);
     return k1 <= 64 ? lf_launch<5, 10, 4>(a, st) : lf_launch<5, 10, 8>(a, st);
 }
+
+// ---- the register-resident layer on exact fp16 row packs (layer_rp.hip) ------------------------------------------------------------
+extern "C" int gsn_layer_fused_pack16_supported(const gsn_chain_stage *edge, int64_t d_x, const gsn_chain_stage *node0,
+                                                const gsn_chain_stage *node1) {
+    if (!edge || !node0 || !node1) return 0;
+    return rp_supported(edge, d_x, node0, node1);
+}
+
+extern "C" int64_t gsn_layer_fused_pack16_prepared_bytes(const gsn_chain_stage *edge, int64_t d_x, const gsn_chain_stage *node0,
+                                                         const gsn_chain_stage *node1) {
+    if (!gsn_layer_fused_pack16_supported(edge, d_x, node0, node1)) return 0;
+    return rr_prepared_bytes(edge, d_x, node0, node1);
+}
+
+extern "C" int gsn_layer_fused_pack16_prepare_hip(const gsn_chain_stage *edge, int64_t d_x, const gsn_chain_stage *node0,
+                                                  const gsn_chain_stage *node1, void *prepared, void *stream) {
+    if (!gsn_layer_fused_pack16_supported(edge, d_x, node0, node1))
+        return set_error(GSN_E_UNSUPPORTED, "gsn_layer_fused_pack16_prepare_hip: shape outside the packed-row layer kernel");
+    if (!prepared || (reinterpret_cast<uintptr_t>(prepared) & 15)) return set_error(GSN_E_INVALID, "gsn_layer_fused_pack16_prepare_hip: prepared must be a 16-byte aligned device buffer");
+    return rr_prepare(edge, d_x, node0, node1, prepared, reinterpret_cast<hipStream_t>(stream), true);
+}
+
+extern "C" int gsn_layer_fused_fwd_pack16_hip(int64_t n_nodes, int64_t n_edges, const int32_t *seg_ptr, const gsn_chain_stage *edge,
+                                              const float *x, int64_t d_x, const gsn_chain_stage *node0, const gsn_chain_stage *node1,
+                                              const void *prepared, const gsn_pack16 *pack, int64_t edge_rows, float *out, void *stream) {
+    if (!gsn_layer_fused_pack16_supported(edge, d_x, node0, node1))
+        return set_error(GSN_E_UNSUPPORTED, "gsn_layer_fused_fwd_pack16_hip: shape outside the packed-row layer kernel");
+    if (!seg_ptr || !out || !prepared || !pack) return set_error(GSN_E_INVALID, "gsn_layer_fused_fwd_pack16_hip: null seg_ptr / out / prepared / pack");
+    if (reinterpret_cast<uintptr_t>(prepared) & 15) return set_error(GSN_E_INVALID, "gsn_layer_fused_fwd_pack16_hip: prepared must be 16-byte aligned");
+    if (n_nodes > (int64_t)2000000000 || n_edges > (int64_t)2000000000 || edge_rows < 0) return set_error(GSN_E_UNSUPPORTED, "gsn_layer_fused_fwd_pack16_hip: 32-bit row arithmetic");
+    if (n_nodes <= 0) return GSN_OK;
+    const int rc = rp_forward(n_nodes, n_edges, seg_ptr, edge, x, d_x, node0, node1, prepared, pack, edge_rows, out, reinterpret_cast<hipStream_t>(stream));
+    if (rc == 1) return set_error(GSN_E_UNSUPPORTED, "gsn_layer_fused_fwd_pack16_hip: packs beyond 2 GiB (32-bit buffer offsets); use gsn_layer_fused_fwd_hip");
+    return rc;
+}

@@ -45,20 +45,9 @@
 #include "chain_common.h"
 #include "layer_rr.h"
 #include "layer_rr_inl.h"
+#include "layer_rr_core.h"
 
 namespace gsn {
-
-constexpr int RR_TN = 32;          // nodes per tile
-constexpr int RR_TE = 64;          // a tile's in-edges: a whole number of 64-row chunks where the degrees allow it
-constexpr int RR_BE = 32;          // edge rows per block (the unit of the edge stage)
-constexpr int RR_NKE = 5;          // 16-column chunks of the edge rows (K_e <= 80)
-constexpr int RR_NSLOT = 2 * RR_NKE;   // 16-byte loads per lane and edge block
-constexpr int RR_MAXROLE = 3;      // distinct row-index arrays of the edge blocks (sorted target, sorted source, perm)
-constexpr int RR_HDR = 32;         // header words of the prepared buffer
-constexpr unsigned RR_MAGIC = 0x52523031u;
-
-// header of the prepared buffer (words)
-enum { RRH_MAGIC = 0, RRH_EE = 1, RRH_E0 = 2, RRH_E1 = 3, RRH_EMIN = 4, RRH_BAD = 5, RRH_ACT = 6 };
 
 // what one half of the lanes loads for one 16-byte slot of an edge row: address = base + row_index[role] * stride
 struct RrSlotHalf { unsigned long long base; unsigned stride, role; };
@@ -74,77 +63,6 @@ struct RrArgs {
     const unsigned *prep;
     int n_ranges;                  // node ranges (one per wave slot; slot = wave * gridDim.x + blockIdx.x)
 };
-
-template <int WB, int NKX>
-struct RrShape {
-    static constexpr int NKS = 2 * WB;                       // chunks of the S part of node stage 0 / of node stage 1's input
-    static constexpr int NK0 = NKS + NKX;
-    static constexpr int F_WE = 0;                           // fragment indices (1 KiB each): edge stage [fb][c][plane]
-    static constexpr int F_W0H = F_WE + WB * RR_NKE * 2;     // node stage 0, high plane [fbo][c], c < NK0
-    static constexpr int F_W0XL = F_W0H + WB * NK0;          // node stage 0, low plane of the [x | deg] chunks [fbo][cq]
-    static constexpr int F_W1 = F_W0XL + WB * NKX;           // node stage 1 [fb][c][plane]
-    static constexpr int F_LDS = F_W1 + WB * NKS * 2;        // fragments held in LDS
-    static constexpr int F_W0SL = F_LDS;                     // node stage 0, low plane of the S chunks, in the order of use [c][fbo]: streamed from L2
-    static constexpr int F_ALL = F_W0SL + NKS * WB;
-    static constexpr int TAB_WORDS = 3 * 32 * WB;            // c0 of the three stages
-    static constexpr int LDS_BYTES = F_LDS * 1024 + TAB_WORDS * 4 + RR_NSLOT * 2 * 16;
-    static constexpr int PREP_WORDS = RR_HDR + F_ALL * 256 + TAB_WORDS;
-};
-
-// ------------------------------------------------------------------------------------------------------------------------------
-// tile iterator of one wave (the one of layer_fused.hip, wave-local): tiles of <= 32 nodes whose in-edges are a whole number of
-// 64-row chunks where possible, handed out as BLOCKS of <= 32 edge rows (the unit of the edge stage and of the gather pipeline)
-struct RrDesc {
-    int m0, e0, pk;                         // pk: valid | first << 1 | last << 2 | nn << 6 | ne << 12
-    __device__ __forceinline__ int valid() const { return pk & 1; }
-    __device__ __forceinline__ int first() const { return (pk >> 1) & 1; }
-    __device__ __forceinline__ int last() const { return (pk >> 2) & 1; }
-    __device__ __forceinline__ int nn() const { return (pk >> 6) & 63; }
-    __device__ __forceinline__ int ne() const { return (pk >> 12) & 63; }
-};
-
-struct RrIter {
-    const int32_t *seg;
-    int n_nodes, m_next, m_end;
-    int m0, nn, eb, ee, ec, pending;
-    int win;                                // lane l: seg_ptr[m_next + l] (window of the NEXT tile, fetched when the current one is formed)
-};
-
-__device__ __forceinline__ void rr_iter_load(RrIter &it, int lane) {
-    int idx = it.m_next + lane;
-    idx = idx < it.n_nodes ? idx : it.n_nodes;
-    it.win = it.seg[idx];
-}
-
-__device__ __forceinline__ RrDesc rr_iter_next(RrIter &it, int lane) {
-    RrDesc d; d.m0 = 0; d.e0 = 0; d.pk = 0;
-    if (!(it.pending || it.ec < it.ee)) {
-        if (it.m_next >= it.m_end) return d;
-        int nmax = it.m_end - it.m_next;
-        nmax = nmax < RR_TN ? nmax : RR_TN;
-        const int w0 = __builtin_amdgcn_readfirstlane(it.win);
-        const int cnt = it.win - w0;
-        const int ne_all = __builtin_amdgcn_readlane(cnt, nmax);
-        int nn = nmax;
-        if (ne_all > RR_TE) {
-            const int cap = ne_all / RR_TE * RR_TE;
-            const unsigned long long ok = __ballot(lane <= nmax && cnt <= cap);
-            nn = __popcll(ok) - 1;
-            nn = nn < 1 ? 1 : nn;
-        }
-        nn = __builtin_amdgcn_readfirstlane(nn);
-        it.m0 = it.m_next; it.nn = nn; it.eb = w0; it.ee = __builtin_amdgcn_readlane(it.win, nn);
-        it.ec = it.eb; it.pending = 1;
-        it.m_next += nn;
-        rr_iter_load(it, lane);
-    }
-    d.m0 = it.m0; d.e0 = it.ec;
-    const int left = it.ee - it.ec;
-    const int ne = left < RR_BE ? left : RR_BE;
-    d.pk = 1 | ((it.ec == it.eb) << 1) | ((it.ec + RR_BE >= it.ee) << 2) | (it.nn << 6) | (ne << 12);
-    it.ec += RR_BE; it.pending = 0;
-    return d;
-}
 
 // what a block needs before its gathers can be issued / its incidence operand built: the row indices of its edge rows, the
 // segment bounds of the lane's target
@@ -190,9 +108,6 @@ __device__ __forceinline__ void rr_gather_issue(const rr_u4 *slot_tab, int lh, c
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
-#ifndef RR_NW
-#define RR_NW 8            // waves per workgroup (one workgroup per CU): 8 = two per SIMD, 256 registers each
-#endif
 template <int WB, int NKX, bool PROF>
 __global__ __launch_bounds__(64 * RR_NW) __attribute__((amdgpu_waves_per_eu(RR_NW / 4, RR_NW / 4))) void layer_fused_kernel_rr(RrArgs a, unsigned long long *prof) {
     // diagnostic build (GSN_FUSED_PROF=1): cycles per phase of wave 0 of workgroup 0 and of one wave in the middle of the grid
@@ -235,6 +150,7 @@ __global__ __launch_bounds__(64 * RR_NW) __attribute__((amdgpu_waves_per_eu(RR_N
     __syncthreads();
     const int Ee = (int)a.prep[RRH_EE], E0 = (int)a.prep[RRH_E0], E1 = (int)a.prep[RRH_E1], e_min = (int)a.prep[RRH_EMIN];
     const bool w_bad = a.prep[RRH_BAD] != 0;
+    if (a.prep[RRH_PACK] != 0u) __builtin_trap();              // (prepared for layer_rp.hip: another k-slot order)
     const unsigned acts = a.prep[RRH_ACT];
     // (wave-uniform: scalar registers -- as vector registers they are spilled, and a reload waits for every load in flight)
     auto sgpr = [](float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); };
@@ -734,6 +650,7 @@ struct RrPrepArgs {
     const float *W[3], *bias[3], *bn_mean[3], *bn_scale[3], *bn_shift[3];
     int k_total[3], n_out[3], act[3];
     int d_x;
+    int pack16;                    // k-slot order of layer_rp.hip
 };
 
 __device__ __forceinline__ float rr_prep_bn(const RrPrepArgs &p, int st, int row) { return p.bn_scale[st] ? p.bn_scale[st][row] : 1.f; }
@@ -785,7 +702,8 @@ __global__ __launch_bounds__(1024) void layer_rr_prepare_kernel(RrPrepArgs p, un
         prep[RRH_MAGIC] = RR_MAGIC; prep[RRH_EE] = (unsigned)Ee; prep[RRH_E0] = (unsigned)E0; prep[RRH_E1] = (unsigned)E1;
         prep[RRH_EMIN] = (unsigned)emin; prep[RRH_BAD] = bad ? 1u : 0u;
         prep[RRH_ACT] = (p.act[0] == 1 ? 1u : 0u) | (p.act[1] == 1 ? 2u : 0u) | (p.act[2] == 1 ? 4u : 0u);
-        for (int i = 7; i < RR_HDR; ++i) prep[i] = 0;
+        prep[RRH_PACK] = p.pack16 ? 1u : 0u;
+        for (int i = 8; i < RR_HDR; ++i) prep[i] = 0;
     }
     // ---- fragments: one thread per (fragment, lane) --------------------------------------------------------------------------------
     rr_u4 *frag = reinterpret_cast<rr_u4 *>(prep + RR_HDR);
@@ -803,12 +721,19 @@ __global__ __launch_bounds__(1024) void layer_rr_prepare_kernel(RrPrepArgs p, un
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             int k;
-            if (st == 0) { k = 16 * c + 8 * h + s; k = k < p.k_total[0] ? k : (k == 16 * RR_NKE - 1 ? -2 : -1); }
+            if (st == 0 && p.pack16) {
+                // x_i on slots 0 .. 31 (slot 31: the constant 1 of the node pack = the bias), x_j on 32 .. 63, the edge-level columns from 64
+                const int j = 16 * c + 8 * h + s;
+                if (j < 32) k = j < p.d_x ? j : (j == 31 ? -2 : -1);
+                else if (j < 64) k = j - 32 < p.d_x ? p.d_x + (j - 32) : -1;
+                else k = 2 * p.d_x + (j - 64) < p.k_total[0] ? 2 * p.d_x + (j - 64) : -1;
+            } else if (st == 0) { k = 16 * c + 8 * h + s; k = k < p.k_total[0] ? k : (k == 16 * RR_NKE - 1 ? -2 : -1); }
             else if (st == 1) {
                 if (c < NKS) k = p.d_x + rr_kslot_feature(c, h, s);
                 else {
                     const int j = 16 * (c - NKS) + 8 * h + s;
-                    k = j < p.d_x ? j : (j < p.d_x + 4 ? p.d_x + Wd + (j - p.d_x) : -1);
+                    if (p.pack16) k = j < p.d_x ? j : (j < p.d_x + 2 ? p.d_x + Wd : -1);          // (the in-degree as a high / low pair)
+                    else k = j < p.d_x ? j : (j < p.d_x + 4 ? p.d_x + Wd + (j - p.d_x) : -1);
                 }
             } else k = rr_kslot_feature(c, h, s);
             wv[s] = k >= 0 ? p.W[st][(int64_t)row * p.k_total[st] + k] * sc : (k == -2 ? rr_prep_c0(p, 0, row) * rr_pow2(Ee + 127) : 0.f);
@@ -844,10 +769,18 @@ static bool rr_stage_ok(const gsn_chain_stage &g, int width) {
     return true;
 }
 
-int rr_supported(const gsn_chain_stage *edge, int64_t d_x, const gsn_chain_stage *node0, const gsn_chain_stage *node1) {
+// what both register-resident kernels (this file's and layer_rp.hip's) ask of the stages: every stage 128 wide, d_x + 4 <= 32
+int rr_shape_ok(const gsn_chain_stage *edge, int64_t d_x, const gsn_chain_stage *node0, const gsn_chain_stage *node1) {
     if (!rr_enabled() || !edge || !node0 || !node1) return 0;
-    const int width = 128;                              // (instantiated: every stage 128 wide, d_x + 4 <= 32)
+    const int width = 128;
     if (!rr_stage_ok(*edge, width) || !rr_stage_ok(*node0, width) || !rr_stage_ok(*node1, width)) return 0;
+    if (d_x < 4 || (d_x & 3) || d_x + 4 > 32) return 0;
+    if (node0->n_blocks != 0 || node1->n_blocks != 0) return 0;
+    return 1;
+}
+
+int rr_supported(const gsn_chain_stage *edge, int64_t d_x, const gsn_chain_stage *node0, const gsn_chain_stage *node1) {
+    if (!rr_shape_ok(edge, d_x, node0, node1)) return 0;
     if (edge->n_blocks < 1 || edge->n_blocks > 6 || !edge->blocks) return 0;
     int64_t ke = 0;
     const void *roles[RR_MAXROLE];
@@ -862,17 +795,15 @@ int rr_supported(const gsn_chain_stage *edge, int64_t d_x, const gsn_chain_stage
         if (!seen) { if (nroles == RR_MAXROLE) return 0; roles[nroles++] = bl.idx32; }
     }
     if (ke > 16 * RR_NKE - 4) return 0;                // (the last k-slot is the bias column)
-    if (d_x < 4 || (d_x & 3) || d_x + 4 > 32) return 0;
-    if (node0->n_blocks != 0 || node1->n_blocks != 0) return 0;
     return 1;
 }
 
 int64_t rr_prepared_bytes(const gsn_chain_stage *edge, int64_t d_x, const gsn_chain_stage *node0, const gsn_chain_stage *node1) {
-    if (!rr_supported(edge, d_x, node0, node1)) return 0;
+    if (!rr_supported(edge, d_x, node0, node1) && !rp_supported(edge, d_x, node0, node1)) return 0;
     return (int64_t)RrShape<4, 2>::PREP_WORDS * 4;
 }
 
-int rr_prepare(const gsn_chain_stage *edge, int64_t d_x, const gsn_chain_stage *node0, const gsn_chain_stage *node1, void *prepared, hipStream_t st) {
+int rr_prepare(const gsn_chain_stage *edge, int64_t d_x, const gsn_chain_stage *node0, const gsn_chain_stage *node1, void *prepared, hipStream_t st, bool pack16) {
     RrPrepArgs p{};
     const gsn_chain_stage *gs[3] = {edge, node0, node1};
     int ke = 0;
@@ -882,7 +813,7 @@ int rr_prepare(const gsn_chain_stage *edge, int64_t d_x, const gsn_chain_stage *
         p.W[s] = gs[s]->W; p.bias[s] = gs[s]->bias; p.bn_mean[s] = gs[s]->bn_mean; p.bn_scale[s] = gs[s]->bn_scale; p.bn_shift[s] = gs[s]->bn_shift;
         p.k_total[s] = kt[s]; p.n_out[s] = (int)gs[s]->n_out; p.act[s] = gs[s]->act;
     }
-    p.d_x = (int)d_x;
+    p.d_x = (int)d_x; p.pack16 = pack16 ? 1 : 0;
     hipLaunchKernelGGL((layer_rr_prepare_kernel<4, 2>), dim3(1), dim3(1024), 0, st, p, reinterpret_cast<unsigned *>(prepared));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(GSN_E_HIP, "layer_rr_prepare_kernel: %s", hipGetErrorString(e));

@@ -45,15 +45,46 @@ __device__ __forceinline__ void rr_mfma_settle() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// fp32 fma -> one half of a packed fp16 pair, one instruction each (v_fma_mixlo_f16 writes bits 15:0, v_fma_mixhi_f16 bits 31:16, the
+// other half is kept): a pair of planes of (a s, b s) is FOUR instructions -- the scale rides the fma, the residual a s - hi is formed
+// and rounded in one go -- against two multiplies, a packed convert, two v_fma_mix_f32 and another packed convert (r03).  Same roundings,
+// same bits (a s is exact: s is a power of two).
+__device__ __forceinline__ unsigned rr_mix_pack_s(float a, float b, float s) {
+    unsigned r;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(r) : "v"(b), "v"(s));
+    return r;
+}
+__device__ __forceinline__ unsigned rr_mix_res_s(float a, float b, float s, unsigned pair) {
+    unsigned r;
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(a), "v"(s), "v"(pair));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(r) : "v"(b), "v"(s), "v"(pair));
+    return r;
+}
+__device__ __forceinline__ unsigned rr_mix_res(float a, float b, unsigned pair) {
+    unsigned r;
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(a), "v"(pair));
+    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(r) : "v"(b), "v"(pair));
+    return r;
+}
 // (a, b) -> packed fp16 high parts and low parts (round to nearest)
 __device__ __forceinline__ void rr_split2(float a, float b, unsigned &hi, unsigned &lo) {
     hi = rr_pack_h2(a, b);
+#ifdef RR_SPLIT_R03
     lo = rr_pack_h2(rr_res_lo(a, hi), rr_res_hi(b, hi));
+#else
+    lo = rr_mix_res(a, b, hi);
+#endif
 }
 // the same of (a s, b s)
 __device__ __forceinline__ void rr_split2s(float a, float b, float s, unsigned &hi, unsigned &lo) {
+#ifdef RR_SPLIT_R03
     hi = rr_pack_h2(a * s, b * s);
     lo = rr_pack_h2(rr_res_lo_s(a, s, hi), rr_res_hi_s(b, s, hi));
+#else
+    hi = rr_mix_pack_s(a, b, s);
+    lo = rr_mix_res_s(a, b, s, hi);
+#endif
 }
 // the same, also returning the OR of the residuals' bits (zero: both exact in fp16)
 __device__ __forceinline__ void rr_split2r(float a, float b, unsigned &hi, unsigned &res) {

@@ -30,7 +30,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import _abi
+from . import _abi, packs
 
 __all__ = ["mlp", "central_encoder", "GSN_sparse", "GSN_edge_sparse", "MPNN_sparse", "MPNN_edge_sparse",
            "GSN_edge_sparse_ogb", "MPNN_edge_sparse_ogb", "build_csr", "propagate", "run_stages", "one_hot_identifiers",
@@ -756,7 +756,7 @@ def invalidate_caches(module=None):
         _CSR_CACHE.clear()
         return
     for m in module.modules():
-        for attr in ("_fold_cache", "_split_cache", "_fused_prep", "_gsn_eval_cache", "_gsn_wt"):
+        for attr in ("_fold_cache", "_split_cache", "_fused_prep", "_fused_prep16", "_gsn_eval_cache", "_gsn_wt"):
             if hasattr(m, attr):
                 try:
                     delattr(m, attr)
@@ -809,7 +809,10 @@ def _prep_key(st):
 CHAIN_ROW_EXPONENTS = os.environ.get("GSN_CHAIN_ROW_EXP", "1") != "0"      # 128-wide one-launch layers leave their output's row exponents for the next layer
 
 
-def _layer_fused(x, csr, edge_stages, node_stages, training, owner=None, gen=0):
+PACK16_LAYER = os.environ.get("GSN_LAYER_PACK16", "1") != "0"   # tagged exact inputs: the packed-row kernel (csrc/layer_rp.hip)
+
+
+def _layer_fused(x, csr, edge_stages, node_stages, training, owner=None, gen=0, pack16=None):
     """edge stage + per-target sum + two node stages in ONE launch (gsn_layer_fused_fwd_hip); None if the layer does not
     fit (shape, activation, or a BatchNorm1d that needs batch statistics)."""
     if not FUSED_LAYER or len(edge_stages) != 1 or len(node_stages) != 2:
@@ -835,20 +838,48 @@ def _layer_fused(x, csr, edge_stages, node_stages, training, owner=None, gen=0):
     d_x = x.shape[1]
     if node_stages[0].weight.shape[1] != d_x + edge_stages[0].weight.shape[0] + 4:
         return None
-    if not L.gsn_layer_fused_supported(ctypes.byref(ge), d_x, ctypes.byref(g0), ctypes.byref(g1)):
-        return None
     n = x.shape[0]
     E = csr.tgt.numel()
-    out = torch.empty((n, node_stages[1].weight.shape[0]), dtype=torch.float32, device=x.device)
     flops = 2.0 * E * edge_stages[0].weight.shape[1] * edge_stages[0].weight.shape[0]
     flops += 2.0 * n * (node_stages[0].weight.shape[1] * node_stages[0].weight.shape[0] + node_stages[1].weight.shape[1] * node_stages[1].weight.shape[0])
+    # tagged exact inputs (gsn_amd.packs): the same layer on their fp16 packs -- own prepared weights (another k-slot order), kept beside
+    # the fp32 kernel's under their own key
+    if pack16 is not None and PACK16_LAYER and L.gsn_layer_fused_pack16_supported(ctypes.byref(ge), d_x, ctypes.byref(g0), ctypes.byref(g1)):
+        key = (tuple(_prep_key(st) for st in stages), d_x, gen, "pack16")
+        hit = getattr(owner, "_fused_prep16", None) if owner is not None else None
+        if hit is not None and hit[0] == key:
+            prep = hit[1]
+        else:
+            nbytes = int(L.gsn_layer_fused_pack16_prepared_bytes(ctypes.byref(ge), d_x, ctypes.byref(g0), ctypes.byref(g1)))
+            prep = torch.empty(nbytes // 4, dtype=torch.int32, device=x.device)
+            with _abi.device_guard(x.device):
+                _abi.check(L.gsn_layer_fused_pack16_prepare_hip(ctypes.byref(ge), d_x, ctypes.byref(g0), ctypes.byref(g1), prep.data_ptr(),
+                                                                _abi.current_stream()), "gsn_layer_fused_pack16_prepare_hip")
+            if owner is not None:
+                owner._fused_prep16 = (key, prep)
+        out = torch.empty((n, node_stages[1].weight.shape[0]), dtype=torch.float32, device=x.device)
+        pk = _abi.gsn_pack16()
+        pk.node_rows = pack16[0].data_ptr()
+        pk.edge_rows = None if pack16[1] is None else pack16[1].data_ptr()
+        e_rows = 0 if pack16[1] is None else pack16[1].shape[0]
+        with _abi.device_guard(x.device), _timed("layer_fused", flops):
+            rc = L.gsn_layer_fused_fwd_pack16_hip(n, E, csr.seg_ptr.data_ptr(), ctypes.byref(ge), x.data_ptr(), d_x, ctypes.byref(g0), ctypes.byref(g1),
+                                                  prep.data_ptr(), ctypes.byref(pk), e_rows, out.data_ptr(), _abi.current_stream())
+        if rc != -2:                      # (GSN_E_UNSUPPORTED: packs beyond 32-bit offsets -> the fp32 kernel below)
+            _abi.check(rc, "gsn_layer_fused_fwd_pack16_hip")
+            return out
     # the weights as the kernel's register fragments: once per weight version (kept on the layer module)
-    key = (tuple(_prep_key(st) for st in stages), d_x, gen)
+    if not L.gsn_layer_fused_supported(ctypes.byref(ge), d_x, ctypes.byref(g0), ctypes.byref(g1)):
+        return None
+    out = torch.empty((n, node_stages[1].weight.shape[0]), dtype=torch.float32, device=x.device)
+    # (the kernel variant the buffer is for -- this file's kernel alone, with the register-resident fragments appended, the d = 128
+    #  layout -- follows from the block properties of THIS call: its size is part of the key)
+    nbytes = int(L.gsn_layer_fused_prepared_bytes(ctypes.byref(ge), d_x, ctypes.byref(g0), ctypes.byref(g1)))
+    key = (tuple(_prep_key(st) for st in stages), d_x, gen, nbytes)
     hit = getattr(owner, "_fused_prep", None) if owner is not None else None
     if hit is not None and hit[0] == key:
         prep = hit[1]
     else:
-        nbytes = int(L.gsn_layer_fused_prepared_bytes(ctypes.byref(ge), d_x, ctypes.byref(g0), ctypes.byref(g1)))
         prep = torch.empty(nbytes // 4, dtype=torch.int32, device=x.device)
         with _abi.device_guard(x.device):
             _abi.check(L.gsn_layer_fused_prepare_hip(ctypes.byref(ge), d_x, ctypes.byref(g0), ctypes.byref(g1), prep.data_ptr(),
@@ -1729,9 +1760,13 @@ class _SparseLayer(nn.Module):
                     sblocks.append((ef, csr.perm))
                 # the whole layer in one launch where it fits (eval-mode BatchNorm, K_edge <= 80, widths <= 128)
                 if post is None or post[0] is None or post[0].training == uf.training:
+                    pk = None
+                    if PACK16_LAYER and not (self.has_ids and self.id_scope != "local"):
+                        # exact fp16 packs of the inputs, when their producers left them (gsn_amd.packs): looked up on the caller's tensors
+                        pk = packs.lookup(raw[0], [t for t in (raw[1] if self.has_ids else None, raw[2] if self.has_ef else None) if t is not None])
                     y = _layer_fused(x, csr, mf.stages(sblocks, upto=len(mf.fc) - 1),
                                      uf.stages([(x, None)], first_weight=self._folded_first_weight(x.shape[1]), post=post),
-                                     self.training, owner=self, gen=getattr(self, "_fold_gen", 0))
+                                     self.training, owner=self, gen=getattr(self, "_fold_gen", 0), pack16=pk)
                     if y is not None:
                         return y
                 # wide edge rows (K > 160: layers 1.. of a d = 128 model, K = 260): the node part of the Linear once per NODE,

@@ -135,6 +135,15 @@ int gsn_count_encode_hip(const uint32_t *plan_host, const uint32_t *plan_dev, in
                          int64_t edge_row_stride, int ids_are_global, const int32_t *graph_ids, int64_t n_items,
                          int64_t max_nodes, int64_t max_edges, int64_t *out, int32_t *status, const int32_t *n_classes,
                          int clamp, float *enc_out, void *stream);
+/* The same, and the encoded rows a second time as fp16 into columns pack_col0 .. of an exact row pack (gsn_pack16 below: the layout the
+ * packed-row layer kernel reads; 1.0 = 0x3c00): `pack` fp16 device [rows_total][pack_stride], only the sum n_classes columns from
+ * pack_col0 are written.  Written from the kernel's staged class indices: GSN_E_UNSUPPORTED when those are not staged (a graph split
+ * over several workgroups, a column with more than 255 classes) -- pack the fp32 rows with gsn_pack16_rows_hip then. */
+int gsn_count_encode_pack16_hip(const uint32_t *plan_host, const uint32_t *plan_dev, int64_t plan_words, int64_t n_graphs,
+                                const int64_t *node_ptr, const int64_t *edge_ptr, const int64_t *edge_index,
+                                int64_t edge_row_stride, int ids_are_global, const int32_t *graph_ids, int64_t n_items,
+                                int64_t max_nodes, int64_t max_edges, int64_t *out, int32_t *status, const int32_t *n_classes,
+                                int clamp, float *enc_out, uint16_t *pack, int64_t pack_stride, int64_t pack_col0, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * HP-2  aggregation target index (device).  The scatter-add of the layers,
@@ -331,6 +340,39 @@ int gsn_layer_fused_fwd_ws_hip(int64_t n_nodes, int64_t n_edges, const int32_t *
                                const float *x, int64_t d_x, const gsn_chain_stage *node0, const gsn_chain_stage *node1,
                                const void *prepared, float *out, void *workspace, int64_t workspace_bytes,
                                const int32_t *x_row_exp, int32_t *out_row_exp, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * HP-2  the same one-launch layer on EXACT fp16 ROW PACKS (csrc/layer_rp.hip).  Layer 0 of every reference model reads one-hot /
+ * small-integer encodings (utils_graph_learning.py:78-88, :170-187: DiscreteEmbedding('one_hot_encoder')): every value is exact in
+ * fp16.  A producer that knows this (gsn_count_encode_hip, gsn_one_hot_hip, or gsn_pack16_rows_hip over an existing fp32 tensor) writes
+ * the rows a second time as fp16 in the layout the matrix pipe reads, and the layer kernel skips what it otherwise does per edge row:
+ * gathering fp32, converting, testing the conversion for exactness.  Same arithmetic, same results as gsn_layer_fused_fwd_hip.
+ *   node_rows  fp16 [n_nodes][32]   columns 0 .. d_x-1 = x, columns d_x .. 30 = 0, column 31 = 1.0   (16-byte aligned)
+ *   edge_rows  fp16 [edge_rows][16] the edge-level blocks of the edge stage (identifiers, edge features) concatenated in block order,
+ *                                   zero padded; NULL when the edge stage is cat(x[i], x[j]) alone
+ * Every value must be exactly what the fp32 tensors hold and < 2 in magnitude (the edge stage's weight scale is made for that bound);
+ * gsn_pack16_rows_hip checks both and ORs 1 into *status (device int32, caller-zeroed) when a value is not.
+ * The edge stage must be: block 0 = x through an int32 index, block 1 = x through another, blocks 2.. = the edge-level blocks, all through
+ * ONE int32 index (perm of gsn_csr_build_hip), <= 16 columns together; widths as gsn_layer_fused_fwd_hip's register-resident shape
+ * (every stage 128 wide, d_x + 4 <= 32).  The prepared weights are NOT those of gsn_layer_fused_prepare_hip (another k-slot order):
+ * gsn_layer_fused_pack16_prepare_hip into gsn_layer_fused_pack16_prepared_bytes() bytes.  The fp32 `data` pointers of the blocks are not
+ * read.  gsn_layer_fused_fwd_pack16_hip returns GSN_E_UNSUPPORTED when the packs are beyond its 32-bit byte offsets (n_nodes >= 2^25).
+ * ---------------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    const uint16_t *node_rows;
+    const uint16_t *edge_rows;
+} gsn_pack16;
+int gsn_pack16_rows_hip(const float *src, int64_t rows, int64_t width, uint16_t *dst, int64_t dst_stride, int64_t col0,
+                        int64_t one_col, int32_t *status, void *stream);
+int gsn_layer_fused_pack16_supported(const gsn_chain_stage *edge, int64_t d_x, const gsn_chain_stage *node0,
+                                     const gsn_chain_stage *node1);
+int64_t gsn_layer_fused_pack16_prepared_bytes(const gsn_chain_stage *edge, int64_t d_x, const gsn_chain_stage *node0,
+                                              const gsn_chain_stage *node1);
+int gsn_layer_fused_pack16_prepare_hip(const gsn_chain_stage *edge, int64_t d_x, const gsn_chain_stage *node0,
+                                       const gsn_chain_stage *node1, void *prepared, void *stream);
+int gsn_layer_fused_fwd_pack16_hip(int64_t n_nodes, int64_t n_edges, const int32_t *seg_ptr, const gsn_chain_stage *edge,
+                                   const float *x, int64_t d_x, const gsn_chain_stage *node0, const gsn_chain_stage *node1,
+                                   const void *prepared, const gsn_pack16 *pack, int64_t edge_rows, float *out, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * HP-2  dense stage on DIRECT rows with fp16x3 matrix arithmetic (device): the same operation as gsn_linear_fwd_hip

@@ -42,8 +42,18 @@ def main():
     f_alg = 2.0 * E * ((2 * d_in + 16) * 128 + 128 * 128) + 2.0 * N * ((d_in + 128) * 128 + 128 * 128)
     res = {"graphs": args.graphs, "N": N, "E": E, "B_alg_bytes": b_alg, "F_alg_flops": f_alg}
     ys = {}
-    for name, fused in (("fused", True), ("multi_launch", False)):
+    from gsn_amd import packs
+    variants = [("fused", True), ("multi_launch", False)]
+    if not args.float_inputs and not args.wide:
+        variants.insert(0, ("fused_pack16", True))       # tagged exact inputs: csrc/layer_rp.hip
+    for name, fused in variants:
         layers.FUSED_LAYER = fused
+        if name == "fused_pack16":
+            packs.node_pack(x)
+            packs.edge_pack([ids, ef])
+        else:
+            for t in (x, ids, ef):
+                packs.release(t)
         with torch.no_grad():
             for _ in range(10):
                 y = layer(x, ei, identifiers=ids, degrees=deg, edge_features=ef)      # CSR cached: the layer launches only
@@ -62,6 +72,8 @@ def main():
         ys[name] = y
     err = float((ys["fused"] - ys["multi_launch"]).abs().max() / ys["multi_launch"].abs().max())
     res["max_diff_over_max"] = float("%.3g" % err)
+    if "fused_pack16" in ys:
+        res["pack16_max_diff_over_max"] = float("%.3g" % float((ys["fused_pack16"] - ys["multi_launch"]).abs().max() / ys["multi_launch"].abs().max()))
     print(json.dumps(res))
 
 
