@@ -541,9 +541,31 @@ def main():
     if os.environ.get("GSN_BENCH_GENERIC_CSR", "0") == "0":
         layers.set_graph_partition(ei, node_ptr, edge_ptr, max_nodes, max_edges, check=False)
 
-    def step():
+    # Exact fp16 row packs (gsn_amd.packs): every input of this layer is a one-hot encoding, exact in fp16.  The static inputs (x, bond
+    # types) get their packs where their fp32 one-hot rows are made -- once, outside the timed region, like those rows themselves; the
+    # identifiers' columns are written by the counting kernel inside the timed step, next to the fp32 rows it writes anyway.  The layer
+    # then runs csrc/layer_rp.hip (same arithmetic, no fp32 -> fp16 conversion of its gathered rows).  GSN_BENCH_PACK16=0: the fp32-row
+    # kernel (csrc/layer_rr.hip), reported beside the headline as kernels.layer_fp32_rows either way.
+    from gsn_amd import packs
+    use_pack = os.environ.get("GSN_BENCH_PACK16", "1") != "0" and os.environ.get("GSN_FUSED_RR", "1") != "0"
+    epack = None
+    if use_pack:
+        packs.node_pack(x, check=True)
+        epack = packs.new_edge_pack(E, dev)
+        packs._pack_rows(ef, epack, 12, -1, True)
+        packs.claim(ef, epack, 12)
+
+    def step(fork=True, int64_ids=False):
         layers._CSR_CACHE.clear()             # the CSR of a fresh batch is part of the forward pass
         main = torch.cuda.current_stream(dev)
+        if not fork:                          # (the captured variant without a second branch)
+            layers._csr_for(ei, sel, N)
+            with layers._timed("count", 16.0 * E + 4.0 * E * 12):
+                count_batch(plan, node_ptr, edge_ptr, ei, ids_are_global=True, max_nodes=max_nodes, max_edges=max_edges,
+                            device=dev, check=False, encode=([3, 3, 3, 3], True), counts=False, encoded_out=idf_out,
+                            encoded_pack=(epack, 0) if use_pack else None)
+            with torch.no_grad():
+                return layer(x, ei, identifiers=idf_out, degrees=degrees, edge_features=ef)
         # The layer's target-sorted CSR depends only on edge_index, the counting only on the graphs: the CSR build (small
         # memory-bound kernels) runs on a second HIP stream under the VALU-bound counting kernel.  The side stream first
         # waits for the main stream so that CSR buffers recycled by the allocator are no longer read by the previous step.
@@ -554,7 +576,8 @@ def main():
         # int64 identifiers, then DiscreteEmbedding('one_hot_encoder'), utils_graph_learning.py:78 / :170-187) -- no int64 round trip
         with layers._timed("count", 16.0 * E + 4.0 * E * 12):
             count_batch(plan, node_ptr, edge_ptr, ei, ids_are_global=True, max_nodes=max_nodes, max_edges=max_edges,
-                        device=dev, check=False, encode=([3, 3, 3, 3], True), counts=False, encoded_out=idf_out)
+                        device=dev, check=False, encode=([3, 3, 3, 3], True), counts=int64_ids, out=ids_out if int64_ids else None,
+                        encoded_out=idf_out, encoded_pack=(epack, 0) if use_pack else None)
         main.wait_stream(side)
         with torch.no_grad():
             return layer(x, ei, identifiers=idf_out, degrees=degrees, edge_features=ef)
@@ -594,39 +617,78 @@ def main():
     occ_pos, n_maps = work_figures([list(nx.cycle_graph(k).edges) for k in range(3, 7)], ids_out)
 
     # Diagnostic (never `value`): the same K steps replayed from ONE captured HIP graph of the step (same kernels, same inputs).
-    dt_graph, graph_note = None, None
+    dt_graph, graph_note, dt_graph_fork = None, None, None
     if not args.no_graph:
-        ok = 1
-        try:
-            gobj = torch.cuda.CUDAGraph()
-            cap = torch.cuda.Stream(device=dev)
-            cap.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(cap):
-                step()
-            torch.cuda.current_stream(dev).wait_stream(cap)
-            with torch.cuda.graph(gobj):
-                y_g = step()
-            for _ in range(3):
-                gobj.replay()
-            sync()
-            if not (torch.isfinite(y_g).all() and torch.allclose(y_g, y, rtol=1e-4, atol=1e-5)):
-                raise RuntimeError("graph replay output differs from the eager step")
-        except Exception as e:       # capture is best effort
-            ok, graph_note = 0, "capture failed: " + str(e)[:160]
-        if dist is not None:         # every rank takes the same branch
-            f = torch.tensor([ok], device=dev, dtype=torch.int32)
-            dist.all_reduce(f, op=dist.ReduceOp.MIN)
-            ok = int(f.item())
-        if ok:
-            sync()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                gobj.replay()
-            sync()
-            dt_graph = time.perf_counter() - t0
-            dt_graph = gdist.max_over_ranks(dt_graph, dev)
-    dt_eager = dt      # the headline is the eager timing, always; the graph replay is a diagnostic (hipGraph serialises the CSR branch
-                       # that the eager step runs on a second stream under the counting kernel: replay is ~0.3 ms slower)
+        # two captures: the step as it runs eagerly (CSR build forked onto the side stream: two branches in the graph) and the same
+        # kernels in one chain.  hipGraph runs the branches of the forked capture on its own internal streams without the side stream's
+        # priority, and the join costs a cross-stream signal each way: measured 1.02 ms forked vs 0.81 eager in round 3.
+        res_g = {}
+        for tag, fork in (("fork", True), ("chain", False)):
+            ok = 1
+            try:
+                gobj = torch.cuda.CUDAGraph()
+                cap = torch.cuda.Stream(device=dev)
+                cap.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(cap):
+                    step(fork=fork)
+                torch.cuda.current_stream(dev).wait_stream(cap)
+                with torch.cuda.graph(gobj):
+                    y_g = step(fork=fork)
+                for _ in range(3):
+                    gobj.replay()
+                sync()
+                if not (torch.isfinite(y_g).all() and torch.allclose(y_g, y, rtol=1e-4, atol=1e-5)):
+                    raise RuntimeError("graph replay output differs from the eager step")
+            except Exception as e:       # capture is best effort
+                ok, graph_note = 0, "capture failed: " + str(e)[:160]
+            if dist is not None:         # every rank takes the same branch
+                f = torch.tensor([ok], device=dev, dtype=torch.int32)
+                dist.all_reduce(f, op=dist.ReduceOp.MIN)
+                ok = int(f.item())
+            if ok:
+                sync()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    gobj.replay()
+                sync()
+                res_g[tag] = gdist.max_over_ranks(time.perf_counter() - t0, dev)
+            del gobj
+        dt_graph_fork = res_g.get("fork")
+        dt_graph = min(res_g.values()) if res_g else None
+    dt_eager = dt      # the headline is the eager timing, always; the graph replays are diagnostics
+
+    # Supplementary (never `value`): the same step with HP-1's defined output inside the timed region -- the counting kernel also
+    # writes the int64 identifiers (utils_ids.py:19-27), E x 4 x 8 bytes more.
+    for _ in range(3):
+        step(int64_ids=True)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(int64_ids=True)
+    sync()
+    dt_ids = gdist.max_over_ranks(time.perf_counter() - t0, dev)
+
+    # Supplementary: the layer alone, back to back, on its fp16 packs (the timed step's kernel) and on the fp32 rows (csrc/layer_rr.hip)
+    layer_alone = {}
+    if world == 1 and not args.no_extras:
+        with torch.no_grad():
+            for tag in (("pack16_rows", "fp32_rows") if use_pack else ("fp32_rows",)):
+                if tag == "fp32_rows":
+                    saved = [(t, getattr(t, "_gsn_pack16", None)) for t in (x, ef, idf_out)]
+                    for t, _ in saved:
+                        packs.release(t)
+                for _ in range(10):
+                    layer(x, ei, identifiers=idf_out, degrees=degrees, edge_features=ef)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(30):
+                    layer(x, ei, identifiers=idf_out, degrees=degrees, edge_features=ef)
+                e1.record()
+                torch.cuda.synchronize()
+                layer_alone[tag] = round(e0.elapsed_time(e1) / 30, 4)
+                if tag == "fp32_rows":
+                    for t, tg in saved:
+                        t._gsn_pack16 = tg
 
     # Supplementary (never `value`): the same step with the layer fed the integer codes instead of their dense one-hot
     # encodings (layers.Codes -> weight-row-gather edge stage); same parameters, same output to 1e-5.
@@ -782,13 +844,15 @@ def main():
             rr = os.environ.get("GSN_FUSED_RR", "1") != "0"
             if rr:
                 n_t, n_b = rr_tiling(layers._csr_for(ei, sel, N).seg_ptr.cpu().numpy().astype(np.int64), N)
-                f_exec = 32768.0 * (n_b * (5 * 4 * 2 + 2 * 4 * 2) + n_t * (10 + 8) * 4 * 3)
+                # (csrc/layer_rp.hip: the x part of node stage 0 is exact as well -- two products for its two chunks instead of three)
+                f_exec = 32768.0 * (n_b * (5 * 4 * 2 + 2 * 4 * 2) + n_t * ((8 * 3 + 2 * 2 + 8 * 3) if use_pack else (10 + 8) * 3) * 4)
             else:
                 f_exec = 2.0 * (2.0 * E * 72 * 128) + 3.0 * (2.0 * N * ((28 + 128 + 4) * 128 + 128 * 128))
             t_hbm, t_mfma = b_launch / (HBM_PEAK_GBS * 1e9), f_exec / (MFMA_BF16_PEAK_TF * 1e12)
             hbm = b_launch / t_k / 1e9
             executed = f_exec / t_k / 1e12
-            common = {"kernel": ("layer_fused_kernel_rr<4,2> (csrc/layer_rr.hip: " if rr else "layer_fused_kernel<5,10,8,4> (csrc/layer_fused.hip: ") +
+            common = {"kernel": (("layer_fused_kernel_rp<4,2> (csrc/layer_rp.hip, inputs as exact fp16 row packs: " if use_pack else "layer_fused_kernel_rr<4,2> (csrc/layer_rr.hip: ")
+                                 if rr else "layer_fused_kernel<5,10,8,4> (csrc/layer_fused.hip: ") +
                                 "edge stage + per-node sums + node stages 0 and 1 in one launch)",
                       "matrix_dtype": "fp16x3: operands split into two fp16 planes after exact power-of-two row / matrix scaling, three plane "
                                       "products per fp32 product on v_mfma_f32_32x32x16_f16 with fp32 accumulation (two where the rows are exact in fp16)",
@@ -856,6 +920,10 @@ def main():
             "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 4),
             "eager_ms_per_step": round(dt_eager / args.steps * 1e3, 4),
             "hip_graph_ms_per_step": None if dt_graph is None else round(dt_graph / args.steps * 1e3, 4),
+            "hip_graph_forked_ms_per_step": None if dt_graph_fork is None else round(dt_graph_fork / args.steps * 1e3, 4),
+            "step_with_int64_ids": {"ms_per_step": round(dt_ids / args.steps * 1e3, 4), "graphs_per_s": round(world * G * args.steps / dt_ids, 1),
+                                    "note": "the timed step with the int64 identifiers (utils_ids.py:27) written by the counting kernel as well"},
+            "layer_alone_ms": layer_alone,
             "launch": "eager",
         })
         if graph_note:

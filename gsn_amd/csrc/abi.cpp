@@ -37,6 +37,20 @@ extern "C" int gsn_device_count(void) {
     return good;
 }
 
+// 0 when `stream` is not being captured into a graph, else the capture's id (unique per capture sequence, hipStreamGetCaptureInfo).
+// The host side keys its zero-initialised scratch arenas on it: a buffer whose fill was recorded into one capture must not be
+// handed out in another capture or in eager execution (the fill would not run there).
+extern "C" int64_t gsn_stream_capture_id(void *stream) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    unsigned long long id = 0;
+    if (hipStreamGetCaptureInfo(reinterpret_cast<hipStream_t>(stream), &st, &id) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    if (st == hipStreamCaptureStatusNone) return 0;
+    return (int64_t)(id ? id : 1);
+}
+
 namespace gsn {
 int current_device() {
     int dev = -1;

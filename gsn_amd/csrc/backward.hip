@@ -354,8 +354,11 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradArgs a) {
         }
 }
 
+// Workgroups along the rows: every workgroup ends with one fp64 atomic per column onto the SAME n_cols addresses, which the L2
+// serialises (~20 ns each: 1024 workgroups = 20 us whatever the row count -- the whole run time at the reference's batch sizes,
+// E ~ 6 000 rows), so a workgroup takes at least 64 rows (16 per wave).
 static int bgrid(int64_t m_rows) {
-    int64_t b = (m_rows + 3) / 4;
+    int64_t b = (m_rows + 63) / 64;
     return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
 }
 
@@ -400,10 +403,14 @@ extern "C" int gsn_wgrad_hip(int64_t m_rows, int64_t n_out, const float *grad_h,
     a.k_total = k;
     if (m_rows <= 0) return GSN_OK;
     const int tn = (int)((n_out + WG_T - 1) / WG_T), tk = (k + WG_T - 1) / WG_T;
-    // enough row slabs to fill the chip, but slabs of at least 256 rows (each one ends with 128 x 128 atomics)
+    // enough row slabs to fill the chip, but slabs of at least 256 rows (each one ends with 128 x 128 atomics).  Small batches (the
+    // reference's 32 / 128 graphs: M ~ 800 .. 6 000 rows) are bound by the serial chain of 16-row steps inside a slab instead (load ->
+    // split -> LDS -> products, ~1.2 us per step with one workgroup per CU and nothing to hide the latency: 60 us per call at 256 rows):
+    // 64-row slabs there.
     int64_t slabs = (2048 + tn * tk - 1) / (tn * tk);
     int64_t rows_per = (m_rows + slabs - 1) / slabs;
-    if (rows_per < 256) rows_per = 256;
+    const int64_t min_rows = m_rows >= 65536 ? 256 : 64;
+    if (rows_per < min_rows) rows_per = min_rows;
     rows_per = (rows_per + WG_RB - 1) / WG_RB * WG_RB;
     a.rows_per_wg = rows_per;
     slabs = (m_rows + rows_per - 1) / rows_per;

@@ -714,6 +714,7 @@ __global__ __launch_bounds__(1024) void layer_rr_prepare_kernel(RrPrepArgs p, un
         else if (f < SH::F_W0XL) { st = 1; const int q = f - SH::F_W0H; plane = 0; c = q % NK0; blk = q / NK0; }
         else if (f < SH::F_W1) { st = 1; const int q = f - SH::F_W0XL; plane = 1; c = NKS + q % NKX; blk = q / NKX; }
         else if (f < SH::F_W0SL) { st = 2; const int q = f - SH::F_W1; plane = q & 1; c = (q >> 1) % NKS; blk = (q >> 1) / NKS; }
+        else if (p.pack16) { st = 1; const int q = f - SH::F_W0SL; plane = 1; c = (q % (2 * NKS)) >> 1; blk = 2 * (q / (2 * NKS)) + (q & 1); }   // (layer_rp.hip: [pair][c][block of the pair])
         else { st = 1; const int q = f - SH::F_W0SL; plane = 1; c = q / WB; blk = q % WB; }
         const int row = 32 * blk + l31;
         const float sc = rr_pow2((st == 0 ? Ee : (st == 1 ? E0 : E1)) + 127) * rr_prep_bn(p, st, row);

@@ -86,6 +86,27 @@ __device__ __forceinline__ void rr_split2s(float a, float b, float s, unsigned &
     lo = rr_mix_res_s(a, b, s, hi);
 #endif
 }
+// ---- the same splits two pairs at a time, compiler-visible except for the four residual instructions (layer_rp.hip).  The hazard
+// recogniser pads every inline-asm result that the NEXT instruction reads with an s_nop (it cannot know whether the asm wrote a
+// partial register), and it does not see an MFMA result -> asm read hazard at all: here the first readers of an accumulator are plain
+// C (integer max, packed multiply), the asm statements come in an order in which no two neighbours depend on each other.
+__device__ __forceinline__ float rr_imax(float x, int lo_i) { return __int_as_float(max(__float_as_int(x), lo_i)); }   // relu: lo_i = 0, identity: INT_MIN
+__device__ __forceinline__ void rr_res4(float a0, float b0, float a1, float b1, unsigned hi0, unsigned hi1, unsigned &lo0, unsigned &lo1) {
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(lo0) : "v"(a0), "v"(hi0));
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(lo1) : "v"(a1), "v"(hi1));
+    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo0) : "v"(b0), "v"(hi0));
+    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo1) : "v"(b1), "v"(hi1));
+}
+__device__ __forceinline__ void rr_split4(float a0, float b0, float a1, float b1, unsigned &hi0, unsigned &lo0, unsigned &hi1, unsigned &lo1) {
+    hi0 = rr_pack_h2(a0, b0); hi1 = rr_pack_h2(a1, b1);
+    rr_res4(a0, b0, a1, b1, hi0, hi1, lo0, lo1);
+}
+__device__ __forceinline__ void rr_split4s(float a0, float b0, float a1, float b1, float s, unsigned &hi0, unsigned &lo0, unsigned &hi1, unsigned &lo1) {
+    const rr_f2 s2 = rr_f2{s, s};
+    const rr_f2 p0 = rr_f2{a0, b0} * s2, p1 = rr_f2{a1, b1} * s2;           // (exact: s is a power of two)
+    hi0 = rr_pack_h2(p0[0], p0[1]); hi1 = rr_pack_h2(p1[0], p1[1]);
+    rr_res4(p0[0], p0[1], p1[0], p1[1], hi0, hi1, lo0, lo1);
+}
 // the same, also returning the OR of the residuals' bits (zero: both exact in fp16)
 __device__ __forceinline__ void rr_split2r(float a, float b, unsigned &hi, unsigned &res) {
     hi = rr_pack_h2(a, b);

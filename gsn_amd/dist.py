@@ -119,13 +119,36 @@ def shard_by_cost(costs, world: int):
 _BUCKETS = {}
 
 
-def allreduce_gradients(parameters, average: bool = True, group=None):
+class _Bucket:
+    __slots__ = ("flat", "views", "n_grad", "has")
+
+    def __init__(self, params, dtype, device):
+        self.n_grad = sum(p.numel() for p in params)
+        self.flat = torch.zeros(self.n_grad + len(params), dtype=dtype, device=device)
+        self.views, off = [], 0
+        for p in params:
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        self.has = None          # which parameters some rank had a gradient for, as of the last eager call
+
+
+def allreduce_gradients(parameters, average: bool = True, group=None, force: bool = False):
     """Sum (or average) the gradients of ``parameters`` over all ranks with ONE all-reduce of a flat bucket.
 
     The bucket covers EVERY parameter that requires grad -- a parameter whose ``.grad`` is None on this rank (unused
     branch, empty shard) contributes zeros and receives the reduced value -- so all ranks issue an identical collective
-    whatever their local graphs exercised.  The bucket is allocated once per parameter list and reused."""
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    whatever their local graphs exercised.  The bucket is allocated once per parameter list and reused; gradients enter and
+    leave it with one multi-tensor copy each way (not one launch per parameter).
+
+    Behind the gradients ride one has-gradient flag per parameter (summed by the same collective), so that a parameter NO rank
+    produced a gradient for keeps ``grad = None`` -- with zeros instead, weight decay / momentum would move parameters a single-GPU
+    run never touches.  The flags are written with one host-to-device copy and read back once per step.  Inside a stream capture
+    (gsn_amd.graphs.GraphedTrainStep) nothing may be read back: the captured step reduces the gradient part only and reuses the
+    flags of the last eager call with this parameter list (the warm-up steps in front of the capture), which is exact as long as
+    the set of parameters that receive gradients is a property of the model, not of the batch.
+
+    ``force``: run the collective at world size 1 too (tests: the RCCL path on one GPU)."""
+    if not dist.is_available() or not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
         return
     params = [p for p in parameters if p.requires_grad]
     if not params:
@@ -136,36 +159,36 @@ def allreduce_gradients(parameters, average: bool = True, group=None):
             raise TypeError("allreduce_gradients: parameters must share one dtype and device (got %s/%s and %s/%s)"
                             % (dtype, device, p.dtype, p.device))
     key = (tuple(id(p) for p in params), dtype, device)
-    # behind the gradients: one has-gradient flag per parameter (summed by the same collective), so that a parameter no rank produced a
-    # gradient for keeps ``grad = None`` -- with zeros instead, weight decay / momentum would move parameters a single-GPU run never touches
-    n_grad = sum(p.numel() for p in params)
-    n_total = n_grad + len(params)
-    flat = _BUCKETS.get(key)
-    if flat is None or flat.numel() != n_total:
+    b = _BUCKETS.get(key)
+    if b is None or b.flat.numel() != sum(p.numel() for p in params) + len(params):
         if len(_BUCKETS) > 8:
             _BUCKETS.clear()
-        flat = torch.empty(n_total, dtype=dtype, device=device)
-        _BUCKETS[key] = flat
-    off = 0
-    for i, p in enumerate(params):
-        n = p.numel()
-        if p.grad is None:
-            flat[off:off + n].zero_()
+        b = _BUCKETS[key] = _Bucket(params, dtype, device)
+    capturing = device.type == "cuda" and torch.cuda.is_current_stream_capturing()
+    have = [p.grad is not None for p in params]
+    present = [i for i, h in enumerate(have) if h]
+    absent = [i for i, h in enumerate(have) if not h]
+    with torch.no_grad():
+        if present:
+            torch._foreach_copy_([b.views[i] for i in present], [params[i].grad for i in present])
+        if absent:
+            torch._foreach_zero_([b.views[i] for i in absent])
+        if capturing:
+            if b.has is None:
+                raise RuntimeError("allreduce_gradients inside a stream capture needs one eager call with the same parameters first "
+                                   "(GraphedTrainStep's warm-up steps do that)")
+            dist.all_reduce(b.flat[:b.n_grad], op=dist.ReduceOp.SUM, group=group)
+            has = b.has
         else:
-            flat[off:off + n].copy_(p.grad.reshape(-1))
-        flat[n_grad + i] = 0.0 if p.grad is None else 1.0
-        off += n
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-    has = flat[n_grad:].tolist()                      # (one small read-back per step; the gradients themselves stay on the device)
-    if average:
-        flat[:n_grad] /= dist.get_world_size(group)
-    off = 0
-    for i, p in enumerate(params):
-        n = p.numel()
-        if has[i] == 0:
-            pass                                      # no rank has a gradient: stays None, as on one GPU
-        elif p.grad is None:
-            p.grad = flat[off:off + n].view_as(p).clone()
-        else:
-            p.grad.copy_(flat[off:off + n].view_as(p))
-        off += n
+            b.flat[b.n_grad:].copy_(torch.tensor([1.0 if h else 0.0 for h in have], dtype=dtype), non_blocking=True)
+            dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=group)
+            has = b.has = [v != 0 for v in b.flat[b.n_grad:].tolist()]   # (one small read-back per step; the gradients stay on the device)
+        world = dist.get_world_size(group)
+        if average and world > 1:
+            b.flat[:b.n_grad] /= world
+        if present:
+            torch._foreach_copy_([params[i].grad for i in present], [b.views[i] for i in present])
+        for i in absent:
+            if has[i]:
+                params[i].grad = b.views[i].clone()
+            # else: no rank has a gradient: stays None, as on one GPU

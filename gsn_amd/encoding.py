@@ -177,20 +177,47 @@ class zero_encoder(nn.Module):
 
 
 _META_CACHE = {}
+_META_HOST = [None, 0]          # pinned staging ring [tensor, next free word]: slices are handed out once and never rewritten
+_META_HOST_WORDS = 16384
+
+
+def _meta_host(n):
+    ring, off = _META_HOST
+    if ring is None or off + n > ring.numel():
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("embedding launch inside a stream capture: the pinned staging ring for table pointers is exhausted "
+                               "(run the step eagerly once before capturing it)")
+        ring, off = torch.empty(_META_HOST_WORDS, dtype=torch.int64).pin_memory(), 0
+    _META_HOST[0], _META_HOST[1] = ring, off + n
+    return ring[off:off + n]
 
 
 def _table_meta(tables, device):
-    """Device array [table pointers | row counts] of an embedding launch.  Uploading it is a host-to-device copy from pageable memory
-    (the host waits for the stream): the arrays are kept per pointer tuple -- parameters keep their addresses, and the caching
-    allocator hands a step's gradient tables the addresses of the step before."""
+    """Device array [table pointers | row counts] of an embedding launch.  It travels through a slice of a pinned staging ring with an
+    asynchronous copy (from pageable memory the host would wait for the stream, and the copy could not be recorded into a graph
+    capture); the arrays are kept per pointer tuple -- parameters keep their addresses, and the caching allocator hands a step's
+    gradient tables the addresses of the step before.  Inside a capture (gsn_amd.graphs) the copy becomes a node of the graph that
+    re-reads the pinned slice at every replay: slices are never rewritten, entries a capture has used are never evicted, and an
+    entry MADE inside a capture (its device array is only written by replays) is keyed on that capture."""
+    from . import _abi
     ptrs = tuple([t.data_ptr() for t in tables] + [int(t.shape[0]) for t in tables])
-    key = (ptrs, str(device))
-    hit = _META_CACHE.get(key)
+    with _abi.device_guard(device):
+        cap = int(_abi.lib().gsn_stream_capture_id(_abi.current_stream()))
+    hit = _META_CACHE.get((ptrs, str(device), 0))
+    if hit is None and cap:
+        hit = _META_CACHE.get((ptrs, str(device), cap))
     if hit is None:
-        if len(_META_CACHE) > 256:
-            _META_CACHE.clear()
-        hit = _META_CACHE[key] = torch.tensor(ptrs, dtype=torch.int64, device=device)
-    return hit
+        if len(_META_CACHE) > 1024:
+            for k in [k for k, v in _META_CACHE.items() if not v[2]]:
+                del _META_CACHE[k]
+        host = _meta_host(len(ptrs))
+        host.copy_(torch.tensor(ptrs, dtype=torch.int64))
+        dev_t = torch.empty(len(ptrs), dtype=torch.int64, device=device)
+        dev_t.copy_(host, non_blocking=True)
+        hit = _META_CACHE[(ptrs, str(device), cap)] = [dev_t, host, bool(cap)]
+    elif cap:
+        hit[2] = True           # a graph holds its address now
+    return hit[0]
 
 
 # Out-of-range codes.  The reference's nn.Embedding raises IndexError (CPU) / a device-side assert that surfaces later (GPU).  Here the
@@ -216,6 +243,21 @@ def check_embedding_status(wait=False):
             raise IndexError("index out of range in embedding table")
 
 
+def _drain_at_exit():
+    # the status of the LAST embedding launches of a process (a final eval forward) is otherwise never looked at
+    try:
+        check_embedding_status(wait=True)
+    except IndexError as e:
+        import sys
+        print("gsn_amd.encoding: %s (reported at interpreter exit: the launch was asynchronous)" % e, file=sys.stderr)
+    except Exception:
+        pass
+
+
+import atexit  # noqa: E402
+atexit.register(_drain_at_exit)
+
+
 def _defer_status(status):
     if EMBED_STATUS_SYNC:
         if int(status.item()) != 0:
@@ -231,8 +273,11 @@ def _defer_status(status):
     host = _STATUS_RING[_STATUS_NEXT:_STATUS_NEXT + 1]
     _STATUS_NEXT = (_STATUS_NEXT + 1) % 128
     host.copy_(status, non_blocking=True)
-    ev = torch.cuda.Event()
-    ev.record()
+    # (the event goes onto the stream the copy was issued on -- the current stream of the status word's device, which need not be the
+    #  current device: an event of another device's stream could complete before the copy lands and a stale 0 would be read)
+    with torch.cuda.device(status.device):
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(status.device))
     _PENDING_STATUS.append((ev, host))
 
 

@@ -40,3 +40,67 @@ class GraphedStep:
         return self.outputs
 
     replay = __call__
+
+
+class GraphedTrainStep:
+    """One whole training step -- ``optimizer.zero_grad(); loss = loss_fn(); loss.backward(); all-reduce; optimizer.step()``
+    (train_test_funcs.py:88-106) -- captured into ONE HIP graph and replayed with one launch.
+
+    At the reference's batch sizes (README.md:112, :121: 128 / 32 graphs) a step is several hundred launches of a few microseconds
+    each; eager, its time is the Python in front of them (profiles/r03_train_step_progress.txt: 6.6 ms at B = 32 of which < 1 ms is
+    device time).  Captured, forward, the native adjoints, the gradient bucket (+ the RCCL all-reduce when the process group has more
+    than one rank) and the optimizer's multi-tensor update are nodes of one graph.
+
+        step = GraphedTrainStep(lambda: loss_fn(model(data), data.y), optimizer)     # `data`: static tensors, refilled with copy_()
+        loss = step()                                                                # replay; `loss` is the captured 0-d tensor
+
+    What stays correct across replays, and why:
+      * BatchNorm running statistics and ``num_batches_tracked`` live on the device and are advanced by the captured kernels;
+      * dropout draws from PyTorch's generator, whose Philox offset the graph advances per replay (a replay is not a repeat);
+      * the parameters are updated in place by the captured optimizer kernels, which PyTorch's version counters do not see: the
+        derived-weight caches of gsn_amd.layers are keyed on those counters, so every replay bumps them
+        (torch.autograd.graph.increment_version -- no launch) and an eager forward after a replay prepares its weights afresh.
+    The warm-up steps are REAL steps (they update the parameters); shapes are frozen: capture one object per batch shape.
+    Optimizers with a host-side step counter (Adam, AdamW ...) must be built with ``capturable=True``."""
+
+    def __init__(self, loss_fn, optimizer, parameters=None, warmup: int = 3, allreduce: bool = True, average: bool = True, group=None,
+                 force_allreduce: bool = False, device=None):
+        from . import dist as gdist
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if optimizer.defaults.get("capturable") is False:
+            raise ValueError("GraphedTrainStep: build %s with capturable=True (its step counter must live on the device)" % type(optimizer).__name__)
+        self.optimizer = optimizer
+        self.params = [p for g in optimizer.param_groups for p in g["params"]] if parameters is None else list(parameters)
+
+        def step():
+            optimizer.zero_grad(set_to_none=True)
+            loss = loss_fn()
+            loss.backward()
+            if allreduce:
+                gdist.allreduce_gradients(self.params, average=average, group=group, force=force_allreduce)
+            optimizer.step()
+            return loss.detach()
+
+        self._eager = step
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        optimizer.zero_grad(set_to_none=True)          # (the captured backward allocates the gradients from the graph's pool)
+        with torch.cuda.graph(self.graph):
+            self.loss = step()
+        self.replays = 0
+        self.steps_taken = max(1, warmup)              # (a capture records, it does not execute)
+
+    def __call__(self):
+        self.graph.replay()
+        torch.autograd.graph.increment_version(self.params)
+        self.replays += 1
+        self.steps_taken += 1
+        return self.loss
+
+    replay = __call__

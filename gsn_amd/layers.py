@@ -80,6 +80,35 @@ def _need_cuda(t, what):
         raise RuntimeError("gsn_amd.layers: %s is on %s; the layers run on HIP kernels only (no CPU fallback)" % (what, t.device))
 
 
+# Zero-initialised scratch (fp64 column statistics, gradient accumulators of the atomically-adding kernels): handed out as slices of a
+# 256 KiB arena that ONE fill zeroes, instead of a fill launch per request -- at the reference's batch sizes a training step asked for
+# ~45 such buffers of 1-2 KiB, 5 us of launch each.  A slice is handed out once; the arena lives as long as any slice of it.  Keyed on
+# (device, stream, capture id): the fill runs on the stream the consumers run on, and an arena filled inside one graph capture is
+# never used by another capture or by eager launches (its fill is a node of that graph only).
+_ZARENA = {}
+_ZARENA_BYTES = 256 * 1024
+
+
+def _zeros(n, dtype, device):
+    """1-D zero tensor of ``n`` elements of ``dtype`` on ``device`` (cuda) from the arena."""
+    import math
+    item = torch.empty(0, dtype=dtype).element_size()
+    nbytes = (n * item + 255) // 256 * 256
+    if nbytes > _ZARENA_BYTES // 4 or device.type != "cuda":
+        return torch.zeros(n, dtype=dtype, device=device)
+    with _abi.device_guard(device):
+        stream = _abi.current_stream()
+        key = (device.index, stream, int(_abi.lib().gsn_stream_capture_id(stream)))
+    hit = _ZARENA.get(device.index)
+    if hit is None or hit[0] != key or hit[2] + nbytes > _ZARENA_BYTES:
+        with torch.cuda.device(device):
+            hit = [key, torch.zeros(_ZARENA_BYTES, dtype=torch.uint8, device=device), 0]
+        _ZARENA[device.index] = hit
+    off = hit[2]
+    hit[2] = off + nbytes
+    return hit[1][off:off + n * item].view(dtype)
+
+
 def _f32c(t):
     if t.dtype is torch.float32 and t.is_contiguous():
         return t.detach() if t.requires_grad else t
@@ -381,8 +410,17 @@ def add_by_graph(x, table, batch):
 def global_mean_pool_sparse(x, batch, num_graphs=None):
     """Mean readout (utils_graph_learning.py:32-41): sum readout divided by the graph sizes (empty graphs divide by 1)."""
     s = global_add_pool_sparse(x, batch, num_graphs)
-    sizes = torch.bincount(batch.to(torch.int64), minlength=s.shape[0]).to(s.dtype).clamp_(min=1.0)
-    return s / sizes.unsqueeze(1)
+    # max(size, 1) per graph: a property of the batch vector, kept with it (torch.bincount sizes its output from a device read --
+    # a host synchronisation per readout, and not capturable: gsn_amd.graphs)
+    key = (id(batch), "sizes", s.shape[0], s.dtype)
+    inv = _cache_get(key, batch)
+    if inv is None:
+        sizes = torch.zeros(s.shape[0], dtype=s.dtype, device=s.device)
+        if batch.numel():
+            sizes.index_add_(0, batch.to(torch.int64), torch.ones(batch.numel(), dtype=s.dtype, device=s.device))
+        inv = sizes.clamp_(min=1.0).unsqueeze(1)
+        _cache_put(key, batch, inv)
+    return s / inv
 
 
 def one_hot_identifiers(values, n_classes, clamp=False):
@@ -499,7 +537,7 @@ class _PropagateFn(torch.autograd.Function):
                     g_selfs[k] = torch.empty((n, t.shape[1]), dtype=torch.float32, device=dev)
                 gptr[k] = None if g_selfs[k] is None else g_selfs[k].data_ptr()
             need_col = any(w and sg for w, sg in zip(want_self, single))
-            acc = torch.zeros(1 + (d_out if need_col else 0), dtype=torch.float64, device=dev)
+            acc = _zeros(1 + (d_out if need_col else 0), torch.float64, dev)
             with _abi.device_guard(dev):
                 rc = _abi.lib().gsn_propagate_self_bwd_hip(ctx.kind, n, d_out, g_out.data_ptr(), ctx.n_self, arr, gptr,
                                                            eps32.data_ptr() if ctx.has_eps else None, acc.data_ptr() if want_eps else None,
@@ -985,7 +1023,7 @@ def run_stages(stages, m_rows, training, csr=None):
         if st.bn is not None:
             def stats_fn(i=i):
                 n_out = stages[i].weight.shape[0]
-                stats = torch.zeros((2, n_out), dtype=torch.float64, device=stages[i].weight.device)
+                stats = _zeros(2 * n_out, torch.float64, stages[i].weight.device).view(2, n_out)
                 probe = _Stage(stages[i].weight, stages[i].bias, None, "identity", stages[i].blocks)
                 _launch_stages(stages[:i] + [probe], m_rows, stats=stats)
                 return stats
@@ -1012,7 +1050,7 @@ def _run_stages_materialised(stages, m_rows, training):
         blks = st.blocks + ([(y, None)] if y is not None else [])
         if st.bn is not None and (training or st.bn.running_mean is None):
             n_out = st.weight.shape[0]
-            stats = torch.zeros((2, n_out), dtype=torch.float64, device=st.weight.device)
+            stats = _zeros(2 * n_out, torch.float64, st.weight.device).view(2, n_out)
             h = _linear_hip(blks, st.weight, st.bias, None, None, None, 0, m_rows, out=True, stats=stats)
             _bn_resolve(st, lambda: stats, m_rows, training)
             y = _bn_act_hip(h, st.bn_params, st.act)
@@ -1081,7 +1119,7 @@ class _DenseStagesFn(torch.autograd.Function):
                 # batch statistics (train mode), or running statistics with gradients for gamma / beta: pre-BN rows materialised
                 st = _Stage(w, b, bn, sp["act"])
                 if bn_train:
-                    stats = torch.zeros((2, n_out), dtype=torch.float64, device=w.device)
+                    stats = _zeros(2 * n_out, torch.float64, w.device).view(2, n_out)
                     h = _linear_hip(blks, w, b, None, None, None, 0, m_rows, out=True, stats=stats)
                     _bn_resolve(st, lambda: stats, m_rows, True)
                 else:
@@ -1131,9 +1169,10 @@ class _DenseStagesFn(torch.autograd.Function):
         # every zero-initialised accumulator of this backward from two arenas (one fill each instead of three small fills per stage)
         n64 = sum(3 * ent["w"].shape[0] for ent in per)
         n32 = sum(ent["w"].numel() for si, ent in enumerate(per) if ctx.needs_input_grad[1 + ent["w_i"]])
-        z64 = torch.zeros(n64, dtype=torch.float64, device=dev)
-        z32 = torch.zeros(n32, dtype=torch.float32, device=dev)
+        z64 = _zeros(n64, torch.float64, dev)
+        z32 = _zeros(n32, torch.float32, dev)
         o64 = o32 = 0
+        casts = []
         for si in range(len(spec) - 1, -1, -1):
             sp, ent = spec[si], per[si]
             kind, off = meta[si]
@@ -1162,11 +1201,13 @@ class _DenseStagesFn(torch.autograd.Function):
                     rc = L.gsn_bn_act_bwd_hip(m_rows, n_out, g.data_ptr(), y.data_ptr(), None, None, None, None, 0, act, None,
                                               gh.data_ptr(), gbias.data_ptr(), _abi.current_stream())
             _abi.check(rc, "gsn_bn_act_bwd_hip")
+            # (fp64 column sums -> fp32 gradients: ONE conversion of the whole arena behind the loop, the gradients are its slices)
+            o0 = o64 - 3 * n_out
             if kind in ("bn", "bn_eval") and "g_i" in ent:
-                grads[ent["g_i"]] = sums[1].to(torch.float32)
-                grads[ent["beta_i"]] = sums[0].to(torch.float32)
+                casts.append((ent["g_i"], o0 + 2 * n_out, n_out))
+                casts.append((ent["beta_i"], o0 + n_out, n_out))
             if "b_i" in ent:
-                grads[ent["b_i"]] = gbias.to(torch.float32)
+                casts.append((ent["b_i"], o0, n_out))
             # weight gradient
             xin = blocks0 if si == 0 else [saved[meta[si - 1][1] + (1 if meta[si - 1][0] in ("bn", "bn_eval") else 0)]]
             if ctx.needs_input_grad[1 + ent["w_i"]]:
@@ -1204,6 +1245,10 @@ class _DenseStagesFn(torch.autograd.Function):
                                 with torch.no_grad():
                                     grads[bi] = propagate(0, gather[0], mode, gather[1], b=gx[:, o:o + wd].contiguous())
                         o += wd
+        if casts:
+            c32 = z64.to(torch.float32)
+            for gi, o0, n in casts:
+                grads[gi] = c32[o0:o0 + n]
         return (None,) + tuple(grads)
 
 
@@ -1284,7 +1329,7 @@ def _code_stage_segsum(mf, cblocks, csr, m_rows):
     stage = _Stage(lin.weight, lin.bias, bn, mf.activation_name)
 
     def stats_fn():
-        stats = torch.zeros((2, n_out), dtype=torch.float64, device=dev)
+        stats = _zeros(2 * n_out, torch.float64, dev).view(2, n_out)
         launch(None, None, stats)
         return stats
 

@@ -52,6 +52,9 @@ const char *gsn_last_error(void);
 int gsn_version(void);
 /* number of visible gfx950 devices (0 if none / no driver); never fails */
 int gsn_device_count(void);
+/* 0 when `stream` is not being captured into a HIP graph, else an id unique to the capture (hipStreamGetCaptureInfo); never fails.
+ * Host-side scratch that a launch sequence zero-fills is keyed on it (a fill recorded in one capture does not run in another). */
+int64_t gsn_stream_capture_id(void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * HP-1  pattern analysis (host).  Replaces utils_graph_processing.automorphism_orbits (:10-56) and

@@ -49,6 +49,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--layers", type=int, default=5)
     ap.add_argument("--d", type=int, default=300)
+    ap.add_argument("--graph", action="store_true", help="replay the whole step as one HIP graph (gsn_amd.graphs.GraphedTrainStep)")
+    ap.add_argument("--optimizer", default="sgd", choices=["sgd", "adam"])
     args = ap.parse_args()
     rank, world, local = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")))
     torch.cuda.set_device(local)
@@ -65,12 +67,11 @@ def main():
         dist.destroy_process_group()
 
 
-def run(args, dev, dist=None, rank=0, world=1):
-    """The timed training steps; returns the result line as a dict (bench.py's supplementary `train_step_config4` calls this with
-    ``types.SimpleNamespace(batch=4096, steps=5, warmup=2, layers=5, d=300)``)."""
+def build(args, dev, rank=0, dropout=0.5):
+    """(model, data, params, optimizer, loss closure, N, E) of the step."""
     data, d_id, N, E = make_data(args.batch, 100 + rank, dev)
     L, dm = args.layers, args.d
-    kw = dict(seed=0, model_name="GSN_edge_sparse_ogb", readout="mean", dropout_features=[0.5] * (L + 1), bn=[True] * L,
+    kw = dict(seed=0, model_name="GSN_edge_sparse_ogb", readout="mean", dropout_features=[dropout] * (L + 1), bn=[True] * L,
               final_projection=[False] * L + [True], residual=False, inject_ids=True, vn=True, id_scope="local",
               d_msg=[dm] * L, d_out=[dm] * L, d_h=[[2 * dm]] * L, aggr="add", flow="source_to_target", msg_kind="ogb",
               train_eps=[True] * L, activation_mlp="relu", bn_mlp=True, jk_mlp=False, degree_embedding="None",
@@ -82,17 +83,32 @@ def run(args, dev, dist=None, rank=0, world=1):
     model = models.GNN_OGB(9, 1, None, d_id, 3, None, None, None, None, **kw).to(dev).train()
     params = [p for p in model.parameters()]
     n_params = sum(p.numel() for p in params)
-    opt = torch.optim.SGD(params, lr=1e-3)
+    if getattr(args, "optimizer", "sgd") == "adam":
+        opt = torch.optim.Adam(params, lr=1e-3, capturable=True)
+    else:
+        opt = torch.optim.SGD(params, lr=1e-3)
     loss_fn = torch.nn.BCEWithLogitsLoss()
+    return model, data, params, opt, (lambda: loss_fn(model(data), data.y)), N, E
+
+
+def run(args, dev, dist=None, rank=0, world=1):
+    """The timed training steps; returns the result line as a dict (bench.py's supplementary `train_step_config4` calls this with
+    ``types.SimpleNamespace(batch=4096, steps=5, warmup=2, layers=5, d=300)``)."""
+    model, data, params, opt, loss_of, N, E = build(args, dev, rank)
+    L, dm = args.layers, args.d
+    n_params = sum(p.numel() for p in params)
 
     def step():
         opt.zero_grad(set_to_none=True)
-        loss = loss_fn(model(data), data.y)
+        loss = loss_of()
         loss.backward()
         gdist.allreduce_gradients(params, average=True)      # one flat fp32 bucket, one RCCL all-reduce
         opt.step()
         return loss
 
+    if getattr(args, "graph", False):
+        from gsn_amd.graphs import GraphedTrainStep
+        step = GraphedTrainStep(loss_of, opt, params, warmup=max(1, args.warmup))
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -113,6 +129,7 @@ def run(args, dev, dist=None, rank=0, world=1):
             "n_gpus": world, "graphs_per_s": round(world * args.batch * args.steps / dt, 1),
             "ms_per_step": round(dt / args.steps * 1e3, 3), "parameters": n_params,
             "grad_bucket_MB": round(n_params * 4 / 1e6, 2), "loss": float(loss.item()),
+            "launch": "hip_graph" if getattr(args, "graph", False) else "eager", "optimizer": getattr(args, "optimizer", "sgd"),
             "note": "forward and backward on HIP kernels (native adjoints of every stage, DESIGN.md 4); SGD update and glue in PyTorch"}
 
 

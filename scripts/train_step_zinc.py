@@ -21,20 +21,8 @@ from gsn_amd import dist as gdist, encoding, models, synth  # noqa: E402
 from gsn_amd.counting import CountPlan, count_batch  # noqa: E402
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--batch", type=int, default=128)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    args = ap.parse_args()
-    rank, world, local = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    dist = None
-    if "RANK" in os.environ:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+def build(args, dev, rank=0):
+    """(model, data, params, optimizer, loss closure, N, E) of the step."""
     b = synth.zinc_shape_batch(args.batch, seed=200 + rank)
     N, E = b.num_nodes, b.num_edges
     plan = CountPlan.get([list(nx.cycle_graph(k).edges) for k in range(3, 7)], "edge", False)
@@ -56,17 +44,29 @@ def main():
     torch.manual_seed(0)
     model = models.GNNSubstructures(1, 1, None, d_id, 1, [28], [4], None, None, **kw).to(dev).train()
     params = list(model.parameters())
-    opt = torch.optim.SGD(params, lr=1e-3)
+    if getattr(args, "optimizer", "sgd") == "adam":
+        opt = torch.optim.Adam(params, lr=1e-3, capturable=True)
+    else:
+        opt = torch.optim.SGD(params, lr=1e-3)
     loss_fn = torch.nn.L1Loss()
+    return model, data, params, opt, (lambda: loss_fn(model(data), data.y)), N, E
+
+
+def run(args, dev, dist=None, rank=0, world=1):
+    """The timed steps; the result line as a dict (bench.py `train_small_batch` calls this)."""
+    model, data, params, opt, loss_of, N, E = build(args, dev, rank)
 
     def step():
         opt.zero_grad(set_to_none=True)
-        loss = loss_fn(model(data), data.y)
+        loss = loss_of()
         loss.backward()
         gdist.allreduce_gradients(params, average=True)
         opt.step()
         return loss
 
+    if getattr(args, "graph", False):
+        from gsn_amd.graphs import GraphedTrainStep
+        step = GraphedTrainStep(loss_of, opt, params, warmup=max(1, args.warmup))
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -83,11 +83,32 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    n_params = sum(p.numel() for p in params)
+    return ({"workload": "ZINC-shaped GNNSubstructures training step (4 x GSN_edge_sparse general d=128), batch %d graphs/GPU (N=%d, E=%d)" % (args.batch, N, E),
+            "n_gpus": world, "graphs_per_s": round(world * args.batch * args.steps / dt, 1),
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "parameters": n_params, "loss": float(loss.item()),
+            "launch": "hip_graph" if getattr(args, "graph", False) else "eager", "optimizer": getattr(args, "optimizer", "sgd")})
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--graph", action="store_true", help="replay the whole step as one HIP graph (gsn_amd.graphs.GraphedTrainStep)")
+    ap.add_argument("--optimizer", default="sgd", choices=["sgd", "adam"])
+    args = ap.parse_args()
+    rank, world, local = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if "RANK" in os.environ:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    res = run(args, dev, dist, rank, world)
     if rank == 0:
-        n_params = sum(p.numel() for p in params)
-        print(json.dumps({"workload": "ZINC-shaped GNNSubstructures training step (4 x GSN_edge_sparse general d=128), batch %d graphs/GPU (N=%d, E=%d)" % (args.batch, N, E),
-                          "n_gpus": world, "graphs_per_s": round(world * args.batch * args.steps / dt, 1),
-                          "ms_per_step": round(dt / args.steps * 1e3, 3), "parameters": n_params, "loss": float(loss.item())}))
+        print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()
 

@@ -1,0 +1,121 @@
+"""The whole training step as one HIP graph (gsn_amd.graphs.GraphedTrainStep; train_test_funcs.py:88-106 is the step it replays):
+replays equal eager steps to the run-to-run noise of the eager steps themselves, BatchNorm's counters and running statistics advance per replay, dropout draws fresh masks per
+replay, an eager forward after replays sees the updated weights (the version counters are bumped)."""
+import importlib.util
+import os
+import types
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _script(name):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REPO, "scripts", name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _eager_step(params, opt, loss_of):
+    opt.zero_grad(set_to_none=True)
+    loss = loss_of()
+    loss.backward()
+    opt.step()
+    return loss.detach()
+
+
+def _state(model):
+    return {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+
+def _build(kind, optimizer, dropout=None):
+    dev = torch.device("cuda", 0)
+    if kind == "molhiv":
+        m = _script("train_step_molhiv")
+        args = types.SimpleNamespace(batch=32, layers=3, d=64, optimizer=optimizer)
+        return m.build(args, dev, 0, dropout=0.5 if dropout is None else dropout)
+    m = _script("train_step_zinc")
+    return m.build(types.SimpleNamespace(batch=48, optimizer=optimizer), dev, 0)
+
+
+def _run(kind, optimizer, n_steps, warm=None):
+    """State and losses after n_steps (all eager when warm is None; else `warm` eager warm-up steps inside GraphedTrainStep, then replays)."""
+    from gsn_amd.graphs import GraphedTrainStep
+    torch.manual_seed(1234)
+    torch.cuda.manual_seed(99)
+    model, data, params, opt, loss_of, N, E = _build(kind, optimizer, dropout=0.0)
+    for g in opt.param_groups:
+        g["lr"] = 0.02 if optimizer == "sgd" else 2e-3      # large steps: a stale or skipped update shows far above the noise floor
+    if warm is None:
+        losses = [_eager_step(params, opt, loss_of) for _ in range(n_steps)]
+    else:
+        step = GraphedTrainStep(loss_of, opt, params, warmup=warm)
+        assert step.steps_taken == warm
+        losses = [None] * warm + [step().clone() for _ in range(n_steps - warm)]
+        assert step.replays == n_steps - warm
+    torch.cuda.synchronize()
+    return _state(model), losses
+
+
+def _rel(sa, sb):
+    worst = 0.0
+    for k in sa:
+        if sa[k].is_floating_point():
+            worst = max(worst, float((sa[k].double() - sb[k].double()).abs().max() / sa[k].double().abs().max().clamp_min(1e-30)))
+        else:
+            assert torch.equal(sa[k], sb[k]), k
+    return worst
+
+
+@pytest.mark.parametrize("kind,optimizer", [("zinc", "sgd"), ("zinc", "adam"), ("molhiv", "sgd"), ("molhiv", "adam")])
+def test_replay_equals_eager(kind, optimizer):
+    """Replayed steps against eager steps from the same seed.  The adjoint kernels accumulate with floating-point atomics (weight and
+    bias gradients, column statistics, embedding rows), so two EAGER runs already differ in the last bits and the difference grows with
+    the steps: the replays have to stay within a small multiple of that run-to-run noise, measured here, and far below what one
+    missed or stale update would cost (>= 1e-3 with these learning rates).  Integer state (num_batches_tracked, Adam's step) is exact."""
+    n_steps, warm = 6, 2
+    sa, la = _run(kind, optimizer, n_steps)
+    sa2, _ = _run(kind, optimizer, n_steps)
+    sb, lb = _run(kind, optimizer, n_steps, warm=warm)
+    assert set(sa) == set(sb)
+    noise = _rel(sa, sa2)
+    diff = _rel(sa, sb)
+    assert diff <= max(16.0 * noise, 2e-6), "replays drift from eager: %.3g (eager run-to-run: %.3g)" % (diff, noise)
+    for x, y in zip(la[warm:], lb[warm:]):      # (the loss of step k sees the drift of the k - 1 steps before it)
+        assert abs(float(x) - float(y)) <= max(64.0 * noise, 1e-4) * abs(float(x)) + 1e-7
+    nbt = [v for k, v in sb.items() if k.endswith("num_batches_tracked")]
+    assert nbt and all(int(v) == n_steps for v in nbt)
+
+
+def test_dropout_draws_fresh_masks_and_eager_forward_sees_new_weights():
+    from gsn_amd.graphs import GraphedTrainStep
+    torch.manual_seed(5)
+    model, data, params, opt, loss_of, N, E = _build("molhiv", "sgd", dropout=0.5)
+    for g in opt.param_groups:
+        g["lr"] = 0.0                       # frozen weights: the loss varies with the dropout masks (and BatchNorm's batch statistics do not)
+    step = GraphedTrainStep(loss_of, opt, params, warmup=2)
+    losses = [float(step().item()) for _ in range(6)]
+    assert len(set(losses)) > 1, "every replay drew the same dropout masks: %r" % (losses,)
+    # weights move under replays; an eager eval forward afterwards must use them, not fragments prepared before
+    for g in opt.param_groups:
+        g["lr"] = 0.05
+    step2 = GraphedTrainStep(loss_of, opt, params, warmup=1)
+    model.eval()
+    with torch.no_grad():
+        y0 = model(data).clone()
+    model.train()
+    v0 = [p._version for p in params]
+    for _ in range(3):
+        step2()
+    assert all(p._version > v for p, v in zip(params, v0))
+    model.eval()
+    with torch.no_grad():
+        y1 = model(data).clone()
+        from gsn_amd import layers
+        layers.invalidate_caches(model)
+        y2 = model(data).clone()
+    assert not torch.equal(y0, y1)
+    assert torch.equal(y1, y2), "an eager forward after replays used stale prepared weights"
