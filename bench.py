@@ -420,8 +420,28 @@ def train_step_config4(dev):
     spec = importlib.util.spec_from_file_location("train_step_molhiv", os.path.join(os.path.dirname(os.path.abspath(__file__)), "scripts", "train_step_molhiv.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    r = mod.run(types.SimpleNamespace(batch=4096, steps=5, warmup=2, layers=5, d=300), dev)
-    return {"graphs": 4096, "ms_per_step": r["ms_per_step"], "graphs_per_s": r["graphs_per_s"], "parameters": r["parameters"], "workload": r["workload"]}
+    r = mod.run(types.SimpleNamespace(batch=4096, steps=20, warmup=10, layers=5, d=300), dev)
+    return {"graphs": 4096, "ms_per_step": r["ms_per_step"], "graphs_per_s": r["graphs_per_s"], "parameters": r["parameters"], "workload": r["workload"],
+            "steps": 20, "warmup": 10}
+
+
+def train_small_batch(dev):
+    """The reference's own batch sizes (README.md:121: molhiv 32 graphs; :112: ZINC 128): the whole training step eager and replayed as ONE
+    HIP graph (gsn_amd.graphs.GraphedTrainStep: forward, native adjoints, gradient bucket, optimizer update).  Supplementary."""
+    import importlib.util
+    import types
+    out = {}
+    for name, batch in (("train_step_molhiv", 32), ("train_step_zinc", 128)):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(os.path.dirname(os.path.abspath(__file__)), "scripts", name + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        ent = {}
+        for graph in (False, True):
+            r = mod.run(types.SimpleNamespace(batch=batch, steps=100, warmup=5, layers=5, d=300, graph=graph, optimizer="sgd"), dev)
+            ent["hip_graph" if graph else "eager"] = {"ms_per_step": r["ms_per_step"], "graphs_per_s": r["graphs_per_s"]}
+        ent["workload"] = r["workload"]
+        out[name.replace("train_step_", "") + "_b%d" % batch] = ent
+    return out
 
 
 def count_er128(dev):
@@ -775,7 +795,7 @@ def main():
                    "note": "BASELINE configs[1] dataset size: 12 000 ZINC-shaped graphs per step (N=%d, E=%d)" % (b2.num_nodes, b2.num_edges)}
 
     # Supplementary (never `value`): the reference's real batch sizes, the stand-alone aggregation stage, the layer on real-valued inputs
-    small = prop = flt = wide = train4 = lin300 = er128 = None
+    small = prop = flt = wide = train4 = lin300 = er128 = train_small = None
     if world == 1 and not args.no_extras:
         try:
             small = small_batch_steps(plan, layer, dev, graphs=not args.no_graph)
@@ -797,6 +817,10 @@ def main():
             train4 = train_step_config4(dev)
         except Exception as ex:
             train4 = {"error": str(ex)[:200]}
+        try:
+            train_small = train_small_batch(dev)
+        except Exception as ex:
+            train_small = {"error": str(ex)[:200]}
         try:
             lin300 = linear_d300(dev)
         except Exception as ex:
@@ -942,6 +966,8 @@ def main():
             extra["layer_wide_d128"] = wide
         if train4 is not None:
             extra["train_step_config4"] = train4
+        if train_small is not None:
+            extra["train_small_batch"] = train_small
         if lin300 is not None:
             extra["linear_f16x3_d300"] = lin300
         if er128 is not None:

@@ -225,10 +225,23 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(int64_t m_rows, int n_co
             if (code < 0 || code >= meta[n_cols + c]) { atomicMax(status, GSN_ST_BAD_INDEX); out[i] = __builtin_nanf(""); continue; }
             acc = reinterpret_cast<const float *>(meta[c])[code * d + j];
         } else {
-            for (int c = 0; c < n_cols; ++c) {
-                const int64_t code = codes[r * n_cols + c];
-                if (code < 0 || code >= meta[n_cols + c]) { atomicMax(status, GSN_ST_BAD_INDEX); acc = __builtin_nanf(""); continue; }
-                acc += reinterpret_cast<const float *>(meta[c])[code * d + w];
+            // (eight columns at a time: their codes, then their table elements, are in flight together; summed in column order)
+            for (int c0 = 0; c0 < n_cols; c0 += 8) {
+                int64_t code[8];
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) code[u] = c0 + u < n_cols ? codes[r * n_cols + c0 + u] : 0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    v[u] = 0.f;
+                    if (c0 + u < n_cols) {
+                        if (code[u] < 0 || code[u] >= meta[n_cols + c0 + u]) { atomicMax(status, GSN_ST_BAD_INDEX); v[u] = __builtin_nanf(""); }
+                        else v[u] = reinterpret_cast<const float *>(meta[c0 + u])[code[u] * d + w];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (c0 + u < n_cols) acc += v[u];
             }
         }
         out[i] = acc;
@@ -522,7 +535,9 @@ extern "C" int gsn_embed_fwd_hip(int64_t m_rows, int n_cols, int d, int concat, 
     if (n_cols < 1 || d < 1 || !meta || !status || (m_rows > 0 && (!codes || !out)))
         return set_error(GSN_E_INVALID, "gsn_embed_fwd_hip: bad arguments");
     if (m_rows <= 0) return GSN_OK;
-    if (embed_lds_fits(n_cols, table_rows)) {
+    // (few rows -- the reference's batch sizes: 800 .. 6 000 rows -- gather straight from the L2-resident tables: the LDS kernel first copies
+    //  every table slice into every workgroup, ~40 us per call whatever the row count)
+    if (m_rows > 8192 && embed_lds_fits(n_cols, table_rows)) {
         EmbArgs a{};
         a.m_rows = m_rows; a.n_cols = n_cols; a.d = d; a.concat = concat; a.codes = codes; a.meta = meta; a.out = out; a.status = status;
         return launch_embed_lds<false>(a, table_rows, reinterpret_cast<hipStream_t>(stream));
@@ -708,7 +723,7 @@ extern "C" int gsn_embed_bwd_hip(int64_t m_rows, int n_cols, int d, int concat, 
         int64_t rtot = 0;
         bool small_tables = n_cols <= EMB_MAXC;
         for (int c = 0; small_tables && c < n_cols; ++c) { rtot += table_rows[c]; small_tables = table_rows[c] > 0 && table_rows[c] < 0xfffe; }
-        if (!lds_only && !concat && small_tables && rtot <= 4096 && m_rows >= 4096) {
+        if (!lds_only && !concat && small_tables && rtot <= 4096 && m_rows >= 256) {
             EmbMArgs a{};
             a.m_rows = m_rows; a.n_cols = n_cols; a.d = d; a.rtot = (int)rtot; a.codes = codes; a.meta = grad_meta; a.gout = grad_out;
             a.row_off[0] = 0;
@@ -717,7 +732,8 @@ extern "C" int gsn_embed_bwd_hip(int64_t m_rows, int n_cols, int d, int concat, 
             const int nt = a.tn * a.tk;
             int64_t slabs = (2048 + nt - 1) / nt;
             int64_t rows_per = (m_rows + slabs - 1) / slabs;
-            if (rows_per < 256) rows_per = 256;
+            const int64_t min_rows = m_rows >= 65536 ? 256 : 64;      // (small batches: bound by the serial chain of 16-row steps, backward.hip)
+            if (rows_per < min_rows) rows_per = min_rows;
             rows_per = (rows_per + 15) / 16 * 16;
             a.rows_per_wg = rows_per;
             slabs = (m_rows + rows_per - 1) / rows_per;

@@ -281,7 +281,11 @@ __device__ __forceinline__ void vzero(float4 &x) { x = make_float4(0.f, 0.f, 0.f
 // (Taking the edges of a segment four at a time with all row loads in flight together was measured and is no faster:
 // the kernel is limited by DRAM efficiency on 512-byte gathers, not by load latency.)
 // EXT: the layer's own term and / or zero columns (gsn_propagate_self_fwd_hip); the plain kernel is compiled without either
-template <int VEC, int LPR, int MAXC, bool EXT>
+// U4 (launches with less than one workgroup per CU -- the graph-level readouts and the reference's batch sizes, where nothing hides a
+// wave's load latency): a segment's elements four at a time, indices and rows of the four in flight together, added in the same order
+// (the result is bit-identical).  Per element the plain loop pays perm -> src -> row as one dependent chain: 34 us for the 26-row
+// segments of a 32-graph readout, d = 300.
+template <int VEC, int LPR, int MAXC, bool EXT, bool U4 = false>
 __global__ __launch_bounds__(256) void propagate_fwd_kernel(PropArgs p) {
     using V = typename VecT<VEC>::type;
     constexpr int RPW = 64 / LPR;  // rows (targets) per wave
@@ -289,6 +293,30 @@ __global__ __launch_bounds__(256) void propagate_fwd_kernel(PropArgs p) {
     const int sub = lane / LPR, li = lane % LPR;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    // the message element of edge e (source vertex s) in this lane's column chunk i
+    auto msg = [&](int64_t e, int64_t s, int i) -> V {
+        const int col = (i * LPR + li) * VEC;
+        V m;
+        if (p.kind == GSN_MSG_CAT) {
+            // column layout: a | pad_b zeros | b | pad_c zeros | c      (pads only on the scalar path, VEC == 1)
+            constexpr bool PADS = EXT && VEC == 1;
+            int o = col - p.da;
+            if (o < 0) m = *reinterpret_cast<const V *>(p.a + s * p.da + col);
+            else if (PADS && o < p.pad_b) vzero(m);
+            else if ((o -= (PADS ? p.pad_b : 0)) < p.db)
+                m = p.b_per_node ? *reinterpret_cast<const V *>(p.b + s * p.db + o) : vload_once(reinterpret_cast<const V *>(p.b + e * p.db + o));
+            else if (PADS && (o - p.db) < p.pad_c) vzero(m);
+            else m = vload_once(reinterpret_cast<const V *>(p.c + e * p.dc + (o - p.db - (PADS ? p.pad_c : 0))));
+        } else {
+            vzero(m);
+            if (p.a) m = vadd(m, *reinterpret_cast<const V *>(p.a + s * p.d_out + col));
+            // (three d-wide streams per edge: streaming the two per-edge ones past the caches was measured 6 % slower here)
+            if (p.b) m = vadd(m, *reinterpret_cast<const V *>(p.b + (p.b_per_node ? s : e) * p.d_out + col));
+            if (p.c) m = vadd(m, *reinterpret_cast<const V *>(p.c + e * p.d_out + col));
+            m = vrelu(m);
+        }
+        return m;
+    };
     for (int64_t t0 = wave * RPW; t0 < p.n_nodes; t0 += n_waves * RPW) {
         const int64_t t = t0 + sub;
         if (t >= p.n_nodes) continue;
@@ -296,35 +324,33 @@ __global__ __launch_bounds__(256) void propagate_fwd_kernel(PropArgs p) {
 #pragma unroll
         for (int i = 0; i < MAXC; ++i) vzero(acc[i]);
         const int32_t lo = p.seg_ptr[t], hi = p.seg_ptr[t + 1];
-        for (int32_t q = lo; q < hi; ++q) {
+        int32_t q = lo;
+        if (U4) {
+            for (; q + 4 <= hi; q += 4) {
+                int64_t e[4], sv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) e[u] = p.perm ? (int64_t)p.perm[q + u] : (int64_t)(q + u);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) sv[u] = p.sorted_src ? (int64_t)p.sorted_src[q + u] : p.src[e[u]];
+                V m[4][MAXC];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int i = 0; i < MAXC; ++i)
+                        if ((i * LPR + li) * VEC < p.d_out) m[u][i] = msg(e[u], sv[u], i);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int i = 0; i < MAXC; ++i)
+                        if ((i * LPR + li) * VEC < p.d_out) acc[i] = vadd(acc[i], m[u][i]);
+            }
+        }
+        for (; q < hi; ++q) {
             const int64_t e = p.perm ? (int64_t)p.perm[q] : (int64_t)q;
             const int64_t s = p.sorted_src ? (int64_t)p.sorted_src[q] : p.src[e];
 #pragma unroll
-            for (int i = 0; i < MAXC; ++i) {
-                const int col = (i * LPR + li) * VEC;
-                if (col < p.d_out) {
-                    V m;
-                    if (p.kind == GSN_MSG_CAT) {
-                        // column layout: a | pad_b zeros | b | pad_c zeros | c      (pads only on the scalar path, VEC == 1)
-                        constexpr bool PADS = EXT && VEC == 1;
-                        int o = col - p.da;
-                        if (o < 0) m = *reinterpret_cast<const V *>(p.a + s * p.da + col);
-                        else if (PADS && o < p.pad_b) vzero(m);
-                        else if ((o -= (PADS ? p.pad_b : 0)) < p.db)
-                            m = p.b_per_node ? *reinterpret_cast<const V *>(p.b + s * p.db + o) : vload_once(reinterpret_cast<const V *>(p.b + e * p.db + o));
-                        else if (PADS && (o - p.db) < p.pad_c) vzero(m);
-                        else m = vload_once(reinterpret_cast<const V *>(p.c + e * p.dc + (o - p.db - (PADS ? p.pad_c : 0))));
-                    } else {
-                        vzero(m);
-                        if (p.a) m = vadd(m, *reinterpret_cast<const V *>(p.a + s * p.d_out + col));
-                        // (three d-wide streams per edge: streaming the two per-edge ones past the caches was measured 6 % slower here)
-                        if (p.b) m = vadd(m, *reinterpret_cast<const V *>(p.b + (p.b_per_node ? s : e) * p.d_out + col));
-                        if (p.c) m = vadd(m, *reinterpret_cast<const V *>(p.c + e * p.d_out + col));
-                        m = vrelu(m);
-                    }
-                    acc[i] = vadd(acc[i], m);
-                }
-            }
+            for (int i = 0; i < MAXC; ++i)
+                if ((i * LPR + li) * VEC < p.d_out) acc[i] = vadd(acc[i], msg(e, s, i));
         }
         if (EXT && p.n_self) {
             const float sc = 1.f + (p.eps ? *p.eps : 0.f);
@@ -600,6 +626,7 @@ static int launch_fwd(const PropArgs &p, hipStream_t st) {
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     if (p.n_self || p.pad_b || p.pad_c) hipLaunchKernelGGL((propagate_fwd_kernel<VEC, LPR, MAXC, true>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+    else if (blocks <= 128) hipLaunchKernelGGL((propagate_fwd_kernel<VEC, LPR, MAXC, false, true>), dim3((unsigned)blocks), dim3(256), 0, st, p);
     else hipLaunchKernelGGL((propagate_fwd_kernel<VEC, LPR, MAXC, false>), dim3((unsigned)blocks), dim3(256), 0, st, p);
     return hip_check("propagate_fwd_kernel");
 }

@@ -83,9 +83,10 @@ def test_replay_equals_eager(kind, optimizer):
     assert set(sa) == set(sb)
     noise = _rel(sa, sa2)
     diff = _rel(sa, sb)
-    assert diff <= max(16.0 * noise, 2e-6), "replays drift from eager: %.3g (eager run-to-run: %.3g)" % (diff, noise)
+    # (one pair of eager runs can agree by chance: the floor sits well under the 1e-3 of a missed update)
+    assert diff <= max(16.0 * noise, 5e-5), "replays drift from eager: %.3g (eager run-to-run: %.3g)" % (diff, noise)
     for x, y in zip(la[warm:], lb[warm:]):      # (the loss of step k sees the drift of the k - 1 steps before it)
-        assert abs(float(x) - float(y)) <= max(64.0 * noise, 1e-4) * abs(float(x)) + 1e-7
+        assert abs(float(x) - float(y)) <= max(64.0 * noise, 1e-3) * abs(float(x)) + 1e-7
     nbt = [v for k, v in sb.items() if k.endswith("num_batches_tracked")]
     assert nbt and all(int(v) == n_steps for v in nbt)
 
