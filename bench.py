@@ -836,6 +836,26 @@ def main():
         dist.all_gather(tl, torch.tensor([dt_own], device=dev, dtype=torch.float64))
         per_rank_ms = [round(float(t.item()) / args.steps * 1e3, 4) for t in tl]
 
+    # the collective that a data-parallel training step adds (the headline path has none): one flat gradient bucket of the configs[3]
+    # model's size (3.35 M fp32 parameters, 13.4 MB) all-reduced over RCCL, timed on its own -- also at world size 1 under the launcher
+    rccl = None
+    graphs_by_rank = [G]
+    if dist is not None:
+        bucket = torch.zeros(3353406, dtype=torch.float32, device=dev)
+        for _ in range(3):
+            dist.all_reduce(bucket)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            dist.all_reduce(bucket)
+        sync()
+        t_ar = gdist.max_over_ranks((time.perf_counter() - t0) / 10, dev)
+        rccl = {"version": ".".join(str(v) for v in torch.cuda.nccl.version()), "allreduce_ms": round(t_ar * 1e3, 4), "bucket_MB": 13.41,
+                "note": "flat fp32 gradient bucket of the configs[3] model, sum over %d rank(s); not part of the headline step" % world}
+        gl = [torch.zeros(1, device=dev, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(gl, torch.tensor([G], device=dev, dtype=torch.int64))
+        graphs_by_rank = [int(t.item()) for t in gl]
+
     if rank == 0:
         kernels = {}
         merged = {}
@@ -973,6 +993,9 @@ def main():
         if er128 is not None:
             extra["count_er128_config5"] = er128
         extra["ms_per_step_by_rank"] = per_rank_ms
+        extra["graphs_by_rank"] = graphs_by_rank
+        if rccl is not None:
+            extra["rccl"] = rccl
         extra["prewarm_steps_untimed"] = int(os.environ.get("GSN_BENCH_PREWARM", "60"))
         if model4 is not None:
             extra["full_model_step"] = model4
