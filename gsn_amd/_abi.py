@@ -62,6 +62,7 @@ SIGNATURES = {
     "gsn_count_encode_pack16_hip": (c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_i64, c_i64,
                                             c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_i64, c_vp]),
     "gsn_pack16_rows_hip": (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp]),
+    "gsn_one_hot_pack16_hip": (c_int, [c_i64, c_int, c_vp, c_vp, c_int, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp]),
     "gsn_csr_scratch_elems": (c_i64, [c_i64]),
     "gsn_csr_build_hip": (c_int, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "gsn_linear_f16x3_kpad": (c_i64, [c_i64]),

@@ -321,7 +321,7 @@ static int launch_seg_impl(const ChainArgs &a, hipStream_t st) {
     unsigned long long *prof = nullptr;
     int prio = 3;
     { const char *d = getenv("GSN_SEG_PRIO"); if (d) prio = atoi(d); }
-    if (PROF) { hipMalloc(&prof, 2 * 8 * 6 * 8); hipMemset(prof, 0, 2 * 8 * 6 * 8); }
+    if (PROF) { (void)hipMalloc(&prof, 2 * 8 * 6 * 8); (void)hipMemset(prof, 0, 2 * 8 * 6 * 8); }
     const int64_t n_tiles = (a.m_rows + TBM - 1) / TBM;
     int64_t gx = 256 * (lds <= 78 * 1024 ? 2 : 1);
     if (gx > n_tiles) gx = n_tiles;
@@ -331,9 +331,9 @@ static int launch_seg_impl(const ChainArgs &a, hipStream_t st) {
     if (e != hipSuccess) return set_error(GSN_E_HIP, "mlp_chain1_seg_kernel: %s", hipGetErrorString(e));
     if (PROF) {
         unsigned long long h[2 * 8 * 6];
-        hipDeviceSynchronize();
-        hipMemcpy(h, prof, sizeof(h), hipMemcpyDeviceToHost);
-        hipFree(prof);
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(h, prof, sizeof(h), hipMemcpyDeviceToHost);
+        (void)hipFree(prof);
         static int shown = 0;
         if (shown++ % 8 == 7)
             for (int w = 0; w < TBM / 8; ++w) {

@@ -73,6 +73,40 @@ __global__ __launch_bounds__(256) void one_hot_rows_kernel(OneHotArgs a) {
     }
 }
 
+// The same encoding written straight into an exact fp16 row pack (include/gsn_abi.h, HP-2 packs; csrc/layer_rp.hip reads them): one thread
+// per row, the 1s of the row as a bit mask over the pack's columns, the segment [col0, col0 + width) leaves as 32-bit words (16-bit
+// stores at an odd boundary); `one_col` >= 0: that column = 1.0 (the node pack's bias column).  Columns outside are not touched.
+struct OneHotPackArgs {
+    int64_t m_rows;
+    int n_cols, width, clamp;
+    int cls_ptr[OH_MAX_COLS + 1];
+    const int64_t *values;
+    uint16_t *dst;
+    int stride, col0, one_col;
+    int32_t *status;            // OR 1: a code outside its column's classes (no clamp); may be null
+};
+
+__global__ __launch_bounds__(256) void one_hot_pack16_kernel(OneHotPackArgs a) {
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= a.m_rows) return;
+    unsigned long long hot = 0;
+    for (int c = 0; c < a.n_cols; ++c) {
+        int64_t v = a.values[row * a.n_cols + c];
+        const int ncls = a.cls_ptr[c + 1] - a.cls_ptr[c];
+        if (a.clamp) v = v < 0 ? 0 : (v >= ncls ? ncls - 1 : v);
+        if (v >= 0 && v < ncls) hot |= 1ull << (a.col0 + a.cls_ptr[c] + (int)v);
+        else if (a.status) atomicOr(a.status, 1);
+    }
+    uint16_t *d = a.dst + row * a.stride;
+    const int lo = a.col0, hi = a.col0 + a.width;
+    int k = lo;
+    if (k & 1) { d[k] = (hot >> k) & 1 ? 0x3C00 : 0; ++k; }
+    for (; k + 2 <= hi; k += 2)
+        *reinterpret_cast<unsigned *>(d + k) = ((hot >> k) & 1 ? 0x3C00u : 0u) | ((hot >> (k + 1)) & 1 ? 0x3C000000u : 0u);
+    if (k < hi) d[k] = (hot >> k) & 1 ? 0x3C00 : 0;
+    if (a.one_col >= 0) d[a.one_col] = 0x3C00;
+}
+
 }  // namespace gsn
 
 using namespace gsn;
@@ -107,6 +141,29 @@ extern "C" int gsn_one_hot_hip(int64_t m_rows, int n_cols, const int64_t *values
     hipLaunchKernelGGL(one_hot_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(GSN_E_HIP, "one_hot_kernel: %s", hipGetErrorString(e));
+    return GSN_OK;
+}
+
+extern "C" int gsn_one_hot_pack16_hip(int64_t m_rows, int n_cols, const int64_t *values, const int32_t *n_classes, int clamp,
+                                      uint16_t *dst, int64_t dst_stride, int64_t col0, int64_t one_col, int32_t *status, void *stream) {
+    if (n_cols < 1 || n_cols > OH_MAX_COLS || !values || !n_classes || !dst || dst_stride < 1 || dst_stride > 64 || (dst_stride & 1) || col0 < 0)
+        return set_error(GSN_E_INVALID, "gsn_one_hot_pack16_hip: need 1..%d columns, non-null pointers and an even pack width <= 64", OH_MAX_COLS);
+    OneHotPackArgs a{};
+    a.m_rows = m_rows; a.n_cols = n_cols; a.clamp = clamp; a.values = values; a.dst = dst;
+    a.stride = (int)dst_stride; a.col0 = (int)col0; a.one_col = one_col < 0 ? -1 : (int)one_col; a.status = status;
+    a.cls_ptr[0] = 0;
+    for (int c = 0; c < n_cols; ++c) {
+        if (n_classes[c] < 1) return set_error(GSN_E_INVALID, "gsn_one_hot_pack16_hip: n_classes[%d] < 1", c);
+        a.cls_ptr[c + 1] = a.cls_ptr[c] + n_classes[c];
+    }
+    a.width = a.cls_ptr[n_cols];
+    if (col0 + a.width > dst_stride || one_col >= dst_stride || (one_col >= col0 && one_col < col0 + a.width))
+        return set_error(GSN_E_INVALID, "gsn_one_hot_pack16_hip: %d encoded columns at %lld (+ the 1.0 column %lld) do not fit a %lld-column pack", a.width,
+                         (long long)col0, (long long)one_col, (long long)dst_stride);
+    if (m_rows <= 0) return GSN_OK;
+    hipLaunchKernelGGL(one_hot_pack16_kernel, dim3((unsigned)((m_rows + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(GSN_E_HIP, "one_hot_pack16_kernel: %s", hipGetErrorString(e));
     return GSN_OK;
 }
 

@@ -123,7 +123,7 @@ class Codes:
     [R, sum(n_classes)].  Layers accept it for ``x``, ``identifiers`` and ``edge_features``; where all inputs of msg_fn's
     first Linear are Codes that Linear becomes a weight-row gather (gsn_code_stage_fwd_hip) and the dense one-hot
     matrix is never built; everywhere else the layer densifies it."""
-    __slots__ = ("codes", "n_classes", "clamp", "_dense")
+    __slots__ = ("codes", "n_classes", "clamp", "_dense", "_pack16")
 
     def __init__(self, codes, n_classes, clamp=False):
         codes = codes.unsqueeze(-1) if codes.dim() == 1 else codes
@@ -133,6 +133,7 @@ class Codes:
         if len(self.n_classes) != self.codes.shape[1]:
             raise ValueError("Codes: %d columns but %d class counts" % (self.codes.shape[1], len(self.n_classes)))
         self.clamp = bool(clamp)      # values above the last class count as the last class (as gsn_one_hot_hip's clamp)
+        self._pack16 = None           # (pack, first column) once gsn_amd.packs has encoded these codes into an exact fp16 row pack
         self._dense = None
 
     @property
@@ -850,7 +851,7 @@ CHAIN_ROW_EXPONENTS = os.environ.get("GSN_CHAIN_ROW_EXP", "1") != "0"      # 128
 PACK16_LAYER = os.environ.get("GSN_LAYER_PACK16", "1") != "0"   # tagged exact inputs: the packed-row kernel (csrc/layer_rp.hip)
 
 
-def _layer_fused(x, csr, edge_stages, node_stages, training, owner=None, gen=0, pack16=None):
+def _layer_fused(x, csr, edge_stages, node_stages, training, owner=None, gen=0, pack16=None, pack_only=False):
     """edge stage + per-target sum + two node stages in ONE launch (gsn_layer_fused_fwd_hip); None if the layer does not
     fit (shape, activation, or a BatchNorm1d that needs batch statistics)."""
     if not FUSED_LAYER or len(edge_stages) != 1 or len(node_stages) != 2:
@@ -906,6 +907,8 @@ def _layer_fused(x, csr, edge_stages, node_stages, training, owner=None, gen=0, 
         if rc != -2:                      # (GSN_E_UNSUPPORTED: packs beyond 32-bit offsets -> the fp32 kernel below)
             _abi.check(rc, "gsn_layer_fused_fwd_pack16_hip")
             return out
+    if pack_only:                         # (the caller holds no fp32 rows: it makes them and comes back)
+        return None
     # the weights as the kernel's register fragments: once per weight version (kept on the layer module)
     if not L.gsn_layer_fused_supported(ctypes.byref(ge), d_x, ctypes.byref(g0), ctypes.byref(g1)):
         return None
@@ -1758,6 +1761,15 @@ class _SparseLayer(nn.Module):
         raw = (x, ids, ef)
         use_codes = (not self.ogb and self.msg_kind == "general" and len(self.msg_fn.fc) == 2 and E > 0
                      and all(isinstance(t, Codes) for t in raw if t is not None))
+        # integer codes in, one launch: the one-hot encodings go straight into exact fp16 row packs (gsn_one_hot_pack16_hip: 64 / 32 bytes
+        # per row, no fp32 one-hot tensor at all) and the layer runs on them (csrc/layer_rp.hip).  Identifiers may also be the tagged rows
+        # of the counting kernel (gsn_amd.counting.count_batch(encoded_pack=...)).
+        if (PACK16_LAYER and FUSED_LAYER and isinstance(raw[0], Codes) and not self.ogb and self.msg_kind == "general" and len(self.msg_fn.fc) == 2
+                and E > 0 and not self.training and not (self.has_ids and self.id_scope != "local")
+                and (raw[2] is None or isinstance(raw[2], Codes)) and (raw[1] is None or isinstance(raw[1], (Codes, torch.Tensor)))):
+            y = self._fused_on_code_packs(edge_index, raw, n, E, sel, post)
+            if y is not None:
+                return y
         x = _f32c(_dense(x))
         if not use_codes:
             ids, ef = _dense(ids), _dense(ef)
@@ -1828,6 +1840,29 @@ class _SparseLayer(nn.Module):
         agg = propagate(0, edge_index, sel, n, b=msgs)
         return uf.hip_forward([(x, None), (agg, None)], n, post=post)
 
+
+    def _fused_on_code_packs(self, edge_index, raw, n, E, sel, post):
+        """The one-launch layer fed from integer codes (see _hip); None when the shapes are outside the packed-row kernel."""
+        mf, uf = self.msg_fn, self.update_fn
+        if post is not None and post[0] is not None and post[0].training != uf.training:
+            return None
+        per_edge = [t for t in (raw[1] if self.has_ids else None, raw[2] if self.has_ef else None) if t is not None]
+        d_x = sum(raw[0].n_classes)
+        if d_x > packs.NODE_COLS - 4 or sum(packs._width(t) for t in per_edge) > packs.EDGE_COLS:
+            return None
+        pk = packs.from_codes(raw[0], per_edge)
+        if pk is None:
+            return None
+        csr = _csr_for(edge_index, sel, n)
+        dev = edge_index.device
+        # (shapes and block identities for the stage descriptors: the packed-row kernel does not read the fp32 pointers -- no kernel runs here)
+        xph = torch.empty((n, d_x), dtype=torch.float32, device=dev)
+        sblocks = [(xph, csr.tgt), (xph, csr.src)]
+        for t in per_edge:
+            sblocks.append((t if isinstance(t, torch.Tensor) else torch.empty((E, packs._width(t)), dtype=torch.float32, device=dev), csr.perm))
+        return _layer_fused(xph, csr, mf.stages(sblocks, upto=len(mf.fc) - 1),
+                            uf.stages([(xph, None)], first_weight=self._folded_first_weight(d_x), post=post),
+                            self.training, owner=self, gen=getattr(self, "_fold_gen", 0), pack16=pk, pack_only=True)
 
     # -- differentiable `general` path on native adjoints ------------------------------------------------------------------
     def _general_native_ok(self):

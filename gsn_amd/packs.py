@@ -114,6 +114,80 @@ def edge_pack(tensors, check=True, pack=None):
     return pack
 
 
+def _pack_codes(cd, pack, col0, one_col, check=None):
+    """``check`` (default: gsn_amd.layers.CODE_STATUS_CHECK): read the out-of-range flag back -- IndexError, as the weight-row-gather stage
+    and the reference's F.one_hot; clamped codes cannot be out of range and are never read back."""
+    import numpy as np
+    from . import layers
+    ncls = np.ascontiguousarray(cd.n_classes, dtype=np.int32)
+    check = (layers.CODE_STATUS_CHECK if check is None else check) and not cd.clamp
+    status = torch.zeros(1, dtype=torch.int32, device=cd.codes.device) if check else None
+    with _abi.device_guard(cd.codes.device):
+        _abi.check(_abi.lib().gsn_one_hot_pack16_hip(cd.codes.shape[0], cd.codes.shape[1], cd.codes.data_ptr(), _abi.ptr(ncls), int(cd.clamp),
+                                                    pack.data_ptr(), pack.shape[1], int(col0), int(one_col), _abi.ptr(status), _abi.current_stream()),
+                   "gsn_one_hot_pack16_hip")
+    if check and int(status.item()) != 0:
+        raise IndexError("a code outside its column's classes (one-hot encoding of integer codes)")
+
+
+def pack_node_codes(cd, pack=None):
+    """Node pack of the one-hot encoding of ``cd`` (gsn_amd.layers.Codes); kept on the Codes object (codes are immutable by convention).
+    ``pack``: reuse a pack made by new_node_pack for codes of the same width (its zero columns are not rewritten)."""
+    if sum(cd.n_classes) > NODE_COLS - 4:
+        raise ValueError("pack_node_codes: more than %d encoded columns" % (NODE_COLS - 4))
+    if pack is None:
+        pack = new_node_pack(cd.codes.shape[0], cd.codes.device)
+    elif tuple(pack.shape) != (cd.codes.shape[0], NODE_COLS) or pack.dtype != torch.float16:
+        raise ValueError("pack_node_codes: pack must be fp16 [%d, %d]" % (cd.codes.shape[0], NODE_COLS))
+    _pack_codes(cd, pack, 0, NODE_COLS - 1)
+    cd._pack16 = (pack, 0)
+    return pack
+
+
+def pack_edge_codes(cd, pack, col0):
+    """The one-hot encoding of ``cd`` into columns col0.. of the edge pack ``pack`` (its other columns are kept); kept on the Codes object."""
+    if col0 + sum(cd.n_classes) > EDGE_COLS or pack.shape != (cd.codes.shape[0], EDGE_COLS):
+        raise ValueError("pack_edge_codes: columns %d .. %d of a %s pack" % (col0, col0 + sum(cd.n_classes), tuple(pack.shape)))
+    _pack_codes(cd, pack, col0, -1)
+    cd._pack16 = (pack, int(col0))
+    return pack
+
+
+def from_codes(x_codes, per_edge):
+    """(node pack, edge pack or None) of a layer call whose inputs are integer codes (gsn_amd.layers.Codes: the one-hot encoder's INPUT) --
+    the dense fp32 one-hot rows are never written.  ``per_edge``: the edge-level inputs in concatenation order, each a Codes or an fp32
+    tensor that carries a current pack tag (the counting kernel's encoded identifiers).  Codes already encoded (pack_node_codes /
+    pack_edge_codes) are not encoded again.  None when the widths or the tags do not fit together."""
+    per_edge = [c for c in per_edge if c is not None]
+    if sum(x_codes.n_classes) > NODE_COLS - 4 or sum(_width(c) for c in per_edge) > EDGE_COLS:
+        return None
+    npk = x_codes._pack16[0] if x_codes._pack16 is not None else pack_node_codes(x_codes)
+    epk = None
+    if per_edge:
+        rows = per_edge[0].shape[0]
+        col, todo = 0, []
+        for c in per_edge:      # the pack the already-encoded inputs live in (all the same one, columns in order)
+            tg = tag_of(c, rows, EDGE_COLS) if isinstance(c, torch.Tensor) else c._pack16
+            if tg is None:
+                if isinstance(c, torch.Tensor):
+                    return None
+                todo.append((c, col))
+            elif tg[1] != col or (epk is not None and tg[0] is not epk) or tuple(tg[0].shape) != (rows, EDGE_COLS):
+                return None
+            else:
+                epk = tg[0]
+            col += _width(c)
+        if epk is None:
+            epk = new_edge_pack(rows, x_codes.codes.device)
+        for c, col in todo:
+            pack_edge_codes(c, epk, col)
+    return npk, epk
+
+
+def _width(c):
+    return c.shape[1] if isinstance(c, torch.Tensor) else sum(c.n_classes)
+
+
 def lookup(x, per_edge):
     """(node pack, edge pack or None) when ``x`` and every tensor of ``per_edge`` (in concatenation order) carry current tags that
     fit together -- one edge pack, columns in order from 0 --, else None."""

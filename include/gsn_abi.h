@@ -367,6 +367,12 @@ typedef struct {
 } gsn_pack16;
 int gsn_pack16_rows_hip(const float *src, int64_t rows, int64_t width, uint16_t *dst, int64_t dst_stride, int64_t col0,
                         int64_t one_col, int32_t *status, void *stream);
+/* gsn_one_hot_hip's encoding (utils_graph_learning.py:170-187: DiscreteEmbedding('one_hot_encoder') over integer columns) written straight
+ * into columns col0 .. col0 + sum(n_classes) of a pack (dst_stride fp16 columns per row, even, <= 64); one_col >= 0: that column = 1.0.
+ * A code outside its column's classes leaves that column's segment zero (clamp: counted as the nearest class), as gsn_one_hot_hip, and
+ * ORs 1 into *status (device int32, caller-zeroed; may be NULL) -- the reference's F.one_hot raises there. */
+int gsn_one_hot_pack16_hip(int64_t m_rows, int n_cols, const int64_t *values, const int32_t *n_classes, int clamp, uint16_t *dst,
+                           int64_t dst_stride, int64_t col0, int64_t one_col, int32_t *status, void *stream);
 int gsn_layer_fused_pack16_supported(const gsn_chain_stage *edge, int64_t d_x, const gsn_chain_stage *node0,
                                      const gsn_chain_stage *node1);
 int64_t gsn_layer_fused_pack16_prepared_bytes(const gsn_chain_stage *edge, int64_t d_x, const gsn_chain_stage *node0,

@@ -276,3 +276,66 @@ def test_counting_kernel_writes_the_pack(n_graphs):
     # a second call WITHOUT the pack into the same buffer drops the tag
     count_batch(plan, b.node_ptr, b.edge_ptr, b.edge_index, ids_are_global=True, device=dev, encode=([3, 3, 3, 3], True), encoded_out=enc, counts=False)
     assert packs.lookup(x, [enc, ef]) is None
+
+
+@pytest.mark.parametrize("n_graphs,ids_kind", [(1, "codes"), (200, "codes"), (200, "tagged"), (4096, "tagged")])
+def test_integer_codes_go_straight_into_packs(n_graphs, ids_kind):
+    """Codes inputs (the one-hot encoder's INPUT, utils_graph_learning.py:170-187): gsn_one_hot_pack16_hip writes their encodings into the
+    packs (bit-identical to the fp16 of the dense one-hot), no fp32 one-hot of x / the bond types is made, the packed-row kernel runs, and
+    the result equals the oracle on the dense encodings.  Identifiers as Codes over the int64 counts, or as the counting kernel's tagged rows."""
+    import networkx as nx
+    from gsn_amd import layers, packs, synth
+    from gsn_amd.counting import CountPlan, count_batch
+    from oracle import oracle
+    b = synth.zinc_shape_batch(n_graphs, seed=300 + n_graphs)
+    dev = torch.device("cuda")
+    E, N = b.num_edges, b.num_nodes
+    plan = CountPlan.get([list(nx.cycle_graph(k).edges) for k in range(3, 7)], "edge", False)
+    xc = layers.Codes(torch.from_numpy(b.atom_type).to(dev), [28])
+    efc = layers.Codes(torch.from_numpy(b.bond_type).to(dev), [4])
+    x = torch.nn.functional.one_hot(torch.from_numpy(b.atom_type), 28).float()
+    ef = torch.nn.functional.one_hot(torch.from_numpy(b.bond_type), 4).float()
+    if ids_kind == "codes":
+        ids64, _ = count_batch(plan, b.node_ptr, b.edge_ptr, b.edge_index, ids_are_global=True, device=dev)
+        ids_in = layers.Codes(ids64, [3, 3, 3, 3], clamp=True)
+        enc = torch.nn.functional.one_hot(ids64.clamp(max=2), 3).reshape(E, 12).float()
+    else:
+        ep = packs.new_edge_pack(E, dev)
+        _, _, enc = count_batch(plan, b.node_ptr, b.edge_ptr, b.edge_index, ids_are_global=True, device=dev, encode=([3, 3, 3, 3], True),
+                                counts=False, encoded_pack=(ep, 0))
+        ids_in = enc
+    torch.manual_seed(4)
+    layer = layers.GSN_edge_sparse(**CTOR)
+    _randomise_bn(layer, 5)
+    layer.eval()
+    sd = {k: v.clone() for k, v in layer.state_dict().items()}
+    ei = torch.from_numpy(b.edge_index)
+    ref = oracle.layer_forward("GSN_edge_sparse", CTOR, sd, x, ei, identifiers=enc.cpu(), degrees=None, edge_features=ef, training=False)
+    layer.cuda()
+    with torch.no_grad():
+        y, trace = _traced(lambda: layer(xc, ei.to(dev), identifiers=ids_in, degrees=torch.zeros(N, device=dev), edge_features=efc))
+    assert "layer_fused_kernel_rp" in trace, trace[-400:]
+    assert _elementwise_ok(y.cpu(), ref), float((y.cpu() - ref).abs().max() / ref.abs().max())
+    npk, epk = xc._pack16[0], efc._pack16[0]
+    assert torch.equal(npk[:, :28].float().cpu(), x) and bool((npk[:, 28:31] == 0).all()) and bool((npk[:, 31] == 1).all())
+    assert torch.equal(epk[:, 12:].float().cpu(), ef) and torch.equal(epk[:, :12].float(), enc)
+    assert xc._dense is None and efc._dense is None          # (no dense one-hot was made)
+
+
+def test_one_hot_pack_out_of_range_and_odd_boundaries():
+    """gsn_one_hot_pack16_hip: a code outside its classes leaves its segment zero (clamp: nearest class), as gsn_one_hot_hip; segments at
+    odd columns and of odd width keep their neighbours."""
+    from gsn_amd import layers, packs
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(3)
+    codes = torch.randint(-2, 7, (1000, 3), generator=g).to(dev)
+    for clamp in (False, True):
+        cd = layers.Codes(codes, [5, 3, 4], clamp=clamp)
+        pack = torch.full((1000, packs.EDGE_COLS), 7.0, dtype=torch.float16, device=dev)
+        if not clamp:
+            with pytest.raises(IndexError):          # (the reference's F.one_hot raises on such a code)
+                packs._pack_codes(cd, pack, 3, -1)
+        packs._pack_codes(cd, pack, 3, -1, check=False)
+        dense = layers.one_hot_identifiers(codes, [5, 3, 4], clamp=clamp)
+        assert torch.equal(pack[:, 3:15].float(), dense)
+        assert bool((pack[:, :3] == 7).all()) and bool((pack[:, 15:] == 7).all())
