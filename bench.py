@@ -932,24 +932,24 @@ def main():
             roof = {"kernel": {"propagate_fwd": "propagate_fwd_kernel", "count": "count_kernel"}[dom], "bound": "hbm",
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
         # HBM traffic cannot be read from inside the run: PMC needs rocprofv3 around the process.  Report the committed
-        # measurement of the same command (scripts/profile_bench.sh -> profiles/r03_bench_pmc.csv): per launch of the dominant
+        # measurement of the same command (scripts/profile_bench.sh -> profiles/r04_bench_pmc.csv): per launch of the dominant
         # kernel, FETCH_SIZE x2 (gfx950 under-reports wide reads, MI355X_MICROARCH.md) + WRITE_SIZE, in bytes.
         try:
             import csv
-            pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_bench_pmc.csv")
+            pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_bench_pmc.csv")
             key = {"layer_fused": "gsn::layer_fused_kernel", "mlp_chain": "gsn::mlp_chain"}.get(dom, roof["kernel"])   # (not layer_fused_prepare_kernel)
             rows = [r for r in csv.DictReader(open(pmc)) if key in r["kernel"]]
             if rows and G == 65536:
                 tot = sum((2.0 * float(r["FETCH_SIZE_per_dispatch"]) + float(r["WRITE_SIZE_per_dispatch"])) * 1024.0 for r in rows)
                 roof["traffic"] = round(tot / len(rows))
-                roof["traffic_source"] = "profiles/r03_bench_pmc.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
+                roof["traffic_source"] = "profiles/r04_bench_pmc.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
             crow = [r for r in csv.DictReader(open(pmc)) if "count_kernel" in r["kernel"]]
             if crow and G == 65536:      # the counting kernel is VALU-bound, not bandwidth-bound -- show it
                 r0 = crow[0]
                 pmc_count = {"valu_busy_frac_of_wave_cycles": round(float(r0["SQ_ACTIVE_INST_ANY_per_dispatch"]) / float(r0["SQ_WAVE_CYCLES_per_dispatch"]), 4),
                              "valu_instructions_per_dispatch": float(r0["SQ_INSTS_VALU_per_dispatch"]),
                              "hbm_bytes_per_dispatch": round((2.0 * float(r0["FETCH_SIZE_per_dispatch"]) + float(r0["WRITE_SIZE_per_dispatch"])) * 1024.0),
-                             "source": "profiles/r03_bench_pmc.csv"}
+                             "source": "profiles/r04_bench_pmc.csv"}
             else:
                 pmc_count = None
         except Exception:

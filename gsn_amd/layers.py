@@ -963,8 +963,19 @@ def _bn_resolve(stage, stats_fn, m_rows, training):
         stage.bn_params = None
         return
     if training or bn.running_mean is None:
-        if training and m_rows <= 1:
+        if training and m_rows == 1:
             raise ValueError("Expected more than 1 value per channel when training, got input size torch.Size([%d, %d])" % (m_rows, bn.num_features))
+        if m_rows == 0:
+            # no rows (an edge-less batch in front of an edge stage): nn.BatchNorm1d returns the empty tensor, leaves the running statistics
+            # alone and still counts the batch; the vectors below are never applied to a row
+            n_out, dev = bn.num_features, stage.weight.device
+            if training and bn.track_running_stats and bn.num_batches_tracked is not None:
+                bn.num_batches_tracked += 1
+            vec = torch.zeros((4, n_out), dtype=torch.float32, device=dev)
+            vec[1:3] = 1.0
+            stage.bn_params = (vec[0], vec[2], vec[3])
+            stage.bn_invstd = vec[1]
+            return
         stats = stats_fn()
         n_out = stats.shape[1]
         dev = stats.device

@@ -726,3 +726,31 @@ def test_wide_edge_stage_split_into_node_product_and_gather_sum(cls, scope, bn, 
         y_old = layer(x.cuda(), ei.cuda(), **kw).cpu()
     assert elementwise_ok(y, ref), float((y - ref).abs().max() / ref.abs().max())
     assert elementwise_ok(y, y_old)
+
+
+def test_edge_less_training_batch_through_batchnorm():
+    """an edge-less batch in TRAIN mode through a `general` layer whose msg_fn has BatchNorm -- nn.BatchNorm1d takes a [0, C]
+    input (empty output, running statistics untouched, the batch counted), so the layer must not raise: zero aggregates, zero gradients for
+    msg_fn, update_fn trained on [x | 0]."""
+    from gsn_amd import layers
+    from oracle import oracle
+    ctor = dict(d_in=6, d_ef=3, d_id=4, d_degree=1, degree_as_tag=False, retain_features=True, id_scope="local", d_msg=16, d_up=16,
+                d_h=[16], seed=0, activation_name="relu", bn=True, msg_kind="general", flow="source_to_target")
+    torch.manual_seed(0)
+    layer = layers.GSN_edge_sparse(**ctor).train()
+    n = 7
+    x = torch.randn(n, 6)
+    ei = torch.zeros((2, 0), dtype=torch.int64)
+    ids, ef = torch.zeros((0, 4)), torch.zeros((0, 3))
+    sd = {k: v.clone() for k, v in layer.state_dict().items()}
+    ref = oracle.layer_forward("GSN_edge_sparse", ctor, sd, x, ei, training=True, identifiers=ids, degrees=None, edge_features=ef)
+    layer.cuda()
+    rm0 = layer.msg_fn.bn[0].running_mean.clone()
+    nbt0 = int(layer.msg_fn.bn[0].num_batches_tracked)
+    y = layer(x.cuda(), ei.cuda(), identifiers=ids.cuda(), degrees=torch.zeros(n, device="cuda"), edge_features=ef.cuda())
+    y.sum().backward()
+    assert elementwise_ok(y.detach().cpu(), ref.detach())
+    assert torch.equal(layer.msg_fn.bn[0].running_mean, rm0) and int(layer.msg_fn.bn[0].num_batches_tracked) == nbt0 + 1
+    for name, p in layer.msg_fn.named_parameters():
+        assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+    assert any(p.grad is not None and float(p.grad.abs().max()) > 0 for p in layer.update_fn.parameters())
