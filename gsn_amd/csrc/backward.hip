@@ -29,20 +29,32 @@ __device__ __forceinline__ float act_grad_from_y(float y, int act) {
     }
 }
 
+// the same derivative from the pre-activation value z (the stage output is not read: z is recomputed from the pre-BatchNorm rows with the
+// forward pass's own expression, bn_act_kernel in encode.hip)
+__device__ __forceinline__ float act_grad_from_z(float z, int act) {
+    switch (act) {
+        case 1: return z > 0.f ? 1.f : 0.f;
+        case 2: return z > 0.f ? 1.f : expm1f(z) + 1.f;
+        case 3: { const float t = tanhf(z); return 1.f - t * t; }
+        default: return 1.f;
+    }
+}
+
 // pass 1: column sums of gZ and gZ * xh (fp64 [2][C], caller zero-fills).  grid (blocks_x, ceil(C/64)); a wave covers 64
 // adjacent columns of one row, waves stride over rows.
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(int64_t m_rows, int n_cols, const float *gy, const float *y,
                                                                 const float *h, const float *mean, const float *invstd,
-                                                                int act, double *sums) {
+                                                                int act, double *sums, const float *zscale, const float *zshift) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.y * 64 + lane;
     const bool cok = c < n_cols;
     const float mu = (cok && mean) ? mean[c] : 0.f, is = (cok && invstd) ? invstd[c] : 1.f;
+    const float zs = (cok && zscale) ? zscale[c] : 1.f, zb = (cok && zshift) ? zshift[c] : 0.f;
     double s1 = 0.0, s2 = 0.0;
     if (cok) {
         for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < m_rows; r += (int64_t)gridDim.x * 4) {
             const int64_t i = r * n_cols + c;
-            const float gz = gy[i] * act_grad_from_y(y[i], act);
+            const float gz = gy[i] * (y ? act_grad_from_y(y[i], act) : act_grad_from_z((h[i] - mu) * zs + zb, act));
             s1 += (double)gz;
             s2 += (double)gz * (double)((h[i] - mu) * is);
         }
@@ -64,21 +76,23 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(int64_t m_rows, 
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(int64_t m_rows, int n_cols, const float *gy, const float *y,
                                                                const float *h, const float *mean, const float *invstd,
                                                                const float *coef, const double *sums, int act, float *gh,
-                                                               double *gbias) {
+                                                               double *gbias, const float *zshift) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.y * 64 + lane;
     const bool cok = c < n_cols;
     const float mu = (cok && mean) ? mean[c] : 0.f, is = (cok && invstd) ? invstd[c] : 1.f;
     const float cf = (cok && coef) ? coef[c] : 1.f;
+    const float zb = (cok && zshift) ? zshift[c] : 0.f;        // (y == null: z = (h - mean) * coef + shift, coef = gamma * invstd)
     const float m1 = (cok && sums) ? (float)(sums[c] / (double)m_rows) : 0.f;
     const float m2 = (cok && sums) ? (float)(sums[n_cols + c] / (double)m_rows) : 0.f;
     double sb = 0.0;
     if (cok) {
         for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < m_rows; r += (int64_t)gridDim.x * 4) {
             const int64_t i = r * n_cols + c;
-            const float gz = gy[i] * act_grad_from_y(y[i], act);
+            const float hv = y ? 0.f : h[i];
+            const float gz = gy[i] * (y ? act_grad_from_y(y[i], act) : act_grad_from_z((hv - mu) * cf + zb, act));
             float g = gz;
-            if (sums) g = gz - m1 - (h[i] - mu) * is * m2;
+            if (sums) g = gz - m1 - ((y ? h[i] : hv) - mu) * is * m2;
             g *= cf;
             gh[i] = g;
             sb += (double)g;
@@ -366,23 +380,40 @@ static int bgrid(int64_t m_rows) {
 
 using namespace gsn;
 
-extern "C" int gsn_bn_act_bwd_hip(int64_t m_rows, int64_t n_cols, const float *grad_y, const float *y, const float *h,
-                                  const float *mean, const float *invstd, const float *coef, int train_bn, int act,
-                                  double *sums, float *grad_h, double *grad_bias, void *stream) {
-    if (n_cols < 1 || act < 0 || act > 3 || (m_rows > 0 && (!grad_y || !y || !grad_h)) || (train_bn && m_rows > 0 && (!h || !sums)))
-        return set_error(GSN_E_INVALID, "gsn_bn_act_bwd_hip: bad arguments");
+static int bn_act_bwd_launch(int64_t m_rows, int64_t n_cols, const float *grad_y, const float *y, const float *h, const float *mean,
+                             const float *invstd, const float *coef, const float *shift, int train_bn, int act, double *sums, float *grad_h,
+                             double *grad_bias, void *stream, const char *who) {
+    if (n_cols < 1 || act < 0 || act > 3 || (m_rows > 0 && (!grad_y || !grad_h)) || (train_bn && m_rows > 0 && (!h || !sums)) ||
+        (m_rows > 0 && !y && !(train_bn && mean && coef)))
+        return set_error(GSN_E_INVALID, "%s: bad arguments", who);
     if (m_rows <= 0) return GSN_OK;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid(bgrid(m_rows), (unsigned)((n_cols + 63) / 64));
     // train_bn == 2: BatchNorm on its RUNNING statistics (eval mode) with gradients wanted for gamma / beta: the same column sums
     // (xhat from the running mean / invstd), but grad_h = gZ * coef -- the statistics are constants of the rows
     if (train_bn)
-        hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, grid, dim3(256), 0, s, m_rows, (int)n_cols, grad_y, y, h, mean, invstd, act, sums);
-    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, grid, dim3(256), 0, s, m_rows, (int)n_cols, grad_y, y, train_bn == 1 ? h : y, mean,
-                       invstd, coef, train_bn == 1 ? sums : nullptr, act, grad_h, grad_bias);
+        hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, grid, dim3(256), 0, s, m_rows, (int)n_cols, grad_y, y, h, mean, invstd, act, sums, coef, shift);
+    // (y == null: both train_bn modes read the pre-BatchNorm rows for the activation derivative)
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, grid, dim3(256), 0, s, m_rows, (int)n_cols, grad_y, y, (train_bn == 1 || !y) ? h : y, mean,
+                       invstd, coef, train_bn == 1 ? sums : nullptr, act, grad_h, grad_bias, shift);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(GSN_E_HIP, "bn_act_bwd kernels: %s", hipGetErrorString(e));
     return GSN_OK;
+}
+
+extern "C" int gsn_bn_act_bwd_hip(int64_t m_rows, int64_t n_cols, const float *grad_y, const float *y, const float *h,
+                                  const float *mean, const float *invstd, const float *coef, int train_bn, int act,
+                                  double *sums, float *grad_h, double *grad_bias, void *stream) {
+    if (m_rows > 0 && !y) return set_error(GSN_E_INVALID, "gsn_bn_act_bwd_hip: bad arguments");
+    return bn_act_bwd_launch(m_rows, n_cols, grad_y, y, h, mean, invstd, coef, nullptr, train_bn, act, sums, grad_h, grad_bias, stream, "gsn_bn_act_bwd_hip");
+}
+
+extern "C" int gsn_bn_act_bwd_from_h_hip(int64_t m_rows, int64_t n_cols, const float *grad_y, const float *h, const float *mean,
+                                         const float *invstd, const float *coef, const float *shift, int train_bn, int act, double *sums,
+                                         float *grad_h, double *grad_bias, void *stream) {
+    if (train_bn != 1 && train_bn != 2) return set_error(GSN_E_INVALID, "gsn_bn_act_bwd_from_h_hip: a BatchNorm stage (train_bn 1 or 2)");
+    return bn_act_bwd_launch(m_rows, n_cols, grad_y, nullptr, h, mean, invstd, coef, shift, train_bn, act, sums, grad_h, grad_bias, stream,
+                             "gsn_bn_act_bwd_from_h_hip");
 }
 
 extern "C" int gsn_wgrad_hip(int64_t m_rows, int64_t n_out, const float *grad_h, int n_blocks, const gsn_block *blocks,

@@ -1147,8 +1147,8 @@ class _DenseStagesFn(torch.autograd.Function):
                                                          vecs[2].data_ptr(), _ACT_CODE[sp["act"]], yy.data_ptr(),
                                                          _abi.current_stream()), "gsn_bn_act_hip")
                 invstd = st.bn_invstd
-                saved += [h, yy, vecs[0], invstd.contiguous(), vecs[1]]
-                meta.append(("bn" if bn_train else "bn_eval", len(saved) - 5))
+                saved += [h, yy, vecs[0], invstd.contiguous(), vecs[1], vecs[2]]
+                meta.append(("bn" if bn_train else "bn_eval", len(saved) - 6))
                 y = yy
             else:
                 y = _linear_hip(blks, w, b, None, None, None, _ACT_CODE[sp["act"]], m_rows)
@@ -1199,11 +1199,12 @@ class _DenseStagesFn(torch.autograd.Function):
             act = _ACT_CODE[sp["act"]]
             with _abi.device_guard(dev), _timed("bn_act_bwd", 16.0 * m_rows * n_out):
                 if kind in ("bn", "bn_eval"):
-                    h, y, mean32, invstd, scale = saved[off:off + 5]
+                    h, y, mean32, invstd, scale, shift = saved[off:off + 6]
                     sums = sums_z
-                    rc = L.gsn_bn_act_bwd_hip(m_rows, n_out, g.data_ptr(), y.data_ptr(), h.data_ptr(), mean32.data_ptr(),
-                                              invstd.data_ptr(), scale.data_ptr(), 1 if kind == "bn" else 2, act, sums.data_ptr(),
-                                              gh.data_ptr(), gbias.data_ptr(), _abi.current_stream())
+                    # (the activation's derivative from z recomputed out of the pre-BN rows: the stage output is not read again)
+                    rc = L.gsn_bn_act_bwd_from_h_hip(m_rows, n_out, g.data_ptr(), h.data_ptr(), mean32.data_ptr(), invstd.data_ptr(),
+                                                     scale.data_ptr(), shift.data_ptr(), 1 if kind == "bn" else 2, act, sums.data_ptr(),
+                                                     gh.data_ptr(), gbias.data_ptr(), _abi.current_stream())
                 elif kind == "affine":
                     y, scale = saved[off:off + 2]
                     sums = None

@@ -546,6 +546,12 @@ int gsn_column_stats_hip(int64_t m_rows, int64_t n_cols, const float *h, double 
 int gsn_bn_act_bwd_hip(int64_t m_rows, int64_t n_cols, const float *grad_y, const float *y, const float *h,
                        const float *mean, const float *invstd, const float *coef, int train_bn, int act, double *sums,
                        float *grad_h, double *grad_bias, void *stream);
+/* The same for a BatchNorm stage (train_bn 1 or 2) WITHOUT reading the stage output: the activation's derivative is taken from
+ * z = (h - mean) * coef + shift, recomputed from the pre-BN rows with the forward pass's expression (gsn_bn_act_hip) -- one read of
+ * [M][C] less in each of the two passes (they are HBM-bound: 3 -> 2 and 4 -> 3 array passes). */
+int gsn_bn_act_bwd_from_h_hip(int64_t m_rows, int64_t n_cols, const float *grad_y, const float *h, const float *mean,
+                              const float *invstd, const float *coef, const float *shift, int train_bn, int act, double *sums,
+                              float *grad_h, double *grad_bias, void *stream);
 int gsn_wgrad_hip(int64_t m_rows, int64_t n_out, const float *grad_h, int n_blocks, const gsn_block *blocks, float *grad_w,
                   void *stream);
 
