@@ -242,6 +242,9 @@ __device__ __forceinline__ void wg_split3(float x, unsigned &h, unsigned &m, uns
 }
 __device__ __forceinline__ unsigned wg_pack_hi(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
 
+// GATHER: some block of X is read through a row-index array (compiled out otherwise: the index selects and the dependent loads in the
+// staging loop cost the plain-row stages of the d = 300 model 2x -- 347 -> 731 us per call at 214 k rows, r04 A/B)
+template <bool GATHER>
 __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradArgs a) {
     __shared__ wg_u32x4 ta[2][3][WG_T][2];        // [buffer][plane][column][row half]: 8 bf16 = rows 8 h .. 8 h + 7 of the chunk
     __shared__ wg_u32x4 tb[2][3][WG_T][2];
@@ -268,8 +271,8 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradArgs a) {
     const bool kb_ok = kb < a.k_total;
     const float *xb = a.bdata[0];
     int xw = a.bwidth[0];
-    const int64_t *xi = a.bidx[0];
-    const int32_t *xi32 = a.bidx32[0];
+    const int64_t *xi = GATHER ? a.bidx[0] : nullptr;
+    const int32_t *xi32 = GATHER ? a.bidx32[0] : nullptr;
     {
         int blk = 0, col = kb_ok ? kb : 0;
 #pragma unroll
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradArgs a) {
             if (b < a.n_blocks - 1 && blk == b && col >= a.bwidth[b]) { col -= a.bwidth[b]; blk = b + 1; }
 #pragma unroll
         for (int b = 1; b < WG_MAXB; ++b)
-            if (blk == b) { xb = a.bdata[b]; xw = a.bwidth[b]; xi = a.bidx[b]; xi32 = a.bidx32[b]; }
+            if (blk == b) { xb = a.bdata[b]; xw = a.bwidth[b]; if (GATHER) { xi = a.bidx[b]; xi32 = a.bidx32[b]; } }
         xb += col;
     }
     const float *ga = a.gh + (ca_ok ? ca : 0);
@@ -298,7 +301,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradArgs a) {
             const int64_t rc = r < r_end ? r : r_begin;            // clamped: masked to zero when stored
             pa[i] = ga[rc * a.n_out];
             // (a gathered block: the row index is the same for the 128 threads of a row half -- one broadcast load)
-            const int64_t rx = xi ? xi[rc] : (xi32 ? (int64_t)xi32[rc] : rc);
+            const int64_t rx = !GATHER ? rc : (xi ? xi[rc] : (xi32 ? (int64_t)xi32[rc] : rc));
             pb[i] = xb[rx * xw];
         }
     };
@@ -453,8 +456,8 @@ extern "C" int gsn_wgrad_hip(int64_t m_rows, int64_t n_out, const float *grad_h,
     else {
         a.tn = tn; a.tk = tk;
         const int64_t slab_groups = (slabs + 7) / 8;
-        hipLaunchKernelGGL(wgrad_bf16_kernel, dim3((unsigned)(slab_groups * tn * tk * 8)), dim3(256), 0,
-                           reinterpret_cast<hipStream_t>(stream), a);
+        if (gathered) hipLaunchKernelGGL(wgrad_bf16_kernel<true>, dim3((unsigned)(slab_groups * tn * tk * 8)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+        else hipLaunchKernelGGL(wgrad_bf16_kernel<false>, dim3((unsigned)(slab_groups * tn * tk * 8)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(GSN_E_HIP, "wgrad_kernel: %s", hipGetErrorString(e));
