@@ -84,27 +84,41 @@ struct OneHotPackArgs {
     uint16_t *dst;
     int stride, col0, one_col;
     int32_t *status;            // OR 1: a code outside its column's classes (no clamp); may be null
+    int whole_row;              // the call owns every column of the pack (col0 == 0 and a 1.0 column: a node pack): full 16-byte stores
 };
 
 __global__ __launch_bounds__(256) void one_hot_pack16_kernel(OneHotPackArgs a) {
-    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (row >= a.m_rows) return;
+    // one thread per (row, group of 8 pack columns = 16 bytes): a group that lies inside the segment -- or anywhere in a pack this call owns
+    // entirely (a node pack: its other columns are zero by contract) -- leaves as ONE 16-byte store, neighbouring threads write
+    // neighbouring groups of a row
+    const int Q = a.stride >> 3;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.m_rows * Q) return;
+    const int64_t row = i / Q;
+    const int q = (int)(i - row * Q);
     unsigned long long hot = 0;
     for (int c = 0; c < a.n_cols; ++c) {
         int64_t v = a.values[row * a.n_cols + c];
         const int ncls = a.cls_ptr[c + 1] - a.cls_ptr[c];
         if (a.clamp) v = v < 0 ? 0 : (v >= ncls ? ncls - 1 : v);
         if (v >= 0 && v < ncls) hot |= 1ull << (a.col0 + a.cls_ptr[c] + (int)v);
-        else if (a.status) atomicOr(a.status, 1);
+        else if (a.status && q == 0) atomicOr(a.status, 1);
     }
+    if (a.one_col >= 0) hot |= 1ull << a.one_col;
     uint16_t *d = a.dst + row * a.stride;
-    const int lo = a.col0, hi = a.col0 + a.width;
+    const int g0 = 8 * q, seg_lo = a.col0, seg_hi = a.col0 + a.width;
+    const int lo = g0 > seg_lo ? g0 : seg_lo, hi = g0 + 8 < seg_hi ? g0 + 8 : seg_hi;
+    auto word = [&](int k) { return ((hot >> k) & 1 ? 0x3C00u : 0u) | ((hot >> (k + 1)) & 1 ? 0x3C000000u : 0u); };
+    if (a.whole_row || (lo == g0 && hi == g0 + 8)) {
+        typedef unsigned u4 __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<u4 *>(d + g0) = u4{word(g0), word(g0 + 2), word(g0 + 4), word(g0 + 6)};
+        return;
+    }
     int k = lo;
-    if (k & 1) { d[k] = (hot >> k) & 1 ? 0x3C00 : 0; ++k; }
-    for (; k + 2 <= hi; k += 2)
-        *reinterpret_cast<unsigned *>(d + k) = ((hot >> k) & 1 ? 0x3C00u : 0u) | ((hot >> (k + 1)) & 1 ? 0x3C000000u : 0u);
+    if (k < hi && (k & 1)) { d[k] = (hot >> k) & 1 ? 0x3C00 : 0; ++k; }
+    for (; k + 2 <= hi; k += 2) *reinterpret_cast<unsigned *>(d + k) = word(k);
     if (k < hi) d[k] = (hot >> k) & 1 ? 0x3C00 : 0;
-    if (a.one_col >= 0) d[a.one_col] = 0x3C00;
+    if (a.one_col >= g0 && a.one_col < g0 + 8) d[a.one_col] = 0x3C00;
 }
 
 }  // namespace gsn
@@ -151,6 +165,7 @@ extern "C" int gsn_one_hot_pack16_hip(int64_t m_rows, int n_cols, const int64_t 
     OneHotPackArgs a{};
     a.m_rows = m_rows; a.n_cols = n_cols; a.clamp = clamp; a.values = values; a.dst = dst;
     a.stride = (int)dst_stride; a.col0 = (int)col0; a.one_col = one_col < 0 ? -1 : (int)one_col; a.status = status;
+    a.whole_row = (col0 == 0 && one_col >= 0 && (dst_stride & 7) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) ? 1 : 0;
     a.cls_ptr[0] = 0;
     for (int c = 0; c < n_cols; ++c) {
         if (n_classes[c] < 1) return set_error(GSN_E_INVALID, "gsn_one_hot_pack16_hip: n_classes[%d] < 1", c);
@@ -161,7 +176,8 @@ extern "C" int gsn_one_hot_pack16_hip(int64_t m_rows, int n_cols, const int64_t 
         return set_error(GSN_E_INVALID, "gsn_one_hot_pack16_hip: %d encoded columns at %lld (+ the 1.0 column %lld) do not fit a %lld-column pack", a.width,
                          (long long)col0, (long long)one_col, (long long)dst_stride);
     if (m_rows <= 0) return GSN_OK;
-    hipLaunchKernelGGL(one_hot_pack16_kernel, dim3((unsigned)((m_rows + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    if ((dst_stride & 7) || (reinterpret_cast<uintptr_t>(dst) & 15)) return set_error(GSN_E_INVALID, "gsn_one_hot_pack16_hip: pack rows must be multiples of 16 bytes, 16-byte aligned");
+    hipLaunchKernelGGL(one_hot_pack16_kernel, dim3((unsigned)((m_rows * (dst_stride >> 3) + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(GSN_E_HIP, "one_hot_pack16_kernel: %s", hipGetErrorString(e));
     return GSN_OK;

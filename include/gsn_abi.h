@@ -368,7 +368,9 @@ typedef struct {
 int gsn_pack16_rows_hip(const float *src, int64_t rows, int64_t width, uint16_t *dst, int64_t dst_stride, int64_t col0,
                         int64_t one_col, int32_t *status, void *stream);
 /* gsn_one_hot_hip's encoding (utils_graph_learning.py:170-187: DiscreteEmbedding('one_hot_encoder') over integer columns) written straight
- * into columns col0 .. col0 + sum(n_classes) of a pack (dst_stride fp16 columns per row, even, <= 64); one_col >= 0: that column = 1.0.
+ * into columns col0 .. col0 + sum(n_classes) of a pack (dst_stride fp16 columns per row, a multiple of 8, <= 64, rows 16-byte aligned);
+ * one_col >= 0: that column = 1.0.  With col0 == 0 and one_col >= 0 the call owns the whole pack (a node pack: its remaining columns are
+ * zero by contract) and writes every column of every row.
  * A code outside its column's classes leaves that column's segment zero (clamp: counted as the nearest class), as gsn_one_hot_hip, and
  * ORs 1 into *status (device int32, caller-zeroed; may be NULL) -- the reference's F.one_hot raises there. */
 int gsn_one_hot_pack16_hip(int64_t m_rows, int n_cols, const int64_t *values, const int32_t *n_classes, int clamp, uint16_t *dst,
