@@ -58,8 +58,9 @@ class GraphedTrainStep:
       * BatchNorm running statistics and ``num_batches_tracked`` live on the device and are advanced by the captured kernels;
       * dropout draws from PyTorch's generator, whose Philox offset the graph advances per replay (a replay is not a repeat);
       * the parameters are updated in place by the captured optimizer kernels, which PyTorch's version counters do not see: the
-        derived-weight caches of gsn_amd.layers are keyed on those counters, so every replay bumps them
-        (torch.autograd.graph.increment_version -- no launch) and an eager forward after a replay prepares its weights afresh.
+        derived-weight caches of gsn_amd.layers are keyed on those counters, so every replay bumps them -- parameters and the BatchNorm
+        buffers the captured kernels write (torch.autograd.graph.increment_version -- no launch) -- and an eager forward after a replay
+        prepares its weights and eval-mode BatchNorm vectors afresh.
     The warm-up steps are REAL steps (they update the parameters); shapes are frozen: capture one object per batch shape.
     Optimizers with a host-side step counter (Adam, AdamW ...) must be built with ``capturable=True``."""
 
@@ -91,14 +92,25 @@ class GraphedTrainStep:
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
         optimizer.zero_grad(set_to_none=True)          # (the captured backward allocates the gradients from the graph's pool)
-        with torch.cuda.graph(self.graph):
-            self.loss = step()
+        from . import layers
+        layers.RAW_WRITTEN = []
+        try:
+            with torch.cuda.graph(self.graph):
+                self.loss = step()
+            seen, extra = set(id(p) for p in self.params), []
+            for t in layers.RAW_WRITTEN:               # BatchNorm running statistics / counters the captured kernels update in place
+                if id(t) not in seen:
+                    seen.add(id(t))
+                    extra.append(t)
+            self._bump = self.params + extra
+        finally:
+            layers.RAW_WRITTEN = None
         self.replays = 0
         self.steps_taken = max(1, warmup)              # (a capture records, it does not execute)
 
     def __call__(self):
         self.graph.replay()
-        torch.autograd.graph.increment_version(self.params)
+        torch.autograd.graph.increment_version(self._bump)
         self.replays += 1
         self.steps_taken += 1
         return self.loss

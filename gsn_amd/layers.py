@@ -786,6 +786,61 @@ def _module_fingerprint(module):
     return tuple(torch.stack(vals).tolist()) if vals else ()
 
 
+# Asynchronous validation of the per-weight caches (default on; GSN_ASYNC_VALIDATE=0 turns it off).  Behind every eval-mode forward of a
+# layer ONE kernel fingerprints the layer's parameters and buffers (gsn_fingerprint_hip); the 8 bytes travel to pinned host memory behind
+# it and are looked at -- without waiting -- at the layer's next forward.  A fingerprint that moved while no version counter did is a
+# write through `.data`: the layer's caches are dropped there and then and a RuntimeWarning names the layer.  The forward(s) between the
+# write and that point used the old derived weights (the check costs no synchronisation; GSN_VALIDATE_CACHES=1 checks BEFORE every
+# forward at the price of one); `invalidate_caches` after such a write remains the contract for code that cannot afford one stale call.
+ASYNC_VALIDATE = os.environ.get("GSN_ASYNC_VALIDATE", "1") != "0"
+RAW_WRITTEN = None      # a list while gsn_amd.graphs.GraphedTrainStep captures: tensors that captured kernels write through raw pointers
+_FP_RING = [None, 0]
+
+
+def _fp_slot():
+    if _FP_RING[0] is None:
+        _FP_RING[0] = torch.zeros(1024, dtype=torch.int64).pin_memory()
+    i = _FP_RING[1]
+    _FP_RING[1] = (i + 1) % 1024
+    return _FP_RING[0][i:i + 1]
+
+
+def _async_validate(module):
+    tensors = [t for t in list(module.parameters()) + list(module.buffers()) if t.is_floating_point() and t.numel() and t.is_cuda and t.element_size() == 4]
+    if not tensors:
+        return
+    dev = tensors[0].device
+    ptrs = tuple(t.data_ptr() for t in tensors)
+    versions = tuple(t._version for t in tensors)
+    st = module.__dict__.get("_gsn_fp_state")
+    if st is None or st["ptrs"] != ptrs:
+        meta = torch.tensor(list(ptrs) + [t.numel() for t in tensors], dtype=torch.int64).to(dev)       # (once per layer: parameters keep their addresses)
+        st = {"ptrs": ptrs, "meta": meta, "max_words": max(t.numel() for t in tensors), "last": None, "pending": []}
+        module.__dict__["_gsn_fp_state"] = st
+    pend = st["pending"]
+    while pend and (len(pend) > 32 or pend[0][0].query()):
+        ev, slot, vers = pend.pop(0)
+        ev.synchronize()
+        val = int(slot[0])
+        last = st["last"]
+        if last is not None and last[0] != val and last[1] == vers:
+            import warnings
+            invalidate_caches(module)
+            warnings.warn("gsn_amd: a parameter or buffer of %s was written through `.data` (its version counter did not move): the forward(s) since "
+                          "that write used weights prepared before it; the caches are dropped now (call gsn_amd.layers.invalidate_caches "
+                          "after such a write, or set GSN_VALIDATE_CACHES=1)" % type(module).__name__, RuntimeWarning, stacklevel=3)
+        st["last"] = (val, vers)
+    acc = _zeros(1, torch.int64, dev)
+    with _abi.device_guard(dev):
+        _abi.check(_abi.lib().gsn_fingerprint_hip(len(tensors), st["meta"].data_ptr(), int(st["max_words"]), acc.data_ptr(), _abi.current_stream()),
+                   "gsn_fingerprint_hip")
+        slot = _fp_slot()
+        slot.copy_(acc, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+    pend.append((ev, slot, versions))
+
+
 def invalidate_caches(module=None):
     """Drop the derived tensors this module keeps per parameter VERSION (folded first weight of the `general` layers,
     eval-mode BatchNorm scale / shift vectors, transposed weights) -- needed only after writing a parameter or buffer
@@ -999,6 +1054,14 @@ def _bn_resolve(stage, stats_fn, m_rows, training):
                                                       p0, p0 + 4 * n_out, p0 + 8 * n_out, p0 + 12 * n_out,
                                                       _abi.ptr(nbt), _abi.current_stream())
         _abi.check(rc, "gsn_bn_finalize_count_hip")
+        if track:
+            # the kernel wrote the running statistics (and the counter) through raw pointers: PyTorch's version counters, on which the
+            # eval-mode vectors of this module are cached, have to move with them (no launch); a step being captured into a graph notes
+            # the tensors so that every REPLAY can do the same (gsn_amd.graphs.GraphedTrainStep)
+            touched = [bn.running_mean, bn.running_var] + ([nbt] if nbt is not None else [])
+            torch.autograd.graph.increment_version(touched)
+            if RAW_WRITTEN is not None:
+                RAW_WRITTEN.extend(touched)
         stage.bn_params = (v0, v2, v3)
         stage.bn_invstd = v1
         return
@@ -1686,6 +1749,8 @@ class _SparseLayer(nn.Module):
             if fp != getattr(self, "_gsn_fingerprint", None):
                 invalidate_caches(self)
                 self._gsn_fingerprint = fp
+        elif ASYNC_VALIDATE and not self.training and not torch.cuda.is_current_stream_capturing():
+            _async_validate(self)
         # Row counts of the per-edge / per-vertex inputs: the reference fails in torch.cat / indexing when they do not fit
         # (GSN_sparse.py:118-132); the kernels would read past the tensors instead.
         n_rows, n_cols_e = x.shape[0], edge_index.shape[1]

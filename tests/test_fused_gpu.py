@@ -311,6 +311,50 @@ def test_parameter_written_through_data_is_noticed():
         layers.VALIDATE_CACHES = was
 
 
+def test_parameter_written_through_data_is_noticed_without_any_flag():
+    """VERDICT r03 item 9, the default mode: the layer fingerprints its parameters behind every eval forward (gsn_fingerprint_hip, no host
+    synchronisation); a `.data` write is noticed at the NEXT forward whose predecessor's fingerprint has landed -- RuntimeWarning, caches
+    dropped -- and from there on the results are those of the new weights.  An ordinary in-place update (version counter moves) never warns."""
+    import warnings
+    from gsn_amd import layers
+    from oracle import oracle
+    assert layers.ASYNC_VALIDATE and not layers.VALIDATE_CACHES
+    b, x, ef, ei = _zinc(300, seed=43)
+    ids = (torch.rand(b.num_edges, 12, generator=torch.Generator().manual_seed(1)) < 0.2).float()
+    torch.manual_seed(3)
+    layer = layers.GSN_edge_sparse(**CTOR)
+    _randomise_bn(layer, 9)
+    layer.eval().cuda()
+    kw = dict(identifiers=ids.cuda(), degrees=torch.zeros(x.shape[0], device="cuda"), edge_features=ef.cuda())
+
+    def ref_now():
+        sd = {k: v.detach().cpu().clone() for k, v in layer.state_dict().items()}
+        return oracle.layer_forward("GSN_edge_sparse", CTOR, sd, x, ei, training=False, identifiers=ids, degrees=None, edge_features=ef)
+    with torch.no_grad(), warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        for _ in range(3):
+            y0 = layer(x.cuda(), ei.cuda(), **kw)
+            torch.cuda.synchronize()
+        assert _elementwise_ok(y0.cpu(), ref_now())
+        layer.update_fn.fc[1].weight.mul_(1.25)                    # in-place with a version bump: ordinary, re-prepared at once, no warning
+        y1 = layer(x.cuda(), ei.cuda(), **kw)
+        torch.cuda.synchronize()
+        assert _elementwise_ok(y1.cpu(), ref_now())
+        y1 = layer(x.cuda(), ei.cuda(), **kw)
+        torch.cuda.synchronize()
+        assert not [w for w in rec if issubclass(w.category, RuntimeWarning)]
+        layer.msg_fn.fc[0].weight.data.mul_(2.0)                   # the hole: no version counter moves
+        layer.update_fn.bn[0].running_var.data.mul_(1.5)
+        r1 = ref_now()
+        layer(x.cuda(), ei.cuda(), **kw)                           # (may still use the old fragments: its fingerprint is what reveals the write)
+        torch.cuda.synchronize()
+        layer(x.cuda(), ei.cuda(), **kw)                           # sees the fingerprint of the call before: warns, drops the caches
+        torch.cuda.synchronize()
+        y2 = layer(x.cuda(), ei.cuda(), **kw)
+        assert [w for w in rec if issubclass(w.category, RuntimeWarning) and "written through" in str(w.message)]
+        assert _elementwise_ok(y2.cpu(), r1), float((y2.cpu() - r1).abs().max() / r1.abs().max())
+
+
 def test_wide_layers_chain_their_row_exponents(capfd):
     """Two d = 128 layers in a row: the first leaves the row exponents of its output on the tensor, the second takes them instead of
     its own pass over x (trace: one row-exponent pass, two layer launches) and gives the same result as with the pass; a tensor that

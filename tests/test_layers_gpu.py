@@ -754,3 +754,32 @@ def test_edge_less_training_batch_through_batchnorm():
     for name, p in layer.msg_fn.named_parameters():
         assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
     assert any(p.grad is not None and float(p.grad.abs().max()) > 0 for p in layer.update_fn.parameters())
+
+
+def test_eval_after_training_uses_the_updated_running_statistics():
+    """eval forward (fills the eval-mode BatchNorm vector cache) -> train forward (the finalize kernel writes running_mean / running_var through
+    raw pointers) -> eval forward: must see the NEW running statistics (their version counters are moved with the kernel's write)."""
+    from gsn_amd import layers
+    from oracle import oracle
+    ctor = dict(d_in=6, d_ef=3, d_id=4, d_degree=1, degree_as_tag=False, retain_features=True, id_scope="local", d_msg=16, d_up=16,
+                d_h=[16], seed=0, activation_name="relu", bn=True, msg_kind="general", flow="source_to_target")
+    torch.manual_seed(1)
+    g = torch.Generator().manual_seed(2)
+    n, E = 40, 160
+    x, ei = torch.randn(n, 6, generator=g), torch.randint(0, n, (2, E), generator=g)
+    ids, ef = torch.randn(E, 4, generator=g), torch.randn(E, 3, generator=g)
+    layer = layers.GSN_edge_sparse(**ctor).cuda()
+    kw = dict(identifiers=ids.cuda(), degrees=torch.zeros(n, device="cuda"), edge_features=ef.cuda())
+    with torch.no_grad():
+        layer.eval()
+        layer(x.cuda(), ei.cuda(), **kw)
+        layer.train()
+        v0 = layer.msg_fn.bn[0].running_mean._version
+        for _ in range(3):
+            layer(x.cuda() * 3.0 + 1.0, ei.cuda(), **kw)
+        assert layer.msg_fn.bn[0].running_mean._version > v0
+        layer.eval()
+        y = layer(x.cuda(), ei.cuda(), **kw)
+    sd = {k: v.detach().cpu().clone() for k, v in layer.state_dict().items()}
+    ref = oracle.layer_forward("GSN_edge_sparse", ctor, sd, x, ei, training=False, identifiers=ids, degrees=None, edge_features=ef)
+    assert elementwise_ok(y.cpu(), ref), rel_err(y.cpu(), ref)
