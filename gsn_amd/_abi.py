@@ -52,7 +52,7 @@ SIGNATURES = {
     "gsn_version": (c_int, []),
     "gsn_device_count": (c_int, []),
     "gsn_stream_capture_id": (c_i64, [c_vp]),
-    "gsn_fingerprint_hip": (c_int, [c_int, c_vp, c_i64, c_vp, c_vp]),
+    "gsn_fingerprint_hip": (c_int, [c_int, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "gsn_pattern_orbits": (c_int, [c_i64, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "gsn_graph_vertex_orbits": (c_int, [c_i64, c_i64, c_vp, c_vp, c_vp]),
     "gsn_count_plan_build": (c_int, [c_int, c_int, c_int, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),

@@ -32,12 +32,17 @@ __global__ __launch_bounds__(256) void fingerprint_kernel(int n, const int64_t *
 
 using namespace gsn;
 
-extern "C" int gsn_fingerprint_hip(int n_tensors, const int64_t *meta, int64_t max_words, unsigned long long *acc, void *stream) {
+extern "C" int gsn_fingerprint_hip(int n_tensors, const int64_t *meta, int64_t max_words, unsigned long long *acc, unsigned long long *host_out,
+                                   void *stream) {
     if (n_tensors < 1 || n_tensors > 65535 || !meta || !acc || max_words < 0) return set_error(GSN_E_INVALID, "gsn_fingerprint_hip: bad arguments");
     int64_t bx = (max_words + 2047) / 2048;      // ~8 words per thread
     bx = bx < 1 ? 1 : (bx > 64 ? 64 : bx);
     hipLaunchKernelGGL(fingerprint_kernel, dim3((unsigned)bx, (unsigned)n_tensors), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), n_tensors, meta, acc);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(GSN_E_HIP, "fingerprint_kernel: %s", hipGetErrorString(e));
+    if (host_out) {      // pinned host memory: the copy is asynchronous, ordered behind the kernel on the stream
+        e = hipMemcpyAsync(host_out, acc, sizeof(unsigned long long), hipMemcpyDeviceToHost, reinterpret_cast<hipStream_t>(stream));
+        if (e != hipSuccess) return set_error(GSN_E_HIP, "gsn_fingerprint_hip: copy to the host: %s", hipGetErrorString(e));
+    }
     return GSN_OK;
 }

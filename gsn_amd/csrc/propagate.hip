@@ -611,6 +611,46 @@ __global__ __launch_bounds__(256) void propagate_self_bwd_kernel(SelfBwdArgs p) 
     }
 }
 
+// Few targets, long segments (the graph-level readouts at the reference's batch sizes: 32 .. 128 graphs, ~26 rows each): ONE WORKGROUP per
+// target, its rows dealt to the four waves (row q to wave q mod 4, four rows in flight per wave), partial sums added in wave order through
+// LDS -- a fixed order, so the result is deterministic (it differs in the last bit from the sequential order of propagate_fwd_kernel,
+// which spends ~1.3 us of load latency per row when one wave walks a segment alone: 29 us per readout at d = 300).
+__global__ __launch_bounds__(256) void segment_sum_wg_kernel(PropArgs p) {
+    __shared__ float4 red[3][256];
+    const int t = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int32_t lo = p.seg_ptr[t], hi = p.seg_ptr[t + 1];
+    const int q4 = p.d_out >> 2;
+    for (int c0 = 0; c0 < q4; c0 += 64) {
+        const int col = c0 + lane;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (col < q4) {
+            int32_t q = lo + wave;
+            for (; q + 12 < hi; q += 16) {
+                int64_t e[4];
+                float4 m[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) e[u] = p.perm ? (int64_t)p.perm[q + 4 * u] : (int64_t)(q + 4 * u);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) m[u] = *reinterpret_cast<const float4 *>(p.b + e[u] * p.db + 4 * col);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc = vadd(acc, m[u]);
+            }
+            for (; q < hi; q += 4) {
+                const int64_t e = p.perm ? (int64_t)p.perm[q] : (int64_t)q;
+                acc = vadd(acc, *reinterpret_cast<const float4 *>(p.b + e * p.db + 4 * col));
+            }
+        }
+        if (wave) red[wave - 1][lane] = acc;
+        __syncthreads();
+        if (wave == 0 && col < q4) {
+            acc = vadd(vadd(vadd(acc, red[0][lane]), red[1][lane]), red[2][lane]);
+            *reinterpret_cast<float4 *>(p.out + (int64_t)t * p.d_out + 4 * col) = acc;
+        }
+        __syncthreads();
+    }
+}
+
 static int hip_check(const char *what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(GSN_E_HIP, "%s: %s", what, hipGetErrorString(e));
@@ -943,6 +983,10 @@ extern "C" int gsn_propagate_self_fwd_hip(int kind, int64_t n_nodes, int64_t n_e
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const bool aligned = ((da | db | dc | pad_b | pad_c | self_or) % 4 == 0) && pad_b == 0 && pad_c == 0 &&
                          (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)out | self_align) % 16 == 0);
+    if (aligned && kind == GSN_MSG_CAT && !da && !dc && db && !b_per_node && !n_self && n_nodes <= 512 && n_edges >= 8 * n_nodes) {
+        hipLaunchKernelGGL(segment_sum_wg_kernel, dim3((unsigned)n_nodes), dim3(256), 0, st, p);
+        return hip_check("segment_sum_wg_kernel");
+    }
     if (aligned) {
         const int64_t q = d_out / 4;  // float4 per row
         if (q <= 8) return launch_fwd<4, 8, 1>(p, st);

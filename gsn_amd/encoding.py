@@ -291,7 +291,8 @@ class _EmbedFn(torch.autograd.Function):
         tabs = [t if (t.dtype == torch.float32 and t.is_contiguous()) else t.detach().to(torch.float32).contiguous() for t in tables]
         meta = _table_meta(tabs, dev)
         out = torch.empty((M, C * d if concat else d), dtype=torch.float32, device=dev)
-        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        from .layers import _zeros
+        status = _zeros(1, torch.int32, dev)
         rows = np.ascontiguousarray([t.shape[0] for t in tabs], dtype=np.int64)
         with _abi.device_guard(dev):
             rc = _abi.lib().gsn_embed_fwd_hip(M, C, d, int(concat), codes.data_ptr() if M else None, meta.data_ptr(),
@@ -313,7 +314,8 @@ class _EmbedFn(torch.autograd.Function):
         # gradient tables: ONE zero fill for all of them (nine tables of the atom encoder: nine launches otherwise); offsets rounded to
         # 16 bytes so that every table keeps the alignment of a tensor of its own
         sizes = [(s[0] * s[1] + 3) // 4 * 4 for s in ctx.shapes]
-        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        from .layers import _zeros
+        flat = _zeros(sum(sizes), torch.float32, dev)       # (from the zero arena: one fill per 8 MiB of such buffers)
         grads, o = [], 0
         for s_, n_ in zip(ctx.shapes, sizes):
             grads.append(flat[o:o + s_[0] * s_[1]].view(s_))

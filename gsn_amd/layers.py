@@ -86,24 +86,28 @@ def _need_cuda(t, what):
 # (device, stream, capture id): the fill runs on the stream the consumers run on, and an arena filled inside one graph capture is
 # never used by another capture or by eager launches (its fill is a node of that graph only).
 _ZARENA = {}
-_ZARENA_BYTES = 256 * 1024
+ZERO_ARENA = os.environ.get("GSN_ZERO_ARENA", "1") != "0"      # (0: every request is its own torch.zeros -- A/B and fault isolation)
+_ZARENA_TIERS = ((256 * 1024, 64 * 1024), (8 * 1024 * 1024, 2 * 1024 * 1024))     # (arena bytes, largest request served from it)
 
 
 def _zeros(n, dtype, device):
-    """1-D zero tensor of ``n`` elements of ``dtype`` on ``device`` (cuda) from the arena."""
-    import math
+    """1-D zero tensor of ``n`` elements of ``dtype`` on ``device`` (cuda) from the arenas: small requests (statistics, status words) from a
+    256 KiB arena, the weight-gradient accumulators of a dense backward (up to 2 MiB) from an 8 MiB one -- a d = 300 training step asks for
+    ~20 of those, one fill of 8 MiB costs what one fill of 700 KiB does."""
     item = torch.empty(0, dtype=dtype).element_size()
     nbytes = (n * item + 255) // 256 * 256
-    if nbytes > _ZARENA_BYTES // 4 or device.type != "cuda":
+    tier = 0 if nbytes <= _ZARENA_TIERS[0][1] else (1 if nbytes <= _ZARENA_TIERS[1][1] else -1)
+    if tier < 0 or device.type != "cuda" or not ZERO_ARENA:
         return torch.zeros(n, dtype=dtype, device=device)
+    size = _ZARENA_TIERS[tier][0]
     with _abi.device_guard(device):
         stream = _abi.current_stream()
         key = (device.index, stream, int(_abi.lib().gsn_stream_capture_id(stream)))
-    hit = _ZARENA.get(device.index)
-    if hit is None or hit[0] != key or hit[2] + nbytes > _ZARENA_BYTES:
+    hit = _ZARENA.get((device.index, tier))
+    if hit is None or hit[0] != key or hit[2] + nbytes > size:
         with torch.cuda.device(device):
-            hit = [key, torch.zeros(_ZARENA_BYTES, dtype=torch.uint8, device=device), 0]
-        _ZARENA[device.index] = hit
+            hit = [key, torch.zeros(size, dtype=torch.uint8, device=device), 0]
+        _ZARENA[(device.index, tier)] = hit
     off = hit[2]
     hit[2] = off + nbytes
     return hit[1][off:off + n * item].view(dtype)
@@ -222,7 +226,7 @@ def build_csr_graphs(index, n_nodes, node_ptr, edge_ptr, max_nodes, max_edges, o
     perm = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
     tgt = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
     src = torch.empty(max(E, 1), dtype=torch.int32, device=dev) if other is not None else None
-    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    status = _zeros(1, torch.int32, dev)
     if other is not None:
         other = other.contiguous()
     G = node_ptr.numel() - 1
@@ -832,10 +836,9 @@ def _async_validate(module):
         st["last"] = (val, vers)
     acc = _zeros(1, torch.int64, dev)
     with _abi.device_guard(dev):
-        _abi.check(_abi.lib().gsn_fingerprint_hip(len(tensors), st["meta"].data_ptr(), int(st["max_words"]), acc.data_ptr(), _abi.current_stream()),
-                   "gsn_fingerprint_hip")
         slot = _fp_slot()
-        slot.copy_(acc, non_blocking=True)
+        _abi.check(_abi.lib().gsn_fingerprint_hip(len(tensors), st["meta"].data_ptr(), int(st["max_words"]), acc.data_ptr(), slot.data_ptr(),
+                                                  _abi.current_stream()), "gsn_fingerprint_hip")
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))
     pend.append((ev, slot, versions))
@@ -1393,7 +1396,7 @@ def _code_stage_segsum(mf, cblocks, csr, m_rows):
             off += ncls
     wt = _transposed_weight(lin)
     bias = _f32c(lin.bias)
-    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    status = _zeros(1, torch.int32, dev)
 
     def launch(bn_params, out, stats):
         vecs = [None if v is None else _f32c(v) for v in (bn_params or (None, None, None))]

@@ -57,9 +57,11 @@ int gsn_device_count(void);
 int64_t gsn_stream_capture_id(void *stream);
 /* 64-bit content fingerprint of n device tensors, ADDED into *acc (device, caller-zeroed): meta (device int64) = n base pointers, then
  * n sizes in 4-byte words; max_words = the largest of them (sizes the grid).  Order-independent sum of mixed (tensor, position, word)
- * values; one launch.  The host mirror enqueues it behind a layer forward and compares the value at the next forward (a parameter
+ * values; one launch.  host_out (PINNED host memory, may be NULL): the value is also copied there asynchronously behind the kernel.
+ * The host mirror enqueues it behind a layer forward and compares the value at the next forward (a parameter
  * written through `.data` does not move PyTorch's version counter, on which the derived-weight caches are keyed). */
-int gsn_fingerprint_hip(int n_tensors, const int64_t *meta, int64_t max_words, unsigned long long *acc, void *stream);
+int gsn_fingerprint_hip(int n_tensors, const int64_t *meta, int64_t max_words, unsigned long long *acc, unsigned long long *host_out,
+                        void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * HP-1  pattern analysis (host).  Replaces utils_graph_processing.automorphism_orbits (:10-56) and

@@ -48,7 +48,7 @@ def _run(kind, optimizer, n_steps, warm=None):
     torch.cuda.manual_seed(99)
     model, data, params, opt, loss_of, N, E = _build(kind, optimizer, dropout=0.0)
     for g in opt.param_groups:
-        g["lr"] = 0.02 if optimizer == "sgd" else 2e-3      # large steps: a stale or skipped update shows far above the noise floor
+        g["lr"] = 3e-3 if optimizer == "sgd" else 3e-4      # (larger steps amplify the atomics' last-bit noise chaotically: 2 % after four steps at 0.02)
     if warm is None:
         losses = [_eager_step(params, opt, loss_of) for _ in range(n_steps)]
     else:
@@ -61,10 +61,14 @@ def _run(kind, optimizer, n_steps, warm=None):
 
 
 def _rel(sa, sb):
+    """max over the floating-point tensors of max|a - b| / max(max|a|, 1 % of the largest magnitude in the state): a tensor that is itself
+    (nearly) zero -- a bias a few steps after its zero initialisation -- is measured against the scale of the state, not against itself."""
+    scale = max(float(v.double().abs().max()) for v in sa.values() if v.is_floating_point() and v.numel())
     worst = 0.0
     for k in sa:
         if sa[k].is_floating_point():
-            worst = max(worst, float((sa[k].double() - sb[k].double()).abs().max() / sa[k].double().abs().max().clamp_min(1e-30)))
+            den = max(float(sa[k].double().abs().max()), 0.01 * scale)
+            worst = max(worst, float((sa[k].double() - sb[k].double()).abs().max()) / den)
         else:
             assert torch.equal(sa[k], sb[k]), k
     return worst
@@ -75,7 +79,7 @@ def test_replay_equals_eager(kind, optimizer):
     """Replayed steps against eager steps from the same seed.  The adjoint kernels accumulate with floating-point atomics (weight and
     bias gradients, column statistics, embedding rows), so two EAGER runs already differ in the last bits and the difference grows with
     the steps: the replays have to stay within a small multiple of that run-to-run noise, measured here, and far below what one
-    missed or stale update would cost (>= 1e-3 with these learning rates).  Integer state (num_batches_tracked, Adam's step) is exact."""
+    missed or stale update would cost.  Integer state (num_batches_tracked, Adam's step) is exact."""
     n_steps, warm = 6, 2
     sa, la = _run(kind, optimizer, n_steps)
     sa2, _ = _run(kind, optimizer, n_steps)
@@ -83,8 +87,8 @@ def test_replay_equals_eager(kind, optimizer):
     assert set(sa) == set(sb)
     noise = _rel(sa, sa2)
     diff = _rel(sa, sb)
-    # (one pair of eager runs can agree by chance: the floor sits well under the 1e-3 of a missed update)
-    assert diff <= max(16.0 * noise, 5e-5), "replays drift from eager: %.3g (eager run-to-run: %.3g)" % (diff, noise)
+    # (one pair of eager runs can agree by chance: the floor sits well under what a missed update costs, ~lr x |g| / |w| >= 1e-4)
+    assert diff <= max(16.0 * noise, 2e-5), "replays drift from eager: %.3g (eager run-to-run: %.3g)" % (diff, noise)
     for x, y in zip(la[warm:], lb[warm:]):      # (the loss of step k sees the drift of the k - 1 steps before it)
         assert abs(float(x) - float(y)) <= max(64.0 * noise, 1e-3) * abs(float(x)) + 1e-7
     nbt = [v for k, v in sb.items() if k.endswith("num_batches_tracked")]
