@@ -314,8 +314,9 @@ class _EmbedFn(torch.autograd.Function):
         # gradient tables: ONE zero fill for all of them (nine tables of the atom encoder: nine launches otherwise); offsets rounded to
         # 16 bytes so that every table keeps the alignment of a tensor of its own
         sizes = [(s[0] * s[1] + 3) // 4 * 4 for s in ctx.shapes]
-        from .layers import _zeros
-        flat = _zeros(sum(sizes), torch.float32, dev)       # (from the zero arena: one fill per 8 MiB of such buffers)
+        # (its own allocation, not the zero arena: the caching allocator hands a step the addresses of the step before, which keeps the
+        #  pointer arrays of _table_meta cached -- arena slices move every step)
+        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
         grads, o = [], 0
         for s_, n_ in zip(ctx.shapes, sizes):
             grads.append(flat[o:o + s_[0] * s_[1]].view(s_))
