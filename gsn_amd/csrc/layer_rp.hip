@@ -409,6 +409,8 @@ __global__ __launch_bounds__(64 * RR_NW) __attribute__((amdgpu_waves_per_eu(RR_N
         //      fragments ahead; the high planes one step ahead from LDS.
 #ifdef RR_ABL_NOSTREAM
 #define RP_STREAM(I) rr_u4{(unsigned)(I), (unsigned)lane, 0x3c003c00u, 0u}
+#elif defined(RR_ABL_STREAM1)       // (ablation: every stream load hits the same two fragments -- L1 hits instead of the L2 path; results wrong)
+#define RP_STREAM(I) __builtin_bit_cast(rr_u4, __builtin_amdgcn_raw_buffer_load_b128(wstream, 16 * lane, ((I) & 1) * 1024, 0))
 #else
 #define RP_STREAM(I) __builtin_bit_cast(rr_u4, __builtin_amdgcn_raw_buffer_load_b128(wstream, 16 * lane, (I) * 1024, 0))
 #endif
