@@ -95,6 +95,9 @@ __device__ __forceinline__ unsigned rp_pk_max_u16(unsigned a, unsigned b) { unsi
 #ifndef RP_PD
 #define RP_PD 8              // fragments of the low-plane weight stream in flight (layer_rr.hip: 4)
 #endif
+#ifndef RP_STAGGER
+#define RP_STAGGER 0          // start delay of the second wave of each SIMD, units of 64 x 64 = 4096 cycles
+#endif
 #ifndef RP_S1T
 #define RP_S1T 0             // 1: node stage 1 transposed (a lane holds four consecutive features of its own target: 16-byte stores, 32-byte pieces of a row)
 #endif
@@ -159,6 +162,15 @@ __global__ __launch_bounds__(64 * RR_NW) __attribute__((amdgpu_waves_per_eu(RR_N
     // ---- this wave's node range -----------------------------------------------------------------------------------------------
     const int range = wave * (int)gridDim.x + (int)blockIdx.x;
     if (range >= a.n_ranges) return;
+#if RP_STAGGER > 0
+    // the second wave of every SIMD starts a fraction of a tile late: both waves run the same tile loop on tiles of (nearly) the same
+    // shape, so a phase offset set here persists -- one wave's matrix segments beside the other's conversions instead of beside its
+    // matrix segments (MI355X_MICROARCH.md, two waves per SIMD: the matrix pipe is per SIMD)
+    if (wave >= RR_NW / 2) {
+#pragma unroll 1
+        for (int i = 0; i < RP_STAGGER; ++i) __builtin_amdgcn_s_sleep(64);
+    }
+#endif
     RrIter it;
     it.seg = a.seg_ptr; it.n_nodes = a.n_nodes;
     it.m_next = (int)((int64_t)a.n_nodes * range / a.n_ranges);

@@ -1,6 +1,7 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-.}
-for v in "" stream1 "" stream1; do
+for rep in 1 2; do
+for v in "" stag1 stag2 stag3 stag4 stag6; do
   lib=gsn_amd/lib/libgsn_hip.so; [ -n "$v" ] && lib=gsn_amd/lib/variants/libgsn_hip_$v.so
-  GSN_LIB_PATH=$(pwd)/$lib timeout 300 python scripts/bench_layer.py 2>/dev/null | python -c "import json,sys; d=json.load(sys.stdin); print('${v:-product}', {k: d[k]['ms_per_layer'] for k in ('fused_pack16','fused') if k in d})"
-done
+  GSN_LIB_PATH=$(pwd)/$lib timeout 300 python scripts/bench_layer.py 2>/dev/null | python -c "import json,sys; d=json.load(sys.stdin); print('${v:-product}', {k: d[k]['ms_per_layer'] for k in ('fused_pack16','fused') if k in d}, d.get('pack16_max_diff_over_max'))"
+done; done
