@@ -425,7 +425,7 @@ def train_step_config4(dev):
             "steps": 20, "warmup": 10}
 
 
-def train_small_batch(dev):
+def train_small_batch(dev, graphs=True):
     """The reference's own batch sizes (README.md:121: molhiv 32 graphs; :112: ZINC 128): the whole training step eager and replayed as ONE
     HIP graph (gsn_amd.graphs.GraphedTrainStep: forward, native adjoints, gradient bucket, optimizer update).  Supplementary."""
     import importlib.util
@@ -436,7 +436,7 @@ def train_small_batch(dev):
         mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mod)
         ent = {}
-        for graph in (False, True):
+        for graph in ((False, True) if graphs else (False,)):
             r = mod.run(types.SimpleNamespace(batch=batch, steps=100, warmup=5, layers=5, d=300, graph=graph, optimizer="sgd"), dev)
             ent["hip_graph" if graph else "eager"] = {"ms_per_step": r["ms_per_step"], "graphs_per_s": r["graphs_per_s"]}
         ent["workload"] = r["workload"]
@@ -828,7 +828,7 @@ def main():
         except Exception as ex:
             train4 = {"error": str(ex)[:200]}
         try:
-            train_small = train_small_batch(dev)
+            train_small = train_small_batch(dev, graphs=not args.no_graph)
         except Exception as ex:
             train_small = {"error": str(ex)[:200]}
         try:
