@@ -69,6 +69,9 @@ SIGNATURES = {
     "gsn_linear_f16x3_kpad": (c_i64, [c_i64]),
     "gsn_linear_f16x3_scratch_bytes": (c_i64, [c_i64, c_i64]),
     "gsn_linear_f16x3_prepare_hip": (c_int, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp]),
+    "gsn_linear_f16x3_prepare_strided_hip": (c_int, [c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp]),
+    "gsn_linear_fwd_strided_hip": (c_int, [c_i64, c_int, ctypes.POINTER(gsn_block), c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_int,
+                                           c_vp, c_vp, c_vp]),
     "gsn_linear_f16x3_fwd_hip": (c_int, [c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),
     "gsn_edge_split_sum_hip": (c_int, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_vp]),
     "gsn_csr_build_graphs_hip": (c_int, [c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
@@ -100,6 +103,8 @@ SIGNATURES = {
     "gsn_wgrad_hip": (c_int, [c_i64, c_i64, c_vp, c_int, ctypes.POINTER(gsn_block), c_vp, c_vp]),
     "gsn_gather_cat_hip": (c_int, [c_i64, c_int, ctypes.POINTER(gsn_block), c_vp, c_vp]),
     "gsn_bn_finalize_hip": (c_int, [c_i64, c_i64, ctypes.c_double, ctypes.c_double, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "gsn_bn_finalize_act_hip": (c_int, [c_i64, c_i64, ctypes.c_double, ctypes.c_double, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                        c_vp, c_int, c_vp, c_vp]),
     "gsn_bn_finalize_count_hip": (c_int, [c_i64, c_i64, ctypes.c_double, ctypes.c_double, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                           c_vp]),
     "gsn_column_stats_hip": (c_int, [c_i64, c_i64, c_vp, c_vp, c_vp]),

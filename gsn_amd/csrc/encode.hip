@@ -988,6 +988,62 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(int n_cols, double m_r
 }
 }  // namespace gsn
 
+namespace gsn {
+// bn_finalize_kernel and bn_act_kernel in ONE launch (the train-mode BatchNorm of a materialised stage at the reference's batch sizes, where a
+// launch costs more than the pass): a lane owns a column, computes its mean / invstd / scale / shift from the fp64 sums with bn_finalize_kernel's
+// expressions (every workgroup the same values), the first row block writes the vectors and the running statistics, then the rows are
+// normalised and activated with bn_act_kernel's expression.  grid (row blocks, ceil(C / 64)).
+__global__ __launch_bounds__(256) void bn_finalize_act_kernel(int n_cols, int64_t m_rows_i, double eps, double momentum, const double *stats,
+                                                              const float *gamma, const float *beta, float *running_mean, float *running_var,
+                                                              float *mean, float *invstd, float *scale, float *shift,
+                                                              int64_t *num_batches_tracked, const float *h, int act, float *out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + lane;
+    if (c >= n_cols) return;
+    const double m_rows = (double)m_rows_i;
+    const double mu = stats[c] / m_rows;
+    double var = stats[n_cols + c] / m_rows - mu * mu;
+    var = var > 0.0 ? var : 0.0;
+    const float is = (float)(1.0 / sqrt(var + eps));
+    const float mf = (float)mu, sc = gamma ? is * gamma[c] : is, sh = beta ? beta[c] : 0.f;
+    if (blockIdx.x == 0 && wave == 0) {
+        if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
+        mean[c] = mf; invstd[c] = is; scale[c] = sc; shift[c] = sh;
+        if (running_mean) {
+            const double unbiased = var * (m_rows / (m_rows > 1.0 ? m_rows - 1.0 : 1.0));
+            running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * (double)(float)mu);
+            running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * (double)(float)unbiased);
+        }
+    }
+    for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < m_rows_i; r += (int64_t)gridDim.x * 4) {
+        const int64_t i = r * n_cols + c;
+        float y = (h[i] - mf) * sc + sh;
+        switch (act) {
+            case 1: y = y > 0.f ? y : 0.f; break;
+            case 2: y = y > 0.f ? y : expm1f(y); break;
+            case 3: y = tanhf(y); break;
+            default: break;
+        }
+        out[i] = y;
+    }
+}
+}  // namespace gsn
+
+extern "C" int gsn_bn_finalize_act_hip(int64_t n_cols, int64_t m_rows, double eps, double momentum, const double *stats, const float *gamma,
+                                       const float *beta, float *running_mean, float *running_var, float *mean, float *invstd, float *scale,
+                                       float *shift, int64_t *num_batches_tracked, const float *h, int act, float *out, void *stream) {
+    if (n_cols < 1 || m_rows < 1 || !stats || !mean || !invstd || !scale || !shift || !h || !out || act < 0 || act > 3 ||
+        ((running_mean != nullptr) != (running_var != nullptr)))
+        return set_error(GSN_E_INVALID, "gsn_bn_finalize_act_hip: bad arguments");
+    int64_t bx = (m_rows + 15) / 16;
+    bx = bx < 1 ? 1 : (bx > 1024 ? 1024 : bx);
+    hipLaunchKernelGGL(bn_finalize_act_kernel, dim3((unsigned)bx, (unsigned)((n_cols + 63) / 64)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       (int)n_cols, m_rows, eps, momentum, stats, gamma, beta, running_mean, running_var, mean, invstd, scale, shift,
+                       num_batches_tracked, h, act, out);
+    GSN_LAUNCH_CHECK("bn_finalize_act_kernel");
+    return GSN_OK;
+}
+
 extern "C" int gsn_bn_finalize_hip(int64_t n_cols, int64_t m_rows, double eps, double momentum, const double *stats,
                                    const float *gamma, const float *beta, float *running_mean, float *running_var, float *mean,
                                    float *invstd, float *scale, float *shift, void *stream) {

@@ -48,6 +48,7 @@ struct LinArgs {
     const int32_t *bidx32[MAX_BLOCKS];
     int bwidth[MAX_BLOCKS];
     const float *W, *bias, *bn_mean, *bn_scale, *bn_shift;
+    int64_t w_rs, w_cs;        // element strides of W[j][k] (k_total, 1: row-major; 1, ld: a transposed view -- the scalar staging path of the bf16x6 kernel only)
     int k_total, n_out, act;
     const int32_t *row_perm;
     float *out;
@@ -405,7 +406,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int i = 0; i < NPRE8; ++i) {
             int j = n0 + r0 + 16 * i;
             j = j < a.n_out ? j : 0;
-            preW[i] = a.W[(int64_t)j * a.k_total + kk];
+            preW[i] = a.W[(int64_t)j * a.w_rs + (int64_t)kk * a.w_cs];
         }
     };
     // registers -> three bf16 planes.  Rows of W^T past K / columns past n_out are zeroed by a 0/1 factor applied to values
@@ -594,9 +595,29 @@ static int launch_linear(const LinArgs &a, int k_pad, size_t lds, int64_t gx, in
 
 using namespace gsn;
 
+static int linear_fwd_impl(int64_t m_rows, int n_blocks, const gsn_block *blocks, const float *W, int64_t w_rs, int64_t w_cs, const float *bias,
+                           int64_t n_out, const float *bn_mean, const float *bn_scale, const float *bn_shift, int act,
+                           const int32_t *row_perm, float *out, double *stats, void *stream);
+
 extern "C" int gsn_linear_fwd_hip(int64_t m_rows, int n_blocks, const gsn_block *blocks, const float *W, const float *bias,
                                   int64_t n_out, const float *bn_mean, const float *bn_scale, const float *bn_shift, int act,
                                   const int32_t *row_perm, float *out, double *stats, void *stream) {
+    return linear_fwd_impl(m_rows, n_blocks, blocks, W, 0, 0, bias, n_out, bn_mean, bn_scale, bn_shift, act, row_perm, out, stats, stream);
+}
+
+// W given through element strides (W[j][k] at W + j * w_row_stride + k * w_col_stride): the input-gradient product gX = gH W of a dense stage
+// reads the stage's own [n_out][K] weight as its transpose (row stride 1, column stride K) instead of a transposed copy per stage and step.
+// The bf16x6 kernel's scalar staging path; GSN_E_UNSUPPORTED when that kernel is switched off.
+extern "C" int gsn_linear_fwd_strided_hip(int64_t m_rows, int n_blocks, const gsn_block *blocks, const float *W, int64_t w_row_stride,
+                                          int64_t w_col_stride, const float *bias, int64_t n_out, const float *bn_mean, const float *bn_scale,
+                                          const float *bn_shift, int act, float *out, double *stats, void *stream) {
+    if (w_row_stride < 1 || w_col_stride < 1) return set_error(GSN_E_INVALID, "gsn_linear_fwd_strided_hip: strides must be positive");
+    return linear_fwd_impl(m_rows, n_blocks, blocks, W, w_row_stride, w_col_stride, bias, n_out, bn_mean, bn_scale, bn_shift, act, nullptr, out, stats, stream);
+}
+
+static int linear_fwd_impl(int64_t m_rows, int n_blocks, const gsn_block *blocks, const float *W, int64_t w_rs, int64_t w_cs, const float *bias,
+                           int64_t n_out, const float *bn_mean, const float *bn_scale, const float *bn_shift, int act,
+                           const int32_t *row_perm, float *out, double *stats, void *stream) {
     if (n_blocks < 1 || n_blocks > MAX_BLOCKS || !blocks || !W || n_out <= 0)
         return set_error(GSN_E_INVALID, "gsn_linear_fwd_hip: need 1..%d input blocks, W and n_out > 0", MAX_BLOCKS);
     if (!out && !stats) return set_error(GSN_E_INVALID, "gsn_linear_fwd_hip: neither out nor stats given");
@@ -604,6 +625,7 @@ extern "C" int gsn_linear_fwd_hip(int64_t m_rows, int n_blocks, const gsn_block 
         return set_error(GSN_E_INVALID, "gsn_linear_fwd_hip: bn_mean, bn_scale and bn_shift go together");
     if (act < 0 || act > 3) return set_error(GSN_E_INVALID, "gsn_linear_fwd_hip: act must be 0..3");
     if (m_rows <= 0) return GSN_OK;
+    const bool strided = w_rs != 0;
     LinArgs a{};
     a.m_rows = m_rows; a.n_blocks = n_blocks;
     int k_total = 0;
@@ -614,6 +636,7 @@ extern "C" int gsn_linear_fwd_hip(int64_t m_rows, int n_blocks, const gsn_block 
         k_total += (int)blocks[b].width;
     }
     a.k_total = k_total; a.n_out = (int)n_out; a.act = act;
+    a.w_rs = strided ? w_rs : k_total; a.w_cs = strided ? w_cs : 1;
     {
         const float *cb[MAX_BLOCKS]; int cw[MAX_BLOCKS];
         for (int b = 0; b < MAX_BLOCKS; ++b) { cb[b] = b < n_blocks ? a.bdata[b] : a.bdata[0]; cw[b] = b < n_blocks ? a.bwidth[b] : (1 << 27); }
@@ -628,13 +651,14 @@ extern "C" int gsn_linear_fwd_hip(int64_t m_rows, int n_blocks, const gsn_block 
     const int k_pad = (k_total + BK - 1) / BK * BK;
     {   // default: the bf16x6 kernel (GSN_LINEAR_BF16X6=0 selects the fp32-MFMA kernel below for A/B measurements)
         static const bool bf16x6 = [] { const char *d = getenv("GSN_LINEAR_BF16X6"); return !(d && atoi(d) == 0); }();
-        bool vec4 = (k_total & 3) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0;   // float4 staging of A and W
+        bool vec4 = !strided && (k_total & 3) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0;   // float4 staging of A and W
         for (int b = 0; b < n_blocks; ++b)
             if ((a.bwidth[b] & 3) || (reinterpret_cast<uintptr_t>(a.bdata[b]) & 15)) vec4 = false;
         { const char *d = getenv("GSN_LINEAR_VEC4"); if (d && atoi(d) == 0) vec4 = false; }
         if (bf16x6 && vec4) return stats ? launch_linear_bf16<true, true>(a, k_pad, n_tiles, col_tiles, st) : launch_linear_bf16<false, true>(a, k_pad, n_tiles, col_tiles, st);
         if (bf16x6) return stats ? launch_linear_bf16<true, false>(a, k_pad, n_tiles, col_tiles, st) : launch_linear_bf16<false, false>(a, k_pad, n_tiles, col_tiles, st);
     }
+    if (strided) return set_error(GSN_E_UNSUPPORTED, "gsn_linear_fwd_strided_hip: the bf16x6 kernel is switched off");
     const size_t common = (size_t)2 * BM * APITCH * 4 + 2 * MAX_BLOCKS * BM * 4;
     const size_t lds_res = (size_t)k_pad * WPITCH * 4 + common;
     const size_t lds_str = (size_t)2 * BK * WPITCH * 4 + common;

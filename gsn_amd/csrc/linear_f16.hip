@@ -109,11 +109,11 @@ __device__ __forceinline__ L16Col l16_col(const L16Args &a, int kg) {
 
 // ---- weights: one wave per output column -----------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void lin16_prepare_kernel(const float *__restrict__ W, int n_out, int k_total, int k_pad, _Float16 *planes,
-                                                          float *colinv) {
+                                                          float *colinv, int64_t w_rs, int64_t w_cs) {
     const int j = blockIdx.x, lane = threadIdx.x;
-    const float *w = W + (int64_t)j * k_total;
+    const float *w = W + (int64_t)j * w_rs;      // (element k of output column j at w[k * w_cs]: row-major, or a transposed view)
     unsigned m = 0;
-    for (int k = lane; k < k_total; k += 64) m = max(m, __float_as_uint(w[k]) & 0x7fffffffu);
+    for (int k = lane; k < k_total; k += 64) m = max(m, __float_as_uint(w[k * w_cs]) & 0x7fffffffu);
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
     float s, inv;
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(64) void lin16_prepare_kernel(const float *__restri
     if (m >= 0x7f800000u) inv = __uint_as_float(0x7fc00000u);        // a non-finite weight: the whole output column is NaN
     _Float16 *row = planes + (int64_t)j * k_pad * 2;
     for (int k = lane; k < k_pad; k += 64) {
-        const float v = k < k_total ? w[k] * s : 0.f;
+        const float v = k < k_total ? w[k * w_cs] * s : 0.f;
         const _Float16 h = (_Float16)v;
         _Float16 *line = row + (k >> 5) * 64 + (k & 31);
         line[0] = h;
@@ -727,17 +727,27 @@ extern "C" int64_t gsn_linear_f16x3_scratch_bytes(int64_t m_rows, int64_t k_tota
     return m_pad * 4 + m_rows * k_pad * 4;                                // inverse row scales | the rows' planes
 }
 
-extern "C" int gsn_linear_f16x3_prepare_hip(const float *W, int64_t n_out, int64_t k_total, void *planes, float *col_inv, void *stream) {
-    if (!W || !planes || !col_inv || n_out <= 0 || k_total <= 0 || n_out > (1 << 24) || k_total > (1 << 20))
+static int l16_prepare(const float *W, int64_t n_out, int64_t k_total, int64_t w_rs, int64_t w_cs, void *planes, float *col_inv, void *stream) {
+    if (!W || !planes || !col_inv || n_out <= 0 || k_total <= 0 || n_out > (1 << 24) || k_total > (1 << 20) || w_rs < 1 || w_cs < 1)
         return set_error(GSN_E_INVALID, "gsn_linear_f16x3_prepare_hip: bad argument");
     const int k_pad = (int)gsn_linear_f16x3_kpad(k_total);
     if (n_out * (int64_t)k_pad * 4 >= ((int64_t)1 << 31))
         return set_error(GSN_E_UNSUPPORTED, "gsn_linear_f16x3_prepare_hip: weight planes of 2 GiB and more are not supported");
     hipLaunchKernelGGL(lin16_prepare_kernel, dim3((unsigned)n_out), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), W, (int)n_out, (int)k_total,
-                       k_pad, reinterpret_cast<_Float16 *>(planes), col_inv);
+                       k_pad, reinterpret_cast<_Float16 *>(planes), col_inv, w_rs, w_cs);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(GSN_E_HIP, "lin16_prepare_kernel: %s", hipGetErrorString(e));
     return GSN_OK;
+}
+
+extern "C" int gsn_linear_f16x3_prepare_hip(const float *W, int64_t n_out, int64_t k_total, void *planes, float *col_inv, void *stream) {
+    return l16_prepare(W, n_out, k_total, k_total, 1, planes, col_inv, stream);
+}
+
+// the same from a weight given through element strides (a transposed view: row stride 1, column stride = the leading dimension)
+extern "C" int gsn_linear_f16x3_prepare_strided_hip(const float *W, int64_t n_out, int64_t k_total, int64_t w_row_stride, int64_t w_col_stride,
+                                                    void *planes, float *col_inv, void *stream) {
+    return l16_prepare(W, n_out, k_total, w_row_stride, w_col_stride, planes, col_inv, stream);
 }
 
 extern "C" int gsn_linear_f16x3_fwd_hip(int64_t m_rows, int n_blocks, const gsn_block *blocks, const void *planes, const float *col_inv,

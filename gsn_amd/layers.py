@@ -578,6 +578,9 @@ LINEAR_F16X3_MIN_N = int(os.environ.get("GSN_LINEAR_F16X3_MIN_N", "128"))
 LINEAR_F16X3_STATS = os.environ.get("GSN_LINEAR_F16X3_STATS", "0") != "0"
 
 
+STRIDED_WEIGHTS = os.environ.get("GSN_STRIDED_WEIGHTS", "1") != "0"      # transposed weight views read through their strides (0: a contiguous copy first)
+
+
 def _f16x3_weights(weight, w32):
     """fp16 planes + inverse column scales of a weight matrix for gsn_linear_f16x3_fwd_hip, made once per weight VERSION and kept
     on the tensor object (parameters, folded weights and the cached derived matrices all live across calls)."""
@@ -591,8 +594,12 @@ def _f16x3_weights(weight, w32):
     planes = torch.empty(2 * n_out * kpad, dtype=torch.float16, device=w32.device)
     col_inv = torch.empty(n_out, dtype=torch.float32, device=w32.device)
     with _abi.device_guard(w32.device):
-        _abi.check(L.gsn_linear_f16x3_prepare_hip(w32.data_ptr(), n_out, k, planes.data_ptr(), col_inv.data_ptr(), _abi.current_stream()),
-                   "gsn_linear_f16x3_prepare_hip")
+        if w32.is_contiguous():
+            _abi.check(L.gsn_linear_f16x3_prepare_hip(w32.data_ptr(), n_out, k, planes.data_ptr(), col_inv.data_ptr(), _abi.current_stream()),
+                       "gsn_linear_f16x3_prepare_hip")
+        else:       # (a transposed view: read through its strides, no copy)
+            _abi.check(L.gsn_linear_f16x3_prepare_strided_hip(w32.data_ptr(), n_out, k, w32.stride(0), w32.stride(1), planes.data_ptr(), col_inv.data_ptr(),
+                                                              _abi.current_stream()), "gsn_linear_f16x3_prepare_strided_hip")
     try:
         weight._gsn_f16x3 = (key, planes, col_inv)
     except (AttributeError, RuntimeError):
@@ -625,7 +632,11 @@ def _linear_hip(blocks, weight, bias, bn_mean, bn_scale, bn_shift, act, m_rows, 
     y = torch.empty((m_rows, n_out), dtype=torch.float32, device=dev) if out else None
     if m_rows == 0:
         return y                      # (no rows: nothing to launch; `stats` keeps its zeros)
-    w = _f32c(weight)
+    # a transposed VIEW of a row-major fp32 matrix (the input-gradient product gX = gH W reads the stage's weight as its transpose) is taken
+    # through its strides by both dense kernels: no transposed copy per stage and step
+    w_view = (weight.dim() == 2 and weight.dtype is torch.float32 and not weight.is_contiguous() and weight.stride(0) == 1
+              and weight.stride(1) >= weight.shape[0] and STRIDED_WEIGHTS)
+    w = (weight.detach() if weight.requires_grad else weight) if w_view else _f32c(weight)
     vecs = [None if v is None else _f32c(v) for v in (bias, bn_mean, bn_scale, bn_shift)]
     # direct rows (node-level stages): the fp16x3 kernel with the weights split once per weight version
     # (from two column tiles on: the pre-pass over the rows that finds their scales is then amortised -- at n_out <= 128 the
@@ -645,6 +656,15 @@ def _linear_hip(blocks, weight, bias, bn_mean, bn_scale, bn_shift, act, m_rows, 
             with _abi.device_guard(dev), _timed("column_stats", 2.0 * m_rows * n_out):
                 _abi.check(_abi.lib().gsn_column_stats_hip(m_rows, n_out, y.data_ptr(), stats.data_ptr(), _abi.current_stream()), "gsn_column_stats_hip")
         return y
+    if w_view:
+        with _abi.device_guard(dev), _timed("linear_fwd", 2.0 * m_rows * w.shape[1] * n_out):
+            rc = _abi.lib().gsn_linear_fwd_strided_hip(m_rows, len(blocks), arr, w.data_ptr(), w.stride(0), w.stride(1), _abi.ptr(vecs[0]), n_out,
+                                                       _abi.ptr(vecs[1]), _abi.ptr(vecs[2]), _abi.ptr(vecs[3]), act, _abi.ptr(y), _abi.ptr(stats),
+                                                       _abi.current_stream())
+        if rc != -2:                  # (GSN_E_UNSUPPORTED: the bf16x6 kernel is switched off -> a contiguous copy below)
+            _abi.check(rc, "gsn_linear_fwd_strided_hip")
+            return y
+        w = w.contiguous()
     with _abi.device_guard(dev), _timed("linear_fwd", 2.0 * m_rows * w.shape[1] * n_out):
         rc = _abi.lib().gsn_linear_fwd_hip(m_rows, len(blocks), arr, w.data_ptr(), _abi.ptr(vecs[0]), n_out, _abi.ptr(vecs[1]),
                                            _abi.ptr(vecs[2]), _abi.ptr(vecs[3]), act, None, _abi.ptr(y), _abi.ptr(stats),
@@ -1013,7 +1033,10 @@ def _layer_fused(x, csr, edge_stages, node_stages, training, owner=None, gen=0, 
     return out
 
 
-def _bn_resolve(stage, stats_fn, m_rows, training):
+FUSE_BN_ACT_ROWS = int(os.environ.get("GSN_FUSE_BN_ACT_ROWS", "16384"))      # train-mode stages of at most this many rows: finalize + normalise in one launch
+
+
+def _bn_resolve(stage, stats_fn, m_rows, training, fuse_act=None):
     """Fill stage.bn_params = (mean, scale, shift).  Train mode: batch statistics from a statistics pass (fp64 column
     sums), running statistics updated exactly like nn.BatchNorm1d."""
     bn = stage.bn
@@ -1052,10 +1075,18 @@ def _bn_resolve(stage, stats_fn, m_rows, training):
         v0, v1, v2, v3 = vec.unbind(0)           # (the four rows: one call, and their addresses by arithmetic -- this runs per BatchNorm per step)
         p0 = vec.data_ptr()
         with _abi.device_guard(dev):
-            rc = _abi.lib().gsn_bn_finalize_count_hip(n_out, m_rows, float(bn.eps), float(mom), stats.data_ptr(), _abi.ptr(gamma), _abi.ptr(beta),
-                                                      bn.running_mean.data_ptr() if track else None, bn.running_var.data_ptr() if track else None,
-                                                      p0, p0 + 4 * n_out, p0 + 8 * n_out, p0 + 12 * n_out,
-                                                      _abi.ptr(nbt), _abi.current_stream())
+            if fuse_act is not None:
+                # (h, act code, out): the normalise + activate pass rides the same launch (FUSE_BN_ACT_ROWS: where a launch costs more than it)
+                fh, fact, fout = fuse_act
+                rc = _abi.lib().gsn_bn_finalize_act_hip(n_out, m_rows, float(bn.eps), float(mom), stats.data_ptr(), _abi.ptr(gamma), _abi.ptr(beta),
+                                                        bn.running_mean.data_ptr() if track else None, bn.running_var.data_ptr() if track else None,
+                                                        p0, p0 + 4 * n_out, p0 + 8 * n_out, p0 + 12 * n_out, _abi.ptr(nbt),
+                                                        fh.data_ptr(), int(fact), fout.data_ptr(), _abi.current_stream())
+            else:
+                rc = _abi.lib().gsn_bn_finalize_count_hip(n_out, m_rows, float(bn.eps), float(mom), stats.data_ptr(), _abi.ptr(gamma), _abi.ptr(beta),
+                                                          bn.running_mean.data_ptr() if track else None, bn.running_var.data_ptr() if track else None,
+                                                          p0, p0 + 4 * n_out, p0 + 8 * n_out, p0 + 12 * n_out,
+                                                          _abi.ptr(nbt), _abi.current_stream())
         _abi.check(rc, "gsn_bn_finalize_count_hip")
         if track:
             # the kernel wrote the running statistics (and the counter) through raw pointers: PyTorch's version counters, on which the
@@ -1198,20 +1229,24 @@ class _DenseStagesFn(torch.autograd.Function):
             elif bn is not None:
                 # batch statistics (train mode), or running statistics with gradients for gamma / beta: pre-BN rows materialised
                 st = _Stage(w, b, bn, sp["act"])
+                fused_act = False
                 if bn_train:
                     stats = _zeros(2 * n_out, torch.float64, w.device).view(2, n_out)
                     h = _linear_hip(blks, w, b, None, None, None, 0, m_rows, out=True, stats=stats)
-                    _bn_resolve(st, lambda: stats, m_rows, True)
+                    yy = torch.empty_like(h)
+                    fused_act = 1 < m_rows <= FUSE_BN_ACT_ROWS
+                    _bn_resolve(st, lambda: stats, m_rows, True, fuse_act=(h, _ACT_CODE[sp["act"]], yy) if fused_act else None)
                 else:
                     h = _linear_hip(blks, w, b, None, None, None, 0, m_rows, out=True)
+                    yy = torch.empty_like(h)
                     _bn_resolve(st, None, m_rows, False)
                 mean32, scale, shift = st.bn_params
-                yy = torch.empty_like(h)
                 vecs = [_f32c(v) for v in (mean32, scale, shift)]
-                with _abi.device_guard(h.device), _timed("bn_act", 8.0 * h.numel()):
-                    _abi.check(_abi.lib().gsn_bn_act_hip(m_rows, n_out, h.data_ptr(), vecs[0].data_ptr(), vecs[1].data_ptr(),
-                                                         vecs[2].data_ptr(), _ACT_CODE[sp["act"]], yy.data_ptr(),
-                                                         _abi.current_stream()), "gsn_bn_act_hip")
+                if not fused_act:
+                    with _abi.device_guard(h.device), _timed("bn_act", 8.0 * h.numel()):
+                        _abi.check(_abi.lib().gsn_bn_act_hip(m_rows, n_out, h.data_ptr(), vecs[0].data_ptr(), vecs[1].data_ptr(),
+                                                             vecs[2].data_ptr(), _ACT_CODE[sp["act"]], yy.data_ptr(),
+                                                             _abi.current_stream()), "gsn_bn_act_hip")
                 invstd = st.bn_invstd
                 saved += [h, yy, vecs[0], invstd.contiguous(), vecs[1], vecs[2]]
                 meta.append(("bn" if bn_train else "bn_eval", len(saved) - 6))
@@ -1310,7 +1345,10 @@ class _DenseStagesFn(torch.autograd.Function):
             # input gradient
             need_x = si > 0 or any(ctx.needs_input_grad[1 + bi] for bi in range(len(blocks0)))
             if need_x:
-                gx = _linear_hip([(gh, None)], _transposed(w), None, None, None, None, 0, m_rows)
+                # gX = gH W: W read as its transpose.  The fp16x3 kernel prepares its planes from any strides; the bf16x6 kernel stages a
+                # strided W with scalar loads -- fine where a launch costs more than the staging (small batches), a copy + float4 staging above
+                wt = w.detach().t() if (w.shape[1] > LINEAR_F16X3_MIN_N or m_rows <= 16384) else _transposed(w)
+                gx = _linear_hip([(gh, None)], wt, None, None, None, None, 0, m_rows)
                 if si > 0:
                     g = gx
                 else:

@@ -262,6 +262,12 @@ typedef struct {
 int gsn_linear_fwd_hip(int64_t m_rows, int n_blocks, const gsn_block *blocks, const float *W, const float *bias,
                        int64_t n_out, const float *bn_mean, const float *bn_scale, const float *bn_shift, int act,
                        const int32_t *row_perm, float *out, double *stats, void *stream);
+/* gsn_linear_fwd_hip with W given through element strides (W[j][k] at W + j * w_row_stride + k * w_col_stride): the input-gradient product
+ * gX = gH W of a dense stage reads the stage's own weight as its transpose (1, K) -- no transposed copy per stage and step.  No row_perm.
+ * GSN_E_UNSUPPORTED when the bf16x6 kernel is switched off (GSN_LINEAR_BF16X6=0). */
+int gsn_linear_fwd_strided_hip(int64_t m_rows, int n_blocks, const gsn_block *blocks, const float *W, int64_t w_row_stride,
+                               int64_t w_col_stride, const float *bias, int64_t n_out, const float *bn_mean, const float *bn_scale,
+                               const float *bn_shift, int act, float *out, double *stats, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * HP-2  fused MLP chain (device; fp32 in / fp32 out; matrix products as in gsn_linear_fwd_hip: bf16x6 by default,
@@ -413,6 +419,10 @@ int gsn_layer_fused_fwd_pack16_hip(int64_t n_nodes, int64_t n_edges, const int32
 int64_t gsn_linear_f16x3_kpad(int64_t k_total);
 int64_t gsn_linear_f16x3_scratch_bytes(int64_t m_rows, int64_t k_total);
 int gsn_linear_f16x3_prepare_hip(const float *W, int64_t n_out, int64_t k_total, void *planes, float *col_inv, void *stream);
+/* the same from a weight given through element strides (W[j][k] at W + j * w_row_stride + k * w_col_stride; a transposed view of a row-major
+ * matrix: 1, leading dimension) */
+int gsn_linear_f16x3_prepare_strided_hip(const float *W, int64_t n_out, int64_t k_total, int64_t w_row_stride, int64_t w_col_stride,
+                                         void *planes, float *col_inv, void *stream);
 int gsn_linear_f16x3_fwd_hip(int64_t m_rows, int n_blocks, const gsn_block *blocks, const void *planes, const float *col_inv,
                              const float *bias, int64_t n_out, const float *bn_mean, const float *bn_scale, const float *bn_shift,
                              int act, float *row_scratch, float *out, void *stream);
@@ -586,6 +596,12 @@ int gsn_add_gathered_hip(int64_t n_rows, int64_t d, const float *x, const float 
 int gsn_bn_finalize_hip(int64_t n_cols, int64_t m_rows, double eps, double momentum, const double *stats, const float *gamma,
                         const float *beta, float *running_mean, float *running_var, float *mean, float *invstd, float *scale,
                         float *shift, void *stream);
+/* gsn_bn_finalize_count_hip and gsn_bn_act_hip in one launch (same expressions, same values): the batch statistics' vectors, the running
+ * statistics and the counter are written, then out = act((h - mean) * scale + shift) over the M rows.  For row counts where a launch costs
+ * more than the pass (the reference's batch sizes: 32 .. 128 graphs). */
+int gsn_bn_finalize_act_hip(int64_t n_cols, int64_t m_rows, double eps, double momentum, const double *stats, const float *gamma,
+                            const float *beta, float *running_mean, float *running_var, float *mean, float *invstd, float *scale,
+                            float *shift, int64_t *num_batches_tracked, const float *h, int act, float *out, void *stream);
 
 /* The same with nn.BatchNorm1d's `num_batches_tracked` (int64 [1], device; NULL = none) incremented by the kernel. */
 int gsn_bn_finalize_count_hip(int64_t n_cols, int64_t m_rows, double eps, double momentum, const double *stats, const float *gamma,
