@@ -24,6 +24,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import time
 import weakref
 
 import torch
@@ -817,6 +818,9 @@ def _module_fingerprint(module):
 # write and that point used the old derived weights (the check costs no synchronisation; GSN_VALIDATE_CACHES=1 checks BEFORE every
 # forward at the price of one); `invalidate_caches` after such a write remains the contract for code that cannot afford one stale call.
 ASYNC_VALIDATE = os.environ.get("GSN_ASYNC_VALIDATE", "1") != "0"
+# at most one fingerprint per layer and interval (seconds of wall clock): a tight inference loop pays one 5 us launch per layer every 20 ms, not
+# one per forward; a `.data` write is then noticed within the interval plus one forward.  0: behind every eval forward.
+ASYNC_VALIDATE_INTERVAL = float(os.environ.get("GSN_ASYNC_VALIDATE_INTERVAL", "0.02"))
 RAW_WRITTEN = None      # a list while gsn_amd.graphs.GraphedTrainStep captures: tensors that captured kernels write through raw pointers
 _FP_RING = [None, 0]
 
@@ -854,6 +858,10 @@ def _async_validate(module):
                           "that write used weights prepared before it; the caches are dropped now (call gsn_amd.layers.invalidate_caches "
                           "after such a write, or set GSN_VALIDATE_CACHES=1)" % type(module).__name__, RuntimeWarning, stacklevel=3)
         st["last"] = (val, vers)
+    now = time.monotonic()
+    if now - st.get("t_last", -1e9) < ASYNC_VALIDATE_INTERVAL:
+        return
+    st["t_last"] = now
     acc = _zeros(1, torch.int64, dev)
     with _abi.device_guard(dev):
         slot = _fp_slot()

@@ -319,6 +319,7 @@ def test_parameter_written_through_data_is_noticed_without_any_flag():
     from gsn_amd import layers
     from oracle import oracle
     assert layers.ASYNC_VALIDATE and not layers.VALIDATE_CACHES
+    interval, layers.ASYNC_VALIDATE_INTERVAL = layers.ASYNC_VALIDATE_INTERVAL, 0.0      # (a fingerprint behind EVERY forward of this test)
     b, x, ef, ei = _zinc(300, seed=43)
     ids = (torch.rand(b.num_edges, 12, generator=torch.Generator().manual_seed(1)) < 0.2).float()
     torch.manual_seed(3)
@@ -351,6 +352,7 @@ def test_parameter_written_through_data_is_noticed_without_any_flag():
         layer(x.cuda(), ei.cuda(), **kw)                           # sees the fingerprint of the call before: warns, drops the caches
         torch.cuda.synchronize()
         y2 = layer(x.cuda(), ei.cuda(), **kw)
+        layers.ASYNC_VALIDATE_INTERVAL = interval
         assert [w for w in rec if issubclass(w.category, RuntimeWarning) and "written through" in str(w.message)]
         assert _elementwise_ok(y2.cpu(), r1), float((y2.cpu() - r1).abs().max() / r1.abs().max())
 
