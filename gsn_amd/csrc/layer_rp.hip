@@ -603,6 +603,19 @@ __global__ __launch_bounds__(64 * RR_NW) __attribute__((amdgpu_waves_per_eu(RR_N
         // four output rows (registers 4 j .. + 4) of one 32 x 32 tile: un-scale, bias, activation, store
         auto put4 = [&](const f32x16 &o, int fbn, float cb, int j) {
             const rr_f2 cb2 = rr_f2{cb, cb};
+#ifdef RR_ABL_STORE4      // (ablation, results in the wrong places: the four values as ONE 16-byte store, every instruction two full 512-byte rows)
+            {
+                unsigned v4[4];
+#pragma unroll
+                for (int r = 4 * j; r < 4 * j + 4; r += 2) {
+                    const rr_f2 t = __builtin_elementwise_fma(rr_f2{o[r], o[r + 1]}, rr_f2{invr[r], invr[r + 1]}, cb2);
+                    v4[r - 4 * j] = (unsigned)max(__float_as_int(t[0]), lo_1); v4[r - 4 * j + 1] = (unsigned)max(__float_as_int(t[1]), lo_1);
+                }
+                typedef unsigned u4s __attribute__((__vector_size__(4 * sizeof(unsigned))));
+                __builtin_amdgcn_raw_buffer_store_b128(u4s{v4[0], v4[1], v4[2], v4[3]}, orow, (lh * 32 * WB + 4 * li) * 4, (2 * (4 * fbn + j)) * (32 * WB * 4), RP_STORE_AUX);
+                return;
+            }
+#endif
 #pragma unroll
             for (int r = 4 * j; r < 4 * j + 4; r += 2) {
                 const rr_f2 t = __builtin_elementwise_fma(rr_f2{o[r], o[r + 1]}, rr_f2{invr[r], invr[r + 1]}, cb2);
