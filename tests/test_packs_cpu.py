@@ -1,0 +1,65 @@
+"""Host logic of the exact fp16 row packs (gsn_amd/packs.py) on CPU tensors -- no kernel runs: who owns which columns of a pack, when a tag is
+current (version counter, claimed columns, shapes), how a layer call's inputs are matched to ONE node pack and ONE edge pack."""
+import torch
+
+from gsn_amd import packs
+
+
+def _tagged(rows, width, pack, col0):
+    t = torch.zeros(rows, width)
+    packs.claim(t, pack, col0)
+    return t
+
+
+def test_tag_lifecycle_version_and_release():
+    npk = torch.zeros(10, packs.NODE_COLS, dtype=torch.float16)
+    x = _tagged(10, 28, npk, 0)
+    assert packs.tag_of(x, 10, packs.NODE_COLS) == (npk, 0)
+    assert packs.tag_of(x, 11, packs.NODE_COLS) is None            # another row count
+    x.add_(1.0)                                                    # an in-place write moves the version counter: the pack no longer describes x
+    assert packs.tag_of(x, 10, packs.NODE_COLS) is None
+    y = _tagged(10, 28, npk, 0)
+    packs.release(y)                                               # a raw-pointer rewrite is announced by its producer
+    assert packs.tag_of(y, 10, packs.NODE_COLS) is None
+
+
+def test_columns_claimed_by_another_tensor_end_the_tag():
+    epk = torch.zeros(7, packs.EDGE_COLS, dtype=torch.float16)
+    ids = _tagged(7, 12, epk, 0)
+    ef = _tagged(7, 4, epk, 12)
+    assert packs.tag_of(ids, 7, packs.EDGE_COLS) == (epk, 0) and packs.tag_of(ef, 7, packs.EDGE_COLS) == (epk, 12)
+    other = _tagged(7, 6, epk, 10)                                 # overlaps both
+    assert packs.tag_of(ids, 7, packs.EDGE_COLS) is None and packs.tag_of(ef, 7, packs.EDGE_COLS) is None
+    assert packs.tag_of(other, 7, packs.EDGE_COLS) == (epk, 10)
+    again = _tagged(7, 12, epk, 0)                                 # the same columns re-claimed by a new tensor: the newest owner wins
+    assert packs.tag_of(again, 7, packs.EDGE_COLS) == (epk, 0) and packs.tag_of(other, 7, packs.EDGE_COLS) is None
+
+
+def test_lookup_matches_one_node_pack_and_one_edge_pack_in_concatenation_order():
+    npk = torch.zeros(5, packs.NODE_COLS, dtype=torch.float16)
+    epk = torch.zeros(9, packs.EDGE_COLS, dtype=torch.float16)
+    x = _tagged(5, 28, npk, 0)
+    ids, ef = _tagged(9, 12, epk, 0), _tagged(9, 4, epk, 12)
+    assert packs.lookup(x, [ids, ef]) == (npk, epk)
+    assert packs.lookup(x, []) == (npk, None)                      # cat(x_i, x_j) alone
+    assert packs.lookup(x, [ef, ids]) is None                      # wrong order: ef would have to start at column 0
+    epk2 = torch.zeros(9, packs.EDGE_COLS, dtype=torch.float16)
+    ef2 = _tagged(9, 4, epk2, 12)
+    assert packs.lookup(x, [ids, ef2]) is None                     # two different edge packs
+    assert packs.lookup(torch.zeros(5, 28), [ids, ef]) is None     # untagged x
+    assert packs.lookup(x, [ids, torch.zeros(9, 4)]) is None       # one untagged per-edge tensor
+    x_off = _tagged(5, 20, npk, 4)
+    assert packs.lookup(x_off, [ids, ef]) is None                  # the node block must start at column 0
+
+
+def test_tag_dies_with_its_tensor():
+    import gc
+    epk = torch.zeros(3, packs.EDGE_COLS, dtype=torch.float16)
+    t = _tagged(3, 8, epk, 0)
+    assert 0 in epk._gsn_owners
+    del t
+    gc.collect()
+    assert epk._gsn_owners[0][0]() is None                         # a dead weak reference never matches a live tensor
+    u = torch.zeros(3, 8)
+    u._gsn_pack16 = (epk, 0, u._version)                           # a forged tag without a claim
+    assert packs.tag_of(u, 3, packs.EDGE_COLS) is None
