@@ -201,8 +201,10 @@ def _table_meta(tables, device):
     entry MADE inside a capture (its device array is only written by replays) is keyed on that capture."""
     from . import _abi
     ptrs = tuple([t.data_ptr() for t in tables] + [int(t.shape[0]) for t in tables])
-    with _abi.device_guard(device):
-        cap = int(_abi.lib().gsn_stream_capture_id(_abi.current_stream()))
+    cap = 0
+    if torch._C._cuda_isCurrentStreamCapturing():
+        with _abi.device_guard(device):
+            cap = int(_abi.lib().gsn_stream_capture_id(_abi.current_stream()))
     hit = _META_CACHE.get((ptrs, str(device), 0))
     if hit is None and cap:
         hit = _META_CACHE.get((ptrs, str(device), cap))

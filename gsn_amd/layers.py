@@ -91,24 +91,33 @@ ZERO_ARENA = os.environ.get("GSN_ZERO_ARENA", "1") != "0"      # (0: every reque
 _ZARENA_TIERS = ((256 * 1024, 64 * 1024), (8 * 1024 * 1024, 2 * 1024 * 1024))     # (arena bytes, largest request served from it)
 
 
+_ITEMSIZE = {torch.float64: 8, torch.float32: 4, torch.int64: 8, torch.int32: 4, torch.float16: 2, torch.uint8: 1}
+
+
 def _zeros(n, dtype, device):
     """1-D zero tensor of ``n`` elements of ``dtype`` on ``device`` (cuda) from the arenas: small requests (statistics, status words) from a
     256 KiB arena, the weight-gradient accumulators of a dense backward (up to 2 MiB) from an 8 MiB one -- a d = 300 training step asks for
     ~20 of those, one fill of 8 MiB costs what one fill of 700 KiB does."""
-    item = torch.empty(0, dtype=dtype).element_size()
+    item = _ITEMSIZE[dtype]
     nbytes = (n * item + 255) // 256 * 256
-    tier = 0 if nbytes <= _ZARENA_TIERS[0][1] else (1 if nbytes <= _ZARENA_TIERS[1][1] else -1)
+    tier = 0 if nbytes <= 65536 else (1 if nbytes <= 2097152 else -1)
     if tier < 0 or device.type != "cuda" or not ZERO_ARENA:
         return torch.zeros(n, dtype=dtype, device=device)
-    size = _ZARENA_TIERS[tier][0]
-    with _abi.device_guard(device):
-        stream = _abi.current_stream()
-        key = (device.index, stream, int(_abi.lib().gsn_stream_capture_id(stream)))
-    hit = _ZARENA.get((device.index, tier))
-    if hit is None or hit[0] != key or hit[2] + nbytes > size:
-        with torch.cuda.device(device):
-            hit = [key, torch.zeros(size, dtype=torch.uint8, device=device), 0]
-        _ZARENA[(device.index, tier)] = hit
+    idx = device.index
+    if idx is None:
+        idx = torch._C._cuda_getDevice()
+    stream = torch._C._cuda_getCurrentRawStream(idx)
+    # (the capture id is asked of the library only while PyTorch says a capture is under way: this runs ~50 times per training step)
+    if idx == torch._C._cuda_getDevice():
+        cap = int(_abi.lib().gsn_stream_capture_id(stream)) if torch._C._cuda_isCurrentStreamCapturing() else 0
+    else:       # (not the current device: PyTorch's query is about the current one)
+        with _abi.device_guard(device):
+            cap = int(_abi.lib().gsn_stream_capture_id(stream))
+    hit = _ZARENA.get((idx, tier))
+    if hit is None or hit[0] != stream or hit[3] != cap or hit[2] + nbytes > _ZARENA_TIERS[tier][0]:
+        with _abi.device_guard(device):
+            hit = [stream, torch.zeros(_ZARENA_TIERS[tier][0], dtype=torch.uint8, device=device), 0, cap]
+        _ZARENA[(idx, tier)] = hit
     off = hit[2]
     hit[2] = off + nbytes
     return hit[1][off:off + n * item].view(dtype)
