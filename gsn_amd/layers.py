@@ -843,33 +843,37 @@ def _fp_slot():
 
 
 def _async_validate(module):
+    st = module.__dict__.get("_gsn_fp_state")
+    now = time.monotonic()
+    if st is not None:
+        pend = st["pending"]
+        # (the common case of a tight loop: nothing landed, nothing due -- two dictionary reads and a clock)
+        if now - st["t_last"] < ASYNC_VALIDATE_INTERVAL and (not pend or not pend[0][0].query()):
+            return
+        while pend and (len(pend) > 32 or pend[0][0].query()):
+            ev, slot, vers = pend.pop(0)
+            ev.synchronize()
+            val = int(slot[0])
+            last = st["last"]
+            if last is not None and last[0] != val and last[1] == vers:
+                import warnings
+                invalidate_caches(module)
+                warnings.warn("gsn_amd: a parameter or buffer of %s was written through `.data` (its version counter did not move): the forward(s) since "
+                              "that write used weights prepared before it; the caches are dropped now (call gsn_amd.layers.invalidate_caches "
+                              "after such a write, or set GSN_VALIDATE_CACHES=1)" % type(module).__name__, RuntimeWarning, stacklevel=3)
+            st["last"] = (val, vers)
+        if now - st["t_last"] < ASYNC_VALIDATE_INTERVAL:
+            return
     tensors = [t for t in list(module.parameters()) + list(module.buffers()) if t.is_floating_point() and t.numel() and t.is_cuda and t.element_size() == 4]
     if not tensors:
         return
     dev = tensors[0].device
     ptrs = tuple(t.data_ptr() for t in tensors)
     versions = tuple(t._version for t in tensors)
-    st = module.__dict__.get("_gsn_fp_state")
     if st is None or st["ptrs"] != ptrs:
         meta = torch.tensor(list(ptrs) + [t.numel() for t in tensors], dtype=torch.int64).to(dev)       # (once per layer: parameters keep their addresses)
-        st = {"ptrs": ptrs, "meta": meta, "max_words": max(t.numel() for t in tensors), "last": None, "pending": []}
+        st = {"ptrs": ptrs, "meta": meta, "max_words": max(t.numel() for t in tensors), "last": None, "pending": [], "t_last": -1e9}
         module.__dict__["_gsn_fp_state"] = st
-    pend = st["pending"]
-    while pend and (len(pend) > 32 or pend[0][0].query()):
-        ev, slot, vers = pend.pop(0)
-        ev.synchronize()
-        val = int(slot[0])
-        last = st["last"]
-        if last is not None and last[0] != val and last[1] == vers:
-            import warnings
-            invalidate_caches(module)
-            warnings.warn("gsn_amd: a parameter or buffer of %s was written through `.data` (its version counter did not move): the forward(s) since "
-                          "that write used weights prepared before it; the caches are dropped now (call gsn_amd.layers.invalidate_caches "
-                          "after such a write, or set GSN_VALIDATE_CACHES=1)" % type(module).__name__, RuntimeWarning, stacklevel=3)
-        st["last"] = (val, vers)
-    now = time.monotonic()
-    if now - st.get("t_last", -1e9) < ASYNC_VALIDATE_INTERVAL:
-        return
     st["t_last"] = now
     acc = _zeros(1, torch.int64, dev)
     with _abi.device_guard(dev):
@@ -878,7 +882,7 @@ def _async_validate(module):
                                                   _abi.current_stream()), "gsn_fingerprint_hip")
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))
-    pend.append((ev, slot, versions))
+    st["pending"].append((ev, slot, versions))
 
 
 def invalidate_caches(module=None):
