@@ -267,9 +267,12 @@ def set_graph_partition(edge_index, node_ptr, edge_ptr, max_nodes, max_edges, ch
     key = id(edge_index)
 
     def _gone(_ref, key=key):
-        hit = _PARTITION.get(key)
+        cache = _PARTITION
+        if cache is None:                   # (interpreter shutdown: module globals are already cleared)
+            return
+        hit = cache.get(key)
         if hit is not None and hit[0] is _ref:
-            del _PARTITION[key]
+            del cache[key]
     _PARTITION[key] = (weakref.ref(edge_index, _gone), edge_index._version,
                        (node_ptr.to(device=edge_index.device, dtype=torch.int64).contiguous(),
                         edge_ptr.to(device=edge_index.device, dtype=torch.int64).contiguous(), int(max_nodes), int(max_edges), bool(check)))
@@ -294,9 +297,12 @@ def set_batch_partition(batch, node_ptr):
     key = id(batch)
 
     def _gone(_ref, key=key):
-        hit = _BATCH_PTR.get(key)
+        cache = _BATCH_PTR
+        if cache is None:                   # (interpreter shutdown: module globals are already cleared)
+            return
+        hit = cache.get(key)
         if hit is not None and hit[0] is _ref:
-            del _BATCH_PTR[key]
+            del cache[key]
     _BATCH_PTR[key] = (weakref.ref(batch, _gone), batch._version, node_ptr.to(device=batch.device, dtype=torch.int32).contiguous())
 
 
@@ -311,9 +317,12 @@ def _cache_put(key, owner, value):
     """_CSR_CACHE entry that disappears with the tensor it belongs to (weak-reference callback), so batches that are
     dropped do not leave E-sized index tensors behind."""
     def _gone(_ref, key=key):
-        hit = _CSR_CACHE.get(key)
+        cache = _CSR_CACHE
+        if cache is None:                   # (interpreter shutdown: module globals are already cleared)
+            return
+        hit = cache.get(key)
         if hit is not None and hit[0] is _ref:
-            del _CSR_CACHE[key]
+            del cache[key]
     ref = weakref.ref(owner, _gone)
     _CSR_CACHE[key] = (ref, owner._version, value)
 
