@@ -140,7 +140,7 @@ def pack_node_codes(cd, pack=None):
     elif tuple(pack.shape) != (cd.codes.shape[0], NODE_COLS) or pack.dtype != torch.float16:
         raise ValueError("pack_node_codes: pack must be fp16 [%d, %d]" % (cd.codes.shape[0], NODE_COLS))
     _pack_codes(cd, pack, 0, NODE_COLS - 1)
-    cd._pack16 = (pack, 0)
+    cd._pack16 = (pack, 0, cd.codes._version)
     return pack
 
 
@@ -149,7 +149,7 @@ def pack_edge_codes(cd, pack, col0):
     if col0 + sum(cd.n_classes) > EDGE_COLS or pack.shape != (cd.codes.shape[0], EDGE_COLS):
         raise ValueError("pack_edge_codes: columns %d .. %d of a %s pack" % (col0, col0 + sum(cd.n_classes), tuple(pack.shape)))
     _pack_codes(cd, pack, col0, -1)
-    cd._pack16 = (pack, int(col0))
+    cd._pack16 = (pack, int(col0), cd.codes._version)
     return pack
 
 
@@ -161,13 +161,13 @@ def from_codes(x_codes, per_edge):
     per_edge = [c for c in per_edge if c is not None]
     if sum(x_codes.n_classes) > NODE_COLS - 4 or sum(_width(c) for c in per_edge) > EDGE_COLS:
         return None
-    npk = x_codes._pack16[0] if x_codes._pack16 is not None else pack_node_codes(x_codes)
+    npk = x_codes._pack16[0] if _codes_tag(x_codes) is not None else pack_node_codes(x_codes)
     epk = None
     if per_edge:
         rows = per_edge[0].shape[0]
         col, todo = 0, []
         for c in per_edge:      # the pack the already-encoded inputs live in (all the same one, columns in order)
-            tg = tag_of(c, rows, EDGE_COLS) if isinstance(c, torch.Tensor) else c._pack16
+            tg = tag_of(c, rows, EDGE_COLS) if isinstance(c, torch.Tensor) else _codes_tag(c)
             if tg is None:
                 if isinstance(c, torch.Tensor):
                     return None
@@ -182,6 +182,12 @@ def from_codes(x_codes, per_edge):
         for c, col in todo:
             pack_edge_codes(c, epk, col)
     return npk, epk
+
+
+def _codes_tag(cd):
+    """(pack, first column, ..) of an encoded Codes object while its code tensor is unchanged (an in-place write moves the version counter)"""
+    tg = cd._pack16
+    return tg if tg is not None and tg[2] == cd.codes._version else None
 
 
 def _width(c):

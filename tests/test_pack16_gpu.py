@@ -339,3 +339,34 @@ def test_one_hot_pack_out_of_range_and_odd_boundaries():
         dense = layers.one_hot_identifiers(codes, [5, 3, 4], clamp=clamp)
         assert torch.equal(pack[:, 3:15].float(), dense)
         assert bool((pack[:, :3] == 7).all()) and bool((pack[:, 15:] == 7).all())
+
+
+def test_codes_rewritten_in_place_are_encoded_again():
+    """A Codes object keeps the pack made from it; writing its code tensor in place (a reused input buffer) moves the version counter and the next
+    layer call encodes the new codes instead of reading the pack of the old ones."""
+    from gsn_amd import layers, packs
+    from oracle import oracle
+    b, x, ef, ei = _zinc(50, seed=7)
+    dev = torch.device("cuda")
+    atom = torch.from_numpy(b.atom_type).to(dev)
+    xc = layers.Codes(atom, [28])
+    efc = layers.Codes(torch.from_numpy(b.bond_type).to(dev), [4])
+    ids = (torch.rand(b.num_edges, 12, generator=torch.Generator().manual_seed(1)) < 0.2).float()
+    torch.manual_seed(6)
+    layer = layers.GSN_edge_sparse(**CTOR)
+    _randomise_bn(layer, 2)
+    layer.eval()
+    sd = {k: v.clone() for k, v in layer.state_dict().items()}
+    layer.cuda()
+    idg = ids.to(dev)
+    packs.edge_pack([idg])
+    kw = dict(identifiers=idg, degrees=torch.zeros(b.num_nodes, device=dev), edge_features=efc)
+    with torch.no_grad():
+        layer(xc, ei.to(dev), **kw)
+        first = xc._pack16[0]
+        xc.codes.copy_((xc.codes + 5) % 28)                    # the same buffer, other atoms
+        y = layer(xc, ei.to(dev), **kw)
+    assert xc._pack16[0] is not first
+    x2 = torch.nn.functional.one_hot(xc.codes[:, 0].cpu(), 28).float()
+    ref = oracle.layer_forward("GSN_edge_sparse", CTOR, sd, x2, ei, identifiers=ids, degrees=None, edge_features=ef, training=False)
+    assert _elementwise_ok(y.cpu(), ref), float((y.cpu() - ref).abs().max() / ref.abs().max())
