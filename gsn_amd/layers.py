@@ -165,9 +165,10 @@ class Codes:
         return 2
 
     def dense(self):
-        if self._dense is None:
-            self._dense = one_hot_identifiers(self.codes, self.n_classes, clamp=self.clamp)
-        return self._dense
+        # (kept with the code tensor's version counter: a reused input buffer rewritten in place is encoded again)
+        if self._dense is None or self._dense[1] != self.codes._version:
+            self._dense = (one_hot_identifiers(self.codes, self.n_classes, clamp=self.clamp), self.codes._version)
+        return self._dense[0]
 
 
 def _dense(v):
