@@ -610,7 +610,8 @@ extern "C" int gsn_embed_fwd_hip(int64_t m_rows, int n_cols, int d, int concat, 
     if (m_rows <= 0) return GSN_OK;
     // (few rows -- the reference's batch sizes: 800 .. 6 000 rows -- gather straight from the L2-resident tables: the LDS kernel first copies
     //  every table slice into every workgroup, ~40 us per call whatever the row count)
-    if (m_rows > 8192 && embed_lds_fits(n_cols, table_rows)) {
+    static const int64_t lds_min_rows = [] { const char *e = getenv("GSN_EMBED_LDS_MIN_ROWS"); return e ? atoll(e) : (int64_t)8192; }();
+    if (m_rows > lds_min_rows && embed_lds_fits(n_cols, table_rows)) {
         EmbArgs a{};
         a.m_rows = m_rows; a.n_cols = n_cols; a.d = d; a.concat = concat; a.codes = codes; a.meta = meta; a.out = out; a.status = status;
         return launch_embed_lds<false>(a, table_rows, reinterpret_cast<hipStream_t>(stream));
