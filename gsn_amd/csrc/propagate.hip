@@ -991,8 +991,19 @@ extern "C" int gsn_propagate_self_fwd_hip(int kind, int64_t n_nodes, int64_t n_e
         const int64_t q = d_out / 4;  // float4 per row
         if (q <= 8) return launch_fwd<4, 8, 1>(p, st);
         if (q <= 16) return launch_fwd<4, 16, 1>(p, st);
-        if (q <= 32) return launch_fwd<4, 32, 1>(p, st);
+        // lanes per target row: the widths up to 128 floats take 16 (four targets per wave: four rows' loads in flight per wave instead of two
+        // -- 0.656 -> 0.463 ms for the 112-wide concatenation, 0.422 -> 0.394 at d = 128, r04); GSN_PROP_LPR=8/16/32/64 forces a mapping
+        static const int forced = [] { const char *e = getenv("GSN_PROP_LPR"); return e ? atoi(e) : 0; }();
+        if (forced) {
+            const int m = (int)((q + forced - 1) / forced);
+            if (forced == 8) { if (m <= 1) return launch_fwd<4, 8, 1>(p, st); if (m <= 2) return launch_fwd<4, 8, 2>(p, st); if (m <= 4) return launch_fwd<4, 8, 4>(p, st); }
+            if (forced == 16) { if (m <= 1) return launch_fwd<4, 16, 1>(p, st); if (m <= 2) return launch_fwd<4, 16, 2>(p, st); if (m <= 4) return launch_fwd<4, 16, 4>(p, st);
+                                if (m <= 5) return launch_fwd<4, 16, 5>(p, st); }
+            if (forced == 32) { if (m <= 1) return launch_fwd<4, 32, 1>(p, st); if (m <= 2) return launch_fwd<4, 32, 2>(p, st); if (m <= 3) return launch_fwd<4, 32, 3>(p, st); }
+        }
+        if (q <= 32) return launch_fwd<4, 16, 2>(p, st);
         if (q <= 64) return launch_fwd<4, 64, 1>(p, st);
+        if (q <= 96) return launch_fwd<4, 32, 3>(p, st);       // (d = 300: 75 float4 per row -- 2.57 -> 2.51 ms against 64 lanes x 2)
         if (q <= 128) return launch_fwd<4, 64, 2>(p, st);
         return launch_fwd<4, 64, 4>(p, st);
     }
