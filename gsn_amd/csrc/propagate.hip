@@ -509,14 +509,25 @@ __global__ __launch_bounds__(256) void propagate_bwd_node_edge4_kernel(PropBwdAr
         const int64_t s = s0 + sub;
         if (s >= p.n_nodes) continue;
         const int32_t lo = p.seg_ptr_src[s], hi = p.seg_ptr_src[s + 1];
-        for (int c4 = li; c4 < q; c4 += 16) {
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        // five column chunks of a row per lane and pass (d <= 320 in one): an edge's index is read once and its row's loads are in flight together
+        for (int c0 = li; c0 < q; c0 += 80) {
+            float4 acc[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
             for (int32_t qq = lo; qq < hi; ++qq) {
-                const int64_t e = p.perm_src[qq];
-                acc = vadd(acc, reinterpret_cast<const float4 *>(p.g_edge + e * p.d_out)[c4]);
+                const float4 *row = reinterpret_cast<const float4 *>(p.g_edge + (int64_t)p.perm_src[qq] * p.d_out);
+#pragma unroll
+                for (int k = 0; k < 5; ++k)
+                    if (c0 + 16 * k < q) acc[k] = vadd(acc[k], row[c0 + 16 * k]);
             }
-            if (p.g_a) reinterpret_cast<float4 *>(p.g_a + s * p.d_out)[c4] = acc;
-            if (p.b_per_node && p.g_b) reinterpret_cast<float4 *>(p.g_b + s * p.d_out)[c4] = acc;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const int c4 = c0 + 16 * k;
+                if (c4 < q) {
+                    if (p.g_a) reinterpret_cast<float4 *>(p.g_a + s * p.d_out)[c4] = acc[k];
+                    if (p.b_per_node && p.g_b) reinterpret_cast<float4 *>(p.g_b + s * p.d_out)[c4] = acc[k];
+                }
+            }
         }
     }
 }
