@@ -1012,7 +1012,9 @@ extern "C" int gsn_propagate_self_fwd_hip(int kind, int64_t n_nodes, int64_t n_e
                                 if (m <= 5) return launch_fwd<4, 16, 5>(p, st); }
             if (forced == 32) { if (m <= 1) return launch_fwd<4, 32, 1>(p, st); if (m <= 2) return launch_fwd<4, 32, 2>(p, st); if (m <= 3) return launch_fwd<4, 32, 3>(p, st); }
         }
-        if (q <= 32) return launch_fwd<4, 16, 2>(p, st);
+        // (short segments -- ~2 edges per target, the message aggregation -- want many targets per wave; long ones -- a readout's ~23 rows per
+        //  graph -- walk their rows serially per lane group and want the wider group: 42.7 vs 59.9 us per 16 384-graph readout)
+        if (q <= 32) return (q > 16 && n_edges >= 8 * n_nodes) ? launch_fwd<4, 32, 1>(p, st) : launch_fwd<4, 16, 2>(p, st);
         if (q <= 64) return launch_fwd<4, 64, 1>(p, st);
         if (q <= 96) return launch_fwd<4, 32, 3>(p, st);       // (d = 300: 75 float4 per row -- 2.57 -> 2.51 ms against 64 lanes x 2)
         if (q <= 128) return launch_fwd<4, 64, 2>(p, st);
