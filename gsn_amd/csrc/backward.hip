@@ -52,7 +52,25 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(int64_t m_rows, 
     const float zs = (cok && zscale) ? zscale[c] : 1.f, zb = (cok && zshift) ? zshift[c] : 0.f;
     double s1 = 0.0, s2 = 0.0;
     if (cok) {
-        for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < m_rows; r += (int64_t)gridDim.x * 4) {
+        const int64_t step = (int64_t)gridDim.x * 4;
+        int64_t r = (int64_t)blockIdx.x * 4 + wave;
+        // four rows per pass: their loads are in flight together (the pass is a stream over M x C; one row per iteration left a wave with
+        // two loads in flight), summed in the same order
+        for (; r + 3 * step < m_rows; r += 4 * step) {
+            float g4[4], h4[4], y4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t i = (r + u * step) * n_cols + c;
+                g4[u] = gy[i]; h4[u] = h[i]; y4[u] = y ? y[i] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float gz = g4[u] * (y ? act_grad_from_y(y4[u], act) : act_grad_from_z((h4[u] - mu) * zs + zb, act));
+                s1 += (double)gz;
+                s2 += (double)gz * (double)((h4[u] - mu) * is);
+            }
+        }
+        for (; r < m_rows; r += step) {
             const int64_t i = r * n_cols + c;
             const float gz = gy[i] * (y ? act_grad_from_y(y[i], act) : act_grad_from_z((h[i] - mu) * zs + zb, act));
             s1 += (double)gz;
@@ -87,15 +105,30 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(int64_t m_rows, i
     const float m2 = (cok && sums) ? (float)(sums[n_cols + c] / (double)m_rows) : 0.f;
     double sb = 0.0;
     if (cok) {
-        for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < m_rows; r += (int64_t)gridDim.x * 4) {
-            const int64_t i = r * n_cols + c;
-            const float hv = y ? 0.f : h[i];
-            const float gz = gy[i] * (y ? act_grad_from_y(y[i], act) : act_grad_from_z((hv - mu) * cf + zb, act));
+        const int64_t step = (int64_t)gridDim.x * 4;
+        int64_t r = (int64_t)blockIdx.x * 4 + wave;
+        const bool need_h = !y || sums;
+        auto one = [&](int64_t i, float gyv, float yv, float hv) {
+            const float gz = gyv * (y ? act_grad_from_y(yv, act) : act_grad_from_z((hv - mu) * cf + zb, act));
             float g = gz;
-            if (sums) g = gz - m1 - ((y ? h[i] : hv) - mu) * is * m2;
+            if (sums) g = gz - m1 - (hv - mu) * is * m2;
             g *= cf;
             gh[i] = g;
             sb += (double)g;
+        };
+        for (; r + 3 * step < m_rows; r += 4 * step) {      // (four rows' loads in flight, as in the reduce pass)
+            float g4[4], h4[4], y4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t i = (r + u * step) * n_cols + c;
+                g4[u] = gy[i]; y4[u] = y ? y[i] : 0.f; h4[u] = need_h ? h[i] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) one((r + u * step) * n_cols + c, g4[u], y4[u], h4[u]);
+        }
+        for (; r < m_rows; r += step) {
+            const int64_t i = r * n_cols + c;
+            one(i, gy[i], y ? y[i] : 0.f, need_h ? h[i] : 0.f);
         }
     }
     if (gbias) {
