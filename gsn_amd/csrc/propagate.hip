@@ -428,6 +428,29 @@ __global__ __launch_bounds__(256) void propagate_bwd_edge_kernel(PropBwdArgs p) 
     }
 }
 
+// concatenation, every width a multiple of four floats, no zero columns (the readout's and the virtual node's adjoints: a pure row
+// broadcast g_b[e] = g_out[tgt[e]]): a row group of 16 lanes per edge, float4 columns, the target read once per group -- the element-per-thread
+// kernel above pays a 64-bit division and an 8-byte index load per float (70 -> ~25 us at 105 k x 300)
+__global__ __launch_bounds__(256) void propagate_bwd_edge_cat4_kernel(PropBwdArgs p) {
+    const int lane = threadIdx.x & 63, sub = lane >> 4, li = lane & 15;
+    const int qa = p.da >> 2, qb = p.db >> 2, qc = p.dc >> 2;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t e0 = wave * 4; e0 < p.n_edges; e0 += n_waves * 4) {
+        const int64_t e = e0 + sub;
+        if (e >= p.n_edges) continue;
+        const float4 *go = reinterpret_cast<const float4 *>(p.g_out + p.tgt[e] * p.d_out);
+        if (!p.b_per_node && p.g_b) {
+            float4 *gb = reinterpret_cast<float4 *>(p.g_b + e * p.db);
+            for (int k = li; k < qb; k += 16) gb[k] = go[qa + k];
+        }
+        if (p.g_c) {
+            float4 *gc = reinterpret_cast<float4 *>(p.g_c + e * p.dc);
+            for (int k = li; k < qc; k += 16) gc[k] = go[qa + qb + k];
+        }
+    }
+}
+
 // the same for relu-sum messages whose width is a multiple of four floats (the d = 300 ogb layers): a row group of 16 lanes per edge,
 // float4 columns, the edge's two indices read once per group instead of once per element (r03: 500 -> ~330 us at E = 214 k, d = 300)
 __global__ __launch_bounds__(256) void propagate_bwd_edge_relu4_kernel(PropBwdArgs p) {
@@ -1064,10 +1087,13 @@ extern "C" int gsn_propagate_pad_bwd_hip(int kind, int64_t n_nodes, int64_t n_ed
     if (need_edge && n_edges > 0) {
         const bool vec4 = kind == GSN_MSG_RELU_SUM && d_out % 4 == 0 &&
                           (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)g_out | (uintptr_t)g_b | (uintptr_t)g_c) % 16 == 0);
-        if (vec4) {
+        const bool cat4 = kind == GSN_MSG_CAT && !pad_b && !pad_c && ((da | db | dc) & 3) == 0 &&
+                          (((uintptr_t)g_out | (uintptr_t)g_b | (uintptr_t)g_c) % 16 == 0);
+        if (vec4 || cat4) {
             int64_t blocks = (n_edges + 15) / 16;
             if (blocks > 16384) blocks = 16384;
-            hipLaunchKernelGGL(propagate_bwd_edge_relu4_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
+            if (vec4) hipLaunchKernelGGL(propagate_bwd_edge_relu4_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
+            else hipLaunchKernelGGL(propagate_bwd_edge_cat4_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
         } else {
             int64_t blocks = (n_edges * d_out + 255) / 256;
             if (blocks > 16384) blocks = 16384;
