@@ -327,6 +327,18 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float pa[8], pb[8];
+    // GATHER: the row indices of a chunk are loaded one chunk ahead of its rows (nidx: those of the chunk the next fetch reads), so that a fetch's
+    // row loads do not wait for an index load in front of them -- two serial latencies per chunk otherwise, with one chunk in flight
+    int nidx[8];                                                   // (row indices fit 32 bits: the blocks' rows are counted in int32 everywhere)
+    auto idx_load = [&](int64_t row0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int64_t r = row0 + 8 * sh + i;
+            const int64_t rc = r < r_end ? r : r_begin;
+            nidx[i] = xi ? (int)xi[rc] : (xi32 ? xi32[rc] : (int)rc);
+        }
+    };
+    if (GATHER) idx_load(r_begin);
     auto fetch = [&](int64_t row0) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -334,9 +346,9 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradArgs a) {
             const int64_t rc = r < r_end ? r : r_begin;            // clamped: masked to zero when stored
             pa[i] = ga[rc * a.n_out];
             // (a gathered block: the row index is the same for the 128 threads of a row half -- one broadcast load)
-            const int64_t rx = !GATHER ? rc : (xi ? xi[rc] : (xi32 ? (int64_t)xi32[rc] : rc));
-            pb[i] = xb[rx * xw];
+            pb[i] = xb[(GATHER ? (int64_t)nidx[i] : rc) * xw];
         }
+        if (GATHER) idx_load(row0 + 16);                           // (past the slab's end: clamped to r_begin, never used)
     };
     auto store_one = [&](wg_u32x4 (*dst)[WG_T][2], const float (&v)[8], bool col_ok, int64_t row0) {
         unsigned h[8], m[8], l[8];
