@@ -229,6 +229,7 @@ struct PropArgs {
     const int32_t *sorted_src;   // src[perm[q]] per segment position, or null
     const float *a, *b, *c;
     int da, db, dc, d_out;
+    int64_t ldb;                 // row stride of b in floats (= db unless b is a column slice of wider rows: gsn_segment_sum_rows_hip)
     int b_per_node;
     float *out;
     // r03: the layer's own term and the central encoders' column padding inside the same pass (GSN_sparse.py:157-163,
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(256) void propagate_fwd_kernel(PropArgs p) {
             if (o < 0) m = *reinterpret_cast<const V *>(p.a + s * p.da + col);
             else if (PADS && o < p.pad_b) vzero(m);
             else if ((o -= (PADS ? p.pad_b : 0)) < p.db)
-                m = p.b_per_node ? *reinterpret_cast<const V *>(p.b + s * p.db + o) : vload_once(reinterpret_cast<const V *>(p.b + e * p.db + o));
+                m = p.b_per_node ? *reinterpret_cast<const V *>(p.b + s * p.ldb + o) : vload_once(reinterpret_cast<const V *>(p.b + e * p.ldb + o));
             else if (PADS && (o - p.db) < p.pad_c) vzero(m);
             else m = vload_once(reinterpret_cast<const V *>(p.c + e * p.dc + (o - p.db - (PADS ? p.pad_c : 0))));
         } else {
@@ -666,13 +667,13 @@ __global__ __launch_bounds__(256) void segment_sum_wg_kernel(PropArgs p) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) e[u] = p.perm ? (int64_t)p.perm[q + 4 * u] : (int64_t)(q + 4 * u);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) m[u] = *reinterpret_cast<const float4 *>(p.b + e[u] * p.db + 4 * col);
+                for (int u = 0; u < 4; ++u) m[u] = *reinterpret_cast<const float4 *>(p.b + e[u] * p.ldb + 4 * col);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) acc = vadd(acc, m[u]);
             }
             for (; q < hi; q += 4) {
                 const int64_t e = p.perm ? (int64_t)p.perm[q] : (int64_t)q;
-                acc = vadd(acc, *reinterpret_cast<const float4 *>(p.b + e * p.db + 4 * col));
+                acc = vadd(acc, *reinterpret_cast<const float4 *>(p.b + e * p.ldb + 4 * col));
             }
         }
         if (wave) red[wave - 1][lane] = acc;
@@ -961,10 +962,32 @@ extern "C" int gsn_propagate_fwd_hip(int kind, int64_t n_nodes, int64_t n_edges,
                                       nullptr, nullptr, out, stream);
 }
 
+static int propagate_fwd_impl(int kind, int64_t n_nodes, int64_t n_edges, const int64_t *src, const int32_t *seg_ptr,
+                              const int32_t *perm, const int32_t *sorted_src, const float *a, int64_t da, const float *b,
+                              int64_t db, int64_t ldb, int b_per_node, const float *c, int64_t dc, int64_t pad_b, int64_t pad_c,
+                              int n_self, const gsn_self_block *self_blocks, const float *eps, float *out, void *stream);
+
 extern "C" int gsn_propagate_self_fwd_hip(int kind, int64_t n_nodes, int64_t n_edges, const int64_t *src, const int32_t *seg_ptr,
                                           const int32_t *perm, const int32_t *sorted_src, const float *a, int64_t da, const float *b,
                                           int64_t db, int b_per_node, const float *c, int64_t dc, int64_t pad_b, int64_t pad_c,
                                           int n_self, const gsn_self_block *self_blocks, const float *eps, float *out, void *stream) {
+    return propagate_fwd_impl(kind, n_nodes, n_edges, src, seg_ptr, perm, sorted_src, a, da, b, db, db, b_per_node, c, dc, pad_b, pad_c, n_self,
+                              self_blocks, eps, out, stream);
+}
+
+// out[t] = sum over the rows of t's segment of b[row][0 .. width), b a COLUMN SLICE of wider rows (row stride ld floats): the per-vertex sums of
+// a gathered block's input gradient, taken where the input-gradient product left it (no contiguous copy of the slice)
+extern "C" int gsn_segment_sum_rows_hip(int64_t n_nodes, int64_t n_edges, const int64_t *src, const int32_t *seg_ptr, const int32_t *perm,
+                                        const int32_t *sorted_src, const float *b, int64_t width, int64_t ld, float *out, void *stream) {
+    if (width < 1 || ld < width) return set_error(GSN_E_INVALID, "gsn_segment_sum_rows_hip: width %lld, row stride %lld", (long long)width, (long long)ld);
+    return propagate_fwd_impl(GSN_MSG_CAT, n_nodes, n_edges, src, seg_ptr, perm, sorted_src, nullptr, 0, b, width, ld, 0, nullptr, 0, 0, 0, 0, nullptr,
+                              nullptr, out, stream);
+}
+
+static int propagate_fwd_impl(int kind, int64_t n_nodes, int64_t n_edges, const int64_t *src, const int32_t *seg_ptr,
+                              const int32_t *perm, const int32_t *sorted_src, const float *a, int64_t da, const float *b,
+                              int64_t db, int64_t ldb, int b_per_node, const float *c, int64_t dc, int64_t pad_b, int64_t pad_c,
+                              int n_self, const gsn_self_block *self_blocks, const float *eps, float *out, void *stream) {
     if (kind != GSN_MSG_CAT && kind != GSN_MSG_RELU_SUM) return set_error(GSN_E_INVALID, "gsn_propagate_fwd_hip: unknown kind %d", kind);
     if (pad_b < 0 || pad_c < 0 || n_self < 0 || n_self > 3 || (n_self > 0 && !self_blocks))
         return set_error(GSN_E_INVALID, "gsn_propagate_self_fwd_hip: bad pads / self blocks");
@@ -1012,10 +1035,10 @@ extern "C" int gsn_propagate_self_fwd_hip(int kind, int64_t n_nodes, int64_t n_e
     p.kind = kind; p.n_nodes = n_nodes; p.n_edges = n_edges; p.src = src; p.seg_ptr = seg_ptr; p.perm = perm;
     p.sorted_src = sorted_src;
     p.a = da ? a : nullptr; p.b = db ? b : nullptr; p.c = dc ? c : nullptr;
-    p.da = (int)da; p.db = (int)db; p.dc = (int)dc; p.d_out = (int)d_out;
+    p.da = (int)da; p.db = (int)db; p.dc = (int)dc; p.d_out = (int)d_out; p.ldb = ldb;
     p.b_per_node = b_per_node; p.out = out;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const bool aligned = ((da | db | dc | pad_b | pad_c | self_or) % 4 == 0) && pad_b == 0 && pad_c == 0 &&
+    const bool aligned = ((da | db | dc | ldb | pad_b | pad_c | self_or) % 4 == 0) && pad_b == 0 && pad_c == 0 &&
                          (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)out | self_align) % 16 == 0);
     if (aligned && kind == GSN_MSG_CAT && !da && !dc && db && !b_per_node && !n_self && n_nodes <= 512 && n_edges >= 8 * n_nodes) {
         hipLaunchKernelGGL(segment_sum_wg_kernel, dim3((unsigned)n_nodes), dim3(256), 0, st, p);

@@ -1392,14 +1392,32 @@ class _DenseStagesFn(torch.autograd.Function):
                             if mode is None:
                                 grads[bi] = gx[:, o:o + wd]
                             else:       # rows gathered through edge_index[mode]: the per-edge gradients summed per vertex (the propagate kernel)
-                                with torch.no_grad():
-                                    grads[bi] = propagate(0, gather[0], mode, gather[1], b=gx[:, o:o + wd].contiguous())
+                                grads[bi] = _segment_sum_cols(gather[0], mode, gather[1], gx, o, wd)
                         o += wd
         if casts:
             c32 = z64.to(torch.float32)
             for gi, o0, n in casts:
                 grads[gi] = c32[o0:o0 + n]
         return (None,) + tuple(grads)
+
+
+def _segment_sum_cols(edge_index, mode, n_nodes, rows, col0, width):
+    """sum over the columns e of edge_index with edge_index[mode, e] = v of rows[e, col0 : col0 + width] -> [n_nodes, width]: the input gradient
+    of a block gathered through edge_index[mode], read where the input-gradient product left it (gsn_segment_sum_rows_hip: the slice is not
+    copied).  Slices that are not 16-byte aligned take the copy + propagate route."""
+    E = rows.shape[0]
+    if E == 0 or rows.dtype is not torch.float32 or rows.stride(1) != 1 or (col0 | width | rows.stride(0)) % 4 or rows.data_ptr() % 16:
+        with torch.no_grad():
+            return propagate(0, edge_index, mode, n_nodes, b=rows[:, col0:col0 + width].contiguous())
+    csr = _csr_for(edge_index, mode, n_nodes)
+    src = edge_index[1 - mode].contiguous()
+    out = torch.empty((n_nodes, width), dtype=torch.float32, device=rows.device)
+    with _abi.device_guard(rows.device), _timed("propagate_fwd", 12.0 * E + 4.0 * n_nodes + 4.0 * (E + n_nodes) * width):
+        rc = _abi.lib().gsn_segment_sum_rows_hip(n_nodes, E, src.data_ptr(), csr.seg_ptr.data_ptr(), csr.perm.data_ptr(),
+                                                 csr.src.data_ptr() if csr.src is not None else None, rows.data_ptr() + 4 * col0, width,
+                                                 rows.stride(0), out.data_ptr(), _abi.current_stream())
+    _abi.check(rc, "gsn_segment_sum_rows_hip")
+    return out
 
 
 def _dense_native_ok(stages, training=None):

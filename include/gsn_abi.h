@@ -193,6 +193,12 @@ int gsn_propagate_fwd_hip(int kind, int64_t n_nodes, int64_t n_edges, const int6
                           const int32_t *perm, const int32_t *sorted_src, const float *a, int64_t da, const float *b, int64_t db,
                           int b_per_node, const float *c, int64_t dc, float *out, void *stream);
 
+/* out[t][0 .. width) = sum over the rows q of t's segment of b[row(q)][0 .. width), where b is a COLUMN SLICE of wider rows (row stride ld
+ * floats; row(q) = perm[q], or q when perm is NULL): gsn_propagate_fwd_hip's concatenation with the per-edge block alone, reading the slice in
+ * place -- the per-vertex sums of a gathered block's input gradient (the x_i / x_j blocks of an edge stage, GSN_sparse.py:166-171). */
+int gsn_segment_sum_rows_hip(int64_t n_nodes, int64_t n_edges, const int64_t *src, const int32_t *seg_ptr, const int32_t *perm,
+                             const int32_t *sorted_src, const float *b, int64_t width, int64_t ld, float *out, void *stream);
+
 int gsn_propagate_bwd_hip(int kind, int64_t n_nodes, int64_t n_edges, const int64_t *src, const int64_t *tgt,
                           const int32_t *seg_ptr_src, const int32_t *perm_src, const float *a, int64_t da,
                           const float *b, int64_t db, int b_per_node, const float *c, int64_t dc,
