@@ -783,3 +783,23 @@ def test_eval_after_training_uses_the_updated_running_statistics():
     sd = {k: v.detach().cpu().clone() for k, v in layer.state_dict().items()}
     ref = oracle.layer_forward("GSN_edge_sparse", ctor, sd, x, ei, training=False, identifiers=ids, degrees=None, edge_features=ef)
     assert elementwise_ok(y.cpu(), ref), rel_err(y.cpu(), ref)
+
+
+def test_segment_sums_of_a_column_slice():
+    """gsn_segment_sum_rows_hip (layers._segment_sum_cols): per-vertex sums of rows[:, col0 : col0 + width] through edge_index[mode], read in
+    place (row stride = the full row), against index_add_ in fp64; short segments, a hub, isolated vertices, both modes, several slices."""
+    from gsn_amd.layers import _segment_sum_cols, _CSR_CACHE
+    g = torch.Generator().manual_seed(11)
+    for n, E, K in ((1, 0, 8), (50, 170, 272), (3000, 9000, 272), (40, 4000, 36), (20000, 50000, 140)):
+        ei = torch.randint(0, n, (2, E), generator=g)
+        if E:
+            ei[1, : E // 3] = 0                                 # a hub
+        rows = torch.randn(E, K, generator=g)
+        eig, rg = ei.cuda(), rows.cuda()
+        _CSR_CACHE.clear()
+        for mode in (0, 1):
+            for col0, width in {(0, K), (4, min(12, K - 4)), (K - 8, 8), (max(K - 132, 0), min(128, K))}:
+                got = _segment_sum_cols(eig, mode, n, rg, col0, width).cpu()
+                ref = torch.zeros(n, width, dtype=torch.float64).index_add_(0, ei[mode], rows[:, col0:col0 + width].double())
+                assert got.shape == (n, width)
+                assert float((got.double() - ref).abs().max()) <= 1e-5 * max(float(ref.abs().max()), 1.0), (n, E, K, mode, col0, width)
