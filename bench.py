@@ -608,6 +608,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def diag(tag):
+        if not os.environ.get("GSN_BENCH_DIAG_ORDER"):
+            return
+        for _ in range(3):
+            step()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync()
+        print("diag position %s: %.4f ms" % (tag, (time.perf_counter() - t0) / args.steps * 1e3), file=sys.stderr)
+
     # untimed, before the W warm-up steps: first-launch costs and the GPU clock ramp after the idle host-side data generation
     # (the device needs ~0.1 s of load to reach its steady state: 5 steps 1.44 ms/step, 60 steps 1.39; GSN_BENCH_PREWARM)
     for _ in range(int(os.environ.get("GSN_BENCH_PREWARM", "60"))):
@@ -615,21 +627,47 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
+    diag("before the timed region")
+    diag("before the timed region, again")
+    # HIP events inside the timed region bracket the DOMINANT kernel only (the layer: `roofline.avg_launch_ms`); the full per-kernel breakdown
+    # (`ms_per_step_by_kernel`) comes from K more steps right behind the timed region, bracketed everywhere (an event pair around every launch
+    # keeps consecutive kernels from overlapping their ends: ~1 % of the step).
     layers.KERNEL_TIMER = {}
+    layers.KERNEL_TIMER_ONLY = {"layer_fused"} if os.environ.get("GSN_BENCH_NO_EVENTS", "0") == "0" else set()      # (diagnostic: no event at all)
     import gc
-    gc.collect()
+    _dm = os.environ.get("GSN_BENCH_DIAG_MODE", "")
+    if "collect" in _dm:                      # (diagnostic: a collection here frees blocks and changes where the step's buffers land -- 0.754 -> 0.854 ms)
+        gc.collect()
     gc.disable()                              # (the timed region is ~16 ms: one collector pause of the interpreter would be a tenth of it)
+    if "empty" in _dm:
+        torch.cuda.empty_cache()
+        for _ in range(10):
+            step()
+        sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        if "drop" in _dm:
+            step()
+            continue
         y = step()
     t_enq = time.perf_counter() - t0          # host time to enqueue the K steps (the GPU runs behind it)
     sync()
     dt = time.perf_counter() - t0
     gc.enable()
+    if "drop" in _dm:
+        y = step()
+        sync()
+    timer_dom, layers.KERNEL_TIMER, layers.KERNEL_TIMER_ONLY = layers.KERNEL_TIMER, {}, None
+    for _ in range(args.steps):              # (untimed: the same K steps with every kernel family bracketed)
+        step()
+    sync()
     timer, layers.KERNEL_TIMER = layers.KERNEL_TIMER, None
+    timer["layer_fused"] = timer_dom.get("layer_fused", timer.get("layer_fused", []))      # the dominant kernel's events are those of the TIMED steps
     dt_own = dt
     dt = gdist.max_over_ranks(dt, dev)
     assert torch.isfinite(y).all()
+    print("diag timed region: %.4f ms" % (dt / args.steps * 1e3), file=sys.stderr) if os.environ.get("GSN_BENCH_DIAG_ORDER") else None
+    diag("right behind the timed region")
     # (outside the timed region) the timed batch's own results against the oracle, and the counting work figures: the int64
     # counts of the same batch (one more launch), the timed step's encoded rows against their one-hot, a tile against the oracle
     count_batch(plan, node_ptr, edge_ptr, ei, ids_are_global=True, max_nodes=max_nodes, max_edges=max_edges, device=dev, out=ids_out, check=False)
@@ -640,6 +678,7 @@ def main():
         checked["encoded_rows_equal_one_hot_of_counts"] = enc_ok
     occ_pos, n_maps = work_figures([list(nx.cycle_graph(k).edges) for k in range(3, 7)], ids_out)
 
+    diag("behind the oracle checks")
     # Diagnostic (never `value`): the same K steps replayed from ONE captured HIP graph of the step (same kernels, same inputs).
     dt_graph, graph_note, dt_graph_fork = None, None, None
     if not args.no_graph:
@@ -691,6 +730,20 @@ def main():
         step(int64_ids=True)
     sync()
     dt_ids = gdist.max_over_ranks(time.perf_counter() - t0, dev)
+
+    if os.environ.get("GSN_BENCH_DIAG_ORDER"):       # (diagnostic: the two step variants timed alternately, keeping / dropping the output)
+        for tag, kw, keep in (("A keep", {}, True), ("B", {"int64_ids": True}, False), ("A drop", {}, False), ("B keep", {"int64_ids": True}, True), ("A keep", {}, True)):
+            for _ in range(3):
+                step(**kw)
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                if keep:
+                    y = step(**kw)
+                else:
+                    step(**kw)
+            sync()
+            print("diag %s: %.4f ms" % (tag, (time.perf_counter() - t0) / args.steps * 1e3), file=sys.stderr)
 
     # Supplementary: the layer alone, back to back, on its fp16 packs (the timed step's kernel) and on the fp32 rows (csrc/layer_rr.hip)
     layer_alone = {}

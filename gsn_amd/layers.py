@@ -43,21 +43,23 @@ _MAX_BLOCKS = 5
 # Optional per-kernel timing hook for bench.py: a dict name -> list of (start_event, end_event, work) recorded on the
 # launch stream around every kernel family; None = off (no events, no overhead).
 KERNEL_TIMER = None
+KERNEL_TIMER_ONLY = None       # a set of family names: only those are bracketed (an event pair per launch is not free: bench.py)
 
 
 class _timed:
     def __init__(self, name, work=0.0):
         self.name, self.work = name, work
+        self.on = KERNEL_TIMER is not None and (KERNEL_TIMER_ONLY is None or name in KERNEL_TIMER_ONLY)
 
     def __enter__(self):
-        if KERNEL_TIMER is not None:
+        if self.on:
             self.e0 = torch.cuda.Event(enable_timing=True)
             self.e1 = torch.cuda.Event(enable_timing=True)
             self.e0.record()
         return self
 
     def __exit__(self, *exc):
-        if KERNEL_TIMER is not None:
+        if self.on:
             self.e1.record()
             KERNEL_TIMER.setdefault(self.name, []).append((self.e0, self.e1, self.work))
         return False
