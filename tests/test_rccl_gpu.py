@@ -3,6 +3,7 @@ initialisation over RCCL, the flat-bucket gradient all-reduce (forced at world s
 training step, and bench.py / the training-step script under torch.distributed.run."""
 import json
 import os
+import socket
 import subprocess
 import sys
 
@@ -12,11 +13,28 @@ pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port(preferred):
+    """`preferred` when nothing listens there, else a port the kernel hands out (a rendezvous left in TIME_WAIT by an earlier launcher)."""
+    for port in (preferred, 0):
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+            try:
+                s.bind(("127.0.0.1", port))
+                return s.getsockname()[1]
+            except OSError:
+                continue
+    return preferred
+
+
 def _launch(script_args, port, timeout=600):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = _free_port(port)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(port)] + script_args
     r = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=timeout)
+    if r.returncode != 0:                   # (kept for the post-mortem: gpurun merges gpurun_out/ back)
+        os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(REPO, "gpurun_out", "launcher_failure_%d.log" % port), "w") as f:
+            f.write(" ".join(cmd) + "\n" + r.stdout + "\n" + r.stderr)
     assert r.returncode == 0, r.stdout[-2000:] + "\n" + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert lines, r.stdout[-2000:]
