@@ -1422,6 +1422,46 @@ def _segment_sum_cols(edge_index, mode, n_nodes, rows, col0, width):
     return out
 
 
+FOLD_KERNEL = os.environ.get("GSN_FOLD_KERNEL", "1") != "0"      # A/B switch: the fold as tensor ops over the dense stages (~18 launches per layer and step)
+
+
+class _FoldWeightsFn(torch.autograd.Function):
+    """w_first = [W3[:, :d_x] | W3[:, d_x:] W2 | W3[:, d_x:] b2]: update_fn's first weight with msg_fn's last Linear (W2, b2) folded in
+    (GSN_edge_sparse.py:153-170: update_fn(cat(x, sum_e msg_fn(...)))), differentiable in W3, W2 and b2; one launch each way."""
+
+    @staticmethod
+    def takes(w3, last, d_x):
+        w2, b2 = last.weight, last.bias
+        return (b2 is not None and w3.is_cuda and all(t.dtype is torch.float32 and t.is_contiguous() for t in (w3, w2, b2))
+                and w3.shape[1] - d_x == w2.shape[0] and max(w3.shape[0], w2.shape[0], w2.shape[1]) <= 8192
+                and w3.shape[0] * w2.shape[0] * w2.shape[1] <= (1 << 25))      # (plain FMA dot products: the matrices of a layer, not a workload)
+
+    @staticmethod
+    def forward(ctx, w3, w2, b2, d_x):
+        R, A, H = w3.shape[0], w2.shape[0], w2.shape[1]
+        out = torch.empty((R, d_x + H + 1), dtype=torch.float32, device=w3.device)
+        with _abi.device_guard(w3.device):
+            rc = _abi.lib().gsn_fold_weights_fwd_hip(R, d_x, A, H, w3.data_ptr(), w3.stride(0), w2.data_ptr(), w2.stride(0), b2.data_ptr(),
+                                                     out.data_ptr(), _abi.current_stream())
+        _abi.check(rc, "gsn_fold_weights_fwd_hip")
+        ctx.save_for_backward(w3, w2, b2)
+        ctx.d_x = d_x
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        w3, w2, b2 = ctx.saved_tensors
+        d_x, R, A, H = ctx.d_x, w3.shape[0], w2.shape[0], w2.shape[1]
+        if g.dtype is not torch.float32 or g.stride(1) != 1:
+            g = g.to(torch.float32).contiguous()
+        g_w3, g_w2, g_b2 = torch.empty_like(w3), torch.empty_like(w2), torch.empty_like(b2)
+        with _abi.device_guard(w3.device):
+            rc = _abi.lib().gsn_fold_weights_bwd_hip(R, d_x, A, H, g.data_ptr(), g.stride(0), w3.data_ptr(), w3.stride(0), w2.data_ptr(), w2.stride(0),
+                                                     b2.data_ptr(), g_w3.data_ptr(), g_w2.data_ptr(), g_b2.data_ptr(), _abi.current_stream())
+        _abi.check(rc, "gsn_fold_weights_bwd_hip")
+        return g_w3, g_w2, g_b2, None
+
+
 def _dense_native_ok(stages, training=None):
     """Native backward covers: plain (un-gathered) blocks, <= 5 of them; BatchNorm on batch statistics or (r03) on its running
     statistics -- each BatchNorm1d module's own ``training`` flag decides, as in the reference (models_misc.py:41-45)."""
@@ -2065,11 +2105,15 @@ class _SparseLayer(nn.Module):
         csr = _csr_for(edge_index, sel, n)
         last, w3 = mf.fc[-1], uf.fc[0].weight
         d_x = x.shape[1]
-        w3x, w3a = w3[:, :d_x], w3[:, d_x:].contiguous()
-        # the fold  W3a W2 | W3a b2  as two dense stages with their own adjoints (rows = W3a; no library GEMM in the step)
-        w_fold = run_stages_autograd([_Stage(last.weight.t(), None, None, "identity", [(w3a, None)])], w3a.shape[0], True)
-        b_fold = run_stages_autograd([_Stage(last.bias.unsqueeze(0), None, None, "identity", [(w3a, None)])], w3a.shape[0], True)
-        w_first = torch.cat([w3x, w_fold, b_fold], 1)
+        if FOLD_KERNEL and _FoldWeightsFn.takes(w3, last, d_x):
+            # the fold  W3x | W3a W2 | W3a b2  and its adjoint: one launch each (gsn_fold_weights_{fwd,bwd}_hip)
+            w_first = _FoldWeightsFn.apply(w3, last.weight, last.bias, d_x)
+        else:
+            # ... as two dense stages with their own adjoints (rows = W3a; no library GEMM in the step)
+            w3x, w3a = w3[:, :d_x], w3[:, d_x:].contiguous()
+            w_fold = run_stages_autograd([_Stage(last.weight.t(), None, None, "identity", [(w3a, None)])], w3a.shape[0], True)
+            b_fold = run_stages_autograd([_Stage(last.bias.unsqueeze(0), None, None, "identity", [(w3a, None)])], w3a.shape[0], True)
+            w_first = torch.cat([w3x, w_fold, b_fold], 1)
         stages = uf.stages([(x, None), (s_agg, None), (csr.deg, None)], first_weight=w_first, post=post)
         return run_stages_autograd(stages, n, True)
 
