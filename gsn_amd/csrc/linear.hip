@@ -568,6 +568,200 @@ static int launch_linear_bf16_impl(const LinArgs &a, int k_pad, int64_t n_tiles,
     return GSN_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same product on 32-row tiles, for row counts at which the 128-row tiles above leave most of the chip idle (a training step at the
+// reference's batch sizes: M = 10^3 .. 10^4 rows is 8 .. 50 tiles of 128 rows on 256 CUs, each a serial chain of K / 32 slices x 48 MFMAs).
+// Workgroup = 4 waves = 32 rows x 128 output columns, wave w owns columns 32 w .. + 32 (one accumulator tile); one tile per workgroup; the
+// same staging (three bf16 planes per operand, truncation split), the same six plane products in the same order and the same K order, so a
+// row's result does not depend on which of the two kernels computed it.  W is re-staged by four times as many workgroups (from L2).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int SBM = 32;
+constexpr int SAPLANE = SBM * BKP / 2;            // floats per A plane
+constexpr int SBUF = 3 * SAPLANE + 3 * BPLANE;    // floats per buffer: A planes, W planes
+
+template <bool STATS, bool VEC4>
+__global__ __launch_bounds__(256) void linear_fwd_bf16_small_kernel(LinArgs a, int k_pad) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    auto a_planes = [&](int buf) { return lds + buf * SBUF; };
+    auto w_planes = [&](int buf) { return lds + buf * SBUF + 3 * SAPLANE; };
+    int *rsrc = reinterpret_cast<int *>(lds + 2 * SBUF);       // [MAX_BLOCKS][SBM]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wn = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    // scalar staging: column kc of rows r0 + 8 i (4) and of output columns r0 + 8 i (16); VEC4: columns kc .. kc + 3 of row r0 and of output columns r0 + 32 i (4)
+    const int kc = VEC4 ? 4 * (tid & 7) : (tid & 31), r0 = VEC4 ? (tid >> 3) : (tid >> 5);
+    const int n0 = blockIdx.y * BN;
+    const int64_t row0 = (int64_t)blockIdx.x * SBM;
+    const int n_slices = k_pad / BK;
+
+    if (tid < MAX_BLOCKS * SBM) {
+        const int b = tid >> 5;
+        const int64_t grow = row0 + (tid & 31);
+        int r = 0;                      // rows past the end read row 0 (never emitted)
+        if (b < a.n_blocks && grow < a.m_rows) {
+            const int64_t logical = a.row_perm ? (int64_t)a.row_perm[grow] : grow;
+            r = a.bidx32[b] ? a.bidx32[b][logical] : (a.bidx[b] ? (int)a.bidx[b][logical] : (int)logical);
+        }
+        rsrc[tid] = r;
+    }
+    __syncthreads();
+
+    const int col = n0 + wn * 32 + li;
+    const bool cok = col < a.n_out;
+    const float e_bias = (cok && a.bias) ? a.bias[col] : 0.f;
+    float e_scale = 1.f, e_c0 = e_bias;
+    if (cok && a.bn_scale) { e_scale = a.bn_scale[col]; e_c0 = (e_bias - a.bn_mean[col]) * e_scale + a.bn_shift[col]; }
+
+    float preA[4], preW[16];
+    auto fetch = [&](int c) {
+        const ColMapL cm = col_map_l(a, c * BK + kc);
+        const int *rp = rsrc + (cm.rsoff / (BM / SBM)) + r0;
+        const int kg = c * BK + kc;
+        const int kk = kg < a.k_total ? kg : 0;
+        if (VEC4) {
+            const float4 v = *reinterpret_cast<const float4 *>(cm.base + (int64_t)rp[0] * cm.bw);
+            preA[0] = v.x; preA[1] = v.y; preA[2] = v.z; preA[3] = v.w;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int j = n0 + r0 + 32 * i;
+                j = j < a.n_out ? j : 0;
+                const float4 u = *reinterpret_cast<const float4 *>(a.W + (int64_t)j * a.k_total + kk);
+                preW[4 * i] = u.x; preW[4 * i + 1] = u.y; preW[4 * i + 2] = u.z; preW[4 * i + 3] = u.w;
+            }
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) preA[i] = cm.base[(int64_t)rp[8 * i] * cm.bw];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            int j = n0 + r0 + 8 * i;
+            j = j < a.n_out ? j : 0;
+            preW[i] = a.W[(int64_t)j * a.w_rs + (int64_t)kk * a.w_cs];
+        }
+    };
+    auto pack2 = [](unsigned lo, unsigned hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); };
+    typedef unsigned u32x2s __attribute__((ext_vector_type(2)));
+    auto stage = [&](int buf, int c) {
+        const float km = (c * BK + kc < a.k_total) ? 1.f : 0.f;
+        if (VEC4) {
+            {
+                unsigned h[4], m[4], l[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) split3l(preA[e], h[e], m[e], l[e]);
+                float *pa = a_planes(buf) + (r0 * BKP + kc) / 2;
+                u32x2s v;
+                v[0] = pack2(h[0], h[1]); v[1] = pack2(h[2], h[3]); *reinterpret_cast<u32x2s *>(pa) = v;
+                v[0] = pack2(m[0], m[1]); v[1] = pack2(m[2], m[3]); *reinterpret_cast<u32x2s *>(pa + SAPLANE) = v;
+                v[0] = pack2(l[0], l[1]); v[1] = pack2(l[2], l[3]); *reinterpret_cast<u32x2s *>(pa + 2 * SAPLANE) = v;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float jm = (n0 + r0 + 32 * i < a.n_out) ? km : 0.f;
+                unsigned h[4], m[4], l[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) split3l(preW[4 * i + e] * jm, h[e], m[e], l[e]);
+                float *pw = w_planes(buf) + ((r0 + 32 * i) * BKP + kc) / 2;
+                u32x2s v;
+                v[0] = pack2(h[0], h[1]); v[1] = pack2(h[2], h[3]); *reinterpret_cast<u32x2s *>(pw) = v;
+                v[0] = pack2(m[0], m[1]); v[1] = pack2(m[2], m[3]); *reinterpret_cast<u32x2s *>(pw + BPLANE) = v;
+                v[0] = pack2(l[0], l[1]); v[1] = pack2(l[2], l[3]); *reinterpret_cast<u32x2s *>(pw + 2 * BPLANE) = v;
+            }
+            return;
+        }
+        unsigned short *pa = reinterpret_cast<unsigned short *>(a_planes(buf)) + r0 * BKP + kc;
+        unsigned short *pw = reinterpret_cast<unsigned short *>(w_planes(buf)) + r0 * BKP + kc;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            unsigned h, m, l;
+            split3l(preA[i], h, m, l);
+            pa[8 * i * BKP] = (unsigned short)(h >> 16);
+            pa[8 * i * BKP + 2 * SAPLANE] = (unsigned short)(m >> 16);
+            pa[8 * i * BKP + 4 * SAPLANE] = (unsigned short)(l >> 16);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            unsigned h, m, l;
+            const float jm = (n0 + r0 + 8 * i < a.n_out) ? km : 0.f;
+            split3l(preW[i] * jm, h, m, l);
+            pw[8 * i * BKP] = (unsigned short)(h >> 16);
+            pw[8 * i * BKP + 2 * BPLANE] = (unsigned short)(m >> 16);
+            pw[8 * i * BKP + 4 * BPLANE] = (unsigned short)(l >> 16);
+        }
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    fetch(0);
+    int cur = 0;
+#define GSN_MFS(x, y) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8l, x), __builtin_bit_cast(bf16x8l, y), acc, 0, 0, 0)
+    for (int c = 0; c < n_slices; ++c) {
+        stage(cur, c);
+        lds_barrier_l();                        // (the buffer written two slices later is the one read here: a barrier lies between)
+        if (c + 1 < n_slices) fetch(c + 1);
+        const float *ap = a_planes(cur) + (li * BKP + 8 * lh) / 2;
+        const float *bp = w_planes(cur) + ((wn * 32 + li) * BKP + 8 * lh) / 2;
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+            const u32x4l bh = *reinterpret_cast<const u32x4l *>(bp + 8 * s);
+            const u32x4l bm = *reinterpret_cast<const u32x4l *>(bp + 8 * s + BPLANE);
+            const u32x4l bl = *reinterpret_cast<const u32x4l *>(bp + 8 * s + 2 * BPLANE);
+            const u32x4l ah = *reinterpret_cast<const u32x4l *>(ap + 8 * s);
+            const u32x4l am = *reinterpret_cast<const u32x4l *>(ap + 8 * s + SAPLANE);
+            const u32x4l al = *reinterpret_cast<const u32x4l *>(ap + 8 * s + 2 * SAPLANE);
+            GSN_MFS(al, bh); GSN_MFS(ah, bl); GSN_MFS(am, bm);     // small terms first (the order of the 128-row kernel)
+            GSN_MFS(ah, bm); GSN_MFS(am, bh); GSN_MFS(ah, bh);
+        }
+        cur ^= 1;
+    }
+#undef GSN_MFS
+    // epilogue.  C layout of a 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    double st_sum = 0.0, st_sq = 0.0;
+    const int64_t rbase = row0 + 4 * lh;
+    float *op = a.out + rbase * a.n_out + col;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int dr = (r & 3) + 8 * (r >> 2);
+        if (!cok || rbase + dr >= a.m_rows) continue;
+        if (STATS) {
+            const float h = acc[r] + e_bias;
+            st_sum += (double)h;
+            st_sq += (double)h * (double)h;
+            if (a.out) op[(int64_t)dr * a.n_out] = h;
+        } else {
+            op[(int64_t)dr * a.n_out] = apply_act(fmaf(acc[r], e_scale, e_c0), a.act);
+        }
+    }
+    if (STATS) {
+        double s = st_sum, q = st_sq;
+        s += __shfl_xor(s, 32);
+        q += __shfl_xor(q, 32);
+        if (lh == 0 && cok) {
+            atomicAdd(&a.stats[col], s);
+            atomicAdd(&a.stats[a.n_out + col], q);
+        }
+    }
+}
+
+template <bool STATS, bool VEC4>
+static int launch_linear_bf16_small(const LinArgs &a, int k_pad, int col_tiles, hipStream_t st) {
+    const size_t lds = ((size_t)2 * SBUF + (size_t)MAX_BLOCKS * SBM) * 4;
+    static DeviceOnce attr_set;
+    const int attr_dev = current_device();
+    if (!attr_set.done(attr_dev)) {
+        hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_fwd_bf16_small_kernel<STATS, VEC4>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e0 != hipSuccess) return set_error(GSN_E_HIP, "hipFuncSetAttribute(linear_fwd_bf16_small_kernel): %s", hipGetErrorString(e0));
+        attr_set.mark(attr_dev);
+    }
+    const int64_t gx = (a.m_rows + SBM - 1) / SBM;
+    hipLaunchKernelGGL((linear_fwd_bf16_small_kernel<STATS, VEC4>), dim3((unsigned)gx, (unsigned)col_tiles), dim3(256), lds, st, a, k_pad);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(GSN_E_HIP, "linear_fwd_bf16_small_kernel: %s", hipGetErrorString(e));
+    return GSN_OK;
+}
+
 template <bool STATS, bool VEC4>
 static int launch_linear_bf16(const LinArgs &a, int k_pad, int64_t n_tiles, int col_tiles, hipStream_t st) {
     // (D = 2, loads two slices ahead, was measured at the same speed: the kernel is bound by its lock-step phases --
@@ -655,6 +849,12 @@ static int linear_fwd_impl(int64_t m_rows, int n_blocks, const gsn_block *blocks
         for (int b = 0; b < n_blocks; ++b)
             if ((a.bwidth[b] & 3) || (reinterpret_cast<uintptr_t>(a.bdata[b]) & 15)) vec4 = false;
         { const char *d = getenv("GSN_LINEAR_VEC4"); if (d && atoi(d) == 0) vec4 = false; }
+        // few 128-row tiles: 32-row tiles on four times as many CUs (GSN_LINEAR_SMALL_MAX = the largest count of 128-row tiles that takes them, 0 = never)
+        static const int small_max = [] { const char *d = getenv("GSN_LINEAR_SMALL_MAX"); return d ? atoi(d) : 96; }();
+        if (bf16x6 && n_tiles * col_tiles <= small_max) {
+            if (vec4) return stats ? launch_linear_bf16_small<true, true>(a, k_pad, col_tiles, st) : launch_linear_bf16_small<false, true>(a, k_pad, col_tiles, st);
+            return stats ? launch_linear_bf16_small<true, false>(a, k_pad, col_tiles, st) : launch_linear_bf16_small<false, false>(a, k_pad, col_tiles, st);
+        }
         if (bf16x6 && vec4) return stats ? launch_linear_bf16<true, true>(a, k_pad, n_tiles, col_tiles, st) : launch_linear_bf16<false, true>(a, k_pad, n_tiles, col_tiles, st);
         if (bf16x6) return stats ? launch_linear_bf16<true, false>(a, k_pad, n_tiles, col_tiles, st) : launch_linear_bf16<false, false>(a, k_pad, n_tiles, col_tiles, st);
     }
