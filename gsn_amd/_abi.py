@@ -100,7 +100,7 @@ SIGNATURES = {
                                        c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "gsn_bn_act_hip": (c_int, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
     "gsn_bn_act_bwd_hip": (c_int, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
-    "gsn_fold_weights_fwd_hip": (c_int, [c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "gsn_fold_weights_fwd_hip": (c_int, [c_i64, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "gsn_fold_weights_bwd_hip": (c_int, [c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "gsn_bn_act_bwd_from_h_hip": (c_int, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "gsn_wgrad_hip": (c_int, [c_i64, c_i64, c_vp, c_int, ctypes.POINTER(gsn_block), c_vp, c_vp]),

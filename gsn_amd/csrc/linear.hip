@@ -579,7 +579,7 @@ constexpr int SBM = 32;
 constexpr int SAPLANE = SBM * BKP / 2;            // floats per A plane
 constexpr int SBUF = 3 * SAPLANE + 3 * BPLANE;    // floats per buffer: A planes, W planes
 
-template <bool STATS, bool VEC4>
+template <bool STATS, bool VEC4, bool WT>
 __global__ __launch_bounds__(256) void linear_fwd_bf16_small_kernel(LinArgs a, int k_pad) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     auto a_planes = [&](int buf) { return lds + buf * SBUF; };
@@ -613,8 +613,13 @@ __global__ __launch_bounds__(256) void linear_fwd_bf16_small_kernel(LinArgs a, i
     float e_scale = 1.f, e_c0 = e_bias;
     if (cok && a.bn_scale) { e_scale = a.bn_scale[col]; e_c0 = (e_bias - a.bn_mean[col]) * e_scale + a.bn_shift[col]; }
 
-    float preA[4], preW[16];
-    auto fetch = [&](int c) {
+    // SD register sets of staged values: the loads of slice c + SD are issued while slice c computes (a slice's matrix phase is 12 MFMAs per
+    // wave, far shorter than a round trip to L2: one slice ahead left the kernel waiting for its loads in every iteration)
+    constexpr int SD = 3;
+    float preAs[SD][4], preWs[SD][16];
+    // WT (a transposed view of a row-major matrix, w_rs = 1): output column jj of W^T rows k0 + 2 i -- the lanes walk the contiguous direction
+    const int jj = tid & 127, k0 = tid >> 7;
+    auto fetch = [&](float *preA, float *preW, int c) {
         const ColMapL cm = col_map_l(a, c * BK + kc);
         const int *rp = rsrc + (cm.rsoff / (BM / SBM)) + r0;
         const int kg = c * BK + kc;
@@ -633,6 +638,15 @@ __global__ __launch_bounds__(256) void linear_fwd_bf16_small_kernel(LinArgs a, i
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) preA[i] = cm.base[(int64_t)rp[8 * i] * cm.bw];
+        if (WT) {
+            const int j = n0 + jj < a.n_out ? n0 + jj : 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int kgi = c * BK + k0 + 2 * i;
+                preW[i] = a.W[(int64_t)j * a.w_rs + (int64_t)(kgi < a.k_total ? kgi : 0) * a.w_cs];
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             int j = n0 + r0 + 8 * i;
@@ -642,7 +656,7 @@ __global__ __launch_bounds__(256) void linear_fwd_bf16_small_kernel(LinArgs a, i
     };
     auto pack2 = [](unsigned lo, unsigned hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); };
     typedef unsigned u32x2s __attribute__((ext_vector_type(2)));
-    auto stage = [&](int buf, int c) {
+    auto stage = [&](const float *preA, const float *preW, int buf, int c) {
         const float km = (c * BK + kc < a.k_total) ? 1.f : 0.f;
         if (VEC4) {
             {
@@ -679,6 +693,20 @@ __global__ __launch_bounds__(256) void linear_fwd_bf16_small_kernel(LinArgs a, i
             pa[8 * i * BKP + 2 * SAPLANE] = (unsigned short)(m >> 16);
             pa[8 * i * BKP + 4 * SAPLANE] = (unsigned short)(l >> 16);
         }
+        if (WT) {
+            unsigned short *pt = reinterpret_cast<unsigned short *>(w_planes(buf)) + jj * BKP + k0;
+            const bool jok = n0 + jj < a.n_out;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                unsigned h, m, l;
+                const float jm = (jok && c * BK + k0 + 2 * i < a.k_total) ? 1.f : 0.f;
+                split3l(preW[i] * jm, h, m, l);
+                pt[2 * i] = (unsigned short)(h >> 16);
+                pt[2 * i + 2 * BPLANE] = (unsigned short)(m >> 16);
+                pt[2 * i + 4 * BPLANE] = (unsigned short)(l >> 16);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             unsigned h, m, l;
@@ -693,13 +721,15 @@ __global__ __launch_bounds__(256) void linear_fwd_bf16_small_kernel(LinArgs a, i
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    fetch(0);
+#pragma unroll
+    for (int d = 0; d < SD; ++d)
+        if (d < n_slices) fetch(preAs[d], preWs[d], d);
     int cur = 0;
 #define GSN_MFS(x, y) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8l, x), __builtin_bit_cast(bf16x8l, y), acc, 0, 0, 0)
-    for (int c = 0; c < n_slices; ++c) {
-        stage(cur, c);
+    auto body = [&](float *preA, float *preW, int c) {
+        stage(preA, preW, cur, c);
         lds_barrier_l();                        // (the buffer written two slices later is the one read here: a barrier lies between)
-        if (c + 1 < n_slices) fetch(c + 1);
+        if (c + SD < n_slices) fetch(preA, preW, c + SD);
         const float *ap = a_planes(cur) + (li * BKP + 8 * lh) / 2;
         const float *bp = w_planes(cur) + ((wn * 32 + li) * BKP + 8 * lh) / 2;
 #pragma unroll
@@ -714,6 +744,11 @@ __global__ __launch_bounds__(256) void linear_fwd_bf16_small_kernel(LinArgs a, i
             GSN_MFS(ah, bm); GSN_MFS(am, bh); GSN_MFS(ah, bh);
         }
         cur ^= 1;
+    };
+    for (int c = 0; c < n_slices; c += SD) {
+#pragma unroll
+        for (int d = 0; d < SD; ++d)
+            if (c + d < n_slices) body(preAs[d], preWs[d], c + d);
     }
 #undef GSN_MFS
     // epilogue.  C layout of a 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -744,19 +779,19 @@ __global__ __launch_bounds__(256) void linear_fwd_bf16_small_kernel(LinArgs a, i
     }
 }
 
-template <bool STATS, bool VEC4>
+template <bool STATS, bool VEC4, bool WT = false>
 static int launch_linear_bf16_small(const LinArgs &a, int k_pad, int col_tiles, hipStream_t st) {
     const size_t lds = ((size_t)2 * SBUF + (size_t)MAX_BLOCKS * SBM) * 4;
     static DeviceOnce attr_set;
     const int attr_dev = current_device();
     if (!attr_set.done(attr_dev)) {
-        hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_fwd_bf16_small_kernel<STATS, VEC4>),
+        hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_fwd_bf16_small_kernel<STATS, VEC4, WT>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e0 != hipSuccess) return set_error(GSN_E_HIP, "hipFuncSetAttribute(linear_fwd_bf16_small_kernel): %s", hipGetErrorString(e0));
         attr_set.mark(attr_dev);
     }
     const int64_t gx = (a.m_rows + SBM - 1) / SBM;
-    hipLaunchKernelGGL((linear_fwd_bf16_small_kernel<STATS, VEC4>), dim3((unsigned)gx, (unsigned)col_tiles), dim3(256), lds, st, a, k_pad);
+    hipLaunchKernelGGL((linear_fwd_bf16_small_kernel<STATS, VEC4, WT>), dim3((unsigned)gx, (unsigned)col_tiles), dim3(256), lds, st, a, k_pad);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(GSN_E_HIP, "linear_fwd_bf16_small_kernel: %s", hipGetErrorString(e));
     return GSN_OK;
@@ -853,6 +888,8 @@ static int linear_fwd_impl(int64_t m_rows, int n_blocks, const gsn_block *blocks
         static const int small_max = [] { const char *d = getenv("GSN_LINEAR_SMALL_MAX"); return d ? atoi(d) : 96; }();
         if (bf16x6 && n_tiles * col_tiles <= small_max) {
             if (vec4) return stats ? launch_linear_bf16_small<true, true>(a, k_pad, col_tiles, st) : launch_linear_bf16_small<false, true>(a, k_pad, col_tiles, st);
+            if (strided && w_rs < w_cs)     // a transposed view: staged along its contiguous direction
+                return stats ? launch_linear_bf16_small<true, false, true>(a, k_pad, col_tiles, st) : launch_linear_bf16_small<false, false, true>(a, k_pad, col_tiles, st);
             return stats ? launch_linear_bf16_small<true, false>(a, k_pad, col_tiles, st) : launch_linear_bf16_small<false, false>(a, k_pad, col_tiles, st);
         }
         if (bf16x6 && vec4) return stats ? launch_linear_bf16<true, true>(a, k_pad, n_tiles, col_tiles, st) : launch_linear_bf16<false, true>(a, k_pad, n_tiles, col_tiles, st);

@@ -595,6 +595,9 @@ def propagate(kind, edge_index, sel, n_nodes, a=None, b=None, c=None, b_per_node
 # ------------------------------------------------------------------------------------------------------------------
 LINEAR_F16X3 = os.environ.get("GSN_LINEAR_F16X3", "1") != "0"     # direct-row dense stages on the fp16x3 kernel (else bf16x6 / fp32)
 LINEAR_F16X3_MIN_N = int(os.environ.get("GSN_LINEAR_F16X3_MIN_N", "128"))
+# products of at most this many 128 x 128 output tiles stay on the bf16x6 kernel (its 32-row-tile twin, csrc/linear.hip): one launch of ~10-19 us
+# instead of weight split + row pre-pass + product = three launches of ~20-30 us together (molhiv B = 32: 837 x 300 -> 600)
+LINEAR_F16X3_MIN_TILES = int(os.environ.get("GSN_LINEAR_F16X3_MIN_TILES", "96"))
 # train-mode stages too (statistics by gsn_column_stats_hip from the rows the kernel wrote).  Off by default: 0.6 % of a molhiv-sized training
 # step, and the statistics then come from the ROUNDED rows, which moves the 5 x 300 model's gradient digests by 1.2e-4 (bar: 1e-4)
 LINEAR_F16X3_STATS = os.environ.get("GSN_LINEAR_F16X3_STATS", "0") != "0"
@@ -666,6 +669,7 @@ def _linear_hip(blocks, weight, bias, bn_mean, bn_scale, bn_shift, act, m_rows, 
     # (a train-mode stage that keeps its pre-BN rows: the same kernel, then the column statistics of the rows it wrote -- 0.13 + 0.06 ms
     #  instead of 0.28 ms inside the bf16x6 kernel at 105 k x 300 -> 600)
     if (LINEAR_F16X3 and out and (stats is None or (LINEAR_F16X3_STATS and bn_mean is None and act == 0)) and m_rows > 0 and n_out > LINEAR_F16X3_MIN_N
+            and ((m_rows + 127) // 128) * ((n_out + 127) // 128) > LINEAR_F16X3_MIN_TILES
             and all(idx is None for _, idx in blocks) and all(d.shape[1] % 4 == 0 and d.data_ptr() % 16 == 0 for d in keep)):
         planes, col_inv = _f16x3_weights(weight, w)
         scratch = torch.empty(int(_abi.lib().gsn_linear_f16x3_scratch_bytes(m_rows, w.shape[1])), dtype=torch.uint8, device=dev)
@@ -1426,7 +1430,7 @@ FOLD_KERNEL = os.environ.get("GSN_FOLD_KERNEL", "1") != "0"      # A/B switch: t
 
 
 class _FoldWeightsFn(torch.autograd.Function):
-    """w_first = [W3[:, :d_x] | W3[:, d_x:] W2 | W3[:, d_x:] b2]: update_fn's first weight with msg_fn's last Linear (W2, b2) folded in
+    """w_first = [W3[:, :d_x] | W3[:, d_x:] W2 | W3[:, d_x:] b2 | pad zero columns]: update_fn's first weight with msg_fn's last Linear (W2, b2) folded in
     (GSN_edge_sparse.py:153-170: update_fn(cat(x, sum_e msg_fn(...)))), differentiable in W3, W2 and b2; one launch each way."""
 
     @staticmethod
@@ -1437,11 +1441,11 @@ class _FoldWeightsFn(torch.autograd.Function):
                 and w3.shape[0] * w2.shape[0] * w2.shape[1] <= (1 << 25))      # (plain FMA dot products: the matrices of a layer, not a workload)
 
     @staticmethod
-    def forward(ctx, w3, w2, b2, d_x):
+    def forward(ctx, w3, w2, b2, d_x, pad=0):
         R, A, H = w3.shape[0], w2.shape[0], w2.shape[1]
-        out = torch.empty((R, d_x + H + 1), dtype=torch.float32, device=w3.device)
+        out = torch.empty((R, d_x + H + 1 + pad), dtype=torch.float32, device=w3.device)
         with _abi.device_guard(w3.device):
-            rc = _abi.lib().gsn_fold_weights_fwd_hip(R, d_x, A, H, w3.data_ptr(), w3.stride(0), w2.data_ptr(), w2.stride(0), b2.data_ptr(),
+            rc = _abi.lib().gsn_fold_weights_fwd_hip(R, d_x, A, H, pad, w3.data_ptr(), w3.stride(0), w2.data_ptr(), w2.stride(0), b2.data_ptr(),
                                                      out.data_ptr(), _abi.current_stream())
         _abi.check(rc, "gsn_fold_weights_fwd_hip")
         ctx.save_for_backward(w3, w2, b2)
@@ -1459,7 +1463,7 @@ class _FoldWeightsFn(torch.autograd.Function):
             rc = _abi.lib().gsn_fold_weights_bwd_hip(R, d_x, A, H, g.data_ptr(), g.stride(0), w3.data_ptr(), w3.stride(0), w2.data_ptr(), w2.stride(0),
                                                      b2.data_ptr(), g_w3.data_ptr(), g_w2.data_ptr(), g_b2.data_ptr(), _abi.current_stream())
         _abi.check(rc, "gsn_fold_weights_bwd_hip")
-        return g_w3, g_w2, g_b2, None
+        return g_w3, g_w2, g_b2, None, None
 
 
 def _dense_native_ok(stages, training=None):
@@ -2107,7 +2111,11 @@ class _SparseLayer(nn.Module):
         d_x = x.shape[1]
         if FOLD_KERNEL and _FoldWeightsFn.takes(w3, last, d_x):
             # the fold  W3x | W3a W2 | W3a b2  and its adjoint: one launch each (gsn_fold_weights_{fwd,bwd}_hip)
-            w_first = _FoldWeightsFn.apply(w3, last.weight, last.bias, d_x)
+            # (three zero columns behind the degree column: the degree block goes in four floats wide, csr.deg4, and the stage's rows are staged
+            #  as float4 -- K = d_x + d_h + 1 is odd otherwise)
+            w_first = _FoldWeightsFn.apply(w3, last.weight, last.bias, d_x, 3)
+            stages = uf.stages([(x, None), (s_agg, None), (csr.deg4, None)], first_weight=w_first, post=post)
+            return run_stages_autograd(stages, n, True)
         else:
             # ... as two dense stages with their own adjoints (rows = W3a; no library GEMM in the step)
             w3x, w3a = w3[:, :d_x], w3[:, d_x:].contiguous()

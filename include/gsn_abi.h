@@ -581,12 +581,13 @@ int gsn_wgrad_hip(int64_t m_rows, int64_t n_out, const float *grad_h, int n_bloc
                   void *stream);
 /* The folded first weight of update_fn for a `general` layer whose aggregation runs in front of msg_fn's last Linear (W2, b2) --
  * GSN_edge_sparse.py:153-170 / GSN_sparse.py:166-171 with  update_fn.fc[0](cat(x, sum_e(W2 r_e + b2))) = cat(x, S, deg) out^T:
- *   out [rows][d_x + h_cols + 1] = [ w3[:, :d_x] | w3[:, d_x:] W2 | w3[:, d_x:] b2 ],   w3 [rows][d_x + a_cols] (row stride ld3),
- *   w2 [a_cols][h_cols] (row stride ld2), b2 [a_cols].  One launch, fp32 FMA dot products.
- * _bwd: g [rows][d_x + h_cols + 1] (row stride ldg) -> g_w3 [rows][d_x + a_cols], g_w2 [a_cols][h_cols], g_b2 [a_cols] (all written,
+ *   out [rows][d_x + h_cols + 1 + pad_cols] = [ w3[:, :d_x] | w3[:, d_x:] W2 | w3[:, d_x:] b2 | 0 ],   w3 [rows][d_x + a_cols] (row stride ld3),
+ *   w2 [a_cols][h_cols] (row stride ld2), b2 [a_cols]; pad_cols zero columns (the degree block is passed four floats wide so that the
+ *   stage's rows are staged as float4).  One launch, fp32 FMA dot products.
+ * _bwd: g [rows][>= d_x + h_cols + 1] (row stride ldg; columns past d_x + h_cols are not read) -> g_w3 [rows][d_x + a_cols], g_w2 [a_cols][h_cols], g_b2 [a_cols] (all written,
  *   contiguous), one launch.  A training step rebuilds the fold at every step (the three matrices move). */
-int gsn_fold_weights_fwd_hip(int64_t rows, int64_t d_x, int64_t a_cols, int64_t h_cols, const float *w3, int64_t ld3, const float *w2,
-                             int64_t ld2, const float *b2, float *out, void *stream);
+int gsn_fold_weights_fwd_hip(int64_t rows, int64_t d_x, int64_t a_cols, int64_t h_cols, int64_t pad_cols, const float *w3, int64_t ld3,
+                             const float *w2, int64_t ld2, const float *b2, float *out, void *stream);
 int gsn_fold_weights_bwd_hip(int64_t rows, int64_t d_x, int64_t a_cols, int64_t h_cols, const float *g, int64_t ldg, const float *w3,
                              int64_t ld3, const float *w2, int64_t ld2, const float *b2, float *g_w3, float *g_w2, float *g_b2,
                              void *stream);

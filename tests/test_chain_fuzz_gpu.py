@@ -127,13 +127,14 @@ def test_random_chain_shapes_vs_fp64(seed):
                                                 (257, [36], 131, "relu", False), (70000, [64], 1028, "identity", False),
                                                 (20000, [352], 300, "relu", False), (60000, [600], 256, "relu", True),
                                                 (1, [4], 132, "relu", False), (5, [8, 4], 200, "identity", True), (129, [32], 129, "relu", True)])
-def test_direct_rows_on_the_fp16x3_linear_kernel(m, widths, n, act, bn, capfd):
+def test_direct_rows_on_the_fp16x3_linear_kernel(m, widths, n, act, bn, capfd, monkeypatch):
     """gsn_linear_f16x3_fwd_hip (direct rows, n_out > 128): several input blocks, K not a multiple of the slice and wider than the
     pre-pass keeps in registers, a ragged last row tile and column tile, n_out not a multiple of 4 (4-byte output stores), more
     row tiles than workgroups with an odd number of K slices (the shapes on which a 16-byte store's data register was once
     overwritten behind the store), every epilogue -- against fp64, element-wise, with the product's own condition scale as floor."""
     import os
     from gsn_amd import layers
+    monkeypatch.setattr(layers, "LINEAR_F16X3_MIN_TILES", 0)       # (products of few tiles go to the bf16x6 kernel's 32-row twin by default: tests/test_linear_small_gpu.py)
     g = torch.Generator().manual_seed(m + n)
     xs = [torch.randn(m, w, generator=g) * (10.0 ** i) for i, w in enumerate(widths)]
     k = sum(widths)

@@ -23,7 +23,7 @@ def test_fold_forward_and_adjoint_against_float64(R, d_x, A, H):
     want = torch.autograd.grad(ref, [w3d, w2d, b2d], gy.double())
     assert torch.equal(out[:, :d_x], w3[:, :d_x])
     scale = float(ref.detach().abs().max())
-    assert float((out.double() - ref).abs().max()) <= 2e-6 * scale
+    assert float((out.double() - ref.detach()).abs().max()) <= 2e-6 * scale
     for a, b in zip(got, want):
         assert a.shape == b.shape
         assert float((a.double() - b).abs().max()) <= 2e-6 * float(b.abs().max()) + 1e-30
