@@ -95,6 +95,8 @@ SIGNATURES = {
     "gsn_column_ranks_hip": (c_int, [c_i64, c_int, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "gsn_embed_fwd_hip": (c_int, [c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "gsn_embed_bwd_hip": (c_int, [c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "gsn_embed_bwd_flat_supported": (c_int, [c_i64, c_int, c_int, c_vp]),
+    "gsn_embed_bwd_flat_hip": (c_int, [c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "gsn_code_stage_supported": (c_int, [c_int, c_i64, c_i64]),
     "gsn_code_stage_fwd_hip": (c_int, [c_i64, c_int, ctypes.POINTER(gsn_code_slot), c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp,
                                        c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),

@@ -375,6 +375,8 @@ struct EmbArgs {
     float *out;                   // forward
     int32_t *status;              // forward
     int rows_per_wg;              // input rows per workgroup (multiple of 32, <= EMB_ROWS)
+    float *gflat;                 // backward, flat variant: the gradient tables live in ONE allocation, table c at gflat + goff[c]
+    int64_t goff[EMB_MAXC];       // (no device pointer array: nothing to copy per step, nothing for a graph replay to re-read)
 };
 
 // NSUB: 64-column sub-slices per workgroup (slice = 64 NSUB columns of the embedding).  When the tables are small enough a workgroup
@@ -485,7 +487,7 @@ __global__ __launch_bounds__(256) void embed_lds_kernel(EmbArgs a) {
     if (BWD) {
         __syncthreads();
         for (int c = 0; c < a.n_cols; ++c) {
-            float *t = reinterpret_cast<float *>(a.meta[c]);
+            float *t = a.gflat ? a.gflat + a.goff[c] : reinterpret_cast<float *>(a.meta[c]);
             const int rows_c = a.row_off[c + 1] - a.row_off[c];
             for (int i = threadIdx.x; i < rows_c * DCH; i += blockDim.x) {
                 const int row = i / DCH, jj = j0 + (i - row * DCH);
@@ -645,6 +647,8 @@ struct EmbMArgs {
     const int64_t *meta;           // gradient table pointers (device)
     int row_off[EMB_MAXC + 1];
     const float *gout;
+    float *gflat;                  // flat variant (see EmbArgs): table c at gflat + goff[c]
+    int64_t goff[EMB_MAXC];
 };
 
 __device__ __forceinline__ void embm_split3(float x, unsigned &h, unsigned &m, unsigned &l) {
@@ -774,9 +778,13 @@ __global__ __launch_bounds__(256) void embed_bwd_mfma_kernel(EmbMArgs a) {
         for (int r = 0; r < 16; ++r) {
             const int nrow = n0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             if (nrow >= a.rtot) continue;
-            int c = 0;
-            for (int q = 1; q < a.n_cols; ++q) c = nrow >= a.row_off[q] ? q : c;
-            float *t = reinterpret_cast<float *>(a.meta[c]) + (int64_t)(nrow - a.row_off[c]) * a.d;
+            int c = 0, roff = 0;
+            int64_t go = a.goff[0];
+            for (int q = 1; q < a.n_cols; ++q) {        // (uniform q: scalar loads of the argument block, no per-lane indexing of it)
+                const bool in = nrow >= a.row_off[q];
+                c = in ? q : c; roff = in ? a.row_off[q] : roff; go = in ? a.goff[q] : go;
+            }
+            float *t = (a.gflat ? a.gflat + go : reinterpret_cast<float *>(a.meta[c])) + (int64_t)(nrow - roff) * a.d;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int kcol = k0 + wn * 64 + j * 32 + li;
@@ -787,19 +795,58 @@ __global__ __launch_bounds__(256) void embed_bwd_mfma_kernel(EmbMArgs a) {
 }
 }  // namespace gsn
 
+namespace gsn {
+static bool embed_bwd_mfma_fits(int64_t m_rows, int n_cols, int concat, const int64_t *table_rows, int64_t *rtot_out) {
+    static const bool lds_only = [] { const char *e = getenv("GSN_EMBED_BWD_LDS"); return e && e[0] == '1'; }();
+    int64_t rtot = 0;
+    bool small_tables = n_cols <= EMB_MAXC;
+    for (int c = 0; small_tables && c < n_cols; ++c) { rtot += table_rows[c]; small_tables = table_rows[c] > 0 && table_rows[c] < 0xfffe; }
+    if (rtot_out) *rtot_out = rtot;
+    return !lds_only && !concat && small_tables && rtot <= 4096 && m_rows >= 256;
+}
+}  // namespace gsn
+
+static int embed_bwd_impl(int64_t m_rows, int n_cols, int d, int concat, const int64_t *codes, const int64_t *grad_meta, float *grad_flat,
+                          const int64_t *table_offsets, const int64_t *table_rows, const float *grad_out, void *stream);
+
 extern "C" int gsn_embed_bwd_hip(int64_t m_rows, int n_cols, int d, int concat, const int64_t *codes, const int64_t *grad_meta,
                                  const int64_t *table_rows, const float *grad_out, void *stream) {
-    if (n_cols < 1 || d < 1 || !grad_meta || !table_rows || (m_rows > 0 && (!codes || !grad_out)))
+    if (!grad_meta) return set_error(GSN_E_INVALID, "gsn_embed_bwd_hip: bad arguments");
+    return embed_bwd_impl(m_rows, n_cols, d, concat, codes, grad_meta, nullptr, nullptr, table_rows, grad_out, stream);
+}
+
+// 1 when gsn_embed_bwd_flat_hip handles the shape (the kernels that take their table addresses as launch arguments: <= 16 code columns and
+// tables that fit LDS slices or the matrix-pipe product), else 0
+extern "C" int gsn_embed_bwd_flat_supported(int64_t m_rows, int n_cols, int concat, const int64_t *table_rows) {
+    if (n_cols < 1 || n_cols > EMB_MAXC || !table_rows) return 0;
+    return (embed_bwd_mfma_fits(m_rows, n_cols, concat, table_rows, nullptr) || embed_lds_fits(n_cols, table_rows)) ? 1 : 0;
+}
+
+// The same accumulation with the gradient tables inside ONE caller-zeroed allocation: table c at grad_flat + table_offsets[c] floats
+// (table_offsets: HOST array [C]).  The addresses travel as launch arguments -- no device pointer array, hence no host-to-device copy per
+// call (eager) and no memcpy node per gradient table set in a captured training step (gsn_amd.graphs).
+extern "C" int gsn_embed_bwd_flat_hip(int64_t m_rows, int n_cols, int d, int concat, const int64_t *codes, float *grad_flat,
+                                      const int64_t *table_offsets, const int64_t *table_rows, const float *grad_out, void *stream) {
+    if (!grad_flat || !table_offsets || !table_rows) return set_error(GSN_E_INVALID, "gsn_embed_bwd_flat_hip: bad arguments");
+    if (!gsn_embed_bwd_flat_supported(m_rows > 0 ? m_rows : 1, n_cols, concat, table_rows))
+        return set_error(GSN_E_UNSUPPORTED, "gsn_embed_bwd_flat_hip: tables outside the flat variant (ask gsn_embed_bwd_flat_supported)");
+    for (int c = 0; c < n_cols; ++c)
+        if (table_offsets[c] < 0) return set_error(GSN_E_INVALID, "gsn_embed_bwd_flat_hip: negative table offset");
+    return embed_bwd_impl(m_rows, n_cols, d, concat, codes, nullptr, grad_flat, table_offsets, table_rows, grad_out, stream);
+}
+
+static int embed_bwd_impl(int64_t m_rows, int n_cols, int d, int concat, const int64_t *codes, const int64_t *grad_meta, float *grad_flat,
+                          const int64_t *table_offsets, const int64_t *table_rows, const float *grad_out, void *stream) {
+    if (n_cols < 1 || d < 1 || !table_rows || (m_rows > 0 && (!codes || !grad_out)))
         return set_error(GSN_E_INVALID, "gsn_embed_bwd_hip: bad arguments");
     if (m_rows <= 0) return GSN_OK;
     {   // summed embeddings of enough rows: the one-hot product on the matrix pipe (GSN_EMBED_BWD_LDS=1: the LDS-accumulating kernel)
-        static const bool lds_only = [] { const char *e = getenv("GSN_EMBED_BWD_LDS"); return e && e[0] == '1'; }();
         int64_t rtot = 0;
-        bool small_tables = n_cols <= EMB_MAXC;
-        for (int c = 0; small_tables && c < n_cols; ++c) { rtot += table_rows[c]; small_tables = table_rows[c] > 0 && table_rows[c] < 0xfffe; }
-        if (!lds_only && !concat && small_tables && rtot <= 4096 && m_rows >= 256) {
+        if (embed_bwd_mfma_fits(m_rows, n_cols, concat, table_rows, &rtot)) {
             EmbMArgs a{};
             a.m_rows = m_rows; a.n_cols = n_cols; a.d = d; a.rtot = (int)rtot; a.codes = codes; a.meta = grad_meta; a.gout = grad_out;
+            a.gflat = grad_flat;
+            for (int c = 0; c < n_cols && grad_flat; ++c) a.goff[c] = table_offsets[c];
             a.row_off[0] = 0;
             for (int c = 0; c < n_cols; ++c) a.row_off[c + 1] = a.row_off[c] + (int)table_rows[c];
             a.tn = (int)((rtot + EMBM_T - 1) / EMBM_T); a.tk = (d + EMBM_T - 1) / EMBM_T;
@@ -820,8 +867,11 @@ extern "C" int gsn_embed_bwd_hip(int64_t m_rows, int n_cols, int d, int concat, 
     if (embed_lds_fits(n_cols, table_rows)) {
         EmbArgs a{};
         a.m_rows = m_rows; a.n_cols = n_cols; a.d = d; a.concat = concat; a.codes = codes; a.meta = grad_meta; a.gout = grad_out;
+        a.gflat = grad_flat;
+        for (int c = 0; c < n_cols && grad_flat; ++c) a.goff[c] = table_offsets[c];
         return launch_embed_lds<true>(a, table_rows, reinterpret_cast<hipStream_t>(stream));
     }
+    if (!grad_meta) return set_error(GSN_E_UNSUPPORTED, "gsn_embed_bwd_flat_hip: tables outside the flat variant");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     for (int c = 0; c < n_cols; ++c)
         hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for(m_rows * d)), dim3(256), 0, s, m_rows, n_cols, d, concat, codes, grad_meta,

@@ -228,6 +228,7 @@ def _table_meta(tables, device):
 # its event has completed -- at the next embedding call, in the backward, or by check_embedding_status() -- i.e. the IndexError arrives
 # one call late, like any asynchronous device error.  GSN_EMBED_STATUS_SYNC=1 checks at once.
 EMBED_STATUS_SYNC = os.environ.get("GSN_EMBED_STATUS_SYNC", "0") == "1"
+EMBED_BWD_FLAT = os.environ.get("GSN_EMBED_BWD_FLAT", "1") != "0"      # (0: gradient tables through a device pointer array, A/B)
 _PENDING_STATUS = []
 _STATUS_RING, _STATUS_NEXT = None, 0
 
@@ -316,16 +317,32 @@ class _EmbedFn(torch.autograd.Function):
         # gradient tables: ONE zero fill for all of them (nine tables of the atom encoder: nine launches otherwise); offsets rounded to
         # 16 bytes so that every table keeps the alignment of a tensor of its own
         sizes = [(s[0] * s[1] + 3) // 4 * 4 for s in ctx.shapes]
-        # (its own allocation, not the zero arena: the caching allocator hands a step the addresses of the step before, which keeps the
-        #  pointer arrays of _table_meta cached -- arena slices move every step)
-        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
-        grads, o = [], 0
+        rows = np.ascontiguousarray([s[0] for s in ctx.shapes], dtype=np.int64)
+        g = gout.to(torch.float32).contiguous()
+        with _abi.device_guard(dev):
+            flat_ok = EMBED_BWD_FLAT and bool(_abi.lib().gsn_embed_bwd_flat_supported(max(M, 1), C, int(ctx.concat), _abi.ptr(rows)))
+        if flat_ok:
+            # the tables' addresses as launch arguments (base + host offsets): no device pointer array -- no copy per call, no memcpy node per
+            # embedding in a captured step -- and therefore nothing that needs the tables at the addresses of the step before: zeros from the arena
+            from .layers import _zeros
+            flat = _zeros(sum(sizes), torch.float32, dev)
+        else:
+            # (its own allocation, not the zero arena: the caching allocator hands a step the addresses of the step before, which keeps the
+            #  pointer arrays of _table_meta cached -- arena slices move every step)
+            flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        grads, offs, o = [], [], 0
         for s_, n_ in zip(ctx.shapes, sizes):
             grads.append(flat[o:o + s_[0] * s_[1]].view(s_))
+            offs.append(o)
             o += n_
+        if flat_ok:
+            offs = np.ascontiguousarray(offs, dtype=np.int64)
+            with _abi.device_guard(dev):
+                rc = _abi.lib().gsn_embed_bwd_flat_hip(M, C, d, int(ctx.concat), codes.data_ptr() if M else None, flat.data_ptr(),
+                                                       _abi.ptr(offs), _abi.ptr(rows), g.data_ptr() if M else None, _abi.current_stream())
+            _abi.check(rc, "gsn_embed_bwd_flat_hip")
+            return (None, None) + tuple(grads)
         meta = _table_meta(grads, dev)
-        g = gout.to(torch.float32).contiguous()
-        rows = np.ascontiguousarray([s[0] for s in ctx.shapes], dtype=np.int64)
         with _abi.device_guard(dev):
             rc = _abi.lib().gsn_embed_bwd_hip(M, C, d, int(ctx.concat), codes.data_ptr() if M else None, meta.data_ptr(),
                                               _abi.ptr(rows), g.data_ptr() if M else None, _abi.current_stream())

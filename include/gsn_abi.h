@@ -511,6 +511,15 @@ int gsn_embed_fwd_hip(int64_t m_rows, int n_cols, int d, int concat, const int64
                       const int64_t *table_rows, float *out, int32_t *status, void *stream);
 int gsn_embed_bwd_hip(int64_t m_rows, int n_cols, int d, int concat, const int64_t *codes, const int64_t *grad_meta,
                       const int64_t *table_rows, const float *grad_out, void *stream);
+/* The same backward with the gradient tables inside ONE caller-zeroed device allocation: table c starts at grad_flat +
+ * table_offsets[c] floats (table_offsets, table_rows: HOST arrays [C]).  The table addresses travel as launch arguments: no device pointer
+ * array, so no host-to-device copy per call and no memcpy node per embedding in a captured training step (utils_graph_learning.py:134-167
+ * under train_test_funcs.py:88-106 at the reference's batch sizes).  gsn_embed_bwd_flat_supported: 1 when the shape is handled (<= 16
+ * code columns; tables that fit the LDS slices or the matrix-pipe product), else 0 and gsn_embed_bwd_flat_hip returns
+ * GSN_E_UNSUPPORTED -- use gsn_embed_bwd_hip then. */
+int gsn_embed_bwd_flat_supported(int64_t m_rows, int n_cols, int concat, const int64_t *table_rows);
+int gsn_embed_bwd_flat_hip(int64_t m_rows, int n_cols, int d, int concat, const int64_t *codes, float *grad_flat,
+                           const int64_t *table_offsets, const int64_t *table_rows, const float *grad_out, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * First Linear of msg_fn over one-hot encoded inputs as a weight-row gather with fused bias / BatchNorm / activation

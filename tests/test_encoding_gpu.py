@@ -207,3 +207,44 @@ def test_summed_embedding_backward_on_the_matrix_pipe(m_rows, dims, d):
         bound = torch.zeros(p.shape, dtype=torch.float64, device="cuda").index_add_(0, codes[:, c], g.double().abs())
         err = ((p.grad.double() - ref).abs() / bound.clamp_min(1e-300)).max().item()
         assert err <= 3e-7 * max(1.0, (m_rows / dims[c]) ** 0.5), (name, err)
+
+
+@pytest.mark.parametrize("m_rows,dims,d,concat", [(32, [1], 300, False), (837, [119, 4, 12, 12, 10, 6, 6, 2, 2], 300, False), (1720, [5, 6, 2], 300, False),
+                                                  (1720, [3, 9, 2, 2, 5, 7], 64, True), (300, [500, 7], 32, False), (100, [5000], 16, False), (0, [4, 4], 8, False)])
+def test_embedding_backward_with_the_tables_as_launch_arguments(m_rows, dims, d, concat, monkeypatch):
+    """gsn_embed_bwd_flat_hip (gradient tables inside one zeroed allocation, base + host offsets as launch arguments: no device pointer array)
+    against gsn_embed_bwd_hip on the same inputs and against an fp64 index_add: the LDS-accumulating kernel (few rows), the matrix-pipe
+    product (>= 256 rows), concatenated tables, and shapes the flat variant refuses (tables beyond LDS below 256 rows, > 4096 table rows),
+    where the module falls back to the pointer-array entry point."""
+    from gsn_amd import _abi
+    torch.manual_seed(m_rows + d)
+    aggr = "concat" if concat else "sum"
+    m = encoding.multi_embedding(list(dims), d, aggr).cuda()
+    codes = torch.stack([torch.randint(0, n, (m_rows,)) for n in dims], 1).cuda()
+    g = torch.randn(m_rows, d * (len(dims) if concat else 1), device="cuda")
+    rows = np.ascontiguousarray(dims, dtype=np.int64)
+    supported = bool(_abi.lib().gsn_embed_bwd_flat_supported(max(m_rows, 1), len(dims), int(concat), _abi.ptr(rows)))
+    assert supported == (len(dims) <= 16 and (sum(dims) <= 448 or (not concat and sum(dims) <= 4096 and m_rows >= 256)))
+    got = {}
+    for flat in (True, False):
+        monkeypatch.setattr(encoding, "EMBED_BWD_FLAT", flat)
+        m.zero_grad(set_to_none=True)
+        m(codes).backward(g)
+        got[flat] = [p.grad.clone() for p in m.parameters()]
+    for c, p in enumerate(m.parameters()):
+        gc = (g[:, c * d:(c + 1) * d] if concat else g).double()
+        ref = torch.zeros(p.shape, dtype=torch.float64, device="cuda").index_add_(0, codes[:, c], gc)
+        bound = torch.zeros(p.shape, dtype=torch.float64, device="cuda").index_add_(0, codes[:, c], gc.abs()).clamp_min(1e-300)
+        for flat in (True, False):
+            err = ((got[flat][c].double() - ref).abs() / bound).max().item()
+            assert err <= 3e-7 * max(1.0, (max(m_rows, 1) / dims[c]) ** 0.5), (flat, c, err)
+    if supported:
+        return
+    # asked for a shape it does not handle, the flat entry point refuses and touches nothing
+    flat_buf = torch.zeros(sum(n * d for n in dims), device="cuda")
+    offs = np.ascontiguousarray(np.cumsum([0] + [n * d for n in dims[:-1]]), dtype=np.int64)
+    rc = _abi.lib().gsn_embed_bwd_flat_hip(m_rows, len(dims), d, int(concat), codes.data_ptr(), flat_buf.data_ptr(), _abi.ptr(offs), _abi.ptr(rows),
+                                           g.data_ptr(), _abi.current_stream())
+    assert rc != 0
+    torch.cuda.synchronize()
+    assert float(flat_buf.abs().max()) == 0.0
