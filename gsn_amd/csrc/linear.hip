@@ -617,7 +617,9 @@ __global__ __launch_bounds__(256) void linear_fwd_bf16_small_kernel(LinArgs a, i
     // wave, far shorter than a round trip to L2: one slice ahead left the kernel waiting for its loads in every iteration)
     constexpr int SD = 3;
     float preAs[SD][4], preWs[SD][16];
-    // WT (a transposed view of a row-major matrix, w_rs = 1): output column jj of W^T rows k0 + 2 i -- the lanes walk the contiguous direction
+    // WT (a transposed view of a row-major matrix, w_rs = 1): output column jj of W^T rows 16 k0 .. 16 k0 + 15 -- the lanes walk the contiguous
+    // direction, and a thread's sixteen values are the 32 contiguous bytes of a plane row: two 16-byte LDS writes per plane (a thread with
+    // every other row k0 + 2 i wrote 48 two-byte pieces per slice -- the slice time of these launches is their instruction count, one wave per SIMD)
     const int jj = tid & 127, k0 = tid >> 7;
     auto fetch = [&](float *preA, float *preW, int c) {
         const ColMapL cm = col_map_l(a, c * BK + kc);
@@ -642,7 +644,7 @@ __global__ __launch_bounds__(256) void linear_fwd_bf16_small_kernel(LinArgs a, i
             const int j = n0 + jj < a.n_out ? n0 + jj : 0;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int kgi = c * BK + k0 + 2 * i;
+                const int kgi = c * BK + 16 * k0 + i;
                 preW[i] = a.W[(int64_t)j * a.w_rs + (int64_t)(kgi < a.k_total ? kgi : 0) * a.w_cs];
             }
             return;
@@ -694,16 +696,26 @@ __global__ __launch_bounds__(256) void linear_fwd_bf16_small_kernel(LinArgs a, i
             pa[8 * i * BKP + 4 * SAPLANE] = (unsigned short)(l >> 16);
         }
         if (WT) {
-            unsigned short *pt = reinterpret_cast<unsigned short *>(w_planes(buf)) + jj * BKP + k0;
+            float *pt = w_planes(buf) + (jj * BKP + 16 * k0) / 2;       // (80-byte rows, 32-byte halves: 16-byte aligned)
             const bool jok = n0 + jj < a.n_out;
+            unsigned h[16], m[16], l[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                unsigned h, m, l;
-                const float jm = (jok && c * BK + k0 + 2 * i < a.k_total) ? 1.f : 0.f;
-                split3l(preW[i] * jm, h, m, l);
-                pt[2 * i] = (unsigned short)(h >> 16);
-                pt[2 * i + 2 * BPLANE] = (unsigned short)(m >> 16);
-                pt[2 * i + 4 * BPLANE] = (unsigned short)(l >> 16);
+                const float jm = (jok && c * BK + 16 * k0 + i < a.k_total) ? 1.f : 0.f;
+                split3l(preW[i] * jm, h[i], m[i], l[i]);
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                u32x4l vh, vm, vl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    vh[e] = pack2(h[8 * q + 2 * e], h[8 * q + 2 * e + 1]);
+                    vm[e] = pack2(m[8 * q + 2 * e], m[8 * q + 2 * e + 1]);
+                    vl[e] = pack2(l[8 * q + 2 * e], l[8 * q + 2 * e + 1]);
+                }
+                *reinterpret_cast<u32x4l *>(pt + 4 * q) = vh;
+                *reinterpret_cast<u32x4l *>(pt + 4 * q + BPLANE) = vm;
+                *reinterpret_cast<u32x4l *>(pt + 4 * q + 2 * BPLANE) = vl;
             }
             return;
         }
