@@ -641,11 +641,23 @@ __global__ __launch_bounds__(256) void linear_fwd_bf16_small_kernel(LinArgs a, i
 #pragma unroll
         for (int i = 0; i < 4; ++i) preA[i] = cm.base[(int64_t)rp[8 * i] * cm.bw];
         if (WT) {
-            const int j = n0 + jj < a.n_out ? n0 + jj : 0;
+            // 32-bit BYTE offsets from the matrix base (the launcher takes this instantiation only when the view spans < 4 GiB): a load is
+            // base (scalar) + offset (one register), the next row one add -- a 64-bit multiply per element was ~100 of a slice's ~400 vector
+            // instructions, and with one wave per SIMD a slice's time IS its instruction count
+            const unsigned j = n0 + jj < a.n_out ? (unsigned)(n0 + jj) : 0u;
+            const int kb = c * BK + 16 * k0;
+            const unsigned cs4 = 4u * (unsigned)a.w_cs;
+            const char *wb = reinterpret_cast<const char *>(a.W);
+            if (kb + 16 <= a.k_total) {                 // (wave-uniform)
+                unsigned off = 4u * j * (unsigned)a.w_rs + (unsigned)kb * cs4;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int kgi = c * BK + 16 * k0 + i;
-                preW[i] = a.W[(int64_t)j * a.w_rs + (int64_t)(kgi < a.k_total ? kgi : 0) * a.w_cs];
+                for (int i = 0; i < 16; ++i) { preW[i] = *reinterpret_cast<const float *>(wb + off); off += cs4; }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int kgi = kb + i;
+                    preW[i] = *reinterpret_cast<const float *>(wb + (4u * j * (unsigned)a.w_rs + (unsigned)(kgi < a.k_total ? kgi : 0) * cs4));
+                }
             }
             return;
         }
@@ -900,7 +912,7 @@ static int linear_fwd_impl(int64_t m_rows, int n_blocks, const gsn_block *blocks
         static const int small_max = [] { const char *d = getenv("GSN_LINEAR_SMALL_MAX"); return d ? atoi(d) : 96; }();
         if (bf16x6 && n_tiles * col_tiles <= small_max) {
             if (vec4) return stats ? launch_linear_bf16_small<true, true>(a, k_pad, col_tiles, st) : launch_linear_bf16_small<false, true>(a, k_pad, col_tiles, st);
-            if (strided && w_rs < w_cs)     // a transposed view: staged along its contiguous direction
+            if (strided && w_rs < w_cs && ((n_out - 1) * w_rs + (int64_t)(k_total - 1) * w_cs) < (int64_t(1) << 30))     // a transposed view: staged along its contiguous direction (32-bit byte offsets)
                 return stats ? launch_linear_bf16_small<true, false, true>(a, k_pad, col_tiles, st) : launch_linear_bf16_small<false, false, true>(a, k_pad, col_tiles, st);
             return stats ? launch_linear_bf16_small<true, false>(a, k_pad, col_tiles, st) : launch_linear_bf16_small<false, false>(a, k_pad, col_tiles, st);
         }
