@@ -38,6 +38,10 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+
+#ifndef RR_STORE_AUX
+#define RR_STORE_AUX 2        // cache policy bits of the output stores (2: nt -- the rows are written once and read by the NEXT launch; as in layer_rp.hip)
+#endif
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -623,7 +627,7 @@ __global__ __launch_bounds__(64 * RR_NW) __attribute__((amdgpu_waves_per_eu(RR_N
                             asm volatile("" :: "v"(y));
                             if (false)
 #endif
-                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), orow, voff_lane + ((r & 3) + 8 * (r >> 2)) * (32 * WB * 4) + 32 * (fp + u) * 4, 0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), orow, voff_lane + ((r & 3) + 8 * (r >> 2)) * (32 * WB * 4) + 32 * (fp + u) * 4, 0, RR_STORE_AUX);
                         }
                     };
                     if (anybad) put(std::true_type{}); else put(std::false_type{});
