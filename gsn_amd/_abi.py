@@ -127,6 +127,9 @@ SIGNATURES = {
     "gsn_layer_fused_workspace_bytes": (c_i64, [c_i64, ctypes.POINTER(gsn_chain_stage), c_i64, ctypes.POINTER(gsn_chain_stage), ctypes.POINTER(gsn_chain_stage)]),
     "gsn_layer_fused_fwd_ws_hip": (c_int, [c_i64, c_i64, c_vp, ctypes.POINTER(gsn_chain_stage), c_vp, c_i64, ctypes.POINTER(gsn_chain_stage),
                                            ctypes.POINTER(gsn_chain_stage), c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "gsn_layer_fused_graphs_supported": (c_int, [ctypes.POINTER(gsn_chain_stage), c_i64, ctypes.POINTER(gsn_chain_stage), ctypes.POINTER(gsn_chain_stage)]),
+    "gsn_layer_fused_fwd_graphs_hip": (c_int, [c_i64, c_i64, c_vp, ctypes.POINTER(gsn_chain_stage), c_vp, c_i64, ctypes.POINTER(gsn_chain_stage),
+                                               ctypes.POINTER(gsn_chain_stage), c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),
     "gsn_mlp_chain_fwd_hip": (c_int, [c_i64, c_int, ctypes.POINTER(gsn_chain_stage), c_vp, c_vp, c_vp, c_vp, c_vp]),
 }
 

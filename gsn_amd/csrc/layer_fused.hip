@@ -51,6 +51,7 @@
 #include "chain_common.h"
 #include "layer_rr.h"
 #include "layer_w.h"
+#include "layer_g.h"
 
 namespace gsn {
 
@@ -1155,6 +1156,26 @@ static int lf_forward(int64_t n_nodes, int64_t n_edges, const int32_t *seg_ptr, 
     if (w64) return lf_launch<5, 6, 4, 2>(a, st);
     if (k0 <= 96) return k1 <= 64 ? lf_launch<5, 6, 4>(a, st) : lf_launch<5, 6, 8>(a, st);
     return k1 <= 64 ? lf_launch<5, 10, 4>(a, st) : lf_launch<5, 10, 8>(a, st);
+}
+
+// ---- the d = 128 layer on graph-aligned tiles (layer_g.hip): same shapes, same prepared buffer as the d = 128 kernel above ------------
+extern "C" int gsn_layer_fused_graphs_supported(const gsn_chain_stage *edge, int64_t d_x, const gsn_chain_stage *node0,
+                                                const gsn_chain_stage *node1) {
+    if (!edge || !node0 || !node1) return 0;
+    return g_supported(edge, d_x, node0, node1);
+}
+
+extern "C" int gsn_layer_fused_fwd_graphs_hip(int64_t n_nodes, int64_t n_edges, const int32_t *seg_ptr, const gsn_chain_stage *edge,
+                                              const float *x, int64_t d_x, const gsn_chain_stage *node0, const gsn_chain_stage *node1,
+                                              const void *prepared, int64_t n_graphs, const int64_t *node_ptr, int64_t max_nodes,
+                                              float *out, void *stream) {
+    if (!gsn_layer_fused_graphs_supported(edge, d_x, node0, node1))
+        return set_error(GSN_E_UNSUPPORTED, "gsn_layer_fused_fwd_graphs_hip: shape outside the graph-aligned d = 128 kernel");
+    if (!seg_ptr || !x || !out || !prepared || !node_ptr) return set_error(GSN_E_INVALID, "gsn_layer_fused_fwd_graphs_hip: null seg_ptr / x / out / prepared / node_ptr");
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(prepared)) & 15) return set_error(GSN_E_INVALID, "gsn_layer_fused_fwd_graphs_hip: x and prepared must be 16-byte aligned");
+    if (n_nodes > (int64_t)2000000000 || n_edges > (int64_t)2000000000 || n_graphs > (int64_t)2000000000) return set_error(GSN_E_UNSUPPORTED, "gsn_layer_fused_fwd_graphs_hip: 32-bit row arithmetic");
+    if (n_nodes <= 0) return GSN_OK;
+    return g_forward(n_nodes, n_edges, seg_ptr, edge, x, d_x, node0, node1, prepared, n_graphs, node_ptr, max_nodes, out, reinterpret_cast<hipStream_t>(stream));
 }
 
 // ---- the register-resident layer on exact fp16 row packs (layer_rp.hip) ------------------------------------------------------------

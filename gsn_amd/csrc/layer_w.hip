@@ -48,40 +48,6 @@
 
 namespace gsn {
 
-constexpr int W_TN = 32;           // nodes per tile
-constexpr int W_UE = 64;           // edge rows per unit (two sub-blocks of 32)
-constexpr int W_DX = 128;          // node row width
-constexpr int W_NXC = W_DX / 16;   // chunks of a node row
-constexpr int W_NST = 2 * W_NXC + 1;   // chunk steps of the edge stage: the per-edge chunk first, then x_i, x_j
-constexpr int W_MAXROLE = 3;
-constexpr int W_HDR = 32;
-constexpr unsigned W_MAGIC = 0x57573031u;
-#ifndef W_SD_N
-#define W_SD_N 4
-#endif
-constexpr int W_SD = W_SD_N;       // chunk steps a wave's share of the node-stage fragments is requested ahead of its write to the ring
-constexpr int W_PDG = 2;           // gathered chunks in flight ahead of the one being converted
-
-enum { WH_MAGIC = 0, WH_EE = 1, WH_E0 = 2, WH_E1 = 3, WH_EMIN = 4, WH_BAD = 5, WH_ACT = 6 };
-
-struct WShape {
-    static constexpr int WB = 4;
-    static constexpr int NKS = 2 * WB;                       // chunks of S / of the hidden rows
-    static constexpr int NK0 = NKS + W_NXC;                  // chunks of node stage 0 ([S | x]; deg enters with the bias)
-    static constexpr int F_WE = 0;                           // edge stage [step][fb][plane]                      (LDS)
-    static constexpr int F_LDS = F_WE + W_NST * WB * 2;
-    static constexpr int F_W0 = F_LDS;                       // node stage 0 [c][fbo][plane], c < NK0             (streamed)
-    static constexpr int F_W1 = F_W0 + NK0 * WB * 2;         // node stage 1 [c][fb][plane]                       (streamed)
-    static constexpr int F_WB = F_W1 + NKS * WB * 2;         // node stage 0's (c0, deg column) as bf16 planes [fbo]   (read per tile)
-    static constexpr int F_ALL = F_WB + WB;
-    static constexpr int N_STREAM = F_WB - F_LDS;
-    static constexpr int TAB_WORDS = 4 * 32 * WB;            // c0 of the edge stage (matrix units), c0 of node stage 0, its deg column, c0 of node stage 1
-    static constexpr int LDS_BYTES = F_LDS * 1024 + 3 * 8192;     // the edge stage's fragments + a three-slot ring of node-stage chunk steps
-    static constexpr int PREP_WORDS = W_HDR + F_ALL * 256 + TAB_WORDS;
-};
-
-struct WQuad { unsigned long long base; unsigned stride, role; };
-
 struct WArgs {
     int n_nodes, n_edges;
     const int32_t *seg_ptr;

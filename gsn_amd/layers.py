@@ -184,7 +184,7 @@ class _CSR:
     """Target-sorted CSR of one aggregation index.  ``deg`` / ``deg4`` (in-degree as a float column, and the same padded to
     four columns) are only needed by the multi-launch path of the `general` layers and are built on first use: the one-launch
     layer kernel takes the degrees from ``seg_ptr`` itself."""
-    __slots__ = ("seg_ptr", "perm", "tgt", "src", "_deg", "_deg4")
+    __slots__ = ("seg_ptr", "perm", "tgt", "src", "_deg", "_deg4", "part")
 
     @property
     def deg(self):
@@ -349,6 +349,7 @@ def _csr_for(edge_index, row, n_nodes):
         return c
     c = _CSR()
     part = _partition_of(edge_index)
+    c.part = part                           # (graph boundaries of a collated batch: the graph-aligned d = 128 layer kernel reads them)
     if part is not None:
         c.seg_ptr, c.perm, c.tgt, c.src = build_csr_graphs(edge_index[row], n_nodes, part[0], part[1], part[2], part[3],
                                                            other=edge_index[1 - row], check=part[4])
@@ -963,6 +964,7 @@ def _prep_key(st):
 CHAIN_ROW_EXPONENTS = os.environ.get("GSN_CHAIN_ROW_EXP", "1") != "0"      # 128-wide one-launch layers leave their output's row exponents for the next layer
 
 
+GRAPH_ALIGNED_LAYER = os.environ.get("GSN_LAYER_GRAPHS", "1") != "0"   # d = 128 layers of a collated batch: node products on graph-aligned tiles (csrc/layer_g.hip)
 PACK16_LAYER = os.environ.get("GSN_LAYER_PACK16", "1") != "0"   # tagged exact inputs: the packed-row kernel (csrc/layer_rp.hip)
 
 
@@ -1042,6 +1044,18 @@ def _layer_fused(x, csr, edge_stages, node_stages, training, owner=None, gen=0, 
                                                      _abi.current_stream()), "gsn_layer_fused_prepare_hip")
         if owner is not None:
             owner._fused_prep = (key, prep)
+    # a collated batch with known graph boundaries, every graph <= 128 vertices: the d = 128 layer on graph-aligned tiles (csrc/layer_g.hip:
+    # the node part of the edge stage once per node); same prepared buffer, no workspace, no row exponents
+    part = getattr(csr, "part", None)
+    if (GRAPH_ALIGNED_LAYER and part is not None and d_x == 128 and part[2] <= 128 and int(part[0].numel()) > 1
+            and L.gsn_layer_fused_graphs_supported(ctypes.byref(ge), d_x, ctypes.byref(g0), ctypes.byref(g1))):
+        with _abi.device_guard(x.device), _timed("layer_fused", flops):
+            rc = L.gsn_layer_fused_fwd_graphs_hip(n, E, csr.seg_ptr.data_ptr(), ctypes.byref(ge), x.data_ptr(), d_x, ctypes.byref(g0),
+                                                  ctypes.byref(g1), prep.data_ptr(), int(part[0].numel()) - 1, part[0].data_ptr(), int(part[2]),
+                                                  out.data_ptr(), _abi.current_stream())
+        if rc != -2:
+            _abi.check(rc, "gsn_layer_fused_fwd_graphs_hip")
+            return out
     # layers of a d = 128 model hand the row exponents of their output to the next one (csrc/layer_w.hip takes its edge rows' scales from
     # them): kept on the output tensor together with its version counter, used only while the tensor is unchanged
     x_exp = None

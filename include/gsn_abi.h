@@ -363,6 +363,20 @@ int gsn_layer_fused_fwd_ws_hip(int64_t n_nodes, int64_t n_edges, const int32_t *
                                const void *prepared, float *out, void *workspace, int64_t workspace_bytes,
                                const int32_t *x_row_exp, int32_t *out_row_exp, void *stream);
 
+/* The d = 128 shape on GRAPH-ALIGNED tiles (csrc/layer_g.hip): the same layer, the same `prepared` buffer as gsn_layer_fused_fwd_hip for that
+ * shape, for a collated batch whose graph boundaries the caller knows (torch_geometric's Batch.ptr; the pointers of
+ * gsn_csr_build_graphs_hip): graph g owns the consecutive vertices node_ptr[g] .. node_ptr[g+1] and no edge leaves its graph.  The node
+ * part of the edge stage, x [W_i | W_j]^T, is then computed once per NODE (MPNN_edge_sparse.py:139-151 evaluates it once per EDGE:
+ * cat(x_i, x_j, e) W^T), on tiles of whole graphs, and the edge stage is a gather-add of P_i[target] + P_j[source] + z_e W_z^T.
+ * No workspace, no row exponents.  Every graph must have <= 128 vertices (max_nodes, the caller's bound): GSN_E_UNSUPPORTED otherwise --
+ * the caller then uses gsn_layer_fused_fwd_ws_hip.  node_ptr int64 [n_graphs + 1] device, node_ptr[0] = 0, node_ptr[n_graphs] = n_nodes. */
+int gsn_layer_fused_graphs_supported(const gsn_chain_stage *edge, int64_t d_x, const gsn_chain_stage *node0,
+                                     const gsn_chain_stage *node1);
+int gsn_layer_fused_fwd_graphs_hip(int64_t n_nodes, int64_t n_edges, const int32_t *seg_ptr, const gsn_chain_stage *edge,
+                                   const float *x, int64_t d_x, const gsn_chain_stage *node0, const gsn_chain_stage *node1,
+                                   const void *prepared, int64_t n_graphs, const int64_t *node_ptr, int64_t max_nodes,
+                                   float *out, void *stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * HP-2  the same one-launch layer on EXACT fp16 ROW PACKS (csrc/layer_rp.hip).  Layer 0 of every reference model reads one-hot /
  * small-integer encodings (utils_graph_learning.py:78-88, :170-187: DiscreteEmbedding('one_hot_encoder')): every value is exact in
