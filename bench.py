@@ -384,10 +384,33 @@ def float_input_layer(layer, b, ei, dev):
     return {"layer_launch_ms": round(ms, 4)}
 
 
+def g_tiling(node_ptr, seg, n_wg=256, rows=128):
+    """(workgroup tiles, 32-row wave tiles in use, edge rounds) of csrc/layer_g.hip on this batch: every workgroup takes its share of the
+    graphs in runs of whole graphs of <= 128 vertices; a wave's rounds = the largest in-degree among its 32 targets"""
+    G = len(node_ptr) - 1
+    n_wg = min(n_wg, G)
+    deg = np.diff(seg)
+    tiles = wave_tiles = rounds = 0
+    for w in range(n_wg):
+        g, g_end = G * w // n_wg, G * (w + 1) // n_wg
+        while g < g_end:
+            k = max(1, int(np.searchsorted(node_ptr[g + 1:min(g_end, g + 63) + 1], node_ptr[g] + rows, side="right")))
+            n0, n1 = int(node_ptr[g]), int(node_ptr[g + k])
+            tiles += 1
+            for r in range(n0, n1, 32):
+                wave_tiles += 1
+                d = deg[r:min(r + 32, n1)]
+                rounds += int(d.max()) if len(d) else 0
+            g += k
+    return tiles, wave_tiles, rounds
+
+
 def wide_layer(b, ei, dev):
-    """A hidden layer of the d = 128 model on the bench batch (GSN_edge_sparse, d_in = 128, K = 272 edge rows: csrc/layer_w.hip, one
-    launch behind the row-exponent pass).  Executed MFMA flops per launch: one tile of <= 32 nodes / one unit of <= 64 in-edges =
-    744 products of 32 x 32 x 16 (408 edge stage + 48 incidence + 192 + 96 node stages)."""
+    """A hidden layer of the d = 128 model on the bench batch (GSN_edge_sparse, d_in = 128, K = 272 edge rows), on the collated batch with
+    its graph boundaries registered (what gsn_amd.models does): csrc/layer_g.hip -- node products once per node on tiles of whole graphs.
+    Executed MFMA flops per launch: per 32-row wave tile 288 (x against [Wj | Wi | W0x]) + 100 (S part of node stage 0 with its bias
+    product) + 96 (node stage 1) products of 32 x 32 x 16, + 12 per edge round.  `layer_w`: the same layer on csrc/layer_w.hip (edge
+    rows multiplied by all 272 columns; the kernel of a batch without registered boundaries or with a graph above 128 vertices)."""
     import torch
     from gsn_amd import layers
     N, E = b.num_nodes, b.num_edges
@@ -400,24 +423,46 @@ def wide_layer(b, ei, dev):
     ctor = dict(d_in=128, d_ef=4, d_id=12, d_degree=1, degree_as_tag=False, retain_features=True, id_scope="local", d_msg=128, d_up=128,
                 d_h=[128], seed=0, activation_name="relu", bn=True, msg_kind="general", flow="source_to_target")
     layer = layers.GSN_edge_sparse(**ctor).to(dev).eval()
-    with torch.no_grad():
-        spin_up(lambda: layer(x, ei, identifiers=ids, degrees=deg, edge_features=ef))
-        layers.KERNEL_TIMER = {}
-        for _ in range(10):
-            layer(x, ei, identifiers=ids, degrees=deg, edge_features=ef)
-        torch.cuda.synchronize()
-    evs = layers.KERNEL_TIMER.get("layer_fused", [])
-    layers.KERNEL_TIMER = None
-    if not evs:
-        return {"error": "the layer did not take the one-launch path"}
-    ms = sum(e0.elapsed_time(e1) for e0, e1, _ in evs) / len(evs)
+    eiw = ei.clone()
+    layers.set_graph_partition(eiw, torch.from_numpy(b.node_ptr).to(dev), torch.from_numpy(b.edge_ptr).to(dev),
+                               int(np.diff(b.node_ptr).max()), int(np.diff(b.edge_ptr).max()))
+    out = {}
+    ys = {}
+    for name, flag in (("g", True), ("w", False)):
+        was = layers.GRAPH_ALIGNED_LAYER
+        layers.GRAPH_ALIGNED_LAYER = flag
+        try:
+            with torch.no_grad():
+                spin_up(lambda: layer(x, eiw, identifiers=ids, degrees=deg, edge_features=ef))
+                layers.KERNEL_TIMER = {}
+                for _ in range(10):
+                    ys[name] = layer(x, eiw, identifiers=ids, degrees=deg, edge_features=ef)
+                torch.cuda.synchronize()
+            evs = layers.KERNEL_TIMER.get("layer_fused", [])
+        finally:
+            layers.KERNEL_TIMER = None
+            layers.GRAPH_ALIGNED_LAYER = was
+        if not evs:
+            return {"error": "the layer did not take the one-launch path"}
+        out[name] = sum(e0.elapsed_time(e1) for e0, e1, _ in evs) / len(evs)
+    ms = out["g"]
     b_alg = 16.0 * E + 4.0 * (N * 128 + E * 16 + N * 128)
     seg = np.concatenate([[0], np.cumsum(np.bincount(b.edge_index[1], minlength=N))])
+    tiles, wave_tiles, rounds = g_tiling(np.asarray(b.node_ptr), seg)
+    f_exec = 32768.0 * (wave_tiles * 484 + rounds * 12)
     n_t, n_b = rr_tiling(seg, N, grid=128, unit=64)
-    f_exec = 32768.0 * (n_b * 456 + n_t * 288)
-    return {"ms": round(ms, 4), "algorithmic_bytes": int(b_alg), "hbm_GBs": round(b_alg / ms / 1e6, 1), "hbm_frac": round(b_alg / ms / 1e6 / 8000.0, 4),
-            "mfma_executed_TFLOPs": round(f_exec / ms / 1e9, 1), "mfma_frac": round(f_exec / ms / 1e9 / 2500.0, 4), "units": int(n_b), "tiles": int(n_t),
-            "note": "row-exponent pass + layer_fused_kernel_w, HIP events around both"}
+    f_exec_w = 32768.0 * (n_b * 456 + n_t * 288)
+    ref = ys["w"]
+    same = bool(((ys["g"] - ref).abs() <= 1e-5 * ref.abs() + 1e-5 * ref.abs().amax(dim=1, keepdim=True)).all())
+    return {"ms": round(ms, 4), "kernel": "layer_fused_kernel_g", "algorithmic_bytes": int(b_alg), "hbm_GBs": round(b_alg / ms / 1e6, 1),
+            "hbm_frac": round(b_alg / ms / 1e6 / 8000.0, 4), "mfma_executed_TFLOPs": round(f_exec / ms / 1e9, 1),
+            "mfma_frac": round(f_exec / ms / 1e9 / 2500.0, 4), "workgroup_tiles": int(tiles), "wave_tiles": int(wave_tiles),
+            "row_occupancy": round(N / (32.0 * wave_tiles), 4), "edge_rounds": int(rounds),
+            "layer_w": {"ms": round(out["w"], 4), "hbm_frac": round(b_alg / out["w"] / 1e6 / 8000.0, 4),
+                        "mfma_executed_TFLOPs": round(f_exec_w / out["w"] / 1e9, 1), "mfma_frac": round(f_exec_w / out["w"] / 1e9 / 2500.0, 4),
+                        "note": "row-exponent pass + layer_fused_kernel_w, HIP events around both"},
+            "equal_to_layer_w_elementwise_1e-5": same,
+            "note": "graph boundaries registered (layers.set_graph_partition); one launch, HIP events around it"}
 
 
 def train_step_config4(dev):

@@ -248,6 +248,173 @@ def test_fused_layer_wide_rows_non_finite():
     assert _elementwise_ok(y[~bad], ref[~bad])
 
 
+def _run_graphs(cls, ctor, b, x, ids, ef, seed, capfd, expect="layer_fused_kernel_g "):
+    """the layer on a collated batch whose graph boundaries are registered (layers.set_graph_partition): csrc/layer_g.hip where every
+    graph has <= 128 vertices -> (graph-aligned output, output of csrc/layer_w.hip on the same inputs, oracle)"""
+    from gsn_amd import layers
+    from oracle import oracle
+    ei = torch.from_numpy(b.edge_index)
+    torch.manual_seed(seed)
+    layer = getattr(layers, cls)(**ctor)
+    _randomise_bn(layer, seed + 1)
+    layer.eval()
+    sd = {k: v.clone() for k, v in layer.state_dict().items()}
+    kw = dict(identifiers=ids, degrees=None)
+    if ef is not None:
+        kw["edge_features"] = ef
+    ref = oracle.layer_forward(cls, ctor, sd, x, ei, training=False, **kw)
+    layer.cuda()
+    eic = ei.cuda()
+    kwg = dict(identifiers=None if ids is None else ids.cuda(), degrees=torch.zeros(x.shape[0], device="cuda"))
+    if ef is not None:
+        kwg["edge_features"] = ef.cuda()
+    mn, me = int(np.diff(b.node_ptr).max()), int(np.diff(b.edge_ptr).max())
+    assert layers.set_graph_partition(eic, torch.from_numpy(b.node_ptr).cuda(), torch.from_numpy(b.edge_ptr).cuda(), mn, me)
+    outs = []
+    for flag in (True, False):
+        was = layers.GRAPH_ALIGNED_LAYER
+        layers.GRAPH_ALIGNED_LAYER = flag
+        os.environ["GSN_CHAIN_TRACE"] = "1"
+        try:
+            layers._CSR_CACHE.clear()
+            with torch.no_grad():
+                outs.append(layer(x.cuda(), eic, **kwg).cpu())
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("GSN_CHAIN_TRACE", None)
+            layers.GRAPH_ALIGNED_LAYER = was
+        err = capfd.readouterr().err
+        assert (expect if flag else "layer_fused_kernel_w ") in err, err[-400:]
+    return outs[0], outs[1], ref
+
+
+@pytest.mark.parametrize("cls,ctor_kw,d_id,d_ef", WIDE)
+@pytest.mark.parametrize("n_graphs", [1, 7, 300])
+def test_graph_aligned_wide_layer(cls, ctor_kw, d_id, d_ef, n_graphs, capfd):
+    """d_x = 128 on a collated batch with registered graph boundaries: csrc/layer_g.hip (node products once per node on tiles of whole
+    graphs), every class / id scope of the d = 128 kernel, against the oracle and against csrc/layer_w.hip"""
+    b, _, _, _ = _zinc(n_graphs, seed=41 + n_graphs)
+    g = torch.Generator().manual_seed(13)
+    N, E = b.num_nodes, b.num_edges
+    x = torch.randn(N, 128, generator=g).relu()
+    ctor = _wide_ctor(cls, ctor_kw)
+    ids = torch.randn(N if ctor.get("id_scope") == "global" else E, d_id, generator=g).abs() if d_id else None
+    ef = torch.randn(E, d_ef, generator=g) if d_ef else None
+    y, yw, ref = _run_graphs(cls, ctor, b, x, ids, ef, 9, capfd)
+    assert _elementwise_ok(y, ref), float((y - ref).abs().max() / ref.abs().max())
+    assert _elementwise_ok(y, yw)
+
+
+def _mixed_batch(with_big_graph):
+    from gsn_amd import synth
+    rng = np.random.default_rng(5)
+    graphs = [(5, np.zeros((2, 0), dtype=np.int64)), synth.er_graph(40, 300, 1)]
+    star = np.stack([np.zeros(100, dtype=np.int64), np.arange(1, 101)])
+    graphs.append((128, np.concatenate([star, star[::-1]], axis=1)))                   # a hub with 100 in-edges, a graph of exactly 128 vertices
+    graphs += [synth.zinc_shape_graph(rng) for _ in range(40)]
+    graphs.append(synth.er_graph(128, 1000, 2))
+    graphs.append((70, np.zeros((2, 0), dtype=np.int64)))
+    graphs += [(1, np.zeros((2, 0), dtype=np.int64)) for _ in range(150)]              # more graphs than a tile's window of 63
+    graphs += [synth.zinc_shape_graph(rng) for _ in range(11)]
+    if with_big_graph:
+        graphs.append(synth.er_graph(129, 500, 3))
+    return _graph_batch(graphs)
+
+
+def test_graph_aligned_wide_layer_mixed_magnitudes_hubs(capfd):
+    """row magnitudes 2^-20 .. 2^20, a hub with 100 in-edges (rounds past the prefetched four), edge-less graphs, runs of one-vertex graphs,
+    graphs of exactly 128 vertices, both flows"""
+    b = _mixed_batch(False)
+    g = torch.Generator().manual_seed(19)
+    N, E = b.num_nodes, b.num_edges
+    x = torch.randn(N, 128, generator=g) * torch.exp2(torch.randint(-20, 21, (N, 1), generator=g).float())
+    x[::7] *= torch.logspace(-4, 0, 128)
+    x[5] = 0.0                                                                         # an all-zero row: the bias alone
+    ef = torch.randn(E, 4, generator=g) * torch.exp2(torch.randint(-10, 11, (E, 1), generator=g).float())
+    ids = torch.randint(0, 3, (E, 12), generator=g).float()
+    cls, ctor_kw = WIDE[0][0], WIDE[0][1]
+    for flow in ("source_to_target", "target_to_source"):
+        y, yw, ref = _run_graphs(cls, _wide_ctor(cls, ctor_kw, flow=flow), b, x, ids, ef, 10, capfd)
+        assert _elementwise_ok(y, ref), (flow, float((y - ref).abs().max() / ref.abs().max()))
+
+
+def test_graph_aligned_wide_layer_declines_big_graphs(capfd):
+    """a graph of 129 vertices in the batch: the graph-aligned kernel is not launched, the layer runs on csrc/layer_w.hip (launch trace)"""
+    b = _mixed_batch(True)
+    g = torch.Generator().manual_seed(21)
+    N, E = b.num_nodes, b.num_edges
+    x = torch.randn(N, 128, generator=g)
+    ef = torch.randn(E, 4, generator=g)
+    ids = torch.randn(E, 12, generator=g)
+    cls, ctor_kw = WIDE[0][0], WIDE[0][1]
+    y, yw, ref = _run_graphs(cls, _wide_ctor(cls, ctor_kw), b, x, ids, ef, 12, capfd, expect="layer_fused_kernel_w ")
+    assert _elementwise_ok(y, ref)
+    # and the entry point itself refuses it with GSN_E_UNSUPPORTED
+    from gsn_amd import _abi
+    assert _abi.lib().gsn_layer_fused_fwd_graphs_hip is not None
+
+
+def test_graph_aligned_wide_layer_non_finite(capfd):
+    """an Inf in one node row and a NaN in one edge's features make exactly the output rows that see them NaN"""
+    b, _, _, _ = _zinc(40, seed=77)
+    g = torch.Generator().manual_seed(23)
+    N, E = b.num_nodes, b.num_edges
+    x = torch.randn(N, 128, generator=g)
+    ef = torch.randn(E, 4, generator=g)
+    ids = torch.randn(E, 12, generator=g)
+    x[17, 5] = float("inf")
+    ef[33, 2] = float("nan")
+    cls, ctor_kw = WIDE[0][0], WIDE[0][1]
+    y, yw, ref = _run_graphs(cls, _wide_ctor(cls, ctor_kw), b, x, ids, ef, 11, capfd)
+    bad_ref = ~torch.isfinite(ref).all(dim=1)
+    bad = ~torch.isfinite(y).all(dim=1)
+    assert torch.equal(bad, bad_ref) and bool(bad.any()) and not bool(bad.all())
+    assert bool(torch.isnan(y[bad]).all())
+    assert _elementwise_ok(y[~bad], ref[~bad])
+
+
+def test_graph_aligned_wide_layer_full_size_properties(capfd):
+    """65 536 ZINC-shaped graphs (the bench shape): equal to csrc/layer_w.hip element-wise; the batch is a disjoint union -- the first 1000
+    graphs alone give the same rows bit for bit (another tiling of the same graphs: a tile's rows depend on nothing outside their graphs)"""
+    from gsn_amd import layers
+    b, _, ef, ei = _zinc(65536, seed=78)
+    g = torch.Generator().manual_seed(3)
+    N, E = b.num_nodes, b.num_edges
+    x = torch.randn(N, 128, generator=g).relu().cuda()
+    efc = ef.cuda()
+    torch.manual_seed(0)
+    cls, ctor_kw = WIDE[1][0], WIDE[1][1]
+    layer = getattr(layers, cls)(**_wide_ctor(cls, ctor_kw))
+    _randomise_bn(layer, 5)
+    layer.eval().cuda()
+    eic = ei.cuda()
+    mn, me = int(np.diff(b.node_ptr).max()), int(np.diff(b.edge_ptr).max())
+    layers.set_graph_partition(eic, torch.from_numpy(b.node_ptr).cuda(), torch.from_numpy(b.edge_ptr).cuda(), mn, me)
+    deg = torch.zeros(N, device="cuda")
+    os.environ["GSN_CHAIN_TRACE"] = "1"
+    try:
+        with torch.no_grad():
+            y = layer(x, eic, identifiers=None, degrees=deg, edge_features=efc)
+            torch.cuda.synchronize()
+    finally:
+        os.environ.pop("GSN_CHAIN_TRACE", None)
+    assert "layer_fused_kernel_g " in capfd.readouterr().err
+    was = layers.GRAPH_ALIGNED_LAYER
+    layers.GRAPH_ALIGNED_LAYER = False
+    try:
+        with torch.no_grad():
+            yw = layer(x, eic, identifiers=None, degrees=deg, edge_features=efc)
+    finally:
+        layers.GRAPH_ALIGNED_LAYER = was
+    assert _elementwise_ok(y.cpu(), yw.cpu())
+    n1, e1 = int(b.node_ptr[1000]), int(b.edge_ptr[1000])
+    ei1 = eic[:, :e1].contiguous()
+    layers.set_graph_partition(ei1, torch.from_numpy(b.node_ptr[:1001]).cuda(), torch.from_numpy(b.edge_ptr[:1001]).cuda(), mn, me)
+    with torch.no_grad():
+        y1 = layer(x[:n1].contiguous(), ei1, identifiers=None, degrees=deg[:n1], edge_features=efc[:e1].contiguous())
+    assert torch.equal(y1, y[:n1])
+
+
 def test_fused_layer_full_size_properties():
     """65 536 ZINC-shaped graphs (the bench shape): the fused layer equals the multi-launch path element-wise, and the batch
     is a disjoint union -- the first 1000 graphs alone give the same rows."""
