@@ -579,6 +579,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path is HIP-only; there is no CPU fallback)")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    gdist.require_devices(max(int(os.environ.get("LOCAL_WORLD_SIZE", "1")), local_rank + 1))     # (fails loudly, before any collective)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # launched by torch.distributed.run (also with one process): RCCL is used for the barrier and the max-over-ranks only
@@ -627,32 +628,55 @@ def main():
         packs._pack_rows(ef, epack, 12, -1, True)
         packs.claim(ef, epack, 12)
 
-    def step(fork=True, int64_ids=False):
+    # The headline step takes what the reference path takes and leaves what it leaves: integer atom / bond codes in
+    # (utils_graph_learning.py:170-187 encodes them inside the model), int64 substructure identifiers (utils_ids.py:19-27) AND the layer's
+    # output rows out.  Atom and bond codes go straight into exact fp16 row packs (gsn_one_hot_pack16_hip) inside the step, on the side
+    # stream under the counting kernel; the counting kernel writes the int64 identifiers, their one-hot rows and the packs' identifier
+    # columns.  `prepacked=True` is the step of rounds 2-4 (dense one-hot inputs and their packs made outside the step, no int64
+    # identifiers written): reported as kernels.step_prepacked.
+    xc = layers.Codes(torch.from_numpy(b.atom_type).to(dev), [28])
+    efc = layers.Codes(torch.from_numpy(b.bond_type).to(dev), [4])
+    layers.CODE_STATUS_CHECK = False          # atom / bond codes are in range by construction, counts are clamped
+    epack_c = packs.new_edge_pack(E, dev) if use_pack else None
+    npack_c = packs.new_node_pack(N, dev) if use_pack else None
+
+    def step(fork=True, int64_ids=True, prepacked=not use_pack):
         layers._CSR_CACHE.clear()             # the CSR of a fresh batch is part of the forward pass
         main = torch.cuda.current_stream(dev)
-        if not fork:                          # (the captured variant without a second branch)
-            layers._csr_for(ei, sel, N)
-            with layers._timed("count", 16.0 * E + 4.0 * E * 12):
+        ep = epack if prepacked else epack_c
+
+        def count():
+            # gsn_count_encode_hip: the counts leave the kernel as the int64 identifiers AND as the one-hot rows of min(count, 2) the layer
+            # consumes (the reference: int64 identifiers, then DiscreteEmbedding('one_hot_encoder'), utils_graph_learning.py:78 / :170-187)
+            with layers._timed("count", 16.0 * E + 4.0 * E * 12 + (8.0 * E * 4 if int64_ids else 0.0)):
                 count_batch(plan, node_ptr, edge_ptr, ei, ids_are_global=True, max_nodes=max_nodes, max_edges=max_edges,
-                            device=dev, check=False, encode=([3, 3, 3, 3], True), counts=False, encoded_out=idf_out,
-                            encoded_pack=(epack, 0) if use_pack else None)
+                            device=dev, check=False, encode=([3, 3, 3, 3], True), counts=int64_ids, out=ids_out if int64_ids else None,
+                            encoded_out=idf_out, encoded_pack=(ep, 0) if use_pack else None)
+
+        def independent_of_counts():
+            layers._csr_for(ei, sel, N)
+            if not prepacked:
+                packs.pack_node_codes(xc, npack_c)
+                packs.pack_edge_codes(efc, epack_c, 12)
+
+        def run_layer():
             with torch.no_grad():
-                return layer(x, ei, identifiers=idf_out, degrees=degrees, edge_features=ef)
-        # The layer's target-sorted CSR depends only on edge_index, the counting only on the graphs: the CSR build (small
-        # memory-bound kernels) runs on a second HIP stream under the VALU-bound counting kernel.  The side stream first
-        # waits for the main stream so that CSR buffers recycled by the allocator are no longer read by the previous step.
+                if prepacked:
+                    return layer(x, ei, identifiers=idf_out, degrees=degrees, edge_features=ef)
+                return layer(xc, ei, identifiers=idf_out, degrees=degrees, edge_features=efc)
+        if not fork:                          # (the captured variant without a second branch)
+            independent_of_counts()
+            count()
+            return run_layer()
+        # The layer's target-sorted CSR depends only on edge_index, the atom / bond packs only on the codes, the counting only on the graphs:
+        # the former (small memory-bound kernels) run on a second HIP stream under the VALU-bound counting kernel.  The side stream first
+        # waits for the main stream so that buffers recycled by the allocator are no longer read by the previous step.
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            layers._csr_for(ei, sel, N)
-        # gsn_count_encode_hip: the counts leave the kernel as the one-hot rows of min(count, 2) the layer consumes (the reference:
-        # int64 identifiers, then DiscreteEmbedding('one_hot_encoder'), utils_graph_learning.py:78 / :170-187) -- no int64 round trip
-        with layers._timed("count", 16.0 * E + 4.0 * E * 12):
-            count_batch(plan, node_ptr, edge_ptr, ei, ids_are_global=True, max_nodes=max_nodes, max_edges=max_edges,
-                        device=dev, check=False, encode=([3, 3, 3, 3], True), counts=int64_ids, out=ids_out if int64_ids else None,
-                        encoded_out=idf_out, encoded_pack=(epack, 0) if use_pack else None)
+            independent_of_counts()
+        count()
         main.wait_stream(side)
-        with torch.no_grad():
-            return layer(x, ei, identifiers=idf_out, degrees=degrees, edge_features=ef)
+        return run_layer()
 
     def sync():
         torch.cuda.synchronize()
@@ -772,19 +796,26 @@ def main():
         dt_graph = min(res_g.values()) if res_g else None
     dt_eager = dt      # the headline is the eager timing, always; the graph replays are diagnostics
 
-    # Supplementary (never `value`): the same step with HP-1's defined output inside the timed region -- the counting kernel also
-    # writes the int64 identifiers (utils_ids.py:19-27), E x 4 x 8 bytes more.
-    for _ in range(3):
-        step(int64_ids=True)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(int64_ids=True)
-    sync()
-    dt_ids = gdist.max_over_ranks(time.perf_counter() - t0, dev)
+    # Supplementary (never `value`): the step of rounds 2-4 -- dense one-hot inputs and their packs made OUTSIDE the step, no int64
+    # identifiers written (E x 4 x 8 bytes less) -- and the headline step without the int64 identifiers.
+    dt_pre = dt_noids = None
+    if use_pack:
+        for kw in ({"prepacked": True, "int64_ids": False}, {"int64_ids": False}):
+            for _ in range(3):
+                step(**kw)
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step(**kw)
+            sync()
+            t_kw = gdist.max_over_ranks(time.perf_counter() - t0, dev)
+            if kw.get("prepacked"):
+                dt_pre = t_kw
+            else:
+                dt_noids = t_kw
 
     if os.environ.get("GSN_BENCH_DIAG_ORDER"):       # (diagnostic: the two step variants timed alternately, keeping / dropping the output)
-        for tag, kw, keep in (("A keep", {}, True), ("B", {"int64_ids": True}, False), ("A drop", {}, False), ("B keep", {"int64_ids": True}, True), ("A keep", {}, True)):
+        for tag, kw, keep in (("A keep", {}, True), ("B", {"int64_ids": False}, False), ("A drop", {}, False), ("B keep", {"int64_ids": False}, True), ("A keep", {}, True)):
             for _ in range(3):
                 step(**kw)
             sync()
@@ -800,6 +831,8 @@ def main():
     # Supplementary: the layer alone, back to back, on its fp16 packs (the timed step's kernel) and on the fp32 rows (csrc/layer_rr.hip)
     layer_alone = {}
     if world == 1 and not args.no_extras:
+        if use_pack:
+            step(prepacked=True, int64_ids=False)      # (the dense tensors' pack tags all point at one edge pack again)
         with torch.no_grad():
             for tag in (("pack16_rows", "fp32_rows") if use_pack else ("fp32_rows",)):
                 if tag == "fp32_rows":
@@ -819,43 +852,7 @@ def main():
                     for t, tg in saved:
                         t._gsn_pack16 = tg
 
-    # Supplementary (never `value`): the same step with the layer fed the integer codes instead of their dense one-hot
-    # encodings (layers.Codes -> weight-row-gather edge stage); same parameters, same output to 1e-5.
     fused = None
-    if world == 1 and not args.no_extras:
-        xc = layers.Codes(torch.from_numpy(b.atom_type).to(dev), [28])
-        efc = layers.Codes(torch.from_numpy(b.bond_type).to(dev), [4])
-        layers.CODE_STATUS_CHECK = False          # atom / bond codes are in range by construction, counts are clamped
-
-        epack_c = packs.new_edge_pack(E, dev)
-        npack_c = packs.new_node_pack(N, dev)
-
-        def step_codes():
-            layers._CSR_CACHE.clear()
-            main = torch.cuda.current_stream(dev)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):         # what does not depend on the counts runs under the counting kernel: CSR build, atom / bond codes -> packs
-                layers._csr_for(ei, sel, N)
-                packs.pack_node_codes(xc, npack_c)
-                packs.pack_edge_codes(efc, epack_c, 12)
-            count_batch(plan, node_ptr, edge_ptr, ei, ids_are_global=True, max_nodes=max_nodes, max_edges=max_edges,
-                        device=dev, check=False, encode=([3, 3, 3, 3], True), counts=False, encoded_out=idf_out, encoded_pack=(epack_c, 0))
-            main.wait_stream(side)
-            with torch.no_grad():
-                return layer(xc, ei, identifiers=idf_out, degrees=degrees, edge_features=efc)
-        yc = step_codes()
-        spin_up(step_codes)
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            yc = step_codes()
-        torch.cuda.synchronize()
-        dtc = time.perf_counter() - t1
-        err = float((yc - y).abs().max() / y.abs().max())
-        assert err < 1e-4, err
-        fused = {"graphs_per_s": round(G * args.steps / dtc, 1), "ms_per_step": round(dtc / args.steps * 1e3, 4),
-                 "max_rel_diff_vs_dense": float("%.2e" % err),
-                 "note": "same step with the atom / bond inputs as integer codes, encoded inside the step straight into exact fp16 row packs "
-                         "(gsn_one_hot_pack16_hip, under the counting kernel on the side stream); no fp32 one-hot tensor of x or the bond types exists"}
 
     # Supplementary (never `value`): count + the FULL model of BASELINE configs[1] (GNNSubstructures, 4 layers: layer 0 is
     # GSN_edge_sparse, layers 1-3 MPNN_edge_sparse with K = 260 edge rows -- the any-shape dense kernels; one-hot encoders, sum
@@ -967,8 +964,15 @@ def main():
             dist.all_reduce(bucket)
         sync()
         t_ar = gdist.max_over_ranks((time.perf_counter() - t0) / 10, dev)
+        ranks = gdist.rank_report(dev)
+        buses = [r.get("pci_bus_id") for r in ranks]
         rccl = {"version": ".".join(str(v) for v in torch.cuda.nccl.version()), "allreduce_ms": round(t_ar * 1e3, 4), "bucket_MB": 13.41,
+                "allreduce_busbw_GBs": round(2.0 * (world - 1) / world * 13.41e-3 / t_ar, 1) if world > 1 else None,
+                "world_size_reported": dist.get_world_size(), "backend": dist.get_backend(),
+                "ranks": ranks, "distinct_devices": len(set(buses)) == len(buses) if all(b is not None for b in buses) else None,
                 "note": "flat fp32 gradient bucket of the configs[3] model, sum over %d rank(s); not part of the headline step" % world}
+        if world > 1 and rccl["distinct_devices"] is False:
+            raise SystemExit("bench.py: two ranks share one GPU: %r" % (ranks,))
         gl = [torch.zeros(1, device=dev, dtype=torch.int64) for _ in range(world)]
         dist.all_gather(gl, torch.tensor([G], device=dev, dtype=torch.int64))
         graphs_by_rank = [int(t.item()) for t in gl]
@@ -1082,8 +1086,12 @@ def main():
             "eager_ms_per_step": round(dt_eager / args.steps * 1e3, 4),
             "hip_graph_ms_per_step": None if dt_graph is None else round(dt_graph / args.steps * 1e3, 4),
             "hip_graph_forked_ms_per_step": None if dt_graph_fork is None else round(dt_graph_fork / args.steps * 1e3, 4),
-            "step_with_int64_ids": {"ms_per_step": round(dt_ids / args.steps * 1e3, 4), "graphs_per_s": round(world * G * args.steps / dt_ids, 1),
-                                    "note": "the timed step with the int64 identifiers (utils_ids.py:27) written by the counting kernel as well"},
+            "step_prepacked": None if dt_pre is None else {
+                "ms_per_step": round(dt_pre / args.steps * 1e3, 4), "graphs_per_s": round(world * G * args.steps / dt_pre, 1),
+                "note": "the headline step of rounds 2-4: dense one-hot x / bond rows and their fp16 packs made outside the step, no int64 identifiers written"},
+            "step_without_int64_ids": None if dt_noids is None else {
+                "ms_per_step": round(dt_noids / args.steps * 1e3, 4), "graphs_per_s": round(world * G * args.steps / dt_noids, 1),
+                "note": "the headline step with the counting kernel writing the encoded identifier rows only"},
             "layer_alone_ms": layer_alone,
             "launch": "eager",
         })
@@ -1121,8 +1129,10 @@ def main():
             "value": round(world * G * args.steps / dt, 1), "unit": "graphs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int64 counts + f32 message passing (matrix products: fp16x3 -- two fp16 planes per fp32 operand, three plane products, f32 accumulate)", "data": "synthetic",
-            "config": {"workload": "ZINC-shape x%d graphs/GPU (N=%d, E=%d): cycle_graph k<=6 GSN-e (id_scope=local) orbit count "
-                                   "+ GSN_edge_sparse layer-0 forward (general, d_in=28, d_ef=4, d_id=12, d=128, bn, eval)" % (G, N, E),
+            "config": {"workload": "ZINC-shape x%d graphs/GPU (N=%d, E=%d): integer atom / bond codes in -> cycle_graph k<=6 GSN-e (id_scope=local) "
+                                   "orbit count (int64 identifiers written) + one-hot encoding + GSN_edge_sparse layer-0 forward (general, d_in=28, "
+                                   "d_ef=4, d_id=12, d=128, bn, eval) -> layer rows out" % (G, N, E),
+                       "inputs": "int64 atom codes [N], bond codes [E], edge_index [2, E], graph pointers", "outputs": "int64 identifiers [E, 4], fp32 layer rows [N, 128]",
                        "graphs_per_step_per_gpu": G, "parallelism": "graph-shard x%d, no data-path collective" % world},
             "roofline": roof, "kernels": extra,
             "counts_checked": bool(checked["counts_bit_exact"]), "checked": checked,

@@ -62,6 +62,35 @@ def init_from_env(backend: str = "nccl", device=None):
     return rank, world, local_rank, dist
 
 
+def require_devices(n: int) -> None:
+    """Fail loudly, before any collective, when this node shows fewer GPUs than the ranks that were started on it."""
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n:
+        raise SystemExit("gsn_amd.dist: %d rank(s) were started on this node but torch.cuda.device_count() = %d "
+                         "(HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES = %r / %r)"
+                         % (n, have, os.environ.get("HIP_VISIBLE_DEVICES"), os.environ.get("ROCR_VISIBLE_DEVICES")))
+
+
+def rank_report(device, group=None):
+    """What makes a first multi-GPU run diagnosable: per rank its device ordinal, PCI bus id, device name and memory, the world size the
+    process group reports, the backend -- gathered to every rank (list of dicts, rank order) with one all_gather_object."""
+    info = {"rank": dist.get_rank(group) if dist.is_initialized() else 0, "pid": os.getpid(), "host": os.uname().nodename}
+    if device is not None and torch.device(device).type == "cuda":
+        idx = torch.device(device).index
+        idx = torch.cuda.current_device() if idx is None else idx
+        pr = torch.cuda.get_device_properties(idx)
+        info.update(device=idx, current_device=torch.cuda.current_device(), name=pr.name, total_memory_GiB=round(pr.total_memory / 2 ** 30, 1),
+                    multi_processor_count=pr.multi_processor_count, pci_bus_id=getattr(pr, "pci_bus_id", None),
+                    pci_device_id=getattr(pr, "pci_device_id", None), gcn_arch=getattr(pr, "gcnArchName", None),
+                    visible=os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES"))
+    if not dist.is_available() or not dist.is_initialized():
+        return [info]
+    info.update(world_size=dist.get_world_size(group), backend=dist.get_backend(group))
+    out = [None] * dist.get_world_size(group)
+    dist.all_gather_object(out, info, group=group)
+    return out
+
+
 def max_over_ranks(value: float, device=None) -> float:
     """MAX of a host scalar over all ranks (the step time every rank reports is the slowest rank's)."""
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
@@ -119,8 +148,12 @@ def shard_by_cost(costs, world: int):
 _BUCKETS = {}
 
 
+FLAG_STABLE_CALLS = 3        # eager calls with identical reduced has-gradient flags before the flags stop being exchanged every step
+FLAG_REVALIDATE_EVERY = 64   # ... and every this many calls they are exchanged (and read back) again, on all ranks alike
+
+
 class _Bucket:
-    __slots__ = ("flat", "views", "n_grad", "has")
+    __slots__ = ("flat", "views", "n_grad", "has", "pinned", "calls", "stable")
 
     def __init__(self, params, dtype, device):
         self.n_grad = sum(p.numel() for p in params)
@@ -129,7 +162,10 @@ class _Bucket:
         for p in params:
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
-        self.has = None          # which parameters some rank had a gradient for, as of the last eager call
+        self.has = None          # which parameters some rank had a gradient for, as of the last eager call that exchanged the flags
+        self.pinned = False      # a captured graph holds this bucket's addresses: never evicted
+        self.calls = 0           # eager calls so far (identical on every rank: the schedule of flag exchanges is derived from it)
+        self.stable = 0          # consecutive flag exchanges that returned the same flags
 
 
 def allreduce_gradients(parameters, average: bool = True, group=None, force: bool = False):
@@ -162,9 +198,13 @@ def allreduce_gradients(parameters, average: bool = True, group=None, force: boo
     b = _BUCKETS.get(key)
     if b is None or b.flat.numel() != sum(p.numel() for p in params) + len(params):
         if len(_BUCKETS) > 8:
-            _BUCKETS.clear()
+            # (a bucket that a captured step copies into and all-reduces lives at addresses the graph recorded: it stays)
+            for k in [k for k, v in _BUCKETS.items() if not v.pinned]:
+                del _BUCKETS[k]
         b = _BUCKETS[key] = _Bucket(params, dtype, device)
     capturing = device.type == "cuda" and torch.cuda.is_current_stream_capturing()
+    if capturing:
+        b.pinned = True
     have = [p.grad is not None for p in params]
     present = [i for i, h in enumerate(have) if h]
     absent = [i for i, h in enumerate(have) if not h]
@@ -179,10 +219,20 @@ def allreduce_gradients(parameters, average: bool = True, group=None, force: boo
                                    "(GraphedTrainStep's warm-up steps do that)")
             dist.all_reduce(b.flat[:b.n_grad], op=dist.ReduceOp.SUM, group=group)
             has = b.has
+        elif b.has is not None and b.stable >= FLAG_STABLE_CALLS and b.calls % FLAG_REVALIDATE_EVERY != 0:
+            # steady state: which parameters receive gradients is a property of the model -- after FLAG_STABLE_CALLS identical exchanges
+            # the gradient part alone is reduced and nothing is read back (no host synchronisation in the step); the exchange is repeated
+            # every FLAG_REVALIDATE_EVERY calls.  `calls` and the reduced flags are the same on every rank, so all ranks switch together.
+            b.calls += 1
+            dist.all_reduce(b.flat[:b.n_grad], op=dist.ReduceOp.SUM, group=group)
+            has = b.has
         else:
+            b.calls += 1
             b.flat[b.n_grad:].copy_(torch.tensor([1.0 if h else 0.0 for h in have], dtype=dtype), non_blocking=True)
             dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=group)
-            has = b.has = [v != 0 for v in b.flat[b.n_grad:].tolist()]   # (one small read-back per step; the gradients stay on the device)
+            has = [v != 0 for v in b.flat[b.n_grad:].tolist()]          # (one small read-back; the gradients stay on the device)
+            b.stable = b.stable + 1 if has == b.has else 1
+            b.has = has
         world = dist.get_world_size(group)
         if average and world > 1:
             b.flat[:b.n_grad] /= world

@@ -8,8 +8,10 @@ at B = 128).  Every launch of this package goes to PyTorch's current stream, so 
     y = step()                                                                          # one hipGraphLaunch; y is the captured output
 
 Rules of stream capture apply: shapes, pointers and launch arguments are frozen (re-capture for another batch shape), nothing inside the step
-may synchronise (status read-backs are deferred or off: `check=False` for the CSR build, the embedding status ring), caches that the step
-would FILL must be filled before the capture (the warm-up runs do that: prepared weights, CSR of a registered partition, constant rows).
+may synchronise (status read-backs are deferred or off: `check=False` for the CSR build, the embedding status ring).  Caches keyed on
+PARAMETERS (prepared weights, constant rows) are filled by the warm-up runs and stay valid; caches keyed on the INPUT tensors (the
+aggregation index of `edge_index`, readout index pairs, graph sizes) are dropped right before the capture, so that the kernels that build
+them become nodes of the graph: a replay after `static_edge_index.copy_(new_batch)` rebuilds them from the new contents.
 """
 from __future__ import annotations
 
@@ -29,9 +31,12 @@ class GraphedStep:
                 fn()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
+        from . import layers
+        layers.drop_input_caches()                     # (the index builds of the static inputs are recorded, not looked up)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.outputs = fn()
+        layers.drop_input_caches()                     # (what the capture cached lives in graph-pool memory no eager call has written)
         self.replays = 0
 
     def __call__(self):
@@ -94,6 +99,9 @@ class GraphedTrainStep:
         optimizer.zero_grad(set_to_none=True)          # (the captured backward allocates the gradients from the graph's pool)
         from . import layers
         layers.RAW_WRITTEN = []
+        # caches keyed on the INPUT tensors (aggregation index, readout pairs, graph sizes) were filled by the warm-up steps: dropped, so
+        # that their builds are recorded -- a replay after data.edge_index.copy_(new_batch) then runs them on the new contents
+        layers.drop_input_caches()
         try:
             with torch.cuda.graph(self.graph):
                 self.loss = step()
@@ -105,6 +113,10 @@ class GraphedTrainStep:
             self._bump = self.params + extra
         finally:
             layers.RAW_WRITTEN = None
+        # what the capture cached -- derived weights keyed on the parameters' versions, indices of the inputs -- lives in graph-pool memory
+        # that nothing has written yet (a capture records): an eager forward before the first replay must not find it
+        layers.drop_input_caches()
+        torch.autograd.graph.increment_version(self._bump)
         self.replays = 0
         self.steps_taken = max(1, warmup)              # (a capture records, it does not execute)
 

@@ -35,7 +35,7 @@ from . import _abi, packs
 
 __all__ = ["mlp", "central_encoder", "GSN_sparse", "GSN_edge_sparse", "MPNN_sparse", "MPNN_edge_sparse",
            "GSN_edge_sparse_ogb", "MPNN_edge_sparse_ogb", "build_csr", "propagate", "run_stages", "one_hot_identifiers",
-           "global_add_pool_sparse", "global_mean_pool_sparse", "Codes", "run_linear_module", "invalidate_caches", "set_graph_partition", "build_csr_graphs"]
+           "global_add_pool_sparse", "global_mean_pool_sparse", "Codes", "run_linear_module", "invalidate_caches", "drop_input_caches", "set_graph_partition", "build_csr_graphs"]
 
 _ACT_CODE = {"identity": 0, "relu": 1, "elu": 2, "tanh": 3}
 _MAX_BLOCKS = 5
@@ -900,6 +900,15 @@ def _async_validate(module):
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))
     st["pending"].append((ev, slot, versions))
+
+
+def drop_input_caches():
+    """Drop everything cached per INPUT tensor (aggregation index of an ``edge_index``, readout index pairs and graph sizes of a
+    ``batch`` vector): the next forward builds them again.  gsn_amd.graphs calls this in front of a stream capture."""
+    # (the NUMBER of graphs of a batch vector is a shape, not contents: a captured step is bound to it anyway, and reading it again would
+    #  synchronise inside the capture)
+    for k in [k for k in _CSR_CACHE if not (isinstance(k, tuple) and len(k) == 2 and k[1] == "n_graphs")]:
+        del _CSR_CACHE[k]
 
 
 def invalidate_caches(module=None):

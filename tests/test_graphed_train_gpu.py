@@ -143,3 +143,84 @@ def test_dropout_draws_fresh_masks_and_eager_forward_sees_new_weights():
         y2 = model(data).clone()
     assert not torch.equal(y0, y1)
     assert torch.equal(y1, y2), "an eager forward after replays used stale prepared weights"
+
+
+def _reversed_batch(data, node_ptr, edge_ptr):
+    """the same graphs in reverse order: another batch of the SAME shape (N, E, G) with other contents everywhere -> dict of tensors"""
+    import numpy as np
+    G = len(node_ptr) - 1
+    nodes, edges, shift, batch = [], [], [], []
+    off = 0
+    for k, g in enumerate(range(G - 1, -1, -1)):
+        n0, n1, e0, e1 = int(node_ptr[g]), int(node_ptr[g + 1]), int(edge_ptr[g]), int(edge_ptr[g + 1])
+        nodes.append(np.arange(n0, n1)); edges.append(np.arange(e0, e1))
+        shift.append(np.full(e1 - e0, off - n0)); batch.append(np.full(n1 - n0, k))
+        off += n1 - n0
+    nodes, edges = torch.from_numpy(np.concatenate(nodes)).cuda(), torch.from_numpy(np.concatenate(edges)).cuda()
+    shift = torch.from_numpy(np.concatenate(shift)).cuda()
+    new_np = np.concatenate([[0], np.cumsum(np.diff(node_ptr)[::-1])]).astype(np.int64)
+    new_ep = np.concatenate([[0], np.cumsum(np.diff(edge_ptr)[::-1])]).astype(np.int64)
+    return dict(x=data.x[nodes], edge_index=data.edge_index[:, edges] + shift[None, :], edge_features=data.edge_features[edges],
+                identifiers=data.identifiers[edges], batch=torch.from_numpy(np.concatenate(batch).astype(np.int64)).cuda(),
+                y=data.y.flip(0), node_ptr=torch.from_numpy(new_np).cuda(), edge_ptr=torch.from_numpy(new_ep).cuda())
+
+
+@pytest.mark.parametrize("partition", [False, True])
+def test_replay_on_a_refilled_static_batch_equals_the_eager_step_on_that_batch(partition):
+    """the static tensors are refilled with copy_() and the step is replayed -- the aggregation index, the readout's
+    index and the graph sizes must be REBUILT by the replay (their builds are nodes of the graph), not looked up from the warm-up batch.
+    Batch B = batch A's graphs in reverse order (same N, E, G; other topology, features, targets).  Reference: eager steps on A, A, B."""
+    import numpy as np
+    from gsn_amd import synth
+    from gsn_amd.graphs import GraphedTrainStep
+
+    def fresh():
+        torch.manual_seed(77)
+        torch.cuda.manual_seed(7)
+        model, data, params, opt, loss_of, N, E = _build("zinc", "sgd", dropout=0.0)
+        for g in opt.param_groups:
+            g["lr"] = 3e-3
+        b = synth.zinc_shape_batch(48, seed=200)
+        node_ptr, edge_ptr = np.asarray(b.node_ptr), np.asarray(b.edge_ptr)
+        if partition:
+            data.graph_partition = (torch.from_numpy(node_ptr.astype(np.int64)).cuda(), torch.from_numpy(edge_ptr.astype(np.int64)).cuda(),
+                                    int(np.diff(node_ptr).max()), int(np.diff(edge_ptr).max()), False)
+        return model, data, params, opt, loss_of, node_ptr, edge_ptr
+
+    def refill(data, other):
+        for k in ("x", "edge_index", "edge_features", "identifiers", "batch", "y"):
+            getattr(data, k).copy_(other[k])
+        if partition:
+            data.graph_partition[0].copy_(other["node_ptr"]); data.graph_partition[1].copy_(other["edge_ptr"])
+
+    # reference: all eager
+    model, data, params, opt, loss_of, node_ptr, edge_ptr = fresh()
+    other = _reversed_batch(data, node_ptr, edge_ptr)
+    assert not torch.equal(other["edge_index"], data.edge_index) and other["edge_index"].shape == data.edge_index.shape
+    for _ in range(2):
+        _eager_step(params, opt, loss_of)
+    refill(data, other)
+    loss_ref = float(_eager_step(params, opt, loss_of))
+    ref = _state(model)
+    # a second eager run: the run-to-run noise of the atomics
+    model, data, params, opt, loss_of, node_ptr, edge_ptr = fresh()
+    for _ in range(2):
+        _eager_step(params, opt, loss_of)
+    refill(data, _reversed_batch(data, node_ptr, edge_ptr))
+    _eager_step(params, opt, loss_of)
+    noise = _rel(ref, _state(model))
+    # two warm-up steps on A inside the captured step object, refill with B, ONE replay
+    model, data, params, opt, loss_of, node_ptr, edge_ptr = fresh()
+    other = _reversed_batch(data, node_ptr, edge_ptr)
+    step = GraphedTrainStep(loss_of, opt, params, warmup=2)
+    refill(data, other)
+    loss = float(step())
+    torch.cuda.synchronize()
+    diff = _rel(ref, _state(model))
+    assert diff <= max(16.0 * noise, 2e-5), "the replay on the refilled batch drifts from the eager step on it: %.3g at %s (eager run-to-run %.3g)" % (diff, _rel.where, noise)
+    assert abs(loss - loss_ref) <= 1e-3 * abs(loss_ref) + 1e-6, (loss, loss_ref)
+    # and the replay is NOT the step on batch A again (what a stale index would give: measurably different)
+    model, data, params, opt, loss_of, node_ptr, edge_ptr = fresh()
+    for _ in range(3):
+        _eager_step(params, opt, loss_of)
+    assert _rel(ref, _state(model)) > 10.0 * max(diff, 1e-7)
