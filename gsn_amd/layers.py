@@ -908,7 +908,7 @@ def drop_input_caches():
     # (the NUMBER of graphs of a batch vector is a shape, not contents: a captured step is bound to it anyway, and reading it again would
     #  synchronise inside the capture)
     for k in [k for k in _CSR_CACHE if not (isinstance(k, tuple) and len(k) == 2 and k[1] == "n_graphs")]:
-        del _CSR_CACHE[k]
+        _CSR_CACHE.pop(k, None)              # (dropping an entry can free a tensor whose weak-reference callback removes another key)
 
 
 def invalidate_caches(module=None):
