@@ -115,9 +115,19 @@ def verify_tile(plan, b, ids_out, y, layer, n_check):
     err_max = float((ygot - yref).abs().max() / yref.abs().max())
     # element-wise: |got - ref| <= 1e-5 |ref| + 1e-5 * (row scale): the floor is 1e-5 of the row's largest |value|
     floor = 1e-5 * yref.abs().amax(dim=1, keepdim=True)
-    elem_ok = bool(((ygot - yref).abs() <= 1e-5 * yref.abs() + floor).all())
+    diff = (ygot - yref).abs()
+    elem_ok = bool((diff <= 1e-5 * yref.abs() + floor).all())
+    # how much the floor is needed: elements that fail the PURE relative test |got - ref| <= 1e-5 |ref|, and how small they
+    # are against their row (cancellation-small elements: their absolute error is that of the row's large ones)
+    pure_bad = diff > 1e-5 * yref.abs()
+    n_bad = int(pure_bad.sum())
+    rel_to_row = (yref.abs() / yref.abs().amax(dim=1, keepdim=True).clamp_min(1e-30))[pure_bad]
     return {"graphs": g, "counts_bit_exact": counts_ok, "layer_max_err_over_max": float("%.3g" % err_max),
-            "layer_elementwise_1e-5_rel_plus_1e-5_rowmax": elem_ok}
+            "layer_elementwise_1e-5_rel_plus_1e-5_rowmax": elem_ok,
+            "layer_elements": int(yref.numel()), "layer_elements_failing_pure_1e-5_relative": n_bad,
+            "layer_fraction_failing_pure_1e-5_relative": float("%.3g" % (n_bad / max(int(yref.numel()), 1))),
+            "largest_abs_ref_over_rowmax_among_those": float("%.3g" % (float(rel_to_row.max()) if n_bad else 0.0)),
+            "largest_abs_err_over_rowmax_among_those": float("%.3g" % (float((diff / yref.abs().amax(dim=1, keepdim=True).clamp_min(1e-30))[pure_bad].max()) if n_bad else 0.0))}
 
 
 def work_figures(plan_patterns, ids_out):

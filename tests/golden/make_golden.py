@@ -1133,6 +1133,63 @@ def gen_directed(ref, out):
     print("directed: %d cases, %d patterns" % (len(rec["names"]), len(pats)))
 
 
+def gen_cliques(ref, out):
+    """The heaviest clique cases of BASELINE config 3, which gen_counts leaves out for networkx-VF2 speed (the three IMDB-BINARY graphs among
+    the first 24 with > 1 M K5 maps; K5 on the largest graph: 1.6e9 maps through utils_graph_processing.py:116-127) -- from an enumerator
+    that is neither VF2 nor this repo's oracle: networkx.enumerate_all_cliques, tallied per vertex and per directed edge column.
+    Reference semantics for K_k, non-induced (one vertex orbit, one edge orbit, |Aut| = k!): counts[v] = # k-cliques containing v
+    (utils_graph_processing.py:119-127), counts[(u, v)] = # k-cliques containing u and v (:158-176); the TU loader's edge lists hold every
+    pair once per direction, so no duplicate-column rule applies.  The reference's own path is cross-checked here on K3 / K4 of the same
+    graphs (VF2 stand-in), so the tally convention is pinned to the reference, not to this function's reading of it."""
+    rec = {}
+    t0 = time.time()
+    clq = lambda ks: [list(nx.complete_graph(k).edges) for k in ks]
+    imdb = imdb_graphs()
+    sizes = np.array([n for n, _ in imdb])
+    heavy = [imdb[i] for i in (8, 11, 15)]
+    big = [imdb[int(np.argmax(sizes))]]
+
+    def tally(n, ei, ks):
+        g = nx.Graph()
+        g.add_nodes_from(range(n))
+        g.add_edges_from((int(u), int(v)) for u, v in ei.T if u != v)
+        col = {}
+        for c in range(ei.shape[1]):
+            col[(int(ei[0, c]), int(ei[1, c]))] = c          # (last duplicate wins, utils_graph_processing.py:142-144; none here)
+        vc = np.zeros((n, len(ks)), np.int64)
+        ec = np.zeros((ei.shape[1], len(ks)), np.int64)
+        kmax = max(ks)
+        for cl in nx.enumerate_all_cliques(g):              # (by increasing size)
+            k = len(cl)
+            if k > kmax:
+                break
+            if k in ks:
+                j = ks.index(k)
+                for v in cl:
+                    vc[v, j] += 1
+                for a in cl:
+                    for b in cl:
+                        if a != b:
+                            ec[col[(a, b)], j] += 1
+        return vc, ec
+    for name, graphs in (("imdb_heavy", heavy), ("imdb_largest", big)):
+        ks = [3, 4, 5]
+        vs, es = [], []
+        for n, ei in graphs:
+            vc, ec = tally(n, ei, ks)
+            vs.append(vc); es.append(ec)
+            print(name, "n=%d E=%d K5 total %d" % (n, ei.shape[1], int(vc[:, 2].sum()) // 5), "%.0fs" % (time.time() - t0), flush=True)
+        # the same K3 / K4 columns through the REFERENCE's functions (over the VF2 stand-in): the convention check
+        for mode, arr in (("vertex", vs), ("edge", es)):
+            o = run_counts(ref, graphs, clq([3, 4]), mode, False)
+            for a, b in zip(o, arr):
+                assert np.array_equal(a, b[:, :2]), (name, mode)
+            save_case(rec, "%s_clique3-5_mono_%s" % (name, mode), graphs, clq(ks), mode, False, arr)
+        print(name, "reference K3/K4 cross-check ok", "%.0fs" % (time.time() - t0), flush=True)
+    rec["names"] = np.asarray(rec["names"])
+    np.savez_compressed(os.path.join(out, "counts_cliques.npz"), **rec)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="orbits,counts,layers")
@@ -1154,6 +1211,8 @@ def main():
         gen_directed(ref, args.out)
     if "ogb300" in only:
         gen_model_ogb300(ref, args.out)
+    if "cliques" in only:
+        gen_cliques(ref, args.out)
 
 
 if __name__ == "__main__":

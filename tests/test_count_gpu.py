@@ -31,6 +31,18 @@ def test_golden_counts(name):
     assert torch.equal(out, out2)
 
 
+@pytest.mark.parametrize("name", case_names("counts_cliques"))
+def test_golden_heavy_clique_counts(name):
+    """the overflow-risk inputs of BASELINE config 3: K3..K5 on the IMDB-BINARY graphs with the most 5-cliques, bit-exact against
+    tallies of networkx.enumerate_all_cliques (independent of VF2 and of the oracle)"""
+    from gsn_amd.counting import CountPlan, count_batch
+    c = count_case(name, "counts_cliques")
+    plan = CountPlan.get(c["patterns"], c["mode"], c["induced"], c["directed_orbits"])
+    out, st = count_batch(plan, c["node_ptr"], c["edge_ptr"], _global_ei(c), ids_are_global=True)
+    assert (st.cpu().numpy() == 0).all()
+    assert np.array_equal(out.cpu().numpy(), c["counts"])
+
+
 def _cycles(ks):
     return [list(nx.cycle_graph(k).edges) for k in ks]
 

@@ -45,3 +45,18 @@ def test_dropin_imports_resolve_to_gsn_amd():
     out = subprocess.run([sys.executable, "-c", SNIPPET], env=env, cwd="/tmp", capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     assert "dropin ok" in out.stdout
+
+
+def test_reference_callers_bind_to_the_dropins():
+    """scripts/check_reference_binding.py: the reference's unchanged utils.py (process_arguments, get_custom_edge_list) and the
+    subgraph_dicts loop of utils_data_gen.py:35-42 over gsn_amd/dropin -- selected callables are ours, 213 orbit tables equal orbits.npz.
+    Build container only (/root/reference does not exist on the GPU box)."""
+    import pytest
+    if not os.path.isdir("/root/reference"):
+        pytest.skip("needs /root/reference")
+    env = dict(os.environ)
+    env.pop("PYTHONPATH", None)
+    out = subprocess.run([sys.executable, os.path.join(REPO, "scripts", "check_reference_binding.py")], env=env, cwd="/tmp",
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "binding ok" in out.stdout

@@ -157,8 +157,10 @@ def test_layer_forward_golden(name):
                 assert int(sd[k[9:]]) == int(c[k])
 
 
-@pytest.mark.parametrize("name", [n for n in case_names("layers") if "/zinc/" in n or "real_widths" in n or "degree_as_tag" in n])
+@pytest.mark.parametrize("name", case_names("layers"))
 def test_layer_backward_golden(name):
+    """input and parameter gradients of EVERY reference-generated case -- the molecule graphs and the hub / isolated-node graph --
+    against the reference's own autograd gradients (g_x, g_identifiers, g_edge_features, gp/* of layers.npz)"""
     c = layer_case(name)
     layer = _build(c)
     x, ei, kw, ids, ef = _inputs(c, grad=True)

@@ -31,6 +31,16 @@ def test_counts(name):
     assert np.array_equal(got, c["counts"])
 
 
+@pytest.mark.parametrize("name", case_names("counts_cliques"))
+def test_heavy_clique_counts(name):
+    """K3..K5 on the IMDB-BINARY graphs the VF2-backed goldens leave out (> 1 M K5 maps each; the 136-vertex graph): per-vertex / per-edge
+    tallies of networkx.enumerate_all_cliques -- an enumerator independent of VF2 and of this oracle (make_golden.py --only cliques)"""
+    c = count_case(name, "counts_cliques")
+    got = oracle.counts2ids(c["mode"], c["induced"], c["node_ptr"], c["edge_ptr"], c["edge_index_local"], c["patterns"],
+                            directed_orbits=c["directed_orbits"], n_threads=4)
+    assert np.array_equal(got, c["counts"])
+
+
 def test_directed_orbits_and_counts():
     """directed=True (main.py --directed): digraph patterns and targets, vertex counts (counts_directed.npz = the reference's
     automorphism_orbits / subgraph_isomorphism_vertex_counts with directed=True over networkx's DiGraphMatcher)."""
