@@ -146,7 +146,8 @@ def test_dropout_draws_fresh_masks_and_eager_forward_sees_new_weights():
 
 
 def _reversed_batch(data, node_ptr, edge_ptr):
-    """the same graphs in reverse order: another batch of the SAME shape (N, E, G) with other contents everywhere -> dict of tensors"""
+    """the same graphs in reverse order with the targets left where they were (graph k of the new batch is regressed onto the old graph
+    k's target: a different problem, not a permutation of the old one): another batch of the SAME shape (N, E, G) -> dict of tensors"""
     import numpy as np
     G = len(node_ptr) - 1
     nodes, edges, shift, batch = [], [], [], []
@@ -162,7 +163,7 @@ def _reversed_batch(data, node_ptr, edge_ptr):
     new_ep = np.concatenate([[0], np.cumsum(np.diff(edge_ptr)[::-1])]).astype(np.int64)
     return dict(x=data.x[nodes], edge_index=data.edge_index[:, edges] + shift[None, :], edge_features=data.edge_features[edges],
                 identifiers=data.identifiers[edges], batch=torch.from_numpy(np.concatenate(batch).astype(np.int64)).cuda(),
-                y=data.y.flip(0), node_ptr=torch.from_numpy(new_np).cuda(), edge_ptr=torch.from_numpy(new_ep).cuda())
+                y=data.y.clone(), node_ptr=torch.from_numpy(new_np).cuda(), edge_ptr=torch.from_numpy(new_ep).cuda())
 
 
 @pytest.mark.parametrize("partition", [False, True])
