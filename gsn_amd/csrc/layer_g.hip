@@ -188,6 +188,45 @@ __global__ __launch_bounds__(256) void layer_fused_kernel_g(GArgs a, unsigned lo
         asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(lane16), "s"(ub), "s"(ldst) : "memory");
     };
+    // n (2 .. 4) CONSECUTIVE fragments -> consecutive ring fragments: one M0 write, the further requests through the instruction offset
+    // (it moves the memory address and the LDS address alike)
+    auto dman = [&](int src_frag, int slot, int dst_frag, int n) {
+#ifdef G_ABL_NODMA
+        return;
+#endif
+        const unsigned char *ub = gfrag + (size_t)src_frag * 1024;
+        const unsigned ldst = lds0 + (unsigned)(GL_RING + slot * G_SLOT + dst_frag * 1024);
+        unsigned keep;
+        if (n == 2)
+            asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                         "global_load_lds_dwordx4 %1, %2 offset:1024\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(lane16), "s"(ub), "s"(ldst) : "memory");
+        else if (n == 3)
+            asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                         "global_load_lds_dwordx4 %1, %2 offset:1024\n\tglobal_load_lds_dwordx4 %1, %2 offset:2048\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(lane16), "s"(ub), "s"(ldst) : "memory");
+        else
+            asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                         "global_load_lds_dwordx4 %1, %2 offset:1024\n\tglobal_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+                         "global_load_lds_dwordx4 %1, %2 offset:3072\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(lane16), "s"(ub), "s"(ldst) : "memory");
+    };
+    // all requests of step k in as few M0 writes as their placement allows (same loads, same order as dma_one(k, 0 ..))
+    auto dma_grouped = [&](int k) {
+        const int slot = k % 3;
+        if (k < 8) {
+            const int runs[3] = {SH::F_WE + 8 * (1 + W_NXC + k), SH::F_WE + 8 * (1 + k), SH::F_W0 + 8 * (SH::NKS + k)};
+#pragma unroll
+            for (int r = 0; r < 3; ++r) dman(runs[r] + 2 * wave, slot, 8 * r + 2 * wave, 2);
+        } else if (k < 12) {
+            dman(SH::F_W0 + 16 * (k - 8) + 4 * wave, slot, 4 * wave, 4);
+        } else {
+            const int kk = k - 12;
+            const int per = kk < 2 ? 6 : 4;
+            dman(SH::F_W1 + 24 * kk + per * wave, slot, per * wave, per == 6 ? 3 : 4);
+            if (per == 6) dman(SH::F_W1 + 24 * kk + per * wave + 3, slot, per * wave + 3, 3);
+        }
+    };
     // the j-th request of step k (j < g_step_loads(k))
     auto dma_one = [&](int k, int j) {
         const int slot = k % 3;
@@ -205,6 +244,10 @@ __global__ __launch_bounds__(256) void layer_fused_kernel_g(GArgs a, unsigned lo
         }
     };
     auto dma = [&](int k) {
+#ifndef G_DMA_SINGLE
+        dma_grouped(k);
+        return;
+#endif
 #pragma unroll
         for (int j = 0; j < 6; ++j)
             if (j < g_step_loads(k)) dma_one(k, j);
@@ -399,6 +442,13 @@ __global__ __launch_bounds__(256) void layer_fused_kernel_g(GArgs a, unsigned lo
             rr_u4 f[8], fn[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) f[q] = frag(slot, q);
+#ifndef G_NOHEAD
+            // the step's first eight fragment reads are in flight while the requests of step c + 2 issue: their issue time (~60 cycles
+            // each between products) runs under the reads' latency instead of between two products
+            RR_SB();
+            dma(kq);
+            RR_SB();
+#endif
             rr_f4 ov[2];
             const int r0p = __builtin_amdgcn_readfirstlane(p_r0 < a.n_nodes ? p_r0 : 0), nnwp = __builtin_amdgcn_readfirstlane(p_nnw);
             const __amdgpu_buffer_rsrc_t orow = __builtin_amdgcn_make_buffer_rsrc(a.out + (int64_t)r0p * (32 * WB), 0, nnwp * (32 * WB * 4), 0x00020000);
@@ -425,7 +475,9 @@ __global__ __launch_bounds__(256) void layer_fused_kernel_g(GArgs a, unsigned lo
                     }
                     G_MIX(4, grp < 2 ? 4 : 0)
                     RR_SB();
+#ifdef G_NOHEAD
                     if (th < 2 && 2 * grp + th < g_step_loads(kq)) dma_one(kq, 2 * grp + th);
+#endif
                     if (grp == 1 && th < 2) {
 #ifdef G_ABL_NOSTORE
                         if (ov[th].x == 12345.678f)
@@ -626,11 +678,18 @@ __global__ __launch_bounds__(256) void layer_fused_kernel_g(GArgs a, unsigned lo
             for (int c = 0; c < SH::NKS; ++c) {
                 const int kk = c >> 1, cc = c & 1, k = 8 + kk, slot = k % 3;
                 if (cc == 0) {
+#ifdef G_NOHEAD
                     if (kk > 0) { xload(n_n0, n_nn, wave, li, lh, xraw, kk, 1); dma((k + 2) % G_NSTEP); }
+#endif
 #pragma unroll
                     for (int q = 0; q < 8; ++q) f[q] = frag(slot, q);
 #pragma unroll
                     for (int q = 0; q < 8; ++q) fn[q] = frag(slot, 8 + q);
+#ifndef G_NOHEAD
+                    RR_SB();
+                    if (kk > 0) { xload(n_n0, n_nn, wave, li, lh, xraw, kk, 1); dma((k + 2) % G_NSTEP); }
+                    RR_SB();
+#endif
                 }
                 const rr_u4 bh = rr_u4{ph[0], ph[1], ph[2], ph[3]}, bl = rr_u4{pl[0], pl[1], pl[2], pl[3]};
 #pragma unroll
@@ -700,10 +759,18 @@ __global__ __launch_bounds__(256) void layer_fused_kernel_g(GArgs a, unsigned lo
                 const int kk = c / 3, cc = c % 3, k = 12 + kk, slot = k % 3;
                 const bool last_of_step = cc == 2 || c == SH::NKS - 1;
                 if (cc == 0) {
+#ifdef G_NOHEAD
                     xload(n_n0, n_nn, wave, li, lh, xraw, 4 + kk, 1);
                     dma((k + 2) % G_NSTEP);
+#endif
 #pragma unroll
                     for (int q = 0; q < 8; ++q) f[q] = frag(slot, q);
+#ifndef G_NOHEAD
+                    RR_SB();
+                    xload(n_n0, n_nn, wave, li, lh, xraw, 4 + kk, 1);
+                    dma((k + 2) % G_NSTEP);
+                    RR_SB();
+#endif
                 }
                 if (!last_of_step) {
 #pragma unroll
