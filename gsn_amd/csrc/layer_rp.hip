@@ -27,6 +27,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
+#include <vector>
 
 #include "chain_common.h"
 #include "layer_rr.h"
@@ -46,6 +47,7 @@ struct RpArgs {
     float *out;
     const unsigned *prep;
     int n_ranges;
+    int n_split;                       // nodes of the older half of the waves (0: equal ranges)
 };
 
 struct RpIdx { int r[3]; int pt, pt1; };
@@ -162,6 +164,7 @@ __global__ __launch_bounds__(64 * RR_NW) __attribute__((amdgpu_waves_per_eu(RR_N
     // ---- this wave's node range -----------------------------------------------------------------------------------------------
     const int range = wave * (int)gridDim.x + (int)blockIdx.x;
     if (range >= a.n_ranges) return;
+    const unsigned long long wave_t0 = PROF ? __builtin_amdgcn_s_memrealtime() : 0ull;
 #if RP_STAGGER > 0
     // the second wave of every SIMD starts a fraction of a tile late: both waves run the same tile loop on tiles of (nearly) the same
     // shape, so a phase offset set here persists -- one wave's matrix segments beside the other's conversions instead of beside its
@@ -173,8 +176,24 @@ __global__ __launch_bounds__(64 * RR_NW) __attribute__((amdgpu_waves_per_eu(RR_N
 #endif
     RrIter it;
     it.seg = a.seg_ptr; it.n_nodes = a.n_nodes;
-    it.m_next = (int)((int64_t)a.n_nodes * range / a.n_ranges);
-    it.m_end = (int)((int64_t)a.n_nodes * (range + 1) / a.n_ranges);
+    // The two waves of a SIMD are not served alike: the older one (waves 0 .. NW/2 - 1 of the workgroup) wins the issue arbitration and
+    // finishes an equal share ~28 % earlier (profiles/r05_layer_rp_issue.txt: first wave done at 308 us, last at 430) -- and the younger
+    // one, then alone on its SIMD, runs at the pair's combined rate: the SIMD's instruction issue is what is full, so cutting the node
+    // ranges unevenly (the first a.n_split nodes to the older half of the waves; GSN_RP_OLD_SHARE, default 0.6) only trims the tail:
+    // 0.519-0.529 -> 0.514 ms on one box, both waves ending within 15 % of each other instead of 28 %.
+    {
+        const int half_n = a.n_ranges >> 1;
+        if (a.n_split > 0 && half_n > 0 && (a.n_ranges & 1) == 0 && (int)gridDim.x * (RR_NW / 2) == half_n) {
+            const int young = wave >= RR_NW / 2 ? 1 : 0;
+            const int idx = range - young * half_n;
+            const int64_t base = young ? a.n_split : 0, cnt = young ? a.n_nodes - a.n_split : a.n_split;
+            it.m_next = (int)(base + cnt * idx / half_n);
+            it.m_end = (int)(base + cnt * (idx + 1) / half_n);
+        } else {
+            it.m_next = (int)((int64_t)a.n_nodes * range / a.n_ranges);
+            it.m_end = (int)((int64_t)a.n_nodes * (range + 1) / a.n_ranges);
+        }
+    }
     it.m0 = 0; it.nn = 0; it.eb = 0; it.ee = 0; it.ec = 0; it.pending = 0; it.win = 0;
     rr_iter_load(it, lane0);
     RrDesc cur = rr_iter_next(it, lane0);
@@ -704,6 +723,10 @@ __global__ __launch_bounds__(64 * RR_NW) __attribute__((amdgpu_waves_per_eu(RR_N
         for (int q = 0; q < 8; ++q) o[q] = pc[q];
         o[8] = clk() - t_start;
     }
+    if (PROF && prof && lane0 == 0) {                  // every wave's life on the constant 100 MHz clock: how evenly the ranges end
+        prof[32 + 2 * range] = wave_t0;
+        prof[32 + 2 * range + 1] = __builtin_amdgcn_s_memrealtime();
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -777,6 +800,10 @@ int rp_forward(int64_t n_nodes, int64_t n_edges, const int32_t *seg_ptr, const g
     if (ranges > n_tiles) ranges = n_tiles;
     if (gx > ranges) gx = ranges;
     a.n_ranges = (int)ranges;
+    {
+        static const double share = [] { const char *d = getenv("GSN_RP_OLD_SHARE"); return d ? atof(d) : 0.6; }();
+        a.n_split = (ranges == gx * RR_NW && share > 0.0 && share < 1.0) ? (int)((double)n_nodes * share) : 0;
+    }
     static const bool prof_on = [] { const char *d = getenv("GSN_FUSED_PROF"); return d && atoi(d) != 0; }();
     const void *fn = prof_on ? reinterpret_cast<const void *>(&layer_fused_kernel_rp<4, 2, true>) : reinterpret_cast<const void *>(&layer_fused_kernel_rp<4, 2, false>);
     static DeviceOnce attr_set;
@@ -789,13 +816,28 @@ int rp_forward(int64_t n_nodes, int64_t n_edges, const int32_t *seg_ptr, const g
     if (getenv("GSN_CHAIN_TRACE")) fprintf(stderr, "gsn chain: layer_fused_kernel_rp<4,2> nodes %d edges %d grid %lld ranges %d\n", a.n_nodes, a.n_edges, (long long)gx, a.n_ranges);
     if (prof_on) {
         unsigned long long *prof = nullptr;
-        (void)hipMalloc(&prof, 32 * 8); (void)hipMemsetAsync(prof, 0, 32 * 8, st);
+        const size_t pn = 32 + 2 * (size_t)a.n_ranges;
+        (void)hipMalloc(&prof, pn * 8); (void)hipMemsetAsync(prof, 0, pn * 8, st);
         hipLaunchKernelGGL((layer_fused_kernel_rp<4, 2, true>), dim3((unsigned)gx), dim3(64 * RR_NW), SH::LDS_BYTES, st, a, prof);
-        unsigned long long h[32];
+        std::vector<unsigned long long> hv(pn);
+        unsigned long long *h = hv.data();
         (void)hipStreamSynchronize(st);
-        (void)hipMemcpy(h, prof, sizeof(h), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(h, prof, pn * 8, hipMemcpyDeviceToHost);
         (void)hipFree(prof);
         static int shown = 0;
+        if (shown % 8 == 7) {
+            unsigned long long t_lo = ~0ull, t_hi = 0, e_lo = ~0ull;
+            double life = 0.0, lmin = 1e30, lmax = 0.0;
+            for (int r = 0; r < a.n_ranges; ++r) {
+                const unsigned long long s0 = h[32 + 2 * r], s1 = h[32 + 2 * r + 1];
+                t_lo = s0 < t_lo ? s0 : t_lo; t_hi = s1 > t_hi ? s1 : t_hi; e_lo = s1 < e_lo ? s1 : e_lo;
+                const double l = (double)(s1 - s0);
+                life += l; lmin = l < lmin ? l : lmin; lmax = l > lmax ? l : lmax;
+            }
+            fprintf(stderr, "rpprof waves %d: first start -> last end %.1f us | wave life mean %.1f min %.1f max %.1f us | first end after %.1f us | mean life / span %.3f\n",
+                    a.n_ranges, (t_hi - t_lo) / 100.0, life / a.n_ranges / 100.0, lmin / 100.0, lmax / 100.0, (e_lo - t_lo) / 100.0,
+                    life / a.n_ranges / (double)(t_hi - t_lo));
+        }
         if (shown++ % 8 == 7)
             for (int w = 0; w < 2; ++w) {
                 const unsigned long long *o = h + 16 * w;
