@@ -53,6 +53,7 @@ struct CountArgs {
     int core_mask;             // bit d: some plan needs the d-core
     int off_ain;               // directed plans: the in-neighbour bit matrix
     int stride;                // words per plan (plan_stride)
+    int pull_batch;            // idle lanes that wait before the pool's pull arm runs (1: every trip; GSN_PULL_BATCH)
     // fused identifier encoding (gsn_count_encode_hip): column c of a finished cell also / instead leaves as n_classes[c] floats
     // with a single 1 (utils_graph_learning.one_hot_encoder, :170-187) -- the int64 round trip through HBM and the one-hot launch go
     unsigned short enc_n[GSN_ENC_MAX_COLS];   // n_classes per output column (blocks in column order)
@@ -67,7 +68,7 @@ struct CountArgs {
 // diagnostic build (-DCOUNT_PROF, scripts/rr_variant.sh with RR_VARIANT_SRC=count): cycles of thread 0 per phase, summed over the workgroups
 #ifdef COUNT_PROF
 __device__ unsigned long long *g_count_prof;   // [items][8], set by the launcher
-#define COUNT_T(I) do { __syncthreads(); if (threadIdx.x == 0 && g_count_prof) { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); g_count_prof[(size_t)blockIdx.x * 8 + (I)] = t_now - t_prev; t_prev = t_now; } } while (0)
+#define COUNT_T(I) do { __syncthreads(); if (threadIdx.x == 0 && g_count_prof) { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); g_count_prof[(size_t)blockIdx.x * 16 + (I)] = t_now - t_prev; t_prev = t_now; } } while (0)
 #else
 #define COUNT_T(I)
 #endif
@@ -343,6 +344,15 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
     const int lane = tid & 63;
     const uint64_t lane_lt = (1ull << lane) - 1ull;
 
+#ifdef COUNT_PROF
+    unsigned prof_iters = 0, prof_lanes = 0;          // pool loop trips of the wave, lanes inside a rooted search summed over the trips
+    unsigned prof_arm[4] = {0, 0, 0, 0};              // cycles of the wave in the pull / begin / step / finish arm
+#define COUNT_ARM(I, T0) do { prof_arm[I] += (unsigned)(__builtin_amdgcn_s_memtime() - (T0)); } while (0)
+#define COUNT_ARM_T0() __builtin_amdgcn_s_memtime()
+#else
+#define COUNT_ARM(I, T0)
+#define COUNT_ARM_T0() 0ull
+#endif
     Lane<W> s;
     s.l = -1; s.cnt = 0; s.k = 0; s.nfix = 0; s.fvec = fv_roots<W>(0, 0); s.plan = plans;
     s.balls = balls; s.ball_n = a.n_cap; s.degp = nullptr; s.loop = 0;
@@ -356,9 +366,17 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
     int mirror_row = -1;
     const uint64_t *lane_valid = valid;     // candidate universe of the lane's current plan (a core of the graph)
 
+    // The loop is a state machine per lane (pull a cell, begin a plan, one search step, finish the cell) and a wave executes every arm
+    // some lane is in: on molecules a trip is ~350 instructions of which the step arm is ~100, and the whole pool is ~9 trips of ~4 000
+    // cycles (profiles/r05_count_phase_profile.txt) -- dependent LDS round trips, not arithmetic.  So (i) a cell that ends inside a begin
+    // or a step is finished in the SAME trip (its own arm behind them), and (ii) idle lanes are refilled in batches: the pull arm (an LDS
+    // atomic, the task decode, five dependent table reads) runs when GSN_PULL_BATCH lanes wait or when no lane is inside a search, not
+    // in every trip for the one lane that happened to finish.
     for (;;) {
         const bool need = !has_task && !exhausted;
-        const uint64_t m = __ballot(need);
+        uint64_t m = __ballot(need);
+        if (m && __popcll(m) < a.pull_batch && __ballot(has_task) != 0ull) m = 0ull;
+        const unsigned long long arm_t0 = COUNT_ARM_T0();
         if (m) {
             const int leader = __ffsll((unsigned long long)m) - 1;
             int base = 0;
@@ -402,29 +420,43 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
                 }
             }
         }
+        if (m) COUNT_ARM(0, arm_t0);
         if (__ballot(has_task) == 0ull) break;
+#ifdef COUNT_PROF
+        prof_iters += 1; prof_lanes += (unsigned)__popcll(__ballot(has_task && s.l >= 0));
+#endif
         if (has_task) {
             if (s.l < 0) {
                 if (p_i < p_e) {
+                    const unsigned long long t0 = COUNT_ARM_T0();
                     const uint32_t *pl = plans + p_i * (DIR ? PLAN_STRIDE_DIRECTED : PLAN_STRIDE_WORDS);
                     lane_valid = cores + plan_core(pl) * W;
                     lane_begin<W, DIR, TAIL>(s, pl, roots, A, lane_valid, stack, T, tid, A_in);
                     ++p_i;
-                } else {
-                    // cell finished
-                    emit_cell(t_row, t_col, s.cnt);
-                    if (mirror_row >= 0) emit_cell(mirror_row, t_col, s.cnt);
-                    if (edge_mode && rev_missing && s.cnt != 0) atomicMax(&misc[2], (int)GSN_ST_KEYERROR);
-                    has_task = false;
+                    COUNT_ARM(1, t0);
                 }
             } else {
+                const unsigned long long t0 = COUNT_ARM_T0();
                 lane_step<W, DIR, TAIL>(s, A, lane_valid, stack, T, tid, A_in);
+                COUNT_ARM(2, t0);
+            }
+            const unsigned long long t0f = COUNT_ARM_T0();
+            if (s.l < 0 && p_i >= p_e) {
+                // cell finished (its last plan ended in this trip's begin or step, or it had none)
+                emit_cell(t_row, t_col, s.cnt);
+                if (mirror_row >= 0) emit_cell(mirror_row, t_col, s.cnt);
+                if (edge_mode && rev_missing && s.cnt != 0) atomicMax(&misc[2], (int)GSN_ST_KEYERROR);
+                has_task = false;
+                COUNT_ARM(3, t0f);
             }
         }
     }
     __syncthreads();
 
     COUNT_T(5);
+#ifdef COUNT_PROF
+    if (threadIdx.x == 0 && g_count_prof) { g_count_prof[(size_t)blockIdx.x * 16 + 7] = ((unsigned long long)prof_iters << 32) | prof_lanes; for (int q = 0; q < 4; ++q) g_count_prof[(size_t)blockIdx.x * 16 + 8 + q] = prof_arm[q]; }
+#endif
     // ---- phase 4: coalesced write of the staged rows --------------------------------------------------------------
     if (a.stage_out) {   // (only with split == 1)
         int64_t *dst = a.out + row0 * n_cols;
@@ -525,15 +557,22 @@ static int launch_d(CountArgs &a, int n_items, size_t lds, hipStream_t stream) {
         static int shown = 0;
         if (shown++ % 16 == 15) {
             unsigned long long *buf = nullptr;
-            (void)hipMalloc(&buf, (size_t)n_items * 64);
-            (void)hipMemset(buf, 0, (size_t)n_items * 64);
+            (void)hipMalloc(&buf, (size_t)n_items * 128);
+            (void)hipMemset(buf, 0, (size_t)n_items * 128);
             (void)hipMemcpyToSymbol(HIP_SYMBOL(g_count_prof), &buf, sizeof(buf));
             hipLaunchKernelGGL((count_kernel<W, T, DIR, TAIL>), dim3((unsigned)n_items), dim3(T), lds, stream, a);
             (void)hipStreamSynchronize(stream);
-            unsigned long long *h = new unsigned long long[(size_t)n_items * 8];
-            (void)hipMemcpy(h, buf, (size_t)n_items * 64, hipMemcpyDeviceToHost);
+            unsigned long long *h = new unsigned long long[(size_t)n_items * 16];
+            (void)hipMemcpy(h, buf, (size_t)n_items * 128, hipMemcpyDeviceToHost);
             double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (int i = 0; i < n_items; ++i) for (int q = 0; q < 8; ++q) s[q] += (double)h[(size_t)i * 8 + q];
+            double it_sum = 0, ln_sum = 0, arm[4] = {0, 0, 0, 0};
+            for (int i = 0; i < n_items; ++i) {
+                for (int q = 0; q < 7; ++q) s[q] += (double)h[(size_t)i * 16 + q];
+                it_sum += (double)(h[(size_t)i * 16 + 7] >> 32); ln_sum += (double)(h[(size_t)i * 16 + 7] & 0xffffffffull);
+                for (int q = 0; q < 4; ++q) arm[q] += (double)h[(size_t)i * 16 + 8 + q];
+            }
+            fprintf(stderr, "countprof pool: %.1f loop trips per workgroup (wave 0), %.1f lanes of 64 inside a search per trip; cycles per workgroup in the arms: pull %.0f begin %.0f step %.0f finish %.0f\n",
+                    it_sum / n_items, it_sum > 0 ? ln_sum / it_sum : 0.0, arm[0] / n_items, arm[1] / n_items, arm[2] / n_items, arm[3] / n_items);
             fprintf(stderr, "countprof W %d T %d items %d: cycles per workgroup: clear+plan %.0f adjacency %.0f cores %.0f balls %.0f edge ranks %.0f task pool %.0f write %.0f\n", W, T, n_items,
                     s[0] / n_items, s[1] / n_items, s[2] / n_items, s[3] / n_items, s[4] / n_items, s[5] / n_items, s[6] / n_items);
             delete[] h;
@@ -585,6 +624,10 @@ static int count_launch(const uint32_t *plan_host, const uint32_t *plan_dev, int
     a.sym = (a.mode == GSN_MODE_EDGE && (plan_host[6] & 1u) == 0) ? 1 : 0;
     const bool directed = (plan_host[6] & 2u) != 0;
     a.stride = plan_stride(plan_host[6]);
+    {
+        static const int pull_batch = [] { const char *d = getenv("GSN_PULL_BATCH"); const int v = d ? atoi(d) : 8; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
+        a.pull_batch = pull_batch;
+    }
     if (directed && a.mode != GSN_MODE_VERTEX) return set_error(GSN_E_UNSUPPORTED, "gsn_count_hip: directed plans are vertex-mode plans");
     a.node_ptr = node_ptr; a.edge_ptr = edge_ptr;
     a.src = edge_index; a.dst = edge_index ? edge_index + edge_row_stride : nullptr;
