@@ -68,94 +68,89 @@ class S2VGraph:
         self.max_neighbor = 0
 
 
-class _InsertionOrderedGraph:
-    """The slice of networkx.Graph semantics the TU loader depends on: nodes and adjacency keep insertion order,
-    ``edges()`` lists every undirected edge once, at the endpoint that comes first in node order, and a repeated
-    ``add_edge`` does not move anything."""
+def _tu_records(path, name):
+    """Tokenise a TU "powerful-gnns" file once: yields ``(label, tags, neighbour_lists)`` per graph.  A node line is
+    ``tag m n_1 .. n_m`` optionally followed by attribute columns the reference drops (utils_data_prep.py:58-66)."""
+    with open(os.path.join(path, name + ".txt"), "r") as fh:
+        lines = iter(fh.read().split("\n"))
+    n_graphs = int(next(lines).split()[0])
+    for _ in range(n_graphs):
+        n_nodes, label = (int(w) for w in next(lines).split()[:2])
+        tags, nbrs = [], []
+        for _ in range(n_nodes):
+            tok = next(lines).split()
+            m = int(tok[1])
+            tags.append(int(tok[0]))
+            nbrs.append([int(w) for w in tok[2:2 + m]])
+        yield label, tags, nbrs
 
-    def __init__(self):
-        self.adj = {}
 
-    def add_node(self, u):
-        if u not in self.adj:
-            self.adj[u] = {}
+def _undirected_in_first_touch_order(nbrs):
+    """What the reference gets out of networkx for one graph (utils_data_prep.py:52-72, :104-108), without networkx: vertices in the order
+    they are first touched (vertex j when its line is read, a neighbour when the first line naming it is read), every vertex's
+    adjacency in the order its edges first appear, each undirected edge listed once at whichever endpoint comes first in vertex order;
+    a self loop counts twice in the degree.  -> (vertex order, edge list, degree per vertex in vertex order)"""
+    rank, adjacency = {}, []
 
-    def add_edge(self, u, v):
-        self.add_node(u)
-        self.add_node(v)
-        self.adj[u][v] = True
-        self.adj[v][u] = True
+    def touch(u):
+        if u not in rank:
+            rank[u] = len(adjacency)
+            adjacency.append({})
+        return rank[u]
 
-    def __len__(self):
-        return len(self.adj)
+    for j, row in enumerate(nbrs):
+        rj = touch(j)
+        for v in row:
+            rv = touch(v)
+            adjacency[rj].setdefault(v, None)
+            adjacency[rv].setdefault(j, None)
+    order = sorted(rank, key=rank.get)
+    edges = [(u, v) for u in order for v in adjacency[rank[u]] if rank[v] >= rank[u]]
+    degrees = [len(adjacency[rank[u]]) + (1 if u in adjacency[rank[u]] else 0) for u in order]
+    return order, edges, degrees
 
-    def edges(self):
-        done = set()
-        out = []
-        for u, nbrs in self.adj.items():
-            for v in nbrs:
-                if v not in done:
-                    out.append((u, v))
-            done.add(u)
-        return out
 
-    def degrees(self):
-        # networkx counts a self loop twice in the degree view
-        return [len(nb) + (1 if u in nb else 0) for u, nb in self.adj.items()]
+def _first_seen(values):
+    """value -> index in order of first appearance"""
+    table = {}
+    for v in values:
+        table.setdefault(v, len(table))
+    return table
 
 
 def load_data(path, name, degree_as_tag):
     """TU txt reader -> ``(list of S2VGraph, num_classes)`` (utils_data_prep.py:35-136).
 
-    edge_mat = the graph's undirected edges in insertion order followed by the same list reversed pairwise
+    edge_mat = the graph's undirected edges in first-touch order followed by the same list reversed pairwise
     (:104-108); node_features = one-hot of the node tag over the dataset's tag set (:114-125)."""
-    g_list, graphs = [], []
-    label_dict, feat_dict = {}, {}
-    with open("%s/%s.txt" % (path, name), "r") as f:
-        n_g = int(f.readline().strip())
-        for _ in range(n_g):
-            n, l = [int(w) for w in f.readline().strip().split()]
-            if l not in label_dict:
-                label_dict[l] = len(label_dict)
-            g = _InsertionOrderedGraph()
-            node_tags = []
-            for j in range(n):
-                g.add_node(j)
-                row = f.readline().strip().split()
-                tmp = int(row[1]) + 2
-                row = [int(w) for w in row[:tmp]] if tmp != len(row) else [int(w) for w in row]
-                if row[0] not in feat_dict:
-                    feat_dict[row[0]] = len(feat_dict)
-                node_tags.append(feat_dict[row[0]])
-                for k in range(2, len(row)):
-                    g.add_edge(j, row[k])
-            assert len(g) == n
-            g_list.append(S2VGraph(l, node_tags))
-            graphs.append(g)
-    for s, g in zip(g_list, graphs):
-        order = list(g.adj.keys())
-        s.neighbors = [[] for _ in range(len(g))]
-        edges = g.edges()
-        for i, j in edges:
-            s.neighbors[i].append(j)
-            s.neighbors[j].append(i)
-        s.max_neighbor = max(len(nb) for nb in s.neighbors) if len(g) else 0
-        s.label = label_dict[s.label]
-        pairs = [list(p) for p in edges]
-        pairs.extend([[i, j] for j, i in pairs])
-        s.edge_mat = torch.LongTensor(pairs).transpose(0, 1) if pairs else torch.zeros((2, 0), dtype=torch.long)
-        if degree_as_tag:
-            deg = dict(zip(order, g.degrees()))
-            s.node_tags = [deg[u] for u in order]
-    tagset = set([])
-    for s in g_list:
-        tagset = tagset.union(set(s.node_tags))
-    tagset = list(tagset)
-    tag2index = {tagset[i]: i for i in range(len(tagset))}
-    for s in g_list:
-        s.node_features = torch.zeros(len(s.node_tags), len(tagset))
-        s.node_features[range(len(s.node_tags)), [tag2index[t] for t in s.node_tags]] = 1
-    return g_list, len(label_dict)
+    records = list(_tu_records(path, name))
+    class_of = _first_seen(label for label, _, _ in records)
+    tag_of = _first_seen(t for _, tags, _ in records for t in tags)
+    out = []
+    for label, tags, nbrs in records:
+        order, edges, degrees = _undirected_in_first_touch_order(nbrs)
+        if len(order) != len(nbrs):
+            raise AssertionError("%s: a neighbour id outside 0 .. %d" % (name, len(nbrs) - 1))
+        g = S2VGraph(class_of[label], degrees if degree_as_tag else [tag_of[t] for t in tags])
+        g.neighbors = [[] for _ in order]
+        for u, v in edges:
+            g.neighbors[u].append(v)
+            g.neighbors[v].append(u)
+        g.max_neighbor = max((len(nb) for nb in g.neighbors), default=0)
+        both = edges + [(v, u) for u, v in edges]
+        g.edge_mat = torch.tensor(both, dtype=torch.long).t().contiguous() if both else torch.zeros((2, 0), dtype=torch.long)
+        out.append(g)
+    # the feature COLUMN of a tag is its position in CPython's iteration order of the set grown by these unions (:114-118) -- not sorted
+    # order once the tags (degrees) exceed the table size, so the set is grown the same way
+    seen = set()
+    for g in out:
+        seen = seen.union(set(g.node_tags))
+    column = {t: i for i, t in enumerate(seen)}
+    for g in out:
+        idx = torch.tensor([column[t] for t in g.node_tags], dtype=torch.long)
+        g.node_features = torch.zeros(len(g.node_tags), len(column))
+        g.node_features[torch.arange(len(g.node_tags)), idx] = 1
+    return out, len(class_of)
 
 
 def load_g6_graphs(path, name):

@@ -31,7 +31,7 @@ extern "C" {
 enum {
     GSN_OK = 0,
     GSN_E_INVALID = -1,     /* bad argument */
-    GSN_E_UNSUPPORTED = -2, /* valid in the reference but outside this build (e.g. k > GSN_KMAX, n > 1024) */
+    GSN_E_UNSUPPORTED = -2, /* valid in the reference but outside this build (e.g. k > GSN_KMAX, n > 768: INTEGRATION.md 11) */
     GSN_E_HIP = -3,         /* HIP runtime error (message has hipGetErrorString) */
     GSN_E_NOSPACE = -4,     /* caller buffer too small */
     GSN_E_NODEVICE = -5     /* no gfx950 device visible */
