@@ -36,7 +36,8 @@ class GraphedStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.outputs = fn()
-        layers.drop_input_caches()                     # (what the capture cached lives in graph-pool memory no eager call has written)
+        layers.drop_input_caches()                     # (what the capture cached lives in graph-pool memory no eager call has written:
+        layers.drop_capture_caches()                   #  indices of the inputs, and the derived weights keyed on the parameters' versions)
         self.replays = 0
 
     def __call__(self):
@@ -116,6 +117,7 @@ class GraphedTrainStep:
         # what the capture cached -- derived weights keyed on the parameters' versions, indices of the inputs -- lives in graph-pool memory
         # that nothing has written yet (a capture records): an eager forward before the first replay must not find it
         layers.drop_input_caches()
+        layers.drop_capture_caches()
         torch.autograd.graph.increment_version(self._bump)
         self.replays = 0
         self.steps_taken = max(1, warmup)              # (a capture records, it does not execute)

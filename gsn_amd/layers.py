@@ -35,7 +35,7 @@ from . import _abi, packs
 
 __all__ = ["mlp", "central_encoder", "GSN_sparse", "GSN_edge_sparse", "MPNN_sparse", "MPNN_edge_sparse",
            "GSN_edge_sparse_ogb", "MPNN_edge_sparse_ogb", "build_csr", "propagate", "run_stages", "one_hot_identifiers",
-           "global_add_pool_sparse", "global_mean_pool_sparse", "Codes", "run_linear_module", "invalidate_caches", "drop_input_caches", "set_graph_partition", "build_csr_graphs"]
+           "global_add_pool_sparse", "global_mean_pool_sparse", "Codes", "run_linear_module", "invalidate_caches", "drop_input_caches", "drop_capture_caches", "set_graph_partition", "build_csr_graphs"]
 
 _ACT_CODE = {"identity": 0, "relu": 1, "elu": 2, "tanh": 3}
 _MAX_BLOCKS = 5
@@ -139,7 +139,7 @@ class Codes:
     [R, sum(n_classes)].  Layers accept it for ``x``, ``identifiers`` and ``edge_features``; where all inputs of msg_fn's
     first Linear are Codes that Linear becomes a weight-row gather (gsn_code_stage_fwd_hip) and the dense one-hot
     matrix is never built; everywhere else the layer densifies it."""
-    __slots__ = ("codes", "n_classes", "clamp", "_dense", "_pack16")
+    __slots__ = ("codes", "n_classes", "clamp", "_dense", "_pack16", "__weakref__")
 
     def __init__(self, codes, n_classes, clamp=False):
         codes = codes.unsqueeze(-1) if codes.dim() == 1 else codes
@@ -628,6 +628,7 @@ def _f16x3_weights(weight, w32):
                                                               _abi.current_stream()), "gsn_linear_f16x3_prepare_strided_hip")
     try:
         weight._gsn_f16x3 = (key, planes, col_inv)
+        _note_cache(weight, "_gsn_f16x3")
     except (AttributeError, RuntimeError):
         pass
     return planes, col_inv
@@ -902,6 +903,29 @@ def _async_validate(module):
     st["pending"].append((ev, slot, versions))
 
 
+_CAPTURE_CACHED = []     # (owner, attribute) of every derived-weight cache entry made while a stream capture was under way
+
+
+def _note_cache(owner, attr):
+    """A derived tensor (prepared weights, folded weight, eval-mode BatchNorm vectors, transposed weight, fp16 planes) was just cached
+    on ``owner``.  Made during a stream capture it lives in graph-pool memory that nothing has written until the first replay: noted, so
+    that gsn_amd.graphs drops it behind the capture and an eager call before the first replay prepares its own."""
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        _CAPTURE_CACHED.append((weakref.ref(owner), attr))
+
+
+def drop_capture_caches():
+    """Drop the cache entries noted by _note_cache (called by gsn_amd.graphs right behind a capture)."""
+    while _CAPTURE_CACHED:
+        ref, attr = _CAPTURE_CACHED.pop()
+        owner = ref()
+        if owner is not None and hasattr(owner, attr):
+            try:
+                delattr(owner, attr)
+            except AttributeError:
+                pass
+
+
 def drop_input_caches():
     """Drop everything cached per INPUT tensor (aggregation index of an ``edge_index``, readout index pairs and graph sizes of a
     ``batch`` vector): the next forward builds them again.  gsn_amd.graphs calls this in front of a stream capture."""
@@ -1022,6 +1046,7 @@ def _layer_fused(x, csr, edge_stages, node_stages, training, owner=None, gen=0, 
                                                                 _abi.current_stream()), "gsn_layer_fused_pack16_prepare_hip")
             if owner is not None:
                 owner._fused_prep16 = (key, prep)
+                _note_cache(owner, "_fused_prep16")
         out = torch.empty((n, node_stages[1].weight.shape[0]), dtype=torch.float32, device=x.device)
         pk = _abi.gsn_pack16()
         pk.node_rows = pack16[0].data_ptr()
@@ -1053,6 +1078,7 @@ def _layer_fused(x, csr, edge_stages, node_stages, training, owner=None, gen=0, 
                                                      _abi.current_stream()), "gsn_layer_fused_prepare_hip")
         if owner is not None:
             owner._fused_prep = (key, prep)
+            _note_cache(owner, "_fused_prep")
     # a collated batch with known graph boundaries, every graph <= 128 vertices: the d = 128 layer on graph-aligned tiles (csrc/layer_g.hip:
     # the node part of the edge stage once per node); same prepared buffer, no workspace, no row exponents
     part = getattr(csr, "part", None)
@@ -1111,7 +1137,9 @@ def _bn_resolve(stage, stats_fn, m_rows, training, fuse_act=None):
             # alone and still counts the batch; the vectors below are never applied to a row
             n_out, dev = bn.num_features, stage.weight.device
             if training and bn.track_running_stats and bn.num_batches_tracked is not None:
-                bn.num_batches_tracked += 1
+                bn.num_batches_tracked += 1             # (an ordinary in-place op: the version counter moves with it eagerly ...)
+                if RAW_WRITTEN is not None:              # (... and a replay of the captured add must move it too)
+                    RAW_WRITTEN.append(bn.num_batches_tracked)
             vec = torch.zeros((4, n_out), dtype=torch.float32, device=dev)
             vec[1:3] = 1.0
             stage.bn_params = (vec[0], vec[2], vec[3])
@@ -1147,7 +1175,7 @@ def _bn_resolve(stage, stats_fn, m_rows, training, fuse_act=None):
                                                           bn.running_mean.data_ptr() if track else None, bn.running_var.data_ptr() if track else None,
                                                           p0, p0 + 4 * n_out, p0 + 8 * n_out, p0 + 12 * n_out,
                                                           _abi.ptr(nbt), _abi.current_stream())
-        _abi.check(rc, "gsn_bn_finalize_count_hip")
+        _abi.check(rc, "gsn_bn_finalize_act_hip" if fuse_act is not None else "gsn_bn_finalize_count_hip")
         if track:
             # the kernel wrote the running statistics (and the counter) through raw pointers: PyTorch's version counters, on which the
             # eval-mode vectors of this module are cached, have to move with them (no launch); a step being captured into a graph notes
@@ -1175,6 +1203,7 @@ def _bn_resolve(stage, stats_fn, m_rows, training, fuse_act=None):
         stage.bn_params = (mean32.contiguous(), scale.contiguous(), shift.contiguous())
         stage.bn_invstd = invstd.contiguous()
         bn._gsn_eval_cache = (key, stage.bn_params, stage.bn_invstd)
+        _note_cache(bn, "_gsn_eval_cache")
         return
     scale = invstd * bn.weight.detach() if bn.affine else invstd
     shift = bn.bias.detach() if bn.affine else torch.zeros_like(invstd)
@@ -1527,6 +1556,7 @@ def _transposed_weight(lin):
     if hit is None or hit[0] != key:
         hit = (key, lin.weight.detach().to(torch.float32).t().contiguous())
         lin._gsn_wt = hit
+        _note_cache(lin, "_gsn_wt")
     return hit[1]
 
 
@@ -2198,6 +2228,7 @@ class _SparseLayer(nn.Module):
             wz_t = w_z.t().contiguous() if d_r else None                                  # [d_r, d_h]
             cache = (key, w_n, bias_n, wz_t)
             self._split_cache = cache
+            _note_cache(self, "_split_cache")
         _, w_n, bias_n, wz_t = cache
         P = _linear_hip([(b, None) for b in node_blocks], w_n, bias_n, None, None, None, 0, n)          # [N, 2 d_h]
         zs = [_f32c(b) for b in edge_blocks]
@@ -2227,6 +2258,7 @@ class _SparseLayer(nn.Module):
         # three zero columns after the degree column: the degree block is passed 4 floats wide (csr.deg4)
         w_first = torch.cat([w3x, w_fold, b_fold, torch.zeros_like(b_fold).expand(-1, 3)], 1).contiguous()
         self._fold_cache = (key, w_first)
+        _note_cache(self, "_fold_cache")
         self._fold_gen = getattr(self, "_fold_gen", 0) + 1        # (a new tensor may reuse the old one's address)
         return w_first
 

@@ -49,6 +49,20 @@ def claim(t, pack, col0):
     t._gsn_pack16 = (pack, int(col0), t._version)
 
 
+def _claim_codes(cd, pack, col0):
+    """The same for a gsn_amd.layers.Codes object whose one-hot encoding was just written into columns col0.. of ``pack``: the claim
+    enters the pack's owner table (a later producer that writes those columns ends it), the tag is bound to the code tensor's version."""
+    owners = getattr(pack, "_gsn_owners", None)
+    if owners is None:
+        owners = {}
+        pack._gsn_owners = owners
+    w = sum(cd.n_classes)
+    for c in [c for c, (ref, cw) in owners.items() if c < col0 + w and col0 < c + cw]:
+        del owners[c]
+    owners[int(col0)] = (weakref.ref(cd), w)
+    cd._pack16 = (pack, int(col0), cd.codes._version)
+
+
 def release(t):
     """Drop the tag of ``t`` (a kernel is about to overwrite it through its raw pointer: the version counter will not move)."""
     if getattr(t, "_gsn_pack16", None) is not None:
@@ -90,6 +104,7 @@ def node_pack(x, check=True):
         raise ValueError("node_pack: x must be [N, d_x] with d_x <= %d" % (NODE_COLS - 4))
     pack = new_node_pack(x.shape[0], x.device)
     _pack_rows(x, pack, 0, NODE_COLS - 1, check)
+    pack._gsn_node_pack = True
     claim(x, pack, 0)
     return pack
 
@@ -140,7 +155,8 @@ def pack_node_codes(cd, pack=None):
     elif tuple(pack.shape) != (cd.codes.shape[0], NODE_COLS) or pack.dtype != torch.float16:
         raise ValueError("pack_node_codes: pack must be fp16 [%d, %d]" % (cd.codes.shape[0], NODE_COLS))
     _pack_codes(cd, pack, 0, NODE_COLS - 1)
-    cd._pack16 = (pack, 0, cd.codes._version)
+    pack._gsn_node_pack = True          # (column 31 = 1.0 has been written: the edge stage's bias rides it)
+    _claim_codes(cd, pack, 0)
     return pack
 
 
@@ -149,7 +165,7 @@ def pack_edge_codes(cd, pack, col0):
     if col0 + sum(cd.n_classes) > EDGE_COLS or pack.shape != (cd.codes.shape[0], EDGE_COLS):
         raise ValueError("pack_edge_codes: columns %d .. %d of a %s pack" % (col0, col0 + sum(cd.n_classes), tuple(pack.shape)))
     _pack_codes(cd, pack, col0, -1)
-    cd._pack16 = (pack, int(col0), cd.codes._version)
+    _claim_codes(cd, pack, col0)
     return pack
 
 
@@ -161,7 +177,8 @@ def from_codes(x_codes, per_edge):
     per_edge = [c for c in per_edge if c is not None]
     if sum(x_codes.n_classes) > NODE_COLS - 4 or sum(_width(c) for c in per_edge) > EDGE_COLS:
         return None
-    npk = x_codes._pack16[0] if _codes_tag(x_codes) is not None else pack_node_codes(x_codes)
+    tgx = _codes_tag(x_codes)
+    npk = tgx[0] if tgx is not None and tgx[1] == 0 and getattr(tgx[0], "_gsn_node_pack", False) else pack_node_codes(x_codes)
     epk = None
     if per_edge:
         rows = per_edge[0].shape[0]
@@ -187,7 +204,10 @@ def from_codes(x_codes, per_edge):
 def _codes_tag(cd):
     """(pack, first column, ..) of an encoded Codes object while its code tensor is unchanged (an in-place write moves the version counter)"""
     tg = cd._pack16
-    return tg if tg is not None and tg[2] == cd.codes._version else None
+    if tg is None or tg[2] != cd.codes._version:
+        return None
+    own = getattr(tg[0], "_gsn_owners", {}).get(tg[1])      # (another Codes / tensor encoded into these columns since: the claim is gone)
+    return tg if own is not None and own[0]() is cd else None
 
 
 def _width(c):
@@ -200,7 +220,7 @@ def lookup(x, per_edge):
     if not isinstance(x, torch.Tensor) or x.dim() != 2:
         return None
     nt = tag_of(x, x.shape[0], NODE_COLS)
-    if nt is None or nt[1] != 0:
+    if nt is None or nt[1] != 0 or not getattr(nt[0], "_gsn_node_pack", False):      # (a node pack: made by node_pack / pack_node_codes, column 31 = 1.0)
         return None
     epack, col = None, 0
     for t in per_edge:

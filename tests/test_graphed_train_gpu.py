@@ -242,3 +242,44 @@ def test_replay_on_a_refilled_static_batch_equals_the_eager_step_on_that_batch(p
             return
         problems.append("attempt %d: %s" % (attempt, "; ".join(bad)))
     raise AssertionError(" | ".join(problems))
+
+
+def test_derived_weights_cached_during_a_capture_are_dropped_behind_it():
+    """prepared weights / folded weights / eval-mode BatchNorm vectors made WHILE a stream capture is under way live in
+    graph-pool memory nothing has written before the first replay.  They are noted and dropped behind the capture: an eager forward between
+    construction and first replay prepares its own and returns the right rows; the first replay does too."""
+    from gsn_amd import layers, synth
+    from gsn_amd.graphs import GraphedStep
+    b = synth.zinc_shape_batch(24, seed=5)
+    torch.manual_seed(3)
+    ctor = dict(d_in=28, d_ef=4, d_id=4, d_degree=1, degree_as_tag=False, retain_features=True, id_scope="local", d_msg=128,
+                d_up=128, d_h=[128], seed=0, activation_name="relu", bn=True, msg_kind="general", flow="source_to_target")
+    layer = layers.GSN_edge_sparse(**ctor).cuda().eval()
+    x = torch.nn.functional.one_hot(torch.from_numpy(b.atom_type), 28).float().cuda()
+    ef = torch.nn.functional.one_hot(torch.from_numpy(b.bond_type), 4).float().cuda()
+    ids = torch.rand(b.num_edges, 4).cuda()
+    ei = torch.from_numpy(b.edge_index).cuda()
+    deg = torch.zeros(b.num_nodes, device="cuda")
+    calls = [0]
+
+    def fn():
+        calls[0] += 1
+        if calls[0] == 3:                       # the third call is the capture (two warm-up calls): everything derived is made inside it
+            layers.invalidate_caches(layer)
+        with torch.no_grad():
+            return layer(x, ei, identifiers=ids, degrees=deg, edge_features=ef)
+    with torch.no_grad():
+        y0 = layer(x, ei, identifiers=ids, degrees=deg, edge_features=ef).clone()
+    step = GraphedStep(fn, warmup=2)
+    assert calls[0] == 3
+    assert not layers._CAPTURE_CACHED
+    for m in layer.modules():
+        for attr in ("_fold_cache", "_split_cache", "_fused_prep", "_fused_prep16", "_gsn_eval_cache", "_gsn_wt"):
+            assert not hasattr(m, attr), (type(m).__name__, attr)
+    with torch.no_grad():
+        y_eager = layer(x, ei, identifiers=ids, degrees=deg, edge_features=ef).clone()     # before the first replay
+    torch.cuda.synchronize()
+    assert torch.equal(y_eager, y0)
+    y_replay = step().clone()
+    torch.cuda.synchronize()
+    assert torch.equal(y_replay, y0)

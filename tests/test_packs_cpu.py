@@ -40,6 +40,8 @@ def test_lookup_matches_one_node_pack_and_one_edge_pack_in_concatenation_order()
     epk = torch.zeros(9, packs.EDGE_COLS, dtype=torch.float16)
     x = _tagged(5, 28, npk, 0)
     ids, ef = _tagged(9, 12, epk, 0), _tagged(9, 4, epk, 12)
+    assert packs.lookup(x, [ids, ef]) is None                      # a [N, 32] pack that no node-pack producer marked: column 31 may not be 1.0
+    npk._gsn_node_pack = True                                      # (what node_pack / pack_node_codes set behind writing column 31)
     assert packs.lookup(x, [ids, ef]) == (npk, epk)
     assert packs.lookup(x, []) == (npk, None)                      # cat(x_i, x_j) alone
     assert packs.lookup(x, [ef, ids]) is None                      # wrong order: ef would have to start at column 0
@@ -63,3 +65,29 @@ def test_tag_dies_with_its_tensor():
     u = torch.zeros(3, 8)
     u._gsn_pack16 = (epk, 0, u._version)                           # a forged tag without a claim
     assert packs.tag_of(u, 3, packs.EDGE_COLS) is None
+
+
+class _FakeCodes:
+    """the slice of gsn_amd.layers.Codes the ownership logic reads (a real Codes needs a GPU tensor)"""
+    def __init__(self, rows, n_classes):
+        self.codes = torch.zeros(rows, len(n_classes), dtype=torch.int64)
+        self.n_classes = list(n_classes)
+        self._pack16 = None
+
+
+def test_codes_claims_enter_the_owner_table():
+    """a Codes tag used to be checked against the code tensor's version only -- re-using a pack for another batch's codes left the
+    first Codes object believing its encoding was still in the pack."""
+    epk = torch.zeros(6, packs.EDGE_COLS, dtype=torch.float16)
+    a, b = _FakeCodes(6, [4]), _FakeCodes(6, [4])
+    packs._claim_codes(a, epk, 12)
+    assert packs._codes_tag(a) is not None and packs._codes_tag(a)[:2] == (epk, 12)
+    packs._claim_codes(b, epk, 12)                                 # the same columns encoded again from other codes
+    assert packs._codes_tag(a) is None and packs._codes_tag(b)[:2] == (epk, 12)
+    ids = _tagged(6, 14, epk, 0)                                   # a tensor claiming columns 0 .. 13 overlaps b's 12 .. 15
+    assert packs._codes_tag(b) is None and packs.tag_of(ids, 6, packs.EDGE_COLS) == (epk, 0)
+    c = _FakeCodes(6, [4])
+    packs._claim_codes(c, epk, 12)                                 # ... and the other way round
+    assert packs.tag_of(ids, 6, packs.EDGE_COLS) is None
+    c.codes.add_(1)                                                # codes rewritten in place: the version counter moved
+    assert packs._codes_tag(c) is None
