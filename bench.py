@@ -1057,20 +1057,22 @@ def main():
         # kernel, FETCH_SIZE x2 (gfx950 under-reports wide reads, MI355X_MICROARCH.md) + WRITE_SIZE, in bytes.
         try:
             import csv
-            pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_bench_pmc.csv")
+            import glob
+            pmc = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r[0-9][0-9]_bench_pmc.csv")))[-1]   # the latest round's
+            pmc_name = "profiles/" + os.path.basename(pmc)
             key = {"layer_fused": "gsn::layer_fused_kernel", "mlp_chain": "gsn::mlp_chain"}.get(dom, roof["kernel"])   # (not layer_fused_prepare_kernel)
             rows = [r for r in csv.DictReader(open(pmc)) if key in r["kernel"]]
             if rows and G == 65536:
                 tot = sum((2.0 * float(r["FETCH_SIZE_per_dispatch"]) + float(r["WRITE_SIZE_per_dispatch"])) * 1024.0 for r in rows)
                 roof["traffic"] = round(tot / len(rows))
-                roof["traffic_source"] = "profiles/r04_bench_pmc.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
+                roof["traffic_source"] = pmc_name + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
             crow = [r for r in csv.DictReader(open(pmc)) if "count_kernel" in r["kernel"]]
             if crow and G == 65536:      # the counting kernel is VALU-bound, not bandwidth-bound -- show it
                 r0 = crow[0]
                 pmc_count = {"valu_busy_frac_of_wave_cycles": round(float(r0["SQ_ACTIVE_INST_ANY_per_dispatch"]) / float(r0["SQ_WAVE_CYCLES_per_dispatch"]), 4),
                              "valu_instructions_per_dispatch": float(r0["SQ_INSTS_VALU_per_dispatch"]),
                              "hbm_bytes_per_dispatch": round((2.0 * float(r0["FETCH_SIZE_per_dispatch"]) + float(r0["WRITE_SIZE_per_dispatch"])) * 1024.0),
-                             "source": "profiles/r04_bench_pmc.csv"}
+                             "source": pmc_name}
             else:
                 pmc_count = None
         except Exception:
@@ -1091,6 +1093,15 @@ def main():
             "count_maps_per_s": round(n_maps / (ck["ms_per_step"] * 1e-3), 1),
             "count_hbm_GBs": round(ck["work_per_step"] / (ck["ms_per_step"] * 1e-3) / 1e9, 1),
             "count_pmc": pmc_count,
+            # SURVEY 8(d) for HP-1: integer vector work against the chip's integer-VALU ceiling (256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz =
+            # 78.6 T lane-ops/s) -- the counting kernel is neither bandwidth- nor issue-bound but latency-bound (profiles/r05_count_phase_profile.txt)
+            "count_roofline": None if pmc_count is None else {
+                "lane_ops_per_s": round(pmc_count["valu_instructions_per_dispatch"] * 64.0 / (ck["ms_per_step"] * 1e-3), 1),
+                "frac_of_78.6T_integer_valu": round(pmc_count["valu_instructions_per_dispatch"] * 64.0 / (ck["ms_per_step"] * 1e-3) / 78.6e12, 4),
+                "valu_busy": pmc_count["valu_busy_frac_of_wave_cycles"],
+                "hbm_frac": round(ck["work_per_step"] / (ck["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "bound": "latency x occupancy (5 one-wave workgroups per SIMD): not VALU issue, not HBM",
+                "valu_instructions_source": pmc_count["source"]},
             "ms_per_step_by_kernel": per_launch,
             "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 4),
             "eager_ms_per_step": round(dt_eager / args.steps * 1e3, 4),
