@@ -80,7 +80,11 @@ __device__ unsigned long long *g_count_prof;   // [items][8], set by the launche
 // tables, edge ranks: latency of dependent LDS round trips, half of a workgroup's life) are paid once per pair, and the task pool
 // keeps 64 lanes busy twice as long.  report = false (a pair): nothing is reported, a pair that does not fit or holds an error
 // returns 1 and the caller redoes its graphs one by one.
-template <int W, int T, bool DIR, bool TAIL>
+// MOL: the launch's invariants of the molecule datasets' identifier pass as compile-time constants -- edge mode with undirected orbit
+// classes (symmetric rows), four output columns, one workgroup per pair of graphs (no split), encoded rows staged as class
+// indices -- instead of ~12 launch arguments that are tested in every arm of the pool and held in scalar registers
+// through the whole kernel (106 of them + spills before).  The launcher selects it when all of that holds (launch<>()).
+template <int W, int T, bool DIR, bool TAIL, bool MOL>
 __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *smem, const int item, const int part, const int g, const int ng, const bool report) {
 #ifdef COUNT_PROF
     unsigned long long t_prev = __builtin_amdgcn_s_memtime();
@@ -111,10 +115,12 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
     const int64_t n0 = a.node_ptr[g], e0 = a.edge_ptr[g];
     const int64_t n64 = a.node_ptr[g + ng] - n0, E64 = a.edge_ptr[g + ng] - e0;
     const int64_t nA64 = a.node_ptr[g + 1] - n0, EA64 = a.edge_ptr[g + 1] - e0;      // the first graph's share (ng = 1: everything)
-    const bool edge_mode = a.mode == GSN_MODE_EDGE;
+    const bool edge_mode = MOL || a.mode == GSN_MODE_EDGE;
     const int64_t rows64 = edge_mode ? E64 : n64;
     const int64_t row0 = edge_mode ? e0 : n0;
-    const int n_cols = a.n_cols;
+    const int n_cols = MOL ? 4 : a.n_cols;
+    const bool a_stage_out = a.stage_out != 0, a_sym = MOL || a.sym != 0, a_enc = MOL || a.enc_out != nullptr, a_enc_stage = MOL || a.enc_stage != 0;
+    const int a_split = MOL ? 1 : a.split;
 
     if (ng > 1 && (n64 > a.n_cap || E64 > a.e_cap || n64 > W * 64)) return 1;
     if (ng == 1 && (n64 > a.n_decl || E64 > a.e_decl || n64 > W * 64)) {
@@ -132,14 +138,14 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
 
     // one finished cell (row, column) = cnt: the int64 row (staged or direct), the staged class index or the encoded floats
     auto emit_cell = [&](int row, int col, uint64_t cnt) {
-        if (a.stage_out) out_lds[row * n_cols + col] = cnt;
+        if (a_stage_out) out_lds[row * n_cols + col] = cnt;
         else if (a.out) a.out[(row0 + row) * n_cols + col] = (int64_t)cnt;
-        if (a.enc_out) {
+        if (a_enc) {
             const int *enc_t = reinterpret_cast<const int *>(smem + a.off_enc);
             const int eo = enc_t[2 * col], ncls = enc_t[2 * col + 1];
             uint64_t v = cnt;
             if (a.enc_clamp && v >= (uint64_t)ncls) v = (uint64_t)(ncls - 1);
-            if (a.enc_stage) {
+            if (a_enc_stage) {
                 (smem + a.off_encst)[row * n_cols + col] = v < (uint64_t)ncls ? (unsigned char)v : (unsigned char)0xff;
             } else {
                 float *d0 = a.enc_out + (row0 + row) * a.enc_width + eo;
@@ -153,7 +159,7 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
     if (DIR)
         for (int i = tid; i < n * W; i += T) A_in[i] = 0ull;
     for (int i = tid; i < a.plan_words; i += T) plan[i] = a.plan[i];
-    if (a.enc_out)                                      // (first float, n_classes) per column
+    if (a_enc)                                          // (first float, n_classes) per column
         for (int c = tid; c < n_cols; c += T) {
             int o = 0;
             for (int x = 0; x < c; ++x) o += a.enc_n[x];
@@ -307,7 +313,7 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
                         rev = last[rr];
                     }
                     revof[c] = rev < 0 ? (uint16_t)0xffffu : (uint16_t)rev;
-                    primary = live && !(a.sym && rev >= 0 && u > v);
+                    primary = live && !(a_sym && rev >= 0 && u > v);
                     if (!live && part == 0)
                         for (int col = 0; col < n_cols; ++col) emit_cell(c, col, 0ull);
                 }
@@ -335,7 +341,7 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
     // pattern family are spread over all the workgroups of a graph); n_tasks = how many of them
     const int n_div = edge_mode ? misc[3] : rows;            // rows that run searches
     const int n_tasks_all = n_div * n_cols;
-    const int n_tasks = n_tasks_all > part ? (n_tasks_all - part + a.split - 1) / a.split : 0;
+    const int n_tasks = n_tasks_all > part ? (n_tasks_all - part + a_split - 1) / a_split : 0;
     const float div_rcp = n_div > 0 ? 1.0f / (float)n_div : 0.f;
     const bool div_float = n_tasks_all < (1 << 22);        // task index exact in fp32: quotient by one multiply + one correction
     const uint32_t *col_ptr = plan + PLAN_HEADER_WORDS;
@@ -385,7 +391,7 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
             if (need) {
                 const int t = base + __popcll(m & lane_lt);
                 if (t < n_tasks) {
-                    const int tt = part + t * a.split;
+                    const int tt = part + t * a_split;
                     int t_idx;
                     if (div_float) {
                         t_col = (int)((float)tt * div_rcp);
@@ -408,7 +414,7 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
                         t_row = prim[t_idx];
                         const int rev = revof[t_row] == 0xffffu ? -1 : (int)revof[t_row];
                         rev_missing = rev < 0;
-                        if (a.sym && rev >= 0) mirror_row = rev;
+                        if (a_sym && rev >= 0) mirror_row = rev;
                         roots = fv_roots<W>(eu[t_row], ev[t_row]);
                     } else {
                         t_row = t_idx;
@@ -458,17 +464,17 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
     if (threadIdx.x == 0 && g_count_prof) { g_count_prof[(size_t)blockIdx.x * 16 + 7] = ((unsigned long long)prof_iters << 32) | prof_lanes; for (int q = 0; q < 4; ++q) g_count_prof[(size_t)blockIdx.x * 16 + 8 + q] = prof_arm[q]; }
 #endif
     // ---- phase 4: coalesced write of the staged rows --------------------------------------------------------------
-    if (a.stage_out) {   // (only with split == 1)
+    if (a_stage_out) {   // (only with split == 1)
         int64_t *dst = a.out + row0 * n_cols;
         for (int i = tid; i < rows * n_cols; i += T) dst[i] = (int64_t)out_lds[i];
     }
     // ---- phase 4': encoded rows from the staged class indices, one float per thread and trip, consecutive addresses ----------
-    if (a.enc_out && a.enc_stage) {
+    if (a_enc && a_enc_stage) {
         const unsigned char *est = smem + a.off_encst;
         float *dst = a.enc_out + row0 * a.enc_width;
         const int total = rows * a.enc_width;
         const bool pack_ok = !a.enc16 || (((a.enc16_stride | a.enc16_col0) & 3) == 0 && (reinterpret_cast<uintptr_t>(a.enc16) & 7) == 0);
-        if (n_cols == 4 && (a.enc_width & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0 && pack_ok) {
+        if ((MOL || n_cols == 4) && (a.enc_width & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0 && pack_ok) {
             // four identifier columns (the cycle / clique families of the reference's configurations): a thread owns a row, reads
             // its four class indices as one word and writes the row as float4s
             int hot0 = enc[0], hot1 = enc[2], hot2 = enc[4], hot3 = enc[6];
@@ -520,18 +526,35 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
 // (Measured and dropped: amdgpu_waves_per_eu(6 / 7) on the molecule instantiation spills 72 / 104 bytes per lane for 1.4 / 2 % on the kernel
 //  and 0.5 % on the step; even a bound of 5 -- no tighter than what the allocator picks by itself -- changed its choices: 94 registers and
 //  36 bytes of scratch instead of 83 and none, +3 % kernel time.  No occupancy attribute.)
-template <int W, int T, bool DIR, bool TAIL>
+template <int W, int T, bool DIR, bool TAIL, bool MOL = false>
 __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int item = (int)blockIdx.x / a.split, part = (int)blockIdx.x - item * a.split;
+    const int item = MOL ? (int)blockIdx.x : (int)blockIdx.x / a.split, part = MOL ? 0 : (int)blockIdx.x - item * a.split;
     // one call site (the body is inlined once): pass 0 = the graph, or the pair 2 i, 2 i + 1 as one; passes 1, 2 = the pair's graphs one by
     // one when it did not fit or held an error
-    const int g0 = a.pair ? 2 * item : (a.graph_ids ? a.graph_ids[item] : item);
-    const bool two = a.pair && g0 + 1 < a.n_graphs;
+    const int g0 = (MOL || a.pair) ? 2 * item : (a.graph_ids ? a.graph_ids[item] : item);
+    const bool two = (MOL || a.pair) && g0 + 1 < a.n_graphs;
     for (int pass = 0; pass < 3; ++pass) {
         const int g = pass == 2 ? g0 + 1 : g0;
         const int ng = (pass == 0 && two) ? 2 : 1;
-        const int rc = count_body<W, T, DIR, TAIL>(a, smem, item, a.pair ? 0 : part, g, ng, ng == 1);
+        const int rc = count_body<W, T, DIR, TAIL, MOL>(a, smem, item, (MOL || a.pair) ? 0 : part, g, ng, ng == 1);
+        if (!two || (pass == 0 && rc == 0)) break;
+    }
+}
+
+// the molecule instantiation as its own kernel: its register bound is set apart from the generic instantiations
+#ifndef COUNT_MOL_WAVES
+#define COUNT_MOL_WAVES 6
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(COUNT_MOL_WAVES))) void count_kernel_mol(CountArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int item = (int)blockIdx.x;
+    const int g0 = 2 * item;
+    const bool two = g0 + 1 < a.n_graphs;
+    for (int pass = 0; pass < 3; ++pass) {
+        const int g = pass == 2 ? g0 + 1 : g0;
+        const int ng = (pass == 0 && two) ? 2 : 1;
+        const int rc = count_body<1, 64, false, false, true>(a, smem, item, 0, g, ng, ng == 1);
         if (!two || (pass == 0 && rc == 0)) break;
     }
 }
@@ -543,12 +566,12 @@ __global__ void status_zero_kernel(const int32_t *graph_ids, int n, int32_t *sta
 
 static inline int align_up(int x, int a) { return (x + a - 1) / a * a; }
 
-template <int W, int T, bool DIR, bool TAIL>
+template <int W, int T, bool DIR, bool TAIL, bool MOL = false>
 static int launch_d(CountArgs &a, int n_items, size_t lds, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&count_kernel<W, T, DIR, TAIL>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&count_kernel<W, T, DIR, TAIL, MOL>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return set_error(GSN_E_HIP, "hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
-    hipLaunchKernelGGL((count_kernel<W, T, DIR, TAIL>), dim3((unsigned)n_items), dim3(T), lds, stream, a);
+    hipLaunchKernelGGL((count_kernel<W, T, DIR, TAIL, MOL>), dim3((unsigned)n_items), dim3(T), lds, stream, a);
     e = hipGetLastError();
     if (e != hipSuccess) return set_error(GSN_E_HIP, "count_kernel launch: %s", hipGetErrorString(e));
 #ifdef COUNT_PROF
@@ -560,7 +583,7 @@ static int launch_d(CountArgs &a, int n_items, size_t lds, hipStream_t stream) {
             (void)hipMalloc(&buf, (size_t)n_items * 128);
             (void)hipMemset(buf, 0, (size_t)n_items * 128);
             (void)hipMemcpyToSymbol(HIP_SYMBOL(g_count_prof), &buf, sizeof(buf));
-            hipLaunchKernelGGL((count_kernel<W, T, DIR, TAIL>), dim3((unsigned)n_items), dim3(T), lds, stream, a);
+            hipLaunchKernelGGL((count_kernel<W, T, DIR, TAIL, MOL>), dim3((unsigned)n_items), dim3(T), lds, stream, a);
             (void)hipStreamSynchronize(stream);
             unsigned long long *h = new unsigned long long[(size_t)n_items * 16];
             (void)hipMemcpy(h, buf, (size_t)n_items * 128, hipMemcpyDeviceToHost);
@@ -593,6 +616,26 @@ static int launch(CountArgs &a, int n_items, size_t lds, hipStream_t stream) {
     } else {
         const bool tail = a.any_tail != 0 || a.tail_loop != 0;
         if (a.off_ain >= 0) return tail ? launch_d<W, T, true, true>(a, n_items, lds, stream) : launch_d<W, T, true, false>(a, n_items, lds, stream);
+        if constexpr (T == 64) {
+#ifdef COUNT_PROF
+            static const bool mol_on = false;           // (the phase profile is read from the generic instantiation)
+#else
+            static const bool mol_on = [] { const char *d = getenv("GSN_COUNT_MOL"); return !d || atoi(d) != 0; }();
+#endif
+            const bool mol = mol_on && !tail && a.mode == GSN_MODE_EDGE && a.sym && a.n_cols == 4 && a.pair && a.split == 1 && a.enc_out &&
+                             a.enc_stage && !a.graph_ids;
+            if (getenv("GSN_CHAIN_TRACE"))
+                fprintf(stderr, "gsn count: molecule instantiation %d (tail %d mode %d sym %d cols %d pair %d split %d stage %d out %d enc %d enc_stage %d ids %d)\n", (int)mol, (int)tail,
+                        a.mode, a.sym, a.n_cols, a.pair, a.split, a.stage_out, a.out != nullptr, a.enc_out != nullptr, a.enc_stage, a.graph_ids != nullptr);
+            if (mol) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&count_kernel_mol), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return set_error(GSN_E_HIP, "hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
+                hipLaunchKernelGGL(count_kernel_mol, dim3((unsigned)n_items), dim3(64), lds, stream, a);
+                e = hipGetLastError();
+                if (e != hipSuccess) return set_error(GSN_E_HIP, "count_kernel_mol launch: %s", hipGetErrorString(e));
+                return GSN_OK;
+            }
+        }
         return tail ? launch_d<W, T, false, true>(a, n_items, lds, stream) : launch_d<W, T, false, false>(a, n_items, lds, stream);
     }
 }
