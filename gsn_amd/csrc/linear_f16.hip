@@ -53,6 +53,7 @@ struct L16Args {
     const float *bias, *bn_mean, *bn_scale, *bn_shift;
     int k_total, k_pad, n_out, act;
     float *out;
+    double *stats;                 // train-mode stage: [2][n_out] fp64 column sums / sums of squares of the rows written (added to), or null
     float *rowinv;                 // [m_pad] inverse row scales (0 past m_rows)
     unsigned char *aplanes;        // [m_rows][k_pad / 32][2][32] halfs
     int64_t m_pad;
@@ -477,9 +478,13 @@ __global__ __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(2, 2))
 // the fragment reads.  Two slice buffers; slice c + 1 is in flight while slice c is multiplied; one barrier per slice.
 constexpr int D_BM = 128, D_BN = 128, D_NT = 256;
 constexpr int D_BUF = (D_BM + D_BN) * L_LINE;          // bytes per slice buffer
-template <bool PROF, bool VEC>
+// STATS (a train-mode BatchNorm stage, models_misc.py:52-58 with bn in train mode): the rows written are the pre-BN rows h = x W^T + b, and
+// their column sums / sums of squares go to a.stats from the SAME values on their way out, in fp64 registers across the workgroup's tiles (as
+// linear_fwd_bf16_kernel<STATS> does), one atomic pair per column and workgroup at the end.  Rows past m_rows (inverse scale 0: they would count as `bias`) are masked.
+template <bool PROF, bool VEC, bool STATS = false>
 __global__ __launch_bounds__(D_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void linear_f16x3_dma_kernel(L16Args a) {
     constexpr int NJ = 2;
+    double st_sum[NJ] = {0.0, 0.0}, st_sq[NJ] = {0.0, 0.0};
     const int dbg = PROF ? a.dbg : 0;
     extern __shared__ __attribute__((aligned(16))) unsigned l16_lds[];
     unsigned char *const lds = reinterpret_cast<unsigned char *>(l16_lds);
@@ -673,6 +678,11 @@ __global__ __launch_bounds__(D_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
                                 if (decltype(simple)::value) y = y < act_lo ? act_lo : y;       // (a NaN stays a NaN)
                                 else y = l16_act_slow(y, a.act);
                                 *reinterpret_cast<float *>(scr + (r + 4 * lh) * SP + (li + 32 * j) * 4) = y;
+                                if (STATS) {
+                                    const double ym = rl + 4 * lh + r < nrows ? (double)y : 0.0;
+                                    st_sum[j] += ym;
+                                    st_sq[j] = fma(ym, ym, st_sq[j]);
+                                }
                             }
                         if ((dbg & 1) && acc[i][0][4 * gq] != 12345.f) continue;
                         if (VEC) {
@@ -703,6 +713,19 @@ __global__ __launch_bounds__(D_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
 #pragma unroll
             for (int i = 0; i < 4; ++i) aofs[i] = aofs_next[i];
             abase = abase_next;
+        }
+    }
+    if (STATS) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            double sv = st_sum[j], qv = st_sq[j];
+            sv += __shfl_xor(sv, 32);
+            qv += __shfl_xor(qv, 32);
+            const int col = n0 + wn * 32 * NJ + 32 * j + li;
+            if (lh == 0 && col < a.n_out && n_mine > 0) {
+                atomicAdd(a.stats + col, sv);
+                atomicAdd(a.stats + a.n_out + col, qv);
+            }
         }
     }
     if (PROF && a.prof && blockIdx.x == 0 && tid == 0)
@@ -750,9 +773,9 @@ extern "C" int gsn_linear_f16x3_prepare_strided_hip(const float *W, int64_t n_ou
     return l16_prepare(W, n_out, k_total, w_row_stride, w_col_stride, planes, col_inv, stream);
 }
 
-extern "C" int gsn_linear_f16x3_fwd_hip(int64_t m_rows, int n_blocks, const gsn_block *blocks, const void *planes, const float *col_inv,
-                                        const float *bias, int64_t n_out, const float *bn_mean, const float *bn_scale, const float *bn_shift,
-                                        int act, float *row_scratch, float *out, void *stream) {
+static int l16_fwd(int64_t m_rows, int n_blocks, const gsn_block *blocks, const void *planes, const float *col_inv,
+                   const float *bias, int64_t n_out, const float *bn_mean, const float *bn_scale, const float *bn_shift,
+                   int act, float *row_scratch, float *out, double *stats, void *stream) {
     if (n_blocks < 1 || n_blocks > L_MAXB || !blocks || !planes || !col_inv || !row_scratch || !out || n_out <= 0)
         return set_error(GSN_E_INVALID, "gsn_linear_f16x3_fwd_hip: need 1..%d input blocks, the weight planes, scratch and out", L_MAXB);
     if ((bn_scale != nullptr) != (bn_shift != nullptr) || (bn_scale != nullptr) != (bn_mean != nullptr))
@@ -780,7 +803,7 @@ extern "C" int gsn_linear_f16x3_fwd_hip(int64_t m_rows, int n_blocks, const gsn_
         return set_error(GSN_E_UNSUPPORTED, "gsn_linear_f16x3_fwd_hip: weight planes of 2 GiB and more are not supported");
     a.wplanes = reinterpret_cast<const unsigned char *>(planes); a.colinv = col_inv;
     a.bias = bias; a.bn_mean = bn_mean; a.bn_scale = bn_scale; a.bn_shift = bn_shift;
-    a.out = out;
+    a.out = out; a.stats = stats;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     // scratch: [m_pad] inverse row scales | [m_rows][k_pad / 32] lines of the rows' planes
     a.m_pad = (m_rows + 255) / 256 * 256;
@@ -809,7 +832,9 @@ extern "C" int gsn_linear_f16x3_fwd_hip(int64_t m_rows, int n_blocks, const gsn_
                 groups, col_tiles);
     const dim3 grid((unsigned)(8 * groups * col_tiles));
     const bool vec = n_out % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && !getenv("GSN_L16_NOVEC");      // 16-byte output stores
-    static DeviceOnce attr_set[6];
+    if (stats && (!vec || act != 0 || bn_scale))
+        return set_error(GSN_E_UNSUPPORTED, "gsn_linear_f16x3_fwd_stats_hip: statistics go with plain pre-BN rows (act 0, no bn vectors), n_out a multiple of 4, out 16-byte aligned");
+    static DeviceOnce attr_set[7];
     const int attr_dev = current_device();
     hipError_t e0 = hipSuccess;
     auto launch = [&](auto kern, int which) {
@@ -821,7 +846,10 @@ extern "C" int gsn_linear_f16x3_fwd_hip(int64_t m_rows, int n_blocks, const gsn_
         hipLaunchKernelGGL(kern, grid, dim3(128 * wm), lds, st, a);
     };
     static const bool reg_stage = getenv("GSN_L16_REGSTAGE") != nullptr;  // (A/B: slices staged through registers)
-    if (reg_stage) {
+    if (stats) {
+        lds = (size_t)2 * D_BUF + 4 * (2 * D_BM + 2 * D_BN) + 4 * (2 * 2 * 64 + 2 * 2 * 32);
+        launch(linear_f16x3_dma_kernel<false, true, true>, 6);
+    } else if (reg_stage) {
         if (want_prof || a.dbg) launch(linear_f16x3_planes_kernel<2, 2, true, true>, 0);       // diagnostic build
         else if (!vec) launch(linear_f16x3_planes_kernel<2, 2, false, false>, 1);
         else launch(linear_f16x3_planes_kernel<2, 2, false, true>, 2);
@@ -844,4 +872,18 @@ extern "C" int gsn_linear_f16x3_fwd_hip(int64_t m_rows, int n_blocks, const gsn_
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(GSN_E_HIP, "linear_f16x3_kernel: %s", hipGetErrorString(e));
     return GSN_OK;
+}
+
+extern "C" int gsn_linear_f16x3_fwd_hip(int64_t m_rows, int n_blocks, const gsn_block *blocks, const void *planes, const float *col_inv,
+                                        const float *bias, int64_t n_out, const float *bn_mean, const float *bn_scale, const float *bn_shift,
+                                        int act, float *row_scratch, float *out, void *stream) {
+    return l16_fwd(m_rows, n_blocks, blocks, planes, col_inv, bias, n_out, bn_mean, bn_scale, bn_shift, act, row_scratch, out, nullptr, stream);
+}
+
+// train-mode BatchNorm stage: out = the pre-BN rows x W^T + b, stats[2][n_out] (fp64, ADDED to: the caller zeroes it) their column sums and
+// sums of squares, from the same launch (linear_fwd_bf16_kernel<STATS>'s contract, at half its matrix work)
+extern "C" int gsn_linear_f16x3_fwd_stats_hip(int64_t m_rows, int n_blocks, const gsn_block *blocks, const void *planes, const float *col_inv,
+                                              const float *bias, int64_t n_out, float *row_scratch, float *out, double *stats, void *stream) {
+    if (!stats) return set_error(GSN_E_INVALID, "gsn_linear_f16x3_fwd_stats_hip: stats is null");
+    return l16_fwd(m_rows, n_blocks, blocks, planes, col_inv, bias, n_out, nullptr, nullptr, nullptr, 0, row_scratch, out, stats, stream);
 }

@@ -599,9 +599,10 @@ LINEAR_F16X3_MIN_N = int(os.environ.get("GSN_LINEAR_F16X3_MIN_N", "128"))
 # products of at most this many 128 x 128 output tiles stay on the bf16x6 kernel (its 32-row-tile twin, csrc/linear.hip): one launch of ~10-19 us
 # instead of weight split + row pre-pass + product = three launches of ~20-30 us together (molhiv B = 32: 837 x 300 -> 600)
 LINEAR_F16X3_MIN_TILES = int(os.environ.get("GSN_LINEAR_F16X3_MIN_TILES", "96"))
-# train-mode stages too (statistics by gsn_column_stats_hip from the rows the kernel wrote).  Off by default: 0.6 % of a molhiv-sized training
-# step, and the statistics then come from the ROUNDED rows, which moves the 5 x 300 model's gradient digests by 1.2e-4 (bar: 1e-4)
-LINEAR_F16X3_STATS = os.environ.get("GSN_LINEAR_F16X3_STATS", "0") != "0"
+# train-mode BatchNorm stages too: the pre-BN rows AND their fp64 column statistics from one launch of the fp16x3 kernel
+# (gsn_linear_f16x3_fwd_stats_hip: linear_fwd_bf16_kernel<STATS>'s contract at half its matrix work -- 105 k x 300 -> 600: 0.27 -> 0.18 ms with
+# the row pre-pass; rows as accurate as the bf16x6 kernel's against fp64, scripts/gpu/stats_ab.py).  0: those stages stay on the bf16x6 kernel
+LINEAR_F16X3_STATS = os.environ.get("GSN_LINEAR_F16X3_STATS", "1") != "0"
 
 
 STRIDED_WEIGHTS = os.environ.get("GSN_STRIDED_WEIGHTS", "1") != "0"      # transposed weight views read through their strides (0: a contiguous copy first)
@@ -668,21 +669,21 @@ def _linear_hip(blocks, weight, bias, bn_mean, bn_scale, bn_shift, act, m_rows, 
     # direct rows (node-level stages): the fp16x3 kernel with the weights split once per weight version
     # (from two column tiles on: the pre-pass over the rows that finds their scales is then amortised -- at n_out <= 128 the
     #  bf16x6 kernel, which reads the rows once, is faster: 99 vs 90 TF/s at K = 260)
-    # (a train-mode stage that keeps its pre-BN rows: the same kernel, then the column statistics of the rows it wrote -- 0.13 + 0.06 ms
-    #  instead of 0.28 ms inside the bf16x6 kernel at 105 k x 300 -> 600)
-    if (LINEAR_F16X3 and out and (stats is None or (LINEAR_F16X3_STATS and bn_mean is None and act == 0)) and m_rows > 0 and n_out > LINEAR_F16X3_MIN_N
+    # (a train-mode stage that keeps its pre-BN rows: the same kernel with the column statistics taken in its epilogue)
+    if (LINEAR_F16X3 and out and (stats is None or (LINEAR_F16X3_STATS and bn_mean is None and act == 0 and n_out % 4 == 0)) and m_rows > 0 and n_out > LINEAR_F16X3_MIN_N
             and ((m_rows + 127) // 128) * ((n_out + 127) // 128) > LINEAR_F16X3_MIN_TILES
             and all(idx is None for _, idx in blocks) and all(d.shape[1] % 4 == 0 and d.data_ptr() % 16 == 0 for d in keep)):
         planes, col_inv = _f16x3_weights(weight, w)
         scratch = torch.empty(int(_abi.lib().gsn_linear_f16x3_scratch_bytes(m_rows, w.shape[1])), dtype=torch.uint8, device=dev)
         with _abi.device_guard(dev), _timed("linear_fwd", 2.0 * m_rows * w.shape[1] * n_out):
-            rc = _abi.lib().gsn_linear_f16x3_fwd_hip(m_rows, len(blocks), arr, planes.data_ptr(), col_inv.data_ptr(), _abi.ptr(vecs[0]), n_out,
-                                                     _abi.ptr(vecs[1]), _abi.ptr(vecs[2]), _abi.ptr(vecs[3]), act, scratch.data_ptr(),
-                                                     y.data_ptr(), _abi.current_stream())
-        _abi.check(rc, "gsn_linear_f16x3_fwd_hip")
-        if stats is not None:
-            with _abi.device_guard(dev), _timed("column_stats", 2.0 * m_rows * n_out):
-                _abi.check(_abi.lib().gsn_column_stats_hip(m_rows, n_out, y.data_ptr(), stats.data_ptr(), _abi.current_stream()), "gsn_column_stats_hip")
+            if stats is not None:
+                rc = _abi.lib().gsn_linear_f16x3_fwd_stats_hip(m_rows, len(blocks), arr, planes.data_ptr(), col_inv.data_ptr(), _abi.ptr(vecs[0]), n_out,
+                                                               scratch.data_ptr(), y.data_ptr(), stats.data_ptr(), _abi.current_stream())
+            else:
+                rc = _abi.lib().gsn_linear_f16x3_fwd_hip(m_rows, len(blocks), arr, planes.data_ptr(), col_inv.data_ptr(), _abi.ptr(vecs[0]), n_out,
+                                                         _abi.ptr(vecs[1]), _abi.ptr(vecs[2]), _abi.ptr(vecs[3]), act, scratch.data_ptr(),
+                                                         y.data_ptr(), _abi.current_stream())
+        _abi.check(rc, "gsn_linear_f16x3_fwd_stats_hip" if stats is not None else "gsn_linear_f16x3_fwd_hip")
         return y
     if w_view:
         with _abi.device_guard(dev), _timed("linear_fwd", 2.0 * m_rows * w.shape[1] * n_out):

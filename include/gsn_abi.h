@@ -435,6 +435,9 @@ int gsn_layer_fused_fwd_pack16_hip(int64_t n_nodes, int64_t n_edges, const int32
  *   gsn_linear_f16x3_fwd_hip          blocks: data + width only (idx / idx32 must be NULL), widths multiples of 4, 16-byte
  *                                     aligned; row_scratch: gsn_linear_f16x3_scratch_bytes(m_rows, K) bytes, 16-byte aligned;
  *                                     bias / bn_* / act as gsn_linear_fwd_hip
+ *   gsn_linear_f16x3_fwd_stats_hip    the train-mode BatchNorm stage (models_misc.py:52-58, bn in train mode): out = the pre-BN rows
+ *                                     x W^T + b, and their fp64 column sums / sums of squares ADDED to stats[2][n_out] by the same
+ *                                     launch (gsn_linear_fwd_hip's `stats` contract); n_out a multiple of 4, out 16-byte aligned
  * ---------------------------------------------------------------------------------------------------------------- */
 int64_t gsn_linear_f16x3_kpad(int64_t k_total);
 int64_t gsn_linear_f16x3_scratch_bytes(int64_t m_rows, int64_t k_total);
@@ -446,6 +449,8 @@ int gsn_linear_f16x3_prepare_strided_hip(const float *W, int64_t n_out, int64_t 
 int gsn_linear_f16x3_fwd_hip(int64_t m_rows, int n_blocks, const gsn_block *blocks, const void *planes, const float *col_inv,
                              const float *bias, int64_t n_out, const float *bn_mean, const float *bn_scale, const float *bn_shift,
                              int act, float *row_scratch, float *out, void *stream);
+int gsn_linear_f16x3_fwd_stats_hip(int64_t m_rows, int n_blocks, const gsn_block *blocks, const void *planes, const float *col_inv,
+                                   const float *bias, int64_t n_out, float *row_scratch, float *out, double *stats, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * HP-2  edge stage of a `general` layer with the node part of its Linear taken out of the edge loop (device, fp32).

@@ -36,3 +36,11 @@ for ng in (256, 1024):
     if have64:
         eo = (xr.grad.double() - x64.grad).abs() / sc; eg = (xg.grad.cpu().double() - x64.grad).abs() / sc
         print("   vs fp64: oracle32 max", float(eo.max()), "n>3e-4", int((eo > 3e-4).sum()), "| ours max", float(eg.max()), "n>3e-4", int((eg > 3e-4).sum()))
+    # the per-edge blocks' gradient (d relu(x_j + e) / d e): the same kinks, seen from the edge rows
+    sce = float(efr.grad.abs().max())
+    ee = (efg.grad.cpu() - efr.grad).abs() / sce
+    print("   d ef: max", float(ee.max()), "rows with an entry >= 2e-5:", int(((ee >= 2e-5).sum(1) > 0).sum()), "of", E, "median", float(ee.median()),
+          "| GSN_LINEAR_F16X3_STATS", os.environ.get("GSN_LINEAR_F16X3_STATS", "default"))
+    if have64:
+        eo = (efr.grad.double() - ef64.grad).abs() / sce; eg = (efg.grad.cpu().double() - ef64.grad).abs() / sce
+        print("   d ef vs fp64: oracle32 max", float(eo.max()), "rows", int(((eo >= 2e-5).sum(1) > 0).sum()), "| ours max", float(eg.max()), "rows", int(((eg >= 2e-5).sum(1) > 0).sum()))

@@ -155,13 +155,22 @@ def test_train_mode_backward_on_many_row_tiles(cls, d, kind):
         err = (xg.grad.cpu() - xr.grad).abs() / scale
         bad_rows = int(((err >= BT).sum(1) > 0).sum())
         assert bad_rows <= 24 and float(err.max()) < 0.05 and float(err.median()) < 2e-6, (bad_rows, float(err.max()), float(err.median()))
+        # the per-edge blocks see the same kinks from the edge rows (d relu(x_j + id + e) / d e): one flipped unit = the rows of that vertex's
+        # edges (scripts/gpu/diag_ogb300.py: 1-3 of 12 444 rows on this batch under either dense kernel, <= 0.04 of the largest entry; on a
+        # 49 k-row batch the fp32 oracle itself has 5 such rows against fp64) -- same criterion as for x
+        for got, want in ((idg, idr), (efg, efr)):
+            if got is not None:
+                sc_e = max(float(want.grad.abs().max()), FL)
+                err_e = (got.grad.cpu() - want.grad).abs() / sc_e
+                bad_e = int(((err_e >= BT).sum(1) > 0).sum())
+                assert bad_e <= 24 and float(err_e.max()) < 0.05 and float(err_e.median()) < 2e-6, (bad_e, float(err_e.max()), float(err_e.median()))
         BT = 1e-3
     else:
         assert rel_err(xg.grad.cpu(), xr.grad, FL) < BT
-    if idg is not None:
-        assert rel_err(idg.grad.cpu(), idr.grad, FL) < BT
-    if efg is not None:
-        assert rel_err(efg.grad.cpu(), efr.grad, FL) < BT
+        if idg is not None:
+            assert rel_err(idg.grad.cpu(), idr.grad, FL) < BT
+        if efg is not None:
+            assert rel_err(efg.grad.cpu(), efr.grad, FL) < BT
     n_checked = 0
     gmax = max(float(g.abs().max()) for g in grads.values())
     for k, p in layer.named_parameters():

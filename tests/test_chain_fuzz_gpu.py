@@ -167,6 +167,49 @@ def test_direct_rows_on_the_fp16x3_linear_kernel(m, widths, n, act, bn, capfd, m
     assert bool((err <= 1e-5 * ref.abs() + 2e-6 * scale).all()), float((err / (1e-5 * ref.abs() + 2e-6 * scale)).max())
 
 
+@pytest.mark.parametrize("m,widths,n", [(1000, [132], 256), (4097, [128, 128, 4], 384), (130, [300], 600), (105083, [300], 600), (60001, [600], 300),
+                                         (257, [36], 132), (1, [4], 132), (129, [32], 260), (70000, [64], 1028)])
+def test_train_mode_stage_on_the_fp16x3_kernel_rows_and_statistics(m, widths, n, capfd, monkeypatch):
+    """gsn_linear_f16x3_fwd_stats_hip (layers._linear_hip with ``stats``: a train-mode BatchNorm stage, models_misc.py:52-58): the pre-BN
+    rows against fp64 element-wise, their fp64 column sums / sums of squares against the fp64 rows' own -- ragged last row tile (the rows
+    past M must not be counted) and column tile, several blocks, more row tiles than workgroups, stats ADDED to what the buffer holds --
+    and against the bf16x6 kernel's statistics of the same stage."""
+    import os
+    from gsn_amd import layers
+    g = torch.Generator().manual_seed(m + n + 1)
+    xs = [torch.randn(m, w, generator=g) * (10.0 ** i) + 0.3 for i, w in enumerate(widths)]
+    k = sum(widths)
+    w = torch.randn(n, k, generator=g) / k ** 0.5
+    w[3] *= 1e-6; w[7] *= 1e4
+    b = torch.randn(n, generator=g)
+    blocks = [(x.cuda(), None) for x in xs]
+    wd, bd = w.cuda(), b.cuda()
+    got = {}
+    for name, f16 in (("fp16x3", True), ("bf16x6", False)):
+        monkeypatch.setattr(layers, "LINEAR_F16X3_STATS", f16)
+        monkeypatch.setattr(layers, "LINEAR_F16X3_MIN_TILES", 0)
+        stats = torch.full((2, n), 1.5, dtype=torch.float64, device="cuda")
+        os.environ["GSN_CHAIN_TRACE"] = "1"
+        try:
+            y = layers._linear_hip(blocks, wd, bd, None, None, None, 0, m, out=True, stats=stats)
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("GSN_CHAIN_TRACE", None)
+        assert ("linear_f16x3_kernel" in capfd.readouterr().err) == f16
+        got[name] = (y.cpu().double(), stats.cpu() - 1.5)
+    x = torch.cat(xs, 1).double()
+    ref = x @ w.double().t() + b.double()
+    scale = x.abs() @ w.double().abs().t() + b.double().abs()
+    for name, (y, st) in got.items():
+        err = (y - ref).abs()
+        assert bool((err <= 1e-5 * ref.abs() + 2e-6 * scale).all()), (name, float((err / (1e-5 * ref.abs() + 2e-6 * scale)).max()))
+        # the statistics are those of the rows the kernel WROTE (fp32 values, fp64 sums): tight; and within the product's error of the fp64 rows'
+        assert bool(((st[0] - y.sum(0)).abs() <= 1e-11 * y.abs().sum(0) + 1e-300).all()), name
+        assert bool(((st[1] - (y * y).sum(0)).abs() <= 1e-11 * (y * y).sum(0) + 1e-300).all()), name
+        assert bool(((st[0] - ref.sum(0)).abs() <= 2e-6 * scale.sum(0)).all()), name
+    assert bool(((got["fp16x3"][1][1] - got["bf16x6"][1][1]).abs() <= 1e-4 * got["bf16x6"][1][1].abs() + 1e-300).all())
+
+
 @pytest.mark.parametrize("m,k,widths", [(70000, 132, [96]), (70000, 128, [64]), (50000, 36, [32]), (70000, 100, [64, 64]), (40000, 160, [128, 96]),
                                           (70000, 260, [64]), (70000, 132, [128])])
 def test_narrow_stages_over_many_row_tiles(m, k, widths):
