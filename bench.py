@@ -50,7 +50,7 @@ def cpu_baseline(seed):
     small graphs).  `value` / `cores` are the all-cores run; the other two ride along."""
     import torch
     import networkx as nx
-    from gsn_amd import synth, layers
+    from gsn_amd import flags, synth, layers
     from oracle import oracle
     pats = [list(nx.cycle_graph(k).edges) for k in range(3, 7)]
     torch.manual_seed(0)
@@ -151,7 +151,7 @@ def full_model_closure(dev, gm, batch=None, check=True):
     import types
     import networkx as nx
     import torch
-    from gsn_amd import layers, models
+    from gsn_amd import flags, layers, models
     from gsn_amd.counting import CountPlan, count_batch
     if batch is None:
         b = make_batch(gm, seed=1000)
@@ -261,7 +261,7 @@ def small_batch_steps(plan, layer, dev, graphs=True):
     per step: eager (host-bound: ~8 launches) and replayed from one captured HIP graph (what is left is the serial latency of the
     small dependent kernels).  Supplementary, never `value`."""
     import torch
-    from gsn_amd import layers
+    from gsn_amd import flags, layers
     from gsn_amd.counting import count_batch
     out = {}
     for G in (32, 128):
@@ -347,7 +347,7 @@ def propagate_figures(b, dev):
     is quoted on: the scatter-add of per-edge messages with d = 128 and the ogb message relu(x_j + id_e + e) with d = 300.
     Algorithmic bytes: the CSR's three int32 arrays + seg_ptr, every message operand once, the output once."""
     import torch
-    from gsn_amd import layers
+    from gsn_amd import flags, layers
     N, E = b.num_nodes, b.num_edges
     ei = torch.from_numpy(b.edge_index).to(dev)
     out = {}
@@ -358,12 +358,12 @@ def propagate_figures(b, dev):
         with torch.no_grad():
             y = layers.propagate(kind, ei, 1, N, a=a, b=bb, c=c)
             spin_up(lambda: layers.propagate(kind, ei, 1, N, a=a, b=bb, c=c))
-            layers.KERNEL_TIMER = {}
+            flags.KERNEL_TIMER = {}
             for _ in range(10):
                 layers.propagate(kind, ei, 1, N, a=a, b=bb, c=c)
             torch.cuda.synchronize()
-        evs = layers.KERNEL_TIMER.get("propagate_fwd", [])
-        layers.KERNEL_TIMER = None
+        evs = flags.KERNEL_TIMER.get("propagate_fwd", [])
+        flags.KERNEL_TIMER = None
         ms = sum(e0.elapsed_time(e1) for e0, e1, _ in evs) / max(len(evs), 1)
         byt = 12.0 * E + 4.0 * (N + 1) + 4.0 * (N * da + E * db + E * dc) + 4.0 * N * y.shape[1]
         out[name] = {"ms": round(ms, 4), "GBps": round(byt / ms / 1e6, 1), "hbm_frac": round(byt / ms / 1e6 / HBM_PEAK_GBS, 4)}
@@ -375,7 +375,7 @@ def float_input_layer(layer, b, ei, dev):
     """The layer launch alone with real-valued inputs (no row exact in fp16: three plane products in the edge stage, every row scaled,
     the activated rows as three bf16 planes) beside the one-hot headline: the best case is not the only case."""
     import torch
-    from gsn_amd import layers
+    from gsn_amd import flags, layers
     N, E = b.num_nodes, b.num_edges
     g = torch.Generator().manual_seed(5)
     x = torch.randn(N, 28, generator=g).to(dev)
@@ -384,12 +384,12 @@ def float_input_layer(layer, b, ei, dev):
     deg = torch.zeros(N, device=dev)
     with torch.no_grad():
         spin_up(lambda: layer(x, ei, identifiers=ids, degrees=deg, edge_features=ef))
-        layers.KERNEL_TIMER = {}
+        flags.KERNEL_TIMER = {}
         for _ in range(10):
             layer(x, ei, identifiers=ids, degrees=deg, edge_features=ef)
         torch.cuda.synchronize()
-    evs = layers.KERNEL_TIMER.get("layer_fused", [])
-    layers.KERNEL_TIMER = None
+    evs = flags.KERNEL_TIMER.get("layer_fused", [])
+    flags.KERNEL_TIMER = None
     ms = sum(e0.elapsed_time(e1) for e0, e1, _ in evs) / max(len(evs), 1)
     return {"layer_launch_ms": round(ms, 4)}
 
@@ -422,7 +422,7 @@ def wide_layer(b, ei, dev):
     product) + 96 (node stage 1) products of 32 x 32 x 16, + 12 per edge round.  `layer_w`: the same layer on csrc/layer_w.hip (edge
     rows multiplied by all 272 columns; the kernel of a batch without registered boundaries or with a graph above 128 vertices)."""
     import torch
-    from gsn_amd import layers
+    from gsn_amd import flags, layers
     N, E = b.num_nodes, b.num_edges
     g = torch.Generator().manual_seed(6)
     x = torch.randn(N, 128, generator=g).relu().to(dev)
@@ -439,19 +439,19 @@ def wide_layer(b, ei, dev):
     out = {}
     ys = {}
     for name, flag in (("g", True), ("w", False)):
-        was = layers.GRAPH_ALIGNED_LAYER
-        layers.GRAPH_ALIGNED_LAYER = flag
+        was = flags.GRAPH_ALIGNED_LAYER
+        flags.GRAPH_ALIGNED_LAYER = flag
         try:
             with torch.no_grad():
                 spin_up(lambda: layer(x, eiw, identifiers=ids, degrees=deg, edge_features=ef))
-                layers.KERNEL_TIMER = {}
+                flags.KERNEL_TIMER = {}
                 for _ in range(10):
                     ys[name] = layer(x, eiw, identifiers=ids, degrees=deg, edge_features=ef)
                 torch.cuda.synchronize()
-            evs = layers.KERNEL_TIMER.get("layer_fused", [])
+            evs = flags.KERNEL_TIMER.get("layer_fused", [])
         finally:
-            layers.KERNEL_TIMER = None
-            layers.GRAPH_ALIGNED_LAYER = was
+            flags.KERNEL_TIMER = None
+            flags.GRAPH_ALIGNED_LAYER = was
         if not evs:
             return {"error": "the layer did not take the one-launch path"}
         out[name] = sum(e0.elapsed_time(e1) for e0, e1, _ in evs) / len(evs)
@@ -538,7 +538,7 @@ def linear_d300(dev):
     """The d = 300 node-level dense stage of the ogb layers (196 608 x 300 -> 600, gsn_linear_f16x3_fwd_hip incl. its row pre-pass) against
     the roofs of the pipe it uses: 2.5 PF/s fp16 / 3 plane products = 833 TF/s fp32-equivalent, and 8 TB/s on its algorithmic bytes."""
     import torch
-    from gsn_amd import layers
+    from gsn_amd import flags, layers
     M, K, Nn = 196608, 300, 600
     x = torch.randn(M, K, device=dev)
     W = torch.randn(Nn, K, device=dev) / K ** 0.5
@@ -583,7 +583,7 @@ def main():
     if args.dry_run:
         return dry_run(args)
     import networkx as nx
-    from gsn_amd import layers
+    from gsn_amd import flags, layers
     from gsn_amd.counting import CountPlan, count_batch
 
     if not torch.cuda.is_available():
@@ -646,7 +646,7 @@ def main():
     # identifiers written): reported as kernels.step_prepacked.
     xc = layers.Codes(torch.from_numpy(b.atom_type).to(dev), [28])
     efc = layers.Codes(torch.from_numpy(b.bond_type).to(dev), [4])
-    layers.CODE_STATUS_CHECK = False          # atom / bond codes are in range by construction, counts are clamped
+    flags.CODE_STATUS_CHECK = False          # atom / bond codes are in range by construction, counts are clamped
     epack_c = packs.new_edge_pack(E, dev) if use_pack else None
     npack_c = packs.new_node_pack(N, dev) if use_pack else None
 
@@ -718,8 +718,8 @@ def main():
     # HIP events inside the timed region bracket the DOMINANT kernel only (the layer: `roofline.avg_launch_ms`); the full per-kernel breakdown
     # (`ms_per_step_by_kernel`) comes from K more steps right behind the timed region, bracketed everywhere (an event pair around every launch
     # keeps consecutive kernels from overlapping their ends: ~1 % of the step).
-    layers.KERNEL_TIMER = {}
-    layers.KERNEL_TIMER_ONLY = {"layer_fused"} if os.environ.get("GSN_BENCH_NO_EVENTS", "0") == "0" else set()      # (diagnostic: no event at all)
+    flags.KERNEL_TIMER = {}
+    flags.KERNEL_TIMER_ONLY = {"layer_fused"} if os.environ.get("GSN_BENCH_NO_EVENTS", "0") == "0" else set()      # (diagnostic: no event at all)
     import gc
     _dm = os.environ.get("GSN_BENCH_DIAG_MODE", "")
     if "collect" in _dm:                      # (diagnostic: a collection here frees blocks and changes where the step's buffers land -- 0.754 -> 0.854 ms)
@@ -743,11 +743,11 @@ def main():
     if "drop" in _dm:
         y = step()
         sync()
-    timer_dom, layers.KERNEL_TIMER, layers.KERNEL_TIMER_ONLY = layers.KERNEL_TIMER, {}, None
+    timer_dom, flags.KERNEL_TIMER, flags.KERNEL_TIMER_ONLY = flags.KERNEL_TIMER, {}, None
     for _ in range(args.steps):              # (untimed: the same K steps with every kernel family bracketed)
         step()
     sync()
-    timer, layers.KERNEL_TIMER = layers.KERNEL_TIMER, None
+    timer, flags.KERNEL_TIMER = flags.KERNEL_TIMER, None
     timer["layer_fused"] = timer_dom.get("layer_fused", timer.get("layer_fused", []))      # the dominant kernel's events are those of the TIMED steps
     dt_own = dt
     dt = gdist.max_over_ranks(dt, dev)

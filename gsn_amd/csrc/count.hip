@@ -102,7 +102,7 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
     // (column tables as 16-bit values: a workgroup whose per-column state fits LDS has far fewer than 65535 columns; 0xffff = none)
     uint16_t *prim = reinterpret_cast<uint16_t *>(smem + a.off_prim);
     uint16_t *revof = reinterpret_cast<uint16_t *>(smem + a.off_revof);
-    uint64_t *out_lds = reinterpret_cast<uint64_t *>(smem + a.off_out);
+    uint16_t *out_lds = reinterpret_cast<uint16_t *>(smem + a.off_out);   // staged counts as 16-bit values; 0xffff = this cell went to HBM by itself
     int *misc = reinterpret_cast<int *>(smem + a.off_misc);  // [0] next task  [1] n_active  [2] status
     uint64_t *balls = a.off_ball >= 0 ? reinterpret_cast<uint64_t *>(smem + a.off_ball) : nullptr;
     uint64_t *cores = reinterpret_cast<uint64_t *>(smem + a.off_core);   // [CORE_MAX + 1][W]
@@ -138,7 +138,12 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
 
     // one finished cell (row, column) = cnt: the int64 row (staged or direct), the staged class index or the encoded floats
     auto emit_cell = [&](int row, int col, uint64_t cnt) {
-        if (a_stage_out) out_lds[row * n_cols + col] = cnt;
+        if (a_stage_out) {
+            // two bytes per staged cell (eight cost a ZINC pair 5.6 KiB: more than its LDS budget, so every cell went to HBM by itself from
+            // inside the pool -- 12.5 M scattered 8-byte stores per 65 536 molecules); the rare count that does not fit goes out directly
+            if (cnt < 0xffffull) out_lds[row * n_cols + col] = (uint16_t)cnt;
+            else { out_lds[row * n_cols + col] = (uint16_t)0xffff; a.out[(row0 + row) * n_cols + col] = (int64_t)cnt; }
+        }
         else if (a.out) a.out[(row0 + row) * n_cols + col] = (int64_t)cnt;
         if (a_enc) {
             const int *enc_t = reinterpret_cast<const int *>(smem + a.off_enc);
@@ -466,7 +471,10 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
     // ---- phase 4: coalesced write of the staged rows --------------------------------------------------------------
     if (a_stage_out) {   // (only with split == 1)
         int64_t *dst = a.out + row0 * n_cols;
-        for (int i = tid; i < rows * n_cols; i += T) dst[i] = (int64_t)out_lds[i];
+        for (int i = tid; i < rows * n_cols; i += T) {
+            const uint16_t v = out_lds[i];
+            if (v != (uint16_t)0xffff) dst[i] = (int64_t)v;
+        }
     }
     // ---- phase 4': encoded rows from the staged class indices, one float per thread and trip, consecutive addresses ----------
     if (a_enc && a_enc_stage) {
@@ -770,7 +778,7 @@ static int count_launch(const uint32_t *plan_host, const uint32_t *plan_dev, int
         a.tail_loop = forced >= 0 ? (forced != 0) : ((int64_t)a.e_decl >= 8 * (int64_t)a.n_decl);     // (the caller's capacities, before pairing)
     }
     a.off_out = o;
-    const int64_t stage_bytes = rows_cap_u * a.n_cols * 8;
+    const int64_t stage_bytes = align_up((int)(rows_cap_u * a.n_cols * 2 < ((int64_t)1 << 28) ? rows_cap_u * a.n_cols * 2 : ((int64_t)1 << 28)), 16);      // (16-bit staged counts)
     // Stage the output rows in LDS (coalesced final write) only while that keeps the workgroup small: the search is
     // latency-bound on dependent LDS reads, so heavy graphs want as many co-resident workgroups per CU as possible
     // (>= 8 waves per SIMD) and write their cells straight to HBM instead.

@@ -1,0 +1,65 @@
+"""Switches of the host side in one place: A/B and fault-isolation switches read from the environment at import, and the run-time hooks
+(kernel timers, the capture's list of raw-written tensors).  Every reader looks them up at call time (``flags.X``), so tests, scripts and
+bench.py set them here: ``from gsn_amd import flags; flags.KERNEL_TIMER = {}``."""
+import os
+
+# Optional per-kernel timing hook for bench.py: a dict name -> list of (start_event, end_event, work) recorded on the
+# launch stream around every kernel family; None = off (no events, no overhead).
+KERNEL_TIMER = None
+
+KERNEL_TIMER_ONLY = None       # a set of family names: only those are bracketed (an event pair per launch is not free: bench.py)
+
+ZERO_ARENA = os.environ.get("GSN_ZERO_ARENA", "1") != "0"      # (0: every request is its own torch.zeros -- A/B and fault isolation)
+
+LINEAR_F16X3 = os.environ.get("GSN_LINEAR_F16X3", "1") != "0"     # direct-row dense stages on the fp16x3 kernel (else bf16x6 / fp32)
+
+LINEAR_F16X3_MIN_N = int(os.environ.get("GSN_LINEAR_F16X3_MIN_N", "128"))
+
+# products of at most this many 128 x 128 output tiles stay on the bf16x6 kernel (its 32-row-tile twin, csrc/linear.hip): one launch of ~10-19 us
+# instead of weight split + row pre-pass + product = three launches of ~20-30 us together (molhiv B = 32: 837 x 300 -> 600)
+LINEAR_F16X3_MIN_TILES = int(os.environ.get("GSN_LINEAR_F16X3_MIN_TILES", "96"))
+
+# train-mode BatchNorm stages too: the pre-BN rows AND their fp64 column statistics from one launch of the fp16x3 kernel
+# (gsn_linear_f16x3_fwd_stats_hip: linear_fwd_bf16_kernel<STATS>'s contract at half its matrix work -- 105 k x 300 -> 600: 0.27 -> 0.18 ms with
+# the row pre-pass; rows as accurate as the bf16x6 kernel's against fp64, scripts/gpu/stats_ab.py).  0: those stages stay on the bf16x6 kernel
+LINEAR_F16X3_STATS = os.environ.get("GSN_LINEAR_F16X3_STATS", "1") != "0"
+
+STRIDED_WEIGHTS = os.environ.get("GSN_STRIDED_WEIGHTS", "1") != "0"      # transposed weight views read through their strides (0: a contiguous copy first)
+
+VALIDATE_CACHES = os.environ.get("GSN_VALIDATE_CACHES", "0") != "0"   # re-derive-and-compare mode for the per-weight caches (below)
+
+# Asynchronous validation of the per-weight caches (default on; GSN_ASYNC_VALIDATE=0 turns it off).  Behind every eval-mode forward of a
+# layer ONE kernel fingerprints the layer's parameters and buffers (gsn_fingerprint_hip); the 8 bytes travel to pinned host memory behind
+# it and are looked at -- without waiting -- at the layer's next forward.  A fingerprint that moved while no version counter did is a
+# write through `.data`: the layer's caches are dropped there and then and a RuntimeWarning names the layer.  The forward(s) between the
+# write and that point used the old derived weights (the check costs no synchronisation; GSN_VALIDATE_CACHES=1 checks BEFORE every
+# forward at the price of one); `invalidate_caches` after such a write remains the contract for code that cannot afford one stale call.
+ASYNC_VALIDATE = os.environ.get("GSN_ASYNC_VALIDATE", "1") != "0"
+
+# at most one fingerprint per layer and interval (seconds of wall clock): a tight inference loop pays one 5 us launch per layer every 20 ms, not
+# one per forward; a `.data` write is then noticed within the interval plus one forward.  0: behind every eval forward.
+ASYNC_VALIDATE_INTERVAL = float(os.environ.get("GSN_ASYNC_VALIDATE_INTERVAL", "0.02"))
+
+RAW_WRITTEN = None      # a list while gsn_amd.graphs.GraphedTrainStep captures: tensors that captured kernels write through raw pointers
+
+SPLIT_EDGE_STAGE = os.environ.get("GSN_SPLIT_EDGE", "1") != "0"        # node part of a wide edge Linear once per node (K > SPLIT_EDGE_MIN_K)
+
+SPLIT_EDGE_MIN_K = int(os.environ.get("GSN_SPLIT_EDGE_MIN_K", "160"))
+
+FUSED_LAYER = os.environ.get("GSN_LAYER_FUSED", "1") != "0"   # one-launch `general` layer (gsn_layer_fused_fwd_hip) where it fits
+
+CHAIN_ROW_EXPONENTS = os.environ.get("GSN_CHAIN_ROW_EXP", "1") != "0"      # 128-wide one-launch layers leave their output's row exponents for the next layer
+
+GRAPH_ALIGNED_LAYER = os.environ.get("GSN_LAYER_GRAPHS", "1") != "0"   # d = 128 layers of a collated batch: node products on graph-aligned tiles (csrc/layer_g.hip)
+
+PACK16_LAYER = os.environ.get("GSN_LAYER_PACK16", "1") != "0"   # tagged exact inputs: the packed-row kernel (csrc/layer_rp.hip)
+
+FUSE_BN_ACT_ROWS = int(os.environ.get("GSN_FUSE_BN_ACT_ROWS", "16384"))      # train-mode stages of at most this many rows: finalize + normalise in one launch
+
+NATIVE_DENSE_BACKWARD = True      # False: every mlp backward goes through the PyTorch twin (for comparison)
+
+GATHER_CAT_TRAIN = os.environ.get("GSN_GATHER_CAT_TRAIN", "0") == "1"    # 1: training assembles the edge rows first (gsn_gather_cat_hip), as before r03
+
+FOLD_KERNEL = os.environ.get("GSN_FOLD_KERNEL", "1") != "0"      # A/B switch: the fold as tensor ops over the dense stages (~18 launches per layer and step)
+
+CODE_STATUS_CHECK = True   # read the out-of-range flag back after every code-gather launch (one host sync)

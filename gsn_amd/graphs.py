@@ -31,7 +31,7 @@ class GraphedStep:
                 fn()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
-        from . import layers
+        from . import flags, layers
         layers.drop_input_caches()                     # (the index builds of the static inputs are recorded, not looked up)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
@@ -98,8 +98,8 @@ class GraphedTrainStep:
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
         optimizer.zero_grad(set_to_none=True)          # (the captured backward allocates the gradients from the graph's pool)
-        from . import layers
-        layers.RAW_WRITTEN = []
+        from . import flags, layers
+        flags.RAW_WRITTEN = []
         # caches keyed on the INPUT tensors (aggregation index, readout pairs, graph sizes) were filled by the warm-up steps: dropped, so
         # that their builds are recorded -- a replay after data.edge_index.copy_(new_batch) then runs them on the new contents
         layers.drop_input_caches()
@@ -107,13 +107,13 @@ class GraphedTrainStep:
             with torch.cuda.graph(self.graph):
                 self.loss = step()
             seen, extra = set(id(p) for p in self.params), []
-            for t in layers.RAW_WRITTEN:               # BatchNorm running statistics / counters the captured kernels update in place
+            for t in flags.RAW_WRITTEN:               # BatchNorm running statistics / counters the captured kernels update in place
                 if id(t) not in seen:
                     seen.add(id(t))
                     extra.append(t)
             self._bump = self.params + extra
         finally:
-            layers.RAW_WRITTEN = None
+            flags.RAW_WRITTEN = None
         # what the capture cached -- derived weights keyed on the parameters' versions, indices of the inputs -- lives in graph-pool memory
         # that nothing has written yet (a capture records): an eager forward before the first replay must not find it
         layers.drop_input_caches()

@@ -130,12 +130,12 @@ def edge_pack(tensors, check=True, pack=None):
 
 
 def _pack_codes(cd, pack, col0, one_col, check=None):
-    """``check`` (default: gsn_amd.layers.CODE_STATUS_CHECK): read the out-of-range flag back -- IndexError, as the weight-row-gather stage
+    """``check`` (default: gsn_amd.flags.CODE_STATUS_CHECK): read the out-of-range flag back -- IndexError, as the weight-row-gather stage
     and the reference's F.one_hot; clamped codes cannot be out of range and are never read back."""
     import numpy as np
-    from . import layers
+    from . import flags, layers
     ncls = np.ascontiguousarray(cd.n_classes, dtype=np.int32)
-    check = (layers.CODE_STATUS_CHECK if check is None else check) and not cd.clamp
+    check = (flags.CODE_STATUS_CHECK if check is None else check) and not cd.clamp
     status = torch.zeros(1, dtype=torch.int32, device=cd.codes.device) if check else None
     with _abi.device_guard(cd.codes.device):
         _abi.check(_abi.lib().gsn_one_hot_pack16_hip(cd.codes.shape[0], cd.codes.shape[1], cd.codes.data_ptr(), _abi.ptr(ncls), int(cd.clamp),

@@ -9,7 +9,7 @@ import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import bench  # noqa: E402
-from gsn_amd import layers  # noqa: E402
+from gsn_amd import flags, layers  # noqa: E402
 
 
 def main():
@@ -22,7 +22,7 @@ def main():
     ic = layers.Codes(torch.randint(0, 3, (E, 4), device=dev), [3, 3, 3, 3])
     torch.manual_seed(0)
     lay = layers.GSN_edge_sparse(**bench.CTOR).to(dev).eval()
-    layers.CODE_STATUS_CHECK = False
+    flags.CODE_STATUS_CHECK = False
     deg = torch.zeros(N, device=dev)
     out = []
     for name, a in (("dense", (xc.dense(), ic.dense(), ec.dense())), ("codes", (xc, ic, ec))):
@@ -32,13 +32,13 @@ def main():
         for _ in range(3):
             run()
         torch.cuda.synchronize()
-        layers.KERNEL_TIMER = {}
+        flags.KERNEL_TIMER = {}
         reps = 10
         for _ in range(reps):
             run()
         torch.cuda.synchronize()
-        kt = {k: round(sum(x.elapsed_time(y) for x, y, _ in v) / reps, 4) for k, v in layers.KERNEL_TIMER.items()}
-        layers.KERNEL_TIMER = None
+        kt = {k: round(sum(x.elapsed_time(y) for x, y, _ in v) / reps, 4) for k, v in flags.KERNEL_TIMER.items()}
+        flags.KERNEL_TIMER = None
         out.append({"inputs": name, "N": N, "E": E, "kernel_ms": kt, "total_ms": round(sum(kt.values()), 4)})
     print(json.dumps(out))
 

@@ -12,7 +12,7 @@ import torch
 import networkx as nx
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from gsn_amd import synth, layers  # noqa: E402
+from gsn_amd import flags, synth, layers  # noqa: E402
 from gsn_amd.counting import CountPlan, count_batch  # noqa: E402
 
 
@@ -160,7 +160,7 @@ def main():
     idcodes = layers.Codes(torch.randint(0, 3, (Eb, 4), device=dev), [3, 3, 3, 3])
     torch.manual_seed(0)
     lay = layers.GSN_edge_sparse(**gen).to(dev).eval()
-    layers.CODE_STATUS_CHECK = False
+    flags.CODE_STATUS_CHECK = False
     degb = torch.zeros(Nb, device=dev)
     xd, idd, efd = xcodes.dense(), idcodes.dense(), efcodes.dense()
     for name, args_ in (("dense one-hot inputs (reference boundary)", (xd, idd, efd)), ("integer codes (weight-row gather edge stage)", (xcodes, idcodes, efcodes))):
@@ -168,10 +168,10 @@ def main():
             with torch.no_grad():
                 lay(args_[0], eib, identifiers=args_[1], degrees=degb, edge_features=args_[2])
         dt = timeit(run, reps=10, warm=3)
-        layers.KERNEL_TIMER = {}
+        flags.KERNEL_TIMER = {}
         run(); torch.cuda.synchronize()
-        kt = {k: round(sum(a.elapsed_time(b_) for a, b_, _ in v), 3) for k, v in layers.KERNEL_TIMER.items()}
-        layers.KERNEL_TIMER = None
+        kt = {k: round(sum(a.elapsed_time(b_) for a, b_, _ in v), 3) for k, v in flags.KERNEL_TIMER.items()}
+        flags.KERNEL_TIMER = None
         res["next_rows"].append({"case": "GSN_edge_sparse L0 general d=128 eval fwd, 65536 graphs, " + name, "ms": round(dt * 1e3, 3),
                                  "graphs_per_s": round(65536 / dt, 1), "kernels": kt})
     print(json.dumps(res))

@@ -9,7 +9,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-from gsn_amd import layers, synth  # noqa: E402
+from gsn_amd import flags, layers, synth  # noqa: E402
 
 CTOR = dict(d_in=28, d_ef=4, d_id=12, d_degree=1, degree_as_tag=False, retain_features=True, id_scope="local", d_msg=128,
             d_up=128, d_h=[128], seed=0, activation_name="relu", bn=True, msg_kind="general", flow="source_to_target")
@@ -47,7 +47,7 @@ def main():
     if not args.float_inputs and not args.wide:
         variants.insert(0, ("fused_pack16", True))       # tagged exact inputs: csrc/layer_rp.hip
     for name, fused in variants:
-        layers.FUSED_LAYER = fused
+        flags.FUSED_LAYER = fused
         if name == "fused_pack16":
             packs.node_pack(x)
             packs.edge_pack([ids, ef])
@@ -58,14 +58,14 @@ def main():
             for _ in range(10):
                 y = layer(x, ei, identifiers=ids, degrees=deg, edge_features=ef)      # CSR cached: the layer launches only
             torch.cuda.synchronize()
-            layers.KERNEL_TIMER = {}
+            flags.KERNEL_TIMER = {}
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(args.steps):
                 y = layer(x, ei, identifiers=ids, degrees=deg, edge_features=ef)
             e1.record()
             torch.cuda.synchronize()
-            timer, layers.KERNEL_TIMER = layers.KERNEL_TIMER, None
+            timer, flags.KERNEL_TIMER = flags.KERNEL_TIMER, None
         ms = e0.elapsed_time(e1) / args.steps
         per = {k: round(sum(a.elapsed_time(bb) for a, bb, _ in v) / args.steps, 4) for k, v in timer.items()}
         res[name] = {"ms_per_layer": round(ms, 4), "hbm_frac_of_B_alg": round(b_alg / (ms * 1e-3) / 8e12, 4), "kernels_ms": per}

@@ -10,7 +10,7 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from gsn_amd import layers  # noqa: E402
+from gsn_amd import flags, layers  # noqa: E402
 
 
 def main():
@@ -38,7 +38,7 @@ def main():
         err = float((y[:4096].double() - ref).abs().max() / ref.abs().max())
         out.append({"M": M, "K": K, "N": N, "ms": round(dt * 1e3, 3), "fp32_equivalent_TFLOPs": round(2.0 * M * K * N / dt / 1e12, 1),
                     "max_rel_err_vs_fp64": err})
-    kern = "fp16x3" if layers.LINEAR_F16X3 else ("bf16x6" if os.environ.get("GSN_LINEAR_BF16X6", "1") != "0" else "fp32 mfma")
+    kern = "fp16x3" if flags.LINEAR_F16X3 else ("bf16x6" if os.environ.get("GSN_LINEAR_BF16X6", "1") != "0" else "fp32 mfma")
     print(json.dumps({"kernel": kern, "cases": out}))
 
 

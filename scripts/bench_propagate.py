@@ -9,7 +9,7 @@ import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import bench  # noqa: E402
-from gsn_amd import layers  # noqa: E402
+from gsn_amd import flags, layers  # noqa: E402
 
 
 def main():
@@ -31,12 +31,12 @@ def main():
             for _ in range(3):
                 f()
             torch.cuda.synchronize()
-            layers.KERNEL_TIMER = {}
+            flags.KERNEL_TIMER = {}
             for _ in range(10):
                 f()
             torch.cuda.synchronize()
-        evs = layers.KERNEL_TIMER.get("propagate_fwd", [])
-        layers.KERNEL_TIMER = None
+        evs = flags.KERNEL_TIMER.get("propagate_fwd", [])
+        flags.KERNEL_TIMER = None
         ms = sum(x.elapsed_time(z) for x, z, _ in evs) / max(len(evs), 1)
         d_out = y.shape[1]
         byt = 12.0 * E + 4.0 * (N + 1) + 4.0 * (N * da + (N if per_node else E) * db + E * dc) + 4.0 * N * d_out

@@ -11,7 +11,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 
-from gsn_amd import layers, synth  # noqa: E402
+from gsn_amd import flags, layers, synth  # noqa: E402
 from oracle import oracle  # noqa: E402
 from test_fused_gpu import WIDE, _wide_ctor, _randomise_bn, _elementwise_ok  # noqa: E402
 
@@ -37,11 +37,11 @@ def run_case(cls, ctor, b, x, ids, ef, seed, ref=True, partition=True):
         assert layers.set_graph_partition(eic, torch.from_numpy(b.node_ptr).cuda(), torch.from_numpy(b.edge_ptr).cuda(), mn, me)
     outs = {}
     for name, flag in (("g", True), ("w", False)):
-        layers.GRAPH_ALIGNED_LAYER = flag
+        flags.GRAPH_ALIGNED_LAYER = flag
         layers._CSR_CACHE.clear()
         with torch.no_grad():
             outs[name] = layer(x.cuda(), eic, **kwg).cpu()
-    layers.GRAPH_ALIGNED_LAYER = True
+    flags.GRAPH_ALIGNED_LAYER = True
     return outs, yref
 
 
@@ -133,23 +133,23 @@ def main():
         layer = layers.GSN_edge_sparse(**ctor).to(dev).eval()
         res = {}
         for name, flag in (("g", True), ("w", False), ("g", True), ("w", False)):
-            layers.GRAPH_ALIGNED_LAYER = flag
+            flags.GRAPH_ALIGNED_LAYER = flag
             with torch.no_grad():
                 for _ in range(20):
                     y = layer(x, ei, identifiers=ids, degrees=deg, edge_features=ef)
                 torch.cuda.synchronize()
-                layers.KERNEL_TIMER = {}
+                flags.KERNEL_TIMER = {}
                 for _ in range(20):
                     y = layer(x, ei, identifiers=ids, degrees=deg, edge_features=ef)
                 torch.cuda.synchronize()
-            evs = layers.KERNEL_TIMER.get("layer_fused", [])
-            layers.KERNEL_TIMER = None
+            evs = flags.KERNEL_TIMER.get("layer_fused", [])
+            flags.KERNEL_TIMER = None
             ms = sum(e0.elapsed_time(e1) for e0, e1, _ in evs) / max(len(evs), 1)
             res.setdefault(name, []).append(round(ms, 4))
             res[name + "_y"] = y
         print("graphs %d N %d E %d: layer_g %s ms, layer_w %s ms" % (args.graphs, N, E, res["g"], res["w"]), flush=True)
         print("g vs w element-wise:", _elementwise_ok(res["g_y"].cpu(), res["w_y"].cpu()), flush=True)
-        layers.GRAPH_ALIGNED_LAYER = True
+        flags.GRAPH_ALIGNED_LAYER = True
 
 
 if __name__ == "__main__":

@@ -3,8 +3,8 @@ a transposed weight view)."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
-from gsn_amd import layers
-layers.LINEAR_F16X3 = False
+from gsn_amd import flags, layers
+flags.LINEAR_F16X3 = False
 dev = torch.device("cuda", 0)
 def timeit(fn, n=20):
     for _ in range(5): fn()

@@ -4,7 +4,7 @@ import os
 import sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import torch
-from gsn_amd import layers
+from gsn_amd import flags, layers
 
 dev = "cuda:0"
 torch.manual_seed(0)
@@ -17,8 +17,8 @@ for (M, K, N, kind) in ((5000, 300, 600, "randn"), (5000, 600, 300, "relu"), (25
     ref = x.double() @ w.double().t() + b.double()
     rs, rq = ref.sum(0), (ref * ref).sum(0)
     for name, f16 in (("bf16x6", False), ("fp16x3", True)):
-        layers.LINEAR_F16X3_STATS = f16
-        layers.LINEAR_F16X3_MIN_TILES = 0 if f16 else 10 ** 9
+        flags.LINEAR_F16X3_STATS = f16
+        flags.LINEAR_F16X3_MIN_TILES = 0 if f16 else 10 ** 9
         stats = torch.zeros(2 * N, dtype=torch.float64, device=dev)
         y = layers._linear_hip([(x, None)], w, b, None, None, None, 0, M, out=True, stats=stats)
         torch.cuda.synchronize()

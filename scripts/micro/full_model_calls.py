@@ -6,17 +6,17 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch                      # noqa: E402
 import bench                      # noqa: E402
-from gsn_amd import layers        # noqa: E402
+from gsn_amd import flags, layers        # noqa: E402
 
 dev = torch.device("cuda", 0)
 step, G = bench.full_model_closure(dev, 16384)
 for _ in range(5):
     step()
 torch.cuda.synchronize()
-layers.KERNEL_TIMER = {}
+flags.KERNEL_TIMER = {}
 step()
 torch.cuda.synchronize()
-timer, layers.KERNEL_TIMER = layers.KERNEL_TIMER, None
+timer, flags.KERNEL_TIMER = flags.KERNEL_TIMER, None
 rows = []
 for k, evs in timer.items():
     for a, b, w in evs:

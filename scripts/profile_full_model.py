@@ -8,7 +8,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch                      # noqa: E402
 import bench                      # noqa: E402
-from gsn_amd import layers        # noqa: E402
+from gsn_amd import flags, layers        # noqa: E402
 
 
 def main():
@@ -17,14 +17,14 @@ def main():
     for _ in range(5):
         step()
     torch.cuda.synchronize()
-    layers.KERNEL_TIMER = {}
+    flags.KERNEL_TIMER = {}
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(10):
         step()
     e1.record()
     torch.cuda.synchronize()
-    timer, layers.KERNEL_TIMER = layers.KERNEL_TIMER, None
+    timer, flags.KERNEL_TIMER = flags.KERNEL_TIMER, None
     fam = {}
     for k, evs in timer.items():
         fam[k] = round(sum(a.elapsed_time(b) for a, b, _w in evs) / 10, 4)

@@ -94,7 +94,8 @@ def test_layer_classes_at_several_widths_on_many_row_tiles(cls, d, kind, trainin
 
 @pytest.mark.parametrize("cls,d,kind", [("GSN_edge_sparse", 64, "general"), ("GSN_edge_sparse", 128, "general"), ("GSN_sparse", 64, "gin"),
                                         ("MPNN_edge_sparse", 96, "general"), ("GSN_edge_sparse_ogb", 64, "ogb"), ("GSN_edge_sparse", 32, "gin"),
-                                        ("GSN_edge_sparse_ogb", 300, "ogb"), ("MPNN_edge_sparse_ogb", 300, "ogb")])
+                                        ("GSN_edge_sparse_ogb", 300, "ogb"), ("MPNN_edge_sparse_ogb", 300, "ogb"),
+                                        ("GSN_edge_sparse_ogb", 300, "ogb-elu"), ("MPNN_edge_sparse_ogb", 300, "ogb-elu")])
 def test_train_mode_backward_on_many_row_tiles(cls, d, kind):
     """Forward + backward in training mode (batch-statistics BatchNorm) on the multi-tile batch: gradients of the inputs and of
     every parameter against PyTorch autograd over the oracle's restatement (the goldens' backward cases are small graphs).
@@ -106,8 +107,14 @@ def test_train_mode_backward_on_many_row_tiles(cls, d, kind):
     torch.manual_seed(d + len(cls) + 1)
     b = synth.zinc_shape_batch(256 if d == 300 else 2048, seed=22)     # (d = 300: config 4's width on linear_f16x3 + wgrad; the oracle's pass stays at seconds)
     N, E = b.num_nodes, b.num_edges
+    # "ogb-elu": the d = 300 ogb layers with a C1 activation in update_fn.  Their message relu(x_j + id + e) (*_ogb.py:100) is one or two
+    # fp32 additions in the reference's order -- the same bits on both sides, no kink to disagree on -- so with elu in the hidden layer of
+    # update_fn the whole case is sharp (2e-5 everywhere); plain "ogb" keeps update_fn's relu (the reference's configuration) under the
+    # kink-aware criterion below.
+    sharp_ogb = kind == "ogb-elu"
+    kind = "ogb" if sharp_ogb else kind
     ctor, d_x, d_id, d_ef = _case(cls, d, kind)
-    if not cls.endswith("_ogb"):
+    if not cls.endswith("_ogb") or sharp_ogb:
         ctor["activation_name"] = "elu"           # (the ogb message is relu(x_j + ..) by definition, *_ogb.py:100)
     layer = getattr(layers, cls)(**ctor)
     layer.train()
@@ -142,7 +149,8 @@ def test_train_mode_backward_on_many_row_tiles(cls, d, kind):
     BT = 2e-5
     grads = {k: v.grad for k, v in sd.items() if v.requires_grad and v.grad is not None}
     FL = 0.02 * max([float(g.abs().max()) for g in grads.values()] + [0.5])
-    if cls.endswith("_ogb") and d == 300:
+    kinked = cls.endswith("_ogb") and d == 300 and not sharp_ogb
+    if kinked:
         # The ogb layers are relu by definition (message relu(x_j + ..), *_ogb.py:100; hidden layer of update_fn): no C1 variant.  With
         # millions of relu units in this pass some pre-activation lies within rounding distance of zero, and two correct implementations
         # then put that unit on different sides of the kink: a flipped hidden unit of vertex v changes the whole gradient ROW of v (and
@@ -164,7 +172,10 @@ def test_train_mode_backward_on_many_row_tiles(cls, d, kind):
                 err_e = (got.grad.cpu() - want.grad).abs() / sc_e
                 bad_e = int(((err_e >= BT).sum(1) > 0).sum())
                 assert bad_e <= 24 and float(err_e.max()) < 0.05 and float(err_e.median()) < 2e-6, (bad_e, float(err_e.max()), float(err_e.median()))
-        BT = 1e-3
+        # parameter gradients: a weight gradient is a sum over the batch's ~6 k rows with random signs, so ONE flipped unit with a large
+        # upstream gradient moves its row of dW by ~1 / sqrt(rows) of the largest entry (seen 1.8e-2 on update_fn.fc.0.weight with 2 rows
+        # of dx off by a unit's worth); the sharp bars for these widths and kernels are the "ogb-elu" cases'
+        BT = 5e-2
     else:
         assert rel_err(xg.grad.cpu(), xr.grad, FL) < BT
         if idg is not None:
@@ -184,7 +195,10 @@ def test_train_mode_backward_on_many_row_tiles(cls, d, kind):
             if p.numel() == 1:
                 # the scalar `eps` of a gin / ogb layer: ONE sum over every vertex and feature, with cancellation -- both sides' fp32 sums
                 # carry ~1e-3 of their value; compared on the scale of the largest parameter gradient
-                assert float((p.grad.cpu() - grads[k]).abs().max()) < 1e-3 * gmax, (k, float(p.grad), float(grads[k]))
+                # (the relu-only d = 300 case: a flipped unit moves this sum by that unit's whole contribution -- seen 3e-3 of the largest
+                #  parameter gradient with 2 of 5 931 gradient rows off by a unit's worth, fp64 referee in scripts/gpu/diag_ogb300.py)
+                eps_bar = 1e-2 if kinked else 1e-3
+                assert float((p.grad.cpu() - grads[k]).abs().max()) < eps_bar * gmax, (k, float(p.grad), float(grads[k]))
                 continue
             assert rel_err(p.grad.cpu(), grads[k], FL) < BT, (k, rel_err(p.grad.cpu(), grads[k], FL))
             n_checked += 1

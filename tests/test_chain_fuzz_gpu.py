@@ -133,8 +133,8 @@ def test_direct_rows_on_the_fp16x3_linear_kernel(m, widths, n, act, bn, capfd, m
     row tiles than workgroups with an odd number of K slices (the shapes on which a 16-byte store's data register was once
     overwritten behind the store), every epilogue -- against fp64, element-wise, with the product's own condition scale as floor."""
     import os
-    from gsn_amd import layers
-    monkeypatch.setattr(layers, "LINEAR_F16X3_MIN_TILES", 0)       # (products of few tiles go to the bf16x6 kernel's 32-row twin by default: tests/test_linear_small_gpu.py)
+    from gsn_amd import flags, layers
+    monkeypatch.setattr(flags, "LINEAR_F16X3_MIN_TILES", 0)       # (products of few tiles go to the bf16x6 kernel's 32-row twin by default: tests/test_linear_small_gpu.py)
     g = torch.Generator().manual_seed(m + n)
     xs = [torch.randn(m, w, generator=g) * (10.0 ** i) for i, w in enumerate(widths)]
     k = sum(widths)
@@ -175,7 +175,7 @@ def test_train_mode_stage_on_the_fp16x3_kernel_rows_and_statistics(m, widths, n,
     past M must not be counted) and column tile, several blocks, more row tiles than workgroups, stats ADDED to what the buffer holds --
     and against the bf16x6 kernel's statistics of the same stage."""
     import os
-    from gsn_amd import layers
+    from gsn_amd import flags, layers
     g = torch.Generator().manual_seed(m + n + 1)
     xs = [torch.randn(m, w, generator=g) * (10.0 ** i) + 0.3 for i, w in enumerate(widths)]
     k = sum(widths)
@@ -186,8 +186,8 @@ def test_train_mode_stage_on_the_fp16x3_kernel_rows_and_statistics(m, widths, n,
     wd, bd = w.cuda(), b.cuda()
     got = {}
     for name, f16 in (("fp16x3", True), ("bf16x6", False)):
-        monkeypatch.setattr(layers, "LINEAR_F16X3_STATS", f16)
-        monkeypatch.setattr(layers, "LINEAR_F16X3_MIN_TILES", 0)
+        monkeypatch.setattr(flags, "LINEAR_F16X3_STATS", f16)
+        monkeypatch.setattr(flags, "LINEAR_F16X3_MIN_TILES", 0)
         stats = torch.full((2, n), 1.5, dtype=torch.float64, device="cuda")
         os.environ["GSN_CHAIN_TRACE"] = "1"
         try:
@@ -215,7 +215,7 @@ def test_train_mode_stage_on_the_fp16x3_kernel_rows_and_statistics(m, widths, n,
 def test_narrow_stages_over_many_row_tiles(m, k, widths):
     """Stages with fewer than 128 output columns over more rows than one pass of the persistent workgroups covers (regression: see
     test_narrow_layers_on_a_big_batch_vs_oracle), one and two stages, against fp64 element-wise."""
-    from gsn_amd import layers
+    from gsn_amd import flags, layers
     g = torch.Generator().manual_seed(m + k + sum(widths))
     x = torch.randn(m, k, generator=g)
     stages, cur, ref = [], k, x.double()
@@ -237,7 +237,7 @@ def test_random_wide_linear_shapes_over_many_row_tiles_vs_fp64(seed):
     """gsn_linear_fwd_hip / gsn_linear_f16x3_fwd_hip (layers._linear_hip: the stages too wide for the chain kernels) with random
     block lists (direct and gathered rows), K 164-700, n_out 40-600, 20-70 k rows, with and without the train-mode column sums:
     output and fp64 column sums / sums of squares against fp64."""
-    from gsn_amd import layers
+    from gsn_amd import flags, layers
     rng = np.random.default_rng(9000 + seed)
     dev = torch.device("cuda")
     for _ in range(8):

@@ -46,7 +46,7 @@ def test_fold_takes_a_row_strided_gradient():
 
 @pytest.mark.parametrize("cls", ["GSN_edge_sparse", "GSN_sparse"])
 def test_general_training_layer_same_gradients_with_and_without_the_fold_kernel(cls, monkeypatch):
-    from gsn_amd import layers
+    from gsn_amd import flags, layers
     torch.manual_seed(11)
     n, E, d = 300, 1400, 64
     x = torch.randn(n, 24).cuda()
@@ -63,7 +63,7 @@ def test_general_training_layer_same_gradients_with_and_without_the_fold_kernel(
     layer.train()
     outs = {}
     for on in (True, False):
-        monkeypatch.setattr(layers, "FOLD_KERNEL", on)
+        monkeypatch.setattr(flags, "FOLD_KERNEL", on)
         layer.zero_grad(set_to_none=True)
         xx = x.clone().requires_grad_()
         y = layer(xx, ei, **kw)

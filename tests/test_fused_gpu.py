@@ -31,7 +31,7 @@ def _randomise_bn(layer, seed):
 
 
 def _run(cls, ctor, x, ei, ids, ef, seed=0, expect_fused=True, capfd=None):
-    from gsn_amd import layers
+    from gsn_amd import flags, layers
     from oracle import oracle
     torch.manual_seed(seed)
     layer = getattr(layers, cls)(**ctor)
@@ -58,13 +58,13 @@ def _run(cls, ctor, x, ei, ids, ef, seed=0, expect_fused=True, capfd=None):
     if capfd is not None:
         err = capfd.readouterr().err
         assert ("layer_fused_kernel" in err) == expect_fused, err[-500:]
-    was = layers.FUSED_LAYER
-    layers.FUSED_LAYER = False
+    was = flags.FUSED_LAYER
+    flags.FUSED_LAYER = False
     try:
         with torch.no_grad():
             y2 = layer(x.cuda(), ei.cuda(), **kwg)
     finally:
-        layers.FUSED_LAYER = was
+        flags.FUSED_LAYER = was
     return y.cpu(), y2.cpu(), ref
 
 
@@ -251,7 +251,7 @@ def test_fused_layer_wide_rows_non_finite():
 def _run_graphs(cls, ctor, b, x, ids, ef, seed, capfd, expect="layer_fused_kernel_g "):
     """the layer on a collated batch whose graph boundaries are registered (layers.set_graph_partition): csrc/layer_g.hip where every
     graph has <= 128 vertices -> (graph-aligned output, output of csrc/layer_w.hip on the same inputs, oracle)"""
-    from gsn_amd import layers
+    from gsn_amd import flags, layers
     from oracle import oracle
     ei = torch.from_numpy(b.edge_index)
     torch.manual_seed(seed)
@@ -272,8 +272,8 @@ def _run_graphs(cls, ctor, b, x, ids, ef, seed, capfd, expect="layer_fused_kerne
     assert layers.set_graph_partition(eic, torch.from_numpy(b.node_ptr).cuda(), torch.from_numpy(b.edge_ptr).cuda(), mn, me)
     outs = []
     for flag in (True, False):
-        was = layers.GRAPH_ALIGNED_LAYER
-        layers.GRAPH_ALIGNED_LAYER = flag
+        was = flags.GRAPH_ALIGNED_LAYER
+        flags.GRAPH_ALIGNED_LAYER = flag
         os.environ["GSN_CHAIN_TRACE"] = "1"
         try:
             layers._CSR_CACHE.clear()
@@ -282,7 +282,7 @@ def _run_graphs(cls, ctor, b, x, ids, ef, seed, capfd, expect="layer_fused_kerne
             torch.cuda.synchronize()
         finally:
             os.environ.pop("GSN_CHAIN_TRACE", None)
-            layers.GRAPH_ALIGNED_LAYER = was
+            flags.GRAPH_ALIGNED_LAYER = was
         err = capfd.readouterr().err
         assert (expect if flag else "layer_fused_kernel_w ") in err, err[-400:]
     return outs[0], outs[1], ref
@@ -376,7 +376,7 @@ def test_graph_aligned_wide_layer_non_finite(capfd):
 def test_graph_aligned_wide_layer_full_size_properties(capfd):
     """65 536 ZINC-shaped graphs (the bench shape): equal to csrc/layer_w.hip element-wise; the batch is a disjoint union -- the first 1000
     graphs alone give the same rows bit for bit (another tiling of the same graphs: a tile's rows depend on nothing outside their graphs)"""
-    from gsn_amd import layers
+    from gsn_amd import flags, layers
     b, _, ef, ei = _zinc(65536, seed=78)
     g = torch.Generator().manual_seed(3)
     N, E = b.num_nodes, b.num_edges
@@ -399,13 +399,13 @@ def test_graph_aligned_wide_layer_full_size_properties(capfd):
     finally:
         os.environ.pop("GSN_CHAIN_TRACE", None)
     assert "layer_fused_kernel_g " in capfd.readouterr().err
-    was = layers.GRAPH_ALIGNED_LAYER
-    layers.GRAPH_ALIGNED_LAYER = False
+    was = flags.GRAPH_ALIGNED_LAYER
+    flags.GRAPH_ALIGNED_LAYER = False
     try:
         with torch.no_grad():
             yw = layer(x, eic, identifiers=None, degrees=deg, edge_features=efc)
     finally:
-        layers.GRAPH_ALIGNED_LAYER = was
+        flags.GRAPH_ALIGNED_LAYER = was
     assert _elementwise_ok(y.cpu(), yw.cpu())
     n1, e1 = int(b.node_ptr[1000]), int(b.edge_ptr[1000])
     ei1 = eic[:, :e1].contiguous()
@@ -418,7 +418,7 @@ def test_graph_aligned_wide_layer_full_size_properties(capfd):
 def test_fused_layer_full_size_properties():
     """65 536 ZINC-shaped graphs (the bench shape): the fused layer equals the multi-launch path element-wise, and the batch
     is a disjoint union -- the first 1000 graphs alone give the same rows."""
-    from gsn_amd import layers
+    from gsn_amd import flags, layers
     b, x, ef, ei = _zinc(65536, seed=77)
     ids = torch.nn.functional.one_hot(torch.randint(0, 3, (b.num_edges, 4), generator=torch.Generator().manual_seed(2)), 3).reshape(-1, 12).float()
     torch.manual_seed(0)
@@ -429,11 +429,11 @@ def test_fused_layer_full_size_properties():
     deg = torch.zeros(b.num_nodes, device="cuda")
     with torch.no_grad():
         y = layer(xg, eig, identifiers=idg, degrees=deg, edge_features=efg)
-        layers.FUSED_LAYER = False
+        flags.FUSED_LAYER = False
         try:
             y2 = layer(xg, eig, identifiers=idg, degrees=deg, edge_features=efg)
         finally:
-            layers.FUSED_LAYER = True
+            flags.FUSED_LAYER = True
         n1, e1 = int(b.node_ptr[1000]), int(b.edge_ptr[1000])
         y3 = layer(xg[:n1].contiguous(), eig[:, :e1].contiguous(), identifiers=idg[:e1].contiguous(), degrees=deg[:n1], edge_features=efg[:e1].contiguous())
     assert torch.isfinite(y).all()
@@ -443,9 +443,9 @@ def test_fused_layer_full_size_properties():
 
 def test_parameter_written_through_data_is_noticed():
     """VERDICT r02 / ADVICE r02: ``p.data.mul_()`` does not bump ``p._version``, on which the prepared-weight caches are keyed.  With the
-    validation mode on (``layers.VALIDATE_CACHES`` / ``GSN_VALIDATE_CACHES=1``) the next forward notices the write by content; without
+    validation mode on (``flags.VALIDATE_CACHES`` / ``GSN_VALIDATE_CACHES=1``) the next forward notices the write by content; without
     it ``layers.invalidate_caches(layer)`` is the documented call.  Either way the result must equal the oracle WITH the new weight."""
-    from gsn_amd import layers
+    from gsn_amd import flags, layers
     from oracle import oracle
     b, x, ef, ei = _zinc(300, seed=41)
     ids = (torch.rand(b.num_edges, 12, generator=torch.Generator().manual_seed(1)) < 0.2).float()
@@ -458,10 +458,10 @@ def test_parameter_written_through_data_is_noticed():
     def ref_now():
         sd = {k: v.detach().cpu().clone() for k, v in layer.state_dict().items()}
         return oracle.layer_forward("GSN_edge_sparse", CTOR, sd, x, ei, training=False, identifiers=ids, degrees=None, edge_features=ef)
-    was = layers.VALIDATE_CACHES
+    was = flags.VALIDATE_CACHES
     try:
         for mode in ("validate", "explicit"):
-            layers.VALIDATE_CACHES = mode == "validate"
+            flags.VALIDATE_CACHES = mode == "validate"
             with torch.no_grad():
                 y0 = layer(x.cuda(), ei.cuda(), **kw)
                 assert _elementwise_ok(y0.cpu(), ref_now())
@@ -475,7 +475,7 @@ def test_parameter_written_through_data_is_noticed():
             assert not _elementwise_ok(y0.cpu(), r1)                    # (the write matters)
             assert _elementwise_ok(y1.cpu(), r1), (mode, float((y1.cpu() - r1).abs().max() / r1.abs().max()))
     finally:
-        layers.VALIDATE_CACHES = was
+        flags.VALIDATE_CACHES = was
 
 
 def test_parameter_written_through_data_is_noticed_without_any_flag():
@@ -483,10 +483,10 @@ def test_parameter_written_through_data_is_noticed_without_any_flag():
     synchronisation); a `.data` write is noticed at the NEXT forward whose predecessor's fingerprint has landed -- RuntimeWarning, caches
     dropped -- and from there on the results are those of the new weights.  An ordinary in-place update (version counter moves) never warns."""
     import warnings
-    from gsn_amd import layers
+    from gsn_amd import flags, layers
     from oracle import oracle
-    assert layers.ASYNC_VALIDATE and not layers.VALIDATE_CACHES
-    interval, layers.ASYNC_VALIDATE_INTERVAL = layers.ASYNC_VALIDATE_INTERVAL, 0.0      # (a fingerprint behind EVERY forward of this test)
+    assert flags.ASYNC_VALIDATE and not flags.VALIDATE_CACHES
+    interval, flags.ASYNC_VALIDATE_INTERVAL = flags.ASYNC_VALIDATE_INTERVAL, 0.0      # (a fingerprint behind EVERY forward of this test)
     b, x, ef, ei = _zinc(300, seed=43)
     ids = (torch.rand(b.num_edges, 12, generator=torch.Generator().manual_seed(1)) < 0.2).float()
     torch.manual_seed(3)
@@ -519,7 +519,7 @@ def test_parameter_written_through_data_is_noticed_without_any_flag():
         layer(x.cuda(), ei.cuda(), **kw)                           # sees the fingerprint of the call before: warns, drops the caches
         torch.cuda.synchronize()
         y2 = layer(x.cuda(), ei.cuda(), **kw)
-        layers.ASYNC_VALIDATE_INTERVAL = interval
+        flags.ASYNC_VALIDATE_INTERVAL = interval
         assert [w for w in rec if issubclass(w.category, RuntimeWarning) and "written through" in str(w.message)]
         assert _elementwise_ok(y2.cpu(), r1), float((y2.cpu() - r1).abs().max() / r1.abs().max())
 
@@ -531,7 +531,7 @@ def test_wide_layers_chain_their_row_exponents(capfd):
     other kernels the entry point makes it by that pass."""
     import ctypes
     import os
-    from gsn_amd import layers, _abi
+    from gsn_amd import flags, layers, _abi
     b, _, _, ei = _zinc(200, seed=91)
     g = torch.Generator().manual_seed(29)
     N, E = b.num_nodes, b.num_edges
@@ -545,8 +545,8 @@ def test_wide_layers_chain_their_row_exponents(capfd):
     eic = ei.cuda()
 
     def two(chain):
-        was = layers.CHAIN_ROW_EXPONENTS
-        layers.CHAIN_ROW_EXPONENTS = chain
+        was = flags.CHAIN_ROW_EXPONENTS
+        flags.CHAIN_ROW_EXPONENTS = chain
         os.environ["GSN_CHAIN_TRACE"] = "1"
         try:
             with torch.no_grad():
@@ -555,7 +555,7 @@ def test_wide_layers_chain_their_row_exponents(capfd):
                 torch.cuda.synchronize()
         finally:
             os.environ.pop("GSN_CHAIN_TRACE")
-            layers.CHAIN_ROW_EXPONENTS = was
+            flags.CHAIN_ROW_EXPONENTS = was
         return h, y, capfd.readouterr().err
     h0, y0, err0 = two(False)
     h1, y1, err1 = two(True)
@@ -575,12 +575,12 @@ def test_wide_layers_chain_their_row_exponents(capfd):
         finally:
             os.environ.pop("GSN_CHAIN_TRACE")
         assert "layer_w_row_exp_kernel" in capfd.readouterr().err
-        was = layers.CHAIN_ROW_EXPONENTS
-        layers.CHAIN_ROW_EXPONENTS = False
+        was = flags.CHAIN_ROW_EXPONENTS
+        flags.CHAIN_ROW_EXPONENTS = False
         try:
             y3 = l2(h1.clone(), eic, **kw)
         finally:
-            layers.CHAIN_ROW_EXPONENTS = was
+            flags.CHAIN_ROW_EXPONENTS = was
     assert torch.equal(y2, y3)
 
 
@@ -589,7 +589,7 @@ def test_wide_layer_inside_a_captured_graph(capfd):
     """gsn_layer_fused_fwd_ws_hip: with caller-owned scratch the d = 128 layer allocates nothing, so the SAME kernel runs inside a captured
     HIP graph (trace printed during capture) and the replay equals the eager result bit for bit"""
     import os
-    from gsn_amd import layers
+    from gsn_amd import flags, layers
     b, _, _, ei = _zinc(64, seed=17)
     g = torch.Generator().manual_seed(31)
     N, E = b.num_nodes, b.num_edges

@@ -116,7 +116,7 @@ def test_linear_kernel_vs_torch():
 
 
 def _build(c):
-    from gsn_amd import layers
+    from gsn_amd import flags, layers
     layer = getattr(layers, c["cls"])(**c["ctor"])
     layer.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in c.items() if k.startswith("sd/")})
     return layer.cuda().train(c["train"])
@@ -184,7 +184,7 @@ def test_layer_backward_golden(name):
 
 def test_layer_vs_oracle_big_batch():
     """A 4096-graph ZINC-shaped batch at the real layer-0 widths (BASELINE config 2) against the oracle's fp32 torch restatement."""
-    from gsn_amd import layers, synth
+    from gsn_amd import flags, layers, synth
     from oracle import oracle
     torch.manual_seed(5)
     b = synth.zinc_shape_batch(4096, seed=11)
@@ -215,7 +215,7 @@ def test_narrow_layers_on_a_big_batch_vs_oracle(cls, kind):
     dense kernels handles several row tiles, with stages that have fewer output columns than a workgroup has column waves
     (regression: the waves without output columns of mlp_chain_kernel skipped their share of the next tile's loads -- rows
     past the first 128 x gridDim were computed from the previous tile's inputs; the small-batch goldens never got there)."""
-    from gsn_amd import layers, synth
+    from gsn_amd import flags, layers, synth
     from oracle import oracle
     torch.manual_seed(8)
     b = synth.zinc_shape_batch(4096, seed=12)
@@ -286,7 +286,7 @@ def test_readout_pooling_vs_torch():
 def test_readout_of_a_registered_sorted_batch():
     """layers.set_batch_partition: the readout of a collated batch takes its segment bounds from the node pointers (no index build
     -- the timer sees no csr_build launch); same sums, forward and backward, graphs without vertices included."""
-    from gsn_amd import layers
+    from gsn_amd import flags, layers
     torch.manual_seed(5)
     sizes = torch.randint(0, 40, (400,))
     sizes[0] = 0; sizes[-1] = 0; sizes[17] = 0
@@ -296,13 +296,13 @@ def test_readout_of_a_registered_sorted_batch():
     ref = torch.zeros(400, 96, device="cuda").index_add(0, batch, x)
     layers.invalidate_caches()
     layers.set_batch_partition(batch, node_ptr)
-    layers.KERNEL_TIMER = {}
+    flags.KERNEL_TIMER = {}
     try:
         got = layers.global_add_pool_sparse(x, batch, 400)
         torch.cuda.synchronize()
-        families = set(layers.KERNEL_TIMER)
+        families = set(flags.KERNEL_TIMER)
     finally:
-        layers.KERNEL_TIMER = None
+        flags.KERNEL_TIMER = None
     assert "csr_build" not in families and "propagate_fwd" in families
     assert rel_err(got, ref.detach()) < TOL
     w = torch.randn_like(got)
@@ -432,7 +432,7 @@ def test_fused_scatter_add_vs_torch(N, E, hub, wx, we, n_out):
 def test_wide_mlp_train_mode_materialised_path(act):
     """Shapes outside the fused chain (n_out > 128) in train mode: pre-BN rows + statistics in one linear pass, then
     gsn_bn_act_hip -- against nn.Sequential of the same parameters, incl. the running statistics and a fused post-BN."""
-    from gsn_amd import layers
+    from gsn_amd import flags, layers
     torch.manual_seed(3)
     m = layers.mlp(70, 150, [200], 0, act, True).cuda().train()
     post = torch.nn.BatchNorm1d(150).cuda().train()
@@ -442,14 +442,15 @@ def test_wide_mlp_train_mode_materialised_path(act):
     ref[3].load_state_dict(m.fc[1].state_dict()); ref[4].load_state_dict(post.state_dict())
     x = torch.randn(777, 70, device="cuda")
     called = []
-    orig = layers._run_stages_materialised
-    layers._run_stages_materialised = lambda *a, **k: (called.append(1), orig(*a, **k))[1]
+    from gsn_amd import _dense          # (run_stages looks the function up in its own module)
+    orig = _dense._run_stages_materialised
+    _dense._run_stages_materialised = lambda *a, **k: (called.append(1), orig(*a, **k))[1]
     try:
         with torch.no_grad():
             y = m(x, post=(post, "relu"))
             want = ref(x)
     finally:
-        layers._run_stages_materialised = orig
+        _dense._run_stages_materialised = orig
     assert called, "wide train-mode stages must take the materialised path"
     assert float((y - want).abs().max()) <= 2e-5 * max(float(want.abs().max()), 1.0)
     for a, b in ((m.bn[0], ref[1]), (post, ref[4])):
@@ -463,7 +464,7 @@ def test_wide_mlp_train_mode_materialised_path(act):
 def test_mlp_native_backward_matches_autograd(shape, act, bn, post):
     """gsn_bn_act_bwd_hip + gsn_wgrad_hip + the forward kernel on W^T against PyTorch autograd on the same parameters
     (train mode: batch-statistics BatchNorm)."""
-    from gsn_amd import layers
+    from gsn_amd import flags, layers
     m_rows, d_in, d_h, d_out = shape
     torch.manual_seed(5)
     m = layers.mlp(d_in, d_out, list(d_h), 0, act, bn).cuda().train()
@@ -478,7 +479,7 @@ def test_mlp_native_backward_matches_autograd(shape, act, bn, post):
     state = [b.clone() for b in m.buffers()] + ([b.clone() for b in pbn.buffers()] if post else [])
 
     def run(native):
-        layers.NATIVE_DENSE_BACKWARD = native
+        flags.NATIVE_DENSE_BACKWARD = native
         for b, s0 in zip(list(m.buffers()) + (list(pbn.buffers()) if post else []), state):
             b.copy_(s0)
         for p in params + [x]:
@@ -490,7 +491,7 @@ def test_mlp_native_backward_matches_autograd(shape, act, bn, post):
         y1, g1, gx1, b1 = run(True)
         y0, g0, gx0, b0 = run(False)
     finally:
-        layers.NATIVE_DENSE_BACKWARD = True
+        flags.NATIVE_DENSE_BACKWARD = True
     scale = lambda t: max(float(t.abs().max()), 1e-6)
     assert float((y1 - y0).abs().max()) <= 2e-5 * scale(y0)
     gmax = max(scale(t) for t in g0)
@@ -505,7 +506,7 @@ def test_mlp_native_backward_matches_autograd(shape, act, bn, post):
 def test_training_paths_use_native_adjoints():
     """In train mode no layer kind falls back to the PyTorch twin: general -> _general_train, gin / ogb -> propagate +
     native mlp; gradients reach every parameter and the inputs."""
-    from gsn_amd import layers, synth
+    from gsn_amd import flags, layers, synth
     b = synth.zinc_shape_batch(6, seed=3)
     ei = torch.from_numpy(b.edge_index).cuda()
     n, E = b.num_nodes, b.num_edges
@@ -545,7 +546,7 @@ def test_full_size_properties_of_the_headline_layer():
     (ii) edge order is irrelevant: permuting the columns of edge_index (and the per-edge inputs with them) leaves the
     output unchanged up to fp32 summation order;  (iii) the integer-coded inputs give the same result."""
     import bench
-    from gsn_amd import layers
+    from gsn_amd import flags, layers
     b = bench.make_batch(65536, 3)
     dev = "cuda"
     N, E = b.num_nodes, b.num_edges
@@ -564,7 +565,7 @@ def test_full_size_properties_of_the_headline_layer():
                    edge_features=ef[:e1].contiguous())
         perm = torch.randperm(E, device=dev)
         yp = layer(x, ei[:, perm].contiguous(), identifiers=idf[perm].contiguous(), degrees=deg, edge_features=ef[perm].contiguous())
-        layers.CODE_STATUS_CHECK = True
+        flags.CODE_STATUS_CHECK = True
         yc = layer(xc, ei, identifiers=ic, degrees=deg, edge_features=ec)
     scale = float(y.abs().max())
     assert torch.isfinite(y).all() and y.shape == (N, 128)
@@ -619,7 +620,7 @@ def test_csr_of_a_collated_batch_in_one_launch():
     perm, sorted targets and sources for both rows of edge_index; duplicates, self loops, empty graphs, vertices without
     columns; pointers that do not describe the batch are reported; graphs beyond the LDS bound fall back."""
     import numpy as np
-    from gsn_amd import layers, synth
+    from gsn_amd import flags, layers, synth
     rng = np.random.default_rng(3)
     graphs = [synth.zinc_shape_graph(rng) for _ in range(700)]
     graphs[5] = (4, np.zeros((2, 0), np.int64))                                    # no columns
@@ -685,7 +686,7 @@ def test_csr_of_a_collated_batch_in_one_launch():
 def test_wide_edge_stage_split_into_node_product_and_gather_sum(cls, scope, bn, d, monkeypatch):
     """Layers 1.. of a d = 128 model (edge rows K = 260): cat(x_i, x_j, z) W^T = x_i W_i^T + x_j W_j^T + z W_z^T -- node
     product + gsn_edge_split_sum_hip -- against the fp32 oracle at 1e-5 element-wise, and against the E-row product path."""
-    from gsn_amd import layers, synth
+    from gsn_amd import flags, layers, synth
     from oracle import oracle
     b = synth.zinc_shape_batch(300, seed=31)
     N, E = b.num_nodes, b.num_edges
@@ -719,11 +720,11 @@ def test_wide_edge_stage_split_into_node_product_and_gather_sum(cls, scope, bn, 
         calls.append(r is not None)
         return r
     monkeypatch.setattr(layers._SparseLayer, "_split_edge_stage", spy)
-    monkeypatch.setattr(layers, "FUSED_LAYER", False)      # (d = 128 goes to the one-launch kernel of csrc/layer_w.hip otherwise: tests/test_fused_gpu.py)
+    monkeypatch.setattr(flags, "FUSED_LAYER", False)      # (d = 128 goes to the one-launch kernel of csrc/layer_w.hip otherwise: tests/test_fused_gpu.py)
     with torch.no_grad():
         y = layer(x.cuda(), ei.cuda(), **kw).cpu()
         assert calls == [True]
-        monkeypatch.setattr(layers, "SPLIT_EDGE_STAGE", False)
+        monkeypatch.setattr(flags, "SPLIT_EDGE_STAGE", False)
         layers._CSR_CACHE.clear()
         y_old = layer(x.cuda(), ei.cuda(), **kw).cpu()
     assert elementwise_ok(y, ref), float((y - ref).abs().max() / ref.abs().max())
@@ -734,7 +735,7 @@ def test_edge_less_training_batch_through_batchnorm():
     """an edge-less batch in TRAIN mode through a `general` layer whose msg_fn has BatchNorm -- nn.BatchNorm1d takes a [0, C]
     input (empty output, running statistics untouched, the batch counted), so the layer must not raise: zero aggregates, zero gradients for
     msg_fn, update_fn trained on [x | 0]."""
-    from gsn_amd import layers
+    from gsn_amd import flags, layers
     from oracle import oracle
     ctor = dict(d_in=6, d_ef=3, d_id=4, d_degree=1, degree_as_tag=False, retain_features=True, id_scope="local", d_msg=16, d_up=16,
                 d_h=[16], seed=0, activation_name="relu", bn=True, msg_kind="general", flow="source_to_target")
@@ -761,7 +762,7 @@ def test_edge_less_training_batch_through_batchnorm():
 def test_eval_after_training_uses_the_updated_running_statistics():
     """eval forward (fills the eval-mode BatchNorm vector cache) -> train forward (the finalize kernel writes running_mean / running_var through
     raw pointers) -> eval forward: must see the NEW running statistics (their version counters are moved with the kernel's write)."""
-    from gsn_amd import layers
+    from gsn_amd import flags, layers
     from oracle import oracle
     ctor = dict(d_in=6, d_ef=3, d_id=4, d_degree=1, degree_as_tag=False, retain_features=True, id_scope="local", d_msg=16, d_up=16,
                 d_h=[16], seed=0, activation_name="relu", bn=True, msg_kind="general", flow="source_to_target")

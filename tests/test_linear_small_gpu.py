@@ -39,9 +39,9 @@ CASES = [  # m_rows, block widths, gathered?, n_out, act, bn, bias, transposed w
 @pytest.mark.parametrize("case", CASES, ids=[str(c[0]) + "x" + str(sum(c[1])) + "x" + str(c[3]) for c in CASES])
 @pytest.mark.parametrize("with_stats", [False, True])
 def test_small_row_counts_against_float64(case, with_stats, monkeypatch):
-    from gsn_amd import layers
+    from gsn_amd import flags, layers
     m, widths, gath, n_out, act, use_bn, use_bias, transposed = case
-    monkeypatch.setattr(layers, "LINEAR_F16X3", False)
+    monkeypatch.setattr(flags, "LINEAR_F16X3", False)
     rng = np.random.default_rng(m * 31 + n_out)
     dev = torch.device("cuda")
     blocks = []
@@ -78,9 +78,9 @@ def test_small_row_counts_against_float64(case, with_stats, monkeypatch):
 
 def test_a_row_does_not_depend_on_the_tile_height():
     """The same rows as part of a product with many 128-row tiles (the 128-row kernel) and as a small product (32-row tiles): identical bits."""
-    from gsn_amd import layers
-    old = layers.LINEAR_F16X3
-    layers.LINEAR_F16X3 = False
+    from gsn_amd import flags, layers
+    old = flags.LINEAR_F16X3
+    flags.LINEAR_F16X3 = False
     try:
         g = torch.Generator().manual_seed(8)
         big = torch.randn(40000, 272, generator=g).cuda()
@@ -90,4 +90,4 @@ def test_a_row_does_not_depend_on_the_tile_height():
         y_small = layers._linear_hip([(big[:3000].contiguous(), None)], w, b, None, None, None, 1, 3000)
         assert torch.equal(y_big[:3000], y_small)
     finally:
-        layers.LINEAR_F16X3 = old
+        flags.LINEAR_F16X3 = old
