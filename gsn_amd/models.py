@@ -270,6 +270,7 @@ class GNN_OGB(nn.Module):
         kwargs = {"degrees": self.degree_encoder(data.degrees)}
         memo = {}
         edge_index = data.edge_index
+        _register_partition(data, edge_index)
         if self.vn:
             n_graphs = layers.num_graphs_of(data.batch)            # (data.batch[-1] + 1 of the reference: sorted graph ids; one read per batch)
             vn_embedding = self.vn_encoder(torch.zeros(n_graphs, dtype=edge_index.dtype, device=edge_index.device))

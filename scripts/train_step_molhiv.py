@@ -39,6 +39,11 @@ def make_data(n_graphs, seed, dev):
         edge_features=torch.from_numpy(rng.integers(0, encoding.BOND_FEATURE_DIMS, size=(E, 3))).to(dev),
         identifiers=codes.to(dev), batch=torch.from_numpy(np.asarray(b.batch).astype(np.int64)).to(dev),
         degrees=torch.zeros(N, device=dev), y=torch.from_numpy(rng.integers(0, 2, size=(n_graphs, 1)).astype(np.float32)).to(dev))
+    if os.environ.get("GSN_TRAIN_PARTITION", "1") != "0":
+        # the collated batch's graph boundaries (what the counting kernel takes as well): the layers' aggregation index is then ONE launch per
+        # direction (gsn_csr_build_graphs_hip) instead of the generic build, the readout needs none (models._register_partition)
+        d.graph_partition = (torch.from_numpy(b.node_ptr.astype(np.int64)).to(dev), torch.from_numpy(b.edge_ptr.astype(np.int64)).to(dev),
+                             int(np.diff(b.node_ptr).max()), int(np.diff(b.edge_ptr).max()), False)
     return d, d_id, N, E
 
 

@@ -33,6 +33,11 @@ def build(args, dev, rank=0):
                                  edge_features=torch.from_numpy(b.bond_type).unsqueeze(1).to(dev), identifiers=codes.to(dev),
                                  batch=torch.from_numpy(np.asarray(b.batch).astype(np.int64)).to(dev), degrees=torch.zeros(N, device=dev),
                                  y=torch.from_numpy(rng.standard_normal((args.batch, 1)).astype(np.float32)).to(dev))
+    if os.environ.get("GSN_TRAIN_PARTITION", "1") != "0":
+        # the collated batch's graph boundaries (what the counting kernel takes as well): the layers' aggregation index is then ONE launch per
+        # direction (gsn_csr_build_graphs_hip) instead of the generic build, the readout needs none (models._register_partition)
+        data.graph_partition = (torch.from_numpy(b.node_ptr.astype(np.int64)).to(dev), torch.from_numpy(b.edge_ptr.astype(np.int64)).to(dev),
+                                int(np.diff(b.node_ptr).max()), int(np.diff(b.edge_ptr).max()), False)
     L, d = 4, 128
     kw = dict(seed=0, model_name="GSN_edge_sparse", readout="sum", dropout_features=[0.0] * (L + 1), bn=[True] * L,
               final_projection=[False] * L + [True], inject_ids=False, inject_edge_features=True, random_features=False,
