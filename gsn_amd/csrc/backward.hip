@@ -486,7 +486,8 @@ extern "C" int gsn_wgrad_hip(int64_t m_rows, int64_t n_out, const float *grad_h,
     // reference's 32 / 128 graphs: M ~ 800 .. 6 000 rows) are bound by the serial chain of 16-row steps inside a slab instead (load ->
     // split -> LDS -> products, ~1.2 us per step with one workgroup per CU and nothing to hide the latency: 60 us per call at 256 rows):
     // 64-row slabs there.
-    int64_t slabs = (2048 + tn * tk - 1) / (tn * tk);
+    static const int64_t wg_target = [] { const char *e = getenv("GSN_WGRAD_WGS"); const int64_t v = e ? atoll(e) : 0; return v > 0 ? v : (int64_t)2048; }();   // (A/B: workgroups per call)
+    int64_t slabs = (wg_target + tn * tk - 1) / (tn * tk);
     int64_t rows_per = (m_rows + slabs - 1) / slabs;
     const int64_t min_rows = m_rows >= 65536 ? 256 : 64;
     if (rows_per < min_rows) rows_per = min_rows;

@@ -54,6 +54,7 @@ struct CountArgs {
     int off_ain;               // directed plans: the in-neighbour bit matrix
     int stride;                // words per plan (plan_stride)
     int pull_batch;            // idle lanes that wait before the pool's pull arm runs (1: every trip; GSN_PULL_BATCH)
+    int zero_status;           // 1: a workgroup owns its graphs' status words (no split, no graph list) and zeroes them itself -- no memset launch in front
     // fused identifier encoding (gsn_count_encode_hip): column c of a finished cell also / instead leaves as n_classes[c] floats
     // with a single 1 (utils_graph_learning.one_hot_encoder, :170-187) -- the int64 round trip through HBM and the one-hot launch go
     unsigned short enc_n[GSN_ENC_MAX_COLS];   // n_classes per output column (blocks in column order)
@@ -526,7 +527,7 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
     COUNT_T(6);
     if (misc[2] != 0) {
         if (!report) return 1;
-        if (tid == 0) atomicMax(&a.status[g], misc[2]);   // status[] is zeroed by the launcher
+        if (tid == 0) atomicMax(&a.status[g], misc[2]);   // status[] starts at zero: zeroed by this workgroup (zero_status) or by the launcher
     }
     return 0;
 }
@@ -542,6 +543,10 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
     // one when it did not fit or held an error
     const int g0 = (MOL || a.pair) ? 2 * item : (a.graph_ids ? a.graph_ids[item] : item);
     const bool two = (MOL || a.pair) && g0 + 1 < a.n_graphs;
+    if (a.zero_status && threadIdx.x == 0) {           // (the thread that raises them later: same address, program order)
+        a.status[g0] = 0;
+        if (two) a.status[g0 + 1] = 0;
+    }
     for (int pass = 0; pass < 3; ++pass) {
         const int g = pass == 2 ? g0 + 1 : g0;
         const int ng = (pass == 0 && two) ? 2 : 1;
@@ -559,6 +564,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(COUNT_MOL_WA
     const int item = (int)blockIdx.x;
     const int g0 = 2 * item;
     const bool two = g0 + 1 < a.n_graphs;
+    if (a.zero_status && threadIdx.x == 0) {
+        a.status[g0] = 0;
+        if (two) a.status[g0 + 1] = 0;
+    }
     for (int pass = 0; pass < 3; ++pass) {
         const int g = pass == 2 ? g0 + 1 : g0;
         const int ng = (pass == 0 && two) ? 2 : 1;
@@ -809,7 +818,10 @@ static int count_launch(const uint32_t *plan_host, const uint32_t *plan_dev, int
                                             "n_classes <= 255); pack the fp32 rows with gsn_pack16_rows_hip instead");
 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    {   // per-graph status words start at OK; workgroups raise them with atomicMax
+    // per-graph status words start at OK; workgroups raise them with atomicMax.  One workgroup per graph (or pair) and every graph taken:
+    // the workgroup zeroes its own words -- the memset was a 6 us launch (+ the gap behind it) in front of every counting launch
+    a.zero_status = (!graph_ids && a.split == 1) ? 1 : 0;
+    if (!a.zero_status) {
         hipError_t e = graph_ids ? hipSuccess : hipMemsetAsync(status, 0, sizeof(int32_t) * (size_t)n_graphs, st);
         if (graph_ids) hipLaunchKernelGGL(status_zero_kernel, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, st, graph_ids, (int)n_items, status);
         if (e != hipSuccess) return set_error(GSN_E_HIP, "hipMemsetAsync(status): %s", hipGetErrorString(e));

@@ -101,6 +101,30 @@ def test_dense_cliques_vs_oracle():
         assert np.array_equal(got, ref)
 
 
+def test_counts_beyond_16_bits_leave_the_lds_staging_exactly():
+    """The output rows of a small graph are staged in LDS as 16-bit counts (count.hip, emit_cell); a count that does not fit leaves by
+    itself.  Complete graphs give closed forms on both sides of 65 535 in ONE launch (and in one workgroup: K_20 + K_40 are a pair):
+    a vertex of K_n lies in C(n - 1, k - 1) cliques K_k, an edge in C(n - 2, k - 2) (utils_graph_processing.py:103-179 counts each
+    occurrence once per orbit position) -- K_40: C(39, 4) = 82 251 K_5 per vertex, C(39, 5) = 575 757 K_6; K_20: 3 876 / 11 628."""
+    from math import comb
+    from gsn_amd import synth
+    from gsn_amd.counting import counts2ids_batch
+    sizes = [20, 40, 40, 12, 33, 40]
+    graphs = [(n, synth.undirected_to_edge_index(n, np.argwhere(np.triu(np.ones((n, n), dtype=bool), 1)))) for n in sizes]
+    b = synth.collate(graphs)
+    ks = (3, 4, 5, 6)
+    pats = [list(nx.complete_graph(k).edges) for k in ks]
+    v = counts2ids_batch(b, pats, "vertex", False).cpu().numpy()
+    e = counts2ids_batch(b, pats, "edge", False).cpu().numpy()
+    assert v.max() > 65535 and v.min() < 65535
+    for g, n in enumerate(sizes):
+        rows_v = v[b.node_ptr[g]:b.node_ptr[g + 1]]
+        rows_e = e[b.edge_ptr[g]:b.edge_ptr[g + 1]]
+        for c, k in enumerate(ks):
+            assert (rows_v[:, c] == comb(n - 1, k - 1)).all(), (n, k, rows_v[0, c], comb(n - 1, k - 1))
+            assert (rows_e[:, c] == comb(n - 2, k - 2)).all(), (n, k, rows_e[0, c], comb(n - 2, k - 2))
+
+
 def test_vertex_edge_consistency_at_full_size():
     """Size-independent property at the ZINC-12k size of BASELINE config 2: for the cycle C_k,
     sum_v counts_v = k * #cycles and sum_e counts_e = 2k * #cycles, so both modes must agree; and the run is deterministic."""
