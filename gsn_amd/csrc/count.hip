@@ -62,6 +62,7 @@ struct CountArgs {
     int enc_width, enc_clamp, off_enc;
     int enc_stage;             // 1: cells leave their class index in an LDS byte array, the rows are expanded and written coalesced at the end
     int off_encst;             // that array: [rows_cap][n_cols] bytes, 0xff = no class (count out of range, unclamped)
+    int enc_from_counts;       // 1: no byte array -- the staged 16-bit counts (stage_out) give the class indices at the end (LDS per workgroup: occupancy)
     uint16_t *enc16;           // the same rows as fp16 into a column range of an exact row pack (gsn_count_encode_pack16_hip), or null; staged rows only
     int enc16_stride, enc16_col0;
 };
@@ -98,7 +99,10 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
     typedef typename std::conditional<(W <= 4), uint8_t, uint16_t>::type vid_t;   // column endpoints
     vid_t *eu = reinterpret_cast<vid_t *>(smem + a.off_eu);
     vid_t *ev = reinterpret_cast<vid_t *>(smem + a.off_ev);
-    int *rowstart = reinterpret_cast<int *>(smem + a.off_rowstart);
+    // (prefix sums of the distinct-neighbour degrees: one-word graphs -- at most 64 x 63 pairs -- keep them as 16-bit values: 128 bytes of
+    //  a molecule pair's 6.9 KiB, the difference between 23 and 24 workgroups per CU)
+    typedef typename std::conditional<(W == 1), uint16_t, int>::type rs_t;
+    rs_t *rowstart = reinterpret_cast<rs_t *>(smem + a.off_rowstart);
     int *last = reinterpret_cast<int *>(smem + a.off_last);
     // (column tables as 16-bit values: a workgroup whose per-column state fits LDS has far fewer than 65535 columns; 0xffff = none)
     uint16_t *prim = reinterpret_cast<uint16_t *>(smem + a.off_prim);
@@ -121,6 +125,7 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
     const int64_t row0 = edge_mode ? e0 : n0;
     const int n_cols = MOL ? 4 : a.n_cols;
     const bool a_stage_out = a.stage_out != 0, a_sym = MOL || a.sym != 0, a_enc = MOL || a.enc_out != nullptr, a_enc_stage = MOL || a.enc_stage != 0;
+    const bool a_enc_from_counts = a.enc_from_counts != 0;
     const int a_split = MOL ? 1 : a.split;
 
     if (ng > 1 && (n64 > a.n_cap || E64 > a.e_cap || n64 > W * 64)) return 1;
@@ -152,7 +157,7 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
             uint64_t v = cnt;
             if (a.enc_clamp && v >= (uint64_t)ncls) v = (uint64_t)(ncls - 1);
             if (a_enc_stage) {
-                (smem + a.off_encst)[row * n_cols + col] = v < (uint64_t)ncls ? (unsigned char)v : (unsigned char)0xff;
+                if (!a_enc_from_counts) (smem + a.off_encst)[row * n_cols + col] = v < (uint64_t)ncls ? (unsigned char)v : (unsigned char)0xff;
             } else {
                 float *d0 = a.enc_out + (row0 + row) * a.enc_width + eo;
                 for (int j = 0; j < ncls; ++j) d0[j] = (uint64_t)j == v ? 1.f : 0.f;
@@ -272,8 +277,8 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
                 const int t = __shfl_up(incl, o);
                 if (tid >= o) incl += t;
             }
-            if (tid <= n) rowstart[tid] = incl - d;
-            if (tid == 63 && n == 64) rowstart[64] = incl;
+            if (tid <= n) rowstart[tid] = (rs_t)(incl - d);
+            if (tid == 63 && n == 64) rowstart[64] = (rs_t)incl;
         } else {
             for (int u = tid; u <= n; u += T) {
                 int s = 0;
@@ -281,7 +286,7 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
 #pragma unroll
                     for (int w = 0; w < W; ++w) s += popc64(A[x * W + w]);
                 }
-                rowstart[u] = s;
+                rowstart[u] = (rs_t)s;
             }
         }
         for (int i = tid; i < E; i += T) last[i] = -1;
@@ -480,6 +485,13 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
     // ---- phase 4': encoded rows from the staged class indices, one float per thread and trip, consecutive addresses ----------
     if (a_enc && a_enc_stage) {
         const unsigned char *est = smem + a.off_encst;
+        // class index of cell (r, c): the staged byte, or from the staged 16-bit count (0xffff = a count of 65 535 and more: the last class
+        // when clamped, none otherwise -- class counts fit a byte here)
+        auto cls_from_count = [&](unsigned v, int c) -> int {
+            const int ncls = enc[2 * c + 1];
+            if (a.enc_clamp) return (int)v >= ncls ? ncls - 1 : (int)v;
+            return (int)v < ncls ? (int)v : 0xff;
+        };
         float *dst = a.enc_out + row0 * a.enc_width;
         const int total = rows * a.enc_width;
         const bool pack_ok = !a.enc16 || (((a.enc16_stride | a.enc16_col0) & 3) == 0 && (reinterpret_cast<uintptr_t>(a.enc16) & 7) == 0);
@@ -488,8 +500,15 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
             // its four class indices as one word and writes the row as float4s
             int hot0 = enc[0], hot1 = enc[2], hot2 = enc[4], hot3 = enc[6];
             for (int r = tid; r < rows; r += T) {
-                const unsigned cw = *reinterpret_cast<const unsigned *>(est + 4 * r);
-                const int c0 = (int)(cw & 0xffu), c1 = (int)((cw >> 8) & 0xffu), c2 = (int)((cw >> 16) & 0xffu), c3 = (int)(cw >> 24);
+                int c0, c1, c2, c3;
+                if (a_enc_from_counts) {
+                    const uint2 q = *reinterpret_cast<const uint2 *>(out_lds + 4 * r);
+                    c0 = cls_from_count(q.x & 0xffffu, 0); c1 = cls_from_count(q.x >> 16, 1);
+                    c2 = cls_from_count(q.y & 0xffffu, 2); c3 = cls_from_count(q.y >> 16, 3);
+                } else {
+                    const unsigned cw = *reinterpret_cast<const unsigned *>(est + 4 * r);
+                    c0 = (int)(cw & 0xffu); c1 = (int)((cw >> 8) & 0xffu); c2 = (int)((cw >> 16) & 0xffu); c3 = (int)(cw >> 24);
+                }
                 const int h0 = c0 == 0xff ? -1 : hot0 + c0, h1 = c1 == 0xff ? -1 : hot1 + c1;
                 const int h2 = c2 == 0xff ? -1 : hot2 + c2, h3 = c3 == 0xff ? -1 : hot3 + c3;
                 float4 *d4 = reinterpret_cast<float4 *>(dst + r * a.enc_width);
@@ -519,7 +538,8 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
             int c = 0;
             while (c + 1 < n_cols && enc[2 * (c + 1)] <= j) ++c;
             const int k = j - enc[2 * c];
-            const bool hot = k < enc[2 * c + 1] && (int)est[r * n_cols + c] == k;
+            const int cls = a_enc_from_counts ? cls_from_count(out_lds[r * n_cols + c], c) : (int)est[r * n_cols + c];
+            const bool hot = k < enc[2 * c + 1] && cls == k;
             dst[i] = hot ? 1.f : 0.f;
             if (a.enc16) a.enc16[(row0 + r) * a.enc16_stride + a.enc16_col0 + j] = hot ? (uint16_t)0x3c00 : (uint16_t)0;
         }
@@ -756,7 +776,7 @@ static int count_launch(const uint32_t *plan_host, const uint32_t *plan_dev, int
     const int vid_bytes = W > 4 ? 2 : 1;
     a.off_eu = o; o += edge_mode ? align_up((int)max_edges * vid_bytes, 16) : 0;
     a.off_ev = o; o += edge_mode ? align_up((int)max_edges * vid_bytes, 16) : 0;
-    a.off_rowstart = o; o += edge_mode ? align_up(((int)max_nodes + 1) * 4, 16) : 0;
+    a.off_rowstart = o; o += edge_mode ? align_up(((int)max_nodes + 1) * (W == 1 ? 2 : 4), 16) : 0;
     a.off_last = o; o += edge_mode ? align_up((int)max_edges * 4, 16) : 0;
     if (edge_mode && max_edges >= 65535) return set_error(GSN_E_UNSUPPORTED, "gsn_count_hip: %lld columns per workgroup (16-bit column tables; LDS ends far earlier)", (long long)max_edges);
     a.off_prim = o; o += edge_mode ? align_up((int)max_edges * 2, 16) : 0;
@@ -806,11 +826,13 @@ static int count_launch(const uint32_t *plan_host, const uint32_t *plan_dev, int
     if (a.stage_out) o += (int)stage_bytes;
     // class indices of the encoded rows: staged whenever one workgroup owns the whole graph and the indices fit a byte; else
     // every cell writes its floats itself
-    a.enc_stage = 0; a.off_encst = o;
+    a.enc_stage = 0; a.off_encst = o; a.enc_from_counts = 0;
     a.enc16 = enc16; a.enc16_stride = (int)enc16_stride; a.enc16_col0 = (int)enc16_col0;
     if (enc_out && a.split == 1 && enc_bytes && rows_cap_u * enc_width < (int64_t)1 << 24 && o + rows_cap_u * a.n_cols <= 150 * 1024) {
         a.enc_stage = 1;
-        o += align_up((int)(rows_cap_u * a.n_cols), 16);     // (16-byte aligned: with four columns a row's indices are read as one word)
+        static const bool bytes_forced = getenv("GSN_COUNT_ENC_BYTES") != nullptr;      // (A/B: keep the byte array beside staged counts)
+        if (a.stage_out && !bytes_forced) a.enc_from_counts = 1;      // the staged 16-bit counts hold what the class indices need: no second array
+        else o += align_up((int)(rows_cap_u * a.n_cols), 16);         // (16-byte aligned: with four columns a row's indices are read as one word)
     }
     if (o > 160 * 1024) return set_error(GSN_E_UNSUPPORTED, "graph too large for LDS (%d B needed)", o);
     if (enc16 && !a.enc_stage)
