@@ -18,9 +18,9 @@ class Codes:
     [R, sum(n_classes)].  Layers accept it for ``x``, ``identifiers`` and ``edge_features``; where all inputs of msg_fn's
     first Linear are Codes that Linear becomes a weight-row gather (gsn_code_stage_fwd_hip) and the dense one-hot
     matrix is never built; everywhere else the layer densifies it."""
-    __slots__ = ("codes", "n_classes", "clamp", "_dense", "_pack16", "__weakref__")
+    __slots__ = ("codes", "n_classes", "clamp", "check", "_dense", "_pack16", "__weakref__")
 
-    def __init__(self, codes, n_classes, clamp=False):
+    def __init__(self, codes, n_classes, clamp=False, check=None):
         codes = codes.unsqueeze(-1) if codes.dim() == 1 else codes
         _need_cuda(codes, "codes")
         self.codes = codes.to(torch.int64).contiguous()
@@ -28,6 +28,9 @@ class Codes:
         if len(self.n_classes) != self.codes.shape[1]:
             raise ValueError("Codes: %d columns but %d class counts" % (self.codes.shape[1], len(self.n_classes)))
         self.clamp = bool(clamp)      # values above the last class count as the last class (as gsn_one_hot_hip's clamp)
+        # read the out-of-range flag back after encoding / gathering these codes (a host synchronisation; IndexError as F.one_hot): None = the
+        # process-wide flags.CODE_STATUS_CHECK, False = never (what the dense one_hot_encoder does: an out-of-range code gives a zero block)
+        self.check = check
         self._pack16 = None           # (pack, first column) once gsn_amd.packs has encoded these codes into an exact fp16 row pack
         self._dense = None
 

@@ -14,9 +14,9 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import layers
+from . import flags, layers
 from .encoding import DiscreteEmbedding
-from .layers import (GSN_edge_sparse, GSN_edge_sparse_ogb, GSN_sparse, MPNN_edge_sparse, MPNN_edge_sparse_ogb, MPNN_sparse,
+from .layers import (Codes, GSN_edge_sparse, GSN_edge_sparse_ogb, GSN_sparse, MPNN_edge_sparse, MPNN_edge_sparse_ogb, MPNN_sparse,
                      add_by_graph, choose_activation, global_add_pool_sparse, global_mean_pool_sparse, mlp, run_linear_module)
 
 
@@ -35,6 +35,18 @@ def _register_partition(data, edge_index):
 
 
 _PARAMETER_FREE_ENCODERS = ("one_hot_encoder", "atom_one_hot_encoder", "bond_one_hot_encoder")
+
+
+def _codes_of(enc, t):
+    """``Codes`` standing for ``enc(t)`` when ``enc`` is a parameter-free one-hot encoder over integer codes on the GPU (the encoder's own
+    class counts, no clamp, no read-back of the out-of-range flag: exactly what its dense rows would hold), else None."""
+    if getattr(enc, "encoder_name", None) not in _PARAMETER_FREE_ENCODERS or not isinstance(t, torch.Tensor) or not t.is_cuda or t.is_floating_point():
+        return None
+    t = t.unsqueeze(-1) if t.dim() == 1 else t
+    dims = list(enc.encoder.d_in)
+    if t.dim() != 2 or t.shape[1] != len(dims):
+        return None
+    return Codes(t, dims, clamp=False, check=False)
 
 
 def _encode_once(memo, enc, x, training):
@@ -147,17 +159,32 @@ class GNNSubstructures(nn.Module):
         memo = {}
         edge_index = data.edge_index
         _register_partition(data, edge_index)
-        x = self.input_node_encoder(data.x)
+        # Eval forward over integer codes with one-hot encoders everywhere in front of layer 0 (BASELINE configs[1]'s model): layer 0 takes
+        # the CODES (layers.Codes) -- its inputs go straight into exact fp16 row packs (gsn_one_hot_pack16_hip) and the layer runs on
+        # csrc/layer_rp.hip; the dense one-hot rows of x and of the identifiers are never written (those of the edge features still are, for
+        # the layers behind).  Any layer that cannot use the codes densifies them itself: same rows as the encoders'.
+        codes0 = None
+        if (not self.training and flags.PACK16_LAYER and flags.FUSED_LAYER and not self.random_features and len(self.conv) > 0
+                and not self.final_projection[0]):
+            cx = _codes_of(self.input_node_encoder, data.x)
+            ci = _codes_of(self.id_encoder[0], getattr(data, "identifiers", None))
+            ce = _codes_of(self.edge_encoder[0], data.edge_features) if hasattr(data, "edge_features") else None
+            if cx is not None and ci is not None and (ce is not None or not hasattr(data, "edge_features")):
+                codes0 = (cx, ci, ce)
+        x = codes0[0] if codes0 is not None else self.input_node_encoder(data.x)
         if self.random_features:
             r = torch.rand(size=(x.shape[0], self.r_d_out), device=x.device).float()
             x = torch.cat((x, r), 1)
         x_interm = [x]
         for i in range(len(self.conv)):
-            kwargs["identifiers"] = _encode_once(memo, self.id_encoder[i] if self.inject_ids else self.id_encoder[0], data.identifiers, self.training)
-            if hasattr(data, "edge_features"):
-                kwargs["edge_features"] = _encode_once(memo, self.edge_encoder[i] if self.inject_edge_features else self.edge_encoder[0], data.edge_features, self.training)
+            if i == 0 and codes0 is not None:
+                kwargs["identifiers"], kwargs["edge_features"] = codes0[1], codes0[2]
             else:
-                kwargs["edge_features"] = None
+                kwargs["identifiers"] = _encode_once(memo, self.id_encoder[i] if self.inject_ids else self.id_encoder[0], data.identifiers, self.training)
+                if hasattr(data, "edge_features"):
+                    kwargs["edge_features"] = _encode_once(memo, self.edge_encoder[i] if self.inject_edge_features else self.edge_encoder[0], data.edge_features, self.training)
+                else:
+                    kwargs["edge_features"] = None
             # BatchNorm1d + activation of models_graph_classification.py:226-228 ride in the layer's last epilogue
             x = self.conv[i](x, edge_index, post_bn=self.batch_norms[i] if self.bn[i] else None,
                              post_act=self.activation_name, **kwargs)
@@ -170,6 +197,8 @@ class GNNSubstructures(nn.Module):
                 y = jk(x_global) if isinstance(jk, mlp) else run_linear_module(jk, x_global)
                 prediction = prediction + F.dropout(y, p=self.dropout_features[i], training=self.training)
         if return_intermediate:
+            if isinstance(x_interm[0], Codes):
+                x_interm[0] = x_interm[0].dense()           # (the encoder's rows, for whoever asks for them)
             return prediction, x_interm
         return prediction
 
