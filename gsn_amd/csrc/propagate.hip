@@ -10,6 +10,7 @@
 // LPR * VEC >= d_out where possible), 64/LPR vertices per wave, 4 waves per workgroup; lanes stride over the feature
 // dimension with float4 (VEC=4) accesses when every block width is a multiple of 4, scalar otherwise.
 #include <hip/hip_runtime.h>
+#include <cstdio>
 
 #include "gsn_internal.h"
 
@@ -385,6 +386,239 @@ __global__ __launch_bounds__(256) void propagate_fwd_kernel(PropArgs p) {
     }
 }
 
+// The ogb message  relu(x_j + id_e + e_e)  (GSN_edge_sparse_ogb.py:103-106: three d-wide streams per edge, float4 columns) with the index
+// chain taken out of the row loop: per target the kernel above walks seg_ptr -> perm / sorted_src -> rows as three dependent round trips and
+// only the last one carries data.  Here a lane group keeps a three-deep pipeline over its targets (grid stride): the segment bounds of the
+// target two steps ahead, the first four edges' indices of the next target and the rows of this one are requested back to back, and the rows
+// of UNR edges are in flight together.  Same order of additions as propagate_fwd_kernel (bit-identical result).
+template <int LPR, int MAXC, int UNR, bool NT, bool EXT>
+__global__ __launch_bounds__(256) void relu_sum3_kernel(PropArgs p) {
+    constexpr int RPW = 64 / LPR;
+    constexpr int NPF = 4;                       // edges per target whose indices are fetched ahead (longer segments: plain tail loop)
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / LPR, li = lane % LPR;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t step = n_waves * RPW, nn = p.n_nodes;
+    const int q4 = p.d_out >> 2;
+    const float4 *A = reinterpret_cast<const float4 *>(p.a), *B = reinterpret_cast<const float4 *>(p.b), *C = reinterpret_cast<const float4 *>(p.c);
+    auto ldseg = [&](int64_t tt, int32_t &lo, int32_t &hi) {
+        lo = hi = 0;
+        if (tt < nn) { lo = p.seg_ptr[tt]; hi = p.seg_ptr[tt + 1]; }
+    };
+    auto ldidx = [&](int32_t lo, int32_t hi, int32_t *e, int32_t *s) {
+#pragma unroll
+        for (int u = 0; u < NPF; ++u) {
+            const int32_t q = lo + u;
+            e[u] = 0; s[u] = 0;
+            if (q < hi) {
+                e[u] = p.perm ? p.perm[q] : q;
+                s[u] = p.sorted_src ? p.sorted_src[q] : (int32_t)p.src[e[u]];
+            }
+        }
+    };
+    auto row = [&](const float4 *base, int32_t r, int i) -> float4 { return base[(int64_t)r * q4 + (i * LPR + li)]; };
+    auto row_once = [&](const float4 *base, int32_t r, int i) -> float4 {
+        const float4 *ptr = base + (int64_t)r * q4 + (i * LPR + li);
+        return NT ? vload_once(ptr) : *ptr;
+    };
+    int64_t t = wave * RPW + sub;
+    int32_t lo0, hi0, lo1, hi1, e0[NPF], s0[NPF];
+    ldseg(t, lo0, hi0);
+    ldseg(t + step, lo1, hi1);
+    ldidx(lo0, hi0, e0, s0);
+    for (int64_t t0 = wave * RPW; t0 < nn; t0 += step, t += step) {
+        int32_t lo2, hi2, e1[NPF], s1[NPF];
+        ldseg(t + 2 * step, lo2, hi2);
+        ldidx(lo1, hi1, e1, s1);
+        float4 acc[MAXC];
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) vzero(acc[i]);
+        const int deg = hi0 - lo0;
+#pragma unroll
+        for (int u0 = 0; u0 < NPF; u0 += UNR) {
+            if (u0 < deg) {
+                float4 ra[UNR][MAXC], rb[UNR][MAXC], rc[UNR][MAXC];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u)
+#pragma unroll
+                    for (int i = 0; i < MAXC; ++i) {
+                        vzero(ra[u][i]); vzero(rb[u][i]); vzero(rc[u][i]);
+                        if (u0 + u < deg && (i * LPR + li) < q4) {
+                            ra[u][i] = row(A, s0[u0 + u], i);
+                            rb[u][i] = row_once(B, e0[u0 + u], i);
+                            rc[u][i] = row_once(C, e0[u0 + u], i);
+                        }
+                    }
+#pragma unroll
+                for (int u = 0; u < UNR; ++u)
+                    if (u0 + u < deg) {
+#pragma unroll
+                        for (int i = 0; i < MAXC; ++i) acc[i] = vadd(acc[i], vrelu(vadd(vadd(ra[u][i], rb[u][i]), rc[u][i])));
+                    }
+            }
+        }
+        for (int32_t q = lo0 + NPF; q < hi0; ++q) {
+            const int32_t e = p.perm ? p.perm[q] : q;
+            const int32_t s = p.sorted_src ? p.sorted_src[q] : (int32_t)p.src[e];
+#pragma unroll
+            for (int i = 0; i < MAXC; ++i)
+                if ((i * LPR + li) < q4) acc[i] = vadd(acc[i], vrelu(vadd(vadd(row(A, s, i), row_once(B, e, i)), row_once(C, e, i))));
+        }
+        if (t < nn) {
+            if (EXT && p.n_self) {
+                const float sc = 1.f + (p.eps ? *p.eps : 0.f);
+#pragma unroll
+                for (int i = 0; i < MAXC; ++i) {
+                    const int col = (i * LPR + li) * 4;
+                    if (col < p.d_out) {
+                        float4 sv;
+                        vzero(sv);
+#pragma unroll
+                        for (int k = 0; k < 3; ++k)
+                            if (k < p.n_self) sv = vadd(sv, *reinterpret_cast<const float4 *>(p.self_data[k] + t * p.self_stride[k] + col));
+                        acc[i] = vfma(sc, sv, acc[i]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < MAXC; ++i) {
+                const int col = (i * LPR + li) * 4;
+                if (col < p.d_out) vstore_once(reinterpret_cast<float4 *>(p.out + t * p.d_out + col), acc[i]);
+            }
+        }
+        lo0 = lo1; hi0 = hi1; lo1 = lo2; hi1 = hi2;
+#pragma unroll
+        for (int u = 0; u < NPF; ++u) { e0[u] = e1[u]; s0[u] = s1[u]; }
+    }
+}
+
+// The same pipeline for a concatenation of float4-aligned blocks without zero columns (the gin messages, the scatter-add of per-edge message
+// rows, the readouts): a | b | c, b per edge or per source vertex.  Segments longer than the four prefetched edges (a readout's ~23 rows per
+// graph) continue four rows at a time, their indices and rows in flight together, added in segment order (bit-identical to the plain loop).
+template <int LPR, int MAXC, int UNR, bool EXT>
+__global__ __launch_bounds__(256) void cat_pipe_kernel(PropArgs p) {
+    constexpr int RPW = 64 / LPR;
+    constexpr int NPF = 4;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / LPR, li = lane % LPR;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t step = n_waves * RPW, nn = p.n_nodes;
+    auto ldseg = [&](int64_t tt, int32_t &lo, int32_t &hi) {
+        lo = hi = 0;
+        if (tt < nn) { lo = p.seg_ptr[tt]; hi = p.seg_ptr[tt + 1]; }
+    };
+    auto ldidx = [&](int32_t lo, int32_t hi, int32_t *e, int32_t *s) {
+#pragma unroll
+        for (int u = 0; u < NPF; ++u) {
+            const int32_t q = lo + u;
+            e[u] = 0; s[u] = 0;
+            if (q < hi) {
+                e[u] = p.perm ? p.perm[q] : q;
+                s[u] = p.sorted_src ? p.sorted_src[q] : (int32_t)p.src[e[u]];
+            }
+        }
+    };
+    // this lane's chunk i of the message of edge e (source vertex s); every block boundary is a multiple of four floats
+    auto msg = [&](int32_t e, int32_t s, int i) -> float4 {
+        const int col = (i * LPR + li) * 4;
+        int o = col - p.da;
+        if (o < 0) return *reinterpret_cast<const float4 *>(p.a + (int64_t)s * p.da + col);
+        if (o < p.db)
+            return p.b_per_node ? *reinterpret_cast<const float4 *>(p.b + (int64_t)s * p.ldb + o)
+                                : vload_once(reinterpret_cast<const float4 *>(p.b + (int64_t)e * p.ldb + o));
+        return vload_once(reinterpret_cast<const float4 *>(p.c + (int64_t)e * p.dc + (o - p.db)));
+    };
+    int64_t t = wave * RPW + sub;
+    int32_t lo0, hi0, lo1, hi1, e0[NPF], s0[NPF];
+    ldseg(t, lo0, hi0);
+    ldseg(t + step, lo1, hi1);
+    ldidx(lo0, hi0, e0, s0);
+    for (int64_t t0 = wave * RPW; t0 < nn; t0 += step, t += step) {
+        int32_t lo2, hi2, e1[NPF], s1[NPF];
+        ldseg(t + 2 * step, lo2, hi2);
+        ldidx(lo1, hi1, e1, s1);
+        float4 acc[MAXC];
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) vzero(acc[i]);
+        const int deg = hi0 - lo0;
+#pragma unroll
+        for (int u0 = 0; u0 < NPF; u0 += UNR) {
+            if (u0 < deg) {
+                float4 m[UNR][MAXC];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u)
+#pragma unroll
+                    for (int i = 0; i < MAXC; ++i) {
+                        vzero(m[u][i]);
+                        if (u0 + u < deg && (i * LPR + li) * 4 < p.d_out) m[u][i] = msg(e0[u0 + u], s0[u0 + u], i);
+                    }
+#pragma unroll
+                for (int u = 0; u < UNR; ++u)
+                    if (u0 + u < deg) {
+#pragma unroll
+                        for (int i = 0; i < MAXC; ++i) acc[i] = vadd(acc[i], m[u][i]);
+                    }
+            }
+        }
+        for (int32_t q = lo0 + NPF; q < hi0; q += 4) {
+            int32_t e[4], sv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                e[u] = 0; sv[u] = 0;
+                if (q + u < hi0) {
+                    e[u] = p.perm ? p.perm[q + u] : q + u;
+                    sv[u] = p.sorted_src ? p.sorted_src[q + u] : (int32_t)p.src[e[u]];
+                }
+            }
+            float4 m[4][MAXC];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < MAXC; ++i) {
+                    vzero(m[u][i]);
+                    if (q + u < hi0 && (i * LPR + li) * 4 < p.d_out) m[u][i] = msg(e[u], sv[u], i);
+                }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (q + u < hi0) {
+#pragma unroll
+                    for (int i = 0; i < MAXC; ++i) acc[i] = vadd(acc[i], m[u][i]);
+                }
+        }
+        if (t < nn) {
+            if (EXT && p.n_self) {
+                const float sc = 1.f + (p.eps ? *p.eps : 0.f);
+#pragma unroll
+                for (int i = 0; i < MAXC; ++i) {
+                    const int col = (i * LPR + li) * 4;
+                    if (col < p.d_out) {
+                        float4 sv;
+                        vzero(sv);
+                        int o = col;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k)
+                            if (k < p.n_self) {
+                                if (o >= 0 && o < p.self_w[k]) sv = *reinterpret_cast<const float4 *>(p.self_data[k] + t * p.self_stride[k] + o);
+                                o -= p.self_w[k];
+                            }
+                        acc[i] = vfma(sc, sv, acc[i]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < MAXC; ++i) {
+                const int col = (i * LPR + li) * 4;
+                if (col < p.d_out) vstore_once(reinterpret_cast<float4 *>(p.out + t * p.d_out + col), acc[i]);
+            }
+        }
+        lo0 = lo1; hi0 = hi1; lo1 = lo2; hi1 = hi2;
+#pragma unroll
+        for (int u = 0; u < NPF; ++u) { e0[u] = e1[u]; s0[u] = s1[u]; }
+    }
+}
+
 // ----------------------------------------------------------------------------------------------------------------
 // backward
 // ----------------------------------------------------------------------------------------------------------------
@@ -482,6 +716,58 @@ __global__ __launch_bounds__(256) void propagate_bwd_edge_relu4_kernel(PropBwdAr
     }
 }
 
+// the same with every column chunk of the edge's rows in flight together (d <= 320: five chunks of 16 float4) and the indices of the group's
+// next edge requested before this edge's rows (the kernel above: index -> rows as two dependent round trips per edge, one chunk at a time)
+__global__ __launch_bounds__(256) void propagate_bwd_edge_relu4p_kernel(PropBwdArgs p) {
+    const int lane = threadIdx.x & 63, sub = lane >> 4, li = lane & 15;
+    const int q = p.d_out >> 2;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t stride = (((int64_t)gridDim.x * blockDim.x) >> 6) * 4;
+    int64_t e = wave * 4 + sub;
+    int64_t t = 0, s = 0;
+    if (e < p.n_edges) { t = p.tgt[e]; s = p.src[e]; }
+    for (int64_t e0 = wave * 4; e0 < p.n_edges; e0 += stride, e += stride) {
+        int64_t tn = 0, sn = 0;
+        if (e + stride < p.n_edges) { tn = p.tgt[e + stride]; sn = p.src[e + stride]; }
+        if (e < p.n_edges) {
+            const float4 *go = reinterpret_cast<const float4 *>(p.g_out + t * p.d_out);
+            const float4 *pa = p.a ? reinterpret_cast<const float4 *>(p.a + s * p.d_out) : nullptr;
+            const float4 *pb = p.b ? reinterpret_cast<const float4 *>(p.b + (p.b_per_node ? s : e) * p.d_out) : nullptr;
+            const float4 *pc = p.c ? reinterpret_cast<const float4 *>(p.c + e * p.d_out) : nullptr;
+            float4 *gb = (!p.b_per_node && p.g_b) ? reinterpret_cast<float4 *>(p.g_b + e * p.d_out) : nullptr;
+            float4 *gc = p.g_c ? reinterpret_cast<float4 *>(p.g_c + e * p.d_out) : nullptr;
+            float4 g[5], va[5], vb[5], vc[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const int c4 = li + 16 * k;
+                vzero(g[k]); vzero(va[k]); vzero(vb[k]); vzero(vc[k]);
+                if (c4 < q) {
+                    g[k] = go[c4];
+                    if (pa) va[k] = pa[c4];
+                    if (pb) vb[k] = p.b_per_node ? pb[c4] : vload_once(pb + c4);
+                    if (pc) vc[k] = vload_once(pc + c4);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const int c4 = li + 16 * k;
+                if (c4 < q) {
+                    // (0 + a) + b + c: the forward kernel's order of additions -- the mask must be the forward's mask
+                    float4 pre = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (pa) pre = vadd(pre, va[k]);
+                    if (pb) pre = vadd(pre, vb[k]);
+                    if (pc) pre = vadd(pre, vc[k]);
+                    float4 m = g[k];
+                    m.x = pre.x > 0.f ? m.x : 0.f; m.y = pre.y > 0.f ? m.y : 0.f; m.z = pre.z > 0.f ? m.z : 0.f; m.w = pre.w > 0.f ? m.w : 0.f;
+                    if (gb) gb[c4] = m;
+                    if (gc) gc[c4] = m;
+                }
+            }
+        }
+        t = tn; s = sn;
+    }
+}
+
 // per-node gradients through the source-sorted CSR: g_a[s] (and g_b[s] if per node) = sum over edges leaving s
 __global__ __launch_bounds__(256) void propagate_bwd_node_kernel(PropBwdArgs p) {
     const int lane = threadIdx.x & 63;
@@ -553,6 +839,77 @@ __global__ __launch_bounds__(256) void propagate_bwd_node_edge4_kernel(PropBwdAr
                 }
             }
         }
+    }
+}
+
+// the same with the segment bounds of the group's next vertex and its first four edge ids requested before this vertex's rows, and the rows of two
+// edges in flight together (d <= 320); same order of additions
+__global__ __launch_bounds__(256) void propagate_bwd_node_edge4p_kernel(PropBwdArgs p) {
+    const int lane = threadIdx.x & 63, sub = lane >> 4, li = lane & 15;
+    const int q = p.d_out >> 2;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t stride = (((int64_t)gridDim.x * blockDim.x) >> 6) * 4, nn = p.n_nodes;
+    auto ldseg = [&](int64_t v, int32_t &lo, int32_t &hi) {
+        lo = hi = 0;
+        if (v < nn) { lo = p.seg_ptr_src[v]; hi = p.seg_ptr_src[v + 1]; }
+    };
+    auto ldidx = [&](int32_t lo, int32_t hi, int32_t *e) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { e[u] = 0; if (lo + u < hi) e[u] = p.perm_src[lo + u]; }
+    };
+    int64_t s = wave * 4 + sub;
+    int32_t lo0, hi0, lo1, hi1, e0[4];
+    ldseg(s, lo0, hi0);
+    ldseg(s + stride, lo1, hi1);
+    ldidx(lo0, hi0, e0);
+    for (int64_t s0 = wave * 4; s0 < nn; s0 += stride, s += stride) {
+        int32_t lo2, hi2, e1[4];
+        ldseg(s + 2 * stride, lo2, hi2);
+        ldidx(lo1, hi1, e1);
+        float4 acc[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) vzero(acc[k]);
+        const int deg = hi0 - lo0;
+#pragma unroll
+        for (int u0 = 0; u0 < 4; u0 += 2) {
+            if (u0 < deg) {
+                float4 r[2][5];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const float4 *row = reinterpret_cast<const float4 *>(p.g_edge + (int64_t)e0[u0 + u] * p.d_out);
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) {
+                        vzero(r[u][k]);
+                        if (u0 + u < deg && li + 16 * k < q) r[u][k] = row[li + 16 * k];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    if (u0 + u < deg) {
+#pragma unroll
+                        for (int k = 0; k < 5; ++k) acc[k] = vadd(acc[k], r[u][k]);
+                    }
+            }
+        }
+        for (int32_t qq = lo0 + 4; qq < hi0; ++qq) {
+            const float4 *row = reinterpret_cast<const float4 *>(p.g_edge + (int64_t)p.perm_src[qq] * p.d_out);
+#pragma unroll
+            for (int k = 0; k < 5; ++k)
+                if (li + 16 * k < q) acc[k] = vadd(acc[k], row[li + 16 * k]);
+        }
+        if (s < nn) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const int c4 = li + 16 * k;
+                if (c4 < q) {
+                    if (p.g_a) reinterpret_cast<float4 *>(p.g_a + s * p.d_out)[c4] = acc[k];
+                    if (p.b_per_node && p.g_b) reinterpret_cast<float4 *>(p.g_b + s * p.d_out)[c4] = acc[k];
+                }
+            }
+        }
+        lo0 = lo1; hi0 = hi1; lo1 = lo2; hi1 = hi2;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) e0[u] = e1[u];
     }
 }
 
@@ -704,6 +1061,76 @@ static int launch_fwd(const PropArgs &p, hipStream_t st) {
     else if (blocks <= 128) hipLaunchKernelGGL((propagate_fwd_kernel<VEC, LPR, MAXC, false, true>), dim3((unsigned)blocks), dim3(256), 0, st, p);
     else hipLaunchKernelGGL((propagate_fwd_kernel<VEC, LPR, MAXC, false>), dim3((unsigned)blocks), dim3(256), 0, st, p);
     return hip_check("propagate_fwd_kernel");
+}
+
+template <int LPR, int MAXC, int UNR, bool NT>
+static int launch_rs3(const PropArgs &p, hipStream_t st, int64_t cap) {
+    constexpr int RPW = 64 / LPR;
+    const int64_t waves_needed = (p.n_nodes + RPW - 1) / RPW;
+    int64_t blocks = (waves_needed + 3) / 4;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    if (p.n_self) hipLaunchKernelGGL((relu_sum3_kernel<LPR, MAXC, UNR, NT, true>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((relu_sum3_kernel<LPR, MAXC, UNR, NT, false>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+    return hip_check("relu_sum3_kernel");
+}
+
+template <int LPR, int MAXC, int UNR>
+static int launch_cp(const PropArgs &p, hipStream_t st, int64_t cap) {
+    constexpr int RPW = 64 / LPR;
+    const int64_t waves_needed = (p.n_nodes + RPW - 1) / RPW;
+    int64_t blocks = (waves_needed + 3) / 4;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    if (p.n_self) hipLaunchKernelGGL((cat_pipe_kernel<LPR, MAXC, UNR, true>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((cat_pipe_kernel<LPR, MAXC, UNR, false>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+    return hip_check("cat_pipe_kernel");
+}
+
+// Where cat_pipe_kernel is taken (A/B on one box, 65 536 ZINC-shaped graphs, scripts/gpu/prop_cp.py, plain kernel -> pipelined): long segments
+// (the readouts: every row of a graph is one "edge") d = 300 over 4 096 graphs 74.5 -> 44.9 us with 64 lanes x 2 chunks and four rows in flight,
+// d = 128 over 65 536 graphs 176.8 -> 161.3 us (32 lanes, four rows); the gin aggregation of x_j alone, d = 128: 0.4005 -> 0.3819 ms (32 lanes, two
+// edges).  NOT taken where it measured no better: the scatter-add of 128-wide per-edge rows (0.450 plain, 0.448-0.494 pipelined), the 112-wide and
+// 104-wide gin concatenations (0.479 -> 0.470 at best, 0.384 -> 0.400).  GSN_PROP_CP = "lpr,unr[,blocks]" forces a mapping ("0": the plain
+// kernel everywhere); -1 = not taken
+static int launch_cat_pipe(const PropArgs &p, hipStream_t st) {
+    const int q = p.d_out / 4;
+    const bool long_segments = p.n_edges >= 8 * p.n_nodes;
+    int l = 0, u = 4, b = 256 * 8 * 4;
+    if (long_segments) l = q <= 8 ? 8 : q <= 16 ? 16 : q <= 32 ? 32 : 64;
+    else if (p.da && !p.db && !p.dc && q > 16 && q <= 32) { l = 32; u = 2; }
+    if (l && (q + l - 1) / l > 2) u = 2;
+    if (const char *e = getenv("GSN_PROP_CP")) sscanf(e, "%d,%d,%d", &l, &u, &b);
+    if (l == 0) return -1;
+    const int m = (q + l - 1) / l;
+    const int64_t cap = b;
+#define CP(L, M) do { if (u == 1) return launch_cp<L, M, 1>(p, st, cap); if (u == 4 && M <= 2) return launch_cp<L, M, (M <= 2 ? 4 : 2)>(p, st, cap); return launch_cp<L, M, 2>(p, st, cap); } while (0)
+    if (l == 8) { if (m <= 1) CP(8, 1); if (m <= 2) CP(8, 2); if (m <= 4) CP(8, 4); }
+    if (l == 16) { if (m <= 1) CP(16, 1); if (m <= 2) CP(16, 2); if (m <= 4) CP(16, 4); if (m <= 5) CP(16, 5); }
+    if (l == 32) { if (m <= 1) CP(32, 1); if (m <= 2) CP(32, 2); if (m <= 3) CP(32, 3); }
+    if (l == 64) { if (m <= 1) CP(64, 1); if (m <= 2) CP(64, 2); if (m <= 4) CP(64, 4); }
+#undef CP
+    return -1;
+}
+
+// Mapping of relu_sum3_kernel by row width (A/B on one box, 65 536 ZINC-shaped graphs, d = 300, scripts/gpu/prop_rs.py; generic kernel 2.405 ms plain /
+// 2.766 ms with the self term):  16 lanes x 5 chunks, 2 edges' rows in flight 2.010 / 2.082;  16 x 5, 1 edge 2.073 / 2.028;  32 x 3, 4 edges 2.075 / 2.250;
+// 32 x 3, 2 edges 2.117 / 2.052;  64 x 2 2.14-2.25;  nontemporal per-edge loads +4 %;  fewer workgroups +1..4 %.  All variants: the same bits.
+// GSN_PROP_RS = "lpr,unr,nt[,blocks]" forces one ("0": the generic kernel); -1 = not taken
+static int launch_relu_sum3(const PropArgs &p, hipStream_t st) {
+    const int q = p.d_out / 4;
+    int l = q <= 80 ? 16 : 32, u = 0, n = 0, b = 256 * 8 * 4;
+    if (const char *e = getenv("GSN_PROP_RS")) sscanf(e, "%d,%d,%d,%d", &l, &u, &n, &b);
+    if (l == 0) return -1;
+    if (u == 0) u = l == 16 ? (p.n_self ? 1 : 2) : (p.n_self ? 2 : 4);
+    const bool nt = n != 0;
+    const int64_t cap = b;
+#define RS3(L, M, U) return nt ? launch_rs3<L, M, U, true>(p, st, cap) : launch_rs3<L, M, U, false>(p, st, cap)
+    if (l == 32 && q <= 96) { if (u == 1) RS3(32, 3, 1); if (u == 2) RS3(32, 3, 2); if (u == 4) RS3(32, 3, 4); }
+    if (l == 16 && q <= 80) { if (u == 1) RS3(16, 5, 1); if (u == 2) RS3(16, 5, 2); }
+    if (l == 64 && q <= 128) { if (u == 1) RS3(64, 2, 1); if (u == 2) RS3(64, 2, 2); if (u == 4) RS3(64, 2, 4); }
+#undef RS3
+    return -1;
 }
 
 
@@ -1044,6 +1471,14 @@ static int propagate_fwd_impl(int kind, int64_t n_nodes, int64_t n_edges, const 
         hipLaunchKernelGGL(segment_sum_wg_kernel, dim3((unsigned)n_nodes), dim3(256), 0, st, p);
         return hip_check("segment_sum_wg_kernel");
     }
+    if (aligned && kind == GSN_MSG_RELU_SUM && p.a && p.b && p.c && !b_per_node && d_out >= 132 && d_out <= 384) {
+        const int rc3 = launch_relu_sum3(p, st);
+        if (rc3 != -1) return rc3;
+    }
+    if (aligned && kind == GSN_MSG_CAT) {
+        const int rcp = launch_cat_pipe(p, st);
+        if (rcp != -1) return rcp;
+    }
     if (aligned) {
         const int64_t q = d_out / 4;  // float4 per row
         if (q <= 8) return launch_fwd<4, 8, 1>(p, st);
@@ -1115,7 +1550,9 @@ extern "C" int gsn_propagate_pad_bwd_hip(int kind, int64_t n_nodes, int64_t n_ed
         if (vec4 || cat4) {
             int64_t blocks = (n_edges + 15) / 16;
             if (blocks > 16384) blocks = 16384;
-            if (vec4) hipLaunchKernelGGL(propagate_bwd_edge_relu4_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
+            static const bool pipe = [] { const char *e = getenv("GSN_PROP_BWD_PIPE"); return !e || atoi(e) != 0; }();
+            if (vec4 && pipe && d_out <= 320) hipLaunchKernelGGL(propagate_bwd_edge_relu4p_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
+            else if (vec4) hipLaunchKernelGGL(propagate_bwd_edge_relu4_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
             else hipLaunchKernelGGL(propagate_bwd_edge_cat4_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
         } else {
             int64_t blocks = (n_edges * d_out + 255) / 256;
@@ -1132,7 +1569,9 @@ extern "C" int gsn_propagate_pad_bwd_hip(int kind, int64_t n_nodes, int64_t n_ed
         if (edge4) {
             int64_t blocks = (n_nodes + 15) / 16;
             if (blocks > 16384) blocks = 16384;
-            hipLaunchKernelGGL(propagate_bwd_node_edge4_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
+            static const bool pipe = [] { const char *e = getenv("GSN_PROP_BWD_PIPE"); return !e || atoi(e) != 0; }();
+            if (pipe && d_out <= 320) hipLaunchKernelGGL(propagate_bwd_node_edge4p_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
+            else hipLaunchKernelGGL(propagate_bwd_node_edge4_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
         } else {
             int64_t blocks = (n_nodes + 3) / 4;
             if (blocks > 16384) blocks = 16384;
