@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256) void propagate_fwd_kernel(PropArgs p) {
 // only the last one carries data.  Here a lane group keeps a three-deep pipeline over its targets (grid stride): the segment bounds of the
 // target two steps ahead, the first four edges' indices of the next target and the rows of this one are requested back to back, and the rows
 // of UNR edges are in flight together.  Same order of additions as propagate_fwd_kernel (bit-identical result).
-template <int LPR, int MAXC, int UNR, bool NT, bool EXT>
+template <int LPR, int MAXC, int UNR, bool NT, bool EXT, bool HASC = true>
 __global__ __launch_bounds__(256) void relu_sum3_kernel(PropArgs p) {
     constexpr int RPW = 64 / LPR;
     constexpr int NPF = 4;                       // edges per target whose indices are fetched ahead (longer segments: plain tail loop)
@@ -438,23 +438,28 @@ __global__ __launch_bounds__(256) void relu_sum3_kernel(PropArgs p) {
 #pragma unroll
         for (int u0 = 0; u0 < NPF; u0 += UNR) {
             if (u0 < deg) {
-                float4 ra[UNR][MAXC], rb[UNR][MAXC], rc[UNR][MAXC];
+                float4 ra[UNR][MAXC], rb[UNR][MAXC], rc[UNR][HASC ? MAXC : 1];
 #pragma unroll
                 for (int u = 0; u < UNR; ++u)
 #pragma unroll
                     for (int i = 0; i < MAXC; ++i) {
-                        vzero(ra[u][i]); vzero(rb[u][i]); vzero(rc[u][i]);
+                        vzero(ra[u][i]); vzero(rb[u][i]);
+                        if (HASC) vzero(rc[u][HASC ? i : 0]);
                         if (u0 + u < deg && (i * LPR + li) < q4) {
                             ra[u][i] = row(A, s0[u0 + u], i);
                             rb[u][i] = row_once(B, e0[u0 + u], i);
-                            rc[u][i] = row_once(C, e0[u0 + u], i);
+                            if (HASC) rc[u][HASC ? i : 0] = row_once(C, e0[u0 + u], i);
                         }
                     }
 #pragma unroll
                 for (int u = 0; u < UNR; ++u)
                     if (u0 + u < deg) {
 #pragma unroll
-                        for (int i = 0; i < MAXC; ++i) acc[i] = vadd(acc[i], vrelu(vadd(vadd(ra[u][i], rb[u][i]), rc[u][i])));
+                        for (int i = 0; i < MAXC; ++i) {
+                            float4 m = vadd(ra[u][i], rb[u][i]);
+                            if (HASC) m = vadd(m, rc[u][HASC ? i : 0]);
+                            acc[i] = vadd(acc[i], vrelu(m));
+                        }
                     }
             }
         }
@@ -463,7 +468,11 @@ __global__ __launch_bounds__(256) void relu_sum3_kernel(PropArgs p) {
             const int32_t s = p.sorted_src ? p.sorted_src[q] : (int32_t)p.src[e];
 #pragma unroll
             for (int i = 0; i < MAXC; ++i)
-                if ((i * LPR + li) < q4) acc[i] = vadd(acc[i], vrelu(vadd(vadd(row(A, s, i), row_once(B, e, i)), row_once(C, e, i))));
+                if ((i * LPR + li) < q4) {
+                    float4 m = vadd(row(A, s, i), row_once(B, e, i));
+                    if (HASC) m = vadd(m, row_once(C, e, i));
+                    acc[i] = vadd(acc[i], vrelu(m));
+                }
         }
         if (t < nn) {
             if (EXT && p.n_self) {
@@ -1070,7 +1079,10 @@ static int launch_rs3(const PropArgs &p, hipStream_t st, int64_t cap) {
     int64_t blocks = (waves_needed + 3) / 4;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    if (p.n_self) hipLaunchKernelGGL((relu_sum3_kernel<LPR, MAXC, UNR, NT, true>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+    if (!p.c) {        // two streams: relu(x_j + e_e), or the identifier and edge-feature embeddings summed by their encoder (models.GNN_OGB)
+        if (p.n_self) hipLaunchKernelGGL((relu_sum3_kernel<LPR, MAXC, UNR, NT, true, false>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((relu_sum3_kernel<LPR, MAXC, UNR, NT, false, false>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+    } else if (p.n_self) hipLaunchKernelGGL((relu_sum3_kernel<LPR, MAXC, UNR, NT, true>), dim3((unsigned)blocks), dim3(256), 0, st, p);
     else hipLaunchKernelGGL((relu_sum3_kernel<LPR, MAXC, UNR, NT, false>), dim3((unsigned)blocks), dim3(256), 0, st, p);
     return hip_check("relu_sum3_kernel");
 }
@@ -1471,7 +1483,8 @@ static int propagate_fwd_impl(int kind, int64_t n_nodes, int64_t n_edges, const 
         hipLaunchKernelGGL(segment_sum_wg_kernel, dim3((unsigned)n_nodes), dim3(256), 0, st, p);
         return hip_check("segment_sum_wg_kernel");
     }
-    if (aligned && kind == GSN_MSG_RELU_SUM && p.a && p.b && p.c && !b_per_node && d_out >= 132 && d_out <= 384) {
+    if (aligned && kind == GSN_MSG_RELU_SUM && p.a && (p.b || p.c) && !b_per_node && d_out >= 132 && d_out <= 384) {
+        if (!p.b) { p.b = p.c; p.c = nullptr; }        // (one per-edge stream: it is the kernel's block b)
         const int rc3 = launch_relu_sum3(p, st);
         if (rc3 != -1) return rc3;
     }

@@ -297,7 +297,8 @@ class _EmbedFn(torch.autograd.Function):
         from .layers import _zeros
         status = _zeros(1, torch.int32, dev)
         rows = np.ascontiguousarray([t.shape[0] for t in tabs], dtype=np.int64)
-        with _abi.device_guard(dev):
+        from ._runtime import _timed
+        with _abi.device_guard(dev), _timed("embed_fwd", 8.0 * M * C + 4.0 * out.numel()):
             rc = _abi.lib().gsn_embed_fwd_hip(M, C, d, int(concat), codes.data_ptr() if M else None, meta.data_ptr(),
                                               _abi.ptr(rows), out.data_ptr() if M else None, status.data_ptr(),
                                               _abi.current_stream())

@@ -62,4 +62,10 @@ GATHER_CAT_TRAIN = os.environ.get("GSN_GATHER_CAT_TRAIN", "0") == "1"    # 1: tr
 
 FOLD_KERNEL = os.environ.get("GSN_FOLD_KERNEL", "1") != "0"      # A/B switch: the fold as tensor ops over the dense stages (~18 launches per layer and step)
 
+# GNN_OGB with the GSN_edge_sparse_ogb layers (msg = relu(x_j + id_e + e_e)): when the identifier encoder and the edge-feature encoder of a layer
+# are both sums of embedding rows (multi_embedding 'sum', BondEncoder) of one width, ONE launch sums the rows of both encoders' tables
+# (encoding.embed_columns over the concatenated code columns) and the layer reads one per-edge stream instead of two; one adjoint launch hands
+# every table its gradient.  The sum is associated as ((id_0 + ..) + e_0 + ..) instead of (id) + (e): a reassociation of fp32 additions.
+FUSE_EDGE_ENCODERS = os.environ.get("GSN_FUSE_EDGE_ENCODERS", "1") != "0"
+
 CODE_STATUS_CHECK = True   # read the out-of-range flag back after every code-gather launch (one host sync)

@@ -267,7 +267,12 @@ class _SparseLayer(nn.Module):
         ef = None
         if self.has_ef:
             ef = kwargs["edge_features"]
-            ef = ef.unsqueeze(-1) if ef.dim() == 1 else ef
+            if ef is None and not (self.ogb and identifiers is not None):
+                raise RuntimeError("%s: edge_features missing" % type(self).__name__)
+            # (None on an ogb layer with identifiers: the caller has added the edge-feature embedding into the identifier embedding,
+            #  models._fused_edge_encoding -- relu(x_j + id_e + e_e) with the last two terms as one stream)
+            if ef is not None:
+                ef = ef.unsqueeze(-1) if ef.dim() == 1 else ef
         return x, identifiers, ef
 
     def forward(self, x, edge_index, **kwargs):

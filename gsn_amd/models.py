@@ -67,6 +67,45 @@ def _encode_once(memo, enc, x, training):
     return hit
 
 
+def _sum_tables(enc):
+    """The embedding tables of an encoder that is a plain sum of one table row per code column (multi_embedding with aggr 'sum', the ogb
+    Atom / Bond encoders), else None."""
+    name = getattr(enc, "encoder_name", None)
+    e = getattr(enc, "encoder", None)
+    if name == "embedding" and getattr(e, "aggr", None) == "sum":
+        return [m.weight for m in e.encoder]
+    if name in ("atom_encoder", "bond_encoder"):
+        return [m.weight for m in getattr(e, e._list_name)]
+    return None
+
+
+def _integer_codes(t):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda or t.is_floating_point() or t.dim() not in (1, 2):
+        return None
+    return t.unsqueeze(-1) if t.dim() == 1 else t
+
+
+def _fused_edge_encoding(memo, id_enc, ef_enc, identifiers, edge_features):
+    """``id_enc(identifiers) + ef_enc(edge_features)`` in ONE launch when both encoders are sums of table rows of one width over integer codes
+    with one row per edge (flags.FUSE_EDGE_ENCODERS); None when they are not."""
+    if not flags.FUSE_EDGE_ENCODERS:
+        return None
+    ti, te = _sum_tables(id_enc), _sum_tables(ef_enc)
+    ci, ce = _integer_codes(identifiers), _integer_codes(edge_features)
+    if ti is None or te is None or ci is None or ce is None:
+        return None
+    if ci.shape[0] != ce.shape[0] or ci.shape[1] != len(ti) or ce.shape[1] != len(te) or len(ti) + len(te) > 16:
+        return None
+    if ti[0].shape[1] != te[0].shape[1] or ti[0].device != ci.device:
+        return None
+    key = ("edge codes", id(identifiers), id(edge_features))
+    codes = memo.get(key)
+    if codes is None:            # (the concatenated code columns: once per forward, every layer's encoders read them)
+        codes = memo[key] = torch.cat([ci.to(torch.int64), ce.to(torch.int64)], 1).contiguous()
+    from .encoding import embed_columns
+    return embed_columns(codes, ti + te, False)
+
+
 class GNNSubstructures(nn.Module):
     def __init__(self, in_features, out_features, encoder_ids, d_in_id, in_edge_features=None, d_in_node_encoder=None,
                  d_in_edge_encoder=None, encoder_degrees=None, d_degree=None, **kwargs):
@@ -307,8 +346,16 @@ class GNN_OGB(nn.Module):
         x_interm = [x]
         n_layers = len(self.conv)
         for i in range(n_layers):
-            kwargs["identifiers"] = _encode_once(memo, self.id_encoder[i] if self.inject_ids else self.id_encoder[0], data.identifiers, self.training)
-            kwargs["edge_features"] = _encode_once(memo, self.edge_encoder[i], data.edge_features, self.training) if hasattr(data, "edge_features") else None
+            id_enc = self.id_encoder[i] if self.inject_ids else self.id_encoder[0]
+            fused = None
+            if isinstance(self.conv[i], GSN_edge_sparse_ogb) and self.conv[i].id_scope == "local" and hasattr(data, "edge_features"):
+                fused = _fused_edge_encoding(memo, id_enc, self.edge_encoder[i], data.identifiers, data.edge_features)
+            if fused is not None:
+                # relu(x_j + (id_e + e_e)): the two encoders' rows summed by one launch, one per-edge stream into the layer
+                kwargs["identifiers"], kwargs["edge_features"] = fused, None
+            else:
+                kwargs["identifiers"] = _encode_once(memo, id_enc, data.identifiers, self.training)
+                kwargs["edge_features"] = _encode_once(memo, self.edge_encoder[i], data.edge_features, self.training) if hasattr(data, "edge_features") else None
             if self.vn:
                 x_interm[i] = add_by_graph(x_interm[i], vn_embedding, data.batch)
             last = i == n_layers - 1
