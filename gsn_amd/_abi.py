@@ -72,6 +72,8 @@ SIGNATURES = {
     "gsn_linear_f16x3_prepare_strided_hip": (c_int, [c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp]),
     "gsn_linear_fwd_strided_hip": (c_int, [c_i64, c_int, ctypes.POINTER(gsn_block), c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_int,
                                            c_vp, c_vp, c_vp]),
+    "gsn_linear_splitk_plan": (c_int, [c_i64, c_i64, c_i64]),
+    "gsn_linear_fwd_splitk_hip": (c_int, [c_i64, c_int, ctypes.POINTER(gsn_block), c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp]),
     "gsn_linear_f16x3_fwd_hip": (c_int, [c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),
     "gsn_linear_f16x3_fwd_stats_hip": (c_int, [c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "gsn_edge_split_sum_hip": (c_int, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_vp]),

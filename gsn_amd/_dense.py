@@ -93,6 +93,18 @@ def _linear_hip(blocks, weight, bias, bn_mean, bn_scale, bn_shift, act, m_rows, 
                                                          y.data_ptr(), _abi.current_stream())
         _abi.check(rc, "gsn_linear_f16x3_fwd_stats_hip" if stats is not None else "gsn_linear_f16x3_fwd_hip")
         return y
+    # few rows, identity epilogue (the input-gradient products of a dense backward at the reference's batch sizes): the K slices of an output tile
+    # shared by up to four workgroups that add into a zero-filled output (from the zero arena: no fill launch per product)
+    if out and stats is None and act == 0 and bn_mean is None and bn_scale is None and flags.LINEAR_SPLITK:
+        splits = int(_abi.lib().gsn_linear_splitk_plan(m_rows, w.shape[1], n_out))
+        if splits > 1:
+            from ._runtime import _zeros
+            y = _zeros(m_rows * n_out, torch.float32, dev).view(m_rows, n_out)
+            with _abi.device_guard(dev), _timed("linear_fwd", 2.0 * m_rows * w.shape[1] * n_out):
+                rc = _abi.lib().gsn_linear_fwd_splitk_hip(m_rows, len(blocks), arr, w.data_ptr(), w.stride(0) if w_view else 0, w.stride(1) if w_view else 0,
+                                                          _abi.ptr(vecs[0]), n_out, y.data_ptr(), _abi.current_stream())
+            _abi.check(rc, "gsn_linear_fwd_splitk_hip")
+            return y
     if w_view:
         with _abi.device_guard(dev), _timed("linear_fwd", 2.0 * m_rows * w.shape[1] * n_out):
             rc = _abi.lib().gsn_linear_fwd_strided_hip(m_rows, len(blocks), arr, w.data_ptr(), w.stride(0), w.stride(1), _abi.ptr(vecs[0]), n_out,

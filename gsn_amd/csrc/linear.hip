@@ -579,7 +579,11 @@ constexpr int SBM = 32;
 constexpr int SAPLANE = SBM * BKP / 2;            // floats per A plane
 constexpr int SBUF = 3 * SAPLANE + 3 * BPLANE;    // floats per buffer: A planes, W planes
 
-template <bool STATS, bool VEC4, bool WT>
+// SPLITK: gridDim.z workgroups share an output tile, each takes a contiguous range of the K slices and ADDS its partial product to `out`
+// (zeros on entry; float atomics).  For products whose epilogue is the identity (+ bias, added by the first range): the input-gradient products
+// gX = gH W of a dense backward at the reference's batch sizes, where one workgroup per tile is a serial chain of K / 32 slices of ~1.1 us each
+// on a third of the chip (M = 837 rows: 81 .. 135 workgroups; 22.8 us at K = 600).
+template <bool STATS, bool VEC4, bool WT, bool SPLITK = false>
 __global__ __launch_bounds__(256) void linear_fwd_bf16_small_kernel(LinArgs a, int k_pad) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     auto a_planes = [&](int buf) { return lds + buf * SBUF; };
@@ -593,7 +597,9 @@ __global__ __launch_bounds__(256) void linear_fwd_bf16_small_kernel(LinArgs a, i
     const int kc = VEC4 ? 4 * (tid & 7) : (tid & 31), r0 = VEC4 ? (tid >> 3) : (tid >> 5);
     const int n0 = blockIdx.y * BN;
     const int64_t row0 = (int64_t)blockIdx.x * SBM;
-    const int n_slices = k_pad / BK;
+    const int n_slices_all = k_pad / BK;
+    const int c_first = SPLITK ? (int)((int64_t)blockIdx.z * n_slices_all / gridDim.z) : 0;
+    const int n_slices = SPLITK ? (int)((int64_t)(blockIdx.z + 1) * n_slices_all / gridDim.z) : n_slices_all;      // (one past this range's last slice)
 
     if (tid < MAX_BLOCKS * SBM) {
         const int b = tid >> 5;
@@ -747,7 +753,7 @@ __global__ __launch_bounds__(256) void linear_fwd_bf16_small_kernel(LinArgs a, i
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
     for (int d = 0; d < SD; ++d)
-        if (d < n_slices) fetch(preAs[d], preWs[d], d);
+        if (c_first + d < n_slices) fetch(preAs[d], preWs[d], c_first + d);
     int cur = 0;
 #define GSN_MFS(x, y) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8l, x), __builtin_bit_cast(bf16x8l, y), acc, 0, 0, 0)
     auto body = [&](float *preA, float *preW, int c) {
@@ -769,7 +775,7 @@ __global__ __launch_bounds__(256) void linear_fwd_bf16_small_kernel(LinArgs a, i
         }
         cur ^= 1;
     };
-    for (int c = 0; c < n_slices; c += SD) {
+    for (int c = c_first; c < n_slices; c += SD) {
 #pragma unroll
         for (int d = 0; d < SD; ++d)
             if (c + d < n_slices) body(preAs[d], preWs[d], c + d);
@@ -788,6 +794,8 @@ __global__ __launch_bounds__(256) void linear_fwd_bf16_small_kernel(LinArgs a, i
             st_sum += (double)h;
             st_sq += (double)h * (double)h;
             if (a.out) op[(int64_t)dr * a.n_out] = h;
+        } else if (SPLITK) {
+            atomicAdd(op + (int64_t)dr * a.n_out, blockIdx.z == 0 ? acc[r] + e_bias : acc[r]);
         } else {
             op[(int64_t)dr * a.n_out] = apply_act(fmaf(acc[r], e_scale, e_c0), a.act);
         }
@@ -818,6 +826,24 @@ static int launch_linear_bf16_small(const LinArgs &a, int k_pad, int col_tiles, 
     hipLaunchKernelGGL((linear_fwd_bf16_small_kernel<STATS, VEC4, WT>), dim3((unsigned)gx, (unsigned)col_tiles), dim3(256), lds, st, a, k_pad);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(GSN_E_HIP, "linear_fwd_bf16_small_kernel: %s", hipGetErrorString(e));
+    return GSN_OK;
+}
+
+template <bool VEC4, bool WT>
+static int launch_linear_bf16_splitk(const LinArgs &a, int k_pad, int col_tiles, int splits, hipStream_t st) {
+    const size_t lds = ((size_t)2 * SBUF + (size_t)MAX_BLOCKS * SBM) * 4;
+    static DeviceOnce attr_set;
+    const int attr_dev = current_device();
+    if (!attr_set.done(attr_dev)) {
+        hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_fwd_bf16_small_kernel<false, VEC4, WT, true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e0 != hipSuccess) return set_error(GSN_E_HIP, "hipFuncSetAttribute(linear_fwd_bf16_small_kernel): %s", hipGetErrorString(e0));
+        attr_set.mark(attr_dev);
+    }
+    const int64_t gx = (a.m_rows + SBM - 1) / SBM;
+    hipLaunchKernelGGL((linear_fwd_bf16_small_kernel<false, VEC4, WT, true>), dim3((unsigned)gx, (unsigned)col_tiles, (unsigned)splits), dim3(256), lds, st, a, k_pad);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(GSN_E_HIP, "linear_fwd_bf16_small_kernel (split K): %s", hipGetErrorString(e));
     return GSN_OK;
 }
 
@@ -866,6 +892,68 @@ extern "C" int gsn_linear_fwd_strided_hip(int64_t m_rows, int n_blocks, const gs
                                           const float *bn_shift, int act, float *out, double *stats, void *stream) {
     if (w_row_stride < 1 || w_col_stride < 1) return set_error(GSN_E_INVALID, "gsn_linear_fwd_strided_hip: strides must be positive");
     return linear_fwd_impl(m_rows, n_blocks, blocks, W, w_row_stride, w_col_stride, bias, n_out, bn_mean, bn_scale, bn_shift, act, nullptr, out, stats, stream);
+}
+
+// Ranges of K slices per output tile (1: no split).  Taken where the 32-row tiles leave most CUs idle and the chain is long: at most two
+// workgroups per CU in total, at least three slices per range, at most four ranges.  GSN_LINEAR_SPLITK_RANGES=n forces n ranges (0 or 1: off).
+extern "C" int gsn_linear_splitk_plan(int64_t m_rows, int64_t k_total, int64_t n_out) {
+    static const int forced = [] { const char *d = getenv("GSN_LINEAR_SPLITK_RANGES"); return d ? atoi(d) : -1; }();
+    static const int small_max = [] { const char *d = getenv("GSN_LINEAR_SMALL_MAX"); return d ? atoi(d) : 96; }();
+    static const bool bf16x6 = [] { const char *d = getenv("GSN_LINEAR_BF16X6"); return !(d && atoi(d) == 0); }();
+    if (forced == 0 || !bf16x6 || m_rows <= 0 || k_total <= 0 || n_out <= 0) return 1;
+    const int64_t n_tiles = (m_rows + BM - 1) / BM, col_tiles = (n_out + BN - 1) / BN;
+    if (n_tiles * col_tiles > small_max) return 1;
+    const int64_t n_slices = (k_total + BK - 1) / BK, wgs = (m_rows + SBM - 1) / SBM * col_tiles;
+    int64_t s = forced > 0 ? forced : 4;
+    if (forced <= 0) {
+        if (s > n_slices / 3) s = n_slices / 3;
+        if (s > 512 / wgs) s = 512 / wgs;
+    }
+    if (s > n_slices) s = n_slices;
+    if (s > 16) s = 16;
+    return s < 2 ? 1 : (int)s;
+}
+
+// out (zeros on entry) += blocks W^T (+ bias): the split-K form of gsn_linear_fwd_strided_hip / gsn_linear_fwd_hip (w_row_stride = 0: row-major W)
+// for gsn_linear_splitk_plan(..) > 1 ranges; the sum's order over the ranges varies in the last bits, as the weight gradients' does.
+extern "C" int gsn_linear_fwd_splitk_hip(int64_t m_rows, int n_blocks, const gsn_block *blocks, const float *W, int64_t w_row_stride,
+                                         int64_t w_col_stride, const float *bias, int64_t n_out, float *out, void *stream) {
+    if (n_blocks < 1 || n_blocks > MAX_BLOCKS || !blocks || !W || n_out <= 0 || !out)
+        return set_error(GSN_E_INVALID, "gsn_linear_fwd_splitk_hip: need 1..%d input blocks, W, out and n_out > 0", MAX_BLOCKS);
+    if (w_row_stride < 0 || w_col_stride < 0 || (w_row_stride == 0) != (w_col_stride == 0))
+        return set_error(GSN_E_INVALID, "gsn_linear_fwd_splitk_hip: bad strides");
+    if (m_rows <= 0) return GSN_OK;
+    const bool strided = w_row_stride != 0;
+    LinArgs a{};
+    a.m_rows = m_rows; a.n_blocks = n_blocks;
+    int k_total = 0;
+    for (int b = 0; b < n_blocks; ++b) {
+        if (!blocks[b].data || blocks[b].width <= 0 || blocks[b].width > (1 << 20))
+            return set_error(GSN_E_INVALID, "gsn_linear_fwd_splitk_hip: block %d has no data or a bad width", b);
+        a.bdata[b] = blocks[b].data; a.bidx[b] = blocks[b].idx; a.bidx32[b] = blocks[b].idx32; a.bwidth[b] = (int)blocks[b].width;
+        k_total += (int)blocks[b].width;
+    }
+    a.k_total = k_total; a.n_out = (int)n_out; a.act = 0;
+    a.w_rs = strided ? w_row_stride : k_total; a.w_cs = strided ? w_col_stride : 1;
+    {
+        const float *cb[MAX_BLOCKS]; int cw[MAX_BLOCKS];
+        for (int b = 0; b < MAX_BLOCKS; ++b) { cb[b] = b < n_blocks ? a.bdata[b] : a.bdata[0]; cw[b] = b < n_blocks ? a.bwidth[b] : (1 << 27); }
+        a.cb0 = cb[0]; a.cb1 = cb[1]; a.cb2 = cb[2]; a.cb3 = cb[3]; a.cb4 = cb[4];
+        a.cw0 = cw[0]; a.cw1 = cw[1]; a.cw2 = cw[2]; a.cw3 = cw[3]; a.cw4 = cw[4];
+    }
+    a.W = W; a.bias = bias; a.out = out;
+    const int splits = gsn_linear_splitk_plan(m_rows, k_total, n_out);
+    if (splits < 2) return set_error(GSN_E_INVALID, "gsn_linear_fwd_splitk_hip: gsn_linear_splitk_plan gives one range for this shape (take gsn_linear_fwd_hip)");
+    const int col_tiles = (int)((n_out + BN - 1) / BN);
+    const int k_pad = (k_total + BK - 1) / BK * BK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    bool vec4 = !strided && (k_total & 3) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0;
+    for (int b = 0; b < n_blocks; ++b)
+        if ((a.bwidth[b] & 3) || (reinterpret_cast<uintptr_t>(a.bdata[b]) & 15)) vec4 = false;
+    if (vec4) return launch_linear_bf16_splitk<true, false>(a, k_pad, col_tiles, splits, st);
+    if (strided && a.w_rs < a.w_cs && ((n_out - 1) * a.w_rs + (int64_t)(k_total - 1) * a.w_cs) < (int64_t(1) << 30))
+        return launch_linear_bf16_splitk<false, true>(a, k_pad, col_tiles, splits, st);
+    return launch_linear_bf16_splitk<false, false>(a, k_pad, col_tiles, splits, st);
 }
 
 static int linear_fwd_impl(int64_t m_rows, int n_blocks, const gsn_block *blocks, const float *W, int64_t w_rs, int64_t w_cs, const float *bias,

@@ -24,6 +24,9 @@ LINEAR_F16X3_MIN_TILES = int(os.environ.get("GSN_LINEAR_F16X3_MIN_TILES", "96"))
 # the row pre-pass; rows as accurate as the bf16x6 kernel's against fp64, scripts/gpu/stats_ab.py).  0: those stages stay on the bf16x6 kernel
 LINEAR_F16X3_STATS = os.environ.get("GSN_LINEAR_F16X3_STATS", "1") != "0"
 
+# few-row products with an identity epilogue: K ranges of an output tile on several workgroups (gsn_linear_fwd_splitk_hip; 0: one workgroup per tile)
+LINEAR_SPLITK = os.environ.get("GSN_LINEAR_SPLITK", "1") != "0"
+
 STRIDED_WEIGHTS = os.environ.get("GSN_STRIDED_WEIGHTS", "1") != "0"      # transposed weight views read through their strides (0: a contiguous copy first)
 
 VALIDATE_CACHES = os.environ.get("GSN_VALIDATE_CACHES", "0") != "0"   # re-derive-and-compare mode for the per-weight caches (below)

@@ -275,6 +275,15 @@ int gsn_linear_fwd_strided_hip(int64_t m_rows, int n_blocks, const gsn_block *bl
                                int64_t w_col_stride, const float *bias, int64_t n_out, const float *bn_mean, const float *bn_scale,
                                const float *bn_shift, int act, float *out, double *stats, void *stream);
 
+/* Split-K form of the two entry points above for FEW rows (a dense backward at the reference's batch sizes, train_test_funcs.py:88-106 with
+ * README.md:112,121's batch sizes: M = 10^3 rows is a third of the chip's CUs, each walking all K slices): gsn_linear_splitk_plan gives the
+ * number of K ranges this library would use for the shape (1: take gsn_linear_fwd_hip / _strided_hip); gsn_linear_fwd_splitk_hip ADDS
+ * blocks W^T (+ bias) to `out`, which must hold zeros on entry (float atomics: the order of the ranges' partial sums varies in the last bits).
+ * Identity epilogue only.  w_row_stride = w_col_stride = 0: W is row-major [n_out][K]. */
+int gsn_linear_splitk_plan(int64_t m_rows, int64_t k_total, int64_t n_out);
+int gsn_linear_fwd_splitk_hip(int64_t m_rows, int n_blocks, const gsn_block *blocks, const float *W, int64_t w_row_stride,
+                              int64_t w_col_stride, const float *bias, int64_t n_out, float *out, void *stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * HP-2  fused MLP chain (device; fp32 in / fp32 out; matrix products as in gsn_linear_fwd_hip: bf16x6 by default,
  * GSN_CHAIN_BF16X6=0 for the fp32-MFMA kernels).  One or two dependent stages of models_misc.mlp (models_misc.py:52-58)

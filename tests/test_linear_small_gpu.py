@@ -91,3 +91,60 @@ def test_a_row_does_not_depend_on_the_tile_height():
         assert torch.equal(y_big[:3000], y_small)
     finally:
         flags.LINEAR_F16X3 = old
+
+
+SPLITK_CASES = [  # m_rows, block widths, gathered?, n_out, bias, transposed weight view
+    (837, [600], [0], 300, False, True),        # the input-gradient product of a d = 300 stage at molhiv's batch of 32 graphs
+    (837, [300], [0], 600, False, True),
+    (837, [300], [0], 600, True, False),        # float4 staging
+    (1201, [301], [0], 130, True, False),       # scalar staging, ragged everything
+    (2000, [128, 128, 32], [32, 64, 0], 128, True, False),
+    (65, [1000], [0], 17, False, True),
+]
+
+
+@pytest.mark.parametrize("case", SPLITK_CASES, ids=[str(c[0]) + "x" + str(sum(c[1])) + "x" + str(c[3]) for c in SPLITK_CASES])
+def test_split_k_products_against_float64_and_the_one_range_kernel(case, monkeypatch):
+    """gsn_linear_fwd_splitk_hip (K ranges of an output tile on several workgroups, added into a zero-filled output) against float64 and
+    against the same product with one workgroup per tile."""
+    from gsn_amd import _abi, flags, layers
+    m, widths, gath, n_out, use_bias, transposed = case
+    monkeypatch.setattr(flags, "LINEAR_F16X3", False)
+    rng = np.random.default_rng(m * 17 + n_out)
+    dev = torch.device("cuda")
+    blocks = []
+    for wd, g in zip(widths, gath):
+        if g:
+            src_rows = int(rng.integers(5, 400))
+            d = torch.from_numpy(rng.standard_normal((src_rows, wd)).astype(np.float32)).to(dev)
+            idx = torch.from_numpy(rng.integers(0, src_rows, m)).to(dev)
+            blocks.append((d, idx.to(torch.int32) if g == 32 else idx))
+        else:
+            blocks.append((torch.from_numpy(rng.standard_normal((m, wd)).astype(np.float32)).to(dev), None))
+    k = sum(widths)
+    w = torch.from_numpy(rng.standard_normal((n_out, k)).astype(np.float32) / np.sqrt(k)).to(dev)
+    if transposed:
+        w = w.t().contiguous().t()
+    bias = torch.from_numpy(rng.standard_normal(n_out).astype(np.float32)).to(dev) if use_bias else None
+    assert _abi.lib().gsn_linear_splitk_plan(m, k, n_out) > 1
+    flags.KERNEL_TIMER = None
+    y = layers._linear_hip(blocks, w, bias, None, None, None, 0, m)
+    monkeypatch.setattr(flags, "LINEAR_SPLITK", False)
+    y1 = layers._linear_hip(blocks, w, bias, None, None, None, 0, m)
+    ref, _ = _ref(blocks, w, bias, None, 0, m)
+    scale = float(ref.abs().max())
+    assert float((y.double() - ref).abs().max()) <= 3e-6 * scale
+    assert float((y - y1).abs().max()) <= 1e-6 * scale          # (the ranges' partial sums are added in fp32: an ulp or two of the largest term)
+    # rows past the last tile's end and columns past n_out: nothing written outside [m][n_out] (the output is exactly that large) -- and
+    # a second call must not see the first call's sums (fresh zeros from the arena)
+    y2 = layers._linear_hip(blocks, w, bias, None, None, None, 0, m)
+    assert float((y2 - y1).abs().max()) == 0.0
+
+
+def test_split_k_plan_leaves_activations_statistics_and_large_products_alone():
+    from gsn_amd import _abi
+    lib = _abi.lib()
+    assert lib.gsn_linear_splitk_plan(837, 600, 300) == 4
+    assert lib.gsn_linear_splitk_plan(837, 64, 300) == 1            # two slices: nothing to split
+    assert lib.gsn_linear_splitk_plan(105083, 600, 300) == 1        # config-4 sizes: the 128-row kernels
+    assert lib.gsn_linear_splitk_plan(0, 600, 300) == 1
