@@ -484,8 +484,29 @@ def train_step_config4(dev):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     r = mod.run(types.SimpleNamespace(batch=4096, steps=20, warmup=10, layers=5, d=300), dev)
-    return {"graphs": 4096, "ms_per_step": r["ms_per_step"], "graphs_per_s": r["graphs_per_s"], "parameters": r["parameters"], "workload": r["workload"],
-            "steps": 20, "warmup": 10}
+    out = {"graphs": 4096, "ms_per_step": r["ms_per_step"], "graphs_per_s": r["graphs_per_s"], "parameters": r["parameters"], "workload": r["workload"],
+           "steps": 20, "warmup": 10}
+    # Roofs of the step.  F_alg: the fp32 products of the reference's step -- per layer update_fn = Linear(d, 2d) + Linear(2d, d)
+    # on N rows, the virtual node's mlp on G rows for all layers but the last, each product once forward and twice backward (input and weight
+    # gradient).  B_alg: every activation the step must keep for its backward written once and read once, every gradient row written once and read
+    # once, at 4 bytes: per layer x_in, the aggregated rows, the hidden rows before and after BatchNorm (2d wide), the output rows before and after
+    # BatchNorm, plus the integer codes of the edges (7 columns of 8 bytes) and the parameters / their gradients three times (read, gradient, update).
+    import re
+    m = re.search(r"N=(\d+), E=(\d+)", r["workload"])
+    if m:
+        N, E, G, L, d = int(m.group(1)), int(m.group(2)), 4096, 5, 300
+        f_alg = 3.0 * (L * 2.0 * N * (d * 2 * d * 2) + (L - 1) * 2.0 * G * (d * 2 * d * 2))
+        rows_per_layer = N * (d + d + 2 * d + 2 * d + d + d)
+        b_alg = 4.0 * 2.0 * 2.0 * L * rows_per_layer + 2.0 * L * E * 7 * 8.0 + 3.0 * 4.0 * r["parameters"]
+        t = r["ms_per_step"] * 1e-3
+        out["roofline"] = {"F_alg_GF": round(f_alg / 1e9, 1), "B_alg_GB": round(b_alg / 1e9, 3),
+                           "fp32_equivalent_TFLOPs": round(f_alg / t / 1e12, 1), "frac_of_fp32_mfma_peak_157TF": round(f_alg / t / 1e12 / 157.3, 3),
+                           "frac_of_fp16x3_roof_833TF": round(f_alg / t / 1e12 / 833.0, 3),
+                           "hbm_GBs": round(b_alg / t / 1e9, 1), "hbm_frac": round(b_alg / t / 1e9 / HBM_PEAK_GBS, 3),
+                           "roof_ms": {"hbm": round(b_alg / (HBM_PEAK_GBS * 1e9) * 1e3, 3), "fp16x3": round(f_alg / 833e12 * 1e3, 3)},
+                           "note": "bound: neither single roof -- a sequence of ~470 launches per step, the dense ones on the matrix pipe (weight gradients on six bf16 "
+                                   "plane products, the others on three fp16 ones), the row-wise ones at the HBM copy ceiling (profiles/r05_molhiv_step_kernel_stats.csv)"}
+    return out
 
 
 def train_small_batch(dev, graphs=True):

@@ -416,6 +416,155 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradArgs a) {
         }
 }
 
+// The same kernel for plain rows as a software pipeline INSIDE a wave (r05).  Above, a 16-row step is 24 MFMAs back to back and then ~130 vector
+// instructions that split the next step's values into planes: a SIMD does not overlap one wave's matrix stream with another wave's vector
+// stream (profiles/r03_issue_mix.txt: the sum, not the maximum), but it does issue ~4 independent vector instructions in the shadow of each of a
+// wave's OWN 32x32x16 MFMAs.  Here the rows of step s + 2 are requested at the top of step s, and the values of step s + 1 (requested one step
+// earlier: a load's latency is longer than a step's matrix phase) are split between the MFMAs of step s -- one MFMA, five vector instructions,
+// by sched_group_barrier -- and written to the other LDS buffer behind them.  Branch-free loop body (rows past the slab's end are clamped
+// loads and zero planes), two named register sets, the loop unrolled by two.  Same planes, same products, same order: the same bits.
+// SINGLE: X is one block -- every row address is a scalar base (the row) plus a 32-bit lane offset (the column): no vector arithmetic per load
+template <bool SINGLE, int WG_PIPE_VALU>
+__global__ __launch_bounds__(256) void wgrad_bf16_pipe_kernel(WgradArgs a) {
+    __shared__ wg_u32x4 ta[2][3][WG_T][2];
+    __shared__ wg_u32x4 tb[2][3][WG_T][2];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int ntile = a.tn * a.tk;
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int tile = seq % ntile;
+    const int64_t slab = (int64_t)(seq / ntile) * 8 + xcd;
+    const int n0 = (tile / a.tk) * WG_T, k0 = (tile % a.tk) * WG_T;
+    const int64_t r_begin = slab * a.rows_per_wg;
+    int64_t r_end = r_begin + a.rows_per_wg;
+    if (r_end > a.m_rows) r_end = a.m_rows;
+    if (r_begin >= r_end) return;                 // (block-uniform)
+
+    const int sc = tid & 127, sh = __builtin_amdgcn_readfirstlane(tid >> 7);      // (the row half is the same for a whole wave)
+    const int ca = n0 + sc;
+    const bool ca_ok = ca < a.n_out;
+    const int kb = k0 + sc;
+    const bool kb_ok = kb < a.k_total;
+    const float *xb = a.bdata[0];
+    int xw = a.bwidth[0];
+    {
+        int blk = 0, col = kb_ok ? kb : 0;
+#pragma unroll
+        for (int b = 0; b < WG_MAXB - 1; ++b)
+            if (b < a.n_blocks - 1 && blk == b && col >= a.bwidth[b]) { col -= a.bwidth[b]; blk = b + 1; }
+#pragma unroll
+        for (int b = 1; b < WG_MAXB; ++b)
+            if (blk == b) { xb = a.bdata[b]; xw = a.bwidth[b]; }
+        xb += col;
+    }
+    const float *ga = a.gh + (ca_ok ? ca : 0);
+    const unsigned ca_u = ca_ok ? (unsigned)ca : 0u, kb_u = kb_ok ? (unsigned)kb : 0u;
+
+    f32x16b acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto fetch = [&](float (&pa)[8], float (&pb)[8], int64_t row0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int64_t r = row0 + 8 * sh + i;
+            const int64_t rc = r < r_end ? r : r_begin;            // clamped: masked to zero when split  (scalar: row0, sh and i are)
+            const float *grow = a.gh + rc * a.n_out;
+            pa[i] = grow[ca_u];
+            if (SINGLE) {
+                const float *xrow = a.bdata[0] + rc * a.bwidth[0];
+                pb[i] = xrow[kb_u];
+            } else {
+                pb[i] = xb[rc * xw];
+            }
+        }
+    };
+    auto split = [&](const float (&v)[8], bool col_ok, int64_t row0, wg_u32x4 &ph, wg_u32x4 &pm, wg_u32x4 &pl) {
+        unsigned h[8], m[8], l[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bool ok = col_ok && (row0 + 8 * sh + i < r_end);
+            wg_split3(ok ? v[i] : 0.f, h[i], m[i], l[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ph[i] = wg_pack_hi(h[2 * i], h[2 * i + 1]);
+            pm[i] = wg_pack_hi(m[2 * i], m[2 * i + 1]);
+            pl[i] = wg_pack_hi(l[2 * i], l[2 * i + 1]);
+        }
+    };
+    float pa0[8], pb0[8], pa1[8], pb1[8];
+    {
+        fetch(pa0, pb0, r_begin);
+        fetch(pa1, pb1, r_begin + 16);
+        wg_u32x4 gh, gm, gl, xh, xm, xl;
+        split(pa0, ca_ok, r_begin, gh, gm, gl);
+        split(pb0, kb_ok, r_begin, xh, xm, xl);
+        ta[0][0][sc][sh] = gh; ta[0][1][sc][sh] = gm; ta[0][2][sc][sh] = gl;
+        tb[0][0][sc][sh] = xh; tb[0][1][sc][sh] = xm; tb[0][2][sc][sh] = xl;
+    }
+    __syncthreads();
+#define WG_MF(x, y, c) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wg_bf16x8, x), __builtin_bit_cast(wg_bf16x8, y), c, 0, 0, 0)
+    // one step: products of the rows staged in `buf`; `nxt` (rows row0 + 16, in registers since the step before) split under them into buf ^ 1;
+    // `far` receives the rows row0 + 32
+    auto step = [&](int buf, int64_t row0, const float (&npa)[8], const float (&npb)[8], float (&fpa)[8], float (&fpb)[8]) {
+        wg_u32x4 fa[2][3], fb[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                fa[i][pl] = ta[buf][pl][wm * 64 + i * 32 + li][lh];
+                fb[i][pl] = tb[buf][pl][wn * 64 + i * 32 + li][lh];
+            }
+        wg_u32x4 gh, gm, gl, xh, xm, xl;
+        split(npa, ca_ok, row0 + 16, gh, gm, gl);
+        split(npb, kb_ok, row0 + 16, xh, xm, xl);
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            const int pa_ = (t == 0) ? 0 : (t == 1) ? 2 : (t == 2) ? 1 : (t == 3) ? 0 : (t == 4) ? 1 : 0;
+            const int pb_ = (t == 0) ? 2 : (t == 1) ? 0 : (t == 2) ? 1 : (t == 3) ? 1 : (t == 4) ? 0 : 0;
+            WG_MF(fa[0][pa_], fb[0][pb_], acc[0][0]);
+            WG_MF(fa[0][pa_], fb[1][pb_], acc[0][1]);
+            WG_MF(fa[1][pa_], fb[0][pb_], acc[1][0]);
+            WG_MF(fa[1][pa_], fb[1][pb_], acc[1][1]);
+        }
+        ta[buf ^ 1][0][sc][sh] = gh; ta[buf ^ 1][1][sc][sh] = gm; ta[buf ^ 1][2][sc][sh] = gl;
+        tb[buf ^ 1][0][sc][sh] = xh; tb[buf ^ 1][1][sc][sh] = xm; tb[buf ^ 1][2][sc][sh] = xl;
+        fetch(fpa, fpb, row0 + 32);
+        // the order asked of the scheduler: the fragment reads, then the far rows' requests, then one MFMA : five vector instructions, the plane
+        // writes last
+#pragma unroll
+        for (int t = 0; t < 24; ++t) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, WG_PIPE_VALU, 0);  // VALU
+        }
+        __syncthreads();
+    };
+    int64_t row0 = r_begin;
+    for (; row0 < r_end; row0 += 32) {
+        step(0, row0, pa1, pb1, pa0, pb0);
+        if (row0 + 16 >= r_end) break;            // (block-uniform)
+        step(1, row0 + 16, pa0, pb0, pa1, pb1);
+    }
+#undef WG_MF
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int kcol = k0 + wn * 64 + j * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int nrow = n0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (nrow < a.n_out && kcol < a.k_total) atomicAdd(a.gw + (int64_t)nrow * a.k_total + kcol, acc[i][j][r]);
+            }
+        }
+}
+
 // Workgroups along the rows: every workgroup ends with one fp64 atomic per column onto the SAME n_cols addresses, which the L2
 // serialises (~20 ns each: 1024 workgroups = 20 us whatever the row count -- the whole run time at the reference's batch sizes,
 // E ~ 6 000 rows), so a workgroup takes at least 64 rows (16 per wave).
@@ -502,7 +651,17 @@ extern "C" int gsn_wgrad_hip(int64_t m_rows, int64_t n_out, const float *grad_h,
     else {
         a.tn = tn; a.tk = tk;
         const int64_t slab_groups = (slabs + 7) / 8;
-        if (gathered) hipLaunchKernelGGL(wgrad_bf16_kernel<true>, dim3((unsigned)(slab_groups * tn * tk * 8)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+        // GSN_WGRAD_PIPE: 0 = the kernel above for plain rows too; 4 / 5 / 6 = vector instructions asked for behind each MFMA (default 6; config-4 step on one box: off 19.71, 4: 19.43, 5: 19.22, 6: 19.06-19.21 ms)
+        static const int pipe = [] { const char *e = getenv("GSN_WGRAD_PIPE"); const int v = e ? atoi(e) : 6; return v == 1 ? 6 : v; }();
+        const dim3 grid((unsigned)(slab_groups * tn * tk * 8));
+        hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+        if (gathered) hipLaunchKernelGGL(wgrad_bf16_kernel<true>, grid, dim3(256), 0, st, a);
+        else if (pipe == 4 && n_blocks == 1) hipLaunchKernelGGL((wgrad_bf16_pipe_kernel<true, 4>), grid, dim3(256), 0, st, a);
+        else if (pipe == 4) hipLaunchKernelGGL((wgrad_bf16_pipe_kernel<false, 4>), grid, dim3(256), 0, st, a);
+        else if (pipe == 5 && n_blocks == 1) hipLaunchKernelGGL((wgrad_bf16_pipe_kernel<true, 5>), grid, dim3(256), 0, st, a);
+        else if (pipe == 5) hipLaunchKernelGGL((wgrad_bf16_pipe_kernel<false, 5>), grid, dim3(256), 0, st, a);
+        else if (pipe && n_blocks == 1) hipLaunchKernelGGL((wgrad_bf16_pipe_kernel<true, 6>), grid, dim3(256), 0, st, a);
+        else if (pipe) hipLaunchKernelGGL((wgrad_bf16_pipe_kernel<false, 6>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL(wgrad_bf16_kernel<false>, dim3((unsigned)(slab_groups * tn * tk * 8)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
     }
     hipError_t e = hipGetLastError();
