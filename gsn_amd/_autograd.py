@@ -183,7 +183,7 @@ class _DenseStagesFn(torch.autograd.Function):
                 # gX = gH W: W read as its transpose.  The fp16x3 kernel prepares its planes from any strides; the bf16x6 kernel stages a
                 # strided W with scalar loads -- fine where a launch costs more than the staging (small batches), a copy + float4 staging above
                 wt = w.detach().t() if (w.shape[1] > flags.LINEAR_F16X3_MIN_N or m_rows <= 16384) else _transposed(w)
-                gx = _linear_hip([(gh, None)], wt, None, None, None, None, 0, m_rows)
+                gx = _linear_hip([(gh, None)], wt, None, None, None, None, 0, m_rows, split_k=True)
                 if si > 0:
                     g = gx
                 else:

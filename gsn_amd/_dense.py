@@ -43,8 +43,10 @@ def _f16x3_weights(weight, w32):
     return planes, col_inv
 
 
-def _linear_hip(blocks, weight, bias, bn_mean, bn_scale, bn_shift, act, m_rows, out=True, stats=None):
-    """blocks: list of (data [R,w] fp32 cuda, idx int64 [M] or None)."""
+def _linear_hip(blocks, weight, bias, bn_mean, bn_scale, bn_shift, act, m_rows, out=True, stats=None, split_k=False):
+    """blocks: list of (data [R,w] fp32 cuda, idx int64 [M] or None).  ``split_k``: the caller accepts a sum whose order varies from run to run in the
+    last bits (float atomics over K ranges, gsn_linear_fwd_splitk_hip) -- the input-gradient products of a backward pass, whose weight gradients
+    are accumulated that way already; forward products stay on one workgroup per tile: an eval forward is reproducible bit for bit."""
     if len(blocks) > _MAX_BLOCKS:
         raise NotImplementedError("more than %d input blocks" % _MAX_BLOCKS)
     dev = weight.device
@@ -95,7 +97,7 @@ def _linear_hip(blocks, weight, bias, bn_mean, bn_scale, bn_shift, act, m_rows, 
         return y
     # few rows, identity epilogue (the input-gradient products of a dense backward at the reference's batch sizes): the K slices of an output tile
     # shared by up to four workgroups that add into a zero-filled output (from the zero arena: no fill launch per product)
-    if out and stats is None and act == 0 and bn_mean is None and bn_scale is None and flags.LINEAR_SPLITK:
+    if split_k and out and stats is None and act == 0 and bn_mean is None and bn_scale is None and flags.LINEAR_SPLITK:
         splits = int(_abi.lib().gsn_linear_splitk_plan(m_rows, w.shape[1], n_out))
         if splits > 1:
             from ._runtime import _zeros

@@ -128,17 +128,18 @@ def test_split_k_products_against_float64_and_the_one_range_kernel(case, monkeyp
     bias = torch.from_numpy(rng.standard_normal(n_out).astype(np.float32)).to(dev) if use_bias else None
     assert _abi.lib().gsn_linear_splitk_plan(m, k, n_out) > 1
     flags.KERNEL_TIMER = None
-    y = layers._linear_hip(blocks, w, bias, None, None, None, 0, m)
-    monkeypatch.setattr(flags, "LINEAR_SPLITK", False)
-    y1 = layers._linear_hip(blocks, w, bias, None, None, None, 0, m)
+    y = layers._linear_hip(blocks, w, bias, None, None, None, 0, m, split_k=True)
+    y1 = layers._linear_hip(blocks, w, bias, None, None, None, 0, m)          # (not asked for: one workgroup per tile)
     ref, _ = _ref(blocks, w, bias, None, 0, m)
     scale = float(ref.abs().max())
     assert float((y.double() - ref).abs().max()) <= 3e-6 * scale
     assert float((y - y1).abs().max()) <= 1e-6 * scale          # (the ranges' partial sums are added in fp32: an ulp or two of the largest term)
     # rows past the last tile's end and columns past n_out: nothing written outside [m][n_out] (the output is exactly that large) -- and
     # a second call must not see the first call's sums (fresh zeros from the arena)
-    y2 = layers._linear_hip(blocks, w, bias, None, None, None, 0, m)
-    assert float((y2 - y1).abs().max()) == 0.0
+    y2 = layers._linear_hip(blocks, w, bias, None, None, None, 0, m, split_k=True)
+    assert float((y2.double() - ref).abs().max()) <= 3e-6 * scale
+    y3 = layers._linear_hip(blocks, w, bias, None, None, None, 0, m)
+    assert torch.equal(y3, y1)                                                 # forward products: the same bits every time
 
 
 def test_split_k_plan_leaves_activations_statistics_and_large_products_alone():
