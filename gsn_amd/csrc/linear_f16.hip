@@ -196,6 +196,83 @@ __global__ __launch_bounds__(256) void lin16_split_rows_kernel(L16Args a) {
     }
 }
 
+// r05, rows given as ONE block (every chunk of a row is its base + a constant: no per-chunk block selection, no per-chunk address registers):
+// grid-stride over the 32-row tiles with the NEXT tile's chunks requested before this tile is split (two named register sets): a
+// workgroup that lived for one tile spent a memory round trip with nothing else to do, and 3 284 one-tile workgroups over 2 048 slots left the
+// second round 60 % full.  GSN_L16_SPLIT_WGS (default 1024; 0: one tile per workgroup, the r02 launch).
+__global__ __launch_bounds__(256) void lin16_split_rows1_kernel(L16Args a) {
+    const int q8 = threadIdx.x & 7;
+    const int nch = a.k_total >> 2, nchp = a.k_pad >> 2;
+    const int64_t tiles = a.m_pad / 32;
+    auto load = [&](int64_t tile, float4 (&v)[L_RC]) {
+        const int64_t row = tile * 32 + (threadIdx.x >> 3);
+        const int64_t rr = row < a.m_rows ? row : a.m_rows - 1;
+        const float4 *rp = reinterpret_cast<const float4 *>(a.b0 + rr * a.w0);
+#pragma unroll
+        for (int i = 0; i < L_RC; ++i) {
+            const int c = q8 + 8 * i;
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < nch) v[i] = rp[c];
+        }
+    };
+    auto process = [&](int64_t tile, const float4 (&v)[L_RC]) {
+        const int64_t row = tile * 32 + (threadIdx.x >> 3);     // < m_pad
+        const bool on = row < a.m_rows;
+        const int64_t rr = on ? row : a.m_rows - 1;
+        unsigned m = 0;
+        auto amax = [&](const float4 &x) {
+            m = max(max(m, __float_as_uint(x.x) & 0x7fffffffu), __float_as_uint(x.y) & 0x7fffffffu);
+            m = max(max(m, __float_as_uint(x.z) & 0x7fffffffu), __float_as_uint(x.w) & 0x7fffffffu);
+        };
+#pragma unroll
+        for (int i = 0; i < L_RC; ++i) amax(v[i]);              // (chunks past K hold zeros)
+        const float4 *rp = reinterpret_cast<const float4 *>(a.b0 + rr * a.w0);
+        for (int c = q8 + 8 * L_RC; c < nch; c += 8) amax(rp[c]);
+        m = max(m, (unsigned)__shfl_xor((int)m, 1));
+        m = max(m, (unsigned)__shfl_xor((int)m, 2));
+        m = max(m, (unsigned)__shfl_xor((int)m, 4));
+        float s, inv;
+        l16_scale(m, s, inv);
+        if (m >= 0x7f800000u) inv = __uint_as_float(0x7fc00000u);            // Inf / NaN in the row: its outputs become NaN
+        if (q8 == 0) a.rowinv[row] = on ? inv : 0.f;
+        // (rows past m_rows write no planes; their lanes still take part in the shuffles below)
+        unsigned char *prow = a.aplanes + rr * a.k_pad * 4;                  // (4 bytes per column: a high and a low half)
+        // chunk c = columns 4c .. 4c + 3 of slice c >> 3.  Lane pairs trade halves so that every lane stores 16 bytes: the even lane
+        // the high halfs of both chunks, the odd lane the low halfs -- the 8 lanes of a row write one whole line with one instruction
+        const bool even = (q8 & 1) == 0;
+        auto put = [&](int c, const float4 &x) {
+            unsigned h0, l0, h1, l1;
+            l16_split2(fl2{x.x * s, x.y * s}, h0, l0);
+            l16_split2(fl2{x.z * s, x.w * s}, h1, l1);
+            const unsigned r0 = (unsigned)__shfl_xor((int)(even ? l0 : h0), 1), r1 = (unsigned)__shfl_xor((int)(even ? l1 : h1), 1);
+            unsigned char *line = prow + (c >> 3) * L_LINE + (even ? 0 : 64) + ((c & 7) >> 1) * 16;
+            if (on) *reinterpret_cast<un4 *>(line) = even ? un4{h0, h1, r0, r1} : un4{r0, r1, l0, l1};
+        };
+#pragma unroll
+        for (int i = 0; i < L_RC; ++i) {
+            const int c = q8 + 8 * i;
+            if (c < nchp) put(c, v[i]);                                        // (zero past K: the padding columns)
+        }
+        for (int c = q8 + 8 * L_RC; c < nchp; c += 8) {
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < nch) x = rp[c];
+            put(c, x);
+        }
+    };
+    float4 vc[L_RC], vn[L_RC];
+    const int64_t step = gridDim.x;
+    int64_t t = blockIdx.x;
+    if (t >= tiles) return;
+    load(t, vc);
+    for (; t < tiles; t += step) {
+        const bool more = t + step < tiles;
+        if (more) load(t + step, vn);
+        process(t, vc);
+#pragma unroll
+        for (int i = 0; i < L_RC; ++i) vc[i] = vn[i];
+    }
+}
+
 // ---- the product on pre-split rows ---------------------------------------------------------------------------------------------------
 // A plain fp16 matrix kernel with three plane products per k-step: both operands arrive as fp16 planes and are staged with 16-byte
 // copies (no arithmetic between the load and LDS).  2 WM waves on a (64 WM) x (64 NJ) output tile, wave w = rows 64 (w >> 1)..,
@@ -809,7 +886,17 @@ static int l16_fwd(int64_t m_rows, int n_blocks, const gsn_block *blocks, const 
     a.m_pad = (m_rows + 255) / 256 * 256;
     a.rowinv = row_scratch;
     a.aplanes = reinterpret_cast<unsigned char *>(row_scratch + a.m_pad);
-    hipLaunchKernelGGL(lin16_split_rows_kernel, dim3((unsigned)(a.m_pad / 32)), dim3(256), 0, st, a);
+    {
+        // one block of 16-byte aligned rows: the grid-stride kernel (GSN_L16_SPLIT_WGS workgroups, default 1024; 0: the one-tile-per-workgroup kernel)
+        static const int64_t split_wgs = [] { const char *e = getenv("GSN_L16_SPLIT_WGS"); return e ? (int64_t)atoll(e) : (int64_t)1024; }();
+        int64_t gx = a.m_pad / 32;
+        if (split_wgs > 0 && a.n_blocks == 1 && (a.w0 & 3) == 0) {
+            if (gx > split_wgs) gx = split_wgs;
+            hipLaunchKernelGGL(lin16_split_rows1_kernel, dim3((unsigned)gx), dim3(256), 0, st, a);
+        } else {
+            hipLaunchKernelGGL(lin16_split_rows_kernel, dim3((unsigned)gx), dim3(256), 0, st, a);
+        }
+    }
     // 128 x 128 tiles, two workgroups of 4 waves per CU (256 x 256 tiles with 8 waves measured 3-5 % slower: no registers left
     // for the second set of loads in flight)
     const int wm = 2, nj = 2;
