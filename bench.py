@@ -27,6 +27,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
+PACK_ONLY_IDS = os.environ.get("GSN_BENCH_PACK_ONLY_IDS", "1") != "0"      # headline: no fp32 one-hot identifier rows (0: written, as rounds 2-4 / early r05)
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3    # MI355X_MICROARCH.md: fp32 MFMA (v_mfma_f32_32x32x2_f32) dense peak
 MFMA_BF16_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA (v_mfma_f32_32x32x16_bf16) dense peak (no sparsity)
@@ -676,13 +677,24 @@ def main():
         main = torch.cuda.current_stream(dev)
         ep = epack if prepacked else epack_c
 
+        ids_in = [idf_out]
+
         def count():
-            # gsn_count_encode_hip: the counts leave the kernel as the int64 identifiers AND as the one-hot rows of min(count, 2) the layer
-            # consumes (the reference: int64 identifiers, then DiscreteEmbedding('one_hot_encoder'), utils_graph_learning.py:78 / :170-187)
-            with layers._timed("count", 16.0 * E + 4.0 * E * 12 + (8.0 * E * 4 if int64_ids else 0.0)):
-                count_batch(plan, node_ptr, edge_ptr, ei, ids_are_global=True, max_nodes=max_nodes, max_edges=max_edges,
-                            device=dev, check=False, encode=([3, 3, 3, 3], True), counts=int64_ids, out=ids_out if int64_ids else None,
-                            encoded_out=idf_out, encoded_pack=(ep, 0) if use_pack else None)
+            # the counts leave the kernel as the int64 identifiers AND as the one-hot classes of min(count, 2) the layer consumes (the
+            # reference: int64 identifiers, then DiscreteEmbedding('one_hot_encoder'), utils_graph_learning.py:78 / :170-187).  Headline:
+            # int64 rows + the identifier columns of the exact fp16 pack the layer kernel reads (gsn_count_encode_pack16_hip with no fp32
+            # rows: nothing reads them -- the layer input is a Codes object over the counts, tagged with the pack); the other variants
+            # write the fp32 one-hot rows as rounds 2-4 did
+            pack_only = use_pack and int64_ids and not prepacked and PACK_ONLY_IDS
+            with layers._timed("count", 16.0 * E + (2.0 if pack_only else 4.0) * E * 12 + (8.0 * E * 4 if int64_ids else 0.0)):
+                if pack_only:
+                    ids_in[0] = count_batch(plan, node_ptr, edge_ptr, ei, ids_are_global=True, max_nodes=max_nodes, max_edges=max_edges,
+                                            device=dev, check=False, encode=([3, 3, 3, 3], True), counts=True, out=ids_out,
+                                            encoded_pack=(ep, 0), encoded_rows=False)[2]
+                else:
+                    count_batch(plan, node_ptr, edge_ptr, ei, ids_are_global=True, max_nodes=max_nodes, max_edges=max_edges,
+                                device=dev, check=False, encode=([3, 3, 3, 3], True), counts=int64_ids, out=ids_out if int64_ids else None,
+                                encoded_out=idf_out, encoded_pack=(ep, 0) if use_pack else None)
 
         def independent_of_counts():
             layers._csr_for(ei, sel, N)
@@ -694,7 +706,7 @@ def main():
             with torch.no_grad():
                 if prepacked:
                     return layer(x, ei, identifiers=idf_out, degrees=degrees, edge_features=ef)
-                return layer(xc, ei, identifiers=idf_out, degrees=degrees, edge_features=efc)
+                return layer(xc, ei, identifiers=ids_in[0], degrees=degrees, edge_features=efc)
         if not fork:                          # (the captured variant without a second branch)
             independent_of_counts()
             count()
@@ -777,12 +789,19 @@ def main():
     diag("right behind the timed region")
     # (outside the timed region) the timed batch's own results against the oracle, and the counting work figures: the int64
     # counts of the same batch (one more launch), the timed step's encoded rows against their one-hot, a tile against the oracle
+    ids_timed = ids_out.clone()               # (the int64 identifiers the timed step wrote)
     count_batch(plan, node_ptr, edge_ptr, ei, ids_are_global=True, max_nodes=max_nodes, max_edges=max_edges, device=dev, out=ids_out, check=False)
-    enc_ok = bool(torch.equal(idf_out, torch.nn.functional.one_hot(ids_out.clamp(max=2), 3).reshape(E, 12).float()))
-    assert enc_ok, "encoded identifiers of the timed step differ from one_hot(min(count, 2))"
+    one_hot_ref = torch.nn.functional.one_hot(ids_out.clamp(max=2), 3).reshape(E, 12).float()
+    ids_ok = bool(torch.equal(ids_timed, ids_out))
+    if use_pack and PACK_ONLY_IDS:            # the timed step's identifier columns of the pack (fp16, exact) against one_hot(min(count, 2))
+        enc_ok = bool(torch.equal(epack_c[:, :12].float(), one_hot_ref))
+    else:
+        enc_ok = bool(torch.equal(idf_out, one_hot_ref))
+    assert enc_ok and ids_ok, "identifiers of the timed step differ from a plain counting launch / its encoded form from one_hot(min(count, 2))"
     checked = verify_tile(plan, b, ids_out, y, layer, 4096) if rank == 0 else None
     if checked is not None:
         checked["encoded_rows_equal_one_hot_of_counts"] = enc_ok
+        checked["int64_identifiers_of_the_timed_step_equal_a_plain_counting_launch"] = ids_ok
     occ_pos, n_maps = work_figures([list(nx.cycle_graph(k).edges) for k in range(3, 7)], ids_out)
 
     diag("behind the oracle checks")
@@ -1172,7 +1191,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int64 counts + f32 message passing (matrix products: fp16x3 -- two fp16 planes per fp32 operand, three plane products, f32 accumulate)", "data": "synthetic",
             "config": {"workload": "ZINC-shape x%d graphs/GPU (N=%d, E=%d): integer atom / bond codes in -> cycle_graph k<=6 GSN-e (id_scope=local) "
-                                   "orbit count (int64 identifiers written) + one-hot encoding + GSN_edge_sparse layer-0 forward (general, d_in=28, "
+                                   "orbit count (int64 identifiers written) + one-hot encoding (atoms, bonds and identifiers as exact fp16 operand rows: the layer kernel's "
+                                   "input form; no fp32 one-hot tensor is materialised) + GSN_edge_sparse layer-0 forward (general, d_in=28, "
                                    "d_ef=4, d_id=12, d=128, bn, eval) -> layer rows out" % (G, N, E),
                        "inputs": "int64 atom codes [N], bond codes [E], edge_index [2, E], graph pointers", "outputs": "int64 identifiers [E, 4], fp32 layer rows [N, 128]",
                        "graphs_per_step_per_gpu": G, "parallelism": "graph-shard x%d, no data-path collective" % world},

@@ -76,14 +76,17 @@ def _as_dev_i64(x, device):
 
 
 def count_batch(plan: CountPlan, node_ptr, edge_ptr, edge_index, ids_are_global=True, max_nodes=None, max_edges=None,
-                device=None, graph_ids=None, out=None, check=True, encode=None, counts=True, encoded_out=None, encoded_pack=None):
+                device=None, graph_ids=None, out=None, check=True, encode=None, counts=True, encoded_out=None, encoded_pack=None,
+                encoded_rows=True):
     """Run the counting kernel over a batch.
 
     ``encode=(n_classes, clamp)`` also returns the one-hot encoded identifiers the GSN layers consume (the reference's
     ``DiscreteEmbedding('one_hot_encoder')`` over the counts, utils_graph_learning.py:170-187) straight from the kernel
     (``gsn_count_encode_hip``): the result becomes ``(out, status, encoded)`` with ``encoded`` fp32
     [rows_total, sum(n_classes)] (``encoded_out`` to reuse a buffer); with ``counts=False`` the int64 rows are not written at
-    all (``out`` is None).  ``encoded_pack=(pack, col0)`` (with ``encode``): the kernel writes the encoded rows a second time as
+    all (``out`` is None).  ``encoded_rows=False`` (with ``encoded_pack`` and ``counts=True``): NO fp32 rows are written -- the int64 counts and
+    the pack's identifier columns leave the kernel, and ``encoded`` is a :class:`gsn_amd.layers.Codes` over the counts (clamped one-hot classes:
+    what the columns hold) tagged with the pack: the layers take it as ``identifiers``.  ``encoded_pack=(pack, col0)`` (with ``encode``): the kernel writes the encoded rows a second time as
     fp16 into columns col0.. of the exact row pack ``pack`` (:mod:`gsn_amd.packs`) and ``encoded`` is tagged with it -- the first GSN
     layer then reads the pack (csrc/layer_rp.hip) instead of converting the fp32 rows.
 
@@ -109,6 +112,7 @@ def count_batch(plan: CountPlan, node_ptr, edge_ptr, edge_index, ids_are_global=
     n_graphs = node_ptr_d.numel() - 1
     E_total = ei.shape[1]
     enc = enc_tab = None
+    pack_only = pack_codes_later = False
     rows_total = None
     if encode is not None or out is None:
         # rows follow the pointers the kernel uses, not the tensor length (one host read; pass `out` / `encoded_out` to avoid it)
@@ -124,9 +128,13 @@ def count_batch(plan: CountPlan, node_ptr, edge_ptr, edge_index, ids_are_global=
         if len(n_classes) != plan.n_cols or min(n_classes) < 1:
             raise ValueError("encode: one n_classes >= 1 per output column (%d columns)" % plan.n_cols)
         enc_tab = np.asarray(n_classes, dtype=np.int32)
-        enc = encoded_out if encoded_out is not None else torch.empty((rows_total, sum(n_classes)), dtype=torch.float32, device=device)
-        if enc.shape != (rows_total, sum(n_classes)) or enc.dtype != torch.float32 or not enc.is_contiguous():
-            raise ValueError("encoded_out must be a contiguous fp32 [rows, sum(n_classes)] tensor")
+        pack_only = not encoded_rows
+        if pack_only and (encoded_pack is None or not counts or encoded_out is not None):
+            raise ValueError("encoded_rows=False: the encoded identifiers leave as pack columns next to the int64 counts (encoded_pack and counts=True, no encoded_out)")
+        if not pack_only:
+            enc = encoded_out if encoded_out is not None else torch.empty((rows_total, sum(n_classes)), dtype=torch.float32, device=device)
+            if enc.shape != (rows_total, sum(n_classes)) or enc.dtype != torch.float32 or not enc.is_contiguous():
+                raise ValueError("encoded_out must be a contiguous fp32 [rows, sum(n_classes)] tensor")
     if out is None and (counts or encode is None):
         out = torch.empty((rows_total, plan.n_cols), dtype=torch.int64, device=device)
     # (the library zeroes the status words of the graphs it counts; with a subset the others must read OK as well)
@@ -142,7 +150,18 @@ def count_batch(plan: CountPlan, node_ptr, edge_ptr, edge_index, ids_are_global=
                   ei.data_ptr() if E_total else None, ei.stride(0), int(bool(ids_are_global)), None if gid is None else gid.data_ptr(),
                   n_items, int(max_nodes), int(max_edges), None if out is None else out.data_ptr(), status.data_ptr())
         with _abi.device_guard(device):
-            if enc is None:
+            if encode is not None and pack_only:
+                # the int64 counts + the pack's identifier columns; no fp32 one-hot rows.  The layer input is a Codes object over the counts
+                # (clamped one-hot classes: exactly what the columns hold), tagged with the pack
+                pack, col0 = encoded_pack
+                if pack.dtype != torch.float16 or pack.dim() != 2 or pack.shape[0] != rows_total or not pack.is_contiguous() or pack.device != out.device:
+                    raise ValueError("encoded_pack: a contiguous fp16 [rows, cols] tensor on the device of the counts")
+                rc = _abi.lib().gsn_count_encode_pack16_hip(*common, _abi.ptr(enc_tab), int(bool(encode[1])), None, pack.data_ptr(),
+                                                            pack.shape[1], int(col0), _abi.current_stream())
+                if rc == -2:                         # GSN_E_UNSUPPORTED: rows not staged in this launch configuration -> counts, then the codes' own packer
+                    rc = _abi.lib().gsn_count_hip(*common, _abi.current_stream())
+                    pack_codes_later = True
+            elif enc is None:
                 rc = _abi.lib().gsn_count_hip(*common, _abi.current_stream())
             elif encoded_pack is None:
                 packs.release(enc)                  # (rewritten through its raw pointer: an earlier pack no longer describes it)
@@ -169,6 +188,14 @@ def count_batch(plan: CountPlan, node_ptr, edge_ptr, edge_index, ids_are_global=
         bad = np.nonzero(st > 1)[0]
         if len(bad):
             raise ValueError("graph %d: %s" % (int(bad[0]), _STATUS_MSG.get(int(st[bad[0]]), "status %d" % st[bad[0]])))
+    if encode is not None and pack_only:
+        from ._index import Codes
+        cd = Codes(out, n_classes, clamp=bool(clamp), check=False)
+        if pack_codes_later:
+            packs.pack_edge_codes(cd, encoded_pack[0], int(encoded_pack[1]))
+        elif n_graphs > 0 and n_items > 0:
+            packs._claim_codes(cd, encoded_pack[0], int(encoded_pack[1]))
+        return out, status, cd
     if encode is not None:
         return out, status, enc
     return out, status

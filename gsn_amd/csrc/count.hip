@@ -64,6 +64,7 @@ struct CountArgs {
     int off_encst;             // that array: [rows_cap][n_cols] bytes, 0xff = no class (count out of range, unclamped)
     int enc_from_counts;       // 1: no byte array -- the staged 16-bit counts (stage_out) give the class indices at the end (LDS per workgroup: occupancy)
     uint16_t *enc16;           // the same rows as fp16 into a column range of an exact row pack (gsn_count_encode_pack16_hip), or null; staged rows only
+    int enc_no32;              // 1: the fp16 pack columns are the ONLY form of the encoded rows (enc_out is a placeholder that is never written)
     int enc16_stride, enc16_col0;
 };
 
@@ -133,7 +134,7 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
         // caller under-declared max_nodes / max_edges: report, leave zeros
         if (part == 0) {
             if (a.out) for (int64_t i = tid; i < rows64 * n_cols; i += T) a.out[row0 * n_cols + i] = 0;
-            if (a.enc_out) for (int64_t i = tid; i < rows64 * a.enc_width; i += T) a.enc_out[row0 * a.enc_width + i] = 0.f;
+            if (a.enc_out && !a.enc_no32) for (int64_t i = tid; i < rows64 * a.enc_width; i += T) a.enc_out[row0 * a.enc_width + i] = 0.f;
             if (a.enc16) for (int64_t i = tid; i < rows64 * a.enc_width; i += T) a.enc16[(row0 + i / a.enc_width) * a.enc16_stride + a.enc16_col0 + i % a.enc_width] = 0;
             if (tid == 0) atomicMax(&a.status[g], (int)GSN_ST_TOO_LARGE);
         }
@@ -340,7 +341,8 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
         if (!report) return 1;
         if (part == 0) {
             if (a.out) for (int i = tid; i < rows * n_cols; i += T) a.out[row0 * n_cols + i] = 0;
-            if (a.enc_out) for (int i = tid; i < rows * a.enc_width; i += T) a.enc_out[row0 * a.enc_width + i] = 0.f;
+            if (a.enc_out && !a.enc_no32) for (int i = tid; i < rows * a.enc_width; i += T) a.enc_out[row0 * a.enc_width + i] = 0.f;
+            if (a.enc16 && a.enc_no32) for (int i = tid; i < rows * a.enc_width; i += T) a.enc16[(row0 + i / a.enc_width) * a.enc16_stride + a.enc16_col0 + i % a.enc_width] = 0;
             if (tid == 0) atomicMax(&a.status[g], misc[2]);
         }
         return 0;
@@ -512,6 +514,7 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
                 const int h0 = c0 == 0xff ? -1 : hot0 + c0, h1 = c1 == 0xff ? -1 : hot1 + c1;
                 const int h2 = c2 == 0xff ? -1 : hot2 + c2, h3 = c3 == 0xff ? -1 : hot3 + c3;
                 float4 *d4 = reinterpret_cast<float4 *>(dst + r * a.enc_width);
+                if (!a.enc_no32)
                 for (int k = 0; k < a.enc_width; k += 4) {
                     float4 o;
                     o.x = (h0 == k || h1 == k || h2 == k || h3 == k) ? 1.f : 0.f;
@@ -540,7 +543,7 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
             const int k = j - enc[2 * c];
             const int cls = a_enc_from_counts ? cls_from_count(out_lds[r * n_cols + c], c) : (int)est[r * n_cols + c];
             const bool hot = k < enc[2 * c + 1] && cls == k;
-            dst[i] = hot ? 1.f : 0.f;
+            if (!a.enc_no32) dst[i] = hot ? 1.f : 0.f;
             if (a.enc16) a.enc16[(row0 + r) * a.enc16_stride + a.enc16_col0 + j] = hot ? (uint16_t)0x3c00 : (uint16_t)0;
         }
     }
@@ -685,7 +688,7 @@ static int count_launch(const uint32_t *plan_host, const uint32_t *plan_dev, int
                         const int64_t *node_ptr, const int64_t *edge_ptr, const int64_t *edge_index,
                         int64_t edge_row_stride, int ids_are_global, const int32_t *graph_ids, int64_t n_items,
                         int64_t max_nodes, int64_t max_edges, int64_t *out, int32_t *status, const int32_t *n_classes,
-                        int enc_clamp, float *enc_out, void *stream, uint16_t *enc16 = nullptr, int64_t enc16_stride = 0, int64_t enc16_col0 = 0) {
+                        int enc_clamp, float *enc_out, void *stream, uint16_t *enc16 = nullptr, int64_t enc16_stride = 0, int64_t enc16_col0 = 0, int enc_no32 = 0) {
     if (!plan_host || !plan_dev || plan_words < PLAN_HEADER_WORDS || plan_host[0] != PLAN_MAGIC)
         return set_error(GSN_E_INVALID, "gsn_count_hip: not a plan table (build it with gsn_count_plan_build)");
     if (!node_ptr || !edge_ptr || (!out && !enc_out) || !status) return set_error(GSN_E_INVALID, "gsn_count_hip: null pointer argument");
@@ -828,6 +831,7 @@ static int count_launch(const uint32_t *plan_host, const uint32_t *plan_dev, int
     // every cell writes its floats itself
     a.enc_stage = 0; a.off_encst = o; a.enc_from_counts = 0;
     a.enc16 = enc16; a.enc16_stride = (int)enc16_stride; a.enc16_col0 = (int)enc16_col0;
+    a.enc_no32 = (enc16 && enc_no32) ? 1 : 0;
     if (enc_out && a.split == 1 && enc_bytes && rows_cap_u * enc_width < (int64_t)1 << 24 && o + rows_cap_u * a.n_cols <= 150 * 1024) {
         a.enc_stage = 1;
         static const bool bytes_forced = getenv("GSN_COUNT_ENC_BYTES") != nullptr;      // (A/B: keep the byte array beside staged counts)
@@ -885,11 +889,15 @@ extern "C" int gsn_count_encode_pack16_hip(const uint32_t *plan_host, const uint
                                            int64_t max_nodes, int64_t max_edges, int64_t *out, int32_t *status,
                                            const int32_t *n_classes, int clamp, float *enc_out, uint16_t *pack, int64_t pack_stride,
                                            int64_t pack_col0, void *stream) {
-    if (!enc_out || !pack) return set_error(GSN_E_INVALID, "gsn_count_encode_pack16_hip: enc_out / pack is null");
+    if (!pack) return set_error(GSN_E_INVALID, "gsn_count_encode_pack16_hip: pack is null");
+    // enc_out == NULL (r05): the pack columns are the only form of the encoded rows -- the fp32 one-hot rows (48 bytes per row of four 3-class
+    // columns) are not written at all; the kernel takes the same path with a placeholder address it never stores to
+    const int no32 = enc_out ? 0 : 1;
+    if (no32) enc_out = reinterpret_cast<float *>(pack);
     int64_t w = 0;
     if (n_classes && plan_host && plan_words >= PLAN_HEADER_WORDS) for (uint32_t c = 0; c < plan_host[4] && c < GSN_ENC_MAX_COLS; ++c) w += n_classes[c];
     if (pack_stride <= 0 || pack_stride > 0x7fffffff || pack_col0 < 0 || pack_col0 + w > pack_stride)
         return set_error(GSN_E_INVALID, "gsn_count_encode_pack16_hip: columns %lld .. %lld outside a pack row of %lld", (long long)pack_col0, (long long)(pack_col0 + w), (long long)pack_stride);
     return count_launch(plan_host, plan_dev, plan_words, n_graphs, node_ptr, edge_ptr, edge_index, edge_row_stride, ids_are_global,
-                        graph_ids, n_items, max_nodes, max_edges, out, status, n_classes, clamp, enc_out, stream, pack, pack_stride, pack_col0);
+                        graph_ids, n_items, max_nodes, max_edges, out, status, n_classes, clamp, enc_out, stream, pack, pack_stride, pack_col0, no32);
 }

@@ -148,7 +148,9 @@ int gsn_count_encode_hip(const uint32_t *plan_host, const uint32_t *plan_dev, in
 /* The same, and the encoded rows a second time as fp16 into columns pack_col0 .. of an exact row pack (gsn_pack16 below: the layout the
  * packed-row layer kernel reads; 1.0 = 0x3c00): `pack` fp16 device [rows_total][pack_stride], only the sum n_classes columns from
  * pack_col0 are written.  Written from the kernel's staged class indices: GSN_E_UNSUPPORTED when those are not staged (a graph split
- * over several workgroups, a column with more than 255 classes) -- pack the fp32 rows with gsn_pack16_rows_hip then. */
+ * over several workgroups, a column with more than 255 classes) -- pack the fp32 rows with gsn_pack16_rows_hip then.
+ * enc_out may be NULL (r05): the fp32 rows are then not written at all -- the int64 counts (`out`) and the pack columns are what leaves the
+ * kernel: what utils_ids.py:27 stores, and the encoder output (utils_graph_learning.py:170-187) in the form the packed-row layer reads. */
 int gsn_count_encode_pack16_hip(const uint32_t *plan_host, const uint32_t *plan_dev, int64_t plan_words, int64_t n_graphs,
                                 const int64_t *node_ptr, const int64_t *edge_ptr, const int64_t *edge_index,
                                 int64_t edge_row_stride, int ids_are_global, const int32_t *graph_ids, int64_t n_items,
