@@ -386,6 +386,7 @@ struct EmbArgs {
     float *gflat;                 // backward, flat variant: the gradient tables live in ONE allocation, table c at gflat + goff[c]
     int64_t goff[EMB_MAXC];       // (no device pointer array: nothing to copy per step, nothing for a graph replay to re-read)
     int vec4;                     // forward, whole rows: d a multiple of 4 and out 16-byte aligned -> 16-byte stores
+    int pipe;                     // forward, vec4: codes of the next 8-row group requested ahead, one coalesced load per group (GSN_EMBED_PIPE=0: off)
 };
 
 // NSUB: 64-column sub-slices per workgroup (slice = 64 NSUB columns of the embedding).  When the tables are small enough a workgroup
@@ -418,6 +419,69 @@ __global__ __launch_bounds__(256) void embed_lds_kernel(EmbArgs a) {
     const int64_t r0 = (int64_t)blockIdx.x * a.rows_per_wg;
     const int64_t r1 = r0 + a.rows_per_wg < a.m_rows ? r0 + a.rows_per_wg : a.m_rows;
     const int gw = a.concat ? a.n_cols * a.d : a.d;
+    if (!BWD && NSUB > 1 && a.vec4 && a.pipe) {
+        // r05: whole rows, 16-byte stores (below), with the codes of an 8-row group read by ONE coalesced request (slot s = u C + c on lane s, and on
+        // lane s - 64 as its second value: C <= 16) one group AHEAD, and handed to the wave with v_readlane.  The loop below waits for eight
+        // broadcast loads per code column -- C dependent round trips per 8 rows: 4 x 7 of them per workgroup with both edge encoders of an ogb layer
+        // in one call, which is what the 155 us per 214 500 x 300 rows were made of (the r04 lane-distributed variant had no prefetch and 3-4 columns).
+        constexpr int NV = (DCH / 4 + 63) / 64;
+        const int C = a.n_cols;
+        auto load_codes = [&](int64_t rb, int &c0, int &c1) {
+            c0 = c1 = -1;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int sl = lane + 64 * k;
+                if (sl < 8 * C) {
+                    const int u = sl / C, c = sl - u * C;
+                    const int64_t row = rb + u < r1 ? rb + u : r1 - 1;
+                    const int64_t v = a.codes[row * C + c];
+                    const int lo = a.row_off[c], rows_c = a.row_off[c + 1] - lo;
+                    const bool ok = v >= 0 && v < rows_c;
+                    if (!ok) atomicMax(a.status, GSN_ST_BAD_INDEX);
+                    const int t = ok ? lo + (int)v : -1;          // row of the concatenated LDS table, or none
+                    if (k == 0) c0 = t; else c1 = t;
+                }
+            }
+        };
+        int cur0 = -1, cur1 = -1;
+        int64_t rb = r0 + wave * 8;
+        if (rb < r1) load_codes(rb, cur0, cur1);
+        for (; rb < r1; rb += 8 * nwv) {
+            int nx0 = -1, nx1 = -1;
+            if (rb + 8 * nwv < r1) load_codes(rb + 8 * nwv, nx0, nx1);
+            float4 acc[8][NV];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int pv = 0; pv < NV; ++pv) acc[u][pv] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int c = 0; c < C; ++c) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int sl = u * C + c;                       // (uniform)
+                    const int t = sl < 64 ? __builtin_amdgcn_readlane(cur0, sl) : __builtin_amdgcn_readlane(cur1, sl - 64);
+                    const bool ok = t >= 0;
+                    const float *trow = tab + (ok ? t : 0) * DCH;
+#pragma unroll
+                    for (int pv = 0; pv < NV; ++pv) {
+                        const int j = 4 * (64 * pv + lane);
+                        if (j < DCH) {
+                            float4 v = *reinterpret_cast<const float4 *>(trow + j);
+                            if (!ok) v = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
+                            acc[u][pv].x += v.x; acc[u][pv].y += v.y; acc[u][pv].z += v.z; acc[u][pv].w += v.w;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int pv = 0; pv < NV; ++pv) {
+                    const int j = 4 * (64 * pv + lane);
+                    if (rb + u < r1 && j < a.d) *reinterpret_cast<float4 *>(a.out + (rb + u) * gw + j) = acc[u][pv];
+                }
+            cur0 = nx0; cur1 = nx1;
+        }
+    } else
     if (j0 + lane < a.d) {
         for (int64_t rb = r0 + wave * 8; rb < r1; rb += 8 * nwv) {
             if (BWD && !a.concat) {
@@ -568,6 +632,8 @@ static int launch_embed_lds_n(EmbArgs &a, int nwv, hipStream_t s) {
     const dim3 grid((unsigned)((a.m_rows + rpw - 1) / rpw), (unsigned)n_slices);
     static const bool no_vec4 = getenv("GSN_EMBED_NOVEC4") != nullptr;        // (A/B)
     a.vec4 = (!BWD && NSUB > 1 && !a.concat && a.d % 4 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0 && !no_vec4) ? 1 : 0;
+    static const bool no_pipe = [] { const char *e = getenv("GSN_EMBED_PIPE"); return e && atoi(e) == 0; }();
+    a.pipe = (a.vec4 && a.n_cols <= 16 && !no_pipe) ? 1 : 0;
     hipLaunchKernelGGL((embed_lds_kernel<BWD, NSUB>), grid, dim3(64 * nwv), lds, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(GSN_E_HIP, "embed_lds_kernel: %s", hipGetErrorString(e));
