@@ -938,8 +938,31 @@ def main():
         ids2 = torch.empty((b2.num_edges, plan.n_cols), dtype=torch.int64, device=dev)
         mn2, me2 = int(np.diff(b2.node_ptr).max()), int(np.diff(b2.edge_ptr).max())
 
+        headline_flow = use_pack and PACK_ONLY_IDS
+        if headline_flow:
+            # the headline step's flow at this size: integer codes in, CSR + code packs on the side stream, int64 identifiers + pack columns from
+            # the counting kernel, the packed-row layer kernel (rounds 1-4 and early r05 ran the r01 flow here: counts -> one-hot launch -> the
+            # layer on dense fp32 rows)
+            if os.environ.get("GSN_BENCH_GENERIC_CSR", "0") == "0":
+                layers.set_graph_partition(ei2, np2, ep2, mn2, me2, check=False)
+            xc2 = layers.Codes(torch.from_numpy(b2.atom_type).to(dev), [28])
+            efc2 = layers.Codes(torch.from_numpy(b2.bond_type).to(dev), [4])
+            npk2, epk2 = packs.new_node_pack(b2.num_nodes, dev), packs.new_edge_pack(b2.num_edges, dev)
+
         def step12k():
             layers._CSR_CACHE.clear()
+            if headline_flow:
+                main = torch.cuda.current_stream(dev)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    layers._csr_for(ei2, sel, b2.num_nodes)
+                    packs.pack_node_codes(xc2, npk2)
+                    packs.pack_edge_codes(efc2, epk2, 12)
+                idc2 = count_batch(plan, np2, ep2, ei2, ids_are_global=True, max_nodes=mn2, max_edges=me2, device=dev, check=False,
+                                   encode=([3, 3, 3, 3], True), counts=True, out=ids2, encoded_pack=(epk2, 0), encoded_rows=False)[2]
+                main.wait_stream(side)
+                with torch.no_grad():
+                    return layer(xc2, ei2, identifiers=idc2, degrees=deg2, edge_features=efc2)
             count_batch(plan, np2, ep2, ei2, ids_are_global=True, max_nodes=mn2, max_edges=me2, device=dev, out=ids2, check=False)
             idf2 = layers.one_hot_identifiers(ids2, [3, 3, 3, 3], clamp=True)
             with torch.no_grad():
@@ -956,7 +979,14 @@ def main():
         torch.cuda.synchronize()
         dt2 = time.perf_counter() - t2
         zinc12k = {"graphs_per_s": round(12000 * n12 / dt2, 1), "ms_per_step": round(dt2 / n12 * 1e3, 4), "steps": n12,
-                   "note": "BASELINE configs[1] dataset size: 12 000 ZINC-shaped graphs per step (N=%d, E=%d)" % (b2.num_nodes, b2.num_edges)}
+                   "note": "BASELINE configs[1] dataset size: 12 000 ZINC-shaped graphs per step (N=%d, E=%d); %s" % (
+                       b2.num_nodes, b2.num_edges, "the headline step's flow (codes in, int64 identifiers + layer rows out)" if headline_flow
+                       else "counts -> one-hot launch -> the layer on dense fp32 rows")}
+        # the 12 000-graph step's layer rows against the headline kernel's on the same graphs would need a second oracle pass; its int64
+        # identifiers are compared with a plain counting launch here
+        ids12 = ids2.clone()
+        count_batch(plan, np2, ep2, ei2, ids_are_global=True, max_nodes=mn2, max_edges=me2, device=dev, out=ids2, check=False)
+        zinc12k["int64_identifiers_equal_a_plain_counting_launch"] = bool(torch.equal(ids12, ids2))
 
     # Supplementary (never `value`): the reference's real batch sizes, the stand-alone aggregation stage, the layer on real-valued inputs
     small = prop = flt = wide = train4 = lin300 = er128 = train_small = None
