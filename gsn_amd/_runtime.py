@@ -2,6 +2,8 @@
 arenas, contiguity / device checks."""
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -54,7 +56,7 @@ def _need_cuda(t, what):
 # (device, stream, capture id): the fill runs on the stream the consumers run on, and an arena filled inside one graph capture is
 # never used by another capture or by eager launches (its fill is a node of that graph only).
 _ZARENA = {}
-_ZARENA_TIERS = ((256 * 1024, 64 * 1024), (8 * 1024 * 1024, 2 * 1024 * 1024))     # (arena bytes, largest request served from it)
+_ZARENA_TIERS = ((256 * 1024, 64 * 1024), (int(os.environ.get("GSN_ZERO_ARENA_MB", "32")) * 1024 * 1024, 2 * 1024 * 1024))     # (arena bytes, largest request served from it; the large tier: 8 MiB until the split-K outputs of a small-batch backward -- 18 x 1-2 MB per step -- made it four fills per step)
 
 
 _ITEMSIZE = {torch.float64: 8, torch.float32: 4, torch.int64: 8, torch.int32: 4, torch.float16: 2, torch.uint8: 1}
