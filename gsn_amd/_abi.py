@@ -91,6 +91,8 @@ SIGNATURES = {
                                            c_vp, c_vp]),
     "gsn_propagate_pad_bwd_hip": (c_int, [c_int, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_int,
                                           c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "gsn_propagate_bwd_fold_self_hip": (c_int, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp,
+                                                c_vp, c_vp, c_vp]),
     "gsn_linear_fwd_hip": (c_int, [c_i64, c_int, ctypes.POINTER(gsn_block), c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_int,
                                    c_vp, c_vp, c_vp, c_vp]),
     "gsn_one_hot_hip": (c_int, [c_i64, c_int, c_vp, c_vp, c_int, c_vp, c_vp]),

@@ -7,7 +7,7 @@ import weakref
 
 import torch
 
-from . import _abi
+from . import _abi, flags
 from ._runtime import _f32c, _need_cuda, _timed, _zeros
 
 class Codes:
@@ -421,6 +421,27 @@ class _PropagateFn(torch.autograd.Function):
         shared_bc = ctx.kind == 1 and g_c is not None and g_b is not None and not ctx.b_per_node
         if shared_bc:
             g_b = None
+        # the ogb layers: out = (1 + eps) x + sum relu(x_j + ..) with the self block BEING the gathered block -- its adjoint rides the node pass
+        # (gsn_propagate_bwd_fold_self_hip: g_a receives both contributions, g_eps its fp64 sum; no pass over [N d] for g_self, no
+        # gradient-accumulation add of g_a + g_self behind this function)
+        want_eps = ctx.has_eps and ctx.needs_input_grad[9]
+        folded = False
+        if (ctx.kind == 1 and ctx.n_self == 1 and not ctx.b_per_node and g_a is not None and E > 0 and (g_b is not None or g_c is not None)
+                and a is not None and ss[0].data_ptr() == a.data_ptr() and ss[0].shape == a.shape and ctx.needs_input_grad[10]
+                and ctx.pads == (0, 0) and flags.FOLD_SELF_ADJOINT):
+            acc = _zeros(1, torch.float64, dev) if want_eps else None
+            with _abi.device_guard(dev):
+                rc = _abi.lib().gsn_propagate_bwd_fold_self_hip(n, E, src.data_ptr(), tgt.data_ptr(), csr_s.seg_ptr.data_ptr(), csr_s.perm.data_ptr(),
+                                                                a.data_ptr(), wa, _abi.ptr(b), wb, _abi.ptr(c), wc, g_out.data_ptr(), g_a.data_ptr(),
+                                                                _abi.ptr(g_b), _abi.ptr(g_c), eps32.data_ptr() if ctx.has_eps else None,
+                                                                _abi.ptr(acc), _abi.current_stream())
+            if rc != -2:             # (GSN_E_UNSUPPORTED: nothing was launched -- the two-function path below)
+                _abi.check(rc, "gsn_propagate_bwd_fold_self_hip")
+                folded = True
+                if shared_bc:
+                    g_b = g_c
+                g_eps = acc[0].to(torch.float32).reshape(ctx.eps_shape) if want_eps else None
+                return (None, None, None, None, None, g_a, g_b, g_c, None, g_eps, None)
         if g_a is not None or g_b is not None or g_c is not None:
             with _abi.device_guard(dev):
                 rc = _abi.lib().gsn_propagate_pad_bwd_hip(ctx.kind, n, E, src.data_ptr() if E else None, tgt.data_ptr() if E else None,

@@ -642,6 +642,10 @@ struct PropBwdArgs {
     int pad_b, pad_c;         // CAT: zero columns in front of b / c (no gradient)
     float *g_a, *g_b, *g_c;
     const float *g_edge;      // RELU_SUM: the masked per-edge gradient the edge kernel has just written (g_c, or a per-edge g_b), or null
+    // r05: the layer's own term (1 + eps) * x folded into the node pass when the self block IS a (gsn_propagate_bwd_fold_self_hip)
+    int fold_self;
+    const float *eps;
+    double *g_eps;
 };
 
 // per-edge gradients: g_b[e] (if per-edge) and g_c[e]; one row group per edge, scalar columns
@@ -853,6 +857,10 @@ __global__ __launch_bounds__(256) void propagate_bwd_node_edge4_kernel(PropBwdAr
 
 // the same with the segment bounds of the group's next vertex and its first four edge ids requested before this vertex's rows, and the rows of two
 // edges in flight together (d <= 320); same order of additions
+// FOLD (the ogb layers: out = (1 + eps) x + sum relu(x_j + ..), the self block is the gathered block): g_a[s] += (1 + eps) g_out[s] in the same
+// pass, g_eps = sum g_out . a as fp64 partial sums -- instead of an elementwise pass over [N d] that writes g_self, and the gradient-accumulation
+// add of g_a + g_self behind it (two launches and six [N d] streams per layer and step)
+template <bool FOLD>
 __global__ __launch_bounds__(256) void propagate_bwd_node_edge4p_kernel(PropBwdArgs p) {
     const int lane = threadIdx.x & 63, sub = lane >> 4, li = lane & 15;
     const int q = p.d_out >> 2;
@@ -868,6 +876,8 @@ __global__ __launch_bounds__(256) void propagate_bwd_node_edge4p_kernel(PropBwdA
     };
     int64_t s = wave * 4 + sub;
     int32_t lo0, hi0, lo1, hi1, e0[4];
+    const float fold_sc = FOLD ? 1.f + (p.eps ? *p.eps : 0.f) : 0.f;
+    double fold_dot = 0.0;
     ldseg(s, lo0, hi0);
     ldseg(s + stride, lo1, hi1);
     ldidx(lo0, hi0, e0);
@@ -907,6 +917,22 @@ __global__ __launch_bounds__(256) void propagate_bwd_node_edge4p_kernel(PropBwdA
                 if (li + 16 * k < q) acc[k] = vadd(acc[k], row[li + 16 * k]);
         }
         if (s < nn) {
+            if (FOLD) {
+                const float4 *go = reinterpret_cast<const float4 *>(p.g_out + s * p.d_out);
+                const float4 *av = reinterpret_cast<const float4 *>(p.a + s * p.d_out);
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    const int c4 = li + 16 * k;
+                    if (c4 < q) {
+                        const float4 g = go[c4];
+                        acc[k] = make_float4(acc[k].x + g.x * fold_sc, acc[k].y + g.y * fold_sc, acc[k].z + g.z * fold_sc, acc[k].w + g.w * fold_sc);
+                        if (p.g_eps) {
+                            const float4 v = av[c4];
+                            fold_dot += (double)g.x * v.x + (double)g.y * v.y + (double)g.z * v.z + (double)g.w * v.w;
+                        }
+                    }
+                }
+            }
 #pragma unroll
             for (int k = 0; k < 5; ++k) {
                 const int c4 = li + 16 * k;
@@ -919,6 +945,14 @@ __global__ __launch_bounds__(256) void propagate_bwd_node_edge4p_kernel(PropBwdA
         lo0 = lo1; hi0 = hi1; lo1 = lo2; hi1 = hi2;
 #pragma unroll
         for (int u = 0; u < 4; ++u) e0[u] = e1[u];
+    }
+    if (FOLD && p.g_eps) {
+        double se = fold_dot;
+        for (int off = 32; off > 0; off >>= 1) se += __shfl_down(se, off);
+        __shared__ double red[4];
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = se;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(p.g_eps, red[0] + red[1] + red[2] + red[3]);
     }
 }
 
@@ -1529,10 +1563,44 @@ extern "C" int gsn_propagate_bwd_hip(int kind, int64_t n_nodes, int64_t n_edges,
                                      g_a, g_b, g_c, stream);
 }
 
+static int propagate_bwd_impl(int kind, int64_t n_nodes, int64_t n_edges, const int64_t *src, const int64_t *tgt,
+                              const int32_t *seg_ptr_src, const int32_t *perm_src, const float *a, int64_t da,
+                              const float *b, int64_t db, int b_per_node, const float *c, int64_t dc, int64_t pad_b,
+                              int64_t pad_c, const float *g_out, float *g_a, float *g_b, float *g_c, void *stream,
+                              int fold_self, const float *eps, double *g_eps);
+
 extern "C" int gsn_propagate_pad_bwd_hip(int kind, int64_t n_nodes, int64_t n_edges, const int64_t *src, const int64_t *tgt,
                                          const int32_t *seg_ptr_src, const int32_t *perm_src, const float *a, int64_t da,
                                          const float *b, int64_t db, int b_per_node, const float *c, int64_t dc, int64_t pad_b,
                                          int64_t pad_c, const float *g_out, float *g_a, float *g_b, float *g_c, void *stream) {
+    return propagate_bwd_impl(kind, n_nodes, n_edges, src, tgt, seg_ptr_src, perm_src, a, da, b, db, b_per_node, c, dc, pad_b, pad_c, g_out, g_a, g_b,
+                              g_c, stream, 0, nullptr, nullptr);
+}
+
+// The relu-sum adjoint of a layer whose own term is its gathered block:  out = (1 + eps) a + sum_{e -> t} relu(a[src_e] + b_e + c_e)
+// (GSN_edge_sparse_ogb.py:63-84 / :103-106 with self = x).  g_a receives BOTH contributions -- the per-source sums of the masked per-edge
+// gradients and (1 + eps) g_out -- in the node pass, g_eps (fp64, added to; may be null) = sum g_out . a.  Replaces gsn_propagate_pad_bwd_hip +
+// gsn_propagate_self_bwd_hip + the sum of their two results.  GSN_E_UNSUPPORTED (nothing launched) where the folded pass does not apply: no
+// edges, widths above 320 or not multiples of four, unaligned rows, no per-edge gradient asked for.
+extern "C" int gsn_propagate_bwd_fold_self_hip(int64_t n_nodes, int64_t n_edges, const int64_t *src, const int64_t *tgt,
+                                               const int32_t *seg_ptr_src, const int32_t *perm_src, const float *a, int64_t d, const float *b,
+                                               int64_t db, const float *c, int64_t dc, const float *g_out, float *g_a, float *g_b, float *g_c,
+                                               const float *eps, double *g_eps, void *stream) {
+    static const bool pipe = [] { const char *e = getenv("GSN_PROP_BWD_PIPE"); return !e || atoi(e) != 0; }();
+    static const bool fold = [] { const char *e = getenv("GSN_PROP_FOLD_SELF"); return !e || atoi(e) != 0; }();
+    const bool need_edge = (g_b && db) || (g_c && dc);
+    if (!fold || !pipe || !a || !g_a || !g_out || d <= 0 || d > 320 || (d & 3) || n_edges <= 0 || !need_edge || (db && db != d) || (dc && dc != d) ||
+        (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)g_out | (uintptr_t)g_a | (uintptr_t)g_b | (uintptr_t)g_c) % 16) != 0)
+        return set_error(GSN_E_UNSUPPORTED, "gsn_propagate_bwd_fold_self_hip: shape outside the folded pass");
+    return propagate_bwd_impl(GSN_MSG_RELU_SUM, n_nodes, n_edges, src, tgt, seg_ptr_src, perm_src, a, d, b, db, 0, c, dc, 0, 0, g_out, g_a, g_b, g_c,
+                              stream, 1, eps, g_eps);
+}
+
+static int propagate_bwd_impl(int kind, int64_t n_nodes, int64_t n_edges, const int64_t *src, const int64_t *tgt,
+                              const int32_t *seg_ptr_src, const int32_t *perm_src, const float *a, int64_t da,
+                              const float *b, int64_t db, int b_per_node, const float *c, int64_t dc, int64_t pad_b,
+                              int64_t pad_c, const float *g_out, float *g_a, float *g_b, float *g_c, void *stream,
+                              int fold_self, const float *eps, double *g_eps) {
     if (kind != GSN_MSG_CAT && kind != GSN_MSG_RELU_SUM) return set_error(GSN_E_INVALID, "gsn_propagate_bwd_hip: unknown kind %d", kind);
     if (!g_out || (n_edges > 0 && (!src || !tgt))) return set_error(GSN_E_INVALID, "gsn_propagate_bwd_hip: null pointer");
     if (pad_b < 0 || pad_c < 0 || ((pad_b || pad_c) && (kind != GSN_MSG_CAT || (pad_b && b_per_node))))
@@ -1553,6 +1621,7 @@ extern "C" int gsn_propagate_pad_bwd_hip(int kind, int64_t n_nodes, int64_t n_ed
     p.da = (int)da; p.db = (int)db; p.dc = (int)dc; p.d_out = (int)d_out; p.b_per_node = b_per_node;
     p.pad_b = (int)pad_b; p.pad_c = (int)pad_c;
     p.g_a = g_a; p.g_b = g_b; p.g_c = g_c;
+    p.fold_self = fold_self; p.eps = eps; p.g_eps = g_eps;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const bool need_edge = (g_b && !b_per_node && db) || (g_c && dc);
     if (need_edge && n_edges > 0) {
@@ -1583,7 +1652,10 @@ extern "C" int gsn_propagate_pad_bwd_hip(int kind, int64_t n_nodes, int64_t n_ed
             int64_t blocks = (n_nodes + 15) / 16;
             if (blocks > 16384) blocks = 16384;
             static const bool pipe = [] { const char *e = getenv("GSN_PROP_BWD_PIPE"); return !e || atoi(e) != 0; }();
-            if (pipe && d_out <= 320) hipLaunchKernelGGL(propagate_bwd_node_edge4p_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
+            if (p.fold_self) {
+                if (!(pipe && d_out <= 320)) return set_error(GSN_E_UNSUPPORTED, "gsn_propagate_bwd_fold_self_hip: the folded self term rides the pipelined node pass (d <= 320)");
+                hipLaunchKernelGGL(propagate_bwd_node_edge4p_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, p);
+            } else if (pipe && d_out <= 320) hipLaunchKernelGGL(propagate_bwd_node_edge4p_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, p);
             else hipLaunchKernelGGL(propagate_bwd_node_edge4_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
         } else {
             int64_t blocks = (n_nodes + 3) / 4;

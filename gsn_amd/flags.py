@@ -71,4 +71,7 @@ FOLD_KERNEL = os.environ.get("GSN_FOLD_KERNEL", "1") != "0"      # A/B switch: t
 # every table its gradient.  The sum is associated as ((id_0 + ..) + e_0 + ..) instead of (id) + (e): a reassociation of fp32 additions.
 FUSE_EDGE_ENCODERS = os.environ.get("GSN_FUSE_EDGE_ENCODERS", "1") != "0"
 
+# relu-sum layers whose own term is their gathered block (the ogb layers): the self term's adjoint inside the node pass of the propagate adjoint
+FOLD_SELF_ADJOINT = os.environ.get("GSN_FOLD_SELF_ADJOINT", "1") != "0"
+
 CODE_STATUS_CHECK = True   # read the out-of-range flag back after every code-gather launch (one host sync)

@@ -240,6 +240,13 @@ int gsn_propagate_pad_bwd_hip(int kind, int64_t n_nodes, int64_t n_edges, const 
                               const int32_t *seg_ptr_src, const int32_t *perm_src, const float *a, int64_t da,
                               const float *b, int64_t db, int b_per_node, const float *c, int64_t dc, int64_t pad_b, int64_t pad_c,
                               const float *g_out, float *g_a, float *g_b, float *g_c, void *stream);
+/* The relu-sum adjoint of a layer whose own term is its gathered block (out = (1 + eps) a + sum relu(a[src] + b + c): GSN_edge_sparse_ogb.py:63-84,
+ * :103-106 with self = x) in TWO launches: g_a receives the per-source sums of the masked per-edge gradients AND (1 + eps) g_out, g_eps (fp64, added
+ * to; may be NULL) = sum g_out . a.  Replaces gsn_propagate_pad_bwd_hip + gsn_propagate_self_bwd_hip + the sum of their results.  b / c per edge,
+ * widths d (or 0).  GSN_E_UNSUPPORTED (nothing launched): no edges, d > 320 or not a multiple of 4, unaligned rows, no per-edge gradient wanted. */
+int gsn_propagate_bwd_fold_self_hip(int64_t n_nodes, int64_t n_edges, const int64_t *src, const int64_t *tgt, const int32_t *seg_ptr_src,
+                                    const int32_t *perm_src, const float *a, int64_t d, const float *b, int64_t db, const float *c, int64_t dc,
+                                    const float *g_out, float *g_a, float *g_b, float *g_c, const float *eps, double *g_eps, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * HP-2  fused dense stage (device; fp32 in / fp32 out; matrix products run as six exact bf16 plane products per fp32
