@@ -952,15 +952,13 @@ def main():
         def step12k():
             layers._CSR_CACHE.clear()
             if headline_flow:
-                main = torch.cuda.current_stream(dev)
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    layers._csr_for(ei2, sel, b2.num_nodes)
-                    packs.pack_node_codes(xc2, npk2)
-                    packs.pack_edge_codes(efc2, epk2, 12)
+                # (one stream: at this size the step is 0.18 ms of GPU time and the second stream's events and waits make the HOST the
+                #  bound -- 0.205 ms per step enqueued against 0.178 in one chain, scripts/gpu/z12k.py; from ~16 000 graphs on the fork wins)
+                layers._csr_for(ei2, sel, b2.num_nodes)
+                packs.pack_node_codes(xc2, npk2)
+                packs.pack_edge_codes(efc2, epk2, 12)
                 idc2 = count_batch(plan, np2, ep2, ei2, ids_are_global=True, max_nodes=mn2, max_edges=me2, device=dev, check=False,
                                    encode=([3, 3, 3, 3], True), counts=True, out=ids2, encoded_pack=(epk2, 0), encoded_rows=False)[2]
-                main.wait_stream(side)
                 with torch.no_grad():
                     return layer(xc2, ei2, identifiers=idc2, degrees=deg2, edge_features=efc2)
             count_batch(plan, np2, ep2, ei2, ids_are_global=True, max_nodes=mn2, max_edges=me2, device=dev, out=ids2, check=False)
@@ -973,6 +971,7 @@ def main():
         for _ in range(100):
             step12k()
         torch.cuda.synchronize()
+        spin_up(step12k)
         t2 = time.perf_counter()
         for _ in range(n12):
             step12k()
