@@ -395,7 +395,7 @@ struct EmbArgs {
 template <bool BWD, int NSUB>
 __global__ __launch_bounds__(256) void embed_lds_kernel(EmbArgs a) {
     constexpr int DCH = EMB_DCH * NSUB;
-    extern __shared__ float tab[];                               // [sum rows][DCH]  (BWD: one copy per wave)
+    extern __shared__ __attribute__((aligned(16))) float tab[];      // [sum rows][DCH]  (BWD: one copy per wave)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nwv = blockDim.x >> 6;
     const int j0 = blockIdx.y * DCH;
@@ -405,6 +405,28 @@ __global__ __launch_bounds__(256) void embed_lds_kernel(EmbArgs a) {
     float *mine = tab + (BWD ? wave * total_rows * DCH : 0);
     if (BWD) {
         for (int i = threadIdx.x; i < nwv * total_rows * DCH; i += blockDim.x) tab[i] = 0.f;
+    } else if (NSUB > 1 && a.pipe) {
+        // whole rows, d a multiple of four (a.pipe implies both): the tables' pointers and row offsets go to LDS first (ONE round trip for all
+        // columns instead of one per column in front of that column's copy), then one flat loop of 16-byte copies over every (table row, chunk)
+        __shared__ const float *tps[EMB_MAXC];
+        __shared__ int roff[EMB_MAXC + 1];
+        if (threadIdx.x <= (unsigned)a.n_cols) roff[threadIdx.x] = a.row_off[threadIdx.x];
+        if (threadIdx.x < (unsigned)a.n_cols) tps[threadIdx.x] = reinterpret_cast<const float *>(a.meta[threadIdx.x]);
+        __syncthreads();
+        constexpr int CH = DCH / 4;
+        const int d4 = a.d >> 2;
+        for (int i = threadIdx.x; i < total_rows * CH; i += blockDim.x) {
+            const int trow = i / CH, ch = i - trow * CH;
+            int c = 0;
+            for (int q = 1; q < a.n_cols; ++q) c = trow >= roff[q] ? q : c;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ch < d4) {
+                const float *src = tps[c] + (int64_t)(trow - roff[c]) * a.d + 4 * ch;
+                if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) v = *reinterpret_cast<const float4 *>(src);
+                else v = make_float4(src[0], src[1], src[2], src[3]);        // (a table that is a view at an odd offset of a flat parameter buffer)
+            }
+            *reinterpret_cast<float4 *>(tab + trow * DCH + 4 * ch) = v;
+        }
     } else {
         for (int c = 0; c < a.n_cols; ++c) {
             const float *t = reinterpret_cast<const float *>(a.meta[c]);
