@@ -41,6 +41,26 @@ class gsn_pack16(ctypes.Structure):
     _fields_ = [("node_rows", c_vp), ("edge_rows", c_vp)]
 
 
+class gsn_count_side(ctypes.Structure):
+    _fields_ = [("csr_row", c_int), ("seg_ptr", c_vp), ("perm", c_vp), ("sorted_target", c_vp), ("sorted_other", c_vp),
+                ("n_nodes", c_i64), ("n_edges", c_i64), ("node_codes", c_vp), ("node_code_cols", c_int), ("node_n_classes", c_int * 4),
+                ("node_clamp", c_int), ("node_pack", c_vp), ("edge_codes", c_vp), ("edge_code_cols", c_int), ("edge_n_classes", c_int * 4),
+                ("edge_clamp", c_int), ("edge_col0", c_int), ("code_status", c_vp)]
+
+
+class gsn_count_call(ctypes.Structure):
+    _fields_ = [("plan_host", c_vp), ("plan_dev", c_vp), ("plan_words", c_i64), ("n_graphs", c_i64), ("node_ptr", c_vp), ("edge_ptr", c_vp),
+                ("edge_index", c_vp), ("edge_row_stride", c_i64), ("ids_are_global", c_int), ("max_nodes", c_i64), ("max_edges", c_i64),
+                ("out", c_vp), ("status", c_vp), ("n_classes", c_vp), ("clamp", c_int), ("pack", c_vp), ("pack_stride", c_i64),
+                ("pack_col0", c_i64), ("side", ctypes.POINTER(gsn_count_side))]
+
+
+class gsn_layer_pack16_call(ctypes.Structure):
+    _fields_ = [("n_nodes", c_i64), ("n_edges", c_i64), ("seg_ptr", c_vp), ("edge", ctypes.POINTER(gsn_chain_stage)), ("x", c_vp), ("d_x", c_i64),
+                ("node0", ctypes.POINTER(gsn_chain_stage)), ("node1", ctypes.POINTER(gsn_chain_stage)), ("prepared", c_vp),
+                ("pack", ctypes.POINTER(gsn_pack16)), ("edge_rows", c_i64), ("out", c_vp)]
+
+
 # name -> (restype, argtypes); kept in one place so tests can check it against include/gsn_abi.h
 class gsn_code_slot(ctypes.Structure):
     _fields_ = [("codes", ctypes.c_void_p), ("idx", ctypes.c_void_p), ("stride", ctypes.c_int32), ("col", ctypes.c_int32),
@@ -62,6 +82,9 @@ SIGNATURES = {
                                      c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
     "gsn_count_encode_pack16_hip": (c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_i64, c_i64,
                                             c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_i64, c_vp]),
+    "gsn_count_encode_pack16_side_hip": (c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_int, c_i64, c_i64, c_vp, c_vp, c_vp, c_int,
+                                                 c_vp, c_i64, c_i64, ctypes.POINTER(gsn_count_side), c_vp]),
+    "gsn_count_layer_step_hip": (c_int, [ctypes.POINTER(gsn_count_call), ctypes.POINTER(gsn_layer_pack16_call), c_vp]),
     "gsn_pack16_rows_hip": (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp]),
     "gsn_one_hot_pack16_hip": (c_int, [c_i64, c_int, c_vp, c_vp, c_int, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp]),
     "gsn_csr_scratch_elems": (c_i64, [c_i64]),

@@ -181,13 +181,7 @@ def count_batch(plan: CountPlan, node_ptr, edge_ptr, edge_index, ids_are_global=
                     packs.claim(enc, pack, int(col0))
         _abi.check(rc, "gsn_count_hip" if enc is None else "gsn_count_encode_hip")
     if check:
-        st = status.cpu().numpy()
-        if (st == 1).any():
-            raise KeyError("graph %d: a match maps a pattern edge onto a direction that is not a column of edge_index "
-                           "(reference: utils_graph_processing.py:173)" % int(np.nonzero(st == 1)[0][0]))
-        bad = np.nonzero(st > 1)[0]
-        if len(bad):
-            raise ValueError("graph %d: %s" % (int(bad[0]), _STATUS_MSG.get(int(st[bad[0]]), "status %d" % st[bad[0]])))
+        _raise_statuses(status)
     if encode is not None and pack_only:
         from ._index import Codes
         cd = Codes(out, n_classes, clamp=bool(clamp), check=False)
@@ -199,6 +193,108 @@ def count_batch(plan: CountPlan, node_ptr, edge_ptr, edge_index, ids_are_global=
     if encode is not None:
         return out, status, enc
     return out, status
+
+
+def count_batch_side(plan, node_ptr, edge_ptr, edge_index, max_nodes, max_edges, id_classes=None, clamp=True, x_codes=None, ef_codes=None,
+                     csr_row=None, out=None, ids_are_global=True, register=True, n_nodes=None):
+    """:func:`count_batch` whose workgroups also leave what the first GSN layer needs (``gsn_count_encode_pack16_side_hip``): the
+    target-sorted CSR of ``edge_index[csr_row]`` (``csr_row`` 0 / 1, None: no CSR; GSN_sparse.py:140-143), the node pack of the integer
+    vertex codes ``x_codes`` (:class:`gsn_amd.layers.Codes`; utils_graph_learning.py:170-187) and -- edge-mode plans with ``id_classes`` --
+    the whole edge pack rows: the identifiers' one-hot classes next to the one-hot of the edge codes ``ef_codes``.
+
+    node_ptr / edge_ptr int64 device [G + 1] of a collated batch (node_ptr[0] = 0), edge_index int64 device [2, E].  Returns a dict:
+    ``ids`` int64 [rows, plan.n_cols], ``status`` int32 [G] (not read back), ``code_status`` int32 [1], ``csr`` (a layers-side CSR object
+    or None), ``node_pack`` / ``edge_pack`` (fp16 tensors or None), ``id_codes`` (a Codes object over ``ids`` tagged with the edge pack, or
+    None).  ``register``: enter the CSR into the layers' per-tensor cache for ``edge_index`` and tag the Codes objects with their packs, so
+    that ``layer(x_codes, edge_index, identifiers=id_codes, edge_features=ef_codes)`` right behind this call launches the layer kernel
+    and nothing else.  GsnError(GSN_E_UNSUPPORTED) when this launch configuration cannot write them (a graph split over workgroups)."""
+    from ._index import Codes, _CSR, _cache_put
+    _abi.require_gpu()
+    dev = edge_index.device
+    if not (edge_index.is_cuda and node_ptr.is_cuda and edge_ptr.is_cuda) or edge_index.dtype != torch.int64 or edge_index.stride(1) != 1:
+        raise ValueError("count_batch_side: node_ptr, edge_ptr, edge_index int64 on the GPU (edge_index with unit column stride)")
+    G = node_ptr.numel() - 1
+    E = edge_index.shape[1]
+    N = int(x_codes.codes.shape[0]) if x_codes is not None else (int(n_nodes) if n_nodes is not None else int(node_ptr[-1].item()))      # (one host read without either)
+    rows = E if plan.mode == "edge" else N
+    if out is None:
+        out = torch.empty((rows, plan.n_cols), dtype=torch.int64, device=dev)
+    status = torch.empty(max(G, 1), dtype=torch.int32, device=dev)
+    code_status = torch.zeros(1, dtype=torch.int32, device=dev)
+    side = _abi.gsn_count_side()
+    csr = None
+    if csr_row is not None:
+        csr = _CSR()
+        csr.seg_ptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
+        csr.perm, csr.tgt, csr.src = (torch.empty(max(E, 1), dtype=torch.int32, device=dev)[:E] for _ in range(3))
+        csr._deg = csr._deg4 = None
+        csr.part = None
+        side.csr_row = int(csr_row); side.seg_ptr = csr.seg_ptr.data_ptr(); side.perm = csr.perm.data_ptr() if E else None
+        side.sorted_target = csr.tgt.data_ptr() if E else None; side.sorted_other = csr.src.data_ptr() if E else None
+        if E == 0:
+            side.perm = csr.seg_ptr.data_ptr()          # (never written: no columns)
+    side.n_nodes, side.n_edges = N, E
+    npack = epack = None
+    if x_codes is not None:
+        if len(x_codes.n_classes) > 4 or sum(x_codes.n_classes) > packs.NODE_COLS - 4:
+            raise ValueError("count_batch_side: <= 4 vertex code columns, <= %d classes together" % (packs.NODE_COLS - 4))
+        npack = torch.empty((N, packs.NODE_COLS), dtype=torch.float16, device=dev)
+        side.node_codes = x_codes.codes.data_ptr(); side.node_code_cols = len(x_codes.n_classes); side.node_clamp = int(x_codes.clamp)
+        for i, c in enumerate(x_codes.n_classes):
+            side.node_n_classes[i] = c
+        side.node_pack = npack.data_ptr()
+    enc_tab = None
+    w_ids = 0
+    if id_classes is not None:
+        id_classes = [int(c) for c in id_classes]
+        if plan.mode != "edge" or len(id_classes) != plan.n_cols:
+            raise ValueError("count_batch_side: id_classes = one class count per column of an edge-mode plan")
+        enc_tab = np.asarray(id_classes, dtype=np.int32)
+        w_ids = sum(id_classes)
+        epack = (torch.empty if ef_codes is not None else torch.zeros)((max(E, 1), packs.EDGE_COLS), dtype=torch.float16, device=dev)[:E]
+    if ef_codes is not None:
+        if epack is None or len(ef_codes.n_classes) > 4 or w_ids + sum(ef_codes.n_classes) > packs.EDGE_COLS or w_ids % 4 or sum(ef_codes.n_classes) > 8:
+            raise ValueError("count_batch_side: edge codes ride the identifiers' edge pack (id_classes; <= %d columns together, the identifiers' a "
+                             "multiple of 4, <= 8 edge code classes)" % packs.EDGE_COLS)
+        side.edge_codes = ef_codes.codes.data_ptr(); side.edge_code_cols = len(ef_codes.n_classes); side.edge_clamp = int(ef_codes.clamp)
+        for i, c in enumerate(ef_codes.n_classes):
+            side.edge_n_classes[i] = c
+        side.edge_col0 = w_ids
+    side.code_status = code_status.data_ptr()
+    if G > 0:
+        tab = plan.device_table(dev)
+        with _abi.device_guard(dev):
+            rc = _abi.lib().gsn_count_encode_pack16_side_hip(_abi.ptr(plan.table), tab.data_ptr(), len(plan.table), G, node_ptr.data_ptr(), edge_ptr.data_ptr(),
+                                                             edge_index.data_ptr() if E else None, edge_index.stride(0), int(bool(ids_are_global)),
+                                                             int(max_nodes), int(max_edges), out.data_ptr(), status.data_ptr(), _abi.ptr(enc_tab),
+                                                             int(bool(clamp)), _abi.ptr(epack) if E else None, packs.EDGE_COLS, 0, ctypes.byref(side),
+                                                             _abi.current_stream())
+        _abi.check(rc, "gsn_count_encode_pack16_side_hip")
+    id_codes = None
+    if epack is not None:
+        id_codes = Codes(out, id_classes, clamp=bool(clamp), check=False)
+    if register:
+        if csr is not None:
+            _cache_put((id(edge_index), int(csr_row), N), edge_index, csr)
+        if npack is not None:
+            npack._gsn_node_pack = True
+            packs._claim_codes(x_codes, npack, 0)
+        if id_codes is not None:
+            packs._claim_codes(id_codes, epack, 0)
+            if ef_codes is not None:
+                packs._claim_codes(ef_codes, epack, w_ids)
+    return {"ids": out, "status": status, "code_status": code_status, "csr": csr, "node_pack": npack, "edge_pack": epack, "id_codes": id_codes}
+
+
+def _raise_statuses(status):
+    """Read the per-graph status words back and raise what the reference raises (KeyError: utils_graph_processing.py:173)."""
+    st = status.cpu().numpy()
+    if (st == 1).any():
+        raise KeyError("graph %d: a match maps a pattern edge onto a direction that is not a column of edge_index "
+                       "(reference: utils_graph_processing.py:173)" % int(np.nonzero(st == 1)[0][0]))
+    bad = np.nonzero(st > 1)[0]
+    if len(bad):
+        raise ValueError("graph %d: %s" % (int(bad[0]), _STATUS_MSG.get(int(st[bad[0]]), "status %d" % st[bad[0]])))
 
 
 def counts2ids_batch(batch, pattern_edge_lists, mode, induced, directed_orbits=False, device=None, directed=False):

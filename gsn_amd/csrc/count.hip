@@ -24,6 +24,24 @@ namespace gsn {
 
 constexpr int GSN_ENC_MAX_COLS = 64;
 
+// What gsn_count_encode_pack16_side_hip adds to a counting launch (r06): the target-sorted CSR of the batch's columns, the node pack from
+// integer node codes, the edge codes' one-hot columns of the edge pack.  They are made by SIDE WORKGROUPS of the same launch (side_block
+// below), every (SIDE_EVERY + 1)-th workgroup of the grid; the counting workgroups run count_body exactly as without them.
+struct SideArgs {
+    int32_t *csr_seg, *csr_perm, *csr_tgt, *csr_oth;   // csr_seg == null: no CSR
+    int64_t tot_nodes, tot_edges;
+    const int64_t *ncode;      // node codes [tot_nodes][ncode_cols] or null
+    uint16_t *npack;           // fp16 [tot_nodes][32]
+    const int64_t *ecode;      // edge codes [tot_edges][ecode_cols] or null
+    uint16_t *epack;           // fp16 [tot_edges][16]: columns ecode_col0 .. 15 are written
+    int32_t *code_status;      // or null
+    int csr_row;               // the row of edge_index that is the aggregation target
+    int ncode_cols, ncode_clamp, ecode_cols, ecode_clamp, ecode_col0;
+    unsigned ncode_ptr_w[2], ecode_ptr_w[2];    // first pack column of every code column's classes, one BYTE per column + the end (prefix sums; the
+                                                // edge codes' start at ecode_col0) -- as words: byte-sized kernel arguments are vector loads on gfx9
+};
+constexpr int SIDE_EVERY = 4;  // counting workgroups per side workgroup
+
 struct CountArgs {
     const uint32_t *plan;      // device
     int plan_words;
@@ -66,7 +84,272 @@ struct CountArgs {
     uint16_t *enc16;           // the same rows as fp16 into a column range of an exact row pack (gsn_count_encode_pack16_hip), or null; staged rows only
     int enc_no32;              // 1: the fp16 pack columns are the ONLY form of the encoded rows (enc_out is a placeholder that is never written)
     int enc16_stride, enc16_col0;
+    int side_mask;             // bit 0: CSR, bit 1: node pack, bit 2: edge codes; != 0: the grid holds side workgroups
+    int n_items;               // counting work items of the launch (graphs, or pairs of graphs)
+    int lds_bytes;             // dynamic LDS of the launch (a side workgroup sorts as many graphs at a time as fit there)
+    SideArgs side;
 };
+
+// The side arguments are read from the kernel-argument segment where they are used (scalar loads through a laundered pointer), not held in
+// scalar registers from the kernel's entry: the molecule instantiation runs at its register bound (amdgpu_waves_per_eu).
+typedef const SideArgs __attribute__((address_space(4))) *side_ptr_t;
+__device__ __forceinline__ side_ptr_t side_late() {
+    typedef const unsigned char __attribute__((address_space(4))) *kptr_t;
+    kptr_t k = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(k));
+    return (side_ptr_t)(k + offsetof(CountArgs, side));
+}
+__device__ __forceinline__ int side_byte(const unsigned w0, const unsigned w1, const int c) { return (int)(((c < 4 ? w0 : w1) >> (8 * (c & 3))) & 0xffu); }
+
+// One side workgroup: the graphs g_lo .. g_hi - 1 (those of the SIDE_EVERY counting workgroups dispatched right in front of it), taken in
+// chunks of consecutive graphs that fit the launch's LDS together.  A chunk is a disjoint union -- consecutive vertex ids, consecutive
+// columns, no column between two graphs -- so ONE stable counting sort by target sorts all its graphs (what csr_graphs_kernel does per
+// graph in a launch of its own; GSN_sparse.py:140-143).  Per chunk: (A) every global load -- targets, sources, vertex codes, edge codes --
+// in batches of four per lane, results into LDS; (B) histogram, scan, placement, order restore in LDS; (C) every global store: seg_ptr,
+// perm / sorted targets / sorted sources, the node pack rows (four lanes per 64-byte row; what gsn_one_hot_pack16_hip writes,
+// utils_graph_learning.py:170-187), the edge codes' columns of the edge pack.  Loads and stores are kept apart because gfx9 counts them in one
+// counter: a load issued behind a store waits for the store's acknowledgement too.  Statuses stay with the counting workgroups (they test every
+// column's endpoints against their graph); a code outside its classes ORs 1 into *code_status.
+template <int T>
+__device__ __forceinline__ void side_block(const CountArgs &a, unsigned char *smem, const int g_lo, const int g_hi) {
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+    const side_ptr_t sd = side_late();
+    const int tid = threadIdx.x;
+    const bool do_csr = (a.side_mask & 1) != 0, do_np = (a.side_mask & 2) != 0, do_ec = (a.side_mask & 4) != 0;
+    const int64_t *trow = sd->csr_row ? a.dst : a.src, *orow = sd->csr_row ? a.src : a.dst;
+    auto need = [&](int64_t n, int64_t E) { return (n + 1) * 8 + n * 4 + E * 7 + 16; };
+    if (do_csr) {
+        // the ends of seg_ptr: vertices in front of the first graph (none in a collated batch) and the closing entries behind the last
+        if (g_lo == 0) for (int64_t v = tid; v < a.node_ptr[0]; v += T) sd->csr_seg[v] = 0;
+        if (g_hi == a.n_graphs) for (int64_t v = a.node_ptr[g_hi] + tid; v <= sd->tot_nodes; v += T) sd->csr_seg[v] = (int32_t)sd->tot_edges;
+    }
+    int g = g_lo;
+    while (g < g_hi) {
+        const int64_t n0 = a.node_ptr[g], e0 = a.edge_ptr[g];
+        int g2 = g + 1;
+        int64_t n64 = a.node_ptr[g2] - n0, E64 = a.edge_ptr[g2] - e0;
+        const bool fits = n64 >= 0 && E64 >= 0 && n64 < 65535 && E64 < 65535 && need(n64, E64) <= a.lds_bytes;
+        if (fits && a.ids_are_global)
+            while (g2 < g_hi) {                          // (graph-local ids: one graph per chunk -- the offset of a column depends on its graph)
+                const int64_t n2 = a.node_ptr[g2 + 1] - n0, E2 = a.edge_ptr[g2 + 1] - e0;
+                if (n2 < n64 || E2 < E64 || n2 >= 65535 || E2 >= 65535 || need(n2, E2) > a.lds_bytes) break;
+                n64 = n2; E64 = E2; ++g2;
+            }
+        g = g2;
+        if (!fits) {
+            // a graph beyond what the launch's LDS sorts (the counting workgroup reports it: GSN_ST_TOO_LARGE): its vertices own no columns, its
+            // columns map to themselves (as csr_graphs_kernel); its rows of the packs are encoded by the plain loops
+            if (n64 < 0 || E64 < 0) continue;
+            if (do_csr) {
+                for (int64_t v = tid; v < n64; v += T) sd->csr_seg[n0 + v] = (int32_t)e0;
+                for (int64_t e = tid; e < E64; e += T) {
+                    sd->csr_perm[e0 + e] = (int32_t)(e0 + e);
+                    if (sd->csr_tgt) sd->csr_tgt[e0 + e] = (int32_t)n0;
+                    if (sd->csr_oth) sd->csr_oth[e0 + e] = (int32_t)n0;
+                }
+            }
+            if (do_np) {
+                const unsigned w0 = sd->ncode_ptr_w[0], w1 = sd->ncode_ptr_w[1];
+                for (int64_t i = tid; i < 4 * n64; i += T) {
+                    const int64_t v = i >> 2;
+                    const int q = (int)(i & 3);
+                    unsigned m = 0x80000000u;
+                    for (int c = 0; c < sd->ncode_cols; ++c) {
+                        int64_t x = sd->ncode[(n0 + v) * sd->ncode_cols + c];
+                        const int lo = side_byte(w0, w1, c), ncls = side_byte(w0, w1, c + 1) - lo;
+                        if (sd->ncode_clamp) x = x < 0 ? 0 : (x >= ncls ? ncls - 1 : x);
+                        if (x >= 0 && x < ncls) m |= 1u << (lo + (int)x);
+                        else if (sd->code_status && q == 0) atomicOr(sd->code_status, 1);
+                    }
+                    const unsigned hot = m >> (8 * q);
+                    auto word = [&](int kk) { return ((hot >> kk) & 1u ? 0x3c00u : 0u) | ((hot >> (kk + 1)) & 1u ? 0x3c000000u : 0u); };
+                    *reinterpret_cast<u4v *>(sd->npack + (n0 + v) * 32 + 8 * q) = u4v{word(0), word(2), word(4), word(6)};
+                }
+            }
+            if (do_ec) {
+                const unsigned w0 = sd->ecode_ptr_w[0], w1 = sd->ecode_ptr_w[1];
+                const int q0 = sd->ecode_col0 >> 2;
+                for (int64_t i = tid; i < E64 * (4 - q0); i += T) {
+                    const int64_t r = i / (4 - q0);
+                    const int q = q0 + (int)(i - r * (4 - q0));
+                    unsigned hot = 0;
+                    for (int c = 0; c < sd->ecode_cols; ++c) {
+                        int64_t x = sd->ecode[(e0 + r) * sd->ecode_cols + c];
+                        const int lo = side_byte(w0, w1, c), ncls = side_byte(w0, w1, c + 1) - lo;
+                        if (sd->ecode_clamp) x = x < 0 ? 0 : (x >= ncls ? ncls - 1 : x);
+                        if (x >= 0 && x < ncls) hot |= 1u << (lo + (int)x);
+                        else if (sd->code_status && q == q0) atomicOr(sd->code_status, 1);
+                    }
+                    hot >>= 4 * q;
+                    uint2 o;
+                    o.x = ((hot & 1u) ? 0x3c00u : 0u) | ((hot & 2u) ? 0x3c000000u : 0u);
+                    o.y = ((hot & 4u) ? 0x3c00u : 0u) | ((hot & 8u) ? 0x3c000000u : 0u);
+                    *reinterpret_cast<uint2 *>(sd->epack + (e0 + r) * 16 + 4 * q) = o;
+                }
+            }
+            continue;
+        }
+        const int n = (int)n64, E = (int)E64;
+        int *cstart = reinterpret_cast<int *>(smem);
+        int *ccur = cstart + (n + 1);
+        unsigned *nmask = reinterpret_cast<unsigned *>(ccur + (n + 1));
+        uint16_t *tloc = reinterpret_cast<uint16_t *>(nmask + n);
+        uint16_t *oloc = tloc + E;
+        uint16_t *pl = oloc + E;
+        unsigned char *ecls = reinterpret_cast<unsigned char *>(pl + E);      // bit mask of the edge codes' classes over pack columns ecode_col0 .. +7
+        __syncthreads();                                 // (the chunk before this one has left LDS)
+        for (int v = tid; v <= n; v += T) cstart[v] = 0;
+        __syncthreads();
+        // ---- (A) loads: four per lane in flight --------------------------------------------------------------------------
+        const int64_t off = a.ids_are_global ? n0 : 0;   // (graph-local ids: the chunk is one graph)
+        bool bad_code = false;
+        if (do_csr)
+            for (int c0 = 0; c0 < E; c0 += 4 * T) {
+                int64_t tq[4], oq[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const int c = c0 + j * T + tid; tq[j] = c < E ? trow[e0 + c] : off; oq[j] = c < E ? orow[e0 + c] : off; }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = c0 + j * T + tid;
+                    if (c < E) {
+                        const int64_t t = tq[j] - off, o = oq[j] - off;
+                        const int tl = (t >= 0 && t < n) ? (int)t : 0, ol = (o >= 0 && o < n) ? (int)o : 0;     // (a column that leaves its graph: the counting workgroup reports it)
+                        tloc[c] = (uint16_t)tl; oloc[c] = (uint16_t)ol;
+                        atomicAdd(&cstart[tl], 1);
+                    }
+                }
+            }
+        if (do_np) {
+            const unsigned w0 = sd->ncode_ptr_w[0], w1 = sd->ncode_ptr_w[1];
+            const int nc = sd->ncode_cols;
+            for (int v0 = 0; v0 < n; v0 += 4 * T) {
+                if (nc == 1) {
+                    int64_t xq[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { const int v = v0 + j * T + tid; xq[j] = v < n ? sd->ncode[n0 + v] : 0; }
+                    const int ncls = side_byte(w0, w1, 1);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int v = v0 + j * T + tid;
+                        int64_t x = xq[j];
+                        if (sd->ncode_clamp) x = x < 0 ? 0 : (x >= ncls ? ncls - 1 : x);
+                        const bool ok = x >= 0 && x < ncls;
+                        if (v < n) { nmask[v] = 0x80000000u | (ok ? 1u << (int)x : 0u); bad_code = bad_code || !ok; }
+                    }
+                } else {
+                    for (int j = 0; j < 4; ++j) {
+                        const int v = v0 + j * T + tid;
+                        if (v >= n) break;
+                        unsigned m = 0x80000000u;
+                        for (int c = 0; c < nc; ++c) {
+                            int64_t x = sd->ncode[(n0 + v) * nc + c];
+                            const int lo = side_byte(w0, w1, c), ncls = side_byte(w0, w1, c + 1) - lo;
+                            if (sd->ncode_clamp) x = x < 0 ? 0 : (x >= ncls ? ncls - 1 : x);
+                            if (x >= 0 && x < ncls) m |= 1u << (lo + (int)x); else bad_code = true;
+                        }
+                        nmask[v] = m;
+                    }
+                }
+            }
+        }
+        if (do_ec) {
+            const unsigned w0 = sd->ecode_ptr_w[0], w1 = sd->ecode_ptr_w[1];
+            const int nc = sd->ecode_cols, c00 = sd->ecode_col0;
+            for (int r0 = 0; r0 < E; r0 += 4 * T) {
+                if (nc == 1) {
+                    int64_t xq[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { const int r = r0 + j * T + tid; xq[j] = r < E ? sd->ecode[e0 + r] : 0; }
+                    const int ncls = side_byte(w0, w1, 1) - c00;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int r = r0 + j * T + tid;
+                        int64_t x = xq[j];
+                        if (sd->ecode_clamp) x = x < 0 ? 0 : (x >= ncls ? ncls - 1 : x);
+                        const bool ok = x >= 0 && x < ncls;
+                        if (r < E) { ecls[r] = ok ? (unsigned char)(1u << (int)x) : (unsigned char)0; bad_code = bad_code || !ok; }
+                    }
+                } else {
+                    for (int j = 0; j < 4; ++j) {
+                        const int r = r0 + j * T + tid;
+                        if (r >= E) break;
+                        unsigned m = 0;
+                        for (int c = 0; c < nc; ++c) {
+                            int64_t x = sd->ecode[(e0 + r) * nc + c];
+                            const int lo = side_byte(w0, w1, c) - c00, ncls = side_byte(w0, w1, c + 1) - c00 - lo;
+                            if (sd->ecode_clamp) x = x < 0 ? 0 : (x >= ncls ? ncls - 1 : x);
+                            if (x >= 0 && x < ncls) m |= 1u << (lo + (int)x); else bad_code = true;
+                        }
+                        ecls[r] = (unsigned char)m;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- (B) the sort, in LDS ----------------------------------------------------------------------------------------
+        if (do_csr) {
+            if (tid < 64) {                              // exclusive scan of the n + 1 counters, 64 at a time (start[n] becomes E)
+                int carry = 0;
+                for (int base = 0; base <= n; base += 64) {
+                    const int v = base + tid;
+                    const int cnt = v <= n ? cstart[v] : 0;
+                    int incl = cnt;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const int t = __shfl_up(incl, o);
+                        if (tid >= o) incl += t;
+                    }
+                    const int ex = carry + incl - cnt;
+                    if (v <= n) { cstart[v] = ex; ccur[v] = ex; }
+                    carry += __shfl(incl, 63);
+                }
+            }
+            __syncthreads();
+            for (int c = tid; c < E; c += T) pl[atomicAdd(&ccur[tloc[c]], 1)] = (uint16_t)c;
+            __syncthreads();
+            for (int v = tid; v < n; v += T) {          // column order inside every segment (the cursor hands out slots in arbitrary order)
+                const int lo = cstart[v], hi = cstart[v + 1];
+                for (int i = lo + 1; i < hi; ++i) {
+                    const uint16_t x = pl[i];
+                    int j = i - 1;
+                    while (j >= lo && pl[j] > x) { pl[j + 1] = pl[j]; --j; }
+                    pl[j + 1] = x;
+                }
+            }
+            __syncthreads();
+        }
+        // ---- (C) stores --------------------------------------------------------------------------------------------------
+        if (bad_code && sd->code_status) atomicOr(sd->code_status, 1);
+        if (do_csr) {
+            for (int v = tid; v < n; v += T) sd->csr_seg[n0 + v] = (int32_t)(e0 + cstart[v]);
+            for (int i = tid; i < E; i += T) {
+                const int le = pl[i];
+                sd->csr_perm[e0 + i] = (int32_t)(e0 + le);
+                if (sd->csr_tgt) sd->csr_tgt[e0 + i] = (int32_t)(n0 + tloc[le]);
+                if (sd->csr_oth) sd->csr_oth[e0 + i] = (int32_t)(n0 + oloc[le]);
+            }
+        }
+        if (do_np)
+            for (int i = tid; i < 4 * n; i += T) {
+                const int v = i >> 2, q = i & 3;
+                const unsigned hot = nmask[v] >> (8 * q);
+                auto word = [&](int kk) { return ((hot >> kk) & 1u ? 0x3c00u : 0u) | ((hot >> (kk + 1)) & 1u ? 0x3c000000u : 0u); };
+                *reinterpret_cast<u4v *>(sd->npack + (n0 + v) * 32 + 8 * q) = u4v{word(0), word(2), word(4), word(6)};
+            }
+        if (do_ec) {
+            const int q0 = sd->ecode_col0 >> 2, nq = 4 - q0;      // the 4-column groups from ecode_col0 to the end of the row
+            for (int i = tid; i < E * nq; i += T) {
+                const int r = nq == 1 ? i : i / nq;
+                const int qq = i - r * nq;
+                const unsigned hot = (unsigned)ecls[r] >> (4 * qq);
+                uint2 o;
+                o.x = ((hot & 1u) ? 0x3c00u : 0u) | ((hot & 2u) ? 0x3c000000u : 0u);
+                o.y = ((hot & 4u) ? 0x3c00u : 0u) | ((hot & 8u) ? 0x3c000000u : 0u);
+                *reinterpret_cast<uint2 *>(sd->epack + (e0 + r) * 16 + 4 * (q0 + qq)) = o;
+            }
+        }
+    }
+}
 
 // diagnostic build (-DCOUNT_PROF, scripts/rr_variant.sh with RR_VARIANT_SRC=count): cycles of thread 0 per phase, summed over the workgroups
 #ifdef COUNT_PROF
@@ -561,7 +844,19 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
 template <int W, int T, bool DIR, bool TAIL, bool MOL = false>
 __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int item = MOL ? (int)blockIdx.x : (int)blockIdx.x / a.split, part = MOL ? 0 : (int)blockIdx.x - item * a.split;
+    int bid = (int)blockIdx.x;
+    if (a.side_mask) {                                   // (launches with side workgroups: one workgroup per item, no graph list)
+        const int grp = bid / (SIDE_EVERY + 1), j = bid - grp * (SIDE_EVERY + 1);
+        if (j == SIDE_EVERY) {
+            const int i0 = grp * SIDE_EVERY, i1 = i0 + SIDE_EVERY < a.n_items ? i0 + SIDE_EVERY : a.n_items;
+            const int per = (MOL || a.pair) ? 2 : 1;
+            side_block<T>(a, smem, per * i0, per * i1 < a.n_graphs ? per * i1 : a.n_graphs);
+            return;
+        }
+        bid = grp * SIDE_EVERY + j;
+        if (bid >= a.n_items) return;
+    }
+    const int item = MOL ? bid : bid / a.split, part = MOL ? 0 : bid - item * a.split;
     // one call site (the body is inlined once): pass 0 = the graph, or the pair 2 i, 2 i + 1 as one; passes 1, 2 = the pair's graphs one by
     // one when it did not fit or held an error
     const int g0 = (MOL || a.pair) ? 2 * item : (a.graph_ids ? a.graph_ids[item] : item);
@@ -584,7 +879,17 @@ __global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
 #endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(COUNT_MOL_WAVES))) void count_kernel_mol(CountArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int item = (int)blockIdx.x;
+    int item = (int)blockIdx.x;
+    if (a.side_mask) {
+        const int grp = item / (SIDE_EVERY + 1), j = item - grp * (SIDE_EVERY + 1);
+        if (j == SIDE_EVERY) {
+            const int i0 = grp * SIDE_EVERY, i1 = i0 + SIDE_EVERY < a.n_items ? i0 + SIDE_EVERY : a.n_items;
+            side_block<64>(a, smem, 2 * i0, 2 * i1 < a.n_graphs ? 2 * i1 : a.n_graphs);
+            return;
+        }
+        item = grp * SIDE_EVERY + j;
+        if (item >= a.n_items) return;
+    }
     const int g0 = 2 * item;
     const bool two = g0 + 1 < a.n_graphs;
     if (a.zero_status && threadIdx.x == 0) {
@@ -688,7 +993,8 @@ static int count_launch(const uint32_t *plan_host, const uint32_t *plan_dev, int
                         const int64_t *node_ptr, const int64_t *edge_ptr, const int64_t *edge_index,
                         int64_t edge_row_stride, int ids_are_global, const int32_t *graph_ids, int64_t n_items,
                         int64_t max_nodes, int64_t max_edges, int64_t *out, int32_t *status, const int32_t *n_classes,
-                        int enc_clamp, float *enc_out, void *stream, uint16_t *enc16 = nullptr, int64_t enc16_stride = 0, int64_t enc16_col0 = 0, int enc_no32 = 0) {
+                        int enc_clamp, float *enc_out, void *stream, uint16_t *enc16 = nullptr, int64_t enc16_stride = 0, int64_t enc16_col0 = 0, int enc_no32 = 0,
+                        const gsn_count_side *side = nullptr) {
     if (!plan_host || !plan_dev || plan_words < PLAN_HEADER_WORDS || plan_host[0] != PLAN_MAGIC)
         return set_error(GSN_E_INVALID, "gsn_count_hip: not a plan table (build it with gsn_count_plan_build)");
     if (!node_ptr || !edge_ptr || (!out && !enc_out) || !status) return set_error(GSN_E_INVALID, "gsn_count_hip: null pointer argument");
@@ -731,6 +1037,49 @@ static int count_launch(const uint32_t *plan_host, const uint32_t *plan_dev, int
         a.enc_width = (int)enc_width;
     }
     if (max_edges > 0 && !edge_index) return set_error(GSN_E_INVALID, "gsn_count_hip: edge_index is null");
+    // side outputs (gsn_count_encode_pack16_side_hip): validated here; the grid gets its side workgroups below
+    if (side) {
+        if (graph_ids) return set_error(GSN_E_UNSUPPORTED, "gsn_count_encode_pack16_side_hip: a graph list (the side outputs cover every graph of the batch)");
+        if (side->seg_ptr) {
+            if ((max_edges > 0 && !side->perm) || side->n_nodes < 0 || side->n_edges < 0 || side->n_nodes >= ((int64_t)1 << 31) - 1 || side->n_edges >= (int64_t)1 << 31)
+                return set_error(GSN_E_INVALID, "gsn_count_encode_pack16_side_hip: CSR outputs / totals");
+            a.side_mask |= 1;
+            a.side.csr_seg = side->seg_ptr; a.side.csr_perm = side->perm; a.side.csr_tgt = side->sorted_target; a.side.csr_oth = side->sorted_other;
+        }
+        a.side.csr_row = side->csr_row ? 1 : 0; a.side.tot_nodes = side->n_nodes; a.side.tot_edges = side->n_edges;
+        if (side->node_codes) {
+            if (!side->node_pack || (reinterpret_cast<uintptr_t>(side->node_pack) & 15) || side->node_code_cols < 1 || side->node_code_cols > 4)
+                return set_error(GSN_E_INVALID, "gsn_count_encode_pack16_side_hip: node pack (16-byte aligned) and 1..4 node code columns");
+            int o = 0;
+            for (int c = 0; c < side->node_code_cols; ++c) {
+                if (side->node_n_classes[c] < 1) return set_error(GSN_E_INVALID, "gsn_count_encode_pack16_side_hip: node_n_classes[%d] < 1", c);
+                a.side.ncode_ptr_w[c >> 2] |= (unsigned)o << (8 * (c & 3)); o += side->node_n_classes[c];
+                if (o > 28) return set_error(GSN_E_INVALID, "gsn_count_encode_pack16_side_hip: more than 28 encoded node columns");
+            }
+            a.side.ncode_ptr_w[side->node_code_cols >> 2] |= (unsigned)o << (8 * (side->node_code_cols & 3));
+            a.side_mask |= 2;
+            a.side.ncode = side->node_codes; a.side.npack = side->node_pack; a.side.ncode_cols = side->node_code_cols; a.side.ncode_clamp = side->node_clamp ? 1 : 0;
+        }
+        if (side->edge_codes) {
+            if (!enc16 || enc16_stride != 16 || (reinterpret_cast<uintptr_t>(enc16) & 15) || side->edge_code_cols < 1 || side->edge_code_cols > 4)
+                return set_error(GSN_E_INVALID, "gsn_count_encode_pack16_side_hip: edge codes need a 16-column, 16-byte-aligned edge pack and 1..4 code columns");
+            if (side->edge_col0 < 0 || (side->edge_col0 & 3) || side->edge_col0 < enc16_col0 + enc_width)
+                return set_error(GSN_E_INVALID, "gsn_count_encode_pack16_side_hip: edge_col0 %d must be a multiple of 4 behind the identifier columns (%lld .. %lld)",
+                                 side->edge_col0, (long long)enc16_col0, (long long)(enc16_col0 + enc_width));
+            int o = side->edge_col0;
+            for (int c = 0; c < side->edge_code_cols; ++c) {
+                if (side->edge_n_classes[c] < 1) return set_error(GSN_E_INVALID, "gsn_count_encode_pack16_side_hip: edge_n_classes[%d] < 1", c);
+                a.side.ecode_ptr_w[c >> 2] |= (unsigned)o << (8 * (c & 3)); o += side->edge_n_classes[c];
+            }
+            a.side.ecode_ptr_w[side->edge_code_cols >> 2] |= (unsigned)o << (8 * (side->edge_code_cols & 3));
+            if (o > 16 || o - side->edge_col0 > 8)
+                return set_error(GSN_E_INVALID, "gsn_count_encode_pack16_side_hip: %d edge code classes at column %d (<= 8, inside the 16 columns)", o - side->edge_col0, side->edge_col0);
+            a.side_mask |= 4;
+            a.side.ecode = side->edge_codes; a.side.epack = enc16; a.side.ecode_cols = side->edge_code_cols; a.side.ecode_clamp = side->edge_clamp ? 1 : 0;
+            a.side.ecode_col0 = side->edge_col0;
+        }
+        a.side.code_status = side->code_status;
+    }
 
     const int W = max_nodes <= 64 ? 1 : (max_nodes <= 128 ? 2 : (max_nodes <= 256 ? 4 : (max_nodes <= 512 ? 8 : 12)));
     const bool edge_mode = a.mode == GSN_MODE_EDGE;
@@ -838,6 +1187,16 @@ static int count_launch(const uint32_t *plan_host, const uint32_t *plan_dev, int
         if (a.stage_out && !bytes_forced) a.enc_from_counts = 1;      // the staged 16-bit counts hold what the class indices need: no second array
         else o += align_up((int)(rows_cap_u * a.n_cols), 16);         // (16-byte aligned: with four columns a row's indices are read as one word)
     }
+    if (a.side_mask) {
+        if (a.split != 1)
+            return set_error(GSN_E_UNSUPPORTED, "gsn_count_encode_pack16_side_hip: this launch splits a graph over %d workgroups (few heavy graphs): the side workgroups ride a "
+                                                "one-workgroup-per-item grid; use gsn_csr_build_graphs_hip / gsn_one_hot_pack16_hip", a.split);
+        // a side workgroup sorts a graph of the declared sizes in the launch's LDS (several at a time where they fit)
+        const int64_t need = ((int64_t)a.n_decl + 1) * 8 + (int64_t)a.n_decl * 4 + (int64_t)a.e_decl * 7 + 16;
+        if (a.n_decl >= 65535 || a.e_decl >= 65535 || need > 160 * 1024)
+            return set_error(GSN_E_UNSUPPORTED, "gsn_count_encode_pack16_side_hip: graphs of %d vertices / %d columns do not sort in LDS (%lld B)", a.n_decl, a.e_decl, (long long)need);
+        if (need > o) o = align_up((int)need, 16);
+    }
     if (o > 160 * 1024) return set_error(GSN_E_UNSUPPORTED, "graph too large for LDS (%d B needed)", o);
     if (enc16 && !a.enc_stage)
         return set_error(GSN_E_UNSUPPORTED, "gsn_count_encode_pack16_hip: the fp16 rows are written from the staged class indices (one workgroup per graph, "
@@ -852,7 +1211,9 @@ static int count_launch(const uint32_t *plan_host, const uint32_t *plan_dev, int
         if (graph_ids) hipLaunchKernelGGL(status_zero_kernel, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, st, graph_ids, (int)n_items, status);
         if (e != hipSuccess) return set_error(GSN_E_HIP, "hipMemsetAsync(status): %s", hipGetErrorString(e));
     }
-    const int items = pair ? (int)((n_graphs + 1) / 2) : (int)n_items * a.split;
+    int items = pair ? (int)((n_graphs + 1) / 2) : (int)n_items * a.split;
+    a.n_items = items; a.lds_bytes = o;
+    if (a.side_mask) items = (items + SIDE_EVERY - 1) / SIDE_EVERY * (SIDE_EVERY + 1);      // every (SIDE_EVERY + 1)-th workgroup is a side workgroup
     if (getenv("GSN_CHAIN_TRACE")) fprintf(stderr, "gsn count: count_kernel<%d,%d> workgroups %d pair %d split %d lds %d\n", W, T, items, a.pair, a.split, o);
     if (W == 1 && T == 64) return launch<1, 64>(a, items, (size_t)o, st);
     if (W == 1) return launch<1, 256>(a, items, (size_t)o, st);
@@ -900,4 +1261,22 @@ extern "C" int gsn_count_encode_pack16_hip(const uint32_t *plan_host, const uint
         return set_error(GSN_E_INVALID, "gsn_count_encode_pack16_hip: columns %lld .. %lld outside a pack row of %lld", (long long)pack_col0, (long long)(pack_col0 + w), (long long)pack_stride);
     return count_launch(plan_host, plan_dev, plan_words, n_graphs, node_ptr, edge_ptr, edge_index, edge_row_stride, ids_are_global,
                         graph_ids, n_items, max_nodes, max_edges, out, status, n_classes, clamp, enc_out, stream, pack, pack_stride, pack_col0, no32);
+}
+
+extern "C" int gsn_count_encode_pack16_side_hip(const uint32_t *plan_host, const uint32_t *plan_dev, int64_t plan_words, int64_t n_graphs,
+                                                const int64_t *node_ptr, const int64_t *edge_ptr, const int64_t *edge_index,
+                                                int64_t edge_row_stride, int ids_are_global, int64_t max_nodes, int64_t max_edges, int64_t *out,
+                                                int32_t *status, const int32_t *n_classes, int clamp, uint16_t *pack, int64_t pack_stride,
+                                                int64_t pack_col0, const gsn_count_side *side, void *stream) {
+    if (!side) return set_error(GSN_E_INVALID, "gsn_count_encode_pack16_side_hip: side is null");
+    if (!out) return set_error(GSN_E_INVALID, "gsn_count_encode_pack16_side_hip: the int64 counts are always written (out is null)");
+    if (!pack)          // (no identifier pack: plain counts + the CSR / node pack; edge codes need the pack and are refused in count_launch)
+        return count_launch(plan_host, plan_dev, plan_words, n_graphs, node_ptr, edge_ptr, edge_index, edge_row_stride, ids_are_global, nullptr, n_graphs,
+                            max_nodes, max_edges, out, status, nullptr, 0, nullptr, stream, nullptr, 0, 0, 0, side);
+    int64_t w = 0;
+    if (n_classes && plan_host && plan_words >= PLAN_HEADER_WORDS) for (uint32_t c = 0; c < plan_host[4] && c < GSN_ENC_MAX_COLS; ++c) w += n_classes[c];
+    if (pack_stride <= 0 || pack_stride > 0x7fffffff || pack_col0 < 0 || pack_col0 + w > pack_stride)
+        return set_error(GSN_E_INVALID, "gsn_count_encode_pack16_side_hip: columns %lld .. %lld outside a pack row of %lld", (long long)pack_col0, (long long)(pack_col0 + w), (long long)pack_stride);
+    return count_launch(plan_host, plan_dev, plan_words, n_graphs, node_ptr, edge_ptr, edge_index, edge_row_stride, ids_are_global, nullptr, n_graphs,
+                        max_nodes, max_edges, out, status, n_classes, clamp, reinterpret_cast<float *>(pack), stream, pack, pack_stride, pack_col0, 1, side);
 }

@@ -157,6 +157,46 @@ int gsn_count_encode_pack16_hip(const uint32_t *plan_host, const uint32_t *plan_
                                 int64_t max_nodes, int64_t max_edges, int64_t *out, int32_t *status, const int32_t *n_classes,
                                 int clamp, float *enc_out, uint16_t *pack, int64_t pack_stride, int64_t pack_col0, void *stream);
 
+/* The same launch leaving, from the counting workgroups themselves, what the first GSN layer needs beside the identifiers (r06).  A
+ * counting workgroup holds its graph's columns in LDS anyway, so it also writes
+ *   (i)   the target-sorted CSR of its graph's columns -- seg_ptr / perm / sorted_target / sorted_other exactly as
+ *         gsn_csr_build_graphs_hip writes them (GSN_sparse.py:140-143: the reference re-sorts a COO tensor in every layer);
+ *   (ii)  the node pack: one-hot of integer node codes (utils_graph_learning.py:170-187: DiscreteEmbedding('one_hot_encoder') on
+ *         data.x) as fp16 [n_nodes][32], column 31 = 1.0 -- what gsn_one_hot_pack16_hip(col0 = 0, one_col = 31) writes;
+ *   (iii) the WHOLE edge pack row fp16 [n_edges][16]: identifier classes at pack_col0 .. (as gsn_count_encode_pack16_hip), the
+ *         one-hot of integer edge codes at edge_col0 .., every other column zero -- one 32-byte row store instead of two partial ones.
+ * Each part is optional (null pointers).  Needs what the pack columns need (one workgroup owns a graph: no graph list, no split) and
+ * an edge-mode or vertex-mode plan alike; GSN_E_UNSUPPORTED otherwise, nothing launched -- the caller uses the separate entry points.
+ * node_ptr[0] must be 0, node_ptr[n_graphs] = n_nodes, edge_ptr[n_graphs] = n_edges (a collated batch).  Statuses: a column that leaves
+ * its graph raises GSN_ST_BAD_INDEX on that graph (its CSR entries are then unspecified but inside the graph's ranges), a graph
+ * beyond max_nodes / max_edges GSN_ST_TOO_LARGE (its vertices own no columns, its columns map to themselves: as
+ * gsn_csr_build_graphs_hip); *code_status (device int32, caller-zeroed, may be NULL) gets 1 ORed in when a code lies outside its
+ * column's classes and clamp is 0 (that column's segment stays zero, as gsn_one_hot_pack16_hip). */
+typedef struct {
+    int csr_row;                 /* which row of edge_index is the aggregation target (1: flow = source_to_target) */
+    int32_t *seg_ptr;            /* [n_nodes + 1] or NULL: no CSR */
+    int32_t *perm;               /* [n_edges] */
+    int32_t *sorted_target;      /* [n_edges] or NULL */
+    int32_t *sorted_other;       /* [n_edges] or NULL */
+    int64_t n_nodes, n_edges;    /* batch totals */
+    const int64_t *node_codes;   /* [n_nodes][node_code_cols] or NULL: no node pack */
+    int node_code_cols;          /* 1 .. 4 */
+    int node_n_classes[4];       /* sum <= 28 */
+    int node_clamp;
+    uint16_t *node_pack;         /* fp16 [n_nodes][32], 16-byte aligned */
+    const int64_t *edge_codes;   /* [n_edges][edge_code_cols] or NULL: only the identifier columns of the edge pack are written */
+    int edge_code_cols;          /* 1 .. 4 */
+    int edge_n_classes[4];
+    int edge_clamp;
+    int edge_col0;               /* first pack column of the edge codes' one-hot; must not overlap the identifier columns */
+    int32_t *code_status;        /* or NULL */
+} gsn_count_side;
+int gsn_count_encode_pack16_side_hip(const uint32_t *plan_host, const uint32_t *plan_dev, int64_t plan_words, int64_t n_graphs,
+                                     const int64_t *node_ptr, const int64_t *edge_ptr, const int64_t *edge_index,
+                                     int64_t edge_row_stride, int ids_are_global, int64_t max_nodes, int64_t max_edges, int64_t *out,
+                                     int32_t *status, const int32_t *n_classes, int clamp, uint16_t *pack, int64_t pack_stride,
+                                     int64_t pack_col0, const gsn_count_side *side, void *stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * HP-2  aggregation target index (device).  The scatter-add of the layers,
  *   torch.sparse.FloatTensor(edge_index, msgs, [N,N,d]) + torch.sparse.sum(msgs, aggr_dim).to_dense()
@@ -435,6 +475,43 @@ int gsn_layer_fused_pack16_prepare_hip(const gsn_chain_stage *edge, int64_t d_x,
 int gsn_layer_fused_fwd_pack16_hip(int64_t n_nodes, int64_t n_edges, const int32_t *seg_ptr, const gsn_chain_stage *edge,
                                    const float *x, int64_t d_x, const gsn_chain_stage *node0, const gsn_chain_stage *node1,
                                    const void *prepared, const gsn_pack16 *pack, int64_t edge_rows, float *out, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * HP-1 + HP-2 as ONE host call (r06): the orbit counting of a collated batch with its side outputs
+ * (gsn_count_encode_pack16_side_hip: int64 identifiers, CSR, node pack, whole edge pack rows) and, behind it on the same stream, layer 0
+ * of the model on the packs (gsn_layer_fused_fwd_pack16_hip) -- what the reference reaches through utils_ids.py:7-29
+ * (subgraph_counts2ids), utils_graph_learning.py:170-187 (the one-hot encoders) and GSN_edge_sparse.py:82-170 (forward) as three
+ * Python-level stages.  Two kernel launches, no allocation, no host synchronisation, capturable into a HIP graph; the two structs carry
+ * the arguments of the two entry points verbatim (same meaning, same checks, same status codes), so a host keeps them filled in and
+ * pays one foreign call per step.  layer->seg_ptr and the edge stage's block indices are normally count->side's CSR arrays. */
+typedef struct {
+    const uint32_t *plan_host, *plan_dev;
+    int64_t plan_words, n_graphs;
+    const int64_t *node_ptr, *edge_ptr, *edge_index;
+    int64_t edge_row_stride;
+    int ids_are_global;
+    int64_t max_nodes, max_edges;
+    int64_t *out;
+    int32_t *status;
+    const int32_t *n_classes;
+    int clamp;
+    uint16_t *pack;
+    int64_t pack_stride, pack_col0;
+    const gsn_count_side *side;
+} gsn_count_call;
+typedef struct {
+    int64_t n_nodes, n_edges;
+    const int32_t *seg_ptr;
+    const gsn_chain_stage *edge;
+    const float *x;
+    int64_t d_x;
+    const gsn_chain_stage *node0, *node1;
+    const void *prepared;
+    const gsn_pack16 *pack;
+    int64_t edge_rows;
+    float *out;
+} gsn_layer_pack16_call;
+int gsn_count_layer_step_hip(const gsn_count_call *count, const gsn_layer_pack16_call *layer, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * HP-2  dense stage on DIRECT rows with fp16x3 matrix arithmetic (device): the same operation as gsn_linear_fwd_hip
