@@ -120,6 +120,31 @@ def verify_tile(plan, b, ids_out, y, layer, n_check):
     elem_ok = bool((diff <= 1e-5 * yref.abs() + floor).all())
     # how much the floor is needed: elements that fail the PURE relative test |got - ref| <= 1e-5 |ref|, and how small they
     # are against their row (cancellation-small elements: their absolute error is that of the row's large ones)
+    # fp64 referee: the same layer in float64 (the oracle's code on .double() inputs); PURE relative errors, no floor,
+    # of (i) the HIP kernel and (ii) the fp32 oracle against it -- element-wise, over the elements above 1e-3 of their row's largest magnitude
+    # (below that a 1e-5 relative bar asks for more digits than fp32 sums of 128-260 terms carry on either side)
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    with torch.no_grad():
+        y64 = oracle.layer_forward("GSN_edge_sparse", CTOR, sd64, x.double(), torch.from_numpy(b.edge_index[:, :e1]), identifiers=idf.double(), degrees=None,
+                                   edge_features=ef.double())
+    rowmax64 = y64.abs().amax(dim=1, keepdim=True).clamp_min(1e-300)
+    big = y64.abs() >= 1e-3 * rowmax64
+    rel_hip = ((ygot.double() - y64).abs() / y64.abs().clamp_min(1e-300))
+    rel_orc = ((yref.double() - y64).abs() / y64.abs().clamp_min(1e-300))
+    worse = big & (rel_hip > 2.0 * rel_orc) & (rel_hip > 1e-6)      # elements where the HIP kernel is more than 2x further from fp64 than the fp32 oracle
+    fp64 = {"elements_above_1e-3_of_rowmax": int(big.sum()),
+            "hip_max_rel_err_vs_fp64": float("%.3g" % float(rel_hip[big].max())), "oracle_fp32_max_rel_err_vs_fp64": float("%.3g" % float(rel_orc[big].max())),
+            "hip_mean_rel_err_vs_fp64": float("%.3g" % float(rel_hip[big].mean())), "oracle_fp32_mean_rel_err_vs_fp64": float("%.3g" % float(rel_orc[big].mean())),
+            "hip_elements_over_1e-5_rel": int((big & (rel_hip > 1e-5)).sum()), "oracle_fp32_elements_over_1e-5_rel": int((big & (rel_orc > 1e-5)).sum()),
+            "hip_max_err_over_rowmax_vs_fp64": float("%.3g" % float(((ygot.double() - y64).abs() / rowmax64).max())),
+            "oracle_fp32_max_err_over_rowmax_vs_fp64": float("%.3g" % float(((yref.double() - y64).abs() / rowmax64).max())),
+            "elements_hip_over_2x_the_oracle_error": int(worse.sum()),
+            # per element against the fp32 oracle's own worst error IN THE SAME ROW (two fp32 evaluations of one row differ element by element; what
+            # bounds both is the row's scale): elements where the HIP kernel's error exceeds twice that
+            "elements_hip_error_over_2x_the_oracle_worst_error_of_the_row": int(((ygot.double() - y64).abs() > 2.0 * (yref.double() - y64).abs().amax(dim=1, keepdim=True)).sum()),
+            "largest_abs_ref_over_rowmax_among_those": float("%.3g" % (float((y64.abs() / rowmax64)[worse].max()) if int(worse.sum()) else 0.0)),
+            "hip_max_rel_err_vs_fp64_within_2x_of_the_fp32_oracle": bool(float(rel_hip[big].max()) <= 2.0 * max(float(rel_orc[big].max()), 1e-7)),
+            "note": "pure relative errors |v - v64| / |v64| over the elements with |v64| >= 1e-3 of their row's largest magnitude; v64 = the oracle's layer in float64"}
     pure_bad = diff > 1e-5 * yref.abs()
     n_bad = int(pure_bad.sum())
     rel_to_row = (yref.abs() / yref.abs().amax(dim=1, keepdim=True).clamp_min(1e-30))[pure_bad]
@@ -128,7 +153,8 @@ def verify_tile(plan, b, ids_out, y, layer, n_check):
             "layer_elements": int(yref.numel()), "layer_elements_failing_pure_1e-5_relative": n_bad,
             "layer_fraction_failing_pure_1e-5_relative": float("%.3g" % (n_bad / max(int(yref.numel()), 1))),
             "largest_abs_ref_over_rowmax_among_those": float("%.3g" % (float(rel_to_row.max()) if n_bad else 0.0)),
-            "largest_abs_err_over_rowmax_among_those": float("%.3g" % (float((diff / yref.abs().amax(dim=1, keepdim=True).clamp_min(1e-30))[pure_bad].max()) if n_bad else 0.0))}
+            "largest_abs_err_over_rowmax_among_those": float("%.3g" % (float((diff / yref.abs().amax(dim=1, keepdim=True).clamp_min(1e-30))[pure_bad].max()) if n_bad else 0.0)),
+            "fp64_referee": fp64}
 
 
 def work_figures(plan_patterns, ids_out):
@@ -672,7 +698,17 @@ def main():
     epack_c = packs.new_edge_pack(E, dev) if use_pack else None
     npack_c = packs.new_node_pack(N, dev) if use_pack else None
 
-    def step(fork=True, int64_ids=True, prepacked=not use_pack):
+    # r06: the headline step is ONE host call and TWO kernel launches (gsn_amd.step.CountLayerStep -> gsn_count_layer_step_hip): the counting
+    # launch, whose side workgroups also sort the batch into the layer's CSR and encode the atom / bond codes into the packs, then the layer.
+    # GSN_BENCH_ONE_CALL=0: the six-launch composition of r05 (CSR build + two code encoders on a second stream under the counting kernel),
+    # reported beside the headline as kernels.step_six_launches either way.
+    from gsn_amd.step import CountLayerStep
+    one_call = use_pack and PACK_ONLY_IDS and os.environ.get("GSN_BENCH_ONE_CALL", "1") != "0"
+    stepper = CountLayerStep(plan, layer, [3, 3, 3, 3], clamp=True) if one_call else None
+
+    def step(fork=True, int64_ids=True, prepacked=not use_pack, six=not one_call):
+        if not six:
+            return stepper(node_ptr, edge_ptr, ei, xc, efc, max_nodes, max_edges, ids_out=ids_out)[1]
         layers._CSR_CACHE.clear()             # the CSR of a fresh batch is part of the forward pass
         main = torch.cuda.current_stream(dev)
         ep = epack if prepacked else epack_c
@@ -793,7 +829,20 @@ def main():
     count_batch(plan, node_ptr, edge_ptr, ei, ids_are_global=True, max_nodes=max_nodes, max_edges=max_edges, device=dev, out=ids_out, check=False)
     one_hot_ref = torch.nn.functional.one_hot(ids_out.clamp(max=2), 3).reshape(E, 12).float()
     ids_ok = bool(torch.equal(ids_timed, ids_out))
-    if use_pack and PACK_ONLY_IDS:            # the timed step's identifier columns of the pack (fp16, exact) against one_hot(min(count, 2))
+    side_ok = None
+    if one_call:                              # the packs and the CSR the timed step's counting launch wrote: against the encoders' definition / the CSR entry point
+        npk_t, epk_t = stepper.packs()
+        enc_ok = bool(torch.equal(epk_t[:, :12].float(), one_hot_ref))
+        csr_t = stepper.csr()
+        from gsn_amd._index import build_csr_graphs
+        seg_r, perm_r, tgt_r, src_r = build_csr_graphs(ei[sel], N, node_ptr, edge_ptr, max_nodes, max_edges, other=ei[1 - sel], check=True)
+        side_ok = {"edge_pack_bond_columns_equal_one_hot_of_codes": bool(torch.equal(epk_t[:, 12:].float(), torch.nn.functional.one_hot(efc.codes[:, 0], 4).float())),
+                   "node_pack_equals_one_hot_of_codes": bool(torch.equal(npk_t[:, :28].float(), torch.nn.functional.one_hot(xc.codes[:, 0], 28).float())
+                                                              and bool((npk_t[:, 28:31] == 0).all()) and bool((npk_t[:, 31] == 1).all())),
+                   "csr_arrays_bit_equal_to_gsn_csr_build_graphs_hip": bool(torch.equal(csr_t.seg_ptr, seg_r) and torch.equal(csr_t.perm[:E], perm_r)
+                                                                             and torch.equal(csr_t.tgt[:E], tgt_r) and torch.equal(csr_t.src[:E], src_r))}
+        assert all(side_ok.values()), "side outputs of the timed step: %r" % (side_ok,)
+    elif use_pack and PACK_ONLY_IDS:          # the timed step's identifier columns of the pack (fp16, exact) against one_hot(min(count, 2))
         enc_ok = bool(torch.equal(epack_c[:, :12].float(), one_hot_ref))
     else:
         enc_ok = bool(torch.equal(idf_out, one_hot_ref))
@@ -802,6 +851,8 @@ def main():
     if checked is not None:
         checked["encoded_rows_equal_one_hot_of_counts"] = enc_ok
         checked["int64_identifiers_of_the_timed_step_equal_a_plain_counting_launch"] = ids_ok
+        if side_ok is not None:
+            checked.update(side_ok)
     occ_pos, n_maps = work_figures([list(nx.cycle_graph(k).edges) for k in range(3, 7)], ids_out)
 
     diag("behind the oracle checks")
@@ -812,7 +863,7 @@ def main():
         # kernels in one chain.  hipGraph runs the branches of the forked capture on its own internal streams without the side stream's
         # priority, and the join costs a cross-stream signal each way: measured 1.02 ms forked vs 0.81 eager in round 3.
         res_g = {}
-        for tag, fork in (("fork", True), ("chain", False)):
+        for tag, fork in ((("chain", False),) if one_call else (("fork", True), ("chain", False))):
             ok = 1
             try:
                 gobj = torch.cuda.CUDAGraph()
@@ -823,7 +874,7 @@ def main():
                 torch.cuda.current_stream(dev).wait_stream(cap)
                 with torch.cuda.graph(gobj):
                     y_g = step(fork=fork)
-                for _ in range(3):
+                for _ in range(int(os.environ.get("GSN_BENCH_PREWARM", "60"))):      # (the oracle checks above idled the GPU: clocks, as in front of the timed region)
                     gobj.replay()
                 sync()
                 if not (torch.isfinite(y_g).all() and torch.allclose(y_g, y, rtol=1e-4, atol=1e-5)):
@@ -848,9 +899,19 @@ def main():
 
     # Supplementary (never `value`): the step of rounds 2-4 -- dense one-hot inputs and their packs made OUTSIDE the step, no int64
     # identifiers written (E x 4 x 8 bytes less) -- and the headline step without the int64 identifiers.
-    dt_pre = dt_noids = None
+    dt_pre = dt_noids = dt_six = t_enq_six = None
+    if one_call:
+        for _ in range(30):
+            step(six=True)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(six=True)
+        t_enq_six = time.perf_counter() - t0
+        sync()
+        dt_six = gdist.max_over_ranks(time.perf_counter() - t0, dev)
     if use_pack:
-        for kw in ({"prepacked": True, "int64_ids": False}, {"int64_ids": False}):
+        for kw in ({"prepacked": True, "int64_ids": False, "six": True}, {"int64_ids": False, "six": True}):
             for _ in range(3):
                 step(**kw)
             sync()
@@ -882,7 +943,7 @@ def main():
     layer_alone = {}
     if world == 1 and not args.no_extras:
         if use_pack:
-            step(prepacked=True, int64_ids=False)      # (the dense tensors' pack tags all point at one edge pack again)
+            step(prepacked=True, int64_ids=False, six=True)      # (the dense tensors' pack tags all point at one edge pack again)
         with torch.no_grad():
             for tag in (("pack16_rows", "fp32_rows") if use_pack else ("fp32_rows",)):
                 if tag == "fp32_rows":
@@ -949,7 +1010,11 @@ def main():
             efc2 = layers.Codes(torch.from_numpy(b2.bond_type).to(dev), [4])
             npk2, epk2 = packs.new_node_pack(b2.num_nodes, dev), packs.new_edge_pack(b2.num_edges, dev)
 
+        stepper2 = CountLayerStep(plan, layer, [3, 3, 3, 3], clamp=True) if (headline_flow and one_call) else None
+
         def step12k():
+            if stepper2 is not None:
+                return stepper2(np2, ep2, ei2, xc2, efc2, mn2, me2, ids_out=ids2)[1]
             layers._CSR_CACHE.clear()
             if headline_flow:
                 # (one stream: at this size the step is 0.18 ms of GPU time and the second stream's events and waits make the HOST the
@@ -1087,7 +1152,7 @@ def main():
             # incidence product.)
             rr = os.environ.get("GSN_FUSED_RR", "1") != "0"
             if rr:
-                n_t, n_b = rr_tiling(layers._csr_for(ei, sel, N).seg_ptr.cpu().numpy().astype(np.int64), N)
+                n_t, n_b = rr_tiling((stepper.csr() if one_call else layers._csr_for(ei, sel, N)).seg_ptr.cpu().numpy().astype(np.int64), N)
                 # (csrc/layer_rp.hip: the x part of node stage 0 is exact as well -- two products for its two chunks instead of three)
                 f_exec = 32768.0 * (n_b * (5 * 4 * 2 + 2 * 4 * 2) + n_t * ((8 * 3 + 2 * 2 + 8 * 3) if use_pack else (10 + 8) * 3) * 4)
             else:
@@ -1182,8 +1247,13 @@ def main():
             "step_without_int64_ids": None if dt_noids is None else {
                 "ms_per_step": round(dt_noids / args.steps * 1e3, 4), "graphs_per_s": round(world * G * args.steps / dt_noids, 1),
                 "note": "the headline step with the counting kernel writing the encoded identifier rows only"},
+            "step_six_launches": None if dt_six is None else {
+                "ms_per_step": round(dt_six / args.steps * 1e3, 4), "graphs_per_s": round(world * G * args.steps / dt_six, 1),
+                "host_enqueue_ms_per_step": round(t_enq_six / args.steps * 1e3, 4),
+                "note": "the r05 headline: CSR build + two code encoders on a second stream under the counting kernel, then the layer (six launches, eager)"},
             "layer_alone_ms": layer_alone,
-            "launch": "eager",
+            "launch": ("eager: one host call per step (gsn_count_layer_step_hip), two kernel launches; `value` is this timing, hip_graph_ms_per_step the same two "
+                       "launches replayed from a captured graph") if one_call else "eager (six launches, second stream)",
         })
         if graph_note:
             extra["hip_graph_note"] = graph_note

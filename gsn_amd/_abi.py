@@ -84,7 +84,7 @@ SIGNATURES = {
                                             c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_i64, c_vp]),
     "gsn_count_encode_pack16_side_hip": (c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_int, c_i64, c_i64, c_vp, c_vp, c_vp, c_int,
                                                  c_vp, c_i64, c_i64, ctypes.POINTER(gsn_count_side), c_vp]),
-    "gsn_count_layer_step_hip": (c_int, [ctypes.POINTER(gsn_count_call), ctypes.POINTER(gsn_layer_pack16_call), c_vp]),
+    "gsn_count_layer_step_hip": (c_int, [ctypes.POINTER(gsn_count_call), ctypes.POINTER(gsn_layer_pack16_call), c_vp, c_vp]),
     "gsn_pack16_rows_hip": (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp]),
     "gsn_one_hot_pack16_hip": (c_int, [c_i64, c_int, c_vp, c_vp, c_int, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp]),
     "gsn_csr_scratch_elems": (c_i64, [c_i64]),

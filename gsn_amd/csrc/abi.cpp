@@ -60,12 +60,14 @@ int current_device() {
 }  // namespace gsn
 
 // HP-1 + HP-2 in one host call (include/gsn_abi.h: gsn_count_layer_step_hip): the counting launch with its side outputs, then layer 0 on the packs
-extern "C" int gsn_count_layer_step_hip(const gsn_count_call *c, const gsn_layer_pack16_call *l, void *stream) {
+extern "C" int gsn_count_layer_step_hip(const gsn_count_call *c, const gsn_layer_pack16_call *l, void *event_between, void *stream) {
     if (!c || !l) return gsn::set_error(GSN_E_INVALID, "gsn_count_layer_step_hip: null call struct");
     const int rc = gsn_count_encode_pack16_side_hip(c->plan_host, c->plan_dev, c->plan_words, c->n_graphs, c->node_ptr, c->edge_ptr, c->edge_index,
                                                     c->edge_row_stride, c->ids_are_global, c->max_nodes, c->max_edges, c->out, c->status, c->n_classes,
                                                     c->clamp, c->pack, c->pack_stride, c->pack_col0, c->side, stream);
     if (rc != GSN_OK) return rc;
+    if (event_between && hipEventRecord(reinterpret_cast<hipEvent_t>(event_between), reinterpret_cast<hipStream_t>(stream)) != hipSuccess)
+        return gsn::set_error(GSN_E_HIP, "gsn_count_layer_step_hip: hipEventRecord(event_between)");
     return gsn_layer_fused_fwd_pack16_hip(l->n_nodes, l->n_edges, l->seg_ptr, l->edge, l->x, l->d_x, l->node0, l->node1, l->prepared, l->pack,
                                           l->edge_rows, l->out, stream);
 }

@@ -40,7 +40,10 @@ struct SideArgs {
     unsigned ncode_ptr_w[2], ecode_ptr_w[2];    // first pack column of every code column's classes, one BYTE per column + the end (prefix sums; the
                                                 // edge codes' start at ecode_col0) -- as words: byte-sized kernel arguments are vector loads on gfx9
 };
-constexpr int SIDE_EVERY = 4;  // counting workgroups per side workgroup
+#ifndef GSN_SIDE_EVERY
+#define GSN_SIDE_EVERY 4
+#endif
+constexpr int SIDE_EVERY = GSN_SIDE_EVERY;  // counting workgroups per side workgroup (A/B: 2: +0.0xx, 8: see profiles/r06_count_side_ab.txt)
 
 struct CountArgs {
     const uint32_t *plan;      // device

@@ -157,20 +157,23 @@ int gsn_count_encode_pack16_hip(const uint32_t *plan_host, const uint32_t *plan_
                                 int64_t max_nodes, int64_t max_edges, int64_t *out, int32_t *status, const int32_t *n_classes,
                                 int clamp, float *enc_out, uint16_t *pack, int64_t pack_stride, int64_t pack_col0, void *stream);
 
-/* The same launch leaving, from the counting workgroups themselves, what the first GSN layer needs beside the identifiers (r06).  A
- * counting workgroup holds its graph's columns in LDS anyway, so it also writes
+/* The same launch leaving what the first GSN layer needs beside the identifiers (r06).  Every fifth workgroup of the grid is a SIDE workgroup:
+ * it takes the graphs of the four counting workgroups dispatched in front of it, sorts their columns in LDS and writes
  *   (i)   the target-sorted CSR of its graph's columns -- seg_ptr / perm / sorted_target / sorted_other exactly as
  *         gsn_csr_build_graphs_hip writes them (GSN_sparse.py:140-143: the reference re-sorts a COO tensor in every layer);
  *   (ii)  the node pack: one-hot of integer node codes (utils_graph_learning.py:170-187: DiscreteEmbedding('one_hot_encoder') on
  *         data.x) as fp16 [n_nodes][32], column 31 = 1.0 -- what gsn_one_hot_pack16_hip(col0 = 0, one_col = 31) writes;
- *   (iii) the WHOLE edge pack row fp16 [n_edges][16]: identifier classes at pack_col0 .. (as gsn_count_encode_pack16_hip), the
- *         one-hot of integer edge codes at edge_col0 .., every other column zero -- one 32-byte row store instead of two partial ones.
- * Each part is optional (null pointers).  Needs what the pack columns need (one workgroup owns a graph: no graph list, no split) and
- * an edge-mode or vertex-mode plan alike; GSN_E_UNSUPPORTED otherwise, nothing launched -- the caller uses the separate entry points.
+ *   (iii) columns edge_col0 .. 15 of the edge pack fp16 [n_edges][16]: the one-hot of integer edge codes at edge_col0 .., zeros behind it (the
+ *         counting workgroups write the identifier classes at pack_col0 .. as in gsn_count_encode_pack16_hip; with pack_col0 = 0 and
+ *         edge_col0 = sum n_classes the whole row is written by the launch and the pack needs no zero fill).
+ * Each part is optional (null pointers).  The counting workgroups run exactly what they run without side outputs (the work inside them, where
+ * the graph already sits in LDS, was measured and lost: the molecule instantiation is at its register bound, profiles/r06_count_side_ab.txt).
+ * Needs one workgroup per item (no graph list, no graph split over several workgroups) and graphs whose sort fits LDS, edge-mode or vertex-mode
+ * plan alike; GSN_E_UNSUPPORTED otherwise, nothing launched -- the caller uses the separate entry points.
  * node_ptr[0] must be 0, node_ptr[n_graphs] = n_nodes, edge_ptr[n_graphs] = n_edges (a collated batch).  Statuses: a column that leaves
- * its graph raises GSN_ST_BAD_INDEX on that graph (its CSR entries are then unspecified but inside the graph's ranges), a graph
- * beyond max_nodes / max_edges GSN_ST_TOO_LARGE (its vertices own no columns, its columns map to themselves: as
- * gsn_csr_build_graphs_hip); *code_status (device int32, caller-zeroed, may be NULL) gets 1 ORed in when a code lies outside its
+ * its graph raises GSN_ST_BAD_INDEX on that graph (its CSR entries are then unspecified but inside the batch's ranges), a graph
+ * beyond max_nodes / max_edges GSN_ST_TOO_LARGE (sorted all the same when it fits the launch's LDS, else its vertices own no columns and
+ * its columns map to themselves: as gsn_csr_build_graphs_hip); *code_status (device int32, caller-zeroed, may be NULL) gets 1 ORed in when a code lies outside its
  * column's classes and clamp is 0 (that column's segment stays zero, as gsn_one_hot_pack16_hip). */
 typedef struct {
     int csr_row;                 /* which row of edge_index is the aggregation target (1: flow = source_to_target) */
@@ -188,7 +191,7 @@ typedef struct {
     int edge_code_cols;          /* 1 .. 4 */
     int edge_n_classes[4];
     int edge_clamp;
-    int edge_col0;               /* first pack column of the edge codes' one-hot; must not overlap the identifier columns */
+    int edge_col0;               /* first pack column of the edge codes' one-hot: a multiple of 4, behind the identifier columns; <= 8 classes */
     int32_t *code_status;        /* or NULL */
 } gsn_count_side;
 int gsn_count_encode_pack16_side_hip(const uint32_t *plan_host, const uint32_t *plan_dev, int64_t plan_words, int64_t n_graphs,
@@ -511,7 +514,9 @@ typedef struct {
     int64_t edge_rows;
     float *out;
 } gsn_layer_pack16_call;
-int gsn_count_layer_step_hip(const gsn_count_call *count, const gsn_layer_pack16_call *layer, void *stream);
+int gsn_count_layer_step_hip(const gsn_count_call *count, const gsn_layer_pack16_call *layer, void *event_between, void *stream);
+/* event_between: a hipEvent_t recorded on `stream` between the two launches, or NULL (a measuring host brackets the two kernels of the one
+ * call with it: bench.py's per-kernel HIP-event times). */
 
 /* ------------------------------------------------------------------------------------------------------------------
  * HP-2  dense stage on DIRECT rows with fp16x3 matrix arithmetic (device): the same operation as gsn_linear_fwd_hip
