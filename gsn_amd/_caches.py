@@ -113,6 +113,10 @@ def drop_input_caches():
     #  synchronise inside the capture)
     for k in [k for k in _CSR_CACHE if not (isinstance(k, tuple) and len(k) == 2 and k[1] == "n_graphs")]:
         _CSR_CACHE.pop(k, None)              # (dropping an entry can free a tensor whose weak-reference callback removes another key)
+    # the tags that live ON input objects (a Codes object's fp16 pack and dense rows, an fp32 tensor's pack tag) cannot be enumerated: they carry
+    # the epoch they were made in and are rejected once it has moved
+    from ._runtime import INPUT_EPOCH
+    INPUT_EPOCH[0] += 1
 
 
 def invalidate_caches(module=None):

@@ -8,7 +8,7 @@ import weakref
 import torch
 
 from . import _abi, flags
-from ._runtime import _f32c, _need_cuda, _timed, _zeros
+from ._runtime import INPUT_EPOCH, _f32c, _need_cuda, _timed, _zeros
 
 class Codes:
     """Integer category codes standing in for their one-hot encoding (the output of the reference's
@@ -50,8 +50,8 @@ class Codes:
 
     def dense(self):
         # (kept with the code tensor's version counter: a reused input buffer rewritten in place is encoded again)
-        if self._dense is None or self._dense[1] != self.codes._version:
-            self._dense = (one_hot_identifiers(self.codes, self.n_classes, clamp=self.clamp), self.codes._version)
+        if self._dense is None or self._dense[1] != self.codes._version or self._dense[2] != INPUT_EPOCH[0]:
+            self._dense = (one_hot_identifiers(self.codes, self.n_classes, clamp=self.clamp), self.codes._version, INPUT_EPOCH[0])
         return self._dense[0]
 
 
@@ -149,6 +149,12 @@ def set_graph_partition(edge_index, node_ptr, edge_ptr, max_nodes, max_edges, ch
     _need_cuda(edge_index, "edge_index")
     if (2 * (int(max_nodes) + 1) + 2 * int(max_edges)) * 4 > _CSR_GRAPHS_LDS:
         return False                       # graphs too large for the per-graph kernel: the generic build is used
+    # the declared sizes are trusted by kernels that size their tiles by them (the graph-aligned d = 128 layer stops at 128 rows of a graph):
+    # checked here when that is free (pointers still on the host, as at collate time) or asked for (``check``: one device read)
+    if check or not node_ptr.is_cuda:
+        for name, ptr, cap in (("node_ptr", node_ptr, max_nodes), ("edge_ptr", edge_ptr, max_edges)):
+            if ptr.numel() > 1 and int((ptr[1:] - ptr[:-1]).max()) > int(cap):
+                raise ValueError("set_graph_partition: a graph is larger than the declared max (%s: %d > %d)" % (name, int((ptr[1:] - ptr[:-1]).max()), int(cap)))
     key = id(edge_index)
 
     def _gone(_ref, key=key):

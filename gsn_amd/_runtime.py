@@ -95,3 +95,10 @@ def _f32c(t):
     if t.dtype is torch.float32 and t.is_contiguous():
         return t.detach() if t.requires_grad else t
     return t.detach().to(torch.float32).contiguous()
+
+
+# Epoch of everything cached per INPUT tensor's contents (the CSR of an edge_index, the fp16 pack / dense one-hot rows of a Codes object, the
+# pack tag of an fp32 tensor).  gsn_amd.graphs bumps it in front of a stream capture (drop_input_caches): a tag made before -- by a warm-up step
+# on the same static input objects -- is then stale BY EPOCH, so the capture records the producer launch (encoder, pack, index build) instead of
+# finding a valid tag and recording only the consumer, which would replay on the warm-up's rows after ``static.copy_(new_batch)``.
+INPUT_EPOCH = [0]

@@ -131,6 +131,9 @@ def count_batch(plan: CountPlan, node_ptr, edge_ptr, edge_index, ids_are_global=
         pack_only = not encoded_rows
         if pack_only and (encoded_pack is None or not counts or encoded_out is not None):
             raise ValueError("encoded_rows=False: the encoded identifiers leave as pack columns next to the int64 counts (encoded_pack and counts=True, no encoded_out)")
+        if pack_only and graph_ids is not None:
+            # (the Codes object returned for the layer covers EVERY row of `out` / the pack; rows of graphs outside the list would be torch.empty)
+            raise ValueError("encoded_rows=False: every graph of the batch is counted (no graph_ids)")
         if not pack_only:
             enc = encoded_out if encoded_out is not None else torch.empty((rows_total, sum(n_classes)), dtype=torch.float32, device=device)
             if enc.shape != (rows_total, sum(n_classes)) or enc.dtype != torch.float32 or not enc.is_contiguous():
@@ -186,7 +189,9 @@ def count_batch(plan: CountPlan, node_ptr, edge_ptr, edge_index, ids_are_global=
         from ._index import Codes
         cd = Codes(out, n_classes, clamp=bool(clamp), check=False)
         if pack_codes_later:
-            packs.pack_edge_codes(cd, encoded_pack[0], int(encoded_pack[1]))
+            # (the same shape rules as the kernel path: any fp16 [rows, cols] pack, columns col0 .. col0 + sum(n_classes))
+            packs._pack_codes(cd, encoded_pack[0], int(encoded_pack[1]), -1)
+            packs._claim_codes(cd, encoded_pack[0], int(encoded_pack[1]))
         elif n_graphs > 0 and n_items > 0:
             packs._claim_codes(cd, encoded_pack[0], int(encoded_pack[1]))
         return out, status, cd

@@ -148,12 +148,12 @@ def shard_by_cost(costs, world: int):
 _BUCKETS = {}
 
 
-FLAG_STABLE_CALLS = 3        # eager calls with identical reduced has-gradient flags before the flags stop being exchanged every step
-FLAG_REVALIDATE_EVERY = 64   # ... and every this many calls they are exchanged (and read back) again, on all ranks alike
+FLAG_STABLE_CALLS = 3        # (steady mode) eager calls with identical reduced has-gradient flags before the read-back becomes asynchronous
+STEADY_FLAGS = os.environ.get("GSN_ALLREDUCE_STEADY", "0") != "0"      # default of allreduce_gradients(steady_flags=None)
 
 
 class _Bucket:
-    __slots__ = ("flat", "views", "n_grad", "has", "pinned", "calls", "stable")
+    __slots__ = ("flat", "views", "n_grad", "has", "pinned", "calls", "stable", "late", "late_event")
 
     def __init__(self, params, dtype, device):
         self.n_grad = sum(p.numel() for p in params)
@@ -166,9 +166,11 @@ class _Bucket:
         self.pinned = False      # a captured graph holds this bucket's addresses: never evicted
         self.calls = 0           # eager calls so far (identical on every rank: the schedule of flag exchanges is derived from it)
         self.stable = 0          # consecutive flag exchanges that returned the same flags
+        self.late = None         # (steady mode) pinned host copy of the reduced flags of the last call, read at the NEXT call
+        self.late_event = None
 
 
-def allreduce_gradients(parameters, average: bool = True, group=None, force: bool = False):
+def allreduce_gradients(parameters, average: bool = True, group=None, force: bool = False, steady_flags=None):
     """Sum (or average) the gradients of ``parameters`` over all ranks with ONE all-reduce of a flat bucket.
 
     The bucket covers EVERY parameter that requires grad -- a parameter whose ``.grad`` is None on this rank (unused
@@ -176,11 +178,17 @@ def allreduce_gradients(parameters, average: bool = True, group=None, force: boo
     whatever their local graphs exercised.  The bucket is allocated once per parameter list and reused; gradients enter and
     leave it with one multi-tensor copy each way (not one launch per parameter).
 
-    Behind the gradients ride one has-gradient flag per parameter (summed by the same collective), so that a parameter NO rank
+    Behind the gradients ride one has-gradient flag per parameter, summed by the same collective IN EVERY CALL, so that a parameter NO rank
     produced a gradient for keeps ``grad = None`` -- with zeros instead, weight decay / momentum would move parameters a single-GPU
-    run never touches.  The flags are written with one host-to-device copy and read back once per step.  Inside a stream capture
-    (gsn_amd.graphs.GraphedTrainStep) nothing may be read back: the captured step reduces the gradient part only and reuses the
-    flags of the last eager call with this parameter list (the warm-up steps in front of the capture), which is exact as long as
+    run never touches.  By default the reduced flags are read back in every call (one small device-to-host read: exact whatever the
+    batches exercise -- a data-dependent branch, a parameter first used after an epoch switch).  ``steady_flags=True``
+    (``GSN_ALLREDUCE_STEADY=1``): after FLAG_STABLE_CALLS identical exchanges the read-back becomes asynchronous -- the reduced flags land in
+    pinned memory behind an event and are compared at the NEXT call, the step itself uses the last known flags and does not synchronise.  A
+    rank that holds a gradient the known flags do not list takes the synchronous path for that call by itself (the collective is the same
+    either way); a rank that learns one call late that the set had grown raises RuntimeError (it kept ``grad = None`` where its peers
+    stepped: the replicas are one update apart) -- never silently.  (r05 skipped the exchange itself for up to 63 calls: ADVICE r05.)
+    Inside a stream capture (gsn_amd.graphs.GraphedTrainStep) nothing may be read back: the captured step reduces the gradient part only and
+    reuses the flags of the last eager call with this parameter list (the warm-up steps in front of the capture), which is exact as long as
     the set of parameters that receive gradients is a property of the model, not of the batch.
 
     ``force``: run the collective at world size 1 too (tests: the RCCL path on one GPU)."""
@@ -219,20 +227,34 @@ def allreduce_gradients(parameters, average: bool = True, group=None, force: boo
                                    "(GraphedTrainStep's warm-up steps do that)")
             dist.all_reduce(b.flat[:b.n_grad], op=dist.ReduceOp.SUM, group=group)
             has = b.has
-        elif b.has is not None and b.stable >= FLAG_STABLE_CALLS and b.calls % FLAG_REVALIDATE_EVERY != 0:
-            # steady state: which parameters receive gradients is a property of the model -- after FLAG_STABLE_CALLS identical exchanges
-            # the gradient part alone is reduced and nothing is read back (no host synchronisation in the step); the exchange is repeated
-            # every FLAG_REVALIDATE_EVERY calls.  `calls` and the reduced flags are the same on every rank, so all ranks switch together.
-            b.calls += 1
-            dist.all_reduce(b.flat[:b.n_grad], op=dist.ReduceOp.SUM, group=group)
-            has = b.has
         else:
             b.calls += 1
+            steady = STEADY_FLAGS if steady_flags is None else bool(steady_flags)
+            if b.late_event is not None:
+                # the reduced flags of the call before this one (asynchronous read-back): they must be the flags that call used
+                b.late_event.synchronize()
+                late, b.late_event = [v != 0 for v in b.late.tolist()], None
+                if late != b.has:
+                    grown = [i for i, (x, y) in enumerate(zip(late, b.has)) if x and not y]
+                    b.has, b.stable = late, 0
+                    if grown:
+                        raise RuntimeError("allreduce_gradients(steady_flags=True): in the previous call parameters %r received a gradient on some rank for the "
+                                           "first time; this rank kept grad = None for those it had none for while its peers stepped -- the replicas are one "
+                                           "update apart.  Which parameters receive gradients depends on the batch here: call with steady_flags=False." % (grown,))
             b.flat[b.n_grad:].copy_(torch.tensor([1.0 if h else 0.0 for h in have], dtype=dtype), non_blocking=True)
             dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=group)
-            has = [v != 0 for v in b.flat[b.n_grad:].tolist()]          # (one small read-back; the gradients stay on the device)
-            b.stable = b.stable + 1 if has == b.has else 1
-            b.has = has
+            locally_new = b.has is not None and any(h and not k for h, k in zip(have, b.has))
+            if steady and device.type == "cuda" and b.has is not None and b.stable >= FLAG_STABLE_CALLS and not locally_new:
+                if b.late is None:
+                    b.late = torch.empty(len(params), dtype=dtype).pin_memory()
+                b.late.copy_(b.flat[b.n_grad:], non_blocking=True)
+                b.late_event = torch.cuda.Event()
+                b.late_event.record()
+                has = b.has
+            else:
+                has = [v != 0 for v in b.flat[b.n_grad:].tolist()]          # (one small read-back; the gradients stay on the device)
+                b.stable = b.stable + 1 if has == b.has else 1
+                b.has = has
         world = dist.get_world_size(group)
         if average and world > 1:
             b.flat[:b.n_grad] /= world

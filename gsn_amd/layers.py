@@ -22,8 +22,6 @@ There is no CPU path: calling a layer on CPU tensors raises.
 """
 from __future__ import annotations
 
-from __future__ import annotations
-
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -711,3 +709,26 @@ class MPNN_edge_sparse_ogb(_SparseLayer):
                  aggr="add", msg_kind="ogb", eps=0, train_eps=False, flow="source_to_target", **kwargs):
         super().__init__(d_in, d_degree, degree_as_tag, retain_features, d_msg, d_up, d_h, seed, activation_name, bn,
                          d_ef=d_ef, aggr=aggr, msg_kind=msg_kind, eps=eps, train_eps=train_eps, flow=flow, **kwargs)
+
+
+# The switches moved to gsn_amd.flags in r05 (FUSED_LAYER, PACK16_LAYER, KERNEL_TIMER, CODE_STATUS_CHECK, NATIVE_DENSE_BACKWARD, ...).  Code
+# written against the earlier layout sets them HERE (``layers.FUSED_LAYER = False``): forwarded, both ways, so that such a switch still
+# switches instead of creating a dead attribute.
+import sys as _sys
+import types as _types
+
+
+class _LayersModule(_types.ModuleType):
+    def __setattr__(self, name, value):
+        if name.isupper() and not name.startswith("_") and hasattr(flags, name):
+            setattr(flags, name, value)
+            return
+        super().__setattr__(name, value)
+
+    def __getattr__(self, name):          # (only reached when the module itself has no such attribute)
+        if name.isupper() and not name.startswith("_") and hasattr(flags, name):
+            return getattr(flags, name)
+        raise AttributeError("module %r has no attribute %r" % (self.__name__, name))
+
+
+_sys.modules[__name__].__class__ = _LayersModule

@@ -23,6 +23,7 @@ import weakref
 import torch
 
 from . import _abi
+from ._runtime import INPUT_EPOCH
 
 NODE_COLS = 32      # fp16 columns of a node pack row (64 bytes)
 EDGE_COLS = 16      # fp16 columns of an edge pack row (32 bytes)
@@ -46,7 +47,7 @@ def claim(t, pack, col0):
     for c in [c for c, (ref, cw) in owners.items() if c < col0 + w and col0 < c + cw]:      # overlapping earlier claims end here
         del owners[c]
     owners[int(col0)] = (weakref.ref(t), w)
-    t._gsn_pack16 = (pack, int(col0), t._version)
+    t._gsn_pack16 = (pack, int(col0), t._version, INPUT_EPOCH[0])
 
 
 def _claim_codes(cd, pack, col0):
@@ -60,7 +61,7 @@ def _claim_codes(cd, pack, col0):
     for c in [c for c, (ref, cw) in owners.items() if c < col0 + w and col0 < c + cw]:
         del owners[c]
     owners[int(col0)] = (weakref.ref(cd), w)
-    cd._pack16 = (pack, int(col0), cd.codes._version)
+    cd._pack16 = (pack, int(col0), cd.codes._version, INPUT_EPOCH[0])
 
 
 def release(t):
@@ -74,8 +75,8 @@ def tag_of(t, n_rows, n_cols):
     tag = getattr(t, "_gsn_pack16", None)
     if tag is None:
         return None
-    pack, col0, ver = tag
-    if ver != t._version or pack.device != t.device or pack.shape != (n_rows, n_cols) or pack.dtype != torch.float16 or not pack.is_contiguous():
+    pack, col0, ver, epoch = tag
+    if epoch != INPUT_EPOCH[0] or ver != t._version or pack.device != t.device or pack.shape != (n_rows, n_cols) or pack.dtype != torch.float16 or not pack.is_contiguous():
         return None
     own = getattr(pack, "_gsn_owners", {}).get(col0)
     if own is None or own[0]() is not t:
@@ -206,7 +207,7 @@ def from_codes(x_codes, per_edge):
 def _codes_tag(cd):
     """(pack, first column, ..) of an encoded Codes object while its code tensor is unchanged (an in-place write moves the version counter)"""
     tg = cd._pack16
-    if tg is None or tg[2] != cd.codes._version:
+    if tg is None or tg[2] != cd.codes._version or tg[3] != INPUT_EPOCH[0]:      # (the epoch: a tag made before a stream capture began does not count inside it)
         return None
     own = getattr(tg[0], "_gsn_owners", {}).get(tg[1])      # (another Codes / tensor encoded into these columns since: the claim is gone)
     return tg if own is not None and own[0]() is cd else None

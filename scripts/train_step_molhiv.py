@@ -76,14 +76,15 @@ def build(args, dev, rank=0, dropout=0.5):
     """(model, data, params, optimizer, loss closure, N, E) of the step."""
     data, d_id, N, E = make_data(args.batch, 100 + rank, dev)
     L, dm = args.layers, args.d
+    act = getattr(args, "activation", "relu")      # (the tests of replay == eager use elu in the MLPs; the ogb message keeps its relu)
     kw = dict(seed=0, model_name="GSN_edge_sparse_ogb", readout="mean", dropout_features=[dropout] * (L + 1), bn=[True] * L,
               final_projection=[False] * L + [True], residual=False, inject_ids=True, vn=True, id_scope="local",
               d_msg=[dm] * L, d_out=[dm] * L, d_h=[[2 * dm]] * L, aggr="add", flow="source_to_target", msg_kind="ogb",
-              train_eps=[True] * L, activation_mlp="relu", bn_mlp=True, jk_mlp=False, degree_embedding="None",
+              train_eps=[True] * L, activation_mlp=act, bn_mlp=True, jk_mlp=False, degree_embedding="None",
               degree_as_tag=[False] * L, retain_features=[True] * L, multi_embedding_aggr="sum", features_scope="full",
               input_node_encoder="atom_encoder", d_out_node_encoder=dm, input_vn_encoder="embedding", d_out_vn_encoder=dm,
               edge_encoder="bond_encoder", d_out_edge_encoder=[dm] * L, id_embedding="embedding", d_out_id_embedding=dm,
-              d_out_degree_embedding=dm, d_out_vn=[dm] * (L - 1), vn_pooling="sum", extend_dims=True, activation="relu")
+              d_out_degree_embedding=dm, d_out_vn=[dm] * (L - 1), vn_pooling="sum", extend_dims=True, activation=act)
     torch.manual_seed(0)      # identical replicas
     model = models.GNN_OGB(9, 1, None, d_id, 3, None, None, None, None, **kw).to(dev).train()
     params = [p for p in model.parameters()]
@@ -101,6 +102,7 @@ def run(args, dev, dist=None, rank=0, world=1):
     ``types.SimpleNamespace(batch=4096, steps=5, warmup=2, layers=5, d=300)``)."""
     model, data, params, opt, loss_of, N, E = build(args, dev, rank)
     L, dm = args.layers, args.d
+    act = getattr(args, "activation", "relu")      # (the tests of replay == eager use elu in the MLPs; the ogb message keeps its relu)
     n_params = sum(p.numel() for p in params)
 
     def step():

@@ -39,13 +39,14 @@ def build(args, dev, rank=0):
         data.graph_partition = (torch.from_numpy(b.node_ptr.astype(np.int64)).to(dev), torch.from_numpy(b.edge_ptr.astype(np.int64)).to(dev),
                                 int(np.diff(b.node_ptr).max()), int(np.diff(b.edge_ptr).max()), False)
     L, d = 4, 128
+    act = getattr(args, "activation", "relu")      # (the tests of replay == eager use elu: no ReLU kink for last-bit noise to flip)
     kw = dict(seed=0, model_name="GSN_edge_sparse", readout="sum", dropout_features=[0.0] * (L + 1), bn=[True] * L,
               final_projection=[False] * L + [True], inject_ids=False, inject_edge_features=True, random_features=False,
               id_scope="local", d_msg=[d] * L, d_out=[d] * L, d_h=[[d]] * L, aggr="add", flow="source_to_target",
-              msg_kind="general", train_eps=[False] * L, activation_mlp="relu", bn_mlp=True, jk_mlp=True, degree_embedding="None",
+              msg_kind="general", train_eps=[False] * L, activation_mlp=act, bn_mlp=True, jk_mlp=True, degree_embedding="None",
               degree_as_tag=[False] * L, retain_features=[True] * L, multi_embedding_aggr="sum", input_node_encoder="one_hot_encoder",
               d_out_node_encoder=d, edge_encoder="one_hot_encoder", d_out_edge_encoder=[d] * L, id_embedding="one_hot_encoder",
-              d_out_id_embedding=d, d_out_degree_embedding=d, extend_dims=True, activation="relu")
+              d_out_id_embedding=d, d_out_degree_embedding=d, extend_dims=True, activation=act)
     torch.manual_seed(0)
     model = models.GNNSubstructures(1, 1, None, d_id, 1, [28], [4], None, None, **kw).to(dev).train()
     params = list(model.parameters())

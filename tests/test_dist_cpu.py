@@ -114,15 +114,17 @@ def test_counting_cost_proxy():
 def _train_worker(rank, world, port, q):
     """the only parity statement of the data-parallel step is "n_gpu = 1 equals the reference step" -- here the other way
     round: two ranks with half the batch each, averaged gradients, take the same steps as ONE process on the whole batch (a model
-    without BatchNorm: its statistics stay per replica by design).  Ten steps: the has-gradient flags stop being exchanged after the
-    third (gsn_amd.dist.FLAG_STABLE_CALLS) -- from then on the step reads nothing back -- and one parameter never gets a gradient."""
+    without BatchNorm: its statistics stay per replica by design).  Ten steps; the has-gradient flags ride the collective and are read in
+    EVERY call (skipping the exchange let replicas diverge when the set of used parameters grew); one parameter never gets a
+    gradient, another one gets its first gradient at step 5 and on rank 1's shard only (a data-dependent branch)."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from gsn_amd import dist as gdist
     torch.manual_seed(3)
     model = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.ReLU(), torch.nn.Linear(16, 16), torch.nn.ReLU(), torch.nn.Linear(16, 1)).double()
     unused = torch.nn.Parameter(torch.ones(3, dtype=torch.float64))
-    params = list(model.parameters()) + [unused]
+    late = torch.nn.Parameter(torch.full((1,), 0.5, dtype=torch.float64))
+    params = list(model.parameters()) + [unused, late]
     opt = torch.optim.SGD(params, lr=0.05, momentum=0.9, weight_decay=1e-3)
     g = torch.Generator().manual_seed(5)
     x, y = torch.randn(64, 6, generator=g, dtype=torch.float64), torch.randn(64, 1, generator=g, dtype=torch.float64)
@@ -131,16 +133,18 @@ def _train_worker(rank, world, port, q):
     for step in range(10):
         opt.zero_grad(set_to_none=True)
         # per-rank MEAN over its shard of equal size: the average over ranks is the whole batch's mean (train_test_funcs.py:88-106)
-        torch.nn.functional.mse_loss(model(x[lo:hi]), y[lo:hi]).backward()
-        b = list(gdist._BUCKETS.values())
-        before = b[0].calls if b else 0
+        out = model(x[lo:hi])
+        if step >= 5 and lo >= 32:                       # rows 32 .. 63 only, from the sixth step on
+            out = out + late * x[lo:hi, :1]
+        torch.nn.functional.mse_loss(out, y[lo:hi]).backward()
         gdist.allreduce_gradients(params, average=True)
+        assert (late.grad is not None) == (step >= 5), (rank, step)          # on BOTH ranks, in the very step it appears
         b = list(gdist._BUCKETS.values())[0]
         reads.append(b.stable)
         opt.step()
     assert unused.grad is None and torch.equal(unused.detach(), torch.ones(3, dtype=torch.float64))
-    assert reads[:3] == [1, 2, 3] and reads[3:] == [3] * 7, reads          # (no flag exchange, no read-back after the third call)
-    q.put((rank, [p.detach().clone().numpy() for p in model.parameters()]))
+    assert reads == [1, 2, 3, 4, 5, 1, 2, 3, 4, 5], reads                  # (read in every call; the set changed once)
+    q.put((rank, [p.detach().clone().numpy() for p in list(model.parameters()) + [late]]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -158,15 +162,19 @@ def test_two_ranks_take_the_steps_of_one_process_on_the_whole_batch():
         assert p.exitcode == 0
     torch.manual_seed(3)
     model = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.ReLU(), torch.nn.Linear(16, 16), torch.nn.ReLU(), torch.nn.Linear(16, 1)).double()
-    opt = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-3)
+    late = torch.nn.Parameter(torch.full((1,), 0.5, dtype=torch.float64))
+    opt = torch.optim.SGD(list(model.parameters()) + [late], lr=0.05, momentum=0.9, weight_decay=1e-3)
     g = torch.Generator().manual_seed(5)
     x, y = torch.randn(64, 6, generator=g, dtype=torch.float64), torch.randn(64, 1, generator=g, dtype=torch.float64)
     for step in range(10):
         opt.zero_grad(set_to_none=True)
-        torch.nn.functional.mse_loss(model(x), y).backward()
+        out = model(x)
+        if step >= 5:
+            out = out + late * x[:, :1] * (torch.arange(64) >= 32).to(torch.float64).unsqueeze(1)
+        torch.nn.functional.mse_loss(out, y).backward()
         opt.step()
     for (r, ps) in res:
-        for a, p in zip(ps, model.parameters()):
+        for a, p in zip(ps, list(model.parameters()) + [late]):
             assert abs(a - p.detach().numpy()).max() < 1e-12, r
     for a, b in zip(res[0][1], res[1][1]):
         assert abs(a - b).max() == 0                    # the replicas are identical bit for bit

@@ -63,7 +63,7 @@ def test_tag_dies_with_its_tensor():
     gc.collect()
     assert epk._gsn_owners[0][0]() is None                         # a dead weak reference never matches a live tensor
     u = torch.zeros(3, 8)
-    u._gsn_pack16 = (epk, 0, u._version)                           # a forged tag without a claim
+    u._gsn_pack16 = (epk, 0, u._version, 0)                        # a forged tag without a claim
     assert packs.tag_of(u, 3, packs.EDGE_COLS) is None
 
 
@@ -91,3 +91,36 @@ def test_codes_claims_enter_the_owner_table():
     assert packs.tag_of(ids, 6, packs.EDGE_COLS) is None
     c.codes.add_(1)                                                # codes rewritten in place: the version counter moved
     assert packs._codes_tag(c) is None
+
+
+def test_tags_made_before_a_capture_epoch_do_not_count_inside_it():
+    """drop_input_caches() (called in front of a stream capture) only cleared the CSR cache; a persistent Codes object or fp32 tensor
+    tagged during the warm-up kept a valid tag, the capture skipped the encoder launch, and a replay after ``codes.copy_(new)`` read the warm-up's
+    rows.  Tags carry the epoch they were made in; the epoch moves with drop_input_caches()."""
+    from gsn_amd import _caches
+    epk = torch.zeros(4, packs.EDGE_COLS, dtype=torch.float16)
+    t = _tagged(4, 8, epk, 0)
+    cd = _FakeCodes(4, [4])
+    packs._claim_codes(cd, epk, 12)
+    assert packs.tag_of(t, 4, packs.EDGE_COLS) == (epk, 0) and packs._codes_tag(cd) is not None
+    _caches.drop_input_caches()
+    assert packs.tag_of(t, 4, packs.EDGE_COLS) is None and packs._codes_tag(cd) is None
+    packs.claim(t, epk, 0)                                         # made again in the new epoch (inside the capture: by a recorded launch)
+    packs._claim_codes(cd, epk, 12)
+    assert packs.tag_of(t, 4, packs.EDGE_COLS) == (epk, 0) and packs._codes_tag(cd) is not None
+
+
+def test_switches_set_on_the_layers_module_reach_gsn_amd_flags():
+    """the switches moved from gsn_amd.layers to gsn_amd.flags; ``layers.FUSED_LAYER = False`` in existing user code must still switch."""
+    from gsn_amd import flags, layers
+    old = flags.FUSED_LAYER
+    try:
+        layers.FUSED_LAYER = not old
+        assert flags.FUSED_LAYER == (not old) and layers.FUSED_LAYER == (not old) and "FUSED_LAYER" not in vars(layers)
+        flags.KERNEL_TIMER = {}
+        assert layers.KERNEL_TIMER == {}
+    finally:
+        flags.FUSED_LAYER, flags.KERNEL_TIMER = old, None
+    import pytest
+    with pytest.raises(AttributeError):
+        layers.NO_SUCH_SWITCH

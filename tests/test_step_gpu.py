@@ -273,3 +273,17 @@ def test_step_is_capturable_and_replays_on_refilled_inputs():
     ids1, y1, _ = step(node_ptr, edge_ptr, ei, xc, efc, mn, me)
     torch.cuda.synchronize()
     assert torch.equal(ids_g, ids1) and torch.equal(y_g, y1) and not torch.equal(y1, y0)
+
+
+def test_a_partition_that_under_declares_its_graphs_is_refused():
+    """kernels that size their tiles by the declared max_nodes trusted it silently; checked where that is free (host pointers) or asked for."""
+    from gsn_amd import layers
+    b, node_ptr, edge_ptr, ei, atoms, bonds = _zinc(12, 4)
+    mn, me = int(np.diff(b.node_ptr).max()), int(np.diff(b.edge_ptr).max())
+    assert layers.set_graph_partition(ei, node_ptr, edge_ptr, mn, me, check=True)
+    with pytest.raises(ValueError, match="larger than the declared max"):
+        layers.set_graph_partition(ei, node_ptr, edge_ptr, mn - 1, me, check=True)
+    with pytest.raises(ValueError, match="larger than the declared max"):
+        layers.set_graph_partition(ei, torch.from_numpy(b.node_ptr), torch.from_numpy(b.edge_ptr), mn, me - 1, check=False)      # host pointers: always
+    assert layers.set_graph_partition(ei, node_ptr, edge_ptr, mn - 1, me, check=False)      # device pointers, no check asked for: the caller vouches
+    layers.set_graph_partition(ei, node_ptr, edge_ptr, mn, me, check=False)
