@@ -357,6 +357,7 @@ __device__ __forceinline__ void side_block(const CountArgs &a, unsigned char *sm
 // diagnostic build (-DCOUNT_PROF, scripts/rr_variant.sh with RR_VARIANT_SRC=count): cycles of thread 0 per phase, summed over the workgroups
 #ifdef COUNT_PROF
 __device__ unsigned long long *g_count_prof;   // [items][8], set by the launcher
+__device__ unsigned long long *g_count_prof2;  // [12] wave-level sums over the launch: the arms inside lane_step (count_core.h: Lane::prof)
 #define COUNT_T(I) do { __syncthreads(); if (threadIdx.x == 0 && g_count_prof) { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); g_count_prof[(size_t)blockIdx.x * 16 + (I)] = t_now - t_prev; t_prev = t_now; } } while (0)
 #else
 #define COUNT_T(I)
@@ -659,6 +660,9 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
 #define COUNT_ARM_T0() 0ull
 #endif
     Lane<W> s;
+#ifdef COUNT_PROF
+    for (int q = 0; q < 12; ++q) s.prof[q] = 0;
+#endif
     s.l = -1; s.cnt = 0; s.k = 0; s.nfix = 0; s.fvec = fv_roots<W>(0, 0); s.plan = plans;
     s.balls = balls; s.ball_n = a.n_cap; s.degp = nullptr; s.loop = 0;
     if (TAIL) { s.degp = degp; s.loop = a.tail_loop; }
@@ -744,6 +748,9 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
                 const unsigned long long t0 = COUNT_ARM_T0();
                 lane_step<W, DIR, TAIL>(s, A, lane_valid, stack, T, tid, A_in);
                 COUNT_ARM(2, t0);
+#ifdef COUNT_PROF
+                s.prof[9] += 1; s.prof[10] += (unsigned long long)__popcll(__ballot(1));      // lane_step visits / active lanes
+#endif
             }
             const unsigned long long t0f = COUNT_ARM_T0();
             if (s.l < 0 && p_i >= p_e) {
@@ -760,6 +767,7 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
 
     COUNT_T(5);
 #ifdef COUNT_PROF
+    if ((threadIdx.x & 63) == 0 && g_count_prof2) for (int q = 0; q < 12; ++q) atomicAdd(&g_count_prof2[q], s.prof[q]);
     if (threadIdx.x == 0 && g_count_prof) { g_count_prof[(size_t)blockIdx.x * 16 + 7] = ((unsigned long long)prof_iters << 32) | prof_lanes; for (int q = 0; q < 4; ++q) g_count_prof[(size_t)blockIdx.x * 16 + 8 + q] = prof_arm[q]; }
 #endif
     // ---- phase 4: coalesced write of the staged rows --------------------------------------------------------------
@@ -931,6 +939,9 @@ static int launch_d(CountArgs &a, int n_items, size_t lds, hipStream_t stream) {
             (void)hipMalloc(&buf, (size_t)n_items * 128);
             (void)hipMemset(buf, 0, (size_t)n_items * 128);
             (void)hipMemcpyToSymbol(HIP_SYMBOL(g_count_prof), &buf, sizeof(buf));
+            unsigned long long *buf2 = buf + (size_t)n_items * 16 - 16;      // (the last item's slots 16..: its own row is read first)
+            (void)hipMalloc(&buf2, 128); (void)hipMemset(buf2, 0, 128);
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_count_prof2), &buf2, sizeof(buf2));
             hipLaunchKernelGGL((count_kernel<W, T, DIR, TAIL, MOL>), dim3((unsigned)n_items), dim3(T), lds, stream, a);
             (void)hipStreamSynchronize(stream);
             unsigned long long *h = new unsigned long long[(size_t)n_items * 16];
@@ -947,6 +958,17 @@ static int launch_d(CountArgs &a, int n_items, size_t lds, hipStream_t stream) {
             fprintf(stderr, "countprof W %d T %d items %d: cycles per workgroup: clear+plan %.0f adjacency %.0f cores %.0f balls %.0f edge ranks %.0f task pool %.0f write %.0f\n", W, T, n_items,
                     s[0] / n_items, s[1] / n_items, s[2] / n_items, s[3] / n_items, s[4] / n_items, s[5] / n_items, s[6] / n_items);
             delete[] h;
+            {
+                unsigned long long p2[16];
+                (void)hipMemcpy(p2, buf2, 96, hipMemcpyDeviceToHost);
+                fprintf(stderr, "countprof step arms (summed over the launch's waves): tail_loop %.3g cycles in %.3g visits, %.1f lanes per visit, %.1f iterations per lane, %.1f = the longest lane's per visit | "
+                                "tail_pairs %.3g cycles in %.3g visits, %.1f lanes per visit | lane_step %.3g visits, %.1f lanes per visit\n",
+                        (double)p2[0], (double)p2[1], p2[1] ? (double)p2[2] / p2[1] : 0.0, p2[2] ? (double)p2[3] / p2[2] : 0.0, p2[1] ? (double)p2[4] / p2[1] : 0.0,
+                        (double)p2[5], (double)p2[6], p2[6] ? (double)p2[7] / p2[6] : 0.0, (double)p2[9], p2[9] ? (double)p2[10] / p2[9] : 0.0);
+                unsigned long long *nul2 = nullptr;
+                (void)hipMemcpyToSymbol(HIP_SYMBOL(g_count_prof2), &nul2, sizeof(nul2));
+                (void)hipFree(buf2);
+            }
             unsigned long long *nul = nullptr;
             (void)hipMemcpyToSymbol(HIP_SYMBOL(g_count_prof), &nul, sizeof(nul));
             (void)hipFree(buf);

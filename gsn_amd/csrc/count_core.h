@@ -270,7 +270,18 @@ struct Lane {
     int ball_n;              // vertex capacity of one table
     const uint64_t *degp;    // degree bit planes of the cores (plans with a chain tail) or nullptr
     int loop;                // W == 1: the last two levels in tail_loop all the same (dense small graphs: the launcher decides)
+#if defined(COUNT_PROF) && defined(__HIPCC__)
+    unsigned long long prof[12];   // wave-level: [0..2] tail_loop cycles / visits / active lanes, [3] its iterations summed over lanes, [4] max iterations per visit summed,
+                                   // [5..7] tail_pairs cycles / visits / lanes, [8..10] rest of lane_step (candidates + frames + climb) cycles / visits / lanes
+#endif
 };
+#if defined(COUNT_PROF) && defined(__HIP_DEVICE_COMPILE__)
+#define CP_T0() const unsigned long long cp_t0 = __builtin_amdgcn_s_memtime()
+#define CP_ADD(S, I) do { (S).prof[I] += __builtin_amdgcn_s_memtime() - cp_t0; (S).prof[(I) + 1] += 1; (S).prof[(I) + 2] += (unsigned long long)__popcll(__ballot(1)); } while (0)
+#else
+#define CP_T0()
+#define CP_ADD(S, I)
+#endif
 
 // core index of a plan: images must lie in the min-degree(H) core of the target; cores 0..CORE_MAX are tabulated
 // (core d for d > CORE_MAX uses core CORE_MAX, a superset)
@@ -431,8 +442,28 @@ GSN_HD void lane_step(Lane<W> &s, const uint64_t *A, const uint64_t *valid, uint
     } else if (TAIL && nl == s.k - 2 && (TailLoop<W>::on || s.loop || plan_tail(s.plan))) {
         // the last two levels: in closed form where the plan allows it (level k - 2 is not enumerated), else in one tight loop over its images
         const int tm = plan_tail(s.plan);
-        s.cnt += tm ? tail_pairs<W, DIR>(tm, C, s.plan, s.k, s.fvec, used2, A, valid, s.balls, s.ball_n, A_in, s.degp)
-                    : tail_loop<W, DIR>(C, s.plan, s.k, s.fvec, used2, A, valid, s.balls, s.ball_n, A_in);
+        if (tm) {
+            CP_T0();
+            s.cnt += tail_pairs<W, DIR>(tm, C, s.plan, s.k, s.fvec, used2, A, valid, s.balls, s.ball_n, A_in, s.degp);
+            CP_ADD(s, 5);
+        } else {
+            CP_T0();
+            s.cnt += tail_loop<W, DIR>(C, s.plan, s.k, s.fvec, used2, A, valid, s.balls, s.ball_n, A_in);
+            CP_ADD(s, 0);
+#if defined(COUNT_PROF) && defined(__HIP_DEVICE_COMPILE__)
+            {   // (inside a divergent branch: ballots over the active lanes, no shuffles)
+                const int it = popc<W>(C);
+                unsigned long long alive = __ballot(1), sm = 0;
+                int mx = 0;
+                for (int b = 10; b >= 0; --b) {
+                    const unsigned long long hb = __ballot((it >> b) & 1);
+                    sm += (unsigned long long)__popcll(hb) << b;
+                    if (hb & alive) { mx |= 1 << b; alive &= hb; }
+                }
+                s.prof[3] += sm; s.prof[4] += (unsigned long long)mx;
+            }
+#endif
+        }
     } else {
         bool cempty = true;
 #pragma unroll

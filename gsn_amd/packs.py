@@ -139,6 +139,8 @@ def _pack_codes(cd, pack, col0, one_col, check=None):
     if check is None:
         check = flags.CODE_STATUS_CHECK if cd.check is None else cd.check
     check = check and not cd.clamp
+    if check and torch.cuda.is_current_stream_capturing():
+        check = False          # (nothing can be read back inside a stream capture; an out-of-range code leaves a zero block, as the dense encoder)
     status = torch.zeros(1, dtype=torch.int32, device=cd.codes.device) if check else None
     with _abi.device_guard(cd.codes.device):
         _abi.check(_abi.lib().gsn_one_hot_pack16_hip(cd.codes.shape[0], cd.codes.shape[1], cd.codes.data_ptr(), _abi.ptr(ncls), int(cd.clamp),

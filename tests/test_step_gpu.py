@@ -287,3 +287,32 @@ def test_a_partition_that_under_declares_its_graphs_is_refused():
         layers.set_graph_partition(ei, torch.from_numpy(b.node_ptr), torch.from_numpy(b.edge_ptr), mn, me - 1, check=False)      # host pointers: always
     assert layers.set_graph_partition(ei, node_ptr, edge_ptr, mn - 1, me, check=False)      # device pointers, no check asked for: the caller vouches
     layers.set_graph_partition(ei, node_ptr, edge_ptr, mn, me, check=False)
+
+
+def test_graphed_step_on_persistent_codes_encodes_them_again_in_every_replay():
+    """Codes objects that survive across forwards were tagged with their packs during the warm-up; the capture found valid tags,
+    recorded only the layer kernel, and a replay after ``codes.copy_(new)`` read the warm-up's rows.  Tags now carry a capture epoch."""
+    from gsn_amd import layers
+    from gsn_amd.counting import CountPlan, count_batch
+    from gsn_amd.graphs import GraphedStep
+    b, node_ptr, edge_ptr, ei, atoms, bonds = _zinc(96, 31)
+    N = b.num_nodes
+    dev = _dev()
+    plan = CountPlan.get(_cycles(), "edge", False)
+    ids, _ = count_batch(plan, node_ptr, edge_ptr, ei, ids_are_global=True, device=dev)
+    torch.manual_seed(4)
+    layer = layers.GSN_edge_sparse(flow="source_to_target", **CTOR).to(dev).eval()
+    deg = torch.zeros(N, device=dev)
+    xc, efc, idc = layers.Codes(atoms, [28]), layers.Codes(bonds, [4]), layers.Codes(ids, [3, 3, 3, 3], clamp=True)
+
+    def fn():
+        with torch.no_grad():
+            return layer(xc, ei, identifiers=idc, degrees=deg, edge_features=efc)
+    gs = GraphedStep(fn, warmup=2)
+    y0 = gs().clone()
+    atoms.copy_((atoms + 5) % 28); bonds.copy_((bonds + 1) % 4); ids.copy_((ids + 1) % 3)
+    y1 = gs().clone()
+    with torch.no_grad():
+        y_ref = layer(layers.Codes(atoms.clone(), [28]), ei, identifiers=layers.Codes(ids.clone(), [3, 3, 3, 3], clamp=True), degrees=deg,
+                      edge_features=layers.Codes(bonds.clone(), [4]))
+    assert torch.equal(y1, y_ref) and not torch.equal(y0, y1)
