@@ -96,3 +96,18 @@ torch.cuda.current_stream(dev).wait_stream(s)
 with torch.cuda.graph(g):
     new_step()
 timeit(g.replay, "one-call step, HIP graph")
+
+# (bench.py's capture allocates the layer rows INSIDE the capture: from the graph's private pool)
+def new_step_fresh():
+    return step(node_ptr, edge_ptr, ei, xc, efc, mn, me, ids_out=ids_out)[1]
+timeit(new_step_fresh, "one-call step, fresh rows")
+g2 = torch.cuda.CUDAGraph()
+s.wait_stream(torch.cuda.current_stream(dev))
+with torch.cuda.stream(s):
+    new_step_fresh()
+torch.cuda.current_stream(dev).wait_stream(s)
+with torch.cuda.graph(g2):
+    y_g2 = new_step_fresh()
+timeit(g2.replay, "HIP graph, rows from its pool")
+timeit(g.replay, "HIP graph, caller's rows")
+timeit(new_step, "one-call step")
