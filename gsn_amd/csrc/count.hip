@@ -615,6 +615,23 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
                     primary = live && !(a_sym && rev >= 0 && u > v);
                     if (!live && part == 0)
                         for (int col = 0; col < n_cols; ++col) emit_cell(c, col, 0ull);
+#ifndef COUNT_NO_CORE_FILTER
+                    if (primary) {
+                        // A root outside the WEAKEST core any plan of the launch lives in is the image of nothing (cores are nested: it is outside
+                        // every plan's core; lane_begin would find that out one task at a time -- a pull, a begin and a finish per cell).  Its
+                        // cells, and those of the reverse row it would have written, are zero here and the row never enters the pool: on
+                        // molecules (cycle plans: the 2-core = ring systems and what connects them) more than half of the rows.
+                        const uint64_t *cm = cores + (__ffs(a.core_mask | (1 << CORE_MAX)) - 1) * W;
+                        if (!(((cm[u >> 6] >> (u & 63)) & (cm[v >> 6] >> (v & 63))) & 1ull)) {
+                            primary = false;
+                            if (part == 0)
+                                for (int col = 0; col < n_cols; ++col) {
+                                    emit_cell(c, col, 0ull);
+                                    if (a_sym && rev >= 0) emit_cell(rev, col, 0ull);
+                                }
+                        }
+                    }
+#endif
                 }
                 const uint64_t pm = __ballot(primary);
                 if (primary) prim[n_prim + __popcll(pm & ((1ull << tid) - 1ull))] = (uint16_t)c;
