@@ -354,7 +354,9 @@ __device__ __forceinline__ void side_block(const CountArgs &a, unsigned char *sm
     }
 }
 
-// diagnostic build (-DCOUNT_PROF, scripts/rr_variant.sh with RR_VARIANT_SRC=count): cycles of thread 0 per phase, summed over the workgroups
+// diagnostic build (-DCOUNT_PROF, scripts/rr_variant.sh with RR_VARIANT_SRC=count): cycles of thread 0 per phase, summed over the workgroups;
+// with -DCOUNT_PROF_STEP as well: the arms inside lane_step (count_core.h: Lane::prof -- 24 more registers per lane: for the large-graph
+// instantiations, it distorts the molecule ones)
 #ifdef COUNT_PROF
 __device__ unsigned long long *g_count_prof;   // [items][8], set by the launcher
 __device__ unsigned long long *g_count_prof2;  // [12] wave-level sums over the launch: the arms inside lane_step (count_core.h: Lane::prof)
@@ -466,6 +468,17 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
             reinterpret_cast<int *>(smem + a.off_enc)[2 * c + 1] = a.enc_n[c];
         }
     if (tid < 8) misc[tid] = 0;
+    // staged outputs start at zero: rows that carry nothing (self loops, earlier duplicates) and rows whose roots lie outside every plan's core
+    // then need no cell-by-cell zeros from the one wave that ranks the columns (8 LDS stores per such row: 7 k of a molecule pair's 60 k cycles)
+    const bool bulk_zero = edge_mode && a_stage_out && (!a_enc || a_enc_stage);
+    if (bulk_zero) {
+        uint32_t *z = reinterpret_cast<uint32_t *>(out_lds);
+        for (int i = tid; i < (rows * n_cols + 1) / 2; i += T) z[i] = 0u;
+        if (a_enc && !a_enc_from_counts) {
+            unsigned char *zb = smem + a.off_encst;
+            for (int i = tid; i < rows * n_cols; i += T) zb[i] = 0;      // (count 0 = class 0)
+        }
+    }
     __syncthreads();
 
     COUNT_T(0);
@@ -613,7 +626,7 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
                     }
                     revof[c] = rev < 0 ? (uint16_t)0xffffu : (uint16_t)rev;
                     primary = live && !(a_sym && rev >= 0 && u > v);
-                    if (!live && part == 0)
+                    if (!live && part == 0 && !bulk_zero)
                         for (int col = 0; col < n_cols; ++col) emit_cell(c, col, 0ull);
 #ifndef COUNT_NO_CORE_FILTER
                     if (primary) {
@@ -624,7 +637,7 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
                         const uint64_t *cm = cores + (__ffs(a.core_mask | (1 << CORE_MAX)) - 1) * W;
                         if (!(((cm[u >> 6] >> (u & 63)) & (cm[v >> 6] >> (v & 63))) & 1ull)) {
                             primary = false;
-                            if (part == 0)
+                            if (part == 0 && !bulk_zero)
                                 for (int col = 0; col < n_cols; ++col) {
                                     emit_cell(c, col, 0ull);
                                     if (a_sym && rev >= 0) emit_cell(rev, col, 0ull);
@@ -677,7 +690,7 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
 #define COUNT_ARM_T0() 0ull
 #endif
     Lane<W> s;
-#ifdef COUNT_PROF
+#ifdef COUNT_PROF_STEP
     for (int q = 0; q < 12; ++q) s.prof[q] = 0;
 #endif
     s.l = -1; s.cnt = 0; s.k = 0; s.nfix = 0; s.fvec = fv_roots<W>(0, 0); s.plan = plans;
@@ -765,7 +778,7 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
                 const unsigned long long t0 = COUNT_ARM_T0();
                 lane_step<W, DIR, TAIL>(s, A, lane_valid, stack, T, tid, A_in);
                 COUNT_ARM(2, t0);
-#ifdef COUNT_PROF
+#ifdef COUNT_PROF_STEP
                 s.prof[9] += 1; s.prof[10] += (unsigned long long)__popcll(__ballot(1));      // lane_step visits / active lanes
 #endif
             }
@@ -784,7 +797,9 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
 
     COUNT_T(5);
 #ifdef COUNT_PROF
+#ifdef COUNT_PROF_STEP
     if ((threadIdx.x & 63) == 0 && g_count_prof2) for (int q = 0; q < 12; ++q) atomicAdd(&g_count_prof2[q], s.prof[q]);
+#endif
     if (threadIdx.x == 0 && g_count_prof) { g_count_prof[(size_t)blockIdx.x * 16 + 7] = ((unsigned long long)prof_iters << 32) | prof_lanes; for (int q = 0; q < 4; ++q) g_count_prof[(size_t)blockIdx.x * 16 + 8 + q] = prof_arm[q]; }
 #endif
     // ---- phase 4: coalesced write of the staged rows --------------------------------------------------------------

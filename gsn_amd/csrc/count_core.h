@@ -270,12 +270,12 @@ struct Lane {
     int ball_n;              // vertex capacity of one table
     const uint64_t *degp;    // degree bit planes of the cores (plans with a chain tail) or nullptr
     int loop;                // W == 1: the last two levels in tail_loop all the same (dense small graphs: the launcher decides)
-#if defined(COUNT_PROF) && defined(__HIPCC__)
+#if defined(COUNT_PROF_STEP) && defined(__HIPCC__)
     unsigned long long prof[12];   // wave-level: [0..2] tail_loop cycles / visits / active lanes, [3] its iterations summed over lanes, [4] max iterations per visit summed,
                                    // [5..7] tail_pairs cycles / visits / lanes, [8..10] rest of lane_step (candidates + frames + climb) cycles / visits / lanes
 #endif
 };
-#if defined(COUNT_PROF) && defined(__HIP_DEVICE_COMPILE__)
+#if defined(COUNT_PROF_STEP) && defined(__HIP_DEVICE_COMPILE__)
 #define CP_T0() const unsigned long long cp_t0 = __builtin_amdgcn_s_memtime()
 #define CP_ADD(S, I) do { (S).prof[I] += __builtin_amdgcn_s_memtime() - cp_t0; (S).prof[(I) + 1] += 1; (S).prof[(I) + 2] += (unsigned long long)__popcll(__ballot(1)); } while (0)
 #else
@@ -450,7 +450,7 @@ GSN_HD void lane_step(Lane<W> &s, const uint64_t *A, const uint64_t *valid, uint
             CP_T0();
             s.cnt += tail_loop<W, DIR>(C, s.plan, s.k, s.fvec, used2, A, valid, s.balls, s.ball_n, A_in);
             CP_ADD(s, 0);
-#if defined(COUNT_PROF) && defined(__HIP_DEVICE_COMPILE__)
+#if defined(COUNT_PROF_STEP) && defined(__HIP_DEVICE_COMPILE__)
             {   // (inside a divergent branch: ballots over the active lanes, no shuffles)
                 const int it = popc<W>(C);
                 unsigned long long alive = __ballot(1), sm = 0;

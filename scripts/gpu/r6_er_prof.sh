@@ -1,6 +1,6 @@
 #!/bin/bash
 # r06: BASELINE config 5 (ER G(128,1000) x 21 five-vertex patterns, 2 048 graphs per launch): phase profile (COUNT_PROF build:
-# RR_VARIANT_SRC=count scripts/rr_variant.sh cprof -DCOUNT_PROF), kernel stats and SQ counters of the launch
+# RR_VARIANT_SRC=count scripts/rr_variant.sh cprof -DCOUNT_PROF -DCOUNT_PROF_STEP), kernel stats and SQ counters of the launch
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/r6er
