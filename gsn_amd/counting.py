@@ -22,6 +22,8 @@ from .patterns import PatternGraph
 __all__ = ["CountPlan", "count_batch", "counts2ids_batch", "subgraph_isomorphism_vertex_counts",
            "subgraph_isomorphism_edge_counts", "subgraph_counts2ids"]
 
+GSN_KMAX = 9                                            # include/gsn_abi.h
+PLAN_STRIDE_WORDS = 2 + GSN_KMAX + (GSN_KMAX + 3) // 4  # csrc/gsn_internal.h (undirected plans)
 _MODE = {"vertex": 0, "edge": 1}
 _STATUS_MSG = {2: "graph larger than the max_nodes / max_edges given to the call", 3: "vertex id outside [0, num_nodes)"}
 _PLAN_CACHE = {}

@@ -22,7 +22,12 @@ constexpr uint32_t PLAN_MAGIC = 0x47534e31u;  // 'GSN1'
 constexpr int PLAN_HEADER_WORDS = 8;
 //            directed patterns only: [PLAN_STRIDE_WORDS + l] level l: in_adj_mask | in_nonadj_mask<<8 -- the image must (not) be
 //                         an IN-neighbour of f_j (pattern arc level l -> level j); [2+l] then speaks of OUT-neighbours of f_j
-constexpr int PLAN_STRIDE_WORDS = 2 + GSN_KMAX + GSN_KMAX / 4;
+constexpr int PLAN_BALL_WORDS = (GSN_KMAX + 3) / 4;
+constexpr int PLAN_STRIDE_WORDS = 2 + GSN_KMAX + PLAN_BALL_WORDS;
+// (the partial map of a search holds levels 0 .. 7 -- 8 bits each, or 16 in two registers: count_core.h FVec -- and the masks of a level name
+//  EARLIER levels by bit: a ninth level (GSN_KMAX = 9) needs neither a ninth slot nor a ninth bit, because the last level of a plan is never
+//  enumerated: it is counted by popcount or by a closed form)
+static_assert(GSN_KMAX <= 9, "level masks are 8 bits wide: the last level may be the ninth, no more");
 constexpr int PLAN_STRIDE_DIRECTED = PLAN_STRIDE_WORDS + GSN_KMAX;
 inline int plan_stride(uint32_t flags) { return (flags & 2u) ? PLAN_STRIDE_DIRECTED : PLAN_STRIDE_WORDS; }
 

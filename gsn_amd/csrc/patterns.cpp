@@ -23,7 +23,7 @@ namespace gsn {
 struct Pattern {
     int k = 0;
     bool directed = false;                       // main.py --directed: the rows of the edge list are arcs
-    uint8_t adj[GSN_KMAX] = {0};                 // adj[i] bit j: edge {i,j} (both rows) or, directed, arc i -> j
+    uint16_t adj[GSN_KMAX] = {0};                // adj[i] bit j: edge {i,j} (both rows) or, directed, arc i -> j
     std::vector<std::array<uint8_t, GSN_KMAX>> aut;  // all automorphisms sigma: sigma[i] = image of i
     int vorbit[GSN_KMAX] = {0};
     int n_vorbits = 0;
@@ -65,8 +65,8 @@ static int analyse(int64_t n_edges, const int64_t *edges, int flags, Pattern &P)
     for (int64_t i = 0; i < n_edges; ++i) {
         int u = (int)edges[2 * i], v = (int)edges[2 * i + 1];
         if (u == v) continue;  // gt.stats.remove_self_loops
-        P.adj[u] |= (uint8_t)(1u << v);
-        if (!P.directed) P.adj[v] |= (uint8_t)(1u << u);
+        P.adj[u] |= (uint16_t)(1u << v);
+        if (!P.directed) P.adj[v] |= (uint16_t)(1u << u);
     }
     std::array<uint8_t, GSN_KMAX> sigma{};
     enum_aut(P, 0, sigma, 0, P.aut);
@@ -459,7 +459,7 @@ extern "C" int gsn_count_plan_build(int mode, int induced, int directed_orbits, 
         w[1] = (uint32_t)pl.pattern | ((uint32_t)pl.root_a << 16) | ((uint32_t)pl.min_degree << 20) | ((uint32_t)pl.root_b << 24) |
                ((uint32_t)tail_mode << 28) | ((uint32_t)(twin_run - 2) << 30);
         for (int l = 0; l < GSN_KMAX; ++l) w[2 + l] = pl.level[l];
-        for (int l = 0; l < GSN_KMAX / 4; ++l) w[2 + GSN_KMAX + l] = 0;
+        for (int l = 0; l < PLAN_BALL_WORDS; ++l) w[2 + GSN_KMAX + l] = 0;
         for (int l = 0; l < GSN_KMAX; ++l) w[2 + GSN_KMAX + l / 4] |= (uint32_t)pl.ball[l] << (8 * (l % 4));
         if (directed)
             for (int l = 0; l < GSN_KMAX; ++l) w[PLAN_STRIDE_WORDS + l] = pl.level_in[l];

@@ -61,9 +61,9 @@ def analyse(edge_list, directed_orbits=False, directed=False):
     e = np.ascontiguousarray(np.asarray(list(edge_list), dtype=np.int64).reshape(-1, 2))
     L = _abi.lib()
     k, nvo, na, neo, aut = (ctypes.c_int64() for _ in range(5))
-    vorb = np.zeros(8, dtype=np.int64)
-    arcs = np.zeros((64, 2), dtype=np.int64)
-    aorb = np.zeros(64, dtype=np.int64)
+    vorb = np.zeros(16, dtype=np.int64)          # (GSN_KMAX = 9 vertices, at most 72 arcs)
+    arcs = np.zeros((128, 2), dtype=np.int64)
+    aorb = np.zeros(128, dtype=np.int64)
     rc = L.gsn_pattern_orbits(len(e), _abi.ptr(e), int(bool(directed_orbits)) | (2 if directed else 0), ctypes.addressof(k), _abi.ptr(vorb),
                               ctypes.addressof(nvo), _abi.ptr(arcs), _abi.ptr(aorb), ctypes.addressof(na),
                               ctypes.addressof(neo), ctypes.addressof(aut))

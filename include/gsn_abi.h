@@ -25,7 +25,7 @@ extern "C" {
 #endif
 
 #define GSN_ABI_VERSION 1
-#define GSN_KMAX 8 /* max pattern vertices the counting kernel handles (reference configs use k <= 8) */
+#define GSN_KMAX 9 /* max pattern vertices the counting kernel handles: --k 8 of star_graph is a 9-vertex pattern (utils.py:59-62) */
 #define GSN_SEG_RANGE_ROWS 16 /* rows one thread reduces in the fused scatter-add epilogue (see gsn_segsum_prepare_hip) */
 
 enum {

@@ -98,6 +98,18 @@ def main():
                     assert sorted(tuple(a) for p_ in d['orbit_partition'].values() for a in p_) == sorted(tuple(a) for a in arcs), key
                     assert len(d['orbit_partition']) == int(z[key + "/n_eorbits"]), key
                 n_patterns += 1
+    # --id_type star_graph --k 8 (utils.py:59-62): its largest pattern has NINE vertices (GSN_KMAX 8 -> 9 in r06); tables of counts_stars.npz
+    zs = np.load(os.path.join(REPO, "tests", "golden", "counts_stars.npz"), allow_pickle=False)
+    for scope in ("global", "local"):
+        args = dict(base, id_scope=scope, edge_automorphism="induced", id_type="star_graph", k=[8])
+        res = utils.process_arguments(args)
+        el = res[0]["custom_edge_list"][-1]
+        assert [list(e) for e in el] == zs["star8/edges"].tolist()
+        subgraph, orbit_partition, orbit_membership, aut_count = res[3](edge_list=el, directed=False, directed_orbits=False)
+        assert int(aut_count) == int(zs["star8/aut_count"]) == 40320
+        key = "star8/v_membership" if scope == "global" else "star8/e_membership"
+        assert [int(orbit_membership[i]) for i in range(len(orbit_membership))] == zs[key].tolist()
+        n_patterns += 1
     print("binding ok: reference utils.process_arguments / get_custom_edge_list over gsn_amd/dropin, %d pattern tables equal to orbits.npz" % n_patterns)
 
 

@@ -1190,6 +1190,86 @@ def gen_cliques(ref, out):
     np.savez_compressed(os.path.join(out, "counts_cliques.npz"), **rec)
 
 
+def gen_stars(ref, out):
+    """star_graph(8) -- the 9-vertex pattern of ``--id_type star_graph --k 8`` (utils.py:59-62; GSN_KMAX 8 -> 9 in r06).
+    (a) small graphs whose hubs have degree <= 9, through the REFERENCE's functions over the VF2 stand-in (at most 9! / 1! maps per hub),
+        vertex and edge mode, induced and not; orbits of the pattern (8! = 40 320 automorphisms) in the file as well;
+    (b) the three heaviest IMDB-BINARY graphs (hubs of degree 30-60: 60! / 52! maps -- no enumerator gets there) from the closed form
+            centre orbit  C(deg v, 8)                leaf orbit  sum_{u in N(v)} C(deg u - 1, 7)
+            edge (u, v)   C(deg u - 1, 7) + C(deg v - 1, 7)        (one undirected edge class: centre-leaf)
+        whose convention is pinned to the reference on the graphs of (a) here (asserted equal to the reference's output)."""
+    from math import comb
+    rec = {}
+    t0 = time.time()
+    star = list(nx.star_graph(8).edges)
+    ugp = ref["utils_graph_processing"]
+    import io, contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        sg, part, memb, aut = ugp.automorphism_orbits(edge_list=star, directed=False, directed_orbits=False)
+        sge, eparte, emembe, aute = ugp.induced_edge_automorphism_orbits(edge_list=star, directed=False, directed_orbits=False)
+    rec["star8/v_membership"] = np.asarray([memb[v] for v in range(9)], np.int64)
+    rec["star8/e_membership"] = np.asarray([emembe[i] for i in range(len(emembe))], np.int64)
+    rec["star8/aut_count"] = np.int64(aut)
+    rec["star8/edges"] = np.asarray(star, np.int64)
+    print("star_graph(8): aut", aut, "vertex orbits", len(part), "edge orbits", len(eparte), "%.0fs" % (time.time() - t0), flush=True)
+
+    def closed(n, ei):
+        deg = np.zeros(n, np.int64)
+        und = {(int(min(u, v)), int(max(u, v))) for u, v in ei.T if u != v}
+        nb = [[] for _ in range(n)]
+        for u, v in und:
+            deg[u] += 1; deg[v] += 1; nb[u].append(v); nb[v].append(u)
+        vc = np.zeros((n, 2), np.int64)
+        for v in range(n):
+            vc[v, 0] = comb(int(deg[v]), 8)
+            vc[v, 1] = sum(comb(int(deg[u]) - 1, 7) for u in nb[v])
+        ec = np.zeros((ei.shape[1], 1), np.int64)
+        for c in range(ei.shape[1]):
+            u, v = int(ei[0, c]), int(ei[1, c])
+            if u != v:
+                ec[c, 0] = comb(int(deg[u]) - 1, 7) + comb(int(deg[v]) - 1, 7)
+        return vc, ec
+    rng = np.random.default_rng(88)
+    small = []
+    for gi in range(6):
+        n = int(rng.integers(11, 15))
+        und = set()
+        hub_deg = 8 + (gi % 2)                                   # one hub of degree 8 or 9, a second vertex of degree 8 in two graphs
+        for v in rng.choice(np.arange(1, n), size=hub_deg, replace=False):
+            und.add((0, int(v)))
+        if gi >= 4:
+            for v in rng.choice(np.arange(2, n), size=7, replace=False):
+                und.add((1, int(v)))
+            und.add((0, 1))
+        for _ in range(int(rng.integers(3, 9))):
+            a, b = (int(x) for x in rng.choice(np.arange(1, n), size=2, replace=False))
+            und.add((min(a, b), max(a, b)))
+        # keep every degree <= 9 (the reference enumerates d! / (d - 8)! maps per vertex of degree d)
+        deg = np.zeros(n, int)
+        keep = []
+        for a, b in sorted(und):
+            if deg[a] < 9 and deg[b] < 9:
+                keep.append((a, b)); deg[a] += 1; deg[b] += 1
+        small.append((n, synth.undirected_to_edge_index(n, keep)))
+    for mode in ("vertex", "edge"):
+        for induced in (False, True):
+            o = run_counts(ref, small, [star], mode, induced)
+            if not induced:
+                for (n, ei), a in zip(small, o):
+                    vc, ec = closed(n, ei)
+                    assert np.array_equal(a, vc if mode == "vertex" else ec), ("closed form vs reference", mode)
+            save_case(rec, "small_star8_%s_%s" % ("ind" if induced else "mono", mode), small, [star], mode, induced, o)
+            print("small", mode, induced, "total", int(sum(int(a.sum()) for a in o)), "%.0fs" % (time.time() - t0), flush=True)
+    imdb = imdb_graphs()
+    heavy = [imdb[i] for i in (8, 11, 15)]
+    vs, es = zip(*[closed(n, ei) for n, ei in heavy])
+    save_case(rec, "imdb_heavy_star8_mono_vertex", heavy, [star], "vertex", False, list(vs))
+    save_case(rec, "imdb_heavy_star8_mono_edge", heavy, [star], "edge", False, list(es))
+    print("imdb heavy: centre-orbit total", int(sum(int(v[:, 0].sum()) for v in vs)), flush=True)
+    rec["names"] = np.asarray(rec["names"])
+    np.savez_compressed(os.path.join(out, "counts_stars.npz"), **rec)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="orbits,counts,layers")
@@ -1211,6 +1291,8 @@ def main():
         gen_directed(ref, args.out)
     if "ogb300" in only:
         gen_model_ogb300(ref, args.out)
+    if "stars" in only:
+        gen_stars(ref, args.out)
     if "cliques" in only:
         gen_cliques(ref, args.out)
 

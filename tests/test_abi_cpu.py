@@ -303,11 +303,12 @@ def test_closed_form_tails_of_the_search_core_on_host(lib, harness, mode, induce
             [(0, 1), (0, 2), (0, 3), (1, 4), (2, 5)],
             [(0, 1), (0, 2), (0, 3), (0, 4), (0, 5)], [(0, 1), (0, 2), (0, 3), (0, 4), (0, 5), (0, 6)],      # stars: runs of 5 / 4 .. twin leaves
             [(0, 1), (1, 2), (2, 3), (2, 4), (2, 5), (2, 6)]]                                                # a broom: path + four twin leaves
+    from gsn_amd.counting import PLAN_STRIDE_WORDS as PS
     plan = CountPlan(pats, mode, induced, False)
     n_plans, plans_off = int(plan.table[3]), int(plan.table[7])
-    kinds = {(int(plan.table[plans_off + i * 12 + 1]) >> 28) & 3 for i in range(n_plans)}
+    kinds = {(int(plan.table[plans_off + i * PS + 1]) >> 28) & 3 for i in range(n_plans)}
     assert kinds == ({0} if induced else {0, 1, 2, 3}), kinds
-    runs = {2 + (int(plan.table[plans_off + i * 12 + 1]) >> 30) for i in range(n_plans) if (int(plan.table[plans_off + i * 12 + 1]) >> 28) & 3 == 2}
+    runs = {2 + (int(plan.table[plans_off + i * PS + 1]) >> 30) for i in range(n_plans) if (int(plan.table[plans_off + i * PS + 1]) >> 28) & 3 == 2}
     assert induced or {2, 3, 4, 5} <= runs, runs                 # C(n, r) for r = 2 .. 5 twin levels
     b0 = synth.zinc_shape_batch(6, seed=3)
     graphs = [(int(b0.node_ptr[g + 1] - b0.node_ptr[g]), b0.edge_index[:, b0.edge_ptr[g]:b0.edge_ptr[g + 1]] - b0.node_ptr[g]) for g in range(6)]

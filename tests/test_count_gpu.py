@@ -43,6 +43,36 @@ def test_golden_heavy_clique_counts(name):
     assert np.array_equal(out.cpu().numpy(), c["counts"])
 
 
+@pytest.mark.parametrize("name", case_names("counts_stars"))
+def test_golden_star8_counts(name):
+    """star_graph(8): nine pattern vertices (GSN_KMAX 8 -> 9 in r06; --id_type star_graph --k 8, utils.py:59-62).  Small graphs against the
+    reference's functions (VF2 stand-in), the heaviest IMDB-BINARY graphs against the closed form C(deg, 8) / sum C(deg - 1, 7) that
+    make_golden.py pins to the reference on the small ones; vertex and edge mode, per-graph signatures included."""
+    from gsn_amd.counting import CountPlan, count_batch
+    c = count_case(name, "counts_stars")
+    plan = CountPlan.get(c["patterns"], c["mode"], c["induced"], c["directed_orbits"])
+    out, st = count_batch(plan, c["node_ptr"], c["edge_ptr"], _global_ei(c), ids_are_global=True)
+    assert (st.cpu().numpy() == 0).all()
+    assert np.array_equal(out.cpu().numpy(), c["counts"])
+    out2, _ = count_batch(plan, c["node_ptr"], c["edge_ptr"], c["edge_index_local"], ids_are_global=False)
+    assert torch.equal(out, out2)
+
+
+def test_star8_orbits_and_ten_vertex_patterns_refused():
+    from gsn_amd import _abi, patterns
+    from gsn_amd.counting import CountPlan
+    z = load("counts_stars")
+    el = z["star8/edges"].tolist()
+    _, part, memb, aut = patterns.automorphism_orbits(edge_list=el, print_msgs=False)
+    assert [memb[v] for v in range(9)] == z["star8/v_membership"].tolist() and aut == 40320 and len(part) == 2
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        _, epart, ememb, _ = patterns.induced_edge_automorphism_orbits(edge_list=el)
+    assert [ememb[i] for i in range(len(ememb))] == z["star8/e_membership"].tolist()
+    with pytest.raises(_abi.GsnError, match="k <= 9"):
+        CountPlan.get([list(nx.star_graph(9).edges)], "vertex", False)
+
+
 def _cycles(ks):
     return [list(nx.cycle_graph(k).edges) for k in ks]
 
@@ -528,7 +558,8 @@ def test_closed_form_tails_vs_oracle(mode, induced):
         plan = CountPlan.get(pats, mode, False)
         arr = next(v for v in (getattr(plan, n) for n in dir(plan)) if isinstance(v, np.ndarray) and v.dtype == np.uint32)
         n_plans, plans_off = int(arr[3]), int(arr[7])
-        kinds = {(int(arr[plans_off + i * 12 + 1]) >> 28) & 3 for i in range(n_plans)}
+        from gsn_amd.counting import PLAN_STRIDE_WORDS as PS
+        kinds = {(int(arr[plans_off + i * PS + 1]) >> 28) & 3 for i in range(n_plans)}
         assert kinds == {0, 1, 2, 3}, kinds
     # (seven-vertex stars: the oracle enumerates every map, d! / (d - 6)! per vertex of degree d -- moderate degrees)
     batches = [synth.zinc_shape_batch(40, seed=5),

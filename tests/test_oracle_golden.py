@@ -41,6 +41,20 @@ def test_heavy_clique_counts(name):
     assert np.array_equal(got, c["counts"])
 
 
+@pytest.mark.parametrize("name", [n for n in case_names("counts_stars") if n.startswith("small_")])
+def test_star8_counts(name):
+    """star_graph(8), the 9-vertex pattern of --id_type star_graph --k 8 (utils.py:59-62): the reference's functions over the VF2 stand-in on
+    graphs whose hubs have degree <= 9 (make_golden.py --only stars; the IMDB cases of that file come from a closed form pinned to these and
+    are out of this all-maps enumerator's reach: 20! / 12! maps per hub), and the pattern's orbits."""
+    c = count_case(name, "counts_stars")
+    got = oracle.counts2ids(c["mode"], c["induced"], c["node_ptr"], c["edge_ptr"], c["edge_index_local"], c["patterns"], n_threads=4)
+    assert np.array_equal(got, c["counts"])
+    from helpers import load
+    z = load("counts_stars")
+    m, n_orb, a = oracle.automorphism_orbits(z["star8/edges"].tolist())
+    assert m.tolist() == z["star8/v_membership"].tolist() and a == int(z["star8/aut_count"]) == 40320 and n_orb == 2
+
+
 def test_directed_orbits_and_counts():
     """directed=True (main.py --directed): digraph patterns and targets, vertex counts (counts_directed.npz = the reference's
     automorphism_orbits / subgraph_isomorphism_vertex_counts with directed=True over networkx's DiGraphMatcher)."""
