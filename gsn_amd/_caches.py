@@ -128,7 +128,7 @@ def invalidate_caches(module=None):
         _CSR_CACHE.clear()
         return
     for m in module.modules():
-        for attr in ("_fold_cache", "_split_cache", "_fused_prep", "_fused_prep16", "_gsn_eval_cache", "_gsn_wt"):
+        for attr in ("_fold_cache", "_split_cache", "_fused_prep", "_fused_prep16", "_fplan", "_gsn_eval_cache", "_gsn_wt"):
             if hasattr(m, attr):
                 try:
                     delattr(m, attr)

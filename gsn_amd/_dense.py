@@ -275,7 +275,7 @@ def _prep_key(st):
     return (st.weight.data_ptr(), st.weight._version, tuple(st.weight.shape), bk)
 
 
-def _layer_fused(x, csr, edge_stages, node_stages, training, owner=None, gen=0, pack16=None, pack_only=False):
+def _layer_fused(x, csr, edge_stages, node_stages, training, owner=None, gen=0, pack16=None, pack_only=False, record=None):
     """edge stage + per-target sum + two node stages in ONE launch (gsn_layer_fused_fwd_hip); None if the layer does not
     fit (shape, activation, or a BatchNorm1d that needs batch statistics)."""
     if not flags.FUSED_LAYER or len(edge_stages) != 1 or len(node_stages) != 2:
@@ -321,16 +321,36 @@ def _layer_fused(x, csr, edge_stages, node_stages, training, owner=None, gen=0, 
             if owner is not None:
                 owner._fused_prep16 = (key, prep)
                 _note_cache(owner, "_fused_prep16")
-        out = torch.empty((n, node_stages[1].weight.shape[0]), dtype=torch.float32, device=x.device)
+        n_out = node_stages[1].weight.shape[0]
         pk = _abi.gsn_pack16()
-        pk.node_rows = pack16[0].data_ptr()
-        pk.edge_rows = None if pack16[1] is None else pack16[1].data_ptr()
-        e_rows = 0 if pack16[1] is None else pack16[1].shape[0]
-        with _abi.device_guard(x.device), _timed("layer_fused", flops):
-            rc = L.gsn_layer_fused_fwd_pack16_hip(n, E, csr.seg_ptr.data_ptr(), ctypes.byref(ge), x.data_ptr(), d_x, ctypes.byref(g0), ctypes.byref(g1),
-                                                  prep.data_ptr(), ctypes.byref(pk), e_rows, out.data_ptr(), _abi.current_stream())
-        if rc != -2:                      # (GSN_E_UNSUPPORTED: packs beyond 32-bit offsets -> the fp32 kernel below)
-            _abi.check(rc, "gsn_layer_fused_fwd_pack16_hip")
+        fl_e = 2.0 * edge_stages[0].weight.shape[1] * edge_stages[0].weight.shape[0]
+        fl_n = 2.0 * (node_stages[0].weight.shape[1] * node_stages[0].weight.shape[0] + node_stages[1].weight.shape[1] * n_out)
+
+        def launch16(x_ptr, n_rows, dev, csr_now, idx_now, pack_now):
+            """The recorded call with this forward's pointers (x placeholder / rows, block indices, packs): one foreign call, no Python-side
+            stage building.  None when the library declines (packs beyond 32-bit offsets)."""
+            nb = ge.n_blocks
+            for i in range(nb):
+                ge.blocks[i].data = x_ptr if i < 2 else pack_now[1].data_ptr()
+                ge.blocks[i].idx32 = idx_now[i].data_ptr()
+            y = torch.empty((n_rows, n_out), dtype=torch.float32, device=dev)
+            pk.node_rows = pack_now[0].data_ptr()
+            pk.edge_rows = None if pack_now[1] is None else pack_now[1].data_ptr()
+            e_now = csr_now.tgt.numel()
+            with _abi.device_guard(dev), _timed("layer_fused", fl_e * e_now + fl_n * n_rows):
+                rc16 = L.gsn_layer_fused_fwd_pack16_hip(n_rows, e_now, csr_now.seg_ptr.data_ptr(), ctypes.byref(ge), x_ptr, d_x, ctypes.byref(g0), ctypes.byref(g1),
+                                                        prep.data_ptr(), ctypes.byref(pk), 0 if pack_now[1] is None else pack_now[1].shape[0], y.data_ptr(),
+                                                        _abi.current_stream())
+            if rc16 == -2:
+                return None
+            _abi.check(rc16, "gsn_layer_fused_fwd_pack16_hip")
+            return y
+        launch16._keep = keep
+        out = launch16(x.data_ptr(), n, x.device, csr, [b[1] for b in edge_stages[0].blocks], pack16)
+        if out is not None:               # (None = GSN_E_UNSUPPORTED: packs beyond 32-bit offsets -> the fp32 kernel below)
+            if record is not None and owner is not None and all(b[1] is not None and b[1].dtype == torch.int32 for b in edge_stages[0].blocks):
+                owner._fplan = (record, "pack16", launch16)
+                _note_cache(owner, "_fplan")
             return out
     if pack_only:                         # (the caller holds no fp32 rows: it makes them and comes back)
         return None
@@ -358,13 +378,40 @@ def _layer_fused(x, csr, edge_stages, node_stages, training, owner=None, gen=0, 
     part = getattr(csr, "part", None)
     if (flags.GRAPH_ALIGNED_LAYER and part is not None and d_x == 128 and part[2] <= 128 and int(part[0].numel()) > 1
             and L.gsn_layer_fused_graphs_supported(ctypes.byref(ge), d_x, ctypes.byref(g0), ctypes.byref(g1))):
-        with _abi.device_guard(x.device), _timed("layer_fused", flops):
-            rc = L.gsn_layer_fused_fwd_graphs_hip(n, E, csr.seg_ptr.data_ptr(), ctypes.byref(ge), x.data_ptr(), d_x, ctypes.byref(g0),
-                                                  ctypes.byref(g1), prep.data_ptr(), int(part[0].numel()) - 1, part[0].data_ptr(), int(part[2]),
-                                                  out.data_ptr(), _abi.current_stream())
-        if rc != -2:
-            _abi.check(rc, "gsn_layer_fused_fwd_graphs_hip")
-            return out
+        n_out_g = node_stages[1].weight.shape[0]
+        fl_e = 2.0 * edge_stages[0].weight.shape[1] * edge_stages[0].weight.shape[0]
+        fl_n = 2.0 * (node_stages[0].weight.shape[1] * node_stages[0].weight.shape[0] + node_stages[1].weight.shape[1] * n_out_g)
+        roles = [None if b[0] is x else i for i, b in enumerate(edge_stages[0].blocks)]      # blocks that are x itself follow the call's x
+
+        def launch_g(x_now, csr_now, blocks_now, y=None):
+            """The recorded graph-aligned call with this forward's rows / indices / partition.  None when this batch is outside it."""
+            part_now = getattr(csr_now, "part", None)
+            if part_now is None or part_now[2] > 128 or int(part_now[0].numel()) <= 1 or x_now.data_ptr() % 16:
+                return None
+            for i in range(ge.n_blocks):
+                d_i, idx_i = blocks_now[i]
+                ge.blocks[i].data = d_i.data_ptr()
+                ge.blocks[i].idx = None
+                ge.blocks[i].idx32 = idx_i.data_ptr()
+            n_now, e_now = x_now.shape[0], csr_now.tgt.numel()
+            if y is None:
+                y = torch.empty((n_now, n_out_g), dtype=torch.float32, device=x_now.device)
+            with _abi.device_guard(x_now.device), _timed("layer_fused", fl_e * e_now + fl_n * n_now):
+                rcg = L.gsn_layer_fused_fwd_graphs_hip(n_now, e_now, csr_now.seg_ptr.data_ptr(), ctypes.byref(ge), x_now.data_ptr(), d_x, ctypes.byref(g0),
+                                                       ctypes.byref(g1), prep.data_ptr(), int(part_now[0].numel()) - 1, part_now[0].data_ptr(), int(part_now[2]),
+                                                       y.data_ptr(), _abi.current_stream())
+            if rcg == -2:
+                return None
+            _abi.check(rcg, "gsn_layer_fused_fwd_graphs_hip")
+            return y
+        launch_g._keep = keep
+        got = launch_g(x, csr, edge_stages[0].blocks, out)
+        if got is not None:
+            if (record is not None and owner is not None
+                    and all(b[1] is not None and b[1].dtype == torch.int32 and b[0].dtype == torch.float32 and b[0].is_contiguous() for b in edge_stages[0].blocks)):
+                owner._fplan = (record, "graphs", launch_g)
+                _note_cache(owner, "_fplan")
+            return got
     # layers of a d = 128 model hand the row exponents of their output to the next one (csrc/layer_w.hip takes its edge rows' scales from
     # them): kept on the output tensor together with its version counter, used only while the tensor is unchanged
     x_exp = None

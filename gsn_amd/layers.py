@@ -371,12 +371,85 @@ class _SparseLayer(nn.Module):
                 pads[1] = pad
         return propagate(0, edge_index, sel, n, a=x, b=ids_nb, c=ef_nb, b_per_node=per_node, selfs=selfs, eps=self.eps, pads=pads)
 
+    # -- recorded launch of the one-launch eval forward (r06) --------------------------------------------------------------
+    def _fplan_key(self, raw, post):
+        """What a recorded launch (gsn_amd._dense._layer_fused: stage descriptors, BatchNorm vectors, prepared weights) is valid for: the kinds and
+        widths of the inputs, the post-stage, the switches, and the version counter + address of every parameter / buffer behind it."""
+        # (looked up afresh on every call -- a replaced Parameter object is a different tensor --, by direct traversal of the two mlps: the
+        #  generic parameters() / buffers() walk costs more than the launch)
+        ts = []
+        for m in (self.msg_fn, self.update_fn):
+            for fc in m.fc:
+                ts.append(fc.weight)
+                if fc.bias is not None:
+                    ts.append(fc.bias)
+            if m.batch_norm:
+                for bn in m.bn:
+                    ts.extend(t for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var) if t is not None)
+                    if bn.training:
+                        return None          # (a BatchNorm1d in train mode takes batch statistics: never the recorded eval launch)
+        pb = post[0] if post is not None else None
+        key = [tuple((isinstance(t, Codes), t.shape[1]) if t is not None else None for t in raw), None if post is None else (id(pb), post[1]),
+               flags.FUSED_LAYER, flags.PACK16_LAYER, flags.GRAPH_ALIGNED_LAYER, flags.VALIDATE_CACHES, self.training]
+        key.extend((t._version, t.data_ptr()) for t in ts)
+        if pb is not None:
+            key.append(pb.training)
+            key.extend((t._version, t.data_ptr()) for t in (pb.weight, pb.bias, pb.running_mean, pb.running_var) if t is not None)
+        return tuple(key)
+
+    def _hip_recorded(self, edge_index, raw, n, E, sel, post):
+        """Second and later eval forwards of a `general` layer: the launch recorded by the first one with this call's pointers -- no stage
+        lists, no BatchNorm resolution, no descriptor building (at the reference's batch sizes that Python was 3-4 x the kernel's time:
+        models_graph_classification.py:204-247 calls four layers per forward).  None: no valid record (first call, a parameter moved, other
+        input kinds), or this batch is outside the recorded kernel -- the caller takes the full path, which records again."""
+        plan = getattr(self, "_fplan", None)
+        if plan is None or E == 0 or self.training or torch.cuda.is_current_stream_capturing():
+            return None
+        key = self._fplan_key(raw, post)
+        if key is None or plan[0] != key:
+            return None
+        x, ids, ef = raw
+        per_edge = [t for t in (ids if self.has_ids else None, ef if self.has_ef else None) if t is not None]
+        if plan[1] == "pack16":
+            if isinstance(x, Codes):
+                pk = packs.from_codes(x, per_edge)
+            else:
+                pk = packs.lookup(x, per_edge)
+            if pk is None:
+                return None
+            csr = _csr_for(edge_index, sel, n)
+            x_ptr = pk[0].data_ptr() if isinstance(x, Codes) else x.data_ptr()
+            if x_ptr % 16:
+                return None
+            return plan[2](x_ptr, n, edge_index.device, csr, [csr.tgt, csr.src] + [csr.perm] * len(per_edge), pk)
+        if plan[1] == "graphs":
+            if isinstance(x, Codes) or x.dtype != torch.float32 or not x.is_contiguous():
+                return None
+            csr = _csr_for(edge_index, sel, n)
+            blocks = [(x, csr.tgt), (x, csr.src)]
+            for t in per_edge:
+                if isinstance(t, Codes):
+                    t = t.dense()
+                if t.dtype != torch.float32 or not t.is_contiguous():
+                    return None
+                blocks.append((t, csr.perm))
+            return plan[2](x, csr, blocks)
+        return None
+
     # -- HIP forward ---------------------------------------------------------------------------------------------
     def _hip(self, edge_index, x, ids, ef, post=None):
         n = x.shape[0]
         sel = self._sel()
         E = edge_index.shape[1]
         raw = (x, ids, ef)
+        record = None
+        if (flags.FUSED_LAYER and not self.training and not self.ogb and self.msg_kind == "general" and len(self.msg_fn.fc) == 2
+                and not (self.has_ids and self.id_scope != "local")):
+            y = self._hip_recorded(edge_index, raw, n, E, sel, post)
+            if y is not None:
+                return y
+            record = self._fplan_key(raw, post)
+        self._fplan_record = record
         use_codes = (not self.ogb and self.msg_kind == "general" and len(self.msg_fn.fc) == 2 and E > 0
                      and all(isinstance(t, Codes) for t in raw if t is not None))
         # integer codes in, one launch: the one-hot encodings go straight into exact fp16 row packs (gsn_one_hot_pack16_hip: 64 / 32 bytes
@@ -441,7 +514,7 @@ class _SparseLayer(nn.Module):
                         pk = packs.lookup(raw[0], [t for t in (raw[1] if self.has_ids else None, raw[2] if self.has_ef else None) if t is not None])
                     y = _layer_fused(x, csr, mf.stages(sblocks, upto=len(mf.fc) - 1),
                                      uf.stages([(x, None)], first_weight=self._folded_first_weight(x.shape[1]), post=post),
-                                     self.training, owner=self, gen=getattr(self, "_fold_gen", 0), pack16=pk)
+                                     self.training, owner=self, gen=getattr(self, "_fold_gen", 0), pack16=pk, record=self._fplan_record)
                     if y is not None:
                         return y
                 # wide edge rows (K > 160: layers 1.. of a d = 128 model, K = 260): the node part of the Linear once per NODE,
@@ -480,7 +553,7 @@ class _SparseLayer(nn.Module):
             sblocks.append((t if isinstance(t, torch.Tensor) else torch.empty((E, packs._width(t)), dtype=torch.float32, device=dev), csr.perm))
         return _layer_fused(xph, csr, mf.stages(sblocks, upto=len(mf.fc) - 1),
                             uf.stages([(xph, None)], first_weight=self._folded_first_weight(d_x), post=post),
-                            self.training, owner=self, gen=getattr(self, "_fold_gen", 0), pack16=pk, pack_only=True)
+                            self.training, owner=self, gen=getattr(self, "_fold_gen", 0), pack16=pk, pack_only=True, record=self._fplan_record)
 
     # -- differentiable `general` path on native adjoints ------------------------------------------------------------------
     def _general_native_ok(self):
