@@ -884,8 +884,16 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
 // (Measured and dropped: amdgpu_waves_per_eu(6 / 7) on the molecule instantiation spills 72 / 104 bytes per lane for 1.4 / 2 % on the kernel
 //  and 0.5 % on the step; even a bound of 5 -- no tighter than what the allocator picks by itself -- changed its choices: 94 registers and
 //  36 bytes of scratch instead of 83 and none, +3 % kernel time.  No occupancy attribute.)
+// Register bound of the two-word instantiations (graphs of 65 .. 128 vertices: BASELINE config 5, ER G(128,1000)).  Left to itself the
+// allocator takes 136 registers = 3 waves per SIMD for a kernel that is bound by the latency of dependent LDS reads at 0.30 lane activity
+// (profiles/r06_count_er128_phase.txt); bounded to 80 (6 waves) it spills 188 bytes per lane and the launch is still 22 % faster:
+// 43.6 k -> 53.5 k graphs/s at 2 048 graphs per launch (4 waves 50.0 k, 5: 52.9 k, 8: 52.4 k; scripts/gpu/r6_er_ab.sh).  The molecule
+// instantiation has its own bound (COUNT_MOL_WAVES); the wider ones (W >= 4) are left alone: no BASELINE config runs them.
+#ifndef COUNT_W2_WAVES
+#define COUNT_W2_WAVES 6
+#endif
 template <int W, int T, bool DIR, bool TAIL, bool MOL = false>
-__global__ __launch_bounds__(T) void count_kernel(CountArgs a) {
+__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu((W == 2 && !DIR) ? COUNT_W2_WAVES : 1))) void count_kernel(CountArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int bid = (int)blockIdx.x;
     if (a.side_mask) {                                   // (launches with side workgroups: one workgroup per item, no graph list)
