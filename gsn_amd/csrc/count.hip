@@ -892,8 +892,15 @@ __device__ __forceinline__ int count_body(const CountArgs &a, unsigned char *sme
 #ifndef COUNT_W2_WAVES
 #define COUNT_W2_WAVES 6
 #endif
+#ifndef COUNT_W1_WAVES
+#define COUNT_W1_WAVES 1
+#endif
+#ifndef COUNT_W4_WAVES
+#define COUNT_W4_WAVES 1
+#endif
 template <int W, int T, bool DIR, bool TAIL, bool MOL = false>
-__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu((W == 2 && !DIR) ? COUNT_W2_WAVES : 1))) void count_kernel(CountArgs a) {
+__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(DIR ? 1 : (W == 1 ? COUNT_W1_WAVES : (W == 2 ? COUNT_W2_WAVES : (W == 4 ? COUNT_W4_WAVES : 1))))))
+void count_kernel(CountArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int bid = (int)blockIdx.x;
     if (a.side_mask) {                                   // (launches with side workgroups: one workgroup per item, no graph list)
