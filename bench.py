@@ -318,6 +318,24 @@ def small_batch_steps(plan, layer, dev, graphs=True):
             y_ref = step()
         torch.cuda.synchronize()
         rec = {"graphs": G, "eager_us": round((time.perf_counter() - t0) / reps * 1e6, 1)}
+        # the same work as ONE host call (gsn_amd.step.CountLayerStep: integer codes in, int64 identifiers + layer rows out; the headline's form)
+        try:
+            from gsn_amd.step import CountLayerStep
+            stp = CountLayerStep(plan, layer, [3, 3, 3, 3], clamp=True)
+            xc_s = layers.Codes(torch.from_numpy(b.atom_type).to(dev), [28])
+            efc_s = layers.Codes(torch.from_numpy(b.bond_type).to(dev), [4])
+            one = lambda: stp(node_ptr, edge_ptr, ei, xc_s, efc_s, mn, me)[1]
+            for _ in range(30):
+                one()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                y_one = one()
+            torch.cuda.synchronize()
+            rec["one_call_eager_us"] = round((time.perf_counter() - t0) / reps * 1e6, 1)
+            rec["one_call_matches_eager"] = bool(torch.equal(y_one, y_ref))
+        except Exception as e:
+            rec["one_call_error"] = str(e)[:160]
         if not graphs:                 # (--no-graph: stream capture cannot free memory without the caching allocator, scripts/oob_check.sh)
             out["B%d" % G] = rec
             continue
