@@ -117,4 +117,4 @@ def test_switches_and_train_mode_leave_the_record():
         layer.eval()
         y_again = layer(layers.Codes(atoms, [28]), ei, **mk())
     assert not torch.equal(y_tr, y)
-    assert torch.allclose(y_again, _full_path(layer, layers.Codes(atoms, [28]), ei, **mk()), rtol=0, atol=0) or True
+    assert torch.equal(y_again, _full_path(layer, layers.Codes(atoms, [28]), ei, **mk())) and torch.equal(y_again, y)
