@@ -71,6 +71,16 @@ def prepare_graphs(graphs, subgraph_dicts, subgraph_params, regression, dataset_
         span = (int(bounds[rank]), int(bounds[rank + 1]))
         graphs = graphs[span[0]:span[1]]
 
+    # Width classes.  The counting kernel's instantiation follows the LARGEST graph of a launch (bit rows of 1 / 2 / 4 / 8 / 12 words: 64 ..
+    # 768 vertices), so one 222-vertex molecule would put all 41 k graphs of ogbg-molhiv (25 vertices on average) on the four-word kernel
+    # instead of the molecule kernel (two graphs per wave, compile-time invariants).  Graphs are independent: they are processed grouped by
+    # class -- one launch per class that occurs, each over a contiguous range of the regrouped batch -- and handed back in the caller's order.
+    order = None
+    if len(graphs) > 1:
+        cls = np.searchsorted(np.array([64, 128, 256, 512]), np.array([int(g.node_features.shape[0]) for g in graphs]), side="left")
+        if cls.min() != cls.max():
+            order = np.argsort(cls, kind="stable")
+            graphs = [graphs[int(i)] for i in order]
     G = len(graphs)
     n_nodes = np.array([int(g.node_features.shape[0]) for g in graphs], dtype=np.int64)
     n_raw = np.array([int(g.edge_mat.shape[1]) for g in graphs], dtype=np.int64)
@@ -98,8 +108,20 @@ def prepare_graphs(graphs, subgraph_dicts, subgraph_params, regression, dataset_
 
     n_cols = plan.n_cols
     if G and (mode == "vertex" or edge_ptr[-1] > 0):
-        out, _ = counting.count_batch(plan, node_ptr, edge_ptr, torch.from_numpy(ei), ids_are_global=False,
-                                      max_nodes=int(max(n_nodes.max(), 1)), max_edges=int(n_kept.max()), device=device)
+        if order is None:
+            out, _ = counting.count_batch(plan, node_ptr, edge_ptr, torch.from_numpy(ei), ids_are_global=False,
+                                          max_nodes=int(max(n_nodes.max(), 1)), max_edges=int(n_kept.max()), device=device)
+        else:
+            dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+            ei_d = torch.from_numpy(ei).to(dev)
+            out = torch.empty((int(node_ptr[-1]) if mode == "vertex" else int(edge_ptr[-1]), n_cols), dtype=torch.int64, device=dev)
+            cls_sorted = np.searchsorted(np.array([64, 128, 256, 512]), n_nodes, side="left")
+            for c in np.unique(cls_sorted):
+                lo, hi = int(np.searchsorted(cls_sorted, c, side="left")), int(np.searchsorted(cls_sorted, c, side="right"))
+                if mode == "edge" and edge_ptr[hi] == edge_ptr[lo]:
+                    continue
+                counting.count_batch(plan, node_ptr[lo:hi + 1], edge_ptr[lo:hi + 1], ei_d, ids_are_global=False,
+                                     max_nodes=int(max(n_nodes[lo:hi].max(), 1)), max_edges=int(n_kept[lo:hi].max()), device=dev, out=out)
         ids_all = out.cpu()
     else:
         ids_all = torch.zeros((0, n_cols), dtype=torch.int64)
@@ -135,6 +157,11 @@ def prepare_graphs(graphs, subgraph_dicts, subgraph_params, regression, dataset_
         else:
             setattr(d, "identifiers", ids_all[int(row_ptr[g]):int(row_ptr[g + 1])].clone())
         prepared.append(d)
+    if order is not None:
+        back = [None] * G
+        for j, i in enumerate(order):
+            back[int(i)] = prepared[j]
+        prepared = back
     if shard is not None:
         return prepared, span
     return prepared

@@ -100,3 +100,43 @@ def test_prepare_shards_cover_dataset_in_order(gold):
     for a, b in zip(parts, whole):
         assert torch.equal(a.identifiers, b.identifiers) and torch.equal(a.edge_index, b.edge_index)
     assert all(int(d.identifiers[0, 0]) == 30 for d in whole)     # SRG closed form: k*lambda/2 triangles per vertex
+
+
+@pytest.mark.parametrize("mode", ["vertex", "edge"])
+def test_width_classes_are_counted_apart_and_come_back_in_order(mode):
+    """One 200-vertex graph among molecules must not put the whole dataset on the four-word kernel (ogbg-molhiv: a 222-vertex molecule among
+    41 k of 25): prepare_graphs groups the graphs by width class, counts each class in a launch of its own and returns them in the caller's
+    order -- same records as counting every graph by itself through the reference's per-graph signature (utils_ids.py:7-29)."""
+    import types
+    import networkx as nx
+    from gsn_amd import synth
+    rng = np.random.default_rng(3)
+    raws = []
+    sizes = [20, 200, 23, 70, 9, 130, 31, 64, 65, 12]
+    for i, n in enumerate(sizes):
+        n_, ei = synth.er_graph(n, int(1.3 * n), seed=40 + i)
+        if i == 4:
+            ei = np.zeros((2, 0), np.int64)                      # an edge-less graph in between
+        r = gdata.S2VGraph(int(i % 2), None)
+        r.edge_mat = torch.from_numpy(np.ascontiguousarray(ei))
+        r.node_features = torch.from_numpy(rng.integers(0, 5, (n, 1)))
+        raws.append(r)
+    els = [list(nx.cycle_graph(3).edges), list(nx.path_graph(4).edges)]
+    fn = patterns.automorphism_orbits if mode == "vertex" else patterns.induced_edge_automorphism_orbits
+    cnt = counting.subgraph_isomorphism_vertex_counts if mode == "vertex" else counting.subgraph_isomorphism_edge_counts
+    dicts = []
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        for el in els:
+            sg, part, memb, aut = fn(edge_list=el, directed=False, directed_orbits=False)
+            dicts.append({"subgraph": sg, "orbit_partition": part, "orbit_membership": memb, "aut_count": aut})
+    out = gds.prepare_graphs(raws, dicts, {"induced": False, "directed": False}, False, "X", cnt)
+    assert len(out) == len(raws)
+    for r, d in zip(raws, out):
+        assert d.graph_size == r.node_features.shape[0] and torch.equal(d.x, r.node_features)
+        if r.edge_mat.shape[1] == 0 and mode == "edge":
+            assert d.identifiers.shape[0] == 0
+            continue
+        one = types.SimpleNamespace(edge_index=r.edge_mat, x=r.node_features)
+        ref = counting.subgraph_counts2ids(cnt, one, dicts, {"induced": False, "directed": False})
+        assert torch.equal(d.identifiers, ref.identifiers) and torch.equal(d.edge_index, ref.edge_index)
