@@ -90,6 +90,7 @@ SIGNATURES = {
     "gsn_csr_scratch_elems": (c_i64, [c_i64]),
     "gsn_csr_build_hip": (c_int, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "gsn_linear_f16x3_kpad": (c_i64, [c_i64]),
+    "gsn_linear_f16x3_mpad": (c_i64, [c_i64]),
     "gsn_linear_f16x3_scratch_bytes": (c_i64, [c_i64, c_i64]),
     "gsn_linear_f16x3_prepare_hip": (c_int, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp]),
     "gsn_linear_f16x3_prepare_strided_hip": (c_int, [c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp]),
@@ -99,6 +100,9 @@ SIGNATURES = {
     "gsn_linear_fwd_splitk_hip": (c_int, [c_i64, c_int, ctypes.POINTER(gsn_block), c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp]),
     "gsn_linear_f16x3_fwd_hip": (c_int, [c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),
     "gsn_linear_f16x3_fwd_stats_hip": (c_int, [c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
+    "gsn_linear_f16x3_split_rows_hip": (c_int, [c_i64, c_int, c_vp, c_vp, c_vp]),
+    "gsn_linear_f16x3_fwd_presplit_hip": (c_int, [c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),
+    "gsn_wgrad_f16x3_hip": (c_int, [c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "gsn_edge_split_sum_hip": (c_int, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_vp]),
     "gsn_csr_build_graphs_hip": (c_int, [c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "gsn_segsum_prepare_hip": (c_int, [c_i64, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp]),

@@ -42,7 +42,13 @@ class _DenseStagesFn(torch.autograd.Function):
             m_rows = blocks0[0].shape[0]
         saved, meta = [], []
         y = None
+        # per stage: the forward product's row scratch (fp16 planes of the stage's input rows), kept when the weight wants a gradient and the
+        # product ran on the fp16x3 kernel -- the backward pass multiplies it with the planes of gH (gsn_wgrad_f16x3_hip)
+        x_scratch = []
+        w_pos = spec[0]["n_blocks"]
         for si, sp in enumerate(spec):
+            scr = [] if (flags.WGRAD_F16X3 and ctx.needs_input_grad[1 + w_pos] and (si > 0 or gather is None)) else None
+            w_pos += 1 + (1 if sp["has_bias"] else 0) + (2 if (sp["bn"] is not None and sp["bn"].affine) else 0)
             w = next(it)
             b = next(it) if sp["has_bias"] else None
             bn = sp["bn"]
@@ -58,7 +64,7 @@ class _DenseStagesFn(torch.autograd.Function):
                 st = _Stage(w, b, bn, sp["act"])
                 _bn_resolve(st, None, m_rows, False)
                 mean32, scale, shift = st.bn_params
-                y = _linear_hip(blks, w, b, mean32, scale, shift, _ACT_CODE[sp["act"]], m_rows)
+                y = _linear_hip(blks, w, b, mean32, scale, shift, _ACT_CODE[sp["act"]], m_rows, scratch_out=scr)
                 saved += [y, _f32c(scale)]
                 meta.append(("affine", len(saved) - 2))
             elif bn is not None:
@@ -67,12 +73,12 @@ class _DenseStagesFn(torch.autograd.Function):
                 fused_act = False
                 if bn_train:
                     stats = _zeros(2 * n_out, torch.float64, w.device).view(2, n_out)
-                    h = _linear_hip(blks, w, b, None, None, None, 0, m_rows, out=True, stats=stats)
+                    h = _linear_hip(blks, w, b, None, None, None, 0, m_rows, out=True, stats=stats, scratch_out=scr)
                     yy = torch.empty_like(h)
                     fused_act = 1 < m_rows <= flags.FUSE_BN_ACT_ROWS
                     _bn_resolve(st, lambda: stats, m_rows, True, fuse_act=(h, _ACT_CODE[sp["act"]], yy) if fused_act else None)
                 else:
-                    h = _linear_hip(blks, w, b, None, None, None, 0, m_rows, out=True)
+                    h = _linear_hip(blks, w, b, None, None, None, 0, m_rows, out=True, scratch_out=scr)
                     yy = torch.empty_like(h)
                     _bn_resolve(st, None, m_rows, False)
                 mean32, scale, shift = st.bn_params
@@ -87,10 +93,12 @@ class _DenseStagesFn(torch.autograd.Function):
                 meta.append(("bn" if bn_train else "bn_eval", len(saved) - 6))
                 y = yy
             else:
-                y = _linear_hip(blks, w, b, None, None, None, _ACT_CODE[sp["act"]], m_rows)
+                y = _linear_hip(blks, w, b, None, None, None, _ACT_CODE[sp["act"]], m_rows, scratch_out=scr)
                 saved += [y]
                 meta.append(("plain", len(saved) - 1))
+            x_scratch.append(scr[0] if scr else None)
         ctx.spec, ctx.meta, ctx.m_rows = spec, meta, m_rows
+        ctx.x_scratch = x_scratch
         ctx.n_saved = len(saved)
         ctx.save_for_backward(*saved, *tensors)
         return y
@@ -159,31 +167,49 @@ class _DenseStagesFn(torch.autograd.Function):
                 casts.append((ent["beta_i"], o0 + n_out, n_out))
             if "b_i" in ent:
                 casts.append((ent["b_i"], o0, n_out))
-            # weight gradient
-            xin = blocks0 if si == 0 else [saved[meta[si - 1][1] + (1 if meta[si - 1][0] in ("bn", "bn_eval") else 0)]]
-            if ctx.needs_input_grad[1 + ent["w_i"]]:
-                gw = z32[o32:o32 + n_out * k_total].view(n_out, k_total)
-                o32 += n_out * k_total
-                arr = (_abi.gsn_block * len(xin))()
-                keep = []
-                gather = spec[0].get("gather") if si == 0 else None
-                for bi, t in enumerate(xin):
-                    t = _f32c(t); keep.append(t)
-                    arr[bi].data = t.data_ptr(); arr[bi].idx = None; arr[bi].idx32 = None; arr[bi].width = t.shape[1]
-                    if gather is not None and gather[2][bi] is not None:
-                        ix = gather[0][gather[2][bi]].contiguous(); keep.append(ix)
-                        arr[bi].idx = ix.data_ptr()
-                with _abi.device_guard(dev), _timed("wgrad", 2.0 * m_rows * n_out * k_total):
-                    _abi.check(L.gsn_wgrad_hip(m_rows, n_out, gh.data_ptr(), len(xin), arr, gw.data_ptr(), _abi.current_stream()),
-                               "gsn_wgrad_hip")
-                grads[ent["w_i"]] = gw
-            # input gradient
+            # input gradient first: on the fp16x3 kernel its row pre-pass leaves the fp16 planes of gH, which the weight gradient multiplies as well
             need_x = si > 0 or any(ctx.needs_input_grad[1 + bi] for bi in range(len(blocks0)))
+            want_w = ctx.needs_input_grad[1 + ent["w_i"]]
+            xs = ctx.x_scratch[si] if want_w else None
+            g_scr = [] if xs is not None else None
+            gx = None
             if need_x:
                 # gX = gH W: W read as its transpose.  The fp16x3 kernel prepares its planes from any strides; the bf16x6 kernel stages a
                 # strided W with scalar loads -- fine where a launch costs more than the staging (small batches), a copy + float4 staging above
                 wt = w.detach().t() if (w.shape[1] > flags.LINEAR_F16X3_MIN_N or m_rows <= 16384) else _transposed(w)
-                gx = _linear_hip([(gh, None)], wt, None, None, None, None, 0, m_rows, split_k=True)
+                gx = _linear_hip([(gh, None)], wt, None, None, None, None, 0, m_rows, split_k=True, scratch_out=g_scr)
+            # weight gradient
+            xin = blocks0 if si == 0 else [saved[meta[si - 1][1] + (1 if meta[si - 1][0] in ("bn", "bn_eval") else 0)]]
+            if want_w:
+                gw = z32[o32:o32 + n_out * k_total].view(n_out, k_total)
+                o32 += n_out * k_total
+                if xs is not None and not g_scr and n_out % 4 == 0 and gh.data_ptr() % 16 == 0 and m_rows >= flags.WGRAD_F16X3_SPLIT_ROWS:
+                    # no input-gradient product on the fp16x3 kernel beside it: the planes of gH from the pre-pass alone
+                    sc = torch.empty(int(L.gsn_linear_f16x3_scratch_bytes(m_rows, n_out)), dtype=torch.uint8, device=dev)
+                    one = (_abi.gsn_block * 1)()
+                    one[0].data = gh.data_ptr(); one[0].idx = None; one[0].idx32 = None; one[0].width = n_out
+                    with _abi.device_guard(dev):
+                        _abi.check(L.gsn_linear_f16x3_split_rows_hip(m_rows, 1, one, sc.data_ptr(), _abi.current_stream()), "gsn_linear_f16x3_split_rows_hip")
+                    g_scr.append(sc)
+                if xs is not None and g_scr:
+                    with _abi.device_guard(dev), _timed("wgrad", 2.0 * m_rows * n_out * k_total):
+                        _abi.check(L.gsn_wgrad_f16x3_hip(m_rows, n_out, k_total, g_scr[0].data_ptr(), xs.data_ptr(), gw.data_ptr(), _abi.current_stream()),
+                                   "gsn_wgrad_f16x3_hip")
+                else:
+                    arr = (_abi.gsn_block * len(xin))()
+                    keep = []
+                    gather = spec[0].get("gather") if si == 0 else None
+                    for bi, t in enumerate(xin):
+                        t = _f32c(t); keep.append(t)
+                        arr[bi].data = t.data_ptr(); arr[bi].idx = None; arr[bi].idx32 = None; arr[bi].width = t.shape[1]
+                        if gather is not None and gather[2][bi] is not None:
+                            ix = gather[0][gather[2][bi]].contiguous(); keep.append(ix)
+                            arr[bi].idx = ix.data_ptr()
+                    with _abi.device_guard(dev), _timed("wgrad", 2.0 * m_rows * n_out * k_total):
+                        _abi.check(L.gsn_wgrad_hip(m_rows, n_out, gh.data_ptr(), len(xin), arr, gw.data_ptr(), _abi.current_stream()),
+                                   "gsn_wgrad_hip")
+                grads[ent["w_i"]] = gw
+            if need_x:
                 if si > 0:
                     g = gx
                 else:

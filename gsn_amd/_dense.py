@@ -43,10 +43,12 @@ def _f16x3_weights(weight, w32):
     return planes, col_inv
 
 
-def _linear_hip(blocks, weight, bias, bn_mean, bn_scale, bn_shift, act, m_rows, out=True, stats=None, split_k=False):
+def _linear_hip(blocks, weight, bias, bn_mean, bn_scale, bn_shift, act, m_rows, out=True, stats=None, split_k=False, scratch_out=None):
     """blocks: list of (data [R,w] fp32 cuda, idx int64 [M] or None).  ``split_k``: the caller accepts a sum whose order varies from run to run in the
     last bits (float atomics over K ranges, gsn_linear_fwd_splitk_hip) -- the input-gradient products of a backward pass, whose weight gradients
-    are accumulated that way already; forward products stay on one workgroup per tile: an eval forward is reproducible bit for bit."""
+    are accumulated that way already; forward products stay on one workgroup per tile: an eval forward is reproducible bit for bit.
+    ``scratch_out``: a list that receives the row scratch (inverse row scales + the rows' fp16 planes) when the product ran on the fp16x3 kernel --
+    what gsn_wgrad_f16x3_hip multiplies (the caller keeps it alive)."""
     if len(blocks) > _MAX_BLOCKS:
         raise NotImplementedError("more than %d input blocks" % _MAX_BLOCKS)
     dev = weight.device
@@ -94,6 +96,8 @@ def _linear_hip(blocks, weight, bias, bn_mean, bn_scale, bn_shift, act, m_rows, 
                                                          _abi.ptr(vecs[1]), _abi.ptr(vecs[2]), _abi.ptr(vecs[3]), act, scratch.data_ptr(),
                                                          y.data_ptr(), _abi.current_stream())
         _abi.check(rc, "gsn_linear_f16x3_fwd_stats_hip" if stats is not None else "gsn_linear_f16x3_fwd_hip")
+        if scratch_out is not None:
+            scratch_out.append(scratch)
         return y
     # few rows, identity epilogue (the input-gradient products of a dense backward at the reference's batch sizes): the K slices of an output tile
     # shared by up to four workgroups that add into a zero-filled output (from the zero arena: no fill launch per product)

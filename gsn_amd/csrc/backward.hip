@@ -14,6 +14,7 @@
 // 128 x 128 tile of gW and one slab of rows, accumulates in registers and adds its partial tile with float atomics.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 
 #include "gsn_internal.h"
@@ -643,6 +644,9 @@ extern "C" int gsn_wgrad_hip(int64_t m_rows, int64_t n_out, const float *grad_h,
     rows_per = (rows_per + WG_RB - 1) / WG_RB * WG_RB;
     a.rows_per_wg = rows_per;
     slabs = (m_rows + rows_per - 1) / rows_per;
+    if (getenv("GSN_CHAIN_TRACE"))
+        fprintf(stderr, "gsn wgrad: M %lld N %d K %d blocks %d%s slabs %lld x %lld rows\n", (long long)m_rows, (int)n_out, k, n_blocks, gathered ? " gathered" : "",
+                (long long)slabs, (long long)rows_per);
     // GSN_WGRAD_FP32=1: the fp32-MFMA kernel (v_mfma_f32_32x32x2_f32), for A/B runs
     static const bool fp32_kernel = [] { const char *e = getenv("GSN_WGRAD_FP32"); return e && e[0] == '1'; }();
     if (fp32_kernel && !gathered)      // (gathered blocks: the bf16 kernel only)

@@ -168,12 +168,13 @@ __global__ __launch_bounds__(256) void lin16_split_rows_kernel(L16Args a) {
     l16_scale(m, s, inv);
     if (m >= 0x7f800000u) inv = __uint_as_float(0x7fc00000u);            // Inf / NaN in the row: its outputs become NaN
     if (q8 == 0) a.rowinv[row] = on ? inv : 0.f;
-    if (!on) return;
+    // (rows past m_rows, up to m_pad: ZERO planes -- gsn_wgrad_f16x3_hip walks 16-row steps and requests rows ahead without a bound check)
     unsigned char *prow = a.aplanes + row * a.k_pad * 4;                 // (4 bytes per column: a high and a low half)
     // chunk c = columns 4c .. 4c + 3 of slice c >> 3.  Lane pairs trade halves so that every lane stores 16 bytes: the even lane
     // the high halfs of both chunks, the odd lane the low halfs -- the 8 lanes of a row write one whole line with one instruction
     const bool even = (q8 & 1) == 0;
-    auto put = [&](int c, const float4 &x) {
+    auto put = [&](int c, const float4 &xin) {
+        const float4 x = on ? xin : make_float4(0.f, 0.f, 0.f, 0.f);
         unsigned h0, l0, h1, l1;
         l16_split2(fl2{x.x * s, x.y * s}, h0, l0);
         l16_split2(fl2{x.z * s, x.w * s}, h1, l1);
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(256) void lin16_split_rows_kernel(L16Args a) {
         float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
         if (c < nch) {
             const L16Col cm = l16_col(a, 4 * c);
-            x = *reinterpret_cast<const float4 *>(cm.base + row * cm.bw);
+            x = *reinterpret_cast<const float4 *>(cm.base + rr * cm.bw);
         }
         put(c, x);
     }
@@ -235,18 +236,19 @@ __global__ __launch_bounds__(256) void lin16_split_rows1_kernel(L16Args a) {
         l16_scale(m, s, inv);
         if (m >= 0x7f800000u) inv = __uint_as_float(0x7fc00000u);            // Inf / NaN in the row: its outputs become NaN
         if (q8 == 0) a.rowinv[row] = on ? inv : 0.f;
-        // (rows past m_rows write no planes; their lanes still take part in the shuffles below)
-        unsigned char *prow = a.aplanes + rr * a.k_pad * 4;                  // (4 bytes per column: a high and a low half)
+        // (rows past m_rows, up to m_pad, get ZERO planes: gsn_wgrad_f16x3_hip requests rows ahead without a bound check)
+        unsigned char *prow = a.aplanes + row * a.k_pad * 4;                 // (4 bytes per column: a high and a low half)
         // chunk c = columns 4c .. 4c + 3 of slice c >> 3.  Lane pairs trade halves so that every lane stores 16 bytes: the even lane
         // the high halfs of both chunks, the odd lane the low halfs -- the 8 lanes of a row write one whole line with one instruction
         const bool even = (q8 & 1) == 0;
-        auto put = [&](int c, const float4 &x) {
+        auto put = [&](int c, const float4 &xin) {
+            const float4 x = on ? xin : make_float4(0.f, 0.f, 0.f, 0.f);
             unsigned h0, l0, h1, l1;
             l16_split2(fl2{x.x * s, x.y * s}, h0, l0);
             l16_split2(fl2{x.z * s, x.w * s}, h1, l1);
             const unsigned r0 = (unsigned)__shfl_xor((int)(even ? l0 : h0), 1), r1 = (unsigned)__shfl_xor((int)(even ? l1 : h1), 1);
             unsigned char *line = prow + (c >> 3) * L_LINE + (even ? 0 : 64) + ((c & 7) >> 1) * 16;
-            if (on) *reinterpret_cast<un4 *>(line) = even ? un4{h0, h1, r0, r1} : un4{r0, r1, l0, l1};
+            *reinterpret_cast<un4 *>(line) = even ? un4{h0, h1, r0, r1} : un4{r0, r1, l0, l1};
         };
 #pragma unroll
         for (int i = 0; i < L_RC; ++i) {
@@ -821,10 +823,13 @@ extern "C" int64_t gsn_linear_f16x3_kpad(int64_t k_total) {
     return k < 2 * L_BK ? 2 * L_BK : k;                                   // (the kernel keeps two slices in flight)
 }
 
+// rows of a row scratch: m_rows and at least 128 more (zero planes, zero inverse scales), in whole 256-row tiles
+extern "C" int64_t gsn_linear_f16x3_mpad(int64_t m_rows) { return m_rows <= 0 ? 0 : (m_rows + 128 + 255) / 256 * 256; }
+
 extern "C" int64_t gsn_linear_f16x3_scratch_bytes(int64_t m_rows, int64_t k_total) {
     if (m_rows <= 0 || k_total <= 0) return 0;
-    const int64_t m_pad = (m_rows + 255) / 256 * 256, k_pad = gsn_linear_f16x3_kpad(k_total);
-    return m_pad * 4 + m_rows * k_pad * 4;                                // inverse row scales | the rows' planes
+    const int64_t m_pad = gsn_linear_f16x3_mpad(m_rows), k_pad = gsn_linear_f16x3_kpad(k_total);
+    return m_pad * 4 + m_pad * k_pad * 4;                                 // inverse row scales | the rows' planes (zero past m_rows)
 }
 
 static int l16_prepare(const float *W, int64_t n_out, int64_t k_total, int64_t w_rs, int64_t w_cs, void *planes, float *col_inv, void *stream) {
@@ -850,17 +855,11 @@ extern "C" int gsn_linear_f16x3_prepare_strided_hip(const float *W, int64_t n_ou
     return l16_prepare(W, n_out, k_total, w_row_stride, w_col_stride, planes, col_inv, stream);
 }
 
-static int l16_fwd(int64_t m_rows, int n_blocks, const gsn_block *blocks, const void *planes, const float *col_inv,
-                   const float *bias, int64_t n_out, const float *bn_mean, const float *bn_scale, const float *bn_shift,
-                   int act, float *row_scratch, float *out, double *stats, void *stream) {
-    if (n_blocks < 1 || n_blocks > L_MAXB || !blocks || !planes || !col_inv || !row_scratch || !out || n_out <= 0)
-        return set_error(GSN_E_INVALID, "gsn_linear_f16x3_fwd_hip: need 1..%d input blocks, the weight planes, scratch and out", L_MAXB);
-    if ((bn_scale != nullptr) != (bn_shift != nullptr) || (bn_scale != nullptr) != (bn_mean != nullptr))
-        return set_error(GSN_E_INVALID, "gsn_linear_f16x3_fwd_hip: bn_mean, bn_scale and bn_shift go together");
-    if (act < 0 || act > 3) return set_error(GSN_E_INVALID, "gsn_linear_f16x3_fwd_hip: act must be 0..3");
-    if ((reinterpret_cast<uintptr_t>(row_scratch) & 15) != 0) return set_error(GSN_E_INVALID, "gsn_linear_f16x3_fwd_hip: row_scratch must be 16-byte aligned");
-    if (m_rows <= 0) return GSN_OK;
-    L16Args a{};
+// the rows of a call: blocks -> L16Args (widths, K, the scratch's two parts), then the pre-pass that fills the scratch
+static int l16_rows(int64_t m_rows, int n_blocks, const gsn_block *blocks, float *row_scratch, L16Args &a, const char *who) {
+    if (n_blocks < 1 || n_blocks > L_MAXB || !blocks || !row_scratch)
+        return set_error(GSN_E_INVALID, "%s: need 1..%d input blocks and the row scratch", who, L_MAXB);
+    if ((reinterpret_cast<uintptr_t>(row_scratch) & 15) != 0) return set_error(GSN_E_INVALID, "%s: row_scratch must be 16-byte aligned", who);
     a.m_rows = m_rows; a.n_blocks = n_blocks;
     int k_total = 0;
     const float *bd[L_MAXB] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -868,35 +867,54 @@ static int l16_fwd(int64_t m_rows, int n_blocks, const gsn_block *blocks, const 
     for (int b = 0; b < n_blocks; ++b) {
         if (!blocks[b].data || blocks[b].idx || blocks[b].idx32 || blocks[b].width <= 0 || (blocks[b].width & 3) ||
             (reinterpret_cast<uintptr_t>(blocks[b].data) & 15))
-            return set_error(GSN_E_UNSUPPORTED, "gsn_linear_f16x3_fwd_hip: block %d: direct rows (no index), width a multiple of 4, 16-byte aligned", b);
+            return set_error(GSN_E_UNSUPPORTED, "%s: block %d: direct rows (no index), width a multiple of 4, 16-byte aligned", who, b);
         bd[b] = blocks[b].data; bw[b] = (int)blocks[b].width;
         k_total += (int)blocks[b].width;
     }
     for (int b = n_blocks; b < L_MAXB; ++b) { bd[b] = bd[0]; bw[b] = 1 << 28; }      // (never selected: their first column is past K)
     a.b0 = bd[0]; a.b1 = bd[1]; a.b2 = bd[2]; a.b3 = bd[3]; a.b4 = bd[4];
     a.w0 = bw[0]; a.w1 = bw[1]; a.w2 = bw[2]; a.w3 = bw[3]; a.w4 = bw[4];
-    a.k_total = k_total; a.k_pad = (int)gsn_linear_f16x3_kpad(k_total); a.n_out = (int)n_out; a.act = act;
+    a.k_total = k_total; a.k_pad = (int)gsn_linear_f16x3_kpad(k_total);
+    // scratch: [m_pad] inverse row scales | [m_pad][k_pad / 32] lines of the rows' planes
+    a.m_pad = gsn_linear_f16x3_mpad(m_rows);
+    a.rowinv = row_scratch;
+    a.aplanes = reinterpret_cast<unsigned char *>(row_scratch + a.m_pad);
+    return GSN_OK;
+}
+
+static void l16_split_launch(const L16Args &a, hipStream_t st) {
+    // one block of 16-byte aligned rows: the grid-stride kernel (GSN_L16_SPLIT_WGS workgroups, default 1024; 0: the one-tile-per-workgroup kernel)
+    static const int64_t split_wgs = [] { const char *e = getenv("GSN_L16_SPLIT_WGS"); return e ? (int64_t)atoll(e) : (int64_t)1024; }();
+    int64_t gx = a.m_pad / 32;
+    if (split_wgs > 0 && a.n_blocks == 1 && (a.w0 & 3) == 0) {
+        if (gx > split_wgs) gx = split_wgs;
+        hipLaunchKernelGGL(lin16_split_rows1_kernel, dim3((unsigned)gx), dim3(256), 0, st, a);
+    } else {
+        hipLaunchKernelGGL(lin16_split_rows_kernel, dim3((unsigned)gx), dim3(256), 0, st, a);
+    }
+}
+
+static int l16_fwd(int64_t m_rows, int n_blocks, const gsn_block *blocks, const void *planes, const float *col_inv,
+                   const float *bias, int64_t n_out, const float *bn_mean, const float *bn_scale, const float *bn_shift,
+                   int act, float *row_scratch, float *out, double *stats, void *stream, int rows_are_split) {
+    if (!planes || !col_inv || !out || n_out <= 0)
+        return set_error(GSN_E_INVALID, "gsn_linear_f16x3_fwd_hip: need the weight planes and out");
+    if ((bn_scale != nullptr) != (bn_shift != nullptr) || (bn_scale != nullptr) != (bn_mean != nullptr))
+        return set_error(GSN_E_INVALID, "gsn_linear_f16x3_fwd_hip: bn_mean, bn_scale and bn_shift go together");
+    if (act < 0 || act > 3) return set_error(GSN_E_INVALID, "gsn_linear_f16x3_fwd_hip: act must be 0..3");
+    if (m_rows <= 0) return GSN_OK;
+    L16Args a{};
+    const int rc = l16_rows(m_rows, n_blocks, blocks, row_scratch, a, "gsn_linear_f16x3_fwd_hip");
+    if (rc != GSN_OK) return rc;
+    const int k_total = a.k_total;
+    a.n_out = (int)n_out; a.act = act;
     if (n_out * (int64_t)a.k_pad * 4 >= ((int64_t)1 << 31) || n_out >= (1 << 24))
         return set_error(GSN_E_UNSUPPORTED, "gsn_linear_f16x3_fwd_hip: weight planes of 2 GiB and more are not supported");
     a.wplanes = reinterpret_cast<const unsigned char *>(planes); a.colinv = col_inv;
     a.bias = bias; a.bn_mean = bn_mean; a.bn_scale = bn_scale; a.bn_shift = bn_shift;
     a.out = out; a.stats = stats;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    // scratch: [m_pad] inverse row scales | [m_rows][k_pad / 32] lines of the rows' planes
-    a.m_pad = (m_rows + 255) / 256 * 256;
-    a.rowinv = row_scratch;
-    a.aplanes = reinterpret_cast<unsigned char *>(row_scratch + a.m_pad);
-    {
-        // one block of 16-byte aligned rows: the grid-stride kernel (GSN_L16_SPLIT_WGS workgroups, default 1024; 0: the one-tile-per-workgroup kernel)
-        static const int64_t split_wgs = [] { const char *e = getenv("GSN_L16_SPLIT_WGS"); return e ? (int64_t)atoll(e) : (int64_t)1024; }();
-        int64_t gx = a.m_pad / 32;
-        if (split_wgs > 0 && a.n_blocks == 1 && (a.w0 & 3) == 0) {
-            if (gx > split_wgs) gx = split_wgs;
-            hipLaunchKernelGGL(lin16_split_rows1_kernel, dim3((unsigned)gx), dim3(256), 0, st, a);
-        } else {
-            hipLaunchKernelGGL(lin16_split_rows_kernel, dim3((unsigned)gx), dim3(256), 0, st, a);
-        }
-    }
+    if (!rows_are_split) l16_split_launch(a, st);
     // 128 x 128 tiles, two workgroups of 4 waves per CU (256 x 256 tiles with 8 waves measured 3-5 % slower: no registers left
     // for the second set of loads in flight)
     const int wm = 2, nj = 2;
@@ -964,7 +982,7 @@ static int l16_fwd(int64_t m_rows, int n_blocks, const gsn_block *blocks, const 
 extern "C" int gsn_linear_f16x3_fwd_hip(int64_t m_rows, int n_blocks, const gsn_block *blocks, const void *planes, const float *col_inv,
                                         const float *bias, int64_t n_out, const float *bn_mean, const float *bn_scale, const float *bn_shift,
                                         int act, float *row_scratch, float *out, void *stream) {
-    return l16_fwd(m_rows, n_blocks, blocks, planes, col_inv, bias, n_out, bn_mean, bn_scale, bn_shift, act, row_scratch, out, nullptr, stream);
+    return l16_fwd(m_rows, n_blocks, blocks, planes, col_inv, bias, n_out, bn_mean, bn_scale, bn_shift, act, row_scratch, out, nullptr, stream, 0);
 }
 
 // train-mode BatchNorm stage: out = the pre-BN rows x W^T + b, stats[2][n_out] (fp64, ADDED to: the caller zeroes it) their column sums and
@@ -972,5 +990,24 @@ extern "C" int gsn_linear_f16x3_fwd_hip(int64_t m_rows, int n_blocks, const gsn_
 extern "C" int gsn_linear_f16x3_fwd_stats_hip(int64_t m_rows, int n_blocks, const gsn_block *blocks, const void *planes, const float *col_inv,
                                               const float *bias, int64_t n_out, float *row_scratch, float *out, double *stats, void *stream) {
     if (!stats) return set_error(GSN_E_INVALID, "gsn_linear_f16x3_fwd_stats_hip: stats is null");
-    return l16_fwd(m_rows, n_blocks, blocks, planes, col_inv, bias, n_out, nullptr, nullptr, nullptr, 0, row_scratch, out, stats, stream);
+    return l16_fwd(m_rows, n_blocks, blocks, planes, col_inv, bias, n_out, nullptr, nullptr, nullptr, 0, row_scratch, out, stats, stream, 0);
+}
+
+// the rows' pre-pass by itself: row_scratch as gsn_linear_f16x3_fwd_hip leaves it (inverse row scales | the two fp16 planes) -- for
+// gsn_wgrad_f16x3_hip when no product over these rows runs beside it, and for products over rows split earlier (`rows_are_split`)
+extern "C" int gsn_linear_f16x3_split_rows_hip(int64_t m_rows, int n_blocks, const gsn_block *blocks, float *row_scratch, void *stream) {
+    if (m_rows <= 0) return GSN_OK;
+    L16Args a{};
+    const int rc = l16_rows(m_rows, n_blocks, blocks, row_scratch, a, "gsn_linear_f16x3_split_rows_hip");
+    if (rc != GSN_OK) return rc;
+    l16_split_launch(a, reinterpret_cast<hipStream_t>(stream));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(GSN_E_HIP, "lin16_split_rows_kernel: %s", hipGetErrorString(e));
+    return GSN_OK;
+}
+
+extern "C" int gsn_linear_f16x3_fwd_presplit_hip(int64_t m_rows, int n_blocks, const gsn_block *blocks, const void *planes, const float *col_inv,
+                                                 const float *bias, int64_t n_out, const float *bn_mean, const float *bn_scale, const float *bn_shift,
+                                                 int act, float *row_scratch, float *out, void *stream) {
+    return l16_fwd(m_rows, n_blocks, blocks, planes, col_inv, bias, n_out, bn_mean, bn_scale, bn_shift, act, row_scratch, out, nullptr, stream, 1);
 }

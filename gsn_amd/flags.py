@@ -24,6 +24,14 @@ LINEAR_F16X3_MIN_TILES = int(os.environ.get("GSN_LINEAR_F16X3_MIN_TILES", "96"))
 # the row pre-pass; rows as accurate as the bf16x6 kernel's against fp64, scripts/gpu/stats_ab.py).  0: those stages stay on the bf16x6 kernel
 LINEAR_F16X3_STATS = os.environ.get("GSN_LINEAR_F16X3_STATS", "1") != "0"
 
+# weight gradients of stages whose forward product ran on the fp16x3 kernel: gsn_wgrad_f16x3_hip on the fp16 planes the step already holds (the
+# forward product's row scratch of X, kept for the backward pass, and the input-gradient product's row scratch of gH) -- three plane products
+# instead of six, no per-tile plane split: 105 k x 300 x 600: 0.38 -> 0.22 ms.  Values more than 2^-17 below the largest of their ROW keep an
+# absolute precision of 2^-40 of that largest value instead of fp32's relative one (csrc/wgrad_f16.hip).  0: gsn_wgrad_hip (bf16x6) everywhere
+WGRAD_F16X3 = os.environ.get("GSN_WGRAD_F16X3", "1") != "0"
+# (a stage whose input gradient is not wanted, or not computed on the fp16x3 kernel: the pre-pass over gH by itself, from this many rows on)
+WGRAD_F16X3_SPLIT_ROWS = int(os.environ.get("GSN_WGRAD_F16X3_SPLIT_ROWS", "16384"))
+
 # few-row products with an identity epilogue: K ranges of an output tile on several workgroups (gsn_linear_fwd_splitk_hip; 0: one workgroup per tile)
 LINEAR_SPLITK = os.environ.get("GSN_LINEAR_SPLITK", "1") != "0"
 

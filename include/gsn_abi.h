@@ -540,6 +540,7 @@ int gsn_count_layer_step_hip(const gsn_count_call *count, const gsn_layer_pack16
  *                                     launch (gsn_linear_fwd_hip's `stats` contract); n_out a multiple of 4, out 16-byte aligned
  * ---------------------------------------------------------------------------------------------------------------- */
 int64_t gsn_linear_f16x3_kpad(int64_t k_total);
+int64_t gsn_linear_f16x3_mpad(int64_t m_rows);   /* rows of a row scratch: m_rows + at least 128 rows of zero planes, in whole 256-row tiles */
 int64_t gsn_linear_f16x3_scratch_bytes(int64_t m_rows, int64_t k_total);
 int gsn_linear_f16x3_prepare_hip(const float *W, int64_t n_out, int64_t k_total, void *planes, float *col_inv, void *stream);
 /* the same from a weight given through element strides (W[j][k] at W + j * w_row_stride + k * w_col_stride; a transposed view of a row-major
@@ -551,6 +552,22 @@ int gsn_linear_f16x3_fwd_hip(int64_t m_rows, int n_blocks, const gsn_block *bloc
                              int act, float *row_scratch, float *out, void *stream);
 int gsn_linear_f16x3_fwd_stats_hip(int64_t m_rows, int n_blocks, const gsn_block *blocks, const void *planes, const float *col_inv,
                                    const float *bias, int64_t n_out, float *row_scratch, float *out, double *stats, void *stream);
+/* The rows' pre-pass by itself (row_scratch left exactly as gsn_linear_f16x3_fwd_hip leaves it: [mpad(m_rows)] inverse row scales,
+ * then [mpad(m_rows)] rows of kpad(K) / 32 lines of 32 high | 32 low halfs; rows past m_rows hold zeros), and the product over rows split EARLIER (row_scratch is read, not written; blocks
+ * give the widths only).  A training step splits every row set once: the forward product's scratch of X and the input-gradient product's
+ * scratch of gH are what gsn_wgrad_f16x3_hip multiplies. */
+int gsn_linear_f16x3_split_rows_hip(int64_t m_rows, int n_blocks, const gsn_block *blocks, float *row_scratch, void *stream);
+int gsn_linear_f16x3_fwd_presplit_hip(int64_t m_rows, int n_blocks, const gsn_block *blocks, const void *planes, const float *col_inv,
+                                      const float *bias, int64_t n_out, const float *bn_mean, const float *bn_scale, const float *bn_shift,
+                                      int act, float *row_scratch, float *out, void *stream);
+/* HP-2 adjoint: weight gradient of a dense stage from fp16 planes (r06; torch.nn.Linear's weight.grad under models_misc.py:52-58):
+ *     grad_w[n_out][K] += gH^T X
+ * g_scratch = the row scratch of gH [m_rows][n_out] (its "K" is n_out), x_scratch = the row scratch of X [m_rows][K], both as
+ * gsn_linear_f16x3_fwd_hip / _split_rows_hip leave them.  Three fp16 plane products per fp32 product; the per-row scales of the two
+ * operands are reconciled per slab of rows inside the kernel (csrc/wgrad_f16.hip).  Same contract as gsn_wgrad_hip otherwise: grad_w is
+ * ADDED to with float atomics (order varies in the last bits from run to run); a row with an Inf / NaN in gH or X makes the tile NaN. */
+int gsn_wgrad_f16x3_hip(int64_t m_rows, int64_t n_out, int64_t k_total, const void *g_scratch, const void *x_scratch, float *grad_w,
+                        void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * HP-2  edge stage of a `general` layer with the node part of its Linear taken out of the edge loop (device, fp32).

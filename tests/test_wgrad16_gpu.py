@@ -1,0 +1,124 @@
+"""gsn_wgrad_f16x3_hip (csrc/wgrad_f16.hip): the weight gradient of a dense stage, grad_w += gH^T X (torch.nn.Linear's weight.grad under
+models_misc.py:52-58), from the fp16 planes the f16x3 products of a training step leave behind -- against float64, beside the bf16x6 kernel
+(gsn_wgrad_hip) and an fp32 product; ragged row counts, widths that are not whole K slices, rows of very different magnitude inside a slab,
+zero rows, a non-finite row, both operands' pre-pass by itself (gsn_linear_f16x3_split_rows_hip)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _split(t):
+    from gsn_amd import _abi
+    m, k = t.shape
+    L = _abi.lib()
+    scratch = torch.empty(int(L.gsn_linear_f16x3_scratch_bytes(m, k)), dtype=torch.uint8, device=t.device)
+    arr = (_abi.gsn_block * 1)()
+    arr[0].data = t.data_ptr(); arr[0].idx = None; arr[0].idx32 = None; arr[0].width = k
+    _abi.check(L.gsn_linear_f16x3_split_rows_hip(m, 1, arr, scratch.data_ptr(), _abi.current_stream()), "gsn_linear_f16x3_split_rows_hip")
+    return scratch
+
+
+def _wgrad16(gh, x):
+    from gsn_amd import _abi
+    m, n_out = gh.shape
+    k = x.shape[1]
+    sg, sx = _split(gh), _split(x)
+    gw = torch.zeros(n_out, k, device=gh.device)
+    _abi.check(_abi.lib().gsn_wgrad_f16x3_hip(m, n_out, k, sg.data_ptr(), sx.data_ptr(), gw.data_ptr(), _abi.current_stream()), "gsn_wgrad_f16x3_hip")
+    return gw
+
+
+def _wgrad_bf16(gh, x):
+    from gsn_amd import _abi
+    m, n_out = gh.shape
+    gw = torch.zeros(n_out, x.shape[1], device=gh.device)
+    arr = (_abi.gsn_block * 1)()
+    arr[0].data = x.data_ptr(); arr[0].idx = None; arr[0].idx32 = None; arr[0].width = x.shape[1]
+    _abi.check(_abi.lib().gsn_wgrad_hip(m, n_out, gh.data_ptr(), 1, arr, gw.data_ptr(), _abi.current_stream()), "gsn_wgrad_hip")
+    return gw
+
+
+def _errs(gw, gh, x):
+    ref = gh.double().t() @ x.double()
+    bound = gh.double().abs().t() @ x.double().abs()
+    return ((gw.double() - ref).abs() / bound.clamp_min(1e-300)).max().item(), ref, bound
+
+
+@pytest.mark.parametrize("m_rows,n_out,k", [(5000, 600, 300), (105083, 300, 600), (777, 72, 164), (33, 300, 600), (100000, 128, 260), (17, 12, 8), (1, 4, 4),
+                                            (4096, 600, 300), (257, 132, 36)])
+def test_weight_gradient_f16x3_vs_fp64(m_rows, n_out, k):
+    """Element-wise against sum_r |g||x| (what an fp32 accumulation of the same terms can promise), with column magnitudes over two decades and
+    row magnitudes over six (gH) / four (X): not worse than twice an fp32 product's error (1e-6 where few rows leave nothing to average), and the
+    bf16x6 kernel beside it."""
+    torch.manual_seed(m_rows + n_out)
+    rows_g = torch.logspace(-3, 3, m_rows, device="cuda")[torch.randperm(m_rows, device="cuda")].unsqueeze(1)
+    rows_x = torch.logspace(-2, 2, m_rows, device="cuda")[torch.randperm(m_rows, device="cuda")].unsqueeze(1)
+    gh = torch.randn(m_rows, n_out, device="cuda") * torch.logspace(-1, 1, n_out, device="cuda") * rows_g * 1e-6
+    x = torch.randn(m_rows, k, device="cuda") * torch.logspace(-1, 1, k, device="cuda") * rows_x
+    gw = _wgrad16(gh, x)
+    err, ref, bound = _errs(gw, gh, x)
+    err32 = (((gh.t() @ x).double() - ref).abs() / bound.clamp_min(1e-300)).max().item()
+    err_bf = _errs(_wgrad_bf16(gh, x), gh, x)[0]
+    assert err <= max(2.0 * err32, 1e-6), (err, err32, err_bf)
+
+
+def test_values_far_below_their_rows_largest_keep_an_absolute_precision():
+    """The documented limit of fp16 planes under ONE scale per row: a value v of a row whose largest magnitude is R is held to |v| 2^-22 or R 2^-39,
+    whichever is larger (the low plane ends at fp16's smallest subnormal) -- column magnitudes over eight decades: every element within
+    2^-21 sum|g||x| + 2^-38 sum_r max|g_r| max|x_r|."""
+    torch.manual_seed(11)
+    m, n_out, k = 2000, 128, 64
+    gh = torch.randn(m, n_out, device="cuda") * torch.logspace(-4, 4, n_out, device="cuda")
+    x = torch.randn(m, k, device="cuda") * torch.logspace(-4, 4, k, device="cuda")
+    gw = _wgrad16(gh, x)
+    ref = gh.double().t() @ x.double()
+    bound = 2.0 ** -21 * (gh.double().abs().t() @ x.double().abs()) + 2.0 ** -38 * (gh.double().abs().amax(1) * x.double().abs().amax(1)).sum()
+    assert ((gw.double() - ref).abs() <= bound).all(), ((gw.double() - ref).abs() / bound).max().item()
+
+
+def test_rows_far_below_the_slab_maximum_and_zero_rows():
+    """The reconciliation of the row scales: rows 2^-30 below the largest row of their slab vanish (their terms are below 2^-30 of the sum), zero
+    rows of either operand add nothing, a slab of zero rows adds nothing; error against the sum of magnitudes as above."""
+    torch.manual_seed(5)
+    m, n_out, k = 3000, 256, 128
+    gh = torch.randn(m, n_out, device="cuda")
+    x = torch.randn(m, k, device="cuda")
+    gh[::7] *= 2.0 ** -30
+    x[3::11] *= 2.0 ** -12
+    gh[100:140] = 0
+    x[500:530] = 0
+    gh[1024:2048] = 0                       # (whole slabs at 64 rows per slab)
+    gw = _wgrad16(gh, x)
+    err, ref, bound = _errs(gw, gh, x)
+    assert err <= 6e-7, err
+    z = _wgrad16(torch.zeros_like(gh), x)
+    assert torch.count_nonzero(z) == 0
+    z = _wgrad16(gh, torch.zeros_like(x))
+    assert torch.count_nonzero(z) == 0
+
+
+def test_a_non_finite_row_makes_its_tile_columns_nan_and_nothing_is_read_past_the_rows():
+    torch.manual_seed(6)
+    m, n_out, k = 1000, 132, 72
+    gh = torch.randn(m, n_out, device="cuda")
+    x = torch.randn(m, k, device="cuda")
+    gh[999, 5] = float("inf")
+    gw = _wgrad16(gh, x)
+    assert torch.isnan(gw).any()
+    gh[999, 5] = 1.0
+    gw = _wgrad16(gh, x)
+    assert torch.isfinite(gw).all()
+    err = _errs(gw, gh, x)[0]
+    assert err <= 6e-7, err
+
+
+def test_added_to_not_overwritten():
+    torch.manual_seed(7)
+    gh, x = torch.randn(500, 64, device="cuda"), torch.randn(500, 96, device="cuda")
+    once = _wgrad16(gh, x)
+    from gsn_amd import _abi
+    sg, sx = _split(gh), _split(x)
+    gw = once.clone()
+    _abi.check(_abi.lib().gsn_wgrad_f16x3_hip(500, 64, 96, sg.data_ptr(), sx.data_ptr(), gw.data_ptr(), _abi.current_stream()), "gsn_wgrad_f16x3_hip")
+    assert torch.allclose(gw, 2 * once, rtol=1e-5, atol=1e-5)
