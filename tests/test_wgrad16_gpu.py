@@ -122,3 +122,52 @@ def test_added_to_not_overwritten():
     gw = once.clone()
     _abi.check(_abi.lib().gsn_wgrad_f16x3_hip(500, 64, 96, sg.data_ptr(), sx.data_ptr(), gw.data_ptr(), _abi.current_stream()), "gsn_wgrad_f16x3_hip")
     assert torch.allclose(gw, 2 * once, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("train", [True, False])
+def test_dense_stages_take_the_plane_kernel_and_match_float64_autograd(train, monkeypatch):
+    """Linear -> BatchNorm -> ReLU -> Linear over 20 000 rows under autograd (models_misc.py:41-59; the d = 300 node stages of
+    GSN_edge_sparse_ogb.py:63-129): both weight gradients come from gsn_wgrad_f16x3_hip -- the forward products' row scratches are kept, the
+    input-gradient products leave gH's -- and every gradient agrees with a float64 PyTorch evaluation; with the switch off the same stages run
+    on gsn_wgrad_hip."""
+    from gsn_amd import _abi, _autograd, flags
+    from gsn_amd._dense import _Stage
+    torch.manual_seed(3)
+    m, d, h = 20000, 300, 600
+    x = (torch.randn(m, d, device="cuda") * torch.logspace(-1, 1, m, device="cuda")[:, None]).requires_grad_(True)
+    lin1, bn, lin2 = torch.nn.Linear(d, h).cuda(), torch.nn.BatchNorm1d(h).cuda(), torch.nn.Linear(h, d).cuda()
+    bn.train(train)
+    if not train:
+        with torch.no_grad():
+            bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2.0)
+    wout = torch.randn(m, d, device="cuda")
+
+    def run():
+        for p in (*lin1.parameters(), *bn.parameters(), *lin2.parameters()):
+            p.grad = None
+        x.grad = None
+        stages = [_Stage(lin1.weight, lin1.bias, bn, "relu", blocks=[(x, None)]), _Stage(lin2.weight, lin2.bias, None, "identity")]
+        y = _autograd.run_stages_autograd(stages, m, train)
+        (y * wout).sum().backward()
+        return [t.grad.clone() for t in (x, lin1.weight, lin1.bias, bn.weight, bn.bias, lin2.weight, lin2.bias)]
+
+    called = []
+    real = _abi.check
+    monkeypatch.setattr(_abi, "check", lambda rc, what="": (called.append(what), real(rc, what))[1])
+    got = run()
+    assert called.count("gsn_wgrad_f16x3_hip") == 2 and "gsn_wgrad_hip" not in called
+    monkeypatch.setattr(flags, "WGRAD_F16X3", False)
+    called.clear()
+    old = run()
+    assert called.count("gsn_wgrad_hip") == 2 and "gsn_wgrad_f16x3_hip" not in called
+    # float64 reference
+    x64 = x.detach().double().requires_grad_(True)
+    l1, b64, l2 = torch.nn.Linear(d, h).cuda().double(), torch.nn.BatchNorm1d(h).cuda().double(), torch.nn.Linear(h, d).cuda().double()
+    l1.load_state_dict(lin1.state_dict()); b64.load_state_dict(bn.state_dict()); l2.load_state_dict(lin2.state_dict())
+    b64.train(train)
+    (l2(torch.relu(b64(l1(x64)))) * wout.double()).sum().backward()
+    ref = [x64.grad, l1.weight.grad, l1.bias.grad, b64.weight.grad, b64.bias.grad, l2.weight.grad, l2.bias.grad]
+    for name, g, o, r in zip(("x", "W1", "b1", "gamma", "beta", "W2", "b2"), got, old, ref):
+        scale = r.abs().max().item()
+        e_new, e_old = (g.double() - r).abs().max().item() / scale, (o.double() - r).abs().max().item() / scale
+        assert e_new <= max(2.0 * e_old, 2e-6), (name, e_new, e_old)
