@@ -137,6 +137,7 @@ SIGNATURES = {
     "gsn_fold_weights_fwd_hip": (c_int, [c_i64, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "gsn_fold_weights_bwd_hip": (c_int, [c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "gsn_bn_act_bwd_from_h_hip": (c_int, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
+    "gsn_bn_act_bwd_planes_hip": (c_int, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "gsn_wgrad_hip": (c_int, [c_i64, c_i64, c_vp, c_int, ctypes.POINTER(gsn_block), c_vp, c_vp]),
     "gsn_gather_cat_hip": (c_int, [c_i64, c_int, ctypes.POINTER(gsn_block), c_vp, c_vp]),
     "gsn_bn_finalize_hip": (c_int, [c_i64, c_i64, ctypes.c_double, ctypes.c_double, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),

@@ -6,7 +6,7 @@ import torch
 
 from . import _abi, flags
 from ._caches import _note_cache
-from ._dense import _Stage, _bn_resolve, _linear_hip
+from ._dense import _Stage, _bn_resolve, _f16x3_takes, _linear_hip
 from ._index import _csr_for, propagate
 from ._runtime import _ACT_CODE, _f32c, _timed, _zeros
 
@@ -139,10 +139,24 @@ class _DenseStagesFn(torch.autograd.Function):
             gbias = z64[o64:o64 + n_out]
             sums_z = z64[o64 + n_out:o64 + 3 * n_out].view(2, n_out)
             o64 += 3 * n_out
-            gh = torch.empty((m_rows, n_out), dtype=torch.float32, device=dev)
             act = _ACT_CODE[sp["act"]]
+            # a BatchNorm stage whose gH is read as fp16 planes only -- by the input-gradient product on the fp16x3 kernel (or by nobody) and by the
+            # plane weight gradient: the adjoint pass writes gH's row scratch and no fp32 gH (gsn_bn_act_bwd_planes_hip)
+            need_x = si > 0 or any(ctx.needs_input_grad[1 + bi] for bi in range(len(blocks0)))
+            want_w = ctx.needs_input_grad[1 + ent["w_i"]]
+            planes_only = (flags.BN_BWD_PLANES and kind in ("bn", "bn_eval") and want_w and ctx.x_scratch[si] is not None and n_out % 4 == 0 and n_out <= 640
+                           and g.data_ptr() % 16 == 0 and (not need_x or _f16x3_takes(m_rows, k_total, [n_out])))
+            gh = None if planes_only else torch.empty((m_rows, n_out), dtype=torch.float32, device=dev)
+            gh_scratch = None
             with _abi.device_guard(dev), _timed("bn_act_bwd", 16.0 * m_rows * n_out):
-                if kind in ("bn", "bn_eval"):
+                if planes_only:
+                    h, y, mean32, invstd, scale, shift = saved[off:off + 6]
+                    sums = sums_z
+                    gh_scratch = torch.empty(int(L.gsn_linear_f16x3_scratch_bytes(m_rows, n_out)), dtype=torch.uint8, device=dev)
+                    rc = L.gsn_bn_act_bwd_planes_hip(m_rows, n_out, g.data_ptr(), h.data_ptr(), mean32.data_ptr(), invstd.data_ptr(), scale.data_ptr(),
+                                                     shift.data_ptr(), 1 if kind == "bn" else 2, act, sums.data_ptr(), gh_scratch.data_ptr(),
+                                                     gbias.data_ptr(), _abi.current_stream())
+                elif kind in ("bn", "bn_eval"):
                     h, y, mean32, invstd, scale, shift = saved[off:off + 6]
                     sums = sums_z
                     # (the activation's derivative from z recomputed out of the pre-BN rows: the stage output is not read again)
@@ -159,7 +173,7 @@ class _DenseStagesFn(torch.autograd.Function):
                     sums = None
                     rc = L.gsn_bn_act_bwd_hip(m_rows, n_out, g.data_ptr(), y.data_ptr(), None, None, None, None, 0, act, None,
                                               gh.data_ptr(), gbias.data_ptr(), _abi.current_stream())
-            _abi.check(rc, "gsn_bn_act_bwd_hip")
+            _abi.check(rc, "gsn_bn_act_bwd_planes_hip" if planes_only else "gsn_bn_act_bwd_hip")
             # (fp64 column sums -> fp32 gradients: ONE conversion of the whole arena behind the loop, the gradients are its slices)
             o0 = o64 - 3 * n_out
             if kind in ("bn", "bn_eval") and "g_i" in ent:
@@ -168,8 +182,6 @@ class _DenseStagesFn(torch.autograd.Function):
             if "b_i" in ent:
                 casts.append((ent["b_i"], o0, n_out))
             # input gradient first: on the fp16x3 kernel its row pre-pass leaves the fp16 planes of gH, which the weight gradient multiplies as well
-            need_x = si > 0 or any(ctx.needs_input_grad[1 + bi] for bi in range(len(blocks0)))
-            want_w = ctx.needs_input_grad[1 + ent["w_i"]]
             xs = ctx.x_scratch[si] if want_w else None
             g_scr = [] if xs is not None else None
             gx = None
@@ -177,13 +189,18 @@ class _DenseStagesFn(torch.autograd.Function):
                 # gX = gH W: W read as its transpose.  The fp16x3 kernel prepares its planes from any strides; the bf16x6 kernel stages a
                 # strided W with scalar loads -- fine where a launch costs more than the staging (small batches), a copy + float4 staging above
                 wt = w.detach().t() if (w.shape[1] > flags.LINEAR_F16X3_MIN_N or m_rows <= 16384) else _transposed(w)
-                gx = _linear_hip([(gh, None)], wt, None, None, None, None, 0, m_rows, split_k=True, scratch_out=g_scr)
+                if planes_only:         # (the rows are split already; `h` stands in for gH's shape)
+                    gx = _linear_hip([(saved[off], None)], wt, None, None, None, None, 0, m_rows, split_k=True, presplit=gh_scratch)
+                else:
+                    gx = _linear_hip([(gh, None)], wt, None, None, None, None, 0, m_rows, split_k=True, scratch_out=g_scr)
+            if planes_only:
+                g_scr.append(gh_scratch)
             # weight gradient
             xin = blocks0 if si == 0 else [saved[meta[si - 1][1] + (1 if meta[si - 1][0] in ("bn", "bn_eval") else 0)]]
             if want_w:
                 gw = z32[o32:o32 + n_out * k_total].view(n_out, k_total)
                 o32 += n_out * k_total
-                if xs is not None and not g_scr and n_out % 4 == 0 and gh.data_ptr() % 16 == 0 and m_rows >= flags.WGRAD_F16X3_SPLIT_ROWS:
+                if xs is not None and not g_scr and n_out % 4 == 0 and gh is not None and gh.data_ptr() % 16 == 0 and m_rows >= flags.WGRAD_F16X3_SPLIT_ROWS:
                     # no input-gradient product on the fp16x3 kernel beside it: the planes of gH from the pre-pass alone
                     sc = torch.empty(int(L.gsn_linear_f16x3_scratch_bytes(m_rows, n_out)), dtype=torch.uint8, device=dev)
                     one = (_abi.gsn_block * 1)()

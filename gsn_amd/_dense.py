@@ -43,12 +43,20 @@ def _f16x3_weights(weight, w32):
     return planes, col_inv
 
 
-def _linear_hip(blocks, weight, bias, bn_mean, bn_scale, bn_shift, act, m_rows, out=True, stats=None, split_k=False, scratch_out=None):
+def _f16x3_takes(m_rows, n_out, widths, aligned=True):
+    """Would _linear_hip run this product of direct rows (block widths ``widths``) on the fp16x3 kernel?  (the rule inside it, for callers that
+    decide what to keep or prepare for that kernel)"""
+    return (flags.LINEAR_F16X3 and m_rows > 0 and n_out > flags.LINEAR_F16X3_MIN_N
+            and ((m_rows + 127) // 128) * ((n_out + 127) // 128) > flags.LINEAR_F16X3_MIN_TILES and aligned and all(w % 4 == 0 for w in widths))
+
+
+def _linear_hip(blocks, weight, bias, bn_mean, bn_scale, bn_shift, act, m_rows, out=True, stats=None, split_k=False, scratch_out=None, presplit=None):
     """blocks: list of (data [R,w] fp32 cuda, idx int64 [M] or None).  ``split_k``: the caller accepts a sum whose order varies from run to run in the
     last bits (float atomics over K ranges, gsn_linear_fwd_splitk_hip) -- the input-gradient products of a backward pass, whose weight gradients
     are accumulated that way already; forward products stay on one workgroup per tile: an eval forward is reproducible bit for bit.
     ``scratch_out``: a list that receives the row scratch (inverse row scales + the rows' fp16 planes) when the product ran on the fp16x3 kernel --
-    what gsn_wgrad_f16x3_hip multiplies (the caller keeps it alive)."""
+    what gsn_wgrad_f16x3_hip multiplies (the caller keeps it alive).  ``presplit``: the row scratch of the rows, made earlier (gsn_bn_act_bwd_planes_hip):
+    the product on the fp16x3 kernel without its pre-pass; ``blocks`` then only name the widths (any 16-byte aligned fp32 tensor of that shape)."""
     if len(blocks) > _MAX_BLOCKS:
         raise NotImplementedError("more than %d input blocks" % _MAX_BLOCKS)
     dev = weight.device
@@ -82,20 +90,29 @@ def _linear_hip(blocks, weight, bias, bn_mean, bn_scale, bn_shift, act, m_rows, 
     # (from two column tiles on: the pre-pass over the rows that finds their scales is then amortised -- at n_out <= 128 the
     #  bf16x6 kernel, which reads the rows once, is faster: 99 vs 90 TF/s at K = 260)
     # (a train-mode stage that keeps its pre-BN rows: the same kernel with the column statistics taken in its epilogue)
-    if (flags.LINEAR_F16X3 and out and (stats is None or (flags.LINEAR_F16X3_STATS and bn_mean is None and act == 0 and n_out % 4 == 0)) and m_rows > 0 and n_out > flags.LINEAR_F16X3_MIN_N
-            and ((m_rows + 127) // 128) * ((n_out + 127) // 128) > flags.LINEAR_F16X3_MIN_TILES
-            and all(idx is None for _, idx in blocks) and all(d.shape[1] % 4 == 0 and d.data_ptr() % 16 == 0 for d in keep)):
+    takes16 = (flags.LINEAR_F16X3 and out and (stats is None or (flags.LINEAR_F16X3_STATS and bn_mean is None and act == 0 and n_out % 4 == 0)) and m_rows > 0 and n_out > flags.LINEAR_F16X3_MIN_N
+               and ((m_rows + 127) // 128) * ((n_out + 127) // 128) > flags.LINEAR_F16X3_MIN_TILES
+               and all(idx is None for _, idx in blocks) and all(d.shape[1] % 4 == 0 and d.data_ptr() % 16 == 0 for d in keep))
+    if presplit is not None and not takes16:
+        raise RuntimeError("presplit rows given to a product that does not run on the fp16x3 kernel (_f16x3_takes decides)")
+    if takes16:
         planes, col_inv = _f16x3_weights(weight, w)
-        scratch = torch.empty(int(_abi.lib().gsn_linear_f16x3_scratch_bytes(m_rows, w.shape[1])), dtype=torch.uint8, device=dev)
+        scratch = presplit if presplit is not None else torch.empty(int(_abi.lib().gsn_linear_f16x3_scratch_bytes(m_rows, w.shape[1])), dtype=torch.uint8, device=dev)
         with _abi.device_guard(dev), _timed("linear_fwd", 2.0 * m_rows * w.shape[1] * n_out):
-            if stats is not None:
+            if presplit is not None:
+                if stats is not None:
+                    raise NotImplementedError("presplit rows with column statistics")
+                rc = _abi.lib().gsn_linear_f16x3_fwd_presplit_hip(m_rows, len(blocks), arr, planes.data_ptr(), col_inv.data_ptr(), _abi.ptr(vecs[0]), n_out,
+                                                                  _abi.ptr(vecs[1]), _abi.ptr(vecs[2]), _abi.ptr(vecs[3]), act, scratch.data_ptr(),
+                                                                  y.data_ptr(), _abi.current_stream())
+            elif stats is not None:
                 rc = _abi.lib().gsn_linear_f16x3_fwd_stats_hip(m_rows, len(blocks), arr, planes.data_ptr(), col_inv.data_ptr(), _abi.ptr(vecs[0]), n_out,
                                                                scratch.data_ptr(), y.data_ptr(), stats.data_ptr(), _abi.current_stream())
             else:
                 rc = _abi.lib().gsn_linear_f16x3_fwd_hip(m_rows, len(blocks), arr, planes.data_ptr(), col_inv.data_ptr(), _abi.ptr(vecs[0]), n_out,
                                                          _abi.ptr(vecs[1]), _abi.ptr(vecs[2]), _abi.ptr(vecs[3]), act, scratch.data_ptr(),
                                                          y.data_ptr(), _abi.current_stream())
-        _abi.check(rc, "gsn_linear_f16x3_fwd_stats_hip" if stats is not None else "gsn_linear_f16x3_fwd_hip")
+        _abi.check(rc, "gsn_linear_f16x3_fwd_presplit_hip" if presplit is not None else ("gsn_linear_f16x3_fwd_stats_hip" if stats is not None else "gsn_linear_f16x3_fwd_hip"))
         if scratch_out is not None:
             scratch_out.append(scratch)
         return y

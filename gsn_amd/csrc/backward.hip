@@ -140,6 +140,109 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(int64_t m_rows, i
     }
 }
 
+// pass 2 for a stage whose gH is consumed as fp16 PLANES only (r06): the input-gradient product gX = gH W on the fp16x3 kernel and the weight
+// gradient gsn_wgrad_f16x3_hip both read the row scratch of gH (inverse row scales + a high and a low half per value, linear_f16.hip's layout) --
+// so this pass writes that scratch and no fp32 gH at all: one read of gY and H, one write of 4 bytes per value, instead of apply (read 2, write
+// 1) + row pre-pass (read 1, write 1).  Row-oriented like the pre-pass it replaces: 8 lanes per row, float4 chunks, a row's values stay in
+// registers between the pass that finds its largest magnitude and the one that writes the planes (rows up to 640 columns).  The per-column
+// vectors (mean, invstd, coef, shift, m1, m2) sit in LDS.  Same expression per value as bn_act_bwd_apply_kernel.
+// The bias gradient = the column sums of gH: in train mode sum_r gH = coef (S1 - M m1 - m2 sum_r xhat) = 0 up to the rounding of the batch mean
+// (the batch statistics absorb any shift of H: the true derivative is zero); on running statistics it is coef * S1.  Written by workgroup 0.
+constexpr int BP_NCH = 20;         // float4 chunks per lane: rows up to 8 * 20 * 4 = 640 columns
+typedef _Float16 bp_h16x2 __attribute__((ext_vector_type(2)));
+typedef float bp_fl2 __attribute__((ext_vector_type(2)));
+typedef unsigned bp_un4 __attribute__((ext_vector_type(4)));
+
+struct BwdPlanesArgs {
+    int64_t m_rows, m_pad;
+    int n_cols, k_pad, act, train;  // train 1: batch statistics, 2: running statistics
+    const float *gy, *h, *mean, *invstd, *coef, *shift;
+    const double *sums;             // [2][n_cols] of the reduce pass
+    float *rowinv;
+    unsigned char *planes;
+    double *gbias;
+};
+
+__global__ __launch_bounds__(256) void bn_act_bwd_planes_kernel(BwdPlanesArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float bp_tab[];    // [6][k_pad]: mean | invstd | coef | shift | m1 | m2
+    const int kp = a.k_pad;
+    for (int c = threadIdx.x; c < kp; c += 256) {
+        const bool ok = c < a.n_cols;
+        bp_tab[c] = ok ? a.mean[c] : 0.f;
+        bp_tab[kp + c] = ok ? a.invstd[c] : 0.f;
+        bp_tab[2 * kp + c] = ok ? a.coef[c] : 0.f;                   // (padding columns: coef 0 -> zero planes)
+        bp_tab[3 * kp + c] = ok ? a.shift[c] : 0.f;
+        bp_tab[4 * kp + c] = (ok && a.train == 1) ? (float)(a.sums[c] / (double)a.m_rows) : 0.f;
+        bp_tab[5 * kp + c] = (ok && a.train == 1) ? (float)(a.sums[a.n_cols + c] / (double)a.m_rows) : 0.f;
+        if (blockIdx.x == 0 && ok && a.gbias && a.train == 2) a.gbias[c] += (double)a.coef[c] * a.sums[c];
+    }
+    __syncthreads();
+    const int q8 = threadIdx.x & 7;
+    const int nch = a.n_cols >> 2, nchp = kp >> 2;
+    const bool even = (q8 & 1) == 0;
+    const int act = a.act;
+    const bool train = a.train == 1;
+    for (int64_t tile = blockIdx.x; tile < a.m_pad / 32; tile += gridDim.x) {
+        const int64_t row = tile * 32 + (threadIdx.x >> 3);
+        const bool on = row < a.m_rows;
+        const int64_t rr = on ? row : a.m_rows - 1;
+        const float4 *gp = reinterpret_cast<const float4 *>(a.gy + rr * a.n_cols), *hp = reinterpret_cast<const float4 *>(a.h + rr * a.n_cols);
+        float4 v[BP_NCH];
+        unsigned m = 0;
+#pragma unroll
+        for (int i = 0; i < BP_NCH; ++i) {
+            const int c = q8 + 8 * i;
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < nch && on) {
+                const float4 g = gp[c], hh = hp[c];
+                const float4 mu = *reinterpret_cast<const float4 *>(bp_tab + 4 * c), is = *reinterpret_cast<const float4 *>(bp_tab + kp + 4 * c);
+                const float4 cf = *reinterpret_cast<const float4 *>(bp_tab + 2 * kp + 4 * c), zb = *reinterpret_cast<const float4 *>(bp_tab + 3 * kp + 4 * c);
+                const float4 m1 = *reinterpret_cast<const float4 *>(bp_tab + 4 * kp + 4 * c), m2 = *reinterpret_cast<const float4 *>(bp_tab + 5 * kp + 4 * c);
+                auto one = [&](float gyv, float hv, float mu_, float is_, float cf_, float zb_, float m1_, float m2_) {
+                    const float gz = gyv * act_grad_from_z((hv - mu_) * cf_ + zb_, act);
+                    float g_ = gz;
+                    if (train) g_ = gz - m1_ - (hv - mu_) * is_ * m2_;
+                    return g_ * cf_;
+                };
+                v[i] = make_float4(one(g.x, hh.x, mu.x, is.x, cf.x, zb.x, m1.x, m2.x), one(g.y, hh.y, mu.y, is.y, cf.y, zb.y, m1.y, m2.y),
+                                   one(g.z, hh.z, mu.z, is.z, cf.z, zb.z, m1.z, m2.z), one(g.w, hh.w, mu.w, is.w, cf.w, zb.w, m1.w, m2.w));
+                m = max(max(m, __float_as_uint(v[i].x) & 0x7fffffffu), __float_as_uint(v[i].y) & 0x7fffffffu);
+                m = max(max(m, __float_as_uint(v[i].z) & 0x7fffffffu), __float_as_uint(v[i].w) & 0x7fffffffu);
+            }
+        }
+        m = max(m, (unsigned)__shfl_xor((int)m, 1));
+        m = max(m, (unsigned)__shfl_xor((int)m, 2));
+        m = max(m, (unsigned)__shfl_xor((int)m, 4));
+        // power-of-two scale that puts the row's largest magnitude into [2^14, 2^15), and its inverse (linear_f16.hip: l16_scale)
+        int e = (int)(m >> 23);
+        e = e < 15 ? 15 : (e > 254 ? 254 : e);
+        const float s = __uint_as_float((unsigned)(268 - e) << 23);
+        float inv = __uint_as_float((unsigned)(e - 14) << 23);
+        if (m >= 0x7f800000u) inv = __uint_as_float(0x7fc00000u);            // Inf / NaN in the row: whatever reads its planes gets NaN
+        if (q8 == 0) a.rowinv[row] = on ? inv : 0.f;
+        unsigned char *prow = a.planes + row * (int64_t)kp * 4;
+#pragma unroll
+        for (int i = 0; i < BP_NCH; ++i) {
+            const int c = q8 + 8 * i;
+            if (c < nchp) {                       // (uniform over the lane pairs that trade halves: c and c ^ 1 lie on the same side of nchp, a multiple of 8)
+                auto split2 = [](float x0, float x1, unsigned &hi, unsigned &lo) {
+                    const bp_h16x2 hv = __builtin_convertvector(bp_fl2{x0, x1}, bp_h16x2);
+                    const bp_fl2 r = bp_fl2{x0, x1} - __builtin_convertvector(hv, bp_fl2);
+                    const bp_h16x2 lv = __builtin_convertvector(r, bp_h16x2);
+                    hi = __builtin_bit_cast(unsigned, hv);
+                    lo = __builtin_bit_cast(unsigned, lv);
+                };
+                unsigned h0, l0, h1, l1;
+                split2(v[i].x * s, v[i].y * s, h0, l0);
+                split2(v[i].z * s, v[i].w * s, h1, l1);
+                const unsigned r0 = (unsigned)__shfl_xor((int)(even ? l0 : h0), 1), r1 = (unsigned)__shfl_xor((int)(even ? l1 : h1), 1);
+                unsigned char *line = prow + (c >> 3) * 128 + (even ? 0 : 64) + ((c & 7) >> 1) * 16;
+                *reinterpret_cast<bp_un4 *>(line) = even ? bp_un4{h0, h1, r0, r1} : bp_un4{r0, r1, l0, l1};
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // weight gradient
 // ---------------------------------------------------------------------------------------------------------------------
@@ -612,6 +715,35 @@ extern "C" int gsn_bn_act_bwd_from_h_hip(int64_t m_rows, int64_t n_cols, const f
     if (train_bn != 1 && train_bn != 2) return set_error(GSN_E_INVALID, "gsn_bn_act_bwd_from_h_hip: a BatchNorm stage (train_bn 1 or 2)");
     return bn_act_bwd_launch(m_rows, n_cols, grad_y, nullptr, h, mean, invstd, coef, shift, train_bn, act, sums, grad_h, grad_bias, stream,
                              "gsn_bn_act_bwd_from_h_hip");
+}
+
+// gsn_bn_act_bwd_from_h_hip for a stage whose gH is read as fp16 planes only: reduce pass as there, then bn_act_bwd_planes_kernel writes the
+// row scratch of gH (gsn_linear_f16x3_scratch_bytes(m_rows, n_cols) bytes: what gsn_linear_f16x3_fwd_presplit_hip and gsn_wgrad_f16x3_hip read)
+extern "C" int gsn_bn_act_bwd_planes_hip(int64_t m_rows, int64_t n_cols, const float *grad_y, const float *h, const float *mean, const float *invstd,
+                                         const float *coef, const float *shift, int train_bn, int act, double *sums, float *row_scratch,
+                                         double *grad_bias, void *stream) {
+    if ((train_bn != 1 && train_bn != 2) || n_cols < 4 || (n_cols & 3) || n_cols > 8 * BP_NCH * 4 || act < 0 || act > 3)
+        return set_error(GSN_E_UNSUPPORTED, "gsn_bn_act_bwd_planes_hip: a BatchNorm stage (train_bn 1 or 2) of 4 .. %d columns, a multiple of 4", 8 * BP_NCH * 4);
+    if (m_rows > 0 && (!grad_y || !h || !mean || !invstd || !coef || !shift || !sums || !row_scratch))
+        return set_error(GSN_E_INVALID, "gsn_bn_act_bwd_planes_hip: bad arguments");
+    if (m_rows <= 0) return GSN_OK;
+    if ((reinterpret_cast<uintptr_t>(grad_y) | reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(row_scratch)) & 15)
+        return set_error(GSN_E_INVALID, "gsn_bn_act_bwd_planes_hip: grad_y, h and row_scratch must be 16-byte aligned");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid(bgrid(m_rows), (unsigned)((n_cols + 63) / 64));
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, grid, dim3(256), 0, s, m_rows, (int)n_cols, grad_y, (const float *)nullptr, h, mean, invstd, act, sums, coef, shift);
+    BwdPlanesArgs a{};
+    a.m_rows = m_rows; a.m_pad = gsn_linear_f16x3_mpad(m_rows); a.n_cols = (int)n_cols; a.k_pad = (int)gsn_linear_f16x3_kpad(n_cols);
+    a.act = act; a.train = train_bn;
+    a.gy = grad_y; a.h = h; a.mean = mean; a.invstd = invstd; a.coef = coef; a.shift = shift; a.sums = sums;
+    a.rowinv = row_scratch; a.planes = reinterpret_cast<unsigned char *>(row_scratch + a.m_pad); a.gbias = grad_bias;
+    int64_t gx = a.m_pad / 32;
+    static const int64_t wgs = [] { const char *e = getenv("GSN_BWD_PLANES_WGS"); const int64_t v = e ? atoll(e) : 0; return v > 0 ? v : (int64_t)2048; }();
+    if (gx > wgs) gx = wgs;
+    hipLaunchKernelGGL(bn_act_bwd_planes_kernel, dim3((unsigned)gx), dim3(256), (size_t)6 * a.k_pad * 4, s, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(GSN_E_HIP, "bn_act_bwd_planes kernels: %s", hipGetErrorString(e));
+    return GSN_OK;
 }
 
 extern "C" int gsn_wgrad_hip(int64_t m_rows, int64_t n_out, const float *grad_h, int n_blocks, const gsn_block *blocks,

@@ -53,8 +53,11 @@ struct WfArgs {
     int dbg;                       // diagnostic build: 1 no atomics, 2 no products, 4 no loads behind the first two steps, 8 no staging
 };
 
+#ifndef WF_WAVES
+#define WF_WAVES 2                 // waves per SIMD the register allocation aims at (A/B builds: 3 spills 14-33 registers)
+#endif
 template <int VALU_PER_MFMA, bool DBG>
-__global__ __launch_bounds__(256) void wgrad_f16x3_kernel(WfArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WF_WAVES, WF_WAVES))) void wgrad_f16x3_kernel(WfArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wf_smem[];
     // LDS (no static __shared__ in front of it: the 16-byte accesses need the base aligned).  Per operand and buffer: [plane][k-group] blocks
     // of 128 fragments of 16 bytes, even columns first, then (128 bytes of padding further) the odd columns -- a lane holds columns 2c and

@@ -29,6 +29,9 @@ LINEAR_F16X3_STATS = os.environ.get("GSN_LINEAR_F16X3_STATS", "1") != "0"
 # instead of six, no per-tile plane split: 105 k x 300 x 600: 0.38 -> 0.22 ms.  Values more than 2^-17 below the largest of their ROW keep an
 # absolute precision of 2^-40 of that largest value instead of fp32's relative one (csrc/wgrad_f16.hip).  0: gsn_wgrad_hip (bf16x6) everywhere
 WGRAD_F16X3 = os.environ.get("GSN_WGRAD_F16X3", "1") != "0"
+# BatchNorm stages whose gH is read as planes only (input gradient on the fp16x3 kernel + the plane weight gradient): the adjoint pass writes the
+# row scratch of gH directly (gsn_bn_act_bwd_planes_hip) -- no fp32 gH, no row pre-pass over it.  0: apply pass + pre-pass
+BN_BWD_PLANES = os.environ.get("GSN_BN_BWD_PLANES", "1") != "0"
 # (a stage whose input gradient is not wanted, or not computed on the fp16x3 kernel: the pre-pass over gH by itself, from this many rows on)
 WGRAD_F16X3_SPLIT_ROWS = int(os.environ.get("GSN_WGRAD_F16X3_SPLIT_ROWS", "16384"))
 

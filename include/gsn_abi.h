@@ -722,6 +722,13 @@ int gsn_bn_act_bwd_hip(int64_t m_rows, int64_t n_cols, const float *grad_y, cons
 int gsn_bn_act_bwd_from_h_hip(int64_t m_rows, int64_t n_cols, const float *grad_y, const float *h, const float *mean,
                               const float *invstd, const float *coef, const float *shift, int train_bn, int act, double *sums,
                               float *grad_h, double *grad_bias, void *stream);
+/* The same again for a stage whose grad_h is consumed as fp16 planes only (r06): no fp32 grad_h is written; row_scratch
+ * (gsn_linear_f16x3_scratch_bytes(m_rows, n_cols) bytes, 16-byte aligned) receives grad_h's inverse row scales and planes, ready for
+ * gsn_linear_f16x3_fwd_presplit_hip (the input gradient grad_h W) and gsn_wgrad_f16x3_hip.  n_cols a multiple of 4, at most 640.  grad_bias
+ * receives the column sums analytically: zero under batch statistics (the statistics absorb a shift of H), coef * sum(gZ) on running ones. */
+int gsn_bn_act_bwd_planes_hip(int64_t m_rows, int64_t n_cols, const float *grad_y, const float *h, const float *mean, const float *invstd,
+                              const float *coef, const float *shift, int train_bn, int act, double *sums, float *row_scratch,
+                              double *grad_bias, void *stream);
 int gsn_wgrad_hip(int64_t m_rows, int64_t n_out, const float *grad_h, int n_blocks, const gsn_block *blocks, float *grad_w,
                   void *stream);
 /* The folded first weight of update_fn for a `general` layer whose aggregation runs in front of msg_fn's last Linear (W2, b2) --
