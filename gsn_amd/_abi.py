@@ -103,6 +103,8 @@ SIGNATURES = {
     "gsn_linear_f16x3_split_rows_hip": (c_int, [c_i64, c_int, c_vp, c_vp, c_vp]),
     "gsn_linear_f16x3_fwd_presplit_hip": (c_int, [c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),
     "gsn_wgrad_f16x3_hip": (c_int, [c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp]),
+    "gsn_linear_f16x3_fwd_stats_presplit_hip": (c_int, [c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
+    "gsn_bn_act_planes_hip": (c_int, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),
     "gsn_edge_split_sum_hip": (c_int, [c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_vp]),
     "gsn_csr_build_graphs_hip": (c_int, [c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "gsn_segsum_prepare_hip": (c_int, [c_i64, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp]),

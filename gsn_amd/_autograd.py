@@ -45,17 +45,20 @@ class _DenseStagesFn(torch.autograd.Function):
         # per stage: the forward product's row scratch (fp16 planes of the stage's input rows), kept when the weight wants a gradient and the
         # product ran on the fp16x3 kernel -- the backward pass multiplies it with the planes of gH (gsn_wgrad_f16x3_hip)
         x_scratch = []
+        presplit_next, y_shape, y_dropped = None, None, set()
         w_pos = spec[0]["n_blocks"]
         for si, sp in enumerate(spec):
             scr = [] if (flags.WGRAD_F16X3 and ctx.needs_input_grad[1 + w_pos] and (si > 0 or gather is None)) else None
             w_pos += 1 + (1 if sp["has_bias"] else 0) + (2 if (sp["bn"] is not None and sp["bn"].affine) else 0)
+            # rows split already by the stage before (gsn_bn_act_planes_hip): the product without its pre-pass; `y_shape` stands in for the rows
+            pre, presplit_next = presplit_next, None
             w = next(it)
             b = next(it) if sp["has_bias"] else None
             bn = sp["bn"]
             gamma = beta = None
             if bn is not None and bn.affine:
                 gamma, beta = next(it), next(it)
-            blks = [(t, ix) for t, ix in zip(blocks0, idx0)] if si == 0 else [(y, None)]
+            blks = [(t, ix) for t, ix in zip(blocks0, idx0)] if si == 0 else [(y if pre is None else y_shape, None)]
             n_out = w.shape[0]
             bn_train = bn is not None and (bn.training or bn.running_mean is None)
             bn_affine_grad = bn is not None and bn.affine and (bn.weight.requires_grad or bn.bias.requires_grad)
@@ -64,7 +67,7 @@ class _DenseStagesFn(torch.autograd.Function):
                 st = _Stage(w, b, bn, sp["act"])
                 _bn_resolve(st, None, m_rows, False)
                 mean32, scale, shift = st.bn_params
-                y = _linear_hip(blks, w, b, mean32, scale, shift, _ACT_CODE[sp["act"]], m_rows, scratch_out=scr)
+                y = _linear_hip(blks, w, b, mean32, scale, shift, _ACT_CODE[sp["act"]], m_rows, scratch_out=scr, presplit=pre)
                 saved += [y, _f32c(scale)]
                 meta.append(("affine", len(saved) - 2))
             elif bn is not None:
@@ -73,32 +76,53 @@ class _DenseStagesFn(torch.autograd.Function):
                 fused_act = False
                 if bn_train:
                     stats = _zeros(2 * n_out, torch.float64, w.device).view(2, n_out)
-                    h = _linear_hip(blks, w, b, None, None, None, 0, m_rows, out=True, stats=stats, scratch_out=scr)
-                    yy = torch.empty_like(h)
+                    h = _linear_hip(blks, w, b, None, None, None, 0, m_rows, out=True, stats=stats, scratch_out=scr, presplit=pre)
                     fused_act = 1 < m_rows <= flags.FUSE_BN_ACT_ROWS
+                    yy = torch.empty_like(h) if fused_act else None
                     _bn_resolve(st, lambda: stats, m_rows, True, fuse_act=(h, _ACT_CODE[sp["act"]], yy) if fused_act else None)
                 else:
-                    h = _linear_hip(blks, w, b, None, None, None, 0, m_rows, out=True, scratch_out=scr)
-                    yy = torch.empty_like(h)
+                    h = _linear_hip(blks, w, b, None, None, None, 0, m_rows, out=True, scratch_out=scr, presplit=pre)
+                    yy = None
                     _bn_resolve(st, None, m_rows, False)
                 mean32, scale, shift = st.bn_params
                 vecs = [_f32c(v) for v in (mean32, scale, shift)]
                 if not fused_act:
+                    # the stage output only feeds the next product (on the fp16x3 kernel) and, in the backward pass, that product's plane weight
+                    # gradient: BatchNorm + activation write the row scratch of Y -- no fp32 Y, no pre-pass over it (gsn_bn_act_planes_hip)
+                    to_planes = False
+                    if flags.BN_ACT_PLANES and si + 1 < len(spec) and n_out % 4 == 0 and n_out <= 640 and h.data_ptr() % 16 == 0 and m_rows > 0:
+                        nsp, n_next = spec[si + 1], tensors[w_pos].shape[0]
+                        nbn = nsp["bn"]
+                        next_stats = nbn is not None and (nbn.training or nbn.running_mean is None)
+                        to_planes = (flags.WGRAD_F16X3 and ctx.needs_input_grad[1 + w_pos] and _f16x3_takes(m_rows, n_next, [n_out])
+                                     and (not next_stats or (flags.LINEAR_F16X3_STATS and n_next % 4 == 0)))
                     with _abi.device_guard(h.device), _timed("bn_act", 8.0 * h.numel()):
-                        _abi.check(_abi.lib().gsn_bn_act_hip(m_rows, n_out, h.data_ptr(), vecs[0].data_ptr(), vecs[1].data_ptr(),
-                                                             vecs[2].data_ptr(), _ACT_CODE[sp["act"]], yy.data_ptr(),
-                                                             _abi.current_stream()), "gsn_bn_act_hip")
+                        if to_planes:
+                            presplit_next = torch.empty(int(_abi.lib().gsn_linear_f16x3_scratch_bytes(m_rows, n_out)), dtype=torch.uint8, device=h.device)
+                            _abi.check(_abi.lib().gsn_bn_act_planes_hip(m_rows, n_out, h.data_ptr(), vecs[0].data_ptr(), vecs[1].data_ptr(), vecs[2].data_ptr(),
+                                                                        _ACT_CODE[sp["act"]], None, presplit_next.data_ptr(), _abi.current_stream()),
+                                       "gsn_bn_act_planes_hip")
+                            y_shape = h
+                            y_dropped.add(si)
+                        else:
+                            yy = torch.empty_like(h)
+                            _abi.check(_abi.lib().gsn_bn_act_hip(m_rows, n_out, h.data_ptr(), vecs[0].data_ptr(), vecs[1].data_ptr(),
+                                                                 vecs[2].data_ptr(), _ACT_CODE[sp["act"]], yy.data_ptr(),
+                                                                 _abi.current_stream()), "gsn_bn_act_hip")
                 invstd = st.bn_invstd
-                saved += [h, yy, vecs[0], invstd.contiguous(), vecs[1], vecs[2]]
+                saved += [h, h if yy is None else yy, vecs[0], invstd.contiguous(), vecs[1], vecs[2]]      # (no fp32 Y: h keeps its slot)
                 meta.append(("bn" if bn_train else "bn_eval", len(saved) - 6))
                 y = yy
             else:
-                y = _linear_hip(blks, w, b, None, None, None, _ACT_CODE[sp["act"]], m_rows, scratch_out=scr)
+                y = _linear_hip(blks, w, b, None, None, None, _ACT_CODE[sp["act"]], m_rows, scratch_out=scr, presplit=pre)
                 saved += [y]
                 meta.append(("plain", len(saved) - 1))
+            if pre is not None and scr is not None and not scr:
+                scr.append(pre)
             x_scratch.append(scr[0] if scr else None)
         ctx.spec, ctx.meta, ctx.m_rows = spec, meta, m_rows
         ctx.x_scratch = x_scratch
+        ctx.y_dropped = y_dropped
         ctx.n_saved = len(saved)
         ctx.save_for_backward(*saved, *tensors)
         return y
@@ -196,7 +220,18 @@ class _DenseStagesFn(torch.autograd.Function):
             if planes_only:
                 g_scr.append(gh_scratch)
             # weight gradient
-            xin = blocks0 if si == 0 else [saved[meta[si - 1][1] + (1 if meta[si - 1][0] in ("bn", "bn_eval") else 0)]]
+            def xin_rows():
+                if si == 0:
+                    return blocks0
+                poff = meta[si - 1][1]
+                if (si - 1) in ctx.y_dropped:      # (the stage output was written as planes only: the fp32 rows again, from the pre-BN rows)
+                    ph, _, pmean, _, pscale, pshift = saved[poff:poff + 6]
+                    yy = torch.empty_like(ph)
+                    with _abi.device_guard(dev):
+                        _abi.check(L.gsn_bn_act_hip(m_rows, ph.shape[1], ph.data_ptr(), pmean.data_ptr(), pscale.data_ptr(), pshift.data_ptr(),
+                                                    _ACT_CODE[spec[si - 1]["act"]], yy.data_ptr(), _abi.current_stream()), "gsn_bn_act_hip")
+                    return [yy]
+                return [saved[poff + (1 if meta[si - 1][0] in ("bn", "bn_eval") else 0)]]
             if want_w:
                 gw = z32[o32:o32 + n_out * k_total].view(n_out, k_total)
                 o32 += n_out * k_total
@@ -213,6 +248,7 @@ class _DenseStagesFn(torch.autograd.Function):
                         _abi.check(L.gsn_wgrad_f16x3_hip(m_rows, n_out, k_total, g_scr[0].data_ptr(), xs.data_ptr(), gw.data_ptr(), _abi.current_stream()),
                                    "gsn_wgrad_f16x3_hip")
                 else:
+                    xin = xin_rows()
                     arr = (_abi.gsn_block * len(xin))()
                     keep = []
                     gather = spec[0].get("gather") if si == 0 else None

@@ -99,9 +99,10 @@ def _linear_hip(blocks, weight, bias, bn_mean, bn_scale, bn_shift, act, m_rows, 
         planes, col_inv = _f16x3_weights(weight, w)
         scratch = presplit if presplit is not None else torch.empty(int(_abi.lib().gsn_linear_f16x3_scratch_bytes(m_rows, w.shape[1])), dtype=torch.uint8, device=dev)
         with _abi.device_guard(dev), _timed("linear_fwd", 2.0 * m_rows * w.shape[1] * n_out):
-            if presplit is not None:
-                if stats is not None:
-                    raise NotImplementedError("presplit rows with column statistics")
+            if presplit is not None and stats is not None:
+                rc = _abi.lib().gsn_linear_f16x3_fwd_stats_presplit_hip(m_rows, len(blocks), arr, planes.data_ptr(), col_inv.data_ptr(), _abi.ptr(vecs[0]), n_out,
+                                                                        scratch.data_ptr(), y.data_ptr(), stats.data_ptr(), _abi.current_stream())
+            elif presplit is not None:
                 rc = _abi.lib().gsn_linear_f16x3_fwd_presplit_hip(m_rows, len(blocks), arr, planes.data_ptr(), col_inv.data_ptr(), _abi.ptr(vecs[0]), n_out,
                                                                   _abi.ptr(vecs[1]), _abi.ptr(vecs[2]), _abi.ptr(vecs[3]), act, scratch.data_ptr(),
                                                                   y.data_ptr(), _abi.current_stream())

@@ -153,6 +153,42 @@ typedef _Float16 bp_h16x2 __attribute__((ext_vector_type(2)));
 typedef float bp_fl2 __attribute__((ext_vector_type(2)));
 typedef unsigned bp_un4 __attribute__((ext_vector_type(4)));
 
+// a row's values -> its scale, inverse scale and the two fp16 planes (linear_f16.hip's row scratch: l16_scale, l16_split2 and the lane-pair trade
+// of lin16_split_rows_kernel); all 8 lanes of the row call it
+__device__ __forceinline__ void bp_write_row(const float4 (&v)[BP_NCH], unsigned m, int q8, bool even, int64_t row, bool on, float *rowinv,
+                                             unsigned char *planes, int kp, int nchp) {
+    m = max(m, (unsigned)__shfl_xor((int)m, 1));
+    m = max(m, (unsigned)__shfl_xor((int)m, 2));
+    m = max(m, (unsigned)__shfl_xor((int)m, 4));
+    // power-of-two scale that puts the row's largest magnitude into [2^14, 2^15), and its inverse (linear_f16.hip: l16_scale)
+    int e = (int)(m >> 23);
+    e = e < 15 ? 15 : (e > 254 ? 254 : e);
+    const float s = __uint_as_float((unsigned)(268 - e) << 23);
+    float inv = __uint_as_float((unsigned)(e - 14) << 23);
+    if (m >= 0x7f800000u) inv = __uint_as_float(0x7fc00000u);            // Inf / NaN in the row: whatever reads its planes gets NaN
+    if (q8 == 0) rowinv[row] = on ? inv : 0.f;
+    unsigned char *prow = planes + row * (int64_t)kp * 4;
+#pragma unroll
+    for (int i = 0; i < BP_NCH; ++i) {
+        const int c = q8 + 8 * i;
+        if (c < nchp) {                       // (uniform over the lane pairs that trade halves: c and c ^ 1 lie on the same side of nchp, a multiple of 8)
+            auto split2 = [](float x0, float x1, unsigned &hi, unsigned &lo) {
+                const bp_h16x2 hv = __builtin_convertvector(bp_fl2{x0, x1}, bp_h16x2);
+                const bp_fl2 r = bp_fl2{x0, x1} - __builtin_convertvector(hv, bp_fl2);
+                const bp_h16x2 lv = __builtin_convertvector(r, bp_h16x2);
+                hi = __builtin_bit_cast(unsigned, hv);
+                lo = __builtin_bit_cast(unsigned, lv);
+            };
+            unsigned h0, l0, h1, l1;
+            split2(v[i].x * s, v[i].y * s, h0, l0);
+            split2(v[i].z * s, v[i].w * s, h1, l1);
+            const unsigned r0 = (unsigned)__shfl_xor((int)(even ? l0 : h0), 1), r1 = (unsigned)__shfl_xor((int)(even ? l1 : h1), 1);
+            unsigned char *line = prow + (c >> 3) * 128 + (even ? 0 : 64) + ((c & 7) >> 1) * 16;
+            *reinterpret_cast<bp_un4 *>(line) = even ? bp_un4{h0, h1, r0, r1} : bp_un4{r0, r1, l0, l1};
+        }
+    }
+}
+
 struct BwdPlanesArgs {
     int64_t m_rows, m_pad;
     int n_cols, k_pad, act, train;  // train 1: batch statistics, 2: running statistics
@@ -210,36 +246,69 @@ __global__ __launch_bounds__(256) void bn_act_bwd_planes_kernel(BwdPlanesArgs a)
                 m = max(max(m, __float_as_uint(v[i].z) & 0x7fffffffu), __float_as_uint(v[i].w) & 0x7fffffffu);
             }
         }
-        m = max(m, (unsigned)__shfl_xor((int)m, 1));
-        m = max(m, (unsigned)__shfl_xor((int)m, 2));
-        m = max(m, (unsigned)__shfl_xor((int)m, 4));
-        // power-of-two scale that puts the row's largest magnitude into [2^14, 2^15), and its inverse (linear_f16.hip: l16_scale)
-        int e = (int)(m >> 23);
-        e = e < 15 ? 15 : (e > 254 ? 254 : e);
-        const float s = __uint_as_float((unsigned)(268 - e) << 23);
-        float inv = __uint_as_float((unsigned)(e - 14) << 23);
-        if (m >= 0x7f800000u) inv = __uint_as_float(0x7fc00000u);            // Inf / NaN in the row: whatever reads its planes gets NaN
-        if (q8 == 0) a.rowinv[row] = on ? inv : 0.f;
-        unsigned char *prow = a.planes + row * (int64_t)kp * 4;
+        bp_write_row(v, m, q8, even, row, on, a.rowinv, a.planes, kp, nchp);
+    }
+}
+
+// The forward twin: Y = act((H - mean) * scale + shift) (gsn_bn_act_hip's expression) written as the row scratch of Y -- for a BatchNorm stage
+// whose output only feeds the next product on the fp16x3 kernel (and, in the backward pass, the plane weight gradient of that product): no
+// fp32 Y unless `out` is given, no row pre-pass over it.
+struct FwdPlanesArgs {
+    int64_t m_rows, m_pad;
+    int n_cols, k_pad, act;
+    const float *h, *mean, *scale, *shift;
+    float *out;                     // fp32 rows too, or null
+    float *rowinv;
+    unsigned char *planes;
+};
+
+__global__ __launch_bounds__(256) void bn_act_planes_kernel(FwdPlanesArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float bp_tab[];    // [3][k_pad]: mean | scale | shift
+    const int kp = a.k_pad;
+    for (int c = threadIdx.x; c < kp; c += 256) {
+        const bool ok = c < a.n_cols;
+        bp_tab[c] = (ok && a.mean) ? a.mean[c] : 0.f;
+        bp_tab[kp + c] = ok ? (a.scale ? a.scale[c] : 1.f) : 0.f;
+        bp_tab[2 * kp + c] = (ok && a.shift) ? a.shift[c] : 0.f;
+    }
+    __syncthreads();
+    const int q8 = threadIdx.x & 7;
+    const int nch = a.n_cols >> 2, nchp = kp >> 2;
+    const bool even = (q8 & 1) == 0;
+    const int act = a.act;
+    auto fin = [&](float v, float mf, float sc, float sh) {
+        float y = (v - mf) * sc + sh;
+        switch (act) {
+            case 1: y = y > 0.f ? y : 0.f; break;
+            case 2: y = y > 0.f ? y : expm1f(y); break;
+            case 3: y = tanhf(y); break;
+            default: break;
+        }
+        return y;
+    };
+    for (int64_t tile = blockIdx.x; tile < a.m_pad / 32; tile += gridDim.x) {
+        const int64_t row = tile * 32 + (threadIdx.x >> 3);
+        const bool on = row < a.m_rows;
+        const int64_t rr = on ? row : a.m_rows - 1;
+        const float4 *hp = reinterpret_cast<const float4 *>(a.h + rr * a.n_cols);
+        float4 *op = a.out ? reinterpret_cast<float4 *>(a.out + rr * a.n_cols) : nullptr;
+        float4 v[BP_NCH];
+        unsigned m = 0;
 #pragma unroll
         for (int i = 0; i < BP_NCH; ++i) {
             const int c = q8 + 8 * i;
-            if (c < nchp) {                       // (uniform over the lane pairs that trade halves: c and c ^ 1 lie on the same side of nchp, a multiple of 8)
-                auto split2 = [](float x0, float x1, unsigned &hi, unsigned &lo) {
-                    const bp_h16x2 hv = __builtin_convertvector(bp_fl2{x0, x1}, bp_h16x2);
-                    const bp_fl2 r = bp_fl2{x0, x1} - __builtin_convertvector(hv, bp_fl2);
-                    const bp_h16x2 lv = __builtin_convertvector(r, bp_h16x2);
-                    hi = __builtin_bit_cast(unsigned, hv);
-                    lo = __builtin_bit_cast(unsigned, lv);
-                };
-                unsigned h0, l0, h1, l1;
-                split2(v[i].x * s, v[i].y * s, h0, l0);
-                split2(v[i].z * s, v[i].w * s, h1, l1);
-                const unsigned r0 = (unsigned)__shfl_xor((int)(even ? l0 : h0), 1), r1 = (unsigned)__shfl_xor((int)(even ? l1 : h1), 1);
-                unsigned char *line = prow + (c >> 3) * 128 + (even ? 0 : 64) + ((c & 7) >> 1) * 16;
-                *reinterpret_cast<bp_un4 *>(line) = even ? bp_un4{h0, h1, r0, r1} : bp_un4{r0, r1, l0, l1};
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < nch && on) {
+                const float4 hh = hp[c];
+                const float4 mu = *reinterpret_cast<const float4 *>(bp_tab + 4 * c), sc = *reinterpret_cast<const float4 *>(bp_tab + kp + 4 * c);
+                const float4 sh = *reinterpret_cast<const float4 *>(bp_tab + 2 * kp + 4 * c);
+                v[i] = make_float4(fin(hh.x, mu.x, sc.x, sh.x), fin(hh.y, mu.y, sc.y, sh.y), fin(hh.z, mu.z, sc.z, sh.z), fin(hh.w, mu.w, sc.w, sh.w));
+                if (op) op[c] = v[i];
+                m = max(max(m, __float_as_uint(v[i].x) & 0x7fffffffu), __float_as_uint(v[i].y) & 0x7fffffffu);
+                m = max(max(m, __float_as_uint(v[i].z) & 0x7fffffffu), __float_as_uint(v[i].w) & 0x7fffffffu);
             }
         }
+        bp_write_row(v, m, q8, even, row, on, a.rowinv, a.planes, kp, nchp);
     }
 }
 
@@ -743,6 +812,29 @@ extern "C" int gsn_bn_act_bwd_planes_hip(int64_t m_rows, int64_t n_cols, const f
     hipLaunchKernelGGL(bn_act_bwd_planes_kernel, dim3((unsigned)gx), dim3(256), (size_t)6 * a.k_pad * 4, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(GSN_E_HIP, "bn_act_bwd_planes kernels: %s", hipGetErrorString(e));
+    return GSN_OK;
+}
+
+// gsn_bn_act_hip for a stage output that is read as fp16 planes: row_scratch = the row scratch of Y (gsn_linear_f16x3_scratch_bytes(m_rows, n_cols)),
+// out = the fp32 rows as well, or null
+extern "C" int gsn_bn_act_planes_hip(int64_t m_rows, int64_t n_cols, const float *h, const float *mean, const float *scale, const float *shift, int act,
+                                     float *out, float *row_scratch, void *stream) {
+    if (n_cols < 4 || (n_cols & 3) || n_cols > 8 * BP_NCH * 4 || act < 0 || act > 3)
+        return set_error(GSN_E_UNSUPPORTED, "gsn_bn_act_planes_hip: 4 .. %d columns, a multiple of 4", 8 * BP_NCH * 4);
+    if (m_rows > 0 && (!h || !row_scratch)) return set_error(GSN_E_INVALID, "gsn_bn_act_planes_hip: bad arguments");
+    if (m_rows <= 0) return GSN_OK;
+    if ((reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(row_scratch)) & 15)
+        return set_error(GSN_E_INVALID, "gsn_bn_act_planes_hip: h, out and row_scratch must be 16-byte aligned");
+    FwdPlanesArgs a{};
+    a.m_rows = m_rows; a.m_pad = gsn_linear_f16x3_mpad(m_rows); a.n_cols = (int)n_cols; a.k_pad = (int)gsn_linear_f16x3_kpad(n_cols); a.act = act;
+    a.h = h; a.mean = mean; a.scale = scale; a.shift = shift; a.out = out;
+    a.rowinv = row_scratch; a.planes = reinterpret_cast<unsigned char *>(row_scratch + a.m_pad);
+    int64_t gx = a.m_pad / 32;
+    static const int64_t wgs = [] { const char *e = getenv("GSN_FWD_PLANES_WGS"); const int64_t v = e ? atoll(e) : 0; return v > 0 ? v : (int64_t)2048; }();
+    if (gx > wgs) gx = wgs;
+    hipLaunchKernelGGL(bn_act_planes_kernel, dim3((unsigned)gx), dim3(256), (size_t)3 * a.k_pad * 4, reinterpret_cast<hipStream_t>(stream), a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(GSN_E_HIP, "bn_act_planes_kernel: %s", hipGetErrorString(e));
     return GSN_OK;
 }
 

@@ -1011,3 +1011,9 @@ extern "C" int gsn_linear_f16x3_fwd_presplit_hip(int64_t m_rows, int n_blocks, c
                                                  int act, float *row_scratch, float *out, void *stream) {
     return l16_fwd(m_rows, n_blocks, blocks, planes, col_inv, bias, n_out, bn_mean, bn_scale, bn_shift, act, row_scratch, out, nullptr, stream, 1);
 }
+
+extern "C" int gsn_linear_f16x3_fwd_stats_presplit_hip(int64_t m_rows, int n_blocks, const gsn_block *blocks, const void *planes, const float *col_inv,
+                                                       const float *bias, int64_t n_out, float *row_scratch, float *out, double *stats, void *stream) {
+    if (!stats) return set_error(GSN_E_INVALID, "gsn_linear_f16x3_fwd_stats_presplit_hip: stats is null");
+    return l16_fwd(m_rows, n_blocks, blocks, planes, col_inv, bias, n_out, nullptr, nullptr, nullptr, 0, row_scratch, out, stats, stream, 1);
+}

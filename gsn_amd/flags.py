@@ -32,6 +32,9 @@ WGRAD_F16X3 = os.environ.get("GSN_WGRAD_F16X3", "1") != "0"
 # BatchNorm stages whose gH is read as planes only (input gradient on the fp16x3 kernel + the plane weight gradient): the adjoint pass writes the
 # row scratch of gH directly (gsn_bn_act_bwd_planes_hip) -- no fp32 gH, no row pre-pass over it.  0: apply pass + pre-pass
 BN_BWD_PLANES = os.environ.get("GSN_BN_BWD_PLANES", "1") != "0"
+# the forward twin: a BatchNorm stage whose output only feeds the next product on the fp16x3 kernel writes the row scratch of its output
+# (gsn_bn_act_planes_hip): no fp32 stage output, no row pre-pass in front of the next product.  0: gsn_bn_act_hip + pre-pass
+BN_ACT_PLANES = os.environ.get("GSN_BN_ACT_PLANES", "1") != "0"
 # (a stage whose input gradient is not wanted, or not computed on the fp16x3 kernel: the pre-pass over gH by itself, from this many rows on)
 WGRAD_F16X3_SPLIT_ROWS = int(os.environ.get("GSN_WGRAD_F16X3_SPLIT_ROWS", "16384"))
 

@@ -560,6 +560,13 @@ int gsn_linear_f16x3_split_rows_hip(int64_t m_rows, int n_blocks, const gsn_bloc
 int gsn_linear_f16x3_fwd_presplit_hip(int64_t m_rows, int n_blocks, const gsn_block *blocks, const void *planes, const float *col_inv,
                                       const float *bias, int64_t n_out, const float *bn_mean, const float *bn_scale, const float *bn_shift,
                                       int act, float *row_scratch, float *out, void *stream);
+int gsn_linear_f16x3_fwd_stats_presplit_hip(int64_t m_rows, int n_blocks, const gsn_block *blocks, const void *planes, const float *col_inv,
+                                            const float *bias, int64_t n_out, float *row_scratch, float *out, double *stats, void *stream);
+/* gsn_bn_act_hip (out = act((h - mean) * scale + shift), models_misc.py:52-59's BatchNorm + activation on finished statistics) writing the row
+ * scratch of its output -- for a stage output that only feeds the next product on the fp16x3 kernel (gsn_linear_f16x3_fwd_[stats_]presplit_hip) and
+ * that product's plane weight gradient: no row pre-pass; `out` (fp32 rows) may be NULL.  n_cols a multiple of 4, at most 640. */
+int gsn_bn_act_planes_hip(int64_t m_rows, int64_t n_cols, const float *h, const float *mean, const float *scale, const float *shift, int act,
+                          float *out, float *row_scratch, void *stream);
 /* HP-2 adjoint: weight gradient of a dense stage from fp16 planes (r06; torch.nn.Linear's weight.grad under models_misc.py:52-58):
  *     grad_w[n_out][K] += gH^T X
  * g_scratch = the row scratch of gH [m_rows][n_out] (its "K" is n_out), x_scratch = the row scratch of X [m_rows][K], both as

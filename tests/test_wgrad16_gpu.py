@@ -124,23 +124,26 @@ def test_added_to_not_overwritten():
     assert torch.allclose(gw, 2 * once, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("d_out", [300, 302])
 @pytest.mark.parametrize("train", [True, False])
-def test_dense_stages_take_the_plane_kernel_and_match_float64_autograd(train, monkeypatch):
+def test_dense_stages_take_the_plane_kernel_and_match_float64_autograd(train, d_out, monkeypatch):
     """Linear -> BatchNorm -> ReLU -> Linear over 20 000 rows under autograd (models_misc.py:41-59; the d = 300 node stages of
     GSN_edge_sparse_ogb.py:63-129): both weight gradients come from gsn_wgrad_f16x3_hip -- the forward products' row scratches are kept, the
     input-gradient products leave gH's -- and every gradient agrees with a float64 PyTorch evaluation; with the switch off the same stages run
-    on gsn_wgrad_hip."""
+    on gsn_wgrad_hip.  The BatchNorm stage writes its output as planes only (gsn_bn_act_planes_hip) and its adjoint writes gH as planes only
+    (gsn_bn_act_bwd_planes_hip).  d_out = 302: the second stage's gH cannot be split (width not a multiple of 4) -- its weight gradient falls back to
+    gsn_wgrad_hip on fp32 rows that the forward pass did not keep: they are made again from the pre-BN rows."""
     from gsn_amd import _abi, _autograd, flags
     from gsn_amd._dense import _Stage
     torch.manual_seed(3)
     m, d, h = 20000, 300, 600
     x = (torch.randn(m, d, device="cuda") * torch.logspace(-1, 1, m, device="cuda")[:, None]).requires_grad_(True)
-    lin1, bn, lin2 = torch.nn.Linear(d, h).cuda(), torch.nn.BatchNorm1d(h).cuda(), torch.nn.Linear(h, d).cuda()
+    lin1, bn, lin2 = torch.nn.Linear(d, h).cuda(), torch.nn.BatchNorm1d(h).cuda(), torch.nn.Linear(h, d_out).cuda()
     bn.train(train)
     if not train:
         with torch.no_grad():
             bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2.0)
-    wout = torch.randn(m, d, device="cuda")
+    wout = torch.randn(m, d_out, device="cuda")
 
     def run():
         for p in (*lin1.parameters(), *bn.parameters(), *lin2.parameters()):
@@ -155,14 +158,18 @@ def test_dense_stages_take_the_plane_kernel_and_match_float64_autograd(train, mo
     real = _abi.check
     monkeypatch.setattr(_abi, "check", lambda rc, what="": (called.append(what), real(rc, what))[1])
     got = run()
-    assert called.count("gsn_wgrad_f16x3_hip") == 2 and "gsn_wgrad_hip" not in called
+    if d_out == 300:
+        assert called.count("gsn_wgrad_f16x3_hip") == 2 and "gsn_wgrad_hip" not in called
+    else:
+        assert called.count("gsn_wgrad_f16x3_hip") == 1 and called.count("gsn_wgrad_hip") == 1 and called.count("gsn_bn_act_hip") == 1
+    assert called.count("gsn_bn_act_planes_hip") == 1 and called.count("gsn_bn_act_bwd_planes_hip") == 1
     monkeypatch.setattr(flags, "WGRAD_F16X3", False)
     called.clear()
     old = run()
     assert called.count("gsn_wgrad_hip") == 2 and "gsn_wgrad_f16x3_hip" not in called
     # float64 reference
     x64 = x.detach().double().requires_grad_(True)
-    l1, b64, l2 = torch.nn.Linear(d, h).cuda().double(), torch.nn.BatchNorm1d(h).cuda().double(), torch.nn.Linear(h, d).cuda().double()
+    l1, b64, l2 = torch.nn.Linear(d, h).cuda().double(), torch.nn.BatchNorm1d(h).cuda().double(), torch.nn.Linear(h, d_out).cuda().double()
     l1.load_state_dict(lin1.state_dict()); b64.load_state_dict(bn.state_dict()); l2.load_state_dict(lin2.state_dict())
     b64.train(train)
     (l2(torch.relu(b64(l1(x64)))) * wout.double()).sum().backward()
