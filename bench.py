@@ -551,8 +551,10 @@ def train_step_config4(dev):
                            "frac_of_fp16x3_roof_833TF": round(f_alg / t / 1e12 / 833.0, 3),
                            "hbm_GBs": round(b_alg / t / 1e9, 1), "hbm_frac": round(b_alg / t / 1e9 / HBM_PEAK_GBS, 3),
                            "roof_ms": {"hbm": round(b_alg / (HBM_PEAK_GBS * 1e9) * 1e3, 3), "fp16x3": round(f_alg / 833e12 * 1e3, 3)},
-                           "note": "bound: neither single roof -- a sequence of ~470 launches per step, the dense ones on the matrix pipe (weight gradients on six bf16 "
-                                   "plane products, the others on three fp16 ones), the row-wise ones at the HBM copy ceiling (profiles/r05_molhiv_step_kernel_stats.csv)"}
+                           "note": "bound: neither single roof -- a sequence of ~440 launches per step, the dense ones on the matrix pipe (three fp16 plane products "
+                                   "each; since r06 the weight gradients too, on the planes the forward and input-gradient products leave behind: "
+                                   "gsn_wgrad_f16x3_hip), the BatchNorm passes writing those planes instead of fp32 rows (gsn_bn_act_planes_hip, "
+                                   "gsn_bn_act_bwd_planes_hip), the row-wise ones at the HBM copy ceiling (profiles/r06_molhiv_step_kernel_stats.csv)"}
     return out
 
 
