@@ -50,6 +50,7 @@ struct WfArgs {
     const float *g_inv, *x_inv;    // inverse row scales (powers of two; NaN for a row with a non-finite value)
     const unsigned char *g_planes, *x_planes;
     float *gw;
+    unsigned long long *prof;      // diagnostic build (dbg & 16): cycles of workgroup 0, wave 0: prologue | loop | barrier waits | epilogue | steps
     int dbg;                       // diagnostic build: 1 no atomics, 2 no products, 4 no loads behind the first two steps, 8 no staging
 };
 
@@ -136,6 +137,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WF_WAVES, W
     const unsigned g_odd = lofs + (lh ? g_pitch : 0u), x_odd = lofs + (lh ? x_pitch : 0u);      // (lanes 32..63: the odd row of a pair)
     const unsigned char *gbase = a.g_planes + (int64_t)gs * 128, *xbase = a.x_planes + (int64_t)xs * 128;
     const int dbg = DBG ? a.dbg : 0;
+    const bool prof = DBG && (dbg & 16);
+    unsigned long long q_start = prof ? clock64() : 0, q_bar = 0, q_loop0 = 0, q_loop1 = 0, q_ph[5] = {0, 0, 0, 0, 0};
 
     // (no bound checks: a row scratch holds at least 128 rows of zero planes behind its last row, and the scale table zeroes rows past the slab)
     const int64_t g2 = 2 * (int64_t)g_pitch, x2 = 2 * (int64_t)x_pitch;
@@ -189,7 +192,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WF_WAVES, W
     // (staged in the step before) receives the rows row0 + 48 -- three register sets, two steps of memory latency covered
     auto step = [&](int buf, int64_t row0, const unsigned (&npg)[8], const unsigned (&npx)[8], unsigned (&fpg)[8], unsigned (&fpx)[8]) {
         // (the far rows are requested FIRST: the wait in front of the staging below then leaves them in flight)
+        const unsigned long long p0 = prof ? clock64() : 0;
         if (!(dbg & 4)) fetch(fpg, fpx, row0 + 48);
+        const unsigned long long p1 = prof ? clock64() : 0;
+        if (prof) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");          // (the rows about to be staged)
+        const unsigned long long p2 = prof ? clock64() : 0;
         wf_un4 fa[2][2], fb[2][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -198,8 +205,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WF_WAVES, W
                 fa[i][p] = frag(ta, buf, p, lh, wm * 64 + i * 32 + li);
                 fb[i][p] = frag(tb, buf, p, lh, wn * 64 + i * 32 + li);
             }
+        if (prof) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned long long p3 = prof ? clock64() : 0;
         if (!(dbg & 8)) stage(buf ^ 1, npg, npx, row0 + 16);      // (past the slab: zero scales, a buffer nobody reads -- no branch, so that the
                                                                   //  compiler's vmcnt bookkeeping stays exact: two sets of loads stay in flight)
+        if (prof) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned long long p4 = prof ? clock64() : 0;
         if (!(dbg & 2))
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
@@ -209,24 +220,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WF_WAVES, W
             WF_MF(fa[1][pa_], fb[0][pb_], acc[1][0]);
             WF_MF(fa[1][pa_], fb[1][pb_], acc[1][1]);
         }
+        if (!prof) {
 #pragma unroll
-        for (int t = 0; t < 12; ++t) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              // MFMA
-            __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_MFMA, 0);  // VALU
+            for (int t = 0; t < 12; ++t) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_MFMA, 0);  // VALU
+            }
         }
+        if (prof) { const unsigned long long p5 = clock64(); q_ph[0] += p1 - p0; q_ph[1] += p2 - p1; q_ph[2] += p3 - p2; q_ph[3] += p4 - p3; q_ph[4] += p5 - p4; }
+        const unsigned long long qb0 = prof ? clock64() : 0;
         __syncthreads();
+        if (prof) q_bar += clock64() - qb0;
     };
     {
         // three steps per trip and no exit inside a trip: one basic block, so that the compiler's vmcnt bookkeeping is exact and two sets of loads
         // stay in flight across the back edge (rows past the slab: zero scales; past the operand: the scratch's zero rows)
         int64_t row0 = r_begin;
         int buf = 0;
+        if (prof) q_loop0 = clock64();
         for (int it = n_rows16 / 48; it > 0; --it, row0 += 48) {
             step(buf, row0, pg1, px1, pg0, px0);
             step(buf ^ 1, row0 + 16, pg2, px2, pg1, px1);
             step(buf, row0 + 32, pg0, px0, pg2, px2);
             buf ^= 1;                             // (an odd number of steps per trip: the buffers swap roles from trip to trip)
         }
+        if (prof) q_loop1 = clock64();
     }
 #undef WF_MF
     // 2^(emax - 254) in two exact factors (either may leave the normal range alone, not both)
@@ -244,6 +262,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WF_WAVES, W
                 if (nrow < a.n_out && kcol < a.k_total && !(dbg & 1)) atomicAdd(a.gw + (int64_t)nrow * a.k_total + kcol, acc[i][j][r] * f1 * f2);
             }
         }
+    if (prof && blockIdx.x == 0 && threadIdx.x == 0 && a.prof) {
+        a.prof[0] = q_loop0 - q_start; a.prof[1] = q_loop1 - q_loop0; a.prof[2] = q_bar; a.prof[3] = clock64() - q_loop1; a.prof[4] = (unsigned long long)(n_rows16 / 16);
+        for (int i = 0; i < 5; ++i) a.prof[5 + i] = q_ph[i];
+    }
 }
 
 }  // namespace
@@ -290,7 +312,22 @@ extern "C" int gsn_wgrad_f16x3_hip(int64_t m_rows, int64_t n_out, int64_t k_tota
     static const int valu = [] { const char *e = getenv("GSN_WGRAD16_VALU"); const int v = e ? atoi(e) : 3; return v; }();
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     a.dbg = getenv("GSN_WGRAD16_DBG") ? atoi(getenv("GSN_WGRAD16_DBG")) : 0;
-    if (a.dbg) hipLaunchKernelGGL((wgrad_f16x3_kernel<3, true>), grid, dim3(256), lds, st, a);
+    a.prof = nullptr;
+    if ((a.dbg & 16) && hipMalloc(reinterpret_cast<void **>(&a.prof), 128) != hipSuccess) a.prof = nullptr;
+    if (a.dbg) {
+        hipLaunchKernelGGL((wgrad_f16x3_kernel<3, true>), grid, dim3(256), lds, st, a);
+        if (a.prof) {
+            unsigned long long h[16];
+            (void)hipStreamSynchronize(st);
+            (void)hipMemcpy(h, a.prof, 128, hipMemcpyDeviceToHost);
+            (void)hipFree(a.prof);
+            fprintf(stderr, "wgrad16prof: workgroup 0 wave 0: prologue %llu | loop %llu (%llu steps: %.0f per step, of it waiting at the barrier %.0f) | epilogue %llu cycles (100 MHz clock)\n",
+                    h[0], h[1], h[4], (double)h[1] / (double)(h[4] ? h[4] : 1), (double)h[2] / (double)(h[4] ? h[4] : 1), h[3]);
+            const double n = (double)(h[4] ? h[4] : 1);
+            fprintf(stderr, "wgrad16prof: per step: issue of the far loads %.0f | wait for the rows to stage %.0f | fragment reads %.0f | staging %.0f | products (issue) %.0f\n",
+                    h[5] / n, h[6] / n, h[7] / n, h[8] / n, h[9] / n);
+        }
+    }
     else if (valu == 2) hipLaunchKernelGGL((wgrad_f16x3_kernel<2, false>), grid, dim3(256), lds, st, a);
     else if (valu == 4) hipLaunchKernelGGL((wgrad_f16x3_kernel<4, false>), grid, dim3(256), lds, st, a);
     else hipLaunchKernelGGL((wgrad_f16x3_kernel<3, false>), grid, dim3(256), lds, st, a);
