@@ -199,7 +199,13 @@ struct BwdPlanesArgs {
     double *gbias;
 };
 
-__global__ __launch_bounds__(256) void bn_act_bwd_planes_kernel(BwdPlanesArgs a) {
+#ifndef BP_WAVES
+#define BP_WAVES 2                 // waves per SIMD the adjoint plane kernel's register allocation aims at (3: spills, 300 -> 388 us at 105 k x 600)
+#endif
+#ifndef BP_WAVES_FWD
+#define BP_WAVES_FWD 3             // ... and the forward one's (2: 152 us, 3: 128 us, 4: 147 us at 105 k x 600)
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BP_WAVES, BP_WAVES))) void bn_act_bwd_planes_kernel(BwdPlanesArgs a) {
     extern __shared__ __attribute__((aligned(16))) float bp_tab[];    // [6][k_pad]: mean | invstd | coef | shift | m1 | m2
     const int kp = a.k_pad;
     for (int c = threadIdx.x; c < kp; c += 256) {
@@ -262,7 +268,7 @@ struct FwdPlanesArgs {
     unsigned char *planes;
 };
 
-__global__ __launch_bounds__(256) void bn_act_planes_kernel(FwdPlanesArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BP_WAVES_FWD, BP_WAVES_FWD))) void bn_act_planes_kernel(FwdPlanesArgs a) {
     extern __shared__ __attribute__((aligned(16))) float bp_tab[];    // [3][k_pad]: mean | scale | shift
     const int kp = a.k_pad;
     for (int c = threadIdx.x; c < kp; c += 256) {
