@@ -268,6 +268,179 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WF_WAVES, W
     }
 }
 
+// ---- the same product without staging registers (second kernel of r06) --------------------------------------------------------------------
+// global_load_lds_dwordx4 moves whole lines straight into LDS and ds_read_b64_tr_b16 reads the operand fragments TRANSPOSED out of that image:
+// no byte permutes, no ds_write pass, no registers holding rows in flight (the kernel above keeps three sets of 16).
+//   * one DMA instruction = 8 rows x one K slice x both planes = 8 whole 128-byte lines -> 1 KiB of LDS, lane q's 16 bytes at position q: eight
+//     neighbouring lanes fetch one line (the address unit sees whole lines), rows at a pitch of 128 bytes.  Rows 2, 3, 6, 7 of an image swap
+//     their high and low halves (the lane fetches piece p ^ 4): without it the four rows of a transposing read fall on two sets of banks.
+//   * ds_read_b64_tr_b16 (scripts/micro/tr_probe.hip): in a group of 16 lanes, lane i points at 4 contiguous halfs = row i >> 2, columns
+//     4 (i & 3) .. + 3 of a [4][16] block (any row pitch) and lane c receives column c of it.  MFMA lane l wants column l & 31, rows
+//     8 (l >> 5) .. + 7: two reads (rows 0-3, 4-7 of the lane's 8-row image), lanes 0-15 / 16-31 on the two column blocks, lanes 32-63 on the
+//     slice's second image.  The 32 lanes served together touch 4 rows x 64 bytes on 64 different banks.
+//   * the row factors are applied to the FRAGMENTS (rows run along the fragment: the four packed factors are the same for every lane of a half wave).
+// Three LDS buffers of 16 KiB: the lines of steps s + 1 and s + 2 are in flight while step s is multiplied; one counted wait + barrier per step.
+typedef __fp16 wf_fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef __attribute__((address_space(3))) wf_fp16x4 *wf_lds4_t;
+typedef unsigned wf_un2 __attribute__((ext_vector_type(2)));
+
+template <bool DBG>
+__global__ __launch_bounds__(256) void wgrad_f16x3_dma_kernel(WfArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char wf_smem[];
+    constexpr int WD_OP = 8192, WD_BUF = 2 * WD_OP, WD_TAB = 3 * WD_BUF;     // operand image of a step, buffer (gH | X), tables behind the three buffers
+    unsigned short *ctab = reinterpret_cast<unsigned short *>(wf_smem + WD_TAB + 16);
+    int &s_emax = *reinterpret_cast<int *>(wf_smem + WD_TAB);
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 1, wn = w & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int ntile = a.tn * a.tk;
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int tile = seq % ntile;
+    const int64_t slab = (int64_t)(seq / ntile) * 8 + xcd;
+    const int n0 = (tile / a.tk) * WF_T, k0 = (tile % a.tk) * WF_T;
+    const int64_t r_begin = slab * a.rows_per_wg;
+    int64_t r_end = r_begin + a.rows_per_wg;
+    if (r_end > a.m_rows) r_end = a.m_rows;
+    if (r_begin >= r_end) return;                 // (block-uniform)
+    const int n_rows = (int)(r_end - r_begin);
+    const int n_rows16 = (n_rows + WF_RB - 1) / WF_RB * WF_RB;
+    unsigned short *xtab = ctab + n_rows16 + 16, *raw = reinterpret_cast<unsigned short *>(wf_smem);      // (raw exponents: in the buffers, before any line lands)
+
+    // ---- the slab's scale tables (as above, rows in natural order) ----------------------------------------------------------------------
+    if (tid == 0) s_emax = 0;
+    __syncthreads();
+    {
+        int mymax = 0;
+        for (int r = tid; r < n_rows16; r += 256) {
+            int e = 0;
+            if (r < n_rows) {
+                const unsigned fg = (__float_as_uint(a.g_inv[r_begin + r]) >> 23) & 255u, fx = (__float_as_uint(a.x_inv[r_begin + r]) >> 23) & 255u;
+                if (fg == 255u || fx == 255u) e = 0x7fff;
+                else if (fg != 0u && fx != 0u) { e = (int)(fg + fx); mymax = max(mymax, e); }
+            }
+            raw[r] = (unsigned short)e;
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) mymax = max(mymax, __shfl_xor(mymax, o));
+        if (lane == 0 && mymax > 0) atomicMax(&s_emax, mymax);
+    }
+    __syncthreads();
+    const int emax = s_emax;
+    if (tid < 16) { ctab[n_rows16 + tid] = 0; xtab[n_rows16 + tid] = 0; }
+    auto pow2h = [](int d) -> unsigned short { return d <= 14 ? (unsigned short)((15 - d) << 10) : (d <= 24 ? (unsigned short)(1u << (24 - d)) : (unsigned short)0); };
+    for (int r = tid; r < n_rows16; r += 256) {
+        const int e = raw[r];
+        unsigned short cg = 0, cx = 0;
+        if (e == 0x7fff) { cg = 0x7e00; cx = 0x3c00; }
+        else if (e != 0) {
+            const int d = emax - e, dg = d >> 1;
+            cg = pow2h(dg); cx = pow2h(d - dg);
+        }
+        ctab[r] = cg;
+        xtab[r] = cx;
+    }
+
+    // ---- lanes -> source pieces (DMA) and -> fragment addresses (transposing reads) ---------------------------------------------------------
+    const int gs = min(n0 / 32 + w, a.g_slices - 1), xs = min(k0 / 32 + w, a.x_slices - 1);
+    const unsigned g_pitch = (unsigned)a.g_slices * 128u, x_pitch = (unsigned)a.x_slices * 128u;
+    unsigned g_src, x_src;                        // byte offset of this lane's piece from the first row of an 8-row image
+    {
+        const int row = lane >> 3, piece = (lane & 7) ^ (((row >> 1) & 1) << 2);
+        g_src = (unsigned)row * g_pitch + (unsigned)piece * 16u;
+        x_src = (unsigned)row * x_pitch + (unsigned)piece * 16u;
+    }
+    const unsigned char *gbase = a.g_planes + (int64_t)gs * 128, *xbase = a.x_planes + (int64_t)xs * 128;
+    typedef const __attribute__((address_space(1))) void *gptr_t;
+    typedef __attribute__((address_space(3))) void *lptr_t;
+    const int dbg = DBG ? a.dbg : 0;
+    auto fetch = [&](int buf, int64_t row0) {     // this wave's slice of both operands: 2 x 2 images of 8 rows
+        unsigned char *const dg = wf_smem + buf * WD_BUF + w * 2048, *const dx = dg + WD_OP;
+        const unsigned char *gr = gbase + row0 * g_pitch, *xr = xbase + row0 * x_pitch;
+        __builtin_amdgcn_global_load_lds((gptr_t)(gr + g_src), (lptr_t)dg, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(gr + 8 * (int64_t)g_pitch + g_src), (lptr_t)(dg + 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(xr + x_src), (lptr_t)dx, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(xr + 8 * (int64_t)x_pitch + x_src), (lptr_t)(dx + 1024), 16, 0, 0);
+    };
+    // fragment of 32 columns (K slice sl of the tile) x this lane's 8 rows: image lh of the slice; the lane points at row (lane & 15) >> 2 of the
+    // read's four rows, column quad lane & 3 of column block (lane >> 4) & 1, plane p: piece 4 p + 2 cb + (quad >> 1), swapped halves on rows 2, 3
+    const int t_row = (lane & 15) >> 2, t_cb = (lane >> 4) & 1, t_q = lane & 3;
+    unsigned fr[2][2];                            // [plane][read] byte offset inside the slice's 2 KiB
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int r = 4 * g + t_row, piece = (4 * p + 2 * t_cb + (t_q >> 1)) ^ (((r >> 1) & 1) << 2);
+            fr[p][g] = (unsigned)(lh * 1024 + r * 128 + piece * 16 + (t_q & 1) * 8);
+        }
+    auto frag = [&](const unsigned char *op, int sl, int p, wf_un4 c) -> wf_un4 {
+        const unsigned char *q = op + sl * 2048;
+        const wf_fp16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((wf_lds4_t)(q + fr[p][0]));
+        const wf_fp16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((wf_lds4_t)(q + fr[p][1]));
+        const wf_un2 u0 = __builtin_bit_cast(wf_un2, v0), u1 = __builtin_bit_cast(wf_un2, v1);
+        auto pk_mul = [](unsigned v, unsigned k) { return __builtin_bit_cast(unsigned, __builtin_bit_cast(wf_h16x2, v) * __builtin_bit_cast(wf_h16x2, k)); };
+        return wf_un4{pk_mul(u0.x, c.x), pk_mul(u0.y, c.y), pk_mul(u1.x, c.z), pk_mul(u1.y, c.w)};
+    };
+
+    wf_f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    __syncthreads();                              // (the raw exponents lived in the buffers)
+    fetch(0, r_begin);
+    fetch(1, r_begin + 16);
+    int buf = 0;
+#define WF_MF(x, y, c) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wf_h16x8, x), __builtin_bit_cast(wf_h16x8, y), c, 0, 0, 0)
+    for (int64_t row0 = r_begin; row0 < r_end; row0 += 16) {
+        // the lines of this step have landed (this wave's share -- all but the newest four requests; the barrier makes it everybody's) and nobody
+        // reads the buffer of the step before any more: it takes the lines of the step after the next
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __syncthreads();
+        const int far = buf >= 1 ? buf - 1 : 2;   // (buf + 2) % 3
+        if (!(dbg & 4)) fetch(far, row0 + 32);    // (past the slab: rows nobody multiplies; past the operand: the scratch's zero rows)
+        const unsigned char *og = wf_smem + buf * WD_BUF, *ox = og + WD_OP;
+        const wf_un4 cs = *reinterpret_cast<const wf_un4 *>(ctab + (row0 - r_begin) + lh * 8);
+        const wf_un4 ds = *reinterpret_cast<const wf_un4 *>(xtab + (row0 - r_begin) + lh * 8);
+        wf_un4 fa[2][2], fb[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                fa[i][p] = frag(og, wm * 2 + i, p, cs);
+                fb[i][p] = frag(ox, wn * 2 + i, p, ds);
+            }
+        if (!(dbg & 2))
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int pa_ = t == 2 ? 0 : (t == 0 ? 1 : 0), pb_ = t == 2 ? 0 : (t == 0 ? 0 : 1);      // lh, hl, hh
+            WF_MF(fa[0][pa_], fb[0][pb_], acc[0][0]);
+            WF_MF(fa[0][pa_], fb[1][pb_], acc[0][1]);
+            WF_MF(fa[1][pa_], fb[0][pb_], acc[1][0]);
+            WF_MF(fa[1][pa_], fb[1][pb_], acc[1][1]);
+        }
+        buf = buf == 2 ? 0 : buf + 1;
+    }
+#undef WF_MF
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the last requests: its lines land in an LDS that is about to be released)
+    const int ex = emax - 254;
+    const int e1 = ex < -126 ? -126 : (ex > 127 ? 127 : ex), e2r = ex - e1, e2 = e2r < -126 ? -126 : (e2r > 127 ? 127 : e2r);
+    const float f1 = __uint_as_float((unsigned)(e1 + 127) << 23), f2 = __uint_as_float((unsigned)(e2 + 127) << 23);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int kcol = k0 + wn * 64 + j * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int nrow = n0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (nrow < a.n_out && kcol < a.k_total && !(dbg & 1)) atomicAdd(a.gw + (int64_t)nrow * a.k_total + kcol, acc[i][j][r] * f1 * f2);
+            }
+        }
+}
+
 }  // namespace
 
 }  // namespace gsn
@@ -311,6 +484,22 @@ extern "C" int gsn_wgrad_f16x3_hip(int64_t m_rows, int64_t n_out, int64_t k_tota
     const size_t lds = (size_t)4 * 4 * 2 * (64 * 16 + 128) + 16 + (size_t)(rows_per + 16) * 6;      // fragments | emax | the two scale tables, raw exponents
     static const int valu = [] { const char *e = getenv("GSN_WGRAD16_VALU"); const int v = e ? atoi(e) : 3; return v; }();
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    a.dbg = getenv("GSN_WGRAD16_DBG") ? atoi(getenv("GSN_WGRAD16_DBG")) : 0;
+    // GSN_WGRAD16_DMA=1: the LDS-DMA + transposing-read kernel (read per call: tests switch it).  Measured on one box at 105 083 x 300 x 600:
+    // 240-248 us against 218-227 us for the register-staged kernel -- fewer vector and LDS instructions (SQ_INSTS_VALU 4.5e7 -> 2.9e7,
+    // SQ_LDS_IDX_ACTIVE 2.7e7 -> 1.6e7), three workgroups per CU instead of two, the matrix pipe mostly hidden (no products: -35 us), but 74 us of
+    // waiting for lines that the staged kernel hides behind its own vector work; both move the same 1.5 GB from L2 to the CUs, which bounds
+    // either at ~150 us.  Not the default.
+    const char *dma_env = getenv("GSN_WGRAD16_DMA");
+    const bool dma = dma_env && dma_env[0] == '1';
+    if (dma) {
+        const size_t lds_dma = (size_t)3 * 16384 + 16 + (size_t)(rows_per + 16) * 4;      // three buffers | emax | the two scale tables
+        if (a.dbg) hipLaunchKernelGGL((wgrad_f16x3_dma_kernel<true>), grid, dim3(256), lds_dma, st, a);
+        else hipLaunchKernelGGL((wgrad_f16x3_dma_kernel<false>), grid, dim3(256), lds_dma, st, a);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return set_error(GSN_E_HIP, "wgrad_f16x3_dma_kernel: %s", hipGetErrorString(e));
+        return GSN_OK;
+    }
     a.dbg = getenv("GSN_WGRAD16_DBG") ? atoi(getenv("GSN_WGRAD16_DBG")) : 0;
     a.prof = nullptr;
     if ((a.dbg & 16) && hipMalloc(reinterpret_cast<void **>(&a.prof), 128) != hipSuccess) a.prof = nullptr;

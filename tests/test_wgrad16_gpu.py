@@ -77,6 +77,21 @@ def test_values_far_below_their_rows_largest_keep_an_absolute_precision():
     assert ((gw.double() - ref).abs() <= bound).all(), ((gw.double() - ref).abs() / bound).max().item()
 
 
+@pytest.mark.parametrize("m_rows,n_out,k", [(5000, 600, 300), (777, 72, 164), (105083, 300, 600), (17, 12, 8)])
+def test_the_lds_dma_kernel_gives_the_same_gradient(m_rows, n_out, k, monkeypatch):
+    """GSN_WGRAD16_DMA=1: whole lines straight into LDS (global_load_lds_dwordx4), operand fragments by transposing reads (ds_read_b64_tr_b16) --
+    measured slower than the register-staged kernel and not the default; same planes, same products: the same tile up to the order of the atomic adds."""
+    torch.manual_seed(m_rows)
+    gh = torch.randn(m_rows, n_out, device="cuda") * torch.logspace(-3, 3, m_rows, device="cuda")[:, None] * 1e-5
+    x = torch.randn(m_rows, k, device="cuda") * torch.logspace(-2, 2, m_rows, device="cuda").flip(0)[:, None]
+    staged = _wgrad16(gh, x)
+    monkeypatch.setenv("GSN_WGRAD16_DMA", "1")
+    dma = _wgrad16(gh, x)
+    err, ref, bound = _errs(dma, gh, x)
+    assert err <= 1e-6, err
+    assert torch.allclose(dma, staged, rtol=1e-5, atol=1e-6 * float(ref.abs().max()))
+
+
 def test_rows_far_below_the_slab_maximum_and_zero_rows():
     """The reconciliation of the row scales: rows 2^-30 below the largest row of their slab vanish (their terms are below 2^-30 of the sum), zero
     rows of either operand add nothing, a slab of zero rows adds nothing; error against the sum of magnitudes as above."""
