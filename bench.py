@@ -624,8 +624,49 @@ def linear_d300(dev):
     ms = e0.elapsed_time(e1) / 10
     tf = 2.0 * M * K * Nn / ms / 1e9
     b_alg = 4.0 * (M * K + M * Nn + Nn * K)
-    return {"shape": [M, K, Nn], "ms": round(ms, 4), "fp32_equivalent_TFLOPs": round(tf, 1), "frac_of_fp16x3_roof_833TF": round(tf / (MFMA_BF16_PEAK_TF / 3.0), 4),
-            "algorithmic_bytes": round(b_alg), "hbm_frac": round(b_alg / (ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4)}
+    out = {"shape": [M, K, Nn], "ms": round(ms, 4), "fp32_equivalent_TFLOPs": round(tf, 1), "frac_of_fp16x3_roof_833TF": round(tf / (MFMA_BF16_PEAK_TF / 3.0), 4),
+           "algorithmic_bytes": round(b_alg), "hbm_frac": round(b_alg / (ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4)}
+    # r06: what a TRAINING step runs at this shape -- the product over rows split earlier (the BatchNorm pass in front of it wrote the planes:
+    # gsn_bn_act_planes_hip) and the weight gradient on the planes of X and gH (gsn_wgrad_f16x3_hip), beside the r05 weight gradient (gsn_wgrad_hip)
+    try:
+        from gsn_amd import _abi
+        from gsn_amd._dense import _f16x3_weights
+        L = _abi.lib()
+        planes, col_inv = _f16x3_weights(W, W)
+        y = torch.empty(M, Nn, device=dev)
+        gh = torch.randn(M, Nn, device=dev) * 1e-4
+        one = (_abi.gsn_block * 1)()
+
+        def split(t):
+            sc = torch.empty(int(L.gsn_linear_f16x3_scratch_bytes(t.shape[0], t.shape[1])), dtype=torch.uint8, device=dev)
+            one[0].data = t.data_ptr(); one[0].idx = None; one[0].idx32 = None; one[0].width = t.shape[1]
+            _abi.check(L.gsn_linear_f16x3_split_rows_hip(t.shape[0], 1, one, sc.data_ptr(), _abi.current_stream()), "gsn_linear_f16x3_split_rows_hip")
+            return sc
+        sx, sg = split(x), split(gh)
+        gw = torch.zeros(Nn, K, device=dev)
+        one[0].data = x.data_ptr(); one[0].width = K
+
+        def timed(fn):
+            spin_up(fn)
+            e0.record()
+            for _ in range(10):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / 10
+        ms_pre = timed(lambda: _abi.check(L.gsn_linear_f16x3_fwd_presplit_hip(M, 1, one, planes.data_ptr(), col_inv.data_ptr(), bb.data_ptr(), Nn, None, None, None, 1,
+                                                                                sx.data_ptr(), y.data_ptr(), _abi.current_stream()), "presplit"))
+        ms_w16 = timed(lambda: _abi.check(L.gsn_wgrad_f16x3_hip(M, Nn, K, sg.data_ptr(), sx.data_ptr(), gw.data_ptr(), _abi.current_stream()), "wgrad16"))
+        ms_w = timed(lambda: _abi.check(L.gsn_wgrad_hip(M, Nn, gh.data_ptr(), 1, one, gw.data_ptr(), _abi.current_stream()), "wgrad"))
+        gf = 2.0 * M * K * Nn / 1e9
+        out["rows_split_earlier"] = {"ms": round(ms_pre, 4), "fp32_equivalent_TFLOPs": round(gf / ms_pre, 1), "frac_of_fp16x3_roof_833TF": round(gf / ms_pre / (MFMA_BF16_PEAK_TF / 3.0), 4),
+                                     "note": "gsn_linear_f16x3_fwd_presplit_hip: the product alone, rows split by the producer of the rows (r06 training path)"}
+        out["weight_gradient_same_shape"] = {"planes_ms": round(ms_w16, 4), "planes_fp32_equivalent_TFLOPs": round(gf / ms_w16, 1),
+                                             "bf16x6_ms": round(ms_w, 4), "bf16x6_fp32_equivalent_TFLOPs": round(gf / ms_w, 1),
+                                             "note": "gsn_wgrad_f16x3_hip on the two row scratches vs gsn_wgrad_hip on fp32 rows (profiles/r06_wgrad16_phase.txt)"}
+    except Exception as ex:  # noqa: BLE001
+        out["rows_split_earlier"] = {"error": str(ex)[:200]}
+    return out
 
 
 def main():
