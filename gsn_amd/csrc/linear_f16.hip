@@ -555,15 +555,19 @@ __global__ __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(2, 2))
 // no wait between a load and its LDS write.  Bank conflicts of the fragment reads are avoided by a swizzle instead of a pad: the
 // 16-byte piece p of row r sits at slot p ^ ((r >> 1) & 7) -- applied on the SOURCE side (lane -> which piece it fetches) and on
 // the fragment reads.  Two slice buffers; slice c + 1 is in flight while slice c is multiplied; one barrier per slice.
-constexpr int D_BM = 128, D_BN = 128, D_NT = 256;
-constexpr int D_BUF = (D_BM + D_BN) * L_LINE;          // bytes per slice buffer
+constexpr int D_BM = 128, D_NT = 256;
+// NJ: 32-column blocks per wave (the tile is 128 rows x 64 NJ columns, waves 2 x 2).  NJ = 2: 128 x 128, two workgroups per CU.  NJ = 5 (r06):
+// 128 x 320 for the d = 300 ogb stages -- n_out = 300 is ONE column tile instead of three (384 columns of matrix work -> 320, the rows' planes
+// read once instead of three times), n_out = 600 two instead of five; 160 accumulator registers per wave and 112 KiB of slice buffers: one
+// workgroup per CU, which LDS-DMA staging (no vector work between a load and its use) leaves able to keep the matrix pipe busy.
 // STATS (a train-mode BatchNorm stage, models_misc.py:52-58 with bn in train mode): the rows written are the pre-BN rows h = x W^T + b, and
 // their column sums / sums of squares go to a.stats from the SAME values on their way out, in fp64 registers across the workgroup's tiles (as
 // linear_fwd_bf16_kernel<STATS> does), one atomic pair per column and workgroup at the end.  Rows past m_rows (inverse scale 0: they would count as `bias`) are masked.
-template <bool PROF, bool VEC, bool STATS = false>
-__global__ __launch_bounds__(D_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void linear_f16x3_dma_kernel(L16Args a) {
-    constexpr int NJ = 2;
-    double st_sum[NJ] = {0.0, 0.0}, st_sq[NJ] = {0.0, 0.0};
+template <int NJ, bool PROF, bool VEC, bool STATS = false>
+__global__ __launch_bounds__(D_NT) __attribute__((amdgpu_waves_per_eu(NJ > 2 ? 1 : 2, NJ > 2 ? 1 : 2))) void linear_f16x3_dma_kernel(L16Args a) {
+    constexpr int D_BN = 64 * NJ, D_BUF = (D_BM + D_BN) * L_LINE;          // columns per tile, bytes per slice buffer
+    constexpr int NWI = 2 * NJ;                                              // DMA instructions per wave and slice for the weights' lines (8 rows each)
+    double st_sum[NJ] = {}, st_sq[NJ] = {};
     const int dbg = PROF ? a.dbg : 0;
     extern __shared__ __attribute__((aligned(16))) unsigned l16_lds[];
     unsigned char *const lds = reinterpret_cast<unsigned char *>(l16_lds);
@@ -610,13 +614,13 @@ __global__ __launch_bounds__(D_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
         const int col = n0 + w * 32 * NJ + 32 * j + l;
         vtab[2 * NJ * 64 + q] = col < a.n_out ? col * 4 : 0x7f000000;
     }
-    // staging: wave w moves rows (output columns) 32 w + 8 i .. + 7 with instruction i; lane -> row 8 i + (lane >> 3), slot lane & 7,
+    // staging: wave w moves rows (output columns) 16 NJ w + 8 i .. + 7 with instruction i; lane -> row 8 i + (lane >> 3), slot lane & 7,
     // i.e. piece (lane & 7) ^ swizzle(row)
     const int s_r8 = lane >> 3, s_q = lane & 7;
-    unsigned wofs[4];
+    unsigned wofs[NWI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = 32 * wave + 8 * i + s_r8;
+    for (int i = 0; i < NWI; ++i) {
+        const int r = 8 * NWI * wave + 8 * i + s_r8;
         int j = n0 + r;
         j = j < a.n_out ? j : 0;
         wofs[i] = (unsigned)j * (unsigned)row_bytes + 16u * (unsigned)(s_q ^ ((r >> 1) & 7));
@@ -640,9 +644,9 @@ __global__ __launch_bounds__(D_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
             __builtin_amdgcn_global_load_lds((gptr_t)(abase + aofs[i] + c * L_LINE), (lptr_t)(da + 8 * i * L_LINE), 16, 0, 0);
     };
     auto fetch_weights = [&](int c, int buf) {
-        unsigned char *const dw = lds + buf * D_BUF + (D_BM + 32 * wave) * L_LINE;
+        unsigned char *const dw = lds + buf * D_BUF + (D_BM + 8 * NWI * wave) * L_LINE;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NWI; ++i)
             __builtin_amdgcn_global_load_lds((gptr_t)(a.wplanes + wofs[i] + c * L_LINE), (lptr_t)(dw + 8 * i * L_LINE), 16, 0, 0);
     };
     auto fetch = [&](const unsigned char *abase, const unsigned *aofs, int c, int buf) { fetch_rows(abase, aofs, c, buf); fetch_weights(c, buf); };
@@ -710,7 +714,10 @@ __global__ __launch_bounds__(D_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
                 // (first slice of a later tile: the 16 output stores of the previous tile and the row-scale load below were issued
                 //  AFTER this slice's loads -- memory operations complete in order, so "all but the newest 17" covers the slice
                 //  without waiting for the stores)
-                if (VEC && !PROF && c == 0 && ti > 0) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+                if (VEC && !PROF && c == 0 && ti > 0) {
+                    if (NJ == 2) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");         // (8 NJ stores + the row-scale load)
+                    else asm volatile("s_waitcnt vmcnt(41)" ::: "memory");
+                }
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 l16_barrier();
                 // (the next tile's row scales go to LDS here, where nothing is in flight: consumed at the end of the tile, the
@@ -916,12 +923,22 @@ static int l16_fwd(int64_t m_rows, int n_blocks, const gsn_block *blocks, const 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (!rows_are_split) l16_split_launch(a, st);
     // 128 x 128 tiles, two workgroups of 4 waves per CU (256 x 256 tiles with 8 waves measured 3-5 % slower: no registers left
-    // for the second set of loads in flight)
-    const int wm = 2, nj = 2;
+    // for the second set of loads in flight).  GSN_L16_WIDE=1 (r06, measured, NOT the default): 128 x 320 tiles, one workgroup per CU, where
+    // that wastes fewer columns and the product is large enough to fill the chip that way (the d = 300 ogb stages: n_out = 300 is one column
+    // tile instead of three, 600 two instead of five: 40-60 % less L2 -> CU traffic, 17 % less matrix work at n_out = 300) -- 105 083 rows:
+    // 300 -> 600 194 vs 188 us, 600 -> 300 178 vs 183 us, 196 608 x 300 -> 600 295 vs 318 us (scripts/gpu/r6_l16_wide.py; config-4 step 16.68 vs
+    // 16.45 ms): neither the column waste nor the traffic is what bounds this kernel.
+    const int wm = 2;
+    static const bool wide_on = [] { const char *e = getenv("GSN_L16_WIDE"); return e && e[0] == '1'; }();
+    const int64_t cols128 = (n_out + 127) / 128 * 128, cols320 = (n_out + 319) / 320 * 320;
+    const bool vec_ok = n_out % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && !getenv("GSN_L16_NOVEC");
+    const bool wide = wide_on && vec_ok && n_out > 256 && cols320 <= cols128 && (m_rows + 127) / 128 * (cols320 / 320) >= 512 && !getenv("GSN_L16_REGSTAGE") &&
+                      !getenv("GSN_L16_PROF") && !getenv("GSN_L16_DBG");
+    const int nj = wide ? 5 : 2;
     const int bm = 64 * wm, bn = 64 * nj;
     const int64_t n_tiles = (m_rows + bm - 1) / bm;
     const int col_tiles = (int)((n_out + bn - 1) / bn);
-    const int slots = 64;                                                   // workgroups per XCD
+    const int slots = wide ? 32 : 64;                                       // workgroups per XCD
     int groups = slots / col_tiles;
     if (groups < 1) groups = 1;
     const int64_t need = (n_tiles + 7) / 8;
@@ -933,13 +950,13 @@ static int l16_fwd(int64_t m_rows, int n_blocks, const gsn_block *blocks, const 
     if (want_prof && hipMalloc(reinterpret_cast<void **>(&a.prof), 64) != hipSuccess) a.prof = nullptr;
     size_t lds = (size_t)2 * (bm + bn) * P_PITCH + 8 * bn + 4 * (2 * nj * 64 + 2 * nj * 32);   // slice buffers | epilogue tables
     if (getenv("GSN_CHAIN_TRACE"))
-        fprintf(stderr, "gsn linear: linear_f16x3_kernel (%d x %d tiles) M %lld K %d N %d grid 8 x %d x %d\n", bm, bn, (long long)m_rows, k_total, (int)n_out,
+        fprintf(stderr, "gsn linear: linear_f16x3_kernel (%d x %d tiles) M %lld K %d N %d grid 8 x %d x %d\n", bm, bn, (long long)m_rows, a.k_total, (int)n_out,
                 groups, col_tiles);
     const dim3 grid((unsigned)(8 * groups * col_tiles));
     const bool vec = n_out % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && !getenv("GSN_L16_NOVEC");      // 16-byte output stores
     if (stats && (!vec || act != 0 || bn_scale))
         return set_error(GSN_E_UNSUPPORTED, "gsn_linear_f16x3_fwd_stats_hip: statistics go with plain pre-BN rows (act 0, no bn vectors), n_out a multiple of 4, out 16-byte aligned");
-    static DeviceOnce attr_set[7];
+    static DeviceOnce attr_set[9];
     const int attr_dev = current_device();
     hipError_t e0 = hipSuccess;
     auto launch = [&](auto kern, int which) {
@@ -951,18 +968,23 @@ static int l16_fwd(int64_t m_rows, int n_blocks, const gsn_block *blocks, const 
         hipLaunchKernelGGL(kern, grid, dim3(128 * wm), lds, st, a);
     };
     static const bool reg_stage = getenv("GSN_L16_REGSTAGE") != nullptr;  // (A/B: slices staged through registers)
-    if (stats) {
-        lds = (size_t)2 * D_BUF + 4 * (2 * D_BM + 2 * D_BN) + 4 * (2 * 2 * 64 + 2 * 2 * 32);
-        launch(linear_f16x3_dma_kernel<false, true, true>, 6);
+    const size_t lds_dma = (size_t)2 * (D_BM + bn) * L_LINE + 4 * (2 * D_BM + 2 * bn) + 4 * (2 * nj * 64 + 2 * nj * 32);   // slice buffers | row scales, column tables | store offsets
+    if (stats && wide) {
+        lds = lds_dma;
+        launch(linear_f16x3_dma_kernel<5, false, true, true>, 8);
+    } else if (stats) {
+        lds = lds_dma;
+        launch(linear_f16x3_dma_kernel<2, false, true, true>, 6);
     } else if (reg_stage) {
         if (want_prof || a.dbg) launch(linear_f16x3_planes_kernel<2, 2, true, true>, 0);       // diagnostic build
         else if (!vec) launch(linear_f16x3_planes_kernel<2, 2, false, false>, 1);
         else launch(linear_f16x3_planes_kernel<2, 2, false, true>, 2);
     } else {
-        lds = (size_t)2 * D_BUF + 4 * (2 * D_BM + 2 * D_BN) + 4 * (2 * 2 * 64 + 2 * 2 * 32);
-        if (want_prof || a.dbg) launch(linear_f16x3_dma_kernel<true, true>, 3);
-        else if (!vec) launch(linear_f16x3_dma_kernel<false, false>, 4);
-        else launch(linear_f16x3_dma_kernel<false, true>, 5);
+        lds = lds_dma;
+        if (wide) launch(linear_f16x3_dma_kernel<5, false, true>, 7);
+        else if (want_prof || a.dbg) launch(linear_f16x3_dma_kernel<2, true, true>, 3);
+        else if (!vec) launch(linear_f16x3_dma_kernel<2, false, false>, 4);
+        else launch(linear_f16x3_dma_kernel<2, false, true>, 5);
     }
     if (e0 != hipSuccess) return set_error(GSN_E_HIP, "hipFuncSetAttribute(linear_f16x3_kernel): %s", hipGetErrorString(e0));
     if (a.prof) {
