@@ -929,7 +929,8 @@ static int l16_fwd(int64_t m_rows, int n_blocks, const gsn_block *blocks, const 
     // 300 -> 600 194 vs 188 us, 600 -> 300 178 vs 183 us, 196 608 x 300 -> 600 295 vs 318 us (scripts/gpu/r6_l16_wide.py; config-4 step 16.68 vs
     // 16.45 ms): neither the column waste nor the traffic is what bounds this kernel.
     const int wm = 2;
-    static const bool wide_on = [] { const char *e = getenv("GSN_L16_WIDE"); return e && e[0] == '1'; }();
+    const char *wide_env = getenv("GSN_L16_WIDE");                          // (read per call: a test switches it)
+    const bool wide_on = wide_env && wide_env[0] == '1';
     const int64_t cols128 = (n_out + 127) / 128 * 128, cols320 = (n_out + 319) / 320 * 320;
     const bool vec_ok = n_out % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && !getenv("GSN_L16_NOVEC");
     const bool wide = wide_on && vec_ok && n_out > 256 && cols320 <= cols128 && (m_rows + 127) / 128 * (cols320 / 320) >= 512 && !getenv("GSN_L16_REGSTAGE") &&

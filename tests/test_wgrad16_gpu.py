@@ -193,3 +193,37 @@ def test_dense_stages_take_the_plane_kernel_and_match_float64_autograd(train, d_
         scale = r.abs().max().item()
         e_new, e_old = (g.double() - r).abs().max().item() / scale, (o.double() - r).abs().max().item() / scale
         assert e_new <= max(2.0 * e_old, 2e-6), (name, e_new, e_old)
+
+
+@pytest.mark.parametrize("m,k,n", [(70000, 300, 600), (66000, 600, 300), (131072, 64, 640)])
+def test_product_on_128x320_tiles_matches_the_128x128_kernel(m, k, n, monkeypatch):
+    """GSN_L16_WIDE=1: linear_f16x3_dma_kernel<5> (one workgroup per CU, 160 accumulator registers per wave; measured equal, not the default) --
+    rows, column statistics and the relu epilogue against the default instantiation and float64 (models_misc.py:52-58)."""
+    from gsn_amd import _abi
+    from gsn_amd._dense import _f16x3_weights
+    torch.manual_seed(m)
+    L = _abi.lib()
+    x = torch.randn(m, k, device="cuda") * torch.logspace(-2, 2, m, device="cuda")[:, None]
+    W = torch.randn(n, k, device="cuda") / k ** 0.5
+    b = torch.randn(n, device="cuda")
+    planes, col_inv = _f16x3_weights(W, W)
+    sc = _split(x)
+    one = (_abi.gsn_block * 1)()
+    one[0].data = x.data_ptr(); one[0].idx = None; one[0].idx32 = None; one[0].width = k
+
+    def run():
+        y, h = torch.empty(m, n, device="cuda"), torch.empty(m, n, device="cuda")
+        st = torch.zeros(2, n, dtype=torch.float64, device="cuda")
+        _abi.check(L.gsn_linear_f16x3_fwd_presplit_hip(m, 1, one, planes.data_ptr(), col_inv.data_ptr(), b.data_ptr(), n, None, None, None, 1, sc.data_ptr(),
+                                                       y.data_ptr(), _abi.current_stream()), "product")
+        _abi.check(L.gsn_linear_f16x3_fwd_stats_presplit_hip(m, 1, one, planes.data_ptr(), col_inv.data_ptr(), b.data_ptr(), n, sc.data_ptr(), h.data_ptr(),
+                                                             st.data_ptr(), _abi.current_stream()), "product + statistics")
+        return y, h, st
+    y0, h0, st0 = run()
+    monkeypatch.setenv("GSN_L16_WIDE", "1")
+    y1, h1, st1 = run()
+    assert torch.equal(y0, y1) and torch.equal(h0, h1)              # (same planes, same products in the same order per output element)
+    assert torch.allclose(st0, st1, rtol=1e-12, atol=0)
+    ref = x[:8192].double() @ W.double().t() + b.double()
+    err = ((h1[:8192].double() - ref).abs() / ref.abs().amax(1, keepdim=True)).max().item()
+    assert err <= 2e-6, err
