@@ -844,6 +844,26 @@ extern "C" int gsn_bn_act_planes_hip(int64_t m_rows, int64_t n_cols, const float
     return GSN_OK;
 }
 
+// rows per slab of a weight-gradient call (both kernels): see gsn_wgrad_hip.  wg_target > 0: the r05 rule with that many workgroups asked for
+namespace gsn {
+int64_t gsn_wgrad_slab_rows(int64_t m_rows, int64_t tiles, int64_t wg_target) {
+    if (wg_target > 0) {
+        const int64_t slabs = (wg_target + tiles - 1) / tiles;
+        int64_t rows_per = (m_rows + slabs - 1) / slabs;
+        const int64_t min_rows = m_rows >= 65536 ? 256 : 64;
+        return rows_per < min_rows ? min_rows : rows_per;
+    }
+    int64_t rows_per = (m_rows * tiles + 255) / 256;
+    rows_per = (rows_per + 63) / 64 * 64;
+    rows_per = rows_per < 64 ? 64 : (rows_per > 512 ? 512 : rows_per);
+    if ((m_rows + rows_per - 1) / rows_per * tiles > 2048) {
+        const int64_t slabs = (2048 + tiles - 1) / tiles;
+        rows_per = (m_rows + slabs - 1) / slabs;
+    }
+    return rows_per;
+}
+}  // namespace gsn
+
 extern "C" int gsn_wgrad_hip(int64_t m_rows, int64_t n_out, const float *grad_h, int n_blocks, const gsn_block *blocks,
                              float *grad_w, void *stream) {
     if (n_out < 1 || n_blocks < 1 || n_blocks > WG_MAXB || !blocks || !grad_w || (m_rows > 0 && !grad_h))
@@ -862,18 +882,17 @@ extern "C" int gsn_wgrad_hip(int64_t m_rows, int64_t n_out, const float *grad_h,
     a.k_total = k;
     if (m_rows <= 0) return GSN_OK;
     const int tn = (int)((n_out + WG_T - 1) / WG_T), tk = (k + WG_T - 1) / WG_T;
-    // enough row slabs to fill the chip, but slabs of at least 256 rows (each one ends with 128 x 128 atomics).  Small batches (the
-    // reference's 32 / 128 graphs: M ~ 800 .. 6 000 rows) are bound by the serial chain of 16-row steps inside a slab instead (load ->
-    // split -> LDS -> products, ~1.2 us per step with one workgroup per CU and nothing to hide the latency: 60 us per call at 256 rows):
-    // 64-row slabs there.
-    static const int64_t wg_target = [] { const char *e = getenv("GSN_WGRAD_WGS"); const int64_t v = e ? atoll(e) : 0; return v > 0 ? v : (int64_t)2048; }();   // (A/B: workgroups per call)
-    int64_t slabs = (wg_target + tn * tk - 1) / (tn * tk);
-    int64_t rows_per = (m_rows + slabs - 1) / slabs;
-    const int64_t min_rows = m_rows >= 65536 ? 256 : 64;
-    if (rows_per < min_rows) rows_per = min_rows;
+    // Slab length.  A workgroup = one 128 x 128 tile of gW over one slab of rows; it ends with 128 x 128 float atomics (~15 us when a few hundred
+    // workgroups do it at once) and walks its slab in a serial chain of 16-row steps (~1.4 us each).  Small and mid-size calls (the reference's
+    // batch sizes; the virtual node's stages): ONE round of ~256 workgroups -- slabs of ceil(M tiles / 256) rows, 64 .. 512.  r05 used 64-row
+    // slabs up to 65 536 rows: 1 410 workgroups in three rounds at M = 6 000 x 300 x 600, 82 us; one round of 360: 41 us (M = 4 096: 61 -> 33 us,
+    // profiles/r06_wgrad16_phase.txt).  Large calls: 2 048 workgroups for balance, their slabs are longer than 512 rows by themselves.
+    // GSN_WGRAD_WGS=n: n workgroups per call asked for, as in r05 (A/B)
+    static const int64_t wg_target = [] { const char *e = getenv("GSN_WGRAD_WGS"); const int64_t v = e ? atoll(e) : 0; return v > 0 ? v : (int64_t)0; }();
+    int64_t rows_per = gsn_wgrad_slab_rows(m_rows, (int64_t)tn * tk, wg_target);
     rows_per = (rows_per + WG_RB - 1) / WG_RB * WG_RB;
     a.rows_per_wg = rows_per;
-    slabs = (m_rows + rows_per - 1) / rows_per;
+    int64_t slabs = (m_rows + rows_per - 1) / rows_per;
     if (getenv("GSN_CHAIN_TRACE"))
         fprintf(stderr, "gsn wgrad: M %lld N %d K %d blocks %d%s slabs %lld x %lld rows\n", (long long)m_rows, (int)n_out, k, n_blocks, gathered ? " gathered" : "",
                 (long long)slabs, (long long)rows_per);

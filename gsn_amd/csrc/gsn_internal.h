@@ -41,5 +41,6 @@ struct DeviceOnce {
     void mark(int dev) { if (dev >= 0 && dev < 64) mask.fetch_or(1ull << dev, std::memory_order_release); }
 };
 int current_device();   // hipGetDevice, -1 on error (abi.cpp)
+int64_t gsn_wgrad_slab_rows(int64_t m_rows, int64_t tiles, int64_t wg_target);   // backward.hip: rows per slab of a weight-gradient call
 
 }  // namespace gsn

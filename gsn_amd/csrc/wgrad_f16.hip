@@ -464,17 +464,13 @@ extern "C" int gsn_wgrad_f16x3_hip(int64_t m_rows, int64_t n_out, int64_t k_tota
     a.g_planes = reinterpret_cast<const unsigned char *>(a.g_inv + m_pad); a.x_planes = reinterpret_cast<const unsigned char *>(a.x_inv + m_pad);
     const int tn = (int)((n_out + WF_T - 1) / WF_T), tk = (int)((k_total + WF_T - 1) / WF_T);
     a.tn = tn; a.tk = tk;
-    // slabs as gsn_wgrad_hip takes them: enough workgroups to fill the chip, at least 256 rows each on large inputs (every slab ends with
-    // 128 x 128 atomics), 64 on small ones (the serial chain of steps inside a slab is what a small call waits for)
-    static const int64_t wg_target = [] { const char *e = getenv("GSN_WGRAD16_WGS"); const int64_t v = e ? atoll(e) : 0; return v > 0 ? v : (int64_t)2048; }();
-    int64_t slabs = (wg_target + tn * tk - 1) / (tn * tk);
-    int64_t rows_per = (m_rows + slabs - 1) / slabs;
-    const int64_t min_rows = m_rows >= 65536 ? 256 : 64;
-    if (rows_per < min_rows) rows_per = min_rows;
+    // slabs as gsn_wgrad_hip takes them (one round of ~256 workgroups for small and mid-size calls, 2 048 workgroups for large ones)
+    static const int64_t wg_target = [] { const char *e = getenv("GSN_WGRAD16_WGS"); const int64_t v = e ? atoll(e) : 0; return v > 0 ? v : (int64_t)0; }();
+    int64_t rows_per = gsn_wgrad_slab_rows(m_rows, (int64_t)tn * tk, wg_target);
     if (rows_per > WF_MAX_ROWS) rows_per = WF_MAX_ROWS;
     rows_per = (rows_per + 47) / 48 * 48;                                  // (the kernel's loop: three 16-row steps per trip)
     a.rows_per_wg = rows_per;
-    slabs = (m_rows + rows_per - 1) / rows_per;
+    const int64_t slabs = (m_rows + rows_per - 1) / rows_per;
     const int64_t slab_groups = (slabs + 7) / 8;
     if (slab_groups * tn * tk * 8 >= ((int64_t)1 << 31)) return set_error(GSN_E_UNSUPPORTED, "gsn_wgrad_f16x3_hip: too many workgroups");
     if (getenv("GSN_CHAIN_TRACE"))

@@ -12,7 +12,7 @@ from gsn_amd import _abi  # noqa: E402
 import test_wgrad16_gpu as T  # noqa: E402
 
 L = _abi.lib()
-SHAPES = ((105083, 300, 600),) if os.environ.get("R6_WGRAD16_ONE") else ((105083, 300, 600), (105083, 600, 300), (4096, 300, 600), (837, 600, 300))
+SHAPES = ((105083, 300, 600),) if os.environ.get("R6_WGRAD16_ONE") else tuple((int(m), int(os.environ.get("R6_WGRAD16_N", "300")), int(os.environ.get("R6_WGRAD16_K", "600"))) for m in os.environ["R6_WGRAD16_M"].split(",")) if os.environ.get("R6_WGRAD16_M") else ((105083, 300, 600), (105083, 600, 300), (4096, 300, 600), (837, 600, 300))
 for m, n_out, k in SHAPES:
     torch.manual_seed(0)
     gh = torch.randn(m, n_out, device="cuda") * 1e-4
