@@ -227,3 +227,56 @@ def test_product_on_128x320_tiles_matches_the_128x128_kernel(m, k, n, monkeypatc
     ref = x[:8192].double() @ W.double().t() + b.double()
     err = ((h1[:8192].double() - ref).abs() / ref.abs().amax(1, keepdim=True)).max().item()
     assert err <= 2e-6, err
+
+
+def test_new_entries_refuse_what_they_do_not_take_and_accept_empty_calls():
+    """Error behaviour of the r06 entries: unsupported shapes come back as GSN_E_UNSUPPORTED / GSN_E_INVALID with a message (never a wrong result), zero
+    rows are a no-op (the reference's layers see edge-less and node-less batches: utils_data_gen.py:86-108)."""
+    from gsn_amd import _abi
+    L = _abi.lib()
+    st = _abi.current_stream()
+    h = torch.randn(64, 644, device="cuda"); g = torch.randn(64, 644, device="cuda")
+    v = torch.ones(644, device="cuda")
+    scr = torch.empty(int(L.gsn_linear_f16x3_scratch_bytes(64, 644)), dtype=torch.uint8, device="cuda")
+    sums = torch.zeros(2, 644, dtype=torch.float64, device="cuda")
+    # more than 640 columns / a width that is not a multiple of 4
+    assert L.gsn_bn_act_planes_hip(64, 644, h.data_ptr(), v.data_ptr(), v.data_ptr(), v.data_ptr(), 1, None, scr.data_ptr(), st) == -2
+    assert L.gsn_bn_act_planes_hip(64, 30, h.data_ptr(), v.data_ptr(), v.data_ptr(), v.data_ptr(), 1, None, scr.data_ptr(), st) == -2
+    assert L.gsn_bn_act_bwd_planes_hip(64, 644, g.data_ptr(), h.data_ptr(), v.data_ptr(), v.data_ptr(), v.data_ptr(), v.data_ptr(), 1, 1, sums.data_ptr(), scr.data_ptr(),
+                                       None, st) == -2
+    assert L.gsn_bn_act_bwd_planes_hip(64, 128, g.data_ptr(), h.data_ptr(), v.data_ptr(), v.data_ptr(), v.data_ptr(), v.data_ptr(), 0, 1, sums.data_ptr(), scr.data_ptr(),
+                                       None, st) == -2          # (train_bn 0: not a BatchNorm stage)
+    # misaligned rows / scratch
+    assert L.gsn_bn_act_planes_hip(64, 128, h.data_ptr() + 4, v.data_ptr(), v.data_ptr(), v.data_ptr(), 1, None, scr.data_ptr(), st) == -1
+    assert L.gsn_wgrad_f16x3_hip(64, 128, 128, scr.data_ptr() + 4, scr.data_ptr(), g.data_ptr(), st) == -1
+    assert b"aligned" in L.gsn_last_error()
+    one = (_abi.gsn_block * 1)()
+    one[0].data = h.data_ptr(); one[0].idx = None; one[0].idx32 = None; one[0].width = 30
+    assert L.gsn_linear_f16x3_split_rows_hip(64, 1, one, scr.data_ptr(), st) == -2
+    # zero rows: nothing launched, nothing touched
+    gw = torch.full((8, 8), 3.0, device="cuda")
+    assert L.gsn_wgrad_f16x3_hip(0, 8, 8, None, None, gw.data_ptr(), st) == 0
+    assert L.gsn_bn_act_planes_hip(0, 128, None, None, None, None, 1, None, None, st) == 0
+    assert L.gsn_bn_act_bwd_planes_hip(0, 128, None, None, None, None, None, None, 1, 1, None, None, None, st) == 0
+    assert L.gsn_linear_f16x3_split_rows_hip(0, 1, one, None, st) == 0
+    torch.cuda.synchronize()
+    assert bool((gw == 3.0).all())
+    assert L.gsn_linear_f16x3_mpad(0) == 0 and L.gsn_linear_f16x3_mpad(1) == 256 and L.gsn_linear_f16x3_mpad(128) == 256 and L.gsn_linear_f16x3_mpad(129) == 512
+
+
+def test_mlp_on_an_empty_batch_and_on_one_row_under_the_plane_switches():
+    """Zero rows and one row through run_stages_autograd with every r06 switch on: the plane paths do not apply (too few tiles), nothing breaks."""
+    from gsn_amd import _autograd
+    from gsn_amd._dense import _Stage
+    lin1, bn, lin2 = torch.nn.Linear(300, 600).cuda(), torch.nn.BatchNorm1d(600).cuda(), torch.nn.Linear(600, 300).cuda()
+    bn.eval()
+    for m in (0, 1):
+        x = torch.randn(m, 300, device="cuda", requires_grad=True)
+        stages = [_Stage(lin1.weight, lin1.bias, bn, "relu", blocks=[(x, None)]), _Stage(lin2.weight, lin2.bias, None, "identity")]
+        y = _autograd.run_stages_autograd(stages, m, False)
+        assert y.shape == (m, 300)
+        y.sum().backward()
+        assert x.grad.shape == (m, 300) and torch.isfinite(lin1.weight.grad).all()
+        if m == 1:
+            ref = lin2(torch.relu(bn(lin1(x.detach()))))
+            assert torch.allclose(y, ref, rtol=1e-5, atol=1e-5)
