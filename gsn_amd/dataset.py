@@ -107,10 +107,24 @@ def prepare_graphs(graphs, subgraph_dicts, subgraph_params, regression, dataset_
         max_src = np.full(G, -1, dtype=np.int64)
 
     n_cols = plan.n_cols
+
+    def by_falling_cost(lo, hi):
+        """Graphs of more than 64 vertices take a workgroup each, and a launch ends when its slowest workgroup does: handing the graphs out by
+        falling estimated cost (sum_v deg(v)^(k-1), SURVEY.md 8(e)'s proxy) starts the long searches first -- BASELINE config 5 at 2 048 graphs per
+        launch: 53.3 k -> 55.1 k graphs/s (scripts/gpu/r6_er_order.py).  Molecule-size graphs share a wave in pairs: left in their order."""
+        if hi - lo < 2 or n_nodes[lo:hi].max() <= 64:
+            return None
+        kmax = max(p.num_vertices() for p in pats)
+        w = deg_all.astype(np.float64) ** (kmax - 1)
+        csum = np.concatenate([[0.0], np.cumsum(w)])
+        cost = csum[node_ptr[lo + 1:hi + 1]] - csum[node_ptr[lo:hi]]
+        return np.argsort(-cost, kind="stable").astype(np.int32)
+
     if G and (mode == "vertex" or edge_ptr[-1] > 0):
         if order is None:
             out, _ = counting.count_batch(plan, node_ptr, edge_ptr, torch.from_numpy(ei), ids_are_global=False,
-                                          max_nodes=int(max(n_nodes.max(), 1)), max_edges=int(n_kept.max()), device=device)
+                                          max_nodes=int(max(n_nodes.max(), 1)), max_edges=int(n_kept.max()), device=device,
+                                          graph_ids=by_falling_cost(0, G))
         else:
             dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
             ei_d = torch.from_numpy(ei).to(dev)
@@ -121,7 +135,8 @@ def prepare_graphs(graphs, subgraph_dicts, subgraph_params, regression, dataset_
                 if mode == "edge" and edge_ptr[hi] == edge_ptr[lo]:
                     continue
                 counting.count_batch(plan, node_ptr[lo:hi + 1], edge_ptr[lo:hi + 1], ei_d, ids_are_global=False,
-                                     max_nodes=int(max(n_nodes[lo:hi].max(), 1)), max_edges=int(n_kept[lo:hi].max()), device=dev, out=out)
+                                     max_nodes=int(max(n_nodes[lo:hi].max(), 1)), max_edges=int(n_kept[lo:hi].max()), device=dev, out=out,
+                                     graph_ids=by_falling_cost(lo, hi))
         ids_all = out.cpu()
     else:
         ids_all = torch.zeros((0, n_cols), dtype=torch.int64)

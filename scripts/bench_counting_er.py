@@ -44,8 +44,14 @@ def main():
     ei = torch.from_numpy(b.edge_index).to(dev)
     rows = b.num_edges if args.mode == "edge" else b.num_nodes
     out = torch.empty((rows, plan.n_cols), dtype=torch.int64, device=dev)
+    # graphs handed to the kernel by falling estimated cost (sum_v deg^(k-1)): the long searches start first (scripts/gpu/r6_er_order.py);
+    # GSN_ER_ORDER=0: as they come
+    order = None
+    if os.environ.get("GSN_ER_ORDER", "1") != "0":
+        cost = np.asarray(gdist.counting_cost(b.edge_index, b.edge_ptr, 5), dtype=np.float64)
+        order = torch.from_numpy(np.argsort(-cost, kind="stable").astype(np.int32)).to(dev)
     f = lambda: count_batch(plan, node_ptr, edge_ptr, ei, ids_are_global=True, max_nodes=128, max_edges=int(np.diff(b.edge_ptr).max()),
-                            device=dev, out=out, check=False)
+                            device=dev, out=out, check=False, graph_ids=order)
     f()
     torch.cuda.synchronize()
     if dist is not None:
