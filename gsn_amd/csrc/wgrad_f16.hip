@@ -35,7 +35,7 @@ namespace {
 
 constexpr int WF_T = 128;          // gW tile edge
 constexpr int WF_RB = 16;          // rows per step
-constexpr int WF_MAX_ROWS = 4080;  // rows per slab (the scale table lives in LDS)
+constexpr int WF_MAX_ROWS = 3072;  // rows per slab (the scale tables live in LDS: both kernels stay under 64 KiB of dynamic LDS, 42 / 61 KiB)
 
 typedef float wf_f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 wf_h16x8 __attribute__((ext_vector_type(8)));

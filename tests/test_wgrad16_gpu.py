@@ -280,3 +280,17 @@ def test_mlp_on_an_empty_batch_and_on_one_row_under_the_plane_switches():
         if m == 1:
             ref = lin2(torch.relu(bn(lin1(x.detach()))))
             assert torch.allclose(y, ref, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("dma", ["0", "1"])
+def test_two_million_rows_keep_the_slab_tables_inside_the_lds_budget(dma, monkeypatch):
+    """M = 2 000 000 rows x 64 x 64 (one tile): the slab-length rule asks for more rows per slab than the scale tables may hold -- capped, more slabs
+    instead; both kernels."""
+    monkeypatch.setenv("GSN_WGRAD16_DMA", dma)
+    torch.manual_seed(0)
+    m = 2000000
+    gh = torch.randn(m, 64, device="cuda") * 1e-3
+    x = torch.randn(m, 64, device="cuda")
+    gw = _wgrad16(gh, x)
+    ref = (gh.t().double() @ x.double())
+    assert float((gw.double() - ref).abs().max() / ref.abs().max()) <= 2e-5
