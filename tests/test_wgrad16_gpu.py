@@ -294,3 +294,35 @@ def test_two_million_rows_keep_the_slab_tables_inside_the_lds_budget(dma, monkey
     gw = _wgrad16(gh, x)
     ref = (gh.t().double() @ x.double())
     assert float((gw.double() - ref).abs().max() / ref.abs().max()) <= 2e-5
+
+
+def test_plane_paths_on_one_and_a_half_million_rows():
+    """1 500 000 rows through Linear -> BatchNorm (train) -> elu -> Linear with the plane switches on and off: 64-bit row offsets in the plane kernels,
+    the capped slab tables, the 2 048-workgroup regime of the slab rule -- same gradients as the fp32-row passes."""
+    from gsn_amd import _autograd, flags
+    from gsn_amd._dense import _Stage
+    torch.manual_seed(1)
+    m = 1500000
+    x = torch.randn(m, 128, device="cuda")
+    lin1, bn, lin2 = torch.nn.Linear(128, 256).cuda(), torch.nn.BatchNorm1d(256).cuda(), torch.nn.Linear(256, 132).cuda()
+    wout = torch.randn(m, 132, device="cuda")
+    params = [*lin1.parameters(), *bn.parameters(), *lin2.parameters()]
+
+    def run():
+        for p in params:
+            p.grad = None
+        stages = [_Stage(lin1.weight, lin1.bias, bn, "elu", blocks=[(x, None)]), _Stage(lin2.weight, lin2.bias, None, "identity")]
+        y = _autograd.run_stages_autograd(stages, m, True)
+        (y * wout).sum().backward()
+        return y.detach()[::4097].clone(), [p.grad.clone() for p in params]
+    y1, g1 = run()
+    try:
+        flags.WGRAD_F16X3 = flags.BN_BWD_PLANES = flags.BN_ACT_PLANES = False
+        y0, g0 = run()
+    finally:
+        flags.WGRAD_F16X3 = flags.BN_BWD_PLANES = flags.BN_ACT_PLANES = True
+    assert torch.allclose(y1, y0, rtol=1e-5, atol=1e-5)
+    for a, b, name in zip(g1, g0, ("W1", "b1", "gamma", "beta", "W2", "b2")):
+        if name == "b1":
+            continue                        # (in front of a train-mode BatchNorm: the true gradient is zero, both are rounding noise)
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()), name
