@@ -603,7 +603,11 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradArgs a) {
 // by sched_group_barrier -- and written to the other LDS buffer behind them.  Branch-free loop body (rows past the slab's end are clamped
 // loads and zero planes), two named register sets, the loop unrolled by two.  Same planes, same products, same order: the same bits.
 // SINGLE: X is one block -- every row address is a scalar base (the row) plus a 32-bit lane offset (the column): no vector arithmetic per load
-template <bool SINGLE, int WG_PIPE_VALU>
+// GATHER (r06): blocks read through a row index (the x_i / x_j blocks of an edge stage, GSN_edge_sparse.py:160-165): the row of a load is the same
+// for all lanes of a block, so a gathered block costs one index load per row, requested a step ahead of the rows it addresses (its own register
+// set, alternating like the rows') -- wgrad_bf16_kernel<true> keeps one chunk in flight and splits behind its products: 235 -> 194 us at 194 284 x 128 x 272 (scripts/gpu/r6_wgrad_gather.py;
+// the same rows assembled first: 153; config-2 training step at 4 096 graphs 5.77 -> 5.59 ms)
+template <bool SINGLE, int WG_PIPE_VALU, bool GATHER = false>
 __global__ __launch_bounds__(256) void wgrad_bf16_pipe_kernel(WgradArgs a) {
     __shared__ wg_u32x4 ta[2][3][WG_T][2];
     __shared__ wg_u32x4 tb[2][3][WG_T][2];
@@ -627,6 +631,8 @@ __global__ __launch_bounds__(256) void wgrad_bf16_pipe_kernel(WgradArgs a) {
     const bool kb_ok = kb < a.k_total;
     const float *xb = a.bdata[0];
     int xw = a.bwidth[0];
+    const int64_t *xi = GATHER ? a.bidx[0] : nullptr;
+    const int32_t *xi32 = GATHER ? a.bidx32[0] : nullptr;
     {
         int blk = 0, col = kb_ok ? kb : 0;
 #pragma unroll
@@ -634,9 +640,17 @@ __global__ __launch_bounds__(256) void wgrad_bf16_pipe_kernel(WgradArgs a) {
             if (b < a.n_blocks - 1 && blk == b && col >= a.bwidth[b]) { col -= a.bwidth[b]; blk = b + 1; }
 #pragma unroll
         for (int b = 1; b < WG_MAXB; ++b)
-            if (blk == b) { xb = a.bdata[b]; xw = a.bwidth[b]; }
+            if (blk == b) { xb = a.bdata[b]; xw = a.bwidth[b]; if (GATHER) { xi = a.bidx[b]; xi32 = a.bidx32[b]; } }
         xb += col;
     }
+    auto idx_load = [&](int (&ix)[8], int64_t row0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int64_t r = row0 + 8 * sh + i;
+            const int64_t rc = r < r_end ? r : r_begin;
+            ix[i] = xi ? (int)xi[rc] : (xi32 ? xi32[rc] : (int)rc);
+        }
+    };
     const float *ga = a.gh + (ca_ok ? ca : 0);
     const unsigned ca_u = ca_ok ? (unsigned)ca : 0u, kb_u = kb_ok ? (unsigned)kb : 0u;
 
@@ -648,7 +662,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_pipe_kernel(WgradArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    auto fetch = [&](float (&pa)[8], float (&pb)[8], int64_t row0) {
+    auto fetch = [&](float (&pa)[8], float (&pb)[8], int64_t row0, const int (&ix)[8]) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int64_t r = row0 + 8 * sh + i;
@@ -659,7 +673,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_pipe_kernel(WgradArgs a) {
                 const float *xrow = a.bdata[0] + rc * a.bwidth[0];
                 pb[i] = xrow[kb_u];
             } else {
-                pb[i] = xb[rc * xw];
+                pb[i] = xb[(GATHER ? (int64_t)ix[i] : rc) * xw];
             }
         }
     };
@@ -678,9 +692,12 @@ __global__ __launch_bounds__(256) void wgrad_bf16_pipe_kernel(WgradArgs a) {
         }
     };
     float pa0[8], pb0[8], pa1[8], pb1[8];
+    int ix0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ix1[8] = {0, 0, 0, 0, 0, 0, 0, 0};    // (GATHER: row indices of the rows the NEXT fetch reads / the one after)
     {
-        fetch(pa0, pb0, r_begin);
-        fetch(pa1, pb1, r_begin + 16);
+        if (GATHER) { idx_load(ix0, r_begin); idx_load(ix1, r_begin + 16); }
+        fetch(pa0, pb0, r_begin, ix0);
+        fetch(pa1, pb1, r_begin + 16, ix1);
+        if (GATHER) idx_load(ix0, r_begin + 32);
         wg_u32x4 gh, gm, gl, xh, xm, xl;
         split(pa0, ca_ok, r_begin, gh, gm, gl);
         split(pb0, kb_ok, r_begin, xh, xm, xl);
@@ -691,7 +708,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_pipe_kernel(WgradArgs a) {
 #define WG_MF(x, y, c) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wg_bf16x8, x), __builtin_bit_cast(wg_bf16x8, y), c, 0, 0, 0)
     // one step: products of the rows staged in `buf`; `nxt` (rows row0 + 16, in registers since the step before) split under them into buf ^ 1;
     // `far` receives the rows row0 + 32
-    auto step = [&](int buf, int64_t row0, const float (&npa)[8], const float (&npb)[8], float (&fpa)[8], float (&fpb)[8]) {
+    auto step = [&](int buf, int64_t row0, const float (&npa)[8], const float (&npb)[8], float (&fpa)[8], float (&fpb)[8], const int (&fix)[8], int (&nix)[8]) {
         wg_u32x4 fa[2][3], fb[2][3];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -714,7 +731,8 @@ __global__ __launch_bounds__(256) void wgrad_bf16_pipe_kernel(WgradArgs a) {
         }
         ta[buf ^ 1][0][sc][sh] = gh; ta[buf ^ 1][1][sc][sh] = gm; ta[buf ^ 1][2][sc][sh] = gl;
         tb[buf ^ 1][0][sc][sh] = xh; tb[buf ^ 1][1][sc][sh] = xm; tb[buf ^ 1][2][sc][sh] = xl;
-        fetch(fpa, fpb, row0 + 32);
+        fetch(fpa, fpb, row0 + 32, fix);
+        if (GATHER) idx_load(nix, row0 + 48);       // (the indices of the rows the next step requests)
         // the order asked of the scheduler: the fragment reads, then the far rows' requests, then one MFMA : five vector instructions, the plane
         // writes last
 #pragma unroll
@@ -726,9 +744,9 @@ __global__ __launch_bounds__(256) void wgrad_bf16_pipe_kernel(WgradArgs a) {
     };
     int64_t row0 = r_begin;
     for (; row0 < r_end; row0 += 32) {
-        step(0, row0, pa1, pb1, pa0, pb0);
+        step(0, row0, pa1, pb1, pa0, pb0, ix0, ix1);
         if (row0 + 16 >= r_end) break;            // (block-uniform)
-        step(1, row0 + 16, pa0, pb0, pa1, pb1);
+        step(1, row0 + 16, pa0, pb0, pa1, pb1, ix1, ix0);
     }
 #undef WG_MF
 #pragma unroll
@@ -908,7 +926,8 @@ extern "C" int gsn_wgrad_hip(int64_t m_rows, int64_t n_out, const float *grad_h,
         static const int pipe = [] { const char *e = getenv("GSN_WGRAD_PIPE"); const int v = e ? atoi(e) : 6; return v == 1 ? 6 : v; }();
         const dim3 grid((unsigned)(slab_groups * tn * tk * 8));
         hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-        if (gathered) hipLaunchKernelGGL(wgrad_bf16_kernel<true>, grid, dim3(256), 0, st, a);
+        if (gathered && pipe) hipLaunchKernelGGL((wgrad_bf16_pipe_kernel<false, 6, true>), grid, dim3(256), 0, st, a);
+        else if (gathered) hipLaunchKernelGGL(wgrad_bf16_kernel<true>, grid, dim3(256), 0, st, a);
         else if (pipe == 4 && n_blocks == 1) hipLaunchKernelGGL((wgrad_bf16_pipe_kernel<true, 4>), grid, dim3(256), 0, st, a);
         else if (pipe == 4) hipLaunchKernelGGL((wgrad_bf16_pipe_kernel<false, 4>), grid, dim3(256), 0, st, a);
         else if (pipe == 5 && n_blocks == 1) hipLaunchKernelGGL((wgrad_bf16_pipe_kernel<true, 5>), grid, dim3(256), 0, st, a);
